@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of edge_follow-v0 (UR5 + TacTip, 128x128 tactile obs), BASELINE.json configs[1].
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one VecEnv.step() of the whole batch: controller + 24 sim ticks + tactile render for every env, random
+actions ~ U(-0.25, 0.25) generated on the device (synthetic), auto-reset on (episodes of 200 steps, so resets fall
+inside the timed region whenever K + W crosses a multiple of 200; reported separately via `resets_in_timed_region`).
+Observations stay resident in HBM (device tensors); the PCIe-inclusive rate is quoted in DESIGN.md, never here.
+Weak scaling: every rank owns --num-envs envs; rank 0 receives all observations / rewards / dones by one RCCL gather per
+step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
+             reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+ALGO_BYTES_PER_ENV_STEP = 16600.0   # BASELINE.md section 3 / SURVEY 8(d): 16 384 B image + ~0.2 KB state/action/reward
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def _cpu_worker(args):
+    seed, seconds = args
+    import numpy as np
+    from oracle.ref_env import OracleEdgeFollowEnv
+    env = OracleEdgeFollowEnv(seed=seed, max_steps=200, image_size=(128, 128), env_modes=MODES)
+    env.reset()
+    rng = np.random.default_rng(seed)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        _, _, done, _ = env.step(rng.uniform(-0.25, 0.25, 2))
+        n += 1
+        if done:
+            env.reset()
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(seconds=12.0):
+    """The CPU oracle (oracle/: a port, not PyBullet — PyBullet is not installable here) on this box's host cores."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    n1, t1 = _cpu_worker((1, min(4.0, seconds / 3)))
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(1 + i, seconds) for i in range(cores)])
+    total = sum(r[0] for r in res) / max(r[1] for r in res)
+    return {"value": round(total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes x 1 oracle env (edge_follow-v0, 128x128, random actions, resets included) for {seconds:.0f} s; "
+                      f"single process: {n1 / t1:.1f} env-steps/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--num-envs", type=int, default=1024, help="envs per GPU (BASELINE configs[1]: 1024)")
+    ap.add_argument("--image-size", type=int, default=128)
+    ap.add_argument("--physics", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import tactile_gym_amd as tg
+    from tactile_gym_amd.parallel import ShardedVecEnv, TorchShard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the env step has no CPU fallback (the CPU oracle is only the reported baseline)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    n = args.num_envs
+    venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[args.image_size, args.image_size], env_modes=MODES,
+                       seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch")
+    shard = TorchShard(venv)
+    env = ShardedVecEnv(shard, dist) if world > 1 else shard
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+
+    def actions():
+        return (torch.rand(n, 2, device="cuda", generator=gen) - 0.5) * 0.5
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    env.reset()
+    for _ in range(args.warmup):
+        env.step(actions())
+    venv.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        env.step(actions())
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = venv.profile_get()
+    venv.profile(False)
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_envs = n * world
+        value = total_envs * args.steps / dt
+        step_ms, step_n = prof["step"]
+        rend_ms, rend_n = prof["render"]
+        rst_ms, rst_n = prof["reset"]
+        k_step = step_ms / max(step_n, 1)                      # ms per launch
+        k_render_main = rend_ms / max(rend_n, 1)
+        dominant = "k_step" if step_ms >= rend_ms else "k_render_tactile"
+        dom_ms = k_step if dominant == "k_step" else k_render_main
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (128x128 tactile obs) at N envs", "value": round(value, 1), "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.physics == "f64" else "f32", "data": "synthetic",
+            "config": {"workload": f"edge_follow-v0, UR5 + TacTip, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
+                                   "random actions, TCP_velocity_control, 24 ticks x 150 PGS sweeps per step, auto-reset on",
+                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world} + gather to rank 0"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                         "kernel_ms": {"k_step": round(k_step, 4), "k_render_tactile": round(k_render_main, 4),
+                                       "k_reset_per_launch": round(rst_ms / max(rst_n, 1), 4)},
+                         "launches": {"k_step": step_n, "k_render_tactile": rend_n, "k_reset": rst_n},
+                         "note": "latency-bound by construction: 24 x 150 serial Gauss-Seidel sweeps per env step (BASELINE.md section 3)"},
+            "resets_in_timed_region": bool((args.warmup % 200) + args.steps >= 200),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    venv.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,174 @@
+/*
+ * tactile_gym_hip.h — C ABI of libtactile_gym_hip.so: the MI355X-native vectorised tactile-env step.
+ *
+ * The reference (ac-93/tactile_gym) has no FFI layer of its own: its hot path is Python calling the PyBullet C
+ * extension.  This header is therefore the boundary a maintainer would bind *instead of* those PyBullet calls;
+ * every entry point cites the reference call sites it replaces (paths relative to tactile_gym/).  All arguments
+ * are plain pointers and sizes; no torch or HIP types appear in signatures (streams and device pointers travel as
+ * `void*`).  Every function returns 0 on success or a negative error code; tg_last_error() gives the message
+ * (the reference calls sys.exit(msg) on bad mode strings — base_tactile_env.py:264, robot.py:65,174 — the Python
+ * host layer turns a non-zero status into an exception).
+ *
+ * Threading: one context per (process, GPU); calls on one context are not re-entrant (the reference is single
+ * threaded per env with one PyBullet client per process, base_tactile_env.py:51,59).  tg_step() only enqueues work
+ * on the context's stream; tg_sync() waits — they map to SB3's VecEnv.step_async()/step_wait().
+ */
+#ifndef TACTILE_GYM_HIP_H
+#define TACTILE_GYM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_MAX_DOF 8
+#define TG_MAX_BODIES_PER_LINK 4
+#define TG_ABI_VERSION 1
+
+/* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
+typedef struct {
+    int32_t ndof;
+    int32_t topology;                       /* 0: serial chain (UR5), 1: MG400 tree {-1,0,1,2,3,0,5,6} */
+    double joint_pos[TG_MAX_DOF][3];        /* joint origin in parent link frame */
+    double joint_rot[TG_MAX_DOF][9];        /* joint frame in parent link frame, row-major */
+    double joint_axis[TG_MAX_DOF][3];
+    /* rigid bodies welded to each moving link (URDF links incl. fixed children); mass 0 = empty slot */
+    double body_mass[TG_MAX_DOF][TG_MAX_BODIES_PER_LINK];
+    double body_com[TG_MAX_DOF][TG_MAX_BODIES_PER_LINK][3];
+    double body_rot[TG_MAX_DOF][TG_MAX_BODIES_PER_LINK][9];
+    double body_inertia[TG_MAX_DOF][TG_MAX_BODIES_PER_LINK][3];
+    /* frames the reference reads with getLinkState (PyBullet inertial-frame convention) */
+    int32_t tcp_link;     double tcp_pos[3];    double tcp_rot[9];     /* base_robot_arm.py:136-151 */
+    int32_t sensor_link;  double sensor_pos[3]; double sensor_rot[9];  /* tactile_sensor.py:153-155 */
+    double gravity[3];                      /* base_tactile_env.py:126 */
+    double linear_damping, angular_damping; /* base_robot_arm.py:24 */
+    double joint_damping;                   /* base_robot_arm.py:25 */
+    double max_force, pos_gain, vel_gain;   /* ur5.py:19-21, mg400.py:27-29 */
+    double rest_q[TG_MAX_DOF];              /* rest_poses.py (movable joints) */
+} tg_robot;
+
+/* ---- tactile sensor: camera + reference images (sensors/tactile_sensor.py:63-80,127-187) ------------------------- */
+typedef struct {
+    int32_t image_h, image_w;
+    double cam_pos[3];                      /* camera mount in the sensor-body frame */
+    double cam_rpy[3];
+    double fov_deg, near_plane, far_plane;
+    int32_t turn_off_border;
+    const float*   nodef_dep;               /* host pointers, [h*w]; copied at tg_create */
+    const float*   nodef_gray;
+    const uint8_t* border_mask;
+} tg_sensor;
+
+/* ---- stimulus mesh seen by the tactile camera (edge_follow_env.py:218-235 loadURDF of the edge) ------------------ */
+typedef struct {
+    int32_t n_verts, n_tris;
+    const float*   verts;                   /* host, [n_verts][3], object frame */
+    const int32_t* tris;                    /* host, [n_tris][3] */
+} tg_mesh;
+
+enum { TG_ENV_EDGE_FOLLOW = 0 };
+enum { TG_MOVE_XY = 0, TG_MOVE_XYZ = 1, TG_MOVE_XYRZ = 2, TG_MOVE_XYZRZ = 3 };
+enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };
+enum { TG_REWARD_DENSE = 0, TG_REWARD_SPARSE = 1 };
+enum { TG_PHYSICS_F64 = 0, TG_PHYSICS_F32 = 1 };
+
+/* ---- task + engine configuration (env ctor kwargs / env_modes, edge_follow_env.py:23-134) ------------------------- */
+typedef struct {
+    int32_t abi_version;                    /* TG_ABI_VERSION */
+    int32_t env_kind;                       /* TG_ENV_* */
+    int32_t num_envs;
+    int32_t max_steps;                      /* episode length cap */
+    int32_t movement_mode, noise_mode, reward_mode;
+    int32_t physics_dtype;                  /* TG_PHYSICS_* */
+    int32_t action_repeat;                  /* sim ticks per env step: 24 (edge_follow_env.py:35-37) */
+    int32_t solver_iterations;              /* 150 (base_tactile_env.py:128-130) */
+    int32_t auto_reset;                     /* VecEnv semantics: reset finished envs inside tg_step */
+    int32_t device;                         /* HIP device ordinal */
+    double sim_dt;                          /* 1/240 */
+    double min_action, max_action;          /* edge_follow_env.py:140 */
+    double act_lo[6], act_hi[6];            /* per-dimension physical ranges, :143-166 */
+    double tcp_lims[6][2];                  /* :75-90 */
+    double workframe_pos[3], workframe_rpy[3]; /* :106-107 */
+    double stim_pos[3];                     /* edge_pos :201 */
+    double edge_height, edge_len;           /* :203-207 */
+    double termination_dist;                /* :67 */
+    double embed_dist, embed_lo, embed_hi;  /* :94-99, :291-298 */
+} tg_config;
+
+typedef struct tg_ctx tg_ctx;
+
+const char* tg_last_error(void);
+int tg_abi_version(void);
+
+/* gym.make(...) / env ctor: uploads constants, allocates per-env SoA state for num_envs envs, seeds env i with i. */
+int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sensor, const tg_mesh* stimulus, tg_ctx** out);
+int tg_destroy(tg_ctx* ctx);                                  /* env.close(), base_tactile_env.py:69-74 */
+
+/* Use an existing HIP stream (e.g. torch's current stream) for all work; NULL = the context's own stream. */
+int tg_set_stream(tg_ctx* ctx, void* hip_stream);
+
+/* env.seed(s): per-env 64-bit seeds (SB3 convention seed+i), base_tactile_env.py:61-64. */
+int tg_seed(tg_ctx* ctx, const uint64_t* seeds, int32_t n);
+
+/* env.reset() for the envs whose mask byte is non-zero (NULL = all): task randomisation, rest pose, IK,
+ * blocking move, first observation.  edge_follow_env.py:311-336, robot.py:114-125,188-260. Asynchronous. */
+int tg_reset(tg_ctx* ctx, const uint8_t* host_mask);
+
+/* env.step(a): actions float32[num_envs][act_dim] (device pointer if on_device, else host). Asynchronous.
+ * base_tactile_env.py:166-185 -> robot.py:156-186 -> 24 x robot.py:131-141 -> tactile_sensor.py:261-294. */
+int tg_step(tg_ctx* ctx, const float* actions, int32_t on_device);
+
+int tg_sync(tg_ctx* ctx);                                     /* VecEnv.step_wait(): wait for enqueued work */
+
+/* Device-resident results of the last step/reset (valid after tg_sync or on the context's stream). */
+int tg_get_obs_tactile(tg_ctx* ctx, void** dev_ptr);           /* uint8 [num_envs][H][W][1] */
+int tg_get_terminal_obs(tg_ctx* ctx, void** dev_ptr);          /* uint8 [num_envs][H][W][1], rows valid where done */
+int tg_get_reward_done_dev(tg_ctx* ctx, void** reward_f32, void** done_u8);
+/* Host copies (synchronise). */
+int tg_get_reward_done(tg_ctx* ctx, float* reward, uint8_t* done);
+int tg_copy_obs_tactile(tg_ctx* ctx, uint8_t* host_dst, int32_t terminal);
+
+/* Parity / inspection view of the per-env state, host arrays sized by the caller ([num_envs][...]), any may be NULL. */
+typedef struct {
+    double*  q;              /* [num_envs][ndof] */
+    double*  qd;             /* [num_envs][ndof] */
+    double*  qd_target;      /* [num_envs][ndof] joint velocity targets of the last controller call */
+    double*  tcp_pos;        /* [num_envs][3] world, inertial-frame convention */
+    double*  tcp_rpy;        /* [num_envs][3] */
+    double*  edge_ang;       /* [num_envs] */
+    double*  embed_dist;     /* [num_envs] */
+    float*   stim_xform;     /* [num_envs][12] camera<-stimulus transform used by the last render */
+    int32_t* step_count;     /* [num_envs] */
+    int32_t* reset_ticks;    /* [num_envs] sim ticks used by the last reset's blocking move */
+    uint64_t* rng_state;     /* [num_envs] */
+} tg_state_view;
+int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
+/* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */
+int tg_set_joint_state(tg_ctx* ctx, const double* q, const double* qd);
+
+/* Per-kernel timing with HIP events on the launch stream (bench.py roofline leg). which: 0 step, 1 render, 2 reset. */
+int tg_profile_enable(tg_ctx* ctx, int32_t enable);
+int tg_profile_get(tg_ctx* ctx, int32_t which, double* total_ms, int64_t* launches);
+
+/* ---- function-level entry points (parity tests call the device implementations through these) --------------------- */
+/* calculateInverseDynamics (base_robot_arm.py:176-178), batch of n states; physics_dtype as in tg_config. */
+int tg_inverse_dynamics(const tg_robot* robot, int32_t physics_dtype, int32_t n, const double* q, const double* qd,
+                        const double* qdd, double* tau);
+/* joint-space inertia matrix, [n][ndof][ndof]. */
+int tg_mass_matrix(const tg_robot* robot, int32_t physics_dtype, int32_t n, const double* q, double* M);
+/* calculateJacobian at the TCP frame (base_robot_arm.py:300-307): J [n][6][ndof]; also TCP pose [n][3], [n][9]. */
+int tg_jacobian_tcp(const tg_robot* robot, int32_t physics_dtype, int32_t n, const double* q, double* J, double* pos,
+                    double* rot);
+/* n_ticks x stepSimulation (robot.py:131-141) with gravity compensation and velocity (mode 1) or position (mode 2)
+ * motors; q, qd updated in place ([n][ndof]). */
+int tg_sim_ticks(const tg_robot* robot, int32_t physics_dtype, int32_t n, int32_t n_ticks, int32_t solver_iterations,
+                 double dt, int32_t motor_mode, const double* q_des, const double* qd_des, double max_force, double* q,
+                 double* qd);
+/* getCameraImage depth + t_s_camera (tactile_sensor.py:239-294) for n transforms [n][12] -> uint8 [n][h][w]. */
+int tg_render_tactile(const tg_sensor* sensor, const tg_mesh* mesh, int32_t n, const float* cam_from_obj, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+/*
+ * oracle/minibullet.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU (double precision, scalar, deliberately naive) restatement of the handful of PyBullet calls that the
+ * reference's per-step hot path makes.  The reference is pure Python; all arithmetic on this path lives in the
+ * un-vendored third-party `pybullet` wheel (requirements.txt:6, `pybullet>=3.1.0`, no pinned version), which is
+ * not installable here.  Each function below therefore restates the *published* Bullet algorithm for the call
+ * site it replaces and cites that call site; every Bullet-internal behaviour that is assumed rather than
+ * verified is listed in PARITY_ASSUMPTIONS.md.
+ *
+ * Pinning status:
+ *   - mb_render_depth / camera chain: PINNED against the reference's committed fixtures
+ *     (assets/robot_assets/<sensor>/reference_images/<type>/<N>x<N>/nodef_dep.npy) — tests/test_oracle_golden.py.
+ *   - mb_fk: pinned against the reference's rest poses / work frames (edge_follow/rest_poses.py:6-20,
+ *     edge_follow_env.py:95,106-107,305).
+ *   - mb_step / mb_inverse_dynamics / mb_ik (post-step poses): PARITY UNPINNED — the reference holds no golden
+ *     vectors for them and PyBullet cannot be run here.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#ifndef MINIBULLET_H
+#define MINIBULLET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MB_MAX_DOF 8
+#define MB_MAX_BODIES 24
+
+typedef struct {
+    int32_t ndof;
+    int32_t nbodies;
+    int32_t parent[MB_MAX_DOF];          /* parent moving link, -1 = fixed base */
+    double joint_pos[MB_MAX_DOF][3];     /* joint origin in parent link frame */
+    double joint_rot[MB_MAX_DOF][9];     /* joint frame orientation in parent link frame (row major) */
+    double joint_axis[MB_MAX_DOF][3];    /* revolute axis in joint frame */
+    int32_t body_link[MB_MAX_BODIES];
+    double body_com[MB_MAX_BODIES][3];
+    double body_rot[MB_MAX_BODIES][9];
+    double body_mass[MB_MAX_BODIES];
+    double body_inertia[MB_MAX_BODIES][3];
+    double gravity[3];                   /* base_tactile_env.py:126 setGravity(0,0,-9.81) */
+    double linear_damping;               /* base_robot_arm.py:24 (0.04) */
+    double angular_damping;              /* base_robot_arm.py:24 (0.04) */
+    double joint_damping;                /* base_robot_arm.py:25 (0.01) */
+} mb_model;
+
+enum { MB_MOTOR_OFF = 0, MB_MOTOR_VELOCITY = 1, MB_MOTOR_POSITION = 2 };
+
+typedef struct {
+    double q[MB_MAX_DOF];
+    double qd[MB_MAX_DOF];
+    double applied_torque[MB_MAX_DOF];   /* TORQUE_CONTROL feed-forward, cleared every tick like Bullet's forces */
+    int32_t motor_mode[MB_MAX_DOF];
+    double motor_q_des[MB_MAX_DOF];
+    double motor_qd_des[MB_MAX_DOF];
+    double motor_kp[MB_MAX_DOF];
+    double motor_kd[MB_MAX_DOF];
+    double motor_max_force[MB_MAX_DOF];
+} mb_state;
+
+/* getLinkState(..)[0:2] forward kinematics: world rotation (row-major 3x3) and origin of every moving link. */
+void mb_fk(const mb_model* m, const double* q, double* R /*[ndof][9]*/, double* p /*[ndof][3]*/);
+
+/* getLinkState for a frame rigidly attached to moving link `link` (PyBullet reports the inertial frame):
+ * pos[3], rot[9], and (computeLinkVelocity=1) world linear velocity of the frame origin and angular velocity. */
+void mb_frame_state(const mb_model* m, const double* q, const double* qd, int link, const double* fpos,
+                    const double* frot, double* pos, double* rot, double* linvel, double* angvel);
+
+/* calculateInverseDynamics(q, qd, qdd) — base_robot_arm.py:176-178. */
+void mb_inverse_dynamics(const mb_model* m, const double* q, const double* qd, const double* qdd, double* tau);
+
+/* joint-space inertia matrix M(q) [ndof x ndof] (used by mb_step; exposed for tests). */
+void mb_mass_matrix(const mb_model* m, const double* q, double* M);
+
+/* calculateJacobian(link, localPosition=[0,0,0]) — base_robot_arm.py:300-307.  J is [6][ndof] row-major,
+ * rows 0-2 translational, 3-5 rotational, world frame. */
+void mb_jacobian(const mb_model* m, const double* q, int link, const double* fpos, double* J);
+
+/* stepSimulation() — robot.py:141 with base_tactile_env.py:127-130 parameters. */
+void mb_step(const mb_model* m, mb_state* s, double dt, int solver_iterations);
+
+/* calculateInverseKinematics(link, pos, orn, maxNumIterations, residualThreshold) — base_robot_arm.py:201-209.
+ * target_rot row-major 3x3.  q is updated in place from its starting value.  Returns iterations used. */
+int mb_ik(const mb_model* m, int link, const double* fpos, const double* frot, const double* target_pos,
+          const double* target_rot, double* q, int max_iters, double residual_threshold);
+
+/* ----------------------------------------------------------------------------------------------------------
+ * getCameraImage() depth channel — tactile_sensor.py:239-246 — for a triangle soup given in object coordinates
+ * and a camera<-object rigid transform (GL eye space: x right, y up, -z forward).  Single precision, following the
+ * raster specification in DESIGN.md section "Raster specification" operation by operation.
+ * depth[h*w] must be pre-filled (1.0f = far plane or an existing depth image); the routine z-tests into it. */
+void mb_render_depth(const float* verts /*[nv][3]*/, int nv, const int32_t* tris /*[nt][3]*/, int nt,
+                     const float* cam_from_obj /*[12]: R row-major 3x3 then t[3]*/, float fov_deg, float near_,
+                     float far_, int w, int h, float* depth);
+
+/* TactileSensor.t_s_camera() post-process — tactile_sensor.py:271-292 — on a current depth image. */
+void mb_t_s_camera(const float* cur_dep, const float* nodef_dep, const float* nodef_gray, const uint8_t* border_mask,
+                   int npix, int turn_off_border, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

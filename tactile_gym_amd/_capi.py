@@ -1,0 +1,134 @@
+"""ctypes binding of libtactile_gym_hip.so (C ABI declared in include/tactile_gym_hip.h).
+
+The HIP library is the product path; there is no CPU fallback.  Importing this module is cheap, loading the library
+(`lib()`) fails loudly with build instructions if the shared object is missing.
+"""
+import ctypes as C
+import os
+
+MAX_DOF = 8
+MAX_BODIES_PER_LINK = 4
+ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtactile_gym_hip.so")
+
+ENV_EDGE_FOLLOW = 0
+MOVE = {"xy": 0, "xyz": 1, "xyRz": 2, "xyzRz": 3}
+NOISE = {"fixed_height": 0, "rand_height": 1}
+REWARD = {"dense": 0, "sparse": 1}
+PHYSICS = {"f64": 0, "f32": 1}
+MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
+
+_d3 = C.c_double * 3
+_d9 = C.c_double * 9
+
+
+class TgRobot(C.Structure):
+    _fields_ = [
+        ("ndof", C.c_int32), ("topology", C.c_int32),
+        ("joint_pos", _d3 * MAX_DOF), ("joint_rot", _d9 * MAX_DOF), ("joint_axis", _d3 * MAX_DOF),
+        ("body_mass", (C.c_double * MAX_BODIES_PER_LINK) * MAX_DOF),
+        ("body_com", (_d3 * MAX_BODIES_PER_LINK) * MAX_DOF),
+        ("body_rot", (_d9 * MAX_BODIES_PER_LINK) * MAX_DOF),
+        ("body_inertia", (_d3 * MAX_BODIES_PER_LINK) * MAX_DOF),
+        ("tcp_link", C.c_int32), ("tcp_pos", _d3), ("tcp_rot", _d9),
+        ("sensor_link", C.c_int32), ("sensor_pos", _d3), ("sensor_rot", _d9),
+        ("gravity", _d3), ("linear_damping", C.c_double), ("angular_damping", C.c_double), ("joint_damping", C.c_double),
+        ("max_force", C.c_double), ("pos_gain", C.c_double), ("vel_gain", C.c_double),
+        ("rest_q", C.c_double * MAX_DOF),
+    ]
+
+
+class TgSensor(C.Structure):
+    _fields_ = [
+        ("image_h", C.c_int32), ("image_w", C.c_int32), ("cam_pos", _d3), ("cam_rpy", _d3),
+        ("fov_deg", C.c_double), ("near_plane", C.c_double), ("far_plane", C.c_double), ("turn_off_border", C.c_int32),
+        ("nodef_dep", C.POINTER(C.c_float)), ("nodef_gray", C.POINTER(C.c_float)), ("border_mask", C.POINTER(C.c_uint8)),
+    ]
+
+
+class TgMesh(C.Structure):
+    _fields_ = [("n_verts", C.c_int32), ("n_tris", C.c_int32), ("verts", C.POINTER(C.c_float)), ("tris", C.POINTER(C.c_int32))]
+
+
+class TgConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("env_kind", C.c_int32), ("num_envs", C.c_int32), ("max_steps", C.c_int32),
+        ("movement_mode", C.c_int32), ("noise_mode", C.c_int32), ("reward_mode", C.c_int32), ("physics_dtype", C.c_int32),
+        ("action_repeat", C.c_int32), ("solver_iterations", C.c_int32), ("auto_reset", C.c_int32), ("device", C.c_int32),
+        ("sim_dt", C.c_double), ("min_action", C.c_double), ("max_action", C.c_double),
+        ("act_lo", C.c_double * 6), ("act_hi", C.c_double * 6), ("tcp_lims", (C.c_double * 2) * 6),
+        ("workframe_pos", _d3), ("workframe_rpy", _d3), ("stim_pos", _d3),
+        ("edge_height", C.c_double), ("edge_len", C.c_double), ("termination_dist", C.c_double),
+        ("embed_dist", C.c_double), ("embed_lo", C.c_double), ("embed_hi", C.c_double),
+    ]
+
+
+class TgStateView(C.Structure):
+    _fields_ = [
+        ("q", C.POINTER(C.c_double)), ("qd", C.POINTER(C.c_double)), ("qd_target", C.POINTER(C.c_double)),
+        ("tcp_pos", C.POINTER(C.c_double)), ("tcp_rpy", C.POINTER(C.c_double)), ("edge_ang", C.POINTER(C.c_double)),
+        ("embed_dist", C.POINTER(C.c_double)), ("stim_xform", C.POINTER(C.c_float)), ("step_count", C.POINTER(C.c_int32)),
+        ("reset_ticks", C.POINTER(C.c_int32)), ("rng_state", C.POINTER(C.c_uint64)),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/tactile_gym_hip.h declares
+_dp, _fp, _u8p, _vpp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_void_p)
+_ctx = C.c_void_p
+SYMBOLS = {
+    "tg_last_error": (C.c_char_p, []),
+    "tg_abi_version": (C.c_int, []),
+    "tg_create": (C.c_int, [C.POINTER(TgConfig), C.POINTER(TgRobot), C.POINTER(TgSensor), C.POINTER(TgMesh), C.POINTER(_ctx)]),
+    "tg_destroy": (C.c_int, [_ctx]),
+    "tg_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "tg_seed": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.c_int32]),
+    "tg_reset": (C.c_int, [_ctx, _u8p]),
+    "tg_step": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
+    "tg_sync": (C.c_int, [_ctx]),
+    "tg_get_obs_tactile": (C.c_int, [_ctx, _vpp]),
+    "tg_get_terminal_obs": (C.c_int, [_ctx, _vpp]),
+    "tg_get_reward_done_dev": (C.c_int, [_ctx, _vpp, _vpp]),
+    "tg_get_reward_done": (C.c_int, [_ctx, _fp, _u8p]),
+    "tg_copy_obs_tactile": (C.c_int, [_ctx, _u8p, C.c_int32]),
+    "tg_get_state": (C.c_int, [_ctx, C.POINTER(TgStateView)]),
+    "tg_set_joint_state": (C.c_int, [_ctx, _dp, _dp]),
+    "tg_profile_enable": (C.c_int, [_ctx, C.c_int32]),
+    "tg_profile_get": (C.c_int, [_ctx, C.c_int32, _dp, C.POINTER(C.c_int64)]),
+    "tg_inverse_dynamics": (C.c_int, [C.POINTER(TgRobot), C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
+    "tg_mass_matrix": (C.c_int, [C.POINTER(TgRobot), C.c_int32, C.c_int32, _dp, _dp]),
+    "tg_jacobian_tcp": (C.c_int, [C.POINTER(TgRobot), C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
+    "tg_sim_ticks": (C.c_int, [C.POINTER(TgRobot), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _dp,
+                               C.c_double, _dp, _dp]),
+    "tg_render_tactile": (C.c_int, [C.POINTER(TgSensor), C.POINTER(TgMesh), C.c_int32, _fp, _u8p]),
+}
+
+_lib = None
+
+
+class TactileGymHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtactile_gym_hip.so; raise with build instructions if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise TactileGymHipError(
+                f"{LIB_PATH} is missing.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                f"`tactile_gym_amd/csrc/build.sh` (hipcc, --offload-arch=gfx950).  There is no CPU fallback for the env step.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if L.tg_abi_version() != ABI_VERSION:
+            raise TactileGymHipError("libtactile_gym_hip.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TactileGymHipError(lib().tg_last_error().decode("utf-8", "replace") or f"libtactile_gym_hip error {rc}")

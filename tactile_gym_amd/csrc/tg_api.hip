@@ -1,0 +1,987 @@
+// tg_api.hip — env-step / reset kernels and the C ABI of libtactile_gym_hip.so (see include/tactile_gym_hip.h).
+//
+// Per-env state lives in HBM as struct-of-arrays with the env index minor ([field][num_envs], doubles), so a
+// wavefront of 64 consecutive envs reads or writes one 512-byte contiguous run per field: the whole dynamic state
+// crosses HBM exactly once per env step (in) and once (out); the 24 sim ticks in between run out of registers.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tactile_gym_hip.h"
+#include "tg_physics.hpp"
+#include "tg_raster.h"
+
+namespace tg {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define TG_HIP(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ task constants
+template <typename T> struct EnvConst {
+    int num_envs, act_dim, movement_mode, noise_mode, reward_mode, max_steps, action_repeat, solver_iters;
+    T dt, min_action, max_action, act_lo[6], act_hi[6], tcp_lims[6][2];
+    T work_pos[3];
+    Q4<T> work_q, work_qinv;
+    M3<T> work_R, work_Rinv;
+    T work_inv_pos[3];
+    T stim_pos[3], edge_height, edge_len, term_dist, embed_default;
+    double embed_lo, embed_hi;   // random draws are evaluated in double on every path
+    M3<T> cam_rot;               // R(cam_rpy) in the sensor-body frame
+    T cam_pos[3];
+};
+
+struct State {   // device pointers, SoA [field][num_envs]
+    double *q, *qd, *qd_target, *tcp_pos, *tcp_rpy, *edge_ang, *embed;
+    float *stim_xform, *reward;
+    int32_t *step_count, *reset_ticks;
+    uint64_t* rng;
+    uint8_t* done;
+};
+
+// SplitMix64 (identical integer stream in oracle/ref_env.py: Rng)
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+__device__ inline double rng_uniform(uint64_t& s, double lo, double hi) {
+    s += kGolden;
+    const double u = (double)(mix64(s) >> 11) * (1.0 / 9007199254740992.0);
+    return lo + (hi - lo) * u;
+}
+
+// World pose of the TCP frame -> work-frame position / rpy, following the reference's chain of PyBullet helpers
+// (base_robot_arm.py:62-75, 153-172): matrix -> quaternion -> euler -> quaternion -> multiply -> euler.
+template <typename T>
+__device__ __forceinline__ void world_to_work(const EnvConst<T>& c, V3<T> pos, const M3<T>& R, V3<T>& wpos, T (&wrpy)[3], T (&rpy_world)[3]) {
+    Q4<T> q = quat_from_mat(R);
+    euler_from_quat(q, rpy_world[0], rpy_world[1], rpy_world[2]);
+    const Q4<T> q2 = quat_from_euler(rpy_world[0], rpy_world[1], rpy_world[2]);
+    wpos = load_v3(c.work_inv_pos) + mul(c.work_Rinv, pos);
+    const Q4<T> qw = quat_mul(c.work_qinv, q2);
+    euler_from_quat(qw, wrpy[0], wrpy[1], wrpy[2]);
+}
+
+// Everything that follows the physics of a step or a reset: TCP pose read-back, reward / termination
+// (edge_follow_env.py:371-452) and the camera<-stimulus transform handed to the raster (tactile_sensor.py:150-229).
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                           T edge_ang, int step_count, bool write_reward_done) {
+    const int n = c.num_envs;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    T rpy[3];
+    { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
+    st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
+    st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    T se, ce;
+    tsincos(edge_ang, &se, &ce);
+    if (write_reward_done) {
+        const T gx = c.stim_pos[0] + c.edge_len * ce, gy = c.stim_pos[1] + c.edge_len * se;
+        const T dx = ptcp.x - gx, dy = ptcp.y - gy;
+        const T goal_dist = tsqrt(dx * dx + dy * dy);
+        const bool done = goal_dist < c.term_dist || step_count >= c.max_steps;
+        // perpendicular distance to the edge centre line: |(p2-p1) x (p1-p3)| / |p2-p1|
+        const T p1x = c.stim_pos[0] - c.edge_len * ce, p1y = c.stim_pos[1] - c.edge_len * se;
+        const T d21x = gx - p1x, d21y = gy - p1y, d13x = p1x - ptcp.x, d13y = p1y - ptcp.y;
+        const T edge_dist = tabs(d21x * d13y - d21y * d13x) / tsqrt(d21x * d21x + d21y * d21y);
+        T reward;
+        if (c.reward_mode == TG_REWARD_SPARSE) reward = goal_dist < c.term_dist ? T(1) : T(0);
+        else reward = -((T(1) * goal_dist) + (T(10) * edge_dist) + T(0));
+        st.reward[env] = (float)reward;
+        st.done[env] = done ? 1 : 0;
+    }
+    // camera frame = sensor-body frame o cam offset; eye axes (right, up, -forward) with forward = R[:,0], up = R[:,2]
+    V3<T> pb; M3<T> Rb;
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
+    const M3<T> Rc = mul(Rb, c.cam_rot);
+    V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
+    f = (T(1) / norm(f)) * f;
+    V3<T> s = cross(f, up);
+    s = (T(1) / norm(s)) * s;
+    const V3<T> u = cross(s, f);
+    // object rotation: yaw about z by edge_ang
+    const V3<T> ox{ce, se, T(0)}, oy{-se, ce, T(0)}, oz{T(0), T(0), T(1)};
+    const V3<T> dp = load_v3(c.stim_pos) - pc;
+    const V3<T> nf = mk<T>(0, 0, 0) - f;
+    float* X = st.stim_xform;
+    X[0 * n + env] = (float)dot(s, ox);  X[1 * n + env] = (float)dot(s, oy);  X[2 * n + env] = (float)dot(s, oz);
+    X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
+    X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
+    X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+}
+
+// ------------------------------------------------------------------------------------------------ step kernel
+// BaseTactileEnv.step (base_tactile_env.py:166-185): encode + scale the action, tcp_velocity_control
+// (base_robot_arm.py:281-332), action_repeat sim ticks (robot.py:182-183), reward / done, render transform.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                             const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    // encode_actions (edge_follow_env.py:345-369)
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    const float* a = actions + (size_t)env * c.act_dim;
+    enc[0] = (T)a[0]; enc[1] = (T)a[1];
+    if (c.movement_mode == TG_MOVE_XYZ) enc[2] = (T)a[2];
+    else if (c.movement_mode == TG_MOVE_XYRZ) enc[5] = (T)a[2];
+    else if (c.movement_mode == TG_MOVE_XYZRZ) { enc[2] = (T)a[2]; enc[5] = (T)a[3]; }
+    // scale_actions (base_tactile_env.py:141-164)
+    T vels[6];
+    const T in_range = c.max_action - c.min_action;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        T x = enc[d];
+        x = x < c.min_action ? c.min_action : (x > c.max_action ? c.max_action : x);
+        vels[d] = (((x - c.min_action) * (c.act_hi[d] - c.act_lo[d])) / in_range) + c.act_lo[d];
+    }
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+
+    // tcp_velocity_control
+    T qd_des[N];
+    {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> ptcp; M3<T> Rtcp;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+        V3<T> wpos; T wrpy[3], rpyw[3];
+        world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpyw);
+        const T cur[6] = {wpos.x, wpos.y, wpos.z, wrpy[0], wrpy[1], wrpy[2]};
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {   // check_TCP_vel_lims (base_robot_arm.py:357-380)
+            const bool ex = (cur[d] < c.tcp_lims[d][0] && vels[d] < T(0)) || (cur[d] > c.tcp_lims[d][1] && vels[d] > T(0));
+            if (ex) vels[d] = T(0);
+        }
+        const V3<T> lin = mul(c.work_R, mk(vels[0], vels[1], vels[2]));   // workvel_to_worldvel (:96-105)
+        const V3<T> ang = mul(c.work_R, mk(vels[3], vels[4], vels[5]));
+        T J[6][N];
+        tcp_jacobian<T, TOPO>(m, k, ptcp, J);
+        if (N == 6) {  // square: inverse (reference takes np.linalg.inv when rank is full, :316-319)
+            T A[6][6], b[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z}, x[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) A[r][cc] = J[r][cc < N ? cc : 0];
+            solve_pivoted<T, 6>(A, b, x);
+#pragma unroll
+            for (int i = 0; i < N; ++i) qd_des[i] = x[i < 6 ? i : 0];
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) qd_des[i] = T(0);   // MG400 pseudo-inverse path: not built yet
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+
+    T qdummy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    for (int t = 0; t < c.action_repeat; ++t)
+        sim_tick<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, true);
+
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true);
+}
+
+// ------------------------------------------------------------------------------------------------ reset kernel
+template <typename T> __device__ __forceinline__ V3<T> rot_error(const M3<T>& Rt, const M3<T>& R) {
+    // rotation vector of Rt R^T
+    M3<T> E;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) E.m[3 * i + j] = Rt.m[3 * i] * R.m[3 * j] + Rt.m[3 * i + 1] * R.m[3 * j + 1] + Rt.m[3 * i + 2] * R.m[3 * j + 2];
+    T cosang = T(0.5) * (E.m[0] + E.m[4] + E.m[8] - T(1));
+    cosang = cosang > T(1) ? T(1) : (cosang < T(-1) ? T(-1) : cosang);
+    const T ang = tacos(cosang);
+    const V3<T> ax{E.m[7] - E.m[5], E.m[2] - E.m[6], E.m[3] - E.m[1]};
+    const T s = norm(ax);
+    if (s < T(1e-12)) return T(0.5) * ax;
+    return (ang / s) * ax;
+}
+
+// EdgeFollowEnv.reset (edge_follow_env.py:311-336): reset_task (:285-299), Robot.reset (robot.py:114-125) =
+// rest pose + IK to the start pose (base_robot_arm.py:191-226) + blocking_move (robot.py:188-260).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                              const uint8_t* __restrict__ mask) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    if (mask != nullptr && mask[env] == 0) return;
+
+    uint64_t rs = st.rng[env];
+    double embed = (double)c.embed_default;
+    if (c.noise_mode == TG_NOISE_RAND_HEIGHT) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
+    const double edge_ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+    st.rng[env] = rs;
+    st.embed[env] = embed;
+    st.edge_ang[env] = edge_ang;
+    st.step_count[env] = 0;
+
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+
+    // start pose: work frame (0, 0, embed), rpy 0 -> world (workframe_to_worldframe, base_robot_arm.py:46-60)
+    const V3<T> tpos = load_v3(c.work_pos) + mul(c.work_R, mk(T(0), T(0), (T)embed));
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+
+    // calculateInverseKinematics: damped least squares from the rest pose
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    for (int it = 0; it < 100; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, qik, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const V3<T> ep = tpos - p, er = rot_error(Rt, R);
+        T e[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
+        T res = T(0);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) res += e[d] * e[d];
+        if (tsqrt(res) <= T(1e-8)) break;
+        T J[6][N];
+        tcp_jacobian<T, TOPO>(m, k, p, J);
+        T A[6][6], y[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+                T acc = (r == cc) ? T(1e-8) : T(0);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc += J[r][i] * J[cc][i];
+                A[r][cc] = acc;
+            }
+        solve_pivoted<T, 6>(A, e, y);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc += J[r][i] * y[r];
+            qik[i] += acc;
+        }
+    }
+
+    // blocking_move(max_steps=1000, constant_vel=0.001)
+    T cv = T(0.001);
+    T zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    int used = 0;
+    for (int it = 0; it < 1000; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], step_j[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        if (all_small) cv = cv / T(2);
+        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, true);
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        const T orn_err = tacos(ca);
+        if (pos_err < T(2e-4) && orn_err < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.reset_ticks[env] = used;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+    finish_env<T, TOPO>(m, c, st, env, q, (T)edge_ang, 0, false);
+}
+
+// Recompute cached read-backs after tg_set_joint_state.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_refresh(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st) {
+    constexpr int N = Topo<TOPO>::N;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = cp->num_envs;
+    if (env >= n) return;
+    T q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = (T)st.q[i * n + env];
+    finish_env<T, TOPO>(*mp, *cp, st, env, q, (T)st.edge_ang[env], st.step_count[env], false);
+}
+
+// ------------------------------------------------------------------------------------------------ function-level kernels
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_inverse_dynamics(const DevRobot<T>* __restrict__ mp, int n, const double* q, const double* qd, const double* qdd, double* tau) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T qq[N], qv[N], hb[N], qdm[N], Minv[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { qq[i] = (T)q[s * N + i]; qv[i] = (T)qd[s * N + i]; }
+    dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv);
+    // tau = M qdd + h ; M qdd obtained by solving Minv x = qdd would be circular, so rebuild M from Minv^-1 is avoided:
+    // use linearity  ID(q, qd, qdd) = h + M qdd with M = inverse(Minv) computed by the pivoted solver column by column.
+    T A[N][N], b[N], x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[i][j] = Minv[i][j];
+        b[i] = (T)qdd[s * N + i];
+    }
+    solve_pivoted<T, N>(A, b, x);   // x = M qdd
+#pragma unroll
+    for (int i = 0; i < N; ++i) tau[s * N + i] = (double)(hb[i] + x[i]);
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_mass_matrix(const DevRobot<T>* __restrict__ mp, int n, const double* q, double* M) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T qq[N], qv[N], hb[N], qdm[N], Minv[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { qq[i] = (T)q[s * N + i]; qv[i] = T(0); }
+    dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {   // column j of M = solve(Minv, e_j)
+        T A[N][N], b[N], x[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < N; ++jj) A[i][jj] = Minv[i][jj];
+            b[i] = (i == j) ? T(1) : T(0);
+        }
+        solve_pivoted<T, N>(A, b, x);
+#pragma unroll
+        for (int i = 0; i < N; ++i) M[(size_t)s * N * N + i * N + j] = (double)x[i];
+    }
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_jacobian(const DevRobot<T>* __restrict__ mp, int n, const double* q, double* J, double* pos, double* rot) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T qq[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qq[i] = (T)q[s * N + i];
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(*mp, qq, k);
+    V3<T> p; M3<T> R;
+    link_frame<T, TOPO>(k, mp->tcp_link, mp->tcp_pos, mp->tcp_rot, p, R);
+    T Jm[6][N];
+    tcp_jacobian<T, TOPO>(*mp, k, p, Jm);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int i = 0; i < N; ++i) J[(size_t)s * 6 * N + r * N + i] = (double)Jm[r][i];
+    pos[s * 3 + 0] = (double)p.x; pos[s * 3 + 1] = (double)p.y; pos[s * 3 + 2] = (double)p.z;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) rot[s * 9 + e] = (double)R.m[e];
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_sim_ticks(const DevRobot<T>* __restrict__ mp, int n, int n_ticks, int iters, double dt, int motor_mode, const double* q_des,
+                            const double* qd_des, double max_force, double* q, double* qd) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T qq[N], qv[N], qdes[N], vdes[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        qq[i] = (T)q[s * N + i]; qv[i] = (T)qd[s * N + i];
+        qdes[i] = q_des ? (T)q_des[s * N + i] : T(0); vdes[i] = qd_des ? (T)qd_des[s * N + i] : T(0);
+    }
+    for (int t = 0; t < n_ticks; ++t) {
+        if (motor_mode == kMotorVelocity) sim_tick<T, TOPO, kMotorVelocity>(*mp, qq, qv, qdes, vdes, T(0), mp->vel_gain, (T)max_force, (T)dt, iters, true);
+        else if (motor_mode == kMotorPosition) sim_tick<T, TOPO, kMotorPosition>(*mp, qq, qv, qdes, vdes, mp->pos_gain, mp->vel_gain, (T)max_force, (T)dt, iters, true);
+        else sim_tick<T, TOPO, kMotorOff>(*mp, qq, qv, qdes, vdes, T(0), T(0), T(0), (T)dt, iters, true);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[s * N + i] = (double)qq[i]; qd[s * N + i] = (double)qv[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------ host helpers
+static void h_quat_from_euler(const double* rpy, double* q) {
+    const double phi = 0.5 * rpy[0], the = 0.5 * rpy[1], psi = 0.5 * rpy[2];
+    q[0] = sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi);
+    q[1] = cos(phi) * sin(the) * cos(psi) + sin(phi) * cos(the) * sin(psi);
+    q[2] = cos(phi) * cos(the) * sin(psi) - sin(phi) * sin(the) * cos(psi);
+    q[3] = cos(phi) * cos(the) * cos(psi) + sin(phi) * sin(the) * sin(psi);
+    const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; ++k) q[k] /= nrm;
+}
+static void h_mat_from_quat(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;
+    const double xs = x * s, ys = y * s, zs = z * s, wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys,
+                 yz = y * zs, zz = z * zs;
+    R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+    R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
+}
+
+template <typename T> static int build_dev_robot(const tg_robot& r, DevRobot<T>& d) {
+    memset(&d, 0, sizeof d);
+    const int N = r.ndof;
+    for (int i = 0; i < N; ++i) {
+        for (int k = 0; k < 3; ++k) { d.jpos[i][k] = (T)r.joint_pos[i][k]; d.jaxis[i][k] = (T)r.joint_axis[i][k]; }
+        for (int k = 0; k < 9; ++k) d.jrot[i][k] = (T)r.joint_rot[i][k];
+        // merge the bodies welded to link i: m, com, inertia about com in link coordinates
+        double m = 0, com[3] = {0, 0, 0};
+        for (int b = 0; b < TG_MAX_BODIES_PER_LINK; ++b) {
+            m += r.body_mass[i][b];
+            for (int k = 0; k < 3; ++k) com[k] += r.body_mass[i][b] * r.body_com[i][b][k];
+        }
+        if (m > 0) for (int k = 0; k < 3; ++k) com[k] /= m;
+        double I[3][3] = {{0}};
+        for (int b = 0; b < TG_MAX_BODIES_PER_LINK; ++b) {
+            const double mb = r.body_mass[i][b];
+            if (mb <= 0) continue;
+            const double* R = r.body_rot[i][b];
+            for (int a = 0; a < 3; ++a)
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < 3; ++k) I[a][c] += R[3 * a + k] * r.body_inertia[i][b][k] * R[3 * c + k];
+            double dv[3];
+            for (int k = 0; k < 3; ++k) dv[k] = r.body_com[i][b][k] - com[k];
+            const double dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+            for (int a = 0; a < 3; ++a)
+                for (int c = 0; c < 3; ++c) I[a][c] += mb * ((a == c ? dd : 0.0) - dv[a] * dv[c]);
+        }
+        d.lmass[i] = (T)m;
+        for (int k = 0; k < 3; ++k) d.lcom[i][k] = (T)com[k];
+        d.linert[i][0] = (T)I[0][0]; d.linert[i][1] = (T)I[0][1]; d.linert[i][2] = (T)I[0][2];
+        d.linert[i][3] = (T)I[1][1]; d.linert[i][4] = (T)I[1][2]; d.linert[i][5] = (T)I[2][2];
+        for (int b = 0; b < TG_MAX_BODIES_PER_LINK; ++b) {
+            d.bmass[i][b] = (T)r.body_mass[i][b];
+            for (int k = 0; k < 3; ++k) { d.bcom[i][b][k] = (T)r.body_com[i][b][k]; d.binert[i][b][k] = (T)r.body_inertia[i][b][k]; }
+            for (int k = 0; k < 9; ++k) d.brot[i][b][k] = (T)r.body_rot[i][b][k];
+        }
+        d.rest_q[i] = (T)r.rest_q[i];
+    }
+    d.tcp_link = r.tcp_link; d.sensor_link = r.sensor_link;
+    for (int k = 0; k < 3; ++k) { d.tcp_pos[k] = (T)r.tcp_pos[k]; d.sensor_pos[k] = (T)r.sensor_pos[k]; d.gravity[k] = (T)r.gravity[k]; }
+    for (int k = 0; k < 9; ++k) { d.tcp_rot[k] = (T)r.tcp_rot[k]; d.sensor_rot[k] = (T)r.sensor_rot[k]; }
+    d.lin_damp = (T)r.linear_damping; d.ang_damp = (T)r.angular_damping; d.joint_damp = (T)r.joint_damping;
+    d.max_force = (T)r.max_force; d.pos_gain = (T)r.pos_gain; d.vel_gain = (T)r.vel_gain;
+    return 0;
+}
+
+static int check_robot(const tg_robot* r) {
+    if (!r) return fail(-1, "robot is NULL");
+    if (r->topology == 0 && r->ndof != Topo<0>::N) return fail(-1, "topology 0 (serial chain) is built for ndof = 6");
+    if (r->topology == 1 && r->ndof != Topo<1>::N) return fail(-1, "topology 1 (MG400 tree) needs ndof = 8");
+    if (r->topology != 0 && r->topology != 1) return fail(-1, "unknown robot topology");
+    if (r->tcp_link < 0 || r->tcp_link >= r->ndof || r->sensor_link < 0 || r->sensor_link >= r->ndof) return fail(-1, "frame link out of range");
+    return 0;
+}
+
+template <typename T> static int build_env_const(const tg_config& cfg, const tg_sensor& sen, EnvConst<T>& c) {
+    memset(&c, 0, sizeof c);
+    c.num_envs = cfg.num_envs;
+    c.movement_mode = cfg.movement_mode; c.noise_mode = cfg.noise_mode; c.reward_mode = cfg.reward_mode;
+    switch (cfg.movement_mode) {
+        case TG_MOVE_XY: c.act_dim = 2; break;
+        case TG_MOVE_XYZ: case TG_MOVE_XYRZ: c.act_dim = 3; break;
+        case TG_MOVE_XYZRZ: c.act_dim = 4; break;
+        default: return fail(-1, "Incorrect movement mode specified");
+    }
+    c.max_steps = cfg.max_steps; c.action_repeat = cfg.action_repeat; c.solver_iters = cfg.solver_iterations;
+    c.dt = (T)cfg.sim_dt; c.min_action = (T)cfg.min_action; c.max_action = (T)cfg.max_action;
+    for (int d = 0; d < 6; ++d) { c.act_lo[d] = (T)cfg.act_lo[d]; c.act_hi[d] = (T)cfg.act_hi[d]; c.tcp_lims[d][0] = (T)cfg.tcp_lims[d][0]; c.tcp_lims[d][1] = (T)cfg.tcp_lims[d][1]; }
+    double wq[4], wqi[4], R[9], Ri[9];
+    h_quat_from_euler(cfg.workframe_rpy, wq);
+    wqi[0] = -wq[0]; wqi[1] = -wq[1]; wqi[2] = -wq[2]; wqi[3] = wq[3];
+    h_mat_from_quat(wq, R); h_mat_from_quat(wqi, Ri);
+    c.work_q = {(T)wq[0], (T)wq[1], (T)wq[2], (T)wq[3]};
+    c.work_qinv = {(T)wqi[0], (T)wqi[1], (T)wqi[2], (T)wqi[3]};
+    for (int k = 0; k < 9; ++k) { c.work_R.m[k] = (T)R[k]; c.work_Rinv.m[k] = (T)Ri[k]; }
+    for (int k = 0; k < 3; ++k) {
+        c.work_pos[k] = (T)cfg.workframe_pos[k];
+        c.work_inv_pos[k] = (T)(-(Ri[3 * k] * cfg.workframe_pos[0] + Ri[3 * k + 1] * cfg.workframe_pos[1] + Ri[3 * k + 2] * cfg.workframe_pos[2]));
+        c.stim_pos[k] = (T)cfg.stim_pos[k];
+        c.cam_pos[k] = (T)sen.cam_pos[k];
+    }
+    c.edge_height = (T)cfg.edge_height; c.edge_len = (T)cfg.edge_len; c.term_dist = (T)cfg.termination_dist;
+    c.embed_default = (T)cfg.embed_dist; c.embed_lo = cfg.embed_lo; c.embed_hi = cfg.embed_hi;
+    double cq[4], cR[9];
+    h_quat_from_euler(sen.cam_rpy, cq);
+    h_mat_from_quat(cq, cR);
+    for (int k = 0; k < 9; ++k) c.cam_rot.m[k] = (T)cR[k];
+    return 0;
+}
+
+}  // namespace tg
+
+// ==================================================================================================== context
+struct tg_ctx {
+    tg_config cfg;
+    tg_robot robot;
+    int H, W, act_dim;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    void *d_robot = nullptr, *d_const = nullptr;   // DevRobot<T>, EnvConst<T>
+    tg::State st{};
+    tg::RasterParams rp{};
+    float *d_nodef_dep = nullptr, *d_nodef_gray = nullptr, *d_verts = nullptr, *d_actions = nullptr;
+    uint8_t *d_border = nullptr, *d_obs = nullptr, *d_term = nullptr, *d_mask = nullptr;
+    int32_t* d_tris = nullptr;
+    int n_tris = 0;
+    // profiling
+    bool profile = false;
+    struct Ev { hipEvent_t a, b; int which; };
+    std::vector<Ev> events;
+    double prof_ms[3] = {0, 0, 0};
+    int64_t prof_n[3] = {0, 0, 0};
+};
+
+namespace tg {
+
+struct Timer {
+    tg_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
+    Timer(tg_ctx* ctx, int w) : c(ctx), which(w) {
+        if (c->profile) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
+    }
+    ~Timer() {
+        if (c->profile) { (void)hipEventRecord(b, c->stream); c->events.push_back({a, b, which}); }
+    }
+};
+
+static void drain_events(tg_ctx* c) {
+    for (auto& e : c->events) {
+        (void)hipEventSynchronize(e.b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e.a, e.b);
+        c->prof_ms[e.which] += ms;
+        c->prof_n[e.which] += 1;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    c->events.clear();
+}
+
+template <typename T, int TOPO> static void launch_step_t(tg_ctx* c, const float* d_actions) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_step<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_actions);
+}
+template <typename T, int TOPO> static void launch_reset_t(tg_ctx* c, const uint8_t* d_mask) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_reset<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_mask);
+}
+template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_refresh<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st);
+}
+
+#define TG_DISPATCH(ctx_dtype, ctx_topo, CALL)                                               \
+    do {                                                                                     \
+        if ((ctx_dtype) == TG_PHYSICS_F64) {                                                 \
+            if ((ctx_topo) == 0) { CALL(double, 0); } else { CALL(double, 1); }              \
+        } else {                                                                             \
+            if ((ctx_topo) == 0) { CALL(float, 0); } else { CALL(float, 1); }                \
+        }                                                                                    \
+    } while (0)
+
+static void render(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
+    Timer t(c, 1);
+    launch_render(c->rp, c->d_verts, c->d_tris, c->n_tris, c->st.stim_xform, 1, c->cfg.num_envs, d_mask, c->d_nodef_dep, c->d_nodef_gray,
+                  c->d_border, c->d_obs, save_prev ? c->d_term : nullptr, c->stream);
+}
+
+// SoA [field][n] device -> AoS [n][field] host
+template <typename T> static int fetch_soa(tg_ctx* c, const T* dev, int fields, T* host) {
+    const int n = c->cfg.num_envs;
+    std::vector<T> tmp((size_t)fields * n);
+    hipError_t e = hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) return fail(-2, hipGetErrorString(e));
+    e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(-2, hipGetErrorString(e));
+    for (int f = 0; f < fields; ++f)
+        for (int i = 0; i < n; ++i) host[(size_t)i * fields + f] = tmp[(size_t)f * n + i];
+    return 0;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
+};
+
+template <typename T> static int upload_robot(const tg_robot* robot, DevBuf& buf) {
+    DevRobot<T> dr;
+    build_dev_robot(*robot, dr);
+    if (buf.alloc(sizeof dr)) return fail(-2, "hipMalloc failed");
+    if (hipMemcpy(buf.p, &dr, sizeof dr, hipMemcpyHostToDevice) != hipSuccess) return fail(-2, "hipMemcpy failed");
+    return 0;
+}
+
+static int need_device() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "no HIP device visible — no CPU fallback");
+    return 0;
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+const char* tg_last_error(void) { return g_err.c_str(); }
+int tg_abi_version(void) { return TG_ABI_VERSION; }
+
+int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sensor, const tg_mesh* stim, tg_ctx** out) {
+    if (!cfg || !robot || !sensor || !stim || !out) return fail(-1, "tg_create: NULL argument");
+    if (cfg->abi_version != TG_ABI_VERSION) return fail(-1, "tg_create: ABI version mismatch");
+    if (cfg->env_kind != TG_ENV_EDGE_FOLLOW) return fail(-1, "tg_create: unknown env_kind");
+    if (cfg->num_envs <= 0) return fail(-1, "tg_create: num_envs must be positive");
+    if (int rc = check_robot(robot)) return rc;
+    const int H = sensor->image_h, W = sensor->image_w;
+    if (!((H % 128 == 0 && W % 128 == 0) || (H == 64 && W == 64))) return fail(-1, "tg_create: image size must be 64x64 or a multiple of 128");
+    if (!sensor->nodef_dep || !sensor->nodef_gray || !sensor->border_mask) return fail(-1, "tg_create: sensor reference images missing");
+    if (cfg->physics_dtype != TG_PHYSICS_F64 && cfg->physics_dtype != TG_PHYSICS_F32) return fail(-1, "tg_create: bad physics_dtype");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(-3, "tg_create: no HIP device visible — the tactile-env step has no CPU fallback");
+    TG_HIP(hipSetDevice(cfg->device));
+    tg_ctx* c = new tg_ctx();
+    c->cfg = *cfg; c->robot = *robot; c->H = H; c->W = W;
+    TG_HIP(hipStreamCreate(&c->own_stream));
+    c->stream = c->own_stream;
+    const int n = cfg->num_envs;
+    const size_t npix = (size_t)H * W;
+    if (cfg->physics_dtype == TG_PHYSICS_F64) {
+        DevRobot<double> dr; EnvConst<double> ec;
+        build_dev_robot(*robot, dr);
+        if (int rc = build_env_const(*cfg, *sensor, ec)) { delete c; return rc; }
+        c->act_dim = ec.act_dim;
+        TG_HIP(hipMalloc(&c->d_robot, sizeof dr)); TG_HIP(hipMemcpy(c->d_robot, &dr, sizeof dr, hipMemcpyHostToDevice));
+        TG_HIP(hipMalloc(&c->d_const, sizeof ec)); TG_HIP(hipMemcpy(c->d_const, &ec, sizeof ec, hipMemcpyHostToDevice));
+    } else {
+        DevRobot<float> dr; EnvConst<float> ec;
+        build_dev_robot(*robot, dr);
+        if (int rc = build_env_const(*cfg, *sensor, ec)) { delete c; return rc; }
+        c->act_dim = ec.act_dim;
+        TG_HIP(hipMalloc(&c->d_robot, sizeof dr)); TG_HIP(hipMemcpy(c->d_robot, &dr, sizeof dr, hipMemcpyHostToDevice));
+        TG_HIP(hipMalloc(&c->d_const, sizeof ec)); TG_HIP(hipMemcpy(c->d_const, &ec, sizeof ec, hipMemcpyHostToDevice));
+    }
+    State& s = c->st;
+    const size_t nd = (size_t)TG_MAX_DOF * n;
+    TG_HIP(hipMalloc(&s.q, nd * 8)); TG_HIP(hipMalloc(&s.qd, nd * 8)); TG_HIP(hipMalloc(&s.qd_target, nd * 8));
+    TG_HIP(hipMalloc(&s.tcp_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.tcp_rpy, 3 * n * 8));
+    TG_HIP(hipMalloc(&s.edge_ang, n * 8)); TG_HIP(hipMalloc(&s.embed, n * 8));
+    TG_HIP(hipMalloc(&s.stim_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.reward, n * 4));
+    TG_HIP(hipMalloc(&s.step_count, n * 4)); TG_HIP(hipMalloc(&s.reset_ticks, n * 4));
+    TG_HIP(hipMalloc(&s.rng, n * 8)); TG_HIP(hipMalloc(&s.done, n));
+    TG_HIP(hipMemset(s.q, 0, nd * 8)); TG_HIP(hipMemset(s.qd, 0, nd * 8)); TG_HIP(hipMemset(s.qd_target, 0, nd * 8));
+    TG_HIP(hipMemset(s.tcp_pos, 0, 3 * n * 8)); TG_HIP(hipMemset(s.tcp_rpy, 0, 3 * n * 8));
+    TG_HIP(hipMemset(s.edge_ang, 0, n * 8)); TG_HIP(hipMemset(s.embed, 0, n * 8));
+    TG_HIP(hipMemset(s.stim_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.reward, 0, n * 4));
+    TG_HIP(hipMemset(s.step_count, 0, n * 4)); TG_HIP(hipMemset(s.reset_ticks, 0, n * 4)); TG_HIP(hipMemset(s.done, 0, n));
+    std::vector<uint64_t> seeds(n);
+    for (int i = 0; i < n; ++i) seeds[i] = mix64((uint64_t)i + kGolden);
+    TG_HIP(hipMemcpy(s.rng, seeds.data(), n * 8, hipMemcpyHostToDevice));
+    TG_HIP(hipMalloc(&c->d_nodef_dep, npix * 4)); TG_HIP(hipMemcpy(c->d_nodef_dep, sensor->nodef_dep, npix * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMalloc(&c->d_nodef_gray, npix * 4)); TG_HIP(hipMemcpy(c->d_nodef_gray, sensor->nodef_gray, npix * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMalloc(&c->d_border, npix)); TG_HIP(hipMemcpy(c->d_border, sensor->border_mask, npix, hipMemcpyHostToDevice));
+    TG_HIP(hipMalloc(&c->d_verts, (size_t)stim->n_verts * 12)); TG_HIP(hipMemcpy(c->d_verts, stim->verts, (size_t)stim->n_verts * 12, hipMemcpyHostToDevice));
+    TG_HIP(hipMalloc(&c->d_tris, (size_t)stim->n_tris * 12)); TG_HIP(hipMemcpy(c->d_tris, stim->tris, (size_t)stim->n_tris * 12, hipMemcpyHostToDevice));
+    c->n_tris = stim->n_tris;
+    TG_HIP(hipMalloc(&c->d_obs, npix * n)); TG_HIP(hipMemset(c->d_obs, 0, npix * n));
+    TG_HIP(hipMalloc(&c->d_term, npix * n)); TG_HIP(hipMemset(c->d_term, 0, npix * n));
+    TG_HIP(hipMalloc(&c->d_mask, n));
+    TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 4 * sizeof(float)));
+    c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border);
+    *out = c;
+    return 0;
+}
+
+int tg_destroy(tg_ctx* c) {
+    if (!c) return 0;
+    (void)hipStreamSynchronize(c->stream);
+    drain_events(c);
+    State& s = c->st;
+    void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.reward,
+                    s.step_count, s.reset_ticks, s.rng, s.done, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+int tg_set_stream(tg_ctx* c, void* s) {
+    if (!c) return fail(-1, "NULL ctx");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+int tg_seed(tg_ctx* c, const uint64_t* seeds, int32_t n) {
+    if (!c || !seeds) return fail(-1, "tg_seed: NULL argument");
+    if (n != c->cfg.num_envs) return fail(-1, "tg_seed: need one seed per env");
+    std::vector<uint64_t> st(n);
+    for (int i = 0; i < n; ++i) st[i] = mix64(seeds[i] + kGolden);
+    TG_HIP(hipMemcpyAsync(c->st.rng, st.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
+    if (!c) return fail(-1, "NULL ctx");
+    const uint8_t* dmask = nullptr;
+    if (host_mask) {
+        TG_HIP(hipMemcpyAsync(c->d_mask, host_mask, c->cfg.num_envs, hipMemcpyHostToDevice, c->stream));
+        dmask = c->d_mask;
+    }
+    {
+        Timer t(c, 2);
+#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, dmask)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    }
+    render(c, dmask, false);
+    TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
+    if (!c || !actions) return fail(-1, "tg_step: NULL argument");
+    const float* d_act = actions;
+    if (!on_device) {
+        TG_HIP(hipMemcpyAsync(c->d_actions, actions, (size_t)c->cfg.num_envs * c->act_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d_act = c->d_actions;
+    }
+    {
+        Timer t(c, 0);
+#define CALL(T, TOPO) launch_step_t<T, TOPO>(c, d_act)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    }
+    render(c, nullptr, false);
+    if (c->cfg.auto_reset) {
+        {
+            Timer t(c, 2);
+#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, c->st.done)
+            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+        }
+        render(c, c->st.done, true);   // terminal observation is saved, then the post-reset observation is drawn
+    }
+    TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_sync(tg_ctx* c) {
+    if (!c) return fail(-1, "NULL ctx");
+    TG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tg_get_obs_tactile(tg_ctx* c, void** p) { if (!c || !p) return fail(-1, "NULL argument"); *p = c->d_obs; return 0; }
+int tg_get_terminal_obs(tg_ctx* c, void** p) { if (!c || !p) return fail(-1, "NULL argument"); *p = c->d_term; return 0; }
+int tg_get_reward_done_dev(tg_ctx* c, void** r, void** d) {
+    if (!c) return fail(-1, "NULL ctx");
+    if (r) *r = c->st.reward;
+    if (d) *d = c->st.done;
+    return 0;
+}
+int tg_get_reward_done(tg_ctx* c, float* reward, uint8_t* done) {
+    if (!c) return fail(-1, "NULL ctx");
+    const int n = c->cfg.num_envs;
+    if (reward) TG_HIP(hipMemcpyAsync(reward, c->st.reward, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (done) TG_HIP(hipMemcpyAsync(done, c->st.done, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int tg_copy_obs_tactile(tg_ctx* c, uint8_t* dst, int32_t terminal) {
+    if (!c || !dst) return fail(-1, "NULL argument");
+    TG_HIP(hipMemcpyAsync(dst, terminal ? c->d_term : c->d_obs, (size_t)c->cfg.num_envs * c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tg_get_state(tg_ctx* c, const tg_state_view* v) {
+    if (!c || !v) return fail(-1, "NULL argument");
+    const int nd = c->robot.ndof;
+    int rc = 0;
+    if (v->q && (rc = fetch_soa(c, c->st.q, nd, v->q))) return rc;
+    if (v->qd && (rc = fetch_soa(c, c->st.qd, nd, v->qd))) return rc;
+    if (v->qd_target && (rc = fetch_soa(c, c->st.qd_target, nd, v->qd_target))) return rc;
+    if (v->tcp_pos && (rc = fetch_soa(c, c->st.tcp_pos, 3, v->tcp_pos))) return rc;
+    if (v->tcp_rpy && (rc = fetch_soa(c, c->st.tcp_rpy, 3, v->tcp_rpy))) return rc;
+    if (v->edge_ang && (rc = fetch_soa(c, c->st.edge_ang, 1, v->edge_ang))) return rc;
+    if (v->embed_dist && (rc = fetch_soa(c, c->st.embed, 1, v->embed_dist))) return rc;
+    if (v->stim_xform && (rc = fetch_soa(c, c->st.stim_xform, 12, v->stim_xform))) return rc;
+    if (v->step_count && (rc = fetch_soa(c, c->st.step_count, 1, v->step_count))) return rc;
+    if (v->reset_ticks && (rc = fetch_soa(c, c->st.reset_ticks, 1, v->reset_ticks))) return rc;
+    if (v->rng_state && (rc = fetch_soa(c, c->st.rng, 1, v->rng_state))) return rc;
+    return 0;
+}
+
+int tg_set_joint_state(tg_ctx* c, const double* q, const double* qd) {
+    if (!c || !q || !qd) return fail(-1, "NULL argument");
+    const int n = c->cfg.num_envs, nd = c->robot.ndof;
+    std::vector<double> a((size_t)TG_MAX_DOF * n, 0.0), b((size_t)TG_MAX_DOF * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int f = 0; f < nd; ++f) { a[(size_t)f * n + i] = q[(size_t)i * nd + f]; b[(size_t)f * n + i] = qd[(size_t)i * nd + f]; }
+    TG_HIP(hipMemcpyAsync(c->st.q, a.data(), a.size() * 8, hipMemcpyHostToDevice, c->stream));
+    TG_HIP(hipMemcpyAsync(c->st.qd, b.data(), b.size() * 8, hipMemcpyHostToDevice, c->stream));
+#define CALL(T, TOPO) launch_refresh_t<T, TOPO>(c)
+    TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    render(c, nullptr, false);
+    TG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tg_profile_enable(tg_ctx* c, int32_t enable) {
+    if (!c) return fail(-1, "NULL ctx");
+    (void)hipStreamSynchronize(c->stream);
+    drain_events(c);
+    c->profile = enable != 0;
+    for (int k = 0; k < 3; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    return 0;
+}
+int tg_profile_get(tg_ctx* c, int32_t which, double* total_ms, int64_t* launches) {
+    if (!c || which < 0 || which > 2) return fail(-1, "bad argument");
+    (void)hipStreamSynchronize(c->stream);
+    drain_events(c);
+    if (total_ms) *total_ms = c->prof_ms[which];
+    if (launches) *launches = c->prof_n[which];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- function-level entry points
+#define TG_FN_DISPATCH(robot, dtype, KERNEL, n, ...)                                                                              \
+    do {                                                                                                                          \
+        DevBuf rb;                                                                                                                \
+        dim3 grid(((n) + 63) / 64), block(64);                                                                                    \
+        if ((dtype) == TG_PHYSICS_F64) {                                                                                          \
+            if (int rc = upload_robot<double>(robot, rb)) return rc;                                                              \
+            if ((robot)->topology == 0) hipLaunchKernelGGL((KERNEL<double, 0>), grid, block, 0, 0, (const DevRobot<double>*)rb.p, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<double, 1>), grid, block, 0, 0, (const DevRobot<double>*)rb.p, __VA_ARGS__);          \
+        } else {                                                                                                                  \
+            if (int rc = upload_robot<float>(robot, rb)) return rc;                                                               \
+            if ((robot)->topology == 0) hipLaunchKernelGGL((KERNEL<float, 0>), grid, block, 0, 0, (const DevRobot<float>*)rb.p, __VA_ARGS__);   \
+            else hipLaunchKernelGGL((KERNEL<float, 1>), grid, block, 0, 0, (const DevRobot<float>*)rb.p, __VA_ARGS__);            \
+        }                                                                                                                         \
+        TG_HIP(hipDeviceSynchronize());                                                                                           \
+    } while (0)
+
+int tg_inverse_dynamics(const tg_robot* robot, int32_t dtype, int32_t n, const double* q, const double* qd, const double* qdd, double* tau) {
+    if (int rc = check_robot(robot)) return rc;
+    if (int rc = need_device()) return rc;
+    const size_t bytes = (size_t)n * robot->ndof * 8;
+    DevBuf a, b, c, d;
+    if (a.alloc(bytes) || b.alloc(bytes) || c.alloc(bytes) || d.alloc(bytes)) return fail(-2, "hipMalloc failed");
+    TG_HIP(hipMemcpy(a.p, q, bytes, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(b.p, qd, bytes, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(c.p, qdd, bytes, hipMemcpyHostToDevice));
+    TG_FN_DISPATCH(robot, dtype, k_inverse_dynamics, n, n, (const double*)a.p, (const double*)b.p, (const double*)c.p, (double*)d.p);
+    TG_HIP(hipMemcpy(tau, d.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tg_mass_matrix(const tg_robot* robot, int32_t dtype, int32_t n, const double* q, double* M) {
+    if (int rc = check_robot(robot)) return rc;
+    if (int rc = need_device()) return rc;
+    const int nd = robot->ndof;
+    DevBuf a, b;
+    if (a.alloc((size_t)n * nd * 8) || b.alloc((size_t)n * nd * nd * 8)) return fail(-2, "hipMalloc failed");
+    TG_HIP(hipMemcpy(a.p, q, (size_t)n * nd * 8, hipMemcpyHostToDevice));
+    TG_FN_DISPATCH(robot, dtype, k_mass_matrix, n, n, (const double*)a.p, (double*)b.p);
+    TG_HIP(hipMemcpy(M, b.p, (size_t)n * nd * nd * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tg_jacobian_tcp(const tg_robot* robot, int32_t dtype, int32_t n, const double* q, double* J, double* pos, double* rot) {
+    if (int rc = check_robot(robot)) return rc;
+    if (int rc = need_device()) return rc;
+    const int nd = robot->ndof;
+    DevBuf a, b, c, d;
+    if (a.alloc((size_t)n * nd * 8) || b.alloc((size_t)n * 6 * nd * 8) || c.alloc((size_t)n * 24) || d.alloc((size_t)n * 72)) return fail(-2, "hipMalloc failed");
+    TG_HIP(hipMemcpy(a.p, q, (size_t)n * nd * 8, hipMemcpyHostToDevice));
+    TG_FN_DISPATCH(robot, dtype, k_jacobian, n, n, (const double*)a.p, (double*)b.p, (double*)c.p, (double*)d.p);
+    if (J) TG_HIP(hipMemcpy(J, b.p, (size_t)n * 6 * nd * 8, hipMemcpyDeviceToHost));
+    if (pos) TG_HIP(hipMemcpy(pos, c.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (rot) TG_HIP(hipMemcpy(rot, d.p, (size_t)n * 72, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tg_sim_ticks(const tg_robot* robot, int32_t dtype, int32_t n, int32_t n_ticks, int32_t iters, double dt, int32_t motor_mode,
+                 const double* q_des, const double* qd_des, double max_force, double* q, double* qd) {
+    if (int rc = check_robot(robot)) return rc;
+    if (int rc = need_device()) return rc;
+    const size_t bytes = (size_t)n * robot->ndof * 8;
+    DevBuf a, b, c, d;
+    if (a.alloc(bytes) || b.alloc(bytes) || c.alloc(bytes) || d.alloc(bytes)) return fail(-2, "hipMalloc failed");
+    TG_HIP(hipMemcpy(a.p, q, bytes, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(b.p, qd, bytes, hipMemcpyHostToDevice));
+    if (q_des) TG_HIP(hipMemcpy(c.p, q_des, bytes, hipMemcpyHostToDevice));
+    if (qd_des) TG_HIP(hipMemcpy(d.p, qd_des, bytes, hipMemcpyHostToDevice));
+    TG_FN_DISPATCH(robot, dtype, k_sim_ticks, n, n, n_ticks, iters, dt, motor_mode, q_des ? (const double*)c.p : (const double*)nullptr,
+                   qd_des ? (const double*)d.p : (const double*)nullptr, max_force, (double*)a.p, (double*)b.p);
+    TG_HIP(hipMemcpy(q, a.p, bytes, hipMemcpyDeviceToHost)); TG_HIP(hipMemcpy(qd, b.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, const float* xf, uint8_t* out) {
+    if (!sen || !mesh || !xf || !out) return fail(-1, "NULL argument");
+    if (int rc = need_device()) return rc;
+    const int H = sen->image_h, W = sen->image_w;
+    if (!((H % 128 == 0 && W % 128 == 0) || (H == 64 && W == 64))) return fail(-1, "image size must be 64x64 or a multiple of 128");
+    const size_t npix = (size_t)H * W;
+    DevBuf nd, ng, bm, vv, tt, xx, oo;
+    if (nd.alloc(npix * 4) || ng.alloc(npix * 4) || bm.alloc(npix) || vv.alloc((size_t)mesh->n_verts * 12) || tt.alloc((size_t)mesh->n_tris * 12) ||
+        xx.alloc((size_t)n * 48) || oo.alloc(npix * n))
+        return fail(-2, "hipMalloc failed");
+    TG_HIP(hipMemcpy(nd.p, sen->nodef_dep, npix * 4, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(ng.p, sen->nodef_gray, npix * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(bm.p, sen->border_mask, npix, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(vv.p, mesh->verts, (size_t)mesh->n_verts * 12, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(tt.p, mesh->tris, (size_t)mesh->n_tris * 12, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(xx.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
+    TG_HIP(hipMemset(oo.p, 0, npix * n));
+    RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border);
+    launch_render(P, (const float*)vv.p, (const int32_t*)tt.p, mesh->n_tris, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p,
+                  (const float*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
+    TG_HIP(hipDeviceSynchronize());
+    TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,515 @@
+// tg_physics.hpp — per-env articulated-body dynamics and control, one lane per env (gfx950).
+//
+// Replaces what the reference delegates to PyBullet on every sim tick (tactile_gym/robots/arms/robot.py:131-141):
+//   calculateInverseDynamics (base_robot_arm.py:176-178), the TORQUE_CONTROL feed-forward (:184-189) and
+//   stepSimulation() (robot.py:141) with its joint-motor constraint rows (base_robot_arm.py:211-220, 325-332),
+// plus, once per env step, calculateJacobian + the Jacobian inverse of tcp_velocity_control (:281-332) and, on reset,
+// calculateInverseKinematics (:201-209).
+//
+// Formulation (deliberately different from the CPU oracle, which sums body by body):
+//   * bodies welded to the same moving link are merged on the host into one (m, com, I) per link;
+//   * one root->leaf sweep gives world-frame link origins, joint axes, velocities and the velocity-product
+//     accelerations; one leaf->root sweep accumulates Newton-Euler bias wrenches and composite inertias about each
+//     joint origin; M(q) follows as  M_ij = a_i . ( Io_j a_j + (o_j - o_i) x (a_j x h_j) )  for i above j;
+//   * M is Cholesky-factored and explicitly inverted (n <= 8) because the motor rows of the projected Gauss-Seidel
+//     solver need columns of M^-1 (Bullet gets the same columns from calcAccelerationDeltasMultiDof);
+//   * everything is fully unrolled over compile-time link indices so per-link quantities live in VGPRs: a lane never
+//     indexes a private array dynamically, and the robot constants are wave-uniform scalar loads.
+//
+// Why one lane per env and not one wavefront per env: the constraint system has ndof <= 8 rows and Gauss-Seidel is
+// a serial chain over rows and sweeps; 64 lanes cannot shorten that chain, they can only idle.  One lane per env
+// keeps all 64 lanes busy with 64 independent chains and makes every global access (SoA, env-minor) a perfectly
+// coalesced 512-byte (f64) wavefront transaction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+constexpr int kMaxDof = 8;
+constexpr int kMaxBodiesPerLink = 4;
+
+// ------------------------------------------------------------------------------------------------ topology
+template <int TOPO> struct Topo;
+template <> struct Topo<0> {  // serial 6-DoF chain (UR5)
+    static constexpr int N = 6;
+    __host__ __device__ static constexpr int parent(int i) { return i - 1; }
+};
+template <> struct Topo<1> {  // MG400: j1 -> {j2_1 -> j3_1 -> j4_1 -> j5, j2_2 -> j3_2 -> j4_2}
+    static constexpr int N = 8;
+    __host__ __device__ static constexpr int parent(int i) { return i == 0 ? -1 : (i == 5 ? 0 : i - 1); }
+};
+template <int TOPO> __host__ __device__ constexpr bool is_ancestor_or_self(int anc, int i) {
+    while (i >= 0) { if (i == anc) return true; i = Topo<TOPO>::parent(i); }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ device constants
+template <typename T> struct DevRobot {
+    T jpos[kMaxDof][3], jrot[kMaxDof][9], jaxis[kMaxDof][3];
+    T lmass[kMaxDof], lcom[kMaxDof][3], linert[kMaxDof][6];       // merged per-link inertia about lcom, link frame (xx,xy,xz,yy,yz,zz)
+    T bmass[kMaxDof][kMaxBodiesPerLink], bcom[kMaxDof][kMaxBodiesPerLink][3], brot[kMaxDof][kMaxBodiesPerLink][9],
+        binert[kMaxDof][kMaxBodiesPerLink][3];                     // individual bodies (velocity damping is per body)
+    int tcp_link; T tcp_pos[3], tcp_rot[9];
+    int sensor_link; T sensor_pos[3], sensor_rot[9];
+    T gravity[3], lin_damp, ang_damp, joint_damp, max_force, pos_gain, vel_gain;
+    T rest_q[kMaxDof];
+};
+
+// ------------------------------------------------------------------------------------------------ small vector algebra
+template <typename T> struct V3 { T x, y, z; };
+template <typename T> __device__ __forceinline__ V3<T> mk(T x, T y, T z) { return V3<T>{x, y, z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator*(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename T> __device__ __forceinline__ V3<T> cross(V3<T> a, V3<T> b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> __device__ __forceinline__ T tsqrt(T x);
+template <> __device__ __forceinline__ double tsqrt<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float tsqrt<float>(float x) { return sqrtf(x); }
+template <typename T> __device__ __forceinline__ void tsincos(T x, T* s, T* c);
+template <> __device__ __forceinline__ void tsincos<double>(double x, double* s, double* c) { sincos(x, s, c); }
+template <> __device__ __forceinline__ void tsincos<float>(float x, float* s, float* c) { sincosf(x, s, c); }
+template <typename T> __device__ __forceinline__ T tatan2(T y, T x);
+template <> __device__ __forceinline__ double tatan2<double>(double y, double x) { return atan2(y, x); }
+template <> __device__ __forceinline__ float tatan2<float>(float y, float x) { return atan2f(y, x); }
+template <typename T> __device__ __forceinline__ T tasin(T x);
+template <> __device__ __forceinline__ double tasin<double>(double x) { return asin(x); }
+template <> __device__ __forceinline__ float tasin<float>(float x) { return asinf(x); }
+template <typename T> __device__ __forceinline__ T tacos(T x);
+template <> __device__ __forceinline__ double tacos<double>(double x) { return acos(x); }
+template <> __device__ __forceinline__ float tacos<float>(float x) { return acosf(x); }
+template <typename T> __device__ __forceinline__ T tabs(T x) { return x < T(0) ? -x : x; }
+template <typename T> __device__ __forceinline__ T norm(V3<T> a) { return tsqrt(dot(a, a)); }
+
+template <typename T> struct M3 { T m[9]; };  // row major
+template <typename T> __device__ __forceinline__ V3<T> mul(const M3<T>& A, V3<T> v) {
+    return {A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z, A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z};
+}
+template <typename T> __device__ __forceinline__ V3<T> mulT(const M3<T>& A, V3<T> v) {
+    return {A.m[0] * v.x + A.m[3] * v.y + A.m[6] * v.z, A.m[1] * v.x + A.m[4] * v.y + A.m[7] * v.z, A.m[2] * v.x + A.m[5] * v.y + A.m[8] * v.z};
+}
+template <typename T> __device__ __forceinline__ M3<T> mul(const M3<T>& A, const M3<T>& B) {
+    M3<T> C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return C;
+}
+template <typename T> __device__ __forceinline__ M3<T> load_m3(const T* p) {
+    M3<T> A;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) A.m[k] = p[k];
+    return A;
+}
+template <typename T> __device__ __forceinline__ V3<T> load_v3(const T* p) { return {p[0], p[1], p[2]}; }
+template <typename T> __device__ __forceinline__ M3<T> axis_angle(V3<T> a, T q) {
+    T s, c;
+    tsincos(q, &s, &c);
+    const T v = T(1) - c;
+    M3<T> R;
+    R.m[0] = c + a.x * a.x * v;       R.m[1] = a.x * a.y * v - a.z * s; R.m[2] = a.x * a.z * v + a.y * s;
+    R.m[3] = a.y * a.x * v + a.z * s; R.m[4] = c + a.y * a.y * v;       R.m[5] = a.y * a.z * v - a.x * s;
+    R.m[6] = a.z * a.x * v - a.y * s; R.m[7] = a.z * a.y * v + a.x * s; R.m[8] = c + a.z * a.z * v;
+    return R;
+}
+
+// symmetric 3x3 (xx, xy, xz, yy, yz, zz)
+template <typename T> struct S3 { T xx, xy, xz, yy, yz, zz; };
+template <typename T> __device__ __forceinline__ V3<T> mul(const S3<T>& S, V3<T> v) {
+    return {S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z, S.xz * v.x + S.yz * v.y + S.zz * v.z};
+}
+template <typename T> __device__ __forceinline__ S3<T> operator+(const S3<T>& a, const S3<T>& b) {
+    return {a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz};
+}
+// R S R^T for symmetric S
+template <typename T> __device__ __forceinline__ S3<T> rotate(const M3<T>& R, const S3<T>& S) {
+    // columns of S R^T = S * (rows of R)
+    const V3<T> r0{R.m[0], R.m[1], R.m[2]}, r1{R.m[3], R.m[4], R.m[5]}, r2{R.m[6], R.m[7], R.m[8]};
+    const V3<T> s0 = mul(S, r0), s1 = mul(S, r1), s2 = mul(S, r2);
+    return {dot(r0, s0), dot(r0, s1), dot(r0, s2), dot(r1, s1), dot(r1, s2), dot(r2, s2)};
+}
+// m [ (r.r) E - r r^T ]
+template <typename T> __device__ __forceinline__ S3<T> point_inertia(T m, V3<T> r) {
+    const T rr = dot(r, r);
+    return {m * (rr - r.x * r.x), -m * r.x * r.y, -m * r.x * r.z, m * (rr - r.y * r.y), -m * r.y * r.z, m * (rr - r.z * r.z)};
+}
+// 2 (h.r) E - h r^T - r h^T
+template <typename T> __device__ __forceinline__ S3<T> cross_inertia(V3<T> h, V3<T> r) {
+    const T hr2 = T(2) * dot(h, r);
+    return {hr2 - T(2) * h.x * r.x, -(h.x * r.y + r.x * h.y), -(h.x * r.z + r.x * h.z), hr2 - T(2) * h.y * r.y, -(h.y * r.z + r.y * h.z),
+            hr2 - T(2) * h.z * r.z};
+}
+
+// ------------------------------------------------------------------------------------------------ kinematics
+template <typename T, int TOPO> struct Kin {
+    static constexpr int N = Topo<TOPO>::N;
+    M3<T> R[N];
+    V3<T> o[N], a[N];
+};
+
+template <typename T, int TOPO> __device__ __forceinline__ void forward_kinematics(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], Kin<T, TOPO>& k) {
+    constexpr int N = Topo<TOPO>::N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int p = Topo<TOPO>::parent(i);
+        const V3<T> ax = load_v3(m.jaxis[i]);
+        const M3<T> Rq = axis_angle(ax, q[i]);
+        const M3<T> Rj = load_m3(m.jrot[i]);
+        if (p < 0) {
+            k.R[i] = mul(Rj, Rq);
+            k.o[i] = load_v3(m.jpos[i]);
+        } else {
+            k.R[i] = mul(mul(k.R[p], Rj), Rq);
+            k.o[i] = k.o[p] + mul(k.R[p], load_v3(m.jpos[i]));
+        }
+        k.a[i] = mul(k.R[i], ax);
+    }
+}
+
+// World pose of a frame welded to moving link `link` (link index is wave-uniform; resolved by an unrolled select).
+template <typename T, int TOPO> __device__ __forceinline__ void link_frame(const Kin<T, TOPO>& k, int link, const T* fpos, const T* frot,
+                                                                             V3<T>& pos, M3<T>& rot) {
+    constexpr int N = Topo<TOPO>::N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (i == link) {
+            pos = k.o[i] + mul(k.R[i], load_v3(fpos));
+            rot = mul(k.R[i], load_m3(frot));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dynamics
+// Outputs of one dynamics evaluation at (q, qd):
+//   hbias  = ID(q, qd, 0)      (gravity + velocity-product generalised forces: the gravity-compensation torque)
+//   qdamp  = generalised force of Bullet's per-body linear/angular velocity damping
+//   Minv   = inverse joint-space inertia (full symmetric storage)
+template <typename T, int TOPO>
+__device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], const T (&qd)[Topo<TOPO>::N],
+                                               T (&hbias)[Topo<TOPO>::N], T (&qdamp)[Topo<TOPO>::N],
+                                               T (&Minv)[Topo<TOPO>::N][Topo<TOPO>::N]) {
+    constexpr int N = Topo<TOPO>::N;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> w[N], wd[N], vo[N], ao[N];
+    V3<T> WF[N], WN[N], DF[N], DN[N], hc[N];     // bias wrench, damping wrench (about o_i), composite first moment
+    S3<T> Io[N];
+    T mc[N];
+    const V3<T> g = load_v3(m.gravity);
+    // root -> leaf: velocities, velocity-product accelerations (qdd = 0), per-link wrenches about the joint origin
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int p = Topo<TOPO>::parent(i);
+        const V3<T> aq = qd[i] * k.a[i];
+        if (p < 0) {
+            w[i] = aq;
+            wd[i] = mk<T>(0, 0, 0);
+            vo[i] = mk<T>(0, 0, 0);
+            ao[i] = mk<T>(0, 0, 0) - g;             // fictitious base acceleration = -gravity
+        } else {
+            const V3<T> r = k.o[i] - k.o[p];
+            w[i] = w[p] + aq;
+            wd[i] = wd[p] + cross(w[p], aq);
+            vo[i] = vo[p] + cross(w[p], r);
+            ao[i] = ao[p] + cross(wd[p], r) + cross(w[p], cross(w[p], r));
+        }
+        // merged link body
+        const V3<T> rc = mul(k.R[i], load_v3(m.lcom[i]));
+        const S3<T> Il{m.linert[i][0], m.linert[i][1], m.linert[i][2], m.linert[i][3], m.linert[i][4], m.linert[i][5]};
+        const S3<T> Iw = rotate(k.R[i], Il);
+        const V3<T> ac = ao[i] + cross(wd[i], rc) + cross(w[i], cross(w[i], rc));
+        const V3<T> F = m.lmass[i] * ac;
+        const V3<T> Nc = mul(Iw, wd[i]) + cross(w[i], mul(Iw, w[i]));
+        WF[i] = F;
+        WN[i] = Nc + cross(rc, F);
+        mc[i] = m.lmass[i];
+        hc[i] = m.lmass[i] * rc;
+        Io[i] = Iw + point_inertia(m.lmass[i], rc);
+        // per-body velocity damping  F = -m v (K + K|v|),  N = -(I w)(K + K|w|)
+        V3<T> dF = mk<T>(0, 0, 0), dN = mk<T>(0, 0, 0);
+        const T wn = norm(w[i]);
+        const T sw = m.ang_damp + m.ang_damp * wn;
+#pragma unroll
+        for (int b = 0; b < kMaxBodiesPerLink; ++b) {
+            if (m.bmass[i][b] > T(0)) {  // wave-uniform
+                const V3<T> rb = mul(k.R[i], load_v3(m.bcom[i][b]));
+                const V3<T> vb = vo[i] + cross(w[i], rb);
+                const T sv = m.lin_damp + m.lin_damp * norm(vb);
+                const V3<T> Fb = (-m.bmass[i][b] * sv) * vb;
+                const M3<T> Rb = mul(k.R[i], load_m3(m.brot[i][b]));
+                const V3<T> wl = mulT(Rb, w[i]);
+                const V3<T> Iwl{m.binert[i][b][0] * wl.x, m.binert[i][b][1] * wl.y, m.binert[i][b][2] * wl.z};
+                const V3<T> Nb = (-sw) * mul(Rb, Iwl);
+                dF = dF + Fb;
+                dN = dN + Nb + cross(rb, Fb);
+            }
+        }
+        DF[i] = dF;
+        DN[i] = dN;
+    }
+    // leaf -> root: accumulate subtree wrenches and composite inertias about each joint origin
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        hbias[i] = dot(k.a[i], WN[i]);
+        qdamp[i] = dot(k.a[i], DN[i]);
+        const int p = Topo<TOPO>::parent(i);
+        if (p >= 0) {
+            const V3<T> r = k.o[i] - k.o[p];
+            WF[p] = WF[p] + WF[i];
+            WN[p] = WN[p] + WN[i] + cross(r, WF[i]);
+            DF[p] = DF[p] + DF[i];
+            DN[p] = DN[p] + DN[i] + cross(r, DF[i]);
+            Io[p] = Io[p] + Io[i] + point_inertia(mc[i], r) + cross_inertia(hc[i], r);
+            hc[p] = hc[p] + hc[i] + mc[i] * r;
+            mc[p] = mc[p] + mc[i];
+        }
+    }
+    // joint-space inertia, lower triangle
+    T L[N][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const V3<T> F = cross(k.a[j], hc[j]);
+        const V3<T> Nj = mul(Io[j], k.a[j]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i == j) L[j][j] = dot(k.a[j], Nj);
+            else if (i < j) L[j][i] = is_ancestor_or_self<TOPO>(i, j) ? dot(k.a[i], Nj + cross(k.o[j] - k.o[i], F)) : T(0);
+        }
+    }
+    // in-place Cholesky  M = L L^T
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        T d = L[j][j];
+#pragma unroll
+        for (int c = 0; c < j; ++c) d -= L[j][c] * L[j][c];
+        d = tsqrt(d);
+        L[j][j] = d;
+        const T inv = T(1) / d;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            T s = L[i][j];
+#pragma unroll
+            for (int c = 0; c < j; ++c) s -= L[i][c] * L[j][c];
+            L[i][j] = s * inv;
+        }
+    }
+    // Linv (lower), then Minv = Linv^T Linv
+    T Li[N][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        Li[j][j] = T(1) / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            T s = T(0);
+#pragma unroll
+            for (int c = j; c < i; ++c) s -= L[i][c] * Li[c][j];
+            Li[i][j] = s / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            T s = T(0);
+#pragma unroll
+            for (int c = i; c < N; ++c) s += Li[c][i] * Li[c][j];
+            Minv[i][j] = s;
+            Minv[j][i] = s;
+        }
+}
+
+enum { kMotorOff = 0, kMotorVelocity = 1, kMotorPosition = 2 };
+
+// One stepSimulation() tick with the reference's per-tick gravity compensation (robot.py:131-141).
+//   applied torque  = ID(q, qd, 0)                     (base_robot_arm.py:174-189, TORQUE_CONTROL feed-forward)
+//                   - joint_damping * qd                (changeDynamics(jointDamping), base_robot_arm.py:25)
+//   unconstrained   qdd = Minv (applied - hbias + qdamp);  v = qd + dt qdd
+//   motors          projected Gauss-Seidel on the velocity-level rows  v_i -> target_i,  |impulse| <= max_force dt,
+//                   `iters` sweeps alternating reverse/forward row order, early exit on an exactly-zero sweep
+//   integration     q += dt qd
+template <typename T, int TOPO, int MOTOR>
+__device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
+                                         const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
+                                         int iters, bool gravity_comp) {
+    constexpr int N = Topo<TOPO>::N;
+    T hb[N], qdm[N], Minv[N][N];
+    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv);
+    T rhs[N], v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const T applied = (gravity_comp ? hb[i] : T(0)) - m.joint_damp * qd[i];
+        rhs[i] = (applied - hb[i]) + qdm[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc += Minv[i][j] * rhs[j];
+        v[i] = qd[i] + dt * acc;
+    }
+    if (MOTOR != kMotorOff) {
+        T rimp[N], jdi[N], lam[N], dv[N];
+        const T maximp = max_force * dt;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const T pos_term = (MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0);
+            const T des = pos_term + v[i] + kd * (qd_des[i] - v[i]);
+            jdi[i] = T(1) / Minv[i][i];
+            rimp[i] = (des - v[i]) * jdi[i];
+            lam[i] = T(0);
+            dv[i] = T(0);
+        }
+        for (int it = 0; it < iters; ++it) {
+            T residual = T(0);
+            if (it & 1) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    T delta = rimp[i] - dv[i] * jdi[i];
+                    const T sum = lam[i] + delta;
+                    if (sum < -maximp) { delta = -maximp - lam[i]; lam[i] = -maximp; }
+                    else if (sum > maximp) { delta = maximp - lam[i]; lam[i] = maximp; }
+                    else lam[i] = sum;
+#pragma unroll
+                    for (int r = 0; r < N; ++r) dv[r] += Minv[r][i] * delta;
+                    const T d2 = delta * delta;
+                    residual = d2 > residual ? d2 : residual;
+                }
+            } else {
+#pragma unroll
+                for (int i = N - 1; i >= 0; --i) {
+                    T delta = rimp[i] - dv[i] * jdi[i];
+                    const T sum = lam[i] + delta;
+                    if (sum < -maximp) { delta = -maximp - lam[i]; lam[i] = -maximp; }
+                    else if (sum > maximp) { delta = maximp - lam[i]; lam[i] = maximp; }
+                    else lam[i] = sum;
+#pragma unroll
+                    for (int r = 0; r < N; ++r) dv[r] += Minv[r][i] * delta;
+                    const T d2 = delta * delta;
+                    residual = d2 > residual ? d2 : residual;
+                }
+            }
+            if (residual <= T(0)) break;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += dv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        qd[i] = v[i];
+        q[i] += dt * v[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ quaternion / Euler helpers
+// (pybullet getQuaternionFromEuler / getEulerFromQuaternion / btMatrix3x3::getRotation; quaternions are x,y,z,w)
+template <typename T> struct Q4 { T x, y, z, w; };
+template <typename T> __device__ __forceinline__ Q4<T> quat_from_euler(T r, T p, T y) {
+    T sr, cr, sp, cp, sy, cy;
+    tsincos(T(0.5) * r, &sr, &cr); tsincos(T(0.5) * p, &sp, &cp); tsincos(T(0.5) * y, &sy, &cy);
+    Q4<T> q{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+    const T n = T(1) / tsqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return {q.x * n, q.y * n, q.z * n, q.w * n};
+}
+template <typename T> __device__ __forceinline__ void euler_from_quat(Q4<T> q, T& r, T& p, T& y) {
+    const T sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, sqw = q.w * q.w;
+    const T sarg = T(-2) * (q.x * q.z - q.w * q.y);
+    const T half_pi = T(1.5707963267948966);
+    if (sarg <= T(-0.99999)) { r = T(0); p = -half_pi; y = T(2) * tatan2(q.x, -q.y); }
+    else if (sarg >= T(0.99999)) { r = T(0); p = half_pi; y = T(2) * tatan2(-q.x, q.y); }
+    else {
+        r = tatan2(T(2) * (q.y * q.z + q.w * q.x), sqw - sqx - sqy + sqz);
+        p = tasin(sarg);
+        y = tatan2(T(2) * (q.x * q.y + q.w * q.z), sqw + sqx - sqy - sqz);
+    }
+}
+template <typename T> __device__ __forceinline__ M3<T> mat_from_quat(Q4<T> q) {
+    const T d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, s = T(2) / d;
+    const T xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    const T wx = q.w * xs, wy = q.w * ys, wz = q.w * zs, xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    M3<T> R;
+    R.m[0] = T(1) - (yy + zz); R.m[1] = xy - wz; R.m[2] = xz + wy;
+    R.m[3] = xy + wz; R.m[4] = T(1) - (xx + zz); R.m[5] = yz - wx;
+    R.m[6] = xz - wy; R.m[7] = yz + wx; R.m[8] = T(1) - (xx + yy);
+    return R;
+}
+template <typename T> __device__ __forceinline__ Q4<T> quat_from_mat(const M3<T>& R) {
+    const T tr = R.m[0] + R.m[4] + R.m[8];
+    Q4<T> q;
+    if (tr > T(0)) {
+        T s = tsqrt(tr + T(1));
+        q.w = T(0.5) * s; s = T(0.5) / s;
+        q.x = (R.m[7] - R.m[5]) * s; q.y = (R.m[2] - R.m[6]) * s; q.z = (R.m[3] - R.m[1]) * s;
+    } else if (R.m[0] >= R.m[4] && R.m[0] >= R.m[8]) {          // i = 0
+        T s = tsqrt(R.m[0] - R.m[4] - R.m[8] + T(1));
+        q.x = T(0.5) * s; s = T(0.5) / s;
+        q.w = (R.m[7] - R.m[5]) * s; q.y = (R.m[3] + R.m[1]) * s; q.z = (R.m[6] + R.m[2]) * s;
+    } else if (R.m[4] > R.m[0] && R.m[4] >= R.m[8]) {           // i = 1
+        T s = tsqrt(R.m[4] - R.m[8] - R.m[0] + T(1));
+        q.y = T(0.5) * s; s = T(0.5) / s;
+        q.w = (R.m[2] - R.m[6]) * s; q.z = (R.m[7] + R.m[5]) * s; q.x = (R.m[1] + R.m[3]) * s;
+    } else {                                                    // i = 2
+        T s = tsqrt(R.m[8] - R.m[0] - R.m[4] + T(1));
+        q.z = T(0.5) * s; s = T(0.5) / s;
+        q.w = (R.m[3] - R.m[1]) * s; q.x = (R.m[2] + R.m[6]) * s; q.y = (R.m[5] + R.m[7]) * s;
+    }
+    return q;
+}
+template <typename T> __device__ __forceinline__ Q4<T> quat_mul(Q4<T> a, Q4<T> b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+            a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+
+// ------------------------------------------------------------------------------------------------ small dense solves
+// Solve A x = b for NxN A by Gaussian elimination with partial pivoting.  Row exchanges are conditional swaps
+// (selects), so every index is a compile-time constant and nothing leaves the register file.
+template <typename T, int N> __device__ __forceinline__ void solve_pivoted(T (&A)[N][N], T (&b)[N], T (&x)[N]) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) {
+            const bool sw = tabs(A[r][c]) > tabs(A[c][c]);
+#pragma unroll
+            for (int j = c; j < N; ++j) { const T t0 = A[c][j], t1 = A[r][j]; A[c][j] = sw ? t1 : t0; A[r][j] = sw ? t0 : t1; }
+            const T b0 = b[c], b1 = b[r]; b[c] = sw ? b1 : b0; b[r] = sw ? b0 : b1;
+        }
+        const T piv = A[c][c];
+        const T inv = (piv != T(0)) ? T(1) / piv : T(0);
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) {
+            const T f = A[r][c] * inv;
+#pragma unroll
+            for (int j = c + 1; j < N; ++j) A[r][j] -= f * A[c][j];
+            b[r] -= f * b[c];
+        }
+    }
+#pragma unroll
+    for (int r = N - 1; r >= 0; --r) {
+        T s = b[r];
+#pragma unroll
+        for (int j = r + 1; j < N; ++j) s -= A[r][j] * x[j];
+        x[r] = (A[r][r] != T(0)) ? s / A[r][r] : T(0);
+    }
+}
+
+// Geometric Jacobian of the TCP frame origin, world frame: rows 0-2 translational, 3-5 rotational
+// (calculateJacobian(link, localPosition = 0), base_robot_arm.py:300-310).
+template <typename T, int TOPO>
+__device__ __forceinline__ void tcp_jacobian(const DevRobot<T>& m, const Kin<T, TOPO>& k, V3<T> ptcp, T (&J)[6][Topo<TOPO>::N]) {
+    constexpr int N = Topo<TOPO>::N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        bool on_path = false;
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+            if (l == m.tcp_link && is_ancestor_or_self<TOPO>(i, l)) on_path = true;
+        const V3<T> jt = cross(k.a[i], ptcp - k.o[i]);
+        J[0][i] = on_path ? jt.x : T(0); J[1][i] = on_path ? jt.y : T(0); J[2][i] = on_path ? jt.z : T(0);
+        J[3][i] = on_path ? k.a[i].x : T(0); J[4][i] = on_path ? k.a[i].y : T(0); J[5][i] = on_path ? k.a[i].z : T(0);
+    }
+}
+
+}  // namespace tg

@@ -1,0 +1,24 @@
+// tg_raster.h — interface between the host API (tg_api.hip) and the raster translation unit (tg_raster.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+// Projection constants of the in-sensor camera (tactile_sensor.py:127-148), derived on the host in double precision
+// and rounded once to float so that the oracle and the device use identical values:
+//   kx = (1/tan(fov/2)) * W/2, ky likewise with H; window x = hw + kx * x/w, y = hh - ky * y/w;
+//   depth = C0 + C1/w with C0 = far/(far-near), C1 = -near*far/(far-near)   (OpenGL depth-buffer value in [0,1]).
+struct RasterParams {
+    int W, H;
+    float kx, ky, hw, hh, C0, C1, near_;
+    int turn_off_border;
+};
+
+RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border);
+
+void launch_render(const RasterParams& P, const float* verts, const int32_t* tris, int n_tris, const float* xform, int xform_soa, int n_envs,
+                   const uint8_t* mask, const float* nodef_dep, const float* nodef_gray, const uint8_t* border, uint8_t* out,
+                   uint8_t* save_prev, hipStream_t stream);
+
+}  // namespace tg

@@ -1,0 +1,209 @@
+// tg_raster.hip — tactile depth raster + t_s_camera post-process for gfx950 (MI355X).
+//
+// Replaces, per env and per step, PyBullet's getCameraImage(...) depth channel and the numpy post-process of
+// TactileSensor.t_s_camera (reference tactile_gym/sensors/tactile_sensor.py:239-246, 261-294).
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off.  Every float expression below follows the raster specification in
+// DESIGN.md operation by operation (same association, no fused multiply-adds, IEEE division) so the image is
+// bit-identical to the CPU oracle's scalar restatement (oracle/minibullet.c: mb_render_depth, mb_t_s_camera).
+//
+// Mapping to the hardware
+//   * one 256-thread workgroup (4 wavefronts) per (env, 128x128 image tile); a launch of 1024 envs is 1024-4096
+//     workgroups >> 256 CUs, and consecutive workgroups land on different XCDs (block b -> XCD b % 8) while the
+//     only shared data (reference images, stimulus mesh: < 200 KB) is read-only and L2-resident on every XCD;
+//   * triangle set-up (transform, near clip, project) is done once per workgroup, one lane per input triangle,
+//     and staged as compact records in LDS; the pixel phase then reads each record as an LDS broadcast;
+//   * each lane owns 4 horizontally adjacent pixels x 16 rows (64 depth values in VGPRs = the z-buffer), so
+//     a wavefront covers two full 128-pixel rows per pass: depth reduction is a register min, the reference
+//     images are read as 16-byte vectors and the uint8 image is written as 4-byte vectors, 256 B per wavefront
+//     store instruction, fully coalesced.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tg_raster.h"
+
+namespace tg {
+
+struct TriRec {      // projected triangle, window coordinates + depth
+    float x0, y0, d0, x1, y1, d1, x2, y2, d2;
+    float ymin, ymax, xmin, xmax;
+};
+
+constexpr int kThreads = 256;
+constexpr int kBatch = 1024;         // triangle records staged in LDS per pass (52 KB)
+
+RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border) {
+    RasterParams P;
+    const double ys = 1.0 / tan(0.5 * fov_deg * (3.14159265358979323846 / 180.0));
+    P.W = W; P.H = H;
+    P.kx = (float)(ys * 0.5 * W); P.ky = (float)(ys * 0.5 * H);
+    P.hw = 0.5f * (float)W; P.hh = 0.5f * (float)H;
+    P.C0 = (float)(far_ / (far_ - near_));
+    P.C1 = (float)(-(near_ * far_) / (far_ - near_));
+    P.near_ = (float)near_;
+    P.turn_off_border = turn_off_border;
+    return P;
+}
+
+__device__ __forceinline__ void project_vertex(float cx, float cy, float cw, const RasterParams& P, float& sx, float& sy, float& d) {
+    float iw = 1.0f / cw;
+    sx = P.hw + P.kx * (cx * iw);
+    sy = P.hh - P.ky * (cy * iw);
+    d = P.C0 + P.C1 * iw;
+}
+
+__device__ __forceinline__ void emit(TriRec* recs, int* count, const float* vx, const float* vy, const float* vw, int a, int b, int c,
+                                     const RasterParams& P, float tx0, float ty0, float tx1, float ty1) {
+    TriRec r;
+    project_vertex(vx[a], vy[a], vw[a], P, r.x0, r.y0, r.d0);
+    project_vertex(vx[b], vy[b], vw[b], P, r.x1, r.y1, r.d1);
+    project_vertex(vx[c], vy[c], vw[c], P, r.x2, r.y2, r.d2);
+    r.xmin = fminf(r.x0, fminf(r.x1, r.x2)); r.xmax = fmaxf(r.x0, fmaxf(r.x1, r.x2));
+    r.ymin = fminf(r.y0, fminf(r.y1, r.y2)); r.ymax = fmaxf(r.y0, fmaxf(r.y1, r.y2));
+    // conservative cull against this workgroup's tile (coverage itself is decided per pixel)
+    if (r.xmax < tx0 || r.xmin > tx1 || r.ymax < ty0 || r.ymin > ty1) return;
+    int slot = atomicAdd(count, 1);
+    recs[slot] = r;
+}
+
+// grid: (tiles_x * tiles_y, num_envs); block: 256.  TW = tile edge (128, or 64 for 64x64 images).
+template <int TW>
+__global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, const float* __restrict__ verts, const int32_t* __restrict__ tris,
+                                                             int n_tris, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
+                                                             int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
+                                                             const float* __restrict__ nodef_dep, const float* __restrict__ nodef_gray,
+                                                             const uint8_t* __restrict__ border, uint8_t* __restrict__ out,
+                                                             uint8_t* __restrict__ save_prev /*nullable: copy old image here first*/) {
+    constexpr int kTile = TW;
+    constexpr int QPR = TW / 4;            // pixel quads per tile row
+    constexpr int RPP = kThreads / QPR;    // tile rows covered per pass of the workgroup
+    constexpr int NK = TW / RPP;           // rows owned by each lane
+    __shared__ TriRec recs[kBatch];
+    __shared__ int count;
+    const int env = blockIdx.y;
+    if (mask != nullptr && mask[env] == 0) return;
+    const int tiles_x = P.W / kTile;
+    const int tile_x = (blockIdx.x % tiles_x) * kTile, tile_y = (blockIdx.x / tiles_x) * kTile;
+    const int tid = threadIdx.x;
+
+    float M[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xform[(size_t)k * n_envs + env] : xform[(size_t)env * 12 + k];
+
+    // this lane's pixels: quad column qx (4 px), rows ry + 8*k
+    const int qx = tile_x + 4 * (tid % QPR);
+    const int ry = tile_y + (tid / QPR);
+    float z[NK][4];
+    {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float4 nd = *reinterpret_cast<const float4*>(nodef_dep + (size_t)(ry + RPP * k) * P.W + qx);
+            z[k][0] = nd.x; z[k][1] = nd.y; z[k][2] = nd.z; z[k][3] = nd.w;
+        }
+    }
+    const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + kTile), ty1 = (float)(tile_y + kTile);
+
+    for (int base = 0; base < n_tris; base += kBatch / 2) {
+        if (tid == 0) count = 0;
+        __syncthreads();
+        const int lim = min(n_tris, base + kBatch / 2);
+        for (int t = base + tid; t < lim; t += kThreads) {
+            float cx[3], cy[3], cw[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float* v = verts + 3 * tris[3 * t + k];
+                const float vx = v[0], vy = v[1], vz = v[2];
+                cx[k] = ((M[0] * vx + M[1] * vy) + M[2] * vz) + M[9];
+                cy[k] = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
+                cw[k] = -(((M[6] * vx + M[7] * vy) + M[8] * vz) + M[11]);
+            }
+            // near-plane clip (Sutherland-Hodgman on w >= near), vertex order 0,1,2
+            float ox[4], oy[4], ow[4];
+            int no = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int k1 = (k + 1) % 3;
+                const bool ain = cw[k] >= P.near_, bin = cw[k1] >= P.near_;
+                if (ain) { ox[no] = cx[k]; oy[no] = cy[k]; ow[no] = cw[k]; ++no; }
+                if (ain != bin) {
+                    const float tt = (P.near_ - cw[k]) / (cw[k1] - cw[k]);
+                    ox[no] = cx[k] + tt * (cx[k1] - cx[k]);
+                    oy[no] = cy[k] + tt * (cy[k1] - cy[k]);
+                    ow[no] = P.near_;
+                    ++no;
+                }
+            }
+            if (no >= 3) emit(recs, &count, ox, oy, ow, 0, 1, 2, P, tx0, ty0, tx1, ty1);
+            if (no == 4) emit(recs, &count, ox, oy, ow, 0, 2, 3, P, tx0, ty0, tx1, ty1);
+        }
+        __syncthreads();
+        const int n = count;
+        for (int t = 0; t < n; ++t) {
+            const TriRec r = recs[t];   // same address on every lane: LDS broadcast
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const float fy = (float)(ry + RPP * k) + 0.5f;
+                if (fy < r.ymin || fy > r.ymax) continue;
+                const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float fx = (float)(qx + p) + 0.5f;
+                    const float e0 = (r.x1 - fx) * a0 - (r.x2 - fx) * a1;
+                    const float e1 = (r.x2 - fx) * a2 - (r.x0 - fx) * a0;
+                    const float e2 = (r.x0 - fx) * a1 - (r.x1 - fx) * a2;
+                    const bool in = (fx >= r.xmin && fx <= r.xmax) &&
+                                    ((e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) || (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f));
+                    const float s = (e0 + e1) + e2;
+                    if (in && s != 0.0f) {
+                        const float d = ((e0 * r.d0 + e1 * r.d1) + e2 * r.d2) / s;
+                        if (d < z[k][p]) z[k][p] = d;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // t_s_camera: depth difference -> uint8 penetration image, border paste (tactile_sensor.py:271-292)
+    const float eps = 1e-4f, max_pen = 0.05f;
+    uint8_t* dst = out + (size_t)env * P.W * P.H;
+    uint8_t* prev = save_prev ? save_prev + (size_t)env * P.W * P.H : nullptr;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const size_t off = (size_t)(ry + RPP * k) * P.W + qx;
+        const float4 nd = *reinterpret_cast<const float4*>(nodef_dep + off);
+        const float4 ng = *reinterpret_cast<const float4*>(nodef_gray + off);
+        const uchar4 bm = *reinterpret_cast<const uchar4*>(border + off);
+        const float ndv[4] = {nd.x, nd.y, nd.z, nd.w}, ngv[4] = {ng.x, ng.y, ng.z, ng.w};
+        const uint8_t bmv[4] = {bm.x, bm.y, bm.z, bm.w};
+        uint8_t o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float diff = z[k][p] - ndv[p];
+            if (diff >= -eps && diff <= eps) diff = 0.0f;
+            const float pen = fabsf(diff);
+            const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
+            uint8_t v = (uint8_t)((cl / max_pen) * 255.0f);
+            if (!P.turn_off_border && bmv[p] == 1) v = (uint8_t)ngv[p];
+            o[p] = v;
+        }
+        if (prev) *reinterpret_cast<uchar4*>(prev + off) = *reinterpret_cast<const uchar4*>(dst + off);
+        *reinterpret_cast<uchar4*>(dst + off) = make_uchar4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+void launch_render(const RasterParams& P, const float* verts, const int32_t* tris, int n_tris, const float* xform, int xform_soa, int n_envs,
+                   const uint8_t* mask, const float* nodef_dep, const float* nodef_gray, const uint8_t* border, uint8_t* out,
+                   uint8_t* save_prev, hipStream_t stream) {
+    if (P.W % 128 == 0 && P.H % 128 == 0) {
+        dim3 grid((P.W / 128) * (P.H / 128), n_envs);
+        hipLaunchKernelGGL(k_render_tactile<128>, grid, dim3(kThreads), 0, stream, P, verts, tris, n_tris, xform, xform_soa, n_envs, mask,
+                           nodef_dep, nodef_gray, border, out, save_prev);
+    } else {  // 64x64 images
+        dim3 grid((P.W / 64) * (P.H / 64), n_envs);
+        hipLaunchKernelGGL(k_render_tactile<64>, grid, dim3(kThreads), 0, stream, P, verts, tris, n_tris, xform, xform_soa, n_envs, mask,
+                           nodef_dep, nodef_gray, border, out, save_prev);
+    }
+}
+
+}  // namespace tg

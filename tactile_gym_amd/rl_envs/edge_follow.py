@@ -1,0 +1,152 @@
+"""edge_follow-v0 on the HIP path.
+
+Reference: tactile_gym/rl_envs/exploration/edge_follow/edge_follow_env.py (task constants, action space, reset
+randomisation, reward) on top of base_tactile_env.py (step / observation plumbing).  All per-step arithmetic runs in
+libtactile_gym_hip.so; this module only assembles the constants the kernels need and presents the gym.Env /
+VecEnv surface (old 4-tuple gym API, base_tactile_env.py:185).
+"""
+import math
+
+import numpy as np
+
+from .. import _capi as capi
+from ..robot_model import MeshDesc, SensorDesc, load_tgmodel, make_robot
+from ..vec_env import TactileVecEnv
+
+# rest_poses.py:6-20 etc. — movable joints only, [arm][sensor][type]
+REST_POSES = {
+    "ur5": {
+        "tactip": {"standard": [0.166827, -2.16515, -1.64365, -0.90317, 1.57315, 1.74001]},
+        "digit": {"standard": [0.1666452116249431, -2.2334888481855204, -1.6642245054428424, -0.8142762445463524,
+                               1.573151527964482, 1.7398309441833082]},
+        "digitac": {"standard": [0.16664443404149898, -2.2242489977536737, -1.6618744232210114, -0.8258663681806591,
+                                 1.5731514988184077, 1.7398302172182332]},
+    },
+}
+
+env_modes_default = {  # edge_follow_env.py:12-19 (the reference default omits tactile_sensor_name and cannot be constructed)
+    "movement_mode": "xy",
+    "control_mode": "TCP_velocity_control",
+    "noise_mode": "fixed_height",
+    "observation_mode": "oracle",
+    "reward_mode": "dense",
+    "arm_type": "ur5",
+    "tactile_sensor_name": "tactip",
+}
+
+
+def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64", auto_reset=True, device=0):
+    """env ctor kwargs -> (tg_config, tg_robot, SensorDesc, MeshDesc).  Line refs: edge_follow_env.py."""
+    modes = dict(env_modes)
+    for k in ("movement_mode", "control_mode", "noise_mode", "observation_mode", "reward_mode", "arm_type", "tactile_sensor_name"):
+        if k not in modes:
+            raise KeyError(k)  # same failure as the reference when a mode is missing (:45-59)
+    arm, t_s_name, t_s_type = modes["arm_type"], modes["tactile_sensor_name"], "standard"      # :52,59-64
+    if modes["control_mode"] != "TCP_velocity_control":
+        if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
+            raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
+        raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")             # robot.py:174
+    if arm != "ur5":
+        if arm in ("mg400", "franka_panda", "kuka_iiwa"):
+            raise NotImplementedError(f"arm_type {arm} is not built yet for edge_follow (BASELINE configs 1-2 use ur5)")
+        raise SystemExit(f"Incorrect arm type specified {arm}")                                  # robot.py:65
+    if modes["movement_mode"] not in capi.MOVE:
+        raise ValueError(f"unknown movement_mode {modes['movement_mode']}")
+    cfg = capi.TgConfig()
+    cfg.abi_version, cfg.env_kind = capi.ABI_VERSION, capi.ENV_EDGE_FOLLOW
+    cfg.num_envs, cfg.max_steps = int(num_envs), int(max_steps)
+    cfg.movement_mode = capi.MOVE[modes["movement_mode"]]
+    cfg.noise_mode = capi.NOISE.get(modes["noise_mode"], 0)
+    cfg.reward_mode = capi.REWARD[modes["reward_mode"]]
+    cfg.physics_dtype = capi.PHYSICS[physics_dtype]
+    sim_dt, control_rate = 1.0 / 240.0, 1.0 / 10.0                                               # :33-34
+    cfg.sim_dt = sim_dt
+    cfg.action_repeat = int(np.floor(control_rate / sim_dt))                                     # :35-37 -> 24
+    cfg.solver_iterations = 150                                                                  # base_tactile_env.py:128-130
+    cfg.auto_reset, cfg.device = int(auto_reset), int(device)
+    cfg.min_action, cfg.max_action = -0.25, 0.25                                                 # :140
+    max_pos_vel, max_ang_vel = 0.01, 5.0 * (math.pi / 180)                                       # :158-159
+    lo = [-max_pos_vel] * 3 + [0.0, 0.0, -max_ang_vel]                                           # :161-166
+    hi = [max_pos_vel] * 3 + [0.0, 0.0, max_ang_vel]
+    lims = [(-0.175, 0.175), (-0.175, 0.175), (-0.1, 0.1), (0.0, 0.0), (0.0, 0.0), (-math.pi, math.pi)]  # :85-90
+    for d in range(6):
+        cfg.act_lo[d], cfg.act_hi[d] = lo[d], hi[d]
+        cfg.tcp_lims[d][0], cfg.tcp_lims[d][1] = lims[d]
+    edge_pos, edge_height, edge_len = (0.65, 0.0, 0.0), 0.035, 0.175                             # :84,201-207
+    wf_pos, wf_rpy = (edge_pos[0], edge_pos[1], edge_height), (-math.pi, 0.0, math.pi / 2)       # :106-107
+    for k in range(3):
+        cfg.workframe_pos[k], cfg.workframe_rpy[k], cfg.stim_pos[k] = wf_pos[k], wf_rpy[k], edge_pos[k]
+    cfg.edge_height, cfg.edge_len, cfg.termination_dist = edge_height, edge_len, 0.01            # :67
+    cfg.embed_dist = 0.0035                                                                      # :94-99
+    cfg.embed_lo, cfg.embed_hi = {"tactip": (0.0015, 0.0065), "digit": (0.0011, 0.0028), "digitac": (0.0015, 0.0045)}[t_s_name]  # :291-298
+    tg = load_tgmodel(arm, t_s_type, t_s_name)
+    robot = make_robot(tg, REST_POSES[arm][t_s_name][t_s_type], t_s_name)
+    sensor = SensorDesc(t_s_name, t_s_type, image_size, turn_off_border=False)                   # :121
+    mesh = MeshDesc.load("long_edge")                                                            # :223
+    return cfg, robot, sensor, mesh, modes
+
+
+class EdgeFollowVecEnv(TactileVecEnv):
+    def __init__(self, num_envs, max_steps=250, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64",
+                 auto_reset=True, device=0, obs_mode="numpy", seed=None):
+        cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
+        self.env_modes = modes
+        self.min_action, self.max_action = cfg.min_action, cfg.max_action
+        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed)
+
+    def oracle_obs(self):
+        """edge_follow_env.py:454-476: [tcp_pos_work(3), tcp_lin_vel_work(3), goal_pos_work(3), edge_ang], float32 [N,10].
+        Computed on the host from the device state read-back (the tactile path does not need it)."""
+        from .. import hip_ops
+        st = self.get_state()
+        J, pos, _ = hip_ops.jacobian_tcp(self._robot, st["q"], dtype="f64")
+        lin = np.einsum("nij,nj->ni", J[:, :3, :], st["qd"])
+        wp = np.array([self._cfg.workframe_pos[k] for k in range(3)])
+        r, p, y = (self._cfg.workframe_rpy[k] for k in range(3))
+        cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+        Rw = np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr], [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                       [-sp, cp * sr, cp * cr]])
+        ang = st["edge_ang"]
+        goal = np.stack([self._cfg.stim_pos[0] + self._cfg.edge_len * np.cos(ang), self._cfg.stim_pos[1] + self._cfg.edge_len * np.sin(ang),
+                         np.full_like(ang, self._cfg.stim_pos[2] + self._cfg.edge_height)], axis=1)
+        return np.hstack([(pos - wp) @ Rw, lin @ Rw, (goal - wp) @ Rw, ang[:, None]]).astype(np.float32)
+
+
+class EdgeFollowEnv:
+    """Single-env gym.Env surface (reset/step/render/seed/close, action_space, observation_space) backed by a 1-env
+    EdgeFollowVecEnv.  Constructor signature as edge_follow_env.py:23-30."""
+
+    metadata = {"render.modes": ["rgb_array"]}
+
+    def __init__(self, max_steps=250, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
+                 physics_dtype="f64", device=0):
+        if show_gui or show_tactile:
+            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
+        self._vec = EdgeFollowVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
+        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
+        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
+        self._max_steps, self._image_size = max_steps, list(image_size)
+        self._seed = None
+
+    @classmethod
+    def make_vec(cls, num_envs, **kwargs):
+        kwargs.pop("show_gui", None)
+        kwargs.pop("show_tactile", None)
+        return EdgeFollowVecEnv(num_envs, **kwargs)
+
+    def seed(self, seed=None):
+        self._seed = seed
+        return self._vec.seed(seed)[:1]
+
+    def reset(self):
+        return {k: v[0] for k, v in self._vec.reset().items()}
+
+    def step(self, action):
+        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
+        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
+
+    def render(self, mode="rgb_array"):
+        return self._vec.render(mode)
+
+    def close(self):
+        self._vec.close()

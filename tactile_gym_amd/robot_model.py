@@ -1,0 +1,136 @@
+"""Host-side descriptions handed to the C ABI: robot (flattened URDF), tactile sensor, stimulus mesh.
+
+Mirrors what the reference assembles in `Robot.__init__` / `TactileSensor.__init__`
+(tactile_gym/robots/arms/robot.py:18-112, tactile_gym/sensors/tactile_sensor.py:9-80,127-187).
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import _capi as capi
+from .urdf_compile import TGModel
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+_TOPOLOGIES = {(-1, 0, 1, 2, 3, 4): 0, (-1, 0, 1, 2, 3, 0, 5, 6): 1}
+
+
+def load_tgmodel(arm_type, t_s_type, t_s_name, inertia_mode="collision_aabb"):
+    suffix = "" if inertia_mode == "collision_aabb" else "_urdfinertia"
+    path = os.path.join(ASSETS, "robots", f"{arm_type}_{t_s_type}_{t_s_name}{suffix}.npz")
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"no compiled robot model {path}; run tools/extract_assets.py or urdf_compile.compile_urdf")
+    return TGModel.from_npz(np.load(path))
+
+
+def make_robot(tg, rest_q, t_s_name, gravity=(0.0, 0.0, -9.81), linear_damping=0.04, angular_damping=0.04, joint_damping=0.01,
+               max_force=1000.0, pos_gain=1.0, vel_gain=1.0):
+    """TGModel -> tg_robot.  Dynamics constants: base_tactile_env.py:126, base_robot_arm.py:22-25, ur5.py:19-21."""
+    topo = _TOPOLOGIES.get(tuple(int(p) for p in tg.parent))
+    if topo is None:
+        raise ValueError(f"unsupported kinematic tree {tg.parent.tolist()} (built: UR5 serial chain, MG400 tree)")
+    r = capi.TgRobot()
+    r.ndof, r.topology = tg.ndof, topo
+    for i in range(tg.ndof):
+        for k in range(3):
+            r.joint_pos[i][k] = float(tg.joint_pos[i][k])
+            r.joint_axis[i][k] = float(tg.joint_axis[i][k])
+        flat = np.asarray(tg.joint_rot[i], dtype=np.float64).reshape(9)
+        for k in range(9):
+            r.joint_rot[i][k] = float(flat[k])
+        r.rest_q[i] = float(rest_q[i])
+    slots = [0] * tg.ndof
+    for b in range(len(tg.body_mass)):
+        l = int(tg.body_link[b])
+        if l < 0:
+            continue
+        s = slots[l]
+        if s >= capi.MAX_BODIES_PER_LINK:
+            raise ValueError(f"more than {capi.MAX_BODIES_PER_LINK} bodies welded to link {l}")
+        slots[l] += 1
+        r.body_mass[l][s] = float(tg.body_mass[b])
+        flat = np.asarray(tg.body_rot[b], dtype=np.float64).reshape(9)
+        for k in range(3):
+            r.body_com[l][s][k] = float(tg.body_com[b][k])
+            r.body_inertia[l][s][k] = float(tg.body_inertia[b][k])
+        for k in range(9):
+            r.body_rot[l][s][k] = float(flat[k])
+    for name, (lf, pf, rf) in (("tcp_link", ("tcp_link", "tcp_pos", "tcp_rot")),
+                               (f"{t_s_name}_body_link", ("sensor_link", "sensor_pos", "sensor_rot"))):
+        link, pos, rot = tg.frames[name]
+        setattr(r, lf, int(link))
+        for k in range(3):
+            getattr(r, pf)[k] = float(pos[k])
+        flat = np.asarray(rot, dtype=np.float64).reshape(9)
+        for k in range(9):
+            getattr(r, rf)[k] = float(flat[k])
+    for k in range(3):
+        r.gravity[k] = float(gravity[k])
+    r.linear_damping, r.angular_damping, r.joint_damping = linear_damping, angular_damping, joint_damping
+    r.max_force, r.pos_gain, r.vel_gain = max_force, pos_gain, vel_gain
+    return r
+
+
+def sensor_camera(t_s_name, t_s_type):
+    """Camera intrinsics / mounting per sensor (tactile_sensor.py:127-187)."""
+    if t_s_name == "tactip":
+        fov = 60.0
+        if t_s_type in ("standard", "mini_standard", "flat"):
+            pos, rpy = (0.0, 0.0, 0.03), (0.0, -math.pi / 2, math.pi)
+        elif t_s_type in ("right_angle", "forward"):
+            pos, rpy = (0.0, 0.0, 0.03), (0.0, -math.pi / 2, 140 * math.pi / 180)
+        elif t_s_type == "mini_right_angle":
+            pos, rpy = (0.0, 0.0, 0.001), (0.0, -math.pi / 2, 140 * math.pi / 180)
+        else:
+            raise ValueError(f"unknown tactip type {t_s_type}")
+    elif t_s_name in ("digit", "digitac"):
+        fov = 40.0
+        pos = (-0.00095, 0.0139, 0.020 if t_s_type == "standard" else 0.005)
+        rpy = (math.pi, -math.pi / 2, math.pi / 2)
+    else:
+        raise ValueError(f"unknown tactile sensor {t_s_name}")
+    return dict(fov=fov, pos=pos, rpy=rpy, near=0.01, far=1.0)
+
+
+class SensorDesc:
+    """tg_sensor plus the numpy arrays that back its pointers (kept alive here)."""
+
+    def __init__(self, t_s_name, t_s_type, image_size, turn_off_border=False):
+        n = int(image_size[0])  # the reference picks the reference-image directory by image_size[0] only (tactile_sensor.py:70)
+        path = os.path.join(ASSETS, "sensors", f"{t_s_name}_{t_s_type}_{n}.npz")
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"no reference images for {t_s_name}/{t_s_type}/{n}x{n} ({path})")
+        z = np.load(path)
+        self.nodef_dep = np.ascontiguousarray(z["nodef_dep"], dtype=np.float32)
+        self.nodef_gray = np.ascontiguousarray(z["nodef_gray"], dtype=np.float32)
+        self.border_mask = np.ascontiguousarray(z["border_mask"], dtype=np.uint8)
+        cam = sensor_camera(t_s_name, t_s_type)
+        self.cam = cam
+        s = capi.TgSensor()
+        s.image_h, s.image_w = int(image_size[0]), int(image_size[1])
+        for k in range(3):
+            s.cam_pos[k] = float(cam["pos"][k])
+            s.cam_rpy[k] = float(cam["rpy"][k])
+        s.fov_deg, s.near_plane, s.far_plane = cam["fov"], cam["near"], cam["far"]
+        s.turn_off_border = int(turn_off_border)
+        s.nodef_dep = self.nodef_dep.ctypes.data_as(C.POINTER(C.c_float))
+        s.nodef_gray = self.nodef_gray.ctypes.data_as(C.POINTER(C.c_float))
+        s.border_mask = self.border_mask.ctypes.data_as(C.POINTER(C.c_uint8))
+        self.struct = s
+
+
+class MeshDesc:
+    def __init__(self, verts, tris):
+        self.verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        self.tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        m = capi.TgMesh()
+        m.n_verts, m.n_tris = self.verts.shape[0], self.tris.shape[0]
+        m.verts = self.verts.ctypes.data_as(C.POINTER(C.c_float))
+        m.tris = self.tris.ctypes.data_as(C.POINTER(C.c_int32))
+        self.struct = m
+
+    @staticmethod
+    def load(name):
+        z = np.load(os.path.join(ASSETS, "stimuli", name + ".npz"))
+        return MeshDesc(z["verts"], z["tris"])

@@ -1,0 +1,236 @@
+"""Device-resident vectorised tactile env: the SB3 `VecEnv` surface over the HIP C ABI.
+
+Replaces `make_vec_env(env_id, n_envs, vec_env_cls=SubprocVecEnv)` (reference sb3_helpers/rl_utils.py:17-30): instead
+of N OS processes each running one PyBullet server, all N envs live in one process on one MI355X; `step_async`
+enqueues the step kernels on a HIP stream and `step_wait` synchronises, mirroring SubprocVecEnv's async split.
+
+Observations follow the reference layout: dict of arrays, tactile image uint8 [N, H, W, 1]
+(base_tactile_env.py:200-210, 247-282).  With `obs_mode="numpy"` (default, what SB3 wrappers such as VecFrameStack /
+VecTransposeImage expect) they are copied to host; with `obs_mode="torch"` the tactile observation is returned as a
+zero-copy `torch.uint8` CUDA(HIP) tensor aliasing the library's device buffer.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from . import spaces
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier for a raw device pointer owned by the HIP library."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class TactileVecEnv:
+    """N environments stepped by libtactile_gym_hip.so.  Duck-types stable_baselines3.common.vec_env.VecEnv."""
+
+    metadata = {"render.modes": ["rgb_array"]}
+
+    def __init__(self, cfg, robot, sensor_desc, mesh_desc, observation_mode="tactile", obs_mode="numpy", seed=None):
+        self._L = capi.lib()
+        self.num_envs = int(cfg.num_envs)
+        self._cfg, self._robot, self._sensor, self._mesh = cfg, robot, sensor_desc, mesh_desc
+        self.observation_mode = observation_mode
+        if observation_mode not in ("oracle", "tactile", "visual", "visuotactile", "tactile_and_feature", "visual_and_feature",
+                                    "visuotactile_and_feature"):
+            raise SystemExit(f"Incorrect observation mode specified: {observation_mode}")  # base_tactile_env.py:264
+        if "visual" in observation_mode or "visuo" in observation_mode:
+            raise NotImplementedError("visual (RGB scene camera) observations are outside the built hot path (SURVEY 8f rank 4)")
+        self.obs_mode = obs_mode
+        self._ctx = C.c_void_p()
+        capi.check(self._L.tg_create(C.byref(cfg), C.byref(robot), C.byref(sensor_desc.struct), C.byref(mesh_desc.struct),
+                                     C.byref(self._ctx)))
+        self.H, self.W = sensor_desc.struct.image_h, sensor_desc.struct.image_w
+        self.ndof = robot.ndof
+        self.act_dim = {0: 2, 1: 3, 2: 3, 3: 4}[cfg.movement_mode]
+        self.action_space = spaces.Box(low=cfg.min_action, high=cfg.max_action, shape=(self.act_dim,), dtype=np.float32)
+        obs_spaces = {}
+        if "oracle" in observation_mode:
+            obs_spaces["oracle"] = spaces.Box(low=-np.inf, high=np.inf, shape=(10,), dtype=np.float32)
+        if "tactile" in observation_mode:
+            obs_spaces["tactile"] = spaces.Box(low=0, high=255, shape=(self.H, self.W, 1), dtype=np.uint8)
+        if "feature" in observation_mode:
+            obs_spaces["extended_feature"] = spaces.Box(low=-np.inf, high=np.inf, shape=(0,), dtype=np.float32)
+        self.observation_space = spaces.Dict(obs_spaces)
+        self._actions = np.zeros((self.num_envs, self.act_dim), dtype=np.float32)
+        self._reward = np.zeros(self.num_envs, dtype=np.float32)
+        self._done = np.zeros(self.num_envs, dtype=np.uint8)
+        self._obs_host = np.zeros((self.num_envs, self.H, self.W, 1), dtype=np.uint8)
+        self._term_host = None
+        self._closed = False
+        self._torch_obs = None
+        if seed is not None:
+            self.seed(seed)
+
+    # ------------------------------------------------------------------ VecEnv API
+    def seed(self, seed=None):
+        """env i gets seed + i (SB3 make_vec_env convention; reference base_tactile_env.py:61-64)."""
+        base = 0 if seed is None else int(seed)
+        seeds = (np.arange(self.num_envs, dtype=np.uint64) + np.uint64(base)).astype(np.uint64)
+        capi.check(self._L.tg_seed(self._ctx, seeds.ctypes.data_as(C.POINTER(C.c_uint64)), self.num_envs))
+        return [base + i for i in range(self.num_envs)]
+
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert m.shape == (self.num_envs,)
+        capi.check(self._L.tg_reset(self._ctx, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None))
+        capi.check(self._L.tg_sync(self._ctx))
+        return self._observation()
+
+    def step_async(self, actions):
+        """actions: numpy float32 [N, act_dim], or a torch CUDA tensor (used in place, no copy)."""
+        if hasattr(actions, "data_ptr") and getattr(actions, "is_cuda", False):
+            assert actions.dtype.is_floating_point and actions.element_size() == 4 and actions.is_contiguous()
+            assert tuple(actions.shape) == (self.num_envs, self.act_dim)
+            self._held = actions  # keep alive until step_wait
+            capi.check(self._L.tg_step(self._ctx, C.c_void_p(actions.data_ptr()), 1))
+        else:
+            np.copyto(self._actions, np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim))
+            capi.check(self._L.tg_step(self._ctx, C.c_void_p(self._actions.ctypes.data), 0))
+
+    def step_wait(self):
+        capi.check(self._L.tg_get_reward_done(self._ctx, self._reward.ctypes.data_as(C.POINTER(C.c_float)),
+                                              self._done.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._held = None
+        obs = self._observation()
+        dones = self._done.astype(bool)
+        infos = [{} for _ in range(self.num_envs)]
+        if self._cfg.auto_reset and dones.any():
+            term = self._terminal_observation()
+            for i in np.nonzero(dones)[0]:
+                infos[i]["terminal_observation"] = {k: v[i] for k, v in term.items()}
+                infos[i]["TimeLimit.truncated"] = False
+        return obs, self._reward.copy(), dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        if not self._closed:
+            self._closed = True
+            self._L.tg_destroy(self._ctx)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if np.isscalar(indices) else indices)
+        return [getattr(self, attr_name) for _ in idx]
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        idx = range(self.num_envs) if indices is None else ([indices] if np.isscalar(indices) else indices)
+        return [getattr(self, method_name)(*args, **kwargs) for _ in idx]
+
+    def get_images(self):
+        return list(self.tactile_numpy()[..., 0])
+
+    def render(self, mode="rgb_array"):
+        """Tiled tactile images (the reference concatenates the RGB scene view, which is not built: SURVEY 8f rank 4)."""
+        if mode != "rgb_array":
+            return np.array([])
+        img = self.tactile_numpy()[..., 0]
+        cols = int(np.ceil(np.sqrt(self.num_envs)))
+        rows = int(np.ceil(self.num_envs / cols))
+        canvas = np.zeros((rows * self.H, cols * self.W), dtype=np.uint8)
+        for i in range(self.num_envs):
+            r, c = divmod(i, cols)
+            canvas[r * self.H:(r + 1) * self.H, c * self.W:(c + 1) * self.W] = img[i]
+        return np.repeat(canvas[..., None], 3, axis=2)
+
+    # ------------------------------------------------------------------ device / host views
+    def sync(self):
+        capi.check(self._L.tg_sync(self._ctx))
+
+    def set_stream(self, hip_stream_ptr):
+        capi.check(self._L.tg_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
+
+    def tactile_device_ptr(self, terminal=False):
+        p = C.c_void_p()
+        fn = self._L.tg_get_terminal_obs if terminal else self._L.tg_get_obs_tactile
+        capi.check(fn(self._ctx, C.byref(p)))
+        return p.value
+
+    def tactile_torch(self, terminal=False):
+        """Zero-copy torch.uint8 [N,H,W,1] view of the device observation buffer."""
+        import torch
+        arr = _DevArray(self.tactile_device_ptr(terminal), (self.num_envs, self.H, self.W, 1), "|u1")
+        return torch.as_tensor(arr, device=f"cuda:{self._cfg.device}")
+
+    def reward_done_torch(self):
+        import torch
+        r, d = C.c_void_p(), C.c_void_p()
+        capi.check(self._L.tg_get_reward_done_dev(self._ctx, C.byref(r), C.byref(d)))
+        dev = f"cuda:{self._cfg.device}"
+        return (torch.as_tensor(_DevArray(r.value, (self.num_envs,), "<f4"), device=dev),
+                torch.as_tensor(_DevArray(d.value, (self.num_envs,), "|u1"), device=dev))
+
+    def tactile_numpy(self, terminal=False):
+        buf = self._obs_host if not terminal else np.zeros_like(self._obs_host)
+        capi.check(self._L.tg_copy_obs_tactile(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint8)), int(terminal)))
+        return buf
+
+    def _observation(self):
+        obs = {}
+        if "oracle" in self.observation_mode:
+            obs["oracle"] = self.oracle_obs()
+        if "tactile" in self.observation_mode:
+            obs["tactile"] = self.tactile_torch() if self.obs_mode == "torch" else self.tactile_numpy().copy()
+        if "feature" in self.observation_mode:
+            obs["extended_feature"] = np.zeros((self.num_envs, 0), dtype=np.float32)
+        return obs
+
+    def _terminal_observation(self):
+        obs = {}
+        if "tactile" in self.observation_mode:
+            obs["tactile"] = self.tactile_torch(True) if self.obs_mode == "torch" else self.tactile_numpy(True)
+        return obs
+
+    def oracle_obs(self):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ parity / inspection
+    def get_state(self):
+        """Host copy of the per-env state (tg_get_state)."""
+        n, nd = self.num_envs, self.ndof
+        out = dict(q=np.zeros((n, nd)), qd=np.zeros((n, nd)), qd_target=np.zeros((n, nd)), tcp_pos=np.zeros((n, 3)),
+                   tcp_rpy=np.zeros((n, 3)), edge_ang=np.zeros(n), embed_dist=np.zeros(n), stim_xform=np.zeros((n, 12), np.float32),
+                   step_count=np.zeros(n, np.int32), reset_ticks=np.zeros(n, np.int32), rng_state=np.zeros(n, np.uint64))
+        v = capi.TgStateView()
+        for k, a in out.items():
+            ct = {np.dtype(np.float64): C.c_double, np.dtype(np.float32): C.c_float, np.dtype(np.int32): C.c_int32,
+                  np.dtype(np.uint64): C.c_uint64}[a.dtype]
+            setattr(v, k, a.ctypes.data_as(C.POINTER(ct)))
+        capi.check(self._L.tg_get_state(self._ctx, C.byref(v)))
+        return out
+
+    def set_joint_state(self, q, qd):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(self.num_envs, self.ndof)
+        qd = np.ascontiguousarray(qd, dtype=np.float64).reshape(self.num_envs, self.ndof)
+        dp = C.POINTER(C.c_double)
+        capi.check(self._L.tg_set_joint_state(self._ctx, q.ctypes.data_as(dp), qd.ctypes.data_as(dp)))
+
+    def profile(self, enable=True):
+        capi.check(self._L.tg_profile_enable(self._ctx, int(enable)))
+
+    def profile_get(self):
+        out = {}
+        for which, name in enumerate(("step", "render", "reset")):
+            ms, cnt = C.c_double(), C.c_int64()
+            capi.check(self._L.tg_profile_get(self._ctx, which, C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out

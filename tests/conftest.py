@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EDGE_MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
+                  reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def edge_modes():
+    return dict(EDGE_MODES)
+
+
+@pytest.fixture(scope="session")
+def ur5_tactip():
+    """(TGModel, oracle Arm factory, tg_robot) for UR5 + standard TacTip."""
+    from oracle import minibullet as mb
+    from tactile_gym_amd.rl_envs.edge_follow import REST_POSES
+    from tactile_gym_amd.robot_model import load_tgmodel, make_robot
+    tg = load_tgmodel("ur5", "standard", "tactip")
+    rest = REST_POSES["ur5"]["tactip"]["standard"]
+    return tg, (lambda: mb.Arm(tg)), make_robot(tg, rest, "tactip"), rest

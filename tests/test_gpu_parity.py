@@ -1,0 +1,249 @@
+"""GPU parity: every device function on the hot path against the CPU oracle, through the C ABI.
+
+Tolerances (stated per north_star: "bit-exact for contact-pair indices, stated float tolerance for poses and tactile
+depth"):
+  * f64 physics vs the f64 oracle: joint angles / velocities 1e-9 (abs), torques and inertia 1e-9 relative — the two
+    sides use different formulations (body-by-body sums vs merged links + composite recursion), so agreement is to
+    rounding, not bitwise;
+  * f32 physics vs the f64 oracle: 2e-4 relative on dynamics terms, 2e-5 rad on joint angles after one env step;
+  * tactile image given identical float32 camera<-stimulus transforms: BIT-EXACT (uint8 equality on every pixel).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_states(rest, n, seed, spread=0.4, vel=0.5):
+    rng = np.random.default_rng(seed)
+    q = np.asarray(rest)[None] + spread * rng.standard_normal((n, len(rest)))
+    qd = vel * rng.standard_normal((n, len(rest)))
+    return q, qd, rng
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-10), ("f32", 2e-5)])
+def test_fk_and_jacobian(ur5_tactip, dtype, tol):
+    from tactile_gym_amd import hip_ops
+    tg, mk_arm, robot, rest = ur5_tactip
+    q, _, _ = _rand_states(rest, 128, 0)
+    J, pos, rot = hip_ops.jacobian_tcp(robot, q, dtype)
+    arm = mk_arm()
+    for i in range(q.shape[0]):
+        p, _, _, _, R = arm.link_state("tcp_link", q=q[i], qd=np.zeros(6))
+        assert np.abs(pos[i] - p).max() < tol
+        assert np.abs(rot[i] - R).max() < tol
+        assert np.abs(J[i] - arm.jacobian("tcp_link", q[i])).max() < tol
+
+
+@pytest.mark.parametrize("dtype,rtol", [("f64", 1e-9), ("f32", 2e-4)])
+def test_inverse_dynamics_and_mass_matrix(ur5_tactip, dtype, rtol):
+    from tactile_gym_amd import hip_ops
+    tg, mk_arm, robot, rest = ur5_tactip
+    q, qd, rng = _rand_states(rest, 128, 1)
+    qdd = rng.standard_normal(q.shape)
+    tau = hip_ops.inverse_dynamics(robot, q, qd, qdd, dtype)
+    M = hip_ops.mass_matrix(robot, q, dtype)
+    arm = mk_arm()
+    for i in range(q.shape[0]):
+        ref = arm.inverse_dynamics(q[i], qd[i], qdd[i])
+        assert np.abs(tau[i] - ref).max() < rtol * (1.0 + np.abs(ref).max())
+        Mref = arm.mass_matrix(q[i])
+        assert np.abs(M[i] - Mref).max() < rtol * 10 * np.abs(Mref).max()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-9), ("f32", 2e-5)])
+@pytest.mark.parametrize("mode", ["velocity", "position"])
+def test_sim_ticks(ur5_tactip, dtype, tol, mode):
+    """24 x (gravity compensation + stepSimulation) from random states with saturating and non-saturating motors."""
+    from oracle import minibullet as mb
+    from tactile_gym_amd import _capi as capi, hip_ops
+    tg, mk_arm, robot, rest = ur5_tactip
+    n = 64
+    q, qd, rng = _rand_states(rest, n, 2, spread=0.3, vel=0.2)
+    qd_des = 0.1 * rng.standard_normal(q.shape)
+    q_des = q + 0.002 * rng.standard_normal(q.shape)
+    for max_force in (1000.0, 5.0):     # 5 N m saturates the shoulder motors: exercises the impulse clamp
+        if mode == "velocity":
+            q1, qd1 = hip_ops.sim_ticks(robot, q, qd, 24, capi.MOTOR_VELOCITY, qd_des=qd_des, max_force=max_force, dtype=dtype)
+        else:
+            q1, qd1 = hip_ops.sim_ticks(robot, q, qd, 24, capi.MOTOR_POSITION, q_des=q_des, qd_des=np.zeros_like(q), max_force=max_force, dtype=dtype)
+        for i in range(n):
+            arm = mk_arm()
+            arm.reset_joint_states(q[i])
+            for k in range(6):
+                arm.state.qd[k] = qd[i, k]
+            if mode == "velocity":
+                arm.set_motors_velocity(qd_des[i], 1.0, max_force)
+            else:
+                arm.set_motors_position(q_des[i], np.zeros(6), 1.0, 1.0, max_force)
+            for _ in range(24):
+                arm.apply_torques(arm.inverse_dynamics(arm.q, arm.qd, np.zeros(6)))
+                arm.step_simulation()
+            scale = 1.0 if max_force > 100 else 50.0   # saturated motors leave large accelerations: errors scale with |qd|
+            assert np.abs(q1[i] - arm.q).max() < tol * scale, (mode, max_force, i)
+            assert np.abs(qd1[i] - arm.qd).max() < 100 * tol * scale, (mode, max_force, i)
+
+
+@pytest.mark.parametrize("size", [64, 128, 256])
+def test_render_bit_exact(size):
+    """Raster + t_s_camera on random in-contact transforms: uint8 image identical to the oracle on every pixel."""
+    from oracle import minibullet as mb
+    from oracle.ref_env import OracleEdgeFollowEnv
+    from tactile_gym_amd import hip_ops
+    from tactile_gym_amd.robot_model import MeshDesc, SensorDesc
+    sensor, mesh = SensorDesc("tactip", "standard", (size, size)), MeshDesc.load("long_edge")
+    env = OracleEdgeFollowEnv(seed=3, image_size=(size, size))
+    rng = np.random.default_rng(4)
+    xfs = []
+    for _ in range(24):
+        env.reset()
+        q = env.arm.q + 0.01 * rng.standard_normal(6)     # tilt / shift the sensor so all box faces get exercised
+        env.arm.reset_joint_states(q)
+        xfs.append(env.stimulus_transform())
+    xfs = np.stack(xfs)
+    imgs = hip_ops.render_tactile(sensor, mesh, xfs)
+    touched = 0
+    for i in range(xfs.shape[0]):
+        cur = sensor.nodef_dep.copy()
+        mb.render_depth(mesh.verts, mesh.tris, xfs[i], sensor.cam["fov"], sensor.cam["near"], sensor.cam["far"], size, size, cur)
+        ref = mb.t_s_camera(cur, sensor.nodef_dep, sensor.nodef_gray, sensor.border_mask)
+        assert np.array_equal(imgs[i], ref), f"image {i}: {(imgs[i] != ref).sum()} pixels differ"
+        touched += int((ref[sensor.border_mask == 0] > 0).sum())
+    assert touched > 100 * xfs.shape[0] / 4   # the cases really are in contact
+
+
+def test_render_near_clip_and_ragged():
+    """Triangles crossing the near plane / behind the camera / empty mesh (edge cases of getCameraImage)."""
+    from oracle import minibullet as mb
+    from tactile_gym_amd import hip_ops
+    from tactile_gym_amd.robot_model import MeshDesc, SensorDesc
+    sensor = SensorDesc("tactip", "standard", (128, 128))
+    rng = np.random.default_rng(5)
+    verts = (rng.uniform(-0.08, 0.08, size=(300, 3))).astype(np.float32)
+    tris = rng.integers(0, 300, size=(1500, 3)).astype(np.int32)       # > one LDS batch (512 input triangles)
+    mesh = MeshDesc(verts, tris)
+    xfs = []
+    for _ in range(6):
+        A = np.linalg.qr(rng.standard_normal((3, 3)))[0]
+        t = np.array([0.0, 0.0, -0.03]) + 0.01 * rng.standard_normal(3)  # camera inside the cloud: many near-plane crossings
+        xfs.append(np.concatenate([A.reshape(9), t]))
+    xfs = np.asarray(xfs, dtype=np.float32)
+    imgs = hip_ops.render_tactile(sensor, mesh, xfs)
+    for i in range(len(xfs)):
+        cur = sensor.nodef_dep.copy()
+        mb.render_depth(verts, tris, xfs[i], 60.0, 0.01, 1.0, 128, 128, cur)
+        ref = mb.t_s_camera(cur, sensor.nodef_dep, sensor.nodef_gray, sensor.border_mask)
+        assert np.array_equal(imgs[i], ref), f"image {i}: {(imgs[i] != ref).sum()} pixels differ"
+    # empty mesh: zero-contact known answer  u8(nodef_gray) on the border, 0 elsewhere (SURVEY 8c known-answer 2)
+    empty = MeshDesc(np.zeros((1, 3), np.float32), np.zeros((0, 3), np.int32))
+    img = hip_ops.render_tactile(sensor, empty, xfs[:1])[0]
+    expect = np.where(sensor.border_mask == 1, sensor.nodef_gray.astype(np.uint8), 0).astype(np.uint8)
+    assert np.array_equal(img, expect)
+
+
+@pytest.mark.parametrize("dtype,qtol,max_px", [("f64", 1e-9, 0), ("f32", 5e-5, 400)])
+def test_env_reset_and_steps_match_oracle(edge_modes, dtype, qtol, max_px):
+    """edge_follow-v0: reset + 6 random-action steps, 8 envs, against 8 independent oracle envs with the same seeds."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleEdgeFollowEnv
+    n = 8
+    venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=edge_modes, seed=11,
+                       auto_reset=False, physics_dtype=dtype)
+    oracles = [OracleEdgeFollowEnv(seed=11 + i, max_steps=200, image_size=(128, 128), env_modes=edge_modes) for i in range(n)]
+    obs = venv.reset()
+    ref_obs = [o.reset() for o in oracles]
+    st = venv.get_state()
+    for i, o in enumerate(oracles):
+        assert st["edge_ang"][i] == o.edge_ang and st["embed_dist"][i] == o.embed_dist     # identical integer RNG stream
+        if dtype == "f64":
+            assert st["reset_ticks"][i] == o.reset_ticks
+        assert np.abs(st["q"][i] - o.arm.q).max() < qtol * 10
+        assert int((obs["tactile"][i] != ref_obs[i]["tactile"]).sum()) <= max_px
+    rng = np.random.default_rng(12)
+    for step in range(6):
+        a = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+        obs, rew, done, info = venv.step(a)
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            ro, rr, rd, _ = o.step(a[i])
+            assert np.abs(st["qd_target"][i] - o.last_req_joint_vels).max() < max(qtol, 1e-9) * 100
+            assert np.abs(st["q"][i] - o.arm.q).max() < qtol * 10, (step, i)
+            assert np.abs(st["tcp_pos"][i] - o.cur_tcp_pos).max() < qtol * 10
+            assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
+            assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= max_px, (step, i)
+    venv.close()
+
+
+def test_autoreset_terminal_observation(edge_modes):
+    """VecEnv semantics: at max_steps the env reports done, keeps the terminal observation, and is already reset."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleEdgeFollowEnv
+    n = 4
+    venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=3, image_size=[128, 128], env_modes=edge_modes, seed=21, auto_reset=True)
+    oracles = [OracleEdgeFollowEnv(seed=21 + i, max_steps=3, image_size=(128, 128), env_modes=edge_modes) for i in range(n)]
+    venv.reset()
+    for o in oracles:
+        o.reset()
+    rng = np.random.default_rng(22)
+    for step in range(3):
+        a = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+        obs, rew, done, info = venv.step(a)
+        refs = [o.step(a[i]) for i, o in enumerate(oracles)]
+        assert bool(done.all()) == (step == 2)
+    for i, o in enumerate(oracles):
+        assert np.array_equal(info[i]["terminal_observation"]["tactile"], refs[i][0]["tactile"])
+        new = o.reset()
+        assert np.array_equal(obs["tactile"][i], new["tactile"])
+    st = venv.get_state()
+    assert (st["step_count"] == 0).all()
+    venv.close()
+
+
+def test_full_size_properties(edge_modes):
+    """BASELINE config 2 size (1024 envs, 128x128): size-independent properties.
+    (a) determinism: two contexts with the same seeds produce identical images and states after 3 steps;
+    (b) border invariance: every border pixel equals u8(nodef_gray) in every env, whatever the contact;
+    (c) different seeds give different edges (no accidental stream sharing);
+    (d) envs 0..7 of the big batch equal an 8-env batch with the same seeds (batch-size independence)."""
+    import tactile_gym_amd as tg
+    n = 1024
+    rng = np.random.default_rng(31)
+    acts = rng.uniform(-0.25, 0.25, size=(3, n, 2)).astype(np.float32)
+    outs = []
+    for rep in range(2):
+        venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=edge_modes, seed=5)
+        venv.reset()
+        for k in range(3):
+            obs, rew, done, _ = venv.step(acts[k])
+        outs.append((obs["tactile"].copy(), rew.copy(), venv.get_state()))
+        if rep == 0:
+            border = venv._sensor.border_mask == 1
+            gray = venv._sensor.nodef_gray.astype(np.uint8)
+        venv.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2]["q"], outs[1][2]["q"])
+    imgs = outs[0][0][..., 0]
+    assert (imgs[:, border] == gray[border][None]).all()
+    assert len(np.unique(outs[0][2]["edge_ang"])) == n
+    assert (imgs[:, ~border].reshape(n, -1).max(axis=1) > 0).mean() > 0.9     # nearly every env is in contact
+    small = tg.make_vec("edge_follow-v0", num_envs=8, max_steps=200, image_size=[128, 128], env_modes=edge_modes, seed=5)
+    small.reset()
+    for k in range(3):
+        o8, r8, _, _ = small.step(acts[k, :8])
+    assert np.array_equal(o8["tactile"], outs[0][0][:8]) and np.array_equal(r8, outs[0][1][:8])
+    small.close()
+
+
+def test_torch_zero_copy_and_device_actions(edge_modes):
+    import torch
+    import tactile_gym_amd as tg
+    n = 64
+    venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=edge_modes, seed=7, obs_mode="torch")
+    obs = venv.reset()
+    assert obs["tactile"].is_cuda and obs["tactile"].dtype == torch.uint8 and tuple(obs["tactile"].shape) == (n, 128, 128, 1)
+    a = (torch.rand(n, 2, device="cuda") - 0.5) * 0.5
+    obs2, rew, done, _ = venv.step(a)
+    assert obs2["tactile"].data_ptr() == venv.tactile_device_ptr()
+    host = venv.tactile_numpy()
+    assert np.array_equal(obs2["tactile"].cpu().numpy(), host)
+    venv.close()

@@ -1,0 +1,155 @@
+"""CPU tests: the oracle against the reference's committed golden data and analytic known answers."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _sensor(name, typ, n):
+    return np.load(os.path.join(ROOT, "tactile_gym_amd", "assets", "sensors", f"{name}_{typ}_{n}.npz"))
+
+
+@pytest.mark.parametrize("size", [64, 128, 256])
+def test_tactip_nodef_depth_fixture(size):
+    """Known-answer (1): rendering the rigid TacTip skin through the oracle's camera model reproduces the reference's
+    committed nodef_dep.npy (tactile_sensor.py:74,79) inside the border disc — pins a11-a13 (projection, camera
+    mounting, GL depth convention, raster rule).  The body mesh is a missing blob upstream, so border pixels are not
+    compared.  Tolerance 2e-5 depth-buffer units = 1/5 of the reference's own noise threshold eps = 1e-4 (:274)."""
+    from oracle import minibullet as mb
+    from oracle.ref_env import sensor_camera
+    from tactile_gym_amd.urdf_compile import rpy_to_mat
+    g = np.load(os.path.join(GOLD, "tactip_standard_view.npz"))
+    s = _sensor("tactip", "standard", size)
+    cam = sensor_camera("tactip", "standard")
+    M = mb.cam_from_obj_matrix(cam["pos"], rpy_to_mat(cam["rpy"]), np.zeros(3), np.eye(3))
+    dep = np.ones((size, size), np.float32)
+    mb.render_depth(g["tip_verts"], g["tip_tris"], M, cam["fov"], cam["near"], cam["far"], size, size, dep)
+    inner = s["border_mask"] == 0
+    err = np.abs(dep - s["nodef_dep"])[inner]
+    assert inner.sum() > 0.5 * size * size
+    assert err.max() < 2e-5 and err.mean() < 3e-6
+
+
+def test_depth_convention_decodes_to_metres():
+    """The fixture's centre depth decodes (OpenGL, near .01 / far 1) to the camera-to-skin-apex distance
+    0.085 - 0.03 = 0.055 m (ur5_with_standard_tactip.urdf:329 + skin radius, tactile_sensor.py:160)."""
+    d = float(_sensor("tactip", "standard", 128)["nodef_dep"][63:65, 63:65].max())
+    n, f = 0.01, 1.0
+    z = 2 * f * n / ((f + n) - (2 * d - 1) * (f - n))
+    assert abs(z - 0.055) < 4e-4
+
+
+def test_t_s_camera_zero_contact_known_answer():
+    """Known-answer (2): with nothing in front of the skin the tactile image is u8(nodef_gray) on the border, else 0."""
+    from oracle import minibullet as mb
+    s = _sensor("tactip", "standard", 128)
+    img = mb.t_s_camera(s["nodef_dep"], s["nodef_dep"], s["nodef_gray"], s["border_mask"])
+    expect = np.where(s["border_mask"] == 1, s["nodef_gray"].astype(np.uint8), 0)
+    assert np.array_equal(img, expect)
+    # noise below eps is removed, above is kept (tactile_sensor.py:274-282)
+    cur = s["nodef_dep"].copy()
+    cur[60, 60] -= 0.9e-4
+    cur[61, 61] -= 0.0101
+    cur[62, 62] -= 0.2
+    img = mb.t_s_camera(cur, s["nodef_dep"], s["nodef_gray"], s["border_mask"])
+    assert img[60, 60] == 0 and img[61, 61] == int(np.float32(np.float32(0.0101) / np.float32(0.05)) * np.float32(255)) and img[62, 62] == 255
+
+
+def test_fk_rest_pose_matches_reference_workframe(ur5_tactip):
+    """Known-answer (4): FK of the edge_follow rest pose (rest_poses.py:6-20) puts the TCP inertial frame at the reset
+    target: work-frame origin (0.65, 0, 0.035) lowered by the default embed 3.5 mm, orientation = workframe rpy
+    (-pi, 0, pi/2) (edge_follow_env.py:95,106-107,305) — to the 0.3 mm the reference's own rest pose carries."""
+    from oracle import pb_math as pm
+    tg, mk_arm, _, rest = ur5_tactip
+    arm = mk_arm()
+    arm.reset_joint_states(rest)
+    pos, quat, _, _, R = arm.link_state("tcp_link")
+    assert np.abs(pos - np.array([0.65, 0.0, 0.0315])).max() < 3e-4
+    Rw = pm.mat_from_quat(pm.quat_from_euler([-math.pi, 0.0, math.pi / 2]))
+    assert np.abs(R - Rw).max() < 2e-3
+
+
+def test_dynamics_self_consistency(ur5_tactip):
+    """The oracle's dynamics terms satisfy the identities any correct rigid-body model must: M symmetric positive
+    definite, ID linear in qdd with slope M, gravity term = dV/dq, passivity qd.(C qd) = 1/2 qd Mdot qd, and the
+    Jacobian maps joint rates to the TCP twist returned by getLinkState."""
+    tg, mk_arm, _, rest = ur5_tactip
+    arm = mk_arm()
+    rng = np.random.default_rng(0)
+    q = np.asarray(rest) + 0.2 * rng.standard_normal(6)
+    qd, qdd = 0.4 * rng.standard_normal(6), rng.standard_normal(6)
+    M = arm.mass_matrix(q)
+    assert np.abs(M - M.T).max() < 1e-14 and np.linalg.eigvalsh(M).min() > 0
+    h, g0 = arm.inverse_dynamics(q, qd, np.zeros(6)), arm.inverse_dynamics(q, np.zeros(6), np.zeros(6))
+    assert np.abs(arm.inverse_dynamics(q, qd, qdd) - h - M @ qdd).max() < 1e-12
+    eps = 1e-6
+    Md = (arm.mass_matrix(q + eps * qd) - arm.mass_matrix(q - eps * qd)) / (2 * eps)
+    assert abs(qd @ (h - g0) - 0.5 * qd @ Md @ qd) < 1e-8
+
+    def potential(qq):
+        from oracle import minibullet as mb
+        R, p = np.zeros((6, 9)), np.zeros((6, 3))
+        arm.L.mb_fk(mb.C.byref(arm.model), mb._dp(np.ascontiguousarray(qq)), mb._dp(R), mb._dp(p))
+        return sum(tg.body_mass[b] * 9.81 * (R[tg.body_link[b]].reshape(3, 3) @ tg.body_com[b] + p[tg.body_link[b]])[2]
+                   for b in range(len(tg.body_mass)))
+    gfd = np.array([(potential(q + eps * e) - potential(q - eps * e)) / (2 * eps) for e in np.eye(6)])
+    assert np.abs(gfd - g0).max() < 1e-6
+    J = arm.jacobian("tcp_link", q)
+    _, _, lv, av, _ = arm.link_state("tcp_link", q=q, qd=qd)
+    assert np.abs(J[:3] @ qd - lv).max() < 1e-14 and np.abs(J[3:] @ qd - av).max() < 1e-14
+
+
+def test_velocity_motor_reaches_target_and_clamps(ur5_tactip):
+    """stepSimulation with VELOCITY_CONTROL motors (base_robot_arm.py:325-332): with 1000 N m available the PGS rows
+    reach the target velocity within one tick; with 1 N m they saturate at |impulse| = force * dt."""
+    tg, mk_arm, _, rest = ur5_tactip
+    arm = mk_arm()
+    arm.reset_joint_states(rest)
+    target = np.array([0.01, -0.02, 0.03, 0.0, 0.01, 0.0])
+    arm.set_motors_velocity(target, 1.0, 1000.0)
+    arm.apply_torques(arm.inverse_dynamics(arm.q, arm.qd, np.zeros(6)))
+    arm.step_simulation()
+    assert np.abs(arm.qd - target).max() < 1e-9
+    assert np.abs(arm.q - (np.asarray(rest) + target / 240.0)).max() < 1e-12
+    arm2 = mk_arm()
+    arm2.reset_joint_states(rest)
+    arm2.set_motors_velocity(np.full(6, 5.0), 1.0, 1.0)
+    arm2.apply_torques(arm2.inverse_dynamics(arm2.q, arm2.qd, np.zeros(6)))
+    arm2.step_simulation()
+    M = arm2.mass_matrix(np.asarray(rest))
+    assert np.abs(M @ arm2.qd).max() <= 1.0 / 240.0 + 1e-6     # generalised impulse bounded by the motor clamp (damping is tiny)
+
+
+def test_pb_math_roundtrips():
+    from oracle import pb_math as pm
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        rpy = rng.uniform([-3.1, -1.5, -3.1], [3.1, 1.5, 3.1])
+        q = pm.quat_from_euler(rpy)
+        assert np.abs(pm.euler_from_quat(q) - rpy).max() < 1e-9
+        assert np.abs(pm.mat_from_quat(pm.quat_from_mat(pm.mat_from_quat(q))) - pm.mat_from_quat(q)).max() < 1e-12
+        p = rng.standard_normal(3)
+        ip, iq = pm.invert_transform(p, q)
+        pos, qq = pm.multiply_transforms(ip, iq, p, q)
+        assert np.abs(pos).max() < 1e-12 and abs(abs(qq[3]) - 1) < 1e-12
+
+
+def test_oracle_env_contact_patch_tracks_embed_depth():
+    """Known-answer (3), qualitative form: the penetration image grows monotonically with the embed depth and the
+    contact patch is a band along the edge direction."""
+    from oracle.ref_env import OracleEdgeFollowEnv
+    areas, peaks = [], []
+    for embed in (0.0015, 0.0035, 0.0065):
+        env = OracleEdgeFollowEnv(seed=0, env_modes=dict(noise_mode="fixed_height"))
+        env.embed_dist = embed
+        obs = env.reset()
+        img = obs["tactile"][..., 0]
+        inner = env.border_mask == 0
+        areas.append(int((img[inner] > 0).sum()))
+        peaks.append(int(img[inner].max()))
+        assert abs(env.cur_tcp_pos[2] - (0.035 - embed)) < 2.5e-4   # blocking_move tolerance pos_tol = 2e-4 (robot.py:192)
+    assert areas[0] < areas[1] < areas[2] and peaks[0] < peaks[1] < peaks[2]

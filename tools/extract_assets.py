@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Compile the reference's *data* assets into the compact blobs this repo ships.
+
+Run in the build container (where /root/reference exists):   python tools/extract_assets.py
+
+Reads (never copies verbatim) from /root/reference/tactile_gym/assets:
+  * robot URDFs + collision meshes  -> tactile_gym_amd/assets/robots/<arm>_<type>_<sensor>.npz   (TGModel arrays)
+  * sensor reference images (.npy)  -> tactile_gym_amd/assets/sensors/<sensor>_<type>_<N>.npz     (hot-path constants a15)
+  * stimulus meshes                 -> tactile_gym_amd/assets/stimuli/<name>.npz                  (float32 verts, int32 tris)
+  * skin / body visual meshes       -> tests/golden/<sensor>_<type>_view.npz                      (fixture-pinning only)
+
+Nothing under tests/, bench.py or smoke() reads /root/reference at run time; they read these blobs.
+Provenance and licences: tactile_gym_amd/assets/PROVENANCE.md.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tactile_gym_amd.urdf_compile import compile_urdf, load_mesh, parse_urdf, rpy_to_mat, visual_meshes_of_link  # noqa: E402
+
+REF = os.environ.get("TG_REFERENCE_ASSETS", "/root/reference/tactile_gym/assets")
+OUT = os.path.join(ROOT, "tactile_gym_amd", "assets")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# The standard TacTip body mesh is a missing large blob in the reference checkout (.MISSING_LARGE_BLOBS); its
+# collision is filtered out (tactile_sensor.py:51) so it only matters through the AABB-derived inertia of a
+# 0.25 kg link.  Stand-in AABB: a 50 mm x 50 mm x 65 mm housing (65 mm = tip joint offset, urdf:329)
+# [PARITY_ASSUMPTIONS A3b].
+MISSING = {"tactip_body.obj": ([-0.025, -0.025, 0.0], [0.025, 0.025, 0.065])}
+
+ROBOTS = [
+    # (arm, sensor, type, frames of interest)
+    ("ur5", "tactip", "standard"),
+    ("ur5", "digit", "standard"),
+    ("ur5", "digitac", "standard"),
+    ("mg400", "tactip", "standard"),
+    ("mg400", "digitac", "right_angle"),
+    ("mg400", "digit", "right_angle"),
+    ("mg400", "tactip", "right_angle"),
+]
+
+SENSOR_IMAGES = [
+    ("tactip", "standard", (64, 128, 256)),
+    ("tactip", "right_angle", (64, 128, 256)),
+    ("digit", "standard", (64, 128, 256)),
+    ("digit", "right_angle", (64, 128, 256)),
+    ("digitac", "standard", (64, 128, 256)),
+    ("digitac", "right_angle", (64, 128, 256)),
+]
+
+
+def save(path, **arrays):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path)} B)")
+
+
+def robots():
+    for arm, sensor, typ in ROBOTS:
+        urdf = os.path.join(REF, "robot_assets", arm, sensor, f"{arm}_with_{typ}_{sensor}.urdf")
+        if not os.path.isfile(urdf):
+            print("skip (missing)", urdf)
+            continue
+        links, _ = parse_urdf(urdf)
+        foi = [n for n in links if n in ("tcp_link", "ee_link", f"{sensor}_body_link", f"{sensor}_tip_link",
+                                         "tactip_adapter_link", "link4_1", "link4_2", "link5")]
+        for mode in ("collision_aabb", "urdf"):
+            try:
+                m = compile_urdf(urdf, frames_of_interest=foi, inertia_mode=mode, missing_mesh_aabb=MISSING,
+                                 name=f"{arm}_{typ}_{sensor}")
+            except FileNotFoundError as e:
+                print("skip", arm, sensor, typ, mode, e)
+                continue
+            suffix = "" if mode == "collision_aabb" else "_urdfinertia"
+            save(os.path.join(OUT, "robots", f"{arm}_{typ}_{sensor}{suffix}.npz"), **m.to_npz_dict())
+
+
+def sensors():
+    for sensor, typ, sizes in SENSOR_IMAGES:
+        for n in sizes:
+            d = os.path.join(REF, "robot_assets", sensor, "reference_images", typ, f"{n}x{n}")
+            if not os.path.isdir(d):
+                print("skip (missing)", d)
+                continue
+            save(os.path.join(OUT, "sensors", f"{sensor}_{typ}_{n}.npz"),
+                 nodef_dep=np.load(os.path.join(d, "nodef_dep.npy")).astype(np.float32),
+                 nodef_gray=np.load(os.path.join(d, "nodef_gray.npy")).astype(np.float32),
+                 border_mask=np.load(os.path.join(d, "border_mask.npy")).astype(np.uint8))
+
+
+def stimuli():
+    v, t = load_mesh(os.path.join(REF, "rl_env_assets/exploration/edge_follow/edge_stimuli/long_edge_flat/long_edge.obj"))
+    save(os.path.join(OUT, "stimuli", "long_edge.npz"), verts=v.astype(np.float32), tris=t.astype(np.int32))
+    # short_edge.urdf re-uses long_edge.obj with a mesh scale; read it from the URDF
+    links, _ = parse_urdf(os.path.join(REF, "rl_env_assets/exploration/edge_follow/edge_stimuli/long_edge_flat/short_edge.urdf"))
+    g = next(iter(links.values())).visuals[0]
+    save(os.path.join(OUT, "stimuli", "short_edge.npz"), verts=(v * np.asarray(g.scale)).astype(np.float32), tris=t.astype(np.int32))
+
+
+def golden_views():
+    """Visual meshes the in-sensor camera sees at rest, expressed in the sensor-body inertial frame."""
+    for arm, sensor, typ in (("ur5", "tactip", "standard"), ("ur5", "digit", "standard"), ("mg400", "digitac", "right_angle")):
+        urdf = os.path.join(REF, "robot_assets", arm, sensor, f"{arm}_with_{typ}_{sensor}.urdf")
+        links, joints = parse_urdf(urdf)
+        body, tip = f"{sensor}_body_link", f"{sensor}_tip_link"
+        jt = next(j for j in joints if j.child == tip and j.parent == body)
+        vb, tb = visual_meshes_of_link(urdf, body)           # body inertial frame
+        vt, tt = visual_meshes_of_link(urdf, tip)            # tip inertial frame
+        Lb, Lt = links[body], links[tip]
+        Rb, pb = rpy_to_mat(Lb.com_rpy), np.asarray(Lb.com_xyz)
+        Rt, pt = rpy_to_mat(Lt.com_rpy), np.asarray(Lt.com_xyz)
+        Rj, pj = rpy_to_mat(jt.rpy), np.asarray(jt.xyz)
+        # tip inertial -> tip link -> body link -> body inertial
+        v = vt @ Rt.T + pt
+        v = v @ Rj.T + pj
+        v = (v - pb) @ Rb
+        save(os.path.join(GOLD, f"{sensor}_{typ}_view.npz"), tip_verts=v.astype(np.float32), tip_tris=tt.astype(np.int32),
+             body_verts=vb.astype(np.float32), body_tris=tb.astype(np.int32))
+
+
+if __name__ == "__main__":
+    robots()
+    sensors()
+    stimuli()
+    golden_views()

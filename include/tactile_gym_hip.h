@@ -165,6 +165,10 @@ int tg_jacobian_tcp(const tg_robot* robot, int32_t physics_dtype, int32_t n, con
 int tg_sim_ticks(const tg_robot* robot, int32_t physics_dtype, int32_t n, int32_t n_ticks, int32_t solver_iterations,
                  double dt, int32_t motor_mode, const double* q_des, const double* qd_des, double max_force, double* q,
                  double* qd);
+/* calculateInverseKinematics at the TCP frame (base_robot_arm.py:201-209, maxNumIterations=100, residualThreshold=1e-8):
+ * q0 [n][ndof] start, target_pos [n][3], target_rot [n][9] row-major -> q_out [n][ndof], iters [n] (nullable). */
+int tg_inverse_kinematics(const tg_robot* robot, int32_t physics_dtype, int32_t n, const double* q0, const double* target_pos,
+                          const double* target_rot, int32_t max_iters, double threshold, double* q_out, int32_t* iters);
 /* getCameraImage depth + t_s_camera (tactile_sensor.py:239-294) for n transforms [n][12] -> uint8 [n][h][w]. */
 int tg_render_tactile(const tg_sensor* sensor, const tg_mesh* mesh, int32_t n, const float* cam_from_obj, uint8_t* out);
 

@@ -296,11 +296,9 @@ static void rot_error(const double* Rt, const double* R, double* e) {
         for (int j = 0; j < 3; ++j) E[3 * i + j] = Rt[3 * i] * R[3 * j] + Rt[3 * i + 1] * R[3 * j + 1] + Rt[3 * i + 2] * R[3 * j + 2];
     double tr = E[0] + E[4] + E[8];
     double cosang = 0.5 * (tr - 1.0);
-    if (cosang > 1.0) cosang = 1.0;
-    if (cosang < -1.0) cosang = -1.0;
-    double ang = acos(cosang);
     double ax[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
-    double s = norm3(ax);
+    double s = norm3(ax);                      /* = 2 sin(angle) */
+    double ang = atan2(0.5 * s, cosang);       /* well conditioned for small angles (acos is not) */
     if (s < 1e-12) { e[0] = 0.5 * ax[0]; e[1] = 0.5 * ax[1]; e[2] = 0.5 * ax[2]; return; }
     for (int c = 0; c < 3; ++c) e[c] = ax[c] / s * ang;
 }

@@ -101,6 +101,8 @@ SYMBOLS = {
     "tg_jacobian_tcp": (C.c_int, [C.POINTER(TgRobot), C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
     "tg_sim_ticks": (C.c_int, [C.POINTER(TgRobot), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _dp,
                                C.c_double, _dp, _dp]),
+    "tg_inverse_kinematics": (C.c_int, [C.POINTER(TgRobot), C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int32, C.c_double, _dp,
+                                        C.POINTER(C.c_int32)]),
     "tg_render_tactile": (C.c_int, [C.POINTER(TgSensor), C.POINTER(TgMesh), C.c_int32, _fp, _u8p]),
 }
 
@@ -111,6 +113,28 @@ class TactileGymHipError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64; a process must not end up with two HIP runtimes (torch then
+    reports "No HIP GPUs are available").  Load torch's copy first (without importing torch) so this library binds to
+    the same runtime whichever is imported first; with no torch installed the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.isfile(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libtactile_gym_hip.so; raise with build instructions if it has not been built."""
     global _lib
@@ -119,6 +143,7 @@ def lib():
             raise TactileGymHipError(
                 f"{LIB_PATH} is missing.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
                 f"`tactile_gym_amd/csrc/build.sh` (hipcc, --offload-arch=gfx950).  There is no CPU fallback for the env step.")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch

@@ -55,9 +55,11 @@ __host__ __device__ inline uint64_t mix64(uint64_t z) {
 }
 constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
 __device__ inline double rng_uniform(uint64_t& s, double lo, double hi) {
+#pragma clang fp contract(off)   // lo + (hi - lo) * u must round like the host's two-step evaluation (no FMA)
     s += kGolden;
     const double u = (double)(mix64(s) >> 11) * (1.0 / 9007199254740992.0);
-    return lo + (hi - lo) * u;
+    const double span = (hi - lo) * u;
+    return lo + span;
 }
 
 // World pose of the TCP frame -> work-frame position / rpy, following the reference's chain of PyBullet helpers
@@ -213,13 +215,54 @@ template <typename T> __device__ __forceinline__ V3<T> rot_error(const M3<T>& Rt
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) E.m[3 * i + j] = Rt.m[3 * i] * R.m[3 * j] + Rt.m[3 * i + 1] * R.m[3 * j + 1] + Rt.m[3 * i + 2] * R.m[3 * j + 2];
-    T cosang = T(0.5) * (E.m[0] + E.m[4] + E.m[8] - T(1));
-    cosang = cosang > T(1) ? T(1) : (cosang < T(-1) ? T(-1) : cosang);
-    const T ang = tacos(cosang);
+    const T cosang = T(0.5) * (E.m[0] + E.m[4] + E.m[8] - T(1));
     const V3<T> ax{E.m[7] - E.m[5], E.m[2] - E.m[6], E.m[3] - E.m[1]};
-    const T s = norm(ax);
+    const T s = norm(ax);                         // = 2 sin(angle)
+    const T ang = tatan2(T(0.5) * s, cosang);     // well conditioned for small angles (acos is not)
     if (s < T(1e-12)) return T(0.5) * ax;
     return (ang / s) * ax;
+}
+
+// calculateInverseKinematics(TCP link, pos, orn, maxNumIterations, residualThreshold) (base_robot_arm.py:201-209):
+// damped least squares on the 6-D pose error, q updated in place from its starting value; returns iterations used.
+template <typename T, int TOPO>
+__device__ __forceinline__ int inverse_kinematics(const DevRobot<T>& m, V3<T> tpos, const M3<T>& Rt, T (&qik)[Topo<TOPO>::N], int max_iters,
+                                                  T threshold) {
+    constexpr int N = Topo<TOPO>::N;
+    int it = 0;
+    for (; it < max_iters; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, qik, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const V3<T> ep = tpos - p, er = rot_error(Rt, R);
+        T e[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
+        T res = T(0);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) res += e[d] * e[d];
+        if (tsqrt(res) <= threshold) break;
+        T J[6][N];
+        tcp_jacobian<T, TOPO>(m, k, p, J);
+        T A[6][6], y[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+                T acc = (r == cc) ? T(1e-8) : T(0);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc += J[r][i] * J[cc][i];
+                A[r][cc] = acc;
+            }
+        solve_pivoted<T, 6>(A, e, y);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc += J[r][i] * y[r];
+            qik[i] += acc;
+        }
+    }
+    return it;
 }
 
 // EdgeFollowEnv.reset (edge_follow_env.py:311-336): reset_task (:285-299), Robot.reset (robot.py:114-125) =
@@ -259,38 +302,7 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
     T qik[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qik[i] = q[i];
-    for (int it = 0; it < 100; ++it) {
-        Kin<T, TOPO> k;
-        forward_kinematics<T, TOPO>(m, qik, k);
-        V3<T> p; M3<T> R;
-        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
-        const V3<T> ep = tpos - p, er = rot_error(Rt, R);
-        T e[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
-        T res = T(0);
-#pragma unroll
-        for (int d = 0; d < 6; ++d) res += e[d] * e[d];
-        if (tsqrt(res) <= T(1e-8)) break;
-        T J[6][N];
-        tcp_jacobian<T, TOPO>(m, k, p, J);
-        T A[6][6], y[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                T acc = (r == cc) ? T(1e-8) : T(0);
-#pragma unroll
-                for (int i = 0; i < N; ++i) acc += J[r][i] * J[cc][i];
-                A[r][cc] = acc;
-            }
-        solve_pivoted<T, 6>(A, e, y);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            T acc = T(0);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc += J[r][i] * y[r];
-            qik[i] += acc;
-        }
-    }
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
 
     // blocking_move(max_steps=1000, constant_vel=0.001)
     T cv = T(0.001);
@@ -351,10 +363,10 @@ __global__ __launch_bounds__(64) void k_inverse_dynamics(const DevRobot<T>* __re
     constexpr int N = Topo<TOPO>::N;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    T qq[N], qv[N], hb[N], qdm[N], Minv[N][N];
+    T qq[N], qv[N], hb[N], qdm[N], Minv[N][N], trM;
 #pragma unroll
     for (int i = 0; i < N; ++i) { qq[i] = (T)q[s * N + i]; qv[i] = (T)qd[s * N + i]; }
-    dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv);
+    dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv, trM);
     // tau = M qdd + h ; M qdd obtained by solving Minv x = qdd would be circular, so rebuild M from Minv^-1 is avoided:
     // use linearity  ID(q, qd, qdd) = h + M qdd with M = inverse(Minv) computed by the pivoted solver column by column.
     T A[N][N], b[N], x[N];
@@ -374,10 +386,10 @@ __global__ __launch_bounds__(64) void k_mass_matrix(const DevRobot<T>* __restric
     constexpr int N = Topo<TOPO>::N;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
-    T qq[N], qv[N], hb[N], qdm[N], Minv[N][N];
+    T qq[N], qv[N], hb[N], qdm[N], Minv[N][N], trM;
 #pragma unroll
     for (int i = 0; i < N; ++i) { qq[i] = (T)q[s * N + i]; qv[i] = T(0); }
-    dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv);
+    dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv, trM);
 #pragma unroll
     for (int j = 0; j < N; ++j) {   // column j of M = solve(Minv, e_j)
         T A[N][N], b[N], x[N];
@@ -437,6 +449,24 @@ __global__ __launch_bounds__(64) void k_sim_ticks(const DevRobot<T>* __restrict_
     for (int i = 0; i < N; ++i) { q[s * N + i] = (double)qq[i]; qd[s * N + i] = (double)qv[i]; }
 }
 
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_ik(const DevRobot<T>* __restrict__ mp, int n, const double* q0, const double* tpos, const double* trot,
+                                           int max_iters, double threshold, double* q_out, int32_t* iters) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = (T)q0[s * N + i];
+    M3<T> Rt;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rt.m[e] = (T)trot[s * 9 + e];
+    const int it = inverse_kinematics<T, TOPO>(*mp, mk((T)tpos[s * 3], (T)tpos[s * 3 + 1], (T)tpos[s * 3 + 2]), Rt, q, max_iters, (T)threshold);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q_out[s * N + i] = (double)q[i];
+    iters[s] = it;
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 static void h_quat_from_euler(const double* rpy, double* q) {
     const double phi = 0.5 * rpy[0], the = 0.5 * rpy[1], psi = 0.5 * rpy[2];
@@ -483,6 +513,33 @@ template <typename T> static int build_dev_robot(const tg_robot& r, DevRobot<T>&
             const double dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
             for (int a = 0; a < 3; ++a)
                 for (int c = 0; c < 3; ++c) I[a][c] += mb * ((a == c ? dd : 0.0) - dv[a] * dv[c]);
+        }
+        // FK constants and the merged angular-damping inertia
+        {
+            const double* Rj = r.joint_rot[i];
+            const double* a = r.joint_axis[i];
+            const double aaT[9] = {a[0] * a[0], a[0] * a[1], a[0] * a[2], a[1] * a[0], a[1] * a[1], a[1] * a[2], a[2] * a[0], a[2] * a[1], a[2] * a[2]};
+            const double ax[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+            for (int rr = 0; rr < 3; ++rr)
+                for (int cc = 0; cc < 3; ++cc) {
+                    double sa = 0, sb = 0, sc = 0;
+                    for (int k = 0; k < 3; ++k) {
+                        sa += Rj[3 * rr + k] * aaT[3 * k + cc];
+                        sb += Rj[3 * rr + k] * ((k == cc ? 1.0 : 0.0) - aaT[3 * k + cc]);
+                        sc += Rj[3 * rr + k] * ax[3 * k + cc];
+                    }
+                    d.fkA[i][3 * rr + cc] = (T)sa; d.fkB[i][3 * rr + cc] = (T)sb; d.fkC[i][3 * rr + cc] = (T)sc;
+                }
+            double Ia[3][3] = {{0}};
+            for (int b = 0; b < TG_MAX_BODIES_PER_LINK; ++b) {
+                if (r.body_mass[i][b] <= 0) continue;
+                const double* R = r.body_rot[i][b];
+                for (int aa = 0; aa < 3; ++aa)
+                    for (int c = 0; c < 3; ++c)
+                        for (int k = 0; k < 3; ++k) Ia[aa][c] += R[3 * aa + k] * r.body_inertia[i][b][k] * R[3 * c + k];
+            }
+            d.lang[i][0] = (T)Ia[0][0]; d.lang[i][1] = (T)Ia[0][1]; d.lang[i][2] = (T)Ia[0][2];
+            d.lang[i][3] = (T)Ia[1][1]; d.lang[i][4] = (T)Ia[1][2]; d.lang[i][5] = (T)Ia[2][2];
         }
         d.lmass[i] = (T)m;
         for (int k = 0; k < 3; ++k) d.lcom[i][k] = (T)com[k];
@@ -957,6 +1014,24 @@ int tg_sim_ticks(const tg_robot* robot, int32_t dtype, int32_t n, int32_t n_tick
     TG_FN_DISPATCH(robot, dtype, k_sim_ticks, n, n, n_ticks, iters, dt, motor_mode, q_des ? (const double*)c.p : (const double*)nullptr,
                    qd_des ? (const double*)d.p : (const double*)nullptr, max_force, (double*)a.p, (double*)b.p);
     TG_HIP(hipMemcpy(q, a.p, bytes, hipMemcpyDeviceToHost)); TG_HIP(hipMemcpy(qd, b.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tg_inverse_kinematics(const tg_robot* robot, int32_t dtype, int32_t n, const double* q0, const double* target_pos, const double* target_rot,
+                          int32_t max_iters, double threshold, double* q_out, int32_t* iters) {
+    if (int rc = check_robot(robot)) return rc;
+    if (int rc = need_device()) return rc;
+    const int nd = robot->ndof;
+    DevBuf a, b, c, d, e;
+    if (a.alloc((size_t)n * nd * 8) || b.alloc((size_t)n * 24) || c.alloc((size_t)n * 72) || d.alloc((size_t)n * nd * 8) || e.alloc((size_t)n * 4))
+        return fail(-2, "hipMalloc failed");
+    TG_HIP(hipMemcpy(a.p, q0, (size_t)n * nd * 8, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(b.p, target_pos, (size_t)n * 24, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(c.p, target_rot, (size_t)n * 72, hipMemcpyHostToDevice));
+    TG_FN_DISPATCH(robot, dtype, k_ik, n, n, (const double*)a.p, (const double*)b.p, (const double*)c.p, max_iters, threshold, (double*)d.p,
+                   (int32_t*)e.p);
+    TG_HIP(hipMemcpy(q_out, d.p, (size_t)n * nd * 8, hipMemcpyDeviceToHost));
+    if (iters) TG_HIP(hipMemcpy(iters, e.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -47,6 +47,9 @@ template <int TOPO> __host__ __device__ constexpr bool is_ancestor_or_self(int a
 // ------------------------------------------------------------------------------------------------ device constants
 template <typename T> struct DevRobot {
     T jpos[kMaxDof][3], jrot[kMaxDof][9], jaxis[kMaxDof][3];
+    // Rj Rot(axis, q) = fkA + cos(q) fkB + sin(q) fkC  with  fkA = Rj a a^T, fkB = Rj (I - a a^T), fkC = Rj [a]x
+    T fkA[kMaxDof][9], fkB[kMaxDof][9], fkC[kMaxDof][9];
+    T lang[kMaxDof][6];                                          // sum_b R_b diag(I_b) R_b^T per link (angular damping), link frame
     T lmass[kMaxDof], lcom[kMaxDof][3], linert[kMaxDof][6];       // merged per-link inertia about lcom, link frame (xx,xy,xz,yy,yz,zz)
     T bmass[kMaxDof][kMaxBodiesPerLink], bcom[kMaxDof][kMaxBodiesPerLink][3], brot[kMaxDof][kMaxBodiesPerLink][9],
         binert[kMaxDof][kMaxBodiesPerLink][3];                     // individual bodies (velocity damping is per body)
@@ -157,13 +160,16 @@ template <typename T, int TOPO> __device__ __forceinline__ void forward_kinemati
     for (int i = 0; i < N; ++i) {
         const int p = Topo<TOPO>::parent(i);
         const V3<T> ax = load_v3(m.jaxis[i]);
-        const M3<T> Rq = axis_angle(ax, q[i]);
-        const M3<T> Rj = load_m3(m.jrot[i]);
+        T sq, cq;
+        tsincos(q[i], &sq, &cq);
+        M3<T> Rl;   // Rj * Rot(axis, q)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Rl.m[e] = m.fkA[i][e] + cq * m.fkB[i][e] + sq * m.fkC[i][e];
         if (p < 0) {
-            k.R[i] = mul(Rj, Rq);
+            k.R[i] = Rl;
             k.o[i] = load_v3(m.jpos[i]);
         } else {
-            k.R[i] = mul(mul(k.R[p], Rj), Rq);
+            k.R[i] = mul(k.R[p], Rl);
             k.o[i] = k.o[p] + mul(k.R[p], load_v3(m.jpos[i]));
         }
         k.a[i] = mul(k.R[i], ax);
@@ -191,7 +197,7 @@ template <typename T, int TOPO> __device__ __forceinline__ void link_frame(const
 template <typename T, int TOPO>
 __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], const T (&qd)[Topo<TOPO>::N],
                                                T (&hbias)[Topo<TOPO>::N], T (&qdamp)[Topo<TOPO>::N],
-                                               T (&Minv)[Topo<TOPO>::N][Topo<TOPO>::N]) {
+                                               T (&Minv)[Topo<TOPO>::N][Topo<TOPO>::N], T& traceM) {
     constexpr int N = Topo<TOPO>::N;
     Kin<T, TOPO> k;
     forward_kinematics<T, TOPO>(m, q, k);
@@ -229,10 +235,12 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
         mc[i] = m.lmass[i];
         hc[i] = m.lmass[i] * rc;
         Io[i] = Iw + point_inertia(m.lmass[i], rc);
-        // per-body velocity damping  F = -m v (K + K|v|),  N = -(I w)(K + K|w|)
-        V3<T> dF = mk<T>(0, 0, 0), dN = mk<T>(0, 0, 0);
-        const T wn = norm(w[i]);
-        const T sw = m.ang_damp + m.ang_damp * wn;
+        // per-body velocity damping  F = -m v (K + K|v|),  N = -(I w)(K + K|w|).  |w| is common to the bodies welded to a
+        // link, so their angular parts are merged exactly through lang = sum_b R_b I_b R_b^T; |v| differs per body.
+        const T sw = m.ang_damp + m.ang_damp * norm(w[i]);
+        const S3<T> Ia{m.lang[i][0], m.lang[i][1], m.lang[i][2], m.lang[i][3], m.lang[i][4], m.lang[i][5]};
+        V3<T> dF = mk<T>(0, 0, 0);
+        V3<T> dN = (-sw) * mul(k.R[i], mul(Ia, mulT(k.R[i], w[i])));
 #pragma unroll
         for (int b = 0; b < kMaxBodiesPerLink; ++b) {
             if (m.bmass[i][b] > T(0)) {  // wave-uniform
@@ -240,12 +248,8 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
                 const V3<T> vb = vo[i] + cross(w[i], rb);
                 const T sv = m.lin_damp + m.lin_damp * norm(vb);
                 const V3<T> Fb = (-m.bmass[i][b] * sv) * vb;
-                const M3<T> Rb = mul(k.R[i], load_m3(m.brot[i][b]));
-                const V3<T> wl = mulT(Rb, w[i]);
-                const V3<T> Iwl{m.binert[i][b][0] * wl.x, m.binert[i][b][1] * wl.y, m.binert[i][b][2] * wl.z};
-                const V3<T> Nb = (-sw) * mul(Rb, Iwl);
                 dF = dF + Fb;
-                dN = dN + Nb + cross(rb, Fb);
+                dN = dN + cross(rb, Fb);
             }
         }
         DF[i] = dF;
@@ -270,17 +274,19 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
     }
     // joint-space inertia, lower triangle
     T L[N][N];
+    traceM = T(0);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const V3<T> F = cross(k.a[j], hc[j]);
         const V3<T> Nj = mul(Io[j], k.a[j]);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            if (i == j) L[j][j] = dot(k.a[j], Nj);
+            if (i == j) { L[j][j] = dot(k.a[j], Nj); traceM += L[j][j]; }
             else if (i < j) L[j][i] = is_ancestor_or_self<TOPO>(i, j) ? dot(k.a[i], Nj + cross(k.o[j] - k.o[i], F)) : T(0);
         }
     }
-    // in-place Cholesky  M = L L^T
+    // in-place Cholesky  M = L L^T  (Li = L^-1 shares the pivots' reciprocals)
+    T Li[N][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         T d = L[j][j];
@@ -289,6 +295,7 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
         d = tsqrt(d);
         L[j][j] = d;
         const T inv = T(1) / d;
+        Li[j][j] = inv;
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             T s = L[i][j];
@@ -298,16 +305,14 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
         }
     }
     // Linv (lower), then Minv = Linv^T Linv
-    T Li[N][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        Li[j][j] = T(1) / L[j][j];
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             T s = T(0);
 #pragma unroll
             for (int c = j; c < i; ++c) s -= L[i][c] * Li[c][j];
-            Li[i][j] = s / L[i][i];
+            Li[i][j] = s * Li[i][i];
         }
     }
 #pragma unroll
@@ -320,6 +325,81 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
             Minv[i][j] = s;
             Minv[j][i] = s;
         }
+}
+
+// Projected Gauss-Seidel over the joint-motor rows (btMultiBodyJointMotor rows solved by
+// btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric [PARITY_ASSUMPTIONS A7]):
+//   delta = rhs_i - (J_i . dv) jacDiagABInv_i ;  sum = lambda_i + delta ; clamp sum to +-maxImpulse ;  dv += Minv[:, i] delta
+// `iters` sweeps, reverse row order on even sweeps, forward on odd.
+//
+// Bullet leaves the loop after a sweep whose largest squared delta is exactly 0.  Such a sweep leaves (lambda, dv)
+// untouched, so every later sweep recomputes delta = 0 and changes nothing either: running all `iters` sweeps gives
+// bit-identical results, and the exit test (a max-reduction on the serial path plus a divergent branch that only pays
+// once all 64 lanes have converged, which measured practically never happens before sweep 150) is dropped here.
+//
+// pgs_unclamped is used when no row can reach its impulse limit.  Each row update minimises the energy
+// E = 1/2 (l - l*)^T A (l - l*), A = J Minv J^T = Minv, exactly along one coordinate, so E never grows from l = 0:
+//   |l_i| <= ||l||_2 <= 2 ||l*||_A / sqrt(sigma_min(A)) <= 2 sigma_max(M) ||dv*||_2 <= 2 trace(M) ||dv*||_2
+// (dv* = requested velocity change).  The caller checks 2 trace(M) ||dv*||_2 < maxImpulse / 2 per lane; otherwise the
+// wavefront takes pgs_clamped, which evaluates the identical expressions plus the clamp as branch-free selects.
+// Unclamped sweeps are carried in residual form: r_j = rhs_j - dv_j jdi_j is updated directly,
+//   row i:  t = r_i ;  r_j -= (Minv[j][i] jdi_j) t  for all j      (6 FMAs per row, one-FMA serial chain)
+// which is the same Gauss-Seidel recurrence as above with dv eliminated; dv is recovered once at the end.
+template <typename T, int N, bool FWD>
+__device__ __forceinline__ void pgs_sweep_unclamped(const T (&G)[N][N], T (&r)[N]) {
+#pragma unroll
+    for (int jj = 0; jj < N; ++jj) {
+        const int i = FWD ? jj : N - 1 - jj;
+        const T t = r[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) r[j] -= G[j][i] * t;
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void pgs_unclamped(const T (&Minv)[N][N], const T (&rimp)[N], const T (&jdi)[N], int iters, T (&dv)[N]) {
+    T G[N][N], r[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        r[j] = rimp[j];
+#pragma unroll
+        for (int i = 0; i < N; ++i) G[j][i] = Minv[j][i] * jdi[j];
+    }
+    int it = 0;
+    for (; it + 1 < iters; it += 2) {
+        pgs_sweep_unclamped<T, N, false>(G, r);
+        pgs_sweep_unclamped<T, N, true>(G, r);
+    }
+    if (it < iters) pgs_sweep_unclamped<T, N, false>(G, r);
+#pragma unroll
+    for (int j = 0; j < N; ++j) dv[j] = (rimp[j] - r[j]) * Minv[j][j];
+}
+template <typename T, int N, bool FWD>
+__device__ __forceinline__ void pgs_sweep_clamped(const T (&Minv)[N][N], const T (&rimp)[N], const T (&jdi)[N], T maximp, T (&lam)[N],
+                                                  T (&dv)[N]) {
+#pragma unroll
+    for (int jj = 0; jj < N; ++jj) {
+        const int i = FWD ? jj : N - 1 - jj;
+        const T t = rimp[i] - dv[i] * jdi[i];
+        const T sum = lam[i] + t;
+        const T lo = sum < -maximp ? -maximp : sum;
+        const T sc = lo > maximp ? maximp : lo;
+        const T delta = (sc == sum) ? t : sc - lam[i];   // branch-free select: the unclamped case keeps t exactly
+        lam[i] = sc;
+#pragma unroll
+        for (int r = 0; r < N; ++r) dv[r] += Minv[r][i] * delta;
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void pgs_clamped(const T (&Minv)[N][N], const T (&rimp)[N], const T (&jdi)[N], T maximp, int iters, T (&dv)[N]) {
+    T lam[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { lam[i] = T(0); dv[i] = T(0); }
+    int it = 0;
+    for (; it + 1 < iters; it += 2) {
+        pgs_sweep_clamped<T, N, false>(Minv, rimp, jdi, maximp, lam, dv);
+        pgs_sweep_clamped<T, N, true>(Minv, rimp, jdi, maximp, lam, dv);
+    }
+    if (it < iters) pgs_sweep_clamped<T, N, false>(Minv, rimp, jdi, maximp, lam, dv);
 }
 
 enum { kMotorOff = 0, kMotorVelocity = 1, kMotorPosition = 2 };
@@ -336,8 +416,11 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
                                          const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                          int iters, bool gravity_comp) {
     constexpr int N = Topo<TOPO>::N;
-    T hb[N], qdm[N], Minv[N][N];
-    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv);
+    // Compiler barrier: without it the ~250 scalar robot constants are hoisted out of the caller's tick loop, overflow the
+    // 100 SGPRs and get spilled into VGPR lanes (v_readlane per use).  Re-issuing the s_loads every tick is cheaper.
+    asm volatile("" ::: "memory");
+    T hb[N], qdm[N], Minv[N][N], traceM;
+    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv, traceM);
     T rhs[N], v[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -352,48 +435,20 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
         v[i] = qd[i] + dt * acc;
     }
     if (MOTOR != kMotorOff) {
-        T rimp[N], jdi[N], lam[N], dv[N];
+        T rimp[N], jdi[N], dv[N];
         const T maximp = max_force * dt;
+        T dv2 = T(0);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const T pos_term = (MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0);
             const T des = pos_term + v[i] + kd * (qd_des[i] - v[i]);
             jdi[i] = T(1) / Minv[i][i];
             rimp[i] = (des - v[i]) * jdi[i];
-            lam[i] = T(0);
-            dv[i] = T(0);
+            dv2 += (des - v[i]) * (des - v[i]);
         }
-        for (int it = 0; it < iters; ++it) {
-            T residual = T(0);
-            if (it & 1) {
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    T delta = rimp[i] - dv[i] * jdi[i];
-                    const T sum = lam[i] + delta;
-                    if (sum < -maximp) { delta = -maximp - lam[i]; lam[i] = -maximp; }
-                    else if (sum > maximp) { delta = maximp - lam[i]; lam[i] = maximp; }
-                    else lam[i] = sum;
-#pragma unroll
-                    for (int r = 0; r < N; ++r) dv[r] += Minv[r][i] * delta;
-                    const T d2 = delta * delta;
-                    residual = d2 > residual ? d2 : residual;
-                }
-            } else {
-#pragma unroll
-                for (int i = N - 1; i >= 0; --i) {
-                    T delta = rimp[i] - dv[i] * jdi[i];
-                    const T sum = lam[i] + delta;
-                    if (sum < -maximp) { delta = -maximp - lam[i]; lam[i] = -maximp; }
-                    else if (sum > maximp) { delta = maximp - lam[i]; lam[i] = maximp; }
-                    else lam[i] = sum;
-#pragma unroll
-                    for (int r = 0; r < N; ++r) dv[r] += Minv[r][i] * delta;
-                    const T d2 = delta * delta;
-                    residual = d2 > residual ? d2 : residual;
-                }
-            }
-            if (residual <= T(0)) break;
-        }
+        const bool no_clamp_possible = T(4) * traceM * tsqrt(dv2) < maximp;   // 2 trace(M) ||dv*|| < maxImpulse / 2
+        if (__all(no_clamp_possible)) pgs_unclamped<T, N>(Minv, rimp, jdi, iters, dv);
+        else pgs_clamped<T, N>(Minv, rimp, jdi, maximp, iters, dv);
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] += dv[i];
     }

@@ -62,6 +62,19 @@ def sim_ticks(robot, q, qd, n_ticks, motor_mode, q_des=None, qd_des=None, max_fo
     return q, qd
 
 
+def inverse_kinematics(robot, q0, target_pos, target_rot, max_iters=100, threshold=1e-8, dtype="f64"):
+    """calculateInverseKinematics at the TCP frame (base_robot_arm.py:201-209); returns (q [n,ndof], iterations [n])."""
+    q0 = np.atleast_2d(np.asarray(q0, dtype=np.float64))
+    n, nd = q0.shape
+    q0 = _prep(q0, n, nd)
+    tp = np.ascontiguousarray(target_pos, dtype=np.float64).reshape(n, 3)
+    tr = np.ascontiguousarray(target_rot, dtype=np.float64).reshape(n, 9)
+    out, iters = np.zeros((n, nd)), np.zeros(n, dtype=np.int32)
+    capi.check(capi.lib().tg_inverse_kinematics(C.byref(robot), capi.PHYSICS[dtype], n, _dp(q0), _dp(tp), _dp(tr), int(max_iters),
+                                                float(threshold), _dp(out), iters.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out, iters
+
+
 def render_tactile(sensor_desc, mesh_desc, cam_from_obj):
     """getCameraImage depth + t_s_camera (tactile_sensor.py:239-294) for transforms [n,12] -> uint8 [n,H,W]."""
     xf = np.ascontiguousarray(cam_from_obj, dtype=np.float32).reshape(-1, 12)

@@ -169,7 +169,7 @@ def test_env_reset_and_steps_match_oracle(edge_modes, dtype, qtol, max_px):
             assert np.abs(st["qd_target"][i] - o.last_req_joint_vels).max() < max(qtol, 1e-9) * 100
             assert np.abs(st["q"][i] - o.arm.q).max() < qtol * 10, (step, i)
             assert np.abs(st["tcp_pos"][i] - o.cur_tcp_pos).max() < qtol * 10
-            assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
+            assert abs(rew[i] - rr) < (1e-5 if dtype == "f64" else 2e-4) and bool(done[i]) == rd
             assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= max_px, (step, i)
     venv.close()
 
@@ -247,3 +247,33 @@ def test_torch_zero_copy_and_device_actions(edge_modes):
     host = venv.tactile_numpy()
     assert np.array_equal(obs2["tactile"].cpu().numpy(), host)
     venv.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-11), ("f32", 5e-5)])
+def test_inverse_kinematics(ur5_tactip, dtype, tol):
+    """calculateInverseKinematics restatement (base_robot_arm.py:201-209): same root as the oracle, reached in the same
+    number of iterations (f64), residual below the reference's residualThreshold = 1e-8."""
+    from oracle import pb_math as pm
+    from tactile_gym_amd import hip_ops
+    tg, mk_arm, robot, rest = ur5_tactip
+    arm = mk_arm()
+    rng = np.random.default_rng(6)
+    n = 32
+    q_true = np.asarray(rest)[None] + 0.05 * rng.standard_normal((n, 6))
+    tps, trs, refs, its = [], [], [], []
+    for i in range(n):
+        p, quat, _, _, R = arm.link_state("tcp_link", q=q_true[i], qd=np.zeros(6))
+        arm.reset_joint_states(rest)
+        q = arm.q.copy()
+        from oracle import minibullet as mb
+        link, fpos, frot = tg.frames["tcp_link"]
+        it = arm.L.mb_ik(mb.C.byref(arm.model), link, mb._dp(np.ascontiguousarray(fpos)), mb._dp(np.ascontiguousarray(frot)),
+                         mb._dp(np.ascontiguousarray(p)), mb._dp(np.ascontiguousarray(R.reshape(9))), mb._dp(q), 100, 1e-8)
+        tps.append(p); trs.append(R); refs.append(q); its.append(it)
+    q, iters = hip_ops.inverse_kinematics(robot, np.tile(rest, (n, 1)), np.array(tps), np.array(trs), dtype=dtype)
+    assert np.abs(q - np.array(refs)).max() < tol
+    if dtype == "f64":
+        assert np.array_equal(iters, np.array(its)) and iters.max() < 12
+        for i in range(n):
+            p, _, _, _, R = arm.link_state("tcp_link", q=q[i], qd=np.zeros(6))
+            assert np.abs(p - tps[i]).max() < 1e-8 and np.abs(R - trs[i]).max() < 1e-8

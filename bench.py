@@ -92,8 +92,10 @@ def main():
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
 
-    def actions():
-        return (torch.rand(n, 2, device="cuda", generator=gen) - 0.5) * 0.5
+    act_buf = torch.empty(n, 2, device="cuda", dtype=torch.float32)
+
+    def actions():   # action_space.sample() for the whole batch: U(-0.25, 0.25), one device kernel
+        return act_buf.uniform_(-0.25, 0.25, generator=gen)
 
     def barrier():
         torch.cuda.synchronize()
@@ -104,13 +106,18 @@ def main():
     env.reset()
     for _ in range(args.warmup):
         env.step(actions())
-    venv.profile(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         env.step(actions())
     barrier()
     dt = time.perf_counter() - t0
+    # per-kernel durations for the roofline leg: HIP events on the launch stream, outside the timed region
+    # (event records add ~2 x 4 launches of host work per step)
+    venv.profile(True)
+    for _ in range(min(args.steps, 50)):
+        env.step(actions())
+    barrier()
     prof = venv.profile_get()
     venv.profile(False)
     if dist is not None:
@@ -141,7 +148,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "kernel_ms": {"k_step": round(k_step, 4), "k_render_tactile": round(k_render_main, 4),
-                                       "k_reset_per_launch": round(rst_ms / max(rst_n, 1), 4)},
+                                       "k_reset_per_launch": round(rst_ms / max(rst_n, 1), 4),
+                                       "k_render_tactile_masked": round(prof["render_masked"][0] / max(prof["render_masked"][1], 1), 4)},
                          "launches": {"k_step": step_n, "k_render_tactile": rend_n, "k_reset": rst_n},
                          "note": "latency-bound by construction: 24 x 150 serial Gauss-Seidel sweeps per env step (BASELINE.md section 3)"},
             "resets_in_timed_region": bool((args.warmup % 200) + args.steps >= 200),

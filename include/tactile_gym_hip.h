@@ -147,7 +147,8 @@ int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */
 int tg_set_joint_state(tg_ctx* ctx, const double* q, const double* qd);
 
-/* Per-kernel timing with HIP events on the launch stream (bench.py roofline leg). which: 0 step, 1 render, 2 reset. */
+/* Per-kernel timing with HIP events on the launch stream (bench.py roofline leg). which: 0 step, 1 render (all envs),
+ * 2 reset, 3 render (masked: reset / auto-reset envs only). */
 int tg_profile_enable(tg_ctx* ctx, int32_t enable);
 int tg_profile_get(tg_ctx* ctx, int32_t which, double* total_ms, int64_t* launches);
 

@@ -623,8 +623,8 @@ struct tg_ctx {
     bool profile = false;
     struct Ev { hipEvent_t a, b; int which; };
     std::vector<Ev> events;
-    double prof_ms[3] = {0, 0, 0};
-    int64_t prof_n[3] = {0, 0, 0};
+    double prof_ms[4] = {0, 0, 0, 0};
+    int64_t prof_n[4] = {0, 0, 0, 0};
 };
 
 namespace tg {
@@ -677,7 +677,7 @@ template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
     } while (0)
 
 static void render(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
-    Timer t(c, 1);
+    Timer t(c, d_mask ? 3 : 1);
     launch_render(c->rp, c->d_verts, c->d_tris, c->n_tris, c->st.stim_xform, 1, c->cfg.num_envs, d_mask, c->d_nodef_dep, c->d_nodef_gray,
                   c->d_border, c->d_obs, save_prev ? c->d_term : nullptr, c->stream);
 }
@@ -785,7 +785,7 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&c->d_term, npix * n)); TG_HIP(hipMemset(c->d_term, 0, npix * n));
     TG_HIP(hipMalloc(&c->d_mask, n));
     TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 4 * sizeof(float)));
-    c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border);
+    c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border, sensor->nodef_dep);
     *out = c;
     return 0;
 }
@@ -933,11 +933,11 @@ int tg_profile_enable(tg_ctx* c, int32_t enable) {
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
     c->profile = enable != 0;
-    for (int k = 0; k < 3; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    for (int k = 0; k < 4; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     return 0;
 }
 int tg_profile_get(tg_ctx* c, int32_t which, double* total_ms, int64_t* launches) {
-    if (!c || which < 0 || which > 2) return fail(-1, "bad argument");
+    if (!c || which < 0 || which > 3) return fail(-1, "bad argument");
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
     if (total_ms) *total_ms = c->prof_ms[which];
@@ -1051,7 +1051,7 @@ int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, cons
     TG_HIP(hipMemcpy(tt.p, mesh->tris, (size_t)mesh->n_tris * 12, hipMemcpyHostToDevice));
     TG_HIP(hipMemcpy(xx.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
     TG_HIP(hipMemset(oo.p, 0, npix * n));
-    RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border);
+    RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
     launch_render(P, (const float*)vv.p, (const int32_t*)tt.p, mesh->n_tris, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p,
                   (const float*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
     TG_HIP(hipDeviceSynchronize());

@@ -12,10 +12,11 @@ namespace tg {
 struct RasterParams {
     int W, H;
     float kx, ky, hw, hh, C0, C1, near_;
+    float zcull;   // max of the undeformed depth image: triangles entirely behind it can never win the z-test
     int turn_off_border;
 };
 
-RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border);
+RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border, const float* nodef_dep_host);
 
 void launch_render(const RasterParams& P, const float* verts, const int32_t* tris, int n_tris, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const float* nodef_gray, const uint8_t* border, uint8_t* out,

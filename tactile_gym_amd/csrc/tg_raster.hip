@@ -26,13 +26,18 @@ namespace tg {
 
 struct TriRec {      // projected triangle, window coordinates + depth
     float x0, y0, d0, x1, y1, d1, x2, y2, d2;
-    float ymin, ymax, xmin, xmax;
+    float ymin, ymax, xmin, xmax, dmin;
 };
+
+// Depth culling margin.  The interpolated depth ((e0 d0 + e1 d1) + e2 d2) / s has same-signed weights, so it lies within
+// ~6 roundings (< 4e-7 for d <= 1.01) of the convex hull [min d_k, max d_k]; a triangle whose min d_k exceeds a z value
+// by more than kDepthSlack can therefore never pass `d < z` there.  Skipping it does not change the image.
+constexpr float kDepthSlack = 2e-6f;
 
 constexpr int kThreads = 256;
 constexpr int kBatch = 1024;         // triangle records staged in LDS per pass (52 KB)
 
-RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border) {
+RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border, const float* nodef_dep_host) {
     RasterParams P;
     const double ys = 1.0 / tan(0.5 * fov_deg * (3.14159265358979323846 / 180.0));
     P.W = W; P.H = H;
@@ -42,6 +47,8 @@ RasterParams make_raster_params(int W, int H, double fov_deg, double near_, doub
     P.C1 = (float)(-(near_ * far_) / (far_ - near_));
     P.near_ = (float)near_;
     P.turn_off_border = turn_off_border;
+    P.zcull = 0.0f;
+    for (int i = 0; i < W * H; ++i) P.zcull = nodef_dep_host[i] > P.zcull ? nodef_dep_host[i] : P.zcull;
     return P;
 }
 
@@ -60,8 +67,10 @@ __device__ __forceinline__ void emit(TriRec* recs, int* count, const float* vx, 
     project_vertex(vx[c], vy[c], vw[c], P, r.x2, r.y2, r.d2);
     r.xmin = fminf(r.x0, fminf(r.x1, r.x2)); r.xmax = fmaxf(r.x0, fmaxf(r.x1, r.x2));
     r.ymin = fminf(r.y0, fminf(r.y1, r.y2)); r.ymax = fmaxf(r.y0, fmaxf(r.y1, r.y2));
-    // conservative cull against this workgroup's tile (coverage itself is decided per pixel)
+    r.dmin = fminf(r.d0, fminf(r.d1, r.d2)) - kDepthSlack;
+    // conservative culls: outside this workgroup's tile, or entirely behind the undeformed skin/body depth image
     if (r.xmax < tx0 || r.xmin > tx1 || r.ymax < ty0 || r.ymin > ty1) return;
+    if (r.dmin >= P.zcull) return;
     int slot = atomicAdd(count, 1);
     recs[slot] = r;
 }
@@ -144,6 +153,8 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, con
             for (int k = 0; k < NK; ++k) {
                 const float fy = (float)(ry + RPP * k) + 0.5f;
                 if (fy < r.ymin || fy > r.ymax) continue;
+                if ((float)qx + 3.5f < r.xmin || (float)qx + 0.5f > r.xmax) continue;
+                if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
                 const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {

@@ -61,7 +61,7 @@ class TactileVecEnv:
         self._obs_host = np.zeros((self.num_envs, self.H, self.W, 1), dtype=np.uint8)
         self._term_host = None
         self._closed = False
-        self._torch_obs = None
+        self._views = {}
         if seed is not None:
             self.seed(seed)
 
@@ -167,17 +167,22 @@ class TactileVecEnv:
 
     def tactile_torch(self, terminal=False):
         """Zero-copy torch.uint8 [N,H,W,1] view of the device observation buffer."""
-        import torch
-        arr = _DevArray(self.tactile_device_ptr(terminal), (self.num_envs, self.H, self.W, 1), "|u1")
-        return torch.as_tensor(arr, device=f"cuda:{self._cfg.device}")
+        key = "term" if terminal else "obs"
+        if key not in self._views:   # the library's buffers never move: build each aliasing tensor once
+            import torch
+            arr = _DevArray(self.tactile_device_ptr(terminal), (self.num_envs, self.H, self.W, 1), "|u1")
+            self._views[key] = torch.as_tensor(arr, device=f"cuda:{self._cfg.device}")
+        return self._views[key]
 
     def reward_done_torch(self):
-        import torch
-        r, d = C.c_void_p(), C.c_void_p()
-        capi.check(self._L.tg_get_reward_done_dev(self._ctx, C.byref(r), C.byref(d)))
-        dev = f"cuda:{self._cfg.device}"
-        return (torch.as_tensor(_DevArray(r.value, (self.num_envs,), "<f4"), device=dev),
-                torch.as_tensor(_DevArray(d.value, (self.num_envs,), "|u1"), device=dev))
+        if "rd" not in self._views:
+            import torch
+            r, d = C.c_void_p(), C.c_void_p()
+            capi.check(self._L.tg_get_reward_done_dev(self._ctx, C.byref(r), C.byref(d)))
+            dev = f"cuda:{self._cfg.device}"
+            self._views["rd"] = (torch.as_tensor(_DevArray(r.value, (self.num_envs,), "<f4"), device=dev),
+                                 torch.as_tensor(_DevArray(d.value, (self.num_envs,), "|u1"), device=dev))
+        return self._views["rd"]
 
     def tactile_numpy(self, terminal=False):
         buf = self._obs_host if not terminal else np.zeros_like(self._obs_host)
@@ -229,7 +234,7 @@ class TactileVecEnv:
 
     def profile_get(self):
         out = {}
-        for which, name in enumerate(("step", "render", "reset")):
+        for which, name in enumerate(("step", "render", "reset", "render_masked")):
             ms, cnt = C.c_double(), C.c_int64()
             capi.check(self._L.tg_profile_get(self._ctx, which, C.byref(ms), C.byref(cnt)))
             out[name] = (ms.value, cnt.value)

@@ -153,3 +153,27 @@ def test_oracle_env_contact_patch_tracks_embed_depth():
         peaks.append(int(img[inner].max()))
         assert abs(env.cur_tcp_pos[2] - (0.035 - embed)) < 2.5e-4   # blocking_move tolerance pos_tol = 2e-4 (robot.py:192)
     assert areas[0] < areas[1] < areas[2] and peaks[0] < peaks[1] < peaks[2]
+
+
+@pytest.mark.parametrize("name,typ", [("digit", "standard"), ("digitac", "right_angle")])
+def test_digit_digitac_nodef_depth_fixture_full_image(name, typ):
+    """DIGIT / DigiTac: the body and gel meshes are in the reference tree, so the *whole* committed nodef_dep.npy is
+    reproduced (every pixel, max |d| < 2e-5).  These sensors are asymmetric, so this also pins the image orientation
+    (any flip/transpose fails below), the inertial-frame convention of getLinkState for the sensor body
+    (tactile_sensor.py:153-155; the body link has a COM offset) and the strtod-style reading of the malformed URDF
+    numbers (PARITY_ASSUMPTIONS A9)."""
+    from oracle import minibullet as mb
+    from oracle.ref_env import sensor_camera
+    from tactile_gym_amd.urdf_compile import rpy_to_mat
+    g = np.load(os.path.join(GOLD, f"{name}_{typ}_view.npz"))
+    s = _sensor(name, typ, 128)
+    cam = sensor_camera(name, typ)
+    M = mb.cam_from_obj_matrix(cam["pos"], rpy_to_mat(cam["rpy"]), np.zeros(3), np.eye(3))
+    dep = np.ones((128, 128), np.float32)
+    mb.render_depth(g["tip_verts"], g["tip_tris"], M, cam["fov"], cam["near"], cam["far"], 128, 128, dep)
+    mb.render_depth(g["body_verts"], g["body_tris"], M, cam["fov"], cam["near"], cam["far"], 128, 128, dep)
+    err = np.abs(dep - s["nodef_dep"])
+    assert err.max() < 2e-5 and err.mean() < 3e-6
+    for flipped in (dep[:, ::-1], dep[::-1], dep.T):
+        assert np.abs(flipped - s["nodef_dep"]).mean() > 1e-3
+    assert s["border_mask"].sum() == 0            # DIGIT-family sensors have no border paste (SURVEY 8c)

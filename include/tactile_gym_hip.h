@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
 typedef struct {
@@ -67,8 +67,9 @@ typedef struct {
     const int32_t* tris;                    /* host, [n_tris][3] */
 } tg_mesh;
 
-enum { TG_ENV_EDGE_FOLLOW = 0 };
-enum { TG_MOVE_XY = 0, TG_MOVE_XYZ = 1, TG_MOVE_XYRZ = 2, TG_MOVE_XYZRZ = 3 };
+enum { TG_ENV_EDGE_FOLLOW = 0, TG_ENV_SURFACE_FOLLOW_AUTO = 1 };
+enum { TG_MOVE_XY = 0, TG_MOVE_XYZ = 1, TG_MOVE_XYRZ = 2, TG_MOVE_XYZRZ = 3 };            /* edge_follow_env.py:345-369 */
+enum { TG_SMOVE_YZ = 0, TG_SMOVE_XYZ = 1, TG_SMOVE_YZRX = 2, TG_SMOVE_XYZRXRY = 3 };       /* surface_follow_auto_env.py:27-57 */
 enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };
 enum { TG_REWARD_DENSE = 0, TG_REWARD_SPARSE = 1 };
 enum { TG_PHYSICS_F64 = 0, TG_PHYSICS_F32 = 1 };
@@ -94,6 +95,16 @@ typedef struct {
     double edge_height, edge_len;           /* :203-207 */
     double termination_dist;                /* :67 */
     double embed_dist, embed_lo, embed_hi;  /* :94-99, :291-298 */
+    /* surface_follow (base_surface_env.py:234-282): heightfield stimulus generated per episode from OpenSimplex noise.
+     * stim_pos = surface_pos; rows x cols grid of pitch surf_grid_scale; height = noise2(i*interp, j*interp) * range. */
+    int32_t surf_rows, surf_cols;           /* 64, 64 (:240-243) */
+    int32_t surf_center_z;                  /* 1: Bullet's heightfield shape is centred on (min+max)/2 [PARITY_ASSUMPTIONS A15] */
+    int32_t reserved0;
+    double surf_grid_scale;                 /* 0.006 (:238) */
+    double surf_height_range;               /* 0.025 (:239) */
+    double surf_interp;                     /* 0.05  (:244) */
+    double surf_xy_extent;                  /* 0.15  (:245) goal distance and TCP xy limits */
+    double auto_action_scale;               /* 1.0 tactip / 0.9 digitac / 0.7 digit (surface_follow_auto_env.py:33-41) */
 } tg_config;
 
 typedef struct tg_ctx tg_ctx;
@@ -142,6 +153,10 @@ typedef struct {
     int32_t* step_count;     /* [num_envs] */
     int32_t* reset_ticks;    /* [num_envs] sim ticks used by the last reset's blocking move */
     uint64_t* rng_state;     /* [num_envs] */
+    double*  goal_pos;       /* [num_envs][3] world (surface_follow) */
+    double*  direction;      /* [num_envs][2] work-frame auto-drive direction (surface_follow) */
+    double*  heights;        /* [num_envs][rows*cols] heightfield_data[row][col] (surface_follow) */
+    float*   surf_zoff;      /* [num_envs] vertical centring offset applied to the rendered heightfield */
 } tg_state_view;
 int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */
@@ -172,6 +187,13 @@ int tg_inverse_kinematics(const tg_robot* robot, int32_t physics_dtype, int32_t 
                           const double* target_rot, int32_t max_iters, double threshold, double* q_out, int32_t* iters);
 /* getCameraImage depth + t_s_camera (tactile_sensor.py:239-294) for n transforms [n][12] -> uint8 [n][h][w]. */
 int tg_render_tactile(const tg_sensor* sensor, const tg_mesh* mesh, int32_t n, const float* cam_from_obj, uint8_t* out);
+/* Same for a per-image heightfield stimulus (createCollisionShape(GEOM_HEIGHTFIELD), base_surface_env.py:402-432):
+ * heights [n][rows*cols] (double, heightfield_data[row][col]), zoff [n]. */
+int tg_render_tactile_heightfield(const tg_sensor* sensor, int32_t rows, int32_t cols, double grid_scale, int32_t n,
+                                  const double* heights, const float* zoff, const float* cam_from_obj, uint8_t* out);
+/* gen_heigtfield_simplex_2d (base_surface_env.py:319-337) for n seeds: heights [n][rows*cols], zoff [n] (nullable). */
+int tg_gen_heightfield(int32_t n, const int64_t* seeds, int32_t rows, int32_t cols, double interp, double range, double* heights,
+                       float* zoff);
 
 #ifdef __cplusplus
 }

@@ -423,3 +423,83 @@ void mb_t_s_camera(const float* cur_dep, const float* nodef_dep, const float* no
         out[p] = v;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ OpenSimplex 2-D */
+#define OS_STRETCH_2D (-0.211324865405187)   /* (1/sqrt(2+1)-1)/2 */
+#define OS_SQUISH_2D 0.366025403784439       /* (sqrt(2+1)-1)/2 */
+#define OS_NORM_2D 47.0
+static const int8_t os_grad2[16] = {5, 2, 2, 5, -5, 2, -2, 5, 5, -2, 2, -5, -5, -2, -2, -5};
+
+void mb_opensimplex_perm(int64_t seed, int16_t* perm) {
+    int16_t source[256];
+    uint64_t s = (uint64_t)seed;   /* two's-complement wrap-around of the reference's signed 64-bit LCG */
+    for (int i = 0; i < 256; ++i) source[i] = (int16_t)i;
+    s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+    s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+    s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+    for (int i = 255; i >= 0; --i) {
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        int64_t v = (int64_t)(s + 31ULL);
+        int64_t r = v % (int64_t)(i + 1);
+        if (r < 0) r += (i + 1);
+        perm[i] = source[r];
+        source[r] = source[i];
+    }
+}
+
+static double os_extrapolate2(const int16_t* perm, int64_t xsb, int64_t ysb, double dx, double dy) {
+    int index = perm[(perm[xsb & 0xFF] + ysb) & 0xFF] & 0x0E;
+    return (double)os_grad2[index] * dx + (double)os_grad2[index + 1] * dy;
+}
+
+double mb_opensimplex_noise2(const int16_t* perm, double x, double y) {
+    double stretch = (x + y) * OS_STRETCH_2D;
+    double xs = x + stretch, ys = y + stretch;
+    double fxs = floor(xs), fys = floor(ys);
+    int64_t xsb = (int64_t)fxs, ysb = (int64_t)fys;
+    double squish = (fxs + fys) * OS_SQUISH_2D;
+    double xb = fxs + squish, yb = fys + squish;
+    double xins = xs - fxs, yins = ys - fys;
+    double in_sum = xins + yins;
+    double dx0 = x - xb, dy0 = y - yb;
+    double value = 0.0, dx_ext, dy_ext;
+    int64_t xsv_ext, ysv_ext;
+    /* contribution (1,0) */
+    double dx1 = dx0 - 1.0 - OS_SQUISH_2D, dy1 = dy0 - 0.0 - OS_SQUISH_2D;
+    double attn1 = 2.0 - dx1 * dx1 - dy1 * dy1;
+    if (attn1 > 0.0) { attn1 *= attn1; value += attn1 * attn1 * os_extrapolate2(perm, xsb + 1, ysb + 0, dx1, dy1); }
+    /* contribution (0,1) */
+    double dx2 = dx0 - 0.0 - OS_SQUISH_2D, dy2 = dy0 - 1.0 - OS_SQUISH_2D;
+    double attn2 = 2.0 - dx2 * dx2 - dy2 * dy2;
+    if (attn2 > 0.0) { attn2 *= attn2; value += attn2 * attn2 * os_extrapolate2(perm, xsb + 0, ysb + 1, dx2, dy2); }
+    if (in_sum <= 1.0) {          /* inside the triangle (2-simplex) at (0,0) */
+        double zins = 1.0 - in_sum;
+        if (zins > xins || zins > yins) {
+            if (xins > yins) { xsv_ext = xsb + 1; ysv_ext = ysb - 1; dx_ext = dx0 - 1.0; dy_ext = dy0 + 1.0; }
+            else { xsv_ext = xsb - 1; ysv_ext = ysb + 1; dx_ext = dx0 + 1.0; dy_ext = dy0 - 1.0; }
+        } else {
+            xsv_ext = xsb + 1; ysv_ext = ysb + 1;
+            dx_ext = dx0 - 1.0 - 2.0 * OS_SQUISH_2D; dy_ext = dy0 - 1.0 - 2.0 * OS_SQUISH_2D;
+        }
+    } else {                      /* inside the triangle at (1,1) */
+        double zins = 2.0 - in_sum;
+        if (zins < xins || zins < yins) {
+            if (xins > yins) { xsv_ext = xsb + 2; ysv_ext = ysb + 0; dx_ext = dx0 - 2.0 - 2.0 * OS_SQUISH_2D; dy_ext = dy0 + 0.0 - 2.0 * OS_SQUISH_2D; }
+            else { xsv_ext = xsb + 0; ysv_ext = ysb + 2; dx_ext = dx0 + 0.0 - 2.0 * OS_SQUISH_2D; dy_ext = dy0 - 2.0 - 2.0 * OS_SQUISH_2D; }
+        } else { dx_ext = dx0; dy_ext = dy0; xsv_ext = xsb; ysv_ext = ysb; }
+        xsb += 1; ysb += 1;
+        dx0 = dx0 - 1.0 - 2.0 * OS_SQUISH_2D; dy0 = dy0 - 1.0 - 2.0 * OS_SQUISH_2D;
+    }
+    double attn0 = 2.0 - dx0 * dx0 - dy0 * dy0;
+    if (attn0 > 0.0) { attn0 *= attn0; value += attn0 * attn0 * os_extrapolate2(perm, xsb, ysb, dx0, dy0); }
+    double attn_ext = 2.0 - dx_ext * dx_ext - dy_ext * dy_ext;
+    if (attn_ext > 0.0) { attn_ext *= attn_ext; value += attn_ext * attn_ext * os_extrapolate2(perm, xsv_ext, ysv_ext, dx_ext, dy_ext); }
+    return value / OS_NORM_2D;
+}
+
+void mb_heightfield_simplex2d(int64_t seed, int rows, int cols, double interp, double range, double* out) {
+    int16_t perm[256];
+    mb_opensimplex_perm(seed, perm);
+    for (int x = 0; x < rows; ++x)
+        for (int y = 0; y < cols; ++y) out[x * cols + y] = mb_opensimplex_noise2(perm, (double)x * interp, (double)y * interp) * range;
+}

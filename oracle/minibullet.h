@@ -101,6 +101,18 @@ void mb_render_depth(const float* verts /*[nv][3]*/, int nv, const int32_t* tris
 void mb_t_s_camera(const float* cur_dep, const float* nodef_dep, const float* nodef_gray, const uint8_t* border_mask,
                    int npix, int turn_off_border, uint8_t* out);
 
+/* ----------------------------------------------------------------------------------------------------------
+ * OpenSimplex noise (2-D), the third-party `opensimplex` package the reference imports for surface generation
+ * (requirements.txt:4, unpinned; call sites base_surface_env.py:319-337 `noise2(x*.05, y*.05) * .025`, :448
+ * `OpenSimplex(seed=np_random.randint(1e8))`).  Restated from the published algorithm (K. Spencer, 2014:
+ * stretch/squish constants, 8 gradients, 64-bit LCG permutation shuffle) — PARITY UNPINNED: the package is not
+ * installed here and the reference holds no golden surfaces.  Compiled without FMA contraction so the HIP
+ * implementation (tactile_gym_amd/csrc/tg_noise.hip) is bit-identical. */
+void mb_opensimplex_perm(int64_t seed, int16_t* perm /*[256]*/);
+double mb_opensimplex_noise2(const int16_t* perm, double x, double y);
+/* gen_heigtfield_simplex_2d (base_surface_env.py:319-337): out[x*cols + y] = noise2(x*interp, y*interp) * range */
+void mb_heightfield_simplex2d(int64_t seed, int rows, int cols, double interp, double range, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 """CPU oracle of the reference's per-env hot path (TEST INFRASTRUCTURE ONLY).
 
-One environment, plain numpy + oracle/libminibullet.so, restating — call for call — what the reference does per
-`reset()` / `step()`.  Each block cites the reference lines it follows (paths relative to
+One environment per object, plain numpy + oracle/libminibullet.so, restating — call for call — what the reference does
+per `reset()` / `step()`.  Each block cites the reference lines it follows (paths relative to
 /root/reference/tactile_gym).  PyBullet itself is replaced by oracle/minibullet.c; see that header for what is and is
 not pinned against golden data.
 
@@ -9,6 +9,7 @@ The random stream is this repo's own (SplitMix64 counter stream, `Rng`); the ref
 generator is not pinned by the reference (no gym version), so seeds are not comparable with it anyway.  The HIP
 product path implements the identical integer stream, so oracle-vs-HIP comparisons see identical task draws.
 """
+import ctypes as C
 import math
 import os
 
@@ -43,6 +44,10 @@ class Rng:
     def uniform(self, lo, hi):
         return lo + (hi - lo) * self.random()
 
+    def randint(self, hi):
+        """np_random.randint(hi): integer in [0, hi)."""
+        return int(self.uniform(0.0, float(hi)))
+
 
 def load_tg(name):
     from tactile_gym_amd.urdf_compile import TGModel  # plain-data loader, no HIP involved
@@ -66,50 +71,34 @@ def sensor_camera(t_s_name, t_s_type):
     return dict(fov=fov, focal=focal, pos=np.array(pos), rpy=np.array(rpy), near=0.01, far=1.0)
 
 
-class OracleEdgeFollowEnv:
-    """edge_follow-v0 (rl_envs/exploration/edge_follow/edge_follow_env.py) on UR5 + TacTip, velocity control."""
+class _OracleArmEnv:
+    """What every task env shares: BaseTactileEnv + Robot + BaseRobotArm + TactileSensor on a UR5, velocity control."""
 
-    SIM_DT = 1.0 / 240.0                 # edge_follow_env.py:33
-    ACTION_REPEAT = 24                   # :35-37  floor((1/10)/(1/240))
+    SIM_DT = 1.0 / 240.0                 # e.g. edge_follow_env.py:33
+    ACTION_REPEAT = 24                   # floor((1/10)/(1/240)), :35-37
     SOLVER_ITERS = 150                   # base_tactile_env.py:128-130
 
-    def __init__(self, seed=0, max_steps=200, image_size=(128, 128), env_modes=None, inertia="collision_aabb"):
-        modes = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height",
-                     observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
-        modes.update(env_modes or {})
+    def _setup_arm(self, seed, modes, max_steps, image_size, t_s_type, rest_poses, inertia):
         assert modes["control_mode"] == "TCP_velocity_control" and modes["arm_type"] == "ur5"
         self.modes, self.max_steps, self.image_size = modes, max_steps, tuple(image_size)
-        self.t_s_name, self.t_s_type = modes["tactile_sensor_name"], "standard"           # :59-64
+        self.t_s_name, self.t_s_type = modes["tactile_sensor_name"], t_s_type
         suffix = "" if inertia == "collision_aabb" else "_urdfinertia"
-        self.tg = load_tg(f"ur5_standard_{self.t_s_name}{suffix}")
+        self.tg = load_tg(f"ur5_{t_s_type}_{self.t_s_name}{suffix}")
         self.arm = mb.Arm(self.tg)
         self.rng = Rng(seed)
-        self.min_action, self.max_action = -0.25, 0.25                                     # :140
-        max_pos_vel, max_ang_vel = 0.01, 5.0 * (math.pi / 180)                             # :158-159
-        self.act_lo = np.array([-max_pos_vel] * 3 + [0.0, 0.0, -max_ang_vel])              # :161-166
-        self.act_hi = np.array([max_pos_vel] * 3 + [0.0, 0.0, max_ang_vel])
-        self.edge_pos = np.array([0.65, 0.0, 0.0])                                         # :84 well_designed_pos
-        self.edge_height, self.edge_len = 0.035, 0.175                                     # :203,207
-        self.termination_dist = 0.01                                                       # :67
-        self.TCP_lims = np.array([[-0.175, 0.175], [-0.175, 0.175], [-0.1, 0.1], [0, 0], [0, 0], [-math.pi, math.pi]])  # :85-90
-        self.embed_dist = 0.0035                                                           # :94-99
-        self.workframe_pos = np.array([0.65, 0.0, self.edge_height])                       # :106
-        self.workframe_rpy = np.array([-math.pi, 0.0, math.pi / 2])                        # :107
-        self.workframe_orn = pm.quat_from_euler(self.workframe_rpy)
-        # edge_follow/rest_poses.py:6-20 (movable joints only)
-        rest = {"tactip": [0.166827, -2.16515, -1.64365, -0.90317, 1.57315, 1.74001],
-                "digit": [0.1666452116249431, -2.2334888481855204, -1.6642245054428424, -0.8142762445463524,
-                          1.573151527964482, 1.7398309441833082]}
-        self.rest_poses = np.array(rest[self.t_s_name])
+        self.min_action, self.max_action = -0.25, 0.25
+        self.rest_poses = np.array(rest_poses)
         self.max_force, self.pos_gain, self.vel_gain = 1000.0, 1.0, 1.0                    # ur5.py:19-21
         self.cam = sensor_camera(self.t_s_name, self.t_s_type)
         n = self.image_size[0]
         s = np.load(os.path.join(_ASSETS, "sensors", f"{self.t_s_name}_{self.t_s_type}_{n}.npz"))
         self.nodef_dep, self.nodef_gray, self.border_mask = s["nodef_dep"], s["nodef_gray"], s["border_mask"]
-        e = np.load(os.path.join(_ASSETS, "stimuli", "long_edge.npz"))
-        self.edge_verts, self.edge_tris = e["verts"], e["tris"]
         self.step_counter = 0
         self.ticks = 0
+
+    def _set_workframe(self, pos, rpy):
+        self.workframe_pos, self.workframe_rpy = np.array(pos, dtype=np.float64), np.array(rpy, dtype=np.float64)
+        self.workframe_orn = pm.quat_from_euler(self.workframe_rpy)
 
     # ---- base_robot_arm.py:46-118 work-frame helpers
     def _world_to_work(self, pos, rpy):
@@ -120,6 +109,9 @@ class OracleEdgeFollowEnv:
     def _work_to_world(self, pos, rpy):
         p, q = pm.multiply_transforms(self.workframe_pos, self.workframe_orn, pos, pm.quat_from_euler(rpy))
         return p, pm.euler_from_quat(q)
+
+    def _workvec_to_worldvec(self, v):
+        return pm.mat_from_quat(self.workframe_orn) @ np.asarray(v, dtype=np.float64)
 
     def _tcp_world(self):  # base_robot_arm.py:136-151
         pos, quat, lv, av, _ = self.arm.link_state("tcp_link")
@@ -157,17 +149,6 @@ class OracleEdgeFollowEnv:
         self.arm.set_motors_velocity(req, self.vel_gain, self.max_force)                # :325-332
         self.last_req_joint_vels = req
 
-    # ---- edge_follow_env.py:237-283
-    def _update_edge(self):
-        self.edge_ang = self.rng.uniform(-math.pi, math.pi)
-        c, s = math.cos(self.edge_ang), math.sin(self.edge_ang)
-        self.edge_rot = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
-        self.goal_pos_world = np.array([self.edge_pos[0] + self.edge_len * c, self.edge_pos[1] + self.edge_len * s,
-                                        self.edge_pos[2] + self.edge_height])
-        self.edge_end_points = np.array([
-            [self.edge_pos[0] - self.edge_len * c, self.edge_pos[1] - self.edge_len * s, self.edge_pos[2] + self.edge_height],
-            [self.edge_pos[0] + self.edge_len * c, self.edge_pos[1] + self.edge_len * s, self.edge_pos[2] + self.edge_height]])
-
     # ---- robot.py:188-260
     def _blocking_move(self, targ_pos, targ_orn, targ_j, max_steps=1000, constant_vel=0.001, pos_tol=2e-4, orn_tol=1e-3,
                        jvel_tol=0.1):
@@ -193,28 +174,93 @@ class OracleEdgeFollowEnv:
                 break
         return n_used
 
+    # ---- robot.py:114-125 (Robot.reset): rest pose, IK to the start pose, blocking move
+    def _reset_robot(self, init_pos_work, init_rpy_work):
+        self.arm.reset_joint_states(self.rest_poses)                                    # base_robot_arm.py:17-37
+        self.arm.set_motors_position(self.rest_poses, np.zeros(self.arm.n), self.pos_gain, self.vel_gain, self.max_force)
+        tpos, trpy = self._work_to_world(init_pos_work, init_rpy_work)                  # :191-226
+        torn = pm.quat_from_euler(trpy)
+        joint_poses = self.arm.inverse_kinematics("tcp_link", tpos, torn, 100, 1e-8)
+        self.arm.set_motors_position(joint_poses, np.zeros(self.arm.n), self.pos_gain, self.vel_gain, self.max_force)
+        self.reset_ticks = self._blocking_move(tpos, torn, joint_poses, max_steps=1000, constant_vel=0.001)
+
+    # ---- base_tactile_env.py:141-185 (scale + apply + step data + observation); encode_actions is per task
+    def step(self, action):
+        enc = np.clip(self._encode_actions(np.asarray(action, dtype=np.float64)), self.min_action, self.max_action)
+        scaled = ((enc - self.min_action) * (self.act_hi - self.act_lo)) / (self.max_action - self.min_action) + self.act_lo
+        self.step_counter += 1
+        self._tcp_velocity_control(scaled)                                              # robot.py:156-183
+        for _ in range(self.ACTION_REPEAT):
+            self._step_sim()
+        reward, done = self._get_step_data()
+        return self._observation(), reward, done, {}
+
+    # ---- tactile_sensor.py:150-294
+    def camera_pose(self):
+        bpos, bquat, _, _, _ = self.arm.link_state(f"{self.t_s_name}_body_link")
+        cpos, cquat = pm.multiply_transforms(bpos, bquat, self.cam["pos"], pm.quat_from_euler(self.cam["rpy"]))
+        return cpos, pm.mat_from_quat(cquat)
+
+    def _observation(self):  # base_tactile_env.py:200-210, 247-282
+        obs = {}
+        mode = self.modes["observation_mode"]
+        if "oracle" in mode:
+            obs["oracle"] = self.oracle_obs()
+        if "tactile" in mode:
+            obs["tactile"] = self.tactile_image()[..., np.newaxis]
+        return obs
+
+
+class OracleEdgeFollowEnv(_OracleArmEnv):
+    """edge_follow-v0 (rl_envs/exploration/edge_follow/edge_follow_env.py) on UR5, velocity control."""
+
+    REST = {"tactip": [0.166827, -2.16515, -1.64365, -0.90317, 1.57315, 1.74001],     # edge_follow/rest_poses.py:6-57
+            "digit": [0.1666452116249431, -2.2334888481855204, -1.6642245054428424, -0.8142762445463524, 1.573151527964482,
+                      1.7398309441833082],
+            "digitac": [0.16664443404149898, -2.2242489977536737, -1.6618744232210114, -0.8258663681806591, 1.5731514988184077,
+                        1.7398302172182332]}
+
+    def __init__(self, seed=0, max_steps=200, image_size=(128, 128), env_modes=None, inertia="collision_aabb"):
+        modes = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height",
+                     observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+        modes.update(env_modes or {})
+        self._setup_arm(seed, modes, max_steps, image_size, "standard", self.REST[modes["tactile_sensor_name"]], inertia)   # :59-64
+        max_pos_vel, max_ang_vel = 0.01, 5.0 * (math.pi / 180)                             # :158-159
+        self.act_lo = np.array([-max_pos_vel] * 3 + [0.0, 0.0, -max_ang_vel])              # :161-166
+        self.act_hi = np.array([max_pos_vel] * 3 + [0.0, 0.0, max_ang_vel])
+        self.edge_pos = np.array([0.65, 0.0, 0.0])                                         # :84 well_designed_pos
+        self.edge_height, self.edge_len = 0.035, 0.175                                     # :203,207
+        self.termination_dist = 0.01                                                       # :67
+        self.TCP_lims = np.array([[-0.175, 0.175], [-0.175, 0.175], [-0.1, 0.1], [0, 0], [0, 0], [-math.pi, math.pi]])  # :85-90
+        self.embed_dist = 0.0035                                                           # :94-99
+        self._set_workframe([0.65, 0.0, self.edge_height], [-math.pi, 0.0, math.pi / 2])   # :106-107
+        e = np.load(os.path.join(_ASSETS, "stimuli", "long_edge.npz"))
+        self.edge_verts, self.edge_tris = e["verts"], e["tris"]
+
+    # ---- edge_follow_env.py:237-283
+    def _update_edge(self):
+        self.edge_ang = self.rng.uniform(-math.pi, math.pi)
+        c, s = math.cos(self.edge_ang), math.sin(self.edge_ang)
+        self.edge_rot = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+        self.goal_pos_world = np.array([self.edge_pos[0] + self.edge_len * c, self.edge_pos[1] + self.edge_len * s,
+                                        self.edge_pos[2] + self.edge_height])
+        self.edge_end_points = np.array([
+            [self.edge_pos[0] - self.edge_len * c, self.edge_pos[1] - self.edge_len * s, self.edge_pos[2] + self.edge_height],
+            [self.edge_pos[0] + self.edge_len * c, self.edge_pos[1] + self.edge_len * s, self.edge_pos[2] + self.edge_height]])
+
     def reset(self):
-        """edge_follow_env.py:311-336 -> robot.py:114-125."""
+        """edge_follow_env.py:311-336."""
         self.step_counter = 0
         if self.modes["noise_mode"] == "rand_height":                                   # :291-298
             lo, hi = {"tactip": (0.0015, 0.0065), "digit": (0.0011, 0.0028), "digitac": (0.0015, 0.0045)}[self.t_s_name]
             self.embed_dist = self.rng.uniform(lo, hi)
         self._update_edge()
-        init_pos, init_rpy = np.array([0.0, 0.0, self.embed_dist]), np.zeros(3)         # :301-309
-        self.arm.reset_joint_states(self.rest_poses)                                    # base_robot_arm.py:17-37
-        self.arm.set_motors_position(self.rest_poses, np.zeros(self.arm.n), self.pos_gain, self.vel_gain, self.max_force)
-        tpos, trpy = self._work_to_world(init_pos, init_rpy)                            # :191-226
-        torn = pm.quat_from_euler(trpy)
-        joint_poses = self.arm.inverse_kinematics("tcp_link", tpos, torn, 100, 1e-8)
-        self.arm.set_motors_position(joint_poses, np.zeros(self.arm.n), self.pos_gain, self.vel_gain, self.max_force)
-        self.reset_ticks = self._blocking_move(tpos, torn, joint_poses, max_steps=1000, constant_vel=0.001)
+        self._reset_robot(np.array([0.0, 0.0, self.embed_dist]), np.zeros(3))           # :301-309
         self._get_step_data()
         return self._observation()
 
-    # ---- base_tactile_env.py:141-185
-    def step(self, action):
-        enc = np.zeros(6)                                                               # encode_actions :345-369
-        a = np.asarray(action, dtype=np.float64)
+    def _encode_actions(self, a):                                                       # :345-369
+        enc = np.zeros(6)
         mm = self.modes["movement_mode"]
         enc[0], enc[1] = a[0], a[1]
         if mm == "xyz":
@@ -223,14 +269,7 @@ class OracleEdgeFollowEnv:
             enc[5] = a[2]
         elif mm == "xyzRz":
             enc[2], enc[5] = a[2], a[3]
-        enc = np.clip(enc, self.min_action, self.max_action)                            # scale_actions :141-164
-        scaled = ((enc - self.min_action) * (self.act_hi - self.act_lo)) / (self.max_action - self.min_action) + self.act_lo
-        self.step_counter += 1
-        self._tcp_velocity_control(scaled)                                              # robot.py:156-183
-        for _ in range(self.ACTION_REPEAT):
-            self._step_sim()
-        reward, done = self._get_step_data()
-        return self._observation(), reward, done, {}
+        return enc
 
     # ---- edge_follow_env.py:371-452
     def _get_step_data(self):
@@ -246,12 +285,6 @@ class OracleEdgeFollowEnv:
             reward = -(1.0 * goal_dist + 10.0 * edge_dist + 0.0)
         return reward, bool(done)
 
-    # ---- tactile_sensor.py:150-294
-    def camera_pose(self):
-        bpos, bquat, _, _, _ = self.arm.link_state(f"{self.t_s_name}_body_link")
-        cpos, cquat = pm.multiply_transforms(bpos, bquat, self.cam["pos"], pm.quat_from_euler(self.cam["rpy"]))
-        return cpos, pm.mat_from_quat(cquat)
-
     def stimulus_transform(self):
         cpos, cR = self.camera_pose()
         return mb.cam_from_obj_matrix(cpos, cR, self.edge_pos, self.edge_rot)
@@ -263,16 +296,137 @@ class OracleEdgeFollowEnv:
                         self.cam["far"], w, h, cur)
         return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)
 
-    def _observation(self):  # base_tactile_env.py:200-210, 247-282
-        obs = {}
-        mode = self.modes["observation_mode"]
-        if "oracle" in mode:
-            obs["oracle"] = self.oracle_obs()
-        if "tactile" in mode:
-            obs["tactile"] = self.tactile_image()[..., np.newaxis]
-        return obs
-
     def oracle_obs(self):  # edge_follow_env.py:454-476
         p, _, lv, _ = self._tcp_work()
         gp, _ = self._world_to_work(self.goal_pos_world, np.zeros(3))
         return np.hstack([p, lv, gp, self.edge_ang]).astype(np.float32)
+
+
+def opensimplex_heightfield(seed, rows=64, cols=64, interp=0.05, height_range=0.025):
+    """gen_heigtfield_simplex_2d (base_surface_env.py:319-337) through oracle/minibullet.c's OpenSimplex restatement."""
+    L = mb.lib()
+    L.mb_heightfield_simplex2d.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    out = np.zeros((rows, cols))
+    L.mb_heightfield_simplex2d(int(seed), rows, cols, interp, height_range, out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def heightfield_mesh(heights, grid_scale, zoff):
+    """Triangle soup of a Bullet heightfield shape [PARITY_ASSUMPTIONS A15-A16]: float32 vertices
+    ((i - (rows-1)/2) s, (j - (cols-1)/2) s, h[j*rows + i] - zoff) and the two triangles per cell."""
+    rows, cols = heights.shape
+    flat = heights.reshape(-1)
+    i, j = np.meshgrid(np.arange(rows), np.arange(cols), indexing="xy")      # vertex k = j*rows + i
+    s = np.float32(grid_scale)
+    vx = (i.astype(np.float32) - np.float32(0.5) * np.float32(rows - 1)) * s
+    vy = (j.astype(np.float32) - np.float32(0.5) * np.float32(cols - 1)) * s
+    vz = flat[(j * rows + i).reshape(-1)].astype(np.float32).reshape(i.shape) - np.float32(zoff)
+    verts = np.stack([vx, vy, vz], axis=-1).reshape(-1, 3).astype(np.float32)
+    tris = []
+    for cj in range(cols - 1):
+        for ci in range(rows - 1):
+            a, b, c_, d = cj * rows + ci, (cj + 1) * rows + ci, cj * rows + ci + 1, (cj + 1) * rows + ci + 1
+            tris.append((a, b, c_))
+            tris.append((c_, b, d))
+    return verts, np.asarray(tris, dtype=np.int32)
+
+
+class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
+    """surface_follow-v0 (base_surface_env.py + surface_follow_auto/surface_follow_auto_env.py), horizontal simplex surface."""
+
+    def __init__(self, seed=0, max_steps=200, image_size=(128, 128), env_modes=None, inertia="collision_aabb", center_z=True):
+        modes = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
+                     reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")
+        modes.update(env_modes or {})
+        assert modes["noise_mode"] == "simplex" and modes["movement_mode"] in ("xyz", "xyzRxRy") and modes["reward_mode"] == "dense"
+        rest = [0.16682, -2.18943, -1.65357, -0.86897, 1.57315, 1.74001]                   # surface_follow/rest_poses.py
+        self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # base_surface_env.py:60-63
+        self.embed_dist = {"tactip": 0.0025, "digitac": 0.0015, "digit": 0.0015}[self.t_s_name]   # :66-75
+        self.termination_dist = 0.01                                                       # :79
+        self.grid_scale, self.height_range, self.rows, self.cols = 0.006, 0.025, 64, 64    # :238-243
+        self.interp, self.x_y_extent = 0.05, 0.15                                          # :244-245
+        self.surface_pos = np.array([0.65, 0.0, self.height_range])                        # :266
+        min_x = self.surface_pos[0] - ((self.rows / 2) * self.grid_scale)                  # :268-282
+        max_x = self.surface_pos[0] + ((self.rows / 2) * self.grid_scale)
+        min_y = self.surface_pos[1] - ((self.cols / 2) * self.grid_scale)
+        max_y = self.surface_pos[1] + ((self.cols / 2) * self.grid_scale)
+        self.x_bins, self.y_bins = np.linspace(min_x, max_x, self.rows), np.linspace(min_y, max_y, self.cols)
+        v, w = 0.01, 5.0 * (math.pi / 180)                                                 # :186-194
+        self.act_lo, self.act_hi = np.array([-v, -v, -v, -w, -w, 0.0]), np.array([v, v, v, w, w, 0.0])
+        self._set_workframe(self.surface_pos, [-math.pi, 0.0, math.pi / 2])                # :106-109
+        e, h = self.x_y_extent, self.height_range
+        self.TCP_lims = np.array([[-e, e], [-e, e], [-h, h], [-math.pi / 4, math.pi / 4], [-math.pi / 4, math.pi / 4], [0.0, 0.0]])  # :112-123
+        self.auto_scale = {"tactip": 1.0, "digitac": 0.9, "digit": 0.7}[self.t_s_name]      # surface_follow_auto_env.py:33-41
+        self.center_z = center_z
+
+    def _xy_to_surface_idx(self, x, y):                                                  # base_surface_env.py:284-300
+        i, j = int(np.digitize(y, self.y_bins)), int(np.digitize(x, self.x_bins))
+        if i == self.cols:
+            i -= 1
+        if j == self.rows:
+            j -= 1
+        return i, j
+
+    def reset(self):
+        """base_surface_env.py:615-636: update_surface (:434-516), make_goal (:518-575), update_init_pose (:590-613)."""
+        self.step_counter = 0
+        self.noise_seed = self.rng.randint(1e8)                                          # :448
+        self.heightfield_data = opensimplex_heightfield(self.noise_seed, self.rows, self.cols, self.interp, self.height_range)
+        X, Y = np.meshgrid(self.x_bins, self.y_bins)
+        self.surface_array = np.dstack((X, Y, self.heightfield_data + self.surface_pos[2]))    # :476-477
+        gy, gx = np.gradient(self.heightfield_data, self.grid_scale)                     # :500-508
+        nrm = np.dstack((-gx, -gy, np.ones_like(self.heightfield_data)))
+        self.surface_normals = nrm / np.linalg.norm(nrm, axis=2)[..., None]
+        ang = self.rng.uniform(-math.pi, math.pi)                                        # :530-534
+        self.workframe_directions = [math.cos(ang), math.sin(ang), 0]
+        wd = self._workvec_to_worldvec(self.workframe_directions)
+        goal = [self.surface_pos[0] + self.x_y_extent * wd[0], self.surface_pos[1] + self.x_y_extent * wd[1]]
+        gi, gj = self._xy_to_surface_idx(goal[0], goal[1])
+        self.goal_pos_world = np.array(goal + [self.surface_array[gi, gj, 2]])
+        hc = self.heightfield_data[int(self.rows / 2), int(self.cols / 2)]               # :594
+        init_world = [self.surface_pos[0], self.surface_pos[1], self.surface_pos[2] + hc - self.embed_dist]
+        init_pos, _ = self._world_to_work(init_world, [0, 0, 0])
+        # Bullet centres a heightfield shape vertically on (min + max)/2 of its float samples [A15]
+        hf = self.heightfield_data.astype(np.float32)
+        self.surf_zoff = np.float32(0.5) * (hf.min() + hf.max()) if self.center_z else np.float32(0.0)
+        self.surf_verts, self.surf_tris = heightfield_mesh(self.heightfield_data, self.grid_scale, self.surf_zoff)
+        self._reset_robot(init_pos, np.zeros(3))
+        self._get_step_data()
+        return self._observation()
+
+    def _encode_actions(self, a):                                                        # surface_follow_auto_env.py:27-57
+        enc = np.zeros(6)
+        enc[0] = self.workframe_directions[0] * self.max_action * self.auto_scale
+        enc[1] = self.workframe_directions[1] * self.max_action * self.auto_scale
+        enc[2] = a[0]
+        if self.modes["movement_mode"] == "xyzRxRy":
+            enc[3], enc[4] = a[1], a[2]
+        return enc
+
+    def _get_step_data(self):                                                            # base_surface_env.py:664-684
+        self.cur_tcp_pos, self.cur_tcp_rpy, self.cur_tcp_orn, _, _ = self._tcp_world()
+        self.tip_i, self.tip_j = self._xy_to_surface_idx(self.cur_tcp_pos[0], self.cur_tcp_pos[1])
+        done = float(np.linalg.norm(self.cur_tcp_pos - self.goal_pos_world)) < self.termination_dist or self.step_counter >= self.max_steps
+        R = pm.mat_from_quat(self.cur_tcp_orn)
+        surf_z = self.surface_array[self.tip_i, self.tip_j, 2]                           # z_dist_to_surface :727-760
+        embedded = self.cur_tcp_pos + R @ np.array([0, 0, -self.embed_dist])
+        surf_dist = abs(embedded[2] - surf_z)
+        n = self.surface_normals[self.tip_i, self.tip_j, :]                              # cos_dist_to_surface_normal :703-725
+        t = R @ np.array([0, 0, -1])
+        cos_dist = 1 - np.dot(n, t) / (np.linalg.norm(n) * np.linalg.norm(t))
+        w_norm = 0.0 if self.modes["movement_mode"] in ("yz", "xyz") else 1.0            # surface_follow_auto_env.py:87-90
+        return -((1.0 * surf_dist) + (w_norm * cos_dist)), bool(done)
+
+    def stimulus_transform(self):
+        cpos, cR = self.camera_pose()
+        return mb.cam_from_obj_matrix(cpos, cR, self.surface_pos, np.eye(3))
+
+    def tactile_image(self):
+        h, w = self.image_size
+        cur = self.nodef_dep.copy()
+        mb.render_depth(self.surf_verts, self.surf_tris, self.stimulus_transform(), self.cam["fov"], self.cam["near"], self.cam["far"],
+                        w, h, cur)
+        return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)
+
+    def oracle_obs(self):
+        raise NotImplementedError

@@ -8,12 +8,13 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtactile_gym_hip.so")
 
-ENV_EDGE_FOLLOW = 0
+ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO = 0, 1
+SMOVE = {"yz": 0, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}
 MOVE = {"xy": 0, "xyz": 1, "xyRz": 2, "xyzRz": 3}
 NOISE = {"fixed_height": 0, "rand_height": 1}
 REWARD = {"dense": 0, "sparse": 1}
@@ -62,6 +63,9 @@ class TgConfig(C.Structure):
         ("workframe_pos", _d3), ("workframe_rpy", _d3), ("stim_pos", _d3),
         ("edge_height", C.c_double), ("edge_len", C.c_double), ("termination_dist", C.c_double),
         ("embed_dist", C.c_double), ("embed_lo", C.c_double), ("embed_hi", C.c_double),
+        ("surf_rows", C.c_int32), ("surf_cols", C.c_int32), ("surf_center_z", C.c_int32), ("reserved0", C.c_int32),
+        ("surf_grid_scale", C.c_double), ("surf_height_range", C.c_double), ("surf_interp", C.c_double),
+        ("surf_xy_extent", C.c_double), ("auto_action_scale", C.c_double),
     ]
 
 
@@ -71,6 +75,8 @@ class TgStateView(C.Structure):
         ("tcp_pos", C.POINTER(C.c_double)), ("tcp_rpy", C.POINTER(C.c_double)), ("edge_ang", C.POINTER(C.c_double)),
         ("embed_dist", C.POINTER(C.c_double)), ("stim_xform", C.POINTER(C.c_float)), ("step_count", C.POINTER(C.c_int32)),
         ("reset_ticks", C.POINTER(C.c_int32)), ("rng_state", C.POINTER(C.c_uint64)),
+        ("goal_pos", C.POINTER(C.c_double)), ("direction", C.POINTER(C.c_double)), ("heights", C.POINTER(C.c_double)),
+        ("surf_zoff", C.POINTER(C.c_float)),
     ]
 
 
@@ -104,6 +110,8 @@ SYMBOLS = {
     "tg_inverse_kinematics": (C.c_int, [C.POINTER(TgRobot), C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int32, C.c_double, _dp,
                                         C.POINTER(C.c_int32)]),
     "tg_render_tactile": (C.c_int, [C.POINTER(TgSensor), C.POINTER(TgMesh), C.c_int32, _fp, _u8p]),
+    "tg_render_tactile_heightfield": (C.c_int, [C.POINTER(TgSensor), C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _fp, _fp, _u8p]),
+    "tg_gen_heightfield": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_double, C.c_double, _dp, _fp]),
 }
 
 _lib = None

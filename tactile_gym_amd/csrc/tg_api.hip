@@ -13,6 +13,7 @@
 
 #include "../../include/tactile_gym_hip.h"
 #include "tg_physics.hpp"
+#include "tg_noise.h"
 #include "tg_raster.h"
 
 namespace tg {
@@ -37,6 +38,10 @@ template <typename T> struct EnvConst {
     double embed_lo, embed_hi;   // random draws are evaluated in double on every path
     M3<T> cam_rot;               // R(cam_rpy) in the sensor-body frame
     T cam_pos[3];
+    // surface_follow
+    int env_kind, surf_rows, surf_cols;
+    double surf_scale, surf_range, surf_interp, surf_extent, auto_scale;
+    double xbin_lo, xbin_hi, ybin_lo, ybin_hi;   // np.linspace bounds of x_bins / y_bins (base_surface_env.py:258-282)
 };
 
 struct State {   // device pointers, SoA [field][num_envs]
@@ -45,6 +50,10 @@ struct State {   // device pointers, SoA [field][num_envs]
     int32_t *step_count, *reset_ticks;
     uint64_t* rng;
     uint8_t* done;
+    // surface_follow
+    double *dir, *goal, *heights;   // [2][n], [3][n], [n][rows*cols]
+    float* surf_zoff;               // [n]
+    int64_t* noise_seed;            // [n]
 };
 
 // SplitMix64 (identical integer stream in oracle/ref_env.py: Rng)
@@ -74,6 +83,26 @@ __device__ __forceinline__ void world_to_work(const EnvConst<T>& c, V3<T> pos, c
     euler_from_quat(qw, wrpy[0], wrpy[1], wrpy[2]);
 }
 
+// np.digitize(v, np.linspace(lo, hi, n)) for increasing bins: the number of bin edges <= v.  Edges are formed exactly like
+// numpy's linspace (k * step + lo in two roundings, last edge = hi), hence no FMA contraction here.
+__device__ inline int digitize_linspace(double v, double lo, double hi, int n) {
+#pragma clang fp contract(off)
+    const double step = (hi - lo) / (double)(n - 1);
+    int count = 0;
+    for (int k = 0; k < n; ++k) {
+        const double prod = (double)k * step;
+        const double edge = (k == n - 1) ? hi : prod + lo;
+        count += (edge <= v) ? 1 : 0;
+    }
+    return count;
+}
+// np.gradient(f, h) along one axis of a rows x cols array (central differences inside, one-sided at the ends)
+__device__ inline double grad_axis(const double* f, int idx, int n, int stride, double h) {
+    if (idx == 0) return (f[stride] - f[0]) / h;
+    if (idx == n - 1) return (f[(size_t)(n - 1) * stride] - f[(size_t)(n - 2) * stride]) / h;
+    return (f[(size_t)(idx + 1) * stride] - f[(size_t)(idx - 1) * stride]) / (2.0 * h);
+}
+
 // Everything that follows the physics of a step or a reset: TCP pose read-back, reward / termination
 // (edge_follow_env.py:371-452) and the camera<-stimulus transform handed to the raster (tactile_sensor.py:150-229).
 template <typename T, int TOPO>
@@ -88,9 +117,9 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
     { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
     st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
     st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
-    T se, ce;
-    tsincos(edge_ang, &se, &ce);
-    if (write_reward_done) {
+    T se = T(0), ce = T(1);   // stimulus yaw: edge angle for edge_follow, none for the surface
+    if (c.env_kind == TG_ENV_EDGE_FOLLOW) tsincos(edge_ang, &se, &ce);
+    if (write_reward_done && c.env_kind == TG_ENV_EDGE_FOLLOW) {
         const T gx = c.stim_pos[0] + c.edge_len * ce, gy = c.stim_pos[1] + c.edge_len * se;
         const T dx = ptcp.x - gx, dy = ptcp.y - gy;
         const T goal_dist = tsqrt(dx * dx + dy * dy);
@@ -102,6 +131,30 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         T reward;
         if (c.reward_mode == TG_REWARD_SPARSE) reward = goal_dist < c.term_dist ? T(1) : T(0);
         else reward = -((T(1) * goal_dist) + (T(10) * edge_dist) + T(0));
+        st.reward[env] = (float)reward;
+        st.done[env] = done ? 1 : 0;
+    }
+    if (write_reward_done && c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        // get_step_data / dense_reward (base_surface_env.py:664-684, 703-760; surface_follow_auto_env.py:75-94)
+        const int R = c.surf_rows, Cc = c.surf_cols;
+        int ti = digitize_linspace((double)ptcp.y, c.ybin_lo, c.ybin_hi, Cc);   // xy_to_surface_idx (:284-300)
+        int tj = digitize_linspace((double)ptcp.x, c.xbin_lo, c.xbin_hi, R);
+        if (ti == Cc) ti -= 1;
+        if (tj == R) tj -= 1;
+        const double* H = st.heights + (size_t)env * R * Cc;
+        const T surf_z = (T)(H[(size_t)ti * Cc + tj] + (double)c.stim_pos[2]);
+        const T gy_ = (T)grad_axis(H + tj, ti, R, Cc, c.surf_scale);               // np.gradient axis 0
+        const T gx_ = (T)grad_axis(H + (size_t)ti * Cc, tj, Cc, 1, c.surf_scale);  // axis 1
+        V3<T> nrm{-gx_, -gy_, T(1)};
+        nrm = (T(1) / norm(nrm)) * nrm;
+        const V3<T> tipv = mul(Rtcp, mk(T(0), T(0), T(-1)));
+        const V3<T> emb = mul(Rtcp, mk(T(0), T(0), -c.embed_default));
+        const T surf_dist = tabs((ptcp.z + emb.z) - surf_z);
+        const T cos_sim = dot(nrm, tipv) / (norm(nrm) * norm(tipv));
+        const T w_norm = (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_XYZ) ? T(0) : T(1);
+        const T reward = -((T(1) * surf_dist) + (w_norm * (T(1) - cos_sim)));
+        const T gdx = ptcp.x - (T)st.goal[0 * n + env], gdy = ptcp.y - (T)st.goal[1 * n + env], gdz = ptcp.z - (T)st.goal[2 * n + env];
+        const bool done = tsqrt(gdx * gdx + gdy * gdy + gdz * gdz) < c.term_dist || step_count >= c.max_steps;
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
     }
@@ -141,13 +194,20 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     T q[N], qd[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
-    // encode_actions (edge_follow_env.py:345-369)
     T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     const float* a = actions + (size_t)env * c.act_dim;
-    enc[0] = (T)a[0]; enc[1] = (T)a[1];
-    if (c.movement_mode == TG_MOVE_XYZ) enc[2] = (T)a[2];
-    else if (c.movement_mode == TG_MOVE_XYRZ) enc[5] = (T)a[2];
-    else if (c.movement_mode == TG_MOVE_XYZRZ) { enc[2] = (T)a[2]; enc[5] = (T)a[3]; }
+    if (c.env_kind == TG_ENV_EDGE_FOLLOW) {               // encode_actions (edge_follow_env.py:345-369)
+        enc[0] = (T)a[0]; enc[1] = (T)a[1];
+        if (c.movement_mode == TG_MOVE_XYZ) enc[2] = (T)a[2];
+        else if (c.movement_mode == TG_MOVE_XYRZ) enc[5] = (T)a[2];
+        else if (c.movement_mode == TG_MOVE_XYZRZ) { enc[2] = (T)a[2]; enc[5] = (T)a[3]; }
+    } else {                                              // surface_follow_auto_env.py:27-57: xy are driven toward the goal
+        enc[0] = (T)((st.dir[0 * n + env] * (double)c.max_action) * c.auto_scale);
+        enc[1] = (T)((st.dir[1 * n + env] * (double)c.max_action) * c.auto_scale);
+        enc[2] = (T)a[0];
+        if (c.movement_mode == TG_SMOVE_YZRX) enc[3] = (T)a[1];
+        else if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[1]; enc[4] = (T)a[2]; }
+    }
     // scale_actions (base_tactile_env.py:141-164)
     T vels[6];
     const T in_range = c.max_action - c.min_action;
@@ -269,7 +329,7 @@ __device__ __forceinline__ int inverse_kinematics(const DevRobot<T>& m, V3<T> tp
 // rest pose + IK to the start pose (base_robot_arm.py:191-226) + blocking_move (robot.py:188-260).
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                              const uint8_t* __restrict__ mask) {
+                                              const uint8_t* __restrict__ mask, int phase /*0 all, 1 task draws only, 2 robot only*/) {
     constexpr int N = Topo<TOPO>::N;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
@@ -278,21 +338,51 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
     if (env >= n) return;
     if (mask != nullptr && mask[env] == 0) return;
 
-    uint64_t rs = st.rng[env];
-    double embed = (double)c.embed_default;
-    if (c.noise_mode == TG_NOISE_RAND_HEIGHT) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
-    const double edge_ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
-    st.rng[env] = rs;
-    st.embed[env] = embed;
-    st.edge_ang[env] = edge_ang;
-    st.step_count[env] = 0;
+    double embed = (double)c.embed_default, edge_ang = 0.0;
+    if (phase != 2) {                                     // reset_task: identical draw order to the reference / oracle
+        uint64_t rs = st.rng[env];
+        if (c.env_kind == TG_ENV_EDGE_FOLLOW) {           // edge_follow_env.py:285-299, :237-241
+            if (c.noise_mode == TG_NOISE_RAND_HEIGHT) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
+            edge_ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+        } else {                                          // base_surface_env.py:448 (simplex seed), :520-534 (goal direction)
+            st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
+            const double ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+            st.dir[0 * n + env] = cos(ang);
+            st.dir[1 * n + env] = sin(ang);
+        }
+        st.rng[env] = rs;
+        st.embed[env] = embed;
+        st.edge_ang[env] = edge_ang;
+        st.step_count[env] = 0;
+        if (phase == 1) return;
+    } else {
+        embed = st.embed[env];
+        edge_ang = st.edge_ang[env];
+    }
+    V3<T> init_world = load_v3(c.work_pos) + mul(c.work_R, mk(T(0), T(0), (T)embed));   // edge: work-frame (0, 0, embed)
+    if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        const int R = c.surf_rows, Cc = c.surf_cols;
+        const double* H = st.heights + (size_t)env * R * Cc;
+        // make_goal (base_surface_env.py:518-575): goal on the surface, x_y_extent away along the drive direction
+        const V3<T> wd = mul(c.work_R, mk((T)st.dir[0 * n + env], (T)st.dir[1 * n + env], T(0)));
+        const double gx = (double)c.stim_pos[0] + c.surf_extent * (double)wd.x, gy = (double)c.stim_pos[1] + c.surf_extent * (double)wd.y;
+        int gi = digitize_linspace(gy, c.ybin_lo, c.ybin_hi, Cc), gj = digitize_linspace(gx, c.xbin_lo, c.xbin_hi, R);
+        if (gi == Cc) gi -= 1;
+        if (gj == R) gj -= 1;
+        st.goal[0 * n + env] = gx; st.goal[1 * n + env] = gy; st.goal[2 * n + env] = H[(size_t)gi * Cc + gj] + (double)c.stim_pos[2];
+        // update_init_pose (:590-613): above the surface centre, embed_dist deep, expressed in and back out of the work frame
+        const double hc = H[(size_t)(R / 2) * Cc + (Cc / 2)];
+        const V3<T> pw = mk(c.stim_pos[0], c.stim_pos[1], (T)((double)c.stim_pos[2] + hc - embed));
+        const V3<T> pwork = load_v3(c.work_inv_pos) + mul(c.work_Rinv, pw);
+        init_world = load_v3(c.work_pos) + mul(c.work_R, pwork);
+    }
 
     T q[N], qd[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
 
-    // start pose: work frame (0, 0, embed), rpy 0 -> world (workframe_to_worldframe, base_robot_arm.py:46-60)
-    const V3<T> tpos = load_v3(c.work_pos) + mul(c.work_R, mk(T(0), T(0), (T)embed));
+    // start pose in the world frame (workframe_to_worldframe, base_robot_arm.py:46-60), rpy 0 in the work frame
+    const V3<T> tpos = init_world;
     T trpy[3];
     euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
     const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
@@ -572,12 +662,32 @@ static int check_robot(const tg_robot* r) {
 template <typename T> static int build_env_const(const tg_config& cfg, const tg_sensor& sen, EnvConst<T>& c) {
     memset(&c, 0, sizeof c);
     c.num_envs = cfg.num_envs;
+    c.env_kind = cfg.env_kind;
     c.movement_mode = cfg.movement_mode; c.noise_mode = cfg.noise_mode; c.reward_mode = cfg.reward_mode;
-    switch (cfg.movement_mode) {
-        case TG_MOVE_XY: c.act_dim = 2; break;
-        case TG_MOVE_XYZ: case TG_MOVE_XYRZ: c.act_dim = 3; break;
-        case TG_MOVE_XYZRZ: c.act_dim = 4; break;
-        default: return fail(-1, "Incorrect movement mode specified");
+    if (cfg.env_kind == TG_ENV_EDGE_FOLLOW) {
+        switch (cfg.movement_mode) {     // get_act_dim, edge_follow_env.py:478-486
+            case TG_MOVE_XY: c.act_dim = 2; break;
+            case TG_MOVE_XYZ: case TG_MOVE_XYRZ: c.act_dim = 3; break;
+            case TG_MOVE_XYZRZ: c.act_dim = 4; break;
+            default: return fail(-1, "Incorrect movement mode specified");
+        }
+    } else {
+        switch (cfg.movement_mode) {     // surface_follow_auto_env.py:96-107
+            case TG_SMOVE_YZ: case TG_SMOVE_XYZ: c.act_dim = 1; break;
+            case TG_SMOVE_YZRX: c.act_dim = 2; break;
+            case TG_SMOVE_XYZRXRY: c.act_dim = 3; break;
+            default: return fail(-1, "Incorrect movement mode specified");
+        }
+        if (cfg.reward_mode != TG_REWARD_DENSE) return fail(-1, "surface_follow: only the dense reward is built");
+        if (cfg.surf_rows < 2 || cfg.surf_cols < 2) return fail(-1, "surface_follow: heightfield needs at least 2x2 samples");
+        c.surf_rows = cfg.surf_rows; c.surf_cols = cfg.surf_cols;
+        c.surf_scale = cfg.surf_grid_scale; c.surf_range = cfg.surf_height_range; c.surf_interp = cfg.surf_interp;
+        c.surf_extent = cfg.surf_xy_extent; c.auto_scale = cfg.auto_action_scale;
+        // x_bins / y_bins = linspace(pos -+ (n/2) * grid_scale, n)   (base_surface_env.py:272-282)
+        c.xbin_lo = cfg.stim_pos[0] - ((cfg.surf_rows / 2.0) * cfg.surf_grid_scale);
+        c.xbin_hi = cfg.stim_pos[0] + ((cfg.surf_rows / 2.0) * cfg.surf_grid_scale);
+        c.ybin_lo = cfg.stim_pos[1] - ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
+        c.ybin_hi = cfg.stim_pos[1] + ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
     }
     c.max_steps = cfg.max_steps; c.action_repeat = cfg.action_repeat; c.solver_iters = cfg.solver_iterations;
     c.dt = (T)cfg.sim_dt; c.min_action = (T)cfg.min_action; c.max_action = (T)cfg.max_action;
@@ -619,6 +729,7 @@ struct tg_ctx {
     uint8_t *d_border = nullptr, *d_obs = nullptr, *d_term = nullptr, *d_mask = nullptr;
     int32_t* d_tris = nullptr;
     int n_tris = 0;
+    tg::Stimulus stim{};
     // profiling
     bool profile = false;
     struct Ev { hipEvent_t a, b; int which; };
@@ -656,10 +767,10 @@ template <typename T, int TOPO> static void launch_step_t(tg_ctx* c, const float
     hipLaunchKernelGGL((k_step<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
                        (const EnvConst<T>*)c->d_const, c->st, d_actions);
 }
-template <typename T, int TOPO> static void launch_reset_t(tg_ctx* c, const uint8_t* d_mask) {
+template <typename T, int TOPO> static void launch_reset_t(tg_ctx* c, const uint8_t* d_mask, int phase) {
     const int n = c->cfg.num_envs;
     hipLaunchKernelGGL((k_reset<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st, d_mask);
+                       (const EnvConst<T>*)c->d_const, c->st, d_mask, phase);
 }
 template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
     const int n = c->cfg.num_envs;
@@ -678,7 +789,7 @@ template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
 
 static void render(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
     Timer t(c, d_mask ? 3 : 1);
-    launch_render(c->rp, c->d_verts, c->d_tris, c->n_tris, c->st.stim_xform, 1, c->cfg.num_envs, d_mask, c->d_nodef_dep, c->d_nodef_gray,
+    launch_render(c->rp, c->stim, c->st.stim_xform, 1, c->cfg.num_envs, d_mask, c->d_nodef_dep, c->d_nodef_gray,
                   c->d_border, c->d_obs, save_prev ? c->d_term : nullptr, c->stream);
 }
 
@@ -715,6 +826,26 @@ static int need_device() {
     return 0;
 }
 
+
+// env.reset() for the masked envs: task randomisation, (surface generation), robot reset.
+static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
+    Timer t(c, 2);
+    if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 1)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+        launch_gen_surface(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
+                           c->cfg.surf_height_range, c->cfg.surf_center_z, c->st.heights, c->st.surf_zoff, c->stream);
+#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 2)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    } else {
+#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 0)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -725,9 +856,10 @@ const char* tg_last_error(void) { return g_err.c_str(); }
 int tg_abi_version(void) { return TG_ABI_VERSION; }
 
 int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sensor, const tg_mesh* stim, tg_ctx** out) {
-    if (!cfg || !robot || !sensor || !stim || !out) return fail(-1, "tg_create: NULL argument");
+    if (!cfg || !robot || !sensor || !out) return fail(-1, "tg_create: NULL argument");
     if (cfg->abi_version != TG_ABI_VERSION) return fail(-1, "tg_create: ABI version mismatch");
-    if (cfg->env_kind != TG_ENV_EDGE_FOLLOW) return fail(-1, "tg_create: unknown env_kind");
+    if (cfg->env_kind != TG_ENV_EDGE_FOLLOW && cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO) return fail(-1, "tg_create: unknown env_kind");
+    if (cfg->env_kind == TG_ENV_EDGE_FOLLOW && !stim) return fail(-1, "tg_create: edge_follow needs a stimulus mesh");
     if (cfg->num_envs <= 0) return fail(-1, "tg_create: num_envs must be positive");
     if (int rc = check_robot(robot)) return rc;
     const int H = sensor->image_h, W = sensor->image_w;
@@ -778,9 +910,21 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&c->d_nodef_dep, npix * 4)); TG_HIP(hipMemcpy(c->d_nodef_dep, sensor->nodef_dep, npix * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMalloc(&c->d_nodef_gray, npix * 4)); TG_HIP(hipMemcpy(c->d_nodef_gray, sensor->nodef_gray, npix * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMalloc(&c->d_border, npix)); TG_HIP(hipMemcpy(c->d_border, sensor->border_mask, npix, hipMemcpyHostToDevice));
-    TG_HIP(hipMalloc(&c->d_verts, (size_t)stim->n_verts * 12)); TG_HIP(hipMemcpy(c->d_verts, stim->verts, (size_t)stim->n_verts * 12, hipMemcpyHostToDevice));
-    TG_HIP(hipMalloc(&c->d_tris, (size_t)stim->n_tris * 12)); TG_HIP(hipMemcpy(c->d_tris, stim->tris, (size_t)stim->n_tris * 12, hipMemcpyHostToDevice));
-    c->n_tris = stim->n_tris;
+    if (cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        const size_t cells = (size_t)cfg->surf_rows * cfg->surf_cols;
+        TG_HIP(hipMalloc(&s.dir, 2 * n * 8)); TG_HIP(hipMalloc(&s.goal, 3 * n * 8)); TG_HIP(hipMalloc(&s.heights, cells * n * 8));
+        TG_HIP(hipMalloc(&s.surf_zoff, n * 4)); TG_HIP(hipMalloc(&s.noise_seed, n * 8));
+        TG_HIP(hipMemset(s.dir, 0, 2 * n * 8)); TG_HIP(hipMemset(s.goal, 0, 3 * n * 8)); TG_HIP(hipMemset(s.heights, 0, cells * n * 8));
+        TG_HIP(hipMemset(s.surf_zoff, 0, n * 4)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8));
+        c->stim.kind = 1; c->stim.heights = s.heights; c->stim.zoff = s.surf_zoff;
+        c->stim.rows = cfg->surf_rows; c->stim.cols = cfg->surf_cols; c->stim.scale = (float)cfg->surf_grid_scale;
+        c->stim.n_tris = (cfg->surf_rows - 1) * (cfg->surf_cols - 1) * 2;
+    } else {
+        TG_HIP(hipMalloc(&c->d_verts, (size_t)stim->n_verts * 12)); TG_HIP(hipMemcpy(c->d_verts, stim->verts, (size_t)stim->n_verts * 12, hipMemcpyHostToDevice));
+        TG_HIP(hipMalloc(&c->d_tris, (size_t)stim->n_tris * 12)); TG_HIP(hipMemcpy(c->d_tris, stim->tris, (size_t)stim->n_tris * 12, hipMemcpyHostToDevice));
+        c->n_tris = stim->n_tris;
+        c->stim.kind = 0; c->stim.verts = c->d_verts; c->stim.tris = c->d_tris; c->stim.n_tris = stim->n_tris;
+    }
     TG_HIP(hipMalloc(&c->d_obs, npix * n)); TG_HIP(hipMemset(c->d_obs, 0, npix * n));
     TG_HIP(hipMalloc(&c->d_term, npix * n)); TG_HIP(hipMemset(c->d_term, 0, npix * n));
     TG_HIP(hipMalloc(&c->d_mask, n));
@@ -796,7 +940,7 @@ int tg_destroy(tg_ctx* c) {
     drain_events(c);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.reward,
-                    s.step_count, s.reset_ticks, s.rng, s.done, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
+                    s.step_count, s.reset_ticks, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -827,12 +971,7 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
         TG_HIP(hipMemcpyAsync(c->d_mask, host_mask, c->cfg.num_envs, hipMemcpyHostToDevice, c->stream));
         dmask = c->d_mask;
     }
-    {
-        Timer t(c, 2);
-#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, dmask)
-        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
-#undef CALL
-    }
+    reset_sequence(c, dmask);
     render(c, dmask, false);
     TG_HIP(hipGetLastError());
     return 0;
@@ -853,12 +992,7 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     }
     render(c, nullptr, false);
     if (c->cfg.auto_reset) {
-        {
-            Timer t(c, 2);
-#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, c->st.done)
-            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
-#undef CALL
-        }
+        reset_sequence(c, c->st.done);
         render(c, c->st.done, true);   // terminal observation is saved, then the post-reset observation is drawn
     }
     TG_HIP(hipGetLastError());
@@ -909,6 +1043,15 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
     if (v->step_count && (rc = fetch_soa(c, c->st.step_count, 1, v->step_count))) return rc;
     if (v->reset_ticks && (rc = fetch_soa(c, c->st.reset_ticks, 1, v->reset_ticks))) return rc;
     if (v->rng_state && (rc = fetch_soa(c, c->st.rng, 1, v->rng_state))) return rc;
+    if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        if (v->goal_pos && (rc = fetch_soa(c, c->st.goal, 3, v->goal_pos))) return rc;
+        if (v->direction && (rc = fetch_soa(c, c->st.dir, 2, v->direction))) return rc;
+        if (v->surf_zoff && (rc = fetch_soa(c, c->st.surf_zoff, 1, v->surf_zoff))) return rc;
+        if (v->heights) {
+            TG_HIP(hipMemcpyAsync(v->heights, c->st.heights, (size_t)c->cfg.num_envs * c->cfg.surf_rows * c->cfg.surf_cols * 8, hipMemcpyDeviceToHost, c->stream));
+            TG_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
     return 0;
 }
 
@@ -1052,10 +1195,51 @@ int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, cons
     TG_HIP(hipMemcpy(xx.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
     TG_HIP(hipMemset(oo.p, 0, npix * n));
     RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
-    launch_render(P, (const float*)vv.p, (const int32_t*)tt.p, mesh->n_tris, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p,
-                  (const float*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
+    Stimulus S{};
+    S.kind = 0; S.verts = (const float*)vv.p; S.tris = (const int32_t*)tt.p; S.n_tris = mesh->n_tris;
+    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const float*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tg_render_tactile_heightfield(const tg_sensor* sen, int32_t rows, int32_t cols, double grid_scale, int32_t n, const double* heights,
+                                  const float* zoff, const float* xf, uint8_t* out) {
+    if (!sen || !heights || !zoff || !xf || !out) return fail(-1, "NULL argument");
+    if (int rc = need_device()) return rc;
+    const int H = sen->image_h, W = sen->image_w;
+    if (!((H % 128 == 0 && W % 128 == 0) || (H == 64 && W == 64))) return fail(-1, "image size must be 64x64 or a multiple of 128");
+    const size_t npix = (size_t)H * W, cells = (size_t)rows * cols;
+    DevBuf nd, ng, bm, hh, zz, xx, oo;
+    if (nd.alloc(npix * 4) || ng.alloc(npix * 4) || bm.alloc(npix) || hh.alloc(cells * n * 8) || zz.alloc((size_t)n * 4) || xx.alloc((size_t)n * 48) ||
+        oo.alloc(npix * n))
+        return fail(-2, "hipMalloc failed");
+    TG_HIP(hipMemcpy(nd.p, sen->nodef_dep, npix * 4, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(ng.p, sen->nodef_gray, npix * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(bm.p, sen->border_mask, npix, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(hh.p, heights, cells * n * 8, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(zz.p, zoff, (size_t)n * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(xx.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
+    TG_HIP(hipMemset(oo.p, 0, npix * n));
+    RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
+    Stimulus S{};
+    S.kind = 1; S.heights = (const double*)hh.p; S.zoff = (const float*)zz.p; S.rows = rows; S.cols = cols; S.scale = (float)grid_scale;
+    S.n_tris = (rows - 1) * (cols - 1) * 2;
+    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const float*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
+    TG_HIP(hipDeviceSynchronize());
+    TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tg_gen_heightfield(int32_t n, const int64_t* seeds, int32_t rows, int32_t cols, double interp, double range, double* heights, float* zoff) {
+    if (!seeds || !heights) return fail(-1, "NULL argument");
+    if (int rc = need_device()) return rc;
+    const size_t cells = (size_t)rows * cols;
+    DevBuf sd, hh, zz;
+    if (sd.alloc((size_t)n * 8) || hh.alloc(cells * n * 8) || zz.alloc((size_t)n * 4)) return fail(-2, "hipMalloc failed");
+    TG_HIP(hipMemcpy(sd.p, seeds, (size_t)n * 8, hipMemcpyHostToDevice));
+    launch_gen_surface(n, nullptr, (const int64_t*)sd.p, rows, cols, interp, range, 1, (double*)hh.p, (float*)zz.p, 0);
+    TG_HIP(hipDeviceSynchronize());
+    TG_HIP(hipMemcpy(heights, hh.p, cells * n * 8, hipMemcpyDeviceToHost));
+    if (zoff) TG_HIP(hipMemcpy(zoff, zz.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -1,0 +1,122 @@
+// tg_noise.hip — per-episode surface generation for surface_follow (gfx950).
+//
+// Replaces BaseSurfaceEnv.update_surface -> gen_heigtfield_simplex_2d (reference
+// tactile_gym/rl_envs/exploration/surface_follow/base_surface_env.py:319-337, :434-452): a 64x64 heightfield
+// height[x][y] = OpenSimplex(seed).noise2(x*0.05, y*0.05) * 0.025 per env and episode.  The noise itself lives in the
+// third-party `opensimplex` package (requirements.txt:4, unpinned); its published algorithm is restated here and,
+// independently, in oracle/minibullet.c.  COMPILED WITH -ffp-contract=off: all arithmetic is IEEE double without
+// fused multiply-adds, so the heights are bit-identical to the CPU oracle's.
+//
+// One 256-thread workgroup per resetting env: lane 0 builds the 256-entry permutation in LDS (a serial 64-bit LCG
+// shuffle, 256 steps), then every lane evaluates rows*cols/256 samples; min/max for Bullet's vertical centring of the
+// heightfield shape are reduced through LDS.  Envs whose mask byte is 0 exit immediately.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tg_noise.h"
+
+namespace tg {
+
+__device__ __constant__ int8_t kGrad2[16] = {5, 2, 2, 5, -5, 2, -2, 5, 5, -2, 2, -5, -5, -2, -2, -5};
+constexpr double kStretch2D = -0.211324865405187;
+constexpr double kSquish2D = 0.366025403784439;
+constexpr double kNorm2D = 47.0;
+
+__device__ __forceinline__ double extrapolate2(const int16_t* perm, long long xsb, long long ysb, double dx, double dy) {
+    const int index = perm[(perm[xsb & 0xFF] + ysb) & 0xFF] & 0x0E;
+    return (double)kGrad2[index] * dx + (double)kGrad2[index + 1] * dy;
+}
+
+__device__ double opensimplex_noise2(const int16_t* perm, double x, double y) {
+    const double stretch = (x + y) * kStretch2D;
+    const double xs = x + stretch, ys = y + stretch;
+    const double fxs = floor(xs), fys = floor(ys);
+    long long xsb = (long long)fxs, ysb = (long long)fys;
+    const double squish = (fxs + fys) * kSquish2D;
+    const double xb = fxs + squish, yb = fys + squish;
+    const double xins = xs - fxs, yins = ys - fys;
+    const double in_sum = xins + yins;
+    double dx0 = x - xb, dy0 = y - yb;
+    double value = 0.0, dx_ext, dy_ext;
+    long long xsv_ext, ysv_ext;
+    const double dx1 = dx0 - 1.0 - kSquish2D, dy1 = dy0 - 0.0 - kSquish2D;
+    double attn1 = 2.0 - dx1 * dx1 - dy1 * dy1;
+    if (attn1 > 0.0) { attn1 *= attn1; value += attn1 * attn1 * extrapolate2(perm, xsb + 1, ysb + 0, dx1, dy1); }
+    const double dx2 = dx0 - 0.0 - kSquish2D, dy2 = dy0 - 1.0 - kSquish2D;
+    double attn2 = 2.0 - dx2 * dx2 - dy2 * dy2;
+    if (attn2 > 0.0) { attn2 *= attn2; value += attn2 * attn2 * extrapolate2(perm, xsb + 0, ysb + 1, dx2, dy2); }
+    if (in_sum <= 1.0) {
+        const double zins = 1.0 - in_sum;
+        if (zins > xins || zins > yins) {
+            if (xins > yins) { xsv_ext = xsb + 1; ysv_ext = ysb - 1; dx_ext = dx0 - 1.0; dy_ext = dy0 + 1.0; }
+            else { xsv_ext = xsb - 1; ysv_ext = ysb + 1; dx_ext = dx0 + 1.0; dy_ext = dy0 - 1.0; }
+        } else {
+            xsv_ext = xsb + 1; ysv_ext = ysb + 1;
+            dx_ext = dx0 - 1.0 - 2.0 * kSquish2D; dy_ext = dy0 - 1.0 - 2.0 * kSquish2D;
+        }
+    } else {
+        const double zins = 2.0 - in_sum;
+        if (zins < xins || zins < yins) {
+            if (xins > yins) { xsv_ext = xsb + 2; ysv_ext = ysb + 0; dx_ext = dx0 - 2.0 - 2.0 * kSquish2D; dy_ext = dy0 + 0.0 - 2.0 * kSquish2D; }
+            else { xsv_ext = xsb + 0; ysv_ext = ysb + 2; dx_ext = dx0 + 0.0 - 2.0 * kSquish2D; dy_ext = dy0 - 2.0 - 2.0 * kSquish2D; }
+        } else { dx_ext = dx0; dy_ext = dy0; xsv_ext = xsb; ysv_ext = ysb; }
+        xsb += 1; ysb += 1;
+        dx0 = dx0 - 1.0 - 2.0 * kSquish2D; dy0 = dy0 - 1.0 - 2.0 * kSquish2D;
+    }
+    double attn0 = 2.0 - dx0 * dx0 - dy0 * dy0;
+    if (attn0 > 0.0) { attn0 *= attn0; value += attn0 * attn0 * extrapolate2(perm, xsb, ysb, dx0, dy0); }
+    double attn_ext = 2.0 - dx_ext * dx_ext - dy_ext * dy_ext;
+    if (attn_ext > 0.0) { attn_ext *= attn_ext; value += attn_ext * attn_ext * extrapolate2(perm, xsv_ext, ysv_ext, dx_ext, dy_ext); }
+    return value / kNorm2D;
+}
+
+// grid: n_envs blocks of 256 threads
+__global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ seeds, int rows,
+                                                     int cols, double interp, double range, int center_z, double* __restrict__ heights,
+                                                     float* __restrict__ zoff) {
+    __shared__ int16_t perm[256];
+    __shared__ int16_t source[256];
+    __shared__ float red_min[256], red_max[256];
+    const int env = blockIdx.x, tid = threadIdx.x;
+    if (env >= n_envs || (mask != nullptr && mask[env] == 0)) return;
+    source[tid] = (int16_t)tid;
+    __syncthreads();
+    if (tid == 0) {   // OpenSimplex.__init__: three warm-up LCG steps, then a Fisher-Yates style draw without replacement
+        unsigned long long s = (unsigned long long)seeds[env];
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        for (int i = 255; i >= 0; --i) {
+            s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+            const long long v = (long long)(s + 31ULL);
+            long long r = v % (long long)(i + 1);
+            if (r < 0) r += (i + 1);
+            perm[i] = source[r];
+            source[r] = source[i];
+        }
+    }
+    __syncthreads();
+    double* out = heights + (size_t)env * rows * cols;
+    float lo = 3.0e38f, hi = -3.0e38f;
+    for (int k = tid; k < rows * cols; k += 256) {
+        const int x = k / cols, y = k % cols;       // heightfield_data[x, y], base_surface_env.py:327-335
+        const double h = opensimplex_noise2(perm, (double)x * interp, (double)y * interp) * range;
+        out[k] = h;
+        const float hf = (float)h;                  // Bullet receives the samples as float (PHY_FLOAT)
+        lo = fminf(lo, hf); hi = fmaxf(hi, hf);
+    }
+    red_min[tid] = lo; red_max[tid] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { red_min[tid] = fminf(red_min[tid], red_min[tid + s]); red_max[tid] = fmaxf(red_max[tid], red_max[tid + s]); }
+        __syncthreads();
+    }
+    if (tid == 0 && zoff != nullptr) zoff[env] = center_z ? 0.5f * (red_min[0] + red_max[0]) : 0.0f;
+}
+
+void launch_gen_surface(int n_envs, const uint8_t* mask, const int64_t* seeds, int rows, int cols, double interp, double range, int center_z,
+                        double* heights, float* zoff, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gen_surface, dim3(n_envs), dim3(256), 0, stream, n_envs, mask, seeds, rows, cols, interp, range, center_z, heights, zoff);
+}
+
+}  // namespace tg

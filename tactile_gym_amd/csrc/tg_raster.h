@@ -16,9 +16,25 @@ struct RasterParams {
     int turn_off_border;
 };
 
+// What the tactile camera looks at: a triangle mesh shared by all envs (edge, cube, ...) placed by a per-env rigid
+// transform, or a per-env heightfield (surface_follow: createCollisionShape(GEOM_HEIGHTFIELD), base_surface_env.py:402-432)
+// whose vertices are synthesised from the height samples:  vertex (i, j) = ((i - (rows-1)/2) s, (j - (cols-1)/2) s,
+// h[j*rows + i] - zoff), cell (i, j) split into (i,j),(i,j+1),(i+1,j) and (i+1,j),(i,j+1),(i+1,j+1)
+// [btHeightfieldTerrainShape::getVertex / processAllTriangles, PARITY_ASSUMPTIONS A15-A16].
+struct Stimulus {
+    int kind;                 // 0 mesh, 1 heightfield
+    const float* verts;       // mesh
+    const int32_t* tris;
+    int n_tris;
+    const double* heights;    // heightfield: [n_envs][rows*cols]
+    const float* zoff;        // [n_envs]
+    int rows, cols;
+    float scale;
+};
+
 RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border, const float* nodef_dep_host);
 
-void launch_render(const RasterParams& P, const float* verts, const int32_t* tris, int n_tris, const float* xform, int xform_soa, int n_envs,
+void launch_render(const RasterParams& P, const Stimulus& stim, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const float* nodef_gray, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, hipStream_t stream);
 

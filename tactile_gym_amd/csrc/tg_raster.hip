@@ -77,8 +77,7 @@ __device__ __forceinline__ void emit(TriRec* recs, int* count, const float* vx, 
 
 // grid: (tiles_x * tiles_y, num_envs); block: 256.  TW = tile edge (128, or 64 for 64x64 images).
 template <int TW>
-__global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, const float* __restrict__ verts, const int32_t* __restrict__ tris,
-                                                             int n_tris, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
+__global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ nodef_dep, const float* __restrict__ nodef_gray,
                                                              const uint8_t* __restrict__ border, uint8_t* __restrict__ out,
@@ -91,6 +90,10 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, con
     __shared__ int count;
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
+    const int n_tris = S.n_tris;
+    const float hf_zoff = (S.kind == 1) ? S.zoff[env] : 0.0f;
+    const double* hf = (S.kind == 1) ? S.heights + (size_t)env * S.rows * S.cols : nullptr;
+    const float hf_cx = 0.5f * (float)(S.rows - 1), hf_cy = 0.5f * (float)(S.cols - 1);
     const int tiles_x = P.W / kTile;
     const int tile_x = (blockIdx.x % tiles_x) * kTile, tile_y = (blockIdx.x / tiles_x) * kTile;
     const int tid = threadIdx.x;
@@ -120,8 +123,21 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, con
             float cx[3], cy[3], cw[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float* v = verts + 3 * tris[3 * t + k];
-                const float vx = v[0], vy = v[1], vz = v[2];
+                float vx, vy, vz;
+                if (S.kind == 1) {
+                    const int cell = t >> 1, half = t & 1;
+                    const int ci = cell % (S.rows - 1), cj = cell / (S.rows - 1);
+                    // half 0: (i,j),(i,j+1),(i+1,j)   half 1: (i+1,j),(i,j+1),(i+1,j+1)
+                    const int di = half == 0 ? (k == 2) : (k != 1);
+                    const int dj = half == 0 ? (k == 1) : (k != 0);
+                    const int vi = ci + di, vj = cj + dj;
+                    vx = ((float)vi - hf_cx) * S.scale;
+                    vy = ((float)vj - hf_cy) * S.scale;
+                    vz = (float)hf[(size_t)vj * S.rows + vi] - hf_zoff;
+                } else {
+                    const float* v = S.verts + 3 * S.tris[3 * t + k];
+                    vx = v[0]; vy = v[1]; vz = v[2];
+                }
                 cx[k] = ((M[0] * vx + M[1] * vy) + M[2] * vz) + M[9];
                 cy[k] = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
                 cw[k] = -(((M[6] * vx + M[7] * vy) + M[8] * vz) + M[11]);
@@ -203,16 +219,16 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, con
     }
 }
 
-void launch_render(const RasterParams& P, const float* verts, const int32_t* tris, int n_tris, const float* xform, int xform_soa, int n_envs,
+void launch_render(const RasterParams& P, const Stimulus& S, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const float* nodef_gray, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, hipStream_t stream) {
     if (P.W % 128 == 0 && P.H % 128 == 0) {
         dim3 grid((P.W / 128) * (P.H / 128), n_envs);
-        hipLaunchKernelGGL(k_render_tactile<128>, grid, dim3(kThreads), 0, stream, P, verts, tris, n_tris, xform, xform_soa, n_envs, mask,
+        hipLaunchKernelGGL(k_render_tactile<128>, grid, dim3(kThreads), 0, stream, P, S, xform, xform_soa, n_envs, mask,
                            nodef_dep, nodef_gray, border, out, save_prev);
     } else {  // 64x64 images
         dim3 grid((P.W / 64) * (P.H / 64), n_envs);
-        hipLaunchKernelGGL(k_render_tactile<64>, grid, dim3(kThreads), 0, stream, P, verts, tris, n_tris, xform, xform_soa, n_envs, mask,
+        hipLaunchKernelGGL(k_render_tactile<64>, grid, dim3(kThreads), 0, stream, P, S, xform, xform_soa, n_envs, mask,
                            nodef_dep, nodef_gray, border, out, save_prev);
     }
 }

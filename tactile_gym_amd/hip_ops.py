@@ -84,3 +84,26 @@ def render_tactile(sensor_desc, mesh_desc, cam_from_obj):
     capi.check(capi.lib().tg_render_tactile(C.byref(sensor_desc.struct), C.byref(mesh_desc.struct), n,
                                             xf.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_uint8))))
     return out
+
+
+def gen_heightfield(seeds, rows=64, cols=64, interp=0.05, height_range=0.025):
+    """gen_heigtfield_simplex_2d (base_surface_env.py:319-337) on the device: (heights [n,rows,cols] f64, zoff [n] f32)."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    n = seeds.shape[0]
+    h, z = np.zeros((n, rows, cols)), np.zeros(n, dtype=np.float32)
+    capi.check(capi.lib().tg_gen_heightfield(n, seeds.ctypes.data_as(C.POINTER(C.c_int64)), rows, cols, float(interp), float(height_range),
+                                             _dp(h), z.ctypes.data_as(C.POINTER(C.c_float))))
+    return h, z
+
+
+def render_tactile_heightfield(sensor_desc, heights, zoff, cam_from_obj, grid_scale=0.006):
+    """Tactile image of per-image heightfields (base_surface_env.py:402-432 + tactile_sensor.py:239-294)."""
+    h = np.ascontiguousarray(heights, dtype=np.float64)
+    n, rows, cols = h.shape
+    z = np.ascontiguousarray(zoff, dtype=np.float32).reshape(n)
+    xf = np.ascontiguousarray(cam_from_obj, dtype=np.float32).reshape(n, 12)
+    out = np.zeros((n, sensor_desc.struct.image_h, sensor_desc.struct.image_w), dtype=np.uint8)
+    capi.check(capi.lib().tg_render_tactile_heightfield(C.byref(sensor_desc.struct), rows, cols, float(grid_scale), n, _dp(h),
+                                                        z.ctypes.data_as(C.POINTER(C.c_float)), xf.ctypes.data_as(C.POINTER(C.c_float)),
+                                                        out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out

@@ -1,0 +1,134 @@
+"""surface_follow-v0 (auto-drive variant) on the HIP path.
+
+Reference: tactile_gym/rl_envs/exploration/surface_follow/base_surface_env.py (surface generation, goal, rewards) and
+surface_follow_auto/surface_follow_auto_env.py (action encoding, dense reward).  -v1 (goal features) and -v2 (vertical
+surface, `forward` sensor) are registered but not built yet.
+"""
+import math
+
+import numpy as np
+
+from .. import _capi as capi
+from ..robot_model import SensorDesc, load_tgmodel, make_robot
+from ..vec_env import TactileVecEnv
+
+# surface_follow/rest_poses.py (movable joints): every ur5 "standard" entry holds the same pose
+REST_POSES = {"ur5": {k: {"standard": [0.16682, -2.18943, -1.65357, -0.86897, 1.57315, 1.74001]} for k in ("tactip", "digit", "digitac")}}
+
+env_modes_default = {  # surface_follow_auto_env.py:6-12
+    "movement_mode": "xyzRxRy",
+    "control_mode": "TCP_velocity_control",
+    "noise_mode": "simplex",
+    "observation_mode": "oracle",
+    "reward_mode": "dense",
+}
+
+
+def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64", auto_reset=True, device=0):
+    modes = dict(env_modes)
+    for k in ("movement_mode", "control_mode", "noise_mode", "observation_mode", "reward_mode", "arm_type", "tactile_sensor_name"):
+        if k not in modes:
+            raise KeyError(k)                                                                   # base_surface_env.py:33-63
+    arm, t_s_name = modes["arm_type"], modes["tactile_sensor_name"]
+    if modes["noise_mode"] == "vertical_simplex":
+        raise NotImplementedError("vertical surfaces (surface_follow-v2, `forward` sensor) are not built yet")
+    if modes["noise_mode"] != "simplex":
+        if modes["noise_mode"] in ("none", "random"):
+            raise NotImplementedError(f"noise_mode {modes['noise_mode']} is not built yet (BASELINE config 3 uses simplex)")
+        raise SystemExit("Incorrect noise mode specified")                                      # :466
+    if modes["movement_mode"] not in capi.SMOVE:
+        raise SystemExit("Incorrect movement mode specified")
+    if modes["movement_mode"] in ("yz", "yzRx"):
+        raise NotImplementedError("1-D surfaces (yz / yzRx) are not built yet")
+    if modes["control_mode"] != "TCP_velocity_control":
+        if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
+            raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
+        raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")
+    if arm != "ur5":
+        if arm in ("mg400", "franka_panda", "kuka_iiwa"):
+            raise NotImplementedError(f"arm_type {arm} is not built yet for surface_follow")
+        raise SystemExit(f"Incorrect arm type specified {arm}")
+    if modes["reward_mode"] != "dense":
+        raise NotImplementedError("only the dense reward is built for surface_follow")
+    t_s_type = "standard"                                                                       # :60-63
+    cfg = capi.TgConfig()
+    cfg.abi_version, cfg.env_kind = capi.ABI_VERSION, capi.ENV_SURFACE_FOLLOW_AUTO
+    cfg.num_envs, cfg.max_steps = int(num_envs), int(max_steps)
+    cfg.movement_mode, cfg.noise_mode, cfg.reward_mode = capi.SMOVE[modes["movement_mode"]], 0, capi.REWARD["dense"]
+    cfg.physics_dtype = capi.PHYSICS[physics_dtype]
+    cfg.sim_dt = 1.0 / 240.0                                                                    # :26
+    cfg.action_repeat = int(np.floor((1.0 / 10.0) / cfg.sim_dt))                                # :27-28
+    cfg.solver_iterations = 150
+    cfg.auto_reset, cfg.device = int(auto_reset), int(device)
+    cfg.min_action, cfg.max_action = -0.25, 0.25                                                # :160
+    v, w = 0.01, 5.0 * (math.pi / 180)                                                          # :186-194
+    lo, hi = [-v, -v, -v, -w, -w, 0.0], [v, v, v, w, w, 0.0]
+    height_range, extent = 0.025, 0.15                                                          # :239,245
+    lims = [(-extent, extent), (-extent, extent), (-height_range, height_range), (-math.pi / 4, math.pi / 4),
+            (-math.pi / 4, math.pi / 4), (0.0, 0.0)]                                            # :112-123
+    for d in range(6):
+        cfg.act_lo[d], cfg.act_hi[d] = lo[d], hi[d]
+        cfg.tcp_lims[d][0], cfg.tcp_lims[d][1] = lims[d]
+    surface_pos = (0.65, 0.0, height_range)                                                     # :57,266
+    wf_rpy = (-math.pi, 0.0, math.pi / 2)                                                       # :108-109
+    for k in range(3):
+        cfg.workframe_pos[k], cfg.workframe_rpy[k], cfg.stim_pos[k] = surface_pos[k], wf_rpy[k], surface_pos[k]
+    cfg.termination_dist = 0.01                                                                 # :79
+    cfg.embed_dist = {"tactip": 0.0025, "digitac": 0.0015, "digit": 0.0015}[t_s_name]           # :66-75
+    cfg.surf_rows, cfg.surf_cols, cfg.surf_center_z = 64, 64, 1                                 # :240-243
+    cfg.surf_grid_scale, cfg.surf_height_range, cfg.surf_interp, cfg.surf_xy_extent = 0.006, height_range, 0.05, extent
+    cfg.auto_action_scale = {"tactip": 1.0, "digitac": 0.9, "digit": 0.7}[t_s_name]             # surface_follow_auto_env.py:33-41
+    tg = load_tgmodel(arm, t_s_type, t_s_name)
+    robot = make_robot(tg, REST_POSES[arm][t_s_name][t_s_type], t_s_name)
+    sensor = SensorDesc(t_s_name, t_s_type, image_size, turn_off_border=False)
+    return cfg, robot, sensor, modes
+
+
+class SurfaceFollowAutoVecEnv(TactileVecEnv):
+    def __init__(self, num_envs, max_steps=200, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
+                 device=0, obs_mode="numpy", seed=None):
+        cfg, robot, sensor, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
+        self.env_modes = modes
+        self.min_action, self.max_action = cfg.min_action, cfg.max_action
+        act_dim = {"xyz": 1, "xyzRxRy": 3}[modes["movement_mode"]]                              # surface_follow_auto_env.py:96-107
+        super().__init__(cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+                         act_dim=act_dim, oracle_dim=21)
+
+    def oracle_obs(self):
+        raise NotImplementedError("oracle observation vector for surface_follow is not built yet (SURVEY 8f rank 1)")
+
+
+class SurfaceFollowAutoEnv:
+    """Single-env gym.Env surface; constructor signature as surface_follow_auto_env.py:16-25."""
+
+    metadata = {"render.modes": ["rgb_array"]}
+
+    def __init__(self, max_steps=200, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
+                 physics_dtype="f64", device=0):
+        if show_gui or show_tactile:
+            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
+        self._vec = SurfaceFollowAutoVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
+        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
+        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
+
+    @classmethod
+    def make_vec(cls, num_envs, **kwargs):
+        kwargs.pop("show_gui", None)
+        kwargs.pop("show_tactile", None)
+        return SurfaceFollowAutoVecEnv(num_envs, **kwargs)
+
+    def seed(self, seed=None):
+        return self._vec.seed(seed)[:1]
+
+    def reset(self):
+        return {k: v[0] for k, v in self._vec.reset().items()}
+
+    def step(self, action):
+        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
+        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
+
+    def render(self, mode="rgb_array"):
+        return self._vec.render(mode)
+
+    def close(self):
+        self._vec.close()

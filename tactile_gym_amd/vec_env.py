@@ -29,7 +29,8 @@ class TactileVecEnv:
 
     metadata = {"render.modes": ["rgb_array"]}
 
-    def __init__(self, cfg, robot, sensor_desc, mesh_desc, observation_mode="tactile", obs_mode="numpy", seed=None):
+    def __init__(self, cfg, robot, sensor_desc, mesh_desc, observation_mode="tactile", obs_mode="numpy", seed=None, act_dim=None,
+                 oracle_dim=10):
         self._L = capi.lib()
         self.num_envs = int(cfg.num_envs)
         self._cfg, self._robot, self._sensor, self._mesh = cfg, robot, sensor_desc, mesh_desc
@@ -41,15 +42,15 @@ class TactileVecEnv:
             raise NotImplementedError("visual (RGB scene camera) observations are outside the built hot path (SURVEY 8f rank 4)")
         self.obs_mode = obs_mode
         self._ctx = C.c_void_p()
-        capi.check(self._L.tg_create(C.byref(cfg), C.byref(robot), C.byref(sensor_desc.struct), C.byref(mesh_desc.struct),
-                                     C.byref(self._ctx)))
+        capi.check(self._L.tg_create(C.byref(cfg), C.byref(robot), C.byref(sensor_desc.struct),
+                                     C.byref(mesh_desc.struct) if mesh_desc is not None else None, C.byref(self._ctx)))
         self.H, self.W = sensor_desc.struct.image_h, sensor_desc.struct.image_w
         self.ndof = robot.ndof
-        self.act_dim = {0: 2, 1: 3, 2: 3, 3: 4}[cfg.movement_mode]
+        self.act_dim = act_dim if act_dim is not None else {0: 2, 1: 3, 2: 3, 3: 4}[cfg.movement_mode]
         self.action_space = spaces.Box(low=cfg.min_action, high=cfg.max_action, shape=(self.act_dim,), dtype=np.float32)
         obs_spaces = {}
         if "oracle" in observation_mode:
-            obs_spaces["oracle"] = spaces.Box(low=-np.inf, high=np.inf, shape=(10,), dtype=np.float32)
+            obs_spaces["oracle"] = spaces.Box(low=-np.inf, high=np.inf, shape=(oracle_dim,), dtype=np.float32)
         if "tactile" in observation_mode:
             obs_spaces["tactile"] = spaces.Box(low=0, high=255, shape=(self.H, self.W, 1), dtype=np.uint8)
         if "feature" in observation_mode:
@@ -215,6 +216,9 @@ class TactileVecEnv:
         out = dict(q=np.zeros((n, nd)), qd=np.zeros((n, nd)), qd_target=np.zeros((n, nd)), tcp_pos=np.zeros((n, 3)),
                    tcp_rpy=np.zeros((n, 3)), edge_ang=np.zeros(n), embed_dist=np.zeros(n), stim_xform=np.zeros((n, 12), np.float32),
                    step_count=np.zeros(n, np.int32), reset_ticks=np.zeros(n, np.int32), rng_state=np.zeros(n, np.uint64))
+        if self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO:
+            out.update(goal_pos=np.zeros((n, 3)), direction=np.zeros((n, 2)), surf_zoff=np.zeros(n, np.float32),
+                       heights=np.zeros((n, self._cfg.surf_rows, self._cfg.surf_cols)))
         v = capi.TgStateView()
         for k, a in out.items():
             ct = {np.dtype(np.float64): C.c_double, np.dtype(np.float32): C.c_float, np.dtype(np.int32): C.c_int32,

@@ -277,3 +277,75 @@ def test_inverse_kinematics(ur5_tactip, dtype, tol):
         for i in range(n):
             p, _, _, _, R = arm.link_state("tcp_link", q=q[i], qd=np.zeros(6))
             assert np.abs(p - tps[i]).max() < 1e-8 and np.abs(R - trs[i]).max() < 1e-8
+
+
+SURF_MODES = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
+                  reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")
+
+
+def test_heightfield_generation_bit_exact():
+    """gen_heigtfield_simplex_2d (base_surface_env.py:319-337): device OpenSimplex == oracle OpenSimplex, every bit."""
+    from oracle.ref_env import opensimplex_heightfield
+    from tactile_gym_amd import hip_ops
+    seeds = np.array([0, 1, 3, 12345, 97984136, 99999999, 2 ** 40 + 17, -5], dtype=np.int64)
+    h, z = hip_ops.gen_heightfield(seeds)
+    for k, s in enumerate(seeds):
+        ref = opensimplex_heightfield(int(s))
+        assert np.array_equal(h[k], ref), f"seed {s}: {(h[k] != ref).sum()} samples differ"
+        rf = ref.astype(np.float32)
+        assert z[k] == np.float32(0.5) * (rf.min() + rf.max())
+        assert np.abs(ref).max() <= 0.025 and np.abs(ref).max() > 0.005
+
+
+def test_render_heightfield_bit_exact():
+    """Tactile image of a per-env heightfield (7 938 triangles each, several LDS batches) — uint8 equal to the oracle."""
+    from oracle import minibullet as mb
+    from oracle.ref_env import OracleSurfaceFollowAutoEnv
+    from tactile_gym_amd import hip_ops
+    from tactile_gym_amd.robot_model import SensorDesc
+    sensor = SensorDesc("digit", "standard", (128, 128))
+    rng = np.random.default_rng(8)
+    hs, zs, xfs, refs = [], [], [], []
+    for k in range(10):
+        env = OracleSurfaceFollowAutoEnv(seed=100 + k, env_modes=SURF_MODES, center_z=(k % 2 == 0))
+        env.reset()
+        q = env.arm.q + np.array([0, 0.004, -0.004, 0.02, 0.02, 0.0]) * rng.standard_normal(6)   # press in / tilt
+        env.arm.reset_joint_states(q)
+        hs.append(env.heightfield_data); zs.append(env.surf_zoff); xfs.append(env.stimulus_transform())
+        refs.append(env.tactile_image())
+    imgs = hip_ops.render_tactile_heightfield(sensor, np.stack(hs), np.array(zs, np.float32), np.stack(xfs))
+    touched = 0
+    for k in range(len(refs)):
+        assert np.array_equal(imgs[k], refs[k]), f"image {k}: {(imgs[k] != refs[k]).sum()} pixels differ"
+        touched += int((refs[k] > 0).sum())
+    assert touched > 2000
+
+
+def test_surface_follow_env_matches_oracle():
+    """surface_follow-v0 (UR5 + DIGIT, BASELINE config 3 modes): reset + 5 steps, 6 envs vs 6 oracle envs."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleSurfaceFollowAutoEnv
+    n = 6
+    venv = tg.make_vec("surface_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=SURF_MODES, seed=51, auto_reset=False)
+    oracles = [OracleSurfaceFollowAutoEnv(seed=51 + i, max_steps=200, image_size=(128, 128), env_modes=SURF_MODES) for i in range(n)]
+    obs = venv.reset()
+    ref = [o.reset() for o in oracles]
+    st = venv.get_state()
+    for i, o in enumerate(oracles):
+        assert np.array_equal(st["heights"][i], o.heightfield_data) and st["surf_zoff"][i] == o.surf_zoff
+        assert np.abs(st["goal_pos"][i] - o.goal_pos_world).max() < 1e-12
+        assert st["reset_ticks"][i] == o.reset_ticks
+        assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8
+        assert np.array_equal(obs["tactile"][i], ref[i]["tactile"])
+    rng = np.random.default_rng(52)
+    for step in range(5):
+        a = rng.uniform(-0.25, 0.25, size=(n, 3)).astype(np.float32)
+        a[:, 0] = np.abs(a[:, 0])          # bias z into the surface so the images are not empty
+        obs, rew, done, _ = venv.step(a)
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            ro, rr, rd, _ = o.step(a[i])
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8, (step, i)
+            assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
+            assert np.array_equal(obs["tactile"][i], ro["tactile"]), (step, i, int((obs["tactile"][i] != ro["tactile"]).sum()))
+    venv.close()

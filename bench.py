@@ -20,9 +20,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SURF_MODES = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
+                  reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")   # BASELINE configs[2], params/surface_follow_auto_params.py
 MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
              reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
 ALGO_BYTES_PER_ENV_STEP = 16600.0   # BASELINE.md section 3 / SURVEY 8(d): 16 384 B image + ~0.2 KB state/action/reward
+ALGO_BYTES_SURFACE = 33000.0        # config 3: + the per-env 64x64 f32 heightfield read
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -64,6 +67,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=128)
     ap.add_argument("--physics", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0"],
+                    help="headline = edge_follow-v0 (BASELINE configs[1]); surface_follow-v0 = configs[2]")
     args = ap.parse_args()
 
     import torch
@@ -85,14 +90,16 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     n = args.num_envs
-    venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[args.image_size, args.image_size], env_modes=MODES,
+    modes = MODES if args.env == "edge_follow-v0" else SURF_MODES
+    act_dim = 2 if args.env == "edge_follow-v0" else 3
+    venv = tg.make_vec(args.env, num_envs=n, max_steps=200, image_size=[args.image_size, args.image_size], env_modes=modes,
                        seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch")
     shard = TorchShard(venv)
     env = ShardedVecEnv(shard, dist) if world > 1 else shard
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
 
-    act_buf = torch.empty(n, 2, device="cuda", dtype=torch.float32)
+    act_buf = torch.empty(n, act_dim, device="cuda", dtype=torch.float32)
 
     def actions():   # action_space.sample() for the whole batch: U(-0.25, 0.25), one device kernel
         return act_buf.uniform_(-0.25, 0.25, generator=gen)
@@ -135,18 +142,19 @@ def main():
         k_render_main = rend_ms / max(rend_n, 1)
         dominant = "k_step" if step_ms >= rend_ms else "k_render_tactile"
         dom_ms = k_step if dominant == "k_step" else k_render_main
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        algo_bytes = ALGO_BYTES_PER_ENV_STEP if args.env == "edge_follow-v0" else ALGO_BYTES_SURFACE
+        achieved = algo_bytes * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (128x128 tactile obs) at N envs", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.physics == "f64" else "f32", "data": "synthetic",
-            "config": {"workload": f"edge_follow-v0, UR5 + TacTip, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
+            "config": {"workload": f"{args.env}, UR5 + {'TacTip' if args.env == 'edge_follow-v0' else 'DIGIT'}, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
                                    "random actions, TCP_velocity_control, 24 ticks x 150 PGS sweeps per step, auto-reset on",
                        "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world} + gather to rank 0"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                         "algorithmic_bytes_per_env_step": algo_bytes,
                          "kernel_ms": {"k_step": round(k_step, 4), "k_render_tactile": round(k_render_main, 4),
                                        "k_reset_per_launch": round(rst_ms / max(rst_n, 1), 4),
                                        "k_render_tactile_masked": round(prof["render_masked"][0] / max(prof["render_masked"][1], 1), 4)},
@@ -154,7 +162,7 @@ def main():
                          "note": "latency-bound by construction: 24 x 150 serial Gauss-Seidel sweeps per env step (BASELINE.md section 3)"},
             "resets_in_timed_region": bool((args.warmup % 200) + args.steps >= 200),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.env == "edge_follow-v0":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     venv.close()

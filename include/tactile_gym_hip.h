@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 2
+#define TG_ABI_VERSION 3
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
 typedef struct {
@@ -67,9 +67,10 @@ typedef struct {
     const int32_t* tris;                    /* host, [n_tris][3] */
 } tg_mesh;
 
-enum { TG_ENV_EDGE_FOLLOW = 0, TG_ENV_SURFACE_FOLLOW_AUTO = 1 };
+enum { TG_ENV_EDGE_FOLLOW = 0, TG_ENV_SURFACE_FOLLOW_AUTO = 1, TG_ENV_OBJECT_BALANCE = 2 };
 enum { TG_MOVE_XY = 0, TG_MOVE_XYZ = 1, TG_MOVE_XYRZ = 2, TG_MOVE_XYZRZ = 3 };            /* edge_follow_env.py:345-369 */
 enum { TG_SMOVE_YZ = 0, TG_SMOVE_XYZ = 1, TG_SMOVE_YZRX = 2, TG_SMOVE_XYZRXRY = 3 };       /* surface_follow_auto_env.py:27-57 */
+enum { TG_BMOVE_XY = 0, TG_BMOVE_XYZ = 1, TG_BMOVE_RXRY = 2, TG_BMOVE_XYRXRY = 3 };         /* object_balance_env.py:398-424 */
 enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };
 enum { TG_REWARD_DENSE = 0, TG_REWARD_SPARSE = 1 };
 enum { TG_PHYSICS_F64 = 0, TG_PHYSICS_F32 = 1 };
@@ -105,6 +106,19 @@ typedef struct {
     double surf_interp;                     /* 0.05  (:244) */
     double surf_xy_extent;                  /* 0.15  (:245) goal distance and TCP xy limits */
     double auto_action_scale;               /* 1.0 tactip / 0.9 digitac / 0.7 digit (surface_follow_auto_env.py:33-41) */
+    /* object_balance (object_balance_env.py): a free rigid body (stimulus mesh = its visual triangles, in the body's base
+     * inertial frame) tied to the TCP link by a point-to-point constraint. embed_lo/hi: rand_embed_dist range (:308-316). */
+    int32_t rand_gravity, rand_embed;       /* env_modes flags (:39-41) */
+    double gravity_lo, gravity_hi, gravity_default;   /* U(-1.0, -0.1) or -0.1 (:301-306) */
+    double obj_mass;
+    double obj_com[3];                      /* composite centre of mass in the base inertial frame */
+    double obj_inertia[9];                  /* about obj_com, base axes, row major */
+    double obj_root_inertial_pos[3];        /* root link's inertial origin in its link frame (loadURDF places the link frame) */
+    double obj_base_width, obj_base_height; /* 0.1, 0.0025 (:158-159) */
+    double obj_init_rpy[3];                 /* (0, 0, -pi/2) (:190) */
+    double ext_force[3];                    /* apply_random_force_base: (0, 0, -0.1) (:360-381) */
+    double term_deg, term_pos;              /* 35 deg, 0.1 m (:50-51) */
+    double p2p_erp, p2p_max_impulse;        /* 0.2, 500 [PARITY_ASSUMPTIONS A18-A19] */
 } tg_config;
 
 typedef struct tg_ctx tg_ctx;
@@ -157,6 +171,11 @@ typedef struct {
     double*  direction;      /* [num_envs][2] work-frame auto-drive direction (surface_follow) */
     double*  heights;        /* [num_envs][rows*cols] heightfield_data[row][col] (surface_follow) */
     float*   surf_zoff;      /* [num_envs] vertical centring offset applied to the rendered heightfield */
+    double*  body_pos;       /* [num_envs][3] free object base frame (object_balance) */
+    double*  body_rot;       /* [num_envs][9] row major */
+    double*  body_linvel;    /* [num_envs][3] velocity of the composite centre of mass */
+    double*  body_angvel;    /* [num_envs][3] */
+    double*  gravity_z;      /* [num_envs] */
 } tg_state_view;
 int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */

@@ -503,3 +503,160 @@ void mb_heightfield_simplex2d(int64_t seed, int rows, int cols, double interp, d
     for (int x = 0; x < rows; ++x)
         for (int y = 0; y < cols; ++y) out[x * cols + y] = mb_opensimplex_noise2(perm, (double)x * interp, (double)y * interp) * range;
 }
+
+/* ------------------------------------------------------------------------------------------------ arm + free body + P2P */
+static void m3_transpose_mul(const double* A, const double* B, double* Cc) { /* A^T B */
+    double t[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) t[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+    memcpy(Cc, t, sizeof t);
+}
+static int invert3(const double* A, double* Ai) {
+    double d = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    if (d == 0.0) return -1;
+    double id = 1.0 / d;
+    Ai[0] = (A[4] * A[8] - A[5] * A[7]) * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    Ai[3] = (A[5] * A[6] - A[3] * A[8]) * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    Ai[6] = (A[3] * A[7] - A[4] * A[6]) * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+    return 0;
+}
+
+/* Orientation update of a free body by world angular velocity w over dt: exponential map with Bullet's small-angle
+ * Taylor branch (btMultiBody::stepPositionsMultiDof / btTransformUtil::integrateTransform) [A21]. */
+static void integrate_rotation(double* R, const double* w, double dt) {
+    double ang = norm3(w), ax[3], qw;
+    if (ang < 0.001) {
+        double k = 0.5 * dt - (dt * dt * dt) * 0.020833333333 * ang * ang;
+        ax[0] = w[0] * k; ax[1] = w[1] * k; ax[2] = w[2] * k;
+    } else {
+        double k = sin(0.5 * ang * dt) / ang;
+        ax[0] = w[0] * k; ax[1] = w[1] * k; ax[2] = w[2] * k;
+    }
+    qw = cos(ang * dt * 0.5);
+    /* dR from quaternion (ax, qw), normalised */
+    double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2] + qw * qw);
+    double x = ax[0] / n, y = ax[1] / n, z = ax[2] / n, ww = qw / n;
+    double dR[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww),
+                    2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww),
+                    2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)};
+    double Rn[9];
+    m3_mul(dR, R, Rn);
+    /* re-orthonormalise (Bullet keeps a unit quaternion): Gram-Schmidt on the columns */
+    double c0[3] = {Rn[0], Rn[3], Rn[6]}, c1[3] = {Rn[1], Rn[4], Rn[7]}, c2[3];
+    double l0 = norm3(c0);
+    for (int k = 0; k < 3; ++k) c0[k] /= l0;
+    double d01 = dot(c0, c1);
+    for (int k = 0; k < 3; ++k) c1[k] -= d01 * c0[k];
+    double l1 = norm3(c1);
+    for (int k = 0; k < 3; ++k) c1[k] /= l1;
+    cross(c0, c1, c2);
+    for (int k = 0; k < 3; ++k) { R[3 * k] = c0[k]; R[3 * k + 1] = c1[k]; R[3 * k + 2] = c2[k]; }
+}
+
+void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, double dt, int iters) {
+    enum { NR = MB_MAX_DOF + 3, NU = MB_MAX_DOF + 6 };
+    int n = m->ndof, nr = n + 3, nu = n + 6;
+    /* ---- arm: unconstrained velocity (same as mb_step) */
+    double tau[MB_MAX_DOF], h[MB_MAX_DOF], Qd[MB_MAX_DOF], v[NU], M[MB_MAX_DOF * MB_MAX_DOF], Mi[MB_MAX_DOF * MB_MAX_DOF], zero[MB_MAX_DOF] = {0};
+    for (int i = 0; i < n; ++i) tau[i] = s->applied_torque[i] - m->joint_damping * s->qd[i];
+    mb_inverse_dynamics(m, s->q, s->qd, zero, h);
+    damping_force(m, s->q, s->qd, Qd);
+    mb_mass_matrix(m, s->q, M);
+    invert(M, n, Mi);
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += Mi[i * n + j] * (tau[j] - h[j] + Qd[j]);
+        v[i] = s->qd[i] + dt * acc;
+    }
+    /* ---- body: gravity, one-shot external force, gyroscopic torque; no velocity damping (object_balance_env.py:338-345) */
+    double Iw[9], Iwi[9], RI[9], cw[3], xc[3];
+    m3_mul(b->rot, b->inertia, RI);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Iw[3 * i + j] = RI[3 * i] * b->rot[3 * j] + RI[3 * i + 1] * b->rot[3 * j + 1] + RI[3 * i + 2] * b->rot[3 * j + 2];
+    invert3(Iw, Iwi);
+    m3_vec(b->rot, b->com, cw);
+    for (int k = 0; k < 3; ++k) xc[k] = b->pos[k] + cw[k];
+    double F[3] = {b->mass * m->gravity[0], b->mass * m->gravity[1], b->mass * m->gravity[2]}, N[3] = {0, 0, 0};
+    if (b->ext_pending) {
+        double r[3] = {b->ext_pos[0] - xc[0], b->ext_pos[1] - xc[1], b->ext_pos[2] - xc[2]}, t[3];
+        cross(r, b->ext_force, t);
+        for (int k = 0; k < 3; ++k) { F[k] += b->ext_force[k]; N[k] += t[k]; }
+        b->ext_pending = 0;
+    }
+    double Iwv[3], gyro[3], wacc[3];
+    m3_vec(Iw, b->angvel, Iwv); cross(b->angvel, Iwv, gyro);
+    for (int k = 0; k < 3; ++k) N[k] -= gyro[k];
+    m3_vec(Iwi, N, wacc);
+    for (int k = 0; k < 3; ++k) { v[n + k] = b->linvel[k] + dt * F[k] / b->mass; v[n + 3 + k] = b->angvel[k] + dt * wacc[k]; }
+    /* ---- constraint rows J [nr][nu]: motors then P2P */
+    double J[NR][NU], W[NU][NR], A[NR][NR], rhs[NR], lim[NR];
+    memset(J, 0, sizeof J);
+    for (int i = 0; i < n; ++i) J[i][i] = 1.0;
+    kin_t k; double z3[3] = {0, 0, 0};
+    kinematics(m, s->q, zero, NULL, z3, &k);
+    double ra[3], pa[3], pb[3], rb[3], tvec[3];
+    m3_vec(k.R[c->link], c->pivot_a, ra);
+    for (int x = 0; x < 3; ++x) pa[x] = k.o[c->link][x] + ra[x];
+    m3_vec(b->rot, c->pivot_b, tvec);
+    for (int x = 0; x < 3; ++x) { pb[x] = b->pos[x] + tvec[x]; rb[x] = pb[x] - xc[x]; }
+    for (int i = 0; i < n; ++i) {
+        if (!is_in_subtree(m, c->link, i)) continue;
+        double r[3] = {pa[0] - k.o[i][0], pa[1] - k.o[i][1], pa[2] - k.o[i][2]}, jt[3];
+        cross(k.a[i], r, jt);
+        for (int x = 0; x < 3; ++x) J[n + x][i] = jt[x];
+    }
+    for (int x = 0; x < 3; ++x) {
+        double e[3] = {0, 0, 0}, rxe[3];
+        e[x] = 1.0;
+        cross(rb, e, rxe);
+        J[n + x][n + x] = -1.0;
+        for (int y = 0; y < 3; ++y) J[n + x][n + 3 + y] = -rxe[y];
+    }
+    /* W = Minv_sys J^T */
+    for (int r = 0; r < nr; ++r) {
+        for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < n; ++j) acc += Mi[i * n + j] * J[r][j]; W[i][r] = acc; }
+        for (int x = 0; x < 3; ++x) W[n + x][r] = J[r][n + x] / b->mass;
+        for (int x = 0; x < 3; ++x) W[n + 3 + x][r] = Iwi[3 * x] * J[r][n + 3] + Iwi[3 * x + 1] * J[r][n + 4] + Iwi[3 * x + 2] * J[r][n + 5];
+    }
+    for (int r = 0; r < nr; ++r)
+        for (int q = 0; q < nr; ++q) { double acc = 0; for (int u = 0; u < nu; ++u) acc += J[r][u] * W[u][q]; A[r][q] = acc; }
+    /* right-hand sides (velocity level) */
+    for (int i = 0; i < n; ++i) {
+        double kp = (s->motor_mode[i] == MB_MOTOR_POSITION) ? s->motor_kp[i] : 0.0;
+        double des = kp * (s->motor_q_des[i] - s->q[i]) / dt + v[i] + s->motor_kd[i] * (s->motor_qd_des[i] - v[i]);
+        rhs[i] = (s->motor_mode[i] != MB_MOTOR_OFF) ? des - v[i] : 0.0;
+        lim[i] = (s->motor_mode[i] != MB_MOTOR_OFF) ? s->motor_max_force[i] * dt : 0.0;
+    }
+    for (int x = 0; x < 3; ++x) {
+        double cv = 0.0;
+        for (int u = 0; u < nu; ++u) cv += J[n + x][u] * v[u];
+        rhs[n + x] = (-c->erp * (pa[x] - pb[x]) / dt) - cv;
+        lim[n + x] = c->max_impulse;
+    }
+    double lam[NR] = {0}, dv[NU] = {0};
+    for (int it = 0; it < iters; ++it) {
+        double residual = 0.0;
+        for (int jj = 0; jj < nr; ++jj) {
+            int r = (it & 1) ? jj : nr - 1 - jj;
+            if (lim[r] == 0.0) continue;
+            double jdv = 0.0;
+            for (int u = 0; u < nu; ++u) jdv += J[r][u] * dv[u];
+            double jdi = 1.0 / A[r][r];
+            double delta = rhs[r] * jdi - jdv * jdi;
+            double sum = lam[r] + delta;
+            if (sum < -lim[r]) { delta = -lim[r] - lam[r]; lam[r] = -lim[r]; }
+            else if (sum > lim[r]) { delta = lim[r] - lam[r]; lam[r] = lim[r]; }
+            else lam[r] = sum;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+            if (delta * delta > residual) residual = delta * delta;
+        }
+        if (residual <= 0.0) break;
+    }
+    /* ---- integrate */
+    for (int i = 0; i < n; ++i) { s->qd[i] = v[i] + dv[i]; s->q[i] += dt * s->qd[i]; s->applied_torque[i] = 0.0; }
+    for (int x = 0; x < 3; ++x) { b->linvel[x] = v[n + x] + dv[n + x]; b->angvel[x] = v[n + 3 + x] + dv[n + 3 + x]; }
+    for (int x = 0; x < 3; ++x) xc[x] += dt * b->linvel[x];
+    integrate_rotation(b->rot, b->angvel, dt);
+    m3_vec(b->rot, b->com, cw);
+    for (int x = 0; x < 3; ++x) b->pos[x] = xc[x] - cw[x];
+}

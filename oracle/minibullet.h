@@ -113,6 +113,35 @@ double mb_opensimplex_noise2(const int16_t* perm, double x, double y);
 /* gen_heigtfield_simplex_2d (base_surface_env.py:319-337): out[x*cols + y] = noise2(x*interp, y*interp) * range */
 void mb_heightfield_simplex2d(int64_t seed, int rows, int cols, double interp, double range, double* out);
 
+/* ----------------------------------------------------------------------------------------------------------
+ * object_balance: a free rigid body (the pole: base plate + pole links welded together) tied to the arm's TCP link by a
+ * point-to-point constraint (object_balance_env.py:261-283 createConstraint(JOINT_POINT2POINT)).  stepSimulation then
+ * solves the arm's joint motors and the three P2P rows in one projected Gauss-Seidel loop [PARITY_ASSUMPTIONS A18-A21].
+ * PARITY UNPINNED (no golden data). */
+typedef struct {
+    double mass;
+    double com[3];          /* composite centre of mass in the base (inertial) frame that get/resetBasePositionAndOrientation use */
+    double inertia[9];      /* composite inertia about com, base-frame axes, row major */
+    double pos[3];          /* base frame origin, world */
+    double rot[9];          /* base frame orientation, world, row major */
+    double linvel[3];       /* velocity of the composite centre of mass, world */
+    double angvel[3];       /* world */
+    double ext_force[3];    /* applyExternalForce(WORLD_FRAME): force and application point; used by the next tick, then cleared */
+    double ext_pos[3];
+    int32_t ext_pending;
+} mb_body;
+
+typedef struct {
+    int32_t link;           /* arm link carrying pivot A */
+    double pivot_a[3];      /* in that link's frame (URDF frame of the moving link) */
+    double pivot_b[3];      /* in the body's base frame */
+    double erp;             /* 0.2 */
+    double max_impulse;     /* 500 */
+} mb_p2p;
+
+/* stepSimulation() for arm + body + P2P.  Row order: joint motors (joint order), then P2P x, y, z. */
+void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, double dt, int solver_iterations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,19 @@ class MBState(C.Structure):
     ]
 
 
+class MBBody(C.Structure):
+    _fields_ = [
+        ("mass", C.c_double), ("com", C.c_double * 3), ("inertia", C.c_double * 9), ("pos", C.c_double * 3), ("rot", C.c_double * 9),
+        ("linvel", C.c_double * 3), ("angvel", C.c_double * 3), ("ext_force", C.c_double * 3), ("ext_pos", C.c_double * 3),
+        ("ext_pending", C.c_int32),
+    ]
+
+
+class MBP2P(C.Structure):
+    _fields_ = [("link", C.c_int32), ("pivot_a", C.c_double * 3), ("pivot_b", C.c_double * 3), ("erp", C.c_double),
+                ("max_impulse", C.c_double)]
+
+
 MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
 _lib = None
 
@@ -58,6 +71,7 @@ def lib():
         _lib.mb_mass_matrix.argtypes = [mp, dp, dp]
         _lib.mb_jacobian.argtypes = [mp, dp, C.c_int, dp, dp]
         _lib.mb_step.argtypes = [mp, sp, C.c_double, C.c_int]
+        _lib.mb_step_body.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.c_double, C.c_int]
         _lib.mb_ik.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_double]
         _lib.mb_ik.restype = C.c_int
         _lib.mb_render_depth.argtypes = [fp, C.c_int, ip, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, fp]
@@ -190,6 +204,10 @@ class Arm:
 
     def step_simulation(self, dt=1.0 / 240.0, iters=150):
         self.L.mb_step(C.byref(self.model), C.byref(self.state), dt, iters)
+
+    def step_simulation_body(self, body, p2p, dt=1.0 / 240.0, iters=150):
+        """stepSimulation with a free rigid body tied to the arm by a point-to-point constraint."""
+        self.L.mb_step_body(C.byref(self.model), C.byref(self.state), C.byref(body), C.byref(p2p), dt, iters)
 
 
 # --------------------------------------------------------------------------------------------------- camera

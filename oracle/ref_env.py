@@ -128,8 +128,11 @@ class _OracleArmEnv:
     def _step_sim(self):
         q, qd = self.arm.q, self.arm.qd
         self.arm.apply_torques(self.arm.inverse_dynamics(q, qd, np.zeros(self.arm.n)))  # base_robot_arm.py:174-189
-        self.arm.step_simulation(self.SIM_DT, self.SOLVER_ITERS)                         # robot.py:141
+        self._step_simulation()                                                          # robot.py:141
         self.ticks += 1
+
+    def _step_simulation(self):
+        self.arm.step_simulation(self.SIM_DT, self.SOLVER_ITERS)
 
     # ---- base_robot_arm.py:281-332
     def _tcp_velocity_control(self, vels):
@@ -426,6 +429,141 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         cur = self.nodef_dep.copy()
         mb.render_depth(self.surf_verts, self.surf_tris, self.stimulus_transform(), self.cam["fov"], self.cam["near"], self.cam["far"],
                         w, h, cur)
+        return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)
+
+    def oracle_obs(self):
+        raise NotImplementedError
+
+
+class OracleObjectBalanceEnv(_OracleArmEnv):
+    """object_balance-v0, object_mode "pole" (nonprehensile_manipulation/object_balance/object_balance_env.py +
+    base_object_env.py): UR5 + TacTip pointing up, a pole tied to the TCP by a point-to-point constraint."""
+
+    ACTION_REPEAT = 12                   # floor((1/20)/(1/240)), object_balance_env.py:33-35
+
+    def __init__(self, seed=0, max_steps=250, image_size=(128, 128), env_modes=None, inertia="collision_aabb"):
+        modes = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=True, rand_embed_dist=True,
+                     observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+        modes.update(env_modes or {})
+        assert modes["object_mode"] == "pole" and modes["movement_mode"] in ("xy", "xyz", "RxRy", "xyRxRy")
+        rest = [0.19826, -2.01062, -1.96602, -0.73808, 4.71286, -3.34064]                  # object_balance/rest_poses.py:4-20
+        self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # :46-48
+        self.termination_dist_deg, self.termination_dist_pos = 35, 0.1                     # :50-51
+        self.embed_dist = {"tactip": 0.0035, "digitac": 0.0015, "digit": 0.0015}[self.t_s_name]   # :53-58
+        self._set_workframe([0.55, 0.0, 0.35], [0.0, 0.0, 0.0])                            # :61-62
+        a = 45 * math.pi / 180
+        self.TCP_lims = np.array([[-0.1, 0.1], [-0.1, 0.1], [-0.1, 0.1], [-a, a], [-a, a], [-a, a]])   # :64-76
+        v, w = 0.01, 5.0 * (math.pi / 180)                                                 # :123-131
+        self.act_lo, self.act_hi = np.array([-v, -v, -v, -w, -w, 0.0]), np.array([v, v, v, w, w, 0.0])
+        self.obj_base_width, self.obj_base_height = 0.1, 0.0025                            # :158-159
+        suffix = "" if inertia == "collision_aabb" else "_urdfinertia"
+        z = np.load(os.path.join(_ASSETS, "objects", f"pole{suffix}.npz"))
+        self.obj_verts, self.obj_tris = z["verts"], z["tris"]
+        self.init_obj_rpy = np.array([0.0, 0.0, -math.pi / 2])                             # :190
+        self.init_obj_rot = pm.mat_from_quat(pm.quat_from_euler(self.init_obj_rpy))
+        self._set_init_obj_pos(buffer_height=0.0)
+        b = mb.MBBody()
+        b.mass = float(z["mass"])
+        for k in range(3):
+            b.com[k] = float(z["com"][k])
+        for k in range(9):
+            b.inertia[k] = float(z["inertia"].reshape(9)[k])
+        self.body = b
+        # load_object (base_object_env.py:66-70): loadURDF places the *link* frame at init_obj_pos; the inertial frame that
+        # get/resetBasePositionAndOrientation use sits root_inertial_pos away
+        self._teleport_body(self.init_obj_pos + self.init_obj_rot @ z["root_inertial_pos"], self.init_obj_rot)
+        link, fpos, _ = self.tg.frames["tcp_link"]
+        c = mb.MBP2P()                                                                      # apply_constraints :261-283
+        c.link, c.erp, c.max_impulse = int(link), 0.2, 500.0
+        for k in range(3):
+            c.pivot_a[k] = float(fpos[k])                                                   # parentFramePosition [0,0,0] in the TCP link's inertial frame
+        self.p2p = c
+        self._update_constraint()
+
+    def _set_init_obj_pos(self, buffer_height):
+        self.init_obj_pos = np.array([self.workframe_pos[0], self.workframe_pos[1],
+                                      self.workframe_pos[2] + buffer_height + (self.obj_base_height / 2) - self.embed_dist])   # :185-189,:317-321
+
+    def _update_constraint(self):                                                           # :285-294
+        piv = [0.0, 0.0, -self.obj_base_height / 2 + self.embed_dist]
+        for k in range(3):
+            self.p2p.pivot_b[k] = piv[k]
+
+    def _teleport_body(self, pos, rot):                                                     # resetBasePositionAndOrientation
+        for k in range(3):
+            self.body.pos[k] = float(pos[k])
+            self.body.linvel[k] = 0.0
+            self.body.angvel[k] = 0.0
+        for k in range(9):
+            self.body.rot[k] = float(np.asarray(rot).reshape(9)[k])
+
+    def _step_simulation(self):
+        self.arm.step_simulation_body(self.body, self.p2p, self.SIM_DT, self.SOLVER_ITERS)
+
+    def body_pose(self):
+        return np.array(self.body.pos[:]), np.array(self.body.rot[:]).reshape(3, 3)
+
+    def reset(self):
+        """base_object_env.py:146-173 with object_balance_env.py:296-381."""
+        self.step_counter = 0
+        self.gravity = self.rng.uniform(-1.0, -0.1) if self.modes["rand_gravity"] else -0.1     # reset_task :301-306
+        self.arm.set_gravity([0.0, 0.0, self.gravity])
+        if self.modes["rand_embed_dist"]:                                                   # :308-322
+            lo, hi = {"tactip": (0.003, 0.006), "digitac": (0.001, 0.0025), "digit": (0.0015, 0.0025)}[self.t_s_name]
+            self.embed_dist = self.rng.uniform(lo, hi)
+            self._set_init_obj_pos(buffer_height=0.0)
+            self._update_constraint()
+        self._reset_robot(np.zeros(3), np.zeros(3))                                         # update_init_pose, base_object_env.py:96-103
+        self._teleport_body(self.init_obj_pos, self.init_obj_rot)                           # reset_object :330-345
+        sx = -1.0 if self.rng.random() < 0.5 else 1.0                                       # apply_random_force_base :360-381
+        rx = self.rng.random()
+        sy = -1.0 if self.rng.random() < 0.5 else 1.0
+        ry = self.rng.random()
+        fpos = self.init_obj_pos + np.array([sx * rx * self.obj_base_width / 2, sy * ry * self.obj_base_width / 2, 0.0])
+        for k in range(3):
+            self.body.ext_force[k] = [0.0, 0.0, -0.1][k]
+            self.body.ext_pos[k] = float(fpos[k])
+        self.body.ext_pending = 1
+        self._get_step_data()
+        return self._observation()
+
+    def _encode_actions(self, a):                                                           # :398-424
+        enc = np.zeros(6)
+        mm = self.modes["movement_mode"]
+        if mm in ("xy", "xyz"):
+            enc[0], enc[1] = a[0], a[1]
+            if mm == "xyz":
+                enc[2] = a[2]
+        elif mm == "RxRy":
+            enc[3], enc[4] = a[0], a[1]
+        elif mm == "xyRxRy":
+            enc[0], enc[1], enc[3], enc[4] = a[0], a[1], a[2], a[3]
+        return enc
+
+    def _check_obj_fall(self):                                                              # :444-463
+        pos, R = self.body_pose()
+        rpy_deg = pm.euler_from_quat(pm.quat_from_mat(R)) * 180 / math.pi
+        rpy_dist = np.abs(((rpy_deg - self.init_obj_rpy * 180 / math.pi) + 180) % 360 - 180)
+        if rpy_dist[0] > self.termination_dist_deg or rpy_dist[1] > self.termination_dist_deg:
+            return True
+        return bool(np.linalg.norm(pos - self.init_obj_pos) > self.termination_dist_pos)
+
+    def _get_step_data(self):                                                               # :426-442, :465-497
+        self.cur_tcp_pos, self.cur_tcp_rpy, self.cur_tcp_orn, _, _ = self._tcp_world()
+        fell = self._check_obj_fall()
+        done = fell or self.step_counter >= self.max_steps
+        reward = (-1 if fell else 0.0) if self.modes["reward_mode"] == "sparse" else 1.0
+        return reward, bool(done)
+
+    def stimulus_transform(self):
+        cpos, cR = self.camera_pose()
+        pos, R = self.body_pose()
+        return mb.cam_from_obj_matrix(cpos, cR, pos, R)
+
+    def tactile_image(self):
+        h, w = self.image_size
+        cur = self.nodef_dep.copy()
+        mb.render_depth(self.obj_verts, self.obj_tris, self.stimulus_transform(), self.cam["fov"], self.cam["near"], self.cam["far"], w, h, cur)
         return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)
 
     def oracle_obs(self):

@@ -8,12 +8,13 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtactile_gym_hip.so")
 
-ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO = 0, 1
+ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO, ENV_OBJECT_BALANCE = 0, 1, 2
+BMOVE = {"xy": 0, "xyz": 1, "RxRy": 2, "xyRxRy": 3}
 SMOVE = {"yz": 0, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}
 MOVE = {"xy": 0, "xyz": 1, "xyRz": 2, "xyzRz": 3}
 NOISE = {"fixed_height": 0, "rand_height": 1}
@@ -66,6 +67,11 @@ class TgConfig(C.Structure):
         ("surf_rows", C.c_int32), ("surf_cols", C.c_int32), ("surf_center_z", C.c_int32), ("reserved0", C.c_int32),
         ("surf_grid_scale", C.c_double), ("surf_height_range", C.c_double), ("surf_interp", C.c_double),
         ("surf_xy_extent", C.c_double), ("auto_action_scale", C.c_double),
+        ("rand_gravity", C.c_int32), ("rand_embed", C.c_int32),
+        ("gravity_lo", C.c_double), ("gravity_hi", C.c_double), ("gravity_default", C.c_double),
+        ("obj_mass", C.c_double), ("obj_com", _d3), ("obj_inertia", _d9), ("obj_root_inertial_pos", _d3),
+        ("obj_base_width", C.c_double), ("obj_base_height", C.c_double), ("obj_init_rpy", _d3), ("ext_force", _d3),
+        ("term_deg", C.c_double), ("term_pos", C.c_double), ("p2p_erp", C.c_double), ("p2p_max_impulse", C.c_double),
     ]
 
 
@@ -77,6 +83,8 @@ class TgStateView(C.Structure):
         ("reset_ticks", C.POINTER(C.c_int32)), ("rng_state", C.POINTER(C.c_uint64)),
         ("goal_pos", C.POINTER(C.c_double)), ("direction", C.POINTER(C.c_double)), ("heights", C.POINTER(C.c_double)),
         ("surf_zoff", C.POINTER(C.c_float)),
+        ("body_pos", C.POINTER(C.c_double)), ("body_rot", C.POINTER(C.c_double)), ("body_linvel", C.POINTER(C.c_double)),
+        ("body_angvel", C.POINTER(C.c_double)), ("gravity_z", C.POINTER(C.c_double)),
     ]
 
 

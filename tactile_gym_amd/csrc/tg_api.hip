@@ -42,6 +42,12 @@ template <typename T> struct EnvConst {
     int env_kind, surf_rows, surf_cols;
     double surf_scale, surf_range, surf_interp, surf_extent, auto_scale;
     double xbin_lo, xbin_hi, ybin_lo, ybin_hi;   // np.linspace bounds of x_bins / y_bins (base_surface_env.py:258-282)
+    // object_balance
+    BodyConst<T> body;
+    M3<T> obj_init_rot;
+    T obj_init_rpy_deg[3], obj_base_width, obj_base_height, term_deg, term_pos, ext_force[3];
+    int rand_gravity, rand_embed;
+    double gravity_lo, gravity_hi, gravity_default;
 };
 
 struct State {   // device pointers, SoA [field][num_envs]
@@ -54,6 +60,9 @@ struct State {   // device pointers, SoA [field][num_envs]
     double *dir, *goal, *heights;   // [2][n], [3][n], [n][rows*cols]
     float* surf_zoff;               // [n]
     int64_t* noise_seed;            // [n]
+    // object_balance
+    double *body_pos, *body_rot, *body_v, *body_w, *ext_pos, *gravity;   // [3][n], [9][n], [3][n], [3][n], [3][n], [n]
+    uint8_t* ext_pending;           // [n]
 };
 
 // SplitMix64 (identical integer stream in oracle/ref_env.py: Rng)
@@ -179,6 +188,53 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
     X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
 }
 
+// scale_actions (base_tactile_env.py:141-164): clip to [min_action, max_action], affine map to the physical range per dimension
+template <typename T> __device__ __forceinline__ void scale_actions(const EnvConst<T>& c, const T (&enc)[6], T (&vels)[6]) {
+    const T in_range = c.max_action - c.min_action;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        T x = enc[d];
+        x = x < c.min_action ? c.min_action : (x > c.max_action ? c.max_action : x);
+        vels[d] = (((x - c.min_action) * (c.act_hi[d] - c.act_lo[d])) / in_range) + c.act_lo[d];
+    }
+}
+
+// BaseRobotArm.tcp_velocity_control (base_robot_arm.py:281-332): TCP limit check, work -> world twist, Jacobian inverse.
+template <typename T, int TOPO>
+__device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const EnvConst<T>& c, const T (&q)[Topo<TOPO>::N], T (&vels)[6],
+                                                     T (&qd_des)[Topo<TOPO>::N]) {
+    constexpr int N = Topo<TOPO>::N;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    V3<T> wpos; T wrpy[3], rpyw[3];
+    world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpyw);
+    const T cur[6] = {wpos.x, wpos.y, wpos.z, wrpy[0], wrpy[1], wrpy[2]};
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {   // check_TCP_vel_lims (base_robot_arm.py:357-380)
+        const bool ex = (cur[d] < c.tcp_lims[d][0] && vels[d] < T(0)) || (cur[d] > c.tcp_lims[d][1] && vels[d] > T(0));
+        if (ex) vels[d] = T(0);
+    }
+    const V3<T> lin = mul(c.work_R, mk(vels[0], vels[1], vels[2]));   // workvel_to_worldvel (:96-105)
+    const V3<T> ang = mul(c.work_R, mk(vels[3], vels[4], vels[5]));
+    T J[6][N];
+    tcp_jacobian<T, TOPO>(m, k, ptcp, J);
+    if (N == 6) {  // square: inverse (reference takes np.linalg.inv when rank is full, :316-319)
+        T A[6][6], b[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z}, x[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) A[r][cc] = J[r][cc < N ? cc : 0];
+        solve_pivoted<T, 6>(A, b, x);
+#pragma unroll
+        for (int i = 0; i < N; ++i) qd_des[i] = x[i < 6 ? i : 0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) qd_des[i] = T(0);   // MG400 pseudo-inverse path: not built yet
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ step kernel
 // BaseTactileEnv.step (base_tactile_env.py:166-185): encode + scale the action, tcp_velocity_control
 // (base_robot_arm.py:281-332), action_repeat sim ticks (robot.py:182-183), reward / done, render transform.
@@ -208,51 +264,12 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
         if (c.movement_mode == TG_SMOVE_YZRX) enc[3] = (T)a[1];
         else if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[1]; enc[4] = (T)a[2]; }
     }
-    // scale_actions (base_tactile_env.py:141-164)
     T vels[6];
-    const T in_range = c.max_action - c.min_action;
-#pragma unroll
-    for (int d = 0; d < 6; ++d) {
-        T x = enc[d];
-        x = x < c.min_action ? c.min_action : (x > c.max_action ? c.max_action : x);
-        vels[d] = (((x - c.min_action) * (c.act_hi[d] - c.act_lo[d])) / in_range) + c.act_lo[d];
-    }
+    scale_actions<T>(c, enc, vels);
     const int step_count = st.step_count[env] + 1;
     st.step_count[env] = step_count;
-
-    // tcp_velocity_control
     T qd_des[N];
-    {
-        Kin<T, TOPO> k;
-        forward_kinematics<T, TOPO>(m, q, k);
-        V3<T> ptcp; M3<T> Rtcp;
-        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
-        V3<T> wpos; T wrpy[3], rpyw[3];
-        world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpyw);
-        const T cur[6] = {wpos.x, wpos.y, wpos.z, wrpy[0], wrpy[1], wrpy[2]};
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {   // check_TCP_vel_lims (base_robot_arm.py:357-380)
-            const bool ex = (cur[d] < c.tcp_lims[d][0] && vels[d] < T(0)) || (cur[d] > c.tcp_lims[d][1] && vels[d] > T(0));
-            if (ex) vels[d] = T(0);
-        }
-        const V3<T> lin = mul(c.work_R, mk(vels[0], vels[1], vels[2]));   // workvel_to_worldvel (:96-105)
-        const V3<T> ang = mul(c.work_R, mk(vels[3], vels[4], vels[5]));
-        T J[6][N];
-        tcp_jacobian<T, TOPO>(m, k, ptcp, J);
-        if (N == 6) {  // square: inverse (reference takes np.linalg.inv when rank is full, :316-319)
-            T A[6][6], b[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z}, x[6];
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) A[r][cc] = J[r][cc < N ? cc : 0];
-            solve_pivoted<T, 6>(A, b, x);
-#pragma unroll
-            for (int i = 0; i < N; ++i) qd_des[i] = x[i < 6 ? i : 0];
-        } else {
-#pragma unroll
-            for (int i = 0; i < N; ++i) qd_des[i] = T(0);   // MG400 pseudo-inverse path: not built yet
-        }
-    }
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
 #pragma unroll
     for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
 
@@ -434,6 +451,207 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
     finish_env<T, TOPO>(m, c, st, env, q, (T)edge_ang, 0, false);
 }
 
+// ------------------------------------------------------------------------------------------------ object_balance kernels
+template <typename T> __device__ __forceinline__ FreeBody<T> load_body(const State& st, int n, int env) {
+    FreeBody<T> b;
+    b.pos = mk((T)st.body_pos[0 * n + env], (T)st.body_pos[1 * n + env], (T)st.body_pos[2 * n + env]);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) b.R.m[e] = (T)st.body_rot[e * n + env];
+    b.v = mk((T)st.body_v[0 * n + env], (T)st.body_v[1 * n + env], (T)st.body_v[2 * n + env]);
+    b.w = mk((T)st.body_w[0 * n + env], (T)st.body_w[1 * n + env], (T)st.body_w[2 * n + env]);
+    return b;
+}
+template <typename T> __device__ __forceinline__ void store_body(const State& st, int n, int env, const FreeBody<T>& b) {
+    st.body_pos[0 * n + env] = (double)b.pos.x; st.body_pos[1 * n + env] = (double)b.pos.y; st.body_pos[2 * n + env] = (double)b.pos.z;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) st.body_rot[e * n + env] = (double)b.R.m[e];
+    st.body_v[0 * n + env] = (double)b.v.x; st.body_v[1 * n + env] = (double)b.v.y; st.body_v[2 * n + env] = (double)b.v.z;
+    st.body_w[0 * n + env] = (double)b.w.x; st.body_w[1 * n + env] = (double)b.w.y; st.body_w[2 * n + env] = (double)b.w.z;
+}
+template <typename T> __device__ __forceinline__ T wrap_deg(T d) {   // ((d + 180) % 360) - 180 with numpy's sign-of-divisor modulo
+    const T x = d + T(180);
+    return (x - T(360) * floor(x / T(360))) - T(180);
+}
+
+// get_step_data / check_obj_fall / termination (object_balance_env.py:426-497) + camera<-object transform
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                            const FreeBody<T>& b, T embed, int step_count, bool write_reward_done) {
+    const int n = c.num_envs;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    T rpy[3];
+    { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
+    st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
+    st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    if (write_reward_done) {
+        T orpy[3];
+        { Q4<T> qq = quat_from_mat(b.R); euler_from_quat(qq, orpy[0], orpy[1], orpy[2]); }
+        const T r2d = T(180) / T(3.141592653589793);
+        const T d0 = tabs(wrap_deg(orpy[0] * r2d - c.obj_init_rpy_deg[0])), d1 = tabs(wrap_deg(orpy[1] * r2d - c.obj_init_rpy_deg[1]));
+        const V3<T> init = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - embed);
+        const bool fell = d0 > c.term_deg || d1 > c.term_deg || norm(b.pos - init) > c.term_pos;
+        const bool done = fell || step_count >= c.max_steps;
+        const T reward = (c.reward_mode == TG_REWARD_SPARSE) ? (fell ? T(-1) : T(0)) : T(1);
+        st.reward[env] = (float)reward;
+        st.done[env] = done ? 1 : 0;
+    }
+    V3<T> pb; M3<T> Rb;
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
+    const M3<T> Rc = mul(Rb, c.cam_rot);
+    V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
+    f = (T(1) / norm(f)) * f;
+    V3<T> s = cross(f, up);
+    s = (T(1) / norm(s)) * s;
+    const V3<T> u = cross(s, f);
+    const V3<T> ox{b.R.m[0], b.R.m[3], b.R.m[6]}, oy{b.R.m[1], b.R.m[4], b.R.m[7]}, oz{b.R.m[2], b.R.m[5], b.R.m[8]};
+    const V3<T> dp = b.pos - pc;
+    const V3<T> nf = mk<T>(0, 0, 0) - f;
+    float* X = st.stim_xform;
+    X[0 * n + env] = (float)dot(s, ox);  X[1 * n + env] = (float)dot(s, oy);  X[2 * n + env] = (float)dot(s, oz);
+    X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
+    X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
+    X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                  const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // encode_actions (object_balance_env.py:398-424)
+    const float* a = actions + (size_t)env * c.act_dim;
+    if (c.movement_mode == TG_BMOVE_XY) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; }
+    else if (c.movement_mode == TG_BMOVE_XYZ) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2]; }
+    else if (c.movement_mode == TG_BMOVE_RXRY) { enc[3] = (T)a[0]; enc[4] = (T)a[1]; }
+    else { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[3] = (T)a[2]; enc[4] = (T)a[3]; }
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+    T qd_des[N];
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+#pragma unroll
+    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+    const T embed = (T)st.embed[env];
+    const V3<T> grav = mk(T(0), T(0), (T)st.gravity[env]);
+    const V3<T> pivot_b = mk(T(0), T(0), -c.obj_base_height / T(2) + embed);
+    const V3<T> fext = load_v3(c.ext_force);
+    const V3<T> pext = mk((T)st.ext_pos[0 * n + env], (T)st.ext_pos[1 * n + env], (T)st.ext_pos[2 * n + env]);
+    const bool pending = st.ext_pending[env] != 0;
+    T qdummy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    for (int t = 0; t < c.action_repeat; ++t)
+        sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body,
+                                               pivot_b, fext, pext, pending && t == 0);
+    st.ext_pending[env] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    store_body<T>(st, n, env, b);
+    finish_body<T, TOPO>(m, c, st, env, q, b, embed, step_count, true);
+}
+
+// BaseObjectEnv.reset (base_object_env.py:146-173) for object_balance: reset_task (gravity, embed), Robot.reset with the pole
+// still tied to the TCP, reset_object (teleport + one-shot random force).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                   const uint8_t* __restrict__ mask) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    uint64_t rs = st.rng[env];
+    const double gz = c.rand_gravity ? rng_uniform(rs, c.gravity_lo, c.gravity_hi) : c.gravity_default;   // reset_task :301-306
+    double embed = st.embed[env];
+    if (c.rand_embed) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);                                    // :308-316
+    st.gravity[env] = gz;
+    st.embed[env] = embed;
+    st.step_count[env] = 0;
+    const V3<T> grav = mk(T(0), T(0), (T)gz);
+    const V3<T> pivot_b = mk(T(0), T(0), -c.obj_base_height / T(2) + (T)embed);
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+    // Robot.reset: IK to the work-frame origin, rpy 0 (update_init_pose, base_object_env.py:96-103)
+    const V3<T> tpos = load_v3(c.work_pos);
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    T cv = T(0.001);
+    T zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    const V3<T> z3 = mk<T>(0, 0, 0);
+    int used = 0;
+    for (int it = 0; it < 1000; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], step_j[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        if (all_small) cv = cv / T(2);
+        sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, grav, b, c.body,
+                                               pivot_b, z3, z3, false);
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.reset_ticks[env] = used;
+    // reset_object (object_balance_env.py:330-381): teleport, then a one-shot downward force at a random point of the base plate
+    b.pos = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - (T)embed);
+    b.R = c.obj_init_rot;
+    b.v = z3; b.w = z3;
+    const double sx = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
+    const double rx = rng_uniform(rs, 0.0, 1.0);
+    const double sy = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
+    const double ry = rng_uniform(rs, 0.0, 1.0);
+    st.rng[env] = rs;
+    st.ext_pos[0 * n + env] = (double)b.pos.x + sx * rx * (double)c.obj_base_width / 2.0;
+    st.ext_pos[1 * n + env] = (double)b.pos.y + sy * ry * (double)c.obj_base_width / 2.0;
+    st.ext_pos[2 * n + env] = (double)b.pos.z;
+    st.ext_pending[env] = 1;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+    store_body<T>(st, n, env, b);
+    finish_body<T, TOPO>(m, c, st, env, q, b, (T)embed, 0, false);
+}
+
 // Recompute cached read-backs after tg_set_joint_state.
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_refresh(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st) {
@@ -456,7 +674,7 @@ __global__ __launch_bounds__(64) void k_inverse_dynamics(const DevRobot<T>* __re
     T qq[N], qv[N], hb[N], qdm[N], Minv[N][N], trM;
 #pragma unroll
     for (int i = 0; i < N; ++i) { qq[i] = (T)q[s * N + i]; qv[i] = (T)qd[s * N + i]; }
-    dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv, trM);
+    { Kin<T, TOPO> kk; dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv, trM, load_v3(mp->gravity), kk); }
     // tau = M qdd + h ; M qdd obtained by solving Minv x = qdd would be circular, so rebuild M from Minv^-1 is avoided:
     // use linearity  ID(q, qd, qdd) = h + M qdd with M = inverse(Minv) computed by the pivoted solver column by column.
     T A[N][N], b[N], x[N];
@@ -479,7 +697,7 @@ __global__ __launch_bounds__(64) void k_mass_matrix(const DevRobot<T>* __restric
     T qq[N], qv[N], hb[N], qdm[N], Minv[N][N], trM;
 #pragma unroll
     for (int i = 0; i < N; ++i) { qq[i] = (T)q[s * N + i]; qv[i] = T(0); }
-    dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv, trM);
+    { Kin<T, TOPO> kk; dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv, trM, load_v3(mp->gravity), kk); }
 #pragma unroll
     for (int j = 0; j < N; ++j) {   // column j of M = solve(Minv, e_j)
         T A[N][N], b[N], x[N];
@@ -659,7 +877,7 @@ static int check_robot(const tg_robot* r) {
     return 0;
 }
 
-template <typename T> static int build_env_const(const tg_config& cfg, const tg_sensor& sen, EnvConst<T>& c) {
+template <typename T> static int build_env_const(const tg_config& cfg, const tg_sensor& sen, const tg_robot& rob, EnvConst<T>& c) {
     memset(&c, 0, sizeof c);
     c.num_envs = cfg.num_envs;
     c.env_kind = cfg.env_kind;
@@ -671,6 +889,30 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
             case TG_MOVE_XYZRZ: c.act_dim = 4; break;
             default: return fail(-1, "Incorrect movement mode specified");
         }
+    } else if (cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
+        switch (cfg.movement_mode) {     // get_act_dim, object_balance_env.py:565-576
+            case TG_BMOVE_XY: case TG_BMOVE_RXRY: c.act_dim = 2; break;
+            case TG_BMOVE_XYZ: c.act_dim = 3; break;
+            case TG_BMOVE_XYRXRY: c.act_dim = 4; break;
+            default: return fail(-1, "Incorrect movement mode specified");
+        }
+        if (cfg.obj_mass <= 0) return fail(-1, "object_balance: object mass must be positive");
+        c.body.mass = (T)cfg.obj_mass;
+        c.body.com = {(T)cfg.obj_com[0], (T)cfg.obj_com[1], (T)cfg.obj_com[2]};
+        c.body.inertia = {(T)cfg.obj_inertia[0], (T)cfg.obj_inertia[1], (T)cfg.obj_inertia[2], (T)cfg.obj_inertia[4], (T)cfg.obj_inertia[5],
+                          (T)cfg.obj_inertia[8]};
+        c.body.erp = (T)cfg.p2p_erp; c.body.max_impulse = (T)cfg.p2p_max_impulse;
+        c.body.link = rob.tcp_link;   // createConstraint parent = TCP link, parentFramePosition 0 in its inertial frame (:271-283)
+        c.body.pivot_a = {(T)rob.tcp_pos[0], (T)rob.tcp_pos[1], (T)rob.tcp_pos[2]};
+        double oq[4], oR[9];
+        h_quat_from_euler(cfg.obj_init_rpy, oq);
+        h_mat_from_quat(oq, oR);
+        for (int k = 0; k < 9; ++k) c.obj_init_rot.m[k] = (T)oR[k];
+        for (int k = 0; k < 3; ++k) { c.obj_init_rpy_deg[k] = (T)(cfg.obj_init_rpy[k] * 180.0 / 3.141592653589793); c.ext_force[k] = (T)cfg.ext_force[k]; }
+        c.obj_base_width = (T)cfg.obj_base_width; c.obj_base_height = (T)cfg.obj_base_height;
+        c.term_deg = (T)cfg.term_deg; c.term_pos = (T)cfg.term_pos;
+        c.rand_gravity = cfg.rand_gravity; c.rand_embed = cfg.rand_embed;
+        c.gravity_lo = cfg.gravity_lo; c.gravity_hi = cfg.gravity_hi; c.gravity_default = cfg.gravity_default;
     } else {
         switch (cfg.movement_mode) {     // surface_follow_auto_env.py:96-107
             case TG_SMOVE_YZ: case TG_SMOVE_XYZ: c.act_dim = 1; break;
@@ -778,6 +1020,17 @@ template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
                        (const EnvConst<T>*)c->d_const, c->st);
 }
 
+template <typename T> static void launch_step_body_t(tg_ctx* c, const float* d_actions) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_step_body<T, 0>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_actions);
+}
+template <typename T> static void launch_reset_body_t(tg_ctx* c, const uint8_t* d_mask) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_reset_body<T, 0>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_mask);
+}
+
 #define TG_DISPATCH(ctx_dtype, ctx_topo, CALL)                                               \
     do {                                                                                     \
         if ((ctx_dtype) == TG_PHYSICS_F64) {                                                 \
@@ -830,7 +1083,10 @@ static int need_device() {
 // env.reset() for the masked envs: task randomisation, (surface generation), robot reset.
 static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
     Timer t(c, 2);
-    if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
+        if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_reset_body_t<double>(c, d_mask);
+        else launch_reset_body_t<float>(c, d_mask);
+    } else if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 1)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
@@ -858,8 +1114,10 @@ int tg_abi_version(void) { return TG_ABI_VERSION; }
 int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sensor, const tg_mesh* stim, tg_ctx** out) {
     if (!cfg || !robot || !sensor || !out) return fail(-1, "tg_create: NULL argument");
     if (cfg->abi_version != TG_ABI_VERSION) return fail(-1, "tg_create: ABI version mismatch");
-    if (cfg->env_kind != TG_ENV_EDGE_FOLLOW && cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO) return fail(-1, "tg_create: unknown env_kind");
-    if (cfg->env_kind == TG_ENV_EDGE_FOLLOW && !stim) return fail(-1, "tg_create: edge_follow needs a stimulus mesh");
+    if (cfg->env_kind != TG_ENV_EDGE_FOLLOW && cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && cfg->env_kind != TG_ENV_OBJECT_BALANCE)
+        return fail(-1, "tg_create: unknown env_kind");
+    if (cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && !stim) return fail(-1, "tg_create: this env needs a stimulus mesh");
+    if (cfg->env_kind == TG_ENV_OBJECT_BALANCE && robot->topology != 0) return fail(-1, "tg_create: object_balance is built for the UR5 chain");
     if (cfg->num_envs <= 0) return fail(-1, "tg_create: num_envs must be positive");
     if (int rc = check_robot(robot)) return rc;
     const int H = sensor->image_h, W = sensor->image_w;
@@ -879,14 +1137,14 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     if (cfg->physics_dtype == TG_PHYSICS_F64) {
         DevRobot<double> dr; EnvConst<double> ec;
         build_dev_robot(*robot, dr);
-        if (int rc = build_env_const(*cfg, *sensor, ec)) { delete c; return rc; }
+        if (int rc = build_env_const(*cfg, *sensor, *robot, ec)) { delete c; return rc; }
         c->act_dim = ec.act_dim;
         TG_HIP(hipMalloc(&c->d_robot, sizeof dr)); TG_HIP(hipMemcpy(c->d_robot, &dr, sizeof dr, hipMemcpyHostToDevice));
         TG_HIP(hipMalloc(&c->d_const, sizeof ec)); TG_HIP(hipMemcpy(c->d_const, &ec, sizeof ec, hipMemcpyHostToDevice));
     } else {
         DevRobot<float> dr; EnvConst<float> ec;
         build_dev_robot(*robot, dr);
-        if (int rc = build_env_const(*cfg, *sensor, ec)) { delete c; return rc; }
+        if (int rc = build_env_const(*cfg, *sensor, *robot, ec)) { delete c; return rc; }
         c->act_dim = ec.act_dim;
         TG_HIP(hipMalloc(&c->d_robot, sizeof dr)); TG_HIP(hipMemcpy(c->d_robot, &dr, sizeof dr, hipMemcpyHostToDevice));
         TG_HIP(hipMalloc(&c->d_const, sizeof ec)); TG_HIP(hipMemcpy(c->d_const, &ec, sizeof ec, hipMemcpyHostToDevice));
@@ -910,6 +1168,30 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&c->d_nodef_dep, npix * 4)); TG_HIP(hipMemcpy(c->d_nodef_dep, sensor->nodef_dep, npix * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMalloc(&c->d_nodef_gray, npix * 4)); TG_HIP(hipMemcpy(c->d_nodef_gray, sensor->nodef_gray, npix * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMalloc(&c->d_border, npix)); TG_HIP(hipMemcpy(c->d_border, sensor->border_mask, npix, hipMemcpyHostToDevice));
+    if (cfg->env_kind == TG_ENV_OBJECT_BALANCE) {
+        TG_HIP(hipMalloc(&s.body_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.body_rot, 9 * n * 8)); TG_HIP(hipMalloc(&s.body_v, 3 * n * 8));
+        TG_HIP(hipMalloc(&s.body_w, 3 * n * 8)); TG_HIP(hipMalloc(&s.ext_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.gravity, n * 8));
+        TG_HIP(hipMalloc(&s.ext_pending, n));
+        TG_HIP(hipMemset(s.body_v, 0, 3 * n * 8)); TG_HIP(hipMemset(s.body_w, 0, 3 * n * 8)); TG_HIP(hipMemset(s.ext_pos, 0, 3 * n * 8));
+        TG_HIP(hipMemset(s.ext_pending, 0, n));
+        // load_object (base_object_env.py:66-70): loadURDF puts the object's *link* frame at init_obj_pos; the inertial frame used by
+        // get/resetBasePositionAndOrientation is obj_root_inertial_pos away.  setup_object (:185-190): default embed distance.
+        double oq[4], oR[9];
+        h_quat_from_euler(cfg->obj_init_rpy, oq);
+        h_mat_from_quat(oq, oR);
+        double p0[3] = {cfg->workframe_pos[0], cfg->workframe_pos[1], cfg->workframe_pos[2] + cfg->obj_base_height / 2 - cfg->embed_dist};
+        for (int a = 0; a < 3; ++a)
+            p0[a] += oR[3 * a] * cfg->obj_root_inertial_pos[0] + oR[3 * a + 1] * cfg->obj_root_inertial_pos[1] + oR[3 * a + 2] * cfg->obj_root_inertial_pos[2];
+        std::vector<double> bp(3 * (size_t)n), br(9 * (size_t)n), gz(n, cfg->gravity_default), em(n, cfg->embed_dist);
+        for (int i = 0; i < n; ++i) {
+            for (int a = 0; a < 3; ++a) bp[(size_t)a * n + i] = p0[a];
+            for (int a = 0; a < 9; ++a) br[(size_t)a * n + i] = oR[a];
+        }
+        TG_HIP(hipMemcpy(s.body_pos, bp.data(), bp.size() * 8, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(s.body_rot, br.data(), br.size() * 8, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(s.gravity, gz.data(), gz.size() * 8, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(s.embed, em.data(), em.size() * 8, hipMemcpyHostToDevice));
+    }
     if (cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         const size_t cells = (size_t)cfg->surf_rows * cfg->surf_cols;
         TG_HIP(hipMalloc(&s.dir, 2 * n * 8)); TG_HIP(hipMalloc(&s.goal, 3 * n * 8)); TG_HIP(hipMalloc(&s.heights, cells * n * 8));
@@ -940,7 +1222,7 @@ int tg_destroy(tg_ctx* c) {
     drain_events(c);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.reward,
-                    s.step_count, s.reset_ticks, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
+                    s.step_count, s.reset_ticks, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -986,9 +1268,14 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     }
     {
         Timer t(c, 0);
+        if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
+            if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_step_body_t<double>(c, d_act);
+            else launch_step_body_t<float>(c, d_act);
+        } else {
 #define CALL(T, TOPO) launch_step_t<T, TOPO>(c, d_act)
-        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
+        }
     }
     render(c, nullptr, false);
     if (c->cfg.auto_reset) {
@@ -1043,6 +1330,13 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
     if (v->step_count && (rc = fetch_soa(c, c->st.step_count, 1, v->step_count))) return rc;
     if (v->reset_ticks && (rc = fetch_soa(c, c->st.reset_ticks, 1, v->reset_ticks))) return rc;
     if (v->rng_state && (rc = fetch_soa(c, c->st.rng, 1, v->rng_state))) return rc;
+    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
+        if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
+        if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;
+        if (v->body_linvel && (rc = fetch_soa(c, c->st.body_v, 3, v->body_linvel))) return rc;
+        if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
+        if (v->gravity_z && (rc = fetch_soa(c, c->st.gravity, 1, v->gravity_z))) return rc;
+    }
     if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         if (v->goal_pos && (rc = fetch_soa(c, c->st.goal, 3, v->goal_pos))) return rc;
         if (v->direction && (rc = fetch_soa(c, c->st.dir, 2, v->direction))) return rc;
@@ -1057,6 +1351,7 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
 
 int tg_set_joint_state(tg_ctx* c, const double* q, const double* qd) {
     if (!c || !q || !qd) return fail(-1, "NULL argument");
+    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) return fail(-1, "tg_set_joint_state: not supported for object_balance");
     const int n = c->cfg.num_envs, nd = c->robot.ndof;
     std::vector<double> a((size_t)TG_MAX_DOF * n, 0.0), b((size_t)TG_MAX_DOF * n, 0.0);
     for (int i = 0; i < n; ++i)

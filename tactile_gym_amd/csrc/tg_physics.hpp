@@ -197,15 +197,13 @@ template <typename T, int TOPO> __device__ __forceinline__ void link_frame(const
 template <typename T, int TOPO>
 __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], const T (&qd)[Topo<TOPO>::N],
                                                T (&hbias)[Topo<TOPO>::N], T (&qdamp)[Topo<TOPO>::N],
-                                               T (&Minv)[Topo<TOPO>::N][Topo<TOPO>::N], T& traceM) {
+                                               T (&Minv)[Topo<TOPO>::N][Topo<TOPO>::N], T& traceM, const V3<T> g, Kin<T, TOPO>& k) {
     constexpr int N = Topo<TOPO>::N;
-    Kin<T, TOPO> k;
     forward_kinematics<T, TOPO>(m, q, k);
     V3<T> w[N], wd[N], vo[N], ao[N];
     V3<T> WF[N], WN[N], DF[N], DN[N], hc[N];     // bias wrench, damping wrench (about o_i), composite first moment
     S3<T> Io[N];
     T mc[N];
-    const V3<T> g = load_v3(m.gravity);
     // root -> leaf: velocities, velocity-product accelerations (qdd = 0), per-link wrenches about the joint origin
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -420,7 +418,8 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
     // 100 SGPRs and get spilled into VGPR lanes (v_readlane per use).  Re-issuing the s_loads every tick is cheaper.
     asm volatile("" ::: "memory");
     T hb[N], qdm[N], Minv[N][N], traceM;
-    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv, traceM);
+    Kin<T, TOPO> kin;
+    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv, traceM, load_v3(m.gravity), kin);
     T rhs[N], v[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -457,6 +456,218 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
         qd[i] = v[i];
         q[i] += dt * v[i];
     }
+}
+
+// ------------------------------------------------------------------------------------------------ arm + free body + P2P
+// object_balance: a free rigid body (the pole, all links welded) tied to an arm link by a point-to-point constraint
+// (object_balance_env.py:261-283).  One tick = arm forward dynamics as above, free-body forward dynamics (gravity,
+// one-shot external force, gyroscopic torque, no velocity damping), then ONE projected Gauss-Seidel loop over the joint
+// motor rows followed by the three P2P rows (reverse order on even sweeps) [PARITY_ASSUMPTIONS A18-A21].
+// The loop is carried in the Delassus/residual form of the same recurrence:  A = J Minv_sys J^T (9x9),
+//   r_j = rhs_j / A_jj - sum_q (A_jq / A_jj) lambda_q ;  row i: delta = clamp(lambda_i + r_i) - lambda_i ; r_j -= G_ji delta.
+template <typename T> struct FreeBody {
+    V3<T> pos;   // base (inertial) frame origin, world — what getBasePositionAndOrientation reports
+    M3<T> R;     // base frame orientation
+    V3<T> v, w;  // velocity of the composite centre of mass, angular velocity (world)
+};
+template <typename T> struct BodyConst {
+    T mass;
+    V3<T> com;        // composite centre of mass in the base frame
+    S3<T> inertia;    // about com, base-frame axes
+    int link;         // arm link carrying pivot A
+    V3<T> pivot_a;    // in that link's frame
+    T erp, max_impulse;
+};
+
+template <typename T> __device__ __forceinline__ S3<T> inverse(const S3<T>& A) {
+    const T c00 = A.yy * A.zz - A.yz * A.yz, c01 = A.xz * A.yz - A.xy * A.zz, c02 = A.xy * A.yz - A.xz * A.yy;
+    const T id = T(1) / (A.xx * c00 + A.xy * c01 + A.xz * c02);
+    return {c00 * id, c01 * id, c02 * id, (A.xx * A.zz - A.xz * A.xz) * id, (A.xy * A.xz - A.xx * A.yz) * id, (A.xx * A.yy - A.xy * A.xy) * id};
+}
+
+// Orientation update by world angular velocity w over dt: exponential map with Bullet's small-angle branch, then
+// Gram-Schmidt (Bullet renormalises its quaternion).
+template <typename T> __device__ __forceinline__ void integrate_rotation(M3<T>& R, V3<T> w, T dt) {
+    const T ang = norm(w);
+    T k;
+    if (ang < T(0.001)) k = T(0.5) * dt - (dt * dt * dt) * T(0.020833333333) * ang * ang;
+    else { T s, c; tsincos(T(0.5) * ang * dt, &s, &c); k = s / ang; }
+    T sh, qw;
+    tsincos(ang * dt * T(0.5), &sh, &qw);
+    const V3<T> ax = k * w;
+    const T nrm = T(1) / tsqrt(dot(ax, ax) + qw * qw);
+    const T x = ax.x * nrm, y = ax.y * nrm, z = ax.z * nrm, ww = qw * nrm;
+    M3<T> dR;
+    dR.m[0] = T(1) - T(2) * (y * y + z * z); dR.m[1] = T(2) * (x * y - z * ww); dR.m[2] = T(2) * (x * z + y * ww);
+    dR.m[3] = T(2) * (x * y + z * ww); dR.m[4] = T(1) - T(2) * (x * x + z * z); dR.m[5] = T(2) * (y * z - x * ww);
+    dR.m[6] = T(2) * (x * z - y * ww); dR.m[7] = T(2) * (y * z + x * ww); dR.m[8] = T(1) - T(2) * (x * x + y * y);
+    const M3<T> Rn = mul(dR, R);
+    V3<T> c0{Rn.m[0], Rn.m[3], Rn.m[6]}, c1{Rn.m[1], Rn.m[4], Rn.m[7]};
+    c0 = (T(1) / norm(c0)) * c0;
+    c1 = c1 - dot(c0, c1) * c0;
+    c1 = (T(1) / norm(c1)) * c1;
+    const V3<T> c2 = cross(c0, c1);
+    R.m[0] = c0.x; R.m[3] = c0.y; R.m[6] = c0.z;
+    R.m[1] = c1.x; R.m[4] = c1.y; R.m[7] = c1.z;
+    R.m[2] = c2.x; R.m[5] = c2.y; R.m[8] = c2.z;
+}
+
+template <typename T, int TOPO, int MOTOR>
+__device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
+                                              const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
+                                              int iters, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b,
+                                              V3<T> ext_force, V3<T> ext_pos, bool ext_pending) {
+    constexpr int N = Topo<TOPO>::N;
+    constexpr int NR = N + 3;
+    asm volatile("" ::: "memory");
+    T hb[N], qdm[N], Minv[N][N], traceM;
+    Kin<T, TOPO> kin;
+    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin);
+    T v[N];
+    {
+        T rhs[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) rhs[i] = ((hb[i] - m.joint_damp * qd[i]) - hb[i]) + qdm[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += Minv[i][j] * rhs[j];
+            v[i] = qd[i] + dt * acc;
+        }
+    }
+    // free body
+    const S3<T> Iw = rotate(b.R, bc.inertia), Iwi = inverse(Iw);
+    const V3<T> cw = mul(b.R, bc.com);
+    V3<T> xc = b.pos + cw;
+    V3<T> F = bc.mass * gravity, Nt = mk<T>(0, 0, 0);
+    if (ext_pending) { F = F + ext_force; Nt = Nt + cross(ext_pos - xc, ext_force); }
+    Nt = Nt - cross(b.w, mul(Iw, b.w));
+    V3<T> vb = b.v + (dt / bc.mass) * F, wb = b.w + dt * mul(Iwi, Nt);
+    // P2P geometry: pivots, arm translational Jacobian at pivot A
+    V3<T> pa; M3<T> Rl;
+    {
+        const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+        const T pav[3] = {bc.pivot_a.x, bc.pivot_a.y, bc.pivot_a.z};
+        link_frame<T, TOPO>(kin, bc.link, pav, ident, pa, Rl);
+    }
+    const V3<T> pb = b.pos + mul(b.R, pivot_b);
+    const V3<T> rb = pb - xc;
+    T Jt[3][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        bool on_path = false;
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+            if (l == bc.link && is_ancestor_or_self<TOPO>(i, l)) on_path = true;
+        const V3<T> jt = cross(kin.a[i], pa - kin.o[i]);
+        Jt[0][i] = on_path ? jt.x : T(0); Jt[1][i] = on_path ? jt.y : T(0); Jt[2][i] = on_path ? jt.z : T(0);
+    }
+    // W_arm[:, x] = Minv Jt[x, :]^T ; body parts: lin -e_x / m, ang -Iw^-1 (rb x e_x)
+    T Wa[N][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += Minv[i][j] * Jt[x][j];
+            Wa[i][x] = acc;
+        }
+    const V3<T> e[3] = {mk<T>(1, 0, 0), mk<T>(0, 1, 0), mk<T>(0, 0, 1)};
+    V3<T> rxe[3], Wang[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { rxe[x] = cross(rb, e[x]); Wang[x] = mul(Iwi, rxe[x]); }
+    // Delassus matrix A (NR x NR), symmetric
+    T A[NR][NR];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[i][j] = Minv[i][j];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { A[i][N + x] = Wa[i][x]; A[N + x][i] = Wa[i][x]; }
+    }
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+            T acc = (x == y) ? T(1) / bc.mass : T(0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc += Jt[x][i] * Wa[i][y];
+            A[N + x][N + y] = acc + dot(rxe[x], Wang[y]);
+        }
+    // velocity-level right-hand sides and limits
+    T r[NR], lim[NR], lam[NR];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const T pos_term = (MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0);
+        const T des = pos_term + v[i] + kd * (qd_des[i] - v[i]);
+        r[i] = (MOTOR != kMotorOff) ? des - v[i] : T(0);
+        lim[i] = (MOTOR != kMotorOff) ? max_force * dt : T(0);
+    }
+    {
+        V3<T> va = mk<T>(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) va = va + v[i] * mk(Jt[0][i], Jt[1][i], Jt[2][i]);
+        const V3<T> vpb = vb + cross(wb, rb);
+        const V3<T> cv = va - vpb, gap = pa - pb;
+        const T cvv[3] = {cv.x, cv.y, cv.z}, gp[3] = {gap.x, gap.y, gap.z};
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { r[N + x] = (-bc.erp * gp[x] / dt) - cvv[x]; lim[N + x] = bc.max_impulse; }
+    }
+    T G[NR][NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const T jdi = T(1) / A[j][j];
+        r[j] = r[j] * jdi;
+        lam[j] = T(0);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) G[j][i] = A[j][i] * jdi;
+    }
+    for (int it = 0; it < iters; ++it) {
+        if (it & 1) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const T t = r[i];
+                const T sum = lam[i] + t;
+                const T lo = sum < -lim[i] ? -lim[i] : sum;
+                const T sc = lo > lim[i] ? lim[i] : lo;
+                const T delta = (sc == sum) ? t : sc - lam[i];
+                lam[i] = sc;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) r[j] -= G[j][i] * delta;
+            }
+        } else {
+#pragma unroll
+            for (int i = NR - 1; i >= 0; --i) {
+                const T t = r[i];
+                const T sum = lam[i] + t;
+                const T lo = sum < -lim[i] ? -lim[i] : sum;
+                const T sc = lo > lim[i] ? lim[i] : lo;
+                const T delta = (sc == sum) ? t : sc - lam[i];
+                lam[i] = sc;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) r[j] -= G[j][i] * delta;
+            }
+        }
+    }
+    // apply impulses
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc += Minv[i][j] * lam[j];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) acc += Wa[i][x] * lam[N + x];
+        qd[i] = v[i] + acc;
+        q[i] += dt * qd[i];
+    }
+    const V3<T> lp = mk(lam[N], lam[N + 1], lam[N + 2]);
+    b.v = vb - (T(1) / bc.mass) * lp;
+    b.w = wb - mul(Iwi, cross(rb, lp));
+    xc = xc + dt * b.v;
+    integrate_rotation(b.R, b.w, dt);
+    b.pos = xc - mul(b.R, bc.com);
 }
 
 // ------------------------------------------------------------------------------------------------ quaternion / Euler helpers

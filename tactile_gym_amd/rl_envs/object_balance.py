@@ -1,0 +1,141 @@
+"""object_balance-v0 (object_mode "pole") on the HIP path.
+
+Reference: tactile_gym/rl_envs/nonprehensile_manipulation/object_balance/object_balance_env.py on top of
+base_object_env.py: a UR5 + TacTip pointing up carries a pole tied to its TCP by a point-to-point constraint; the agent
+moves the TCP to keep the pole upright.  `ball_on_plate` / `spinning_plate` need rigid contacts and are not built.
+"""
+import math
+import os
+
+import numpy as np
+
+from .. import _capi as capi
+from ..robot_model import ASSETS, MeshDesc, SensorDesc, load_tgmodel, make_robot
+from ..vec_env import TactileVecEnv
+
+REST_POSES = {"ur5": {"standard": [0.19826, -2.01062, -1.96602, -0.73808, 4.71286, -3.34064]}}   # object_balance/rest_poses.py:4-20
+
+env_modes_default = {  # object_balance_env.py:11-19
+    "movement_mode": "xy",
+    "control_mode": "TCP_velocity_control",
+    "object_mode": "pole",
+    "rand_gravity": False,
+    "rand_embed_dist": False,
+    "observation_mode": "oracle",
+    "reward_mode": "dense",
+}
+
+
+def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64", auto_reset=True, device=0, inertia_mode="collision_aabb"):
+    modes = dict(env_modes)
+    for k in ("movement_mode", "control_mode", "object_mode", "rand_gravity", "rand_embed_dist", "observation_mode", "reward_mode",
+              "arm_type", "tactile_sensor_name"):
+        if k not in modes:
+            raise KeyError(k)                                                                   # object_balance_env.py:37-44
+    arm, t_s_name, t_s_type = modes["arm_type"], modes["tactile_sensor_name"], "standard"       # :46
+    if modes["object_mode"] != "pole":
+        if modes["object_mode"] in ("ball_on_plate", "spinning_plate"):
+            raise NotImplementedError(f"object_mode {modes['object_mode']} needs rigid contacts, which are not built yet")
+        raise ValueError(f"unknown object_mode {modes['object_mode']}")
+    if modes["movement_mode"] not in capi.BMOVE:
+        raise ValueError(f"unknown movement_mode {modes['movement_mode']}")
+    if modes["control_mode"] != "TCP_velocity_control":
+        if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
+            raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
+        raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")
+    if arm != "ur5":
+        if arm in ("mg400", "franka_panda", "kuka_iiwa"):
+            raise NotImplementedError(f"arm_type {arm} is not built yet for object_balance")
+        raise SystemExit(f"Incorrect arm type specified {arm}")
+    cfg = capi.TgConfig()
+    cfg.abi_version, cfg.env_kind = capi.ABI_VERSION, capi.ENV_OBJECT_BALANCE
+    cfg.num_envs, cfg.max_steps = int(num_envs), int(max_steps)
+    cfg.movement_mode, cfg.noise_mode, cfg.reward_mode = capi.BMOVE[modes["movement_mode"]], 0, capi.REWARD[modes["reward_mode"]]
+    cfg.physics_dtype = capi.PHYSICS[physics_dtype]
+    cfg.sim_dt = 1.0 / 240.0                                                                    # :33
+    cfg.action_repeat = int(np.floor((1.0 / 20.0) / cfg.sim_dt))                                # :34-35 -> 12
+    cfg.solver_iterations = 150
+    cfg.auto_reset, cfg.device = int(auto_reset), int(device)
+    cfg.min_action, cfg.max_action = -0.25, 0.25                                                # :111
+    v, w = 0.01, 5.0 * (math.pi / 180)                                                          # :123-131
+    lo, hi = [-v, -v, -v, -w, -w, 0.0], [v, v, v, w, w, 0.0]
+    a = 45 * math.pi / 180
+    lims = [(-0.1, 0.1)] * 3 + [(-a, a)] * 3                                                    # :64-76
+    for d in range(6):
+        cfg.act_lo[d], cfg.act_hi[d] = lo[d], hi[d]
+        cfg.tcp_lims[d][0], cfg.tcp_lims[d][1] = lims[d]
+    wf_pos, wf_rpy = (0.55, 0.0, 0.35), (0.0, 0.0, 0.0)                                         # :61-62
+    for k in range(3):
+        cfg.workframe_pos[k], cfg.workframe_rpy[k] = wf_pos[k], wf_rpy[k]
+    cfg.embed_dist = {"tactip": 0.0035, "digitac": 0.0015, "digit": 0.0015}[t_s_name]           # :53-58
+    cfg.embed_lo, cfg.embed_hi = {"tactip": (0.003, 0.006), "digitac": (0.001, 0.0025), "digit": (0.0015, 0.0025)}[t_s_name]   # :308-316
+    cfg.rand_gravity, cfg.rand_embed = int(bool(modes["rand_gravity"])), int(bool(modes["rand_embed_dist"]))
+    cfg.gravity_lo, cfg.gravity_hi, cfg.gravity_default = -1.0, -0.1, -0.1                      # :301-306
+    suffix = "" if inertia_mode == "collision_aabb" else "_urdfinertia"
+    z = np.load(os.path.join(ASSETS, "objects", f"pole{suffix}.npz"))
+    cfg.obj_mass = float(z["mass"])
+    for k in range(3):
+        cfg.obj_com[k] = float(z["com"][k])
+        cfg.obj_root_inertial_pos[k] = float(z["root_inertial_pos"][k])
+        cfg.obj_init_rpy[k] = [0.0, 0.0, -math.pi / 2][k]                                       # :190
+        cfg.ext_force[k] = [0.0, 0.0, -0.1][k]                                                  # :347 force_mag 0.1, direction (0,0,-1) :374-375
+    for k in range(9):
+        cfg.obj_inertia[k] = float(z["inertia"].reshape(9)[k])
+    cfg.obj_base_width, cfg.obj_base_height = 0.1, 0.0025                                       # :158-159
+    cfg.term_deg, cfg.term_pos = 35.0, 0.1                                                      # :50-51
+    cfg.p2p_erp, cfg.p2p_max_impulse = 0.2, 500.0                                               # PARITY_ASSUMPTIONS A18-A19
+    tg = load_tgmodel(arm, t_s_type, t_s_name, inertia_mode)
+    robot = make_robot(tg, REST_POSES[arm][t_s_type], t_s_name)
+    sensor = SensorDesc(t_s_name, t_s_type, image_size, turn_off_border=False)
+    mesh = MeshDesc(z["verts"], z["tris"])
+    return cfg, robot, sensor, mesh, modes
+
+
+class ObjectBalanceVecEnv(TactileVecEnv):
+    def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
+                 device=0, obs_mode="numpy", seed=None):
+        cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
+        self.env_modes = modes
+        self.min_action, self.max_action = cfg.min_action, cfg.max_action
+        act_dim = {"xy": 2, "xyz": 3, "RxRy": 2, "xyRxRy": 4}[modes["movement_mode"]]           # :565-576
+        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+                         act_dim=act_dim, oracle_dim=26)
+
+    def oracle_obs(self):
+        raise NotImplementedError("oracle observation vector for object_balance is not built yet (SURVEY 8f rank 1)")
+
+
+class ObjectBalanceEnv:
+    """Single-env gym.Env surface; constructor signature as object_balance_env.py:23-30."""
+
+    metadata = {"render.modes": ["rgb_array"]}
+
+    def __init__(self, max_steps=1000, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
+                 physics_dtype="f64", device=0):
+        if show_gui or show_tactile:
+            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
+        self._vec = ObjectBalanceVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
+        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
+        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
+
+    @classmethod
+    def make_vec(cls, num_envs, **kwargs):
+        kwargs.pop("show_gui", None)
+        kwargs.pop("show_tactile", None)
+        return ObjectBalanceVecEnv(num_envs, **kwargs)
+
+    def seed(self, seed=None):
+        return self._vec.seed(seed)[:1]
+
+    def reset(self):
+        return {k: v[0] for k, v in self._vec.reset().items()}
+
+    def step(self, action):
+        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
+        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
+
+    def render(self, mode="rgb_array"):
+        return self._vec.render(mode)
+
+    def close(self):
+        self._vec.close()

@@ -454,3 +454,83 @@ def visual_meshes_of_link(path, link_name):
     if not out_v:
         return np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int32)
     return np.concatenate(out_v), np.concatenate(out_t)
+
+
+# ----------------------------------------------------------------------------- free objects (pole, cube, ...)
+def _box_mesh(size):
+    hx, hy, hz = (0.5 * float(s) for s in size)
+    v = np.array([[sx * hx, sy * hy, sz * hz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+    # vertex index = 4*ix + 2*iy + iz
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    t = []
+    for a, b, c, d in quads:
+        t += [(a, b, c), (a, c, d)]
+    return v, np.asarray(t, dtype=np.int32)
+
+
+def compile_free_body(path, inertia_mode="collision_aabb"):
+    """Flatten a URDF whose links are all welded together (fixed joints only) into one rigid body.
+
+    Returns a dict in the *inertial frame of the root link* — the frame PyBullet's get/resetBasePositionAndOrientation
+    report: mass, com [3], inertia [3,3] about com (root inertial axes), verts float32 [V,3] / tris int32 [T,3] of the
+    visual geometry (boxes and meshes), link_masses.  Used for the object_balance pole and the object_push cube."""
+    links, joints = parse_urdf(path)
+    assert all(j.jtype == "fixed" for j in joints), "compile_free_body: only welded objects are supported"
+    urdf_dir = os.path.dirname(os.path.abspath(path))
+    children = {j.child for j in joints}
+    root = [n for n in links if n not in children][0]
+    # pose of every link frame in the root link frame
+    pose = {root: (np.eye(3), np.zeros(3))}
+    pending = list(joints)
+    while pending:
+        for j in list(pending):
+            if j.parent in pose:
+                R, p = pose[j.parent]
+                pose[j.child] = (R @ rpy_to_mat(j.rpy), R @ np.asarray(j.xyz, dtype=np.float64) + p)
+                pending.remove(j)
+    Lr = links[root]
+    R0, p0 = rpy_to_mat(Lr.com_rpy), np.asarray(Lr.com_xyz, dtype=np.float64)   # root inertial frame in root link frame
+
+    def to_root_inertial(R, p):   # link-frame pose (R, p in root link frame) -> root inertial frame
+        return R0.T @ R, R0.T @ (p - p0)
+
+    parts, verts, tris, base = [], [], [], 0
+    for name, L in links.items():
+        Rl, pl = pose[name]
+        Rc, pc = rpy_to_mat(L.com_rpy), np.asarray(L.com_xyz, dtype=np.float64)
+        Ri, pi = to_root_inertial(Rl @ Rc, Rl @ pc + pl)                        # this link's inertial frame
+        if inertia_mode == "urdf":
+            ixx, ixy, ixz, iyy, iyz, izz = L.inertia
+            I = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+        else:
+            lo = hi = None
+            for g in L.collisions:
+                a, b = _geom_aabb_in(Rc, pc, g, urdf_dir, None)
+                lo = a if lo is None else np.minimum(lo, a)
+                hi = b if hi is None else np.maximum(hi, b)
+            l = (hi - lo) if lo is not None else np.zeros(3)
+            I = np.diag(L.mass / 12.0 * np.array([l[1] ** 2 + l[2] ** 2, l[0] ** 2 + l[2] ** 2, l[0] ** 2 + l[1] ** 2]))
+        if L.mass > 0:
+            parts.append((L.mass, pi, Ri @ I @ Ri.T))
+        for g in L.visuals:
+            Rg, pg = rpy_to_mat(g.origin_rpy), np.asarray(g.origin_xyz, dtype=np.float64)
+            if g.kind == "box":
+                v, t = _box_mesh(g.size)
+            elif g.kind == "mesh" and find_mesh_file(urdf_dir, g.mesh):
+                v, t = load_mesh(find_mesh_file(urdf_dir, g.mesh))
+                v = v * np.asarray(g.scale, dtype=np.float64)
+            else:
+                continue
+            Rv, pv = to_root_inertial(Rl @ Rg, Rl @ pg + pl)
+            verts.append(v @ Rv.T + pv)
+            tris.append(t + base)
+            base += v.shape[0]
+    mass = sum(m for m, _, _ in parts)
+    com = sum(m * p for m, p, _ in parts) / mass
+    inertia = np.zeros((3, 3))
+    for m, p, I in parts:
+        d = p - com
+        inertia += I + m * ((d @ d) * np.eye(3) - np.outer(d, d))
+    return dict(mass=np.array(mass), com=com, inertia=inertia, verts=np.concatenate(verts).astype(np.float32),
+                tris=np.concatenate(tris).astype(np.int32), link_masses=np.array([m for m, _, _ in parts]),
+                root_inertial_pos=p0, root_inertial_rot=R0)

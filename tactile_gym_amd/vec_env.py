@@ -216,6 +216,9 @@ class TactileVecEnv:
         out = dict(q=np.zeros((n, nd)), qd=np.zeros((n, nd)), qd_target=np.zeros((n, nd)), tcp_pos=np.zeros((n, 3)),
                    tcp_rpy=np.zeros((n, 3)), edge_ang=np.zeros(n), embed_dist=np.zeros(n), stim_xform=np.zeros((n, 12), np.float32),
                    step_count=np.zeros(n, np.int32), reset_ticks=np.zeros(n, np.int32), rng_state=np.zeros(n, np.uint64))
+        if self._cfg.env_kind == capi.ENV_OBJECT_BALANCE:
+            out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
+                       gravity_z=np.zeros(n))
         if self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO:
             out.update(goal_pos=np.zeros((n, 3)), direction=np.zeros((n, 2)), surf_zoff=np.zeros(n, np.float32),
                        heights=np.zeros((n, self._cfg.surf_rows, self._cfg.surf_cols)))

@@ -349,3 +349,44 @@ def test_surface_follow_env_matches_oracle():
             assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
             assert np.array_equal(obs["tactile"][i], ro["tactile"]), (step, i, int((obs["tactile"][i] != ro["tactile"]).sum()))
     venv.close()
+
+
+BAL_MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=True, rand_embed_dist=True,
+                 observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+
+
+@pytest.mark.parametrize("size", [128, 256])
+def test_object_balance_env_matches_oracle(size):
+    """object_balance-v0 (UR5 + TacTip, pole on a point-to-point constraint; BASELINE config 5 modes, 256x256 there): two
+    consecutive episodes (the second reset drags the fallen pole along, base_object_env.py:146-173), 6 envs vs 6 oracle envs.
+    Joint angles 1e-8 rad, pole pose 1e-7 (the coupled solve runs in a different but equivalent form), images bit-exact
+    except where a 1e-8 pose difference straddles a float32 rounding (<= 3 pixels allowed per image)."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleObjectBalanceEnv
+    n = 6
+    venv = tg.make_vec("object_balance-v0", num_envs=n, max_steps=8, image_size=[size, size], env_modes=BAL_MODES, seed=71, auto_reset=False)
+    oracles = [OracleObjectBalanceEnv(seed=71 + i, max_steps=8, image_size=(size, size), env_modes=BAL_MODES) for i in range(n)]
+    rng = np.random.default_rng(72)
+    for episode in range(2):
+        obs = venv.reset()
+        ref = [o.reset() for o in oracles]
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            assert st["gravity_z"][i] == o.gravity and st["embed_dist"][i] == o.embed_dist
+            assert st["reset_ticks"][i] == o.reset_ticks
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8
+            assert np.abs(st["body_pos"][i] - o.body_pose()[0]).max() < 1e-12
+            assert int((obs["tactile"][i] != ref[i]["tactile"]).sum()) <= 3
+        for step in range(8):
+            a = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+            obs, rew, done, _ = venv.step(a)
+            st = venv.get_state()
+            for i, o in enumerate(oracles):
+                ro, rr, rd, _ = o.step(a[i])
+                pos, R = o.body_pose()
+                assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8, (episode, step, i)
+                assert np.abs(st["body_pos"][i] - pos).max() < 1e-7 and np.abs(st["body_rot"][i] - R).max() < 1e-7, (episode, step, i)
+                assert rew[i] == rr and bool(done[i]) == rd
+                assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (episode, step, i)
+        assert done.all()
+    venv.close()

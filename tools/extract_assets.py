@@ -7,6 +7,7 @@ Reads (never copies verbatim) from /root/reference/tactile_gym/assets:
   * robot URDFs + collision meshes  -> tactile_gym_amd/assets/robots/<arm>_<type>_<sensor>.npz   (TGModel arrays)
   * sensor reference images (.npy)  -> tactile_gym_amd/assets/sensors/<sensor>_<type>_<N>.npz     (hot-path constants a15)
   * stimulus meshes                 -> tactile_gym_amd/assets/stimuli/<name>.npz                  (float32 verts, int32 tris)
+  * free objects (pole, cube)       -> tactile_gym_amd/assets/objects/<name>.npz                  (mass, com, inertia, visual triangles)
   * skin / body visual meshes       -> tests/golden/<sensor>_<type>_view.npz                      (fixture-pinning only)
 
 Nothing under tests/, bench.py or smoke() reads /root/reference at run time; they read these blobs.
@@ -19,7 +20,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tactile_gym_amd.urdf_compile import compile_urdf, load_mesh, parse_urdf, rpy_to_mat, visual_meshes_of_link  # noqa: E402
+from tactile_gym_amd.urdf_compile import compile_free_body, compile_urdf, load_mesh, parse_urdf, rpy_to_mat, visual_meshes_of_link  # noqa: E402
 
 REF = os.environ.get("TG_REFERENCE_ASSETS", "/root/reference/tactile_gym/assets")
 OUT = os.path.join(ROOT, "tactile_gym_amd", "assets")
@@ -121,7 +122,18 @@ def golden_views():
              body_verts=vb.astype(np.float32), body_tris=tb.astype(np.int32))
 
 
+def objects():
+    """Free objects (welded URDFs) flattened to one rigid body + their visual triangles."""
+    for name, rel in (("pole", "rl_env_assets/nonprehensile_manipulation/object_balance/pole/pole.urdf"),
+                      ("cube", "rl_env_assets/nonprehensile_manipulation/object_push/cube/cube.urdf")):
+        for mode in ("collision_aabb", "urdf"):
+            d = compile_free_body(os.path.join(REF, rel), inertia_mode=mode)
+            suffix = "" if mode == "collision_aabb" else "_urdfinertia"
+            save(os.path.join(OUT, "objects", f"{name}{suffix}.npz"), **d)
+
+
 if __name__ == "__main__":
+    objects()
     robots()
     sensors()
     stimuli()

@@ -79,11 +79,12 @@ class _OracleArmEnv:
     SOLVER_ITERS = 150                   # base_tactile_env.py:128-130
 
     def _setup_arm(self, seed, modes, max_steps, image_size, t_s_type, rest_poses, inertia):
-        assert modes["control_mode"] == "TCP_velocity_control" and modes["arm_type"] == "ur5"
+        assert modes["control_mode"] == "TCP_velocity_control" and modes["arm_type"] in ("ur5", "mg400")
         self.modes, self.max_steps, self.image_size = modes, max_steps, tuple(image_size)
+        self.arm_type = modes["arm_type"]
         self.t_s_name, self.t_s_type = modes["tactile_sensor_name"], t_s_type
         suffix = "" if inertia == "collision_aabb" else "_urdfinertia"
-        self.tg = load_tg(f"ur5_{t_s_type}_{self.t_s_name}{suffix}")
+        self.tg = load_tg(f"{self.arm_type}_{t_s_type}_{self.t_s_name}{suffix}")
         self.arm = mb.Arm(self.tg)
         self.rng = Rng(seed)
         self.min_action, self.max_action = -0.25, 0.25
@@ -144,11 +145,15 @@ class _OracleArmEnv:
         Rw = pm.mat_from_quat(self.workframe_orn)                                       # workvel_to_worldvel :96-105
         vels = np.concatenate([Rw @ vels[:3], Rw @ vels[3:]])
         jac = self.arm.jacobian("tcp_link", self.arm.q)                                 # :300-310
-        if jac.shape[1] > np.linalg.matrix_rank(jac.T):                                 # :316-319
-            inv_jac = np.linalg.pinv(jac)
+        if self.arm_type == "mg400":                                                    # mg400.py:77-129: always pinv, then slave
+            req = np.linalg.pinv(jac) @ vels                                            # the parallel-linkage joints by hand
+            req[-3], req[-2], req[-1] = req[1], -req[1], req[1] + req[2]
         else:
-            inv_jac = np.linalg.inv(jac)
-        req = inv_jac @ vels                                                            # :322
+            if jac.shape[1] > np.linalg.matrix_rank(jac.T):                             # :316-319
+                inv_jac = np.linalg.pinv(jac)
+            else:
+                inv_jac = np.linalg.inv(jac)
+            req = inv_jac @ vels                                                        # :322
         self.arm.set_motors_velocity(req, self.vel_gain, self.max_force)                # :325-332
         self.last_req_joint_vels = req
 
@@ -185,6 +190,9 @@ class _OracleArmEnv:
         torn = pm.quat_from_euler(trpy)
         joint_poses = self.arm.inverse_kinematics("tcp_link", tpos, torn, 100, 1e-8)
         self.arm.set_motors_position(joint_poses, np.zeros(self.arm.n), self.pos_gain, self.vel_gain, self.max_force)
+        if self.arm_type == "mg400":                                                    # mg400.py:222-227 (target_joints only)
+            joint_poses = joint_poses.copy()
+            joint_poses[-3], joint_poses[-2], joint_poses[-1] = joint_poses[1], -joint_poses[1], joint_poses[1] + joint_poses[2]
         self.reset_ticks = self._blocking_move(tpos, torn, joint_poses, max_steps=1000, constant_vel=0.001)
 
     # ---- base_tactile_env.py:141-185 (scale + apply + step data + observation); encode_actions is per task
@@ -223,21 +231,32 @@ class OracleEdgeFollowEnv(_OracleArmEnv):
             "digitac": [0.16664443404149898, -2.2242489977536737, -1.6618744232210114, -0.8258663681806591, 1.5731514988184077,
                         1.7398302172182332]}
 
+    # mg400 rows of edge_follow/rest_poses.py, control joints (j1, j2_1, j3_1, j4_1, j5, j2_2, j3_2, j4_2)
+    REST_MG400 = {"tactip": [0.0, 1.1199979523765513, -0.027746434948259045, -1.094390587897371, 0.000795099112695166,
+                             1.120002713232204, -1.1199729024887553, 1.0922685386653785],
+                  "digit": [0.0, 1.3190166816731614, -0.057932730559221525, -1.2611243932983605, 0.0006084288058448784,
+                            1.3190195840338783, -1.3189925313906967, 1.2610906509351185],
+                  "digitac": [0.0, 1.3223687315585777, -0.06290495221125363, -1.2594762221064615, 0.0006084288058448784,
+                              1.3223720640647498, -1.3223720640647498, 1.2594757646221153]}
+
     def __init__(self, seed=0, max_steps=200, image_size=(128, 128), env_modes=None, inertia="collision_aabb"):
         modes = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height",
                      observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
         modes.update(env_modes or {})
-        self._setup_arm(seed, modes, max_steps, image_size, "standard", self.REST[modes["tactile_sensor_name"]], inertia)   # :59-64
+        mg = modes["arm_type"] == "mg400"
+        rest = (self.REST_MG400 if mg else self.REST)[modes["tactile_sensor_name"]]
+        self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # :59-64
         max_pos_vel, max_ang_vel = 0.01, 5.0 * (math.pi / 180)                             # :158-159
         self.act_lo = np.array([-max_pos_vel] * 3 + [0.0, 0.0, -max_ang_vel])              # :161-166
         self.act_hi = np.array([max_pos_vel] * 3 + [0.0, 0.0, max_ang_vel])
-        self.edge_pos = np.array([0.65, 0.0, 0.0])                                         # :84 well_designed_pos
-        self.edge_height, self.edge_len = 0.035, 0.175                                     # :203,207
+        self.edge_pos = np.array([0.33, 0.0, 0.0] if mg else [0.65, 0.0, 0.0])             # :76,84 well_designed_pos
+        self.edge_height, self.edge_len = 0.035, (0.105 if mg else 0.175)                  # :203-207
         self.termination_dist = 0.01                                                       # :67
-        self.TCP_lims = np.array([[-0.175, 0.175], [-0.175, 0.175], [-0.1, 0.1], [0, 0], [0, 0], [-math.pi, math.pi]])  # :85-90
+        xy = (0.150, 0.11) if mg else (0.175, 0.175)                                       # :77-90
+        self.TCP_lims = np.array([[-xy[0], xy[0]], [-xy[1], xy[1]], [-0.1, 0.1], [0, 0], [0, 0], [-math.pi, math.pi]])
         self.embed_dist = 0.0035                                                           # :94-99
-        self._set_workframe([0.65, 0.0, self.edge_height], [-math.pi, 0.0, math.pi / 2])   # :106-107
-        e = np.load(os.path.join(_ASSETS, "stimuli", "long_edge.npz"))
+        self._set_workframe([self.edge_pos[0], 0.0, self.edge_height], [-math.pi, 0.0, math.pi / 2])   # :106-107
+        e = np.load(os.path.join(_ASSETS, "stimuli", "short_edge.npz" if mg else "long_edge.npz"))   # :220-223
         self.edge_verts, self.edge_tris = e["verts"], e["tris"]
 
     # ---- edge_follow_env.py:237-283

@@ -229,9 +229,10 @@ __device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const
         solve_pivoted<T, 6>(A, b, x);
 #pragma unroll
         for (int i = 0; i < N; ++i) qd_des[i] = x[i < 6 ? i : 0];
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) qd_des[i] = T(0);   // MG400 pseudo-inverse path: not built yet
+    } else {       // MG400 (mg400.py:77-129): the Jacobian is 6 x 8, always the pseudo-inverse, then the parallel-linkage joints
+        const T b[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z};   // (j2_2, j3_2, j4_2) are slaved to (j2_1, j3_1) by hand (:115-120)
+        pinv_apply<T, N>(J, b, qd_des);
+        if (N == 8) { qd_des[N - 3] = qd_des[1]; qd_des[N - 2] = -qd_des[1]; qd_des[N - 1] = qd_des[1] + qd_des[2]; }
     }
 }
 
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
 #pragma unroll
     for (int i = 0; i < N; ++i) qik[i] = q[i];
     inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }   // mg400.py:222-227 target_joints override
 
     // blocking_move(max_steps=1000, constant_vel=0.001)
     T cv = T(0.001);

@@ -761,6 +761,61 @@ template <typename T, int N> __device__ __forceinline__ void solve_pivoted(T (&A
     }
 }
 
+// x = pinv(J) b for a 6 x N Jacobian (np.linalg.pinv(jac) @ v, mg400.py:105-107): one-sided (Hestenes) Jacobi SVD.
+// Row pairs of A = J are rotated until mutually orthogonal, A_final = U^T J with rows sigma_i v_i^T, so
+//   pinv(J) b = sum_i  row_i(A_final) (u_i . b) / sigma_i^2   over sigma_i > rcond * sigma_max   (numpy: rcond = 1e-15).
+// Fixed sweep count, branch-free rotations, compile-time indices only.
+template <typename T, int N> __device__ __forceinline__ void pinv_apply(const T (&J)[6][N], const T (&b)[6], T (&x)[N]) {
+    T A[6][N], U[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) A[r][c] = J[r][c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) U[r][c] = (r == c) ? T(1) : T(0);   // U[r][:] = u_r^T (rows accumulate the same rotations)
+    }
+    for (int sweep = 0; sweep < 10; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p)
+#pragma unroll
+            for (int qq = p + 1; qq < 6; ++qq) {
+                T alpha = T(0), beta = T(0), gamma = T(0);
+#pragma unroll
+                for (int c = 0; c < N; ++c) { alpha += A[p][c] * A[p][c]; beta += A[qq][c] * A[qq][c]; gamma += A[p][c] * A[qq][c]; }
+                // rotation that zeroes the inner product (skipped when already orthogonal to rounding)
+                const bool rot = tabs(gamma) > T(1e-300) && gamma * gamma > (alpha * beta) * T(1e-32);
+                const T zeta = rot ? (beta - alpha) / (T(2) * gamma) : T(0);
+                const T tt = rot ? ((zeta >= T(0) ? T(1) : T(-1)) / (tabs(zeta) + tsqrt(T(1) + zeta * zeta))) : T(0);
+                const T cs = T(1) / tsqrt(T(1) + tt * tt), sn = cs * tt;
+#pragma unroll
+                for (int c = 0; c < N; ++c) { const T ap = A[p][c], aq = A[qq][c]; A[p][c] = cs * ap - sn * aq; A[qq][c] = sn * ap + cs * aq; }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { const T up = U[p][c], uq = U[qq][c]; U[p][c] = cs * up - sn * uq; U[qq][c] = sn * up + cs * uq; }
+            }
+    }
+    T s2[6], s2max = T(0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        T acc = T(0);
+#pragma unroll
+        for (int c = 0; c < N; ++c) acc += A[r][c] * A[r][c];
+        s2[r] = acc;
+        s2max = acc > s2max ? acc : s2max;
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) x[c] = T(0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        T ub = T(0);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ub += U[r][c] * b[c];
+        const bool keep = s2[r] > s2max * T(1e-30);     // sigma > 1e-15 sigma_max
+        const T w = keep ? ub / s2[r] : T(0);
+#pragma unroll
+        for (int c = 0; c < N; ++c) x[c] += A[r][c] * w;
+    }
+}
+
 // Geometric Jacobian of the TCP frame origin, world frame: rows 0-2 translational, 3-5 rotational
 // (calculateJacobian(link, localPosition = 0), base_robot_arm.py:300-310).
 template <typename T, int TOPO>

@@ -22,6 +22,15 @@ REST_POSES = {
         "digitac": {"standard": [0.16664443404149898, -2.2242489977536737, -1.6618744232210114, -0.8258663681806591,
                                  1.5731514988184077, 1.7398302172182332]},
     },
+    # control joints (j1, j2_1, j3_1, j4_1, j5, j2_2, j3_2, j4_2) = URDF joints 0-4, 9-11 of rest_poses.py:95-153
+    "mg400": {
+        "tactip": {"standard": [0.0, 1.1199979523765513, -0.027746434948259045, -1.094390587897371, 0.000795099112695166,
+                                1.120002713232204, -1.1199729024887553, 1.0922685386653785]},
+        "digit": {"standard": [0.0, 1.3190166816731614, -0.057932730559221525, -1.2611243932983605, 0.0006084288058448784,
+                               1.3190195840338783, -1.3189925313906967, 1.2610906509351185]},
+        "digitac": {"standard": [0.0, 1.3223687315585777, -0.06290495221125363, -1.2594762221064615, 0.0006084288058448784,
+                                 1.3223720640647498, -1.3223720640647498, 1.2594757646221153]},
+    },
 }
 
 env_modes_default = {  # edge_follow_env.py:12-19 (the reference default omits tactile_sensor_name and cannot be constructed)
@@ -46,10 +55,11 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
             raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
         raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")             # robot.py:174
-    if arm != "ur5":
-        if arm in ("mg400", "franka_panda", "kuka_iiwa"):
-            raise NotImplementedError(f"arm_type {arm} is not built yet for edge_follow (BASELINE configs 1-2 use ur5)")
+    if arm not in ("ur5", "mg400"):
+        if arm in ("franka_panda", "kuka_iiwa"):
+            raise NotImplementedError(f"arm_type {arm} is out of scope (SURVEY section 2: preliminary upstream)")
         raise SystemExit(f"Incorrect arm type specified {arm}")                                  # robot.py:65
+    mg = arm == "mg400"
     if modes["movement_mode"] not in capi.MOVE:
         raise ValueError(f"unknown movement_mode {modes['movement_mode']}")
     cfg = capi.TgConfig()
@@ -68,11 +78,12 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     max_pos_vel, max_ang_vel = 0.01, 5.0 * (math.pi / 180)                                       # :158-159
     lo = [-max_pos_vel] * 3 + [0.0, 0.0, -max_ang_vel]                                           # :161-166
     hi = [max_pos_vel] * 3 + [0.0, 0.0, max_ang_vel]
-    lims = [(-0.175, 0.175), (-0.175, 0.175), (-0.1, 0.1), (0.0, 0.0), (0.0, 0.0), (-math.pi, math.pi)]  # :85-90
+    xy = (0.150, 0.11) if mg else (0.175, 0.175)                                                 # :75-90
+    lims = [(-xy[0], xy[0]), (-xy[1], xy[1]), (-0.1, 0.1), (0.0, 0.0), (0.0, 0.0), (-math.pi, math.pi)]
     for d in range(6):
         cfg.act_lo[d], cfg.act_hi[d] = lo[d], hi[d]
         cfg.tcp_lims[d][0], cfg.tcp_lims[d][1] = lims[d]
-    edge_pos, edge_height, edge_len = (0.65, 0.0, 0.0), 0.035, 0.175                             # :84,201-207
+    edge_pos, edge_height, edge_len = ((0.33, 0.0, 0.0) if mg else (0.65, 0.0, 0.0)), 0.035, (0.105 if mg else 0.175)   # :76,84,201-207
     wf_pos, wf_rpy = (edge_pos[0], edge_pos[1], edge_height), (-math.pi, 0.0, math.pi / 2)       # :106-107
     for k in range(3):
         cfg.workframe_pos[k], cfg.workframe_rpy[k], cfg.stim_pos[k] = wf_pos[k], wf_rpy[k], edge_pos[k]
@@ -82,7 +93,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     tg = load_tgmodel(arm, t_s_type, t_s_name)
     robot = make_robot(tg, REST_POSES[arm][t_s_name][t_s_type], t_s_name)
     sensor = SensorDesc(t_s_name, t_s_type, image_size, turn_off_border=False)                   # :121
-    mesh = MeshDesc.load("long_edge")                                                            # :223
+    mesh = MeshDesc.load("short_edge" if mg else "long_edge")                                    # :220-223
     return cfg, robot, sensor, mesh, modes
 
 

@@ -29,3 +29,14 @@ def ur5_tactip():
     tg = load_tgmodel("ur5", "standard", "tactip")
     rest = REST_POSES["ur5"]["tactip"]["standard"]
     return tg, (lambda: mb.Arm(tg)), make_robot(tg, rest, "tactip"), rest
+
+
+@pytest.fixture(scope="session")
+def mg400_tactip():
+    """(TGModel, oracle Arm factory, tg_robot, rest) for MG400 + standard TacTip (8 control joints, tree topology)."""
+    from oracle import minibullet as mb
+    from tactile_gym_amd.rl_envs.edge_follow import REST_POSES
+    from tactile_gym_amd.robot_model import load_tgmodel, make_robot
+    tg = load_tgmodel("mg400", "standard", "tactip")
+    rest = REST_POSES["mg400"]["tactip"]["standard"]
+    return tg, (lambda: mb.Arm(tg)), make_robot(tg, rest, "tactip"), rest

@@ -390,3 +390,68 @@ def test_object_balance_env_matches_oracle(size):
                 assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (episode, step, i)
         assert done.all()
     venv.close()
+
+
+def test_mg400_tree_functions(mg400_tactip):
+    """MG400 (8 control joints, two-branch tree): FK / Jacobian / inverse dynamics / inertia /
+    24 sim ticks / IK against the oracle, f64."""
+    from oracle import minibullet as mb
+    from tactile_gym_amd import _capi as capi, hip_ops
+    tg, mk_arm, robot, rest = mg400_tactip
+    assert robot.ndof == 8 and robot.topology == 1
+    n = 48
+    q, qd, rng = _rand_states(rest, n, 9, spread=0.2, vel=0.3)
+    qdd = rng.standard_normal(q.shape)
+    J, pos, rot = hip_ops.jacobian_tcp(robot, q)
+    tau = hip_ops.inverse_dynamics(robot, q, qd, qdd)
+    M = hip_ops.mass_matrix(robot, q)
+    qd_des = 0.1 * rng.standard_normal(q.shape)
+    q1, qd1 = hip_ops.sim_ticks(robot, q, qd, 24, capi.MOTOR_VELOCITY, qd_des=qd_des, max_force=1000.0)
+    arm = mk_arm()
+    for i in range(n):
+        p, _, _, _, R = arm.link_state("tcp_link", q=q[i], qd=np.zeros(8))
+        assert np.abs(pos[i] - p).max() < 1e-10 and np.abs(rot[i] - R).max() < 1e-10
+        assert np.abs(J[i] - arm.jacobian("tcp_link", q[i])).max() < 1e-10
+        ref = arm.inverse_dynamics(q[i], qd[i], qdd[i])
+        assert np.abs(tau[i] - ref).max() < 1e-9 * (1 + np.abs(ref).max())
+        Mref = arm.mass_matrix(q[i])
+        assert np.abs(M[i] - Mref).max() < 1e-8 * np.abs(Mref).max()
+        a2 = mk_arm()
+        a2.reset_joint_states(q[i])
+        for k in range(8):
+            a2.state.qd[k] = qd[i, k]
+        a2.set_motors_velocity(qd_des[i], 1.0, 1000.0)
+        for _ in range(24):
+            a2.apply_torques(a2.inverse_dynamics(a2.q, a2.qd, np.zeros(8)))
+            a2.step_simulation()
+        assert np.abs(q1[i] - a2.q).max() < 1e-8 and np.abs(qd1[i] - a2.qd).max() < 1e-6
+
+
+def test_edge_follow_mg400_env_matches_oracle(edge_modes):
+    """edge_follow-v0 with arm_type mg400: pseudo-inverse controller + hand-slaved linkage joints (mg400.py:77-129), reset
+    with the target_joints override (:191-232); 6 envs vs 6 oracle envs."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleEdgeFollowEnv
+    modes = dict(edge_modes, arm_type="mg400")
+    n = 6
+    venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=modes, seed=91, auto_reset=False)
+    oracles = [OracleEdgeFollowEnv(seed=91 + i, max_steps=200, image_size=(128, 128), env_modes=modes) for i in range(n)]
+    obs = venv.reset()
+    ref = [o.reset() for o in oracles]
+    st = venv.get_state()
+    for i, o in enumerate(oracles):
+        assert st["reset_ticks"][i] == o.reset_ticks
+        assert np.abs(st["q"][i] - o.arm.q).max() < 1e-7
+        assert int((obs["tactile"][i] != ref[i]["tactile"]).sum()) <= 2
+    rng = np.random.default_rng(92)
+    for step in range(5):
+        a = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+        obs, rew, done, _ = venv.step(a)
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            ro, rr, rd, _ = o.step(a[i])
+            assert np.abs(st["qd_target"][i] - o.last_req_joint_vels).max() < 1e-7, (step, i)
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-7, (step, i)
+            assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
+            assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 2, (step, i)
+    venv.close()

@@ -660,3 +660,218 @@ void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, d
     m3_vec(b->rot, b->com, cw);
     for (int x = 0; x < 3; ++x) b->pos[x] = xc[x] - cw[x];
 }
+
+/* ------------------------------------------------------------------------------------------------ arm + cube + contacts */
+typedef struct { double n[3], pa[3], pb[3], depth, mu, cfm_dt, erp; int arm_a; /* 1: body A is the arm tip, B the cube; 0: A cube, B table */ } contact_t;
+
+void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc, double dt, int iters) {
+    enum { NU = MB_MAX_DOF + 6, MAXC = 5, NR = MB_MAX_DOF + 3 * MAXC };
+    int n = m->ndof, nu = n + 6;
+    /* ---- arm: unconstrained velocity */
+    double tau[MB_MAX_DOF], h[MB_MAX_DOF], Qd[MB_MAX_DOF], v[NU], M[MB_MAX_DOF * MB_MAX_DOF], Mi[MB_MAX_DOF * MB_MAX_DOF], zero[MB_MAX_DOF] = {0};
+    for (int i = 0; i < n; ++i) tau[i] = s->applied_torque[i] - m->joint_damping * s->qd[i];
+    mb_inverse_dynamics(m, s->q, s->qd, zero, h);
+    damping_force(m, s->q, s->qd, Qd);
+    mb_mass_matrix(m, s->q, M);
+    invert(M, n, Mi);
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += Mi[i * n + j] * (tau[j] - h[j] + Qd[j]);
+        v[i] = s->qd[i] + dt * acc;
+    }
+    /* ---- cube: gravity, velocity damping, gyroscopic torque */
+    double Iw[9], Iwi[9], RI[9], cw[3], xc[3];
+    m3_mul(b->rot, b->inertia, RI);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Iw[3 * i + j] = RI[3 * i] * b->rot[3 * j] + RI[3 * i + 1] * b->rot[3 * j + 1] + RI[3 * i + 2] * b->rot[3 * j + 2];
+    invert3(Iw, Iwi);
+    m3_vec(b->rot, b->com, cw);
+    for (int k = 0; k < 3; ++k) xc[k] = b->pos[k] + cw[k];
+    {
+        double sv = sc->lin_damp + sc->lin_damp * norm3(b->linvel), sw = sc->ang_damp + sc->ang_damp * norm3(b->angvel);
+        double Iwv[3], gyro[3], N[3], wacc[3];
+        m3_vec(Iw, b->angvel, Iwv); cross(b->angvel, Iwv, gyro);
+        for (int k = 0; k < 3; ++k) N[k] = -Iwv[k] * sw - gyro[k];
+        m3_vec(Iwi, N, wacc);
+        for (int k = 0; k < 3; ++k) {
+            v[n + k] = b->linvel[k] + dt * (m->gravity[k] - b->linvel[k] * sv);
+            v[n + 3 + k] = b->angvel[k] + dt * wacc[k];
+        }
+    }
+    /* ---- contact generation */
+    contact_t ct[MAXC]; int nc = 0;
+    kin_t k; double z3[3] = {0, 0, 0};
+    kinematics(m, s->q, zero, NULL, z3, &k);
+    {   /* cube - table: broadphase on z, then the cube vertices near the plane (at most 4 kept: the deepest ones) */
+        double zmin = 1e30, vz[8], vw[8][3];
+        for (int c = 0; c < 8; ++c) {
+            double loc[3] = {(c & 4 ? 1 : -1) * sc->half[0], (c & 2 ? 1 : -1) * sc->half[1], (c & 1 ? 1 : -1) * sc->half[2]}, t[3];
+            m3_vec(b->rot, loc, t);
+            for (int x = 0; x < 3; ++x) vw[c][x] = b->pos[x] + t[x];
+            vz[c] = vw[c][2] - sc->table_z;
+            if (vz[c] < zmin) zmin = vz[c];
+        }
+        if (zmin <= sc->breaking) {
+            /* the manifold keeps at most 4 points: drop the shallowest while there are more (ties: the higher index goes);
+               the survivors become rows in vertex order, so exact ties on a flat face cannot reorder the solver */
+            int keep[8], cnt = 0;
+            for (int c = 0; c < 8; ++c) { keep[c] = vz[c] <= sc->breaking; cnt += keep[c]; }
+            while (cnt > 4) {
+                int worst = -1;
+                for (int c = 0; c < 8; ++c) if (keep[c] && (worst < 0 || vz[c] >= vz[worst])) worst = c;
+                keep[worst] = 0; --cnt;
+            }
+            for (int c = 0; c < 8; ++c) {
+                if (!keep[c]) continue;
+                contact_t* q = &ct[nc++];
+                q->n[0] = 0; q->n[1] = 0; q->n[2] = 1; q->depth = vz[c]; q->mu = sc->mu_table; q->arm_a = 0; q->cfm_dt = 0.0; q->erp = sc->erp;
+                for (int x = 0; x < 3; ++x) { q->pa[x] = vw[c][x]; q->pb[x] = vw[c][x]; }
+                q->pb[2] = sc->table_z;
+            }
+        }
+    }
+    sc->tip_depth = 1e30; sc->tip_impulse = 0.0; sc->tip_normal[0] = sc->tip_normal[1] = sc->tip_normal[2] = 0.0;
+    {   /* cube - tip core: deepest hull vertex against the box signed distance field */
+        int l = sc->tip_link, besti = -1; double bestd = 1e30, bestg[3] = {0, 0, 0}, bestw[3] = {0, 0, 0};
+        for (int i = 0; i < sc->n_tip; ++i) {
+            double t[3], w[3], d[3], p[3], q[3], g[3] = {0, 0, 0}, sdf;
+            m3_vec(k.R[l], sc->tip_verts + 3 * i, t);
+            for (int x = 0; x < 3; ++x) { w[x] = k.o[l][x] + t[x]; d[x] = w[x] - b->pos[x]; }
+            for (int x = 0; x < 3; ++x) { p[x] = b->rot[x] * d[0] + b->rot[3 + x] * d[1] + b->rot[6 + x] * d[2]; q[x] = fabs(p[x]) - sc->half[x]; }
+            double ox = q[0] > 0 ? q[0] : 0, oy = q[1] > 0 ? q[1] : 0, oz = q[2] > 0 ? q[2] : 0;
+            double outside = sqrt(ox * ox + oy * oy + oz * oz);
+            if (outside > 0.0) {
+                sdf = outside;
+                g[0] = ox / outside * (p[0] < 0 ? -1 : 1); g[1] = oy / outside * (p[1] < 0 ? -1 : 1); g[2] = oz / outside * (p[2] < 0 ? -1 : 1);
+            } else {
+                int ax = (q[0] >= q[1] && q[0] >= q[2]) ? 0 : ((q[1] >= q[2]) ? 1 : 2);
+                sdf = q[ax];
+                g[ax] = (p[ax] < 0 ? -1 : 1);
+            }
+            if (sdf < bestd) { bestd = sdf; besti = i; memcpy(bestg, g, sizeof g); memcpy(bestw, w, sizeof w); }
+        }
+        /* no separate broadphase: a vertex within margin + breaking distance of the box implies overlapping padded AABBs */
+        double depth = bestd - (sc->margin_tip + sc->margin_cube);
+        if (besti >= 0 && depth <= sc->breaking) {
+            contact_t* q = &ct[nc++];
+            m3_vec(b->rot, bestg, q->n);                       /* from the cube towards the tip */
+            q->depth = depth; q->mu = sc->mu_tip; q->arm_a = 1;
+            double denom = dt * sc->tip_stiffness + sc->tip_damping;   /* soft contact: cfm = 1/(dt (dt k + d)), erp = dt k/(dt k + d) */
+            q->cfm_dt = (1.0 / denom) / dt; q->erp = dt * sc->tip_stiffness / denom;
+            for (int x = 0; x < 3; ++x) { q->pa[x] = bestw[x] - q->n[x] * sc->margin_tip; q->pb[x] = bestw[x] - q->n[x] * (bestd - sc->margin_cube); }
+            sc->tip_depth = depth; memcpy(sc->tip_normal, q->n, sizeof q->n);
+        }
+    }
+    sc->n_contacts = nc;
+    /* ---- rows: motors [0, n), then per contact c: normal n + 3c, friction n + 3c + 1, n + 3c + 2 */
+    int nr = n + 3 * nc;
+    static double J[NR][NU], W[NU][NR];   /* single threaded test infrastructure */
+    double A[NR], rhs[NR], lam[NR], dv[NU];
+    memset(J, 0, sizeof J);
+    for (int i = 0; i < n; ++i) J[i][i] = 1.0;
+    for (int c = 0; c < nc; ++c) {
+        contact_t* q = &ct[c];
+        double t1[3], t2[3];
+        /* btPlaneSpace1 */
+        if (fabs(q->n[2]) > 0.7071067811865475244) {
+            double a = q->n[1] * q->n[1] + q->n[2] * q->n[2], kk = 1.0 / sqrt(a);
+            t1[0] = 0; t1[1] = -q->n[2] * kk; t1[2] = q->n[1] * kk;
+            t2[0] = a * kk; t2[1] = -q->n[0] * t1[2]; t2[2] = q->n[0] * t1[1];
+        } else {
+            double a = q->n[0] * q->n[0] + q->n[1] * q->n[1], kk = 1.0 / sqrt(a);
+            t1[0] = -q->n[1] * kk; t1[1] = q->n[0] * kk; t1[2] = 0;
+            t2[0] = -q->n[2] * t1[1]; t2[1] = q->n[2] * t1[0]; t2[2] = a * kk;
+        }
+        const double* dirs[3] = {q->n, t1, t2};
+        for (int r = 0; r < 3; ++r) {
+            const double* d = dirs[r];
+            double* row = J[n + 3 * c + r];
+            if (q->arm_a) {   /* A = arm tip link (+d), B = cube (-d) */
+                int l = sc->tip_link;
+                for (int i = 0; i < n; ++i) {
+                    if (!is_in_subtree(m, l, i)) continue;
+                    double rr[3] = {q->pa[0] - k.o[i][0], q->pa[1] - k.o[i][1], q->pa[2] - k.o[i][2]}, jt[3];
+                    cross(k.a[i], rr, jt);
+                    row[i] = dot(jt, d);
+                }
+                double rb[3] = {q->pb[0] - xc[0], q->pb[1] - xc[1], q->pb[2] - xc[2]}, rxd[3];
+                cross(rb, d, rxd);
+                for (int x = 0; x < 3; ++x) { row[n + x] = -d[x]; row[n + 3 + x] = -rxd[x]; }
+            } else {          /* A = cube (+d), B = static table */
+                double ra[3] = {q->pa[0] - xc[0], q->pa[1] - xc[1], q->pa[2] - xc[2]}, rxd[3];
+                cross(ra, d, rxd);
+                for (int x = 0; x < 3; ++x) { row[n + x] = d[x]; row[n + 3 + x] = rxd[x]; }
+            }
+        }
+    }
+    for (int r = 0; r < nr; ++r) {
+        for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < n; ++j) acc += Mi[i * n + j] * J[r][j]; W[i][r] = acc; }
+        for (int x = 0; x < 3; ++x) W[n + x][r] = J[r][n + x] / b->mass;
+        for (int x = 0; x < 3; ++x) W[n + 3 + x][r] = Iwi[3 * x] * J[r][n + 3] + Iwi[3 * x + 1] * J[r][n + 4] + Iwi[3 * x + 2] * J[r][n + 5];
+        double acc = 0; for (int u = 0; u < nu; ++u) acc += J[r][u] * W[u][r];
+        A[r] = acc;
+    }
+    for (int i = 0; i < n; ++i) {
+        double kp = (s->motor_mode[i] == MB_MOTOR_POSITION) ? s->motor_kp[i] : 0.0;
+        double des = kp * (s->motor_q_des[i] - s->q[i]) / dt + v[i] + s->motor_kd[i] * (s->motor_qd_des[i] - v[i]);
+        rhs[i] = des - v[i];
+    }
+    double cfm[NR] = {0};
+    for (int c = 0; c < nc; ++c) {
+        contact_t* q = &ct[c];
+        for (int r = 0; r < 3; ++r) {
+            int row = n + 3 * c + r;
+            double rv = 0; for (int u = 0; u < nu; ++u) rv += J[row][u] * v[u];
+            if (r == 0) {
+                double pos_err = 0.0, vel_err = -rv;                 /* restitution 0 */
+                if (q->depth > 0) vel_err -= q->depth / dt; else pos_err = -q->depth * q->erp / dt;
+                rhs[row] = pos_err + vel_err;
+                cfm[row] = q->cfm_dt;
+            } else rhs[row] = -rv;
+        }
+    }
+    memset(lam, 0, sizeof lam); memset(dv, 0, sizeof dv);
+    for (int it = 0; it < iters; ++it) {
+        for (int jj = 0; jj < n; ++jj) {                              /* joint motors: reversed on even sweeps */
+            int r = (it & 1) ? jj : n - 1 - jj;
+            if (s->motor_mode[r] == MB_MOTOR_OFF) continue;
+            double lim = s->motor_max_force[r] * dt, jdi = 1.0 / A[r];
+            double delta = rhs[r] * jdi - dv[r] * jdi, sum = lam[r] + delta;
+            if (sum < -lim) { delta = -lim - lam[r]; lam[r] = -lim; } else if (sum > lim) { delta = lim - lam[r]; lam[r] = lim; } else lam[r] = sum;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+        }
+        for (int c = 0; c < nc; ++c) {                                /* contact normals */
+            int r = n + 3 * c;
+            double jdv = 0; for (int u = 0; u < nu; ++u) jdv += J[r][u] * dv[u];
+            double jdi = 1.0 / (A[r] + cfm[r]);
+            double delta = rhs[r] * jdi - lam[r] * (cfm[r] * jdi) - jdv * jdi, sum = lam[r] + delta;
+            if (sum < 0.0) { delta = -lam[r]; lam[r] = 0.0; } else lam[r] = sum;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+        }
+        for (int c = 0; c < nc; ++c) {                                /* friction */
+            int r1 = n + 3 * c + 1, r2 = r1 + 1;
+            double limit = ct[c].mu * lam[n + 3 * c];
+            double jdv1 = 0, jdv2 = 0;
+            for (int u = 0; u < nu; ++u) { jdv1 += J[r1][u] * dv[u]; jdv2 += J[r2][u] * dv[u]; }
+            double d1 = (rhs[r1] - jdv1) / A[r1], d2 = (rhs[r2] - jdv2) / A[r2];
+            double s1 = lam[r1] + d1, s2 = lam[r2] + d2;
+            if (sc->cone_friction) {
+                double tot = sqrt(s1 * s1 + s2 * s2);
+                if (tot > limit) { double f = tot > 0 ? limit / tot : 0.0; s1 *= f; s2 *= f; }
+            } else {
+                if (s1 < -limit) s1 = -limit; if (s1 > limit) s1 = limit;
+                if (s2 < -limit) s2 = -limit; if (s2 > limit) s2 = limit;
+            }
+            d1 = s1 - lam[r1]; d2 = s2 - lam[r2]; lam[r1] = s1; lam[r2] = s2;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r1] * d1 + W[u][r2] * d2;
+        }
+    }
+    for (int c = 0; c < nc; ++c) if (ct[c].arm_a) sc->tip_impulse = lam[n + 3 * c];
+    /* ---- integrate */
+    for (int i = 0; i < n; ++i) { s->qd[i] = v[i] + dv[i]; s->q[i] += dt * s->qd[i]; s->applied_torque[i] = 0.0; }
+    for (int x = 0; x < 3; ++x) { b->linvel[x] = v[n + x] + dv[n + x]; b->angvel[x] = v[n + 3 + x] + dv[n + 3 + x]; }
+    for (int x = 0; x < 3; ++x) xc[x] += dt * b->linvel[x];
+    integrate_rotation(b->rot, b->angvel, dt);
+    m3_vec(b->rot, b->com, cw);
+    for (int x = 0; x < 3; ++x) b->pos[x] = xc[x] - cw[x];
+}

@@ -142,6 +142,36 @@ typedef struct {
 /* stepSimulation() for arm + body + P2P.  Row order: joint motors (joint order), then P2P x, y, z. */
 void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, double dt, int solver_iterations);
 
+/* ----------------------------------------------------------------------------------------------------------
+ * object_push: a free box (the cube) resting on the table and pushed by the sensor tip's collision core
+ * (object_push_env.py; tip core collision on: t_s_core = "fixed", :60).  Restatement of a Bullet-style pipeline with this
+ * repo's own, explicitly simplified contact generation [PARITY_ASSUMPTIONS A23-A27] — PARITY UNPINNED:
+ *   broadphase   AABB overlap of (cube, table) and (cube, tip core);
+ *   narrowphase  cube-table: cube vertices within the breaking threshold of the table plane (<= 4 when resting flat);
+ *                cube-tip: deepest tip-core hull vertex against the box's signed distance field (one point per tick,
+ *                no persistent manifold, no warm start, no friction anchors);
+ *   solver       joint motors, then contact normals (lambda >= 0, soft-contact cfm/erp for the tip), then friction pairs
+ *                (implicit cone, |f| <= mu lambda_n), `iters` sweeps, in one projected Gauss-Seidel loop. */
+typedef struct {
+    double table_z;                    /* table top plane (base_tactile_env.py:131-139: table at z = -0.625, top at 0) */
+    double half[3];                    /* cube half extents (cube.urdf: 0.08^3) */
+    double mu_table, mu_tip;           /* combined friction: 0.065 x 1.0 and 0.065 x 10 (object_push_env.py:216-225, :61-66) */
+    double margin_cube, margin_tip;    /* collision margins: 1e-4 (:224) and the URDF convex-hull default 1e-3 */
+    double breaking;                   /* contactBreakingThreshold 1e-4 (base_tactile_env.py:128-130) */
+    double erp;                        /* contact ERP 0.2 */
+    double tip_stiffness, tip_damping; /* contactStiffness / contactDamping of the tip link (tactile_sensor.py:324-332) */
+    double lin_damp, ang_damp;         /* cube velocity damping 0.04 (Bullet multibody default) */
+    int32_t tip_link;                  /* arm link carrying the tip core */
+    int32_t n_tip;
+    const double* tip_verts;           /* [n_tip][3] hull vertices in that link's frame */
+    int32_t cone_friction;             /* enableConeFriction = 1 */
+    /* outputs of the last tick (inspection / parity): number of contacts and the tip contact */
+    int32_t n_contacts;
+    double tip_depth, tip_normal[3], tip_impulse;
+} mb_push_scene;
+
+void mb_step_push(const mb_model* m, mb_state* s, mb_body* cube, mb_push_scene* sc, double dt, int solver_iterations);
+
 #ifdef __cplusplus
 }
 #endif

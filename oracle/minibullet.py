@@ -48,6 +48,16 @@ class MBP2P(C.Structure):
                 ("max_impulse", C.c_double)]
 
 
+class MBPushScene(C.Structure):
+    _fields_ = [
+        ("table_z", C.c_double), ("half", C.c_double * 3), ("mu_table", C.c_double), ("mu_tip", C.c_double),
+        ("margin_cube", C.c_double), ("margin_tip", C.c_double), ("breaking", C.c_double), ("erp", C.c_double),
+        ("tip_stiffness", C.c_double), ("tip_damping", C.c_double), ("lin_damp", C.c_double), ("ang_damp", C.c_double),
+        ("tip_link", C.c_int32), ("n_tip", C.c_int32), ("tip_verts", C.POINTER(C.c_double)), ("cone_friction", C.c_int32),
+        ("n_contacts", C.c_int32), ("tip_depth", C.c_double), ("tip_normal", C.c_double * 3), ("tip_impulse", C.c_double),
+    ]
+
+
 MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
 _lib = None
 
@@ -72,6 +82,10 @@ def lib():
         _lib.mb_jacobian.argtypes = [mp, dp, C.c_int, dp, dp]
         _lib.mb_step.argtypes = [mp, sp, C.c_double, C.c_int]
         _lib.mb_step_body.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.c_double, C.c_int]
+        _lib.mb_step_push.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBPushScene), C.c_double, C.c_int]
+        _lib.mb_opensimplex_perm.argtypes = [C.c_int64, C.POINTER(C.c_int16)]
+        _lib.mb_opensimplex_noise2.argtypes = [C.POINTER(C.c_int16), C.c_double, C.c_double]
+        _lib.mb_opensimplex_noise2.restype = C.c_double
         _lib.mb_ik.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_double]
         _lib.mb_ik.restype = C.c_int
         _lib.mb_render_depth.argtypes = [fp, C.c_int, ip, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, fp]
@@ -204,6 +218,10 @@ class Arm:
 
     def step_simulation(self, dt=1.0 / 240.0, iters=150):
         self.L.mb_step(C.byref(self.model), C.byref(self.state), dt, iters)
+
+    def step_simulation_push(self, cube, scene, dt=1.0 / 240.0, iters=150):
+        """stepSimulation with a free cube on the table pushed by the tip's collision core."""
+        self.L.mb_step_push(C.byref(self.model), C.byref(self.state), C.byref(cube), C.byref(scene), dt, iters)
 
     def step_simulation_body(self, body, p2p, dt=1.0 / 240.0, iters=150):
         """stepSimulation with a free rigid body tied to the arm by a point-to-point constraint."""

@@ -587,3 +587,197 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
 
     def oracle_obs(self):
         raise NotImplementedError
+
+
+def opensimplex_noise2(seed, x, y):
+    """OpenSimplex(seed).noise2(x, y) through oracle/minibullet.c."""
+    L = mb.lib()
+    perm = (C.c_int16 * 256)()
+    L.mb_opensimplex_perm(int(seed), perm)
+    return lambda xx, yy: L.mb_opensimplex_noise2(perm, float(xx), float(yy))
+
+
+class OracleObjectPushEnv(_OracleArmEnv):
+    """object_push-v0 (nonprehensile_manipulation/object_push/object_push_env.py + base_object_env.py): MG400 + right-angle
+    sensor pushing a cube along a trajectory of goals on the table; tip collision core ON (t_s_core = "fixed")."""
+
+    REST = {"digitac": [-0.4745979999944637, 1.2836350191938928, 0.254159419927845, -1.5395417027560878, 0.47634420683617346,
+                        1.2838656861791102, -1.283854805915325, 1.5380912693333302],      # object_push/rest_poses.py (mg400, right_angle)
+            "digit": [-0.4558165479388624, 1.2857227247064174, 0.26532296230426017, -1.5518769541832729, 0.45743009274925944,
+                      1.28573249852019, -1.2857285129498681, 1.5510764390458196]}
+
+    def __init__(self, seed=0, max_steps=1000, image_size=(128, 128), env_modes=None, inertia="collision_aabb"):
+        modes = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
+                     observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")
+        modes.update(env_modes or {})
+        assert modes["arm_type"] == "mg400" and modes["tactile_sensor_name"] in ("digitac", "digit")
+        self._setup_arm(seed, modes, max_steps, image_size, "right_angle", self.REST[modes["tactile_sensor_name"]], inertia)   # :47-49
+        self.obj_width = self.obj_height = 0.08                                             # :45-46
+        self.termination_pos_dist = 0.025                                                   # :57
+        a = 45 * math.pi / 180
+        self.TCP_lims = np.array([[-0.0, 0.3], [-0.1, 0.08], [-0.0, 0.0], [-0.0, 0.0], [-0.0, 0.0], [-a, a]])   # :62-68
+        self.well_designed_pos = np.array([0.25, -0.1, self.obj_height / 2])                # :74
+        self._set_workframe(self.well_designed_pos, [-math.pi, 0.0, math.pi / 2])           # :87-88
+        v, w = 0.01, 5.0 * (math.pi / 180)                                                  # :126-134
+        self.act_lo, self.act_hi = np.array([-v, -v, 0.0, 0.0, 0.0, -w]), np.array([v, v, 0.0, 0.0, 0.0, w])
+        self.init_obj_pos = np.array([self.well_designed_pos[0], self.well_designed_pos[1] + self.obj_width / 2, self.obj_height / 2])   # :160
+        suffix = "" if inertia == "collision_aabb" else "_urdfinertia"
+        z = np.load(os.path.join(_ASSETS, "objects", f"cube{suffix}.npz"))
+        self.obj_verts, self.obj_tris = z["verts"], z["tris"]
+        b = mb.MBBody()
+        b.mass = float(z["mass"])
+        for k in range(3):
+            b.com[k] = float(z["com"][k])
+        for k in range(9):
+            b.inertia[k] = float(z["inertia"].reshape(9)[k])
+        self.cube = b
+        r = np.load(os.path.join(_ASSETS, "robots", f"mg400_right_angle_{self.t_s_name}{suffix}.npz"))
+        self._tip_verts = np.ascontiguousarray(r["tip_hull_verts"], dtype=np.float64)
+        sc = mb.MBPushScene()
+        sc.table_z = 0.0
+        for k in range(3):
+            sc.half[k] = 0.04
+        dyn = {"tactip": (50, 100, 10.0), "digitac": (300, 100, 10.0), "digit": (50, 200, 10.0)}[self.t_s_name]   # :50-56
+        sc.mu_table, sc.mu_tip = 0.065 * 1.0, 0.065 * dyn[2]                                # :216-225 cube friction x table / tip friction
+        sc.margin_cube, sc.margin_tip, sc.breaking, sc.erp = 1e-4, 1e-3, 1e-4, 0.2
+        sc.tip_stiffness, sc.tip_damping = float(dyn[0]), float(dyn[1]) + 0.1               # combined damping = tip + Bullet default 0.1
+        sc.lin_damp, sc.ang_damp = 0.04, 0.04
+        sc.tip_link, sc.n_tip = int(r["tip_hull_link"]), self._tip_verts.shape[0]
+        sc.tip_verts = self._tip_verts.ctypes.data_as(C.POINTER(C.c_double))
+        sc.cone_friction = 1                                                                # base_tactile_env.py:128-130
+        self.scene = sc
+        self.traj_n_points, self.traj_spacing, self.traj_max_perturb = 10, 0.025, 0.1       # :229-231
+        self._teleport_cube(0.0)                                                            # load_object at init pose
+
+    def _teleport_cube(self, ang):
+        q = pm.quat_from_euler([-math.pi, 0.0, math.pi / 2 + ang])                          # :158,176
+        self.init_obj_orn = q
+        R = pm.mat_from_quat(q)
+        for k in range(3):
+            self.cube.pos[k] = float(self.init_obj_pos[k])
+            self.cube.linvel[k] = 0.0
+            self.cube.angvel[k] = 0.0
+        for k in range(9):
+            self.cube.rot[k] = float(R.reshape(9)[k])
+
+    def _step_simulation(self):
+        self.arm.step_simulation_push(self.cube, self.scene, self.SIM_DT, self.SOLVER_ITERS)
+
+    def cube_pose(self):
+        return np.array(self.cube.pos[:]), np.array(self.cube.rot[:]).reshape(3, 3)
+
+    def reset(self):
+        """base_object_env.py:146-173 with object_push_env.py:168-340."""
+        self.step_counter = 0
+        self._reset_robot(np.zeros(3), np.zeros(3))                                         # update_init_pose: work-frame origin
+        ang = self.rng.uniform(-math.pi / 32, math.pi / 32) if self.modes["rand_init_orn"] else 0.0   # reset_object :168-176
+        self._teleport_cube(ang)
+        if self.modes["rand_obj_mass"]:                                                     # :190-192
+            self.cube.mass = self.rng.uniform(0.4, 0.8)
+        self._update_trajectory()                                                           # make_goal :316-340
+        self.targ_traj_list_id = -1
+        self._update_goal()
+        self._get_step_data()
+        return self._observation()
+
+    def _update_trajectory(self):                                                           # :248-313
+        n = self.traj_n_points
+        self.traj_pos_work, self.traj_rpy_work = np.zeros((n, 3)), np.zeros((n, 3))
+        init_offset = self.obj_width / 2 + self.traj_spacing
+        if self.modes["traj_type"] == "simplex":
+            noise2 = opensimplex_noise2(self.rng.randint(1e8), 0, 0)
+            for i in range(n):
+                noise = noise2(i * 0.1, 1) * self.traj_max_perturb
+                if i == 0:
+                    init_noise_pos_offset = -noise
+                self.traj_pos_work[i] = [init_offset + (i * self.traj_spacing), init_noise_pos_offset + noise, 0.0]
+        else:
+            traj_ang = self.rng.uniform(-math.pi / 8, math.pi / 8)
+            for i in range(n):
+                dist = i * self.traj_spacing
+                self.traj_pos_work[i] = [init_offset + dist * math.cos(traj_ang), dist * math.sin(traj_ang), 0.0]
+        self.traj_rpy_work[:, 2] = np.gradient(self.traj_pos_work[:, 1], self.traj_spacing)
+        self.traj_pos_world = np.zeros((n, 3))
+        self.traj_orn_world = np.zeros((n, 4))
+        for i in range(n):
+            p, rpy = self._work_to_world(self.traj_pos_work[i], self.traj_rpy_work[i])
+            self.traj_pos_world[i], self.traj_orn_world[i] = p, pm.quat_from_euler(rpy)
+
+    def _update_goal(self):                                                                 # :342-370
+        self.targ_traj_list_id += 1
+        if self.targ_traj_list_id >= self.traj_n_points:
+            return False
+        i = self.targ_traj_list_id
+        self.goal_pos_world, self.goal_orn_world = self.traj_pos_world[i], self.traj_orn_world[i]
+        self.goal_pos_work, self.goal_rpy_work = self.traj_pos_work[i], self.traj_rpy_work[i]
+        return True
+
+    def _encode_actions(self, a):                                                           # :372-454
+        enc = np.zeros(6)
+        mm = self.modes["movement_mode"]
+        if mm in ("y", "yRz", "xyRz"):
+            if mm == "y":
+                enc[0], enc[1] = self.max_action, a[0]
+            elif mm == "yRz":
+                enc[0], enc[1], enc[5] = self.max_action, a[0], a[1]
+            else:
+                enc[0], enc[1], enc[5] = a[0], a[1], a[2]
+            return enc
+        R = pm.mat_from_quat(self.cur_tcp_orn)                                              # encode_TCP_frame_actions
+        _, iq = pm.invert_transform(self.workframe_pos, self.workframe_orn)
+        Rinv = pm.mat_from_quat(iq)
+        par, perp = Rinv @ (R @ np.array([1, 0, 0])), Rinv @ (R @ np.array([0, -1, 0]))
+        if mm == "TyRz":
+            perp_a, par_a = perp * a[0], par * (1.0 * self.max_action)
+            enc[0] += perp_a[0] + par_a[0]
+            enc[1] += perp_a[1] + par_a[1]
+            enc[5] += a[1]
+        else:  # TxTyRz
+            perp_a, par_a = perp * a[1], par * a[0]
+            enc[0] += perp_a[0] + par_a[0]
+            enc[1] += perp_a[1] + par_a[1]
+            enc[5] += a[2]
+        return enc
+
+    def _get_step_data(self):                                                               # :456-569
+        self.cur_tcp_pos, self.cur_tcp_rpy, self.cur_tcp_orn, _, _ = self._tcp_world()
+        pos, R = self.cube_pose()
+        self.cur_obj_pos, self.cur_obj_orn = pos, pm.quat_from_mat(R)
+        pos_dist = float(np.linalg.norm(pos - self.goal_pos_world))
+        if self.modes["reward_mode"] == "sparse":
+            reward = 1.0 if pos_dist < self.termination_pos_dist else 0.0
+        else:
+            orn_dist = math.acos(float(np.clip(2 * (np.inner(self.goal_orn_world, self.cur_obj_orn) ** 2) - 1, -1, 1)))
+            ov, tv = R @ np.array([1, 0, 0]), pm.mat_from_quat(self.cur_tcp_orn) @ np.array([1, 0, 0])
+            cos_dist = 1 - np.dot(ov, tv) / (np.linalg.norm(ov) * np.linalg.norm(tv))
+            reward = -((1.0 * pos_dist) + (1.0 * orn_dist) + (1.0 * cos_dist))
+        done = False                                                                        # termination :520-537
+        if pos_dist < self.termination_pos_dist and not self._update_goal():
+            done = True
+        if self.step_counter >= self.max_steps:
+            done = True
+        return reward, bool(done)
+
+    def extended_feature(self):                                                             # :611-629
+        p, rpy, _, _ = self._tcp_work()
+        return np.array([*p, *rpy, *self.goal_pos_work, *self.goal_rpy_work])
+
+    def _observation(self):
+        obs = {}
+        mode = self.modes["observation_mode"]
+        if "tactile" in mode:
+            obs["tactile"] = self.tactile_image()[..., np.newaxis]
+        if "feature" in mode:
+            obs["extended_feature"] = self.extended_feature()
+        return obs
+
+    def stimulus_transform(self):
+        cpos, cR = self.camera_pose()
+        pos, R = self.cube_pose()
+        return mb.cam_from_obj_matrix(cpos, cR, pos, R)
+
+    def tactile_image(self):
+        h, w = self.image_size
+        cur = self.nodef_dep.copy()
+        mb.render_depth(self.obj_verts, self.obj_tris, self.stimulus_transform(), self.cam["fov"], self.cam["near"], self.cam["far"], w, h, cur)
+        return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)

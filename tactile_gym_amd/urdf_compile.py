@@ -534,3 +534,44 @@ def compile_free_body(path, inertia_mode="collision_aabb"):
     return dict(mass=np.array(mass), com=com, inertia=inertia, verts=np.concatenate(verts).astype(np.float32),
                 tris=np.concatenate(tris).astype(np.int32), link_masses=np.array([m for m, _, _ in parts]),
                 root_inertial_pos=p0, root_inertial_rot=R0)
+
+
+def collision_hull_of_link(path, link_name):
+    """Convex-hull vertices of a link's <collision> meshes, expressed in the frame of the *moving* link the URDF link is
+    welded to (PyBullet turns URDF collision meshes into convex hulls unless flagged concave).  Returns
+    (moving_link_index, float64 [V,3])."""
+    from scipy.spatial import ConvexHull
+    links, joints = parse_urdf(path)
+    urdf_dir = os.path.dirname(os.path.abspath(path))
+    children = {j.child for j in joints}
+    root = [n for n in links if n not in children][0]
+    by_parent = {}
+    for j in joints:
+        by_parent.setdefault(j.parent, []).append(j)
+    attach = {root: (-1, np.eye(3), np.zeros(3))}
+    counter = [0]
+
+    def dfs(link):
+        for j in by_parent.get(link, []):
+            mi, R, p = attach[j.parent]
+            Rj, pj = rpy_to_mat(j.rpy), np.asarray(j.xyz, dtype=np.float64)
+            if j.jtype == "fixed":
+                attach[j.child] = (mi, R @ Rj, R @ pj + p)
+            else:
+                attach[j.child] = (counter[0], np.eye(3), np.zeros(3))
+                counter[0] += 1
+            dfs(j.child)
+
+    dfs(root)
+    mi, R, p = attach[link_name]
+    pts = []
+    for g in links[link_name].collisions:
+        if g.kind != "mesh":
+            continue
+        v, _ = load_mesh(find_mesh_file(urdf_dir, g.mesh))
+        v = v * np.asarray(g.scale, dtype=np.float64)
+        v = v @ rpy_to_mat(g.origin_rpy).T + np.asarray(g.origin_xyz, dtype=np.float64)   # URDF link frame
+        pts.append(v @ R.T + p)                                                              # moving-link frame
+    pts = np.concatenate(pts)
+    hull = ConvexHull(pts)
+    return mi, pts[hull.vertices]

@@ -20,7 +20,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tactile_gym_amd.urdf_compile import compile_free_body, compile_urdf, load_mesh, parse_urdf, rpy_to_mat, visual_meshes_of_link  # noqa: E402
+from tactile_gym_amd.urdf_compile import collision_hull_of_link, compile_free_body, compile_urdf, load_mesh, parse_urdf, rpy_to_mat, visual_meshes_of_link  # noqa: E402
 
 REF = os.environ.get("TG_REFERENCE_ASSETS", "/root/reference/tactile_gym/assets")
 OUT = os.path.join(ROOT, "tactile_gym_amd", "assets")
@@ -76,7 +76,13 @@ def robots():
                 print("skip", arm, sensor, typ, mode, e)
                 continue
             suffix = "" if mode == "collision_aabb" else "_urdfinertia"
-            save(os.path.join(OUT, "robots", f"{arm}_{typ}_{sensor}{suffix}.npz"), **m.to_npz_dict())
+            d = m.to_npz_dict()
+            try:   # collision core of the sensor tip (convex hull, in the frame of the moving link it is welded to)
+                hl, hv = collision_hull_of_link(urdf, f"{sensor}_tip_link")
+                d.update(tip_hull_link=np.array(hl), tip_hull_verts=hv)
+            except Exception as e:  # noqa: BLE001 - e.g. no collision mesh
+                print("  no tip hull:", e)
+            save(os.path.join(OUT, "robots", f"{arm}_{typ}_{sensor}{suffix}.npz"), **d)
 
 
 def sensors():

@@ -24,7 +24,8 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 3
+#define TG_ABI_VERSION 4
+#define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
 typedef struct {
@@ -67,10 +68,12 @@ typedef struct {
     const int32_t* tris;                    /* host, [n_tris][3] */
 } tg_mesh;
 
-enum { TG_ENV_EDGE_FOLLOW = 0, TG_ENV_SURFACE_FOLLOW_AUTO = 1, TG_ENV_OBJECT_BALANCE = 2 };
+enum { TG_ENV_EDGE_FOLLOW = 0, TG_ENV_SURFACE_FOLLOW_AUTO = 1, TG_ENV_OBJECT_BALANCE = 2, TG_ENV_OBJECT_PUSH = 3 };
 enum { TG_MOVE_XY = 0, TG_MOVE_XYZ = 1, TG_MOVE_XYRZ = 2, TG_MOVE_XYZRZ = 3 };            /* edge_follow_env.py:345-369 */
 enum { TG_SMOVE_YZ = 0, TG_SMOVE_XYZ = 1, TG_SMOVE_YZRX = 2, TG_SMOVE_XYZRXRY = 3 };       /* surface_follow_auto_env.py:27-57 */
 enum { TG_BMOVE_XY = 0, TG_BMOVE_XYZ = 1, TG_BMOVE_RXRY = 2, TG_BMOVE_XYRXRY = 3 };         /* object_balance_env.py:398-424 */
+enum { TG_PMOVE_Y = 0, TG_PMOVE_YRZ = 1, TG_PMOVE_XYRZ = 2, TG_PMOVE_TYRZ = 3, TG_PMOVE_TXTYRZ = 4 }; /* object_push_env.py:372-454 */
+enum { TG_TRAJ_SIMPLEX = 0, TG_TRAJ_STRAIGHT = 1 };                                          /* object_push_env.py:248-313 */
 enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };
 enum { TG_REWARD_DENSE = 0, TG_REWARD_SPARSE = 1 };
 enum { TG_PHYSICS_F64 = 0, TG_PHYSICS_F32 = 1 };
@@ -119,6 +122,26 @@ typedef struct {
     double ext_force[3];                    /* apply_random_force_base: (0, 0, -0.1) (:360-381) */
     double term_deg, term_pos;              /* 35 deg, 0.1 m (:50-51) */
     double p2p_erp, p2p_max_impulse;        /* 0.2, 500 [PARITY_ASSUMPTIONS A18-A19] */
+    /* object_push (object_push_env.py): a free cube (obj_mass / obj_com / obj_inertia, stimulus mesh = its visual triangles)
+     * on the table, pushed by the collision core of the sensor tip along a per-episode trajectory of goals.
+     * termination_dist = termination_pos_dist (:57); obj_init_rpy = (-pi, 0, pi/2) (:158). */
+    int32_t traj_type;                      /* TG_TRAJ_* (env_modes["traj_type"]) */
+    int32_t traj_n_points;                  /* 10 (:229), <= TG_MAX_TRAJ_POINTS */
+    int32_t rand_init_orn, rand_obj_mass;   /* env_modes flags (:168-192) */
+    int32_t tip_link, n_tip_verts;          /* moving link carrying the tip's collision core; its convex-hull vertices */
+    int32_t cone_friction, reserved1;       /* enableConeFriction=1 (base_tactile_env.py:128-130) */
+    const double* tip_verts;                /* host, [n_tip_verts][3], link frame; copied at tg_create */
+    double obj_half[3];                     /* cube half extents 0.04 (:45-46) */
+    double obj_init_pos[3];                 /* (:160) */
+    double table_z;                         /* top of the table: 0 */
+    double mu_table, mu_tip;                /* combined friction: cube 0.065 x table 1.0 / x tip lateral friction (:50-56, :216-225) */
+    double margin_cube, margin_tip;         /* collision margins [PARITY_ASSUMPTIONS A24] */
+    double contact_breaking, contact_erp;   /* 1e-4 [A24], 0.2 */
+    double tip_stiffness, tip_damping;      /* contactStiffness / contactDamping of the tip core (:50-56) */
+    double obj_lin_damp, obj_ang_damp;      /* Bullet defaults 0.04 */
+    double traj_spacing, traj_max_perturb, traj_init_offset;   /* 0.025, 0.1, obj_width/2 + spacing (:229-262) */
+    double mass_lo, mass_hi;                /* rand_obj_mass U(0.4, 0.8) (:190-192) */
+    double init_orn_range, traj_ang_range;  /* pi/32 (:170), pi/8 (:283) */
 } tg_config;
 
 typedef struct tg_ctx tg_ctx;
@@ -150,9 +173,13 @@ int tg_sync(tg_ctx* ctx);                                     /* VecEnv.step_wai
 int tg_get_obs_tactile(tg_ctx* ctx, void** dev_ptr);           /* uint8 [num_envs][H][W][1] */
 int tg_get_terminal_obs(tg_ctx* ctx, void** dev_ptr);          /* uint8 [num_envs][H][W][1], rows valid where done */
 int tg_get_reward_done_dev(tg_ctx* ctx, void** reward_f32, void** done_u8);
+/* "extended_feature" observation (object_push_env.py:611-629): float32 [num_envs][*dim]: TCP pos, rpy and current goal
+ * pos, rpy in the work frame; terminal != 0: the copy taken at the last step (rows valid where done). */
+int tg_get_obs_feature(tg_ctx* ctx, void** dev_ptr, int32_t* dim, int32_t terminal);
 /* Host copies (synchronise). */
 int tg_get_reward_done(tg_ctx* ctx, float* reward, uint8_t* done);
 int tg_copy_obs_tactile(tg_ctx* ctx, uint8_t* host_dst, int32_t terminal);
+int tg_copy_obs_feature(tg_ctx* ctx, float* host_dst, int32_t terminal);   /* float32 [num_envs][12] */
 
 /* Parity / inspection view of the per-env state, host arrays sized by the caller ([num_envs][...]), any may be NULL. */
 typedef struct {
@@ -176,6 +203,9 @@ typedef struct {
     double*  body_linvel;    /* [num_envs][3] velocity of the composite centre of mass */
     double*  body_angvel;    /* [num_envs][3] */
     double*  gravity_z;      /* [num_envs] */
+    double*  traj;           /* [num_envs][3][TG_MAX_TRAJ_POINTS] work-frame x, y, yaw of the goal trajectory (object_push) */
+    int32_t* goal_id;        /* [num_envs] targ_traj_list_id (object_push) */
+    double*  obj_mass;       /* [num_envs] (object_push) */
 } tg_state_view;
 int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */

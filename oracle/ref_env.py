@@ -601,7 +601,9 @@ class OracleObjectPushEnv(_OracleArmEnv):
     """object_push-v0 (nonprehensile_manipulation/object_push/object_push_env.py + base_object_env.py): MG400 + right-angle
     sensor pushing a cube along a trajectory of goals on the table; tip collision core ON (t_s_core = "fixed")."""
 
-    REST = {"digitac": [-0.4745979999944637, 1.2836350191938928, 0.254159419927845, -1.5395417027560878, 0.47634420683617346,
+    REST = {"tactip": [-0.5059580369524724, 1.2694708511711394, -0.19901995409914455, -1.0721610064154656, 0.5045899087172413,
+                       1.269469774233031, -1.269469774233031, 1.0704498256453248],
+            "digitac": [-0.4745979999944637, 1.2836350191938928, 0.254159419927845, -1.5395417027560878, 0.47634420683617346,
                         1.2838656861791102, -1.283854805915325, 1.5380912693333302],      # object_push/rest_poses.py (mg400, right_angle)
             "digit": [-0.4558165479388624, 1.2857227247064174, 0.26532296230426017, -1.5518769541832729, 0.45743009274925944,
                       1.28573249852019, -1.2857285129498681, 1.5510764390458196]}
@@ -610,13 +612,13 @@ class OracleObjectPushEnv(_OracleArmEnv):
         modes = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
                      observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")
         modes.update(env_modes or {})
-        assert modes["arm_type"] == "mg400" and modes["tactile_sensor_name"] in ("digitac", "digit")
+        assert modes["arm_type"] == "mg400" and modes["tactile_sensor_name"] in ("tactip", "digitac", "digit")
         self._setup_arm(seed, modes, max_steps, image_size, "right_angle", self.REST[modes["tactile_sensor_name"]], inertia)   # :47-49
         self.obj_width = self.obj_height = 0.08                                             # :45-46
         self.termination_pos_dist = 0.025                                                   # :57
         a = 45 * math.pi / 180
         self.TCP_lims = np.array([[-0.0, 0.3], [-0.1, 0.08], [-0.0, 0.0], [-0.0, 0.0], [-0.0, 0.0], [-a, a]])   # :62-68
-        self.well_designed_pos = np.array([0.25, -0.1, self.obj_height / 2])                # :74
+        self.well_designed_pos = np.array([0.28 if modes["tactile_sensor_name"] == "tactip" else 0.25, -0.1, self.obj_height / 2])   # :70-79
         self._set_workframe(self.well_designed_pos, [-math.pi, 0.0, math.pi / 2])           # :87-88
         v, w = 0.01, 5.0 * (math.pi / 180)                                                  # :126-134
         self.act_lo, self.act_hi = np.array([-v, -v, 0.0, 0.0, 0.0, -w]), np.array([v, v, 0.0, 0.0, 0.0, w])
@@ -631,6 +633,7 @@ class OracleObjectPushEnv(_OracleArmEnv):
         for k in range(9):
             b.inertia[k] = float(z["inertia"].reshape(9)[k])
         self.cube = b
+        self._mass0, self._inertia0 = b.mass, [b.inertia[k] for k in range(9)]
         r = np.load(os.path.join(_ASSETS, "robots", f"mg400_right_angle_{self.t_s_name}{suffix}.npz"))
         self._tip_verts = np.ascontiguousarray(r["tip_hull_verts"], dtype=np.float64)
         sc = mb.MBPushScene()
@@ -672,8 +675,11 @@ class OracleObjectPushEnv(_OracleArmEnv):
         self._reset_robot(np.zeros(3), np.zeros(3))                                         # update_init_pose: work-frame origin
         ang = self.rng.uniform(-math.pi / 32, math.pi / 32) if self.modes["rand_init_orn"] else 0.0   # reset_object :168-176
         self._teleport_cube(ang)
-        if self.modes["rand_obj_mass"]:                                                     # :190-192
-            self.cube.mass = self.rng.uniform(0.4, 0.8)
+        if self.modes["rand_obj_mass"]:                                                     # :190-192; changeDynamics(mass) recomputes
+            new_mass = self.rng.uniform(0.4, 0.8)                                           # the inertia from the collision shape
+            for k in range(9):
+                self.cube.inertia[k] = self._inertia0[k] * (new_mass / self._mass0)
+            self.cube.mass = new_mass
         self._update_trajectory()                                                           # make_goal :316-340
         self.targ_traj_list_id = -1
         self._update_goal()

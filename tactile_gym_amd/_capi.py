@@ -8,12 +8,15 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
+MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtactile_gym_hip.so")
 
-ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO, ENV_OBJECT_BALANCE = 0, 1, 2
+ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO, ENV_OBJECT_BALANCE, ENV_OBJECT_PUSH = 0, 1, 2, 3
+PMOVE = {"y": 0, "yRz": 1, "xyRz": 2, "TyRz": 3, "TxTyRz": 4}
+TRAJ = {"simplex": 0, "straight": 1}
 BMOVE = {"xy": 0, "xyz": 1, "RxRy": 2, "xyRxRy": 3}
 SMOVE = {"yz": 0, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}
 MOVE = {"xy": 0, "xyz": 1, "xyRz": 2, "xyzRz": 3}
@@ -72,6 +75,14 @@ class TgConfig(C.Structure):
         ("obj_mass", C.c_double), ("obj_com", _d3), ("obj_inertia", _d9), ("obj_root_inertial_pos", _d3),
         ("obj_base_width", C.c_double), ("obj_base_height", C.c_double), ("obj_init_rpy", _d3), ("ext_force", _d3),
         ("term_deg", C.c_double), ("term_pos", C.c_double), ("p2p_erp", C.c_double), ("p2p_max_impulse", C.c_double),
+        ("traj_type", C.c_int32), ("traj_n_points", C.c_int32), ("rand_init_orn", C.c_int32), ("rand_obj_mass", C.c_int32),
+        ("tip_link", C.c_int32), ("n_tip_verts", C.c_int32), ("cone_friction", C.c_int32), ("reserved1", C.c_int32),
+        ("tip_verts", C.POINTER(C.c_double)),
+        ("obj_half", _d3), ("obj_init_pos", _d3), ("table_z", C.c_double), ("mu_table", C.c_double), ("mu_tip", C.c_double),
+        ("margin_cube", C.c_double), ("margin_tip", C.c_double), ("contact_breaking", C.c_double), ("contact_erp", C.c_double),
+        ("tip_stiffness", C.c_double), ("tip_damping", C.c_double), ("obj_lin_damp", C.c_double), ("obj_ang_damp", C.c_double),
+        ("traj_spacing", C.c_double), ("traj_max_perturb", C.c_double), ("traj_init_offset", C.c_double),
+        ("mass_lo", C.c_double), ("mass_hi", C.c_double), ("init_orn_range", C.c_double), ("traj_ang_range", C.c_double),
     ]
 
 
@@ -85,6 +96,7 @@ class TgStateView(C.Structure):
         ("surf_zoff", C.POINTER(C.c_float)),
         ("body_pos", C.POINTER(C.c_double)), ("body_rot", C.POINTER(C.c_double)), ("body_linvel", C.POINTER(C.c_double)),
         ("body_angvel", C.POINTER(C.c_double)), ("gravity_z", C.POINTER(C.c_double)),
+        ("traj", C.POINTER(C.c_double)), ("goal_id", C.POINTER(C.c_int32)), ("obj_mass", C.POINTER(C.c_double)),
     ]
 
 
@@ -104,8 +116,10 @@ SYMBOLS = {
     "tg_get_obs_tactile": (C.c_int, [_ctx, _vpp]),
     "tg_get_terminal_obs": (C.c_int, [_ctx, _vpp]),
     "tg_get_reward_done_dev": (C.c_int, [_ctx, _vpp, _vpp]),
+    "tg_get_obs_feature": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32), C.c_int32]),
     "tg_get_reward_done": (C.c_int, [_ctx, _fp, _u8p]),
     "tg_copy_obs_tactile": (C.c_int, [_ctx, _u8p, C.c_int32]),
+    "tg_copy_obs_feature": (C.c_int, [_ctx, _fp, C.c_int32]),
     "tg_get_state": (C.c_int, [_ctx, C.POINTER(TgStateView)]),
     "tg_set_joint_state": (C.c_int, [_ctx, _dp, _dp]),
     "tg_profile_enable": (C.c_int, [_ctx, C.c_int32]),

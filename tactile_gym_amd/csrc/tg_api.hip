@@ -48,6 +48,12 @@ template <typename T> struct EnvConst {
     T obj_init_rpy_deg[3], obj_base_width, obj_base_height, term_deg, term_pos, ext_force[3];
     int rand_gravity, rand_embed;
     double gravity_lo, gravity_hi, gravity_default;
+    // object_push
+    PushScene<T> push;
+    int traj_type, traj_n, rand_init_orn, rand_obj_mass;
+    double traj_spacing, traj_max_perturb, traj_init_offset, mass_lo, mass_hi, init_orn_range, traj_ang_range, obj_mass0;
+    T obj_init_pos[3];
+    double obj_init_rpy[3];
 };
 
 struct State {   // device pointers, SoA [field][num_envs]
@@ -63,6 +69,11 @@ struct State {   // device pointers, SoA [field][num_envs]
     // object_balance
     double *body_pos, *body_rot, *body_v, *body_w, *ext_pos, *gravity;   // [3][n], [9][n], [3][n], [3][n], [3][n], [n]
     uint8_t* ext_pending;           // [n]
+    // object_push
+    double *traj, *obj_mass;        // [3][TG_MAX_TRAJ_POINTS][n] work-frame x, y, yaw; [n]
+    int32_t* goal_id;               // [n]
+    float *feature, *term_feature;  // [n][12] extended_feature observation (object_push_env.py:611-629), AoS
+    const void* tip_verts;          // [n_tip][3] in the physics dtype
 };
 
 // SplitMix64 (identical integer stream in oracle/ref_env.py: Rng)
@@ -654,6 +665,240 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
     finish_body<T, TOPO>(m, c, st, env, q, b, (T)embed, 0, false);
 }
 
+// ------------------------------------------------------------------------------------------------ object_push kernels
+// get_step_data (object_push_env.py:456-569): reward, goal advance / termination, extended_feature (:611-629), camera<-cube.
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_push(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                            const FreeBody<T>& b, int step_count, bool write_reward_done) {
+    const int n = c.num_envs;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    const Q4<T> qtcp = quat_from_mat(Rtcp);
+    V3<T> wpos; T wrpy[3], rpy[3];
+    world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpy);
+    st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
+    st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    int gid = st.goal_id[env];
+    bool done = false;
+    if (write_reward_done) {
+        const int gi = gid < c.traj_n ? gid : c.traj_n - 1;
+        const V3<T> gw = mk((T)st.traj[(0 * TG_MAX_TRAJ_POINTS + gi) * n + env], (T)st.traj[(1 * TG_MAX_TRAJ_POINTS + gi) * n + env], T(0));
+        const T gyaw = (T)st.traj[(2 * TG_MAX_TRAJ_POINTS + gi) * n + env];
+        const V3<T> gpos = load_v3(c.work_pos) + mul(c.work_R, gw);                       // workframe_to_worldframe (:305-313)
+        T grpy[3];
+        euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), gyaw)), grpy[0], grpy[1], grpy[2]);
+        const Q4<T> gq = quat_from_euler(grpy[0], grpy[1], grpy[2]);
+        const Q4<T> oq = quat_from_mat(b.R);
+        const T pos_dist = norm(b.pos - gpos);
+        T reward;
+        if (c.reward_mode == TG_REWARD_SPARSE) reward = pos_dist < c.term_dist ? T(1) : T(0);
+        else {
+            const T ip = gq.x * oq.x + gq.y * oq.y + gq.z * oq.z + gq.w * oq.w;
+            T ca = T(2) * (ip * ip) - T(1);
+            ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+            const T orn_dist = tacos(ca);
+            const M3<T> Rq = mat_from_quat(qtcp);
+            const V3<T> ov = mk(b.R.m[0], b.R.m[3], b.R.m[6]), tv = mk(Rq.m[0], Rq.m[3], Rq.m[6]);
+            const T cos_dist = T(1) - dot(ov, tv) / (norm(ov) * norm(tv));
+            reward = -((T(1) * pos_dist) + (T(1) * orn_dist) + (T(1) * cos_dist));
+        }
+        if (pos_dist < c.term_dist) {                                                     // termination (:520-537), update_goal (:342-370)
+            gid += 1;
+            if (gid >= c.traj_n) done = true;
+            st.goal_id[env] = gid;
+        }
+        if (step_count >= c.max_steps) done = true;
+        st.reward[env] = (float)reward;
+        st.done[env] = done ? 1 : 0;
+    }
+    {   // extended_feature: TCP pose and current goal pose in the work frame
+        const int gi = gid < c.traj_n ? gid : c.traj_n - 1;
+        float f[12] = {(float)wpos.x, (float)wpos.y, (float)wpos.z, (float)wrpy[0], (float)wrpy[1], (float)wrpy[2],
+                       (float)st.traj[(0 * TG_MAX_TRAJ_POINTS + gi) * n + env], (float)st.traj[(1 * TG_MAX_TRAJ_POINTS + gi) * n + env], 0.0f,
+                       0.0f, 0.0f, (float)st.traj[(2 * TG_MAX_TRAJ_POINTS + gi) * n + env]};
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            if (write_reward_done) st.term_feature[(size_t)env * 12 + e] = f[e];
+            st.feature[(size_t)env * 12 + e] = f[e];
+        }
+    }
+    V3<T> pb; M3<T> Rb;
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
+    const M3<T> Rc = mul(Rb, c.cam_rot);
+    V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
+    f = (T(1) / norm(f)) * f;
+    V3<T> s = cross(f, up);
+    s = (T(1) / norm(s)) * s;
+    const V3<T> u = cross(s, f);
+    const V3<T> ox{b.R.m[0], b.R.m[3], b.R.m[6]}, oy{b.R.m[1], b.R.m[4], b.R.m[7]}, oz{b.R.m[2], b.R.m[5], b.R.m[8]};
+    const V3<T> dp = b.pos - pc;
+    const V3<T> nf = mk<T>(0, 0, 0) - f;
+    float* X = st.stim_xform;
+    X[0 * n + env] = (float)dot(s, ox);  X[1 * n + env] = (float)dot(s, oy);  X[2 * n + env] = (float)dot(s, oz);
+    X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
+    X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
+    X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                  const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    __shared__ T lds[kPushLdsWords * 64];
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // encode_actions (object_push_env.py:372-454)
+    const float* a = actions + (size_t)env * c.act_dim;
+    if (c.movement_mode == TG_PMOVE_Y) { enc[0] = c.max_action; enc[1] = (T)a[0]; }
+    else if (c.movement_mode == TG_PMOVE_YRZ) { enc[0] = c.max_action; enc[1] = (T)a[0]; enc[5] = (T)a[1]; }
+    else if (c.movement_mode == TG_PMOVE_XYRZ) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[5] = (T)a[2]; }
+    else {                                               // TCP-frame moves: along / across the sensor's pointing direction
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> ptcp; M3<T> Rtcp;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+        const M3<T> Rq = mat_from_quat(quat_from_mat(Rtcp));
+        const V3<T> par = mul(c.work_Rinv, mul(Rq, mk(T(1), T(0), T(0)))), perp = mul(c.work_Rinv, mul(Rq, mk(T(0), T(-1), T(0))));
+        if (c.movement_mode == TG_PMOVE_TYRZ) {
+            const T pa_ = T(1) * c.max_action;
+            enc[0] += perp.x * (T)a[0] + par.x * pa_;
+            enc[1] += perp.y * (T)a[0] + par.y * pa_;
+            enc[5] += (T)a[1];
+        } else {
+            enc[0] += perp.x * (T)a[1] + par.x * (T)a[0];
+            enc[1] += perp.y * (T)a[1] + par.y * (T)a[0];
+            enc[5] += (T)a[2];
+        }
+    }
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+    T qd_des[N];
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+#pragma unroll
+    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+    const T mass = (T)st.obj_mass[env];
+    T qdummy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    for (int t = 0; t < c.action_repeat; ++t)
+        sim_tick_push<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
+                                               (const T*)st.tip_verts, mass, lds + threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    store_body<T>(st, n, env, b);
+    finish_push<T, TOPO>(m, c, st, env, q, b, step_count, true);
+}
+
+// BaseObjectEnv.reset (base_object_env.py:146-173) for object_push: Robot.reset with the cube where the last episode left it,
+// reset_object (teleport; rand_init_orn / rand_obj_mass draws, object_push_env.py:168-194), make_goal (:316-340; the simplex
+// trajectory itself is filled in by k_gen_traj from the seed drawn here).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                   const uint8_t* __restrict__ mask) {
+    constexpr int N = Topo<TOPO>::N;
+    __shared__ T lds[kPushLdsWords * 64];
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    uint64_t rs = st.rng[env];
+    const double ang = c.rand_init_orn ? rng_uniform(rs, -c.init_orn_range, c.init_orn_range) : 0.0;
+    const double old_mass = st.obj_mass[env];
+    const double new_mass = c.rand_obj_mass ? rng_uniform(rs, c.mass_lo, c.mass_hi) : old_mass;
+    if (c.traj_type == TG_TRAJ_SIMPLEX) st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
+    else {
+        const double ta = rng_uniform(rs, -c.traj_ang_range, c.traj_ang_range);
+        double ys[TG_MAX_TRAJ_POINTS];
+        for (int i = 0; i < c.traj_n; ++i) {
+            const double dist = (double)i * c.traj_spacing;
+            st.traj[(0 * TG_MAX_TRAJ_POINTS + i) * n + env] = c.traj_init_offset + dist * cos(ta);
+            ys[i] = dist * sin(ta);
+            st.traj[(1 * TG_MAX_TRAJ_POINTS + i) * n + env] = ys[i];
+        }
+        for (int i = 0; i < c.traj_n; ++i) {
+            double g;
+            if (i == 0) g = (ys[1] - ys[0]) / c.traj_spacing;
+            else if (i == c.traj_n - 1) g = (ys[i] - ys[i - 1]) / c.traj_spacing;
+            else g = (ys[i + 1] - ys[i - 1]) / (2.0 * c.traj_spacing);
+            st.traj[(2 * TG_MAX_TRAJ_POINTS + i) * n + env] = g;
+        }
+    }
+    st.rng[env] = rs;
+    st.step_count[env] = 0;
+    st.goal_id[env] = 0;
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+    const V3<T> tpos = load_v3(c.work_pos);               // update_init_pose: work-frame origin, rpy 0 (base_object_env.py:96-103)
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }
+    T cv = T(0.001);
+    T zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    int used = 0;
+    for (int it = 0; it < 1000; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], step_j[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        if (all_small) cv = cv / T(2);
+        sim_tick_push<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, b, c.push,
+                                               (const T*)st.tip_verts, (T)old_mass, lds + threadIdx.x);
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.reset_ticks[env] = used;
+    // reset_object: resetBasePositionAndOrientation(init_obj_pos, init_obj_orn), velocities zeroed
+    b.pos = load_v3(c.obj_init_pos);
+    b.R = mat_from_quat(quat_from_euler((T)c.obj_init_rpy[0], (T)c.obj_init_rpy[1], (T)(c.obj_init_rpy[2] + ang)));
+    b.v = mk<T>(0, 0, 0); b.w = mk<T>(0, 0, 0);
+    st.obj_mass[env] = new_mass;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+    store_body<T>(st, n, env, b);
+    finish_push<T, TOPO>(m, c, st, env, q, b, 0, false);
+}
+
 // Recompute cached read-backs after tg_set_joint_state.
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_refresh(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st) {
@@ -915,6 +1160,32 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.term_deg = (T)cfg.term_deg; c.term_pos = (T)cfg.term_pos;
         c.rand_gravity = cfg.rand_gravity; c.rand_embed = cfg.rand_embed;
         c.gravity_lo = cfg.gravity_lo; c.gravity_hi = cfg.gravity_hi; c.gravity_default = cfg.gravity_default;
+    } else if (cfg.env_kind == TG_ENV_OBJECT_PUSH) {
+        switch (cfg.movement_mode) {     // get_act_dim, object_push_env.py:631-644
+            case TG_PMOVE_Y: c.act_dim = 1; break;
+            case TG_PMOVE_YRZ: case TG_PMOVE_TYRZ: c.act_dim = 2; break;
+            case TG_PMOVE_XYRZ: case TG_PMOVE_TXTYRZ: c.act_dim = 3; break;
+            default: return fail(-1, "Incorrect movement mode specified");
+        }
+        if (cfg.obj_mass <= 0) return fail(-1, "object_push: object mass must be positive");
+        if (cfg.traj_n_points < 2 || cfg.traj_n_points > TG_MAX_TRAJ_POINTS) return fail(-1, "object_push: traj_n_points must be in [2, TG_MAX_TRAJ_POINTS]");
+        if (cfg.traj_type != TG_TRAJ_SIMPLEX && cfg.traj_type != TG_TRAJ_STRAIGHT) return fail(-1, "object_push: unknown traj_type");
+        if (cfg.n_tip_verts <= 0 || !cfg.tip_verts) return fail(-1, "object_push: the tip collision hull is missing");
+        if (cfg.tip_link < 0 || cfg.tip_link >= rob.ndof) return fail(-1, "object_push: tip_link out of range");
+        PushScene<T>& ps = c.push;
+        ps.table_z = (T)cfg.table_z;
+        for (int k = 0; k < 3; ++k) { ps.half[k] = (T)cfg.obj_half[k]; ps.com[k] = (T)cfg.obj_com[k]; c.obj_init_pos[k] = (T)cfg.obj_init_pos[k]; c.obj_init_rpy[k] = cfg.obj_init_rpy[k]; }
+        ps.mu_table = (T)cfg.mu_table; ps.mu_tip = (T)cfg.mu_tip; ps.margin_cube = (T)cfg.margin_cube; ps.margin_tip = (T)cfg.margin_tip;
+        ps.breaking = (T)cfg.contact_breaking; ps.erp = (T)cfg.contact_erp; ps.tip_stiffness = (T)cfg.tip_stiffness; ps.tip_damping = (T)cfg.tip_damping;
+        ps.lin_damp = (T)cfg.obj_lin_damp; ps.ang_damp = (T)cfg.obj_ang_damp;
+        const int sym[6] = {0, 1, 2, 4, 5, 8};
+        for (int k = 0; k < 6; ++k) ps.inertia0[k] = (T)cfg.obj_inertia[sym[k]];
+        ps.mass0 = (T)cfg.obj_mass;
+        ps.tip_link = cfg.tip_link; ps.n_tip = cfg.n_tip_verts; ps.cone_friction = cfg.cone_friction;
+        c.traj_type = cfg.traj_type; c.traj_n = cfg.traj_n_points; c.rand_init_orn = cfg.rand_init_orn; c.rand_obj_mass = cfg.rand_obj_mass;
+        c.traj_spacing = cfg.traj_spacing; c.traj_max_perturb = cfg.traj_max_perturb; c.traj_init_offset = cfg.traj_init_offset;
+        c.mass_lo = cfg.mass_lo; c.mass_hi = cfg.mass_hi; c.init_orn_range = cfg.init_orn_range; c.traj_ang_range = cfg.traj_ang_range;
+        c.obj_mass0 = cfg.obj_mass;
     } else {
         switch (cfg.movement_mode) {     // surface_follow_auto_env.py:96-107
             case TG_SMOVE_YZ: case TG_SMOVE_XYZ: c.act_dim = 1; break;
@@ -1033,6 +1304,17 @@ template <typename T> static void launch_reset_body_t(tg_ctx* c, const uint8_t* 
                        (const EnvConst<T>*)c->d_const, c->st, d_mask);
 }
 
+template <typename T, int TOPO> static void launch_step_push_t(tg_ctx* c, const float* d_actions) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_step_push<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_actions);
+}
+template <typename T, int TOPO> static void launch_reset_push_t(tg_ctx* c, const uint8_t* d_mask) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_reset_push<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_mask);
+}
+
 #define TG_DISPATCH(ctx_dtype, ctx_topo, CALL)                                               \
     do {                                                                                     \
         if ((ctx_dtype) == TG_PHYSICS_F64) {                                                 \
@@ -1088,6 +1370,13 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
         if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_reset_body_t<double>(c, d_mask);
         else launch_reset_body_t<float>(c, d_mask);
+    } else if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
+#define CALL(T, TOPO) launch_reset_push_t<T, TOPO>(c, d_mask)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+        if (c->cfg.traj_type == TG_TRAJ_SIMPLEX)
+            launch_gen_traj(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.traj_n_points, c->cfg.traj_spacing, c->cfg.traj_max_perturb,
+                            c->cfg.traj_init_offset, c->st.traj, c->st.feature, c->stream);
     } else if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 1)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
@@ -1116,7 +1405,8 @@ int tg_abi_version(void) { return TG_ABI_VERSION; }
 int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sensor, const tg_mesh* stim, tg_ctx** out) {
     if (!cfg || !robot || !sensor || !out) return fail(-1, "tg_create: NULL argument");
     if (cfg->abi_version != TG_ABI_VERSION) return fail(-1, "tg_create: ABI version mismatch");
-    if (cfg->env_kind != TG_ENV_EDGE_FOLLOW && cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && cfg->env_kind != TG_ENV_OBJECT_BALANCE)
+    if (cfg->env_kind != TG_ENV_EDGE_FOLLOW && cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && cfg->env_kind != TG_ENV_OBJECT_BALANCE &&
+        cfg->env_kind != TG_ENV_OBJECT_PUSH)
         return fail(-1, "tg_create: unknown env_kind");
     if (cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && !stim) return fail(-1, "tg_create: this env needs a stimulus mesh");
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE && robot->topology != 0) return fail(-1, "tg_create: object_balance is built for the UR5 chain");
@@ -1194,6 +1484,38 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
         TG_HIP(hipMemcpy(s.gravity, gz.data(), gz.size() * 8, hipMemcpyHostToDevice));
         TG_HIP(hipMemcpy(s.embed, em.data(), em.size() * 8, hipMemcpyHostToDevice));
     }
+    if (cfg->env_kind == TG_ENV_OBJECT_PUSH) {
+        TG_HIP(hipMalloc(&s.body_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.body_rot, 9 * n * 8)); TG_HIP(hipMalloc(&s.body_v, 3 * n * 8));
+        TG_HIP(hipMalloc(&s.body_w, 3 * n * 8)); TG_HIP(hipMalloc(&s.noise_seed, n * 8)); TG_HIP(hipMalloc(&s.obj_mass, n * 8));
+        TG_HIP(hipMalloc(&s.traj, (size_t)3 * TG_MAX_TRAJ_POINTS * n * 8)); TG_HIP(hipMalloc(&s.goal_id, n * 4));
+        TG_HIP(hipMalloc(&s.feature, (size_t)12 * n * 4)); TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4));
+        TG_HIP(hipMemset(s.body_v, 0, 3 * n * 8)); TG_HIP(hipMemset(s.body_w, 0, 3 * n * 8)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8));
+        TG_HIP(hipMemset(s.traj, 0, (size_t)3 * TG_MAX_TRAJ_POINTS * n * 8)); TG_HIP(hipMemset(s.goal_id, 0, n * 4));
+        TG_HIP(hipMemset(s.feature, 0, (size_t)12 * n * 4)); TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
+        // load_object (base_object_env.py:66-70) at init_obj_pos / init_obj_orn (object_push_env.py:154-160)
+        double oq[4], oR[9];
+        h_quat_from_euler(cfg->obj_init_rpy, oq);
+        h_mat_from_quat(oq, oR);
+        std::vector<double> bp(3 * (size_t)n), br(9 * (size_t)n), ms(n, cfg->obj_mass);
+        for (int i = 0; i < n; ++i) {
+            for (int a = 0; a < 3; ++a) bp[(size_t)a * n + i] = cfg->obj_init_pos[a];
+            for (int a = 0; a < 9; ++a) br[(size_t)a * n + i] = oR[a];
+        }
+        TG_HIP(hipMemcpy(s.body_pos, bp.data(), bp.size() * 8, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(s.body_rot, br.data(), br.size() * 8, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(s.obj_mass, ms.data(), ms.size() * 8, hipMemcpyHostToDevice));
+        const size_t nv = (size_t)cfg->n_tip_verts * 3;
+        void* dv = nullptr;
+        if (cfg->physics_dtype == TG_PHYSICS_F64) {
+            TG_HIP(hipMalloc(&dv, nv * 8)); TG_HIP(hipMemcpy(dv, cfg->tip_verts, nv * 8, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> vf(nv);
+            for (size_t k = 0; k < nv; ++k) vf[k] = (float)cfg->tip_verts[k];
+            TG_HIP(hipMalloc(&dv, nv * 4)); TG_HIP(hipMemcpy(dv, vf.data(), nv * 4, hipMemcpyHostToDevice));
+        }
+        s.tip_verts = dv;
+        c->cfg.tip_verts = nullptr;   // the host pointer is not kept
+    }
     if (cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         const size_t cells = (size_t)cfg->surf_rows * cfg->surf_cols;
         TG_HIP(hipMalloc(&s.dir, 2 * n * 8)); TG_HIP(hipMalloc(&s.goal, 3 * n * 8)); TG_HIP(hipMalloc(&s.heights, cells * n * 8));
@@ -1224,7 +1546,7 @@ int tg_destroy(tg_ctx* c) {
     drain_events(c);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.reward,
-                    s.step_count, s.reset_ticks, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
+                    s.step_count, s.reset_ticks, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1273,6 +1595,10 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
         if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
             if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_step_body_t<double>(c, d_act);
             else launch_step_body_t<float>(c, d_act);
+        } else if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
+#define CALL(T, TOPO) launch_step_push_t<T, TOPO>(c, d_act)
+            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
         } else {
 #define CALL(T, TOPO) launch_step_t<T, TOPO>(c, d_act)
             TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
@@ -1300,6 +1626,20 @@ int tg_get_reward_done_dev(tg_ctx* c, void** r, void** d) {
     if (!c) return fail(-1, "NULL ctx");
     if (r) *r = c->st.reward;
     if (d) *d = c->st.done;
+    return 0;
+}
+int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {
+    if (!c || !p) return fail(-1, "NULL argument");
+    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH) return fail(-1, "tg_get_obs_feature: this env has no extended_feature observation");
+    *p = terminal ? c->st.term_feature : c->st.feature;
+    if (dim) *dim = 12;
+    return 0;
+}
+int tg_copy_obs_feature(tg_ctx* c, float* dst, int32_t terminal) {
+    if (!c || !dst) return fail(-1, "NULL argument");
+    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH) return fail(-1, "tg_copy_obs_feature: this env has no extended_feature observation");
+    TG_HIP(hipMemcpyAsync(dst, terminal ? c->st.term_feature : c->st.feature, (size_t)c->cfg.num_envs * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 int tg_get_reward_done(tg_ctx* c, float* reward, uint8_t* done) {
@@ -1339,6 +1679,15 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
         if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
         if (v->gravity_z && (rc = fetch_soa(c, c->st.gravity, 1, v->gravity_z))) return rc;
     }
+    if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
+        if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
+        if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;
+        if (v->body_linvel && (rc = fetch_soa(c, c->st.body_v, 3, v->body_linvel))) return rc;
+        if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
+        if (v->traj && (rc = fetch_soa(c, c->st.traj, 3 * TG_MAX_TRAJ_POINTS, v->traj))) return rc;
+        if (v->goal_id && (rc = fetch_soa(c, c->st.goal_id, 1, v->goal_id))) return rc;
+        if (v->obj_mass && (rc = fetch_soa(c, c->st.obj_mass, 1, v->obj_mass))) return rc;
+    }
     if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         if (v->goal_pos && (rc = fetch_soa(c, c->st.goal, 3, v->goal_pos))) return rc;
         if (v->direction && (rc = fetch_soa(c, c->st.dir, 2, v->direction))) return rc;
@@ -1353,7 +1702,8 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
 
 int tg_set_joint_state(tg_ctx* c, const double* q, const double* qd) {
     if (!c || !q || !qd) return fail(-1, "NULL argument");
-    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) return fail(-1, "tg_set_joint_state: not supported for object_balance");
+    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE || c->cfg.env_kind == TG_ENV_OBJECT_PUSH)
+        return fail(-1, "tg_set_joint_state: not supported for envs with a free object");
     const int n = c->cfg.num_envs, nd = c->robot.ndof;
     std::vector<double> a((size_t)TG_MAX_DOF * n, 0.0), b((size_t)TG_MAX_DOF * n, 0.0);
     for (int i = 0; i < n; ++i)

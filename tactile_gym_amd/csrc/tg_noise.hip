@@ -114,6 +114,59 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
     if (tid == 0 && zoff != nullptr) zoff[env] = center_z ? 0.5f * (red_min[0] + red_max[0]) : 0.0f;
 }
 
+// object_push make_goal -> update_trajectory_simplex (object_push_env.py:248-281): y_i = noise2(i * 0.1, 1) * max_perturb - y_0,
+// x_i = init_offset + i * spacing, yaw = np.gradient(y, spacing).  One 64-thread workgroup per resetting env.
+// traj layout: [3][TG_MAX_TRAJ_POINTS = 16][n_envs]; feature: float [n_envs][12], goal slots 6..11 refreshed for goal 0.
+__global__ __launch_bounds__(64) void k_gen_traj(int n_envs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ seeds, int n_points,
+                                                 double spacing, double max_perturb, double init_offset, double* __restrict__ traj,
+                                                 float* __restrict__ feature) {
+    __shared__ int16_t perm[256];
+    __shared__ int16_t source[256];
+    __shared__ double ys[16];
+    const int env = blockIdx.x, tid = threadIdx.x;
+    if (env >= n_envs || (mask != nullptr && mask[env] == 0)) return;
+    for (int k = tid; k < 256; k += 64) source[k] = (int16_t)k;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long s = (unsigned long long)seeds[env];
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        for (int i = 255; i >= 0; --i) {
+            s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+            const long long v = (long long)(s + 31ULL);
+            long long r = v % (long long)(i + 1);
+            if (r < 0) r += (i + 1);
+            perm[i] = source[r];
+            source[r] = source[i];
+        }
+    }
+    __syncthreads();
+    if (tid < n_points) ys[tid] = opensimplex_noise2(perm, (double)tid * 0.1, 1.0) * max_perturb;
+    __syncthreads();
+    if (tid < n_points) {
+        const double off = -ys[0];
+        const double y = off + ys[tid];
+        const double x = init_offset + ((double)tid * spacing);
+        double g;   // np.gradient of the offset trajectory
+        if (tid == 0) g = ((off + ys[1]) - (off + ys[0])) / spacing;
+        else if (tid == n_points - 1) g = ((off + ys[tid]) - (off + ys[tid - 1])) / spacing;
+        else g = ((off + ys[tid + 1]) - (off + ys[tid - 1])) / (2.0 * spacing);
+        traj[((size_t)0 * 16 + tid) * n_envs + env] = x;
+        traj[((size_t)1 * 16 + tid) * n_envs + env] = y;
+        traj[((size_t)2 * 16 + tid) * n_envs + env] = g;
+        if (tid == 0 && feature != nullptr) {
+            float* f = feature + (size_t)env * 12;
+            f[6] = (float)x; f[7] = (float)y; f[8] = 0.0f; f[9] = 0.0f; f[10] = 0.0f; f[11] = (float)g;
+        }
+    }
+}
+
+void launch_gen_traj(int n_envs, const uint8_t* mask, const int64_t* seeds, int n_points, double spacing, double max_perturb, double init_offset,
+                     double* traj, float* feature, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gen_traj, dim3(n_envs), dim3(64), 0, stream, n_envs, mask, seeds, n_points, spacing, max_perturb, init_offset, traj, feature);
+}
+
 void launch_gen_surface(int n_envs, const uint8_t* mask, const int64_t* seeds, int rows, int cols, double interp, double range, int center_z,
                         double* heights, float* zoff, hipStream_t stream) {
     hipLaunchKernelGGL(k_gen_surface, dim3(n_envs), dim3(256), 0, stream, n_envs, mask, seeds, rows, cols, interp, range, center_z, heights, zoff);

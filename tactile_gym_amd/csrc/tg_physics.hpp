@@ -670,6 +670,356 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
     b.pos = xc - mul(b.R, bc.com);
 }
 
+// ------------------------------------------------------------------------------------------------ arm + cube + contacts
+// object_push: a free cube on the table, pushed by the collision core of the sensor tip (object_push_env.py:196-227 with the
+// tip core enabled, tactile_sensor.py:58-67).  Restated contact model [PARITY_ASSUMPTIONS A23-A28], identical to
+// oracle/minibullet.c:mb_step_push:
+//   cube-table   the cube vertices within the breaking distance of the plane, at most 4, rows in vertex order, normal +z
+//   cube-tip     the hull vertex of the tip core with the smallest signed distance to the box; one soft contact
+//                (contactStiffness / contactDamping -> cfm, erp)
+//   rows         joint motors (reverse order on even sweeps), then all contact normals (lambda >= 0), then per contact the two
+//                friction rows with the cone |lambda_t| <= mu lambda_n; `iters` sweeps, no warm start
+// Storage: the joint-space part (Minv, tip rows' arm Jacobian) stays in registers; the per-contact data lives in a
+// lane-private LDS column (word k of lane l at L[k * 64]) because 23 rows do not fit the VGPR file.
+template <typename T> struct PushScene {
+    T table_z, half[3], mu_table, mu_tip, margin_cube, margin_tip, breaking, erp, tip_stiffness, tip_damping, lin_damp, ang_damp;
+    T com[3], inertia0[6], mass0;
+    int tip_link, n_tip, cone_friction;
+};
+constexpr int kPushTab = 21;                       // words per table contact: ra[3], Wang[3][3], rhs[3], jdi[3], lam[3]
+constexpr int kPushTipBase = 4 * kPushTab;         // tip rows: 3 x {Jlin[3], Jang[3], Wang[3], rhs, jdi, lam}, then cfm*jdi of the normal row
+constexpr int kPushLdsWords = kPushTipBase + 3 * 12 + 1;
+
+template <typename T> __device__ __forceinline__ T trsqrt(T x);
+template <> __device__ __forceinline__ double trsqrt<double>(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - (0.5 * x) * y * y);
+    y = y * (1.5 - (0.5 * x) * y * y);
+    return y;
+}
+template <> __device__ __forceinline__ float trsqrt<float>(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    y = y * (1.5f - (0.5f * x) * y * y);
+    return y;
+}
+// friction limit of one contact: cone (enableConeFriction=1, base_tactile_env.py:128-130) or pyramid
+template <typename T> __device__ __forceinline__ void friction_clamp(T& s1, T& s2, T limit, int cone) {
+    if (cone) {
+        const T tot2 = s1 * s1 + s2 * s2;
+        const bool over = tot2 > limit * limit;
+        if (__any(over)) {
+            const T f = over ? (limit > T(0) ? limit * trsqrt(tot2) : T(0)) : T(1);
+            s1 *= f; s2 *= f;
+        }
+    } else {
+        s1 = s1 < -limit ? -limit : (s1 > limit ? limit : s1);
+        s2 = s2 < -limit ? -limit : (s2 > limit ? limit : s2);
+    }
+}
+// btPlaneSpace1
+template <typename T> __device__ __forceinline__ void plane_space(V3<T> n, V3<T>& t1, V3<T>& t2) {
+    if (tabs(n.z) > T(0.7071067811865475244)) {
+        const T a = n.y * n.y + n.z * n.z, k = T(1) / tsqrt(a);
+        t1 = mk(T(0), -n.z * k, n.y * k);
+        t2 = mk(a * k, -n.x * t1.z, n.x * t1.y);
+    } else {
+        const T a = n.x * n.x + n.y * n.y, k = T(1) / tsqrt(a);
+        t1 = mk(-n.y * k, n.x * k, T(0));
+        t2 = mk(-n.z * t1.y, n.z * t1.x, a * k);
+    }
+}
+
+template <typename T, int TOPO, int MOTOR>
+__device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
+                                              const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
+                                              int iters, FreeBody<T>& b, const PushScene<T>& sc, const T* __restrict__ tip_verts, T mass,
+                                              T* __restrict__ L) {
+    constexpr int N = Topo<TOPO>::N;
+    asm volatile("" ::: "memory");
+    T hb[N], qdm[N], Minv[N][N], traceM;
+    Kin<T, TOPO> kin;
+    const V3<T> gravity = load_v3(m.gravity);
+    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin);
+    T v[N];
+    {
+        T rhs[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) rhs[i] = ((hb[i] - m.joint_damp * qd[i]) - hb[i]) + qdm[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += Minv[i][j] * rhs[j];
+            v[i] = qd[i] + dt * acc;
+        }
+    }
+    // ---- cube: gravity, Bullet's velocity damping, gyroscopic torque (changeDynamics(mass) rescales the inertia with the mass)
+    const T iscale = mass / sc.mass0, invm = T(1) / mass;
+    const S3<T> I0{sc.inertia0[0] * iscale, sc.inertia0[1] * iscale, sc.inertia0[2] * iscale, sc.inertia0[3] * iscale, sc.inertia0[4] * iscale,
+                   sc.inertia0[5] * iscale};
+    const S3<T> Iw = rotate(b.R, I0), Iwi = inverse(Iw);
+    V3<T> xc = b.pos + mul(b.R, load_v3(sc.com));
+    V3<T> vb, wb;
+    {
+        const T sv = sc.lin_damp + sc.lin_damp * norm(b.v), sw = sc.ang_damp + sc.ang_damp * norm(b.w);
+        const V3<T> Iwv = mul(Iw, b.w);
+        const V3<T> Nt = (-sw) * Iwv - cross(b.w, Iwv);
+        vb = b.v + dt * (gravity - sv * b.v);
+        wb = b.w + dt * mul(Iwi, Nt);
+    }
+    // ---- cube - table contacts
+#pragma unroll
+    for (int k = 0; k < kPushTipBase; ++k) L[k * 64] = T(0);
+    {
+        T vz[8];
+        int keep = 0, cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const T lx = (c & 4) ? sc.half[0] : -sc.half[0], ly = (c & 2) ? sc.half[1] : -sc.half[1], lz = (c & 1) ? sc.half[2] : -sc.half[2];
+            vz[c] = (b.pos.z + (b.R.m[6] * lx + b.R.m[7] * ly + b.R.m[8] * lz)) - sc.table_z;
+            if (vz[c] <= sc.breaking) { keep |= 1 << c; ++cnt; }
+        }
+        while (cnt > 4) {   // manifold capacity: drop the shallowest (ties: the higher index)
+            int worst = -1; T wz = T(0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (((keep >> c) & 1) && (worst < 0 || vz[c] >= wz)) { worst = c; wz = vz[c]; }
+            keep &= ~(1 << worst); --cnt;
+        }
+        int slot = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if ((keep >> c) & 1) {
+                const T lx = (c & 4) ? sc.half[0] : -sc.half[0], ly = (c & 2) ? sc.half[1] : -sc.half[1], lz = (c & 1) ? sc.half[2] : -sc.half[2];
+                const V3<T> ra = (b.pos + mul(b.R, mk(lx, ly, lz))) - xc;
+                T* S = L + (slot * kPushTab) * 64;
+                S[0] = ra.x; S[64] = ra.y; S[128] = ra.z;
+                // rows: n = (0,0,1), t1 = (0,-1,0), t2 = (1,0,0)  (btPlaneSpace1 of +z); J = [d, ra x d]
+                const V3<T> Ja[3] = {mk(ra.y, -ra.x, T(0)), mk(ra.z, T(0), -ra.x), mk(T(0), ra.z, -ra.y)};
+                const T lin[3] = {vb.z, -vb.y, vb.x};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const V3<T> Wa_ = mul(Iwi, Ja[r]);
+                    S[(3 + 3 * r) * 64] = Wa_.x; S[(4 + 3 * r) * 64] = Wa_.y; S[(5 + 3 * r) * 64] = Wa_.z;
+                    const T A = invm + dot(Ja[r], Wa_);
+                    const T rv = lin[r] + dot(Ja[r], wb);
+                    T rhs = -rv;
+                    if (r == 0) rhs = (vz[c] > T(0)) ? (-rv - vz[c] / dt) : (-vz[c] * sc.erp / dt - rv);
+                    S[(12 + r) * 64] = rhs;
+                    S[(15 + r) * 64] = T(1) / A;
+                }
+                ++slot;
+            }
+        }
+    }
+    // ---- cube - tip core contact: hull vertex with the smallest signed distance to the box
+    T Jt[3][N], Wa[N][3];
+    {
+        V3<T> ol; M3<T> Rl;
+        {
+            const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+            const T z3[3] = {T(0), T(0), T(0)};
+            link_frame<T, TOPO>(kin, sc.tip_link, z3, ident, ol, Rl);
+        }
+        M3<T> Mr;   // cube <- link rotation  Rc^T Rl
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Mr.m[3 * i + j] = b.R.m[i] * Rl.m[j] + b.R.m[3 + i] * Rl.m[3 + j] + b.R.m[6 + i] * Rl.m[6 + j];
+        const V3<T> tr = mulT(b.R, ol - b.pos);
+        T best_key = T(1e30); int best_i = 0;
+        for (int i = 0; i < sc.n_tip; ++i) {
+            const V3<T> vv = mk(tip_verts[3 * i], tip_verts[3 * i + 1], tip_verts[3 * i + 2]);
+            const V3<T> p = tr + mul(Mr, vv);
+            const T qx = tabs(p.x) - sc.half[0], qy = tabs(p.y) - sc.half[1], qz = tabs(p.z) - sc.half[2];
+            const T ox = qx > T(0) ? qx : T(0), oy = qy > T(0) ? qy : T(0), oz = qz > T(0) ? qz : T(0);
+            const T s2 = ox * ox + oy * oy + oz * oz;
+            const T mq = qx > qy ? (qx > qz ? qx : qz) : (qy > qz ? qy : qz);
+            const T key = s2 > T(0) ? s2 : mq;         // outside: squared distance (> 0); inside: largest face distance (<= 0)
+            if (key < best_key) { best_key = key; best_i = i; }
+        }
+        const V3<T> vv = mk(tip_verts[3 * best_i], tip_verts[3 * best_i + 1], tip_verts[3 * best_i + 2]);
+        const V3<T> w = ol + mul(Rl, vv);
+        const V3<T> p = mulT(b.R, w - b.pos);
+        const T pp[3] = {p.x, p.y, p.z};
+        T qq[3], oo[3], g[3] = {T(0), T(0), T(0)};
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { qq[x] = tabs(pp[x]) - sc.half[x]; oo[x] = qq[x] > T(0) ? qq[x] : T(0); }
+        const T outside = tsqrt(oo[0] * oo[0] + oo[1] * oo[1] + oo[2] * oo[2]);
+        T sdf;
+        if (outside > T(0)) {
+            sdf = outside;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) g[x] = oo[x] / outside * (pp[x] < T(0) ? T(-1) : T(1));
+        } else {
+            const int ax = (qq[0] >= qq[1] && qq[0] >= qq[2]) ? 0 : ((qq[1] >= qq[2]) ? 1 : 2);
+            sdf = ax == 0 ? qq[0] : (ax == 1 ? qq[1] : qq[2]);
+#pragma unroll
+            for (int x = 0; x < 3; ++x) g[x] = (x == ax) ? (pp[x] < T(0) ? T(-1) : T(1)) : T(0);
+        }
+        const T depth = sdf - (sc.margin_tip + sc.margin_cube);
+        const bool active = depth <= sc.breaking;
+        const V3<T> nrm = mul(b.R, mk(g[0], g[1], g[2]));   // from the cube towards the tip
+        const V3<T> pa = w - sc.margin_tip * nrm, pb = w - (sdf - sc.margin_cube) * nrm;
+        V3<T> t1, t2;
+        plane_space(nrm, t1, t2);
+        const V3<T> dirs[3] = {nrm, t1, t2};
+        const V3<T> rb = pb - xc;
+        V3<T> jt[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            bool on_path = false;
+#pragma unroll
+            for (int l = 0; l < N; ++l)
+                if (l == sc.tip_link && is_ancestor_or_self<TOPO>(i, l)) on_path = true;
+            const V3<T> c = cross(kin.a[i], pa - kin.o[i]);
+            jt[i] = on_path ? c : mk<T>(0, 0, 0);
+        }
+        const T denom = dt * sc.tip_stiffness + sc.tip_damping;   // soft contact: cfm = 1 / (dt (dt k + d)), erp = dt k / (dt k + d)
+        const T cfm = (T(1) / denom) / dt, erp_c = dt * sc.tip_stiffness / denom;
+        T* S = L + kPushTipBase * 64;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const V3<T> d = dirs[r];
+#pragma unroll
+            for (int i = 0; i < N; ++i) Jt[r][i] = dot(jt[i], d);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                T acc = T(0);
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc += Minv[i][j] * Jt[r][j];
+                Wa[i][r] = acc;
+            }
+            const V3<T> Jl = mk<T>(0, 0, 0) - d, Ja = mk<T>(0, 0, 0) - cross(rb, d);
+            const V3<T> Wg = mul(Iwi, Ja);
+            T A = invm + dot(Ja, Wg), rv = dot(Jl, vb) + dot(Ja, wb);
+#pragma unroll
+            for (int i = 0; i < N; ++i) { A += Jt[r][i] * Wa[i][r]; rv += Jt[r][i] * v[i]; }
+            T rhs = -rv, jdi = T(1) / A;
+            if (r == 0) {
+                rhs = (depth > T(0)) ? (-rv - depth / dt) : (-depth * erp_c / dt - rv);
+                jdi = T(1) / (A + cfm);
+                S[36 * 64] = active ? cfm * jdi : T(0);
+            }
+            T* Sr = S + (12 * r) * 64;
+            Sr[0] = Jl.x; Sr[64] = Jl.y; Sr[128] = Jl.z;
+            Sr[3 * 64] = Ja.x; Sr[4 * 64] = Ja.y; Sr[5 * 64] = Ja.z;
+            Sr[6 * 64] = Wg.x; Sr[7 * 64] = Wg.y; Sr[8 * 64] = Wg.z;
+            Sr[9 * 64] = active ? rhs : T(0);
+            Sr[10 * 64] = active ? jdi : T(0);
+            Sr[11 * 64] = T(0);
+        }
+    }
+    // ---- motor rows
+    T rm[N], jm[N], lm[N], dv[N];
+    const T maximp = max_force * dt;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const T pos_term = (MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0);
+        const T des = pos_term + v[i] + kd * (qd_des[i] - v[i]);
+        rm[i] = des - v[i];
+        jm[i] = T(1) / Minv[i][i];
+        lm[i] = T(0); dv[i] = T(0);
+    }
+    V3<T> dvl = mk<T>(0, 0, 0), dva = mk<T>(0, 0, 0);
+    T* S = L + kPushTipBase * 64;
+    for (int it = 0; it < iters; ++it) {
+        // joint motors
+        if (it & 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const T t = (rm[i] - dv[i]) * jm[i], sum = lm[i] + t;
+                const T lo = sum < -maximp ? -maximp : sum, scl = lo > maximp ? maximp : lo;
+                const T delta = (scl == sum) ? t : scl - lm[i];
+                lm[i] = scl;
+#pragma unroll
+                for (int j = 0; j < N; ++j) dv[j] += Minv[j][i] * delta;
+            }
+        } else {
+#pragma unroll
+            for (int i = N - 1; i >= 0; --i) {
+                const T t = (rm[i] - dv[i]) * jm[i], sum = lm[i] + t;
+                const T lo = sum < -maximp ? -maximp : sum, scl = lo > maximp ? maximp : lo;
+                const T delta = (scl == sum) ? t : scl - lm[i];
+                lm[i] = scl;
+#pragma unroll
+                for (int j = 0; j < N; ++j) dv[j] += Minv[j][i] * delta;
+            }
+        }
+        // contact normals: table slots, then the tip
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            T* C = L + (c * kPushTab) * 64;
+            const T rax = C[0], ray = C[64];
+            const T jdv = dvl.z + (ray * dva.x - rax * dva.y);
+            const T lam = C[18 * 64];
+            const T t = (C[12 * 64] - jdv) * C[15 * 64], sum = lam + t;
+            const T nl = sum < T(0) ? T(0) : sum;
+            const T delta = nl - lam;
+            C[18 * 64] = nl;
+            dvl.z += invm * delta;
+            dva = dva + delta * mk(C[3 * 64], C[4 * 64], C[5 * 64]);
+        }
+        {
+            T jdv = S[0] * dvl.x + S[64] * dvl.y + S[128] * dvl.z + S[3 * 64] * dva.x + S[4 * 64] * dva.y + S[5 * 64] * dva.z;
+#pragma unroll
+            for (int i = 0; i < N; ++i) jdv += Jt[0][i] * dv[i];
+            const T lam = S[11 * 64], jdi = S[10 * 64];
+            const T t = (S[9 * 64] - jdv) * jdi - lam * S[36 * 64], sum = lam + t;
+            const T nl = sum < T(0) ? T(0) : sum;
+            const T delta = nl - lam;
+            S[11 * 64] = nl;
+#pragma unroll
+            for (int i = 0; i < N; ++i) dv[i] += Wa[i][0] * delta;
+            dvl = dvl + (invm * delta) * mk(S[0], S[64], S[128]);
+            dva = dva + delta * mk(S[6 * 64], S[7 * 64], S[8 * 64]);
+        }
+        // friction: table slots, then the tip
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            T* C = L + (c * kPushTab) * 64;
+            const T rax = C[0], ray = C[64], raz = C[128];
+            const T limit = sc.mu_table * C[18 * 64];
+            const T jdv1 = -dvl.y + (raz * dva.x - rax * dva.z), jdv2 = dvl.x + (raz * dva.y - ray * dva.z);
+            const T l1 = C[19 * 64], l2 = C[20 * 64];
+            T s1 = l1 + (C[13 * 64] - jdv1) * C[16 * 64], s2 = l2 + (C[14 * 64] - jdv2) * C[17 * 64];
+            friction_clamp(s1, s2, limit, sc.cone_friction);
+            const T d1 = s1 - l1, d2 = s2 - l2;
+            C[19 * 64] = s1; C[20 * 64] = s2;
+            dvl.y -= invm * d1; dvl.x += invm * d2;
+            dva = dva + d1 * mk(C[6 * 64], C[7 * 64], C[8 * 64]) + d2 * mk(C[9 * 64], C[10 * 64], C[11 * 64]);
+        }
+        {
+            T* S1 = S + 12 * 64; T* S2 = S + 24 * 64;
+            const T limit = sc.mu_tip * S[11 * 64];
+            T jdv1 = S1[0] * dvl.x + S1[64] * dvl.y + S1[128] * dvl.z + S1[3 * 64] * dva.x + S1[4 * 64] * dva.y + S1[5 * 64] * dva.z;
+            T jdv2 = S2[0] * dvl.x + S2[64] * dvl.y + S2[128] * dvl.z + S2[3 * 64] * dva.x + S2[4 * 64] * dva.y + S2[5 * 64] * dva.z;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { jdv1 += Jt[1][i] * dv[i]; jdv2 += Jt[2][i] * dv[i]; }
+            const T l1 = S1[11 * 64], l2 = S2[11 * 64];
+            T s1 = l1 + (S1[9 * 64] - jdv1) * S1[10 * 64], s2 = l2 + (S2[9 * 64] - jdv2) * S2[10 * 64];
+            friction_clamp(s1, s2, limit, sc.cone_friction);
+            const T d1 = s1 - l1, d2 = s2 - l2;
+            S1[11 * 64] = s1; S2[11 * 64] = s2;
+#pragma unroll
+            for (int i = 0; i < N; ++i) dv[i] += Wa[i][1] * d1 + Wa[i][2] * d2;
+            dvl = dvl + (invm * d1) * mk(S1[0], S1[64], S1[128]) + (invm * d2) * mk(S2[0], S2[64], S2[128]);
+            dva = dva + d1 * mk(S1[6 * 64], S1[7 * 64], S1[8 * 64]) + d2 * mk(S2[6 * 64], S2[7 * 64], S2[8 * 64]);
+        }
+    }
+    // ---- integrate
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        qd[i] = v[i] + dv[i];
+        q[i] += dt * qd[i];
+    }
+    b.v = vb + dvl;
+    b.w = wb + dva;
+    xc = xc + dt * b.v;
+    integrate_rotation(b.R, b.w, dt);
+    b.pos = xc - mul(b.R, load_v3(sc.com));
+}
+
 // ------------------------------------------------------------------------------------------------ quaternion / Euler helpers
 // (pybullet getQuaternionFromEuler / getEulerFromQuaternion / btMatrix3x3::getRotation; quaternions are x,y,z,w)
 template <typename T> struct Q4 { T x, y, z, w; };

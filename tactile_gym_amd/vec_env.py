@@ -30,7 +30,7 @@ class TactileVecEnv:
     metadata = {"render.modes": ["rgb_array"]}
 
     def __init__(self, cfg, robot, sensor_desc, mesh_desc, observation_mode="tactile", obs_mode="numpy", seed=None, act_dim=None,
-                 oracle_dim=10):
+                 oracle_dim=10, feature_dim=0):
         self._L = capi.lib()
         self.num_envs = int(cfg.num_envs)
         self._cfg, self._robot, self._sensor, self._mesh = cfg, robot, sensor_desc, mesh_desc
@@ -54,7 +54,8 @@ class TactileVecEnv:
         if "tactile" in observation_mode:
             obs_spaces["tactile"] = spaces.Box(low=0, high=255, shape=(self.H, self.W, 1), dtype=np.uint8)
         if "feature" in observation_mode:
-            obs_spaces["extended_feature"] = spaces.Box(low=-np.inf, high=np.inf, shape=(0,), dtype=np.float32)
+            obs_spaces["extended_feature"] = spaces.Box(low=-np.inf, high=np.inf, shape=(feature_dim,), dtype=np.float32)
+        self.feature_dim = feature_dim
         self.observation_space = spaces.Dict(obs_spaces)
         self._actions = np.zeros((self.num_envs, self.act_dim), dtype=np.float32)
         self._reward = np.zeros(self.num_envs, dtype=np.float32)
@@ -197,14 +198,37 @@ class TactileVecEnv:
         if "tactile" in self.observation_mode:
             obs["tactile"] = self.tactile_torch() if self.obs_mode == "torch" else self.tactile_numpy().copy()
         if "feature" in self.observation_mode:
-            obs["extended_feature"] = np.zeros((self.num_envs, 0), dtype=np.float32)
+            obs["extended_feature"] = self.feature_torch() if self.obs_mode == "torch" else self.feature_numpy()
         return obs
 
     def _terminal_observation(self):
         obs = {}
         if "tactile" in self.observation_mode:
             obs["tactile"] = self.tactile_torch(True) if self.obs_mode == "torch" else self.tactile_numpy(True)
+        if "feature" in self.observation_mode:
+            obs["extended_feature"] = self.feature_torch(True) if self.obs_mode == "torch" else self.feature_numpy(True)
         return obs
+
+    def _feature_ptr(self, terminal):
+        p, dim = C.c_void_p(), C.c_int32()
+        capi.check(self._L.tg_get_obs_feature(self._ctx, C.byref(p), C.byref(dim), int(terminal)))
+        return p.value, dim.value
+
+    def feature_torch(self, terminal=False):
+        """Zero-copy torch.float32 [N, feature_dim] view of the device-resident extended_feature observation."""
+        key = ("feat", bool(terminal))
+        if key not in self._views:
+            import torch
+            ptr, dim = self._feature_ptr(terminal)
+            self._views[key] = torch.as_tensor(_DevArray(ptr, (self.num_envs, dim), "<f4"), device=torch.device("cuda", self._cfg.device))
+        return self._views[key]
+
+    def feature_numpy(self, terminal=False):
+        if self.feature_dim == 0:
+            return np.zeros((self.num_envs, 0), dtype=np.float32)
+        buf = np.zeros((self.num_envs, self.feature_dim), dtype=np.float32)
+        capi.check(self._L.tg_copy_obs_feature(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_float)), int(terminal)))
+        return buf
 
     def oracle_obs(self):
         raise NotImplementedError
@@ -219,6 +243,9 @@ class TactileVecEnv:
         if self._cfg.env_kind == capi.ENV_OBJECT_BALANCE:
             out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
                        gravity_z=np.zeros(n))
+        if self._cfg.env_kind == capi.ENV_OBJECT_PUSH:
+            out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
+                       traj=np.zeros((n, 3, capi.MAX_TRAJ_POINTS)), goal_id=np.zeros(n, np.int32), obj_mass=np.zeros(n))
         if self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO:
             out.update(goal_pos=np.zeros((n, 3)), direction=np.zeros((n, 2)), surf_zoff=np.zeros(n, np.float32),
                        heights=np.zeros((n, self._cfg.surf_rows, self._cfg.surf_cols)))

@@ -455,3 +455,83 @@ def test_edge_follow_mg400_env_matches_oracle(edge_modes):
             assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
             assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 2, (step, i)
     venv.close()
+
+
+PUSH_MODES = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=True, rand_obj_mass=True, traj_type="simplex",
+                  observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor,movement,traj", [("digitac", "TyRz", "simplex"), ("tactip", "xyRz", "straight"), ("digit", "TxTyRz", "simplex")])
+def test_object_push_env_matches_oracle(sensor, movement, traj):
+    """object_push-v0 (BASELINE config 4: MG400 + DigiTac right-angle sensor, cube on the table, tip collision core ON): rigid
+    contacts cube-table and cube-tip with friction.  Two consecutive episodes (the second Robot.reset runs with the cube where the
+    first episode left it), 4 envs vs 4 oracle envs.  Contact dynamics amplify rounding differences (the HIP tick uses FMA
+    contraction and the residual-free PGS bookkeeping), so: joints 1e-9 rad, cube pose 1e-8, reward 1e-6, extended_feature to
+    float32, goal index / done exact, tactile images within 3 pixels; the simplex goal trajectory is bit-exact."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleObjectPushEnv
+    modes = dict(PUSH_MODES, tactile_sensor_name=sensor, movement_mode=movement, traj_type=traj)
+    n, steps, size = 4, 7, 128
+    act_dim = {"TyRz": 2, "xyRz": 3, "TxTyRz": 3}[movement]
+    venv = tg.make_vec("object_push-v0", num_envs=n, max_steps=steps, image_size=[size, size], env_modes=modes, seed=31, auto_reset=False)
+    assert venv.observation_space["extended_feature"].shape == (12,) and venv.action_space.shape == (act_dim,)
+    oracles = [OracleObjectPushEnv(seed=31 + i, max_steps=steps, image_size=(size, size), env_modes=modes) for i in range(n)]
+    rng = np.random.default_rng(5)
+    touched = 0
+    for episode in range(2):
+        obs = venv.reset()
+        ref = [o.reset() for o in oracles]
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            assert st["reset_ticks"][i] == o.reset_ticks and st["obj_mass"][i] == o.cube.mass and st["goal_id"][i] == 0
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-9
+            assert np.abs(st["body_pos"][i] - o.cube_pose()[0]).max() < 1e-12 and np.abs(st["body_rot"][i] - o.cube_pose()[1]).max() < 1e-12
+            if traj == "simplex":
+                assert np.array_equal(st["traj"][i][:2, :10].T, o.traj_pos_work[:, :2]) and np.array_equal(st["traj"][i][2, :10], o.traj_rpy_work[:, 2])
+            else:
+                assert np.abs(st["traj"][i][:2, :10].T - o.traj_pos_work[:, :2]).max() < 1e-15
+                assert np.abs(st["traj"][i][2, :10] - o.traj_rpy_work[:, 2]).max() < 1e-12
+            assert np.abs(obs["extended_feature"][i] - ref[i]["extended_feature"]).max() < 1e-6
+            assert int((obs["tactile"][i] != ref[i]["tactile"]).sum()) <= 3
+        for step in range(steps):
+            a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+            if movement != "TyRz":
+                a[:, 0] = np.abs(a[:, 0])          # keep pushing forward
+            obs, rew, done, _ = venv.step(a)
+            st = venv.get_state()
+            for i, o in enumerate(oracles):
+                ro, rr, rd, _ = o.step(a[i])
+                pos, R = o.cube_pose()
+                assert np.abs(st["q"][i] - o.arm.q).max() < 1e-9, (episode, step, i)
+                assert np.abs(st["body_pos"][i] - pos).max() < 1e-8 and np.abs(st["body_rot"][i] - R).max() < 1e-8, (episode, step, i)
+                assert abs(rew[i] - rr) < 1e-6 and bool(done[i]) == rd and st["goal_id"][i] == o.targ_traj_list_id
+                assert np.abs(obs["extended_feature"][i] - ro["extended_feature"]).max() < 1e-6
+                assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (episode, step, i)
+                touched += int(o.scene.tip_depth < 1.0)
+        assert done.all()
+    assert touched > n * steps          # the tip core really pushed the cube in most steps
+    venv.close()
+
+
+@pytest.mark.gpu
+def test_object_push_f32_and_autoreset():
+    """f32 physics variant of object_push: finite, the cube moves forward and stays on the table; auto-reset hands back the terminal
+    observation (tactile + extended_feature) and restarts the episode at goal 0."""
+    import tactile_gym_amd as tg
+    modes = dict(PUSH_MODES, rand_init_orn=False, rand_obj_mass=False)
+    n, steps = 64, 5
+    venv = tg.make_vec("object_push-v0", num_envs=n, max_steps=steps, image_size=[64, 64], env_modes=modes, seed=3, physics_dtype="f32")
+    venv.reset()
+    y0 = venv.get_state()["body_pos"][:, 1].copy()
+    for step in range(steps):
+        obs, rew, done, infos = venv.step(np.zeros((n, 2), np.float32))
+    st = venv.get_state()
+    assert done.all() and all("terminal_observation" in i for i in infos)
+    term = infos[0]["terminal_observation"]
+    assert term["tactile"].shape == (64, 64, 1) and term["extended_feature"].shape == (12,) and (term["tactile"] > 0).sum() > 100
+    assert np.isfinite(rew).all() and np.isfinite(st["q"]).all()
+    assert (st["goal_id"] == 0).all() and (st["step_count"] == 0).all()
+    assert np.abs(st["body_pos"][:, 1] - y0).max() < 1e-12          # teleported back by the auto-reset
+    assert term["extended_feature"][1] > 0.002                      # the TCP advanced along the work-frame push direction
+    venv.close()

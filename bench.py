@@ -24,6 +24,8 @@ SURF_MODES = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", 
                   reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")   # BASELINE configs[2], params/surface_follow_auto_params.py
 BAL_MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=True, rand_embed_dist=True,
                  observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")   # configs[4], params/object_balance_params.py
+PUSH_MODES = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
+                  observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")   # configs[3], params/object_push_params.py
 MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
              reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
 ALGO_BYTES_PER_ENV_STEP = 16600.0   # BASELINE.md section 3 / SURVEY 8(d): 16 384 B image + ~0.2 KB state/action/reward
@@ -69,7 +71,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=128)
     ap.add_argument("--physics", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0", "object_balance-v0"],
+    ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0", "object_balance-v0", "object_push-v0"],
                     help="headline = edge_follow-v0 (BASELINE configs[1]); surface_follow-v0 = configs[2]; object_balance-v0 = configs[4] "
                          "(use --image-size 256)")
     args = ap.parse_args()
@@ -93,9 +95,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     n = args.num_envs
-    modes = {"edge_follow-v0": MODES, "surface_follow-v0": SURF_MODES, "object_balance-v0": BAL_MODES}[args.env]
+    modes = {"edge_follow-v0": MODES, "surface_follow-v0": SURF_MODES, "object_balance-v0": BAL_MODES, "object_push-v0": PUSH_MODES}[args.env]
     act_dim = 3 if args.env == "surface_follow-v0" else 2
-    max_steps = 250 if args.env == "object_balance-v0" else 200        # params/*_params.py max_ep_len
+    max_steps = {"object_balance-v0": 250, "object_push-v0": 1000}.get(args.env, 200)        # params/*_params.py max_ep_len
     venv = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
                        seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch")
     shard = TorchShard(venv)
@@ -147,14 +149,15 @@ def main():
         dominant = "k_step" if step_ms >= rend_ms else "k_render_tactile"
         dom_ms = k_step if dominant == "k_step" else k_render_main
         algo_bytes = {"edge_follow-v0": ALGO_BYTES_PER_ENV_STEP, "surface_follow-v0": ALGO_BYTES_SURFACE,
-                      "object_balance-v0": args.image_size * args.image_size + 300.0}[args.env]   # config 5: 65.8 KB at 256x256
+                      "object_balance-v0": args.image_size * args.image_size + 300.0,             # config 5: 65.8 KB at 256x256
+                      "object_push-v0": args.image_size * args.image_size + 400.0}[args.env]
         achieved = algo_bytes * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (128x128 tactile obs) at N envs", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.physics == "f64" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.env}, UR5 + {'DIGIT' if args.env == 'surface_follow-v0' else 'TacTip'}, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
+            "config": {"workload": f"{args.env}, {'MG400 + DigiTac' if args.env == 'object_push-v0' else 'UR5 + ' + ('DIGIT' if args.env == 'surface_follow-v0' else 'TacTip')}, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
                                    f"random actions, TCP_velocity_control, {12 if args.env == 'object_balance-v0' else 24} ticks x 150 PGS sweeps per step, auto-reset on",
                        "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world} + gather to rank 0"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

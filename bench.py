@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=128)
     ap.add_argument("--physics", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-sweeps", action="store_true",
+                    help="always run all 150 PGS sweeps per tick instead of leaving the loop at convergence to the last bit (DESIGN.md 4.1)")
     ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0", "object_balance-v0", "object_push-v0"],
                     help="headline = edge_follow-v0 (BASELINE configs[1]); surface_follow-v0 = configs[2]; object_balance-v0 = configs[4] "
                          "(use --image-size 256)")
@@ -99,7 +101,8 @@ def main():
     act_dim = 3 if args.env == "surface_follow-v0" else 2
     max_steps = {"object_balance-v0": 250, "object_push-v0": 1000}.get(args.env, 200)        # params/*_params.py max_ep_len
     venv = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
-                       seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch")
+                       seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",
+                       pgs_full_sweeps=args.full_sweeps)
     shard = TorchShard(venv)
     env = ShardedVecEnv(shard, dist) if world > 1 else shard
     gen = torch.Generator(device="cuda")
@@ -168,6 +171,7 @@ def main():
                                        "k_render_tactile_masked": round(prof["render_masked"][0] / max(prof["render_masked"][1], 1), 4)},
                          "launches": {"k_step": step_n, "k_render_tactile": rend_n, "k_reset": rst_n},
                          "note": "latency-bound by construction: 24 x 150 serial Gauss-Seidel sweeps per env step (BASELINE.md section 3)"},
+            "pgs_sweeps": "150 (forced)" if args.full_sweeps else "<= 150, exit at convergence to the last bit (every tick ends within 1e-16 of the 150-sweep result)",
             "resets_in_timed_region": bool((args.warmup % 200) + args.steps >= 200),
         }
         if world == 1 and not args.no_cpu_baseline and args.env == "edge_follow-v0":

@@ -103,7 +103,8 @@ typedef struct {
      * stim_pos = surface_pos; rows x cols grid of pitch surf_grid_scale; height = noise2(i*interp, j*interp) * range. */
     int32_t surf_rows, surf_cols;           /* 64, 64 (:240-243) */
     int32_t surf_center_z;                  /* 1: Bullet's heightfield shape is centred on (min+max)/2 [PARITY_ASSUMPTIONS A15] */
-    int32_t reserved0;
+    int32_t pgs_full_sweeps;                /* 0 (default): the motor-row PGS leaves the loop once no impulse can change in its last bit
+                                             * (Bullet's zero-residual exit, PARITY_ASSUMPTIONS A7b); 1: always run solver_iterations sweeps */
     double surf_grid_scale;                 /* 0.006 (:238) */
     double surf_height_range;               /* 0.025 (:239) */
     double surf_interp;                     /* 0.05  (:244) */

@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+int mb_last_sweeps = 0;   /* inspection: PGS sweeps executed by the last mb_step (exits at the exact fixed point) */
+
 /* ------------------------------------------------------------------------------------------------ 3-vector helpers */
 static void m3_mul(const double* A, const double* B, double* C) {
     double t[9];
@@ -266,8 +268,10 @@ void mb_step(const mb_model* m, mb_state* s, double dt, int iters) {
         lam[i] = 0.0; dv[i] = 0.0;
         maximp[i] = s->motor_max_force[i] * dt;
     }
+    mb_last_sweeps = 0;
     for (int it = 0; it < iters; ++it) {
         double residual = 0.0;
+        mb_last_sweeps = it + 1;
         for (int jj = 0; jj < n; ++jj) {
             int i = (it & 1) ? jj : n - 1 - jj;
             if (!active[i]) continue;
@@ -831,7 +835,10 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
         }
     }
     memset(lam, 0, sizeof lam); memset(dv, 0, sizeof dv);
+    sc->sweeps_used = 0;
     for (int it = 0; it < iters; ++it) {
+        double residual = 0.0;                                        /* largest squared impulse change of the sweep */
+        sc->sweeps_used = it + 1;
         for (int jj = 0; jj < n; ++jj) {                              /* joint motors: reversed on even sweeps */
             int r = (it & 1) ? jj : n - 1 - jj;
             if (s->motor_mode[r] == MB_MOTOR_OFF) continue;
@@ -839,6 +846,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             double delta = rhs[r] * jdi - dv[r] * jdi, sum = lam[r] + delta;
             if (sum < -lim) { delta = -lim - lam[r]; lam[r] = -lim; } else if (sum > lim) { delta = lim - lam[r]; lam[r] = lim; } else lam[r] = sum;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+            if (delta * delta > residual) residual = delta * delta;
         }
         for (int c = 0; c < nc; ++c) {                                /* contact normals */
             int r = n + 3 * c;
@@ -847,6 +855,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             double delta = rhs[r] * jdi - lam[r] * (cfm[r] * jdi) - jdv * jdi, sum = lam[r] + delta;
             if (sum < 0.0) { delta = -lam[r]; lam[r] = 0.0; } else lam[r] = sum;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+            if (delta * delta > residual) residual = delta * delta;
         }
         for (int c = 0; c < nc; ++c) {                                /* friction */
             int r1 = n + 3 * c + 1, r2 = r1 + 1;
@@ -864,7 +873,10 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             }
             d1 = s1 - lam[r1]; d2 = s2 - lam[r2]; lam[r1] = s1; lam[r2] = s2;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r1] * d1 + W[u][r2] * d2;
+            if (d1 * d1 > residual) residual = d1 * d1;
+            if (d2 * d2 > residual) residual = d2 * d2;
         }
+        if (residual <= sc->residual_threshold) break;                /* leastSquaresResidualThreshold [A7b]; 0 = exact fixed point */
     }
     for (int c = 0; c < nc; ++c) if (ct[c].arm_a) sc->tip_impulse = lam[n + 3 * c];
     /* ---- integrate */

@@ -168,8 +168,11 @@ typedef struct {
     /* outputs of the last tick (inspection / parity): number of contacts and the tip contact */
     int32_t n_contacts;
     double tip_depth, tip_normal[3], tip_impulse;
+    double residual_threshold;   /* in: PGS leaves the loop when the largest squared impulse change of a sweep is <= this (0: exact fixed point) */
+    int32_t sweeps_used;         /* out */
 } mb_push_scene;
 
+extern int mb_last_sweeps;   /* PGS sweeps executed by the last mb_step */
 void mb_step_push(const mb_model* m, mb_state* s, mb_body* cube, mb_push_scene* sc, double dt, int solver_iterations);
 
 #ifdef __cplusplus

@@ -55,6 +55,7 @@ class MBPushScene(C.Structure):
         ("tip_stiffness", C.c_double), ("tip_damping", C.c_double), ("lin_damp", C.c_double), ("ang_damp", C.c_double),
         ("tip_link", C.c_int32), ("n_tip", C.c_int32), ("tip_verts", C.POINTER(C.c_double)), ("cone_friction", C.c_int32),
         ("n_contacts", C.c_int32), ("tip_depth", C.c_double), ("tip_normal", C.c_double * 3), ("tip_impulse", C.c_double),
+        ("residual_threshold", C.c_double), ("sweeps_used", C.c_int32),
     ]
 
 

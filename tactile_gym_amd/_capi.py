@@ -67,7 +67,7 @@ class TgConfig(C.Structure):
         ("workframe_pos", _d3), ("workframe_rpy", _d3), ("stim_pos", _d3),
         ("edge_height", C.c_double), ("edge_len", C.c_double), ("termination_dist", C.c_double),
         ("embed_dist", C.c_double), ("embed_lo", C.c_double), ("embed_hi", C.c_double),
-        ("surf_rows", C.c_int32), ("surf_cols", C.c_int32), ("surf_center_z", C.c_int32), ("reserved0", C.c_int32),
+        ("surf_rows", C.c_int32), ("surf_cols", C.c_int32), ("surf_center_z", C.c_int32), ("pgs_full_sweeps", C.c_int32),
         ("surf_grid_scale", C.c_double), ("surf_height_range", C.c_double), ("surf_interp", C.c_double),
         ("surf_xy_extent", C.c_double), ("auto_action_scale", C.c_double),
         ("rand_gravity", C.c_int32), ("rand_embed", C.c_int32),

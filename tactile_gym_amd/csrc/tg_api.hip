@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
     for (int t = 0; t < c.action_repeat; ++t)
-        sim_tick<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, true);
+        sim_tick<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters);
 
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
 #pragma unroll
         for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
         if (all_small) cv = cv / T(2);
-        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, true);
+        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters);
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
@@ -747,7 +747,8 @@ template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
     constexpr int N = Topo<TOPO>::N;
-    __shared__ T lds[kPushLdsWords * 64];
+    extern __shared__ double push_lds_raw[];             // kPushLdsWords * 64 words of T (83 KB in f64: dynamic, above the 64 KB static cap)
+    const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
@@ -808,7 +809,8 @@ template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
     constexpr int N = Topo<TOPO>::N;
-    __shared__ T lds[kPushLdsWords * 64];
+    extern __shared__ double push_lds_raw[];
+    const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
@@ -996,9 +998,9 @@ __global__ __launch_bounds__(64) void k_sim_ticks(const DevRobot<T>* __restrict_
         qdes[i] = q_des ? (T)q_des[s * N + i] : T(0); vdes[i] = qd_des ? (T)qd_des[s * N + i] : T(0);
     }
     for (int t = 0; t < n_ticks; ++t) {
-        if (motor_mode == kMotorVelocity) sim_tick<T, TOPO, kMotorVelocity>(*mp, qq, qv, qdes, vdes, T(0), mp->vel_gain, (T)max_force, (T)dt, iters, true);
-        else if (motor_mode == kMotorPosition) sim_tick<T, TOPO, kMotorPosition>(*mp, qq, qv, qdes, vdes, mp->pos_gain, mp->vel_gain, (T)max_force, (T)dt, iters, true);
-        else sim_tick<T, TOPO, kMotorOff>(*mp, qq, qv, qdes, vdes, T(0), T(0), T(0), (T)dt, iters, true);
+        if (motor_mode == kMotorVelocity) sim_tick<T, TOPO, kMotorVelocity>(*mp, qq, qv, qdes, vdes, T(0), mp->vel_gain, (T)max_force, (T)dt, iters);
+        else if (motor_mode == kMotorPosition) sim_tick<T, TOPO, kMotorPosition>(*mp, qq, qv, qdes, vdes, mp->pos_gain, mp->vel_gain, (T)max_force, (T)dt, iters);
+        else sim_tick<T, TOPO, kMotorOff>(*mp, qq, qv, qdes, vdes, T(0), T(0), T(0), (T)dt, iters);
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) { q[s * N + i] = (double)qq[i]; qd[s * N + i] = (double)qv[i]; }
@@ -1172,6 +1174,7 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         if (cfg.traj_type != TG_TRAJ_SIMPLEX && cfg.traj_type != TG_TRAJ_STRAIGHT) return fail(-1, "object_push: unknown traj_type");
         if (cfg.n_tip_verts <= 0 || !cfg.tip_verts) return fail(-1, "object_push: the tip collision hull is missing");
         if (cfg.tip_link < 0 || cfg.tip_link >= rob.ndof) return fail(-1, "object_push: tip_link out of range");
+        if (rob.topology == 1 && cfg.tip_link >= Topo<1>::NP) return fail(-1, "object_push: the tip must hang off the MG400's main chain (j1..j5)");
         PushScene<T>& ps = c.push;
         ps.table_z = (T)cfg.table_z;
         for (int k = 0; k < 3; ++k) { ps.half[k] = (T)cfg.obj_half[k]; ps.com[k] = (T)cfg.obj_com[k]; c.obj_init_pos[k] = (T)cfg.obj_init_pos[k]; c.obj_init_rpy[k] = cfg.obj_init_rpy[k]; }
@@ -1204,7 +1207,7 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.ybin_lo = cfg.stim_pos[1] - ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
         c.ybin_hi = cfg.stim_pos[1] + ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
     }
-    c.max_steps = cfg.max_steps; c.action_repeat = cfg.action_repeat; c.solver_iters = cfg.solver_iterations;
+    c.max_steps = cfg.max_steps; c.action_repeat = cfg.action_repeat; c.solver_iters = cfg.pgs_full_sweeps ? -cfg.solver_iterations : cfg.solver_iterations;
     c.dt = (T)cfg.sim_dt; c.min_action = (T)cfg.min_action; c.max_action = (T)cfg.max_action;
     for (int d = 0; d < 6; ++d) { c.act_lo[d] = (T)cfg.act_lo[d]; c.act_hi[d] = (T)cfg.act_hi[d]; c.tcp_lims[d][0] = (T)cfg.tcp_lims[d][0]; c.tcp_lims[d][1] = (T)cfg.tcp_lims[d][1]; }
     double wq[4], wqi[4], R[9], Ri[9];
@@ -1306,12 +1309,18 @@ template <typename T> static void launch_reset_body_t(tg_ctx* c, const uint8_t* 
 
 template <typename T, int TOPO> static void launch_step_push_t(tg_ctx* c, const float* d_actions) {
     const int n = c->cfg.num_envs;
-    hipLaunchKernelGGL((k_step_push<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+    constexpr size_t lds_bytes = (size_t)kPushLdsWords * 64 * sizeof(T);
+    static bool attr_set = false;   // one context per (process, GPU): set once per instantiation
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_push<T, TOPO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    hipLaunchKernelGGL((k_step_push<T, TOPO>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
                        (const EnvConst<T>*)c->d_const, c->st, d_actions);
 }
 template <typename T, int TOPO> static void launch_reset_push_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;
-    hipLaunchKernelGGL((k_reset_push<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+    constexpr size_t lds_bytes = (size_t)kPushLdsWords * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reset_push<T, TOPO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    hipLaunchKernelGGL((k_reset_push<T, TOPO>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
                        (const EnvConst<T>*)c->d_const, c->st, d_mask);
 }
 

@@ -33,10 +33,12 @@ constexpr int kMaxBodiesPerLink = 4;
 template <int TOPO> struct Topo;
 template <> struct Topo<0> {  // serial 6-DoF chain (UR5)
     static constexpr int N = 6;
+    static constexpr int NP = 6;   // joints that can lie on the path from the base to the tool
     __host__ __device__ static constexpr int parent(int i) { return i - 1; }
 };
 template <> struct Topo<1> {  // MG400: j1 -> {j2_1 -> j3_1 -> j4_1 -> j5, j2_2 -> j3_2 -> j4_2}
     static constexpr int N = 8;
+    static constexpr int NP = 5;   // j1, j2_1, j3_1, j4_1, j5; the j*_2 branch only carries the parallel linkage
     __host__ __device__ static constexpr int parent(int i) { return i == 0 ? -1 : (i == 5 ? 0 : i - 1); }
 };
 template <int TOPO> __host__ __device__ constexpr bool is_ancestor_or_self(int anc, int i) {
@@ -84,7 +86,12 @@ template <> __device__ __forceinline__ float tasin<float>(float x) { return asin
 template <typename T> __device__ __forceinline__ T tacos(T x);
 template <> __device__ __forceinline__ double tacos<double>(double x) { return acos(x); }
 template <> __device__ __forceinline__ float tacos<float>(float x) { return acosf(x); }
-template <typename T> __device__ __forceinline__ T tabs(T x) { return x < T(0) ? -x : x; }
+__device__ __forceinline__ double tabs(double x) { return __builtin_fabs(x); }     // source modifier |x|, no compare + select
+__device__ __forceinline__ float tabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double tmax(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64 / v_min_f64
+__device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double tmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float tmin(float a, float b) { return __builtin_fminf(a, b); }
 template <typename T> __device__ __forceinline__ T norm(V3<T> a) { return tsqrt(dot(a, a)); }
 
 template <typename T> struct M3 { T m[9]; };  // row major
@@ -194,7 +201,10 @@ template <typename T, int TOPO> __device__ __forceinline__ void link_frame(const
 //   hbias  = ID(q, qd, 0)      (gravity + velocity-product generalised forces: the gravity-compensation torque)
 //   qdamp  = generalised force of Bullet's per-body linear/angular velocity damping
 //   Minv   = inverse joint-space inertia (full symmetric storage)
-template <typename T, int TOPO>
+// BIAS = false skips hbias (left 0): inside a sim tick with the reference's gravity compensation the applied torque ID(q, qd, 0)
+// and the forward dynamics' bias force are the same vector and cancel, (hbias - d) - hbias = -d, so the whole velocity-product /
+// gravity recursion (wd, ao, link wrenches and their leaf-to-root accumulation) is dead weight there.
+template <typename T, int TOPO, bool BIAS = true>
 __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], const T (&qd)[Topo<TOPO>::N],
                                                T (&hbias)[Topo<TOPO>::N], T (&qdamp)[Topo<TOPO>::N],
                                                T (&Minv)[Topo<TOPO>::N][Topo<TOPO>::N], T& traceM, const V3<T> g, Kin<T, TOPO>& k) {
@@ -211,25 +221,31 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
         const V3<T> aq = qd[i] * k.a[i];
         if (p < 0) {
             w[i] = aq;
-            wd[i] = mk<T>(0, 0, 0);
             vo[i] = mk<T>(0, 0, 0);
-            ao[i] = mk<T>(0, 0, 0) - g;             // fictitious base acceleration = -gravity
+            if (BIAS) {
+                wd[i] = mk<T>(0, 0, 0);
+                ao[i] = mk<T>(0, 0, 0) - g;         // fictitious base acceleration = -gravity
+            }
         } else {
             const V3<T> r = k.o[i] - k.o[p];
             w[i] = w[p] + aq;
-            wd[i] = wd[p] + cross(w[p], aq);
             vo[i] = vo[p] + cross(w[p], r);
-            ao[i] = ao[p] + cross(wd[p], r) + cross(w[p], cross(w[p], r));
+            if (BIAS) {
+                wd[i] = wd[p] + cross(w[p], aq);
+                ao[i] = ao[p] + cross(wd[p], r) + cross(w[p], cross(w[p], r));
+            }
         }
         // merged link body
         const V3<T> rc = mul(k.R[i], load_v3(m.lcom[i]));
         const S3<T> Il{m.linert[i][0], m.linert[i][1], m.linert[i][2], m.linert[i][3], m.linert[i][4], m.linert[i][5]};
         const S3<T> Iw = rotate(k.R[i], Il);
-        const V3<T> ac = ao[i] + cross(wd[i], rc) + cross(w[i], cross(w[i], rc));
-        const V3<T> F = m.lmass[i] * ac;
-        const V3<T> Nc = mul(Iw, wd[i]) + cross(w[i], mul(Iw, w[i]));
-        WF[i] = F;
-        WN[i] = Nc + cross(rc, F);
+        if (BIAS) {
+            const V3<T> ac = ao[i] + cross(wd[i], rc) + cross(w[i], cross(w[i], rc));
+            const V3<T> F = m.lmass[i] * ac;
+            const V3<T> Nc = mul(Iw, wd[i]) + cross(w[i], mul(Iw, w[i]));
+            WF[i] = F;
+            WN[i] = Nc + cross(rc, F);
+        }
         mc[i] = m.lmass[i];
         hc[i] = m.lmass[i] * rc;
         Io[i] = Iw + point_inertia(m.lmass[i], rc);
@@ -256,13 +272,15 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
     // leaf -> root: accumulate subtree wrenches and composite inertias about each joint origin
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
-        hbias[i] = dot(k.a[i], WN[i]);
+        hbias[i] = BIAS ? dot(k.a[i], WN[i]) : T(0);
         qdamp[i] = dot(k.a[i], DN[i]);
         const int p = Topo<TOPO>::parent(i);
         if (p >= 0) {
             const V3<T> r = k.o[i] - k.o[p];
-            WF[p] = WF[p] + WF[i];
-            WN[p] = WN[p] + WN[i] + cross(r, WF[i]);
+            if (BIAS) {
+                WF[p] = WF[p] + WF[i];
+                WN[p] = WN[p] + WN[i] + cross(r, WF[i]);
+            }
             DF[p] = DF[p] + DF[i];
             DN[p] = DN[p] + DN[i] + cross(r, DF[i]);
             Io[p] = Io[p] + Io[i] + point_inertia(mc[i], r) + cross_inertia(hc[i], r);
@@ -330,10 +348,10 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
 //   delta = rhs_i - (J_i . dv) jacDiagABInv_i ;  sum = lambda_i + delta ; clamp sum to +-maxImpulse ;  dv += Minv[:, i] delta
 // `iters` sweeps, reverse row order on even sweeps, forward on odd.
 //
-// Bullet leaves the loop after a sweep whose largest squared delta is exactly 0.  Such a sweep leaves (lambda, dv)
-// untouched, so every later sweep recomputes delta = 0 and changes nothing either: running all `iters` sweeps gives
-// bit-identical results, and the exit test (a max-reduction on the serial path plus a divergent branch that only pays
-// once all 64 lanes have converged, which measured practically never happens before sweep 150) is dropped here.
+// Bullet leaves the loop after a sweep whose largest squared delta is <= leastSquaresResidualThreshold (0 here, A7b).  In the
+// oracle's dv-form that happens at the floating-point fixed point (sweep 50-60 in edge_follow) or never, when the iteration
+// settles into a 1-ulp limit cycle; either way the state stops moving beyond its last bit.  pgs_unclamped below detects the same
+// point in its residual form and leaves the loop (see there); pgs_clamped runs all sweeps.
 //
 // pgs_unclamped is used when no row can reach its impulse limit.  Each row update minimises the energy
 // E = 1/2 (l - l*)^T A (l - l*), A = J Minv J^T = Minv, exactly along one coordinate, so E never grows from l = 0:
@@ -353,21 +371,44 @@ __device__ __forceinline__ void pgs_sweep_unclamped(const T (&G)[N][N], T (&r)[N
         for (int j = 0; j < N; ++j) r[j] -= G[j][i] * t;
     }
 }
+// Convergence exit: in this form r_j -> 0 geometrically and dv_j = (rimp_j - r_j) Minv_jj, so once every |r_j| is below
+// 2^-56 max|rimp| (2^-27 in f32) further sweeps cannot move any dv_j by more than a fraction of its last bit.  That is Bullet's
+// own exit (leastSquaresResidual <= threshold, threshold 0 [PARITY_ASSUMPTIONS A7b]) taken where the oracle's dv-form reaches its
+// floating-point fixed point or 1-ulp limit cycle (sweep 50-60 of 150 in edge_follow).  Checked after every block of 4 sweeps, wave-uniform
+// (__all).  iters < 0 runs exactly |iters| sweeps (tg_config.pgs_full_sweeps).
 template <typename T, int N>
 __device__ __forceinline__ void pgs_unclamped(const T (&Minv)[N][N], const T (&rimp)[N], const T (&jdi)[N], int iters, T (&dv)[N]) {
     T G[N][N], r[N];
+    T thr = T(0);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         r[j] = rimp[j];
+        thr = tmax(thr, tabs(rimp[j]));
 #pragma unroll
         for (int i = 0; i < N; ++i) G[j][i] = Minv[j][i] * jdi[j];
     }
+    const bool full = iters < 0;
+    const int n_it = full ? -iters : iters;
+    thr = full ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
     int it = 0;
-    for (; it + 1 < iters; it += 2) {
+    bool converged = false;
+    for (; it + 3 < n_it; it += 4) {          // blocks of four sweeps (reverse, forward, reverse, forward), test after each block
         pgs_sweep_unclamped<T, N, false>(G, r);
         pgs_sweep_unclamped<T, N, true>(G, r);
+        pgs_sweep_unclamped<T, N, false>(G, r);
+        pgs_sweep_unclamped<T, N, true>(G, r);
+        T mx = T(0);
+#pragma unroll
+        for (int j = 0; j < N; ++j) mx = tmax(mx, tabs(r[j]));
+        if (__all(mx <= thr)) { converged = true; break; }
     }
-    if (it < iters) pgs_sweep_unclamped<T, N, false>(G, r);
+    if (!converged) {
+        for (; it + 1 < n_it; it += 2) {
+            pgs_sweep_unclamped<T, N, false>(G, r);
+            pgs_sweep_unclamped<T, N, true>(G, r);
+        }
+        if (it < n_it) pgs_sweep_unclamped<T, N, false>(G, r);
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) dv[j] = (rimp[j] - r[j]) * Minv[j][j];
 }
@@ -392,6 +433,7 @@ __device__ __forceinline__ void pgs_clamped(const T (&Minv)[N][N], const T (&rim
     T lam[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { lam[i] = T(0); dv[i] = T(0); }
+    iters = iters < 0 ? -iters : iters;
     int it = 0;
     for (; it + 1 < iters; it += 2) {
         pgs_sweep_clamped<T, N, false>(Minv, rimp, jdi, maximp, lam, dv);
@@ -409,23 +451,21 @@ enum { kMotorOff = 0, kMotorVelocity = 1, kMotorPosition = 2 };
 //   motors          projected Gauss-Seidel on the velocity-level rows  v_i -> target_i,  |impulse| <= max_force dt,
 //                   `iters` sweeps alternating reverse/forward row order, early exit on an exactly-zero sweep
 //   integration     q += dt qd
-template <typename T, int TOPO, int MOTOR>
+template <typename T, int TOPO, int MOTOR, bool GC = true>
 __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                          const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
-                                         int iters, bool gravity_comp) {
+                                         int iters) {
     constexpr int N = Topo<TOPO>::N;
     // Compiler barrier: without it the ~250 scalar robot constants are hoisted out of the caller's tick loop, overflow the
     // 100 SGPRs and get spilled into VGPR lanes (v_readlane per use).  Re-issuing the s_loads every tick is cheaper.
     asm volatile("" ::: "memory");
     T hb[N], qdm[N], Minv[N][N], traceM;
     Kin<T, TOPO> kin;
-    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv, traceM, load_v3(m.gravity), kin);
+    dynamics_terms<T, TOPO, !GC>(m, q, qd, hb, qdm, Minv, traceM, load_v3(m.gravity), kin);
     T rhs[N], v[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const T applied = (gravity_comp ? hb[i] : T(0)) - m.joint_damp * qd[i];
-        rhs[i] = (applied - hb[i]) + qdm[i];
-    }
+    for (int i = 0; i < N; ++i)   // GC: (hb - d qd) - hb + qdm with the two hb cancelled analytically
+        rhs[i] = GC ? (qdm[i] - m.joint_damp * qd[i]) : ((T(0) - m.joint_damp * qd[i]) - hb[i]) + qdm[i];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         T acc = T(0);
@@ -522,12 +562,12 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
     asm volatile("" ::: "memory");
     T hb[N], qdm[N], Minv[N][N], traceM;
     Kin<T, TOPO> kin;
-    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin);
+    dynamics_terms<T, TOPO, false>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin);
     T v[N];
     {
         T rhs[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) rhs[i] = ((hb[i] - m.joint_damp * qd[i]) - hb[i]) + qdm[i];
+        for (int i = 0; i < N; ++i) rhs[i] = qdm[i] - m.joint_damp * qd[i];   // gravity compensation cancels hbias analytically
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             T acc = T(0);
@@ -624,7 +664,20 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
 #pragma unroll
         for (int i = 0; i < NR; ++i) G[j][i] = A[j][i] * jdi;
     }
-    for (int it = 0; it < iters; ++it) {
+    // same convergence exit as pgs_unclamped: with no row at its limit r -> 0 and lambda stops moving; a clamped row keeps its r_i
+    // away from 0 and simply never triggers it
+    T thr = T(0);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) thr = tmax(thr, tabs(r[j]));
+    thr = iters < 0 ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
+    const int n_it = iters < 0 ? -iters : iters;
+    for (int it = 0; it < n_it; ++it) {
+        if ((it & 7) == 0 && it > 0) {
+            T mx = T(0);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) mx = tmax(mx, tabs(r[j]));
+            if (__all(mx <= thr)) break;
+        }
         if (it & 1) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
@@ -688,7 +741,10 @@ template <typename T> struct PushScene {
 };
 constexpr int kPushTab = 21;                       // words per table contact: ra[3], Wang[3][3], rhs[3], jdi[3], lam[3]
 constexpr int kPushTipBase = 4 * kPushTab;         // tip rows: 3 x {Jlin[3], Jang[3], Wang[3], rhs, jdi, lam}, then cfm*jdi of the normal row
-constexpr int kPushLdsWords = kPushTipBase + 3 * 12 + 1;
+constexpr int kPushJtBase = kPushTipBase + 3 * 12 + 1;   // Jt[3][NP <= 6]: arm part of the tip rows
+constexpr int kPushWaBase = kPushJtBase + 3 * 6;         // Wa[8][3] = Minv Jt^T
+constexpr int kPushLdsWords = kPushWaBase + 8 * 3;
+template <typename T> using lds_ptr = __attribute__((address_space(3))) T*;
 
 template <typename T> __device__ __forceinline__ T trsqrt(T x);
 template <> __device__ __forceinline__ double trsqrt<double>(double x) {
@@ -703,18 +759,17 @@ template <> __device__ __forceinline__ float trsqrt<float>(float x) {
     return y;
 }
 // friction limit of one contact: cone (enableConeFriction=1, base_tactile_env.py:128-130) or pyramid
-template <typename T> __device__ __forceinline__ void friction_clamp(T& s1, T& s2, T limit, int cone) {
-    if (cone) {
-        const T tot2 = s1 * s1 + s2 * s2;
-        const bool over = tot2 > limit * limit;
-        if (__any(over)) {
-            const T f = over ? (limit > T(0) ? limit * trsqrt(tot2) : T(0)) : T(1);
-            s1 *= f; s2 *= f;
-        }
-    } else {
-        s1 = s1 < -limit ? -limit : (s1 > limit ? limit : s1);
-        s2 = s2 < -limit ? -limit : (s2 > limit ? limit : s2);
-    }
+template <typename T> __device__ __forceinline__ void friction_clamp(T& s1, T& s2, T limit, bool cone) {
+    // Branch-free on purpose: any branch here splits the sweep into many scheduling regions and pins every LDS read right in front of
+    // its use.  Both limits are evaluated and selected.
+    const T tot2 = s1 * s1 + s2 * s2;
+    const bool over = tot2 > limit * limit;
+    T r = trsqrt(tmax(tot2, T(1e-30)));    // tot2 == 0 is never `over`
+    asm volatile("" : "+v"(r));             // keep it unconditional: the optimiser would otherwise branch around the rsq
+    const T f = over ? limit * r : T(1);
+    const T p1 = tmin(tmax(s1, -limit), limit), p2 = tmin(tmax(s2, -limit), limit);
+    s1 = cone ? s1 * f : p1;
+    s2 = cone ? s2 * f : p2;
 }
 // btPlaneSpace1
 template <typename T> __device__ __forceinline__ void plane_space(V3<T> n, V3<T>& t1, V3<T>& t2) {
@@ -733,18 +788,18 @@ template <typename T, int TOPO, int MOTOR>
 __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                               const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                               int iters, FreeBody<T>& b, const PushScene<T>& sc, const T* __restrict__ tip_verts, T mass,
-                                              T* __restrict__ L) {
+                                              lds_ptr<T> L) {
     constexpr int N = Topo<TOPO>::N;
     asm volatile("" ::: "memory");
     T hb[N], qdm[N], Minv[N][N], traceM;
     Kin<T, TOPO> kin;
     const V3<T> gravity = load_v3(m.gravity);
-    dynamics_terms<T, TOPO>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin);
+    dynamics_terms<T, TOPO, false>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin);
     T v[N];
     {
         T rhs[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) rhs[i] = ((hb[i] - m.joint_damp * qd[i]) - hb[i]) + qdm[i];
+        for (int i = 0; i < N; ++i) rhs[i] = qdm[i] - m.joint_damp * qd[i];   // gravity compensation cancels hbias analytically
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             T acc = T(0);
@@ -792,7 +847,7 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             if ((keep >> c) & 1) {
                 const T lx = (c & 4) ? sc.half[0] : -sc.half[0], ly = (c & 2) ? sc.half[1] : -sc.half[1], lz = (c & 1) ? sc.half[2] : -sc.half[2];
                 const V3<T> ra = (b.pos + mul(b.R, mk(lx, ly, lz))) - xc;
-                T* S = L + (slot * kPushTab) * 64;
+                lds_ptr<T> S = L + (slot * kPushTab) * 64;
                 S[0] = ra.x; S[64] = ra.y; S[128] = ra.z;
                 // rows: n = (0,0,1), t1 = (0,-1,0), t2 = (1,0,0)  (btPlaneSpace1 of +z); J = [d, ra x d]
                 const V3<T> Ja[3] = {mk(ra.y, -ra.x, T(0)), mk(ra.z, T(0), -ra.x), mk(T(0), ra.z, -ra.y)};
@@ -813,7 +868,8 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         }
     }
     // ---- cube - tip core contact: hull vertex with the smallest signed distance to the box
-    T Jt[3][N], Wa[N][3];
+    constexpr int NP = Topo<TOPO>::NP;   // joints that can carry the tip (validated on the host)
+    T Jt[3][NP], Wa[N][3];
     {
         V3<T> ol; M3<T> Rl;
         {
@@ -828,13 +884,19 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             for (int j = 0; j < 3; ++j) Mr.m[3 * i + j] = b.R.m[i] * Rl.m[j] + b.R.m[3 + i] * Rl.m[3 + j] + b.R.m[6 + i] * Rl.m[6 + j];
         const V3<T> tr = mulT(b.R, ol - b.pos);
         T best_key = T(1e30); int best_i = 0;
-        for (int i = 0; i < sc.n_tip; ++i) {
-            const V3<T> vv = mk(tip_verts[3 * i], tip_verts[3 * i + 1], tip_verts[3 * i + 2]);
+        // the hull is the same for every lane: a wave-uniform pointer turns the vertex fetch into scalar loads
+        typedef const T __attribute__((address_space(4))) * uniform_ptr;   // constant address space: s_load for uniform addresses
+        const uniform_ptr tv = (uniform_ptr)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)tip_verts >> 32)) << 32) |
+                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)tip_verts));
+        const int n_tip = __builtin_amdgcn_readfirstlane(sc.n_tip);
+#pragma unroll 4
+        for (int i = 0; i < n_tip; ++i) {
+            const V3<T> vv = mk(tv[3 * i], tv[3 * i + 1], tv[3 * i + 2]);
             const V3<T> p = tr + mul(Mr, vv);
             const T qx = tabs(p.x) - sc.half[0], qy = tabs(p.y) - sc.half[1], qz = tabs(p.z) - sc.half[2];
-            const T ox = qx > T(0) ? qx : T(0), oy = qy > T(0) ? qy : T(0), oz = qz > T(0) ? qz : T(0);
+            const T ox = tmax(qx, T(0)), oy = tmax(qy, T(0)), oz = tmax(qz, T(0));
             const T s2 = ox * ox + oy * oy + oz * oz;
-            const T mq = qx > qy ? (qx > qz ? qx : qz) : (qy > qz ? qy : qz);
+            const T mq = tmax(tmax(qx, qy), qz);
             const T key = s2 > T(0) ? s2 : mq;         // outside: squared distance (> 0); inside: largest face distance (<= 0)
             if (key < best_key) { best_key = key; best_i = i; }
         }
@@ -865,9 +927,9 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         plane_space(nrm, t1, t2);
         const V3<T> dirs[3] = {nrm, t1, t2};
         const V3<T> rb = pb - xc;
-        V3<T> jt[N];
+        V3<T> jt[NP];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
+        for (int i = 0; i < NP; ++i) {
             bool on_path = false;
 #pragma unroll
             for (int l = 0; l < N; ++l)
@@ -877,31 +939,35 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         }
         const T denom = dt * sc.tip_stiffness + sc.tip_damping;   // soft contact: cfm = 1 / (dt (dt k + d)), erp = dt k / (dt k + d)
         const T cfm = (T(1) / denom) / dt, erp_c = dt * sc.tip_stiffness / denom;
-        T* S = L + kPushTipBase * 64;
+        lds_ptr<T> S = L + kPushTipBase * 64;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const V3<T> d = dirs[r];
 #pragma unroll
-            for (int i = 0; i < N; ++i) Jt[r][i] = dot(jt[i], d);
+            for (int i = 0; i < NP; ++i) Jt[r][i] = dot(jt[i], d);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 T acc = T(0);
 #pragma unroll
-                for (int j = 0; j < N; ++j) acc += Minv[i][j] * Jt[r][j];
+                for (int j = 0; j < NP; ++j) acc += Minv[i][j] * Jt[r][j];
                 Wa[i][r] = acc;
             }
             const V3<T> Jl = mk<T>(0, 0, 0) - d, Ja = mk<T>(0, 0, 0) - cross(rb, d);
             const V3<T> Wg = mul(Iwi, Ja);
             T A = invm + dot(Ja, Wg), rv = dot(Jl, vb) + dot(Ja, wb);
 #pragma unroll
-            for (int i = 0; i < N; ++i) { A += Jt[r][i] * Wa[i][r]; rv += Jt[r][i] * v[i]; }
+            for (int i = 0; i < NP; ++i) { A += Jt[r][i] * Wa[i][r]; rv += Jt[r][i] * v[i]; }
             T rhs = -rv, jdi = T(1) / A;
             if (r == 0) {
                 rhs = (depth > T(0)) ? (-rv - depth / dt) : (-depth * erp_c / dt - rv);
                 jdi = T(1) / (A + cfm);
                 S[36 * 64] = active ? cfm * jdi : T(0);
             }
-            T* Sr = S + (12 * r) * 64;
+            lds_ptr<T> Sr = S + (12 * r) * 64;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) L[(kPushJtBase + r * 6 + i) * 64] = Jt[r][i];
+#pragma unroll
+            for (int i = 0; i < N; ++i) L[(kPushWaBase + i * 3 + r) * 64] = Wa[i][r];
             Sr[0] = Jl.x; Sr[64] = Jl.y; Sr[128] = Jl.z;
             Sr[3 * 64] = Ja.x; Sr[4 * 64] = Ja.y; Sr[5 * 64] = Ja.z;
             Sr[6 * 64] = Wg.x; Sr[7 * 64] = Wg.y; Sr[8 * 64] = Wg.z;
@@ -910,8 +976,9 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             Sr[11 * 64] = T(0);
         }
     }
-    // ---- motor rows
-    T rm[N], jm[N], lm[N], dv[N];
+    // ---- motor rows; Minv keeps only its upper triangle from here on (Ms[tri(i, j)], i <= j)
+    constexpr int NT = N * (N + 1) / 2;
+    T Ms[NT], rm[N], jm[N], lm[N], dv[N];
     const T maximp = max_force * dt;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -920,41 +987,51 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         rm[i] = des - v[i];
         jm[i] = T(1) / Minv[i][i];
         lm[i] = T(0); dv[i] = T(0);
+#pragma unroll
+        for (int j = i; j < N; ++j) Ms[i * N - i * (i - 1) / 2 + (j - i)] = Minv[i][j];
     }
+#define TG_MS(i, j) Ms[((i) <= (j)) ? ((i) * N - (i) * ((i) - 1) / 2 + ((j) - (i))) : ((j) * N - (j) * ((j) - 1) / 2 + ((i) - (j)))]
     V3<T> dvl = mk<T>(0, 0, 0), dva = mk<T>(0, 0, 0);
-    T* S = L + kPushTipBase * 64;
-    for (int it = 0; it < iters; ++it) {
+    // The contact rows stay in LDS: promoted to registers they would live in AGPRs (two v_accvgpr_read per use) with scratch spills on
+    // top.  The per-sweep compiler barrier below forces the re-read; inside a sweep the scheduler is free to cluster the ds_reads.
+    const T mu_table = sc.mu_table, mu_tip = sc.mu_tip;
+    const bool cone = sc.cone_friction != 0;
+    lds_ptr<T> S = L + kPushTipBase * 64;
+    lds_ptr<T> LJ = L + kPushJtBase * 64;
+    lds_ptr<T> LW = L + kPushWaBase * 64;
+    const int n_it = iters < 0 ? -iters : iters;   // contact problems do not reach their fixed point within 150 sweeps: no exit test
+    for (int it = 0; it < n_it; ++it) {
+        asm volatile("" ::: "memory");
         // joint motors
         if (it & 1) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                const T t = (rm[i] - dv[i]) * jm[i], sum = lm[i] + t;
-                const T lo = sum < -maximp ? -maximp : sum, scl = lo > maximp ? maximp : lo;
-                const T delta = (scl == sum) ? t : scl - lm[i];
+                const T sum = lm[i] + (rm[i] - dv[i]) * jm[i];
+                const T scl = tmin(tmax(sum, -maximp), maximp);
+                const T delta = scl - lm[i];
                 lm[i] = scl;
 #pragma unroll
-                for (int j = 0; j < N; ++j) dv[j] += Minv[j][i] * delta;
+                for (int j = 0; j < N; ++j) dv[j] += TG_MS(j, i) * delta;
             }
         } else {
 #pragma unroll
             for (int i = N - 1; i >= 0; --i) {
-                const T t = (rm[i] - dv[i]) * jm[i], sum = lm[i] + t;
-                const T lo = sum < -maximp ? -maximp : sum, scl = lo > maximp ? maximp : lo;
-                const T delta = (scl == sum) ? t : scl - lm[i];
+                const T sum = lm[i] + (rm[i] - dv[i]) * jm[i];
+                const T scl = tmin(tmax(sum, -maximp), maximp);
+                const T delta = scl - lm[i];
                 lm[i] = scl;
 #pragma unroll
-                for (int j = 0; j < N; ++j) dv[j] += Minv[j][i] * delta;
+                for (int j = 0; j < N; ++j) dv[j] += TG_MS(j, i) * delta;
             }
         }
         // contact normals: table slots, then the tip
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            T* C = L + (c * kPushTab) * 64;
+            lds_ptr<T> C = L + (c * kPushTab) * 64;
             const T rax = C[0], ray = C[64];
             const T jdv = dvl.z + (ray * dva.x - rax * dva.y);
             const T lam = C[18 * 64];
-            const T t = (C[12 * 64] - jdv) * C[15 * 64], sum = lam + t;
-            const T nl = sum < T(0) ? T(0) : sum;
+            const T nl = tmax(lam + (C[12 * 64] - jdv) * C[15 * 64], T(0));
             const T delta = nl - lam;
             C[18 * 64] = nl;
             dvl.z += invm * delta;
@@ -963,50 +1040,50 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         {
             T jdv = S[0] * dvl.x + S[64] * dvl.y + S[128] * dvl.z + S[3 * 64] * dva.x + S[4 * 64] * dva.y + S[5 * 64] * dva.z;
 #pragma unroll
-            for (int i = 0; i < N; ++i) jdv += Jt[0][i] * dv[i];
-            const T lam = S[11 * 64], jdi = S[10 * 64];
-            const T t = (S[9 * 64] - jdv) * jdi - lam * S[36 * 64], sum = lam + t;
-            const T nl = sum < T(0) ? T(0) : sum;
+            for (int i = 0; i < NP; ++i) jdv += LJ[i * 64] * dv[i];
+            const T lam = S[11 * 64];
+            const T nl = tmax(lam + ((S[9 * 64] - jdv) * S[10 * 64] - lam * S[36 * 64]), T(0));
             const T delta = nl - lam;
             S[11 * 64] = nl;
 #pragma unroll
-            for (int i = 0; i < N; ++i) dv[i] += Wa[i][0] * delta;
+            for (int i = 0; i < N; ++i) dv[i] += LW[(i * 3) * 64] * delta;
             dvl = dvl + (invm * delta) * mk(S[0], S[64], S[128]);
             dva = dva + delta * mk(S[6 * 64], S[7 * 64], S[8 * 64]);
         }
         // friction: table slots, then the tip
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            T* C = L + (c * kPushTab) * 64;
+            lds_ptr<T> C = L + (c * kPushTab) * 64;
             const T rax = C[0], ray = C[64], raz = C[128];
-            const T limit = sc.mu_table * C[18 * 64];
+            const T limit = mu_table * C[18 * 64];
             const T jdv1 = -dvl.y + (raz * dva.x - rax * dva.z), jdv2 = dvl.x + (raz * dva.y - ray * dva.z);
             const T l1 = C[19 * 64], l2 = C[20 * 64];
             T s1 = l1 + (C[13 * 64] - jdv1) * C[16 * 64], s2 = l2 + (C[14 * 64] - jdv2) * C[17 * 64];
-            friction_clamp(s1, s2, limit, sc.cone_friction);
+            friction_clamp(s1, s2, limit, cone);
             const T d1 = s1 - l1, d2 = s2 - l2;
             C[19 * 64] = s1; C[20 * 64] = s2;
             dvl.y -= invm * d1; dvl.x += invm * d2;
             dva = dva + d1 * mk(C[6 * 64], C[7 * 64], C[8 * 64]) + d2 * mk(C[9 * 64], C[10 * 64], C[11 * 64]);
         }
         {
-            T* S1 = S + 12 * 64; T* S2 = S + 24 * 64;
-            const T limit = sc.mu_tip * S[11 * 64];
+            lds_ptr<T> S1 = S + 12 * 64; lds_ptr<T> S2 = S + 24 * 64;
+            const T limit = mu_tip * S[11 * 64];
             T jdv1 = S1[0] * dvl.x + S1[64] * dvl.y + S1[128] * dvl.z + S1[3 * 64] * dva.x + S1[4 * 64] * dva.y + S1[5 * 64] * dva.z;
             T jdv2 = S2[0] * dvl.x + S2[64] * dvl.y + S2[128] * dvl.z + S2[3 * 64] * dva.x + S2[4 * 64] * dva.y + S2[5 * 64] * dva.z;
 #pragma unroll
-            for (int i = 0; i < N; ++i) { jdv1 += Jt[1][i] * dv[i]; jdv2 += Jt[2][i] * dv[i]; }
+            for (int i = 0; i < NP; ++i) { jdv1 += LJ[(6 + i) * 64] * dv[i]; jdv2 += LJ[(12 + i) * 64] * dv[i]; }
             const T l1 = S1[11 * 64], l2 = S2[11 * 64];
             T s1 = l1 + (S1[9 * 64] - jdv1) * S1[10 * 64], s2 = l2 + (S2[9 * 64] - jdv2) * S2[10 * 64];
-            friction_clamp(s1, s2, limit, sc.cone_friction);
+            friction_clamp(s1, s2, limit, cone);
             const T d1 = s1 - l1, d2 = s2 - l2;
             S1[11 * 64] = s1; S2[11 * 64] = s2;
 #pragma unroll
-            for (int i = 0; i < N; ++i) dv[i] += Wa[i][1] * d1 + Wa[i][2] * d2;
+            for (int i = 0; i < N; ++i) dv[i] += LW[(i * 3 + 1) * 64] * d1 + LW[(i * 3 + 2) * 64] * d2;
             dvl = dvl + (invm * d1) * mk(S1[0], S1[64], S1[128]) + (invm * d2) * mk(S2[0], S2[64], S2[128]);
             dva = dva + d1 * mk(S1[6 * 64], S1[7 * 64], S1[8 * 64]) + d2 * mk(S2[6 * 64], S2[7 * 64], S2[8 * 64]);
         }
     }
+#undef TG_MS
     // ---- integrate
 #pragma unroll
     for (int i = 0; i < N; ++i) {

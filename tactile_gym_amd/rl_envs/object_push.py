@@ -125,8 +125,9 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class ObjectPushVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False):
         cfg, robot, sensor, mesh, modes, tip_verts = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
+        cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
         self._tip_verts = tip_verts   # tg_create copies them; kept only until then
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action

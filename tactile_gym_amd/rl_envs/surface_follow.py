@@ -86,8 +86,9 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class SurfaceFollowAutoVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=200, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False):
         cfg, robot, sensor, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
+        cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"xyz": 1, "xyzRxRy": 3}[modes["movement_mode"]]                              # surface_follow_auto_env.py:96-107

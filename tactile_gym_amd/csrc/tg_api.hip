@@ -288,8 +288,10 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    JointTrig<T, N> trig;
+    trig_init<T, N>(q, trig);
     for (int t = 0; t < c.action_repeat; ++t)
-        sim_tick<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters);
+        sim_tick<T, TOPO, kMotorVelocity, true, true>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, &trig);
 
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }

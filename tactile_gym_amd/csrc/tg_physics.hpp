@@ -92,6 +92,31 @@ __device__ __forceinline__ double tmax(double a, double b) { return __builtin_fm
 __device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double tmin(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ float tmin(float a, float b) { return __builtin_fminf(a, b); }
+// Hardware seeds + Newton steps instead of the library's range-scaled, special-cased sqrt / division (about 8 instructions instead
+// of 20-25); operands here are well-scaled physical quantities.  Results agree with the IEEE ones to 1-2 ulp.
+__device__ __forceinline__ double trsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - (0.5 * x) * y * y);
+    y = y * (1.5 - (0.5 * x) * y * y);
+    return y;
+}
+__device__ __forceinline__ float trsqrt(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    y = y * (1.5f - (0.5f * x) * y * y);
+    return y;
+}
+__device__ __forceinline__ double trcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+__device__ __forceinline__ float trcp(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    y = y * (2.0f - x * y);
+    return y;
+}
+template <typename T> __device__ __forceinline__ T tsqrt_fast(T x) { return x * trsqrt(tmax(x, T(1e-30))); }   // sqrt(0) = 0
 template <typename T> __device__ __forceinline__ T norm(V3<T> a) { return tsqrt(dot(a, a)); }
 
 template <typename T> struct M3 { T m[9]; };  // row major
@@ -161,14 +186,41 @@ template <typename T, int TOPO> struct Kin {
     V3<T> o[N], a[N];
 };
 
-template <typename T, int TOPO> __device__ __forceinline__ void forward_kinematics(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], Kin<T, TOPO>& k) {
+// sin / cos of the joint angles, carried across the ticks of one env step: after q += dq the pair is advanced by the angle-addition
+// formulas with a degree-7/6 Taylor pair for (sin dq, cos dq) (|dq| <= 0.02: truncation < 1e-20), ~12 instructions per joint instead
+// of a full double-precision sincos (~90).  Re-anchored with the exact sincos at every env step (24 ticks: drift < 1e-15).
+template <typename T, int N> struct JointTrig { T s[N], c[N]; };
+template <typename T, int N> __device__ __forceinline__ void trig_init(const T (&q)[N], JointTrig<T, N>& t) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) tsincos(q[i], &t.s[i], &t.c[i]);
+}
+template <typename T, int N> __device__ __forceinline__ void trig_advance(const T (&q)[N], const T (&dq)[N], JointTrig<T, N>& t) {
+    T big = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) big = tmax(big, tabs(dq[i]));
+    if (__any(big > T(0.02))) { trig_init<T, N>(q, t); return; }   // never in the reference's velocity range; exact fallback
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const T d = dq[i], d2 = d * d;
+        const T cd = T(1) + d2 * (T(-0.5) + d2 * (T(1.0 / 24.0) + d2 * T(-1.0 / 720.0)));
+        const T sd = d * (T(1) + d2 * (T(-1.0 / 6.0) + d2 * (T(1.0 / 120.0) + d2 * T(-1.0 / 5040.0))));
+        const T s0 = t.s[i], c0 = t.c[i];
+        t.s[i] = s0 * cd + c0 * sd;
+        t.c[i] = c0 * cd - s0 * sd;
+    }
+}
+
+template <typename T, int TOPO, bool TRIG = false>
+__device__ __forceinline__ void forward_kinematics(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], Kin<T, TOPO>& k,
+                                                   const JointTrig<T, Topo<TOPO>::N>* trig = nullptr) {
     constexpr int N = Topo<TOPO>::N;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int p = Topo<TOPO>::parent(i);
         const V3<T> ax = load_v3(m.jaxis[i]);
         T sq, cq;
-        tsincos(q[i], &sq, &cq);
+        if (TRIG) { sq = trig->s[i]; cq = trig->c[i]; }
+        else tsincos(q[i], &sq, &cq);
         M3<T> Rl;   // Rj * Rot(axis, q)
 #pragma unroll
         for (int e = 0; e < 9; ++e) Rl.m[e] = m.fkA[i][e] + cq * m.fkB[i][e] + sq * m.fkC[i][e];
@@ -204,12 +256,13 @@ template <typename T, int TOPO> __device__ __forceinline__ void link_frame(const
 // BIAS = false skips hbias (left 0): inside a sim tick with the reference's gravity compensation the applied torque ID(q, qd, 0)
 // and the forward dynamics' bias force are the same vector and cancel, (hbias - d) - hbias = -d, so the whole velocity-product /
 // gravity recursion (wd, ao, link wrenches and their leaf-to-root accumulation) is dead weight there.
-template <typename T, int TOPO, bool BIAS = true>
+template <typename T, int TOPO, bool BIAS = true, bool TRIG = false>
 __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], const T (&qd)[Topo<TOPO>::N],
                                                T (&hbias)[Topo<TOPO>::N], T (&qdamp)[Topo<TOPO>::N],
-                                               T (&Minv)[Topo<TOPO>::N][Topo<TOPO>::N], T& traceM, const V3<T> g, Kin<T, TOPO>& k) {
+                                               T (&Minv)[Topo<TOPO>::N][Topo<TOPO>::N], T& traceM, const V3<T> g, Kin<T, TOPO>& k,
+                                               const JointTrig<T, Topo<TOPO>::N>* trig = nullptr) {
     constexpr int N = Topo<TOPO>::N;
-    forward_kinematics<T, TOPO>(m, q, k);
+    forward_kinematics<T, TOPO, TRIG>(m, q, k, trig);
     V3<T> w[N], wd[N], vo[N], ao[N];
     V3<T> WF[N], WN[N], DF[N], DN[N], hc[N];     // bias wrench, damping wrench (about o_i), composite first moment
     S3<T> Io[N];
@@ -251,7 +304,7 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
         Io[i] = Iw + point_inertia(m.lmass[i], rc);
         // per-body velocity damping  F = -m v (K + K|v|),  N = -(I w)(K + K|w|).  |w| is common to the bodies welded to a
         // link, so their angular parts are merged exactly through lang = sum_b R_b I_b R_b^T; |v| differs per body.
-        const T sw = m.ang_damp + m.ang_damp * norm(w[i]);
+        const T sw = m.ang_damp + m.ang_damp * tsqrt_fast(dot(w[i], w[i]));
         const S3<T> Ia{m.lang[i][0], m.lang[i][1], m.lang[i][2], m.lang[i][3], m.lang[i][4], m.lang[i][5]};
         V3<T> dF = mk<T>(0, 0, 0);
         V3<T> dN = (-sw) * mul(k.R[i], mul(Ia, mulT(k.R[i], w[i])));
@@ -260,7 +313,7 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
             if (m.bmass[i][b] > T(0)) {  // wave-uniform
                 const V3<T> rb = mul(k.R[i], load_v3(m.bcom[i][b]));
                 const V3<T> vb = vo[i] + cross(w[i], rb);
-                const T sv = m.lin_damp + m.lin_damp * norm(vb);
+                const T sv = m.lin_damp + m.lin_damp * tsqrt_fast(dot(vb, vb));
                 const V3<T> Fb = (-m.bmass[i][b] * sv) * vb;
                 dF = dF + Fb;
                 dN = dN + cross(rb, Fb);
@@ -308,9 +361,8 @@ __device__ __forceinline__ void dynamics_terms(const DevRobot<T>& m, const T (&q
         T d = L[j][j];
 #pragma unroll
         for (int c = 0; c < j; ++c) d -= L[j][c] * L[j][c];
-        d = tsqrt(d);
-        L[j][j] = d;
-        const T inv = T(1) / d;
+        const T inv = trsqrt(d);
+        L[j][j] = d * inv;
         Li[j][j] = inv;
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
@@ -451,17 +503,17 @@ enum { kMotorOff = 0, kMotorVelocity = 1, kMotorPosition = 2 };
 //   motors          projected Gauss-Seidel on the velocity-level rows  v_i -> target_i,  |impulse| <= max_force dt,
 //                   `iters` sweeps alternating reverse/forward row order, early exit on an exactly-zero sweep
 //   integration     q += dt qd
-template <typename T, int TOPO, int MOTOR, bool GC = true>
+template <typename T, int TOPO, int MOTOR, bool GC = true, bool TRIG = false>
 __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                          const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
-                                         int iters) {
+                                         int iters, JointTrig<T, Topo<TOPO>::N>* trig = nullptr) {
     constexpr int N = Topo<TOPO>::N;
     // Compiler barrier: without it the ~250 scalar robot constants are hoisted out of the caller's tick loop, overflow the
     // 100 SGPRs and get spilled into VGPR lanes (v_readlane per use).  Re-issuing the s_loads every tick is cheaper.
     asm volatile("" ::: "memory");
     T hb[N], qdm[N], Minv[N][N], traceM;
     Kin<T, TOPO> kin;
-    dynamics_terms<T, TOPO, !GC>(m, q, qd, hb, qdm, Minv, traceM, load_v3(m.gravity), kin);
+    dynamics_terms<T, TOPO, !GC, TRIG>(m, q, qd, hb, qdm, Minv, traceM, load_v3(m.gravity), kin, trig);
     T rhs[N], v[N];
 #pragma unroll
     for (int i = 0; i < N; ++i)   // GC: (hb - d qd) - hb + qdm with the two hb cancelled analytically
@@ -481,7 +533,7 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
         for (int i = 0; i < N; ++i) {
             const T pos_term = (MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0);
             const T des = pos_term + v[i] + kd * (qd_des[i] - v[i]);
-            jdi[i] = T(1) / Minv[i][i];
+            jdi[i] = trcp(Minv[i][i]);
             rimp[i] = (des - v[i]) * jdi[i];
             dv2 += (des - v[i]) * (des - v[i]);
         }
@@ -491,11 +543,14 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] += dv[i];
     }
+    T dq[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         qd[i] = v[i];
-        q[i] += dt * v[i];
+        dq[i] = dt * v[i];
+        q[i] += dq[i];
     }
+    if (TRIG) trig_advance<T, N>(q, dq, *trig);
 }
 
 // ------------------------------------------------------------------------------------------------ arm + free body + P2P
@@ -746,18 +801,6 @@ constexpr int kPushWaBase = kPushJtBase + 3 * 6;         // Wa[8][3] = Minv Jt^T
 constexpr int kPushLdsWords = kPushWaBase + 8 * 3;
 template <typename T> using lds_ptr = __attribute__((address_space(3))) T*;
 
-template <typename T> __device__ __forceinline__ T trsqrt(T x);
-template <> __device__ __forceinline__ double trsqrt<double>(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - (0.5 * x) * y * y);
-    y = y * (1.5 - (0.5 * x) * y * y);
-    return y;
-}
-template <> __device__ __forceinline__ float trsqrt<float>(float x) {
-    float y = __builtin_amdgcn_rsqf(x);
-    y = y * (1.5f - (0.5f * x) * y * y);
-    return y;
-}
 // friction limit of one contact: cone (enableConeFriction=1, base_tactile_env.py:128-130) or pyramid
 template <typename T> __device__ __forceinline__ void friction_clamp(T& s1, T& s2, T limit, bool cone) {
     // Branch-free on purpose: any branch here splits the sweep into many scheduling regions and pins every LDS read right in front of

@@ -178,13 +178,14 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                     const float e0 = (r.x1 - fx) * a0 - (r.x2 - fx) * a1;
                     const float e1 = (r.x2 - fx) * a2 - (r.x0 - fx) * a0;
                     const float e2 = (r.x0 - fx) * a1 - (r.x1 - fx) * a2;
-                    const bool in = (fx >= r.xmin && fx <= r.xmax) &&
-                                    ((e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) || (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f));
+                    // bitwise, not short-circuit, and the depth evaluated unconditionally (discarded, possibly inf/NaN, when the
+                    // pixel is not covered): one straight line of VALU work instead of a scalar branch per clause
+                    const bool box = (fx >= r.xmin) & (fx <= r.xmax);
+                    const bool pos = (e0 >= 0.0f) & (e1 >= 0.0f) & (e2 >= 0.0f), neg = (e0 <= 0.0f) & (e1 <= 0.0f) & (e2 <= 0.0f);
                     const float s = (e0 + e1) + e2;
-                    if (in && s != 0.0f) {
-                        const float d = ((e0 * r.d0 + e1 * r.d1) + e2 * r.d2) / s;
-                        if (d < z[k][p]) z[k][p] = d;
-                    }
+                    const float d = ((e0 * r.d0 + e1 * r.d1) + e2 * r.d2) / s;
+                    const bool hit = box & (pos | neg) & (s != 0.0f) & (d < z[k][p]);
+                    z[k][p] = hit ? d : z[k][p];
                 }
             }
         }

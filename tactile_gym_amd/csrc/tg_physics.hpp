@@ -794,11 +794,8 @@ template <typename T> struct PushScene {
     T com[3], inertia0[6], mass0;
     int tip_link, n_tip, cone_friction;
 };
-constexpr int kPushTab = 21;                       // words per table contact: ra[3], Wang[3][3], rhs[3], jdi[3], lam[3]
-constexpr int kPushTipBase = 4 * kPushTab;         // tip rows: 3 x {Jlin[3], Jang[3], Wang[3], rhs, jdi, lam}, then cfm*jdi of the normal row
-constexpr int kPushJtBase = kPushTipBase + 3 * 12 + 1;   // Jt[3][NP <= 6]: arm part of the tip rows
-constexpr int kPushWaBase = kPushJtBase + 3 * 6;         // Wa[8][3] = Minv Jt^T
-constexpr int kPushLdsWords = kPushWaBase + 8 * 3;
+constexpr int kPushTab = 9;                        // staging words per table contact slot: ra[3], rhs[3], 1/A[3]
+constexpr int kPushLdsWords = 4 * kPushTab;
 template <typename T> using lds_ptr = __attribute__((address_space(3))) T*;
 
 // friction limit of one contact: cone (enableConeFriction=1, base_tactile_env.py:128-130) or pyramid
@@ -865,9 +862,10 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         vb = b.v + dt * (gravity - sv * b.v);
         wb = b.w + dt * mul(Iwi, Nt);
     }
-    // ---- cube - table contacts
+    // ---- cube - table contacts.  LDS is only the staging area that turns the per-lane contact count into fixed slots: each kept
+    // vertex writes (ra, rhs[3], 1/A[3]) to the next slot of its lane's column, then the four slots are read back into registers.
 #pragma unroll
-    for (int k = 0; k < kPushTipBase; ++k) L[k * 64] = T(0);
+    for (int k = 0; k < 4 * kPushTab; ++k) L[k * 64] = T(0);
     {
         T vz[8];
         int keep = 0, cnt = 0;
@@ -897,22 +895,32 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
                 const T lin[3] = {vb.z, -vb.y, vb.x};
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const V3<T> Wa_ = mul(Iwi, Ja[r]);
-                    S[(3 + 3 * r) * 64] = Wa_.x; S[(4 + 3 * r) * 64] = Wa_.y; S[(5 + 3 * r) * 64] = Wa_.z;
-                    const T A = invm + dot(Ja[r], Wa_);
+                    const T A = invm + dot(Ja[r], mul(Iwi, Ja[r]));
                     const T rv = lin[r] + dot(Ja[r], wb);
                     T rhs = -rv;
                     if (r == 0) rhs = (vz[c] > T(0)) ? (-rv - vz[c] / dt) : (-vz[c] * sc.erp / dt - rv);
-                    S[(12 + r) * 64] = rhs;
-                    S[(15 + r) * 64] = T(1) / A;
+                    S[(3 + r) * 64] = rhs;
+                    S[(6 + r) * 64] = T(1) / A;
                 }
                 ++slot;
             }
         }
     }
+    T tra[4][3], trhs[4][3], tjdi[4][3], tlam[4][3];   // table contact slots (empty slots: all zero -> their rows never move)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            tra[c][k] = L[(c * kPushTab + k) * 64];
+            trhs[c][k] = L[(c * kPushTab + 3 + k) * 64];
+            tjdi[c][k] = L[(c * kPushTab + 6 + k) * 64];
+            tlam[c][k] = T(0);
+        }
     // ---- cube - tip core contact: hull vertex with the smallest signed distance to the box
     constexpr int NP = Topo<TOPO>::NP;   // joints that can carry the tip (validated on the host)
     T Jt[3][NP], Wa[N][3];
+    V3<T> pd[3], prb;                   // tip rows, cube part: row directions (n, t1, t2) and the contact arm; J = [-d, -(rb x d)]
+    T prhs[3], pjdi[3], plam[3], pcfm;
     {
         V3<T> ol; M3<T> Rl;
         {
@@ -982,7 +990,6 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         }
         const T denom = dt * sc.tip_stiffness + sc.tip_damping;   // soft contact: cfm = 1 / (dt (dt k + d)), erp = dt k / (dt k + d)
         const T cfm = (T(1) / denom) / dt, erp_c = dt * sc.tip_stiffness / denom;
-        lds_ptr<T> S = L + kPushTipBase * 64;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const V3<T> d = dirs[r];
@@ -1004,19 +1011,12 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             if (r == 0) {
                 rhs = (depth > T(0)) ? (-rv - depth / dt) : (-depth * erp_c / dt - rv);
                 jdi = T(1) / (A + cfm);
-                S[36 * 64] = active ? cfm * jdi : T(0);
+                pcfm = active ? cfm * jdi : T(0);
             }
-            lds_ptr<T> Sr = S + (12 * r) * 64;
-#pragma unroll
-            for (int i = 0; i < NP; ++i) L[(kPushJtBase + r * 6 + i) * 64] = Jt[r][i];
-#pragma unroll
-            for (int i = 0; i < N; ++i) L[(kPushWaBase + i * 3 + r) * 64] = Wa[i][r];
-            Sr[0] = Jl.x; Sr[64] = Jl.y; Sr[128] = Jl.z;
-            Sr[3 * 64] = Ja.x; Sr[4 * 64] = Ja.y; Sr[5 * 64] = Ja.z;
-            Sr[6 * 64] = Wg.x; Sr[7 * 64] = Wg.y; Sr[8 * 64] = Wg.z;
-            Sr[9 * 64] = active ? rhs : T(0);
-            Sr[10 * 64] = active ? jdi : T(0);
-            Sr[11 * 64] = T(0);
+            pd[r] = d; prb = rb;
+            prhs[r] = active ? rhs : T(0);
+            pjdi[r] = active ? jdi : T(0);
+            plam[r] = T(0);
         }
     }
     // ---- motor rows; Minv keeps only its upper triangle from here on (Ms[tri(i, j)], i <= j)
@@ -1035,16 +1035,14 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
     }
 #define TG_MS(i, j) Ms[((i) <= (j)) ? ((i) * N - (i) * ((i) - 1) / 2 + ((j) - (i))) : ((j) * N - (j) * ((j) - 1) / 2 + ((i) - (j)))]
     V3<T> dvl = mk<T>(0, 0, 0), dva = mk<T>(0, 0, 0);
-    // The contact rows stay in LDS: promoted to registers they would live in AGPRs (two v_accvgpr_read per use) with scratch spills on
-    // top.  The per-sweep compiler barrier below forces the re-read; inside a sweep the scheduler is free to cluster the ds_reads.
+    // All solver data is register resident (what does not fit the 256 architectural VGPRs is parked in AGPRs by the compiler: two
+    // v_accvgpr_read per use, no memory latency).  The angular response of a table row is recomputed from Iw^-1 and ra instead of
+    // being stored: six FMAs are cheaper than six AGPR reads and bring the footprint under 512 registers, i.e. no scratch.
     const T mu_table = sc.mu_table, mu_tip = sc.mu_tip;
     const bool cone = sc.cone_friction != 0;
-    lds_ptr<T> S = L + kPushTipBase * 64;
-    lds_ptr<T> LJ = L + kPushJtBase * 64;
-    lds_ptr<T> LW = L + kPushWaBase * 64;
+    const V3<T> iw0 = mk(Iwi.xx, Iwi.xy, Iwi.xz), iw1 = mk(Iwi.xy, Iwi.yy, Iwi.yz), iw2 = mk(Iwi.xz, Iwi.yz, Iwi.zz);   // columns
     const int n_it = iters < 0 ? -iters : iters;   // contact problems do not reach their fixed point within 150 sweeps: no exit test
     for (int it = 0; it < n_it; ++it) {
-        asm volatile("" ::: "memory");
         // joint motors
         if (it & 1) {
 #pragma unroll
@@ -1070,60 +1068,55 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         // contact normals: table slots, then the tip
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            lds_ptr<T> C = L + (c * kPushTab) * 64;
-            const T rax = C[0], ray = C[64];
+            const T rax = tra[c][0], ray = tra[c][1];
             const T jdv = dvl.z + (ray * dva.x - rax * dva.y);
-            const T lam = C[18 * 64];
-            const T nl = tmax(lam + (C[12 * 64] - jdv) * C[15 * 64], T(0));
-            const T delta = nl - lam;
-            C[18 * 64] = nl;
+            const T nl = tmax(tlam[c][0] + (trhs[c][0] - jdv) * tjdi[c][0], T(0));
+            const T delta = nl - tlam[c][0];
+            tlam[c][0] = nl;
             dvl.z += invm * delta;
-            dva = dva + delta * mk(C[3 * 64], C[4 * 64], C[5 * 64]);
+            dva = dva + delta * (ray * iw0 - rax * iw1);                 // Iw^-1 (ra x n),  ra x n = (ra.y, -ra.x, 0)
         }
-        {
-            T jdv = S[0] * dvl.x + S[64] * dvl.y + S[128] * dvl.z + S[3 * 64] * dva.x + S[4 * 64] * dva.y + S[5 * 64] * dva.z;
+        {   // the angular parts are rebuilt from (rb, d) each time: as many instructions as fetching them from AGPRs, 15 values fewer live
+            const V3<T> ja = cross(pd[0], prb);                          // -(rb x n)
+            T jdv = dot(ja, dva) - dot(pd[0], dvl);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) jdv += LJ[i * 64] * dv[i];
-            const T lam = S[11 * 64];
-            const T nl = tmax(lam + ((S[9 * 64] - jdv) * S[10 * 64] - lam * S[36 * 64]), T(0));
-            const T delta = nl - lam;
-            S[11 * 64] = nl;
+            for (int i = 0; i < NP; ++i) jdv += Jt[0][i] * dv[i];
+            const T nl = tmax(plam[0] + ((prhs[0] - jdv) * pjdi[0] - plam[0] * pcfm), T(0));
+            const T delta = nl - plam[0];
+            plam[0] = nl;
 #pragma unroll
-            for (int i = 0; i < N; ++i) dv[i] += LW[(i * 3) * 64] * delta;
-            dvl = dvl + (invm * delta) * mk(S[0], S[64], S[128]);
-            dva = dva + delta * mk(S[6 * 64], S[7 * 64], S[8 * 64]);
+            for (int i = 0; i < N; ++i) dv[i] += Wa[i][0] * delta;
+            dvl = dvl - (invm * delta) * pd[0];
+            dva = dva + delta * mul(Iwi, ja);
         }
         // friction: table slots, then the tip
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            lds_ptr<T> C = L + (c * kPushTab) * 64;
-            const T rax = C[0], ray = C[64], raz = C[128];
-            const T limit = mu_table * C[18 * 64];
+            const T rax = tra[c][0], ray = tra[c][1], raz = tra[c][2];
+            const T limit = mu_table * tlam[c][0];
             const T jdv1 = -dvl.y + (raz * dva.x - rax * dva.z), jdv2 = dvl.x + (raz * dva.y - ray * dva.z);
-            const T l1 = C[19 * 64], l2 = C[20 * 64];
-            T s1 = l1 + (C[13 * 64] - jdv1) * C[16 * 64], s2 = l2 + (C[14 * 64] - jdv2) * C[17 * 64];
+            T s1 = tlam[c][1] + (trhs[c][1] - jdv1) * tjdi[c][1], s2 = tlam[c][2] + (trhs[c][2] - jdv2) * tjdi[c][2];
             friction_clamp(s1, s2, limit, cone);
-            const T d1 = s1 - l1, d2 = s2 - l2;
-            C[19 * 64] = s1; C[20 * 64] = s2;
+            const T d1 = s1 - tlam[c][1], d2 = s2 - tlam[c][2];
+            tlam[c][1] = s1; tlam[c][2] = s2;
             dvl.y -= invm * d1; dvl.x += invm * d2;
-            dva = dva + d1 * mk(C[6 * 64], C[7 * 64], C[8 * 64]) + d2 * mk(C[9 * 64], C[10 * 64], C[11 * 64]);
+            // Iw^-1 (ra x t1) d1 + Iw^-1 (ra x t2) d2,  ra x t1 = (ra.z, 0, -ra.x),  ra x t2 = (0, ra.z, -ra.y)
+            dva = dva + (raz * d1) * iw0 + (raz * d2) * iw1 - (rax * d1 + ray * d2) * iw2;
         }
         {
-            lds_ptr<T> S1 = S + 12 * 64; lds_ptr<T> S2 = S + 24 * 64;
-            const T limit = mu_tip * S[11 * 64];
-            T jdv1 = S1[0] * dvl.x + S1[64] * dvl.y + S1[128] * dvl.z + S1[3 * 64] * dva.x + S1[4 * 64] * dva.y + S1[5 * 64] * dva.z;
-            T jdv2 = S2[0] * dvl.x + S2[64] * dvl.y + S2[128] * dvl.z + S2[3 * 64] * dva.x + S2[4 * 64] * dva.y + S2[5 * 64] * dva.z;
+            const V3<T> ja1 = cross(pd[1], prb), ja2 = cross(pd[2], prb);
+            T jdv1 = dot(ja1, dva) - dot(pd[1], dvl), jdv2 = dot(ja2, dva) - dot(pd[2], dvl);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) { jdv1 += LJ[(6 + i) * 64] * dv[i]; jdv2 += LJ[(12 + i) * 64] * dv[i]; }
-            const T l1 = S1[11 * 64], l2 = S2[11 * 64];
-            T s1 = l1 + (S1[9 * 64] - jdv1) * S1[10 * 64], s2 = l2 + (S2[9 * 64] - jdv2) * S2[10 * 64];
+            for (int i = 0; i < NP; ++i) { jdv1 += Jt[1][i] * dv[i]; jdv2 += Jt[2][i] * dv[i]; }
+            const T limit = mu_tip * plam[0];
+            T s1 = plam[1] + (prhs[1] - jdv1) * pjdi[1], s2 = plam[2] + (prhs[2] - jdv2) * pjdi[2];
             friction_clamp(s1, s2, limit, cone);
-            const T d1 = s1 - l1, d2 = s2 - l2;
-            S1[11 * 64] = s1; S2[11 * 64] = s2;
+            const T d1 = s1 - plam[1], d2 = s2 - plam[2];
+            plam[1] = s1; plam[2] = s2;
 #pragma unroll
-            for (int i = 0; i < N; ++i) dv[i] += LW[(i * 3 + 1) * 64] * d1 + LW[(i * 3 + 2) * 64] * d2;
-            dvl = dvl + (invm * d1) * mk(S1[0], S1[64], S1[128]) + (invm * d2) * mk(S2[0], S2[64], S2[128]);
-            dva = dva + d1 * mk(S1[6 * 64], S1[7 * 64], S1[8 * 64]) + d2 * mk(S2[6 * 64], S2[7 * 64], S2[8 * 64]);
+            for (int i = 0; i < N; ++i) dv[i] += Wa[i][1] * d1 + Wa[i][2] * d2;
+            dvl = dvl - (invm * d1) * pd[1] - (invm * d2) * pd[2];
+            dva = dva + mul(Iwi, d1 * ja1 + d2 * ja2);
         }
     }
 #undef TG_MS

@@ -290,8 +290,10 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
     JointTrig<T, N> trig;
     trig_init<T, N>(q, trig);
+    int verified = 0;   // ticks for which sim_tick may take the analytic fixed point (armed by a full solve that converged fast)
     for (int t = 0; t < c.action_repeat; ++t)
-        sim_tick<T, TOPO, kMotorVelocity, true, true>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, &trig);
+        sim_tick<T, TOPO, kMotorVelocity, true, true>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, &trig,
+                                                      &verified);
 
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
     T zero[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) zero[i] = T(0);
-    int used = 0;
+    int used = 0, verified = 0;
     for (int it = 0; it < 1000; ++it) {
         Kin<T, TOPO> k;
         forward_kinematics<T, TOPO>(m, q, k);
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
 #pragma unroll
         for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
         if (all_small) cv = cv / T(2);
-        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters);
+        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, nullptr, &verified);
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
@@ -1116,6 +1118,24 @@ template <typename T> static int build_dev_robot(const tg_robot& r, DevRobot<T>&
     for (int k = 0; k < 9; ++k) { d.tcp_rot[k] = (T)r.tcp_rot[k]; d.sensor_rot[k] = (T)r.sensor_rot[k]; }
     d.lin_damp = (T)r.linear_damping; d.ang_damp = (T)r.angular_damping; d.joint_damp = (T)r.joint_damping;
     d.max_force = (T)r.max_force; d.pos_gain = (T)r.pos_gain; d.vel_gain = (T)r.vel_gain;
+    // Upper bound of trace(M(q)) over all joint angles (sim_tick's a-priori no-clamp test, tg_physics.hpp): M_ii is the inertia of
+    // the subtree of joint i about its axis <= sum over the subtree's links of trace(I_l) + m_l D^2, with D <= the summed lengths of the
+    // joint offsets on the way plus the link's own centre-of-mass offset.
+    {
+        auto parent = [&](int i) { return r.topology == 0 ? Topo<0>::parent(i) : Topo<1>::parent(i); };
+        auto len3 = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+        double tb = 0.0;
+        for (int i = 0; i < N; ++i)
+            for (int l = i; l < N; ++l) {
+                double D = 0.0; int k = l; bool under = false;
+                while (k >= 0) { if (k == i) { under = true; break; } D += len3(r.joint_pos[k]); k = parent(k); }
+                if (!under) continue;
+                const double com[3] = {(double)d.lcom[l][0], (double)d.lcom[l][1], (double)d.lcom[l][2]};
+                D += len3(com);
+                tb += ((double)d.linert[l][0] + (double)d.linert[l][3] + (double)d.linert[l][5]) + (double)d.lmass[l] * D * D;
+            }
+        d.trace_bound = (T)tb;
+    }
     return 0;
 }
 

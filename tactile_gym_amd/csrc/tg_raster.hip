@@ -172,6 +172,22 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                 if ((float)qx + 3.5f < r.xmin || (float)qx + 0.5f > r.xmax) continue;
                 if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
                 const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
+                {   // conservative reject of the 4-pixel quad: e_i is affine in fx (slope y_j - y_k along a row), so its value at the quad
+                    // centre plus 1.5 |slope| plus a bound on the float rounding of the per-pixel expression bounds it over the quad.  e0 + e1 + e2
+                    // is the same at every pixel (twice the signed area): when its sign is certain, a covered pixel needs all three e_i on
+                    // that side, so one edge function provably on the other side rejects the quad.  Skipping changes no pixel.
+                    const float fc = (float)qx + 2.0f;
+                    const float b0 = r.x0 - fc, b1 = r.x1 - fc, b2 = r.x2 - fc;
+                    const float c0 = b1 * a0 - b2 * a1, c1 = b2 * a2 - b0 * a0, c2 = b0 * a1 - b1 * a2;
+                    const float A0 = fabsf(a0), A1 = fabsf(a1), A2 = fabsf(a2);
+                    const float B0 = fabsf(b0) + 1.5f, B1 = fabsf(b1) + 1.5f, B2 = fabsf(b2) + 1.5f;
+                    const float m0 = 1e-5f * (B1 * A0 + B2 * A1), m1 = 1e-5f * (B2 * A2 + B0 * A0), m2 = 1e-5f * (B0 * A1 + B1 * A2);
+                    const float h0 = 1.5f * fabsf(r.y1 - r.y2) + m0, h1 = 1.5f * fabsf(r.y2 - r.y0) + m1, h2 = 1.5f * fabsf(r.y0 - r.y1) + m2;
+                    const float sc = (c0 + c1) + c2, ms = 4.0f * ((m0 + m1) + m2);
+                    const bool out_pos = (sc > ms) & ((c0 < -h0) | (c1 < -h1) | (c2 < -h2));
+                    const bool out_neg = (sc < -ms) & ((c0 > h0) | (c1 > h1) | (c2 > h2));
+                    if (out_pos | out_neg) continue;
+                }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const float fx = (float)(qx + p) + 0.5f;

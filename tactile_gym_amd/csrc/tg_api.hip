@@ -1265,7 +1265,8 @@ struct tg_ctx {
     void *d_robot = nullptr, *d_const = nullptr;   // DevRobot<T>, EnvConst<T>
     tg::State st{};
     tg::RasterParams rp{};
-    float *d_nodef_dep = nullptr, *d_nodef_gray = nullptr, *d_verts = nullptr, *d_actions = nullptr;
+    float *d_nodef_dep = nullptr, *d_verts = nullptr, *d_actions = nullptr;
+    uint8_t* d_nodef_gray = nullptr;   // uint8(nodef_gray)
     uint8_t *d_border = nullptr, *d_obs = nullptr, *d_term = nullptr, *d_mask = nullptr;
     int32_t* d_tris = nullptr;
     int n_tris = 0;
@@ -1489,7 +1490,11 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     for (int i = 0; i < n; ++i) seeds[i] = mix64((uint64_t)i + kGolden);
     TG_HIP(hipMemcpy(s.rng, seeds.data(), n * 8, hipMemcpyHostToDevice));
     TG_HIP(hipMalloc(&c->d_nodef_dep, npix * 4)); TG_HIP(hipMemcpy(c->d_nodef_dep, sensor->nodef_dep, npix * 4, hipMemcpyHostToDevice));
-    TG_HIP(hipMalloc(&c->d_nodef_gray, npix * 4)); TG_HIP(hipMemcpy(c->d_nodef_gray, sensor->nodef_gray, npix * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<uint8_t> g8(npix);
+        make_gray_u8(sensor->nodef_gray, (int)npix, g8.data());
+        TG_HIP(hipMalloc(&c->d_nodef_gray, npix)); TG_HIP(hipMemcpy(c->d_nodef_gray, g8.data(), npix, hipMemcpyHostToDevice));
+    }
     TG_HIP(hipMalloc(&c->d_border, npix)); TG_HIP(hipMemcpy(c->d_border, sensor->border_mask, npix, hipMemcpyHostToDevice));
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE) {
         TG_HIP(hipMalloc(&s.body_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.body_rot, 9 * n * 8)); TG_HIP(hipMalloc(&s.body_v, 3 * n * 8));
@@ -1866,7 +1871,8 @@ int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, cons
     if (nd.alloc(npix * 4) || ng.alloc(npix * 4) || bm.alloc(npix) || vv.alloc((size_t)mesh->n_verts * 12) || tt.alloc((size_t)mesh->n_tris * 12) ||
         xx.alloc((size_t)n * 48) || oo.alloc(npix * n))
         return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(nd.p, sen->nodef_dep, npix * 4, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(ng.p, sen->nodef_gray, npix * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(nd.p, sen->nodef_dep, npix * 4, hipMemcpyHostToDevice));
+    { std::vector<uint8_t> g8(npix); make_gray_u8(sen->nodef_gray, (int)npix, g8.data()); TG_HIP(hipMemcpy(ng.p, g8.data(), npix, hipMemcpyHostToDevice)); }
     TG_HIP(hipMemcpy(bm.p, sen->border_mask, npix, hipMemcpyHostToDevice));
     TG_HIP(hipMemcpy(vv.p, mesh->verts, (size_t)mesh->n_verts * 12, hipMemcpyHostToDevice));
     TG_HIP(hipMemcpy(tt.p, mesh->tris, (size_t)mesh->n_tris * 12, hipMemcpyHostToDevice));
@@ -1875,7 +1881,7 @@ int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, cons
     RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
     Stimulus S{};
     S.kind = 0; S.verts = (const float*)vv.p; S.tris = (const int32_t*)tt.p; S.n_tris = mesh->n_tris;
-    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const float*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
+    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
     return 0;
@@ -1892,7 +1898,8 @@ int tg_render_tactile_heightfield(const tg_sensor* sen, int32_t rows, int32_t co
     if (nd.alloc(npix * 4) || ng.alloc(npix * 4) || bm.alloc(npix) || hh.alloc(cells * n * 8) || zz.alloc((size_t)n * 4) || xx.alloc((size_t)n * 48) ||
         oo.alloc(npix * n))
         return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(nd.p, sen->nodef_dep, npix * 4, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(ng.p, sen->nodef_gray, npix * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(nd.p, sen->nodef_dep, npix * 4, hipMemcpyHostToDevice));
+    { std::vector<uint8_t> g8(npix); make_gray_u8(sen->nodef_gray, (int)npix, g8.data()); TG_HIP(hipMemcpy(ng.p, g8.data(), npix, hipMemcpyHostToDevice)); }
     TG_HIP(hipMemcpy(bm.p, sen->border_mask, npix, hipMemcpyHostToDevice));
     TG_HIP(hipMemcpy(hh.p, heights, cells * n * 8, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(zz.p, zoff, (size_t)n * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMemcpy(xx.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
@@ -1901,7 +1908,7 @@ int tg_render_tactile_heightfield(const tg_sensor* sen, int32_t rows, int32_t co
     Stimulus S{};
     S.kind = 1; S.heights = (const double*)hh.p; S.zoff = (const float*)zz.p; S.rows = rows; S.cols = cols; S.scale = (float)grid_scale;
     S.n_tris = (rows - 1) * (cols - 1) * 2;
-    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const float*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
+    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
     return 0;

@@ -34,8 +34,11 @@ struct Stimulus {
 
 RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border, const float* nodef_dep_host);
 
+// uint8(nodef_gray) per pixel (the border paste value), converted once on the host
+void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host);
+
 void launch_render(const RasterParams& P, const Stimulus& stim, const float* xform, int xform_soa, int n_envs,
-                   const uint8_t* mask, const float* nodef_dep, const float* nodef_gray, const uint8_t* border, uint8_t* out,
+                   const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, hipStream_t stream);
 
 }  // namespace tg

@@ -35,7 +35,8 @@ struct TriRec {      // projected triangle, window coordinates + depth
 constexpr float kDepthSlack = 2e-6f;
 
 constexpr int kThreads = 256;
-constexpr int kBatch = 1024;         // triangle records staged in LDS per pass (52 KB)
+constexpr int kBatch = 1024;         // most triangle records staged in LDS per pass (56 KB); a small mesh allocates 2 * n_tris records only, so
+                                     // that the 12-triangle edge does not hold the occupancy at 2 workgroups per CU (LDS-bound)
 
 RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border, const float* nodef_dep_host) {
     RasterParams P;
@@ -79,14 +80,15 @@ __device__ __forceinline__ void emit(TriRec* recs, int* count, const float* vx, 
 template <int TW>
 __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
-                                                             const float* __restrict__ nodef_dep, const float* __restrict__ nodef_gray,
+                                                             const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
                                                              const uint8_t* __restrict__ border, uint8_t* __restrict__ out,
-                                                             uint8_t* __restrict__ save_prev /*nullable: copy old image here first*/) {
+                                                             uint8_t* __restrict__ save_prev /*nullable: copy old image here first*/,
+                                                             int rec_cap /*records of dynamic LDS, even*/) {
     constexpr int kTile = TW;
     constexpr int QPR = TW / 4;            // pixel quads per tile row
     constexpr int RPP = kThreads / QPR;    // tile rows covered per pass of the workgroup
     constexpr int NK = TW / RPP;           // rows owned by each lane
-    __shared__ TriRec recs[kBatch];
+    extern __shared__ TriRec recs[];
     __shared__ int count;
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     const int qx = tile_x + 4 * (tid % QPR);
     const int ry = tile_y + (tid / QPR);
     float z[NK][4];
+    unsigned touched = 0;      // bit k: some triangle lowered a depth of row k of this lane's quad column
     {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -115,10 +118,10 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     }
     const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + kTile), ty1 = (float)(tile_y + kTile);
 
-    for (int base = 0; base < n_tris; base += kBatch / 2) {
+    for (int base = 0; base < n_tris; base += rec_cap / 2) {   // a clipped triangle can emit two records
         if (tid == 0) count = 0;
         __syncthreads();
-        const int lim = min(n_tris, base + kBatch / 2);
+        const int lim = min(n_tris, base + rec_cap / 2);
         for (int t = base + tid; t < lim; t += kThreads) {
             float cx[3], cy[3], cw[3];
 #pragma unroll
@@ -202,51 +205,65 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                     const float d = ((e0 * r.d0 + e1 * r.d1) + e2 * r.d2) / s;
                     const bool hit = box & (pos | neg) & (s != 0.0f) & (d < z[k][p]);
                     z[k][p] = hit ? d : z[k][p];
+                    touched |= hit ? (1u << k) : 0u;
                 }
             }
         }
         __syncthreads();
     }
 
-    // t_s_camera: depth difference -> uint8 penetration image, border paste (tactile_sensor.py:271-292)
+    // t_s_camera: depth difference -> uint8 penetration image, border paste (tactile_sensor.py:271-292).  A pixel no triangle
+    // lowered still holds nodef_dep bit for bit, so its difference is exactly 0: the reference depth image is read a second time only
+    // for the rows this lane actually touched (the kernel is bound by L2 traffic: 208 KB of reference images per workgroup before,
+    // 64 KB + 32 KB + the touched rows now).  gray_u8 = uint8(nodef_gray), converted once on the host.
     const float eps = 1e-4f, max_pen = 0.05f;
     uint8_t* dst = out + (size_t)env * P.W * P.H;
     uint8_t* prev = save_prev ? save_prev + (size_t)env * P.W * P.H : nullptr;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const size_t off = (size_t)(ry + RPP * k) * P.W + qx;
-        const float4 nd = *reinterpret_cast<const float4*>(nodef_dep + off);
-        const float4 ng = *reinterpret_cast<const float4*>(nodef_gray + off);
+        const uchar4 ng = *reinterpret_cast<const uchar4*>(gray_u8 + off);
         const uchar4 bm = *reinterpret_cast<const uchar4*>(border + off);
-        const float ndv[4] = {nd.x, nd.y, nd.z, nd.w}, ngv[4] = {ng.x, ng.y, ng.z, ng.w};
-        const uint8_t bmv[4] = {bm.x, bm.y, bm.z, bm.w};
-        uint8_t o[4];
+        const uint8_t ngv[4] = {ng.x, ng.y, ng.z, ng.w}, bmv[4] = {bm.x, bm.y, bm.z, bm.w};
+        uint8_t o[4] = {0, 0, 0, 0};
+        if ((touched >> k) & 1u) {
+            const float4 nd = *reinterpret_cast<const float4*>(nodef_dep + off);
+            const float ndv[4] = {nd.x, nd.y, nd.z, nd.w};
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float diff = z[k][p] - ndv[p];
-            if (diff >= -eps && diff <= eps) diff = 0.0f;
-            const float pen = fabsf(diff);
-            const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
-            uint8_t v = (uint8_t)((cl / max_pen) * 255.0f);
-            if (!P.turn_off_border && bmv[p] == 1) v = (uint8_t)ngv[p];
-            o[p] = v;
+            for (int p = 0; p < 4; ++p) {
+                float diff = z[k][p] - ndv[p];
+                if (diff >= -eps && diff <= eps) diff = 0.0f;
+                const float pen = fabsf(diff);
+                const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
+                o[p] = (uint8_t)((cl / max_pen) * 255.0f);
+            }
         }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (!P.turn_off_border && bmv[p] == 1) o[p] = ngv[p];
         if (prev) *reinterpret_cast<uchar4*>(prev + off) = *reinterpret_cast<const uchar4*>(dst + off);
         *reinterpret_cast<uchar4*>(dst + off) = make_uchar4(o[0], o[1], o[2], o[3]);
     }
 }
 
+void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host) {
+    for (int i = 0; i < npix; ++i) out_host[i] = (uint8_t)nodef_gray_host[i];   // the truncating cast of tactile_sensor.py:291-292
+}
+
 void launch_render(const RasterParams& P, const Stimulus& S, const float* xform, int xform_soa, int n_envs,
-                   const uint8_t* mask, const float* nodef_dep, const float* nodef_gray, const uint8_t* border, uint8_t* out,
+                   const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, hipStream_t stream) {
+    int rec_cap = 2 * S.n_tris;
+    rec_cap = rec_cap > kBatch ? kBatch : (rec_cap < 2 ? 2 : rec_cap);
+    const size_t lds = (size_t)rec_cap * sizeof(TriRec);
     if (P.W % 128 == 0 && P.H % 128 == 0) {
         dim3 grid((P.W / 128) * (P.H / 128), n_envs);
-        hipLaunchKernelGGL(k_render_tactile<128>, grid, dim3(kThreads), 0, stream, P, S, xform, xform_soa, n_envs, mask,
-                           nodef_dep, nodef_gray, border, out, save_prev);
+        hipLaunchKernelGGL(k_render_tactile<128>, grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                           nodef_dep, gray_u8, border, out, save_prev, rec_cap);
     } else {  // 64x64 images
         dim3 grid((P.W / 64) * (P.H / 64), n_envs);
-        hipLaunchKernelGGL(k_render_tactile<64>, grid, dim3(kThreads), 0, stream, P, S, xform, xform_soa, n_envs, mask,
-                           nodef_dep, nodef_gray, border, out, save_prev);
+        hipLaunchKernelGGL(k_render_tactile<64>, grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                           nodef_dep, gray_u8, border, out, save_prev, rec_cap);
     }
 }
 

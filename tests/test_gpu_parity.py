@@ -536,3 +536,27 @@ def test_object_push_f32_and_autoreset():
     assert np.abs(st["body_pos"][:, 1] - y0).max() < 1e-12          # teleported back by the auto-reset
     assert term["extended_feature"][0] > 0.002                      # the TCP advanced along the work-frame push direction (x)
     venv.close()
+
+
+@pytest.mark.gpu
+def test_default_solver_equals_literal_solver(edge_modes):
+    """The default tick (PGS convergence exit + analytic fixed point where licensed) against pgs_full_sweeps=1
+    (dynamics + exactly 150 sweeps in every tick) on the same seeds and actions: 40 steps of 64 envs incl. auto-resets.  Joints agree
+    to 1e-11 rad, rewards to float32 rounding, dones exactly, images bit-exact but for float32-rounding straddles (<= 2 pixels)."""
+    import tactile_gym_amd as tg
+    n, steps = 64, 40
+    a = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=15, image_size=[128, 128], env_modes=edge_modes, seed=5)
+    b = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=15, image_size=[128, 128], env_modes=edge_modes, seed=5, pgs_full_sweeps=True)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa["tactile"], ob["tactile"])
+    rng = np.random.default_rng(8)
+    for step in range(steps):
+        act = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.abs(sa["q"] - sb["q"]).max() < 1e-11 and np.abs(sa["qd"] - sb["qd"]).max() < 1e-11, step
+        assert np.array_equal(da, db) and np.abs(ra - rb).max() < 1e-6
+        assert np.array_equal(sa["reset_ticks"], sb["reset_ticks"])
+        assert int((oa["tactile"] != ob["tactile"]).sum(axis=(1, 2, 3)).max()) <= 2, step
+    a.close(); b.close()

@@ -570,9 +570,10 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    int verified = 0;
     for (int t = 0; t < c.action_repeat; ++t)
         sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body,
-                                               pivot_b, fext, pext, pending && t == 0);
+                                               pivot_b, fext, pext, pending && t == 0, &verified);
     st.ext_pending[env] = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
 #pragma unroll
     for (int i = 0; i < N; ++i) zero[i] = T(0);
     const V3<T> z3 = mk<T>(0, 0, 0);
-    int used = 0;
+    int used = 0, verified = 0;
     for (int it = 0; it < 1000; ++it) {
         Kin<T, TOPO> k;
         forward_kinematics<T, TOPO>(m, q, k);
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
         for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
         if (all_small) cv = cv / T(2);
         sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, grav, b, c.body,
-                                               pivot_b, z3, z3, false);
+                                               pivot_b, z3, z3, false, &verified);
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;

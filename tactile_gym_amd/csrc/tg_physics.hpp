@@ -649,9 +649,72 @@ template <typename T, int TOPO, int MOTOR>
 __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                               const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                               int iters, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b,
-                                              V3<T> ext_force, V3<T> ext_pos, bool ext_pending) {
+                                              V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int* verified = nullptr) {
     constexpr int N = Topo<TOPO>::N;
     constexpr int NR = N + 3;
+    // Analytic fixed point (see sim_tick).  The motor rows still prescribe the whole arm velocity, whatever the P2P rows pull: at the
+    // solution of the unclamped system the arm moves with `des` and the three P2P impulses solve the body-only system
+    //   (1/m I + [rb x]^T Iw^-1 [rb x]) lambda = -erp gap/dt - (J_a des - v_pivot_b)        (3x3 SPD, solved directly),
+    // the motors absorbing the reaction.  Same licence as in sim_tick: a full solve of this env step must have converged to the last
+    // bit within 80 % of the sweep budget (the coupled iteration contracts like the arm's alone, ~0.5 per sweep), and no row may be
+    // able to reach its limit (motor bound extended by the P2P reaction, P2P impulse far from its 500 N s cap).
+    if (MOTOR != kMotorOff && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0) {
+        T des[N], dv2 = T(0), v2 = T(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            des[i] = ((MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0)) + qd_des[i];
+            dv2 += (des[i] - qd[i]) * (des[i] - qd[i]);
+            v2 += qd[i] * qd[i];
+        }
+        Kin<T, TOPO> kin;
+        forward_kinematics<T, TOPO>(m, q, kin);
+        const S3<T> Iw = rotate(b.R, bc.inertia), Iwi = inverse(Iw);
+        V3<T> xc = b.pos + mul(b.R, bc.com);
+        V3<T> F = bc.mass * gravity, Nt = mk<T>(0, 0, 0);
+        if (ext_pending) { F = F + ext_force; Nt = Nt + cross(ext_pos - xc, ext_force); }
+        Nt = Nt - cross(b.w, mul(Iw, b.w));
+        const V3<T> vb = b.v + (dt / bc.mass) * F, wb = b.w + dt * mul(Iwi, Nt);
+        V3<T> pa; M3<T> Rl;
+        {
+            const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+            const T pav[3] = {bc.pivot_a.x, bc.pivot_a.y, bc.pivot_a.z};
+            link_frame<T, TOPO>(kin, bc.link, pav, ident, pa, Rl);
+        }
+        const V3<T> pb = b.pos + mul(b.R, pivot_b), rb = pb - xc;
+        V3<T> va = mk<T>(0, 0, 0);      // velocity of pivot A under the prescribed joint velocities
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            bool on_path = false;
+#pragma unroll
+            for (int l = 0; l < N; ++l)
+                if (l == bc.link && is_ancestor_or_self<TOPO>(i, l)) on_path = true;
+            if (on_path) va = va + des[i] * cross(kin.a[i], pa - kin.o[i]);
+        }
+        const V3<T> gap = pa - pb, cv = va - (vb + cross(wb, rb));
+        const V3<T> rhs = (-bc.erp / dt) * gap - cv;
+        const V3<T> e[3] = {mk<T>(1, 0, 0), mk<T>(0, 1, 0), mk<T>(0, 0, 1)};
+        V3<T> rxe[3], Wang[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { rxe[x] = cross(rb, e[x]); Wang[x] = mul(Iwi, rxe[x]); }
+        const T im = T(1) / bc.mass;
+        const S3<T> App{im + dot(rxe[0], Wang[0]), dot(rxe[0], Wang[1]), dot(rxe[0], Wang[2]), im + dot(rxe[1], Wang[1]), dot(rxe[1], Wang[2]),
+                        im + dot(rxe[2], Wang[2])};
+        const V3<T> lp = mul(inverse(App), rhs);
+        const T lpn = tsqrt_fast(dot(lp, lp));
+        const T lam_star = m.trace_bound * tsqrt_fast(dv2) +
+                           dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3) * tsqrt_fast(v2) + T(6) * lpn;
+        if (__all(T(4) * lam_star < max_force * dt && T(8) * lpn < bc.max_impulse)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { qd[i] = des[i]; q[i] += dt * des[i]; }
+            b.v = vb - im * lp;
+            b.w = wb - mul(Iwi, cross(rb, lp));
+            xc = xc + dt * b.v;
+            integrate_rotation(b.R, b.w, dt);
+            b.pos = xc - mul(b.R, bc.com);
+            --*verified;
+            return;
+        }
+    }
     asm volatile("" ::: "memory");
     T hb[N], qdm[N], Minv[N][N], traceM;
     Kin<T, TOPO> kin;
@@ -764,12 +827,13 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
     for (int j = 0; j < NR; ++j) thr = tmax(thr, tabs(r[j]));
     thr = iters < 0 ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
     const int n_it = iters < 0 ? -iters : iters;
+    int conv_sweeps = -1;
     for (int it = 0; it < n_it; ++it) {
         if ((it & 7) == 0 && it > 0) {
             T mx = T(0);
 #pragma unroll
             for (int j = 0; j < NR; ++j) mx = tmax(mx, tabs(r[j]));
-            if (__all(mx <= thr)) break;
+            if (__all(mx <= thr)) { conv_sweeps = it; break; }
         }
         if (it & 1) {
 #pragma unroll
@@ -808,6 +872,7 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
         qd[i] = v[i] + acc;
         q[i] += dt * qd[i];
     }
+    if (verified != nullptr) *verified = (iters > 0 && conv_sweeps > 0 && 5 * conv_sweeps <= 4 * iters) ? 24 : 0;
     const V3<T> lp = mk(lam[N], lam[N + 1], lam[N + 2]);
     b.v = vb - (T(1) / bc.mass) * lp;
     b.w = wb - mul(Iwi, cross(rb, lp));

@@ -48,6 +48,7 @@ template <typename T> struct EnvConst {
     T obj_init_rpy_deg[3], obj_base_width, obj_base_height, term_deg, term_pos, ext_force[3];
     int rand_gravity, rand_embed;
     double gravity_lo, gravity_hi, gravity_default;
+    int fused_reset;             // edge_follow with auto_reset: k_reset keeps the terminal camera transform, one render launch draws both images
     // object_push
     PushScene<T> push;
     int traj_type, traj_n, rand_init_orn, rand_obj_mass;
@@ -58,7 +59,7 @@ template <typename T> struct EnvConst {
 
 struct State {   // device pointers, SoA [field][num_envs]
     double *q, *qd, *qd_target, *tcp_pos, *tcp_rpy, *edge_ang, *embed;
-    float *stim_xform, *reward;
+    float *stim_xform, *term_xform, *reward;   // term_xform: camera<-stimulus transform of the terminal observation (fused reset)
     int32_t *step_count, *reset_ticks;
     uint64_t* rng;
     uint8_t* done;
@@ -361,15 +362,10 @@ __device__ __forceinline__ int inverse_kinematics(const DevRobot<T>& m, V3<T> tp
 // EdgeFollowEnv.reset (edge_follow_env.py:311-336): reset_task (:285-299), Robot.reset (robot.py:114-125) =
 // rest pose + IK to the start pose (base_robot_arm.py:191-226) + blocking_move (robot.py:188-260).
 template <typename T, int TOPO>
-__global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                              const uint8_t* __restrict__ mask, int phase /*0 all, 1 task draws only, 2 robot only*/) {
+__device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env,
+                                          int phase /*0 all, 1 task draws only, 2 robot only*/) {
     constexpr int N = Topo<TOPO>::N;
-    const DevRobot<T>& m = *mp;
-    const EnvConst<T>& c = *cp;
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = c.num_envs;
-    if (env >= n) return;
-    if (mask != nullptr && mask[env] == 0) return;
 
     double embed = (double)c.embed_default, edge_ang = 0.0;
     if (phase != 2) {                                     // reset_task: identical draw order to the reference / oracle
@@ -466,6 +462,20 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
     finish_env<T, TOPO>(m, c, st, env, q, (T)edge_ang, 0, false);
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                              const uint8_t* __restrict__ mask, int phase) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= cp->num_envs) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    if (cp->fused_reset && mask != nullptr) {   // auto-reset inside tg_step: keep the terminal observation's camera transform; the render
+        const int n = cp->num_envs;             // launch that follows draws both images of this env
+#pragma unroll
+        for (int k = 0; k < 12; ++k) st.term_xform[k * n + env] = st.stim_xform[k * n + env];
+    }
+    reset_env<T, TOPO>(*mp, *cp, st, env, phase);
 }
 
 // ------------------------------------------------------------------------------------------------ object_balance kernels
@@ -1230,6 +1240,7 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.ybin_lo = cfg.stim_pos[1] - ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
         c.ybin_hi = cfg.stim_pos[1] + ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
     }
+    c.fused_reset = (cfg.auto_reset && cfg.env_kind == TG_ENV_EDGE_FOLLOW) ? 1 : 0;
     c.max_steps = cfg.max_steps; c.action_repeat = cfg.action_repeat; c.solver_iters = cfg.pgs_full_sweeps ? -cfg.solver_iterations : cfg.solver_iterations;
     c.dt = (T)cfg.sim_dt; c.min_action = (T)cfg.min_action; c.max_action = (T)cfg.max_action;
     for (int d = 0; d < 6; ++d) { c.act_lo[d] = (T)cfg.act_lo[d]; c.act_hi[d] = (T)cfg.act_hi[d]; c.tcp_lims[d][0] = (T)cfg.tcp_lims[d][0]; c.tcp_lims[d][1] = (T)cfg.tcp_lims[d][1]; }
@@ -1360,7 +1371,13 @@ template <typename T, int TOPO> static void launch_reset_push_t(tg_ctx* c, const
 static void render(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
     Timer t(c, d_mask ? 3 : 1);
     launch_render(c->rp, c->stim, c->st.stim_xform, 1, c->cfg.num_envs, d_mask, c->d_nodef_dep, c->d_nodef_gray,
-                  c->d_border, c->d_obs, save_prev ? c->d_term : nullptr, c->stream);
+                  c->d_border, c->d_obs, save_prev ? c->d_term : nullptr, nullptr, nullptr, nullptr, c->stream);
+}
+// fused auto-reset: every env's observation from stim_xform; for the envs flagged in `done` also the terminal observation from term_xform
+static void render_fused(tg_ctx* c) {
+    Timer t(c, 1);
+    launch_render(c->rp, c->stim, c->st.stim_xform, 1, c->cfg.num_envs, nullptr, c->d_nodef_dep, c->d_nodef_gray,
+                  c->d_border, c->d_obs, nullptr, c->st.term_xform, c->st.done, c->d_term, c->stream);
 }
 
 // SoA [field][n] device -> AoS [n][field] host
@@ -1479,13 +1496,13 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&s.q, nd * 8)); TG_HIP(hipMalloc(&s.qd, nd * 8)); TG_HIP(hipMalloc(&s.qd_target, nd * 8));
     TG_HIP(hipMalloc(&s.tcp_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.tcp_rpy, 3 * n * 8));
     TG_HIP(hipMalloc(&s.edge_ang, n * 8)); TG_HIP(hipMalloc(&s.embed, n * 8));
-    TG_HIP(hipMalloc(&s.stim_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.reward, n * 4));
+    TG_HIP(hipMalloc(&s.stim_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.term_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.reward, n * 4));
     TG_HIP(hipMalloc(&s.step_count, n * 4)); TG_HIP(hipMalloc(&s.reset_ticks, n * 4));
     TG_HIP(hipMalloc(&s.rng, n * 8)); TG_HIP(hipMalloc(&s.done, n));
     TG_HIP(hipMemset(s.q, 0, nd * 8)); TG_HIP(hipMemset(s.qd, 0, nd * 8)); TG_HIP(hipMemset(s.qd_target, 0, nd * 8));
     TG_HIP(hipMemset(s.tcp_pos, 0, 3 * n * 8)); TG_HIP(hipMemset(s.tcp_rpy, 0, 3 * n * 8));
     TG_HIP(hipMemset(s.edge_ang, 0, n * 8)); TG_HIP(hipMemset(s.embed, 0, n * 8));
-    TG_HIP(hipMemset(s.stim_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.reward, 0, n * 4));
+    TG_HIP(hipMemset(s.stim_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.term_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.reward, 0, n * 4));
     TG_HIP(hipMemset(s.step_count, 0, n * 4)); TG_HIP(hipMemset(s.reset_ticks, 0, n * 4)); TG_HIP(hipMemset(s.done, 0, n));
     std::vector<uint64_t> seeds(n);
     for (int i = 0; i < n; ++i) seeds[i] = mix64((uint64_t)i + kGolden);
@@ -1582,7 +1599,7 @@ int tg_destroy(tg_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
     State& s = c->st;
-    void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.reward,
+    void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform, s.reward,
                     s.step_count, s.reset_ticks, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1642,10 +1659,15 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
 #undef CALL
         }
     }
-    render(c, nullptr, false);
-    if (c->cfg.auto_reset) {
-        reset_sequence(c, c->st.done);
-        render(c, c->st.done, true);   // terminal observation is saved, then the post-reset observation is drawn
+    if (c->cfg.auto_reset && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {
+        reset_sequence(c, c->st.done); // k_reset keeps the terminal camera transform of the envs it resets
+        render_fused(c);               // one launch draws the terminal and the post-reset observations
+    } else {
+        render(c, nullptr, false);
+        if (c->cfg.auto_reset) {
+            reset_sequence(c, c->st.done);
+            render(c, c->st.done, true);   // terminal observation is saved, then the post-reset observation is drawn
+        }
     }
     TG_HIP(hipGetLastError());
     return 0;
@@ -1882,7 +1904,7 @@ int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, cons
     RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
     Stimulus S{};
     S.kind = 0; S.verts = (const float*)vv.p; S.tris = (const int32_t*)tt.p; S.n_tris = mesh->n_tris;
-    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
+    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, nullptr, nullptr, nullptr, 0);
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
     return 0;
@@ -1909,7 +1931,7 @@ int tg_render_tactile_heightfield(const tg_sensor* sen, int32_t rows, int32_t co
     Stimulus S{};
     S.kind = 1; S.heights = (const double*)hh.p; S.zoff = (const float*)zz.p; S.rows = rows; S.cols = cols; S.scale = (float)grid_scale;
     S.n_tris = (rows - 1) * (cols - 1) * 2;
-    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, 0);
+    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, nullptr, nullptr, nullptr, 0);
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
     return 0;

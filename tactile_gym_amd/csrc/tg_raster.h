@@ -37,8 +37,10 @@ RasterParams make_raster_params(int W, int H, double fov_deg, double near_, doub
 // uint8(nodef_gray) per pixel (the border paste value), converted once on the host
 void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host);
 
+// term_xform / term_mask / term_out (all or none): for the envs whose term_mask byte is non-zero the kernel first draws the image of
+// term_xform (same SoA layout as xform) into term_out, then the regular one: the fused auto-reset of tg_step.
 void launch_render(const RasterParams& P, const Stimulus& stim, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
-                   uint8_t* save_prev, hipStream_t stream);
+                   uint8_t* save_prev, const float* term_xform, const uint8_t* term_mask, uint8_t* term_out, hipStream_t stream);
 
 }  // namespace tg

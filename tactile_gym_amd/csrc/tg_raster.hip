@@ -83,7 +83,9 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                                                              const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
                                                              const uint8_t* __restrict__ border, uint8_t* __restrict__ out,
                                                              uint8_t* __restrict__ save_prev /*nullable: copy old image here first*/,
-                                                             int rec_cap /*records of dynamic LDS, even*/) {
+                                                             int rec_cap /*records of dynamic LDS, even*/,
+                                                             const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
+                                                             uint8_t* __restrict__ term_out /*fused auto-reset: all three or none*/) {
     constexpr int kTile = TW;
     constexpr int QPR = TW / 4;            // pixel quads per tile row
     constexpr int RPP = kThreads / QPR;    // tile rows covered per pass of the workgroup
@@ -100,9 +102,15 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     const int tile_x = (blockIdx.x % tiles_x) * kTile, tile_y = (blockIdx.x / tiles_x) * kTile;
     const int tid = threadIdx.x;
 
+    // fused auto-reset: grid z = 1 draws the terminal observation (term_xform -> term_out) of the envs flagged in term_mask and is
+    // empty for every other env; grid z = 0 is the regular image
+    const int pass = (term_xform != nullptr && blockIdx.z == 1) ? 0 : 1;
+    if (pass == 0 && term_mask[env] == 0) return;
+    const float* __restrict__ xf = pass == 0 ? term_xform : xform;
+    uint8_t* __restrict__ img = pass == 0 ? term_out : out;
     float M[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xform[(size_t)k * n_envs + env] : xform[(size_t)env * 12 + k];
+    for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xf[(size_t)k * n_envs + env] : xf[(size_t)env * 12 + k];
 
     // this lane's pixels: quad column qx (4 px), rows ry + 8*k
     const int qx = tile_x + 4 * (tid % QPR);
@@ -217,8 +225,8 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     // for the rows this lane actually touched (the kernel is bound by L2 traffic: 208 KB of reference images per workgroup before,
     // 64 KB + 32 KB + the touched rows now).  gray_u8 = uint8(nodef_gray), converted once on the host.
     const float eps = 1e-4f, max_pen = 0.05f;
-    uint8_t* dst = out + (size_t)env * P.W * P.H;
-    uint8_t* prev = save_prev ? save_prev + (size_t)env * P.W * P.H : nullptr;
+    uint8_t* dst = img + (size_t)env * P.W * P.H;
+    uint8_t* prev = (save_prev && pass == 1) ? save_prev + (size_t)env * P.W * P.H : nullptr;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const size_t off = (size_t)(ry + RPP * k) * P.W + qx;
@@ -252,18 +260,18 @@ void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host) {
 
 void launch_render(const RasterParams& P, const Stimulus& S, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
-                   uint8_t* save_prev, hipStream_t stream) {
+                   uint8_t* save_prev, const float* term_xform, const uint8_t* term_mask, uint8_t* term_out, hipStream_t stream) {
     int rec_cap = 2 * S.n_tris;
     rec_cap = rec_cap > kBatch ? kBatch : (rec_cap < 2 ? 2 : rec_cap);
     const size_t lds = (size_t)rec_cap * sizeof(TriRec);
     if (P.W % 128 == 0 && P.H % 128 == 0) {
-        dim3 grid((P.W / 128) * (P.H / 128), n_envs);
+        dim3 grid((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
         hipLaunchKernelGGL(k_render_tactile<128>, grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
-                           nodef_dep, gray_u8, border, out, save_prev, rec_cap);
+                           nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
     } else {  // 64x64 images
-        dim3 grid((P.W / 64) * (P.H / 64), n_envs);
+        dim3 grid((P.W / 64) * (P.H / 64), n_envs, term_xform ? 2 : 1);
         hipLaunchKernelGGL(k_render_tactile<64>, grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
-                           nodef_dep, gray_u8, border, out, save_prev, rec_cap);
+                           nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
     }
 }
 

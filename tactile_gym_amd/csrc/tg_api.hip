@@ -5,6 +5,7 @@
 // crosses HBM exactly once per env step (in) and once (out); the 24 sim ticks in between run out of registers.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1283,6 +1284,12 @@ struct tg_ctx {
     int32_t* d_tris = nullptr;
     int n_tris = 0;
     tg::Stimulus stim{};
+    // hipGraph of one tg_step launch sequence, keyed by the device action pointer it was captured with (launch-bound inner loop:
+    // 3-4 kernels per step, one graph launch instead)
+    hipGraphExec_t step_graph = nullptr;
+    const float* step_graph_actions = nullptr;
+    hipStream_t step_graph_stream = nullptr;
+    bool graph_broken = false;
     // profiling
     bool profile = false;
     struct Ev { hipEvent_t a, b; int which; };
@@ -1598,6 +1605,7 @@ int tg_destroy(tg_ctx* c) {
     if (!c) return 0;
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
+    if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform, s.reward,
                     s.step_count, s.reset_ticks, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
@@ -1637,13 +1645,7 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
     return 0;
 }
 
-int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
-    if (!c || !actions) return fail(-1, "tg_step: NULL argument");
-    const float* d_act = actions;
-    if (!on_device) {
-        TG_HIP(hipMemcpyAsync(c->d_actions, actions, (size_t)c->cfg.num_envs * c->act_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        d_act = c->d_actions;
-    }
+static void enqueue_step(tg_ctx* c, const float* d_act) {
     {
         Timer t(c, 0);
         if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
@@ -1669,12 +1671,61 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
             render(c, c->st.done, true);   // terminal observation is saved, then the post-reset observation is drawn
         }
     }
+}
+
+int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
+    if (!c || !actions) return fail(-1, "tg_step: NULL argument");
+    const float* d_act = actions;
+    if (!on_device) {
+        TG_HIP(hipMemcpyAsync(c->d_actions, actions, (size_t)c->cfg.num_envs * c->act_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d_act = c->d_actions;
+    }
+    // The launch sequence of a step is the same every step (all arguments are device pointers owned by the context, the action
+    // buffer aside): capture it once per action pointer / stream and replay it as one graph launch.  Not while profiling (the
+    // per-kernel events are host calls between the launches) and not for the push kernels (hipFuncSetAttribute on first launch).
+    const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH;
+    if (want_graph) {
+        if (c->step_graph && (c->step_graph_actions != d_act || c->step_graph_stream != c->stream)) {
+            (void)hipGraphExecDestroy(c->step_graph);
+            c->step_graph = nullptr;
+        }
+        if (!c->step_graph) {
+            hipGraph_t g = nullptr;
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                enqueue_step(c, d_act);
+                const hipError_t e1 = hipStreamEndCapture(c->stream, &g);
+                if (e1 == hipSuccess && g && hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0) == hipSuccess) {
+                    c->step_graph_actions = d_act; c->step_graph_stream = c->stream;
+                } else {
+                    c->step_graph = nullptr; c->graph_broken = true;
+                }
+                if (g) (void)hipGraphDestroy(g);
+            } else {
+                c->graph_broken = true;
+            }
+            (void)hipGetLastError();
+        }
+        if (c->step_graph) {
+            TG_HIP(hipGraphLaunch(c->step_graph, c->stream));
+            return 0;
+        }
+    }
+    enqueue_step(c, d_act);
     TG_HIP(hipGetLastError());
     return 0;
 }
 
 int tg_sync(tg_ctx* c) {
     if (!c) return fail(-1, "NULL ctx");
+    // A step is ~0.15 ms: the interrupt-driven wake-up of hipStreamSynchronize costs a noticeable fraction of it.  Poll for up to
+    // ~2 ms (VecEnv.step_wait follows step_async immediately), then fall back to the blocking wait.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(-2, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
     TG_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }

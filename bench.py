@@ -8,8 +8,9 @@ A "step" is one VecEnv.step() of the whole batch: controller + 24 sim ticks + ta
 actions ~ U(-0.25, 0.25) generated on the device (synthetic), auto-reset on (episodes of 200 steps, so resets fall
 inside the timed region whenever K + W crosses a multiple of 200; reported separately via `resets_in_timed_region`).
 Observations stay resident in HBM (device tensors); the PCIe-inclusive rate is quoted in DESIGN.md, never here.
-Weak scaling: every rank owns --num-envs envs; rank 0 receives all observations / rewards / dones by one RCCL gather per
-step.  Prints ONE JSON line on rank 0.
+Weak scaling: every rank owns --num-envs envs; rank 0 receives all observations / rewards / dones by one packed RCCL gather
+per step, started asynchronously so that it overlaps the next step's simulation; the last gather is waited for inside
+the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -104,7 +105,7 @@ def main():
                        seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",
                        pgs_full_sweeps=args.full_sweeps)
     shard = TorchShard(venv)
-    env = ShardedVecEnv(shard, dist) if world > 1 else shard
+    env = ShardedVecEnv(shard, dist, overlap=True) if world > 1 else shard   # gather of step t overlaps the simulation of step t+1
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
 
@@ -126,6 +127,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         env.step(actions())
+    if world > 1:
+        env.flush()        # the last step's gather completes inside the timed region: K steps simulated AND delivered to rank 0
     barrier()
     dt = time.perf_counter() - t0
     # per-kernel durations for the roofline leg: HIP events on the launch stream, outside the timed region
@@ -188,7 +191,8 @@ def main():
             "dtype": "f64" if args.physics == "f64" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.env}, {'MG400 + DigiTac' if args.env == 'object_push-v0' else 'UR5 + ' + ('DIGIT' if args.env == 'surface_follow-v0' else 'TacTip')}, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
                                    f"random actions, TCP_velocity_control, {12 if args.env == 'object_balance-v0' else 24} sim ticks per step (PGS budget 150 sweeps per tick), auto-reset on",
-                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world} + gather to rank 0"},
+                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world}" + (" + one packed RCCL gather (obs u8, reward f32, done u8) to rank 0 per step, "
+                                                                          "overlapped with the next step's simulation" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_env_step": algo_bytes,

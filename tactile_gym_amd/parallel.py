@@ -14,9 +14,17 @@ class ShardedVecEnv:
 
     `local` must expose num_envs, reset() -> {"tactile": tensor[n,H,W,1]}, step(a) -> (obs, reward, done, info) with
     torch tensors (device tensors under nccl, CPU tensors under gloo).  Rank 0's step() returns the gathered
-    [world * n] batch; other ranks return their local shard (what an actor-only rank needs)."""
+    [world * n] batch; other ranks return their local shard (what an actor-only rank needs).
 
-    def __init__(self, local, dist=None, root=0):
+    Per step there is ONE collective: tactile obs (uint8), reward (float32) and done (uint8) are packed into one byte
+    buffer per rank and gathered together (three small-latency collectives per 0.15 ms step would cost as much as the step).
+
+    overlap=True ("overlap gather of step t with simulate of step t+1, double-buffered obs"): step() snapshots this
+    rank's results into one of two staging buffers, starts the gather asynchronously and returns; rank 0 is handed the batch of
+    the PREVIOUS step (complete by then), i.e. the learner side runs one step behind the simulators, and flush() waits for the
+    last gather and returns its batch.  With overlap=False every step() returns its own gathered batch (synchronous VecEnv)."""
+
+    def __init__(self, local, dist=None, root=0, overlap=False):
         import torch
         if dist is None:
             import torch.distributed as dist
@@ -24,7 +32,9 @@ class ShardedVecEnv:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.n_local = local.num_envs
         self.num_envs = self.n_local * self.world
+        self.overlap = bool(overlap) and self.world > 1
         self._bufs = {}
+        self._stage, self._full, self._pending, self._tick, self._layout, self._last = [None, None], [None, None], [None, None], 0, None, None
 
     def env_slice(self):
         return slice(self.rank * self.n_local, (self.rank + 1) * self.n_local)
@@ -55,10 +65,73 @@ class ShardedVecEnv:
         obs = self.local.reset()
         return {k: self._gather("obs_" + k, v) for k, v in obs.items()}
 
+    # ---- packed exchange: [tactile bytes | reward bytes | done bytes] per rank
+    def _pack(self, slot, tac, rew, done):
+        torch = self.torch
+        nb_t, nb_r, nb_d = tac.numel(), rew.numel() * 4, done.numel()
+        if self._layout is None:
+            assert tac.dtype == torch.uint8 and rew.dtype == torch.float32 and done.dtype == torch.uint8 and nb_t % 4 == 0
+            self._layout = (tuple(tac.shape), nb_t, nb_r, nb_d)
+        if self._stage[slot] is None:
+            self._stage[slot] = torch.empty(nb_t + nb_r + nb_d, dtype=torch.uint8, device=tac.device)
+            if self.rank == self.root:
+                self._full[slot] = torch.empty((self.world, nb_t + nb_r + nb_d), dtype=torch.uint8, device=tac.device)
+        st = self._stage[slot]
+        st[:nb_t].copy_(tac.reshape(-1))
+        st[nb_t:nb_t + nb_r].view(torch.float32).copy_(rew.reshape(-1))
+        st[nb_t + nb_r:].copy_(done.reshape(-1))
+        return st
+
+    def _start_gather(self, slot, async_op):
+        st = self._stage[slot]
+        if self.rank == self.root:
+            return self.dist.gather(st, gather_list=[self._full[slot][i] for i in range(self.world)], dst=self.root, async_op=async_op)
+        return self.dist.gather(st, gather_list=None, dst=self.root, async_op=async_op)
+
+    def _unpack(self, slot):
+        torch = self.torch
+        shape, nb_t, nb_r, nb_d = self._layout
+        full = self._full[slot]
+        tac = full[:, :nb_t].reshape((self.world * shape[0],) + shape[1:])
+        rew = full[:, nb_t:nb_t + nb_r].contiguous().view(torch.float32).reshape(-1)
+        done = full[:, nb_t + nb_r:].reshape(-1)
+        return {"tactile": tac}, rew, done
+
     def step(self, local_actions):
         obs, rew, done, info = self.local.step(local_actions)
-        obs = {k: self._gather("obs_" + k, v) for k, v in obs.items()}
-        return obs, self._gather("rew", rew), self._gather("done", done), info
+        if self.world == 1:
+            return obs, rew, done, info
+        slot = self._tick & 1
+        if self._pending[slot] is not None:          # this staging buffer's previous gather (two steps ago) must be complete
+            self._pending[slot].wait()
+            self._pending[slot] = None
+        self._pack(slot, obs["tactile"], rew, done)
+        if not self.overlap:
+            self._start_gather(slot, False)
+            self._tick += 1
+            return self._unpack(slot) + (info,) if self.rank == self.root else (obs, rew, done, info)
+        self._pending[slot] = self._start_gather(slot, True)
+        self._tick += 1
+        prev = slot ^ 1
+        if self.rank != self.root:
+            return obs, rew, done, info
+        if self._tick == 1:                          # nothing gathered yet: hand back the local shard's view of step 0
+            return obs, rew, done, info
+        if self._pending[prev] is not None:
+            self._pending[prev].wait()
+            self._pending[prev] = None
+        return self._unpack(prev) + (info,)
+
+    def flush(self):
+        """overlap=True: wait for the outstanding gathers; rank 0 gets the gathered batch of the last step."""
+        if self.world == 1 or not self.overlap or self._tick == 0:
+            return None
+        for k in (0, 1):
+            if self._pending[k] is not None:
+                self._pending[k].wait()
+                self._pending[k] = None
+        last = (self._tick - 1) & 1
+        return self._unpack(last) if self.rank == self.root else None
 
 
 class TorchShard:

@@ -34,12 +34,12 @@ class OracleShard:
                 torch.tensor([o[1] for o in outs], dtype=torch.float32), torch.tensor([o[2] for o in outs], dtype=torch.uint8), {})
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, overlap=False):
     import torch.distributed as dist
     from tactile_gym_amd.parallel import ShardedVecEnv
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    env = ShardedVecEnv(OracleShard(rank, N_LOCAL, SEED), dist)
+    env = ShardedVecEnv(OracleShard(rank, N_LOCAL, SEED), dist, overlap=overlap)
     assert env.num_envs == world * N_LOCAL and env.env_slice() == slice(rank * N_LOCAL, (rank + 1) * N_LOCAL)
     obs = env.reset()
     gen = torch.Generator().manual_seed(7)
@@ -49,6 +49,11 @@ def _worker(rank, world, port, out_path):
         local = env.scatter_actions(acts)            # rank 0's batch is broadcast, every rank keeps its block
         obs, rew, done, _ = env.step(local)
         hist.append(obs["tactile"].clone())
+    if overlap:                                       # pipelined: step k returned the batch of step k-1; flush() hands over the last one
+        last = env.flush()
+        if rank == 0:
+            hist = [hist[0]] + hist[2:] + [last[0]["tactile"].clone()]
+            obs, rew, done = last
     if rank == 0:
         assert obs["tactile"].shape == (world * N_LOCAL, 64, 64, 1) and rew.shape == (world * N_LOCAL,)
         torch.save({"obs": torch.stack(hist), "rew": rew, "done": done}, out_path)
@@ -58,13 +63,14 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_shard_and_gather_world2(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_shard_and_gather_world2(tmp_path, overlap):
     world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, overlap), nprocs=world, join=True)
     got = torch.load(out)
     # single-process reference: the same 4 envs with seeds SEED..SEED+3 stepped with the same actions
     ref = OracleShard(0, world * N_LOCAL, SEED)

@@ -450,8 +450,16 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
                         w, h, cur)
         return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)
 
-    def oracle_obs(self):
-        raise NotImplementedError
+    def _tcp_work_full(self):                                                            # base_robot_arm.py:153-172
+        p, rpy, lv, av = self._tcp_work()
+        return p, rpy, pm.quat_from_euler(rpy), lv, av
+
+    def oracle_obs(self):                                                                # base_surface_env.py:789-819
+        _, iq = pm.invert_transform(self.workframe_pos, self.workframe_orn)
+        nrm = pm.mat_from_quat(iq) @ self.surface_normals[self.tip_i, self.tip_j, :]
+        p, _, q, lv, av = self._tcp_work_full()
+        gp, _ = self._world_to_work(self.goal_pos_world, np.zeros(3))
+        return np.hstack([p, q, lv, av, gp, self.surface_array[self.tip_i, self.tip_j, 2], nrm]).astype(np.float32)
 
 
 class OracleObjectBalanceEnv(_OracleArmEnv):
@@ -585,8 +593,17 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
         mb.render_depth(self.obj_verts, self.obj_tris, self.stimulus_transform(), self.cam["fov"], self.cam["near"], self.cam["far"], w, h, cur)
         return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)
 
-    def oracle_obs(self):
-        raise NotImplementedError
+    def _obj_work(self):                                                                    # base_object_env.py:118-139
+        pos, R = self.body_pose()
+        p, rpy = self._world_to_work(pos, pm.euler_from_quat(pm.quat_from_mat(R)))
+        _, iq = pm.invert_transform(self.workframe_pos, self.workframe_orn)
+        Rinv = pm.mat_from_quat(iq)
+        return p, rpy, pm.quat_from_euler(rpy), Rinv @ np.array(self.body.linvel[:]), Rinv @ np.array(self.body.angvel[:])
+
+    def oracle_obs(self):                                                                   # object_balance_env.py:528-563
+        p, rpy, lv, av = self._tcp_work()
+        op, _, oq, ol, oa = self._obj_work()
+        return np.hstack([p, pm.quat_from_euler(rpy), lv, av, op, oq, ol, oa]).astype(np.float32)
 
 
 def opensimplex_noise2(seed, x, y):
@@ -763,6 +780,15 @@ class OracleObjectPushEnv(_OracleArmEnv):
         if self.step_counter >= self.max_steps:
             done = True
         return reward, bool(done)
+
+    def oracle_obs(self):                                                                   # :571-609
+        p, rpy, lv, av = self._tcp_work()
+        pos, R = self.cube_pose()
+        op, orpy = self._world_to_work(pos, pm.euler_from_quat(pm.quat_from_mat(R)))
+        _, iq = pm.invert_transform(self.workframe_pos, self.workframe_orn)
+        Rinv = pm.mat_from_quat(iq)
+        return np.hstack([p, rpy, lv, av, op, orpy, Rinv @ np.array(self.cube.linvel[:]), Rinv @ np.array(self.cube.angvel[:]),
+                          self.goal_pos_work, self.goal_rpy_work]).astype(np.float32)
 
     def extended_feature(self):                                                             # :611-629
         p, rpy, _, _ = self._tcp_work()

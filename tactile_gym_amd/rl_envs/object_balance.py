@@ -103,7 +103,12 @@ class ObjectBalanceVecEnv(TactileVecEnv):
                          act_dim=act_dim, oracle_dim=26)
 
     def oracle_obs(self):
-        raise NotImplementedError("oracle observation vector for object_balance is not built yet (SURVEY 8f rank 1)")
+        """object_balance_env.py:528-563: TCP pos, orn (quaternion), lin/ang velocity and the pole's pos, orn, lin/ang velocity, all in
+        the work frame; float32 [N, 26]."""
+        st = self.get_state()
+        tp, _, tq, tl, ta = self._tcp_workframe_state(st)
+        op, _, oq, ol, oa = self._obj_workframe_state(st)
+        return np.hstack([tp, tq, tl, ta, op, oq, ol, oa]).astype(np.float32)
 
 
 class ObjectBalanceEnv:

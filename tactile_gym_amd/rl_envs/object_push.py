@@ -133,10 +133,19 @@ class ObjectPushVecEnv(TactileVecEnv):
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"y": 1, "yRz": 2, "xyRz": 3, "TyRz": 2, "TxTyRz": 3}[modes["movement_mode"]]  # :631-644
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
-                         act_dim=act_dim, oracle_dim=18, feature_dim=12)
+                         act_dim=act_dim, oracle_dim=30, feature_dim=12)
 
     def oracle_obs(self):
-        raise NotImplementedError("oracle observation vector for object_push is not built yet (SURVEY 8f rank 1)")
+        """object_push_env.py:571-609: TCP pos, rpy, lin/ang velocity, cube pos, rpy, lin/ang velocity and the current goal pos, rpy,
+        all in the work frame; float32 [N, 30]."""
+        st = self.get_state()
+        tp, tr, _, tl, ta = self._tcp_workframe_state(st)
+        op, orr, _, ol, oa = self._obj_workframe_state(st)
+        gi = np.minimum(st["goal_id"], self._cfg.traj_n_points - 1)
+        idx = np.arange(self.num_envs)
+        gpos = np.stack([st["traj"][idx, 0, gi], st["traj"][idx, 1, gi], np.zeros(self.num_envs)], axis=1)
+        grpy = np.stack([np.zeros(self.num_envs), np.zeros(self.num_envs), st["traj"][idx, 2, gi]], axis=1)
+        return np.hstack([tp, tr, tl, ta, op, orr, ol, oa, gpos, grpy]).astype(np.float32)
 
 
 class ObjectPushEnv:

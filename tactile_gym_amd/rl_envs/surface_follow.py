@@ -93,10 +93,28 @@ class SurfaceFollowAutoVecEnv(TactileVecEnv):
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"xyz": 1, "xyzRxRy": 3}[modes["movement_mode"]]                              # surface_follow_auto_env.py:96-107
         super().__init__(cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
-                         act_dim=act_dim, oracle_dim=21)
+                         act_dim=act_dim, oracle_dim=20)
 
     def oracle_obs(self):
-        raise NotImplementedError("oracle observation vector for surface_follow is not built yet (SURVEY 8f rank 1)")
+        """base_surface_env.py:789-819: TCP pos, orn (quaternion), lin/ang velocity, goal pos (all work frame), the surface height
+        under the tip and the surface normal there (work frame); float32 [N, 20]."""
+        cfg = self._cfg
+        st = self.get_state()
+        tp, _, tq, tl, ta = self._tcp_workframe_state(st)
+        wf = self._workframe()
+        R, Cc, sc = cfg.surf_rows, cfg.surf_cols, cfg.surf_grid_scale
+        sp = np.array([cfg.stim_pos[k] for k in range(3)])
+        x_bins = np.linspace(sp[0] - (R / 2) * sc, sp[0] + (R / 2) * sc, R)                     # :268-282
+        y_bins = np.linspace(sp[1] - (Cc / 2) * sc, sp[1] + (Cc / 2) * sc, Cc)
+        ti = np.minimum(np.digitize(st["tcp_pos"][:, 1], y_bins), Cc - 1)                       # xy_to_surface_idx :284-300
+        tj = np.minimum(np.digitize(st["tcp_pos"][:, 0], x_bins), R - 1)
+        H = st["heights"]
+        idx = np.arange(self.num_envs)
+        gy, gx = np.gradient(H, sc, axis=(1, 2))                                                # :502-503
+        nrm = np.stack([-gx[idx, ti, tj], -gy[idx, ti, tj], np.ones(self.num_envs)], axis=1)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        gp, _ = wf.pose(st["goal_pos"], np.zeros((self.num_envs, 3)))
+        return np.hstack([tp, tq, tl, ta, gp, (H[idx, ti, tj] + sp[2])[:, None], wf.vec(nrm)]).astype(np.float32)
 
 
 class SurfaceFollowAutoEnv:

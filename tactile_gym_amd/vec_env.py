@@ -233,6 +233,32 @@ class TactileVecEnv:
     def oracle_obs(self):
         raise NotImplementedError
 
+    def _workframe(self):
+        from .pb_math import WorkFrame
+        if not hasattr(self, "_wf"):
+            self._wf = WorkFrame([self._cfg.workframe_pos[k] for k in range(3)], [self._cfg.workframe_rpy[k] for k in range(3)])
+        return self._wf
+
+    def _tcp_workframe_state(self, st):
+        """get_current_TCP_pos_vel_workframe (base_robot_arm.py:153-172) for every env: pos, rpy, orn (quaternion), linear and angular
+        velocity of the TCP frame in the work frame, from the device state read-back (host side; the tactile path does not need it)."""
+        from . import hip_ops, pb_math as pm
+        wf = self._workframe()
+        J, pos, rot = hip_ops.jacobian_tcp(self._robot, st["q"], dtype="f64")
+        rpy_world = pm.euler_from_quat(pm.quat_from_mat(rot))
+        p, rpy = wf.pose(pos, rpy_world)
+        lin = wf.vec(np.einsum("nij,nj->ni", J[:, :3, :], st["qd"]))
+        ang = wf.vec(np.einsum("nij,nj->ni", J[:, 3:, :], st["qd"]))
+        return p, rpy, pm.quat_from_euler(rpy), lin, ang
+
+    def _obj_workframe_state(self, st):
+        """get_obj_pos_workframe / get_obj_vel_workframe (base_object_env.py:118-139): object base pose and velocity in the work frame."""
+        from . import pb_math as pm
+        wf = self._workframe()
+        rpy_world = pm.euler_from_quat(pm.quat_from_mat(st["body_rot"]))
+        p, rpy = wf.pose(st["body_pos"], rpy_world)
+        return p, rpy, pm.quat_from_euler(rpy), wf.vec(st["body_linvel"]), wf.vec(st["body_angvel"])
+
     # ------------------------------------------------------------------ parity / inspection
     def get_state(self):
         """Host copy of the per-env state (tg_get_state)."""

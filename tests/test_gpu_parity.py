@@ -560,3 +560,32 @@ def test_default_solver_equals_literal_solver(edge_modes):
         assert np.array_equal(sa["reset_ticks"], sb["reset_ticks"])
         assert int((oa["tactile"] != ob["tactile"]).sum(axis=(1, 2, 3)).max()) <= 2, step
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_oracle_observation_vectors():
+    """observation_mode "oracle" (SURVEY 8f rank 1): the feature vectors of surface_follow (20), object_balance (26) and object_push
+    (30) against the CPU oracle's restatement of the reference's get_oracle_obs, after a reset and three steps; float32, 1e-5."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleObjectBalanceEnv, OracleObjectPushEnv, OracleSurfaceFollowAutoEnv
+    cases = [("surface_follow-v0", OracleSurfaceFollowAutoEnv, dict(SURF_MODES, observation_mode="oracle"), 3, 20),
+             ("object_balance-v0", OracleObjectBalanceEnv, dict(BAL_MODES, observation_mode="oracle"), 2, 26),
+             ("object_push-v0", OracleObjectPushEnv, dict(PUSH_MODES, observation_mode="oracle"), 2, 30)]
+    for env_id, ocls, modes, act_dim, dim in cases:
+        n = 3
+        venv = tg.make_vec(env_id, num_envs=n, max_steps=50, image_size=[128, 128], env_modes=modes, seed=11, auto_reset=False)
+        assert venv.observation_space["oracle"].shape == (dim,)
+        oracles = [ocls(seed=11 + i, max_steps=50, image_size=(128, 128), env_modes=modes) for i in range(n)]
+        obs = venv.reset()
+        for o in oracles:
+            o.reset()
+        rng = np.random.default_rng(4)
+        for step in range(3):
+            a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+            obs, _, _, _ = venv.step(a)
+            for i, o in enumerate(oracles):
+                o.step(a[i])
+                ref = o.oracle_obs()
+                assert obs["oracle"].shape == (n, dim) and ref.shape == (dim,)
+                assert np.abs(obs["oracle"][i] - ref).max() < 1e-5, (env_id, step, i, obs["oracle"][i], ref)
+        venv.close()

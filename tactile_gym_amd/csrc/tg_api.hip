@@ -62,6 +62,7 @@ struct State {   // device pointers, SoA [field][num_envs]
     double *q, *qd, *qd_target, *tcp_pos, *tcp_rpy, *edge_ang, *embed;
     float *stim_xform, *term_xform, *reward;   // term_xform: camera<-stimulus transform of the terminal observation (fused reset)
     int32_t *step_count, *reset_ticks;
+    int32_t* licence;               // [n] env steps for which the analytic fixed point stays licensed without a new full solve (k_step)
     uint64_t* rng;
     uint8_t* done;
     // surface_follow
@@ -129,10 +130,11 @@ __device__ inline double grad_axis(const double* f, int idx, int n, int stride, 
 // (edge_follow_env.py:371-452) and the camera<-stimulus transform handed to the raster (tactile_sensor.py:150-229).
 template <typename T, int TOPO>
 __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
-                                           T edge_ang, int step_count, bool write_reward_done) {
+                                           T edge_ang, int step_count, bool write_reward_done, const JointTrig<T, Topo<TOPO>::N>* trig = nullptr) {
     const int n = c.num_envs;
     Kin<T, TOPO> k;
-    forward_kinematics<T, TOPO>(m, q, k);
+    if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, k, trig);
+    else forward_kinematics<T, TOPO>(m, q, k);
     V3<T> ptcp; M3<T> Rtcp;
     link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
     T rpy[3];
@@ -215,10 +217,11 @@ template <typename T> __device__ __forceinline__ void scale_actions(const EnvCon
 // BaseRobotArm.tcp_velocity_control (base_robot_arm.py:281-332): TCP limit check, work -> world twist, Jacobian inverse.
 template <typename T, int TOPO>
 __device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const EnvConst<T>& c, const T (&q)[Topo<TOPO>::N], T (&vels)[6],
-                                                     T (&qd_des)[Topo<TOPO>::N]) {
+                                                     T (&qd_des)[Topo<TOPO>::N], const JointTrig<T, Topo<TOPO>::N>* trig = nullptr) {
     constexpr int N = Topo<TOPO>::N;
     Kin<T, TOPO> k;
-    forward_kinematics<T, TOPO>(m, q, k);
+    if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, k, trig);
+    else forward_kinematics<T, TOPO>(m, q, k);
     V3<T> ptcp; M3<T> Rtcp;
     link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
     V3<T> wpos; T wrpy[3], rpyw[3];
@@ -282,24 +285,34 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     scale_actions<T>(c, enc, vels);
     const int step_count = st.step_count[env] + 1;
     st.step_count[env] = step_count;
+    JointTrig<T, N> trig;             // sin/cos of the joint angles: exact here, advanced by angle addition through the ticks
+    trig_init<T, N>(q, trig);
     T qd_des[N];
-    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, &trig);
 #pragma unroll
     for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
 
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
-    JointTrig<T, N> trig;
-    trig_init<T, N>(q, trig);
-    int verified = 0;   // ticks for which sim_tick may take the analytic fixed point (armed by a full solve that converged fast)
-    for (int t = 0; t < c.action_repeat; ++t)
+    // Licence for sim_tick's analytic fixed point.  A full solve that converged to the last bit within 80 % of the sweep budget arms it
+    // for the remaining ticks of this step and for the next 7 steps (<= 0.8 s, < 0.1 rad of joint motion: the Gauss-Seidel contraction
+    // is a smooth function of the configuration and the margin is a factor > 2 in sweeps); a reset drops it.  Wave-uniform.
+    const int lic = st.licence[env];
+    int verified = __all(lic > 0) ? 24 : 0;
+    bool ran_full = false;
+    for (int t = 0; t < c.action_repeat; ++t) {
+        const int before = verified;
         sim_tick<T, TOPO, kMotorVelocity, true, true>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, &trig,
                                                       &verified);
+        if (verified != before - 1 || before <= 0) ran_full = true;   // the analytic path decrements; a full solve sets 24 or -1
+        if (verified < 0) verified = 0;
+    }
+    st.licence[env] = ran_full ? (verified > 0 ? 8 : 0) : lic - 1;
 
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
-    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true);
+    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig);
 }
 
 // ------------------------------------------------------------------------------------------------ reset kernel
@@ -451,6 +464,7 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
         for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
         if (all_small) cv = cv / T(2);
         sim_tick<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, nullptr, &verified);
+        if (verified < 0) verified = 0;
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
@@ -460,6 +474,7 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
         if (pos_err < T(2e-4) && orn_err < T(1e-3) && total_v < T(0.1)) break;
     }
     st.reset_ticks[env] = used;
+    st.licence[env] = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
     finish_env<T, TOPO>(m, c, st, env, q, (T)edge_ang, 0, false);
@@ -1504,13 +1519,13 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&s.tcp_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.tcp_rpy, 3 * n * 8));
     TG_HIP(hipMalloc(&s.edge_ang, n * 8)); TG_HIP(hipMalloc(&s.embed, n * 8));
     TG_HIP(hipMalloc(&s.stim_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.term_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.reward, n * 4));
-    TG_HIP(hipMalloc(&s.step_count, n * 4)); TG_HIP(hipMalloc(&s.reset_ticks, n * 4));
+    TG_HIP(hipMalloc(&s.step_count, n * 4)); TG_HIP(hipMalloc(&s.reset_ticks, n * 4)); TG_HIP(hipMalloc(&s.licence, n * 4));
     TG_HIP(hipMalloc(&s.rng, n * 8)); TG_HIP(hipMalloc(&s.done, n));
     TG_HIP(hipMemset(s.q, 0, nd * 8)); TG_HIP(hipMemset(s.qd, 0, nd * 8)); TG_HIP(hipMemset(s.qd_target, 0, nd * 8));
     TG_HIP(hipMemset(s.tcp_pos, 0, 3 * n * 8)); TG_HIP(hipMemset(s.tcp_rpy, 0, 3 * n * 8));
     TG_HIP(hipMemset(s.edge_ang, 0, n * 8)); TG_HIP(hipMemset(s.embed, 0, n * 8));
     TG_HIP(hipMemset(s.stim_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.term_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.reward, 0, n * 4));
-    TG_HIP(hipMemset(s.step_count, 0, n * 4)); TG_HIP(hipMemset(s.reset_ticks, 0, n * 4)); TG_HIP(hipMemset(s.done, 0, n));
+    TG_HIP(hipMemset(s.step_count, 0, n * 4)); TG_HIP(hipMemset(s.reset_ticks, 0, n * 4)); TG_HIP(hipMemset(s.licence, 0, n * 4)); TG_HIP(hipMemset(s.done, 0, n));
     std::vector<uint64_t> seeds(n);
     for (int i = 0; i < n; ++i) seeds[i] = mix64((uint64_t)i + kGolden);
     TG_HIP(hipMemcpy(s.rng, seeds.data(), n * 8, hipMemcpyHostToDevice));
@@ -1608,7 +1623,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform, s.reward,
-                    s.step_count, s.reset_ticks, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -535,7 +535,7 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
         // the constants below are generous (sqrt(N) <= 3, |v| < 1).  Energy argument: no iterate exceeds 2 ||lambda*||.
         const T lam_star = m.trace_bound * tsqrt_fast(dv2) +
                            dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3) * tsqrt_fast(v2);
-        if (__all(T(4) * lam_star < max_force * dt)) {
+        if (__all(T(2.5) * lam_star < max_force * dt)) {   // energy bound: no iterate exceeds 2 ||lambda*||; 25 % margin on top
             T dq[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) { qd[i] = des[i]; dq[i] = dt * des[i]; q[i] += dq[i]; }
@@ -577,7 +577,7 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
         int sweeps = -1;
         if (__all(no_clamp_possible)) sweeps = pgs_unclamped<T, N>(Minv, rimp, jdi, iters, dv);
         else pgs_clamped<T, N>(Minv, rimp, jdi, maximp, iters, dv);
-        if (verified != nullptr) *verified = (iters > 0 && sweeps > 0 && 5 * sweeps <= 4 * iters) ? 24 : 0;
+        if (verified != nullptr) *verified = (iters > 0 && sweeps > 0 && 5 * sweeps <= 4 * iters) ? 24 : -1;   // -1: a full solve ran and did not qualify
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] += dv[i];
     }

@@ -184,6 +184,19 @@ def main():
                       "object_balance-v0": args.image_size * args.image_size + 300.0,             # config 5: 65.8 KB at 256x256
                       "object_push-v0": args.image_size * args.image_size + 400.0}[args.env]
         achieved = algo_bytes * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure measured with
+        # rocprofv3 on this workload (profiles/r1_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) is reported when the
+        # configuration matches, else null.
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            wl = tr["workload"]
+            if (wl["env"], wl["num_envs"], wl["image_size"], wl["physics"]) == (args.env, n, args.image_size, args.physics) and not args.full_sweeps:
+                k = tr["k_step" if dominant == "k_step" else "k_render_tactile"]
+                traffic = {"bytes_per_launch": round((k["fetch_corrected_kb"] + k["write_kb"]) * 1024.0), "source": "profiles/r1_traffic.json (rocprofv3 PMC)",
+                           "vs_algorithmic": round((k["fetch_corrected_kb"] + k["write_kb"]) / (algo_bytes * n / 1024.0), 3)}
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "env-steps/sec (128x128 tactile obs) at N envs", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -194,7 +207,7 @@ def main():
                        "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world}" + (" + one packed RCCL gather (obs u8, reward f32, done u8) to rank 0 per step, "
                                                                           "overlapped with the next step's simulation" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_env_step": algo_bytes,
                          "kernel_ms": {"k_step": round(k_step, 4), "k_render_tactile": round(k_render_main, 4),
                                        "k_reset_per_launch": round(rst_ms / max(rst_n, 1), 4),

@@ -76,8 +76,10 @@ __device__ __forceinline__ void emit(TriRec* recs, int* count, const float* vx, 
     recs[slot] = r;
 }
 
-// grid: (tiles_x * tiles_y, num_envs); block: 256.  TW = tile edge (128, or 64 for 64x64 images).
-template <int TW>
+// grid: (tiles_x * tiles_y, num_envs, 1 or 2); block: 256.  TW x TH = tile (128 x 128; 128 x 64 for small meshes: half the rows
+// per lane halves the z-buffer registers, 4 instead of 2 workgroups fit a CU, and the per-workgroup set-up of a dozen triangles is
+// negligible; 64 x 64 for 64x64 images).
+template <int TW, int TH>
 __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
@@ -86,10 +88,9 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                                                              int rec_cap /*records of dynamic LDS, even*/,
                                                              const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
                                                              uint8_t* __restrict__ term_out /*fused auto-reset: all three or none*/) {
-    constexpr int kTile = TW;
     constexpr int QPR = TW / 4;            // pixel quads per tile row
     constexpr int RPP = kThreads / QPR;    // tile rows covered per pass of the workgroup
-    constexpr int NK = TW / RPP;           // rows owned by each lane
+    constexpr int NK = TH / RPP;           // rows owned by each lane
     extern __shared__ TriRec recs[];
     __shared__ int count;
     const int env = blockIdx.y;
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     const float hf_zoff = (S.kind == 1) ? S.zoff[env] : 0.0f;
     const double* hf = (S.kind == 1) ? S.heights + (size_t)env * S.rows * S.cols : nullptr;
     const float hf_cx = 0.5f * (float)(S.rows - 1), hf_cy = 0.5f * (float)(S.cols - 1);
-    const int tiles_x = P.W / kTile;
-    const int tile_x = (blockIdx.x % tiles_x) * kTile, tile_y = (blockIdx.x / tiles_x) * kTile;
+    const int tiles_x = P.W / TW;
+    const int tile_x = (blockIdx.x % tiles_x) * TW, tile_y = (blockIdx.x / tiles_x) * TH;
     const int tid = threadIdx.x;
 
     // fused auto-reset: grid z = 1 draws the terminal observation (term_xform -> term_out) of the envs flagged in term_mask and is
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
             z[k][0] = nd.x; z[k][1] = nd.y; z[k][2] = nd.z; z[k][3] = nd.w;
         }
     }
-    const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + kTile), ty1 = (float)(tile_y + kTile);
+    const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + TW), ty1 = (float)(tile_y + TH);
 
     for (int base = 0; base < n_tris; base += rec_cap / 2) {   // a clipped triangle can emit two records
         if (tid == 0) count = 0;
@@ -265,12 +266,19 @@ void launch_render(const RasterParams& P, const Stimulus& S, const float* xform,
     rec_cap = rec_cap > kBatch ? kBatch : (rec_cap < 2 ? 2 : rec_cap);
     const size_t lds = (size_t)rec_cap * sizeof(TriRec);
     if (P.W % 128 == 0 && P.H % 128 == 0) {
-        dim3 grid((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
-        hipLaunchKernelGGL(k_render_tactile<128>, grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
-                           nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+        // small shared mesh and a launch that leaves the chip under-filled (< 2 rounds of 128 x 128 workgroups at 2 per CU): 128 x 64 tiles
+        if (S.kind == 0 && S.n_tris <= 256 && (long)n_envs * (P.W / 128) * (P.H / 128) <= 2048) {
+            dim3 grid((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
+            hipLaunchKernelGGL((k_render_tactile<128, 64>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                               nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+        } else {
+            dim3 grid((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
+            hipLaunchKernelGGL((k_render_tactile<128, 128>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                               nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+        }
     } else {  // 64x64 images
         dim3 grid((P.W / 64) * (P.H / 64), n_envs, term_xform ? 2 : 1);
-        hipLaunchKernelGGL(k_render_tactile<64>, grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+        hipLaunchKernelGGL((k_render_tactile<64, 64>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                            nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
     }
 }

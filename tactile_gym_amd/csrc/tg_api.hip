@@ -1293,7 +1293,7 @@ struct tg_ctx {
     void *d_robot = nullptr, *d_const = nullptr;   // DevRobot<T>, EnvConst<T>
     tg::State st{};
     tg::RasterParams rp{};
-    float *d_nodef_dep = nullptr, *d_verts = nullptr, *d_actions = nullptr;
+    float *d_nodef_dep = nullptr, *d_verts = nullptr, *d_soup = nullptr, *d_actions = nullptr;
     uint8_t* d_nodef_gray = nullptr;   // uint8(nodef_gray)
     uint8_t *d_border = nullptr, *d_obs = nullptr, *d_term = nullptr, *d_mask = nullptr;
     int32_t* d_tris = nullptr;
@@ -1605,7 +1605,14 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
         TG_HIP(hipMalloc(&c->d_verts, (size_t)stim->n_verts * 12)); TG_HIP(hipMemcpy(c->d_verts, stim->verts, (size_t)stim->n_verts * 12, hipMemcpyHostToDevice));
         TG_HIP(hipMalloc(&c->d_tris, (size_t)stim->n_tris * 12)); TG_HIP(hipMemcpy(c->d_tris, stim->tris, (size_t)stim->n_tris * 12, hipMemcpyHostToDevice));
         c->n_tris = stim->n_tris;
-        c->stim.kind = 0; c->stim.verts = c->d_verts; c->stim.tris = c->d_tris; c->stim.n_tris = stim->n_tris;
+        {
+            std::vector<float> soup((size_t)stim->n_tris * 9);
+            for (int t = 0; t < stim->n_tris; ++t)
+                for (int k = 0; k < 3; ++k)
+                    for (int a = 0; a < 3; ++a) soup[(size_t)t * 9 + 3 * k + a] = stim->verts[3 * (size_t)stim->tris[3 * t + k] + a];
+            TG_HIP(hipMalloc(&c->d_soup, soup.size() * 4 + 4)); TG_HIP(hipMemcpy(c->d_soup, soup.data(), soup.size() * 4, hipMemcpyHostToDevice));
+        }
+        c->stim.kind = 0; c->stim.verts = c->d_verts; c->stim.tris = c->d_tris; c->stim.soup = c->d_soup; c->stim.n_tris = stim->n_tris;
     }
     TG_HIP(hipMalloc(&c->d_obs, npix * n)); TG_HIP(hipMemset(c->d_obs, 0, npix * n));
     TG_HIP(hipMalloc(&c->d_term, npix * n)); TG_HIP(hipMemset(c->d_term, 0, npix * n));
@@ -1623,7 +1630,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform, s.reward,
-                    s.step_count, s.reset_ticks, s.licence, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1969,7 +1976,16 @@ int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, cons
     TG_HIP(hipMemset(oo.p, 0, npix * n));
     RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
     Stimulus S{};
-    S.kind = 0; S.verts = (const float*)vv.p; S.tris = (const int32_t*)tt.p; S.n_tris = mesh->n_tris;
+    DevBuf sp;
+    {
+        std::vector<float> soup((size_t)mesh->n_tris * 9);
+        for (int t = 0; t < mesh->n_tris; ++t)
+            for (int k = 0; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) soup[(size_t)t * 9 + 3 * k + a] = mesh->verts[3 * (size_t)mesh->tris[3 * t + k] + a];
+        if (sp.alloc(soup.size() * 4 + 4)) return fail(-2, "hipMalloc failed");
+        TG_HIP(hipMemcpy(sp.p, soup.data(), soup.size() * 4, hipMemcpyHostToDevice));
+    }
+    S.kind = 0; S.verts = (const float*)vv.p; S.tris = (const int32_t*)tt.p; S.soup = (const float*)sp.p; S.n_tris = mesh->n_tris;
     launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, nullptr, nullptr, nullptr, 0);
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));

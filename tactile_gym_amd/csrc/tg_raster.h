@@ -25,6 +25,7 @@ struct Stimulus {
     int kind;                 // 0 mesh, 1 heightfield
     const float* verts;       // mesh
     const int32_t* tris;
+    const float* soup;        // mesh, pre-expanded on the host: [n_tris][3][3] vertex coordinates (what the kernel reads)
     int n_tris;
     const double* heights;    // heightfield: [n_envs][rows*cols]
     const float* zoff;        // [n_envs]

@@ -60,7 +60,8 @@ __device__ __forceinline__ void project_vertex(float cx, float cy, float cw, con
     d = P.C0 + P.C1 * iw;
 }
 
-__device__ __forceinline__ void emit(TriRec* recs, int* count, const float* vx, const float* vy, const float* vw, int a, int b, int c,
+// Returns false when the record buffer is full (nothing written): the caller restarts from this triangle in the next round.
+__device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const float* vx, const float* vy, const float* vw, int a, int b, int c,
                                      const RasterParams& P, float tx0, float ty0, float tx1, float ty1) {
     TriRec r;
     project_vertex(vx[a], vy[a], vw[a], P, r.x0, r.y0, r.d0);
@@ -70,10 +71,12 @@ __device__ __forceinline__ void emit(TriRec* recs, int* count, const float* vx, 
     r.ymin = fminf(r.y0, fminf(r.y1, r.y2)); r.ymax = fmaxf(r.y0, fmaxf(r.y1, r.y2));
     r.dmin = fminf(r.d0, fminf(r.d1, r.d2)) - kDepthSlack;
     // conservative culls: outside this workgroup's tile, or entirely behind the undeformed skin/body depth image
-    if (r.xmax < tx0 || r.xmin > tx1 || r.ymax < ty0 || r.ymin > ty1) return;
-    if (r.dmin >= P.zcull) return;
-    int slot = atomicAdd(count, 1);
+    if (r.xmax < tx0 || r.xmin > tx1 || r.ymax < ty0 || r.ymin > ty1) return true;
+    if (r.dmin >= P.zcull) return true;
+    const int slot = atomicAdd(count, 1);
+    if (slot >= cap) return false;
     recs[slot] = r;
+    return true;
 }
 
 // grid: (tiles_x * tiles_y, num_envs, 1 or 2); block: 256.  TW x TH = tile (128 x 128; 128 x 64 for small meshes: half the rows
@@ -91,9 +94,12 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     constexpr int QPR = TW / 4;            // pixel quads per tile row
     constexpr int RPP = kThreads / QPR;    // tile rows covered per pass of the workgroup
     constexpr int NK = TH / RPP;           // rows owned by each lane
-    extern __shared__ TriRec recs[];                       // rec_cap records, then (heightfield stimulus) rows x cols float vertex heights
-    float* hfl = reinterpret_cast<float*>(recs + rec_cap);
-    __shared__ int count;
+    extern __shared__ TriRec recs[];                       // rec_cap records, then (heightfield stimulus) per vertex: height, projected
+    float* hfl = reinterpret_cast<float*>(recs + rec_cap); // depth (-1: behind the near plane), tile outcode; then the survivor list
+    float* hvd = hfl + (S.kind == 1 ? S.rows * S.cols : 0);
+    unsigned short* surv = reinterpret_cast<unsigned short*>(hvd + (S.kind == 1 ? S.rows * S.cols : 0));
+    uint8_t* hcode = reinterpret_cast<uint8_t*>(surv + (S.kind == 1 ? S.n_tris : 0));
+    __shared__ int count, next_start, n_surv;
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
     const int n_tris = S.n_tris;
@@ -126,18 +132,61 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
             z[k][0] = nd.x; z[k][1] = nd.y; z[k][2] = nd.z; z[k][3] = nd.w;
         }
     }
-    if (S.kind == 1) {   // stage the env's vertex heights in LDS once (one coalesced 32 KB read) instead of three dependent global loads
-                         // per triangle; same expression as the direct fetch: (float)h - zoff
-        for (int i = tid; i < S.rows * S.cols; i += kThreads) hfl[i] = (float)hf[i] - hf_zoff;
+    const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + TW), ty1 = (float)(tile_y + TH);
+    if (S.kind == 1) {   // stage the env's vertices in LDS once (one coalesced 32 KB read instead of three dependent global loads per
+                         // triangle): the height, same expression as a direct fetch, (float)h - zoff, and the projected depth of the
+                         // vertex and its window position (depth -1 when it is behind the near plane), which lets the triangle loop apply emit()'s
+                         // depth and tile culls to the 7 938 triangles with a handful of LDS reads, before any transform or clipping
+        for (int i = tid; i < S.rows * S.cols; i += kThreads) {
+            const float vz = (float)hf[i] - hf_zoff;
+            hfl[i] = vz;
+            const int vi = i % S.rows, vj = i / S.rows;
+            const float vx = ((float)vi - hf_cx) * S.scale, vy = ((float)vj - hf_cy) * S.scale;
+            const float cx = ((M[0] * vx + M[1] * vy) + M[2] * vz) + M[9];
+            const float cy = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
+            const float cw = -(((M[6] * vx + M[7] * vy) + M[8] * vz) + M[11]);
+            float d = -1.0f, sx = 0.0f, sy = 0.0f;
+            if (cw >= P.near_) project_vertex(cx, cy, cw, P, sx, sy, d);
+            hvd[i] = d;
+            hcode[i] = (uint8_t)((sx < tx0 ? 1 : 0) | (sx > tx1 ? 2 : 0) | (sy < ty0 ? 4 : 0) | (sy > ty1 ? 8 : 0));   // tile outcode
+        }
         __syncthreads();
     }
-    const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + TW), ty1 = (float)(tile_y + TH);
 
-    for (int base = 0; base < n_tris; base += rec_cap / 2) {   // a clipped triangle can emit two records
-        if (tid == 0) count = 0;
+    // Heightfield: first pass over all triangles with the cheap exact culls on the staged per-vertex data; the survivors (mostly the
+    // triangles that straddle the near plane, a few hundred of 7 938) go to a list, so that the expensive path below runs on dense
+    // wavefronts of survivors instead of once per loop iteration for whichever single lane happened to need it.
+    int total = n_tris;
+    if (S.kind == 1) {
+        if (tid == 0) n_surv = 0;
         __syncthreads();
-        const int lim = min(n_tris, base + rec_cap / 2);
-        for (int t = base + tid; t < lim; t += kThreads) {
+        for (int t = tid; t < n_tris; t += kThreads) {
+            const int cell = t >> 1, half = t & 1;
+            const int ci = cell % (S.rows - 1), cj = cell / (S.rows - 1);
+            const int v0 = (cj + 0) * S.rows + ci + (half == 0 ? 0 : 1);          // (i,j) | (i+1,j)
+            const int v1 = (cj + 1) * S.rows + ci;                                // (i,j+1)
+            const int v2 = (cj + (half == 0 ? 0 : 1)) * S.rows + ci + 1;          // (i+1,j) | (i+1,j+1)
+            const float d0 = hvd[v0], d1 = hvd[v1], d2 = hvd[v2];
+            if (d0 < 0.0f && d1 < 0.0f && d2 < 0.0f) continue;   // wholly behind the near plane (the hills of the surface rise past the
+                                                                 // camera elsewhere): the clipper would return no polygon
+            if (d0 >= 0.0f && d1 >= 0.0f && d2 >= 0.0f) {        // not clipped: the very culls of emit()
+                if (fminf(d0, fminf(d1, d2)) - kDepthSlack >= P.zcull) continue;
+                if ((hcode[v0] & hcode[v1] & hcode[v2]) != 0) continue;   // all three on one outer side of the tile = emit()'s bbox test
+            }
+            surv[atomicAdd(&n_surv, 1)] = (unsigned short)t;
+        }
+        __syncthreads();
+        total = n_surv;
+    }
+
+    // Rounds: every lane takes work items (triangles, or survivors of the first pass) from `start`; a projected triangle that passes
+    // emit()'s culls takes a record slot; when the buffer is full the smallest item index that found no room becomes the next round's
+    // start (re-emitting a triangle is harmless for a depth-min).  Normally one round: two barriers.
+    for (int start = 0; start < total;) {
+        if (tid == 0) { count = 0; next_start = total; }
+        __syncthreads();
+        for (int it = start + tid; it < total; it += kThreads) {
+            const int t = S.kind == 1 ? (int)surv[it] : it;
             float cx[3], cy[3], cw[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -176,11 +225,14 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                     ++no;
                 }
             }
-            if (no >= 3) emit(recs, &count, ox, oy, ow, 0, 1, 2, P, tx0, ty0, tx1, ty1);
-            if (no == 4) emit(recs, &count, ox, oy, ow, 0, 2, 3, P, tx0, ty0, tx1, ty1);
+            bool ok = true;
+            if (no >= 3) ok = emit(recs, &count, rec_cap, ox, oy, ow, 0, 1, 2, P, tx0, ty0, tx1, ty1);
+            if (ok && no == 4) ok = emit(recs, &count, rec_cap, ox, oy, ow, 0, 2, 3, P, tx0, ty0, tx1, ty1);
+            if (!ok) { atomicMin(&next_start, it); break; }
         }
         __syncthreads();
-        const int n = count;
+        const int n = min(count, rec_cap);
+        start = next_start;
         for (int t = 0; t < n; ++t) {
             const TriRec r = recs[t];   // same address on every lane: LDS broadcast
 #pragma unroll
@@ -279,7 +331,8 @@ void launch_render(const RasterParams& P, const Stimulus& S, const float* xform,
                    uint8_t* save_prev, const float* term_xform, const uint8_t* term_mask, uint8_t* term_out, hipStream_t stream) {
     int rec_cap = 2 * S.n_tris;
     rec_cap = rec_cap > kBatch ? kBatch : (rec_cap < 2 ? 2 : rec_cap);
-    const size_t lds = (size_t)rec_cap * sizeof(TriRec) + (S.kind == 1 ? (size_t)S.rows * S.cols * sizeof(float) : 0);
+    if (S.kind == 1 && rec_cap > 256) rec_cap = 256;   // a dozen heightfield triangles survive the depth cull; more just take another round
+    const size_t lds = (size_t)rec_cap * sizeof(TriRec) + (S.kind == 1 ? (size_t)S.rows * S.cols * (2 * sizeof(float) + 1) + (size_t)S.n_tris * sizeof(unsigned short) + 16 : 0);
     if (P.W % 128 == 0 && P.H % 128 == 0) {
         // small shared mesh and a launch that leaves the chip under-filled (< 2 rounds of 128 x 128 workgroups at 2 per CU): 128 x 64 tiles
         if (S.kind == 0 && S.n_tris <= 256 && (long)n_envs * (P.W / 128) * (P.H / 128) <= 2048) {

@@ -14,5 +14,5 @@ for env_id, modes, ad in (("edge_follow-v0", MODES, 2), ("surface_follow-v0", SU
         v.step_async(a.uniform_(-0.25, 0.25)); v.sync()
     L.tg_debug_raster(buf); b1 = np.array(buf[:], dtype=np.float64)
     d = b1 - b0; nwg = d[6]
-    print(env_id, "WGs", nwg, "triangle loop cycles per wave: w0 %.0f w1 %.0f w2 %.0f w3 %.0f | w0: barrier1 wait %.0f barrier2 wait %.0f" % (d[0]/nwg, d[1]/nwg, d[2]/nwg, d[3]/nwg, d[4]/nwg, d[5]/nwg))
+    print(env_id, "WGs", nwg, "final phase cycles: issue loads %.0f, wait loads %.0f, compute+issue stores %.0f, drain stores %.0f" % (d[0]/nwg, d[1]/nwg, d[2]/nwg, d[3]/nwg))
     v.close()

@@ -589,3 +589,48 @@ def test_oracle_observation_vectors():
                 assert obs["oracle"].shape == (n, dim) and ref.shape == (dim,)
                 assert np.abs(obs["oracle"][i] - ref).max() < 1e-5, (env_id, step, i, obs["oracle"][i], ref)
         venv.close()
+
+
+@pytest.mark.gpu
+def test_full_size_properties_surface_balance_push():
+    """BASELINE configs 3-5 at their per-GPU size (1024 envs; balance at 256x256): run-to-run determinism and domain invariants that
+    do not need the oracle: finite state, the pole stays tied to the TCP, the cube stays on the table and is pushed forward, goal
+    indices in range, the tactile image shows contact in most envs, every heightfield sample within the generator's range."""
+    import tactile_gym_amd as tg
+    n = 1024
+    cases = [("surface_follow-v0", dict(SURF_MODES), 3, 128, 3), ("object_balance-v0", dict(BAL_MODES), 2, 256, 3),
+             ("object_push-v0", dict(PUSH_MODES, rand_init_orn=True, rand_obj_mass=True), 2, 128, 4)]
+    for env_id, modes, act_dim, size, steps in cases:
+        rng = np.random.default_rng(17)
+        acts = rng.uniform(-0.25, 0.25, size=(steps, n, act_dim)).astype(np.float32)
+        if env_id == "object_push-v0":
+            acts[:] = 0.0                                    # TyRz with zero input: straight ahead at the maximum pushing speed
+        outs = []
+        for rep in range(2):
+            venv = tg.make_vec(env_id, num_envs=n, max_steps=200, image_size=[size, size], env_modes=modes, seed=9, auto_reset=False)
+            venv.reset()
+            st0 = venv.get_state()
+            for k in range(steps):
+                obs, rew, done, _ = venv.step(acts[k])
+            outs.append((obs["tactile"].copy(), rew.copy(), done.copy(), venv.get_state(), st0))
+            venv.close()
+        (img, rew, done, st, st0), (img2, rew2, done2, st2, _) = outs
+        assert np.array_equal(img, img2) and np.array_equal(rew, rew2) and np.array_equal(done, done2), env_id
+        assert np.array_equal(st["q"], st2["q"]), env_id
+        assert np.isfinite(st["q"]).all() and np.isfinite(rew).all() and img.shape == (n, size, size, 1)
+        contact = (img.reshape(n, -1) > 0).any(axis=1).mean()
+        if env_id == "surface_follow-v0":
+            assert np.abs(st["heights"]).max() <= 0.025 * 0.8660254 + 1e-12      # OpenSimplex 2-D range x height_range
+            assert len(np.unique(st["heights"][:, 5, 7])) > n // 2               # per-env surfaces (noise2(0, 0) is 0 for every seed)
+            assert contact > 0.5
+        elif env_id == "object_balance-v0":
+            gap = np.linalg.norm(st["body_pos"] - st0["body_pos"], axis=1)
+            assert (gap < 0.1).all() and np.isfinite(st["body_rot"]).all()       # 3 steps: nobody has drifted 0.1 m yet
+            assert np.abs(np.linalg.det(st["body_rot"]) - 1.0).max() < 1e-9      # orientation stays a rotation
+        else:
+            assert np.abs(st["body_pos"][:, 2] - 0.04).max() < 2e-3              # the cube rests on the table
+            fwd = st["body_pos"][:, 1] - st0["body_pos"][:, 1]
+            assert (fwd > 5e-4).mean() > 0.95                                    # pushed forward (world +y) in nearly every env
+            assert ((st["goal_id"] >= 0) & (st["goal_id"] <= 10)).all()
+            assert (st["obj_mass"] >= 0.4).all() and (st["obj_mass"] <= 0.8).all()
+            assert contact > 0.9

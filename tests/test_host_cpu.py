@@ -108,3 +108,56 @@ def test_rng_stream_is_splitmix64():
     assert [r2.random() for _ in range(3)] == a
     assert Rng(2).random() != a[0]
     assert Rng.mix(0) == 0 and Rng.mix(1) == 0x5692161D100B05E5   # SplitMix64 finaliser known answer
+
+
+def test_pb_math_matches_oracle_restatement():
+    """tactile_gym_amd/pb_math.py (product side, batched) against oracle/pb_math.py (checker, scalar): the PyBullet frame helpers the
+    oracle-observation vectors chain, including the gimbal branches of getEulerFromQuaternion."""
+    from oracle import pb_math as O
+    from tactile_gym_amd import pb_math as P
+    rng = np.random.default_rng(0)
+    rpy = rng.uniform(-3.1, 3.1, size=(64, 3))
+    rpy[::8, 1] = np.pi / 2
+    rpy[4::8, 1] = -np.pi / 2
+    q = P.quat_from_euler(rpy)
+    R = P.mat_from_quat(q)
+    e = P.euler_from_quat(q)
+    qm = P.quat_from_mat(R)
+    p = rng.normal(size=(64, 3))
+    ip, iq = P.invert_transform(p, q)
+    for i in range(64):
+        assert np.allclose(q[i], O.quat_from_euler(rpy[i]), atol=1e-15)
+        assert np.allclose(R[i], O.mat_from_quat(q[i]), atol=1e-15)
+        assert np.allclose(e[i], O.euler_from_quat(q[i]), atol=1e-12)
+        assert np.allclose(qm[i], O.quat_from_mat(R[i]), atol=1e-15)
+        op, oq = O.invert_transform(p[i], q[i])
+        assert np.allclose(ip[i], op, atol=1e-15) and np.allclose(iq[i], oq, atol=1e-15)
+    wf = P.WorkFrame([0.25, -0.1, 0.04], [-np.pi, 0.0, np.pi / 2])
+    wp, wr = wf.pose(p, rpy)
+    back_p, back_q = P.multiply_transforms(wf.pos, wf.orn, wp, P.quat_from_euler(wr))
+    assert np.allclose(back_p, p, atol=1e-12) and np.allclose(np.abs(np.sum(back_q * q, axis=1)), 1.0, atol=1e-12)
+
+
+def test_object_push_config_and_registry():
+    """object_push-v0 host logic without a GPU: env-id resolution, the config struct filled from the reference's env_modes
+    (object_push_env.py line by line), error behaviour on bad modes."""
+    import tactile_gym_amd as tg
+    from tactile_gym_amd import _capi as capi
+    from tactile_gym_amd.rl_envs import object_push as op
+    assert "object_push-v0" in tg.registered_ids()
+    modes = dict(op.env_modes_default, arm_type="mg400", tactile_sensor_name="digitac", observation_mode="tactile_and_feature")
+    cfg, robot, sensor, mesh, m, tip = op.build_config(8, 1000, (128, 128), modes)
+    assert cfg.env_kind == capi.ENV_OBJECT_PUSH and cfg.action_repeat == 24 and cfg.solver_iterations == 150
+    assert cfg.movement_mode == capi.PMOVE["TyRz"] and cfg.traj_n_points == 10 and cfg.cone_friction == 1
+    assert abs(cfg.mu_tip - 0.65) < 1e-12 and abs(cfg.mu_table - 0.065) < 1e-12 and cfg.tip_stiffness == 300.0
+    assert [cfg.workframe_pos[k] for k in range(3)] == [0.25, -0.1, 0.04] and abs(cfg.obj_init_pos[1] + 0.06) < 1e-15
+    assert robot.ndof == 8 and robot.topology == 1 and cfg.n_tip_verts == tip.shape[0] > 100 and 0 <= cfg.tip_link < 5
+    assert abs(cfg.obj_mass - 0.491) < 1e-9
+    with pytest.raises(KeyError):
+        op.build_config(8, 1000, (128, 128), {"movement_mode": "TyRz"})
+    with pytest.raises(ValueError):
+        op.build_config(8, 1000, (128, 128), dict(modes, movement_mode="sideways"))
+    with pytest.raises(NotImplementedError):
+        op.build_config(8, 1000, (128, 128), dict(modes, arm_type="ur5"))
+    with pytest.raises(SystemExit):
+        op.build_config(8, 1000, (128, 128), dict(modes, traj_type="zigzag"))

@@ -130,7 +130,9 @@ typedef struct {
     int32_t traj_n_points;                  /* 10 (:229), <= TG_MAX_TRAJ_POINTS */
     int32_t rand_init_orn, rand_obj_mass;   /* env_modes flags (:168-192) */
     int32_t tip_link, n_tip_verts;          /* moving link carrying the tip's collision core; its convex-hull vertices */
-    int32_t cone_friction, reserved1;       /* enableConeFriction=1 (base_tactile_env.py:128-130) */
+    int32_t cone_friction;                  /* enableConeFriction=1 (base_tactile_env.py:128-130) */
+    int32_t surf_goal_variant;              /* surface_follow: 0 = -v0 auto-drive (surface_follow_auto_env.py), 1 = -v1: every action dimension from the
+                                             * agent, dense reward -(goal_xy + 10 surf + w_norm cos) (surface_follow_goal_env.py:27-90) */
     const double* tip_verts;                /* host, [n_tip_verts][3], link frame; copied at tg_create */
     double obj_half[3];                     /* cube half extents 0.04 (:45-46) */
     double obj_init_pos[3];                 /* (:160) */

@@ -462,6 +462,42 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         return np.hstack([p, q, lv, av, gp, self.surface_array[self.tip_i, self.tip_j, 2], nrm]).astype(np.float32)
 
 
+class OracleSurfaceFollowGoalEnv(OracleSurfaceFollowAutoEnv):
+    """surface_follow-v1 (surface_follow_goal/surface_follow_goal_env.py): same surface / goal / termination, but every action
+    dimension comes from the agent and the dense reward also pulls towards the goal."""
+
+    def _encode_actions(self, a):                                                        # surface_follow_goal_env.py:27-52
+        enc = np.zeros(6)
+        if self.modes["movement_mode"] == "xyz":
+            enc[0], enc[1], enc[2] = a[0], a[1], a[2]
+        else:  # xyzRxRy
+            enc[0], enc[1], enc[2], enc[3], enc[4] = a[0], a[1], a[2], a[3], a[4]
+        return enc
+
+    def _get_step_data(self):                                                            # :69-90
+        rew_auto, done = super()._get_step_data()                                       # -(surf_dist + w_norm cos_dist)
+        R = pm.mat_from_quat(self.cur_tcp_orn)
+        surf_z = self.surface_array[self.tip_i, self.tip_j, 2]
+        surf_dist = abs((self.cur_tcp_pos + R @ np.array([0, 0, -self.embed_dist]))[2] - surf_z)
+        n = self.surface_normals[self.tip_i, self.tip_j, :]
+        t = R @ np.array([0, 0, -1])
+        cos_dist = 1 - np.dot(n, t) / (np.linalg.norm(n) * np.linalg.norm(t))
+        goal_dist = float(np.linalg.norm(self.cur_tcp_pos[:2] - self.goal_pos_world[:2]))   # xy_dist_to_goal, base_surface_env.py:693-699
+        w_norm = 0.0 if self.modes["movement_mode"] in ("yz", "xyz") else 1.0
+        return -((1.0 * goal_dist) + (10.0 * surf_dist) + (w_norm * cos_dist)), done
+
+    def extended_feature(self):                                                          # :92-110
+        p, _, _, _ = self._tcp_work()
+        gp, _ = self._world_to_work(self.goal_pos_world, np.zeros(3))
+        return np.hstack([p, gp])
+
+    def _observation(self):
+        obs = super()._observation()
+        if "feature" in self.modes["observation_mode"]:
+            obs["extended_feature"] = self.extended_feature()
+        return obs
+
+
 class OracleObjectBalanceEnv(_OracleArmEnv):
     """object_balance-v0, object_mode "pole" (nonprehensile_manipulation/object_balance/object_balance_env.py +
     base_object_env.py): UR5 + TacTip pointing up, a pole tied to the TCP by a point-to-point constraint."""

@@ -76,7 +76,7 @@ class TgConfig(C.Structure):
         ("obj_base_width", C.c_double), ("obj_base_height", C.c_double), ("obj_init_rpy", _d3), ("ext_force", _d3),
         ("term_deg", C.c_double), ("term_pos", C.c_double), ("p2p_erp", C.c_double), ("p2p_max_impulse", C.c_double),
         ("traj_type", C.c_int32), ("traj_n_points", C.c_int32), ("rand_init_orn", C.c_int32), ("rand_obj_mass", C.c_int32),
-        ("tip_link", C.c_int32), ("n_tip_verts", C.c_int32), ("cone_friction", C.c_int32), ("reserved1", C.c_int32),
+        ("tip_link", C.c_int32), ("n_tip_verts", C.c_int32), ("cone_friction", C.c_int32), ("surf_goal_variant", C.c_int32),
         ("tip_verts", C.POINTER(C.c_double)),
         ("obj_half", _d3), ("obj_init_pos", _d3), ("table_z", C.c_double), ("mu_table", C.c_double), ("mu_tip", C.c_double),
         ("margin_cube", C.c_double), ("margin_tip", C.c_double), ("contact_breaking", C.c_double), ("contact_erp", C.c_double),

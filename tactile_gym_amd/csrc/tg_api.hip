@@ -40,7 +40,7 @@ template <typename T> struct EnvConst {
     M3<T> cam_rot;               // R(cam_rpy) in the sensor-body frame
     T cam_pos[3];
     // surface_follow
-    int env_kind, surf_rows, surf_cols;
+    int env_kind, surf_rows, surf_cols, surf_goal;
     double surf_scale, surf_range, surf_interp, surf_extent, auto_scale;
     double xbin_lo, xbin_hi, ybin_lo, ybin_hi;   // np.linspace bounds of x_bins / y_bins (base_surface_env.py:258-282)
     // object_balance
@@ -176,8 +176,9 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         const T surf_dist = tabs((ptcp.z + emb.z) - surf_z);
         const T cos_sim = dot(nrm, tipv) / (norm(nrm) * norm(tipv));
         const T w_norm = (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_XYZ) ? T(0) : T(1);
-        const T reward = -((T(1) * surf_dist) + (w_norm * (T(1) - cos_sim)));
         const T gdx = ptcp.x - (T)st.goal[0 * n + env], gdy = ptcp.y - (T)st.goal[1 * n + env], gdz = ptcp.z - (T)st.goal[2 * n + env];
+        const T reward = c.surf_goal ? -((T(1) * tsqrt(gdx * gdx + gdy * gdy)) + (T(10) * surf_dist) + (w_norm * (T(1) - cos_sim)))   // goal_env :69-90
+                                     : -((T(1) * surf_dist) + (w_norm * (T(1) - cos_sim)));
         const bool done = tsqrt(gdx * gdx + gdy * gdy + gdz * gdz) < c.term_dist || step_count >= c.max_steps;
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
@@ -274,6 +275,9 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
         if (c.movement_mode == TG_MOVE_XYZ) enc[2] = (T)a[2];
         else if (c.movement_mode == TG_MOVE_XYRZ) enc[5] = (T)a[2];
         else if (c.movement_mode == TG_MOVE_XYZRZ) { enc[2] = (T)a[2]; enc[5] = (T)a[3]; }
+    } else if (c.surf_goal) {                             // surface_follow_goal_env.py:27-52: every dimension from the agent
+        enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2];
+        if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[3]; enc[4] = (T)a[4]; }
     } else {                                              // surface_follow_auto_env.py:27-57: xy are driven toward the goal
         enc[0] = (T)((st.dir[0 * n + env] * (double)c.max_action) * c.auto_scale);
         enc[1] = (T)((st.dir[1 * n + env] * (double)c.max_action) * c.auto_scale);
@@ -1239,12 +1243,16 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.mass_lo = cfg.mass_lo; c.mass_hi = cfg.mass_hi; c.init_orn_range = cfg.init_orn_range; c.traj_ang_range = cfg.traj_ang_range;
         c.obj_mass0 = cfg.obj_mass;
     } else {
-        switch (cfg.movement_mode) {     // surface_follow_auto_env.py:96-107
-            case TG_SMOVE_YZ: case TG_SMOVE_XYZ: c.act_dim = 1; break;
-            case TG_SMOVE_YZRX: c.act_dim = 2; break;
-            case TG_SMOVE_XYZRXRY: c.act_dim = 3; break;
+        switch (cfg.movement_mode) {     // surface_follow_auto_env.py:96-107 / surface_follow_goal_env.py:112-123
+            case TG_SMOVE_YZ: c.act_dim = cfg.surf_goal_variant ? 2 : 1; break;
+            case TG_SMOVE_XYZ: c.act_dim = cfg.surf_goal_variant ? 3 : 1; break;
+            case TG_SMOVE_YZRX: c.act_dim = cfg.surf_goal_variant ? 3 : 2; break;
+            case TG_SMOVE_XYZRXRY: c.act_dim = cfg.surf_goal_variant ? 5 : 3; break;
             default: return fail(-1, "Incorrect movement mode specified");
         }
+        c.surf_goal = cfg.surf_goal_variant ? 1 : 0;
+        if (c.surf_goal && (cfg.movement_mode == TG_SMOVE_YZ || cfg.movement_mode == TG_SMOVE_YZRX))
+            return fail(-1, "surface_follow goal variant: the 1-D surface modes (yz, yzRx) are not built");
         if (cfg.reward_mode != TG_REWARD_DENSE) return fail(-1, "surface_follow: only the dense reward is built");
         if (cfg.surf_rows < 2 || cfg.surf_cols < 2) return fail(-1, "surface_follow: heightfield needs at least 2x2 samples");
         c.surf_rows = cfg.surf_rows; c.surf_cols = cfg.surf_cols;
@@ -1617,7 +1625,7 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&c->d_obs, npix * n)); TG_HIP(hipMemset(c->d_obs, 0, npix * n));
     TG_HIP(hipMalloc(&c->d_term, npix * n)); TG_HIP(hipMemset(c->d_term, 0, npix * n));
     TG_HIP(hipMalloc(&c->d_mask, n));
-    TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 4 * sizeof(float)));
+    TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 6 * sizeof(float)));
     c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border, sensor->nodef_dep);
     *out = c;
     return 0;

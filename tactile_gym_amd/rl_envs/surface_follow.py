@@ -1,8 +1,8 @@
-"""surface_follow-v0 (auto-drive variant) on the HIP path.
+"""surface_follow-v0 (auto-drive variant) and -v1 (goal variant) on the HIP path.
 
-Reference: tactile_gym/rl_envs/exploration/surface_follow/base_surface_env.py (surface generation, goal, rewards) and
-surface_follow_auto/surface_follow_auto_env.py (action encoding, dense reward).  -v1 (goal features) and -v2 (vertical
-surface, `forward` sensor) are registered but not built yet.
+Reference: tactile_gym/rl_envs/exploration/surface_follow/base_surface_env.py (surface generation, goal, rewards),
+surface_follow_auto/surface_follow_auto_env.py and surface_follow_goal/surface_follow_goal_env.py (action encoding, dense
+reward, extended_feature).  -v2 (vertical surface, `forward` sensor) is registered but not built yet.
 """
 import math
 
@@ -24,7 +24,7 @@ env_modes_default = {  # surface_follow_auto_env.py:6-12
 }
 
 
-def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64", auto_reset=True, device=0):
+def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64", auto_reset=True, device=0, goal_variant=False):
     modes = dict(env_modes)
     for k in ("movement_mode", "control_mode", "noise_mode", "observation_mode", "reward_mode", "arm_type", "tactile_sensor_name"):
         if k not in modes:
@@ -78,6 +78,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.surf_rows, cfg.surf_cols, cfg.surf_center_z = 64, 64, 1                                 # :240-243
     cfg.surf_grid_scale, cfg.surf_height_range, cfg.surf_interp, cfg.surf_xy_extent = 0.006, height_range, 0.05, extent
     cfg.auto_action_scale = {"tactip": 1.0, "digitac": 0.9, "digit": 0.7}[t_s_name]             # surface_follow_auto_env.py:33-41
+    cfg.surf_goal_variant = int(bool(goal_variant))
     tg = load_tgmodel(arm, t_s_type, t_s_name)
     robot = make_robot(tg, REST_POSES[arm][t_s_name][t_s_type], t_s_name)
     sensor = SensorDesc(t_s_name, t_s_type, image_size, turn_off_border=False)
@@ -115,6 +116,69 @@ class SurfaceFollowAutoVecEnv(TactileVecEnv):
         nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
         gp, _ = wf.pose(st["goal_pos"], np.zeros((self.num_envs, 3)))
         return np.hstack([tp, tq, tl, ta, gp, (H[idx, ti, tj] + sp[2])[:, None], wf.vec(nrm)]).astype(np.float32)
+
+
+class SurfaceFollowGoalVecEnv(SurfaceFollowAutoVecEnv):
+    """surface_follow-v1: the agent drives every dimension; `tactile_and_feature` adds [tcp_pos, goal_pos] in the work frame."""
+
+    def __init__(self, num_envs, max_steps=200, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False):
+        cfg, robot, sensor, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device,
+                                                 goal_variant=True)
+        cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))
+        self.env_modes = modes
+        self.min_action, self.max_action = cfg.min_action, cfg.max_action
+        act_dim = {"xyz": 3, "xyzRxRy": 5}[modes["movement_mode"]]                              # surface_follow_goal_env.py:112-123
+        TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+                               act_dim=act_dim, oracle_dim=20, feature_dim=6)
+
+    def feature_numpy(self, terminal=False):
+        """get_extended_feature_array (surface_follow_goal_env.py:92-110), host side from the state read-back.  (The terminal copy
+        of auto-reset envs is not kept for this vector: the post-reset features are returned for them.)"""
+        st = self.get_state()
+        tp, _, _, _, _ = self._tcp_workframe_state(st)
+        gp, _ = self._workframe().pose(st["goal_pos"], np.zeros((self.num_envs, 3)))
+        return np.hstack([tp, gp]).astype(np.float32)
+
+    def feature_torch(self, terminal=False):
+        import torch
+        return torch.from_numpy(self.feature_numpy(terminal)).to(torch.device("cuda", self._cfg.device))
+
+
+class SurfaceFollowGoalEnv:
+    """Single-env gym.Env surface; constructor signature as surface_follow_goal_env.py:15-25."""
+
+    metadata = {"render.modes": ["rgb_array"]}
+
+    def __init__(self, max_steps=200, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
+                 physics_dtype="f64", device=0):
+        if show_gui or show_tactile:
+            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
+        self._vec = SurfaceFollowGoalVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
+        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
+        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
+
+    @classmethod
+    def make_vec(cls, num_envs, **kwargs):
+        kwargs.pop("show_gui", None)
+        kwargs.pop("show_tactile", None)
+        return SurfaceFollowGoalVecEnv(num_envs, **kwargs)
+
+    def seed(self, seed=None):
+        return self._vec.seed(seed)[:1]
+
+    def reset(self):
+        return {k: v[0] for k, v in self._vec.reset().items()}
+
+    def step(self, action):
+        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
+        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
+
+    def render(self, mode="rgb_array"):
+        return self._vec.render(mode)
+
+    def close(self):
+        self._vec.close()
 
 
 class SurfaceFollowAutoEnv:

@@ -360,7 +360,7 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         modes = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
                      reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")
         modes.update(env_modes or {})
-        assert modes["noise_mode"] == "simplex" and modes["movement_mode"] in ("xyz", "xyzRxRy") and modes["reward_mode"] == "dense"
+        assert modes["noise_mode"] == "simplex" and modes["movement_mode"] in ("yz", "xyz", "yzRx", "xyzRxRy") and modes["reward_mode"] == "dense"
         rest = [0.16682, -2.18943, -1.65357, -0.86897, 1.57315, 1.74001]                   # surface_follow/rest_poses.py
         self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # base_surface_env.py:60-63
         self.embed_dist = {"tactip": 0.0025, "digitac": 0.0015, "digit": 0.0015}[self.t_s_name]   # :66-75
@@ -394,13 +394,21 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         self.step_counter = 0
         self.noise_seed = self.rng.randint(1e8)                                          # :448
         self.heightfield_data = opensimplex_heightfield(self.noise_seed, self.rows, self.cols, self.interp, self.height_range)
+        one_d = self.modes["movement_mode"] in ("yz", "yzRx")
+        if one_d:                                                                         # gen_heigtfield_simplex_1d (:339-357)
+            n2 = opensimplex_noise2(self.noise_seed, 0, 0)
+            row = np.array([n2(1 * self.interp, y * self.interp) * self.height_range for y in range(self.cols)])
+            self.heightfield_data = np.tile(row, (self.rows, 1))
         X, Y = np.meshgrid(self.x_bins, self.y_bins)
         self.surface_array = np.dstack((X, Y, self.heightfield_data + self.surface_pos[2]))    # :476-477
         gy, gx = np.gradient(self.heightfield_data, self.grid_scale)                     # :500-508
         nrm = np.dstack((-gx, -gy, np.ones_like(self.heightfield_data)))
         self.surface_normals = nrm / np.linalg.norm(nrm, axis=2)[..., None]
-        ang = self.rng.uniform(-math.pi, math.pi)                                        # :530-534
-        self.workframe_directions = [math.cos(ang), math.sin(ang), 0]
+        if one_d:                                                                         # :526-528 np_random.choice([-1, 1])
+            self.workframe_directions = [0, -1.0 if self.rng.uniform(0.0, 1.0) < 0.5 else 1.0, 0]
+        else:
+            ang = self.rng.uniform(-math.pi, math.pi)                                    # :530-534
+            self.workframe_directions = [math.cos(ang), math.sin(ang), 0]
         wd = self._workvec_to_worldvec(self.workframe_directions)
         goal = [self.surface_pos[0] + self.x_y_extent * wd[0], self.surface_pos[1] + self.x_y_extent * wd[1]]
         gi, gj = self._xy_to_surface_idx(goal[0], goal[1])
@@ -421,6 +429,8 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         enc[0] = self.workframe_directions[0] * self.max_action * self.auto_scale
         enc[1] = self.workframe_directions[1] * self.max_action * self.auto_scale
         enc[2] = a[0]
+        if self.modes["movement_mode"] == "yzRx":
+            enc[3] = a[1]
         if self.modes["movement_mode"] == "xyzRxRy":
             enc[3], enc[4] = a[1], a[2]
         return enc
@@ -468,7 +478,12 @@ class OracleSurfaceFollowGoalEnv(OracleSurfaceFollowAutoEnv):
 
     def _encode_actions(self, a):                                                        # surface_follow_goal_env.py:27-52
         enc = np.zeros(6)
-        if self.modes["movement_mode"] == "xyz":
+        mm = self.modes["movement_mode"]
+        if mm == "yz":
+            enc[1], enc[2] = a[0], a[1]
+        elif mm == "yzRx":
+            enc[1], enc[2], enc[3] = a[0], a[1], a[2]
+        elif mm == "xyz":
             enc[0], enc[1], enc[2] = a[0], a[1], a[2]
         else:  # xyzRxRy
             enc[0], enc[1], enc[2], enc[3], enc[4] = a[0], a[1], a[2], a[3], a[4]

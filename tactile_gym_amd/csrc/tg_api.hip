@@ -276,8 +276,12 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
         else if (c.movement_mode == TG_MOVE_XYRZ) enc[5] = (T)a[2];
         else if (c.movement_mode == TG_MOVE_XYZRZ) { enc[2] = (T)a[2]; enc[5] = (T)a[3]; }
     } else if (c.surf_goal) {                             // surface_follow_goal_env.py:27-52: every dimension from the agent
-        enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2];
-        if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[3]; enc[4] = (T)a[4]; }
+        if (c.movement_mode == TG_SMOVE_YZ) { enc[1] = (T)a[0]; enc[2] = (T)a[1]; }
+        else if (c.movement_mode == TG_SMOVE_YZRX) { enc[1] = (T)a[0]; enc[2] = (T)a[1]; enc[3] = (T)a[2]; }
+        else {
+            enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2];
+            if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[3]; enc[4] = (T)a[4]; }
+        }
     } else {                                              // surface_follow_auto_env.py:27-57: xy are driven toward the goal
         enc[0] = (T)((st.dir[0 * n + env] * (double)c.max_action) * c.auto_scale);
         enc[1] = (T)((st.dir[1 * n + env] * (double)c.max_action) * c.auto_scale);
@@ -393,9 +397,14 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
             edge_ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
         } else {                                          // base_surface_env.py:448 (simplex seed), :520-534 (goal direction)
             st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
-            const double ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
-            st.dir[0 * n + env] = cos(ang);
-            st.dir[1 * n + env] = sin(ang);
+            if (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_YZRX) {   // no variation in x: np_random.choice([-1, 1])
+                st.dir[0 * n + env] = 0.0;
+                st.dir[1 * n + env] = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
+            } else {
+                const double ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+                st.dir[0 * n + env] = cos(ang);
+                st.dir[1 * n + env] = sin(ang);
+            }
         }
         st.rng[env] = rs;
         st.embed[env] = embed;
@@ -1251,8 +1260,7 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
             default: return fail(-1, "Incorrect movement mode specified");
         }
         c.surf_goal = cfg.surf_goal_variant ? 1 : 0;
-        if (c.surf_goal && (cfg.movement_mode == TG_SMOVE_YZ || cfg.movement_mode == TG_SMOVE_YZRX))
-            return fail(-1, "surface_follow goal variant: the 1-D surface modes (yz, yzRx) are not built");
+
         if (cfg.reward_mode != TG_REWARD_DENSE) return fail(-1, "surface_follow: only the dense reward is built");
         if (cfg.surf_rows < 2 || cfg.surf_cols < 2) return fail(-1, "surface_follow: heightfield needs at least 2x2 samples");
         c.surf_rows = cfg.surf_rows; c.surf_cols = cfg.surf_cols;
@@ -1462,7 +1470,9 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
         launch_gen_surface(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
-                           c->cfg.surf_height_range, c->cfg.surf_center_z, c->st.heights, c->st.surf_zoff, c->stream);
+                           c->cfg.surf_height_range, c->cfg.surf_center_z,
+                           (c->cfg.movement_mode == TG_SMOVE_YZ || c->cfg.movement_mode == TG_SMOVE_YZRX) ? 1 : 0, c->st.heights, c->st.surf_zoff,
+                           c->stream);
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 2)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
@@ -2034,7 +2044,7 @@ int tg_gen_heightfield(int32_t n, const int64_t* seeds, int32_t rows, int32_t co
     DevBuf sd, hh, zz;
     if (sd.alloc((size_t)n * 8) || hh.alloc(cells * n * 8) || zz.alloc((size_t)n * 4)) return fail(-2, "hipMalloc failed");
     TG_HIP(hipMemcpy(sd.p, seeds, (size_t)n * 8, hipMemcpyHostToDevice));
-    launch_gen_surface(n, nullptr, (const int64_t*)sd.p, rows, cols, interp, range, 1, (double*)hh.p, (float*)zz.p, 0);
+    launch_gen_surface(n, nullptr, (const int64_t*)sd.p, rows, cols, interp, range, 1, 0, (double*)hh.p, (float*)zz.p, 0);
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(heights, hh.p, cells * n * 8, hipMemcpyDeviceToHost));
     if (zoff) TG_HIP(hipMemcpy(zoff, zz.p, (size_t)n * 4, hipMemcpyDeviceToHost));

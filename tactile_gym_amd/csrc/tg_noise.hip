@@ -72,8 +72,8 @@ __device__ double opensimplex_noise2(const int16_t* perm, double x, double y) {
 
 // grid: n_envs blocks of 256 threads
 __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ seeds, int rows,
-                                                     int cols, double interp, double range, int center_z, double* __restrict__ heights,
-                                                     float* __restrict__ zoff) {
+                                                     int cols, double interp, double range, int center_z, int one_d,
+                                                     double* __restrict__ heights, float* __restrict__ zoff) {
     __shared__ int16_t perm[256];
     __shared__ int16_t source[256];
     __shared__ float red_min[256], red_max[256];
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
     float lo = 3.0e38f, hi = -3.0e38f;
     for (int k = tid; k < rows * cols; k += 256) {
         const int x = k / cols, y = k % cols;       // heightfield_data[x, y], base_surface_env.py:327-335
-        const double h = opensimplex_noise2(perm, (double)x * interp, (double)y * interp) * range;
+        // 2-D: noise2(x c, y c) (gen_heigtfield_simplex_2d, :319-337); 1-D: noise2(1 c, y c), constant along x (_1d, :339-357)
+        const double h = opensimplex_noise2(perm, (double)(one_d ? 1 : x) * interp, (double)y * interp) * range;
         out[k] = h;
         const float hf = (float)h;                  // Bullet receives the samples as float (PHY_FLOAT)
         lo = fminf(lo, hf); hi = fmaxf(hi, hf);
@@ -168,8 +169,9 @@ void launch_gen_traj(int n_envs, const uint8_t* mask, const int64_t* seeds, int 
 }
 
 void launch_gen_surface(int n_envs, const uint8_t* mask, const int64_t* seeds, int rows, int cols, double interp, double range, int center_z,
-                        double* heights, float* zoff, hipStream_t stream) {
-    hipLaunchKernelGGL(k_gen_surface, dim3(n_envs), dim3(256), 0, stream, n_envs, mask, seeds, rows, cols, interp, range, center_z, heights, zoff);
+                        int one_d, double* heights, float* zoff, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gen_surface, dim3(n_envs), dim3(256), 0, stream, n_envs, mask, seeds, rows, cols, interp, range, center_z, one_d, heights,
+                       zoff);
 }
 
 }  // namespace tg

@@ -38,8 +38,6 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         raise SystemExit("Incorrect noise mode specified")                                      # :466
     if modes["movement_mode"] not in capi.SMOVE:
         raise SystemExit("Incorrect movement mode specified")
-    if modes["movement_mode"] in ("yz", "yzRx"):
-        raise NotImplementedError("1-D surfaces (yz / yzRx) are not built yet")
     if modes["control_mode"] != "TCP_velocity_control":
         if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
             raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
@@ -92,7 +90,7 @@ class SurfaceFollowAutoVecEnv(TactileVecEnv):
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
-        act_dim = {"xyz": 1, "xyzRxRy": 3}[modes["movement_mode"]]                              # surface_follow_auto_env.py:96-107
+        act_dim = {"yz": 1, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}[modes["movement_mode"]]          # surface_follow_auto_env.py:96-107
         super().__init__(cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
                          act_dim=act_dim, oracle_dim=20)
 
@@ -128,7 +126,7 @@ class SurfaceFollowGoalVecEnv(SurfaceFollowAutoVecEnv):
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
-        act_dim = {"xyz": 3, "xyzRxRy": 5}[modes["movement_mode"]]                              # surface_follow_goal_env.py:112-123
+        act_dim = {"yz": 2, "xyz": 3, "yzRx": 3, "xyzRxRy": 5}[modes["movement_mode"]]          # surface_follow_goal_env.py:112-123
         TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
                                act_dim=act_dim, oracle_dim=20, feature_dim=6)
 

@@ -664,3 +664,38 @@ def test_surface_follow_goal_env_matches_oracle():
             assert np.abs(obs["extended_feature"][i] - ro["extended_feature"]).max() < 1e-6
             assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 2, (step, i)
     venv.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,mode,act_dim", [("surface_follow-v0", "yz", 1), ("surface_follow-v0", "yzRx", 2),
+                                                 ("surface_follow-v1", "yz", 2), ("surface_follow-v1", "yzRx", 3)])
+def test_surface_follow_1d_modes_match_oracle(env_id, mode, act_dim):
+    """The 1-D surface modes (gen_heigtfield_simplex_1d, base_surface_env.py:339-357; goal direction = choice([-1, 1]) along y,
+    :526-528): surface constant along x, per-mode action encodings, W_norm = 0 for "yz"; 4 envs vs 4 oracle envs."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleSurfaceFollowAutoEnv, OracleSurfaceFollowGoalEnv
+    modes = dict(SURF_MODES, movement_mode=mode)
+    Oracle = OracleSurfaceFollowAutoEnv if env_id.endswith("v0") else OracleSurfaceFollowGoalEnv
+    n = 4
+    venv = tg.make_vec(env_id, num_envs=n, max_steps=20, image_size=[128, 128], env_modes=modes, seed=61, auto_reset=False)
+    assert venv.action_space.shape == (act_dim,)
+    oracles = [Oracle(seed=61 + i, max_steps=20, image_size=(128, 128), env_modes=modes) for i in range(n)]
+    obs = venv.reset()
+    ref = [o.reset() for o in oracles]
+    st = venv.get_state()
+    for i, o in enumerate(oracles):
+        assert np.array_equal(st["heights"][i], o.heightfield_data) and np.ptp(st["heights"][i], axis=0).max() == 0.0
+        assert np.abs(st["goal_pos"][i] - o.goal_pos_world).max() < 1e-12
+        assert np.array_equal(obs["tactile"][i], ref[i]["tactile"])
+    assert len({float(o.workframe_directions[1]) for o in oracles} | {-1.0, 1.0}) == 2
+    rng = np.random.default_rng(62)
+    for step in range(4):
+        a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+        obs, rew, done, _ = venv.step(a)
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            ro, rr, rd, _ = o.step(a[i])
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8, (step, i)
+            assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
+            assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 2, (step, i)
+    venv.close()

@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 4
+#define TG_ABI_VERSION 5
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -77,6 +77,7 @@ enum { TG_TRAJ_SIMPLEX = 0, TG_TRAJ_STRAIGHT = 1 };                             
 enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };
 enum { TG_REWARD_DENSE = 0, TG_REWARD_SPARSE = 1 };
 enum { TG_PHYSICS_F64 = 0, TG_PHYSICS_F32 = 1 };
+enum { TG_CONTROL_TCP_VELOCITY = 0, TG_CONTROL_TCP_POSITION = 1 };                             /* robot.py:156-186 apply_action */
 
 /* ---- task + engine configuration (env ctor kwargs / env_modes, edge_follow_env.py:23-134) ------------------------- */
 typedef struct {
@@ -145,6 +146,12 @@ typedef struct {
     double traj_spacing, traj_max_perturb, traj_init_offset;   /* 0.025, 0.1, obj_width/2 + spacing (:229-262) */
     double mass_lo, mass_hi;                /* rand_obj_mass U(0.4, 0.8) (:190-192) */
     double init_orn_range, traj_ang_range;  /* pi/32 (:170), pi/8 (:283) */
+    /* control mode (env_modes["control_mode"], robot.py:156-186).  TG_CONTROL_TCP_POSITION: the action is a work-frame pose delta
+     * (act_lo/hi = +-1 mm, +-1 deg, e.g. edge_follow_env.py:143-153); target = clip(current + delta, tcp_lims), inverse kinematics,
+     * POSITION_CONTROL motors (base_robot_arm.py:228-279, mg400.py:131-190), then blocking_move(max_steps = max_blocking_steps,
+     * constant_vel = None) (robot.py:188-260).  Built for edge_follow and surface_follow. */
+    int32_t control_mode;                   /* TG_CONTROL_* */
+    int32_t max_blocking_steps;             /* _max_blocking_pos_move_steps = 10 (edge_follow_env.py:38) */
 } tg_config;
 
 typedef struct tg_ctx tg_ctx;

@@ -79,7 +79,9 @@ class _OracleArmEnv:
     SOLVER_ITERS = 150                   # base_tactile_env.py:128-130
 
     def _setup_arm(self, seed, modes, max_steps, image_size, t_s_type, rest_poses, inertia):
-        assert modes["control_mode"] == "TCP_velocity_control" and modes["arm_type"] in ("ur5", "mg400")
+        assert modes["control_mode"] in ("TCP_velocity_control", "TCP_position_control") and modes["arm_type"] in ("ur5", "mg400")
+        self.position_control = modes["control_mode"] == "TCP_position_control"
+        self.max_blocking_pos_move_steps = 10                                              # e.g. edge_follow_env.py:38
         self.modes, self.max_steps, self.image_size = modes, max_steps, tuple(image_size)
         self.arm_type = modes["arm_type"]
         self.t_s_name, self.t_s_type = modes["tactile_sensor_name"], t_s_type
@@ -157,6 +159,20 @@ class _OracleArmEnv:
         self.arm.set_motors_velocity(req, self.vel_gain, self.max_force)                # :325-332
         self.last_req_joint_vels = req
 
+    # ---- base_robot_arm.py:228-279 (mg400.py:131-190 adds the parallel-linkage override)
+    def _tcp_position_control(self, delta):
+        pos, rpy, _, _ = self._tcp_work()
+        tpos = np.clip(pos + np.asarray(delta[:3]), self.TCP_lims[:3, 0], self.TCP_lims[:3, 1])   # check_TCP_pos_lims :349-355
+        trpy = np.clip(rpy + np.asarray(delta[3:]), self.TCP_lims[3:, 0], self.TCP_lims[3:, 1])
+        tpos, trpy = self._work_to_world(tpos, trpy)
+        torn = pm.quat_from_euler(trpy)
+        joint_poses = self.arm.inverse_kinematics("tcp_link", tpos, torn, 100, 1e-8)
+        if self.arm_type == "mg400":
+            joint_poses = joint_poses.copy()
+            joint_poses[-3], joint_poses[-2], joint_poses[-1] = joint_poses[1], -joint_poses[1], joint_poses[1] + joint_poses[2]
+        self.arm.set_motors_position(joint_poses, np.zeros(self.arm.n), self.pos_gain, self.vel_gain, self.max_force)
+        return tpos, torn, joint_poses
+
     # ---- robot.py:188-260
     def _blocking_move(self, targ_pos, targ_orn, targ_j, max_steps=1000, constant_vel=0.001, pos_tol=2e-4, orn_tol=1e-3,
                        jvel_tol=0.1):
@@ -200,9 +216,13 @@ class _OracleArmEnv:
         enc = np.clip(self._encode_actions(np.asarray(action, dtype=np.float64)), self.min_action, self.max_action)
         scaled = ((enc - self.min_action) * (self.act_hi - self.act_lo)) / (self.max_action - self.min_action) + self.act_lo
         self.step_counter += 1
-        self._tcp_velocity_control(scaled)                                              # robot.py:156-183
-        for _ in range(self.ACTION_REPEAT):
-            self._step_sim()
+        if self.position_control:                                                       # robot.py:164-178
+            tpos, torn, tj = self._tcp_position_control(scaled)
+            self.last_blocking_ticks = self._blocking_move(tpos, torn, tj, max_steps=self.max_blocking_pos_move_steps, constant_vel=None)
+        else:
+            self._tcp_velocity_control(scaled)                                          # robot.py:156-183
+            for _ in range(self.ACTION_REPEAT):
+                self._step_sim()
         reward, done = self._get_step_data()
         return self._observation(), reward, done, {}
 
@@ -247,6 +267,8 @@ class OracleEdgeFollowEnv(_OracleArmEnv):
         rest = (self.REST_MG400 if mg else self.REST)[modes["tactile_sensor_name"]]
         self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # :59-64
         max_pos_vel, max_ang_vel = 0.01, 5.0 * (math.pi / 180)                             # :158-159
+        if self.position_control:
+            max_pos_vel, max_ang_vel = 0.001, 1 * (math.pi / 180)                          # :143-153 (per-step pose change)
         self.act_lo = np.array([-max_pos_vel] * 3 + [0.0, 0.0, -max_ang_vel])              # :161-166
         self.act_hi = np.array([max_pos_vel] * 3 + [0.0, 0.0, max_ang_vel])
         self.edge_pos = np.array([0.33, 0.0, 0.0] if mg else [0.65, 0.0, 0.0])             # :76,84 well_designed_pos
@@ -374,6 +396,8 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         max_y = self.surface_pos[1] + ((self.cols / 2) * self.grid_scale)
         self.x_bins, self.y_bins = np.linspace(min_x, max_x, self.rows), np.linspace(min_y, max_y, self.cols)
         v, w = 0.01, 5.0 * (math.pi / 180)                                                 # :186-194
+        if self.position_control:
+            v, w = 0.001, 1 * (math.pi / 180)                                              # :167-177
         self.act_lo, self.act_hi = np.array([-v, -v, -v, -w, -w, 0.0]), np.array([v, v, v, w, w, 0.0])
         self._set_workframe(self.surface_pos, [-math.pi, 0.0, math.pi / 2])                # :106-109
         e, h = self.x_y_extent, self.height_range

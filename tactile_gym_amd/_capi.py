@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -18,6 +18,7 @@ ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO, ENV_OBJECT_BALANCE, ENV_OBJECT_PUSH = 
 PMOVE = {"y": 0, "yRz": 1, "xyRz": 2, "TyRz": 3, "TxTyRz": 4}
 TRAJ = {"simplex": 0, "straight": 1}
 BMOVE = {"xy": 0, "xyz": 1, "RxRy": 2, "xyRxRy": 3}
+CONTROL = {"TCP_velocity_control": 0, "TCP_position_control": 1}
 SMOVE = {"yz": 0, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}
 MOVE = {"xy": 0, "xyz": 1, "xyRz": 2, "xyzRz": 3}
 NOISE = {"fixed_height": 0, "rand_height": 1}
@@ -83,6 +84,7 @@ class TgConfig(C.Structure):
         ("tip_stiffness", C.c_double), ("tip_damping", C.c_double), ("obj_lin_damp", C.c_double), ("obj_ang_damp", C.c_double),
         ("traj_spacing", C.c_double), ("traj_max_perturb", C.c_double), ("traj_init_offset", C.c_double),
         ("mass_lo", C.c_double), ("mass_hi", C.c_double), ("init_orn_range", C.c_double), ("traj_ang_range", C.c_double),
+        ("control_mode", C.c_int32), ("max_blocking_steps", C.c_int32),
     ]
 
 

@@ -49,6 +49,7 @@ template <typename T> struct EnvConst {
     T obj_init_rpy_deg[3], obj_base_width, obj_base_height, term_deg, term_pos, ext_force[3];
     int rand_gravity, rand_embed;
     double gravity_lo, gravity_hi, gravity_default;
+    int control_mode, max_blocking;   // TG_CONTROL_*; blocking_move's step cap in position control
     int fused_reset;             // edge_follow with auto_reset: k_reset keeps the terminal camera transform, one render launch draws both images
     // object_push
     PushScene<T> push;
@@ -253,23 +254,10 @@ __device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const
     }
 }
 
-// ------------------------------------------------------------------------------------------------ step kernel
-// BaseTactileEnv.step (base_tactile_env.py:166-185): encode + scale the action, tcp_velocity_control
-// (base_robot_arm.py:281-332), action_repeat sim ticks (robot.py:182-183), reward / done, render transform.
-template <typename T, int TOPO>
-__global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                             const float* __restrict__ actions) {
-    constexpr int N = Topo<TOPO>::N;
-    const DevRobot<T>& m = *mp;
-    const EnvConst<T>& c = *cp;
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+// encode_actions of the arm-only tasks: the policy's dimensions scattered into the 6-vector the controller takes.
+template <typename T>
+__device__ __forceinline__ void encode_arm_actions(const EnvConst<T>& c, const State& st, int env, const float* __restrict__ a, T (&enc)[6]) {
     const int n = c.num_envs;
-    if (env >= n) return;
-    T q[N], qd[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
-    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-    const float* a = actions + (size_t)env * c.act_dim;
     if (c.env_kind == TG_ENV_EDGE_FOLLOW) {               // encode_actions (edge_follow_env.py:345-369)
         enc[0] = (T)a[0]; enc[1] = (T)a[1];
         if (c.movement_mode == TG_MOVE_XYZ) enc[2] = (T)a[2];
@@ -289,6 +277,25 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
         if (c.movement_mode == TG_SMOVE_YZRX) enc[3] = (T)a[1];
         else if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[1]; enc[4] = (T)a[2]; }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ step kernel
+// BaseTactileEnv.step (base_tactile_env.py:166-185): encode + scale the action, tcp_velocity_control
+// (base_robot_arm.py:281-332), action_repeat sim ticks (robot.py:182-183), reward / done, render transform.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                             const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    encode_arm_actions<T>(c, st, env, actions + (size_t)env * c.act_dim, enc);
     T vels[6];
     scale_actions<T>(c, enc, vels);
     const int step_count = st.step_count[env] + 1;
@@ -379,6 +386,77 @@ __device__ __forceinline__ int inverse_kinematics(const DevRobot<T>& m, V3<T> tp
         }
     }
     return it;
+}
+
+// TCP_position_control step (robot.py:156-186): BaseRobotArm.tcp_position_control (base_robot_arm.py:228-279; MG400 override
+// mg400.py:131-190) then Robot.blocking_move(max_steps = _max_blocking_pos_move_steps, constant_vel = None) (robot.py:188-260).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step_pos(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                 const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    encode_arm_actions<T>(c, st, env, actions + (size_t)env * c.act_dim, enc);
+    T delta[6];
+    scale_actions<T>(c, enc, delta);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+
+    // target pose = clip(current work-frame pose + delta, TCP_lims) (check_TCP_pos_lims, base_robot_arm.py:349-355), back to the world
+    V3<T> tpos; Q4<T> tq;
+    {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> ptcp; M3<T> Rtcp;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+        V3<T> wpos; T wrpy[3], rpyw[3];
+        world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpyw);
+        T tgt[6] = {wpos.x + delta[0], wpos.y + delta[1], wpos.z + delta[2], wrpy[0] + delta[3], wrpy[1] + delta[4], wrpy[2] + delta[5]};
+#pragma unroll
+        for (int d = 0; d < 6; ++d) tgt[d] = tgt[d] < c.tcp_lims[d][0] ? c.tcp_lims[d][0] : (tgt[d] > c.tcp_lims[d][1] ? c.tcp_lims[d][1] : tgt[d]);
+        tpos = load_v3(c.work_pos) + mul(c.work_R, mk(tgt[0], tgt[1], tgt[2]));        // workframe_to_worldframe (:46-60)
+        T trpy[3];
+        euler_from_quat(quat_mul(c.work_q, quat_from_euler(tgt[3], tgt[4], tgt[5])), trpy[0], trpy[1], trpy[2]);
+        tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    }
+    const M3<T> Rt = mat_from_quat(tq);
+    T qik[N], zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { qik[i] = q[i]; zero[i] = T(0); }
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));                        // from the current joint state
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }   // mg400.py:167-172
+#pragma unroll
+    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = 0.0;
+
+    int verified = 0;
+    for (int it = 0; it < c.max_blocking; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T total_v = T(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) total_v += tabs(qd[i]);
+        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, qik, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, nullptr, &verified);
+        if (verified < 0) verified = 0;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);   // errors of the pose before this tick (:216-247)
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.licence[env] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true);
 }
 
 // EdgeFollowEnv.reset (edge_follow_env.py:311-336): reset_task (:285-299), Robot.reset (robot.py:114-125) =
@@ -1273,6 +1351,13 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.ybin_hi = cfg.stim_pos[1] + ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
     }
     c.fused_reset = (cfg.auto_reset && cfg.env_kind == TG_ENV_EDGE_FOLLOW) ? 1 : 0;
+    if (cfg.control_mode != TG_CONTROL_TCP_VELOCITY && cfg.control_mode != TG_CONTROL_TCP_POSITION) return fail(-1, "Incorrect control mode specified");
+    if (cfg.control_mode == TG_CONTROL_TCP_POSITION) {
+        if (cfg.env_kind != TG_ENV_EDGE_FOLLOW && cfg.env_kind != TG_ENV_SURFACE_FOLLOW_AUTO)
+            return fail(-1, "TCP_position_control is built for edge_follow and surface_follow only");
+        if (cfg.max_blocking_steps < 1) return fail(-1, "TCP_position_control: max_blocking_steps must be >= 1");
+    }
+    c.control_mode = cfg.control_mode; c.max_blocking = cfg.max_blocking_steps;
     c.max_steps = cfg.max_steps; c.action_repeat = cfg.action_repeat; c.solver_iters = cfg.pgs_full_sweeps ? -cfg.solver_iterations : cfg.solver_iterations;
     c.dt = (T)cfg.sim_dt; c.min_action = (T)cfg.min_action; c.max_action = (T)cfg.max_action;
     for (int d = 0; d < 6; ++d) { c.act_lo[d] = (T)cfg.act_lo[d]; c.act_hi[d] = (T)cfg.act_hi[d]; c.tcp_lims[d][0] = (T)cfg.tcp_lims[d][0]; c.tcp_lims[d][1] = (T)cfg.tcp_lims[d][1]; }
@@ -1355,8 +1440,12 @@ static void drain_events(tg_ctx* c) {
 
 template <typename T, int TOPO> static void launch_step_t(tg_ctx* c, const float* d_actions) {
     const int n = c->cfg.num_envs;
-    hipLaunchKernelGGL((k_step<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st, d_actions);
+    if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION)
+        hipLaunchKernelGGL((k_step_pos<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
+    else
+        hipLaunchKernelGGL((k_step<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
 }
 template <typename T, int TOPO> static void launch_reset_t(tg_ctx* c, const uint8_t* d_mask, int phase) {
     const int n = c->cfg.num_envs;

@@ -51,8 +51,8 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         if k not in modes:
             raise KeyError(k)  # same failure as the reference when a mode is missing (:45-59)
     arm, t_s_name, t_s_type = modes["arm_type"], modes["tactile_sensor_name"], "standard"      # :52,59-64
-    if modes["control_mode"] != "TCP_velocity_control":
-        if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
+    if modes["control_mode"] not in capi.CONTROL:
+        if modes["control_mode"] in ("joint_velocity_control",):
             raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
         raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")             # robot.py:174
     if arm not in ("ur5", "mg400"):
@@ -75,9 +75,13 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.solver_iterations = 150                                                                  # base_tactile_env.py:128-130
     cfg.auto_reset, cfg.device = int(auto_reset), int(device)
     cfg.min_action, cfg.max_action = -0.25, 0.25                                                 # :140
-    max_pos_vel, max_ang_vel = 0.01, 5.0 * (math.pi / 180)                                       # :158-159
-    lo = [-max_pos_vel] * 3 + [0.0, 0.0, -max_ang_vel]                                           # :161-166
-    hi = [max_pos_vel] * 3 + [0.0, 0.0, max_ang_vel]
+    cfg.control_mode, cfg.max_blocking_steps = capi.CONTROL[modes["control_mode"]], 10           # :38
+    if modes["control_mode"] == "TCP_position_control":
+        max_pos, max_ang = 0.001, 1 * (math.pi / 180)                                            # :143-153 m / rad per step
+    else:
+        max_pos, max_ang = 0.01, 5.0 * (math.pi / 180)                                           # :155-166 m/s, rad/s
+    lo = [-max_pos] * 3 + [0.0, 0.0, -max_ang]
+    hi = [max_pos] * 3 + [0.0, 0.0, max_ang]
     xy = (0.150, 0.11) if mg else (0.175, 0.175)                                                 # :75-90
     lims = [(-xy[0], xy[0]), (-xy[1], xy[1]), (-0.1, 0.1), (0.0, 0.0), (0.0, 0.0), (-math.pi, math.pi)]
     for d in range(6):

@@ -38,8 +38,8 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         raise SystemExit("Incorrect noise mode specified")                                      # :466
     if modes["movement_mode"] not in capi.SMOVE:
         raise SystemExit("Incorrect movement mode specified")
-    if modes["control_mode"] != "TCP_velocity_control":
-        if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
+    if modes["control_mode"] not in capi.CONTROL:
+        if modes["control_mode"] in ("joint_velocity_control",):
             raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
         raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")
     if arm != "ur5":
@@ -59,7 +59,11 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.solver_iterations = 150
     cfg.auto_reset, cfg.device = int(auto_reset), int(device)
     cfg.min_action, cfg.max_action = -0.25, 0.25                                                # :160
-    v, w = 0.01, 5.0 * (math.pi / 180)                                                          # :186-194
+    cfg.control_mode, cfg.max_blocking_steps = capi.CONTROL[modes["control_mode"]], 10          # :28
+    if modes["control_mode"] == "TCP_position_control":
+        v, w = 0.001, 1 * (math.pi / 180)                                                       # :167-177 m / rad per step
+    else:
+        v, w = 0.01, 5.0 * (math.pi / 180)                                                      # :186-194
     lo, hi = [-v, -v, -v, -w, -w, 0.0], [v, v, v, w, w, 0.0]
     height_range, extent = 0.025, 0.15                                                          # :239,245
     lims = [(-extent, extent), (-extent, extent), (-height_range, height_range), (-math.pi / 4, math.pi / 4),

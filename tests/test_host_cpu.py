@@ -161,3 +161,24 @@ def test_object_push_config_and_registry():
         op.build_config(8, 1000, (128, 128), dict(modes, arm_type="ur5"))
     with pytest.raises(SystemExit):
         op.build_config(8, 1000, (128, 128), dict(modes, traj_type="zigzag"))
+
+
+def test_control_mode_config():
+    """control_mode handling without a GPU: TCP_position_control switches the action ranges to per-step pose changes (1 mm, 1 deg;
+    edge_follow_env.py:143-153, base_surface_env.py:167-177) and sets blocking_move's step cap; unknown modes exit like robot.py:174."""
+    import math
+    from tactile_gym_amd import _capi as capi
+    from tactile_gym_amd.rl_envs import edge_follow as ef, surface_follow as sf
+    modes = dict(ef.env_modes_default, control_mode="TCP_position_control", movement_mode="xyzRz")
+    cfg = ef.build_config(4, 200, (128, 128), modes)[0]
+    assert cfg.control_mode == capi.CONTROL["TCP_position_control"] and cfg.max_blocking_steps == 10
+    assert [cfg.act_hi[d] for d in range(6)] == [0.001, 0.001, 0.001, 0.0, 0.0, math.pi / 180]
+    cfg = ef.build_config(4, 200, (128, 128), dict(modes, control_mode="TCP_velocity_control"))[0]
+    assert cfg.control_mode == 0 and cfg.act_hi[0] == 0.01 and abs(cfg.act_hi[5] - 5 * math.pi / 180) < 1e-15
+    smodes = dict(sf.env_modes_default, control_mode="TCP_position_control", arm_type="ur5", tactile_sensor_name="digit")
+    cfg = sf.build_config(4, 200, (128, 128), smodes)[0]
+    assert cfg.control_mode == 1 and [cfg.act_lo[d] for d in range(6)] == [-0.001] * 3 + [-math.pi / 180] * 2 + [0.0]
+    with pytest.raises(NotImplementedError):
+        ef.build_config(4, 200, (128, 128), dict(modes, control_mode="joint_velocity_control"))
+    with pytest.raises(SystemExit):
+        ef.build_config(4, 200, (128, 128), dict(modes, control_mode="teleport"))

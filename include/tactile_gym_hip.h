@@ -149,7 +149,7 @@ typedef struct {
     /* control mode (env_modes["control_mode"], robot.py:156-186).  TG_CONTROL_TCP_POSITION: the action is a work-frame pose delta
      * (act_lo/hi = +-1 mm, +-1 deg, e.g. edge_follow_env.py:143-153); target = clip(current + delta, tcp_lims), inverse kinematics,
      * POSITION_CONTROL motors (base_robot_arm.py:228-279, mg400.py:131-190), then blocking_move(max_steps = max_blocking_steps,
-     * constant_vel = None) (robot.py:188-260).  Built for edge_follow and surface_follow. */
+     * constant_vel = None) (robot.py:188-260). */
     int32_t control_mode;                   /* TG_CONTROL_* */
     int32_t max_blocking_steps;             /* _max_blocking_pos_move_steps = 10 (edge_follow_env.py:38) */
 } tg_config;

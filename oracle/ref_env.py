@@ -556,6 +556,8 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
         a = 45 * math.pi / 180
         self.TCP_lims = np.array([[-0.1, 0.1], [-0.1, 0.1], [-0.1, 0.1], [-a, a], [-a, a], [-a, a]])   # :64-76
         v, w = 0.01, 5.0 * (math.pi / 180)                                                 # :123-131
+        if self.position_control:
+            v, w = 0.001, 1 * (math.pi / 180)                                              # :129-140
         self.act_lo, self.act_hi = np.array([-v, -v, -v, -w, -w, 0.0]), np.array([v, v, v, w, w, 0.0])
         self.obj_base_width, self.obj_base_height = 0.1, 0.0025                            # :158-159
         suffix = "" if inertia == "collision_aabb" else "_urdfinertia"
@@ -713,6 +715,8 @@ class OracleObjectPushEnv(_OracleArmEnv):
         self.well_designed_pos = np.array([0.28 if modes["tactile_sensor_name"] == "tactip" else 0.25, -0.1, self.obj_height / 2])   # :70-79
         self._set_workframe(self.well_designed_pos, [-math.pi, 0.0, math.pi / 2])           # :87-88
         v, w = 0.01, 5.0 * (math.pi / 180)                                                  # :126-134
+        if self.position_control:
+            v, w = 0.001, 1 * (math.pi / 180)                                               # :137-148
         self.act_lo, self.act_hi = np.array([-v, -v, 0.0, 0.0, 0.0, -w]), np.array([v, v, 0.0, 0.0, 0.0, w])
         self.init_obj_pos = np.array([self.well_designed_pos[0], self.well_designed_pos[1] + self.obj_width / 2, self.obj_height / 2])   # :160
         suffix = "" if inertia == "collision_aabb" else "_urdfinertia"

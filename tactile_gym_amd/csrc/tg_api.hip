@@ -388,6 +388,56 @@ __device__ __forceinline__ int inverse_kinematics(const DevRobot<T>& m, V3<T> tp
     return it;
 }
 
+// BaseRobotArm.tcp_position_control (base_robot_arm.py:228-279; MG400 override mg400.py:131-190): target pose = clip(current
+// work-frame pose + delta, TCP_lims) (check_TCP_pos_lims, :349-355), back to the world (workframe_to_worldframe, :46-60), inverse
+// kinematics from the current joint state.  The POSITION_CONTROL motors then track `qik` (gains pos_gain / vel_gain, max_force).
+template <typename T, int TOPO>
+__device__ __forceinline__ void tcp_position_target(const DevRobot<T>& m, const EnvConst<T>& c, const T (&q)[Topo<TOPO>::N], const T (&delta)[6],
+                                                    V3<T>& tpos, Q4<T>& tq, T (&qik)[Topo<TOPO>::N]) {
+    constexpr int N = Topo<TOPO>::N;
+    {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> ptcp; M3<T> Rtcp;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+        V3<T> wpos; T wrpy[3], rpyw[3];
+        world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpyw);
+        T tgt[6] = {wpos.x + delta[0], wpos.y + delta[1], wpos.z + delta[2], wrpy[0] + delta[3], wrpy[1] + delta[4], wrpy[2] + delta[5]};
+#pragma unroll
+        for (int d = 0; d < 6; ++d) tgt[d] = tgt[d] < c.tcp_lims[d][0] ? c.tcp_lims[d][0] : (tgt[d] > c.tcp_lims[d][1] ? c.tcp_lims[d][1] : tgt[d]);
+        tpos = load_v3(c.work_pos) + mul(c.work_R, mk(tgt[0], tgt[1], tgt[2]));
+        T trpy[3];
+        euler_from_quat(quat_mul(c.work_q, quat_from_euler(tgt[3], tgt[4], tgt[5])), trpy[0], trpy[1], trpy[2]);
+        tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    }
+    const M3<T> Rt = mat_from_quat(tq);
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }   // mg400.py:167-172
+}
+
+// blocking_move's exit test (robot.py:216-258), evaluated on the state BEFORE the tick it follows: pose error of the TCP and the
+// summed joint speed.
+template <typename T, int TOPO>
+__device__ __forceinline__ bool pose_reached(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], const T (&qd)[Topo<TOPO>::N], const V3<T>& tpos,
+                                             const Q4<T>& tq) {
+    constexpr int N = Topo<TOPO>::N;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> p; M3<T> R;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+    const Q4<T> cq = quat_from_mat(R);
+    T total_v = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) total_v += tabs(qd[i]);
+    const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+    const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+    T ca = T(2) * ip * ip - T(1);
+    ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+    return pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1);
+}
+
 // TCP_position_control step (robot.py:156-186): BaseRobotArm.tcp_position_control (base_robot_arm.py:228-279; MG400 override
 // mg400.py:131-190) then Robot.blocking_move(max_steps = _max_blocking_pos_move_steps, constant_vel = None) (robot.py:188-260).
 template <typename T, int TOPO>
@@ -409,49 +459,17 @@ __global__ __launch_bounds__(64) void k_step_pos(const DevRobot<T>* __restrict__
     const int step_count = st.step_count[env] + 1;
     st.step_count[env] = step_count;
 
-    // target pose = clip(current work-frame pose + delta, TCP_lims) (check_TCP_pos_lims, base_robot_arm.py:349-355), back to the world
     V3<T> tpos; Q4<T> tq;
-    {
-        Kin<T, TOPO> k;
-        forward_kinematics<T, TOPO>(m, q, k);
-        V3<T> ptcp; M3<T> Rtcp;
-        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
-        V3<T> wpos; T wrpy[3], rpyw[3];
-        world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpyw);
-        T tgt[6] = {wpos.x + delta[0], wpos.y + delta[1], wpos.z + delta[2], wrpy[0] + delta[3], wrpy[1] + delta[4], wrpy[2] + delta[5]};
-#pragma unroll
-        for (int d = 0; d < 6; ++d) tgt[d] = tgt[d] < c.tcp_lims[d][0] ? c.tcp_lims[d][0] : (tgt[d] > c.tcp_lims[d][1] ? c.tcp_lims[d][1] : tgt[d]);
-        tpos = load_v3(c.work_pos) + mul(c.work_R, mk(tgt[0], tgt[1], tgt[2]));        // workframe_to_worldframe (:46-60)
-        T trpy[3];
-        euler_from_quat(quat_mul(c.work_q, quat_from_euler(tgt[3], tgt[4], tgt[5])), trpy[0], trpy[1], trpy[2]);
-        tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
-    }
-    const M3<T> Rt = mat_from_quat(tq);
     T qik[N], zero[N];
+    tcp_position_target<T, TOPO>(m, c, q, delta, tpos, tq, qik);
 #pragma unroll
-    for (int i = 0; i < N; ++i) { qik[i] = q[i]; zero[i] = T(0); }
-    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));                        // from the current joint state
-    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }   // mg400.py:167-172
-#pragma unroll
-    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = 0.0;
-
+    for (int i = 0; i < N; ++i) { zero[i] = T(0); st.qd_target[i * n + env] = 0.0; }
     int verified = 0;
     for (int it = 0; it < c.max_blocking; ++it) {
-        Kin<T, TOPO> k;
-        forward_kinematics<T, TOPO>(m, q, k);
-        V3<T> p; M3<T> R;
-        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
-        const Q4<T> cq = quat_from_mat(R);
-        T total_v = T(0);
-#pragma unroll
-        for (int i = 0; i < N; ++i) total_v += tabs(qd[i]);
+        const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
         sim_tick<T, TOPO, kMotorPosition>(m, q, qd, qik, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, nullptr, &verified);
         if (verified < 0) verified = 0;
-        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);   // errors of the pose before this tick (:216-247)
-        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
-        T ca = T(2) * ip * ip - T(1);
-        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
-        if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
+        if (stop) break;
     }
     st.licence[env] = 0;
 #pragma unroll
@@ -651,7 +669,7 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
     X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
 }
 
-template <typename T, int TOPO>
+template <typename T, int TOPO, bool POS>
 __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
     constexpr int N = Topo<TOPO>::N;
@@ -675,9 +693,16 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
     const int step_count = st.step_count[env] + 1;
     st.step_count[env] = step_count;
     T qd_des[N];
-    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+    V3<T> tpos; Q4<T> tq;
+    if constexpr (POS) {                                  // TCP_position_control: qd_des carries the joint targets
+        tcp_position_target<T, TOPO>(m, c, q, vels, tpos, tq, qd_des);
 #pragma unroll
-    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = 0.0;
+    } else {
+        tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+    }
     const T embed = (T)st.embed[env];
     const V3<T> grav = mk(T(0), T(0), (T)st.gravity[env]);
     const V3<T> pivot_b = mk(T(0), T(0), -c.obj_base_height / T(2) + embed);
@@ -688,9 +713,18 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
     int verified = 0;
-    for (int t = 0; t < c.action_repeat; ++t)
-        sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body,
-                                               pivot_b, fext, pext, pending && t == 0, &verified);
+    if constexpr (POS) {                                  // blocking_move(max_steps, constant_vel=None), robot.py:188-260
+        for (int t = 0; t < c.max_blocking; ++t) {
+            const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+            sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b,
+                                                   c.body, pivot_b, fext, pext, pending && t == 0, &verified);
+            if (stop) break;
+        }
+    } else {
+        for (int t = 0; t < c.action_repeat; ++t)
+            sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body,
+                                                   pivot_b, fext, pext, pending && t == 0, &verified);
+    }
     st.ext_pending[env] = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
@@ -865,7 +899,7 @@ __device__ __forceinline__ void finish_push(const DevRobot<T>& m, const EnvConst
     X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
 }
 
-template <typename T, int TOPO>
+template <typename T, int TOPO, bool POS>
 __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
     constexpr int N = Topo<TOPO>::N;
@@ -908,16 +942,32 @@ __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict_
     const int step_count = st.step_count[env] + 1;
     st.step_count[env] = step_count;
     T qd_des[N];
-    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+    V3<T> tpos; Q4<T> tq;
+    if constexpr (POS) {                                  // TCP_position_control: qd_des carries the joint targets
+        tcp_position_target<T, TOPO>(m, c, q, vels, tpos, tq, qd_des);
 #pragma unroll
-    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = 0.0;
+    } else {
+        tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+    }
     const T mass = (T)st.obj_mass[env];
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
-    for (int t = 0; t < c.action_repeat; ++t)
-        sim_tick_push<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
-                                               (const T*)st.tip_verts, mass, lds + threadIdx.x);
+    if constexpr (POS) {                                  // blocking_move(max_steps, constant_vel=None), robot.py:188-260
+        for (int t = 0; t < c.max_blocking; ++t) {
+            const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+            sim_tick_push<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
+                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x);
+            if (stop) break;
+        }
+    } else {
+        for (int t = 0; t < c.action_repeat; ++t)
+            sim_tick_push<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
+                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x);
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
     store_body<T>(st, n, env, b);
@@ -1353,8 +1403,6 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
     c.fused_reset = (cfg.auto_reset && cfg.env_kind == TG_ENV_EDGE_FOLLOW) ? 1 : 0;
     if (cfg.control_mode != TG_CONTROL_TCP_VELOCITY && cfg.control_mode != TG_CONTROL_TCP_POSITION) return fail(-1, "Incorrect control mode specified");
     if (cfg.control_mode == TG_CONTROL_TCP_POSITION) {
-        if (cfg.env_kind != TG_ENV_EDGE_FOLLOW && cfg.env_kind != TG_ENV_SURFACE_FOLLOW_AUTO)
-            return fail(-1, "TCP_position_control is built for edge_follow and surface_follow only");
         if (cfg.max_blocking_steps < 1) return fail(-1, "TCP_position_control: max_blocking_steps must be >= 1");
     }
     c.control_mode = cfg.control_mode; c.max_blocking = cfg.max_blocking_steps;
@@ -1460,8 +1508,12 @@ template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
 
 template <typename T> static void launch_step_body_t(tg_ctx* c, const float* d_actions) {
     const int n = c->cfg.num_envs;
-    hipLaunchKernelGGL((k_step_body<T, 0>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st, d_actions);
+    if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION)
+        hipLaunchKernelGGL((k_step_body<T, 0, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
+    else
+        hipLaunchKernelGGL((k_step_body<T, 0, false>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
 }
 template <typename T> static void launch_reset_body_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;
@@ -1473,9 +1525,17 @@ template <typename T, int TOPO> static void launch_step_push_t(tg_ctx* c, const 
     const int n = c->cfg.num_envs;
     constexpr size_t lds_bytes = (size_t)kPushLdsWords * 64 * sizeof(T);
     static bool attr_set = false;   // one context per (process, GPU): set once per instantiation
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_push<T, TOPO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
-    hipLaunchKernelGGL((k_step_push<T, TOPO>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st, d_actions);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_push<T, TOPO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_push<T, TOPO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION)
+        hipLaunchKernelGGL((k_step_push<T, TOPO, true>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
+    else
+        hipLaunchKernelGGL((k_step_push<T, TOPO, false>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
 }
 template <typename T, int TOPO> static void launch_reset_push_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;

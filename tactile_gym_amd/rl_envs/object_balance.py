@@ -39,8 +39,8 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         raise ValueError(f"unknown object_mode {modes['object_mode']}")
     if modes["movement_mode"] not in capi.BMOVE:
         raise ValueError(f"unknown movement_mode {modes['movement_mode']}")
-    if modes["control_mode"] != "TCP_velocity_control":
-        if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
+    if modes["control_mode"] not in capi.CONTROL:
+        if modes["control_mode"] in ("joint_velocity_control",):
             raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
         raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")
     if arm != "ur5":
@@ -58,6 +58,9 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.auto_reset, cfg.device = int(auto_reset), int(device)
     cfg.min_action, cfg.max_action = -0.25, 0.25                                                # :111
     v, w = 0.01, 5.0 * (math.pi / 180)                                                          # :123-131
+    cfg.control_mode, cfg.max_blocking_steps = capi.CONTROL[modes["control_mode"]], 10
+    if modes["control_mode"] == "TCP_position_control":
+        v, w = 0.001, 1 * (math.pi / 180)                                                       # :129-140 m / rad per step
     lo, hi = [-v, -v, -v, -w, -w, 0.0], [v, v, v, w, w, 0.0]
     a = 45 * math.pi / 180
     lims = [(-0.1, 0.1)] * 3 + [(-a, a)] * 3                                                    # :64-76

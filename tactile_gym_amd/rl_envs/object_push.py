@@ -51,8 +51,8 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         raise ValueError(f"unknown movement_mode {modes['movement_mode']}")
     if modes["traj_type"] not in capi.TRAJ:
         raise SystemExit(f"Incorrect traj_type specified: {modes['traj_type']}")               # :339
-    if modes["control_mode"] != "TCP_velocity_control":
-        if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
+    if modes["control_mode"] not in capi.CONTROL:
+        if modes["control_mode"] in ("joint_velocity_control",):
             raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
         raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")
     if arm not in REST_POSES:
@@ -72,6 +72,9 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.auto_reset, cfg.device = int(auto_reset), int(device)
     cfg.min_action, cfg.max_action = -0.25, 0.25                                                # :116
     v, w = 0.01, 5.0 * (math.pi / 180)                                                          # :126-134
+    cfg.control_mode, cfg.max_blocking_steps = capi.CONTROL[modes["control_mode"]], 10
+    if modes["control_mode"] == "TCP_position_control":
+        v, w = 0.001, 1 * (math.pi / 180)                                                       # :137-148 m / rad per step
     lo, hi = [-v, -v, 0.0, 0.0, 0.0, -w], [v, v, 0.0, 0.0, 0.0, w]
     a = 45 * math.pi / 180
     lims = [(-0.0, 0.3), (-0.1, 0.08), (-0.0, 0.0), (-0.0, 0.0), (-0.0, 0.0), (-a, a)]           # :62-68

@@ -742,3 +742,37 @@ def test_tcp_position_control_matches_oracle(env_id, overrides, act_dim, edge_mo
             assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 2, (step, i)
     assert moved > 1e-4                                                       # the arm did move
     venv.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["object_balance-v0", "object_push-v0"])
+def test_tcp_position_control_with_free_body_matches_oracle(env_id):
+    """TCP_position_control on the tasks with a free body: the blocking move runs the coupled arm + pole (P2P constraint) ticks /
+    the arm + cube contact ticks.  4 envs vs 4 oracle envs; tolerances as in the velocity-control tests of the same envs."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleObjectBalanceEnv, OracleObjectPushEnv
+    push = env_id.startswith("object_push")
+    modes = dict(PUSH_MODES if push else BAL_MODES, control_mode="TCP_position_control")
+    if not push:
+        modes["movement_mode"] = "xyRxRy"
+    Oracle, act_dim = (OracleObjectPushEnv, 2) if push else (OracleObjectBalanceEnv, 4)
+    n = 4
+    venv = tg.make_vec(env_id, num_envs=n, max_steps=30, image_size=[128, 128], env_modes=modes, seed=81, auto_reset=False)
+    assert venv.action_space.shape == (act_dim,)
+    oracles = [Oracle(seed=81 + i, max_steps=30, image_size=(128, 128), env_modes=modes) for i in range(n)]
+    venv.reset()
+    for o in oracles:
+        o.reset()
+    rng = np.random.default_rng(82)
+    for step in range(8):
+        a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+        obs, rew, done, _ = venv.step(a)
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            ro, rr, rd, _ = o.step(a[i])
+            pos, R = o.cube_pose() if push else o.body_pose()
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8, (step, i, np.abs(st["q"][i] - o.arm.q).max())
+            assert np.abs(st["body_pos"][i] - pos).max() < 1e-7 and np.abs(st["body_rot"][i] - R).max() < 1e-7, (step, i)
+            assert abs(rew[i] - rr) < 1e-6 and bool(done[i]) == rd
+            assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (step, i)
+    venv.close()

@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=128)
     ap.add_argument("--physics", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="block the host on every step (VecEnv.step_wait semantics) instead of pipelining")
     ap.add_argument("--full-sweeps", action="store_true",
                     help="always run all 150 PGS sweeps per tick instead of leaving the loop at convergence to the last bit (DESIGN.md 4.1)")
     ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0", "object_balance-v0", "object_push-v0"],
@@ -92,9 +93,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the env step has no CPU fallback (the CPU oracle is only the reported baseline)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force = world == 1 and os.environ.get("TG_BENCH_FORCE_COLLECTIVE") == "1"   # 1-GPU check of the RCCL gather path (one rank)
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force:
+            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     n = args.num_envs
@@ -104,8 +108,10 @@ def main():
     venv = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
                        seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",
                        pgs_full_sweeps=args.full_sweeps)
-    shard = TorchShard(venv)
-    env = ShardedVecEnv(shard, dist, overlap=True) if world > 1 else shard   # gather of step t overlaps the simulation of step t+1
+    # device-resident rollout: the step is enqueued on a torch stream and its outputs are consumed on that stream (no host wait per
+    # step); --sync-steps restores the blocking VecEnv.step_wait behaviour
+    shard = TorchShard(venv, pipelined=not args.sync_steps)
+    env = ShardedVecEnv(shard, dist, overlap=True, force_collective=force) if dist is not None else shard   # gather of step t overlaps the simulation of step t+1
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
 
@@ -120,25 +126,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    env.reset()
-    for _ in range(args.warmup):
-        env.step(actions())
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        env.step(actions())
-    if world > 1:
-        env.flush()        # the last step's gather completes inside the timed region: K steps simulated AND delivered to rank 0
-    barrier()
-    dt = time.perf_counter() - t0
-    # per-kernel durations for the roofline leg: HIP events on the launch stream, outside the timed region
-    # (event records add ~2 x 4 launches of host work per step)
-    venv.profile(True)
-    for _ in range(min(args.steps, 50)):
-        env.step(actions())
-    barrier()
-    prof = venv.profile_get()
-    venv.profile(False)
+    import contextlib
+    on_stream = torch.cuda.stream(shard.stream) if shard.pipelined else contextlib.nullcontext()
+    with on_stream:
+        env.reset()
+        for _ in range(args.warmup):
+            env.step(actions())
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            env.step(actions())
+        if dist is not None:
+            env.flush()        # the last step's gather completes inside the timed region: K steps simulated AND delivered to rank 0
+        barrier()
+        dt = time.perf_counter() - t0
+        # per-kernel durations for the roofline leg: HIP events on the launch stream, outside the timed region
+        # (event records add ~2 x 4 launches of host work per step)
+        venv.profile(True)
+        for _ in range(min(args.steps, 50)):
+            env.step(actions())
+            venv.sync()
+        barrier()
+        prof = venv.profile_get()
+        venv.profile(False)
     literal = None
     if world == 1 and not args.full_sweeps:
         # the same workload with the literal solver (every tick: dynamics + all 150 PGS sweeps), for comparison; short run

@@ -183,6 +183,10 @@ int tg_sync(tg_ctx* ctx);                                     /* VecEnv.step_wai
 int tg_get_obs_tactile(tg_ctx* ctx, void** dev_ptr);           /* uint8 [num_envs][H][W][1] */
 int tg_get_terminal_obs(tg_ctx* ctx, void** dev_ptr);          /* uint8 [num_envs][H][W][1], rows valid where done */
 int tg_get_reward_done_dev(tg_ctx* ctx, void** reward_f32, void** done_u8);
+/* The three per-step outputs live in ONE device allocation: [tactile obs u8[N*H*W] | pad to 16 B | reward f32[N] | done u8[N]]
+ * (tg_get_obs_tactile / tg_get_reward_done_dev point into it).  A rank ships this byte range to rank 0 as one message per step
+ * (replaces SubprocVecEnv's per-env pickled pipes, sb3_helpers/rl_utils.py:17-30).  obs_bytes = offset of the reward. */
+int tg_get_packed_outputs(tg_ctx* ctx, void** dev_ptr, int64_t* obs_bytes, int64_t* total_bytes);
 /* "extended_feature" observation (object_push_env.py:611-629): float32 [num_envs][*dim]: TCP pos, rpy and current goal
  * pos, rpy in the work frame; terminal != 0: the copy taken at the last step (rows valid where done). */
 int tg_get_obs_feature(tg_ctx* ctx, void** dev_ptr, int32_t* dim, int32_t terminal);

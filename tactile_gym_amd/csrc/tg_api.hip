@@ -1445,6 +1445,7 @@ struct tg_ctx {
     float *d_nodef_dep = nullptr, *d_verts = nullptr, *d_soup = nullptr, *d_actions = nullptr;
     uint8_t* d_nodef_gray = nullptr;   // uint8(nodef_gray)
     uint8_t *d_border = nullptr, *d_obs = nullptr, *d_term = nullptr, *d_mask = nullptr;
+    size_t packed_obs_bytes = 0, packed_bytes = 0;   // d_obs = [obs | pad to 16 | reward f32[n] | done u8[n]]
     int32_t* d_tris = nullptr;
     int n_tris = 0;
     tg::Stimulus stim{};
@@ -1685,14 +1686,14 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&s.q, nd * 8)); TG_HIP(hipMalloc(&s.qd, nd * 8)); TG_HIP(hipMalloc(&s.qd_target, nd * 8));
     TG_HIP(hipMalloc(&s.tcp_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.tcp_rpy, 3 * n * 8));
     TG_HIP(hipMalloc(&s.edge_ang, n * 8)); TG_HIP(hipMalloc(&s.embed, n * 8));
-    TG_HIP(hipMalloc(&s.stim_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.term_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.reward, n * 4));
+    TG_HIP(hipMalloc(&s.stim_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.term_xform, 12 * n * 4));
     TG_HIP(hipMalloc(&s.step_count, n * 4)); TG_HIP(hipMalloc(&s.reset_ticks, n * 4)); TG_HIP(hipMalloc(&s.licence, n * 4));
-    TG_HIP(hipMalloc(&s.rng, n * 8)); TG_HIP(hipMalloc(&s.done, n));
+    TG_HIP(hipMalloc(&s.rng, n * 8));
     TG_HIP(hipMemset(s.q, 0, nd * 8)); TG_HIP(hipMemset(s.qd, 0, nd * 8)); TG_HIP(hipMemset(s.qd_target, 0, nd * 8));
     TG_HIP(hipMemset(s.tcp_pos, 0, 3 * n * 8)); TG_HIP(hipMemset(s.tcp_rpy, 0, 3 * n * 8));
     TG_HIP(hipMemset(s.edge_ang, 0, n * 8)); TG_HIP(hipMemset(s.embed, 0, n * 8));
-    TG_HIP(hipMemset(s.stim_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.term_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.reward, 0, n * 4));
-    TG_HIP(hipMemset(s.step_count, 0, n * 4)); TG_HIP(hipMemset(s.reset_ticks, 0, n * 4)); TG_HIP(hipMemset(s.licence, 0, n * 4)); TG_HIP(hipMemset(s.done, 0, n));
+    TG_HIP(hipMemset(s.stim_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.term_xform, 0, 12 * n * 4));
+    TG_HIP(hipMemset(s.step_count, 0, n * 4)); TG_HIP(hipMemset(s.reset_ticks, 0, n * 4)); TG_HIP(hipMemset(s.licence, 0, n * 4));
     std::vector<uint64_t> seeds(n);
     for (int i = 0; i < n; ++i) seeds[i] = mix64((uint64_t)i + kGolden);
     TG_HIP(hipMemcpy(s.rng, seeds.data(), n * 8, hipMemcpyHostToDevice));
@@ -1781,7 +1782,13 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
         }
         c->stim.kind = 0; c->stim.verts = c->d_verts; c->stim.tris = c->d_tris; c->stim.soup = c->d_soup; c->stim.n_tris = stim->n_tris;
     }
-    TG_HIP(hipMalloc(&c->d_obs, npix * n)); TG_HIP(hipMemset(c->d_obs, 0, npix * n));
+    // one allocation [tactile obs u8 | reward f32 | done u8]: what a rank ships to rank 0 per step is one contiguous byte range
+    // (tg_get_packed_outputs).  The obs block is padded to 16 bytes so the reward block stays aligned.
+    c->packed_obs_bytes = ((size_t)npix * n + 15) & ~(size_t)15;
+    c->packed_bytes = c->packed_obs_bytes + (size_t)n * 4 + (size_t)n;
+    TG_HIP(hipMalloc(&c->d_obs, c->packed_bytes)); TG_HIP(hipMemset(c->d_obs, 0, c->packed_bytes));
+    s.reward = (float*)(c->d_obs + c->packed_obs_bytes);
+    s.done = c->d_obs + c->packed_obs_bytes + (size_t)n * 4;
     TG_HIP(hipMalloc(&c->d_term, npix * n)); TG_HIP(hipMemset(c->d_term, 0, npix * n));
     TG_HIP(hipMalloc(&c->d_mask, n));
     TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 6 * sizeof(float)));
@@ -1796,8 +1803,8 @@ int tg_destroy(tg_ctx* c) {
     drain_events(c);
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     State& s = c->st;
-    void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform, s.reward,
-                    s.step_count, s.reset_ticks, s.licence, s.rng, s.done, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+    void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
+                    s.step_count, s.reset_ticks, s.licence, s.rng, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1925,6 +1932,13 @@ int tg_get_reward_done_dev(tg_ctx* c, void** r, void** d) {
     if (!c) return fail(-1, "NULL ctx");
     if (r) *r = c->st.reward;
     if (d) *d = c->st.done;
+    return 0;
+}
+int tg_get_packed_outputs(tg_ctx* c, void** p, int64_t* obs_bytes, int64_t* total_bytes) {
+    if (!c || !p) return fail(-1, "NULL argument");
+    *p = c->d_obs;
+    if (obs_bytes) *obs_bytes = (int64_t)c->packed_obs_bytes;
+    if (total_bytes) *total_bytes = (int64_t)c->packed_bytes;
     return 0;
 }
 int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {

@@ -24,7 +24,7 @@ class ShardedVecEnv:
     the PREVIOUS step (complete by then), i.e. the learner side runs one step behind the simulators, and flush() waits for the
     last gather and returns its batch.  With overlap=False every step() returns its own gathered batch (synchronous VecEnv)."""
 
-    def __init__(self, local, dist=None, root=0, overlap=False):
+    def __init__(self, local, dist=None, root=0, overlap=False, force_collective=False):
         import torch
         if dist is None:
             import torch.distributed as dist
@@ -32,9 +32,12 @@ class ShardedVecEnv:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.n_local = local.num_envs
         self.num_envs = self.n_local * self.world
-        self.overlap = bool(overlap) and self.world > 1
+        # force_collective: run the packed gather even with one rank (a 1-GPU box can then exercise the RCCL path end to end)
+        self._solo = self.world == 1 and not force_collective
+        self.overlap = bool(overlap) and not self._solo
         self._bufs = {}
-        self._stage, self._full, self._pending, self._tick, self._layout, self._last = [None, None], [None, None], [None, None], 0, None, None
+        self._stage, self._full, self._views, self._pending = [None, None], [None, None], [None, None], [None, None]
+        self._tick, self._layout, self._last = 0, None, None
 
     def env_slice(self):
         return slice(self.rank * self.n_local, (self.rank + 1) * self.n_local)
@@ -47,7 +50,7 @@ class ShardedVecEnv:
         return t[self.env_slice()]
 
     def _gather(self, name, t):
-        if self.world == 1:
+        if self._solo:
             return t
         t = t.contiguous()
         if self.rank == self.root:
@@ -65,45 +68,54 @@ class ShardedVecEnv:
         obs = self.local.reset()
         return {k: self._gather("obs_" + k, v) for k, v in obs.items()}
 
-    # ---- packed exchange: [tactile bytes | reward bytes | done bytes] per rank
+    # ---- packed exchange: [tactile bytes | pad | reward bytes | done bytes] per rank
     def _pack(self, slot, tac, rew, done):
         torch = self.torch
+        packed = self.local.packed() if hasattr(self.local, "packed") else None   # the library's own contiguous output block
         nb_t, nb_r, nb_d = tac.numel(), rew.numel() * 4, done.numel()
+        off_r = packed[1] if packed is not None else (nb_t + 15) & ~15
         if self._layout is None:
-            assert tac.dtype == torch.uint8 and rew.dtype == torch.float32 and done.dtype == torch.uint8 and nb_t % 4 == 0
-            self._layout = (tuple(tac.shape), nb_t, nb_r, nb_d)
+            assert tac.dtype == torch.uint8 and rew.dtype == torch.float32 and done.dtype == torch.uint8
+            assert packed is None or packed[0].numel() == off_r + nb_r + nb_d
+            self._layout = (tuple(tac.shape), nb_t, off_r, nb_r, nb_d)
+        total = off_r + nb_r + nb_d
         if self._stage[slot] is None:
-            self._stage[slot] = torch.empty(nb_t + nb_r + nb_d, dtype=torch.uint8, device=tac.device)
+            self._stage[slot] = torch.zeros(total, dtype=torch.uint8, device=tac.device)
             if self.rank == self.root:
-                self._full[slot] = torch.empty((self.world, nb_t + nb_r + nb_d), dtype=torch.uint8, device=tac.device)
+                self._full[slot] = torch.empty((self.world, total), dtype=torch.uint8, device=tac.device)
+                self._views[slot] = [self._full[slot][i] for i in range(self.world)]
         st = self._stage[slot]
-        st[:nb_t].copy_(tac.reshape(-1))
-        st[nb_t:nb_t + nb_r].view(torch.float32).copy_(rew.reshape(-1))
-        st[nb_t + nb_r:].copy_(done.reshape(-1))
-        if st.is_cuda:
+        if packed is not None:
+            st.copy_(packed[0])                                                   # one device copy
+        else:
+            st[:nb_t].copy_(tac.reshape(-1))
+            st[off_r:off_r + nb_r].view(torch.float32).copy_(rew.reshape(-1))
+            st[off_r + nb_r:].copy_(done.reshape(-1))
+        if st.is_cuda and not getattr(self.local, "pipelined", False):
             # the sources alias the env library's device buffers, which the next step's kernels (on the library's own stream) overwrite:
-            # the snapshot must have been taken before step() returns (a 17 MB device copy, ~6 us)
+            # the snapshot must have been taken before step() returns (a 17 MB device copy, ~6 us).  A pipelined shard runs the
+            # library on the current stream, where the copy is ordered before the next step by the stream itself.
             torch.cuda.current_stream(st.device).synchronize()
         return st
 
     def _start_gather(self, slot, async_op):
         st = self._stage[slot]
         if self.rank == self.root:
-            return self.dist.gather(st, gather_list=[self._full[slot][i] for i in range(self.world)], dst=self.root, async_op=async_op)
+            return self.dist.gather(st, gather_list=self._views[slot], dst=self.root, async_op=async_op)
         return self.dist.gather(st, gather_list=None, dst=self.root, async_op=async_op)
 
     def _unpack(self, slot):
         torch = self.torch
-        shape, nb_t, nb_r, nb_d = self._layout
+        shape, nb_t, off_r, nb_r, nb_d = self._layout
         full = self._full[slot]
         tac = full[:, :nb_t].reshape((self.world * shape[0],) + shape[1:])
-        rew = full[:, nb_t:nb_t + nb_r].contiguous().view(torch.float32).reshape(-1)
-        done = full[:, nb_t + nb_r:].reshape(-1)
+        rew = full[:, off_r:off_r + nb_r].contiguous().view(torch.float32).reshape(-1)
+        done = full[:, off_r + nb_r:].reshape(-1)
         return {"tactile": tac}, rew, done
 
     def step(self, local_actions):
         obs, rew, done, info = self.local.step(local_actions)
-        if self.world == 1:
+        if self._solo:
             return obs, rew, done, info
         slot = self._tick & 1
         if self._pending[slot] is not None:          # this staging buffer's previous gather (two steps ago) must be complete
@@ -128,7 +140,7 @@ class ShardedVecEnv:
 
     def flush(self):
         """overlap=True: wait for the outstanding gathers; rank 0 gets the gathered batch of the last step."""
-        if self.world == 1 or not self.overlap or self._tick == 0:
+        if self._solo or not self.overlap or self._tick == 0:
             return None
         for k in (0, 1):
             if self._pending[k] is not None:
@@ -139,10 +151,24 @@ class ShardedVecEnv:
 
 
 class TorchShard:
-    """Adapter: a TactileVecEnv (obs_mode='torch') presented with torch reward/done tensors, no host copies."""
+    """Adapter: a TactileVecEnv (obs_mode='torch') presented with torch reward/done tensors, no host copies.
 
-    def __init__(self, venv):
-        self.venv, self.num_envs = venv, venv.num_envs
+    pipelined=False: step() returns after the step has finished on the device (step_async + sync), like VecEnv.step_wait.
+    pipelined=True: the library is put on a torch stream (`self.stream`) and step() only ENQUEUES the step; the returned tensors
+    are valid for work enqueued on that stream afterwards (a policy forward pass, the packed gather), the usual CUDA-stream contract.
+    The host then runs ahead of the device instead of idling through every step, so per-step launch overhead is hidden; the caller
+    must do its torch work under `with torch.cuda.stream(shard.stream)` and synchronise before reading results on the host."""
+
+    def __init__(self, venv, pipelined=False):
+        self.venv, self.num_envs, self.pipelined, self.stream = venv, venv.num_envs, bool(pipelined), None
+        if self.pipelined:
+            import torch
+            self.stream = torch.cuda.Stream(device=venv.tactile_torch().device)
+            venv.sync()
+            venv.set_stream(self.stream.cuda_stream)
+
+    def packed(self):
+        return self.venv.packed_torch()
 
     def reset(self):
         self.venv.reset()
@@ -150,6 +176,7 @@ class TorchShard:
 
     def step(self, actions):
         self.venv.step_async(actions)
-        self.venv.sync()
+        if not self.pipelined:
+            self.venv.sync()
         rew, done = self.venv.reward_done_torch()
         return {"tactile": self.venv.tactile_torch()}, rew, done, {}

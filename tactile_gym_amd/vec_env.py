@@ -186,6 +186,15 @@ class TactileVecEnv:
                                  torch.as_tensor(_DevArray(d.value, (self.num_envs,), "|u1"), device=dev))
         return self._views["rd"]
 
+    def packed_torch(self):
+        """Zero-copy torch.uint8 view of the whole per-step output block [obs | pad | reward f32 | done u8] and the reward offset."""
+        if "packed" not in self._views:
+            import torch
+            p, ob, tot = C.c_void_p(), C.c_int64(), C.c_int64()
+            capi.check(self._L.tg_get_packed_outputs(self._ctx, C.byref(p), C.byref(ob), C.byref(tot)))
+            self._views["packed"] = (torch.as_tensor(_DevArray(p.value, (tot.value,), "|u1"), device=f"cuda:{self._cfg.device}"), ob.value)
+        return self._views["packed"]
+
     def tactile_numpy(self, terminal=False):
         buf = self._obs_host if not terminal else np.zeros_like(self._obs_host)
         capi.check(self._L.tg_copy_obs_tactile(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint8)), int(terminal)))

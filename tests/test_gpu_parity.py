@@ -776,3 +776,38 @@ def test_tcp_position_control_with_free_body_matches_oracle(env_id):
             assert abs(rew[i] - rr) < 1e-6 and bool(done[i]) == rd
             assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (step, i)
     venv.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_shard_and_packed_outputs(edge_modes):
+    """The device-resident rollout path bench.py times: TorchShard(pipelined=True) enqueues steps on a torch stream without a host wait.
+    Same seeds and actions as the blocking path -> identical images / rewards / dones after 30 steps (auto-reset on); the packed output
+    block [obs | pad | reward | done] (tg_get_packed_outputs) aliases the three per-field views."""
+    import torch
+    import tactile_gym_amd as tg
+    from tactile_gym_amd.parallel import TorchShard
+    n = 128
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    acts = [torch.empty(n, 2, device="cuda").uniform_(-0.25, 0.25, generator=g) for _ in range(30)]
+    outs = []
+    for pipelined in (False, True):
+        venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=12, image_size=[128, 128], env_modes=edge_modes, seed=3, auto_reset=True,
+                           obs_mode="torch")
+        shard = TorchShard(venv, pipelined=pipelined)
+        ctx = torch.cuda.stream(shard.stream) if pipelined else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            shard.reset()
+            hist = []
+            for a in acts:
+                obs, rew, done, _ = shard.step(a)
+                hist.append((obs["tactile"].clone(), rew.clone(), done.clone()))      # ordered after the step on the same stream
+            torch.cuda.synchronize()
+        packed, off = shard.packed()
+        assert off == (n * 128 * 128 + 15) // 16 * 16 and packed.numel() == off + 5 * n
+        assert torch.equal(packed[:n * 128 * 128], obs["tactile"].reshape(-1))
+        assert torch.equal(packed[off:off + 4 * n].view(torch.float32), rew) and torch.equal(packed[off + 4 * n:], done)
+        outs.append([(t.cpu(), r.cpu(), d.cpu()) for t, r, d in hist])
+        venv.close()
+    assert any(bool(d.any()) for _, _, d in outs[0])                                   # episodes ended and were reset inside the steps
+    for (t0, r0, d0), (t1, r1, d1) in zip(*outs):
+        assert torch.equal(t0, t1) and torch.equal(r0, r1) and torch.equal(d0, d1)

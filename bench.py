@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=128)
     ap.add_argument("--physics", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-literal", action="store_true", help="skip the literal-solver companion run (keeps a rocprofv3 trace of this command to one solver mode)")
     ap.add_argument("--sync-steps", action="store_true", help="block the host on every step (VecEnv.step_wait semantics) instead of pipelining")
     ap.add_argument("--full-sweeps", action="store_true",
                     help="always run all 150 PGS sweeps per tick instead of leaving the loop at convergence to the last bit (DESIGN.md 4.1)")
@@ -150,7 +151,7 @@ def main():
         prof = venv.profile_get()
         venv.profile(False)
     literal = None
-    if world == 1 and not args.full_sweeps:
+    if world == 1 and not args.full_sweeps and not args.no_literal:
         # the same workload with the literal solver (every tick: dynamics + all 150 PGS sweeps), for comparison; short run
         lit = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
                           seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",

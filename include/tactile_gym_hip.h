@@ -74,7 +74,8 @@ enum { TG_SMOVE_YZ = 0, TG_SMOVE_XYZ = 1, TG_SMOVE_YZRX = 2, TG_SMOVE_XYZRXRY = 
 enum { TG_BMOVE_XY = 0, TG_BMOVE_XYZ = 1, TG_BMOVE_RXRY = 2, TG_BMOVE_XYRXRY = 3 };         /* object_balance_env.py:398-424 */
 enum { TG_PMOVE_Y = 0, TG_PMOVE_YRZ = 1, TG_PMOVE_XYRZ = 2, TG_PMOVE_TYRZ = 3, TG_PMOVE_TXTYRZ = 4 }; /* object_push_env.py:372-454 */
 enum { TG_TRAJ_SIMPLEX = 0, TG_TRAJ_STRAIGHT = 1 };                                          /* object_push_env.py:248-313 */
-enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };
+enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };                               /* edge_follow noise_mode */
+enum { TG_SNOISE_SIMPLEX = 0, TG_SNOISE_NONE = 1, TG_SNOISE_RANDOM = 2 };                   /* surface_follow noise_mode (base_surface_env.py:448-471) */
 enum { TG_REWARD_DENSE = 0, TG_REWARD_SPARSE = 1 };
 enum { TG_PHYSICS_F64 = 0, TG_PHYSICS_F32 = 1 };
 enum { TG_CONTROL_TCP_VELOCITY = 0, TG_CONTROL_TCP_POSITION = 1 };                             /* robot.py:156-186 apply_action */

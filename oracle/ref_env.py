@@ -382,7 +382,8 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         modes = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
                      reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")
         modes.update(env_modes or {})
-        assert modes["noise_mode"] == "simplex" and modes["movement_mode"] in ("yz", "xyz", "yzRx", "xyzRxRy") and modes["reward_mode"] == "dense"
+        assert modes["noise_mode"] in ("simplex", "none", "random") and modes["movement_mode"] in ("yz", "xyz", "yzRx", "xyzRxRy")
+        assert modes["reward_mode"] == "dense"
         rest = [0.16682, -2.18943, -1.65357, -0.86897, 1.57315, 1.74001]                   # surface_follow/rest_poses.py
         self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # base_surface_env.py:60-63
         self.embed_dist = {"tactip": 0.0025, "digitac": 0.0015, "digit": 0.0015}[self.t_s_name]   # :66-75
@@ -416,13 +417,22 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
     def reset(self):
         """base_surface_env.py:615-636: update_surface (:434-516), make_goal (:518-575), update_init_pose (:590-613)."""
         self.step_counter = 0
-        self.noise_seed = self.rng.randint(1e8)                                          # :448
-        self.heightfield_data = opensimplex_heightfield(self.noise_seed, self.rows, self.cols, self.interp, self.height_range)
         one_d = self.modes["movement_mode"] in ("yz", "yzRx")
-        if one_d:                                                                         # gen_heigtfield_simplex_1d (:339-357)
-            n2 = opensimplex_noise2(self.noise_seed, 0, 0)
-            row = np.array([n2(1 * self.interp, y * self.interp) * self.height_range for y in range(self.cols)])
-            self.heightfield_data = np.tile(row, (self.rows, 1))
+        if self.modes["noise_mode"] == "none":                                            # :452-453
+            self.heightfield_data = np.zeros((self.rows, self.cols))
+        elif self.modes["noise_mode"] == "random":                                        # gen_heigtfield_noisey (:302-317)
+            self.heightfield_data = np.zeros((self.rows, self.cols))
+            for j in range(self.cols // 2):
+                for i in range(self.rows // 2):
+                    h = self.rng.uniform(0, self.height_range * 0.2)
+                    self.heightfield_data[2 * i:2 * i + 2, 2 * j:2 * j + 2] = h
+        else:
+            self.noise_seed = self.rng.randint(1e8)                                       # :448
+            self.heightfield_data = opensimplex_heightfield(self.noise_seed, self.rows, self.cols, self.interp, self.height_range)
+            if one_d:                                                                     # gen_heigtfield_simplex_1d (:339-357)
+                n2 = opensimplex_noise2(self.noise_seed, 0, 0)
+                row = np.array([n2(1 * self.interp, y * self.interp) * self.height_range for y in range(self.cols)])
+                self.heightfield_data = np.tile(row, (self.rows, 1))
         X, Y = np.meshgrid(self.x_bins, self.y_bins)
         self.surface_array = np.dstack((X, Y, self.heightfield_data + self.surface_pos[2]))    # :476-477
         gy, gx = np.gradient(self.heightfield_data, self.grid_scale)                     # :500-508

@@ -19,6 +19,7 @@ PMOVE = {"y": 0, "yRz": 1, "xyRz": 2, "TyRz": 3, "TxTyRz": 4}
 TRAJ = {"simplex": 0, "straight": 1}
 BMOVE = {"xy": 0, "xyz": 1, "RxRy": 2, "xyRxRy": 3}
 CONTROL = {"TCP_velocity_control": 0, "TCP_position_control": 1}
+SNOISE = {"simplex": 0, "none": 1, "random": 2}
 SMOVE = {"yz": 0, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}
 MOVE = {"xy": 0, "xyz": 1, "xyRz": 2, "xyzRz": 3}
 NOISE = {"fixed_height": 0, "rand_height": 1}

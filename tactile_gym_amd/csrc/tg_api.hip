@@ -492,7 +492,12 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
             if (c.noise_mode == TG_NOISE_RAND_HEIGHT) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
             edge_ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
         } else {                                          // base_surface_env.py:448 (simplex seed), :520-534 (goal direction)
-            st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
+            if (c.noise_mode == TG_SNOISE_SIMPLEX) {
+                st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
+            } else if (c.noise_mode == TG_SNOISE_RANDOM) {   // gen_heigtfield_noisey draws (rows/2)(cols/2) uniforms: k_gen_surface
+                st.noise_seed[env] = (int64_t)rs;            // evaluates them from this state, the stream moves past them here
+                rs += (uint64_t)((c.surf_rows / 2) * (c.surf_cols / 2)) * kGolden;
+            }
             if (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_YZRX) {   // no variation in x: np_random.choice([-1, 1])
                 st.dir[0 * n + env] = 0.0;
                 st.dir[1 * n + env] = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
@@ -1390,6 +1395,7 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.surf_goal = cfg.surf_goal_variant ? 1 : 0;
 
         if (cfg.reward_mode != TG_REWARD_DENSE) return fail(-1, "surface_follow: only the dense reward is built");
+        if (cfg.noise_mode < TG_SNOISE_SIMPLEX || cfg.noise_mode > TG_SNOISE_RANDOM) return fail(-1, "Incorrect noise mode specified");
         if (cfg.surf_rows < 2 || cfg.surf_cols < 2) return fail(-1, "surface_follow: heightfield needs at least 2x2 samples");
         c.surf_rows = cfg.surf_rows; c.surf_cols = cfg.surf_cols;
         c.surf_scale = cfg.surf_grid_scale; c.surf_range = cfg.surf_height_range; c.surf_interp = cfg.surf_interp;
@@ -1621,8 +1627,9 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
 #undef CALL
         launch_gen_surface(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
                            c->cfg.surf_height_range, c->cfg.surf_center_z,
-                           (c->cfg.movement_mode == TG_SMOVE_YZ || c->cfg.movement_mode == TG_SMOVE_YZRX) ? 1 : 0, c->st.heights, c->st.surf_zoff,
-                           c->stream);
+                           c->cfg.noise_mode == TG_SNOISE_NONE ? TG_SURF_FLAT : c->cfg.noise_mode == TG_SNOISE_RANDOM ? TG_SURF_RANDOM
+                           : (c->cfg.movement_mode == TG_SMOVE_YZ || c->cfg.movement_mode == TG_SMOVE_YZRX) ? TG_SURF_SIMPLEX_1D : TG_SURF_SIMPLEX_2D,
+                           c->st.heights, c->st.surf_zoff, c->stream);
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 2)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL

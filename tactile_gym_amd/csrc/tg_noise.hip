@@ -70,9 +70,21 @@ __device__ double opensimplex_noise2(const int16_t* perm, double x, double y) {
     return value / kNorm2D;
 }
 
+// Draw number d (0-based) of the SplitMix64 stream whose state is `state` (tg_api.hip: rng_uniform; oracle/ref_env.py: Rng.uniform).
+__device__ inline double splitmix_uniform(unsigned long long state, unsigned long long d, double lo, double hi) {
+#pragma clang fp contract(off)
+    unsigned long long z = state + (d + 1ULL) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    const double span = (hi - lo) * u;
+    return lo + span;
+}
+
 // grid: n_envs blocks of 256 threads
 __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ seeds, int rows,
-                                                     int cols, double interp, double range, int center_z, int one_d,
+                                                     int cols, double interp, double range, int center_z, int mode,
                                                      double* __restrict__ heights, float* __restrict__ zoff) {
     __shared__ int16_t perm[256];
     __shared__ int16_t source[256];
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
     if (env >= n_envs || (mask != nullptr && mask[env] == 0)) return;
     source[tid] = (int16_t)tid;
     __syncthreads();
-    if (tid == 0) {   // OpenSimplex.__init__: three warm-up LCG steps, then a Fisher-Yates style draw without replacement
+    if (tid == 0 && mode <= TG_SURF_SIMPLEX_1D) {   // OpenSimplex.__init__: three warm-up LCG steps, then a Fisher-Yates style draw without replacement
         unsigned long long s = (unsigned long long)seeds[env];
         s = s * 6364136223846793005ULL + 1442695040888963407ULL;
         s = s * 6364136223846793005ULL + 1442695040888963407ULL;
@@ -100,8 +112,20 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
     float lo = 3.0e38f, hi = -3.0e38f;
     for (int k = tid; k < rows * cols; k += 256) {
         const int x = k / cols, y = k % cols;       // heightfield_data[x, y], base_surface_env.py:327-335
-        // 2-D: noise2(x c, y c) (gen_heigtfield_simplex_2d, :319-337); 1-D: noise2(1 c, y c), constant along x (_1d, :339-357)
-        const double h = opensimplex_noise2(perm, (double)(one_d ? 1 : x) * interp, (double)y * interp) * range;
+        double h;
+        if (mode == TG_SURF_FLAT) {                 // noise_mode "none" (:452-453)
+            h = 0.0;
+        } else if (mode == TG_SURF_RANDOM) {
+            // noise_mode "random": gen_heigtfield_noisey (:302-317), one np_random.uniform(0, 0.2 range) per 2x2 block, drawn with the
+            // column block j outer and the row block i inner.  seeds[env] is the env's SplitMix64 state before the first of these
+            // draws (k_reset advanced its own copy past them), so draw number d is a pure function of (state, d).
+            const int i = x >> 1, j = y >> 1;
+            const unsigned long long d = (unsigned long long)j * (unsigned long long)(rows / 2) + (unsigned long long)i;
+            h = (2 * i + 1 < rows && 2 * j + 1 < cols) ? splitmix_uniform((unsigned long long)seeds[env], d, 0.0, range * 0.2) : 0.0;
+        } else {
+            // 2-D: noise2(x c, y c) (gen_heigtfield_simplex_2d, :319-337); 1-D: noise2(1 c, y c), constant along x (_1d, :339-357)
+            h = opensimplex_noise2(perm, (double)(mode == TG_SURF_SIMPLEX_1D ? 1 : x) * interp, (double)y * interp) * range;
+        }
         out[k] = h;
         const float hf = (float)h;                  // Bullet receives the samples as float (PHY_FLOAT)
         lo = fminf(lo, hf); hi = fmaxf(hi, hf);
@@ -169,8 +193,8 @@ void launch_gen_traj(int n_envs, const uint8_t* mask, const int64_t* seeds, int 
 }
 
 void launch_gen_surface(int n_envs, const uint8_t* mask, const int64_t* seeds, int rows, int cols, double interp, double range, int center_z,
-                        int one_d, double* heights, float* zoff, hipStream_t stream) {
-    hipLaunchKernelGGL(k_gen_surface, dim3(n_envs), dim3(256), 0, stream, n_envs, mask, seeds, rows, cols, interp, range, center_z, one_d, heights,
+                        int mode, double* heights, float* zoff, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gen_surface, dim3(n_envs), dim3(256), 0, stream, n_envs, mask, seeds, rows, cols, interp, range, center_z, mode, heights,
                        zoff);
 }
 

@@ -32,9 +32,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     arm, t_s_name = modes["arm_type"], modes["tactile_sensor_name"]
     if modes["noise_mode"] == "vertical_simplex":
         raise NotImplementedError("vertical surfaces (surface_follow-v2, `forward` sensor) are not built yet")
-    if modes["noise_mode"] != "simplex":
-        if modes["noise_mode"] in ("none", "random"):
-            raise NotImplementedError(f"noise_mode {modes['noise_mode']} is not built yet (BASELINE config 3 uses simplex)")
+    if modes["noise_mode"] not in capi.SNOISE:
         raise SystemExit("Incorrect noise mode specified")                                      # :466
     if modes["movement_mode"] not in capi.SMOVE:
         raise SystemExit("Incorrect movement mode specified")
@@ -52,7 +50,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg = capi.TgConfig()
     cfg.abi_version, cfg.env_kind = capi.ABI_VERSION, capi.ENV_SURFACE_FOLLOW_AUTO
     cfg.num_envs, cfg.max_steps = int(num_envs), int(max_steps)
-    cfg.movement_mode, cfg.noise_mode, cfg.reward_mode = capi.SMOVE[modes["movement_mode"]], 0, capi.REWARD["dense"]
+    cfg.movement_mode, cfg.noise_mode, cfg.reward_mode = capi.SMOVE[modes["movement_mode"]], capi.SNOISE[modes["noise_mode"]], capi.REWARD["dense"]
     cfg.physics_dtype = capi.PHYSICS[physics_dtype]
     cfg.sim_dt = 1.0 / 240.0                                                                    # :26
     cfg.action_repeat = int(np.floor((1.0 / 10.0) / cfg.sim_dt))                                # :27-28

@@ -811,3 +811,39 @@ def test_pipelined_shard_and_packed_outputs(edge_modes):
     assert any(bool(d.any()) for _, _, d in outs[0])                                   # episodes ended and were reset inside the steps
     for (t0, r0, d0), (t1, r1, d1) in zip(*outs):
         assert torch.equal(t0, t1) and torch.equal(r0, r1) and torch.equal(d0, d1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noise", ["none", "random"])
+def test_surface_follow_noise_modes_match_oracle(noise):
+    """surface_follow noise_mode "none" (flat surface) and "random" (gen_heigtfield_noisey, base_surface_env.py:302-317: one uniform
+    draw per 2x2 block, evaluated in parallel from the env's RNG state): heights bit-exact, two consecutive episodes (the RNG stream
+    moves past the block draws), 4 envs vs 4 oracle envs."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleSurfaceFollowAutoEnv
+    modes = dict(SURF_MODES, noise_mode=noise)
+    n = 4
+    venv = tg.make_vec("surface_follow-v0", num_envs=n, max_steps=3, image_size=[128, 128], env_modes=modes, seed=31, auto_reset=False)
+    oracles = [OracleSurfaceFollowAutoEnv(seed=31 + i, max_steps=3, image_size=(128, 128), env_modes=modes) for i in range(n)]
+    rng = np.random.default_rng(32)
+    for episode in range(2):
+        obs = venv.reset()
+        ref = [o.reset() for o in oracles]
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            assert np.array_equal(st["heights"][i], o.heightfield_data) and st["surf_zoff"][i] == o.surf_zoff
+            assert np.abs(st["goal_pos"][i] - o.goal_pos_world).max() < 1e-12
+            assert np.array_equal(obs["tactile"][i], ref[i]["tactile"])
+        if noise == "random":
+            assert len(np.unique(st["heights"][0])) > 500 and st["heights"].max() <= 0.005
+        for step in range(3):
+            a = rng.uniform(-0.25, 0.25, size=(n, 3)).astype(np.float32)
+            a[:, 0] = np.abs(a[:, 0])
+            obs, rew, done, _ = venv.step(a)
+            st = venv.get_state()
+            for i, o in enumerate(oracles):
+                ro, rr, rd, _ = o.step(a[i])
+                assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8, (episode, step, i)
+                assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
+                assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 2, (episode, step, i)
+    venv.close()

@@ -383,7 +383,7 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
                      reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")
         modes.update(env_modes or {})
         assert modes["noise_mode"] in ("simplex", "none", "random") and modes["movement_mode"] in ("yz", "xyz", "yzRx", "xyzRxRy")
-        assert modes["reward_mode"] == "dense"
+        assert modes["reward_mode"] in ("dense", "sparse")
         rest = [0.16682, -2.18943, -1.65357, -0.86897, 1.57315, 1.74001]                   # surface_follow/rest_poses.py
         self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # base_surface_env.py:60-63
         self.embed_dist = {"tactip": 0.0025, "digitac": 0.0015, "digit": 0.0015}[self.t_s_name]   # :66-75
@@ -447,6 +447,7 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         goal = [self.surface_pos[0] + self.x_y_extent * wd[0], self.surface_pos[1] + self.x_y_extent * wd[1]]
         gi, gj = self._xy_to_surface_idx(goal[0], goal[1])
         self.goal_pos_world = np.array(goal + [self.surface_array[gi, gj, 2]])
+        self.accum_rew = 0.0                                                              # :589-591
         hc = self.heightfield_data[int(self.rows / 2), int(self.cols / 2)]               # :594
         init_world = [self.surface_pos[0], self.surface_pos[1], self.surface_pos[2] + hc - self.embed_dist]
         init_pos, _ = self._world_to_work(init_world, [0, 0, 0])
@@ -470,6 +471,13 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         return enc
 
     def _get_step_data(self):                                                            # base_surface_env.py:664-684
+        rew, done = self._dense_step_data()
+        if self.modes["reward_mode"] == "sparse":                                        # sparse_reward, surface_follow_auto_env.py:59-73
+            self.accum_rew += rew
+            rew = self.accum_rew if float(np.linalg.norm(self.cur_tcp_pos - self.goal_pos_world)) < self.termination_dist else 0
+        return rew, done
+
+    def _dense_step_data(self):
         self.cur_tcp_pos, self.cur_tcp_rpy, self.cur_tcp_orn, _, _ = self._tcp_world()
         self.tip_i, self.tip_j = self._xy_to_surface_idx(self.cur_tcp_pos[0], self.cur_tcp_pos[1])
         done = float(np.linalg.norm(self.cur_tcp_pos - self.goal_pos_world)) < self.termination_dist or self.step_counter >= self.max_steps
@@ -523,8 +531,8 @@ class OracleSurfaceFollowGoalEnv(OracleSurfaceFollowAutoEnv):
             enc[0], enc[1], enc[2], enc[3], enc[4] = a[0], a[1], a[2], a[3], a[4]
         return enc
 
-    def _get_step_data(self):                                                            # :69-90
-        rew_auto, done = super()._get_step_data()                                       # -(surf_dist + w_norm cos_dist)
+    def _dense_step_data(self):                                                          # :69-90
+        rew_auto, done = super()._dense_step_data()                                     # -(surf_dist + w_norm cos_dist)
         R = pm.mat_from_quat(self.cur_tcp_orn)
         surf_z = self.surface_array[self.tip_i, self.tip_j, 2]
         surf_dist = abs((self.cur_tcp_pos + R @ np.array([0, 0, -self.embed_dist]))[2] - surf_z)

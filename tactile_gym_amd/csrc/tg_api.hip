@@ -68,6 +68,7 @@ struct State {   // device pointers, SoA [field][num_envs]
     uint8_t* done;
     // surface_follow
     double *dir, *goal, *heights;   // [2][n], [3][n], [n][rows*cols]
+    double* accum;                  // [n] sparse reward: the episode's accumulated dense reward
     float* surf_zoff;               // [n]
     int64_t* noise_seed;            // [n]
     // object_balance
@@ -159,7 +160,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
     }
-    if (write_reward_done && c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+    if ((write_reward_done || c.reward_mode == TG_REWARD_SPARSE) && c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         // get_step_data / dense_reward (base_surface_env.py:664-684, 703-760; surface_follow_auto_env.py:75-94)
         const int R = c.surf_rows, Cc = c.surf_cols;
         int ti = digitize_linspace((double)ptcp.y, c.ybin_lo, c.ybin_hi, Cc);   // xy_to_surface_idx (:284-300)
@@ -180,9 +181,17 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         const T gdx = ptcp.x - (T)st.goal[0 * n + env], gdy = ptcp.y - (T)st.goal[1 * n + env], gdz = ptcp.z - (T)st.goal[2 * n + env];
         const T reward = c.surf_goal ? -((T(1) * tsqrt(gdx * gdx + gdy * gdy)) + (T(10) * surf_dist) + (w_norm * (T(1) - cos_sim)))   // goal_env :69-90
                                      : -((T(1) * surf_dist) + (w_norm * (T(1) - cos_sim)));
-        const bool done = tsqrt(gdx * gdx + gdy * gdy + gdz * gdz) < c.term_dist || step_count >= c.max_steps;
-        st.reward[env] = (float)reward;
-        st.done[env] = done ? 1 : 0;
+        const bool at_goal = tsqrt(gdx * gdx + gdy * gdy + gdz * gdz) < c.term_dist;
+        T out = reward;
+        if (c.reward_mode == TG_REWARD_SPARSE) {   // sparse_reward (surface_follow_auto_env.py:59-73): the dense reward is accumulated over the
+            const double acc = st.accum[env] + (double)reward;   // episode (from the reset pose on, base_surface_env.py:640) and paid out at the goal
+            st.accum[env] = acc;
+            out = at_goal ? (T)acc : T(0);
+        }
+        if (write_reward_done) {
+            st.reward[env] = (float)out;
+            st.done[env] = (at_goal || step_count >= c.max_steps) ? 1 : 0;
+        }
     }
     // camera frame = sensor-body frame o cam offset; eye axes (right, up, -forward) with forward = R[:,0], up = R[:,2]
     V3<T> pb; M3<T> Rb;
@@ -492,6 +501,7 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
             if (c.noise_mode == TG_NOISE_RAND_HEIGHT) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
             edge_ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
         } else {                                          // base_surface_env.py:448 (simplex seed), :520-534 (goal direction)
+            st.accum[env] = 0.0;                              // make_goal, base_surface_env.py:589-591
             if (c.noise_mode == TG_SNOISE_SIMPLEX) {
                 st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
             } else if (c.noise_mode == TG_SNOISE_RANDOM) {   // gen_heigtfield_noisey draws (rows/2)(cols/2) uniforms: k_gen_surface
@@ -1394,7 +1404,6 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         }
         c.surf_goal = cfg.surf_goal_variant ? 1 : 0;
 
-        if (cfg.reward_mode != TG_REWARD_DENSE) return fail(-1, "surface_follow: only the dense reward is built");
         if (cfg.noise_mode < TG_SNOISE_SIMPLEX || cfg.noise_mode > TG_SNOISE_RANDOM) return fail(-1, "Incorrect noise mode specified");
         if (cfg.surf_rows < 2 || cfg.surf_cols < 2) return fail(-1, "surface_follow: heightfield needs at least 2x2 samples");
         c.surf_rows = cfg.surf_rows; c.surf_cols = cfg.surf_cols;
@@ -1770,9 +1779,9 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     if (cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         const size_t cells = (size_t)cfg->surf_rows * cfg->surf_cols;
         TG_HIP(hipMalloc(&s.dir, 2 * n * 8)); TG_HIP(hipMalloc(&s.goal, 3 * n * 8)); TG_HIP(hipMalloc(&s.heights, cells * n * 8));
-        TG_HIP(hipMalloc(&s.surf_zoff, n * 4)); TG_HIP(hipMalloc(&s.noise_seed, n * 8));
+        TG_HIP(hipMalloc(&s.surf_zoff, n * 4)); TG_HIP(hipMalloc(&s.noise_seed, n * 8)); TG_HIP(hipMalloc(&s.accum, n * 8));
         TG_HIP(hipMemset(s.dir, 0, 2 * n * 8)); TG_HIP(hipMemset(s.goal, 0, 3 * n * 8)); TG_HIP(hipMemset(s.heights, 0, cells * n * 8));
-        TG_HIP(hipMemset(s.surf_zoff, 0, n * 4)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8));
+        TG_HIP(hipMemset(s.surf_zoff, 0, n * 4)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8)); TG_HIP(hipMemset(s.accum, 0, n * 8));
         c->stim.kind = 1; c->stim.heights = s.heights; c->stim.zoff = s.surf_zoff;
         c->stim.rows = cfg->surf_rows; c->stim.cols = cfg->surf_cols; c->stim.scale = (float)cfg->surf_grid_scale;
         c->stim.n_tris = (cfg->surf_rows - 1) * (cfg->surf_cols - 1) * 2;
@@ -1811,7 +1820,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.rng, s.dir, s.goal, s.heights, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -44,13 +44,13 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         if arm in ("mg400", "franka_panda", "kuka_iiwa"):
             raise NotImplementedError(f"arm_type {arm} is not built yet for surface_follow")
         raise SystemExit(f"Incorrect arm type specified {arm}")
-    if modes["reward_mode"] != "dense":
-        raise NotImplementedError("only the dense reward is built for surface_follow")
+    if modes["reward_mode"] not in capi.REWARD:
+        raise SystemExit("Incorrect reward mode specified")
     t_s_type = "standard"                                                                       # :60-63
     cfg = capi.TgConfig()
     cfg.abi_version, cfg.env_kind = capi.ABI_VERSION, capi.ENV_SURFACE_FOLLOW_AUTO
     cfg.num_envs, cfg.max_steps = int(num_envs), int(max_steps)
-    cfg.movement_mode, cfg.noise_mode, cfg.reward_mode = capi.SMOVE[modes["movement_mode"]], capi.SNOISE[modes["noise_mode"]], capi.REWARD["dense"]
+    cfg.movement_mode, cfg.noise_mode, cfg.reward_mode = capi.SMOVE[modes["movement_mode"]], capi.SNOISE[modes["noise_mode"]], capi.REWARD[modes["reward_mode"]]
     cfg.physics_dtype = capi.PHYSICS[physics_dtype]
     cfg.sim_dt = 1.0 / 240.0                                                                    # :26
     cfg.action_repeat = int(np.floor((1.0 / 10.0) / cfg.sim_dt))                                # :27-28

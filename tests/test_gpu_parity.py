@@ -847,3 +847,36 @@ def test_surface_follow_noise_modes_match_oracle(noise):
                 assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
                 assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 2, (episode, step, i)
     venv.close()
+
+
+@pytest.mark.gpu
+def test_surface_follow_sparse_reward_matches_oracle():
+    """reward_mode "sparse" of surface_follow (surface_follow_auto_env.py:59-73): the dense reward is accumulated over the episode
+    (starting with the reset pose, base_surface_env.py:640) and paid out on the step that reaches the goal.  Flat surface so the
+    auto-driven TCP does reach the goal (150 mm at 1 mm per step); 3 envs vs 3 oracle envs until every env is done."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleSurfaceFollowAutoEnv
+    modes = dict(SURF_MODES, noise_mode="none", reward_mode="sparse", tactile_sensor_name="tactip")
+    n = 3
+    venv = tg.make_vec("surface_follow-v0", num_envs=n, max_steps=200, image_size=[64, 64], env_modes=modes, seed=41, auto_reset=False)
+    oracles = [OracleSurfaceFollowAutoEnv(seed=41 + i, max_steps=200, image_size=(64, 64), env_modes=modes) for i in range(n)]
+    venv.reset()
+    for o in oracles:
+        o.reset()
+    finished = np.zeros(n, dtype=bool)
+    paid = np.zeros(n)
+    a = np.zeros((n, 3), dtype=np.float32)
+    for step in range(200):
+        obs, rew, done, _ = venv.step(a)
+        for i, o in enumerate(oracles):
+            if finished[i]:
+                continue
+            ro, rr, rd, _ = o.step(a[i])
+            assert abs(rew[i] - rr) <= 1e-5 * max(1.0, abs(rr)), (step, i, rew[i], rr)
+            assert bool(done[i]) == rd, (step, i)
+            if rd:
+                finished[i], paid[i] = True, rr
+        if finished.all():
+            break
+    assert finished.all() and step < 199 and (paid < 0).all()          # every env reached the goal and was paid its accumulated reward
+    venv.close()

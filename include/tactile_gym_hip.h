@@ -153,6 +153,11 @@ typedef struct {
      * constant_vel = None) (robot.py:188-260). */
     int32_t control_mode;                   /* TG_CONTROL_* */
     int32_t max_blocking_steps;             /* _max_blocking_pos_move_steps = 10 (edge_follow_env.py:38) */
+    /* object_push: goal index right after reset.  reset() ends with get_step_data() (base_object_env.py:183-185), whose termination()
+     * advances the goal when the cube is within termination_pos_dist of it (:520-537); the first goal sits exactly that far from the
+     * cube's start position, so whether index 0 or 1 comes out is decided by double rounding of the work-frame constants.  The host
+     * evaluates that comparison once, the way the reference would (PARITY_ASSUMPTIONS A29). */
+    int32_t reset_goal_id, reserved2;
 } tg_config;
 
 typedef struct tg_ctx tg_ctx;

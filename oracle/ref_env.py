@@ -713,24 +713,36 @@ class OracleObjectPushEnv(_OracleArmEnv):
     """object_push-v0 (nonprehensile_manipulation/object_push/object_push_env.py + base_object_env.py): MG400 + right-angle
     sensor pushing a cube along a trajectory of goals on the table; tip collision core ON (t_s_core = "fixed")."""
 
-    REST = {"tactip": [-0.5059580369524724, 1.2694708511711394, -0.19901995409914455, -1.0721610064154656, 0.5045899087172413,
-                       1.269469774233031, -1.269469774233031, 1.0704498256453248],
-            "digitac": [-0.4745979999944637, 1.2836350191938928, 0.254159419927845, -1.5395417027560878, 0.47634420683617346,
-                        1.2838656861791102, -1.283854805915325, 1.5380912693333302],      # object_push/rest_poses.py (mg400, right_angle)
-            "digit": [-0.4558165479388624, 1.2857227247064174, 0.26532296230426017, -1.5518769541832729, 0.45743009274925944,
-                      1.28573249852019, -1.2857285129498681, 1.5510764390458196]}
+    # object_push/rest_poses.py, control joints; MG400 + TacTip = the mini_right_angle sensor (object_push_env.py:70-75)
+    REST = {"mg400": {"tactip": [-0.4675810386176251, 1.2330268637269028, -0.042146321181746195, -1.1915354526403177, 0.4668115359824357,
+                                 1.2330268635741901, -1.2330268635741901, 1.1908822248875286],
+                      "digitac": [-0.4745979999944637, 1.2836350191938928, 0.254159419927845, -1.5395417027560878, 0.47634420683617346,
+                                  1.2838656861791102, -1.283854805915325, 1.5380912693333302],
+                      "digit": [-0.4558165479388624, 1.2857227247064174, 0.26532296230426017, -1.5518769541832729, 0.45743009274925944,
+                                1.28573249852019, -1.2857285129498681, 1.5510764390458196]},
+            "ur5": {"tactip": [-0.29446578243858357, -2.1633703222876646, -1.7712875440608364, -0.7758826291678864, 1.569501010720629,
+                               -1.8628739133606422],
+                    "digit": [-0.2363248329397155, -2.1381281530498035, -1.8208841358171288, -0.751838113524854, 1.5711258995033301,
+                              -1.80239847761509],
+                    "digitac": [-0.24571108391609556, -2.142076416487341, -1.8135315230114846, -0.7552488203413393, 1.5711290394202047,
+                                -1.8118003855516092]}}
 
     def __init__(self, seed=0, max_steps=1000, image_size=(128, 128), env_modes=None, inertia="collision_aabb"):
         modes = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
                      observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")
         modes.update(env_modes or {})
-        assert modes["arm_type"] == "mg400" and modes["tactile_sensor_name"] in ("tactip", "digitac", "digit")
-        self._setup_arm(seed, modes, max_steps, image_size, "right_angle", self.REST[modes["tactile_sensor_name"]], inertia)   # :47-49
+        assert modes["arm_type"] in ("mg400", "ur5") and modes["tactile_sensor_name"] in ("tactip", "digitac", "digit")
+        mg = modes["arm_type"] == "mg400"
+        t_s_type = "mini_right_angle" if (mg and modes["tactile_sensor_name"] == "tactip") else "right_angle"    # :59, :70-75
+        self._setup_arm(seed, modes, max_steps, image_size, t_s_type, self.REST[modes["arm_type"]][modes["tactile_sensor_name"]], inertia)
         self.obj_width = self.obj_height = 0.08                                             # :45-46
         self.termination_pos_dist = 0.025                                                   # :57
         a = 45 * math.pi / 180
-        self.TCP_lims = np.array([[-0.0, 0.3], [-0.1, 0.08], [-0.0, 0.0], [-0.0, 0.0], [-0.0, 0.0], [-a, a]])   # :62-68
-        self.well_designed_pos = np.array([0.28 if modes["tactile_sensor_name"] == "tactip" else 0.25, -0.1, self.obj_height / 2])   # :70-79
+        self.TCP_lims = np.array([[-0.0, 0.3], [-0.1, 0.08 if mg else 0.1], [-0.0, 0.0], [-0.0, 0.0], [-0.0, 0.0], [-a, a]])   # :62-68, :81-87
+        if mg:
+            self.well_designed_pos = np.array([0.30 if modes["tactile_sensor_name"] == "tactip" else 0.25, -0.1, self.obj_height / 2])   # :70-79
+        else:
+            self.well_designed_pos = np.array([0.55, -0.20, self.obj_height / 2])           # :90
         self._set_workframe(self.well_designed_pos, [-math.pi, 0.0, math.pi / 2])           # :87-88
         v, w = 0.01, 5.0 * (math.pi / 180)                                                  # :126-134
         if self.position_control:
@@ -748,7 +760,7 @@ class OracleObjectPushEnv(_OracleArmEnv):
             b.inertia[k] = float(z["inertia"].reshape(9)[k])
         self.cube = b
         self._mass0, self._inertia0 = b.mass, [b.inertia[k] for k in range(9)]
-        r = np.load(os.path.join(_ASSETS, "robots", f"mg400_right_angle_{self.t_s_name}{suffix}.npz"))
+        r = np.load(os.path.join(_ASSETS, "robots", f"{self.arm_type}_{self.t_s_type}_{self.t_s_name}{suffix}.npz"))
         self._tip_verts = np.ascontiguousarray(r["tip_hull_verts"], dtype=np.float64)
         sc = mb.MBPushScene()
         sc.table_z = 0.0

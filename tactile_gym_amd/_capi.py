@@ -85,7 +85,7 @@ class TgConfig(C.Structure):
         ("tip_stiffness", C.c_double), ("tip_damping", C.c_double), ("obj_lin_damp", C.c_double), ("obj_ang_damp", C.c_double),
         ("traj_spacing", C.c_double), ("traj_max_perturb", C.c_double), ("traj_init_offset", C.c_double),
         ("mass_lo", C.c_double), ("mass_hi", C.c_double), ("init_orn_range", C.c_double), ("traj_ang_range", C.c_double),
-        ("control_mode", C.c_int32), ("max_blocking_steps", C.c_int32),
+        ("control_mode", C.c_int32), ("max_blocking_steps", C.c_int32), ("reset_goal_id", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 

@@ -53,7 +53,7 @@ template <typename T> struct EnvConst {
     int fused_reset;             // edge_follow with auto_reset: k_reset keeps the terminal camera transform, one render launch draws both images
     // object_push
     PushScene<T> push;
-    int traj_type, traj_n, rand_init_orn, rand_obj_mass;
+    int traj_type, traj_n, rand_init_orn, rand_obj_mass, reset_goal_id;
     double traj_spacing, traj_max_perturb, traj_init_offset, mass_lo, mass_hi, init_orn_range, traj_ang_range, obj_mass0;
     T obj_init_pos[3];
     double obj_init_rpy[3];
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict
     }
     st.rng[env] = rs;
     st.step_count[env] = 0;
-    st.goal_id[env] = 0;
+    st.goal_id[env] = c.reset_goal_id;   // get_step_data at the end of reset may already have advanced the goal (tg_config.reset_goal_id)
     FreeBody<T> b = load_body<T>(st, n, env);
     T q[N], qd[N];
 #pragma unroll
@@ -1390,6 +1390,8 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         for (int k = 0; k < 6; ++k) ps.inertia0[k] = (T)cfg.obj_inertia[sym[k]];
         ps.mass0 = (T)cfg.obj_mass;
         ps.tip_link = cfg.tip_link; ps.n_tip = cfg.n_tip_verts; ps.cone_friction = cfg.cone_friction;
+        if (cfg.reset_goal_id < 0 || cfg.reset_goal_id > 1) return fail(-1, "object_push: reset_goal_id must be 0 or 1");
+        c.reset_goal_id = cfg.reset_goal_id;
         c.traj_type = cfg.traj_type; c.traj_n = cfg.traj_n_points; c.rand_init_orn = cfg.rand_init_orn; c.rand_obj_mass = cfg.rand_obj_mass;
         c.traj_spacing = cfg.traj_spacing; c.traj_max_perturb = cfg.traj_max_perturb; c.traj_init_offset = cfg.traj_init_offset;
         c.mass_lo = cfg.mass_lo; c.mass_hi = cfg.mass_hi; c.init_orn_range = cfg.init_orn_range; c.traj_ang_range = cfg.traj_ang_range;
@@ -1629,7 +1631,7 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
 #undef CALL
         if (c->cfg.traj_type == TG_TRAJ_SIMPLEX)
             launch_gen_traj(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.traj_n_points, c->cfg.traj_spacing, c->cfg.traj_max_perturb,
-                            c->cfg.traj_init_offset, c->st.traj, c->st.feature, c->stream);
+                            c->cfg.traj_init_offset, c->cfg.reset_goal_id, c->st.traj, c->st.feature, c->stream);
     } else if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 1)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);

@@ -14,5 +14,5 @@ void launch_gen_surface(int n_envs, const uint8_t* mask, const int64_t* seeds, i
 // object_push goal trajectory (update_trajectory_simplex): traj [3][16][n_envs] work-frame x, y, yaw; refreshes the goal half of
 // the extended_feature rows (feature may be nullptr).
 void launch_gen_traj(int n_envs, const uint8_t* mask, const int64_t* seeds, int n_points, double spacing, double max_perturb, double init_offset,
-                     double* traj, float* feature, hipStream_t stream);
+                     int goal0, double* traj, float* feature, hipStream_t stream);
 }  // namespace tg

@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
 // x_i = init_offset + i * spacing, yaw = np.gradient(y, spacing).  One 64-thread workgroup per resetting env.
 // traj layout: [3][TG_MAX_TRAJ_POINTS = 16][n_envs]; feature: float [n_envs][12], goal slots 6..11 refreshed for goal 0.
 __global__ __launch_bounds__(64) void k_gen_traj(int n_envs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ seeds, int n_points,
-                                                 double spacing, double max_perturb, double init_offset, double* __restrict__ traj,
-                                                 float* __restrict__ feature) {
+                                                 double spacing, double max_perturb, double init_offset, int goal0,
+                                                 double* __restrict__ traj, float* __restrict__ feature) {
     __shared__ int16_t perm[256];
     __shared__ int16_t source[256];
     __shared__ double ys[16];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void k_gen_traj(int n_envs, const uint8_t* __re
         traj[((size_t)0 * 16 + tid) * n_envs + env] = x;
         traj[((size_t)1 * 16 + tid) * n_envs + env] = y;
         traj[((size_t)2 * 16 + tid) * n_envs + env] = g;
-        if (tid == 0 && feature != nullptr) {
+        if (tid == goal0 && feature != nullptr) {   // goal slots of the extended_feature observation: the goal current after reset
             float* f = feature + (size_t)env * 12;
             f[6] = (float)x; f[7] = (float)y; f[8] = 0.0f; f[9] = 0.0f; f[10] = 0.0f; f[11] = (float)g;
         }
@@ -188,8 +188,9 @@ __global__ __launch_bounds__(64) void k_gen_traj(int n_envs, const uint8_t* __re
 }
 
 void launch_gen_traj(int n_envs, const uint8_t* mask, const int64_t* seeds, int n_points, double spacing, double max_perturb, double init_offset,
-                     double* traj, float* feature, hipStream_t stream) {
-    hipLaunchKernelGGL(k_gen_traj, dim3(n_envs), dim3(64), 0, stream, n_envs, mask, seeds, n_points, spacing, max_perturb, init_offset, traj, feature);
+                     int goal0, double* traj, float* feature, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gen_traj, dim3(n_envs), dim3(64), 0, stream, n_envs, mask, seeds, n_points, spacing, max_perturb, init_offset, goal0, traj,
+                       feature);
 }
 
 void launch_gen_surface(int n_envs, const uint8_t* mask, const int64_t* seeds, int rows, int cols, double interp, double range, int center_z,

@@ -15,14 +15,19 @@ from .. import _capi as capi
 from ..robot_model import ASSETS, MeshDesc, SensorDesc, load_tgmodel, make_robot
 from ..vec_env import TactileVecEnv
 
-REST_POSES = {  # object_push/rest_poses.py (right_angle), control-joint order
+REST_POSES = {  # object_push/rest_poses.py, control-joint order; MG400 + TacTip carries the `mini_right_angle` sensor (object_push_env.py:70-75)
     "mg400": {
-        "tactip": [-0.5059580369524724, 1.2694708511711394, -0.19901995409914455, -1.0721610064154656, 0.5045899087172413,
-                   1.269469774233031, -1.269469774233031, 1.0704498256453248],
+        "tactip": [-0.4675810386176251, 1.2330268637269028, -0.042146321181746195, -1.1915354526403177, 0.4668115359824357,
+                   1.2330268635741901, -1.2330268635741901, 1.1908822248875286],
         "digit": [-0.4558165479388624, 1.2857227247064174, 0.26532296230426017, -1.5518769541832729, 0.45743009274925944,
                   1.28573249852019, -1.2857285129498681, 1.5510764390458196],
         "digitac": [-0.4745979999944637, 1.2836350191938928, 0.254159419927845, -1.5395417027560878, 0.47634420683617346,
                     1.2838656861791102, -1.283854805915325, 1.5380912693333302],
+    },
+    "ur5": {
+        "tactip": [-0.29446578243858357, -2.1633703222876646, -1.7712875440608364, -0.7758826291678864, 1.569501010720629, -1.8628739133606422],
+        "digit": [-0.2363248329397155, -2.1381281530498035, -1.8208841358171288, -0.751838113524854, 1.5711258995033301, -1.80239847761509],
+        "digitac": [-0.24571108391609556, -2.142076416487341, -1.8135315230114846, -0.7552488203413393, 1.5711290394202047, -1.8118003855516092],
     },
 }
 
@@ -40,6 +45,25 @@ env_modes_default = {  # object_push_env.py:11-20
 TIP_DYNAMICS = {"tactip": (50.0, 100.0, 10.0), "digitac": (300.0, 100.0, 10.0), "digit": (50.0, 200.0, 10.0)}
 
 
+def _goal_reached_at_reset(wf_pos, wf_rpy, obj_init_pos, init_offset, term_dist):
+    """reset() ends with get_step_data() (base_object_env.py:183-185): termination() (object_push_env.py:520-537) advances the goal if the
+    cube is closer than termination_pos_dist to it.  Goal 0 = work-frame (obj_width/2 + spacing, 0, 0) lies exactly that far from the cube's
+    start position, so the outcome is a rounding question of the configuration's constants.  Evaluated here in double the way the reference
+    chain does (getQuaternionFromEuler -> multiplyTransforms -> np.linalg.norm) [PARITY_ASSUMPTIONS A29]."""
+    phi, the, psi = (0.5 * float(v) for v in wf_rpy)
+    q = np.array([math.sin(phi) * math.cos(the) * math.cos(psi) - math.cos(phi) * math.sin(the) * math.sin(psi),
+                  math.cos(phi) * math.sin(the) * math.cos(psi) + math.sin(phi) * math.cos(the) * math.sin(psi),
+                  math.cos(phi) * math.cos(the) * math.sin(psi) - math.sin(phi) * math.sin(the) * math.cos(psi),
+                  math.cos(phi) * math.cos(the) * math.cos(psi) + math.sin(phi) * math.sin(the) * math.sin(psi)])
+    x, y, z, w = (float(v) for v in q / math.sqrt(float(q @ q)))
+    sc = 2.0 / (x * x + y * y + z * z + w * w)
+    xs, ys, zs = x * sc, y * sc, z * sc
+    wx, wy, wz, xx, xy, xz, yy, yz, zz = w * xs, w * ys, w * zs, x * xs, x * ys, x * zs, y * ys, y * zs, z * zs
+    R = np.array([[1.0 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1.0 - (xx + zz), yz - wx], [xz - wy, yz + wx, 1.0 - (xx + yy)]])
+    goal0 = np.asarray(wf_pos, dtype=np.float64) + R @ np.array([init_offset, 0.0, 0.0])
+    return bool(float(np.linalg.norm(np.asarray(obj_init_pos, dtype=np.float64) - goal0)) < term_dist)
+
+
 def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64", auto_reset=True, device=0, inertia_mode="collision_aabb"):
     modes = dict(env_modes)
     for k in ("movement_mode", "control_mode", "rand_init_orn", "rand_obj_mass", "traj_type", "observation_mode", "reward_mode", "arm_type",
@@ -47,6 +71,8 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         if k not in modes:
             raise KeyError(k)                                                                   # object_push_env.py:34-43
     arm, t_s_name, t_s_type = modes["arm_type"], modes["tactile_sensor_name"], "right_angle"    # :48
+    if arm == "mg400" and t_s_name == "tactip":
+        t_s_type = "mini_right_angle"                                                           # :70-75
     if modes["movement_mode"] not in capi.PMOVE:
         raise ValueError(f"unknown movement_mode {modes['movement_mode']}")
     if modes["traj_type"] not in capi.TRAJ:
@@ -56,7 +82,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
             raise NotImplementedError(f"control_mode {modes['control_mode']} is outside the built hot path (SURVEY 8f rank 2)")
         raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")
     if arm not in REST_POSES:
-        if arm in ("ur5", "franka_panda", "kuka_iiwa"):
+        if arm in ("franka_panda", "kuka_iiwa"):
             raise NotImplementedError(f"arm_type {arm} is not built yet for object_push")
         raise SystemExit(f"Incorrect arm type specified {arm}")
     if t_s_name not in TIP_DYNAMICS:
@@ -77,7 +103,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         v, w = 0.001, 1 * (math.pi / 180)                                                       # :137-148 m / rad per step
     lo, hi = [-v, -v, 0.0, 0.0, 0.0, -w], [v, v, 0.0, 0.0, 0.0, w]
     a = 45 * math.pi / 180
-    lims = [(-0.0, 0.3), (-0.1, 0.08), (-0.0, 0.0), (-0.0, 0.0), (-0.0, 0.0), (-a, a)]           # :62-68
+    lims = [(-0.0, 0.3), (-0.1, 0.08 if arm == "mg400" else 0.1), (-0.0, 0.0), (-0.0, 0.0), (-0.0, 0.0), (-a, a)]   # :62-68 mg400, :81-87 ur5
     for d in range(6):
         cfg.act_lo[d], cfg.act_hi[d] = lo[d], hi[d]
         cfg.tcp_lims[d][0], cfg.tcp_lims[d][1] = lims[d]
@@ -85,7 +111,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     if arm == "mg400" and t_s_name != "tactip":                                                 # :70-79
         wd = (0.25, -0.1, obj_h / 2)
     elif arm == "mg400":
-        wd = (0.28, -0.1, obj_h / 2)
+        wd = (0.30, -0.1, obj_h / 2)
     else:
         wd = (0.55, -0.20, obj_h / 2)
     wf_rpy = (-math.pi, 0.0, math.pi / 2)                                                       # :88
@@ -112,6 +138,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.traj_type, cfg.traj_n_points = capi.TRAJ[modes["traj_type"]], 10                        # :229
     cfg.traj_spacing, cfg.traj_max_perturb = 0.025, 0.1                                         # :230-231
     cfg.traj_init_offset = obj_w / 2 + cfg.traj_spacing                                         # :262
+    cfg.reset_goal_id = int(_goal_reached_at_reset(wd, wf_rpy, init_pos, cfg.traj_init_offset, cfg.termination_dist))
     cfg.rand_init_orn, cfg.rand_obj_mass = int(bool(modes["rand_init_orn"])), int(bool(modes["rand_obj_mass"]))
     cfg.mass_lo, cfg.mass_hi = 0.4, 0.8                                                         # :190-192
     cfg.init_orn_range, cfg.traj_ang_range = math.pi / 32, math.pi / 8                          # :170, :283

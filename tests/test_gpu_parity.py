@@ -462,8 +462,10 @@ PUSH_MODES = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", ran
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sensor,movement,traj", [("digitac", "TyRz", "simplex"), ("tactip", "xyRz", "straight"), ("digit", "TxTyRz", "simplex")])
-def test_object_push_env_matches_oracle(sensor, movement, traj):
+@pytest.mark.parametrize("arm,sensor,movement,traj", [("mg400", "digitac", "TyRz", "simplex"), ("mg400", "tactip", "xyRz", "straight"),
+                                                      ("mg400", "digit", "TxTyRz", "simplex"), ("ur5", "digitac", "TyRz", "simplex"),
+                                                      ("ur5", "tactip", "TxTyRz", "straight")])
+def test_object_push_env_matches_oracle(arm, sensor, movement, traj):
     """object_push-v0 (BASELINE config 4: MG400 + DigiTac right-angle sensor, cube on the table, tip collision core ON): rigid
     contacts cube-table and cube-tip with friction.  Two consecutive episodes (the second Robot.reset runs with the cube where the
     first episode left it), 4 envs vs 4 oracle envs.  Contact dynamics amplify rounding differences (the HIP tick uses FMA
@@ -471,8 +473,8 @@ def test_object_push_env_matches_oracle(sensor, movement, traj):
     float32, goal index / done exact, tactile images within 3 pixels; the simplex goal trajectory is bit-exact."""
     import tactile_gym_amd as tg
     from oracle.ref_env import OracleObjectPushEnv
-    modes = dict(PUSH_MODES, tactile_sensor_name=sensor, movement_mode=movement, traj_type=traj)
-    n, steps, size = 4, 7, 128
+    modes = dict(PUSH_MODES, arm_type=arm, tactile_sensor_name=sensor, movement_mode=movement, traj_type=traj)   # MG400 + TacTip: the
+    n, steps, size = 4, 7, 128                                                   # mini_right_angle sensor; UR5: object_push_env.py:81-90
     act_dim = {"TyRz": 2, "xyRz": 3, "TxTyRz": 3}[movement]
     venv = tg.make_vec("object_push-v0", num_envs=n, max_steps=steps, image_size=[size, size], env_modes=modes, seed=31, auto_reset=False)
     assert venv.observation_space["extended_feature"].shape == (12,) and venv.action_space.shape == (act_dim,)
@@ -484,7 +486,7 @@ def test_object_push_env_matches_oracle(sensor, movement, traj):
         ref = [o.reset() for o in oracles]
         st = venv.get_state()
         for i, o in enumerate(oracles):
-            assert st["reset_ticks"][i] == o.reset_ticks and st["obj_mass"][i] == o.cube.mass and st["goal_id"][i] == 0
+            assert st["reset_ticks"][i] == o.reset_ticks and st["obj_mass"][i] == o.cube.mass and st["goal_id"][i] == o.targ_traj_list_id
             assert np.abs(st["q"][i] - o.arm.q).max() < 1e-9
             assert np.abs(st["body_pos"][i] - o.cube_pose()[0]).max() < 1e-12 and np.abs(st["body_rot"][i] - o.cube_pose()[1]).max() < 1e-12
             if traj == "simplex":

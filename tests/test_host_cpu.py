@@ -157,8 +157,13 @@ def test_object_push_config_and_registry():
         op.build_config(8, 1000, (128, 128), {"movement_mode": "TyRz"})
     with pytest.raises(ValueError):
         op.build_config(8, 1000, (128, 128), dict(modes, movement_mode="sideways"))
+    cfg_u, robot_u, sensor_u, _, _, tip_u = op.build_config(8, 1000, (128, 128), dict(modes, arm_type="ur5"))       # object_push_env.py:81-90
+    assert robot_u.ndof == 6 and robot_u.topology == 0 and [cfg_u.workframe_pos[k] for k in range(3)] == [0.55, -0.2, 0.04]
+    assert cfg_u.tcp_lims[1][1] == 0.1 and cfg_u.tip_link == 5
+    cfg_t, _, sensor_t, _, _, _ = op.build_config(8, 1000, (128, 128), dict(modes, tactile_sensor_name="tactip"))   # :70-75
+    assert cfg_t.workframe_pos[0] == 0.30 and sensor_t.struct.cam_pos[2] == 0.001                                     # mini_right_angle
     with pytest.raises(NotImplementedError):
-        op.build_config(8, 1000, (128, 128), dict(modes, arm_type="ur5"))
+        op.build_config(8, 1000, (128, 128), dict(modes, arm_type="franka_panda"))
     with pytest.raises(SystemExit):
         op.build_config(8, 1000, (128, 128), dict(modes, traj_type="zigzag"))
 

@@ -41,11 +41,16 @@ ROBOTS = [
     ("mg400", "digitac", "right_angle"),
     ("mg400", "digit", "right_angle"),
     ("mg400", "tactip", "right_angle"),
+    ("mg400", "tactip", "mini_right_angle"),     # object_push on the MG400 with a TacTip (object_push_env.py:70-75)
+    ("ur5", "tactip", "right_angle"),            # object_push on the UR5 (object_push_env.py:59)
+    ("ur5", "digit", "right_angle"),
+    ("ur5", "digitac", "right_angle"),
 ]
 
 SENSOR_IMAGES = [
     ("tactip", "standard", (64, 128, 256)),
     ("tactip", "right_angle", (64, 128, 256)),
+    ("tactip", "mini_right_angle", (64, 128, 256)),
     ("digit", "standard", (64, 128, 256)),
     ("digit", "right_angle", (64, 128, 256)),
     ("digitac", "standard", (64, 128, 256)),
@@ -53,7 +58,12 @@ SENSOR_IMAGES = [
 ]
 
 
+ONLY_NEW = "--only-new" in sys.argv     # leave blobs that already exist untouched (zip timestamps would churn the history)
+
+
 def save(path, **arrays):
+    if ONLY_NEW and os.path.isfile(path):
+        return
     os.makedirs(os.path.dirname(path), exist_ok=True)
     np.savez_compressed(path, **arrays)
     print(f"wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path)} B)")

@@ -70,12 +70,12 @@ typedef struct {
 
 enum { TG_ENV_EDGE_FOLLOW = 0, TG_ENV_SURFACE_FOLLOW_AUTO = 1, TG_ENV_OBJECT_BALANCE = 2, TG_ENV_OBJECT_PUSH = 3 };
 enum { TG_MOVE_XY = 0, TG_MOVE_XYZ = 1, TG_MOVE_XYRZ = 2, TG_MOVE_XYZRZ = 3 };            /* edge_follow_env.py:345-369 */
-enum { TG_SMOVE_YZ = 0, TG_SMOVE_XYZ = 1, TG_SMOVE_YZRX = 2, TG_SMOVE_XYZRXRY = 3 };       /* surface_follow_auto_env.py:27-57 */
+enum { TG_SMOVE_YZ = 0, TG_SMOVE_XYZ = 1, TG_SMOVE_YZRX = 2, TG_SMOVE_XYZRXRY = 3, TG_SMOVE_XRZ = 4 };   /* surface_follow_auto_env.py:27-57; xRz: surface_follow_vert_env.py:29-48 */
 enum { TG_BMOVE_XY = 0, TG_BMOVE_XYZ = 1, TG_BMOVE_RXRY = 2, TG_BMOVE_XYRXRY = 3 };         /* object_balance_env.py:398-424 */
 enum { TG_PMOVE_Y = 0, TG_PMOVE_YRZ = 1, TG_PMOVE_XYRZ = 2, TG_PMOVE_TYRZ = 3, TG_PMOVE_TXTYRZ = 4 }; /* object_push_env.py:372-454 */
 enum { TG_TRAJ_SIMPLEX = 0, TG_TRAJ_STRAIGHT = 1 };                                          /* object_push_env.py:248-313 */
 enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };                               /* edge_follow noise_mode */
-enum { TG_SNOISE_SIMPLEX = 0, TG_SNOISE_NONE = 1, TG_SNOISE_RANDOM = 2 };                   /* surface_follow noise_mode (base_surface_env.py:448-471) */
+enum { TG_SNOISE_SIMPLEX = 0, TG_SNOISE_NONE = 1, TG_SNOISE_RANDOM = 2, TG_SNOISE_VERTICAL_SIMPLEX = 3 };                   /* surface_follow noise_mode (base_surface_env.py:448-471) */
 enum { TG_REWARD_DENSE = 0, TG_REWARD_SPARSE = 1 };
 enum { TG_PHYSICS_F64 = 0, TG_PHYSICS_F32 = 1 };
 enum { TG_CONTROL_TCP_VELOCITY = 0, TG_CONTROL_TCP_POSITION = 1 };                             /* robot.py:156-186 apply_action */
@@ -157,7 +157,12 @@ typedef struct {
      * advances the goal when the cube is within termination_pos_dist of it (:520-537); the first goal sits exactly that far from the
      * cube's start position, so whether index 0 or 1 comes out is decided by double rounding of the work-frame constants.  The host
      * evaluates that comparison once, the way the reference would (PARITY_ASSUMPTIONS A29). */
-    int32_t reset_goal_id, reserved2;
+    int32_t reset_goal_id;
+    /* surface_follow-v2 (noise_mode vertical_simplex, movement xRz; the `vertical_simplex` branches of base_surface_env.py and
+     * surface_follow_vert_env.py): the heightfield stands upright, rotated by rpy (0, -pi/2, 0) about stim_pos = surface_pos
+     * (x, y, 0.15 + range); the bins, the goal and the reward follow the reference's flipped surface_array (:476-516, :735-758);
+     * reward -(10 surf_dist + 3 cos_dist) (surface_follow_vert_env.py:66-81). */
+    int32_t surf_vertical;
 } tg_config;
 
 typedef struct tg_ctx tg_ctx;

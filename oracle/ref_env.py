@@ -555,6 +555,128 @@ class OracleSurfaceFollowGoalEnv(OracleSurfaceFollowAutoEnv):
         return obs
 
 
+class OracleSurfaceFollowVertEnv(OracleSurfaceFollowAutoEnv):
+    """surface_follow-v2 (surface_follow_vert/surface_follow_vert_env.py + the `vertical_simplex` branches of base_surface_env.py): the
+    heightfield stands upright (rotated -90 deg about y, facing -x), a `forward` sensor on the MG400 (or UR5) follows it sideways (auto
+    drive along work-frame y) while the agent controls the approach x and the yaw Rz."""
+
+    REST = {"mg400": {"tactip": [0, 0.27678229586424996, 0.6281543378436832, -0.9033290327498503, 0, 0.2767807985667566, -0.276782284688448,
+                                 0.9049031579057567],
+                      "digit": [0, 0.5905679775553622, 0.3143233272531256, -0.904800272812408, 0, 0.5905665736774282, -0.5905665736774282,
+                                0.904800272812408],
+                      "digitac": [0, 0.5212839078833752, 0.4422081884778576, -0.9632925252126955, 0, 0.5212821789748887, -0.5212821789748887,
+                                  0.9632925252126955]},                                  # surface_follow/rest_poses.py (forward)
+            "ur5": {"tactip": [0.20199342416011004, -1.8581332389746197, -1.8168154715398577, -1.0385402849835499, 1.569399439236753,
+                               -1.3656188934713112],
+                    "digit": [0.19148011767408704, -1.92776038604851, -1.7217555613365743, -1.0625670745823885, 1.568310282843754,
+                              -1.3737671809549512],
+                    "digitac": [0.19148011767408704, -1.92776038604851, -1.7217555613365743, -1.0625670745823885, 1.568310282843754,
+                                -1.3737671809549512]}}
+
+    def __init__(self, seed=0, max_steps=200, image_size=(128, 128), env_modes=None, inertia="collision_aabb", center_z=True):
+        modes = dict(movement_mode="xRz", control_mode="TCP_velocity_control", noise_mode="vertical_simplex", observation_mode="tactile",
+                     reward_mode="dense", arm_type="mg400", tactile_sensor_name="tactip")     # sb3_helpers/params/surface_follow_vert_params.py
+        modes.update(env_modes or {})
+        assert modes["noise_mode"] == "vertical_simplex" and modes["movement_mode"] == "xRz" and modes["reward_mode"] in ("dense", "sparse")
+        rest = self.REST[modes["arm_type"]][modes["tactile_sensor_name"]]
+        self._setup_arm(seed, modes, max_steps, image_size, "forward", rest, inertia)      # base_surface_env.py:60-63
+        self.embed_dist = {"tactip": 0.0025, "digitac": 0.0015, "digit": 0.0015}[self.t_s_name]   # :66-75
+        self.termination_dist = 0.01
+        self.grid_scale, self.height_range, self.rows, self.cols = 0.006, 0.025, 64, 64    # :238-243
+        self.interp, self.x_y_extent = 0.05, 0.15
+        wd = [0.33, 0.0, 0.0] if self.arm_type == "mg400" else [0.65, 0.0, 0.0]            # :51-55
+        self.original_surface_pos = np.array([wd[0], wd[1], self.height_range])            # :249-266
+        min_x = self.original_surface_pos[0] - ((self.rows / 2) * self.grid_scale)
+        max_x = self.original_surface_pos[0] + ((self.rows / 2) * self.grid_scale)
+        min_y = self.original_surface_pos[1] - ((self.cols / 2) * self.grid_scale)
+        max_y = self.original_surface_pos[1] + ((self.cols / 2) * self.grid_scale)
+        self.x_bins, self.y_bins = np.linspace(min_x, max_x, self.rows), np.linspace(min_y, max_y, self.cols)
+        self.surface_pos = np.array([wd[0], wd[1], 0.15 + self.height_range])
+        self.surface_orn = pm.quat_from_euler([0.0, -math.pi / 2, 0.0])
+        v, w = 0.01, 5.0 * (math.pi / 180)                                                 # :181-191
+        self.act_lo, self.act_hi = np.array([-v, -v, 0.0, 0.0, 0.0, -w]), np.array([v, v, 0.0, 0.0, 0.0, w])
+        if self.position_control:                                                          # :167-177 (no vertical branch there)
+            v, w = 0.001, 1 * (math.pi / 180)
+            self.act_lo, self.act_hi = np.array([-v, -v, -v, -w, -w, 0.0]), np.array([v, v, v, w, w, 0.0])
+        self._set_workframe(self.surface_pos, [-math.pi, 0.0, 0.0])                        # :87-91
+        e, h = self.x_y_extent, self.height_range
+        self.TCP_lims = np.array([[-h, h], [-e, e], [0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [-math.pi / 4, math.pi / 4]])   # :93-104
+        self.auto_scale = {"tactip": 1.0, "digitac": 0.9, "digit": 0.7}[self.t_s_name]      # surface_follow_vert_env.py:36-41
+        self.center_z = center_z
+
+    def _flip(self, pos):
+        """worldframe_to_surfaceframe -> multiplyTransforms(0, surface_orn, .) -> surfaceframe_to_worldframe (:486-498, :915-947)."""
+        ip, iq = pm.invert_transform(self.surface_pos, pm.quat_from_euler([0.0, 0.0, 0.0]))
+        ps, qs = pm.multiply_transforms(ip, iq, pos, pm.quat_from_euler([0, 0, 0]))
+        qs = pm.quat_from_euler(pm.euler_from_quat(qs))
+        pf, qf = pm.multiply_transforms([0, 0, 0], self.surface_orn, ps, qs)
+        qf = pm.quat_from_euler(pm.euler_from_quat(qf))
+        pw, _ = pm.multiply_transforms(self.surface_pos, pm.quat_from_euler([0.0, 0.0, 0.0]), pf, qf)
+        return pw
+
+    def reset(self):
+        self.step_counter = 0
+        self.noise_seed = self.rng.randint(1e8)                                          # :462-465
+        n2 = opensimplex_noise2(self.noise_seed, 0, 0)
+        col = np.array([n2(x * self.interp, 1 * self.interp) * self.height_range for x in range(self.rows)])   # _1d_vertical :358-381
+        self.heightfield_data = np.tile(col[:, None], (1, self.cols))
+        X, Y = np.meshgrid(self.x_bins, self.y_bins)
+        self.surface_array = np.dstack((X, Y, self.heightfield_data + self.surface_pos[2]))    # :476-477
+        flipped = np.empty_like(self.surface_array)
+        for xi in range(self.surface_array.shape[0]):                                    # :486-498
+            for yi in range(self.surface_array.shape[1]):
+                flipped[xi, yi] = self._flip(self.surface_array[xi, yi])
+        self.surface_array = flipped
+        gy, gx = np.gradient(self.heightfield_data, self.grid_scale)                     # :500-508
+        nrm = np.dstack((-gx, -gy, np.ones_like(self.heightfield_data)))
+        nrm = nrm / np.linalg.norm(nrm, axis=2)[..., None]
+        flip_R = pm.mat_from_quat(pm.quat_from_euler([0, -math.pi / 2, 0]))               # :510-516
+        self.surface_normals = nrm @ flip_R.T
+        self.workframe_directions = [0, -1.0 if self.rng.uniform(0.0, 1.0) < 0.5 else 1.0, 0]   # :536-540 np_random.choice([-1, 1])
+        wd = self._workvec_to_worldvec(self.workframe_directions)
+        goal = [self.original_surface_pos[0] + self.x_y_extent * wd[0], self.original_surface_pos[1] + self.x_y_extent * wd[1]]   # :547-555
+        gi, gj = self._xy_to_surface_idx(goal[0], goal[1])
+        self.goal_pos_world = np.array(self.surface_array[gi, gj])
+        self.accum_rew = 0.0
+        hc = self.heightfield_data[int(self.rows / 2), int(self.cols / 2)]               # :594-603
+        init_world = [self.surface_pos[0] - (hc - self.embed_dist), self.surface_pos[1], self.surface_pos[2]]
+        init_pos, _ = self._world_to_work(init_world, [0, 0, 0])
+        hf = self.heightfield_data.astype(np.float32)
+        self.surf_zoff = np.float32(0.5) * (hf.min() + hf.max()) if self.center_z else np.float32(0.0)
+        self.surf_verts, self.surf_tris = heightfield_mesh(self.heightfield_data, self.grid_scale, self.surf_zoff)
+        self._reset_robot(init_pos, np.zeros(3))
+        self._get_step_data()
+        return self._observation()
+
+    def _encode_actions(self, a):                                                        # surface_follow_vert_env.py:29-48
+        enc = np.zeros(6)
+        enc[1] = self.workframe_directions[1] * self.max_action * self.auto_scale
+        enc[0], enc[5] = a[0], a[1]
+        return enc
+
+    def _dense_step_data(self):                                                          # base_surface_env.py:664-684, vert_env :66-81
+        self.cur_tcp_pos, self.cur_tcp_rpy, self.cur_tcp_orn, _, _ = self._tcp_world()
+        self.tip_i, self.tip_j = self._xy_to_surface_idx(self.cur_tcp_pos[0], self.cur_tcp_pos[1])
+        done = float(np.linalg.norm(self.cur_tcp_pos - self.goal_pos_world)) < self.termination_dist or self.step_counter >= self.max_steps
+        R = pm.mat_from_quat(self.cur_tcp_orn)
+        surf_x = self.surface_array[self.tip_i, self.tip_j, 0]                           # z_dist_to_surface :735-758 (vertical branch)
+        embedded = self.cur_tcp_pos + R @ np.array([-self.embed_dist, 0, 0])
+        surf_dist = abs(embedded[0] - surf_x)
+        n = self.surface_normals[self.tip_i, self.tip_j, :]                              # cos_dist_to_surface_normal :703-725
+        t = R @ np.array([-1, 0, 0])
+        cos_dist = 1 - np.dot(n, t) / (np.linalg.norm(n) * np.linalg.norm(t))
+        return -((10.0 * surf_dist) + (3.0 * cos_dist)), bool(done)
+
+    def stimulus_transform(self):
+        cpos, cR = self.camera_pose()
+        return mb.cam_from_obj_matrix(cpos, cR, self.surface_pos, pm.mat_from_quat(self.surface_orn))
+
+    def extended_feature(self):                                                          # surface_follow_vert_env.py:83-100
+        p, _, _, _ = self._tcp_work()
+        gp, _ = self._world_to_work(self.goal_pos_world, np.zeros(3))
+        return np.hstack([p, gp])
+
+
 class OracleObjectBalanceEnv(_OracleArmEnv):
     """object_balance-v0, object_mode "pole" (nonprehensile_manipulation/object_balance/object_balance_env.py +
     base_object_env.py): UR5 + TacTip pointing up, a pole tied to the TCP by a point-to-point constraint."""

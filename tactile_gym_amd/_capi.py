@@ -19,8 +19,8 @@ PMOVE = {"y": 0, "yRz": 1, "xyRz": 2, "TyRz": 3, "TxTyRz": 4}
 TRAJ = {"simplex": 0, "straight": 1}
 BMOVE = {"xy": 0, "xyz": 1, "RxRy": 2, "xyRxRy": 3}
 CONTROL = {"TCP_velocity_control": 0, "TCP_position_control": 1}
-SNOISE = {"simplex": 0, "none": 1, "random": 2}
-SMOVE = {"yz": 0, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}
+SNOISE = {"simplex": 0, "none": 1, "random": 2, "vertical_simplex": 3}
+SMOVE = {"yz": 0, "xyz": 1, "yzRx": 2, "xyzRxRy": 3, "xRz": 4}
 MOVE = {"xy": 0, "xyz": 1, "xyRz": 2, "xyzRz": 3}
 NOISE = {"fixed_height": 0, "rand_height": 1}
 REWARD = {"dense": 0, "sparse": 1}
@@ -85,7 +85,7 @@ class TgConfig(C.Structure):
         ("tip_stiffness", C.c_double), ("tip_damping", C.c_double), ("obj_lin_damp", C.c_double), ("obj_ang_damp", C.c_double),
         ("traj_spacing", C.c_double), ("traj_max_perturb", C.c_double), ("traj_init_offset", C.c_double),
         ("mass_lo", C.c_double), ("mass_hi", C.c_double), ("init_orn_range", C.c_double), ("traj_ang_range", C.c_double),
-        ("control_mode", C.c_int32), ("max_blocking_steps", C.c_int32), ("reset_goal_id", C.c_int32), ("reserved2", C.c_int32),
+        ("control_mode", C.c_int32), ("max_blocking_steps", C.c_int32), ("reset_goal_id", C.c_int32), ("surf_vertical", C.c_int32),
     ]
 
 

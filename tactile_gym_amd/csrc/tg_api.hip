@@ -40,7 +40,8 @@ template <typename T> struct EnvConst {
     M3<T> cam_rot;               // R(cam_rpy) in the sensor-body frame
     T cam_pos[3];
     // surface_follow
-    int env_kind, surf_rows, surf_cols, surf_goal;
+    int env_kind, surf_rows, surf_cols, surf_goal, surf_vertical;
+    M3<T> stim_R;                // surface_follow-v2: rotation of the upright heightfield (identity otherwise)
     double surf_scale, surf_range, surf_interp, surf_extent, auto_scale;
     double xbin_lo, xbin_hi, ybin_lo, ybin_hi;   // np.linspace bounds of x_bins / y_bins (base_surface_env.py:258-282)
     // object_balance
@@ -121,6 +122,13 @@ __device__ inline int digitize_linspace(double v, double lo, double hi, int n) {
     }
     return count;
 }
+// np.linspace(lo, hi, n)[k], formed like digitize_linspace's edges
+__device__ inline double linspace_value(double lo, double hi, int n, int k) {
+#pragma clang fp contract(off)
+    const double step = (hi - lo) / (double)(n - 1);
+    const double prod = (double)k * step;
+    return (k == n - 1) ? hi : prod + lo;
+}
 // np.gradient(f, h) along one axis of a rows x cols array (central differences inside, one-sided at the ends)
 __device__ inline double grad_axis(const double* f, int idx, int n, int stride, double h) {
     if (idx == 0) return (f[stride] - f[0]) / h;
@@ -173,14 +181,25 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         const T gx_ = (T)grad_axis(H + (size_t)ti * Cc, tj, Cc, 1, c.surf_scale);  // axis 1
         V3<T> nrm{-gx_, -gy_, T(1)};
         nrm = (T(1) / norm(nrm)) * nrm;
-        const V3<T> tipv = mul(Rtcp, mk(T(0), T(0), T(-1)));
-        const V3<T> emb = mul(Rtcp, mk(T(0), T(0), -c.embed_default));
-        const T surf_dist = tabs((ptcp.z + emb.z) - surf_z);
-        const T cos_sim = dot(nrm, tipv) / (norm(nrm) * norm(tipv));
-        const T w_norm = (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_XYZ) ? T(0) : T(1);
         const T gdx = ptcp.x - (T)st.goal[0 * n + env], gdy = ptcp.y - (T)st.goal[1 * n + env], gdz = ptcp.z - (T)st.goal[2 * n + env];
-        const T reward = c.surf_goal ? -((T(1) * tsqrt(gdx * gdx + gdy * gdy)) + (T(10) * surf_dist) + (w_norm * (T(1) - cos_sim)))   // goal_env :69-90
-                                     : -((T(1) * surf_dist) + (w_norm * (T(1) - cos_sim)));
+        T reward;
+        if (c.surf_vertical) {   // the `vertical_simplex` branches (:703-758) on the flipped surface_array / normals (:486-516); vert_env :66-81
+            nrm = mul(c.stim_R, nrm);
+            const V3<T> tipv = mul(Rtcp, mk(T(-1), T(0), T(0)));
+            const V3<T> emb = mul(Rtcp, mk(-c.embed_default, T(0), T(0)));
+            const T surf_x = (T)((double)c.stim_pos[0] - H[(size_t)ti * Cc + tj]);   // flipped point: (sx - h, y_bins[i], sz + x_bins[j] - sx)
+            const T surf_dist = tabs((ptcp.x + emb.x) - surf_x);
+            const T cos_sim = dot(nrm, tipv) / (norm(nrm) * norm(tipv));
+            reward = -((T(10) * surf_dist) + (T(3) * (T(1) - cos_sim)));
+        } else {
+            const V3<T> tipv = mul(Rtcp, mk(T(0), T(0), T(-1)));
+            const V3<T> emb = mul(Rtcp, mk(T(0), T(0), -c.embed_default));
+            const T surf_dist = tabs((ptcp.z + emb.z) - surf_z);
+            const T cos_sim = dot(nrm, tipv) / (norm(nrm) * norm(tipv));
+            const T w_norm = (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_XYZ) ? T(0) : T(1);
+            reward = c.surf_goal ? -((T(1) * tsqrt(gdx * gdx + gdy * gdy)) + (T(10) * surf_dist) + (w_norm * (T(1) - cos_sim)))   // goal_env :69-90
+                                 : -((T(1) * surf_dist) + (w_norm * (T(1) - cos_sim)));
+        }
         const bool at_goal = tsqrt(gdx * gdx + gdy * gdy + gdz * gdz) < c.term_dist;
         T out = reward;
         if (c.reward_mode == TG_REWARD_SPARSE) {   // sparse_reward (surface_follow_auto_env.py:59-73): the dense reward is accumulated over the
@@ -204,7 +223,11 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
     s = (T(1) / norm(s)) * s;
     const V3<T> u = cross(s, f);
     // object rotation: yaw about z by edge_ang
-    const V3<T> ox{ce, se, T(0)}, oy{-se, ce, T(0)}, oz{T(0), T(0), T(1)};
+    V3<T> ox{ce, se, T(0)}, oy{-se, ce, T(0)}, oz{T(0), T(0), T(1)};
+    if (c.surf_vertical) {       // upright heightfield: the columns of its fixed rotation
+        ox = mk(c.stim_R.m[0], c.stim_R.m[3], c.stim_R.m[6]); oy = mk(c.stim_R.m[1], c.stim_R.m[4], c.stim_R.m[7]);
+        oz = mk(c.stim_R.m[2], c.stim_R.m[5], c.stim_R.m[8]);
+    }
     const V3<T> dp = load_v3(c.stim_pos) - pc;
     const V3<T> nf = mk<T>(0, 0, 0) - f;
     float* X = st.stim_xform;
@@ -279,6 +302,9 @@ __device__ __forceinline__ void encode_arm_actions(const EnvConst<T>& c, const S
             enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2];
             if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[3]; enc[4] = (T)a[4]; }
         }
+    } else if (c.surf_vertical) {                         // surface_follow_vert_env.py:29-48: y is driven toward the goal
+        enc[1] = (T)((st.dir[1 * n + env] * (double)c.max_action) * c.auto_scale);
+        enc[0] = (T)a[0]; enc[5] = (T)a[1];
     } else {                                              // surface_follow_auto_env.py:27-57: xy are driven toward the goal
         enc[0] = (T)((st.dir[0 * n + env] * (double)c.max_action) * c.auto_scale);
         enc[1] = (T)((st.dir[1 * n + env] * (double)c.max_action) * c.auto_scale);
@@ -502,13 +528,13 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
             edge_ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
         } else {                                          // base_surface_env.py:448 (simplex seed), :520-534 (goal direction)
             st.accum[env] = 0.0;                              // make_goal, base_surface_env.py:589-591
-            if (c.noise_mode == TG_SNOISE_SIMPLEX) {
+            if (c.noise_mode == TG_SNOISE_SIMPLEX || c.noise_mode == TG_SNOISE_VERTICAL_SIMPLEX) {
                 st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
             } else if (c.noise_mode == TG_SNOISE_RANDOM) {   // gen_heigtfield_noisey draws (rows/2)(cols/2) uniforms: k_gen_surface
                 st.noise_seed[env] = (int64_t)rs;            // evaluates them from this state, the stream moves past them here
                 rs += (uint64_t)((c.surf_rows / 2) * (c.surf_cols / 2)) * kGolden;
             }
-            if (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_YZRX) {   // no variation in x: np_random.choice([-1, 1])
+            if (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_YZRX || c.movement_mode == TG_SMOVE_XRZ) {   // np_random.choice([-1, 1])
                 st.dir[0 * n + env] = 0.0;
                 st.dir[1 * n + env] = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
             } else {
@@ -536,10 +562,18 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
         int gi = digitize_linspace(gy, c.ybin_lo, c.ybin_hi, Cc), gj = digitize_linspace(gx, c.xbin_lo, c.xbin_hi, R);
         if (gi == Cc) gi -= 1;
         if (gj == R) gj -= 1;
-        st.goal[0 * n + env] = gx; st.goal[1 * n + env] = gy; st.goal[2 * n + env] = H[(size_t)gi * Cc + gj] + (double)c.stim_pos[2];
-        // update_init_pose (:590-613): above the surface centre, embed_dist deep, expressed in and back out of the work frame
         const double hc = H[(size_t)(R / 2) * Cc + (Cc / 2)];
-        const V3<T> pw = mk(c.stim_pos[0], c.stim_pos[1], (T)((double)c.stim_pos[2] + hc - embed));
+        V3<T> pw;
+        if (c.surf_vertical) {   // goal = the flipped surface_array[gi, gj] (:486-498, :547-555); init pose :596-603
+            st.goal[0 * n + env] = (double)c.stim_pos[0] - H[(size_t)gi * Cc + gj];
+            st.goal[1 * n + env] = linspace_value(c.ybin_lo, c.ybin_hi, Cc, gi);
+            st.goal[2 * n + env] = (double)c.stim_pos[2] + (linspace_value(c.xbin_lo, c.xbin_hi, R, gj) - (double)c.stim_pos[0]);
+            pw = mk((T)((double)c.stim_pos[0] - (hc - embed)), c.stim_pos[1], c.stim_pos[2]);
+        } else {
+            st.goal[0 * n + env] = gx; st.goal[1 * n + env] = gy; st.goal[2 * n + env] = H[(size_t)gi * Cc + gj] + (double)c.stim_pos[2];
+            // update_init_pose (:590-613): above the surface centre, embed_dist deep, expressed in and back out of the work frame
+            pw = mk(c.stim_pos[0], c.stim_pos[1], (T)((double)c.stim_pos[2] + hc - embed));
+        }
         const V3<T> pwork = load_v3(c.work_inv_pos) + mul(c.work_Rinv, pw);
         init_world = load_v3(c.work_pos) + mul(c.work_R, pwork);
     }
@@ -1402,11 +1436,23 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
             case TG_SMOVE_XYZ: c.act_dim = cfg.surf_goal_variant ? 3 : 1; break;
             case TG_SMOVE_YZRX: c.act_dim = cfg.surf_goal_variant ? 3 : 2; break;
             case TG_SMOVE_XYZRXRY: c.act_dim = cfg.surf_goal_variant ? 5 : 3; break;
+            case TG_SMOVE_XRZ: c.act_dim = 2; break;                         // surface_follow_vert_env.py:102-113
             default: return fail(-1, "Incorrect movement mode specified");
         }
         c.surf_goal = cfg.surf_goal_variant ? 1 : 0;
+        c.surf_vertical = cfg.surf_vertical ? 1 : 0;
+        if (c.surf_vertical != (cfg.movement_mode == TG_SMOVE_XRZ ? 1 : 0) || c.surf_vertical != (cfg.noise_mode == TG_SNOISE_VERTICAL_SIMPLEX ? 1 : 0))
+            return fail(-1, "Incorrect movement mode specified");   // xRz <-> vertical_simplex (base_surface_env.py:462-470)
+        if (c.surf_vertical && c.surf_goal) return fail(-1, "surface_follow: the goal variant has no vertical surface");
+        {
+            const double srpy[3] = {0.0, c.surf_vertical ? -1.5707963267948966 : 0.0, 0.0};   // surface_orn (:263)
+            double sq[4], sR[9];
+            h_quat_from_euler(srpy, sq);
+            h_mat_from_quat(sq, sR);
+            for (int k = 0; k < 9; ++k) c.stim_R.m[k] = (T)sR[k];
+        }
 
-        if (cfg.noise_mode < TG_SNOISE_SIMPLEX || cfg.noise_mode > TG_SNOISE_RANDOM) return fail(-1, "Incorrect noise mode specified");
+        if (cfg.noise_mode < TG_SNOISE_SIMPLEX || cfg.noise_mode > TG_SNOISE_VERTICAL_SIMPLEX) return fail(-1, "Incorrect noise mode specified");
         if (cfg.surf_rows < 2 || cfg.surf_cols < 2) return fail(-1, "surface_follow: heightfield needs at least 2x2 samples");
         c.surf_rows = cfg.surf_rows; c.surf_cols = cfg.surf_cols;
         c.surf_scale = cfg.surf_grid_scale; c.surf_range = cfg.surf_height_range; c.surf_interp = cfg.surf_interp;
@@ -1639,6 +1685,7 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
         launch_gen_surface(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
                            c->cfg.surf_height_range, c->cfg.surf_center_z,
                            c->cfg.noise_mode == TG_SNOISE_NONE ? TG_SURF_FLAT : c->cfg.noise_mode == TG_SNOISE_RANDOM ? TG_SURF_RANDOM
+                           : c->cfg.noise_mode == TG_SNOISE_VERTICAL_SIMPLEX ? TG_SURF_SIMPLEX_1D_VERT
                            : (c->cfg.movement_mode == TG_SMOVE_YZ || c->cfg.movement_mode == TG_SMOVE_YZRX) ? TG_SURF_SIMPLEX_1D : TG_SURF_SIMPLEX_2D,
                            c->st.heights, c->st.surf_zoff, c->stream);
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 2)

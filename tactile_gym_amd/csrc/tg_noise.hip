@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
     if (env >= n_envs || (mask != nullptr && mask[env] == 0)) return;
     source[tid] = (int16_t)tid;
     __syncthreads();
-    if (tid == 0 && mode <= TG_SURF_SIMPLEX_1D) {   // OpenSimplex.__init__: three warm-up LCG steps, then a Fisher-Yates style draw without replacement
+    if (tid == 0 && (mode <= TG_SURF_SIMPLEX_1D || mode == TG_SURF_SIMPLEX_1D_VERT)) {   // OpenSimplex.__init__: three warm-up LCG steps, then a Fisher-Yates style draw without replacement
         unsigned long long s = (unsigned long long)seeds[env];
         s = s * 6364136223846793005ULL + 1442695040888963407ULL;
         s = s * 6364136223846793005ULL + 1442695040888963407ULL;
@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
             const int i = x >> 1, j = y >> 1;
             const unsigned long long d = (unsigned long long)j * (unsigned long long)(rows / 2) + (unsigned long long)i;
             h = (2 * i + 1 < rows && 2 * j + 1 < cols) ? splitmix_uniform((unsigned long long)seeds[env], d, 0.0, range * 0.2) : 0.0;
+        } else if (mode == TG_SURF_SIMPLEX_1D_VERT) {   // gen_heigtfield_simplex_1d_vertical (:358-381): noise2(x c, 1 c), constant along y
+            h = opensimplex_noise2(perm, (double)x * interp, 1.0 * interp) * range;
         } else {
             // 2-D: noise2(x c, y c) (gen_heigtfield_simplex_2d, :319-337); 1-D: noise2(1 c, y c), constant along x (_1d, :339-357)
             h = opensimplex_noise2(perm, (double)(mode == TG_SURF_SIMPLEX_1D ? 1 : x) * interp, (double)y * interp) * range;

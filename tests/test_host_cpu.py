@@ -187,3 +187,26 @@ def test_control_mode_config():
         ef.build_config(4, 200, (128, 128), dict(modes, control_mode="joint_velocity_control"))
     with pytest.raises(SystemExit):
         ef.build_config(4, 200, (128, 128), dict(modes, control_mode="teleport"))
+
+
+def test_surface_follow_vertical_config_and_registry():
+    """surface_follow-v2 host logic without a GPU: the vertical_simplex / xRz pairing, forward sensor, work frame and limits
+    (base_surface_env.py:51-104, 181-191, 249-266), failure modes."""
+    import math
+    import tactile_gym_amd as tg
+    from tactile_gym_amd import _capi as capi
+    from tactile_gym_amd.rl_envs import surface_follow as sf
+    assert "surface_follow-v2" in tg.registered_ids()
+    m = dict(sf.env_modes_default_vert, arm_type="mg400", tactile_sensor_name="digitac", observation_mode="tactile")
+    cfg, robot, sensor, _ = sf.build_config(8, 200, (128, 128), m)
+    assert cfg.surf_vertical == 1 and cfg.movement_mode == capi.SMOVE["xRz"] and cfg.noise_mode == capi.SNOISE["vertical_simplex"]
+    assert [cfg.stim_pos[k] for k in range(3)] == [0.33, 0.0, 0.175] and [cfg.workframe_rpy[k] for k in range(3)] == [-math.pi, 0.0, 0.0]
+    assert [cfg.act_hi[d] for d in range(6)] == [0.01, 0.01, 0.0, 0.0, 0.0, 5.0 * (math.pi / 180)]
+    assert cfg.tcp_lims[0][1] == 0.025 and cfg.tcp_lims[1][1] == 0.15 and cfg.tcp_lims[2][1] == 0.0 and abs(cfg.tcp_lims[5][1] - math.pi / 4) < 1e-15
+    assert robot.ndof == 8 and sensor.struct.cam_pos[2] == 0.005                       # MG400, digitac `forward` camera offset
+    with pytest.raises(SystemExit):
+        sf.build_config(8, 200, (128, 128), dict(m, movement_mode="xyz"))               # vertical surface needs xRz
+    with pytest.raises(SystemExit):
+        sf.build_config(8, 200, (128, 128), dict(m, noise_mode="simplex"))              # xRz needs the vertical surface
+    with pytest.raises(KeyError):
+        sf.build_config(8, 200, (128, 128), dict(m, noise_mode="simplex", movement_mode="xyz"))   # no `standard` rest pose for the MG400 upstream

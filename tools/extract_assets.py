@@ -45,12 +45,21 @@ ROBOTS = [
     ("ur5", "tactip", "right_angle"),            # object_push on the UR5 (object_push_env.py:59)
     ("ur5", "digit", "right_angle"),
     ("ur5", "digitac", "right_angle"),
+    ("mg400", "tactip", "forward"),              # surface_follow-v2: vertical surface (base_surface_env.py:60-63)
+    ("mg400", "digit", "forward"),
+    ("mg400", "digitac", "forward"),
+    ("ur5", "tactip", "forward"),
+    ("ur5", "digit", "forward"),
+    ("ur5", "digitac", "forward"),
 ]
 
 SENSOR_IMAGES = [
     ("tactip", "standard", (64, 128, 256)),
     ("tactip", "right_angle", (64, 128, 256)),
     ("tactip", "mini_right_angle", (64, 128, 256)),
+    ("tactip", "forward", (64, 128, 256)),
+    ("digit", "forward", (64, 128, 256)),
+    ("digitac", "forward", (64, 128, 256)),
     ("digit", "standard", (64, 128, 256)),
     ("digit", "right_angle", (64, 128, 256)),
     ("digitac", "standard", (64, 128, 256)),

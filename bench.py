@@ -58,7 +58,12 @@ def cpu_baseline(seconds=12.0):
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(1 + i, seconds) for i in range(cores)])
     total = sum(r[0] for r in res) / max(r[1] for r in res)
-    return {"value": round(total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+    try:   # time the real reference if the box happens to have it (it does not travel with this repo)
+        import pybullet  # noqa: F401
+        pyb = "importable on this box but not timed: the reference's env classes do not travel with this repo"
+    except Exception:  # noqa: BLE001
+        pyb = "unavailable (import pybullet fails on this box)"
+    return {"value": round(total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port", "pybullet_reference": pyb,
             "sample": f"{cores} processes x 1 oracle env (edge_follow-v0, 128x128, random actions, resets included) for {seconds:.0f} s; "
                       f"single process: {n1 / t1:.1f} env-steps/s"}
 
@@ -150,6 +155,22 @@ def main():
         barrier()
         prof = venv.profile_get()
         venv.profile(False)
+        # SURVEY 8d asks for the rate with and without episode resets: a window that starts right after a reset of every env and
+        # ends before any env can reach max_steps (an env that meets its goal early is still reset, as in any rollout)
+        no_reset = None
+        if dist is None:
+            env.reset()
+            for _ in range(10):
+                env.step(actions())
+            barrier()
+            k_nr = max(10, min(args.steps, max_steps - 20))
+            t_nr = time.perf_counter()
+            for _ in range(k_nr):
+                env.step(actions())
+            barrier()
+            dt_nr = time.perf_counter() - t_nr
+            no_reset = {"value": round(n * k_nr / dt_nr, 1), "unit": "env-steps/s", "steps": k_nr, "ms_per_step": round(1e3 * dt_nr / k_nr, 4),
+                        "what": "window between full-batch resets (no env reaches max_steps inside it)"}
     literal = None
     if world == 1 and not args.full_sweeps and not args.no_literal:
         # the same workload with the literal solver (every tick: dynamics + all 150 PGS sweeps), for comparison; short run
@@ -230,6 +251,7 @@ def main():
                       "default: PGS leaves at last-bit convergence; ticks whose motor solve is provably unclamped and demonstrably converged take "
                       "the solver's analytic fixed point (qd = target); results within 1e-15 of the literal solver (DESIGN.md 4.1)",
             "literal_solver": literal,
+            "without_full_batch_reset": no_reset,
             "resets_in_timed_region": bool((args.warmup % 200) + args.steps >= 200),
         }
         if world == 1 and not args.no_cpu_baseline and args.env == "edge_follow-v0":

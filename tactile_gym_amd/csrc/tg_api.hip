@@ -1341,17 +1341,24 @@ template <typename T> static int build_dev_robot(const tg_robot& r, DevRobot<T>&
     {
         auto parent = [&](int i) { return r.topology == 0 ? Topo<0>::parent(i) : Topo<1>::parent(i); };
         auto len3 = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-        double tb = 0.0;
-        for (int i = 0; i < N; ++i)
+        double tb = 0.0, dmax = 0.0;
+        for (int i = 0; i < kMaxDof; ++i) d.diag_sqrt[i] = (T)0;
+        for (int i = 0; i < N; ++i) {
+            double di = 0.0;
             for (int l = i; l < N; ++l) {
                 double D = 0.0; int k = l; bool under = false;
                 while (k >= 0) { if (k == i) { under = true; break; } D += len3(r.joint_pos[k]); k = parent(k); }
                 if (!under) continue;
                 const double com[3] = {(double)d.lcom[l][0], (double)d.lcom[l][1], (double)d.lcom[l][2]};
                 D += len3(com);
-                tb += ((double)d.linert[l][0] + (double)d.linert[l][3] + (double)d.linert[l][5]) + (double)d.lmass[l] * D * D;
+                di += ((double)d.linert[l][0] + (double)d.linert[l][3] + (double)d.linert[l][5]) + (double)d.lmass[l] * D * D;
             }
+            tb += di;                                      // d_i >= M_ii(q): inertia of joint i's subtree about its axis
+            d.diag_sqrt[i] = (T)(std::sqrt(di) * 1.0000001);
+            dmax = di > dmax ? di : dmax;
+        }
         d.trace_bound = (T)tb;
+        d.diag_sqrt_max = (T)(std::sqrt(dmax) * 1.0000001);
     }
     return 0;
 }

@@ -60,6 +60,7 @@ template <typename T> struct DevRobot {
     T gravity[3], lin_damp, ang_damp, joint_damp, max_force, pos_gain, vel_gain;
     T rest_q[kMaxDof];
     T trace_bound;   // >= trace(M(q)) for every q (host, build_dev_robot)
+    T diag_sqrt[kMaxDof], diag_sqrt_max;   // sqrt of per-joint bounds d_i >= M_ii(q) for every q, and their maximum
 };
 
 // ------------------------------------------------------------------------------------------------ small vector algebra
@@ -524,16 +525,20 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
     // bounded through the same quantity (gravity is compensated).  Then the tick is  qd = des, q += dt des.  iters < 0
     // (pgs_full_sweeps) forces the literal path.
     if (MOTOR != kMotorOff && GC && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0) {
-        T des[N], dv2 = T(0), v2 = T(0);
+        T des[N], dvw = T(0), v2 = T(0);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             des[i] = ((MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0)) + qd_des[i];
-            dv2 += (des[i] - qd[i]) * (des[i] - qd[i]);
+            dvw += m.diag_sqrt[i] * tabs(des[i] - qd[i]);
             v2 += qd[i] * qd[i];
         }
         // lambda* = M (des - v) = M (des - qd) - dt f  with f the damping force, ||f|| <= (joint_damp + 2 (K_lin + K_ang)(1 + |v|) trace(M)) ||qd||;
-        // the constants below are generous (sqrt(N) <= 3, |v| < 1).  Energy argument: no iterate exceeds 2 ||lambda*||.
-        const T lam_star = m.trace_bound * tsqrt_fast(dv2) +
+        // the constants below are generous (sqrt(N) <= 3, |v| < 1).  Energy argument: Gauss-Seidel on the SPD system A = Minv never
+        // increases the A-norm of the error, so ||lambda^k||_A <= 2 ||lambda*||_A; a row obeys |lambda_i| <= sqrt(M_ii) ||lambda||_A
+        // (Cauchy-Schwarz in the A inner product) and ||M dv||_A = ||dv||_M <= sum_j sqrt(M_jj) |dv_j| (triangle inequality), so with the
+        // host's per-joint bounds d_j >= M_jj(q):  |lambda_i^k| <= 2 sqrt(d_max) sum_j sqrt(d_j) |dv_j|  (<= 2 trace ||dv||_2, the
+        // earlier form, but far tighter when the jump sits in the light wrist joints).
+        const T lam_star = m.diag_sqrt_max * dvw +
                            dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3) * tsqrt_fast(v2);
         if (__all(T(2.5) * lam_star < max_force * dt)) {   // energy bound: no iterate exceeds 2 ||lambda*||; 25 % margin on top
             T dq[N];
@@ -659,11 +664,11 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
     // bit within 80 % of the sweep budget (the coupled iteration contracts like the arm's alone, ~0.5 per sweep), and no row may be
     // able to reach its limit (motor bound extended by the P2P reaction, P2P impulse far from its 500 N s cap).
     if (MOTOR != kMotorOff && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0) {
-        T des[N], dv2 = T(0), v2 = T(0);
+        T des[N], dvw = T(0), v2 = T(0);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             des[i] = ((MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0)) + qd_des[i];
-            dv2 += (des[i] - qd[i]) * (des[i] - qd[i]);
+            dvw += m.diag_sqrt[i] * tabs(des[i] - qd[i]);
             v2 += qd[i] * qd[i];
         }
         Kin<T, TOPO> kin;
@@ -701,7 +706,7 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
                         im + dot(rxe[2], Wang[2])};
         const V3<T> lp = mul(inverse(App), rhs);
         const T lpn = tsqrt_fast(dot(lp, lp));
-        const T lam_star = m.trace_bound * tsqrt_fast(dv2) +
+        const T lam_star = m.diag_sqrt_max * dvw +     // per-joint form of the energy bound, see sim_tick
                            dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3) * tsqrt_fast(v2) + T(6) * lpn;
         if (__all(T(4) * lam_star < max_force * dt && T(8) * lpn < bc.max_impulse)) {
 #pragma unroll

@@ -61,8 +61,9 @@ __device__ __forceinline__ void project_vertex(float cx, float cy, float cw, con
 }
 
 // Returns false when the record buffer is full (nothing written): the caller restarts from this triangle in the next round.
+// rbands (banded lane mapping only): per record, bit b = the bounding box reaches pixel centres of the tile's b-th 32-pixel column band.
 __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const float* vx, const float* vy, const float* vw, int a, int b, int c,
-                                     const RasterParams& P, float tx0, float ty0, float tx1, float ty1) {
+                                     const RasterParams& P, float tx0, float ty0, float tx1, float ty1, unsigned* rbands = nullptr) {
     TriRec r;
     project_vertex(vx[a], vy[a], vw[a], P, r.x0, r.y0, r.d0);
     project_vertex(vx[b], vy[b], vw[b], P, r.x1, r.y1, r.d1);
@@ -76,13 +77,22 @@ __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const fl
     const int slot = atomicAdd(count, 1);
     if (slot >= cap) return false;
     recs[slot] = r;
+    if (rbands != nullptr) {
+        unsigned bands = 0u;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)   // band bb holds pixel centres tx0 + 32 bb + 0.5 .. + 31.5; coverage needs xmin <= fx <= xmax
+            bands |= (r.xmax >= tx0 + 32.0f * (float)bb + 0.5f && r.xmin <= tx0 + 32.0f * (float)bb + 31.5f) ? (1u << bb) : 0u;
+        rbands[slot] = bands;
+    }
     return true;
 }
 
 // grid: (tiles_x * tiles_y, num_envs, 1 or 2); block: 256.  TW x TH = tile (128 x 128; 128 x 64 for small meshes: half the rows
 // per lane halves the z-buffer registers, 4 instead of 2 workgroups fit a CU, and the per-workgroup set-up of a dozen triangles is
 // negligible; 64 x 64 for 64x64 images).
-template <int TW, int TH>
+// BAND (heightfield stimuli: hundreds of small triangles per tile): wavefront w owns the w-th 32-pixel column band of the tile (8 quad
+// columns x 8 rows per pass) instead of two full rows, and skips - as one scalar branch - every record whose bounding box misses the band.
+template <int TW, int TH, bool BAND>
 __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
@@ -99,6 +109,7 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     float* hvd = hfl + (S.kind == 1 ? S.rows * S.cols : 0);
     unsigned short* surv = reinterpret_cast<unsigned short*>(hvd + (S.kind == 1 ? S.rows * S.cols : 0));
     uint8_t* hcode = reinterpret_cast<uint8_t*>(surv + (S.kind == 1 ? S.n_tris : 0));
+    unsigned* rbands = reinterpret_cast<unsigned*>(hcode + (((S.kind == 1 ? S.rows * S.cols : 0) + 3) & ~3));   // BAND: rec_cap words
     __shared__ int count, next_start, n_surv;
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
@@ -121,8 +132,10 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xf[(size_t)k * n_envs + env] : xf[(size_t)env * 12 + k];
 
     // this lane's pixels: quad column qx (4 px), rows ry + 8*k
-    const int qx = tile_x + 4 * (tid % QPR);
-    const int ry = tile_y + (tid / QPR);
+    static_assert(!BAND || (TW == 128 && RPP == 8), "banded mapping: 4 wavefronts x 32-pixel bands, 8 rows per pass");
+    const int band = __builtin_amdgcn_readfirstlane(tid / 64);
+    const int qx = BAND ? tile_x + 32 * band + 4 * (tid % 8) : tile_x + 4 * (tid % QPR);
+    const int ry = BAND ? tile_y + ((tid % 64) / 8) : tile_y + (tid / QPR);
     float z[NK][4];
     unsigned touched = 0;      // bit k: some triangle lowered a depth of row k of this lane's quad column
     {
@@ -226,14 +239,15 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                 }
             }
             bool ok = true;
-            if (no >= 3) ok = emit(recs, &count, rec_cap, ox, oy, ow, 0, 1, 2, P, tx0, ty0, tx1, ty1);
-            if (ok && no == 4) ok = emit(recs, &count, rec_cap, ox, oy, ow, 0, 2, 3, P, tx0, ty0, tx1, ty1);
+            if (no >= 3) ok = emit(recs, &count, rec_cap, ox, oy, ow, 0, 1, 2, P, tx0, ty0, tx1, ty1, BAND ? rbands : nullptr);
+            if (ok && no == 4) ok = emit(recs, &count, rec_cap, ox, oy, ow, 0, 2, 3, P, tx0, ty0, tx1, ty1, BAND ? rbands : nullptr);
             if (!ok) { atomicMin(&next_start, it); break; }
         }
         __syncthreads();
         const int n = min(count, rec_cap);
         start = next_start;
         for (int t = 0; t < n; ++t) {
+            if (BAND && !((__builtin_amdgcn_readfirstlane(rbands[t]) >> band) & 1u)) continue;   // wave-uniform
             const TriRec r = recs[t];   // same address on every lane: LDS broadcast
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
@@ -332,21 +346,26 @@ void launch_render(const RasterParams& P, const Stimulus& S, const float* xform,
     int rec_cap = 2 * S.n_tris;
     rec_cap = rec_cap > kBatch ? kBatch : (rec_cap < 2 ? 2 : rec_cap);
     if (S.kind == 1 && rec_cap > 256) rec_cap = 256;   // a dozen heightfield triangles survive the depth cull; more just take another round
-    const size_t lds = (size_t)rec_cap * sizeof(TriRec) + (S.kind == 1 ? (size_t)S.rows * S.cols * (2 * sizeof(float) + 1) + (size_t)S.n_tris * sizeof(unsigned short) + 16 : 0);
+    const size_t lds = (size_t)rec_cap * sizeof(TriRec) + (S.kind == 1 ? (size_t)S.rows * S.cols * (2 * sizeof(float) + 1) + (size_t)S.n_tris * sizeof(unsigned short) + 16
+                                                                       + (size_t)rec_cap * sizeof(unsigned) + 8 : 0);
     if (P.W % 128 == 0 && P.H % 128 == 0) {
         // small shared mesh and a launch that leaves the chip under-filled (< 2 rounds of 128 x 128 workgroups at 2 per CU): 128 x 64 tiles
         if (S.kind == 0 && S.n_tris <= 256 && (long)n_envs * (P.W / 128) * (P.H / 128) <= 2048) {
             dim3 grid((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
-            hipLaunchKernelGGL((k_render_tactile<128, 64>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+            hipLaunchKernelGGL((k_render_tactile<128, 64, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
         } else {
             dim3 grid((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
-            hipLaunchKernelGGL((k_render_tactile<128, 128>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
-                               nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+            if (S.kind == 1)
+                hipLaunchKernelGGL((k_render_tactile<128, 128, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                                   nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+            else
+                hipLaunchKernelGGL((k_render_tactile<128, 128, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                                   nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
         }
     } else {  // 64x64 images
         dim3 grid((P.W / 64) * (P.H / 64), n_envs, term_xform ? 2 : 1);
-        hipLaunchKernelGGL((k_render_tactile<64, 64>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+        hipLaunchKernelGGL((k_render_tactile<64, 64, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                            nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
     }
 }

@@ -92,7 +92,7 @@ __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const fl
 // negligible; 64 x 64 for 64x64 images).
 // BAND (heightfield stimuli: hundreds of small triangles per tile): wavefront w owns the w-th 32-pixel column band of the tile (8 quad
 // columns x 8 rows per pass) instead of two full rows, and skips - as one scalar branch - every record whose bounding box misses the band.
-template <int TW, int TH, bool BAND>
+template <int TW, int TH, bool BAND, bool QREJ>
 __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                 if ((float)qx + 3.5f < r.xmin || (float)qx + 0.5f > r.xmax) continue;
                 if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
                 const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
-                {   // conservative reject of the 4-pixel quad: e_i is affine in fx (slope y_j - y_k along a row), so its value at the quad
+                if (QREJ) {   // conservative reject of the 4-pixel quad (compiled out for stimuli whose few triangles fill the view): e_i is affine in fx (slope y_j - y_k along a row), so its value at the quad
                     // centre plus 1.5 |slope| plus a bound on the float rounding of the per-pixel expression bounds it over the quad.  e0 + e1 + e2
                     // is the same at every pixel (twice the signed area): when its sign is certain, a covered pixel needs all three e_i on
                     // that side, so one edge function provably on the other side rejects the quad.  Skipping changes no pixel.
@@ -352,20 +352,23 @@ void launch_render(const RasterParams& P, const Stimulus& S, const float* xform,
         // small shared mesh and a launch that leaves the chip under-filled (< 2 rounds of 128 x 128 workgroups at 2 per CU): 128 x 64 tiles
         if (S.kind == 0 && S.n_tris <= 256 && (long)n_envs * (P.W / 128) * (P.H / 128) <= 2048) {
             dim3 grid((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
-            hipLaunchKernelGGL((k_render_tactile<128, 64, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+            hipLaunchKernelGGL((k_render_tactile<128, 64, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
         } else {
             dim3 grid((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
             if (S.kind == 1)
-                hipLaunchKernelGGL((k_render_tactile<128, 128, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                hipLaunchKernelGGL((k_render_tactile<128, 128, true, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                                   nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+            else if (S.no_quad_reject)
+                hipLaunchKernelGGL((k_render_tactile<128, 128, false, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
             else
-                hipLaunchKernelGGL((k_render_tactile<128, 128, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                hipLaunchKernelGGL((k_render_tactile<128, 128, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
         }
     } else {  // 64x64 images
         dim3 grid((P.W / 64) * (P.H / 64), n_envs, term_xform ? 2 : 1);
-        hipLaunchKernelGGL((k_render_tactile<64, 64, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+        hipLaunchKernelGGL((k_render_tactile<64, 64, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                            nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
     }
 }

@@ -68,7 +68,7 @@ typedef struct {
     const int32_t* tris;                    /* host, [n_tris][3] */
 } tg_mesh;
 
-enum { TG_ENV_EDGE_FOLLOW = 0, TG_ENV_SURFACE_FOLLOW_AUTO = 1, TG_ENV_OBJECT_BALANCE = 2, TG_ENV_OBJECT_PUSH = 3 };
+enum { TG_ENV_EDGE_FOLLOW = 0, TG_ENV_SURFACE_FOLLOW_AUTO = 1, TG_ENV_OBJECT_BALANCE = 2, TG_ENV_OBJECT_PUSH = 3, TG_ENV_OBJECT_ROLL = 4 };
 enum { TG_MOVE_XY = 0, TG_MOVE_XYZ = 1, TG_MOVE_XYRZ = 2, TG_MOVE_XYZRZ = 3 };            /* edge_follow_env.py:345-369 */
 enum { TG_SMOVE_YZ = 0, TG_SMOVE_XYZ = 1, TG_SMOVE_YZRX = 2, TG_SMOVE_XYZRXRY = 3, TG_SMOVE_XRZ = 4 };   /* surface_follow_auto_env.py:27-57; xRz: surface_follow_vert_env.py:29-48 */
 enum { TG_BMOVE_XY = 0, TG_BMOVE_XYZ = 1, TG_BMOVE_RXRY = 2, TG_BMOVE_XYRXRY = 3 };         /* object_balance_env.py:398-424 */
@@ -163,6 +163,18 @@ typedef struct {
      * (x, y, 0.15 + range); the bins, the goal and the reward follow the reference's flipped surface_array (:476-516, :735-758);
      * reward -(10 surf_dist + 3 cos_dist) (surface_follow_vert_env.py:66-81). */
     int32_t surf_vertical;
+    /* object_roll (object_roll_env.py): a marble (sphere.urdf: obj_mass, roll_radius; stimulus mesh = its tessellation at that radius)
+     * on the table under the flat TacTip, whose tip collides as a URDF cylinder; goal given in the TCP frame.  Shares with object_push:
+     * obj_mass, mu_table, mu_tip, contact_breaking / erp, tip_stiffness / damping, obj_lin / ang_damp, tip_link, cone_friction, table_z,
+     * termination_dist (:60).  workframe_pos z = 2 roll_radius - embed_dist is the default; per episode it is 2 r - embed with
+     * r = roll_radius x U(1, 2) (rand_obj_size) and embed = U(embed_lo, embed_hi) (rand_embed) (:181-201).  Movement "xy" only.
+     * State view: obj_mass = the episode's radius, goal_pos = the goal in the TCP frame. [PARITY_ASSUMPTIONS A30] */
+    int32_t roll_rand_init_pos, roll_rand_size, roll_rand_embed;   /* env_modes flags (:41-43) */
+    double roll_radius;                     /* default_obj_radius 0.0025 (:161) */
+    double roll_init_range;                 /* 0.009 (:210-214) */
+    double roll_goal_lo, roll_goal_hi;      /* goal distance U(0.005 | 0 with rand_init_pos, 0.015) (:256-259) */
+    double tip_cyl_pos[3], tip_cyl_rot[9];  /* tip cylinder frame (axis z) in the frame of tip_link */
+    double tip_cyl_half_len, tip_cyl_radius;
 } tg_config;
 
 typedef struct tg_ctx tg_ctx;

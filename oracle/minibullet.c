@@ -706,6 +706,15 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
     contact_t ct[MAXC]; int nc = 0;
     kin_t k; double z3[3] = {0, 0, 0};
     kinematics(m, s->q, zero, NULL, z3, &k);
+    if (sc->shape == 1) {   /* sphere - table: the lowest point of the sphere against the plane [PARITY_ASSUMPTIONS A30] */
+        double depth = (b->pos[2] - sc->radius) - sc->table_z;
+        if (depth <= sc->breaking) {
+            contact_t* q = &ct[nc++];
+            q->n[0] = 0; q->n[1] = 0; q->n[2] = 1; q->depth = depth; q->mu = sc->mu_table; q->arm_a = 0; q->cfm_dt = 0.0; q->erp = sc->erp;
+            for (int x = 0; x < 3; ++x) { q->pa[x] = b->pos[x]; q->pb[x] = b->pos[x]; }
+            q->pa[2] = b->pos[2] - sc->radius; q->pb[2] = sc->table_z;
+        }
+    } else
     {   /* cube - table: broadphase on z, then the cube vertices near the plane (at most 4 kept: the deepest ones) */
         double zmin = 1e30, vz[8], vw[8][3];
         for (int c = 0; c < 8; ++c) {
@@ -735,6 +744,34 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
         }
     }
     sc->tip_depth = 1e30; sc->tip_impulse = 0.0; sc->tip_normal[0] = sc->tip_normal[1] = sc->tip_normal[2] = 0.0;
+    if (sc->shape == 1) {   /* sphere - tip: closest point of the solid cylinder to the sphere centre [A30] */
+        int l = sc->tip_link;
+        double cw_[3], Rw[9], t[3], d[3], p[3], cl[3], g[3], gw[3];
+        m3_vec(k.R[l], sc->cyl_pos, t);
+        for (int x = 0; x < 3; ++x) cw_[x] = k.o[l][x] + t[x];
+        m3_mul(k.R[l], sc->cyl_rot, Rw);
+        for (int x = 0; x < 3; ++x) d[x] = b->pos[x] - cw_[x];
+        for (int x = 0; x < 3; ++x) p[x] = Rw[x] * d[0] + Rw[3 + x] * d[1] + Rw[6 + x] * d[2];   /* centre in the cylinder frame */
+        double rad = sqrt(p[0] * p[0] + p[1] * p[1]);
+        double sr = rad > sc->cyl_radius ? sc->cyl_radius / rad : 1.0;
+        cl[0] = p[0] * sr; cl[1] = p[1] * sr;
+        cl[2] = p[2] > sc->cyl_half_len ? sc->cyl_half_len : (p[2] < -sc->cyl_half_len ? -sc->cyl_half_len : p[2]);
+        for (int x = 0; x < 3; ++x) g[x] = p[x] - cl[x];
+        double dist = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        double depth = dist - sc->radius;
+        if (dist > 0.0 && depth <= sc->breaking) {
+            contact_t* q = &ct[nc++];
+            for (int x = 0; x < 3; ++x) g[x] /= dist;          /* from the cylinder towards the sphere, cylinder frame */
+            m3_vec(Rw, g, gw);
+            for (int x = 0; x < 3; ++x) q->n[x] = -gw[x];      /* contact normal: from body B (sphere) towards body A (tip) */
+            q->depth = depth; q->mu = sc->mu_tip; q->arm_a = 1;
+            double denom = dt * sc->tip_stiffness + sc->tip_damping;
+            q->cfm_dt = (1.0 / denom) / dt; q->erp = dt * sc->tip_stiffness / denom;
+            double clw[3]; m3_vec(Rw, cl, clw);
+            for (int x = 0; x < 3; ++x) { q->pa[x] = cw_[x] + clw[x]; q->pb[x] = b->pos[x] - gw[x] * sc->radius; }
+            sc->tip_depth = depth; memcpy(sc->tip_normal, q->n, sizeof q->n);
+        }
+    } else
     {   /* cube - tip core: deepest hull vertex against the box signed distance field */
         int l = sc->tip_link, besti = -1; double bestd = 1e30, bestg[3] = {0, 0, 0}, bestw[3] = {0, 0, 0};
         for (int i = 0; i < sc->n_tip; ++i) {

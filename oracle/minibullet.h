@@ -170,6 +170,12 @@ typedef struct {
     double tip_depth, tip_normal[3], tip_impulse;
     double residual_threshold;   /* in: PGS leaves the loop when the largest squared impulse change of a sweep is <= this (0: exact fixed point) */
     int32_t sweeps_used;         /* out */
+    /* object_roll: the free body is a sphere (object_roll/sphere/sphere.urdf) under the flat TacTip, whose tip collision shape is a
+     * URDF cylinder (ur5_with_flat_tactip.urdf:320-325).  shape 0: box vs hull vertices (object_push), 1: sphere vs solid cylinder. */
+    int32_t shape;
+    double radius;               /* sphere radius (default_obj_radius x scaling_factor) */
+    double cyl_pos[3], cyl_rot[9];   /* cylinder frame (axis = local z) in the frame of tip_link */
+    double cyl_half_len, cyl_radius;
 } mb_push_scene;
 
 extern int mb_last_sweeps;   /* PGS sweeps executed by the last mb_step */

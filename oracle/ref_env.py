@@ -1044,3 +1044,145 @@ class OracleObjectPushEnv(_OracleArmEnv):
         cur = self.nodef_dep.copy()
         mb.render_depth(self.obj_verts, self.obj_tris, self.stimulus_transform(), self.cam["fov"], self.cam["near"], self.cam["far"], w, h, cur)
         return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)
+
+
+class OracleObjectRollEnv(_OracleArmEnv):
+    """object_roll-v0 (nonprehensile_manipulation/object_roll/object_roll_env.py + base_object_env.py): UR5 + flat TacTip rolling a
+    marble (sphere.urdf, r = 2.5 mm x scaling) on the table towards a goal given in the TCP frame; tip collision = URDF cylinder,
+    soft contact (stiffness 10, damping 100), friction 10 on both bodies.  Contact model: PARITY_ASSUMPTIONS A30."""
+
+    REST = [0.16682, -2.23156, -1.66642, -0.81399, 1.57315, 1.74001]                        # object_roll/rest_poses.py (ur5, flat)
+
+    def __init__(self, seed=0, max_steps=1000, image_size=(128, 128), env_modes=None, inertia="collision_aabb"):
+        modes = dict(movement_mode="xy", control_mode="TCP_velocity_control", rand_init_obj_pos=False, rand_obj_size=False, rand_embed_dist=False,
+                     observation_mode="tactile_and_feature", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+        modes.update(env_modes or {})
+        assert modes["arm_type"] == "ur5" and modes["tactile_sensor_name"] == "tactip" and modes["movement_mode"] == "xy"
+        self._setup_arm(seed, modes, max_steps, image_size, "flat", self.REST, inertia)    # :55-57
+        self.termination_pos_dist = 0.001                                                  # :60
+        self.embed_dist = 0.0015                                                           # :64
+        self.default_obj_radius = 0.0025                                                   # :161
+        self.scaling_factor, self.scaled_obj_radius = 1.0, self.default_obj_radius
+        self.TCP_lims = np.array([[-0.05, 0.05], [-0.05, 0.05], [-0.01, 0.01], [0, 0], [0, 0], [0, 0]])   # :74-80
+        v = 0.001 if self.position_control else 0.01                                        # :113-135
+        self.act_lo, self.act_hi = np.array([-v, -v, 0, 0, 0, 0.0]), np.array([v, v, 0, 0, 0, 0.0])
+        self._set_workframe([0.65, 0.0, 2 * 0.0025 - self.embed_dist], [-math.pi, 0.0, math.pi / 2])   # :70-71
+        z = np.load(os.path.join(_ASSETS, "objects", "sphere.npz"))
+        self.obj_verts, self.obj_tris = z["verts"], z["tris"]
+        b = mb.MBBody()
+        b.mass = float(z["mass"])
+        self._mass = b.mass
+        self.ball = b
+        self._set_ball_inertia(self.default_obj_radius)
+        r = np.load(os.path.join(_ASSETS, "robots", f"{self.arm_type}_{self.t_s_type}_{self.t_s_name}.npz"))
+        sc = mb.MBPushScene()
+        sc.shape, sc.radius, sc.table_z = 1, self.default_obj_radius, 0.0
+        for k in range(3):
+            sc.cyl_pos[k] = float(r["tip_cyl_pos"][k])
+        for k in range(9):
+            sc.cyl_rot[k] = float(np.asarray(r["tip_cyl_rot"]).reshape(9)[k])
+        sc.cyl_half_len, sc.cyl_radius = 0.5 * float(r["tip_cyl_length"]), float(r["tip_cyl_radius"])
+        sc.mu_table, sc.mu_tip = 10.0 * 1.0, 10.0 * 10.0                                    # :239-248 marble 10; plane 1, tip 10 (:58)
+        sc.margin_cube, sc.margin_tip, sc.breaking, sc.erp = 0.0, 0.0, 1e-4, 0.2
+        sc.tip_stiffness, sc.tip_damping = 10.0, 100.0 + 0.1                                # :58 t_s_dynamics [A25]
+        sc.lin_damp, sc.ang_damp = 0.04, 0.04
+        sc.tip_link, sc.n_tip, sc.cone_friction = int(r["tip_cyl_link"]), 0, 1
+        self.scene = sc
+        self.init_obj_pos = np.array([0.65, 0.0, self.default_obj_radius])                 # :164
+        self._teleport_ball()
+
+    def _set_ball_inertia(self, radius):       # solid sphere about its centre (btSphereShape::calculateLocalInertia) [A30]
+        i = 0.4 * self._mass * radius * radius
+        for k in range(9):
+            self.ball.inertia[k] = i if k in (0, 4, 8) else 0.0
+            self.ball.rot[k] = 1.0 if k in (0, 4, 8) else 0.0
+        for k in range(3):
+            self.ball.com[k] = 0.0
+
+    def _teleport_ball(self):
+        for k in range(3):
+            self.ball.pos[k] = float(self.init_obj_pos[k])
+            self.ball.linvel[k] = 0.0
+            self.ball.angvel[k] = 0.0
+        for k in range(9):
+            self.ball.rot[k] = 1.0 if k in (0, 4, 8) else 0.0
+
+    def _step_simulation(self):
+        self.arm.step_simulation_push(self.ball, self.scene, self.SIM_DT, self.SOLVER_ITERS)
+
+    def ball_pose(self):
+        return np.array(self.ball.pos[:]), np.array(self.ball.rot[:]).reshape(3, 3)
+
+    def reset(self):
+        """base_object_env.py:153-190 with object_roll_env.py:176-266."""
+        self.step_counter = 0
+        self.scaling_factor = self.rng.uniform(1.0, 2.0) if self.modes["rand_obj_size"] else 1.0      # reset_task :181-190
+        self.scaled_obj_radius = self.default_obj_radius * self.scaling_factor
+        if self.modes["rand_embed_dist"]:
+            self.embed_dist = self.rng.uniform(0.0015, 0.003)
+        self._set_workframe([0.65, 0.0, 2 * self.scaled_obj_radius - self.embed_dist], [-math.pi, 0.0, math.pi / 2])   # update_workframe
+        self._reset_robot(np.zeros(3), np.zeros(3))            # the marble of the last episode (old radius) is still in the world
+        if self.modes["rand_init_obj_pos"]:                                                 # reset_object :207-248
+            dx = self.rng.uniform(-0.009, 0.009)
+            dy = self.rng.uniform(-0.009, 0.009)
+            self.init_obj_pos = np.array([0.65 + dx, 0.0 + dy, self.scaled_obj_radius])
+        else:
+            self.init_obj_pos = np.array([0.65, 0.0, self.scaled_obj_radius])
+        self._teleport_ball()
+        self.scene.radius = self.scaled_obj_radius                                          # loadURDF(globalScaling) when rand_obj_size
+        self._set_ball_inertia(self.scaled_obj_radius)
+        goal_ang = self.rng.uniform(-math.pi, math.pi)                                      # make_goal :250-266
+        goal_dist = self.rng.uniform(0.0, 0.015) if self.modes["rand_init_obj_pos"] else self.rng.uniform(0.005, 0.015)
+        self.goal_pos_tcp = np.array([goal_dist * math.cos(goal_ang), goal_dist * math.sin(goal_ang), 0.0])
+        self._get_step_data()
+        return self._observation()
+
+    def _update_goal(self):                                                                 # :268-295
+        pos, _, orn, _, _ = self._tcp_world()
+        self.goal_pos_world, _ = pm.multiply_transforms(pos, orn, self.goal_pos_tcp, pm.quat_from_euler([0.0, 0.0, 0.0]))
+
+    def _encode_actions(self, a):                                                           # :297-309
+        enc = np.zeros(6)
+        enc[0], enc[1] = a[0], a[1]
+        return enc
+
+    def _get_step_data(self):                                                               # :311-340
+        self._update_goal()
+        pos, _ = self.ball_pose()
+        dist = float(np.linalg.norm(pos[:2] - self.goal_pos_world[:2]))                    # xy_obj_dist_to_goal
+        done = dist < self.termination_pos_dist or self.step_counter >= self.max_steps
+        if self.modes["reward_mode"] == "sparse":
+            reward = 1.0 if dist < self.termination_pos_dist else 0.0
+        else:
+            reward = -(1.0 * dist)
+        return reward, bool(done)
+
+    def extended_feature(self):                                                             # :409-415
+        return np.array([*self.goal_pos_tcp])
+
+    def oracle_obs(self):                                                                   # :367-407
+        p, rpy, lv, av = self._tcp_work()
+        pos, R = self.ball_pose()
+        op, orpy = self._world_to_work(pos, pm.euler_from_quat(pm.quat_from_mat(R)))
+        _, iq = pm.invert_transform(self.workframe_pos, self.workframe_orn)
+        Rinv = pm.mat_from_quat(iq)
+        olv, oav = Rinv @ np.array(self.ball.linvel[:]), Rinv @ np.array(self.ball.angvel[:])
+        return np.hstack([p, pm.quat_from_euler(rpy), lv, av, op, pm.quat_from_euler(orpy), olv, oav, self.goal_pos_tcp,
+                          pm.quat_from_euler([0.0, 0.0, 0.0]), self.scaled_obj_radius]).astype(np.float32)
+
+    def _observation(self):
+        obs = super()._observation()
+        if "feature" in self.modes["observation_mode"]:
+            obs["extended_feature"] = self.extended_feature().astype(np.float32)
+        return obs
+
+    def stimulus_transform(self):
+        cpos, cR = self.camera_pose()
+        pos, R = self.ball_pose()
+        return mb.cam_from_obj_matrix(cpos, cR, pos, R * self.scaling_factor)                # globalScaling scales the visual too
+
+    def tactile_image(self):
+        h, w = self.image_size
+        cur = self.nodef_dep.copy()
+        mb.render_depth(self.obj_verts, self.obj_tris, self.stimulus_transform(), self.cam["fov"], self.cam["near"], self.cam["far"], w, h, cur)
+        return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)

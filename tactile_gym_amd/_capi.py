@@ -14,7 +14,7 @@ MAX_TRAJ_POINTS = 16
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtactile_gym_hip.so")
 
-ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO, ENV_OBJECT_BALANCE, ENV_OBJECT_PUSH = 0, 1, 2, 3
+ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO, ENV_OBJECT_BALANCE, ENV_OBJECT_PUSH, ENV_OBJECT_ROLL = 0, 1, 2, 3, 4
 PMOVE = {"y": 0, "yRz": 1, "xyRz": 2, "TyRz": 3, "TxTyRz": 4}
 TRAJ = {"simplex": 0, "straight": 1}
 BMOVE = {"xy": 0, "xyz": 1, "RxRy": 2, "xyRxRy": 3}
@@ -86,6 +86,9 @@ class TgConfig(C.Structure):
         ("traj_spacing", C.c_double), ("traj_max_perturb", C.c_double), ("traj_init_offset", C.c_double),
         ("mass_lo", C.c_double), ("mass_hi", C.c_double), ("init_orn_range", C.c_double), ("traj_ang_range", C.c_double),
         ("control_mode", C.c_int32), ("max_blocking_steps", C.c_int32), ("reset_goal_id", C.c_int32), ("surf_vertical", C.c_int32),
+        ("roll_rand_init_pos", C.c_int32), ("roll_rand_size", C.c_int32), ("roll_rand_embed", C.c_int32),
+        ("roll_radius", C.c_double), ("roll_init_range", C.c_double), ("roll_goal_lo", C.c_double), ("roll_goal_hi", C.c_double),
+        ("tip_cyl_pos", _d3), ("tip_cyl_rot", _d9), ("tip_cyl_half_len", C.c_double), ("tip_cyl_radius", C.c_double),
     ]
 
 

@@ -55,6 +55,9 @@ template <typename T> struct EnvConst {
     // object_push
     PushScene<T> push;
     int traj_type, traj_n, rand_init_orn, rand_obj_mass, reset_goal_id;
+    // object_roll
+    int roll_rand_init_pos, roll_rand_size, roll_rand_embed;
+    double roll_radius, roll_init_range, roll_goal_lo, roll_goal_hi;
     double traj_spacing, traj_max_perturb, traj_init_offset, mass_lo, mass_hi, init_orn_range, traj_ang_range, obj_mass0;
     T obj_init_pos[3];
     double obj_init_rpy[3];
@@ -251,7 +254,8 @@ template <typename T> __device__ __forceinline__ void scale_actions(const EnvCon
 // BaseRobotArm.tcp_velocity_control (base_robot_arm.py:281-332): TCP limit check, work -> world twist, Jacobian inverse.
 template <typename T, int TOPO>
 __device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const EnvConst<T>& c, const T (&q)[Topo<TOPO>::N], T (&vels)[6],
-                                                     T (&qd_des)[Topo<TOPO>::N], const JointTrig<T, Topo<TOPO>::N>* trig = nullptr) {
+                                                     T (&qd_des)[Topo<TOPO>::N], const JointTrig<T, Topo<TOPO>::N>* trig = nullptr,
+                                                     T work_dz = T(0) /* per-env z offset of the work-frame origin (object_roll) */) {
     constexpr int N = Topo<TOPO>::N;
     Kin<T, TOPO> k;
     if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, k, trig);
@@ -259,7 +263,7 @@ __device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const
     V3<T> ptcp; M3<T> Rtcp;
     link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
     V3<T> wpos; T wrpy[3], rpyw[3];
-    world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpyw);
+    world_to_work(c, mk(ptcp.x, ptcp.y, ptcp.z - work_dz), Rtcp, wpos, wrpy, rpyw);
     const T cur[6] = {wpos.x, wpos.y, wpos.z, wrpy[0], wrpy[1], wrpy[2]};
 #pragma unroll
     for (int d = 0; d < 6; ++d) {   // check_TCP_vel_lims (base_robot_arm.py:357-380)
@@ -1146,6 +1150,184 @@ __global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict
     finish_push<T, TOPO>(m, c, st, env, q, b, 0, false);
 }
 
+// ------------------------------------------------------------------------------------------------ object_roll
+// get_step_data (object_roll_env.py:311-365): the goal, given in the TCP frame, is carried along with the TCP (update_goal :268-295);
+// reward -|obj_xy - goal_xy|, done below 1 mm; extended_feature = goal_pos_tcp (:409-415); camera <- marble transform with the
+// episode's scale (loadURDF globalScaling scales the visual).
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_roll(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                            const FreeBody<T>& b, T scale, int step_count, bool write_reward_done) {
+    const int n = c.num_envs;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    T rpy[3];
+    const Q4<T> qtcp = quat_from_mat(Rtcp);
+    euler_from_quat(qtcp, rpy[0], rpy[1], rpy[2]);
+    st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
+    st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    const V3<T> gt = mk((T)st.goal[0 * n + env], (T)st.goal[1 * n + env], (T)st.goal[2 * n + env]);
+    if (write_reward_done) {
+        const V3<T> gw = ptcp + mul(mat_from_quat(qtcp), gt);                              // multiplyTransforms(tcp pose, goal_pos_tcp)
+        const T dx = b.pos.x - gw.x, dy = b.pos.y - gw.y;
+        const T dist = tsqrt(dx * dx + dy * dy);                                           // xy_obj_dist_to_goal
+        const bool at_goal = dist < c.term_dist;
+        st.reward[env] = (float)(c.reward_mode == TG_REWARD_SPARSE ? (at_goal ? T(1) : T(0)) : -(T(1) * dist));
+        st.done[env] = (at_goal || step_count >= c.max_steps) ? 1 : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const float f = e == 0 ? (float)gt.x : (e == 1 ? (float)gt.y : (e == 2 ? (float)gt.z : 0.0f));
+        if (write_reward_done) st.term_feature[(size_t)env * 12 + e] = f;
+        st.feature[(size_t)env * 12 + e] = f;
+    }
+    V3<T> pb; M3<T> Rb;
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
+    const M3<T> Rc = mul(Rb, c.cam_rot);
+    V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
+    f = (T(1) / norm(f)) * f;
+    V3<T> s = cross(f, up);
+    s = (T(1) / norm(s)) * s;
+    const V3<T> u = cross(s, f);
+    const V3<T> ox = scale * mk(b.R.m[0], b.R.m[3], b.R.m[6]), oy = scale * mk(b.R.m[1], b.R.m[4], b.R.m[7]), oz = scale * mk(b.R.m[2], b.R.m[5], b.R.m[8]);
+    const V3<T> dp = b.pos - pc;
+    const V3<T> nf = mk<T>(0, 0, 0) - f;
+    float* X = st.stim_xform;
+    X[0 * n + env] = (float)dot(s, ox);  X[1 * n + env] = (float)dot(s, oy);  X[2 * n + env] = (float)dot(s, oz);
+    X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
+    X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
+    X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                  const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double push_lds_raw[];
+    const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    FreeBody<T> b = load_body<T>(st, n, env);
+    const float* a = actions + (size_t)env * c.act_dim;
+    T enc[6] = {(T)a[0], (T)a[1], T(0), T(0), T(0), T(0)};   // encode_actions "xy" (object_roll_env.py:297-309)
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+    const T radius = (T)st.obj_mass[env];                                  // the episode's radius
+    const T work_dz = (T)((2.0 * st.obj_mass[env] - st.embed[env]) - (double)c.work_pos[2]);   // update_workframe (:192-201)
+    T qd_des[N], zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, nullptr, work_dz);
+#pragma unroll
+    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+    for (int t = 0; t < c.action_repeat; ++t)
+        sim_tick_push<T, TOPO, kMotorVelocity, 1>(m, q, qd, zero, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push, nullptr,
+                                                  radius, lds + threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    store_body<T>(st, n, env, b);
+    finish_roll<T, TOPO>(m, c, st, env, q, b, radius / (T)c.roll_radius, step_count, true);
+}
+
+// BaseObjectEnv.reset (base_object_env.py:153-190) for object_roll: reset_task (marble size, embed distance; :176-190), update_workframe,
+// Robot.reset with the marble of the last episode still in the world, reset_object (:203-248), make_goal (:250-266).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                   const uint8_t* __restrict__ mask) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double push_lds_raw[];
+    const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    uint64_t rs = st.rng[env];
+    const double old_radius = st.obj_mass[env];
+    const double scaling = c.roll_rand_size ? rng_uniform(rs, 1.0, 2.0) : 1.0;
+    const double new_radius = c.roll_radius * scaling;
+    double embed = st.embed[env];
+    if (c.roll_rand_embed) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
+    double ix = 0.0, iy = 0.0;
+    if (c.roll_rand_init_pos) { ix = rng_uniform(rs, -c.roll_init_range, c.roll_init_range); iy = rng_uniform(rs, -c.roll_init_range, c.roll_init_range); }
+    const double gang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+    const double gdist = rng_uniform(rs, c.roll_goal_lo, c.roll_goal_hi);
+    st.rng[env] = rs;
+    st.step_count[env] = 0;
+    st.embed[env] = embed;
+    st.goal[0 * n + env] = gdist * cos(gang); st.goal[1 * n + env] = gdist * sin(gang); st.goal[2 * n + env] = 0.0;
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+    const V3<T> tpos = mk(c.work_pos[0], c.work_pos[1], (T)(2.0 * new_radius - embed));   // work-frame origin of this episode, rpy 0
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }
+    T cv = T(0.001);
+    T zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    int used = 0;
+    for (int it = 0; it < 1000; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], step_j[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        if (all_small) cv = cv / T(2);
+        sim_tick_push<T, TOPO, kMotorPosition, 1>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, b, c.push,
+                                                  nullptr, (T)old_radius, lds + threadIdx.x);
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.reset_ticks[env] = used;
+    // reset_object: teleport (or reload with the new scale), velocities zeroed
+    b.pos = mk((T)((double)c.obj_init_pos[0] + ix), (T)((double)c.obj_init_pos[1] + iy), (T)new_radius);
+    const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) b.R.m[k] = ident[k];
+    b.v = mk<T>(0, 0, 0); b.w = mk<T>(0, 0, 0);
+    st.obj_mass[env] = new_radius;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+    store_body<T>(st, n, env, b);
+    finish_roll<T, TOPO>(m, c, st, env, q, b, (T)scaling, 0, false);
+}
+
 // Recompute cached read-backs after tg_set_joint_state.
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_refresh(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st) {
@@ -1432,6 +1614,28 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.term_deg = (T)cfg.term_deg; c.term_pos = (T)cfg.term_pos;
         c.rand_gravity = cfg.rand_gravity; c.rand_embed = cfg.rand_embed;
         c.gravity_lo = cfg.gravity_lo; c.gravity_hi = cfg.gravity_hi; c.gravity_default = cfg.gravity_default;
+    } else if (cfg.env_kind == TG_ENV_OBJECT_ROLL) {
+        c.act_dim = 2;                   // movement_mode "xy" (object_roll_env.py:417-422)
+        if (cfg.movement_mode != 0) return fail(-1, "Incorrect movement mode specified");
+        if (cfg.control_mode != TG_CONTROL_TCP_VELOCITY) return fail(-1, "object_roll: only TCP_velocity_control is built");
+        if (cfg.obj_mass <= 0 || cfg.roll_radius <= 0) return fail(-1, "object_roll: mass and radius must be positive");
+        if (cfg.tip_link < 0 || cfg.tip_link >= rob.ndof) return fail(-1, "object_roll: tip_link out of range");
+        if (rob.topology == 1 && cfg.tip_link >= Topo<1>::NP) return fail(-1, "object_roll: the tip must hang off the MG400's main chain (j1..j5)");
+        PushScene<T>& ps = c.push;
+        ps.table_z = (T)cfg.table_z;
+        ps.mu_table = (T)cfg.mu_table; ps.mu_tip = (T)cfg.mu_tip;
+        ps.breaking = (T)cfg.contact_breaking; ps.erp = (T)cfg.contact_erp; ps.tip_stiffness = (T)cfg.tip_stiffness; ps.tip_damping = (T)cfg.tip_damping;
+        ps.lin_damp = (T)cfg.obj_lin_damp; ps.ang_damp = (T)cfg.obj_ang_damp;
+        const double i0 = 0.4 * cfg.obj_mass * cfg.roll_radius * cfg.roll_radius;   // solid sphere (btSphereShape::calculateLocalInertia)
+        ps.inertia0[0] = (T)i0; ps.inertia0[3] = (T)i0; ps.inertia0[5] = (T)i0;
+        ps.mass0 = (T)cfg.obj_mass; ps.radius0 = (T)cfg.roll_radius;
+        ps.tip_link = cfg.tip_link; ps.n_tip = 0; ps.cone_friction = cfg.cone_friction;
+        for (int k = 0; k < 3; ++k) { ps.cyl_pos[k] = (T)cfg.tip_cyl_pos[k]; c.obj_init_pos[k] = (T)cfg.obj_init_pos[k]; }
+        for (int k = 0; k < 9; ++k) ps.cyl_rot.m[k] = (T)cfg.tip_cyl_rot[k];
+        ps.cyl_hl = (T)cfg.tip_cyl_half_len; ps.cyl_r = (T)cfg.tip_cyl_radius;
+        c.roll_rand_init_pos = cfg.roll_rand_init_pos; c.roll_rand_size = cfg.roll_rand_size; c.roll_rand_embed = cfg.roll_rand_embed;
+        c.roll_radius = cfg.roll_radius; c.roll_init_range = cfg.roll_init_range; c.roll_goal_lo = cfg.roll_goal_lo; c.roll_goal_hi = cfg.roll_goal_hi;
+        c.obj_mass0 = cfg.obj_mass;
     } else if (cfg.env_kind == TG_ENV_OBJECT_PUSH) {
         switch (cfg.movement_mode) {     // get_act_dim, object_push_env.py:631-644
             case TG_PMOVE_Y: c.act_dim = 1; break;
@@ -1632,6 +1836,22 @@ template <typename T, int TOPO> static void launch_step_push_t(tg_ctx* c, const 
         hipLaunchKernelGGL((k_step_push<T, TOPO, false>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
                            (const EnvConst<T>*)c->d_const, c->st, d_actions);
 }
+template <typename T, int TOPO> static void launch_step_roll_t(tg_ctx* c, const float* d_actions) {
+    const int n = c->cfg.num_envs;
+    constexpr size_t lds_bytes = (size_t)kPushLdsWords * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_roll<T, TOPO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    hipLaunchKernelGGL((k_step_roll<T, TOPO>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_actions);
+}
+template <typename T, int TOPO> static void launch_reset_roll_t(tg_ctx* c, const uint8_t* d_mask) {
+    const int n = c->cfg.num_envs;
+    constexpr size_t lds_bytes = (size_t)kPushLdsWords * 64 * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reset_roll<T, TOPO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    hipLaunchKernelGGL((k_reset_roll<T, TOPO>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_mask);
+}
 template <typename T, int TOPO> static void launch_reset_push_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;
     constexpr size_t lds_bytes = (size_t)kPushLdsWords * 64 * sizeof(T);
@@ -1702,6 +1922,10 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
         if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_reset_body_t<double>(c, d_mask);
         else launch_reset_body_t<float>(c, d_mask);
+    } else if (c->cfg.env_kind == TG_ENV_OBJECT_ROLL) {
+#define CALL(T, TOPO) launch_reset_roll_t<T, TOPO>(c, d_mask)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
     } else if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
 #define CALL(T, TOPO) launch_reset_push_t<T, TOPO>(c, d_mask)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
@@ -1742,7 +1966,7 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     if (!cfg || !robot || !sensor || !out) return fail(-1, "tg_create: NULL argument");
     if (cfg->abi_version != TG_ABI_VERSION) return fail(-1, "tg_create: ABI version mismatch");
     if (cfg->env_kind != TG_ENV_EDGE_FOLLOW && cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && cfg->env_kind != TG_ENV_OBJECT_BALANCE &&
-        cfg->env_kind != TG_ENV_OBJECT_PUSH)
+        cfg->env_kind != TG_ENV_OBJECT_PUSH && cfg->env_kind != TG_ENV_OBJECT_ROLL)
         return fail(-1, "tg_create: unknown env_kind");
     if (cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && !stim) return fail(-1, "tg_create: this env needs a stimulus mesh");
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE && robot->topology != 0) return fail(-1, "tg_create: object_balance is built for the UR5 chain");
@@ -1822,6 +2046,23 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
         TG_HIP(hipMemcpy(s.body_pos, bp.data(), bp.size() * 8, hipMemcpyHostToDevice));
         TG_HIP(hipMemcpy(s.body_rot, br.data(), br.size() * 8, hipMemcpyHostToDevice));
         TG_HIP(hipMemcpy(s.gravity, gz.data(), gz.size() * 8, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(s.embed, em.data(), em.size() * 8, hipMemcpyHostToDevice));
+    }
+    if (cfg->env_kind == TG_ENV_OBJECT_ROLL) {
+        TG_HIP(hipMalloc(&s.body_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.body_rot, 9 * n * 8)); TG_HIP(hipMalloc(&s.body_v, 3 * n * 8));
+        TG_HIP(hipMalloc(&s.body_w, 3 * n * 8)); TG_HIP(hipMalloc(&s.obj_mass, n * 8)); TG_HIP(hipMalloc(&s.goal, 3 * n * 8));
+        TG_HIP(hipMalloc(&s.feature, (size_t)12 * n * 4)); TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4));
+        TG_HIP(hipMemset(s.body_v, 0, 3 * n * 8)); TG_HIP(hipMemset(s.body_w, 0, 3 * n * 8)); TG_HIP(hipMemset(s.goal, 0, 3 * n * 8));
+        TG_HIP(hipMemset(s.feature, 0, (size_t)12 * n * 4)); TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
+        // load_object (base_object_env.py:66-70) at init_obj_pos, identity orientation, default radius (object_roll_env.py:156-166)
+        std::vector<double> bp(3 * (size_t)n), br(9 * (size_t)n, 0.0), rad(n, cfg->roll_radius), em(n, cfg->embed_dist);
+        for (int i = 0; i < n; ++i) {
+            for (int a = 0; a < 3; ++a) bp[(size_t)a * n + i] = cfg->obj_init_pos[a];
+            br[(size_t)0 * n + i] = 1.0; br[(size_t)4 * n + i] = 1.0; br[(size_t)8 * n + i] = 1.0;
+        }
+        TG_HIP(hipMemcpy(s.body_pos, bp.data(), bp.size() * 8, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(s.body_rot, br.data(), br.size() * 8, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(s.obj_mass, rad.data(), rad.size() * 8, hipMemcpyHostToDevice));
         TG_HIP(hipMemcpy(s.embed, em.data(), em.size() * 8, hipMemcpyHostToDevice));
     }
     if (cfg->env_kind == TG_ENV_OBJECT_PUSH) {
@@ -1944,6 +2185,10 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
         if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
             if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_step_body_t<double>(c, d_act);
             else launch_step_body_t<float>(c, d_act);
+        } else if (c->cfg.env_kind == TG_ENV_OBJECT_ROLL) {
+#define CALL(T, TOPO) launch_step_roll_t<T, TOPO>(c, d_act)
+            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
         } else if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
 #define CALL(T, TOPO) launch_step_push_t<T, TOPO>(c, d_act)
             TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
@@ -1976,7 +2221,7 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     // The launch sequence of a step is the same every step (all arguments are device pointers owned by the context, the action
     // buffer aside): capture it once per action pointer / stream and replay it as one graph launch.  Not while profiling (the
     // per-kernel events are host calls between the launches) and not for the push kernels (hipFuncSetAttribute on first launch).
-    const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH;
+    const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL;
     if (want_graph) {
         if (c->step_graph && (c->step_graph_actions != d_act || c->step_graph_stream != c->stream)) {
             (void)hipGraphExecDestroy(c->step_graph);
@@ -2040,14 +2285,16 @@ int tg_get_packed_outputs(tg_ctx* c, void** p, int64_t* obs_bytes, int64_t* tota
 }
 int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {
     if (!c || !p) return fail(-1, "NULL argument");
-    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH) return fail(-1, "tg_get_obs_feature: this env has no extended_feature observation");
+    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL)
+        return fail(-1, "tg_get_obs_feature: this env has no extended_feature observation");
     *p = terminal ? c->st.term_feature : c->st.feature;
     if (dim) *dim = 12;
     return 0;
 }
 int tg_copy_obs_feature(tg_ctx* c, float* dst, int32_t terminal) {
     if (!c || !dst) return fail(-1, "NULL argument");
-    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH) return fail(-1, "tg_copy_obs_feature: this env has no extended_feature observation");
+    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL)
+        return fail(-1, "tg_copy_obs_feature: this env has no extended_feature observation");
     TG_HIP(hipMemcpyAsync(dst, terminal ? c->st.term_feature : c->st.feature, (size_t)c->cfg.num_envs * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     TG_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -2089,6 +2336,14 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
         if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
         if (v->gravity_z && (rc = fetch_soa(c, c->st.gravity, 1, v->gravity_z))) return rc;
     }
+    if (c->cfg.env_kind == TG_ENV_OBJECT_ROLL) {
+        if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
+        if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;
+        if (v->body_linvel && (rc = fetch_soa(c, c->st.body_v, 3, v->body_linvel))) return rc;
+        if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
+        if (v->goal_pos && (rc = fetch_soa(c, c->st.goal, 3, v->goal_pos))) return rc;          // goal_pos_tcp
+        if (v->obj_mass && (rc = fetch_soa(c, c->st.obj_mass, 1, v->obj_mass))) return rc;      // the episode's radius
+    }
     if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
         if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
         if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;
@@ -2112,7 +2367,7 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
 
 int tg_set_joint_state(tg_ctx* c, const double* q, const double* qd) {
     if (!c || !q || !qd) return fail(-1, "NULL argument");
-    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE || c->cfg.env_kind == TG_ENV_OBJECT_PUSH)
+    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE || c->cfg.env_kind == TG_ENV_OBJECT_PUSH || c->cfg.env_kind == TG_ENV_OBJECT_ROLL)
         return fail(-1, "tg_set_joint_state: not supported for envs with a free object");
     const int n = c->cfg.num_envs, nd = c->robot.ndof;
     std::vector<double> a((size_t)TG_MAX_DOF * n, 0.0), b((size_t)TG_MAX_DOF * n, 0.0);

@@ -901,6 +901,10 @@ template <typename T> struct PushScene {
     T table_z, half[3], mu_table, mu_tip, margin_cube, margin_tip, breaking, erp, tip_stiffness, tip_damping, lin_damp, ang_damp;
     T com[3], inertia0[6], mass0;
     int tip_link, n_tip, cone_friction;
+    // object_roll (SHAPE = 1): the free body is a sphere of radius `radius` x scale (inertia0 = that of radius0), the tip collision shape a
+    // solid cylinder (axis = local z) given in the frame of tip_link (ur5_with_flat_tactip.urdf:320-325) [PARITY_ASSUMPTIONS A30]
+    T radius0, cyl_pos[3], cyl_hl, cyl_r;
+    M3<T> cyl_rot;
 };
 constexpr int kPushTab = 9;                        // staging words per table contact slot: ra[3], rhs[3], 1/A[3]
 constexpr int kPushLdsWords = 4 * kPushTab;
@@ -932,7 +936,9 @@ template <typename T> __device__ __forceinline__ void plane_space(V3<T> n, V3<T>
     }
 }
 
-template <typename T, int TOPO, int MOTOR>
+// SHAPE 0: box (object_push; `mass` = the episode's mass, inertia rescaled with it).  SHAPE 1: sphere (object_roll; `mass` carries the
+// episode's RADIUS instead - the mass is fixed - and the inertia scales with its square).
+template <typename T, int TOPO, int MOTOR, int SHAPE = 0>
 __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                               const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                               int iters, FreeBody<T>& b, const PushScene<T>& sc, const T* __restrict__ tip_verts, T mass,
@@ -957,7 +963,8 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         }
     }
     // ---- cube: gravity, Bullet's velocity damping, gyroscopic torque (changeDynamics(mass) rescales the inertia with the mass)
-    const T iscale = mass / sc.mass0, invm = T(1) / mass;
+    const T radius = mass;   // SHAPE 1 only
+    const T iscale = SHAPE == 1 ? (radius / sc.radius0) * (radius / sc.radius0) : mass / sc.mass0, invm = T(1) / (SHAPE == 1 ? sc.mass0 : mass);
     const S3<T> I0{sc.inertia0[0] * iscale, sc.inertia0[1] * iscale, sc.inertia0[2] * iscale, sc.inertia0[3] * iscale, sc.inertia0[4] * iscale,
                    sc.inertia0[5] * iscale};
     const S3<T> Iw = rotate(b.R, I0), Iwi = inverse(Iw);
@@ -974,7 +981,25 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
     // vertex writes (ra, rhs[3], 1/A[3]) to the next slot of its lane's column, then the four slots are read back into registers.
 #pragma unroll
     for (int k = 0; k < 4 * kPushTab; ++k) L[k * 64] = T(0);
-    {
+    if constexpr (SHAPE == 1) {   // sphere - table: its lowest point, one slot
+        const T vz0 = (b.pos.z - radius) - sc.table_z;
+        if (vz0 <= sc.breaking) {
+            const V3<T> ra = mk(T(0), T(0), -radius);
+            lds_ptr<T> S = L;
+            S[0] = ra.x; S[64] = ra.y; S[128] = ra.z;
+            const V3<T> Ja[3] = {mk(ra.y, -ra.x, T(0)), mk(ra.z, T(0), -ra.x), mk(T(0), ra.z, -ra.y)};
+            const T lin[3] = {vb.z, -vb.y, vb.x};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const T A = invm + dot(Ja[r], mul(Iwi, Ja[r]));
+                const T rv = lin[r] + dot(Ja[r], wb);
+                T rhs = -rv;
+                if (r == 0) rhs = (vz0 > T(0)) ? (-rv - vz0 / dt) : (-vz0 * sc.erp / dt - rv);
+                S[(3 + r) * 64] = rhs;
+                S[(6 + r) * 64] = T(1) / A;
+            }
+        }
+    } else {
         T vz[8];
         int keep = 0, cnt = 0;
 #pragma unroll
@@ -1036,6 +1061,24 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             const T z3[3] = {T(0), T(0), T(0)};
             link_frame<T, TOPO>(kin, sc.tip_link, z3, ident, ol, Rl);
         }
+        T depth; bool active; V3<T> nrm, pa, pb;
+        if constexpr (SHAPE == 1) {   // sphere - tip: closest point of the solid cylinder to the sphere centre
+            const V3<T> cw = ol + mul(Rl, load_v3(sc.cyl_pos));
+            const M3<T> Rw = mul(Rl, sc.cyl_rot);
+            const V3<T> p = mulT(Rw, b.pos - cw);                     // centre in the cylinder frame
+            const T rad = tsqrt(p.x * p.x + p.y * p.y);
+            const T sr = rad > sc.cyl_r ? sc.cyl_r / rad : T(1);
+            const V3<T> cl = mk(p.x * sr, p.y * sr, p.z > sc.cyl_hl ? sc.cyl_hl : (p.z < -sc.cyl_hl ? -sc.cyl_hl : p.z));
+            const V3<T> g = p - cl;
+            const T dist = tsqrt(dot(g, g));
+            depth = dist - radius;
+            active = dist > T(0) && depth <= sc.breaking;
+            const T idist = T(1) / (dist > T(0) ? dist : T(1));
+            const V3<T> gw = mul(Rw, idist * g);                      // from the cylinder towards the sphere
+            nrm = mk<T>(0, 0, 0) - gw;                                // contact normal: from the sphere (body B) towards the tip (body A)
+            pa = cw + mul(Rw, cl);
+            pb = b.pos - radius * gw;
+        } else {
         M3<T> Mr;   // cube <- link rotation  Rc^T Rl
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -1078,10 +1121,11 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
 #pragma unroll
             for (int x = 0; x < 3; ++x) g[x] = (x == ax) ? (pp[x] < T(0) ? T(-1) : T(1)) : T(0);
         }
-        const T depth = sdf - (sc.margin_tip + sc.margin_cube);
-        const bool active = depth <= sc.breaking;
-        const V3<T> nrm = mul(b.R, mk(g[0], g[1], g[2]));   // from the cube towards the tip
-        const V3<T> pa = w - sc.margin_tip * nrm, pb = w - (sdf - sc.margin_cube) * nrm;
+        depth = sdf - (sc.margin_tip + sc.margin_cube);
+        active = depth <= sc.breaking;
+        nrm = mul(b.R, mk(g[0], g[1], g[2]));   // from the cube towards the tip
+        pa = w - sc.margin_tip * nrm; pb = w - (sdf - sc.margin_cube) * nrm;
+        }
         V3<T> t1, t2;
         plane_space(nrm, t1, t2);
         const V3<T> dirs[3] = {nrm, t1, t2};

@@ -575,3 +575,33 @@ def collision_hull_of_link(path, link_name):
     pts = np.concatenate(pts)
     hull = ConvexHull(pts)
     return mi, pts[hull.vertices]
+
+
+def collision_cylinder_of_link(path, link_name):
+    """A link's <collision><cylinder> (axis = its local z) expressed in the frame of the *moving* link the URDF link is welded to:
+    (moving_link_index, rot float64 [3,3], pos float64 [3], radius, length).  Used for the flat TacTip's tip (object_roll)."""
+    links, joints = parse_urdf(path)
+    children = {j.child for j in joints}
+    root = [n for n in links if n not in children][0]
+    by_parent = {}
+    for j in joints:
+        by_parent.setdefault(j.parent, []).append(j)
+    attach = {root: (-1, np.eye(3), np.zeros(3))}
+    counter = [0]
+
+    def dfs(link):
+        for j in by_parent.get(link, []):
+            mi, R, p = attach[j.parent]
+            Rj, pj = rpy_to_mat(j.rpy), np.asarray(j.xyz, dtype=np.float64)
+            if j.jtype == "fixed":
+                attach[j.child] = (mi, R @ Rj, R @ pj + p)
+            else:
+                attach[j.child] = (counter[0], np.eye(3), np.zeros(3))
+                counter[0] += 1
+            dfs(j.child)
+
+    dfs(root)
+    mi, R, p = attach[link_name]
+    g = [c for c in links[link_name].collisions if c.kind == "cylinder"][0]
+    Rg, pg = rpy_to_mat(g.origin_rpy), np.asarray(g.origin_xyz, dtype=np.float64)
+    return mi, R @ Rg, R @ pg + p, float(g.size[0]), float(g.size[1])

@@ -281,6 +281,9 @@ class TactileVecEnv:
         if self._cfg.env_kind == capi.ENV_OBJECT_PUSH:
             out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
                        traj=np.zeros((n, 3, capi.MAX_TRAJ_POINTS)), goal_id=np.zeros(n, np.int32), obj_mass=np.zeros(n))
+        if self._cfg.env_kind == capi.ENV_OBJECT_ROLL:   # obj_mass: the episode's marble radius; goal_pos: the goal in the TCP frame
+            out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
+                       goal_pos=np.zeros((n, 3)), obj_mass=np.zeros(n))
         if self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO:
             out.update(goal_pos=np.zeros((n, 3)), direction=np.zeros((n, 2)), surf_zoff=np.zeros(n, np.float32),
                        heights=np.zeros((n, self._cfg.surf_rows, self._cfg.surf_cols)))

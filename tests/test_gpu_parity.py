@@ -928,3 +928,54 @@ def test_surface_follow_vertical_env_matches_oracle(arm, sensor, obs_mode):
         assert done.all()
     assert seen > n * 4                                     # the sensor did touch the surface
     venv.close()
+
+
+ROLL_MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", rand_init_obj_pos=True, rand_obj_size=True, rand_embed_dist=True,
+                  observation_mode="tactile_and_feature", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")   # object_roll_params.py
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rand", [True, False])
+def test_object_roll_env_matches_oracle(rand):
+    """object_roll-v0 (UR5 + flat TacTip, marble between the table and the tip's collision cylinder, soft tip contact, goal in the TCP
+    frame): two consecutive episodes (the second Robot.reset runs with the marble of the first still in the world), 4 envs vs 4
+    oracle envs.  Joints 1e-9 rad, marble pose 1e-8, reward 1e-6, images within 3 pixels, extended_feature and the 34-d oracle vector."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleObjectRollEnv
+    modes = dict(ROLL_MODES, rand_init_obj_pos=rand, rand_obj_size=rand, rand_embed_dist=rand)
+    n, steps = 4, 6
+    venv = tg.make_vec("object_roll-v0", num_envs=n, max_steps=steps, image_size=[128, 128], env_modes=modes, seed=11, auto_reset=False)
+    assert venv.action_space.shape == (2,) and venv.observation_space["extended_feature"].shape == (3,)
+    oracles = [OracleObjectRollEnv(seed=11 + i, max_steps=steps, image_size=(128, 128), env_modes=modes) for i in range(n)]
+    rng = np.random.default_rng(12)
+    rolled = 0.0
+    for episode in range(2):
+        obs = venv.reset()
+        ref = [o.reset() for o in oracles]
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            assert st["reset_ticks"][i] == o.reset_ticks and st["obj_mass"][i] == o.scaled_obj_radius and st["embed_dist"][i] == o.embed_dist
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-9
+            assert np.abs(st["body_pos"][i] - o.ball_pose()[0]).max() < 1e-12
+            assert np.abs(st["goal_pos"][i] - o.goal_pos_tcp).max() < 1e-15
+            assert np.abs(obs["extended_feature"][i] - ref[i]["extended_feature"]).max() < 1e-7
+            assert int((obs["tactile"][i] != ref[i]["tactile"]).sum()) <= 3
+        start = st["body_pos"].copy()
+        for step in range(steps):
+            a = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+            obs, rew, done, _ = venv.step(a)
+            st = venv.get_state()
+            oo = venv.oracle_obs()
+            for i, o in enumerate(oracles):
+                ro, rr, rd, _ = o.step(a[i])
+                pos, R = o.ball_pose()
+                assert np.abs(st["q"][i] - o.arm.q).max() < 1e-9, (episode, step, i)
+                assert np.abs(st["body_pos"][i] - pos).max() < 1e-8 and np.abs(st["body_rot"][i] - R).max() < 1e-8, (episode, step, i)
+                assert abs(rew[i] - rr) < 1e-6 and bool(done[i]) == rd
+                assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (episode, step, i)
+                assert np.abs(oo[i] - o.oracle_obs()).max() < 2e-5, (episode, step, i, np.abs(oo[i] - o.oracle_obs()).argmax())
+        rolled = max(rolled, float(np.abs(st["body_pos"] - start)[:, :2].max()))
+        assert done.all()
+    if rand:
+        assert rolled > 1e-3           # with embed distances above the 1.75 mm skin-to-core gap the marble does roll
+    venv.close()

@@ -210,3 +210,28 @@ def test_surface_follow_vertical_config_and_registry():
         sf.build_config(8, 200, (128, 128), dict(m, noise_mode="simplex"))              # xRz needs the vertical surface
     with pytest.raises(KeyError):
         sf.build_config(8, 200, (128, 128), dict(m, noise_mode="simplex", movement_mode="xyz"))   # no `standard` rest pose for the MG400 upstream
+
+
+def test_object_roll_config_and_registry():
+    """object_roll-v0 host logic without a GPU (object_roll_env.py line by line): flat TacTip, tip cylinder from the URDF, friction
+    products, randomisation flags and ranges, failure modes."""
+    import tactile_gym_amd as tg
+    from tactile_gym_amd import _capi as capi
+    from tactile_gym_amd.rl_envs import object_roll as orl
+    assert "object_roll-v0" in tg.registered_ids()
+    modes = dict(orl.env_modes_default, arm_type="ur5", tactile_sensor_name="tactip", observation_mode="tactile_and_feature",
+                 rand_init_obj_pos=True, rand_obj_size=True, rand_embed_dist=True)
+    cfg, robot, sensor, mesh, _ = orl.build_config(8, 250, (128, 128), modes)
+    assert cfg.env_kind == capi.ENV_OBJECT_ROLL and cfg.action_repeat == 24 and cfg.termination_dist == 0.001
+    assert abs(cfg.workframe_pos[2] - (2 * 0.0025 - 0.0015)) < 1e-15 and cfg.roll_radius == 0.0025 and abs(cfg.obj_mass - 0.05) < 1e-12
+    assert cfg.mu_tip == 100.0 and cfg.mu_table == 10.0 and cfg.tip_stiffness == 10.0
+    assert (cfg.roll_rand_init_pos, cfg.roll_rand_size, cfg.roll_rand_embed) == (1, 1, 1) and cfg.roll_goal_lo == 0.0 and cfg.roll_goal_hi == 0.015
+    assert cfg.tip_link == 5 and cfg.tip_cyl_radius == 0.02 and abs(cfg.tip_cyl_half_len - 0.00325) < 1e-15
+    assert mesh.struct.n_tris == 960 and robot.ndof == 6
+    assert orl.build_config(8, 250, (128, 128), dict(modes, rand_init_obj_pos=False))[0].roll_goal_lo == 0.005
+    with pytest.raises(ValueError):
+        orl.build_config(8, 250, (128, 128), dict(modes, movement_mode="xyz"))
+    with pytest.raises(NotImplementedError):
+        orl.build_config(8, 250, (128, 128), dict(modes, arm_type="mg400"))
+    with pytest.raises(NotImplementedError):
+        orl.build_config(8, 250, (128, 128), dict(modes, control_mode="TCP_position_control"))

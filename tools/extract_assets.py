@@ -20,7 +20,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tactile_gym_amd.urdf_compile import collision_hull_of_link, compile_free_body, compile_urdf, load_mesh, parse_urdf, rpy_to_mat, visual_meshes_of_link  # noqa: E402
+from tactile_gym_amd.urdf_compile import collision_cylinder_of_link, collision_hull_of_link, compile_free_body, compile_urdf, load_mesh, parse_urdf, rpy_to_mat, visual_meshes_of_link  # noqa: E402
 
 REF = os.environ.get("TG_REFERENCE_ASSETS", "/root/reference/tactile_gym/assets")
 OUT = os.path.join(ROOT, "tactile_gym_amd", "assets")
@@ -51,6 +51,7 @@ ROBOTS = [
     ("ur5", "tactip", "forward"),
     ("ur5", "digit", "forward"),
     ("ur5", "digitac", "forward"),
+    ("ur5", "tactip", "flat"),                   # object_roll (object_roll_env.py:57)
 ]
 
 SENSOR_IMAGES = [
@@ -58,6 +59,7 @@ SENSOR_IMAGES = [
     ("tactip", "right_angle", (64, 128, 256)),
     ("tactip", "mini_right_angle", (64, 128, 256)),
     ("tactip", "forward", (64, 128, 256)),
+    ("tactip", "flat", (64, 128, 256)),
     ("digit", "forward", (64, 128, 256)),
     ("digitac", "forward", (64, 128, 256)),
     ("digit", "standard", (64, 128, 256)),
@@ -101,6 +103,12 @@ def robots():
                 d.update(tip_hull_link=np.array(hl), tip_hull_verts=hv)
             except Exception as e:  # noqa: BLE001 - e.g. no collision mesh
                 print("  no tip hull:", e)
+                try:   # the flat TacTip's tip collides as a URDF cylinder
+                    cl, cR, cp, cr, clen = collision_cylinder_of_link(urdf, f"{sensor}_tip_link")
+                    d.update(tip_cyl_link=np.array(cl), tip_cyl_rot=cR, tip_cyl_pos=cp, tip_cyl_radius=np.array(cr), tip_cyl_length=np.array(clen))
+                    print("  tip cylinder: link", cl, "radius", cr, "length", clen)
+                except Exception as e2:  # noqa: BLE001
+                    print("  no tip cylinder:", e2)
             save(os.path.join(OUT, "robots", f"{arm}_{typ}_{sensor}{suffix}.npz"), **d)
 
 
@@ -157,8 +165,21 @@ def objects():
             save(os.path.join(OUT, "objects", f"{name}{suffix}.npz"), **d)
 
 
+def sphere():
+    """object_roll marble: sphere.urdf (mass 0.05, collision sphere r = 0.0025; inertia of a solid sphere, what Bullet computes from the
+    collision shape) + the tessellation upstream ships next to it (sphere.obj, r = 0.0025) as the visual [PARITY_ASSUMPTIONS A30]."""
+    d = os.path.join(REF, "rl_env_assets/nonprehensile_manipulation/object_roll/sphere")
+    links, _ = parse_urdf(os.path.join(d, "sphere.urdf"))
+    L = next(iter(links.values()))
+    r = float(L.collisions[0].size[0])
+    v, t = load_mesh(os.path.join(d, "sphere.obj"))
+    save(os.path.join(OUT, "objects", "sphere.npz"), mass=np.array(L.mass), radius=np.array(r), urdf_inertia=np.array(L.inertia),
+         verts=v.astype(np.float32), tris=t.astype(np.int32))
+
+
 if __name__ == "__main__":
     objects()
+    sphere()
     robots()
     sensors()
     stimuli()

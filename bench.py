@@ -27,6 +27,10 @@ BAL_MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", object
                  observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")   # configs[4], params/object_balance_params.py
 PUSH_MODES = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
                   observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")   # configs[3], params/object_push_params.py
+ROLL_MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", rand_init_obj_pos=True, rand_obj_size=True, rand_embed_dist=True,
+                  observation_mode="tactile_and_feature", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")   # params/object_roll_params.py
+VERT_MODES = dict(movement_mode="xRz", control_mode="TCP_velocity_control", noise_mode="vertical_simplex", observation_mode="tactile",
+                  reward_mode="dense", arm_type="mg400", tactile_sensor_name="tactip")   # params/surface_follow_vert_params.py
 MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
              reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
 ALGO_BYTES_PER_ENV_STEP = 16600.0   # BASELINE.md section 3 / SURVEY 8(d): 16 384 B image + ~0.2 KB state/action/reward
@@ -81,7 +85,7 @@ def main():
     ap.add_argument("--sync-steps", action="store_true", help="block the host on every step (VecEnv.step_wait semantics) instead of pipelining")
     ap.add_argument("--full-sweeps", action="store_true",
                     help="always run all 150 PGS sweeps per tick instead of leaving the loop at convergence to the last bit (DESIGN.md 4.1)")
-    ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0", "object_balance-v0", "object_push-v0"],
+    ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0", "object_balance-v0", "object_push-v0", "object_roll-v0", "surface_follow-v2"],
                     help="headline = edge_follow-v0 (BASELINE configs[1]); surface_follow-v0 = configs[2]; object_balance-v0 = configs[4] "
                          "(use --image-size 256)")
     args = ap.parse_args()
@@ -108,9 +112,10 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     n = args.num_envs
-    modes = {"edge_follow-v0": MODES, "surface_follow-v0": SURF_MODES, "object_balance-v0": BAL_MODES, "object_push-v0": PUSH_MODES}[args.env]
+    modes = {"edge_follow-v0": MODES, "surface_follow-v0": SURF_MODES, "object_balance-v0": BAL_MODES, "object_push-v0": PUSH_MODES,
+             "object_roll-v0": ROLL_MODES, "surface_follow-v2": VERT_MODES}[args.env]
     act_dim = 3 if args.env == "surface_follow-v0" else 2
-    max_steps = {"object_balance-v0": 250, "object_push-v0": 1000}.get(args.env, 200)        # params/*_params.py max_ep_len
+    max_steps = {"object_balance-v0": 250, "object_push-v0": 1000, "object_roll-v0": 250}.get(args.env, 200)   # params/*_params.py max_ep_len
     venv = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
                        seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",
                        pgs_full_sweeps=args.full_sweeps)
@@ -214,7 +219,8 @@ def main():
         dom_ms = k_step if dominant == "k_step" else k_render_main
         algo_bytes = {"edge_follow-v0": ALGO_BYTES_PER_ENV_STEP, "surface_follow-v0": ALGO_BYTES_SURFACE,
                       "object_balance-v0": args.image_size * args.image_size + 300.0,             # config 5: 65.8 KB at 256x256
-                      "object_push-v0": args.image_size * args.image_size + 400.0}[args.env]
+                      "object_push-v0": args.image_size * args.image_size + 400.0,
+                      "object_roll-v0": args.image_size * args.image_size + 400.0, "surface_follow-v2": ALGO_BYTES_SURFACE}[args.env]
         achieved = algo_bytes * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure measured with
         # rocprofv3 on this workload (profiles/r1_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) is reported when the
@@ -234,7 +240,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.physics == "f64" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.env}, {'MG400 + DigiTac' if args.env == 'object_push-v0' else 'UR5 + ' + ('DIGIT' if args.env == 'surface_follow-v0' else 'TacTip')}, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
+            "config": {"workload": f"{args.env}, {modes['arm_type'].upper()} + {modes['tactile_sensor_name']}, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
                                    f"random actions, TCP_velocity_control, {12 if args.env == 'object_balance-v0' else 24} sim ticks per step (PGS budget 150 sweeps per tick), auto-reset on",
                        "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world}" + (" + one packed RCCL gather (obs u8, reward f32, done u8) to rank 0 per step, "
                                                                           "overlapped with the next step's simulation" if world > 1 else "")},

@@ -979,3 +979,47 @@ def test_object_roll_env_matches_oracle(rand):
     if rand:
         assert rolled > 1e-3           # with embed distances above the 1.75 mm skin-to-core gap the marble does roll
     venv.close()
+
+
+@pytest.mark.gpu
+def test_full_size_properties_roll_and_vertical():
+    """object_roll-v0 and surface_follow-v2 at 1024 envs: run-to-run determinism and domain invariants without the oracle: the marble
+    stays on the table at its radius and rolls half as far as the tip that drives it (pure rolling between table and tip) in the envs
+    whose embed distance reaches the tip's collision core; the upright surface varies along one axis only and is touched by most envs."""
+    import tactile_gym_amd as tg
+    n = 1024
+    modes_roll = dict(ROLL_MODES, rand_init_obj_pos=False)
+    outs = []
+    for rep in range(2):
+        venv = tg.make_vec("object_roll-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=modes_roll, seed=5, auto_reset=False)
+        venv.reset()
+        st0 = venv.get_state()
+        a = np.tile(np.array([[0.25, 0.0]], dtype=np.float32), (n, 1))          # +x in the work frame at the maximum speed
+        for k in range(5):
+            obs, rew, done, _ = venv.step(a)
+        outs.append((obs["tactile"].copy(), rew.copy(), venv.get_state(), st0))
+        venv.close()
+    (img, rew, st, st0), (img2, rew2, st2, _) = outs
+    assert np.array_equal(img, img2) and np.array_equal(rew, rew2) and np.array_equal(st["q"], st2["q"]) and np.array_equal(st["body_pos"], st2["body_pos"])
+    assert np.isfinite(st["body_pos"]).all() and np.abs(st["body_pos"][:, 2] - st["obj_mass"]).max() < 1e-4      # resting on the table
+    assert (st["obj_mass"] >= 0.0025).all() and (st["obj_mass"] <= 0.005).all() and (st["embed_dist"] >= 0.0015).all()
+    tip = np.linalg.norm(st["tcp_pos"][:, :2] - st0["tcp_pos"][:, :2], axis=1)
+    ball = np.linalg.norm(st["body_pos"][:, :2] - st0["body_pos"][:, :2], axis=1)
+    # the tip's collision core (cylinder cap) sits 1.75 mm behind the TCP: how far it reaches into the marble after the reset move
+    # (blocking_move may stop one tick short of its target, robot.py:216-258, so the TCP height itself is used, not the nominal embed)
+    reach = 2 * st["obj_mass"] - (st0["tcp_pos"][:, 2] + 0.00175)
+    pressed = reach > 1.5e-4
+    assert pressed.sum() > n // 2 and np.abs(ball[pressed] / tip[pressed] - 0.5).max() < 0.05
+    assert (ball[reach < -1.5e-4] < 1e-6).all()                                 # not touched: does not move
+
+    modes_v = dict(movement_mode="xRz", control_mode="TCP_velocity_control", noise_mode="vertical_simplex", observation_mode="tactile",
+                   reward_mode="dense", arm_type="mg400", tactile_sensor_name="tactip")
+    venv = tg.make_vec("surface_follow-v2", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=modes_v, seed=6, auto_reset=False)
+    obs = venv.reset()
+    st = venv.get_state()
+    assert np.ptp(st["heights"], axis=2).max() == 0.0 and len(np.unique(st["heights"][:, 9, 0])) > n // 2
+    assert set(np.unique(st["direction"][:, 1])) == {-1.0, 1.0} and (st["direction"][:, 0] == 0).all()
+    for k in range(3):
+        obs, rew, done, _ = venv.step(np.tile(np.array([[0.1, 0.0]], dtype=np.float32), (n, 1)))
+    assert np.isfinite(rew).all() and (rew <= 0).all() and ((obs["tactile"].reshape(n, -1) > 0).any(axis=1).mean() > 0.9)
+    venv.close()

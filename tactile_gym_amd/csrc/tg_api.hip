@@ -456,7 +456,8 @@ __device__ __forceinline__ int inverse_kinematics(const DevRobot<T>& m, V3<T> tp
 // kinematics from the current joint state.  The POSITION_CONTROL motors then track `qik` (gains pos_gain / vel_gain, max_force).
 template <typename T, int TOPO>
 __device__ __forceinline__ void tcp_position_target(const DevRobot<T>& m, const EnvConst<T>& c, const T (&q)[Topo<TOPO>::N], const T (&delta)[6],
-                                                    V3<T>& tpos, Q4<T>& tq, T (&qik)[Topo<TOPO>::N]) {
+                                                    V3<T>& tpos, Q4<T>& tq, T (&qik)[Topo<TOPO>::N],
+                                                    T work_dz = T(0) /* per-env z offset of the work-frame origin (object_roll) */) {
     constexpr int N = Topo<TOPO>::N;
     {
         Kin<T, TOPO> k;
@@ -464,11 +465,12 @@ __device__ __forceinline__ void tcp_position_target(const DevRobot<T>& m, const 
         V3<T> ptcp; M3<T> Rtcp;
         link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
         V3<T> wpos; T wrpy[3], rpyw[3];
-        world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpyw);
+        world_to_work(c, mk(ptcp.x, ptcp.y, ptcp.z - work_dz), Rtcp, wpos, wrpy, rpyw);
         T tgt[6] = {wpos.x + delta[0], wpos.y + delta[1], wpos.z + delta[2], wrpy[0] + delta[3], wrpy[1] + delta[4], wrpy[2] + delta[5]};
 #pragma unroll
         for (int d = 0; d < 6; ++d) tgt[d] = tgt[d] < c.tcp_lims[d][0] ? c.tcp_lims[d][0] : (tgt[d] > c.tcp_lims[d][1] ? c.tcp_lims[d][1] : tgt[d]);
         tpos = load_v3(c.work_pos) + mul(c.work_R, mk(tgt[0], tgt[1], tgt[2]));
+        tpos.z += work_dz;
         T trpy[3];
         euler_from_quat(quat_mul(c.work_q, quat_from_euler(tgt[3], tgt[4], tgt[5])), trpy[0], trpy[1], trpy[2]);
         tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
@@ -1201,7 +1203,7 @@ __device__ __forceinline__ void finish_roll(const DevRobot<T>& m, const EnvConst
     X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
 }
 
-template <typename T, int TOPO>
+template <typename T, int TOPO, bool POS>
 __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
     constexpr int N = Topo<TOPO>::N;
@@ -1227,12 +1229,25 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
     T qd_des[N], zero[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) zero[i] = T(0);
-    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, nullptr, work_dz);
+    if constexpr (POS) {                                  // TCP_position_control: qd_des carries the joint targets
+        V3<T> tpos; Q4<T> tq;
+        tcp_position_target<T, TOPO>(m, c, q, vels, tpos, tq, qd_des, work_dz);
 #pragma unroll
-    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
-    for (int t = 0; t < c.action_repeat; ++t)
-        sim_tick_push<T, TOPO, kMotorVelocity, 1>(m, q, qd, zero, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push, nullptr,
-                                                  radius, lds + threadIdx.x);
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = 0.0;
+        for (int t = 0; t < c.max_blocking; ++t) {        // blocking_move(max_steps, constant_vel=None), robot.py:188-260
+            const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+            sim_tick_push<T, TOPO, kMotorPosition, 1>(m, q, qd, qd_des, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
+                                                      nullptr, radius, lds + threadIdx.x);
+            if (stop) break;
+        }
+    } else {
+        tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, nullptr, work_dz);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+        for (int t = 0; t < c.action_repeat; ++t)
+            sim_tick_push<T, TOPO, kMotorVelocity, 1>(m, q, qd, zero, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push, nullptr,
+                                                      radius, lds + threadIdx.x);
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
     store_body<T>(st, n, env, b);
@@ -1617,7 +1632,6 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
     } else if (cfg.env_kind == TG_ENV_OBJECT_ROLL) {
         c.act_dim = 2;                   // movement_mode "xy" (object_roll_env.py:417-422)
         if (cfg.movement_mode != 0) return fail(-1, "Incorrect movement mode specified");
-        if (cfg.control_mode != TG_CONTROL_TCP_VELOCITY) return fail(-1, "object_roll: only TCP_velocity_control is built");
         if (cfg.obj_mass <= 0 || cfg.roll_radius <= 0) return fail(-1, "object_roll: mass and radius must be positive");
         if (cfg.tip_link < 0 || cfg.tip_link >= rob.ndof) return fail(-1, "object_roll: tip_link out of range");
         if (rob.topology == 1 && cfg.tip_link >= Topo<1>::NP) return fail(-1, "object_roll: the tip must hang off the MG400's main chain (j1..j5)");
@@ -1840,9 +1854,17 @@ template <typename T, int TOPO> static void launch_step_roll_t(tg_ctx* c, const 
     const int n = c->cfg.num_envs;
     constexpr size_t lds_bytes = (size_t)kPushLdsWords * 64 * sizeof(T);
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_roll<T, TOPO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
-    hipLaunchKernelGGL((k_step_roll<T, TOPO>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st, d_actions);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_roll<T, TOPO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_roll<T, TOPO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION)
+        hipLaunchKernelGGL((k_step_roll<T, TOPO, true>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
+    else
+        hipLaunchKernelGGL((k_step_roll<T, TOPO, false>), dim3((n + 63) / 64), dim3(64), lds_bytes, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
 }
 template <typename T, int TOPO> static void launch_reset_roll_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;

@@ -2,7 +2,7 @@
 
 Reference: tactile_gym/rl_envs/nonprehensile_manipulation/object_roll/object_roll_env.py (+ base_object_env.py).  The marble is a
 free sphere (sphere.urdf), the flat tip collides as a URDF cylinder (ur5_with_flat_tactip.urdf:320-325); contact model and the
-tessellation used for the marble's visual: PARITY_ASSUMPTIONS A30.  UR5 + TacTip, movement "xy", TCP_velocity_control.
+tessellation used for the marble's visual: PARITY_ASSUMPTIONS A30.  UR5 + TacTip, movement "xy", both control modes.
 """
 import ctypes as C
 import math
@@ -37,8 +37,8 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     arm, t_s_name, t_s_type = modes["arm_type"], modes["tactile_sensor_name"], "flat"           # :57
     if modes["movement_mode"] != "xy":
         raise ValueError(f"unknown movement_mode {modes['movement_mode']}")                     # get_act_dim :417-422
-    if modes["control_mode"] != "TCP_velocity_control":
-        if modes["control_mode"] in ("TCP_position_control", "joint_velocity_control"):
+    if modes["control_mode"] not in capi.CONTROL:
+        if modes["control_mode"] in ("joint_velocity_control",):
             raise NotImplementedError(f"control_mode {modes['control_mode']} is not built for object_roll")
         raise SystemExit(f"Incorrect control mode specified: {modes['control_mode']}")
     if arm not in REST_POSES:
@@ -60,7 +60,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.auto_reset, cfg.device = int(auto_reset), int(device)
     cfg.min_action, cfg.max_action = -0.25, 0.25                                                # :110
     cfg.control_mode, cfg.max_blocking_steps = capi.CONTROL[modes["control_mode"]], 10
-    v = 0.01                                                                                    # :125-135
+    v = 0.001 if modes["control_mode"] == "TCP_position_control" else 0.01                     # :113-135
     lo, hi = [-v, -v, 0.0, 0.0, 0.0, 0.0], [v, v, 0.0, 0.0, 0.0, 0.0]
     lims = [(-0.05, 0.05), (-0.05, 0.05), (-0.01, 0.01), (0.0, 0.0), (0.0, 0.0), (0.0, 0.0)]     # :74-80
     for d in range(6):

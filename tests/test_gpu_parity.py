@@ -935,14 +935,14 @@ ROLL_MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", rand_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rand", [True, False])
-def test_object_roll_env_matches_oracle(rand):
+@pytest.mark.parametrize("rand,control", [(True, "TCP_velocity_control"), (False, "TCP_velocity_control"), (True, "TCP_position_control")])
+def test_object_roll_env_matches_oracle(rand, control):
     """object_roll-v0 (UR5 + flat TacTip, marble between the table and the tip's collision cylinder, soft tip contact, goal in the TCP
     frame): two consecutive episodes (the second Robot.reset runs with the marble of the first still in the world), 4 envs vs 4
     oracle envs.  Joints 1e-9 rad, marble pose 1e-8, reward 1e-6, images within 3 pixels, extended_feature and the 34-d oracle vector."""
     import tactile_gym_amd as tg
     from oracle.ref_env import OracleObjectRollEnv
-    modes = dict(ROLL_MODES, rand_init_obj_pos=rand, rand_obj_size=rand, rand_embed_dist=rand)
+    modes = dict(ROLL_MODES, rand_init_obj_pos=rand, rand_obj_size=rand, rand_embed_dist=rand, control_mode=control)
     n, steps = 4, 6
     venv = tg.make_vec("object_roll-v0", num_envs=n, max_steps=steps, image_size=[128, 128], env_modes=modes, seed=11, auto_reset=False)
     assert venv.action_space.shape == (2,) and venv.observation_space["extended_feature"].shape == (3,)
@@ -973,11 +973,15 @@ def test_object_roll_env_matches_oracle(rand):
                 assert np.abs(st["body_pos"][i] - pos).max() < 1e-8 and np.abs(st["body_rot"][i] - R).max() < 1e-8, (episode, step, i)
                 assert abs(rew[i] - rr) < 1e-6 and bool(done[i]) == rd
                 assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (episode, step, i)
-                assert np.abs(oo[i] - o.oracle_obs()).max() < 2e-5, (episode, step, i, np.abs(oo[i] - o.oracle_obs()).argmax())
+                ref_o, got_o = o.oracle_obs().copy(), oo[i].copy()
+                for sl in (slice(3, 7), slice(16, 20)):          # orientations are quaternions: q and -q are the same rotation (the work
+                    if np.dot(ref_o[sl], got_o[sl]) < 0:         # frame's roll of -pi puts a resting marble right on the +-pi branch cut)
+                        got_o[sl] = -got_o[sl]
+                assert np.abs(got_o - ref_o).max() < 2e-5, (episode, step, i, np.abs(got_o - ref_o).argmax())
         rolled = max(rolled, float(np.abs(st["body_pos"] - start)[:, :2].max()))
         assert done.all()
     if rand:
-        assert rolled > 1e-3           # with embed distances above the 1.75 mm skin-to-core gap the marble does roll
+        assert rolled > (1e-3 if control == "TCP_velocity_control" else 1e-4)   # embed distances above the 1.75 mm skin-to-core gap: it rolls
     venv.close()
 
 

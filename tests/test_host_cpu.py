@@ -233,5 +233,6 @@ def test_object_roll_config_and_registry():
         orl.build_config(8, 250, (128, 128), dict(modes, movement_mode="xyz"))
     with pytest.raises(NotImplementedError):
         orl.build_config(8, 250, (128, 128), dict(modes, arm_type="mg400"))
+    assert orl.build_config(8, 250, (128, 128), dict(modes, control_mode="TCP_position_control"))[0].act_hi[0] == 0.001
     with pytest.raises(NotImplementedError):
-        orl.build_config(8, 250, (128, 128), dict(modes, control_mode="TCP_position_control"))
+        orl.build_config(8, 250, (128, 128), dict(modes, control_mode="joint_velocity_control"))

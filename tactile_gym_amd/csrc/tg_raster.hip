@@ -92,7 +92,7 @@ __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const fl
 // negligible; 64 x 64 for 64x64 images).
 // BAND (heightfield stimuli: hundreds of small triangles per tile): wavefront w owns the w-th 32-pixel column band of the tile (8 quad
 // columns x 8 rows per pass) instead of two full rows, and skips - as one scalar branch - every record whose bounding box misses the band.
-template <int TW, int TH, bool BAND, bool QREJ>
+template <int TW, int TH, bool BAND, bool QREJ, bool BLK = false>
 __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
@@ -131,17 +131,24 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
 #pragma unroll
     for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xf[(size_t)k * n_envs + env] : xf[(size_t)env * 12 + k];
 
-    // this lane's pixels: quad column qx (4 px), rows ry + 8*k
-    static_assert(!BAND || (TW == 128 && RPP == 8), "banded mapping: 4 wavefronts x 32-pixel bands, 8 rows per pass");
+    // Lane -> pixel mapping.  Default: a pass of the workgroup covers RPP full tile rows (a wavefront: a 128 x 2 strip).  BAND (heightfield):
+    // wavefront w owns the w-th 32-pixel column band (8 quad columns x 8 rows per pass) and skips records whose bounding box misses it.
+    // BLK (meshes of a few large triangles): the band is visited as 16 x 16 pixel blocks (pass kk = block (kk & 1, kk >> 1)), so that a pass
+    // which misses a record is skipped by the whole wavefront; for many small triangles the per-pass x test this costs outweighs it
+    // (measured: pole plate 0.45 -> 0.43 ms, heightfield 0.15 -> 0.23 ms, marble 0.80 -> 1.50 ms), hence a launch-time choice.
+    static_assert(!BAND || (TW == 128 && RPP == 8 && !BLK), "banded record skip: 4 wavefronts x 32-pixel bands");
+    static_assert(!BLK || (TW == 128 && kThreads == 256 && NK % 2 == 0), "16 x 16 blocks");
     const int band = __builtin_amdgcn_readfirstlane(tid / 64);
-    const int qx = BAND ? tile_x + 32 * band + 4 * (tid % 8) : tile_x + 4 * (tid % QPR);
-    const int ry = BAND ? tile_y + ((tid % 64) / 8) : tile_y + (tid / QPR);
+    const int qx0 = BLK ? tile_x + 32 * band + 4 * (tid % 4) : (BAND ? tile_x + 32 * band + 4 * (tid % 8) : tile_x + 4 * (tid % QPR));
+    const int ry0 = BLK ? tile_y + ((tid % 64) / 4) : (BAND ? tile_y + ((tid % 64) / 8) : tile_y + (tid / QPR));
+#define TG_QX(kk) (BLK ? qx0 + 16 * ((kk) & 1) : qx0)
+#define TG_RY(kk) (BLK ? ry0 + 16 * ((kk) >> 1) : ry0 + RPP * (kk))
     float z[NK][4];
     unsigned touched = 0;      // bit k: some triangle lowered a depth of row k of this lane's quad column
     {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const float4 nd = *reinterpret_cast<const float4*>(nodef_dep + (size_t)(ry + RPP * k) * P.W + qx);
+            const float4 nd = *reinterpret_cast<const float4*>(nodef_dep + (size_t)TG_RY(k) * P.W + TG_QX(k));
             z[k][0] = nd.x; z[k][1] = nd.y; z[k][2] = nd.z; z[k][3] = nd.w;
         }
     }
@@ -251,7 +258,8 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
             const TriRec r = recs[t];   // same address on every lane: LDS broadcast
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                const float fy = (float)(ry + RPP * k) + 0.5f;
+                const int qx = TG_QX(k);
+                const float fy = (float)TG_RY(k) + 0.5f;
                 if (fy < r.ymin || fy > r.ymax) continue;
                 if ((float)qx + 3.5f < r.xmin || (float)qx + 0.5f > r.xmax) continue;
                 if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     float4 ndk[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const size_t off = (size_t)(ry + RPP * k) * P.W + qx;
+        const size_t off = (size_t)TG_RY(k) * P.W + TG_QX(k);
         ngk[k] = *reinterpret_cast<const uchar4*>(gray_u8 + off);
         bmk[k] = *reinterpret_cast<const uchar4*>(border + off);
         ndk[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const size_t off = (size_t)(ry + RPP * k) * P.W + qx;
+        const size_t off = (size_t)TG_RY(k) * P.W + TG_QX(k);
         const uint8_t ngv[4] = {ngk[k].x, ngk[k].y, ngk[k].z, ngk[k].w}, bmv[4] = {bmk[k].x, bmk[k].y, bmk[k].z, bmk[k].w};
         const float ndv[4] = {ndk[k].x, ndk[k].y, ndk[k].z, ndk[k].w};
         uint8_t o[4] = {0, 0, 0, 0};
@@ -335,6 +343,8 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
         *reinterpret_cast<uchar4*>(dst + off) = make_uchar4(o[0], o[1], o[2], o[3]);
     }
 }
+#undef TG_QX
+#undef TG_RY
 
 // Small shared meshes (the 12-triangle edge): every triangle fits the record buffer in one round (rec_cap = 2 n_tris), so the pixel
 // phase can run in HALVES passes over disjoint row groups, each pass carrying only its own slice of the z-buffer from the reference
@@ -521,7 +531,7 @@ void launch_render(const RasterParams& P, const Stimulus& S, const float* xform,
                 hipLaunchKernelGGL((k_render_tactile<128, 128, true, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
             else if (S.no_quad_reject)
-                hipLaunchKernelGGL((k_render_tactile<128, 128, false, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                hipLaunchKernelGGL((k_render_tactile<128, 128, false, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
             else
                 hipLaunchKernelGGL((k_render_tactile<128, 128, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,

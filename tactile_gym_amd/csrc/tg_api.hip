@@ -380,7 +380,10 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
 #pragma unroll
                     for (int i = 0; i < N; ++i) q[i] += dq[i];
                 }
-                trig_init<T, N>(q, trig);
+                T dqt[N];                           // sines / cosines by one angle addition over the whole jump (exact
+#pragma unroll                                  // evaluation when it exceeds 0.02 rad); they are re-anchored at every step start
+                for (int i = 0; i < N; ++i) dqt[i] = (T)remaining * dq[i];
+                trig_advance<T, N>(q, dqt, trig);
                 verified -= remaining;
                 break;
             }

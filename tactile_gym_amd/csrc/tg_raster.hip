@@ -82,7 +82,12 @@ __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const fl
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb)   // band bb holds pixel centres tx0 + 32 bb + 0.5 .. + 31.5; coverage needs xmin <= fx <= xmax
             bands |= (r.xmax >= tx0 + 32.0f * (float)bb + 0.5f && r.xmin <= tx0 + 32.0f * (float)bb + 31.5f) ? (1u << bb) : 0u;
-        rbands[slot] = bands;
+        // bits 4..: the row groups (8 rows each: one pass of the banded mapping) whose pixel centres the bounding box can reach
+        const float ylo = (r.ymin - ty0 - 7.5f) * 0.125f, yhi = (r.ymax - ty0 - 0.5f) * 0.125f;
+        int k_lo = (int)ceilf(ylo), k_hi = (int)floorf(yhi);
+        k_lo = k_lo < 0 ? 0 : k_lo; k_hi = k_hi > 27 ? 27 : k_hi;
+        const unsigned rows = k_hi >= k_lo ? (((k_hi - k_lo + 1 >= 28) ? 0xFFFFFFFu : ((1u << (k_hi - k_lo + 1)) - 1u)) << k_lo) : 0u;
+        rbands[slot] = bands | (rows << 4);
     }
     return true;
 }
@@ -254,10 +259,15 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
         const int n = min(count, rec_cap);
         start = next_start;
         for (int t = 0; t < n; ++t) {
-            if (BAND && !((__builtin_amdgcn_readfirstlane(rbands[t]) >> band) & 1u)) continue;   // wave-uniform
+            unsigned rb = 0u;
+            if (BAND) {
+                rb = __builtin_amdgcn_readfirstlane(rbands[t]);
+                if (!((rb >> band) & 1u)) continue;   // wave-uniform
+            }
             const TriRec r = recs[t];   // same address on every lane: LDS broadcast
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
+                if (BAND && !((rb >> (4 + k)) & 1u)) continue;   // scalar: this pass's 8 rows are outside the record's row span
                 const int qx = TG_QX(k);
                 const float fy = (float)TG_RY(k) + 0.5f;
                 if (fy < r.ymin || fy > r.ymax) continue;

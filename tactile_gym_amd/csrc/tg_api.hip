@@ -262,8 +262,14 @@ __device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const
     else forward_kinematics<T, TOPO>(m, q, k);
     V3<T> ptcp; M3<T> Rtcp;
     link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
-    V3<T> wpos; T wrpy[3], rpyw[3];
-    world_to_work(c, mk(ptcp.x, ptcp.y, ptcp.z - work_dz), Rtcp, wpos, wrpy, rpyw);
+    V3<T> wpos; T wrpy[3] = {T(0), T(0), T(0)}, rpyw[3];
+    // The work-frame orientation of the TCP (matrix -> quaternion -> euler -> quaternion -> multiply -> euler: nine f64 transcendentals)
+    // only enters the limit check of the rotational components; a movement mode without rotational velocity (a zero stays a zero in that
+    // check) needs the position alone.  Wave-uniform.
+    if (__any(vels[3] != T(0) || vels[4] != T(0) || vels[5] != T(0)))
+        world_to_work(c, mk(ptcp.x, ptcp.y, ptcp.z - work_dz), Rtcp, wpos, wrpy, rpyw);
+    else
+        wpos = load_v3(c.work_inv_pos) + mul(c.work_Rinv, mk(ptcp.x, ptcp.y, ptcp.z - work_dz));
     const T cur[6] = {wpos.x, wpos.y, wpos.z, wrpy[0], wrpy[1], wrpy[2]};
 #pragma unroll
     for (int d = 0; d < 6; ++d) {   // check_TCP_vel_lims (base_robot_arm.py:357-380)

@@ -143,17 +143,20 @@ __device__ inline double grad_axis(const double* f, int idx, int n, int stride, 
 // (edge_follow_env.py:371-452) and the camera<-stimulus transform handed to the raster (tactile_sensor.py:150-229).
 template <typename T, int TOPO>
 __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
-                                           T edge_ang, int step_count, bool write_reward_done, const JointTrig<T, Topo<TOPO>::N>* trig = nullptr) {
+                                           T edge_ang, int step_count, bool write_reward_done, const JointTrig<T, Topo<TOPO>::N>* trig = nullptr,
+                                           bool lazy_rpy = false /* edge_follow steps: tcp_rpy is a read-back only, tg_get_state refreshes it */) {
     const int n = c.num_envs;
     Kin<T, TOPO> k;
     if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, k, trig);
     else forward_kinematics<T, TOPO>(m, q, k);
     V3<T> ptcp; M3<T> Rtcp;
     link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
-    T rpy[3];
-    { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
     st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
-    st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    if (!(lazy_rpy && c.env_kind == TG_ENV_EDGE_FOLLOW)) {
+        T rpy[3];
+        { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
+        st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    }
     T se = T(0), ce = T(1);   // stimulus yaw: edge angle for edge_follow, none for the surface
     if (c.env_kind == TG_ENV_EDGE_FOLLOW) tsincos(edge_ang, &se, &ce);
     if (write_reward_done && c.env_kind == TG_ENV_EDGE_FOLLOW) {
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
 
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
-    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig);
+    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
 }
 
 // ------------------------------------------------------------------------------------------------ reset kernel
@@ -2352,6 +2355,11 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
     if (v->q && (rc = fetch_soa(c, c->st.q, nd, v->q))) return rc;
     if (v->qd && (rc = fetch_soa(c, c->st.qd, nd, v->qd))) return rc;
     if (v->qd_target && (rc = fetch_soa(c, c->st.qd_target, nd, v->qd_target))) return rc;
+    if (v->tcp_rpy && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {   // the step kernel leaves this read-back to be recomputed on demand
+#define CALL(T, TOPO) launch_refresh_t<T, TOPO>(c)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    }
     if (v->tcp_pos && (rc = fetch_soa(c, c->st.tcp_pos, 3, v->tcp_pos))) return rc;
     if (v->tcp_rpy && (rc = fetch_soa(c, c->st.tcp_rpy, 3, v->tcp_rpy))) return rc;
     if (v->edge_ang && (rc = fetch_soa(c, c->st.edge_ang, 1, v->edge_ang))) return rc;

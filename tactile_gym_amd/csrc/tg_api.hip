@@ -68,6 +68,8 @@ struct State {   // device pointers, SoA [field][num_envs]
     float *stim_xform, *term_xform, *reward;   // term_xform: camera<-stimulus transform of the terminal observation (fused reset)
     int32_t *step_count, *reset_ticks;
     int32_t* licence;               // [n] env steps for which the analytic fixed point stays licensed without a new full solve (k_step)
+    double* trig_sc;                // [16][n] sin / cos of the joint angles at the end of the last k_step (valid while the licence holds)
+    double* edge_sc;                // [2][n] sin / cos of the episode's edge angle
     uint64_t* rng;
     uint8_t* done;
     // surface_follow
@@ -157,8 +159,11 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
         st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
     }
-    T se = T(0), ce = T(1);   // stimulus yaw: edge angle for edge_follow, none for the surface
-    if (c.env_kind == TG_ENV_EDGE_FOLLOW) tsincos(edge_ang, &se, &ce);
+    T se = T(0), ce = T(1);   // stimulus yaw: edge angle for edge_follow (sin / cos cached by the reset), none for the surface
+    if (c.env_kind == TG_ENV_EDGE_FOLLOW) {
+        if (lazy_rpy) { se = (T)st.edge_sc[0 * n + env]; ce = (T)st.edge_sc[1 * n + env]; }
+        else { tsincos(edge_ang, &se, &ce); st.edge_sc[0 * n + env] = (double)se; st.edge_sc[1 * n + env] = (double)ce; }
+    }
     if (write_reward_done && c.env_kind == TG_ENV_EDGE_FOLLOW) {
         const T gx = c.stim_pos[0] + c.edge_len * ce, gy = c.stim_pos[1] + c.edge_len * se;
         const T dx = ptcp.x - gx, dy = ptcp.y - gy;
@@ -348,8 +353,14 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     scale_actions<T>(c, enc, vels);
     const int step_count = st.step_count[env] + 1;
     st.step_count[env] = step_count;
-    JointTrig<T, N> trig;             // sin/cos of the joint angles: exact here, advanced by angle addition through the ticks
-    trig_init<T, N>(q, trig);
+    JointTrig<T, N> trig;             // sin/cos of the joint angles, advanced by angle addition through the ticks.  While the licence
+    const int lic = st.licence[env];  // below holds they are carried over from the last step (q has not changed in between: a reset or
+    if (__all(lic > 0)) {             // tg_set_joint_state drops the licence), i.e. they are evaluated exactly once per 8 steps
+#pragma unroll
+        for (int i = 0; i < N; ++i) { trig.s[i] = (T)st.trig_sc[i * n + env]; trig.c[i] = (T)st.trig_sc[(8 + i) * n + env]; }
+    } else {
+        trig_init<T, N>(q, trig);
+    }
     T qd_des[N];
     tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, &trig);
 #pragma unroll
@@ -361,7 +372,6 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     // Licence for sim_tick's analytic fixed point.  A full solve that converged to the last bit within 80 % of the sweep budget arms it
     // for the remaining ticks of this step and for the next 7 steps (<= 0.8 s, < 0.1 rad of joint motion: the Gauss-Seidel contraction
     // is a smooth function of the configuration and the margin is a factor > 2 in sweeps); a reset drops it.  Wave-uniform.
-    const int lic = st.licence[env];
     int verified = __all(lic > 0) ? 24 : 0;
     bool ran_full = false;
     for (int t = 0; t < c.action_repeat; ++t) {
@@ -402,6 +412,8 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
 
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = (double)trig.s[i]; st.trig_sc[(8 + i) * n + env] = (double)trig.c[i]; }
     finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
 }
 
@@ -2042,6 +2054,8 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&s.edge_ang, n * 8)); TG_HIP(hipMalloc(&s.embed, n * 8));
     TG_HIP(hipMalloc(&s.stim_xform, 12 * n * 4)); TG_HIP(hipMalloc(&s.term_xform, 12 * n * 4));
     TG_HIP(hipMalloc(&s.step_count, n * 4)); TG_HIP(hipMalloc(&s.reset_ticks, n * 4)); TG_HIP(hipMalloc(&s.licence, n * 4));
+    TG_HIP(hipMalloc(&s.trig_sc, (size_t)16 * n * 8)); TG_HIP(hipMalloc(&s.edge_sc, (size_t)2 * n * 8));
+    TG_HIP(hipMemset(s.trig_sc, 0, (size_t)16 * n * 8)); TG_HIP(hipMemset(s.edge_sc, 0, (size_t)2 * n * 8));
     TG_HIP(hipMalloc(&s.rng, n * 8));
     TG_HIP(hipMemset(s.q, 0, nd * 8)); TG_HIP(hipMemset(s.qd, 0, nd * 8)); TG_HIP(hipMemset(s.qd_target, 0, nd * 8));
     TG_HIP(hipMemset(s.tcp_pos, 0, 3 * n * 8)); TG_HIP(hipMemset(s.tcp_rpy, 0, 3 * n * 8));
@@ -2176,7 +2190,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -2414,6 +2428,7 @@ int tg_set_joint_state(tg_ctx* c, const double* q, const double* qd) {
         for (int f = 0; f < nd; ++f) { a[(size_t)f * n + i] = q[(size_t)i * nd + f]; b[(size_t)f * n + i] = qd[(size_t)i * nd + f]; }
     TG_HIP(hipMemcpyAsync(c->st.q, a.data(), a.size() * 8, hipMemcpyHostToDevice, c->stream));
     TG_HIP(hipMemcpyAsync(c->st.qd, b.data(), b.size() * 8, hipMemcpyHostToDevice, c->stream));
+    TG_HIP(hipMemsetAsync(c->st.licence, 0, (size_t)n * 4, c->stream));   // new configuration: full solve and exact sines / cosines next
 #define CALL(T, TOPO) launch_refresh_t<T, TOPO>(c)
     TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL

@@ -215,10 +215,9 @@ def main():
         rst_ms, rst_n = prof["reset"]
         k_step = step_ms / max(step_n, 1)                      # ms per launch
         k_render_main = rend_ms / max(rend_n, 1)
-        # the render kernel actually launched (csrc/tg_raster.hip: launch_render): small shared meshes on an under-filled chip take the
-        # two-pass small-mesh kernel, everything else k_render_tactile<128,128>
-        small = (args.env in ("edge_follow-v0", "object_balance-v0", "object_push-v0") and args.image_size % 128 == 0
-                 and n * (args.image_size // 128) ** 2 <= 2048)
+        # the render kernel actually launched (csrc/tg_raster.hip: launch_render): small shared meshes (edge, pole, cube) take the
+        # two-pass small-mesh kernel, the heightfield and the marble k_render_tactile<128,128>
+        small = args.env in ("edge_follow-v0", "object_balance-v0", "object_push-v0") and args.image_size % 128 == 0
         render_name = "k_render_small<128,64,2>" if small else "k_render_tactile"
         dominant = "k_step" if step_ms >= rend_ms else render_name
         dom_ms = k_step if dominant == "k_step" else k_render_main

@@ -31,7 +31,6 @@ struct Stimulus {
     const float* zoff;        // [n_envs]
     int rows, cols;
     float scale;
-    int no_quad_reject;       // 1: skip the per-quad edge-function reject (stimuli whose few triangles fill the view: it rarely rejects there)
 };
 
 RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border, const float* nodef_dep_host);

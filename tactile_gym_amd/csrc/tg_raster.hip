@@ -97,7 +97,7 @@ __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const fl
 // negligible; 64 x 64 for 64x64 images).
 // BAND (heightfield stimuli: hundreds of small triangles per tile): wavefront w owns the w-th 32-pixel column band of the tile (8 quad
 // columns x 8 rows per pass) instead of two full rows, and skips - as one scalar branch - every record whose bounding box misses the band.
-template <int TW, int TH, bool BAND, bool QREJ, bool BLK = false>
+template <int TW, int TH, bool BAND>
 __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
@@ -138,16 +138,14 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
 
     // Lane -> pixel mapping.  Default: a pass of the workgroup covers RPP full tile rows (a wavefront: a 128 x 2 strip).  BAND (heightfield):
     // wavefront w owns the w-th 32-pixel column band (8 quad columns x 8 rows per pass) and skips records whose bounding box misses it.
-    // BLK (meshes of a few large triangles): the band is visited as 16 x 16 pixel blocks (pass kk = block (kk & 1, kk >> 1)), so that a pass
-    // which misses a record is skipped by the whole wavefront; for many small triangles the per-pass x test this costs outweighs it
-    // (measured: pole plate 0.45 -> 0.43 ms, heightfield 0.15 -> 0.23 ms, marble 0.80 -> 1.50 ms), hence a launch-time choice.
-    static_assert(!BAND || (TW == 128 && RPP == 8 && !BLK), "banded record skip: 4 wavefronts x 32-pixel bands");
-    static_assert(!BLK || (TW == 128 && kThreads == 256 && NK % 2 == 0), "16 x 16 blocks");
+    // (Meshes of a few large triangles go to k_render_small and its 16 x 16 pass blocks; for many small triangles the per-pass x test
+    // that mapping needs costs more than it saves: heightfield 0.15 -> 0.23 ms, marble 0.80 -> 1.50 ms.)
+    static_assert(!BAND || (TW == 128 && RPP == 8), "banded record skip: 4 wavefronts x 32-pixel bands");
     const int band = __builtin_amdgcn_readfirstlane(tid / 64);
-    const int qx0 = BLK ? tile_x + 32 * band + 4 * (tid % 4) : (BAND ? tile_x + 32 * band + 4 * (tid % 8) : tile_x + 4 * (tid % QPR));
-    const int ry0 = BLK ? tile_y + ((tid % 64) / 4) : (BAND ? tile_y + ((tid % 64) / 8) : tile_y + (tid / QPR));
-#define TG_QX(kk) (BLK ? qx0 + 16 * ((kk) & 1) : qx0)
-#define TG_RY(kk) (BLK ? ry0 + 16 * ((kk) >> 1) : ry0 + RPP * (kk))
+    const int qx0 = BAND ? tile_x + 32 * band + 4 * (tid % 8) : tile_x + 4 * (tid % QPR);
+    const int ry0 = BAND ? tile_y + ((tid % 64) / 8) : tile_y + (tid / QPR);
+#define TG_QX(kk) (qx0)
+#define TG_RY(kk) (ry0 + RPP * (kk))
     float z[NK][4];
     unsigned touched = 0;      // bit k: some triangle lowered a depth of row k of this lane's quad column
     {
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
                 if ((float)qx + 3.5f < r.xmin || (float)qx + 0.5f > r.xmax) continue;
                 if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
                 const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
-                if (QREJ) {   // conservative reject of the 4-pixel quad (compiled out for stimuli whose few triangles fill the view): e_i is affine in fx (slope y_j - y_k along a row), so its value at the quad
+                {   // conservative reject of the 4-pixel quad: e_i is affine in fx (slope y_j - y_k along a row), so its value at the quad
                     // centre plus 1.5 |slope| plus a bound on the float rounding of the per-pixel expression bounds it over the quad.  e0 + e1 + e2
                     // is the same at every pixel (twice the signed area): when its sign is certain, a covered pixel needs all three e_i on
                     // that side, so one edge function provably on the other side rejects the quad.  Skipping changes no pixel.
@@ -545,30 +543,24 @@ void launch_render(const RasterParams& P, const Stimulus& S, const float* xform,
     const size_t lds = (size_t)rec_cap * sizeof(TriRec) + (S.kind == 1 ? (size_t)S.rows * S.cols * (2 * sizeof(float) + 1) + (size_t)S.n_tris * sizeof(unsigned short) + 16
                                                                        + (size_t)rec_cap * sizeof(unsigned) + 8 : 0);
     if (P.W % 128 == 0 && P.H % 128 == 0) {
-        // small shared mesh and a launch that leaves the chip under-filled (< 2 rounds of 128 x 128 workgroups at 2 per CU): 128 x 64 tiles
-        if (S.kind == 0 && S.n_tris <= 256 && (long)n_envs * (P.W / 128) * (P.H / 128) <= 2048) {
+        if (S.kind == 0 && S.n_tris <= 256 && rec_cap >= 2 * S.n_tris) {
+            // a small shared mesh (edge, cube, pole): every triangle fits the record buffer in one round -> the two-pass kernel with
+            // 16 x 16 pass blocks on 128 x 64 tiles, whatever the launch size (16 384 envs: 0.75 -> 0.42 ms against 128 x 128 tiles)
             dim3 grid((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
-            if (rec_cap >= 2 * S.n_tris)   // single round guaranteed: the two-pass small-mesh kernel (57.3 -> 55.1 us for the edge)
-                hipLaunchKernelGGL((k_render_small<128, 64, 2>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
-                                   nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
-            else
-            hipLaunchKernelGGL((k_render_tactile<128, 64, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+            hipLaunchKernelGGL((k_render_small<128, 64, 2>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
         } else {
             dim3 grid((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
             if (S.kind == 1)
-                hipLaunchKernelGGL((k_render_tactile<128, 128, true, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
-                                   nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
-            else if (S.no_quad_reject)
-                hipLaunchKernelGGL((k_render_tactile<128, 128, false, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                hipLaunchKernelGGL((k_render_tactile<128, 128, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
             else
-                hipLaunchKernelGGL((k_render_tactile<128, 128, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                hipLaunchKernelGGL((k_render_tactile<128, 128, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
         }
     } else {  // 64x64 images
         dim3 grid((P.W / 64) * (P.H / 64), n_envs, term_xform ? 2 : 1);
-        hipLaunchKernelGGL((k_render_tactile<64, 64, false, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+        hipLaunchKernelGGL((k_render_tactile<64, 64, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                            nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
     }
 }

@@ -156,27 +156,54 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
         }
     }
     const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + TW), ty1 = (float)(tile_y + TH);
+    int win_i0 = 0, win_i1 = -1, win_j0 = 0, win_j1 = -1;   // heightfield: window of grid vertices that can reach the image
     if (S.kind == 1) {   // stage the env's vertices in LDS once (one coalesced 32 KB read instead of three dependent global loads per
                          // triangle): the height, same expression as a direct fetch, (float)h - zoff, and the projected depth of the
                          // vertex and its window position (depth -1 when it is behind the near plane), which lets the triangle loop apply emit()'s
                          // depth and tile culls to the 7 938 triangles with a handful of LDS reads, before any transform or clipping
         // (the height samples are fetched in batches of 8 per lane before any of them is used: issued one per iteration each paid its own
         // HBM / L2 round trip - 8.6 us of a 43 us workgroup)
-        const int nv = S.rows * S.cols;
+        // Only a window of the grid can reach the image.  Everything emit() keeps lies inside the view frustum in front of the near plane
+        // and closer than w_cull, the eye depth at which the depth value reaches zcull (beyond it min d_k - slack >= zcull culls the
+        // triangle); that truncated pyramid is convex, so its xy bounding box in the heightfield frame - through its apex and the four far
+        // corners - contains the xy of every visible point, and a grid triangle (one cell across) that touches it has all its vertices within
+        // one cell of the box.  The window is the box widened by two cells; the rest of the 4 096 vertices / 7 938 triangles is never touched
+        // (a DIGIT sees about 6 x 6 cells).  Conservative, hence exact.
+        {
+            const float w_cull = 1.01f * (P.C1 / ((P.zcull + 2.0f * kDepthSlack) - P.C0));   // d = C0 + C1 / w, C1 < 0
+            const float ex = w_cull * (P.hw / P.kx), ey = w_cull * (P.hh / P.ky);
+            float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+#pragma unroll
+            for (int cnr = 0; cnr < 5; ++cnr) {
+                const float pcx = cnr == 0 ? 0.0f : ((cnr & 1) ? ex : -ex), pcy = cnr == 0 ? 0.0f : ((cnr & 2) ? ey : -ey);
+                const float pcz = cnr == 0 ? 0.0f : -w_cull;
+                const float qx_ = pcx - M[9], qy_ = pcy - M[10], qz_ = pcz - M[11];              // object = R^T (camera - t)
+                const float ox_ = (M[0] * qx_ + M[3] * qy_) + M[6] * qz_, oy_ = (M[1] * qx_ + M[4] * qy_) + M[7] * qz_;
+                xlo = fminf(xlo, ox_); xhi = fmaxf(xhi, ox_); ylo = fminf(ylo, oy_); yhi = fmaxf(yhi, oy_);
+            }
+            const float inv = 1.0f / S.scale;
+            int i0 = (int)floorf(xlo * inv + hf_cx) - 2, i1 = (int)ceilf(xhi * inv + hf_cx) + 2;
+            int j0 = (int)floorf(ylo * inv + hf_cy) - 2, j1 = (int)ceilf(yhi * inv + hf_cy) + 2;
+            if (!(xlo <= xhi)) { i0 = 0; i1 = S.rows - 1; j0 = 0; j1 = S.cols - 1; }           // NaN in the transform: take everything
+            win_i0 = max(i0, 0); win_i1 = min(i1, S.rows - 1); win_j0 = max(j0, 0); win_j1 = min(j1, S.cols - 1);
+        }
+        const int wi = win_i1 - win_i0 + 1, wj = win_j1 - win_j0 + 1;
+        const int nv = (wi > 0 && wj > 0) ? wi * wj : 0;
+        // (the height samples are fetched in batches of 8 per lane before any of them is used)
         for (int base = 0; base < nv; base += 8 * kThreads) {
             double hh[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = base + u * kThreads + tid;
-                hh[u] = i < nv ? hf[i] : 0.0;
+                const int w = base + u * kThreads + tid;
+                hh[u] = w < nv ? hf[(win_j0 + w / wi) * S.rows + (win_i0 + w % wi)] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = base + u * kThreads + tid;
-                if (i >= nv) continue;
+                const int w = base + u * kThreads + tid;
+                if (w >= nv) continue;
+                const int vi = win_i0 + w % wi, vj = win_j0 + w / wi, i = vj * S.rows + vi;
                 const float vz = (float)hh[u] - hf_zoff;
                 hfl[i] = vz;
-                const int vi = i % S.rows, vj = i / S.rows;
                 const float vx = ((float)vi - hf_cx) * S.scale, vy = ((float)vj - hf_cy) * S.scale;
                 const float cx = ((M[0] * vx + M[1] * vy) + M[2] * vz) + M[9];
                 const float cy = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
@@ -198,9 +225,11 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
         if (tid == 0) n_surv = 0;
         __syncthreads();
         // one lane per grid cell: its two triangles share the four corner vertices (half as many LDS reads as one lane per triangle)
-        const int n_cells = n_tris >> 1;
-        for (int cell = tid; cell < n_cells; cell += kThreads) {
-            const int ci = cell % (S.rows - 1), cj = cell / (S.rows - 1);
+        const int wci = win_i1 - win_i0, wcj = win_j1 - win_j0;              // cells of the window
+        const int n_cells = (wci > 0 && wcj > 0) ? wci * wcj : 0;
+        for (int wc = tid; wc < n_cells; wc += kThreads) {
+            const int ci = win_i0 + wc % wci, cj = win_j0 + wc / wci;
+            const int cell = cj * (S.rows - 1) + ci;
             const int v00 = cj * S.rows + ci, v10 = v00 + 1, v01 = v00 + S.rows, v11 = v01 + 1;   // (i,j) (i+1,j) (i,j+1) (i+1,j+1)
             const float d00 = hvd[v00], d10 = hvd[v10], d01 = hvd[v01], d11 = hvd[v11];
             const unsigned c00 = hcode[v00], c10 = hcode[v10], c01 = hcode[v01], c11 = hcode[v11];

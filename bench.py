@@ -8,6 +8,10 @@ A "step" is one VecEnv.step() of the whole batch: controller + 24 sim ticks + ta
 actions ~ U(-0.25, 0.25) generated on the device (synthetic), auto-reset on (episodes of 200 steps, so resets fall
 inside the timed region whenever K + W crosses a multiple of 200; reported separately via `resets_in_timed_region`).
 Observations stay resident in HBM (device tensors); the PCIe-inclusive rate is quoted in DESIGN.md, never here.
+The rollout is device resident: steps are enqueued on a torch stream (TorchShard(pipelined=True)) and their outputs consumed on it,
+the host does not wait per step (--sync-steps restores the blocking VecEnv.step_wait path; both rates are in profiles/).
+Extra fields: roofline (dominant kernel, HIP-event durations, PMC traffic), cpu_baseline (the CPU oracle on all host cores),
+literal_solver (the same workload with exactly 150 PGS sweeps in every tick), without_full_batch_reset.
 Weak scaling: every rank owns --num-envs envs; rank 0 receives all observations / rewards / dones by one packed RCCL gather
 per step, started asynchronously so that it overlaps the next step's simulation; the last gather is waited for inside
 the timed region.  Prints ONE JSON line on rank 0.

@@ -1,0 +1,19 @@
+"""Rate of the host-buffer path: VecEnv.step() with numpy actions in and numpy observations / rewards / dones out (PCIe both ways)."""
+import sys, os, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, tactile_gym_amd as tg
+from bench import MODES
+n = 1024
+v = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=MODES, seed=1, auto_reset=True)
+v.reset()
+rng = np.random.default_rng(0)
+acts = rng.uniform(-0.25, 0.25, size=(64, n, 2)).astype(np.float32)
+for k in range(10):
+    v.step(acts[k])
+t = time.perf_counter()
+K = 100
+for k in range(K):
+    obs, rew, done, info = v.step(acts[k % 64])
+dt = time.perf_counter() - t
+print(f"host-buffer path: {n * K / dt:.0f} env-steps/s, {1e3 * dt / K:.3f} ms/step, obs {obs['tactile'].shape} {obs['tactile'].dtype}")
+v.close()

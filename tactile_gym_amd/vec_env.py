@@ -196,7 +196,16 @@ class TactileVecEnv:
         return self._views["packed"]
 
     def tactile_numpy(self, terminal=False):
-        buf = self._obs_host if not terminal else np.zeros_like(self._obs_host)
+        """Host copy of the observation batch.  The device -> host copy lands directly in one of four rotating host buffers, which is
+        what step() hands out (a 16.8 MB `.copy()` per step cost more than the PCIe transfer): an observation array stays untouched for
+        the next three steps - consumers that keep observations longer (replay buffers do their own copy) must copy."""
+        if terminal:
+            buf = np.zeros_like(self._obs_host)
+        else:
+            self._obs_ring_i = (getattr(self, "_obs_ring_i", -1) + 1) % 4
+            if not hasattr(self, "_obs_ring"):
+                self._obs_ring = [self._obs_host] + [np.zeros_like(self._obs_host) for _ in range(3)]
+            buf = self._obs_ring[self._obs_ring_i]
         capi.check(self._L.tg_copy_obs_tactile(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint8)), int(terminal)))
         return buf
 
@@ -205,7 +214,7 @@ class TactileVecEnv:
         if "oracle" in self.observation_mode:
             obs["oracle"] = self.oracle_obs()
         if "tactile" in self.observation_mode:
-            obs["tactile"] = self.tactile_torch() if self.obs_mode == "torch" else self.tactile_numpy().copy()
+            obs["tactile"] = self.tactile_torch() if self.obs_mode == "torch" else self.tactile_numpy()
         if "feature" in self.observation_mode:
             obs["extended_feature"] = self.feature_torch() if self.obs_mode == "torch" else self.feature_numpy()
         return obs

@@ -8,9 +8,10 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../lib
 mkdir -p "$OUT"
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value"
-$HIPCC $COMMON -ffp-contract=off -c tg_raster.hip -o "$OUT/tg_raster.o" &
-$HIPCC $COMMON -ffp-contract=off -c tg_noise.hip -o "$OUT/tg_noise.o" &
-$HIPCC $COMMON -c tg_api.hip -o "$OUT/tg_api.o" &
-wait
+rm -f "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o"
+$HIPCC $COMMON -ffp-contract=off -c tg_raster.hip -o "$OUT/tg_raster.o" & p1=$!
+$HIPCC $COMMON -ffp-contract=off -c tg_noise.hip -o "$OUT/tg_noise.o" & p2=$!
+$HIPCC $COMMON -c tg_api.hip -o "$OUT/tg_api.o" & p3=$!
+wait $p1; wait $p2; wait $p3    # each wait returns its job's status: a failed translation unit fails the build (set -e)
 $HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" -o "$OUT/libtactile_gym_hip.so"
 echo "built $OUT/libtactile_gym_hip.so"

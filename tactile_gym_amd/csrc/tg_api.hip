@@ -824,9 +824,11 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
             if (stop) break;
         }
     } else {
+        JointTrig<T, N> trig;              // sines / cosines of the joint angles, advanced by angle addition through the analytic ticks
+        trig_init<T, N>(q, trig);
         for (int t = 0; t < c.action_repeat; ++t)
             sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body,
-                                                   pivot_b, fext, pext, pending && t == 0, &verified);
+                                                   pivot_b, fext, pext, pending && t == 0, &verified, &trig);
     }
     st.ext_pending[env] = 0;
 #pragma unroll

@@ -654,7 +654,8 @@ template <typename T, int TOPO, int MOTOR>
 __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                               const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                               int iters, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b,
-                                              V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int* verified = nullptr) {
+                                              V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int* verified = nullptr,
+                                              JointTrig<T, Topo<TOPO>::N>* trig = nullptr /* carried sines / cosines (k_step_body) */) {
     constexpr int N = Topo<TOPO>::N;
     constexpr int NR = N + 3;
     // Analytic fixed point (see sim_tick).  The motor rows still prescribe the whole arm velocity, whatever the P2P rows pull: at the
@@ -672,7 +673,8 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
             v2 += qd[i] * qd[i];
         }
         Kin<T, TOPO> kin;
-        forward_kinematics<T, TOPO>(m, q, kin);
+        if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, kin, trig);
+        else forward_kinematics<T, TOPO>(m, q, kin);
         const S3<T> Iw = rotate(b.R, bc.inertia), Iwi = inverse(Iw);
         V3<T> xc = b.pos + mul(b.R, bc.com);
         V3<T> F = bc.mass * gravity, Nt = mk<T>(0, 0, 0);
@@ -709,8 +711,10 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
         const T lam_star = m.diag_sqrt_max * dvw +     // per-joint form of the energy bound, see sim_tick
                            dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3) * tsqrt_fast(v2) + T(6) * lpn;
         if (__all(T(4) * lam_star < max_force * dt && T(8) * lpn < bc.max_impulse)) {
+            T dq[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) { qd[i] = des[i]; q[i] += dt * des[i]; }
+            for (int i = 0; i < N; ++i) { qd[i] = des[i]; dq[i] = dt * des[i]; q[i] += dq[i]; }
+            if (trig != nullptr) trig_advance<T, N>(q, dq, *trig);
             b.v = vb - im * lp;
             b.w = wb - mul(Iwi, cross(rb, lp));
             xc = xc + dt * b.v;
@@ -878,6 +882,7 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
         q[i] += dt * qd[i];
     }
     if (verified != nullptr) *verified = (iters > 0 && conv_sweeps > 0 && 5 * conv_sweeps <= 4 * iters) ? 24 : 0;
+    if (trig != nullptr) trig_init<T, N>(q, *trig);   // a full tick re-anchors the carried sines / cosines exactly
     const V3<T> lp = mk(lam[N], lam[N + 1], lam[N + 2]);
     b.v = vb - (T(1) / bc.mass) * lp;
     b.w = wb - mul(Iwi, cross(rb, lp));

@@ -31,6 +31,7 @@ struct Stimulus {
     const float* zoff;        // [n_envs]
     int rows, cols;
     float scale;
+    int win_side;             // heightfield: largest side (in vertices) the frustum window can have (set by launch_render): sizes the LDS staging
 };
 
 RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border, const float* nodef_dep_host);

@@ -19,6 +19,7 @@
 //     store instruction, fully coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
 
 #include "tg_raster.h"
 
@@ -34,6 +35,9 @@ struct TriRec {      // projected triangle, window coordinates + depth
 // by more than kDepthSlack can therefore never pass `d < z` there.  Skipping it does not change the image.
 constexpr float kDepthSlack = 2e-6f;
 
+#ifndef TG_HF_WAVES
+#define TG_HF_WAVES 3   // 3 wavefronts per SIMD for the 128 x 64 heightfield kernel (167 VGPRs, 64 B of scratch): 0.098 -> 0.078 ms; needs its windowed LDS (< 53 KB)
+#endif
 constexpr int kThreads = 256;
 constexpr int kBatch = 1024;         // most triangle records staged in LDS per pass (56 KB); a small mesh allocates 2 * n_tris records only, so
                                      // that the 12-triangle edge does not hold the occupancy at 2 workgroups per CU (LDS-bound)
@@ -98,7 +102,7 @@ __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const fl
 // BAND (heightfield stimuli: hundreds of small triangles per tile): wavefront w owns the w-th 32-pixel column band of the tile (8 quad
 // columns x 8 rows per pass) instead of two full rows, and skips - as one scalar branch - every record whose bounding box misses the band.
 template <int TW, int TH, bool BAND>
-__global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
+__global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
                                                              const uint8_t* __restrict__ border, uint8_t* __restrict__ out,
@@ -110,11 +114,12 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
     constexpr int RPP = kThreads / QPR;    // tile rows covered per pass of the workgroup
     constexpr int NK = TH / RPP;           // rows owned by each lane
     extern __shared__ TriRec recs[];                       // rec_cap records, then (heightfield stimulus) per vertex: height, projected
-    float* hfl = reinterpret_cast<float*>(recs + rec_cap); // depth (-1: behind the near plane), tile outcode; then the survivor list
-    float* hvd = hfl + (S.kind == 1 ? S.rows * S.cols : 0);
-    unsigned short* surv = reinterpret_cast<unsigned short*>(hvd + (S.kind == 1 ? S.rows * S.cols : 0));
-    uint8_t* hcode = reinterpret_cast<uint8_t*>(surv + (S.kind == 1 ? S.n_tris : 0));
-    unsigned* rbands = reinterpret_cast<unsigned*>(hcode + (((S.kind == 1 ? S.rows * S.cols : 0) + 3) & ~3));   // BAND: rec_cap words
+    float* hfl = reinterpret_cast<float*>(recs + rec_cap); // depth (-1: behind the near plane), tile outcode; then the survivor list.
+    const int wcap = S.kind == 1 ? ((S.win_side * S.win_side + 3) & ~3) : 0;   // All of it indexed within the frustum window (<= win_side^2)
+    float* hvd = hfl + wcap;
+    unsigned short* surv = reinterpret_cast<unsigned short*>(hvd + wcap);      // 2 triangles per window cell
+    uint8_t* hcode = reinterpret_cast<uint8_t*>(surv + 2 * wcap);
+    unsigned* rbands = reinterpret_cast<unsigned*>(hcode + wcap);              // BAND: rec_cap words
     __shared__ int count, next_start, n_surv;
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
@@ -186,6 +191,9 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
             int j0 = (int)floorf(ylo * inv + hf_cy) - 2, j1 = (int)ceilf(yhi * inv + hf_cy) + 2;
             if (!(xlo <= xhi)) { i0 = 0; i1 = S.rows - 1; j0 = 0; j1 = S.cols - 1; }           // NaN in the transform: take everything
             win_i0 = max(i0, 0); win_i1 = min(i1, S.rows - 1); win_j0 = max(j0, 0); win_j1 = min(j1, S.cols - 1);
+            // win_side (host) bounds the window for every camera orientation: the pyramid fits the sphere of radius |far corner| about its
+            // apex.  The clamp below can therefore not cut anything; it only keeps a wrong bound from overrunning the LDS arrays.
+            win_i1 = min(win_i1, win_i0 + S.win_side - 1); win_j1 = min(win_j1, win_j0 + S.win_side - 1);
         }
         const int wi = win_i1 - win_i0 + 1, wj = win_j1 - win_j0 + 1;
         const int nv = (wi > 0 && wj > 0) ? wi * wj : 0;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
             for (int u = 0; u < 4; ++u) {
                 const int w = base + u * kThreads + tid;
                 if (w >= nv) continue;
-                const int vi = win_i0 + w % wi, vj = win_j0 + w / wi, i = vj * S.rows + vi;
+                const int vi = win_i0 + w % wi, vj = win_j0 + w / wi, i = w;   // window-local vertex index
                 const float vz = (float)hh[u] - hf_zoff;
                 hfl[i] = vz;
                 const float vx = ((float)vi - hf_cx) * S.scale, vy = ((float)vj - hf_cy) * S.scale;
@@ -228,9 +236,8 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
         const int wci = win_i1 - win_i0, wcj = win_j1 - win_j0;              // cells of the window
         const int n_cells = (wci > 0 && wcj > 0) ? wci * wcj : 0;
         for (int wc = tid; wc < n_cells; wc += kThreads) {
-            const int ci = win_i0 + wc % wci, cj = win_j0 + wc / wci;
-            const int cell = cj * (S.rows - 1) + ci;
-            const int v00 = cj * S.rows + ci, v10 = v00 + 1, v01 = v00 + S.rows, v11 = v01 + 1;   // (i,j) (i+1,j) (i,j+1) (i+1,j+1)
+            const int cell = wc;                                                                    // window-local cell index
+            const int v00 = (wc / wci) * (wci + 1) + wc % wci, v10 = v00 + 1, v01 = v00 + (wci + 1), v11 = v01 + 1;   // (i,j) (i+1,j) (i,j+1) (i+1,j+1)
             const float d00 = hvd[v00], d10 = hvd[v10], d01 = hvd[v01], d11 = hvd[v11];
             const unsigned c00 = hcode[v00], c10 = hcode[v10], c01 = hcode[v01], c11 = hcode[v11];
 #pragma unroll
@@ -263,15 +270,16 @@ __global__ __launch_bounds__(kThreads) void k_render_tactile(RasterParams P, Sti
             for (int k = 0; k < 3; ++k) {
                 float vx, vy, vz;
                 if (S.kind == 1) {
-                    const int cell = t >> 1, half = t & 1;
-                    const int ci = cell % (S.rows - 1), cj = cell / (S.rows - 1);
+                    const int cell = t >> 1, half = t & 1;              // window-local cell
+                    const int wci = win_i1 - win_i0;
+                    const int lci = cell % wci, lcj = cell / wci;
                     // half 0: (i,j),(i,j+1),(i+1,j)   half 1: (i+1,j),(i,j+1),(i+1,j+1)
                     const int di = half == 0 ? (k == 2) : (k != 1);
                     const int dj = half == 0 ? (k == 1) : (k != 0);
-                    const int vi = ci + di, vj = cj + dj;
+                    const int vi = win_i0 + lci + di, vj = win_j0 + lcj + dj;
                     vx = ((float)vi - hf_cx) * S.scale;
                     vy = ((float)vj - hf_cy) * S.scale;
-                    vz = hfl[vj * S.rows + vi];
+                    vz = hfl[(lcj + dj) * (wci + 1) + (lci + di)];
                 } else {
                     const float* v = S.soup + 9 * t + 3 * k;   // pre-expanded triangles: one round trip instead of index -> vertex
                     vx = v[0]; vy = v[1]; vz = v[2];
@@ -563,14 +571,26 @@ void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host) {
     for (int i = 0; i < npix; ++i) out_host[i] = (uint8_t)nodef_gray_host[i];   // the truncating cast of tactile_sensor.py:291-292
 }
 
-void launch_render(const RasterParams& P, const Stimulus& S, const float* xform, int xform_soa, int n_envs,
+void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, const float* term_xform, const uint8_t* term_mask, uint8_t* term_out, hipStream_t stream) {
+    Stimulus S = S_in;
+    S.win_side = 0;
+    if (S.kind == 1) {
+        // side of the frustum window (k_render_tactile) for any camera orientation: the truncated pyramid lies within the sphere of radius
+        // |apex - far corner| about the camera, so its xy box is at most 2 R wide; + 2 x 2 cells widening, + floor / ceil, + 1 (vertices)
+        const double w_cull = 1.01 * ((double)P.C1 / (((double)P.zcull + 2.0 * (double)kDepthSlack) - (double)P.C0));
+        const double ex = w_cull * ((double)P.hw / (double)P.kx), ey = w_cull * ((double)P.hh / (double)P.ky);
+        const double R = std::sqrt(ex * ex + ey * ey + w_cull * w_cull);
+        int side = (int)std::ceil(2.0 * R / (double)S.scale) + 8;
+        const int full = S.rows > S.cols ? S.rows : S.cols;
+        S.win_side = (side < full && side > 0) ? side : full;
+    }
     int rec_cap = 2 * S.n_tris;
     rec_cap = rec_cap > kBatch ? kBatch : (rec_cap < 2 ? 2 : rec_cap);
     if (S.kind == 1 && rec_cap > 256) rec_cap = 256;   // a dozen heightfield triangles survive the depth cull; more just take another round
-    const size_t lds = (size_t)rec_cap * sizeof(TriRec) + (S.kind == 1 ? (size_t)S.rows * S.cols * (2 * sizeof(float) + 1) + (size_t)S.n_tris * sizeof(unsigned short) + 16
-                                                                       + (size_t)rec_cap * sizeof(unsigned) + 8 : 0);
+    const size_t wcap = S.kind == 1 ? (((size_t)S.win_side * S.win_side + 3) & ~(size_t)3) : 0;
+    const size_t lds = (size_t)rec_cap * sizeof(TriRec) + (S.kind == 1 ? wcap * (2 * sizeof(float) + 2 * sizeof(unsigned short) + 1) + (size_t)rec_cap * sizeof(unsigned) + 16 : 0);
     if (P.W % 128 == 0 && P.H % 128 == 0) {
         if (S.kind == 0 && S.n_tris <= 256 && rec_cap >= 2 * S.n_tris) {
             // a small shared mesh (edge, cube, pole): every triangle fits the record buffer in one round -> the two-pass kernel with

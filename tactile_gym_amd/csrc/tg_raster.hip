@@ -8,15 +8,21 @@
 // bit-identical to the CPU oracle's scalar restatement (oracle/minibullet.c: mb_render_depth, mb_t_s_camera).
 //
 // Mapping to the hardware
-//   * one 256-thread workgroup (4 wavefronts) per (env, 128x128 image tile); a launch of 1024 envs is 1024-4096
-//     workgroups >> 256 CUs, and consecutive workgroups land on different XCDs (block b -> XCD b % 8) while the
-//     only shared data (reference images, stimulus mesh: < 200 KB) is read-only and L2-resident on every XCD;
-//   * triangle set-up (transform, near clip, project) is done once per workgroup, one lane per input triangle,
-//     and staged as compact records in LDS; the pixel phase then reads each record as an LDS broadcast;
-//   * each lane owns 4 horizontally adjacent pixels x 16 rows (64 depth values in VGPRs = the z-buffer), so
-//     a wavefront covers two full 128-pixel rows per pass: depth reduction is a register min, the reference
-//     images are read as 16-byte vectors and the uint8 image is written as 4-byte vectors, 256 B per wavefront
-//     store instruction, fully coalesced.
+//   * one 256-thread workgroup (4 wavefronts) per (env, image tile); a launch of 1024 envs is 2048-8192 workgroups >> 256 CUs, and
+//     consecutive workgroups land on different XCDs (block b -> XCD b % 8) while the only shared data (reference images, stimulus
+//     mesh: < 200 KB) is read-only and L2-resident on every XCD;
+//   * triangle set-up (transform, near clip, project) is done once per workgroup, one lane per input triangle, and staged as compact
+//     records in LDS; the pixel phase then reads each record as an LDS broadcast;
+//   * each lane owns quads of 4 horizontally adjacent pixels whose depth values stay in VGPRs (the z-buffer): depth reduction is a
+//     register min, the reference images are read as 16-byte vectors and the uint8 image is written as 4-byte vectors;
+//   * three kernels, chosen per stimulus by launch_render:
+//       k_render_small<128,64,2>   meshes of a few large triangles (edge, cube, pole): 128 x 64 tiles, the pixel phase in two passes over
+//                                  disjoint row groups (116-128 VGPRs, 4 workgroups per CU), a wavefront visits its 32-pixel column band
+//                                  as 16 x 16 pixel blocks so that passes which miss a record are skipped by the whole wavefront;
+//       k_render_tactile<128,64,true>   per-env heightfields: only the grid window the truncated view frustum can reach is staged
+//                                  (window-local LDS arrays) and culled, survivors are compacted, wavefront = 32-pixel band with per-record
+//                                  band / row-group masks (scalar skips), 3 wavefronts per SIMD;
+//       k_render_tactile<128,128,false> / <64,64,false>   everything else (the 960-triangle marble, 64 x 64 images): full-width rows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>

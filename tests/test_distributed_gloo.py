@@ -34,12 +34,31 @@ class OracleShard:
                 torch.tensor([o[1] for o in outs], dtype=torch.float32), torch.tensor([o[2] for o in outs], dtype=torch.uint8), {})
 
 
-def _worker(rank, world, port, out_path, overlap=False):
+class PackedOracleShard(OracleShard):
+    """Like the HIP shard (TorchShard.packed / tg_get_packed_outputs): the step's outputs also live in one byte block
+    [obs | pad to 16 | reward f32 | done u8], which ShardedVecEnv ships with a single copy."""
+
+    def step(self, actions):
+        obs, rew, done, info = super().step(actions)
+        nb = obs["tactile"].numel()
+        off = (nb + 15) & ~15
+        blk = torch.zeros(off + 4 * rew.numel() + done.numel(), dtype=torch.uint8)
+        blk[:nb] = obs["tactile"].reshape(-1)
+        blk[off:off + 4 * rew.numel()] = rew.view(torch.uint8)
+        blk[off + 4 * rew.numel():] = done
+        self._packed = (blk, off)
+        return obs, rew, done, info
+
+    def packed(self):
+        return self._packed
+
+
+def _worker(rank, world, port, out_path, overlap=False, packed=False):
     import torch.distributed as dist
     from tactile_gym_amd.parallel import ShardedVecEnv
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    env = ShardedVecEnv(OracleShard(rank, N_LOCAL, SEED), dist, overlap=overlap)
+    env = ShardedVecEnv((PackedOracleShard if packed else OracleShard)(rank, N_LOCAL, SEED), dist, overlap=overlap)
     assert env.num_envs == world * N_LOCAL and env.env_slice() == slice(rank * N_LOCAL, (rank + 1) * N_LOCAL)
     obs = env.reset()
     gen = torch.Generator().manual_seed(7)
@@ -63,14 +82,14 @@ def _worker(rank, world, port, out_path, overlap=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_shard_and_gather_world2(tmp_path, overlap):
+@pytest.mark.parametrize("overlap,packed", [(False, False), (True, False), (True, True)])
+def test_shard_and_gather_world2(tmp_path, overlap, packed):
     world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(world, port, out, overlap), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, overlap, packed), nprocs=world, join=True)
     got = torch.load(out)
     # single-process reference: the same 4 envs with seeds SEED..SEED+3 stepped with the same actions
     ref = OracleShard(0, world * N_LOCAL, SEED)

@@ -2167,6 +2167,7 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
                     for (int a = 0; a < 3; ++a) soup[(size_t)t * 9 + 3 * k + a] = stim->verts[3 * (size_t)stim->tris[3 * t + k] + a];
             TG_HIP(hipMalloc(&c->d_soup, soup.size() * 4 + 4)); TG_HIP(hipMemcpy(c->d_soup, soup.data(), soup.size() * 4, hipMemcpyHostToDevice));
         }
+        c->stim.skip_quad_reject = cfg->env_kind == TG_ENV_OBJECT_BALANCE ? 1 : 0;   // the plate fills the camera's view
         c->stim.kind = 0; c->stim.verts = c->d_verts; c->stim.tris = c->d_tris; c->stim.soup = c->d_soup; c->stim.n_tris = stim->n_tris;
     }
     // one allocation [tactile obs u8 | reward f32 | done u8]: what a rank ships to rank 0 per step is one contiguous byte range

@@ -31,6 +31,7 @@ struct Stimulus {
     const float* zoff;        // [n_envs]
     int rows, cols;
     float scale;
+    int skip_quad_reject;     // 1: stimuli whose few triangles fill the camera's view (the pole's plate): the per-quad reject never fires
     int win_side;             // heightfield: largest side (in vertices) the frustum window can have (set by launch_render): sizes the LDS staging
 };
 

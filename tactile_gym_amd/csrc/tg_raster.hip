@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
 // Small shared meshes (the 12-triangle edge): every triangle fits the record buffer in one round (rec_cap = 2 n_tris), so the pixel
 // phase can run in HALVES passes over disjoint row groups, each pass carrying only its own slice of the z-buffer from the reference
 // load to the store: 16 instead of 32 live depth registers, which lifts the kernel over the next occupancy step (VGPR budget).
-template <int TW, int TH, int HALVES>
+template <int TW, int TH, int HALVES, bool QREJ>
 __global__ __launch_bounds__(kThreads) void k_render_small(RasterParams P, Stimulus S, const float* __restrict__ xform, int xform_soa, int n_envs,
                                                            const uint8_t* __restrict__ mask, const float* __restrict__ nodef_dep,
                                                            const uint8_t* __restrict__ gray_u8, const uint8_t* __restrict__ border,
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kThreads) void k_render_small(RasterParams P, Stimu
                 if ((float)qx + 3.5f < r.xmin || (float)qx + 0.5f > r.xmax) continue;
                 if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
                 const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
-                {   // conservative reject of the 4-pixel quad (see k_render_tactile)
+                if (QREJ) {   // conservative reject of the 4-pixel quad (see k_render_tactile)
                     const float fc = (float)qx + 2.0f;
                     const float b0 = r.x0 - fc, b1 = r.x1 - fc, b2 = r.x2 - fc;
                     const float c0 = b1 * a0 - b2 * a1, c1 = b2 * a2 - b0 * a0, c2 = b0 * a1 - b1 * a2;
@@ -602,8 +602,12 @@ void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xfo
             // a small shared mesh (edge, cube, pole): every triangle fits the record buffer in one round -> the two-pass kernel with
             // 16 x 16 pass blocks on 128 x 64 tiles, whatever the launch size (16 384 envs: 0.75 -> 0.42 ms against 128 x 128 tiles)
             dim3 grid((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
-            hipLaunchKernelGGL((k_render_small<128, 64, 2>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
-                               nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+            if (S.skip_quad_reject)
+                hipLaunchKernelGGL((k_render_small<128, 64, 2, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                                   nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+            else
+                hipLaunchKernelGGL((k_render_small<128, 64, 2, true>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                                   nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
         } else {
             dim3 grid((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
             if (S.kind == 1) {   // heightfield: 128 x 64 tiles (the per-workgroup staging is cheap since it is windowed: 0.108 -> 0.098 ms)

@@ -63,6 +63,19 @@ RasterParams make_raster_params(int W, int H, double fov_deg, double near_, doub
     return P;
 }
 
+// a / b rounded like the IEEE division the specification (and the oracle's C `/`) prescribes, for operands whose exponents are far from the
+// ends of the range (pixel-space edge functions: 1e-12 .. 1e6): the refinement the compiler's own expansion performs - reciprocal, one
+// Newton step on it, the product and two residual corrections - without the operand pre-scaling, the denormal-mode switches and the
+// special-case fix-up that only matter beyond 2^+-96.  The result is discarded by the caller when b == 0.
+__device__ __forceinline__ float div_mid_range(float a, float b) {
+    float y = __builtin_amdgcn_rcpf(b);
+    y = __builtin_fmaf(__builtin_fmaf(-b, y, 1.0f), y, y);
+    float q = a * y;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
+    return q;
+}
+
 __device__ __forceinline__ void project_vertex(float cx, float cy, float cw, const RasterParams& P, float& sx, float& sy, float& d) {
     float iw = 1.0f / cw;
     sx = P.hw + P.kx * (cx * iw);
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
                     const bool box = (fx >= r.xmin) & (fx <= r.xmax);
                     const bool pos = (e0 >= 0.0f) & (e1 >= 0.0f) & (e2 >= 0.0f), neg = (e0 <= 0.0f) & (e1 <= 0.0f) & (e2 <= 0.0f);
                     const float s = (e0 + e1) + e2;
-                    const float d = ((e0 * r.d0 + e1 * r.d1) + e2 * r.d2) / s;
+                    const float d = div_mid_range((e0 * r.d0 + e1 * r.d1) + e2 * r.d2, s);
                     const bool hit = box & (pos | neg) & (s != 0.0f) & (d < z[k][p]);
                     z[k][p] = hit ? d : z[k][p];
                     touched |= hit ? (1u << k) : 0u;
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(kThreads) void k_render_small(RasterParams P, Stimu
                     const bool box = (fx >= r.xmin) & (fx <= r.xmax);
                     const bool pos = (e0 >= 0.0f) & (e1 >= 0.0f) & (e2 >= 0.0f), neg = (e0 <= 0.0f) & (e1 <= 0.0f) & (e2 <= 0.0f);
                     const float s = (e0 + e1) + e2;
-                    const float d = ((e0 * r.d0 + e1 * r.d1) + e2 * r.d2) / s;
+                    const float d = div_mid_range((e0 * r.d0 + e1 * r.d1) + e2 * r.d2, s);
                     const bool hit = box & (pos | neg) & (s != 0.0f) & (d < z[k][p]);
                     z[k][p] = hit ? d : z[k][p];
                     touched |= hit ? (1u << k) : 0u;

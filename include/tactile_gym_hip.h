@@ -281,6 +281,11 @@ int tg_render_tactile_heightfield(const tg_sensor* sensor, int32_t rows, int32_t
 int tg_gen_heightfield(int32_t n, const int64_t* seeds, int32_t rows, int32_t cols, double interp, double range, double* heights,
                        float* zoff);
 
+/* Self-test of the raster's depth division (tactile_sensor.py:239-294 reads an IEEE depth buffer): n pseudo-random operand pairs
+ * with exponents 2^-40 .. 2^24 divided by the kernels' refinement and by the correctly rounded `/`; *mismatches = quotients whose
+ * bits differ (must be 0). */
+int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

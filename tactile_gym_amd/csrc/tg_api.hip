@@ -2333,6 +2333,15 @@ int tg_get_packed_outputs(tg_ctx* c, void** p, int64_t* obs_bytes, int64_t* tota
     if (total_bytes) *total_bytes = (int64_t)c->packed_bytes;
     return 0;
 }
+int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches) {
+    if (!mismatches || n < 0) return fail(-1, "tg_selftest_division: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-2, "no HIP device");
+    long long m = 0;
+    if (tg::selftest_division((long long)n, (unsigned long long)seed, &m) != 0) return fail(-3, "tg_selftest_division: launch failed");
+    *mismatches = (int64_t)m;
+    return 0;
+}
 int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {
     if (!c || !p) return fail(-1, "NULL argument");
     if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL)

@@ -46,4 +46,7 @@ void launch_render(const RasterParams& P, const Stimulus& stim, const float* xfo
                    const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, const float* term_xform, const uint8_t* term_mask, uint8_t* term_out, hipStream_t stream);
 
+// div_mid_range vs `/` on n pseudo-random operand pairs (exponents 2^-40 .. 2^24): number of differing quotients
+int selftest_division(long long n, unsigned long long seed, long long* mismatches_host);
+
 }  // namespace tg

@@ -590,6 +590,31 @@ void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host) {
     for (int i = 0; i < npix; ++i) out_host[i] = (uint8_t)nodef_gray_host[i];   // the truncating cast of tactile_sensor.py:291-292
 }
 
+// tg_selftest_division: the refinement above against the compiler's correctly rounded `/` on pseudo-random operand pairs with exponents in
+// 2^-40 .. 2^24 (a superset of what a covered pixel produces); counts the pairs whose quotient bits differ.
+__global__ void k_selftest_division(long long n, unsigned long long seed, unsigned long long* mismatches) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (long long i = i0; i < n; i += stride) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        const unsigned ea = 127u - 40u + (unsigned)((z >> 46) & 0xff) % 65u, eb = 127u - 40u + (unsigned)((z >> 54) & 0xff) % 65u;
+        const float a = __uint_as_float(((unsigned)(z >> 63) << 31) | (ea << 23) | ((unsigned)z & 0x7fffffu));
+        const float b = __uint_as_float(((unsigned)((z >> 62) & 1) << 31) | (eb << 23) | ((unsigned)(z >> 23) & 0x7fffffu));
+        bad += __float_as_uint(div_mid_range(a, b)) != __float_as_uint(a / b);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+int selftest_division(long long n, unsigned long long seed, long long* mismatches_host) {
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, 8) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, 8);
+    hipLaunchKernelGGL(k_selftest_division, dim3(2048), dim3(256), 0, 0, n, seed, d);
+    const hipError_t e = hipMemcpy(mismatches_host, d, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return e == hipSuccess ? 0 : -1;
+}
+
 void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, const float* term_xform, const uint8_t* term_mask, uint8_t* term_out, hipStream_t stream) {

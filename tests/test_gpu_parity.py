@@ -1027,3 +1027,14 @@ def test_full_size_properties_roll_and_vertical():
         obs, rew, done, _ = venv.step(np.tile(np.array([[0.1, 0.0]], dtype=np.float32), (n, 1)))
     assert np.isfinite(rew).all() and (rew <= 0).all() and ((obs["tactile"].reshape(n, -1) > 0).any(axis=1).mean() > 0.9)
     venv.close()
+
+
+def test_raster_division_is_correctly_rounded():
+    """The depth interpolation divides with a reciprocal + residual corrections instead of the range-scaled expansion of `/`
+    (DESIGN 5): on 2^26 operand pairs over the pixel-space exponent range every quotient must carry the bits of the IEEE division."""
+    import ctypes
+    from tactile_gym_amd import _capi as capi
+    for seed in (1, 20240927):
+        m = ctypes.c_int64(-1)
+        capi.check(capi.lib().tg_selftest_division(1 << 26, seed, ctypes.byref(m)))
+        assert m.value == 0

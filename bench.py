@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of edge_follow-v0 (UR5 + TacTip, 128x128 tactile obs), BASELINE.json configs[1].
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 2000 --warmup 100      (the defaults: SURVEY 8d asks for 100 warm-up and >= 2000 timed steps)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one VecEnv.step() of the whole batch: controller + 24 sim ticks + tactile render for every env, random
@@ -79,8 +79,8 @@ def cpu_baseline(seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000, help="timed steps (SURVEY 8d: >= 2000)")
+    ap.add_argument("--warmup", type=int, default=100, help="untimed steps (SURVEY 8d: 100)")
     ap.add_argument("--num-envs", type=int, default=1024, help="envs per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--image-size", type=int, default=128)
     ap.add_argument("--physics", default="f64", choices=["f64", "f32"])

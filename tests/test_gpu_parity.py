@@ -1038,3 +1038,21 @@ def test_raster_division_is_correctly_rounded():
         m = ctypes.c_int64(-1)
         capi.check(capi.lib().tg_selftest_division(1 << 26, seed, ctypes.byref(m)))
         assert m.value == 0
+
+
+def test_bench_launches_under_torchrun_on_the_rccl_gather_path():
+    """The driver's multi-GPU command line with one rank: torch.distributed.run -> RCCL process group -> ShardedVecEnv's gather
+    (forced although world_size is 1) -> one JSON line.  Guards the N > 1 launch path on a 1-GPU box."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TG_BENCH_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "10", "--num-envs", "256",
+           "--no-cpu-baseline", "--no-literal"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["value"] > 0 and d["config"]["total_envs"] == 256
+    assert d["roofline"]["frac"] > 0

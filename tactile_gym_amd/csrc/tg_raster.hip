@@ -447,7 +447,10 @@ __global__ __launch_bounds__(kThreads) void k_render_small(RasterParams P, Stimu
     if (mask != nullptr && mask[env] == 0) return;
     const int n_tris = S.n_tris;
     const int tiles_x = P.W / TW;
-    const int tile_x = (blockIdx.x % tiles_x) * TW, tile_y = (blockIdx.x / tiles_x) * TH;
+    // The workgroups of one image take interleaved 16-row groups (group g of workgroup ty = rows 16 (g tiles_y + ty) ...), not contiguous
+    // halves: they then meet the stimulus about equally, instead of one drawing all of it while the other finds its tile empty.
+    const int tiles_y = P.H / TH;
+    const int tile_x = (blockIdx.x % tiles_x) * TW, ty = blockIdx.x / tiles_x;
     const int tid = threadIdx.x;
     const int pass = (term_xform != nullptr && blockIdx.z == 1) ? 0 : 1;
     if (pass == 0 && term_mask[env] == 0) return;
@@ -456,16 +459,21 @@ __global__ __launch_bounds__(kThreads) void k_render_small(RasterParams P, Stimu
     float M[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xf[(size_t)k * n_envs + env] : xf[(size_t)env * 12 + k];
-    // Lane -> pixel mapping: wavefront w owns the w-th 32-pixel column band of the tile and visits it as 16 x 16 pixel blocks (4 quad
-    // columns x 16 rows per pass, pass kk = block (kk & 1, kk >> 1) of the band).  A pass is skipped by the whole wavefront when no lane's
+    // Lane -> pixel mapping: a wavefront visits its share of the tile as 16 x 16 pixel blocks (4 quad columns x 16 rows per pass, pass kk =
+    // its (kk & 1)-th column block, (kk >> 1)-th row group).  A pass is skipped by the whole wavefront when no lane's
     // quad row meets the record, so compact blocks matter: with the earlier full-width mapping (a pass = a 128 x 2 strip) nearly every pass
     // met the stimulus somewhere and ran with most lanes idle (render 55.1 -> 43.5 us for the edge).
     static_assert(TW == 128 && TH == 64 && NK == 8, "16 x 16 blocks of a 128 x 64 tile");
-    const int qx0 = tile_x + 32 * (tid / 64) + 4 * (tid % 4);
-    const int ry0 = tile_y + ((tid % 64) / 4);
-#define TG_QX(kk) (qx0 + 16 * ((kk) & 1))
-#define TG_RY(kk) (ry0 + 16 * ((kk) >> 1))
-    const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + TW), ty1 = (float)(tile_y + TH);
+    const bool interleave = tiles_y > 2;   // two workgroups per image (128 x 128) gain nothing: contiguous halves keep the tile's record cull
+    // ... and wavefront w the 16-pixel column blocks w and w + 4 of the tile, not the adjacent pair 2w, 2w + 1: the workgroup lasts as long
+    // as its busiest wavefront, and a stimulus that covers one side of the tile now lands on all four (edge render 43.3 -> 39.7 us; dealing
+    // the blocks out diagonally as well measured slower: 43.6 us, the per-pass column no longer folds into the address).
+    const int qx0 = tile_x + 16 * (tid / 64) + 4 * (tid % 4);
+#define TG_QX(kk) (qx0 + 64 * ((kk) & 1))
+    const int ry0 = (interleave ? 16 : TH) * ty + ((tid % 64) / 4), ry_step = interleave ? 16 * tiles_y : 16;
+#define TG_RY(kk) (ry0 + ry_step * ((kk) >> 1))
+    const float tx0 = (float)tile_x, tx1 = (float)(tile_x + TW);
+    const float ty0 = interleave ? 0.0f : (float)(TH * ty), ty1 = interleave ? (float)P.H : (float)(TH * ty + TH);
     if (tid == 0) count = 0;
     __syncthreads();
     for (int t = tid; t < n_tris; t += kThreads) {

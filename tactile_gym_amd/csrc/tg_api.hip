@@ -765,11 +765,16 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
     const V3<T> ox{b.R.m[0], b.R.m[3], b.R.m[6]}, oy{b.R.m[1], b.R.m[4], b.R.m[7]}, oz{b.R.m[2], b.R.m[5], b.R.m[8]};
     const V3<T> dp = b.pos - pc;
     const V3<T> nf = mk<T>(0, 0, 0) - f;
-    float* X = st.stim_xform;
-    X[0 * n + env] = (float)dot(s, ox);  X[1 * n + env] = (float)dot(s, oy);  X[2 * n + env] = (float)dot(s, oz);
-    X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
-    X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
-    X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+    const float xv[12] = {(float)dot(s, ox),  (float)dot(s, oy),  (float)dot(s, oz),  (float)dot(u, ox), (float)dot(u, oy), (float)dot(u, oz),
+                          (float)dot(nf, ox), (float)dot(nf, oy), (float)dot(nf, oz), (float)dot(s, dp), (float)dot(u, dp), (float)dot(nf, dp)};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st.stim_xform[i * n + env] = xv[i];
+    // end of a step: a second copy that the reset of the envs that just finished leaves alone, so that the step's observations can be
+    // drawn (from this copy) while those envs are being reset on a second stream (enqueue_step)
+    if (write_reward_done) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st.term_xform[i * n + env] = xv[i];
+    }
 }
 
 template <typename T, int TOPO, bool POS>
@@ -1789,6 +1794,8 @@ struct tg_ctx {
     tg::Stimulus stim{};
     // hipGraph of one tg_step launch sequence, keyed by the device action pointer it was captured with (launch-bound inner loop:
     // 3-4 kernels per step, one graph launch instead)
+    hipStream_t aux_stream = nullptr;                // object_balance: the reset of finished envs runs here, beside the render
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipGraphExec_t step_graph = nullptr;
     const float* step_graph_actions = nullptr;
     hipStream_t step_graph_stream = nullptr;
@@ -2031,6 +2038,10 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     tg_ctx* c = new tg_ctx();
     c->cfg = *cfg; c->robot = *robot; c->H = H; c->W = W;
     TG_HIP(hipStreamCreate(&c->own_stream));
+    if (cfg->env_kind == TG_ENV_OBJECT_BALANCE) {
+        TG_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+        TG_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); TG_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
     c->stream = c->own_stream;
     const int n = cfg->num_envs;
     const size_t npix = (size_t)H * W;
@@ -2195,6 +2206,9 @@ int tg_destroy(tg_ctx* c) {
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -2252,6 +2266,27 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     if (c->cfg.auto_reset && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {
         reset_sequence(c, c->st.done); // k_reset keeps the terminal camera transform of the envs it resets
         render_fused(c);               // one launch draws the terminal and the post-reset observations
+    } else if (c->cfg.auto_reset && c->aux_stream) {
+        // object_balance: a pole falls somewhere in the batch on nearly every step, and its reset (rest pose, blocking move, settling: a
+        // serial chain of 0.14 ms on a few wavefronts) depends on k_step only.  Fork: it runs on the second stream while this one draws the
+        // step's observations from term_xform (k_step's second copy of the transforms, which the reset does not touch); join; then the
+        // masked launch saves the terminal observations and draws the post-reset ones.  Inside the captured graph this is a fork/join.
+        (void)hipEventRecord(c->ev_fork, c->stream);
+        (void)hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0);
+        {
+            hipStream_t main_stream = c->stream;
+            c->stream = c->aux_stream;
+            reset_sequence(c, c->st.done);
+            c->stream = main_stream;
+        }
+        (void)hipEventRecord(c->ev_join, c->aux_stream);
+        {
+            Timer t(c, 1);
+            launch_render(c->rp, c->stim, c->st.term_xform, 1, c->cfg.num_envs, nullptr, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_obs,
+                          nullptr, nullptr, nullptr, nullptr, c->stream);
+        }
+        (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        render(c, c->st.done, true);
     } else {
         render(c, nullptr, false);
         if (c->cfg.auto_reset) {

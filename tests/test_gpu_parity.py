@@ -392,6 +392,39 @@ def test_object_balance_env_matches_oracle(size):
     venv.close()
 
 
+def test_object_balance_autoreset_forked_reset_matches_oracle():
+    """object_balance with auto_reset: the reset of the finished envs runs on a second stream beside the render of the step's
+    observations (fork/join inside the step graph).  Two auto-resets in a row: terminal observations, post-reset
+    observations and states against oracle envs that are stepped and reset by hand."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleObjectBalanceEnv
+    n, size = 4, 128
+    venv = tg.make_vec("object_balance-v0", num_envs=n, max_steps=3, image_size=[size, size], env_modes=BAL_MODES, seed=91, auto_reset=True)
+    oracles = [OracleObjectBalanceEnv(seed=91 + i, max_steps=3, image_size=(size, size), env_modes=BAL_MODES) for i in range(n)]
+    obs = venv.reset()
+    ref = [o.reset() for o in oracles]
+    rng = np.random.default_rng(92)
+    n_resets = 0
+    for step in range(7):
+        a = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+        obs, rew, done, info = venv.step(a)
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            ro, rr, rd, _ = o.step(a[i])
+            assert rew[i] == rr and bool(done[i]) == rd, (step, i)
+            if rd:
+                n_resets += 1
+                assert int((info[i]["terminal_observation"]["tactile"] != ro["tactile"]).sum()) <= 3, (step, i)
+                ro = o.reset()
+                assert st["gravity_z"][i] == o.gravity and st["embed_dist"][i] == o.embed_dist and st["step_count"][i] == 0
+            pos, R = o.body_pose()
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8, (step, i)
+            assert np.abs(st["body_pos"][i] - pos).max() < 1e-7 and np.abs(st["body_rot"][i] - R).max() < 1e-7, (step, i)
+            assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (step, i)
+    assert n_resets >= 2 * n
+    venv.close()
+
+
 def test_mg400_tree_functions(mg400_tactip):
     """MG400 (8 control joints, two-branch tree): FK / Jacobian / inverse dynamics / inertia /
     24 sim ticks / IK against the oracle, f64."""

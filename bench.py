@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one VecEnv.step() of the whole batch: controller + 24 sim ticks + tactile render for every env, random
-actions ~ U(-0.25, 0.25) generated on the device (synthetic), auto-reset on (episodes of 200 steps, so resets fall
+actions ~ U[-0.25, 0.25) drawn on the device by tg_sample_actions (synthetic), auto-reset on (episodes of 200 steps, so resets fall
 inside the timed region whenever K + W crosses a multiple of 200; reported separately via `resets_in_timed_region`).
 Observations stay resident in HBM (device tensors); the PCIe-inclusive rate is quoted in DESIGN.md, never here.
 The rollout is device resident: steps are enqueued on a torch stream (TorchShard(pipelined=True)) and their outputs consumed on it,
@@ -127,13 +127,12 @@ def main():
     # step); --sync-steps restores the blocking VecEnv.step_wait behaviour
     shard = TorchShard(venv, pipelined=not args.sync_steps)
     env = ShardedVecEnv(shard, dist, overlap=True, force_collective=force) if dist is not None else shard   # gather of step t overlaps the simulation of step t+1
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-
     act_buf = torch.empty(n, act_dim, device="cuda", dtype=torch.float32)
+    draw = [0]
 
-    def actions():   # action_space.sample() for the whole batch: U(-0.25, 0.25), one device kernel
-        return act_buf.uniform_(-0.25, 0.25, generator=gen)
+    def actions():   # action_space.sample() for the whole batch: U[-0.25, 0.25), one device kernel on the env's stream (tg_sample_actions,
+        draw[0] += 1  # counter based: draw k of rank r depends on (1234 + r, k) only), inside the timed region like every step's policy would be
+        return venv.sample_actions(act_buf, 1234 + rank, draw[0])
 
     def barrier():
         torch.cuda.synchronize()

@@ -281,6 +281,11 @@ int tg_render_tactile_heightfield(const tg_sensor* sensor, int32_t rows, int32_t
 int tg_gen_heightfield(int32_t n, const int64_t* seeds, int32_t rows, int32_t cols, double interp, double range, double* heights,
                        float* zoff);
 
+/* action_space.sample() for the whole batch (the reference's demo loops draw env.action_space.sample() per env and step,
+ * examples/demo_rl_env_base.py:34; Box(min_action, max_action) float32, edge_follow_env.py:169-174): dev_actions [num_envs][act_dim]
+ * (device memory) receives U[min_action, max_action) draws, counter based: element i of draw `counter` is a function of
+ * (seed, counter, i) only.  Enqueued on the context's stream, so a tg_step(dev_actions, on_device = 1) that follows sees it. */
+int tg_sample_actions(tg_ctx* ctx, uint64_t seed, uint64_t counter, float* dev_actions);
 /* Self-test of the raster's depth division (tactile_sensor.py:239-294 reads an IEEE depth buffer): n pseudo-random operand pairs
  * with exponents 2^-40 .. 2^24 divided by the kernels' refinement and by the correctly rounded `/`; *mismatches = quotients whose
  * bits differ (must be 0). */

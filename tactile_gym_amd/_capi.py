@@ -123,6 +123,7 @@ SYMBOLS = {
     "tg_get_terminal_obs": (C.c_int, [_ctx, _vpp]),
     "tg_get_reward_done_dev": (C.c_int, [_ctx, _vpp, _vpp]),
     "tg_get_packed_outputs": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "tg_sample_actions": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tg_selftest_division": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
     "tg_get_obs_feature": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32), C.c_int32]),
     "tg_get_reward_done": (C.c_int, [_ctx, _fp, _u8p]),

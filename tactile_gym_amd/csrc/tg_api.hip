@@ -1972,6 +1972,15 @@ static int need_device() {
 
 
 // env.reset() for the masked envs: task randomisation, (surface generation), robot reset.
+// tg_sample_actions: element i of draw `counter`: 24 random bits of splitmix64 over (seed, counter, i) -> lo + (hi - lo) u, u in [0, 1)
+__global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, float lo, float hi, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t z = mix64(mix64(seed + kGolden * (counter + 1)) + kGolden * (uint64_t)(i + 1));
+    const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+    out[i] = lo + (hi - lo) * u;
+}
+
 static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
     Timer t(c, 2);
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
@@ -2366,6 +2375,14 @@ int tg_get_packed_outputs(tg_ctx* c, void** p, int64_t* obs_bytes, int64_t* tota
     *p = c->d_obs;
     if (obs_bytes) *obs_bytes = (int64_t)c->packed_obs_bytes;
     if (total_bytes) *total_bytes = (int64_t)c->packed_bytes;
+    return 0;
+}
+int tg_sample_actions(tg_ctx* c, uint64_t seed, uint64_t counter, float* dev_actions) {
+    if (!c || !dev_actions) return fail(-1, "tg_sample_actions: NULL argument");
+    const int total = c->cfg.num_envs * c->act_dim;
+    hipLaunchKernelGGL(k_sample_actions, dim3((total + 255) / 256), dim3(256), 0, c->stream, total, seed, counter, (float)c->cfg.min_action,
+                       (float)c->cfg.max_action, dev_actions);
+    TG_HIP(hipGetLastError());
     return 0;
 }
 int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches) {

@@ -95,6 +95,13 @@ class TactileVecEnv:
             np.copyto(self._actions, np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim))
             capi.check(self._L.tg_step(self._ctx, C.c_void_p(self._actions.ctypes.data), 0))
 
+    def sample_actions(self, out, seed, counter):
+        """action_space.sample() for the whole batch on the device (tg_sample_actions): fills the torch CUDA float32 tensor `out`
+        [N, act_dim] with U[min_action, max_action) draws that depend on (seed, counter, element) only; enqueued on the env's stream."""
+        assert out.is_cuda and out.is_contiguous() and out.element_size() == 4 and tuple(out.shape) == (self.num_envs, self.act_dim)
+        capi.check(self._L.tg_sample_actions(self._ctx, C.c_uint64(seed), C.c_uint64(counter), C.c_void_p(out.data_ptr())))
+        return out
+
     def step_wait(self):
         capi.check(self._L.tg_get_reward_done(self._ctx, self._reward.ctypes.data_as(C.POINTER(C.c_float)),
                                               self._done.ctypes.data_as(C.POINTER(C.c_uint8))))

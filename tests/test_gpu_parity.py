@@ -1089,3 +1089,27 @@ def test_bench_launches_under_torchrun_on_the_rccl_gather_path():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 60 and d["value"] > 0 and d["config"]["total_envs"] == 256
     assert d["roofline"]["frac"] > 0
+
+
+def test_sample_actions_is_a_counter_based_uniform_box_sample(edge_modes):
+    """tg_sample_actions = action_space.sample() for the batch: float32 in [min_action, max_action), a function of (seed, counter,
+    element) only, flat histogram."""
+    import torch
+    import tactile_gym_amd as tg
+    n = 4096
+    venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=10, image_size=[128, 128], env_modes=edge_modes, seed=5, obs_mode="torch")
+    a = torch.empty(n, 2, device="cuda", dtype=torch.float32)
+    b = torch.empty_like(a)
+    venv.sample_actions(a, 7, 1); venv.sample_actions(b, 7, 1); venv.sync()
+    assert torch.equal(a, b)
+    venv.sample_actions(b, 7, 2); venv.sync()
+    assert not torch.equal(a, b)
+    venv.sample_actions(b, 8, 1); venv.sync()
+    assert not torch.equal(a, b)
+    x = a.cpu().numpy().ravel()
+    assert x.min() >= -0.25 and x.max() < 0.25 and abs(x.mean()) < 0.01 and abs(x.std() - 0.5 / np.sqrt(12.0)) < 0.005
+    hist = np.histogram(x, bins=8, range=(-0.25, 0.25))[0]
+    assert hist.min() > 0.85 * x.size / 8 and hist.max() < 1.15 * x.size / 8
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 0.05
+    venv.reset(); venv.step_async(a); venv.step_wait()   # and a step takes them in place
+    venv.close()

@@ -13,25 +13,83 @@ def _sensor(name, typ, n):
     return np.load(os.path.join(ROOT, "tactile_gym_amd", "assets", "sensors", f"{name}_{typ}_{n}.npz"))
 
 
-@pytest.mark.parametrize("size", [64, 128, 256])
-def test_tactip_nodef_depth_fixture(size):
-    """Known-answer (1): rendering the rigid TacTip skin through the oracle's camera model reproduces the reference's
-    committed nodef_dep.npy (tactile_sensor.py:74,79) inside the border disc — pins a11-a13 (projection, camera
-    mounting, GL depth convention, raster rule).  The body mesh is a missing blob upstream, so border pixels are not
-    compared.  Tolerance 2e-5 depth-buffer units = 1/5 of the reference's own noise threshold eps = 1e-4 (:274)."""
+FAMILIES = [("tactip", "standard"), ("tactip", "flat"), ("tactip", "forward"), ("tactip", "right_angle"), ("tactip", "mini_right_angle"),
+            ("digit", "standard"), ("digit", "forward"), ("digit", "right_angle"),
+            ("digitac", "standard"), ("digitac", "forward"), ("digitac", "right_angle")]
+# Upstream reference_images files that do NOT show what the reference's own camera model (tactile_sensor.py:127-187) sees of the
+# reference's own meshes: several are byte-identical copies of another family's file, the rest were saved with an older sensor
+# mounting.  test_upstream_fixture_aliases (below) demonstrates the copies from the shipped data.  With such a file the reference's
+# depth difference is non-zero on every pixel (a constant-offset image); this build - like its oracle - takes the file as the rigid
+# skin's depth (PARITY_ASSUMPTIONS A14), so these (family, size) combinations are outside the pinned set.  All 11 families are
+# consistent at 128x128 (the size of BASELINE configs 1-4) and tactip/standard at 256x256 (config 5).
+STALE = {
+    ("tactip", "mini_right_angle", 64): "copy of tactip/right_angle/64x64 (camera 29 mm further back)",
+    ("tactip", "mini_right_angle", 256): "copy of tactip/right_angle/256x256",
+    ("digit", "standard", 64): "one file shared by all six digit and digitac 64x64 families (depth range 0.34-0.48 fits neither sensor)",
+    ("digit", "forward", 64): "same shared 64x64 file", ("digit", "right_angle", 64): "same shared 64x64 file",
+    ("digitac", "standard", 64): "same shared 64x64 file", ("digitac", "forward", 64): "same shared 64x64 file",
+    ("digitac", "right_angle", 64): "same shared 64x64 file",
+    ("digit", "standard", 256): "older mounting: uniform 4e-3 depth offset", ("digit", "forward", 256): "older mounting: uniform 5e-3 depth offset",
+    ("digit", "right_angle", 256): "byte-identical copy of digitac/forward/256x256",
+    ("digitac", "standard", 256): "older mounting: uniform 6e-3 depth offset", ("digitac", "forward", 256): "older mounting: uniform 6e-3 depth offset",
+}
+
+
+def _render_view(name, typ, size):
     from oracle import minibullet as mb
     from oracle.ref_env import sensor_camera
     from tactile_gym_amd.urdf_compile import rpy_to_mat
-    g = np.load(os.path.join(GOLD, "tactip_standard_view.npz"))
-    s = _sensor("tactip", "standard", size)
-    cam = sensor_camera("tactip", "standard")
+    g = np.load(os.path.join(GOLD, f"{name}_{typ}_view.npz"))
+    cam = sensor_camera(name, typ)
     M = mb.cam_from_obj_matrix(cam["pos"], rpy_to_mat(cam["rpy"]), np.zeros(3), np.eye(3))
     dep = np.ones((size, size), np.float32)
-    mb.render_depth(g["tip_verts"], g["tip_tris"], M, cam["fov"], cam["near"], cam["far"], size, size, dep)
+    mb.render_depth(g["verts"], g["tris"], M, cam["fov"], cam["near"], cam["far"], size, size, dep)
+    return dep
+
+
+def _family_cases():
+    for name, typ in FAMILIES:
+        for size in (64, 128, 256):
+            why = STALE.get((name, typ, size))
+            marks = [pytest.mark.xfail(strict=True, reason=f"upstream fixture inconsistent with the reference's camera model: {why}")] if why else []
+            yield pytest.param(name, typ, size, marks=marks, id=f"{name}-{typ}-{size}")
+
+
+@pytest.mark.parametrize("name,typ,size", list(_family_cases()))
+def test_nodef_depth_fixture_families(name, typ, size):
+    """Known-answer (1) for every reference_images family x size (tactile_sensor.py:63-80): rendering what the in-sensor camera sees
+    at rest (skin / gel, body, adapter, flange: tests/golden/*_view.npz, sensor-body inertial frame) through the oracle's camera
+    model, mounting table (sensor_camera: tactile_sensor.py:127-187, incl. the 140 deg yaw of right_angle / forward / mini_right_angle)
+    and raster reproduces the committed nodef_dep.npy.  Pins a11-a13: projection, camera mounting, GL depth convention, raster rule, the
+    inertial-frame convention of getLinkState for the sensor body and the strtod-style reading of malformed URDF numbers (A9).
+    TacTip: the body mesh is a missing blob upstream, so only pixels inside the border disc (border_mask == 0) are compared; DIGIT /
+    DigiTac: every pixel.  Tolerance 2e-5 depth-buffer units = 1/5 of the reference's own noise threshold eps = 1e-4 (:274)."""
+    s = _sensor(name, typ, size)
+    dep = _render_view(name, typ, size)
     inner = s["border_mask"] == 0
+    assert inner.sum() > 0.45 * size * size
     err = np.abs(dep - s["nodef_dep"])[inner]
-    assert inner.sum() > 0.5 * size * size
     assert err.max() < 2e-5 and err.mean() < 3e-6
+    if name != "tactip":
+        assert s["border_mask"].sum() == 0            # DIGIT-family sensors have no border paste (SURVEY 8c)
+        for flipped in (dep[:, ::-1], dep[::-1], dep.T):   # asymmetric sensors: any flip / transpose of the image fails
+            assert np.abs(flipped - s["nodef_dep"]).mean() > 1e-3
+
+
+def test_upstream_fixture_aliases():
+    """The reason behind most STALE entries, shown from the shipped data: those upstream files are byte-identical copies of another
+    family's file, while the 128x128 files of the same families differ from each other as their mountings do."""
+    def dep(name, typ, size):
+        return _sensor(name, typ, size)["nodef_dep"]
+    for size in (64, 256):
+        assert np.array_equal(dep("tactip", "mini_right_angle", size), dep("tactip", "right_angle", size))
+    assert np.abs(dep("tactip", "mini_right_angle", 128) - dep("tactip", "right_angle", 128)).max() > 0.5
+    shared = dep("digit", "standard", 64)
+    for name in ("digit", "digitac"):
+        for typ in ("standard", "forward", "right_angle"):
+            assert np.array_equal(dep(name, typ, 64), shared)
+    assert np.array_equal(dep("digit", "right_angle", 256), dep("digitac", "forward", 256))                # a DigiTac image in the DIGIT directory
+    assert np.abs(dep("digit", "right_angle", 128) - dep("digitac", "right_angle", 128)).max() > 0.05
 
 
 def test_depth_convention_decodes_to_metres():
@@ -153,27 +211,3 @@ def test_oracle_env_contact_patch_tracks_embed_depth():
         peaks.append(int(img[inner].max()))
         assert abs(env.cur_tcp_pos[2] - (0.035 - embed)) < 2.5e-4   # blocking_move tolerance pos_tol = 2e-4 (robot.py:192)
     assert areas[0] < areas[1] < areas[2] and peaks[0] < peaks[1] < peaks[2]
-
-
-@pytest.mark.parametrize("name,typ", [("digit", "standard"), ("digitac", "right_angle")])
-def test_digit_digitac_nodef_depth_fixture_full_image(name, typ):
-    """DIGIT / DigiTac: the body and gel meshes are in the reference tree, so the *whole* committed nodef_dep.npy is
-    reproduced (every pixel, max |d| < 2e-5).  These sensors are asymmetric, so this also pins the image orientation
-    (any flip/transpose fails below), the inertial-frame convention of getLinkState for the sensor body
-    (tactile_sensor.py:153-155; the body link has a COM offset) and the strtod-style reading of the malformed URDF
-    numbers (PARITY_ASSUMPTIONS A9)."""
-    from oracle import minibullet as mb
-    from oracle.ref_env import sensor_camera
-    from tactile_gym_amd.urdf_compile import rpy_to_mat
-    g = np.load(os.path.join(GOLD, f"{name}_{typ}_view.npz"))
-    s = _sensor(name, typ, 128)
-    cam = sensor_camera(name, typ)
-    M = mb.cam_from_obj_matrix(cam["pos"], rpy_to_mat(cam["rpy"]), np.zeros(3), np.eye(3))
-    dep = np.ones((128, 128), np.float32)
-    mb.render_depth(g["tip_verts"], g["tip_tris"], M, cam["fov"], cam["near"], cam["far"], 128, 128, dep)
-    mb.render_depth(g["body_verts"], g["body_tris"], M, cam["fov"], cam["near"], cam["far"], 128, 128, dep)
-    err = np.abs(dep - s["nodef_dep"])
-    assert err.max() < 2e-5 and err.mean() < 3e-6
-    for flipped in (dep[:, ::-1], dep[::-1], dep.T):
-        assert np.abs(flipped - s["nodef_dep"]).mean() > 1e-3
-    assert s["border_mask"].sum() == 0            # DIGIT-family sensors have no border paste (SURVEY 8c)

@@ -1,0 +1,292 @@
+"""CPU tests: the oracle against (b) every entry of the reference's rest-pose tables, (c) a closed-form depth image and
+(d) analytic physics known answers (VERDICT r1 "next" item 1).  None of these use the HIP path."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+PI = math.pi
+
+# ---------------------------------------------------------------------------------------------------------------- (b) rest poses
+# Reset targets of the envs that read each table: work-frame origin + orientation, and where known the TCP position the table
+# entry was recorded at.  Sources (paths relative to tactile_gym/rl_envs):
+#   edge_follow     exploration/edge_follow/edge_follow_env.py:70-107   workframe (x_arm, 0, 0.035), rpy (-pi, 0, pi/2); reset at z - embed
+#   surface_follow  exploration/surface_follow/base_surface_env.py:52-123  horizontal: (x_arm, 0, 0.025) rpy (-pi, 0, pi/2);
+#                   vertical (`forward` sensors): (x_arm, 0, 0.175) rpy (-pi, 0, 0)
+#   object_push     nonprehensile_manipulation/object_push/object_push_env.py:62-90  ur5 (0.55, -0.2, 0.04); mg400 (0.25 | 0.30 tactip, -0.1, 0.04)
+#   object_balance  .../object_balance/object_balance_env.py:61-62  (0.55, 0, 0.35) rpy (0, 0, 0)
+#   object_roll     .../object_roll/object_roll_env.py:70-71  (0.65, 0, 2 r - embed) rpy (-pi, 0, pi/2)
+X_ARM = {"ur5": 0.65, "mg400": 0.33}
+
+
+def _target(table, arm, sensor, typ):
+    """(workframe rpy, expected TCP position or None per axis, position tolerance).  `None` on an axis = the upstream entry was
+    recorded at another embed depth / surface height than the env's nominal one (it is only the IK seed of Robot.reset,
+    robot.py:114-125, which then drives to the real target), so that axis carries no golden information."""
+    if table == "edge_follow":
+        # only UR5 + TacTip was recorded at the nominal reset pose (z = 0.035 - 0.0035); the other rows sit 1-9 mm off in z, the
+        # MG400 rows also in x
+        exact = (arm, sensor) == ("ur5", "tactip")
+        return (-PI, 0.0, PI / 2), (X_ARM[arm] if arm == "ur5" else None, 0.0, 0.0315 if exact else None), 3e-4
+    if table == "surface_follow":
+        if typ == "forward":
+            return (-PI, 0.0, 0.0), (None, 0.0, 0.175), 3e-4
+        return (-PI, 0.0, PI / 2), (0.65, 0.0, None), 8e-4
+    if table == "object_push":
+        if arm == "ur5":
+            return (-PI, 0.0, PI / 2), (0.55, -0.2, 0.04), 7e-4
+        if (sensor, typ) == ("tactip", "right_angle"):          # unused by the env (MG400 + TacTip takes mini_right_angle, :70-75)
+            return (-PI, 0.0, PI / 2), (None, None, None), 0.0
+        return (-PI, 0.0, PI / 2), (0.30 if sensor == "tactip" else 0.25, -0.1, 0.04), 7e-4
+    if table == "object_balance":
+        # recorded with the TacTip; the DIGIT / DigiTac bodies are 45 / 40 mm shorter, which the same joints show as a lower TCP
+        return (0.0, 0.0, 0.0), (0.55, 0.0, 0.35 if sensor == "tactip" else None), 8e-4
+    if table == "object_roll":
+        return (-PI, 0.0, PI / 2), (0.65, 0.0, 2 * 0.0025 - 0.0015), 3e-4
+    raise KeyError(table)
+
+
+def _rest_rows():
+    G = json.load(open(os.path.join(GOLD, "rest_poses.json")))
+    for table, d in G.items():
+        for r in d["rows"]:
+            sensors = [r["sensor"]] if r["sensor"] else (["tactip", "digit", "digitac"] if table == "object_balance" else ["tactip"])
+            for s in sensors:
+                yield pytest.param(table, r["arm"], s, r["type"], r["joints"], id=f"{table}-{r['arm']}-{s}-{r['type']}")
+
+
+@pytest.mark.parametrize("table,arm,sensor,typ,joints", list(_rest_rows()))
+def test_fk_of_every_reference_rest_pose(table, arm, sensor, typ, joints):
+    """Known-answer (4) over all five rest_poses.py tables (tests/golden/rest_poses.json, written by tools/extract_rest_poses.py):
+    each entry is a PyBullet-produced joint vector, indexed by URDF joint, for a TCP pose the env defines.  Through THIS repo's URDF
+    compiler + the oracle's FK + the inertial-frame convention of getLinkState (base_robot_arm.py:146-147) every entry must show
+    the env's work-frame orientation to 2 mrad, and the recorded TCP position to the sub-millimetre accuracy the entry carries -
+    for every arm x sensor x sensor type the product ships (26 URDFs).  A mis-parsed URDF, a wrong joint order, a link-frame (instead
+    of inertial-frame) TCP or a wrong fixed-joint chain fails here without any HIP == oracle comparison being able to mask it."""
+    from oracle import minibullet as mb, pb_math as pm
+    from tactile_gym_amd.robot_model import load_tgmodel
+    tg = load_tgmodel(arm, typ, sensor)
+    n_urdf = len(tg.urdf_joint_names)
+    assert len(joints) >= n_urdf              # Robot.reset indexes rest_poses[i] for i < getNumJoints (base_robot_arm.py:21-22)
+    q = np.zeros(tg.ndof)
+    for j, dof in enumerate(tg.dof_of_urdf_joint):
+        if dof >= 0:
+            q[dof] = joints[j]
+        else:
+            assert joints[j] == 0.0           # fixed joints carry 0 in every table
+    a = mb.Arm(tg)
+    a.reset_joint_states(q)
+    pos, quat, _, _, R = a.link_state("tcp_link")
+    rpy, want, tol = _target(table, arm, sensor, typ)
+    Rw = pm.mat_from_quat(pm.quat_from_euler(rpy))
+    ang = math.acos(max(-1.0, min(1.0, 0.5 * (np.trace(Rw.T @ R) - 1.0))))
+    assert ang < 2.5e-3, (ang, pm.euler_from_quat(quat))
+    for k in range(3):
+        if want[k] is not None:
+            assert abs(pos[k] - want[k]) < tol, (k, pos, want)
+    if arm == "mg400":                        # parallel linkage closed in the recorded pose (mg400.py:115-120), to the table's own precision
+        j = {n: joints[i] for i, n in enumerate(tg.urdf_joint_names)}
+        assert abs(j["j2_2"] - j["j2_1"]) < 3e-4 and abs(j["j3_2"] + j["j2_1"]) < 3e-4 and abs(j["j4_2"] - (j["j2_1"] + j["j3_1"])) < 3e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------- (c) closed-form image
+def _raycast_box_depth(M, lo, hi, fov, near, far, W, H):
+    """Closed form: GL depth of the axis-aligned box [lo, hi] (object frame) seen through eye<-object transform M, per pixel centre,
+    by the slab method - no triangles, no edge functions, no clipping.  Returns (depth float64[H, W], hit mask)."""
+    Rm, t = np.asarray(M[:9], np.float64).reshape(3, 3), np.asarray(M[9:], np.float64)
+    k = 1.0 / math.tan(0.5 * fov * PI / 180.0)
+    px, py = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)
+    a, b = (px - 0.5 * W) / (k * 0.5 * W), (0.5 * H - py) / (k * 0.5 * H)          # x/w, y/w of the pixel centre
+    o = -Rm.T @ t                                                                   # eye in the object frame
+    d = np.stack([a, b, -np.ones_like(a)], -1) @ Rm                                 # Rm^T (a, b, -1): ray per unit eye depth w
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0, t1 = (lo - o) / d, (hi - o) / d
+    tn, tf = np.minimum(t0, t1).max(-1), np.maximum(t0, t1).min(-1)
+    hit = (tn <= tf) & (tn >= near)
+    w = np.where(hit, tn, 1.0)
+    return far / (far - near) - (near * far / (far - near)) / w, hit
+
+
+def test_edge_depth_image_closed_form():
+    """Known-answer (3) in closed form: edge_follow-v0 right after reset - edge box 0.18 x 0.035 x 0.035 (one corner at the origin (0.65, 0, 0)) yawed
+    by the episode's angle (edge_follow_env.py:201-283), UR5 + TacTip at the work-frame origin lowered by the embed depth 3.5 mm
+    (:94-107, :301-309).
+      1. The camera: TCP at (0.65, 0, 0.035 - 0.0035) pointing down puts the in-sensor camera (0.085 - 0.03 = 0.055 m behind the skin
+         apex, ur5_with_standard_tactip.urdf:329 + tactile_sensor.py:160) at (0.65, 0, 0.0865) looking along -z: the oracle's FK + camera
+         chain must land there to the blocking move's 0.2 mm.
+      2. The image: the edge's top face is the plane z = 0.035, i.e. eye depth w = 0.0515 -> GL depth 1.0101 - 0.010101/0.0515 for every
+         pixel that sees it; the whole box is ray-cast per pixel (slab method) and compared with the oracle's triangle raster: same
+         depth to 2e-6 wherever both hit, coverage differing only on the silhouette, and the resulting tactile image (t_s_camera)
+         equal on > 99.5 % of the pixels with every difference on the silhouette."""
+    from oracle import minibullet as mb
+    from oracle.ref_env import OracleEdgeFollowEnv
+    env = OracleEdgeFollowEnv(seed=3, env_modes=dict(noise_mode="fixed_height"))
+    env.reset()
+    cpos, cR = env.camera_pose()
+    assert np.abs(cpos - np.array([0.65, 0.0, 0.035 - 0.0035 + 0.055])).max() < 3e-4
+    assert np.abs(cR[:, 0] - np.array([0.0, 0.0, -1.0])).max() < 2e-3            # forward axis = straight down
+    M = env.stimulus_transform()
+    lo, hi = env.edge_verts.min(0).astype(np.float64), env.edge_verts.max(0).astype(np.float64)
+    assert np.allclose(lo, 0.0, atol=1e-7) and np.allclose(hi, [0.18, 0.035, 0.035], atol=1e-6)   # long_edge.obj is this box: the followed edge is its y = 0 rim
+    H = W = 128
+    cam = env.cam
+    d_ray, hit = _raycast_box_depth(M, lo, hi, cam["fov"], cam["near"], cam["far"], W, H)
+    d_ras = np.ones((H, W), np.float32)
+    mb.render_depth(env.edge_verts, env.edge_tris, M, cam["fov"], cam["near"], cam["far"], W, H, d_ras)
+    ras_hit = d_ras < 1.0
+    both = hit & ras_hit
+    assert both.sum() > 2000
+    assert np.abs(d_ras[both] - d_ray[both]).max() < 2e-6
+    # top face: constant eye depth -> one depth value (the camera axis is vertical to ~1e-3 rad, so allow the tilt's 2e-5)
+    top = both & (np.abs(d_ray - (cam["far"] / (cam["far"] - cam["near"]) - (cam["near"] * cam["far"] / (cam["far"] - cam["near"])) / (cpos[2] - 0.035))) < 4e-5)
+    assert top.sum() > 0.9 * both.sum()
+    # coverage can differ only on the silhouette: every disagreeing pixel has a neighbour of the other kind
+    dis = hit != ras_hit
+    assert dis.sum() < 0.01 * H * W
+    grown = np.zeros_like(hit)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            grown |= np.roll(np.roll(hit, dy, 0), dx, 1) != hit
+    assert not (dis & ~grown).any()
+    # the tactile images agree except on that silhouette
+    cur = np.minimum(env.nodef_dep, np.where(hit, d_ray, 1.0).astype(np.float32))
+    img_ray = mb.t_s_camera(cur, env.nodef_dep, env.nodef_gray, env.border_mask)
+    img_ras = env.tactile_image()
+    diff = img_ray != img_ras
+    assert diff.mean() < 0.005 and not (diff & ~grown).any()
+    assert int(img_ras[env.border_mask == 0].max()) > 0                          # and there is a contact patch to agree on
+
+
+# ---------------------------------------------------------------------------------------------------------------- (d) physics
+def _push_env(**kw):
+    from oracle.ref_env import OracleObjectPushEnv
+    env = OracleObjectPushEnv(seed=0, image_size=(64, 64), env_modes=dict(tactile_sensor_name="tactip", **kw))
+    return env
+
+
+def _park_arm(env):
+    """Hold the arm where it is (velocity motors at zero), far from the cube."""
+    env.arm.reset_joint_states(env.rest_poses)
+    env.arm.set_motors_velocity(np.zeros(env.arm.n), 1.0, 1000.0)
+
+
+def _tick(env):
+    env.arm.apply_torques(env.arm.inverse_dynamics(env.arm.q, env.arm.qd, np.zeros(env.arm.n)))
+    env._step_simulation()
+
+
+def test_free_fall_known_answer():
+    """A body with no contact falls by the semi-implicit Euler recurrence  v_n = -n g dt,  z_n = z_0 - g dt^2 n (n + 1) / 2
+    (stepSimulation order A4; damping switched off for the closed form), and with Bullet's velocity damping F = -m v (K + K |v|)
+    (A27) by the same recurrence with the damping term."""
+    env = _push_env()
+    _park_arm(env)
+    env.scene.lin_damp = env.scene.ang_damp = 0.0
+    env.cube.pos[2] = 1.0
+    g, dt, n = 9.81, 1.0 / 240.0, 60
+    for _ in range(n):
+        _tick(env)
+    assert env.scene.n_contacts == 0
+    assert abs(env.cube.linvel[2] + n * g * dt) < 1e-12
+    assert abs(env.cube.pos[2] - (1.0 - g * dt * dt * n * (n + 1) / 2)) < 1e-12
+    assert max(abs(env.cube.pos[0] - env.init_obj_pos[0]), abs(env.cube.pos[1] - env.init_obj_pos[1])) < 1e-15
+    env2 = _push_env()
+    _park_arm(env2)
+    env2.cube.pos[2] = 1.0
+    v = z = 0.0
+    z = 1.0
+    for _ in range(n):
+        _tick(env2)
+        v = v + dt * (-g - v * (0.04 + 0.04 * abs(v)))
+        z = z + dt * v
+    assert abs(env2.cube.linvel[2] - v) < 1e-12 and abs(env2.cube.pos[2] - z) < 1e-12
+
+
+def test_coulomb_sliding_deceleration_known_answer():
+    """The cube (m = 0.491 kg, cube.urdf) sliding on the table with combined friction 0.065 x 1.0 (object_push_env.py:216-225, A26)
+    decelerates at mu g: per tick dv = -mu g dt, until it stops - and then stays.  Cone friction over four vertex contacts must sum
+    to mu m g; the normal impulses must carry the weight (sum lambda_n = m g dt)."""
+    env = _push_env()
+    _park_arm(env)
+    env.scene.lin_damp = env.scene.ang_damp = 0.0
+    for _ in range(20):                      # settle on the table (ERP pulls the 1e-16-level start gap in)
+        _tick(env)
+    assert env.scene.n_contacts == 4 and abs(env.cube.linvel[2]) < 1e-9
+    mu, g, dt = 0.065, 9.81, 1.0 / 240.0
+    v0 = 0.05
+    env.cube.linvel[0] = v0
+    n_stop = v0 / (mu * g * dt)              # 18.8 ticks
+    vs = []
+    for _ in range(30):
+        _tick(env)
+        vs.append(env.cube.linvel[0])
+    for k in range(int(n_stop) - 1):
+        assert abs(vs[k] - (v0 - (k + 1) * mu * g * dt)) < 2e-6, (k, vs[k])
+    assert all(abs(v) < 1e-6 for v in vs[int(n_stop) + 1:])       # stick: friction holds the cube once it has stopped
+    assert abs(env.cube.angvel[2]) < 1e-6 and abs(env.cube.linvel[1]) < 1e-6
+
+
+def test_p2p_pendulum_period_known_answer():
+    """object_balance's pole (m = 0.11 kg, all links welded) hung from the resting TCP by the point-to-point constraint
+    (object_balance_env.py:261-283; erp 0.2, A18) under the env's weakest gravity, g = 0.1 (object_balance_env.py:301-306), pointing
+    away from the pivot so that the pole is a stable physical pendulum: small oscillations have the period
+    T = 2 pi sqrt(I_pivot / (m g L)), I_pivot = I_com + m L^2."""
+    from oracle.ref_env import OracleObjectBalanceEnv
+    env = OracleObjectBalanceEnv(seed=0, image_size=(64, 64), env_modes=dict(rand_gravity=False, rand_embed_dist=False))
+    env.arm.reset_joint_states(env.rest_poses)
+    env.arm.set_motors_velocity(np.zeros(env.arm.n), 1.0, 1000.0)
+    g = 0.1
+    env.arm.set_gravity([0.0, 0.0, +g])        # the pole stands above the pivot: gravity UP makes it hang
+    pa, _, _, _, _ = env.arm.link_state("tcp_link")
+    com = np.array(env.body.com[:])
+    piv = np.array(env.p2p.pivot_b[:])
+    Lvec = com - piv                           # pivot -> centre of mass, body frame
+    Lc = float(np.linalg.norm(Lvec))
+    I = np.array(env.body.inertia[:]).reshape(3, 3)
+    # tilt about the body's x axis; moment of inertia about the pivot for that axis (parallel axis, L is along z to 1e-3)
+    ax = np.array([1.0, 0.0, 0.0])
+    Ipiv = float(ax @ I @ ax) + env.body.mass * (Lc ** 2 - float(Lvec @ ax) ** 2)
+    T = 2 * PI * math.sqrt(Ipiv / (env.body.mass * g * Lc))
+    th0 = 0.02
+    c, s = math.cos(th0), math.sin(th0)
+    R = np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    env._teleport_body(pa - R @ piv, R)
+    dt = env.SIM_DT
+    ys, n = [], int(2.6 * T / dt)
+    for _ in range(n):
+        env.arm.apply_torques(env.arm.inverse_dynamics(env.arm.q, env.arm.qd, np.zeros(env.arm.n)))
+        env._step_simulation()
+        Rb = np.array(env.body.rot[:]).reshape(3, 3)
+        ys.append(math.atan2(Rb[2, 1], Rb[2, 2]))     # tilt about x
+    ys = np.array(ys)
+    down = [i for i in range(1, n) if ys[i - 1] > 0 >= ys[i]]      # downward zero crossings, one per period
+    assert len(down) >= 2
+    frac = [i - 1 + ys[i - 1] / (ys[i - 1] - ys[i]) for i in down]
+    T_meas = (frac[-1] - frac[0]) / (len(frac) - 1) * dt
+    assert abs(T_meas - T) / T < 0.01, (T_meas, T)
+    assert 0.8 * th0 < np.abs(ys).max() <= 1.02 * th0              # neither blown up nor damped away by the constraint's ERP
+    pb_w = np.array(env.body.pos[:]) + Rb @ piv
+    assert np.abs(pb_w - pa).max() < 1e-4                           # the pivots stay together
+
+
+def test_soft_tip_contact_steady_state_depth_known_answer():
+    """While the MG400 pushes the cube at constant speed, the tip's soft contact (contactStiffness k, contactDamping d: cfm/erp of A25)
+    sits at the depth where the spring alone carries the load: the normal velocity error is zero in steady state, so
+    depth = F / k with F = the table's sliding friction mu m g (+ the cube's velocity damping m v K, < 1 %).  DigiTac: k = 300 N/m
+    (object_push_env.py:61-66) -> 0.313 N / 300 = 1.04 mm; and the tip's normal impulse per tick is F dt."""
+    from oracle.ref_env import OracleObjectPushEnv
+    env = OracleObjectPushEnv(seed=1, image_size=(64, 64), env_modes=dict(movement_mode="y", traj_type="straight"))
+    env.reset()
+    for _ in range(40):
+        env.step(np.array([0.0]))            # movement "y": constant push along the work-frame x at max_action, no lateral action
+    m, mu, g, k = env.cube.mass, 0.065, 9.81, 300.0
+    vx = float(np.linalg.norm(env.cube.linvel[:2]))
+    F = mu * m * g + m * vx * (0.04 + 0.04 * vx)
+    assert env.scene.n_contacts == 5
+    assert abs(-env.scene.tip_depth - F / k) < 0.03 * F / k, (env.scene.tip_depth, F / k)
+    assert abs(env.scene.tip_impulse - F / 240.0) < 0.03 * F / 240.0
+    assert abs(vx - 0.01) < 2e-4              # the cube moves with the tip: max_pos_vel = 0.01 m/s (object_push_env.py:126-134)

@@ -38,6 +38,8 @@ ROBOTS = [
     ("ur5", "digit", "standard"),
     ("ur5", "digitac", "standard"),
     ("mg400", "tactip", "standard"),
+    ("mg400", "digit", "standard"),              # edge_follow on the MG400 (edge_follow/rest_poses.py:114-153)
+    ("mg400", "digitac", "standard"),
     ("mg400", "digitac", "right_angle"),
     ("mg400", "digit", "right_angle"),
     ("mg400", "tactip", "right_angle"),
@@ -134,25 +136,75 @@ def stimuli():
     save(os.path.join(OUT, "stimuli", "short_edge.npz"), verts=(v * np.asarray(g.scale)).astype(np.float32), tris=t.astype(np.int32))
 
 
+GOLDEN_FAMILIES = [   # one URDF per (sensor, type) family of reference_images/ (the mounting inside the sensor does not depend on the arm)
+    ("ur5", "tactip", "standard"), ("ur5", "tactip", "flat"), ("ur5", "tactip", "forward"), ("ur5", "tactip", "right_angle"),
+    ("mg400", "tactip", "mini_right_angle"), ("ur5", "digit", "standard"), ("ur5", "digit", "forward"), ("ur5", "digit", "right_angle"),
+    ("ur5", "digitac", "standard"), ("ur5", "digitac", "forward"), ("mg400", "digitac", "right_angle"),
+]
+
+
+def rigid_group_meshes(urdf, body):
+    """Visual triangles of every URDF link welded (fixed joints) to the moving link that carries `body`, expressed in `body`'s
+    *inertial* frame - the frame getLinkState(...)[0:2] reports and the in-sensor camera is mounted in (tactile_sensor.py:153-187)."""
+    links, joints = parse_urdf(urdf)
+    par = {j.child: j for j in joints}
+    root = body
+    while root in par and par[root].jtype == "fixed":
+        root = par[root].parent
+    poses = {root: (np.eye(3), np.zeros(3))}      # link frame of each welded link in the root link's frame
+    grew = True
+    while grew:
+        grew = False
+        for j in joints:
+            if j.jtype == "fixed" and j.parent in poses and j.child not in poses:
+                R, p = poses[j.parent]
+                Rj, pj = rpy_to_mat(j.rpy), np.asarray(j.xyz)
+                poses[j.child] = (R @ Rj, R @ pj + p)
+                grew = True
+    Rb, pb = poses[body]
+    Lb = links[body]
+    Rbi, pbi = rpy_to_mat(Lb.com_rpy), np.asarray(Lb.com_xyz)
+    vs, ts, names, base = [], [], [], 0
+    for name, (R, p) in poses.items():
+        v, t = visual_meshes_of_link(urdf, name)           # that link's inertial frame
+        if len(t) == 0:
+            continue
+        L = links[name]
+        v = v @ rpy_to_mat(L.com_rpy).T + np.asarray(L.com_xyz)   # -> link frame
+        v = v @ R.T + p                                     # -> root link frame
+        v = (v - pb) @ Rb                                   # -> body link frame
+        v = (v - pbi) @ Rbi                                 # -> body inertial frame
+        vs.append(v); ts.append(t + base); names.append(name); base += len(v)
+    return np.concatenate(vs).astype(np.float32), np.concatenate(ts).astype(np.int32), names
+
+
 def golden_views():
-    """Visual meshes the in-sensor camera sees at rest, expressed in the sensor-body inertial frame."""
-    for arm, sensor, typ in (("ur5", "tactip", "standard"), ("ur5", "digit", "standard"), ("mg400", "digitac", "right_angle")):
+    """tests/golden/<sensor>_<type>_view.npz: what the in-sensor camera sees at rest (skin / gel, body, adapter, flange), in the
+    sensor-body inertial frame, for every reference_images family.  Only the triangles that own at least one pixel of the 64x64,
+    128x128 or 256x256 render are kept (the rest cannot change those images: the depth test is a min), which keeps the blobs small."""
+    from oracle import minibullet as mb
+    from oracle.ref_env import sensor_camera
+    for arm, sensor, typ in GOLDEN_FAMILIES:
         urdf = os.path.join(REF, "robot_assets", arm, sensor, f"{arm}_with_{typ}_{sensor}.urdf")
-        links, joints = parse_urdf(urdf)
-        body, tip = f"{sensor}_body_link", f"{sensor}_tip_link"
-        jt = next(j for j in joints if j.child == tip and j.parent == body)
-        vb, tb = visual_meshes_of_link(urdf, body)           # body inertial frame
-        vt, tt = visual_meshes_of_link(urdf, tip)            # tip inertial frame
-        Lb, Lt = links[body], links[tip]
-        Rb, pb = rpy_to_mat(Lb.com_rpy), np.asarray(Lb.com_xyz)
-        Rt, pt = rpy_to_mat(Lt.com_rpy), np.asarray(Lt.com_xyz)
-        Rj, pj = rpy_to_mat(jt.rpy), np.asarray(jt.xyz)
-        # tip inertial -> tip link -> body link -> body inertial
-        v = vt @ Rt.T + pt
-        v = v @ Rj.T + pj
-        v = (v - pb) @ Rb
-        save(os.path.join(GOLD, f"{sensor}_{typ}_view.npz"), tip_verts=v.astype(np.float32), tip_tris=tt.astype(np.int32),
-             body_verts=vb.astype(np.float32), body_tris=tb.astype(np.int32))
+        v, t, names = rigid_group_meshes(urdf, f"{sensor}_body_link")
+        cam = sensor_camera(sensor, typ)
+        M = mb.cam_from_obj_matrix(cam["pos"], rpy_to_mat(cam["rpy"]), np.zeros(3), np.eye(3))
+        keep = np.zeros(len(t), bool)
+        for n in (64, 128, 256):
+            full = np.ones((n, n), np.float32)
+            mb.render_depth(v, t, M, cam["fov"], cam["near"], cam["far"], n, n, full)
+            one = np.ones((n, n), np.float32)
+            for k in range(len(t)):
+                if keep[k]:
+                    continue
+                one.fill(1.0)
+                mb.render_depth(v, t[k:k + 1], M, cam["fov"], cam["near"], cam["far"], n, n, one)
+                keep[k] = bool(np.any((one < 1.0) & (one == full)))
+        tk = t[keep]
+        used, inv = np.unique(tk.reshape(-1), return_inverse=True)
+        save(os.path.join(GOLD, f"{sensor}_{typ}_view.npz"), verts=v[used], tris=inv.reshape(-1, 3).astype(np.int32),
+             links=np.array(",".join(names)), urdf=np.array(f"{arm}_with_{typ}_{sensor}.urdf"))
+        print(f"  {sensor}/{typ}: {int(keep.sum())} of {len(t)} triangles own a pixel; links {names}")
 
 
 def objects():

@@ -1,0 +1,15 @@
+"""Per-wavefront means of rocprofv3 --pmc counter_collection.csv for the tg:: kernels (used by tools/gpu_profile.sh)."""
+import collections
+import csv
+import glob
+import sys
+
+files = glob.glob(f"{sys.argv[1]}/**/*counter_collection.csv", recursive=True)
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in files:
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in agg.items():
+    if "tg::" in k and v.get("SQ_WAVES"):
+        w = sum(v["SQ_WAVES"]) / len(v["SQ_WAVES"])
+        print(k, {c: round(sum(x) / len(x) / w, 1) for c, x in v.items() if c != "SQ_WAVES"}, "waves", w, "launches", len(v["SQ_WAVES"]))

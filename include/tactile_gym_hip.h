@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 5
+#define TG_ABI_VERSION 6
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -210,6 +210,10 @@ int tg_get_reward_done_dev(tg_ctx* ctx, void** reward_f32, void** done_u8);
  * (tg_get_obs_tactile / tg_get_reward_done_dev point into it).  A rank ships this byte range to rank 0 as one message per step
  * (replaces SubprocVecEnv's per-env pickled pipes, sb3_helpers/rl_utils.py:17-30).  obs_bytes = offset of the reward. */
 int tg_get_packed_outputs(tg_ctx* ctx, void** dev_ptr, int64_t* obs_bytes, int64_t* total_bytes);
+/* Envs with an "extended_feature" observation (object_push, object_roll) append it to the same allocation, so that config 4's
+ * tactile_and_feature observation still travels as one message: [... | done u8[N] | pad to 4 B | feature f32[N][dim]]
+ * (object_push_env.py:611-629).  *feature_off = byte offset of the feature block (-1: this env has none). */
+int tg_get_packed_feature(tg_ctx* ctx, int64_t* feature_off, int32_t* dim);
 /* "extended_feature" observation (object_push_env.py:611-629): float32 [num_envs][*dim]: TCP pos, rpy and current goal
  * pos, rpy in the work frame; terminal != 0: the copy taken at the last step (rows valid where done). */
 int tg_get_obs_feature(tg_ctx* ctx, void** dev_ptr, int32_t* dim, int32_t terminal);
@@ -243,6 +247,13 @@ typedef struct {
     double*  traj;           /* [num_envs][3][TG_MAX_TRAJ_POINTS] work-frame x, y, yaw of the goal trajectory (object_push) */
     int32_t* goal_id;        /* [num_envs] targ_traj_list_id (object_push) */
     double*  obj_mass;       /* [num_envs] (object_push) */
+    /* Contact pairs of the last stepSimulation tick (robot.py:141), in solver row order (object_push / object_roll; 0 elsewhere:
+     * the other envs filter every sensor contact out, tactile_sensor.py:46-57, base_surface_env.py:432).  An id names the pair by its
+     * feature: 0-7 = cube vertex (index 4 ix + 2 iy + iz of the +-half extents) against the table, the marble's table contact is 0;
+     * 8 + k = hull vertex k of the sensor tip's collision core against the cube (8 for the marble against the tip's cylinder).
+     * Unused slots are -1.  Integer data: compared bit-exactly with the oracle. */
+    int32_t* contact_count;  /* [num_envs] */
+    int32_t* contact_ids;    /* [num_envs][5] */
 } tg_state_view;
 int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */

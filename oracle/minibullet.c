@@ -509,12 +509,6 @@ void mb_heightfield_simplex2d(int64_t seed, int rows, int cols, double interp, d
 }
 
 /* ------------------------------------------------------------------------------------------------ arm + free body + P2P */
-static void m3_transpose_mul(const double* A, const double* B, double* Cc) { /* A^T B */
-    double t[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) t[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
-    memcpy(Cc, t, sizeof t);
-}
 static int invert3(const double* A, double* Ai) {
     double d = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
     if (d == 0.0) return -1;
@@ -704,6 +698,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
     }
     /* ---- contact generation */
     contact_t ct[MAXC]; int nc = 0;
+    for (int c = 0; c < MAXC; ++c) sc->contact_ids[c] = -1;
     kin_t k; double z3[3] = {0, 0, 0};
     kinematics(m, s->q, zero, NULL, z3, &k);
     if (sc->shape == 1) {   /* sphere - table: the lowest point of the sphere against the plane [PARITY_ASSUMPTIONS A30] */
@@ -713,6 +708,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             q->n[0] = 0; q->n[1] = 0; q->n[2] = 1; q->depth = depth; q->mu = sc->mu_table; q->arm_a = 0; q->cfm_dt = 0.0; q->erp = sc->erp;
             for (int x = 0; x < 3; ++x) { q->pa[x] = b->pos[x]; q->pb[x] = b->pos[x]; }
             q->pa[2] = b->pos[2] - sc->radius; q->pb[2] = sc->table_z;
+            sc->contact_ids[nc - 1] = 0;
         }
     } else
     {   /* cube - table: broadphase on z, then the cube vertices near the plane (at most 4 kept: the deepest ones) */
@@ -740,6 +736,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
                 q->n[0] = 0; q->n[1] = 0; q->n[2] = 1; q->depth = vz[c]; q->mu = sc->mu_table; q->arm_a = 0; q->cfm_dt = 0.0; q->erp = sc->erp;
                 for (int x = 0; x < 3; ++x) { q->pa[x] = vw[c][x]; q->pb[x] = vw[c][x]; }
                 q->pb[2] = sc->table_z;
+                sc->contact_ids[nc - 1] = c;
             }
         }
     }
@@ -769,6 +766,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             q->cfm_dt = (1.0 / denom) / dt; q->erp = dt * sc->tip_stiffness / denom;
             double clw[3]; m3_vec(Rw, cl, clw);
             for (int x = 0; x < 3; ++x) { q->pa[x] = cw_[x] + clw[x]; q->pb[x] = b->pos[x] - gw[x] * sc->radius; }
+            sc->contact_ids[nc - 1] = 8;
             sc->tip_depth = depth; memcpy(sc->tip_normal, q->n, sizeof q->n);
         }
     } else
@@ -800,6 +798,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             double denom = dt * sc->tip_stiffness + sc->tip_damping;   /* soft contact: cfm = 1/(dt (dt k + d)), erp = dt k/(dt k + d) */
             q->cfm_dt = (1.0 / denom) / dt; q->erp = dt * sc->tip_stiffness / denom;
             for (int x = 0; x < 3; ++x) { q->pa[x] = bestw[x] - q->n[x] * sc->margin_tip; q->pb[x] = bestw[x] - q->n[x] * (bestd - sc->margin_cube); }
+            sc->contact_ids[nc - 1] = 8 + besti;
             sc->tip_depth = depth; memcpy(sc->tip_normal, q->n, sizeof q->n);
         }
     }
@@ -905,8 +904,8 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
                 double tot = sqrt(s1 * s1 + s2 * s2);
                 if (tot > limit) { double f = tot > 0 ? limit / tot : 0.0; s1 *= f; s2 *= f; }
             } else {
-                if (s1 < -limit) s1 = -limit; if (s1 > limit) s1 = limit;
-                if (s2 < -limit) s2 = -limit; if (s2 > limit) s2 = limit;
+                s1 = s1 < -limit ? -limit : (s1 > limit ? limit : s1);
+                s2 = s2 < -limit ? -limit : (s2 > limit ? limit : s2);
             }
             d1 = s1 - lam[r1]; d2 = s2 - lam[r2]; lam[r1] = s1; lam[r2] = s2;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r1] * d1 + W[u][r2] * d2;

@@ -176,6 +176,10 @@ typedef struct {
     double radius;               /* sphere radius (default_obj_radius x scaling_factor) */
     double cyl_pos[3], cyl_rot[9];   /* cylinder frame (axis = local z) in the frame of tip_link */
     double cyl_half_len, cyl_radius;
+    /* out: the tick's contact pairs in solver row order (n_contacts of them, the rest -1), named by their feature: 0-7 = the cube
+     * vertex (4 ix + 2 iy + iz) that touches the table (the marble's table contact: 0); 8 + k = hull vertex k of the tip core against
+     * the cube (the marble against the tip's cylinder: 8).  north_star: "bit-exact for contact-pair indices". */
+    int32_t contact_ids[5];
 } mb_push_scene;
 
 extern int mb_last_sweeps;   /* PGS sweeps executed by the last mb_step */

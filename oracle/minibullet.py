@@ -57,7 +57,7 @@ class MBPushScene(C.Structure):
         ("n_contacts", C.c_int32), ("tip_depth", C.c_double), ("tip_normal", C.c_double * 3), ("tip_impulse", C.c_double),
         ("residual_threshold", C.c_double), ("sweeps_used", C.c_int32),
         ("shape", C.c_int32), ("radius", C.c_double), ("cyl_pos", C.c_double * 3), ("cyl_rot", C.c_double * 9),
-        ("cyl_half_len", C.c_double), ("cyl_radius", C.c_double),
+        ("cyl_half_len", C.c_double), ("cyl_radius", C.c_double), ("contact_ids", C.c_int32 * 5),
     ]
 
 

@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -103,6 +103,7 @@ class TgStateView(C.Structure):
         ("body_pos", C.POINTER(C.c_double)), ("body_rot", C.POINTER(C.c_double)), ("body_linvel", C.POINTER(C.c_double)),
         ("body_angvel", C.POINTER(C.c_double)), ("gravity_z", C.POINTER(C.c_double)),
         ("traj", C.POINTER(C.c_double)), ("goal_id", C.POINTER(C.c_int32)), ("obj_mass", C.POINTER(C.c_double)),
+        ("contact_count", C.POINTER(C.c_int32)), ("contact_ids", C.POINTER(C.c_int32)),
     ]
 
 
@@ -123,6 +124,7 @@ SYMBOLS = {
     "tg_get_terminal_obs": (C.c_int, [_ctx, _vpp]),
     "tg_get_reward_done_dev": (C.c_int, [_ctx, _vpp, _vpp]),
     "tg_get_packed_outputs": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "tg_get_packed_feature": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_sample_actions": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tg_selftest_division": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
     "tg_get_obs_feature": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32), C.c_int32]),

@@ -83,6 +83,7 @@ struct State {   // device pointers, SoA [field][num_envs]
     // object_push
     double *traj, *obj_mass;        // [3][TG_MAX_TRAJ_POINTS][n] work-frame x, y, yaw; [n]
     int32_t* goal_id;               // [n]
+    int32_t* contact_code;          // [n] contact pairs of the last sim tick (sim_tick_push's contact_code)
     float *feature, *term_feature;  // [n][12] extended_feature observation (object_push_env.py:611-629), AoS
     const void* tip_verts;          // [n_tip][3] in the physics dtype
 };
@@ -1063,6 +1064,7 @@ __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict_
         for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
     }
     const T mass = (T)st.obj_mass[env];
+    int ccode = 0;
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
@@ -1070,14 +1072,15 @@ __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict_
         for (int t = 0; t < c.max_blocking; ++t) {
             const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
             sim_tick_push<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
-                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x);
+                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x, ccode);
             if (stop) break;
         }
     } else {
         for (int t = 0; t < c.action_repeat; ++t)
             sim_tick_push<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
-                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x);
+                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x, ccode);
     }
+    st.contact_code[env] = ccode;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
     store_body<T>(st, n, env, b);
@@ -1142,7 +1145,7 @@ __global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict
     T zero[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) zero[i] = T(0);
-    int used = 0;
+    int used = 0, ccode = 0;
     for (int it = 0; it < 1000; ++it) {
         Kin<T, TOPO> k;
         forward_kinematics<T, TOPO>(m, q, k);
@@ -1163,7 +1166,7 @@ __global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict
         for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
         if (all_small) cv = cv / T(2);
         sim_tick_push<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, b, c.push,
-                                               (const T*)st.tip_verts, (T)old_mass, lds + threadIdx.x);
+                                               (const T*)st.tip_verts, (T)old_mass, lds + threadIdx.x, ccode);
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
@@ -1172,6 +1175,7 @@ __global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict
         if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
     }
     st.reset_ticks[env] = used;
+    st.contact_code[env] = ccode;
     // reset_object: resetBasePositionAndOrientation(init_obj_pos, init_obj_orn), velocities zeroed
     b.pos = load_v3(c.obj_init_pos);
     b.R = mat_from_quat(quat_from_euler((T)c.obj_init_rpy[0], (T)c.obj_init_rpy[1], (T)(c.obj_init_rpy[2] + ang)));
@@ -1256,6 +1260,7 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
     const int step_count = st.step_count[env] + 1;
     st.step_count[env] = step_count;
     const T radius = (T)st.obj_mass[env];                                  // the episode's radius
+    int ccode = 0;
     const T work_dz = (T)((2.0 * st.obj_mass[env] - st.embed[env]) - (double)c.work_pos[2]);   // update_workframe (:192-201)
     T qd_des[N], zero[N];
 #pragma unroll
@@ -1268,7 +1273,7 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
         for (int t = 0; t < c.max_blocking; ++t) {        // blocking_move(max_steps, constant_vel=None), robot.py:188-260
             const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
             sim_tick_push<T, TOPO, kMotorPosition, 1>(m, q, qd, qd_des, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
-                                                      nullptr, radius, lds + threadIdx.x);
+                                                      nullptr, radius, lds + threadIdx.x, ccode);
             if (stop) break;
         }
     } else {
@@ -1277,8 +1282,9 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
         for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
         for (int t = 0; t < c.action_repeat; ++t)
             sim_tick_push<T, TOPO, kMotorVelocity, 1>(m, q, qd, zero, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push, nullptr,
-                                                      radius, lds + threadIdx.x);
+                                                      radius, lds + threadIdx.x, ccode);
     }
+    st.contact_code[env] = ccode;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
     store_body<T>(st, n, env, b);
@@ -1331,7 +1337,7 @@ __global__ __launch_bounds__(64) void k_reset_roll(const DevRobot<T>* __restrict
     T zero[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) zero[i] = T(0);
-    int used = 0;
+    int used = 0, ccode = 0;
     for (int it = 0; it < 1000; ++it) {
         Kin<T, TOPO> k;
         forward_kinematics<T, TOPO>(m, q, k);
@@ -1352,7 +1358,7 @@ __global__ __launch_bounds__(64) void k_reset_roll(const DevRobot<T>* __restrict
         for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
         if (all_small) cv = cv / T(2);
         sim_tick_push<T, TOPO, kMotorPosition, 1>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, b, c.push,
-                                                  nullptr, (T)old_radius, lds + threadIdx.x);
+                                                  nullptr, (T)old_radius, lds + threadIdx.x, ccode);
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
@@ -1361,6 +1367,7 @@ __global__ __launch_bounds__(64) void k_reset_roll(const DevRobot<T>* __restrict
         if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
     }
     st.reset_ticks[env] = used;
+    st.contact_code[env] = ccode;
     // reset_object: teleport (or reload with the new scale), velocities zeroed
     b.pos = mk((T)((double)c.obj_init_pos[0] + ix), (T)((double)c.obj_init_pos[1] + iy), (T)new_radius);
     const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
@@ -1788,7 +1795,7 @@ struct tg_ctx {
     float *d_nodef_dep = nullptr, *d_verts = nullptr, *d_soup = nullptr, *d_actions = nullptr;
     uint8_t* d_nodef_gray = nullptr;   // uint8(nodef_gray)
     uint8_t *d_border = nullptr, *d_obs = nullptr, *d_term = nullptr, *d_mask = nullptr;
-    size_t packed_obs_bytes = 0, packed_bytes = 0;   // d_obs = [obs | pad to 16 | reward f32[n] | done u8[n]]
+    size_t packed_obs_bytes = 0, packed_bytes = 0, packed_feature_off = 0;   // d_obs = [obs | pad to 16 | reward f32[n] | done u8[n] | pad to 4 | feature f32[n][12]]
     int32_t* d_tris = nullptr;
     int n_tris = 0;
     tg::Stimulus stim{};
@@ -2118,12 +2125,13 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
         TG_HIP(hipMemcpy(s.gravity, gz.data(), gz.size() * 8, hipMemcpyHostToDevice));
         TG_HIP(hipMemcpy(s.embed, em.data(), em.size() * 8, hipMemcpyHostToDevice));
     }
+    TG_HIP(hipMalloc(&s.contact_code, (size_t)n * 4)); TG_HIP(hipMemset(s.contact_code, 0, (size_t)n * 4));
     if (cfg->env_kind == TG_ENV_OBJECT_ROLL) {
         TG_HIP(hipMalloc(&s.body_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.body_rot, 9 * n * 8)); TG_HIP(hipMalloc(&s.body_v, 3 * n * 8));
         TG_HIP(hipMalloc(&s.body_w, 3 * n * 8)); TG_HIP(hipMalloc(&s.obj_mass, n * 8)); TG_HIP(hipMalloc(&s.goal, 3 * n * 8));
-        TG_HIP(hipMalloc(&s.feature, (size_t)12 * n * 4)); TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4));
+        TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4));
         TG_HIP(hipMemset(s.body_v, 0, 3 * n * 8)); TG_HIP(hipMemset(s.body_w, 0, 3 * n * 8)); TG_HIP(hipMemset(s.goal, 0, 3 * n * 8));
-        TG_HIP(hipMemset(s.feature, 0, (size_t)12 * n * 4)); TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
+        TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
         // load_object (base_object_env.py:66-70) at init_obj_pos, identity orientation, default radius (object_roll_env.py:156-166)
         std::vector<double> bp(3 * (size_t)n), br(9 * (size_t)n, 0.0), rad(n, cfg->roll_radius), em(n, cfg->embed_dist);
         for (int i = 0; i < n; ++i) {
@@ -2139,10 +2147,10 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
         TG_HIP(hipMalloc(&s.body_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.body_rot, 9 * n * 8)); TG_HIP(hipMalloc(&s.body_v, 3 * n * 8));
         TG_HIP(hipMalloc(&s.body_w, 3 * n * 8)); TG_HIP(hipMalloc(&s.noise_seed, n * 8)); TG_HIP(hipMalloc(&s.obj_mass, n * 8));
         TG_HIP(hipMalloc(&s.traj, (size_t)3 * TG_MAX_TRAJ_POINTS * n * 8)); TG_HIP(hipMalloc(&s.goal_id, n * 4));
-        TG_HIP(hipMalloc(&s.feature, (size_t)12 * n * 4)); TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4));
+        TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4));
         TG_HIP(hipMemset(s.body_v, 0, 3 * n * 8)); TG_HIP(hipMemset(s.body_w, 0, 3 * n * 8)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8));
         TG_HIP(hipMemset(s.traj, 0, (size_t)3 * TG_MAX_TRAJ_POINTS * n * 8)); TG_HIP(hipMemset(s.goal_id, 0, n * 4));
-        TG_HIP(hipMemset(s.feature, 0, (size_t)12 * n * 4)); TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
+        TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
         // load_object (base_object_env.py:66-70) at init_obj_pos / init_obj_orn (object_push_env.py:154-160)
         double oq[4], oR[9];
         h_quat_from_euler(cfg->obj_init_rpy, oq);
@@ -2194,9 +2202,15 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     // (tg_get_packed_outputs).  The obs block is padded to 16 bytes so the reward block stays aligned.
     c->packed_obs_bytes = ((size_t)npix * n + 15) & ~(size_t)15;
     c->packed_bytes = c->packed_obs_bytes + (size_t)n * 4 + (size_t)n;
+    const bool has_feature = cfg->env_kind == TG_ENV_OBJECT_PUSH || cfg->env_kind == TG_ENV_OBJECT_ROLL;
+    if (has_feature) {   // extended_feature rides in the same message (config 4's tactile_and_feature observation)
+        c->packed_feature_off = (c->packed_bytes + 3) & ~(size_t)3;
+        c->packed_bytes = c->packed_feature_off + (size_t)n * 12 * 4;
+    }
     TG_HIP(hipMalloc(&c->d_obs, c->packed_bytes)); TG_HIP(hipMemset(c->d_obs, 0, c->packed_bytes));
     s.reward = (float*)(c->d_obs + c->packed_obs_bytes);
     s.done = c->d_obs + c->packed_obs_bytes + (size_t)n * 4;
+    if (has_feature) s.feature = (float*)(c->d_obs + c->packed_feature_off);
     TG_HIP(hipMalloc(&c->d_term, npix * n)); TG_HIP(hipMemset(c->d_term, 0, npix * n));
     TG_HIP(hipMalloc(&c->d_mask, n));
     TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 6 * sizeof(float)));
@@ -2212,7 +2226,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.feature, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -2377,6 +2391,13 @@ int tg_get_packed_outputs(tg_ctx* c, void** p, int64_t* obs_bytes, int64_t* tota
     if (total_bytes) *total_bytes = (int64_t)c->packed_bytes;
     return 0;
 }
+int tg_get_packed_feature(tg_ctx* c, int64_t* feature_off, int32_t* dim) {
+    if (!c || !feature_off) return fail(-1, "NULL argument");
+    const bool has = c->cfg.env_kind == TG_ENV_OBJECT_PUSH || c->cfg.env_kind == TG_ENV_OBJECT_ROLL;
+    *feature_off = has ? (int64_t)c->packed_feature_off : -1;
+    if (dim) *dim = has ? 12 : 0;
+    return 0;
+}
 int tg_sample_actions(tg_ctx* c, uint64_t seed, uint64_t counter, float* dev_actions) {
     if (!c || !dev_actions) return fail(-1, "tg_sample_actions: NULL argument");
     const int total = c->cfg.num_envs * c->act_dim;
@@ -2468,6 +2489,21 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
         if (v->traj && (rc = fetch_soa(c, c->st.traj, 3 * TG_MAX_TRAJ_POINTS, v->traj))) return rc;
         if (v->goal_id && (rc = fetch_soa(c, c->st.goal_id, 1, v->goal_id))) return rc;
         if (v->obj_mass && (rc = fetch_soa(c, c->st.obj_mass, 1, v->obj_mass))) return rc;
+    }
+    if (v->contact_count || v->contact_ids) {
+        // contact pairs of the last sim tick, in solver row order: the cube vertices on the table in vertex order (ids 0-7; the marble's
+        // single table contact is id 0), then the tip contact (id 8 + index of the tip-core hull vertex that made it; 8 for the marble)
+        const int n = c->cfg.num_envs;
+        std::vector<int32_t> code(n);
+        if ((rc = fetch_soa(c, c->st.contact_code, 1, code.data()))) return rc;
+        for (int i = 0; i < n; ++i) {
+            int cnt = 0;
+            int32_t ids[5] = {-1, -1, -1, -1, -1};
+            for (int b = 0; b < 8 && cnt < 4; ++b) if ((code[i] >> b) & 1) ids[cnt++] = b;
+            if ((code[i] >> 8) & 1) ids[cnt++] = 8 + (code[i] >> 9);
+            if (v->contact_count) v->contact_count[i] = cnt;
+            if (v->contact_ids) for (int k = 0; k < 5; ++k) v->contact_ids[(size_t)i * 5 + k] = ids[k];
+        }
     }
     if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         if (v->goal_pos && (rc = fetch_soa(c, c->st.goal, 3, v->goal_pos))) return rc;

@@ -947,7 +947,9 @@ template <typename T, int TOPO, int MOTOR, int SHAPE = 0>
 __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                               const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                               int iters, FreeBody<T>& b, const PushScene<T>& sc, const T* __restrict__ tip_verts, T mass,
-                                              lds_ptr<T> L) {
+                                              lds_ptr<T> L, int& contact_code) {
+    // contact_code (out): the tick's contact pairs - bits 0-7 the cube vertices kept as cube-table contacts (SHAPE 1: bit 0 = the
+    // sphere-table contact), bit 8 the tip contact, bits 9+ the hull vertex of the tip core that made it (tg_state_view.contact_ids)
     constexpr int N = Topo<TOPO>::N;
     asm volatile("" ::: "memory");
     T hb[N], qdm[N], Minv[N][N], traceM;
@@ -988,6 +990,7 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
     for (int k = 0; k < 4 * kPushTab; ++k) L[k * 64] = T(0);
     if constexpr (SHAPE == 1) {   // sphere - table: its lowest point, one slot
         const T vz0 = (b.pos.z - radius) - sc.table_z;
+        contact_code = (vz0 <= sc.breaking) ? 1 : 0;
         if (vz0 <= sc.breaking) {
             const V3<T> ra = mk(T(0), T(0), -radius);
             lds_ptr<T> S = L;
@@ -1020,6 +1023,7 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
                 if (((keep >> c) & 1) && (worst < 0 || vz[c] >= wz)) { worst = c; wz = vz[c]; }
             keep &= ~(1 << worst); --cnt;
         }
+        contact_code = keep;
         int slot = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -1078,6 +1082,7 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             const T dist = tsqrt(dot(g, g));
             depth = dist - radius;
             active = dist > T(0) && depth <= sc.breaking;
+            contact_code |= active ? (1 << 8) : 0;
             const T idist = T(1) / (dist > T(0) ? dist : T(1));
             const V3<T> gw = mul(Rw, idist * g);                      // from the cylinder towards the sphere
             nrm = mk<T>(0, 0, 0) - gw;                                // contact normal: from the sphere (body B) towards the tip (body A)
@@ -1128,6 +1133,7 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
         }
         depth = sdf - (sc.margin_tip + sc.margin_cube);
         active = depth <= sc.breaking;
+        contact_code |= active ? ((1 << 8) | (best_i << 9)) : 0;
         nrm = mul(b.R, mk(g[0], g[1], g[2]));   // from the cube towards the tip
         pa = w - sc.margin_tip * nrm; pb = w - (sdf - sc.margin_cube) * nrm;
         }

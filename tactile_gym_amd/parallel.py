@@ -68,17 +68,29 @@ class ShardedVecEnv:
         obs = self.local.reset()
         return {k: self._gather("obs_" + k, v) for k, v in obs.items()}
 
-    # ---- packed exchange: [tactile bytes | pad | reward bytes | done bytes] per rank
-    def _pack(self, slot, tac, rew, done):
+    # ---- packed exchange: [tactile bytes | pad to 16 | reward f32 | done u8 | pad to 4 | extended_feature f32[n][K] (if any)] per rank
+    def _pack(self, slot, obs, rew, done):
         torch = self.torch
+        tac, feat = obs["tactile"], obs.get("extended_feature")
         packed = self.local.packed() if hasattr(self.local, "packed") else None   # the library's own contiguous output block
+        n = tac.shape[0]
         nb_t, nb_r, nb_d = tac.numel(), rew.numel() * 4, done.numel()
-        off_r = packed[1] if packed is not None else (nb_t + 15) & ~15
+        fw_obs = int(feat.shape[1]) if feat is not None else 0
+        if packed is not None:                       # (block, reward offset[, feature offset or -1]): the library's layout rules
+            off_r = packed[1]
+            off_f = packed[2] if len(packed) > 2 and packed[2] is not None else -1
+            total = packed[0].numel()
+            fw = (total - off_f) // (4 * n) if off_f >= 0 else 0       # the block's feature rows may be wider than the observation's
+        else:
+            off_r = (nb_t + 15) & ~15
+            off_f = ((off_r + nb_r + nb_d + 3) & ~3) if feat is not None else -1
+            fw = fw_obs
+            total = off_f + 4 * n * fw if feat is not None else off_r + nb_r + nb_d
         if self._layout is None:
             assert tac.dtype == torch.uint8 and rew.dtype == torch.float32 and done.dtype == torch.uint8
-            assert packed is None or packed[0].numel() == off_r + nb_r + nb_d
-            self._layout = (tuple(tac.shape), nb_t, off_r, nb_r, nb_d)
-        total = off_r + nb_r + nb_d
+            assert feat is None or (feat.dtype == torch.float32 and off_f >= 0 and fw >= fw_obs)
+            assert total >= off_r + nb_r + nb_d
+            self._layout = (tuple(tac.shape), nb_t, off_r, nb_r, nb_d, off_f, fw, fw_obs)
         if self._stage[slot] is None:
             self._stage[slot] = torch.zeros(total, dtype=torch.uint8, device=tac.device)
             if self.rank == self.root:
@@ -90,7 +102,9 @@ class ShardedVecEnv:
         else:
             st[:nb_t].copy_(tac.reshape(-1))
             st[off_r:off_r + nb_r].view(torch.float32).copy_(rew.reshape(-1))
-            st[off_r + nb_r:].copy_(done.reshape(-1))
+            st[off_r + nb_r:off_r + nb_r + nb_d].copy_(done.reshape(-1))
+            if feat is not None:
+                st[off_f:off_f + 4 * n * fw].view(torch.float32).reshape(n, fw)[:, :fw_obs].copy_(feat)
         if st.is_cuda and not getattr(self.local, "pipelined", False):
             # the sources alias the env library's device buffers, which the next step's kernels (on the library's own stream) overwrite:
             # the snapshot must have been taken before step() returns (a 17 MB device copy, ~6 us).  A pipelined shard runs the
@@ -106,12 +120,15 @@ class ShardedVecEnv:
 
     def _unpack(self, slot):
         torch = self.torch
-        shape, nb_t, off_r, nb_r, nb_d = self._layout
+        shape, nb_t, off_r, nb_r, nb_d, off_f, fw, fw_obs = self._layout
         full = self._full[slot]
-        tac = full[:, :nb_t].reshape((self.world * shape[0],) + shape[1:])
+        obs = {"tactile": full[:, :nb_t].reshape((self.world * shape[0],) + shape[1:])}
         rew = full[:, off_r:off_r + nb_r].contiguous().view(torch.float32).reshape(-1)
-        done = full[:, off_r + nb_r:].reshape(-1)
-        return {"tactile": tac}, rew, done
+        done = full[:, off_r + nb_r:off_r + nb_r + nb_d].reshape(-1)
+        if fw_obs:   # config 4's tactile_and_feature observation (object_push_env.py:611-629) reaches rank 0 in the same message
+            feat = full[:, off_f:off_f + 4 * shape[0] * fw].contiguous().view(torch.float32).reshape(self.world * shape[0], fw)
+            obs["extended_feature"] = feat[:, :fw_obs]
+        return obs, rew, done
 
     def step(self, local_actions):
         obs, rew, done, info = self.local.step(local_actions)
@@ -121,7 +138,7 @@ class ShardedVecEnv:
         if self._pending[slot] is not None:          # this staging buffer's previous gather (two steps ago) must be complete
             self._pending[slot].wait()
             self._pending[slot] = None
-        self._pack(slot, obs["tactile"], rew, done)
+        self._pack(slot, obs, rew, done)
         if not self.overlap:
             self._start_gather(slot, False)
             self._tick += 1
@@ -170,13 +187,19 @@ class TorchShard:
     def packed(self):
         return self.venv.packed_torch()
 
+    def _obs(self):
+        obs = {"tactile": self.venv.tactile_torch()}
+        if "feature" in self.venv.observation_mode and self.venv.feature_dim:
+            obs["extended_feature"] = self.venv.feature_torch()
+        return obs
+
     def reset(self):
         self.venv.reset()
-        return {"tactile": self.venv.tactile_torch()}
+        return self._obs()
 
     def step(self, actions):
         self.venv.step_async(actions)
         if not self.pipelined:
             self.venv.sync()
         rew, done = self.venv.reward_done_torch()
-        return {"tactile": self.venv.tactile_torch()}, rew, done, {}
+        return self._obs(), rew, done, {}

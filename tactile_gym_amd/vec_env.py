@@ -194,12 +194,14 @@ class TactileVecEnv:
         return self._views["rd"]
 
     def packed_torch(self):
-        """Zero-copy torch.uint8 view of the whole per-step output block [obs | pad | reward f32 | done u8] and the reward offset."""
+        """Zero-copy torch.uint8 view of the whole per-step output block [obs | pad | reward f32 | done u8 | pad | feature f32[N][12]],
+        the reward offset and the feature offset (-1: this env has no extended_feature)."""
         if "packed" not in self._views:
             import torch
-            p, ob, tot = C.c_void_p(), C.c_int64(), C.c_int64()
+            p, ob, tot, fo, fd = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
             capi.check(self._L.tg_get_packed_outputs(self._ctx, C.byref(p), C.byref(ob), C.byref(tot)))
-            self._views["packed"] = (torch.as_tensor(_DevArray(p.value, (tot.value,), "|u1"), device=f"cuda:{self._cfg.device}"), ob.value)
+            capi.check(self._L.tg_get_packed_feature(self._ctx, C.byref(fo), C.byref(fd)))
+            self._views["packed"] = (torch.as_tensor(_DevArray(p.value, (tot.value,), "|u1"), device=f"cuda:{self._cfg.device}"), ob.value, fo.value)
         return self._views["packed"]
 
     def tactile_numpy(self, terminal=False):
@@ -300,6 +302,8 @@ class TactileVecEnv:
         if self._cfg.env_kind == capi.ENV_OBJECT_ROLL:   # obj_mass: the episode's marble radius; goal_pos: the goal in the TCP frame
             out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
                        goal_pos=np.zeros((n, 3)), obj_mass=np.zeros(n))
+        if self._cfg.env_kind in (capi.ENV_OBJECT_PUSH, capi.ENV_OBJECT_ROLL):   # contact pairs of the last sim tick (tg_state_view)
+            out.update(contact_count=np.zeros(n, np.int32), contact_ids=np.zeros((n, 5), np.int32))
         if self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO:
             out.update(goal_pos=np.zeros((n, 3)), direction=np.zeros((n, 2)), surf_zoff=np.zeros(n, np.float32),
                        heights=np.zeros((n, self._cfg.surf_rows, self._cfg.surf_cols)))

@@ -53,6 +53,92 @@ class PackedOracleShard(OracleShard):
         return self._packed
 
 
+PUSH_MODES = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
+                  observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")
+
+
+class PushOracleShard:
+    """BASELINE config 4's shard (object_push-v0, tactile_and_feature): the observation dict carries `extended_feature` f32[n, 12]
+    (object_push_env.py:611-629) next to the tactile image.  packed=True mimics the library's output block
+    [obs | pad 16 | reward | done | pad 4 | feature] (tg_get_packed_outputs + tg_get_packed_feature)."""
+
+    def __init__(self, rank, n_local, seed, packed):
+        from oracle.ref_env import OracleObjectPushEnv
+        self.num_envs, self._use_packed = n_local, packed
+        self.envs = [OracleObjectPushEnv(seed=seed + rank * n_local + i, max_steps=1000, image_size=(128, 128), env_modes=PUSH_MODES)
+                     for i in range(n_local)]
+
+    @staticmethod
+    def _obs(dicts):
+        return {"tactile": torch.from_numpy(np.stack([d["tactile"] for d in dicts])),
+                "extended_feature": torch.from_numpy(np.stack([d["extended_feature"] for d in dicts]).astype(np.float32))}
+
+    def reset(self):
+        return self._obs([e.reset() for e in self.envs])
+
+    def step(self, actions):
+        outs = [e.step(actions[i].numpy()) for i, e in enumerate(self.envs)]
+        obs = self._obs([o[0] for o in outs])
+        rew = torch.tensor([o[1] for o in outs], dtype=torch.float32)
+        done = torch.tensor([o[2] for o in outs], dtype=torch.uint8)
+        nb = obs["tactile"].numel()
+        off = (nb + 15) & ~15
+        off_f = (off + 4 * rew.numel() + done.numel() + 3) & ~3
+        blk = torch.zeros(off_f + 4 * obs["extended_feature"].numel(), dtype=torch.uint8)
+        blk[:nb] = obs["tactile"].reshape(-1)
+        blk[off:off + 4 * rew.numel()] = rew.view(torch.uint8)
+        blk[off + 4 * rew.numel():off + 4 * rew.numel() + done.numel()] = done
+        blk[off_f:] = obs["extended_feature"].reshape(-1).view(torch.uint8)
+        self._packed = (blk, off, off_f)
+        return obs, rew, done, {}
+
+    def __getattr__(self, name):
+        if name == "packed" and self.__dict__.get("_use_packed"):
+            return lambda: self._packed
+        raise AttributeError(name)
+
+
+def _push_worker(rank, world, port, out_path, overlap, packed):
+    import torch.distributed as dist
+    from tactile_gym_amd.parallel import ShardedVecEnv
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    env = ShardedVecEnv(PushOracleShard(rank, N_LOCAL, SEED, packed), dist, overlap=overlap)
+    obs = env.reset()
+    assert obs["extended_feature"].shape == ((world if rank == 0 else 1) * N_LOCAL, 12)
+    gen = torch.Generator().manual_seed(11)
+    for _ in range(3):
+        acts = (torch.rand(world * N_LOCAL, 2, generator=gen) - 0.5) * 0.5 if rank == 0 else torch.zeros(world * N_LOCAL, 2)
+        obs, rew, done, _ = env.step(env.scatter_actions(acts))
+    if overlap:
+        last = env.flush()
+        if rank == 0:
+            obs, rew, done = last
+    if rank == 0:
+        torch.save({"tactile": obs["tactile"].clone(), "feature": obs["extended_feature"].clone(), "rew": rew.clone(), "done": done.clone()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap,packed", [(False, False), (True, True)])
+def test_tactile_and_feature_reaches_rank0_world2(tmp_path, overlap, packed):
+    """SURVEY 8e / BASELINE config 4: `extended_feature f32[N/R, 12]` travels to rank 0 in the same per-step message as the images."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_push_worker, args=(world, port, out, overlap, packed), nprocs=world, join=True)
+    got = torch.load(out)
+    ref = PushOracleShard(0, world * N_LOCAL, SEED, False)
+    ref.reset()
+    gen = torch.Generator().manual_seed(11)
+    for _ in range(3):
+        obs, rew, done, _ = ref.step((torch.rand(world * N_LOCAL, 2, generator=gen) - 0.5) * 0.5)
+    assert got["feature"].shape == (world * N_LOCAL, 12) and torch.equal(got["feature"], obs["extended_feature"])
+    assert torch.equal(got["tactile"], obs["tactile"]) and torch.allclose(got["rew"], rew) and torch.equal(got["done"], done)
+
+
 def _worker(rank, world, port, out_path, overlap=False, packed=False):
     import torch.distributed as dist
     from tactile_gym_amd.parallel import ShardedVecEnv

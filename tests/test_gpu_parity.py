@@ -513,13 +513,14 @@ def test_object_push_env_matches_oracle(arm, sensor, movement, traj):
     assert venv.observation_space["extended_feature"].shape == (12,) and venv.action_space.shape == (act_dim,)
     oracles = [OracleObjectPushEnv(seed=31 + i, max_steps=steps, image_size=(size, size), env_modes=modes) for i in range(n)]
     rng = np.random.default_rng(5)
-    touched = 0
+    touched, tip_ids = 0, set()
     for episode in range(2):
         obs = venv.reset()
         ref = [o.reset() for o in oracles]
         st = venv.get_state()
         for i, o in enumerate(oracles):
             assert st["reset_ticks"][i] == o.reset_ticks and st["obj_mass"][i] == o.cube.mass and st["goal_id"][i] == o.targ_traj_list_id
+            assert st["contact_count"][i] == o.scene.n_contacts and list(st["contact_ids"][i]) == list(o.scene.contact_ids)   # last blocking-move tick
             assert np.abs(st["q"][i] - o.arm.q).max() < 1e-9
             assert np.abs(st["body_pos"][i] - o.cube_pose()[0]).max() < 1e-12 and np.abs(st["body_rot"][i] - o.cube_pose()[1]).max() < 1e-12
             if traj == "simplex":
@@ -543,9 +544,14 @@ def test_object_push_env_matches_oracle(arm, sensor, movement, traj):
                 assert abs(rew[i] - rr) < 1e-6 and bool(done[i]) == rd and st["goal_id"][i] == o.targ_traj_list_id
                 assert np.abs(obs["extended_feature"][i] - ro["extended_feature"]).max() < 1e-6
                 assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (episode, step, i)
+                # contact-pair indices of the step's last sim tick: BIT-EXACT (count and ids in solver row order)
+                assert st["contact_count"][i] == o.scene.n_contacts, (episode, step, i)
+                assert list(st["contact_ids"][i]) == list(o.scene.contact_ids), (episode, step, i, st["contact_ids"][i], list(o.scene.contact_ids))
                 touched += int(o.scene.tip_depth < 1.0)
+                tip_ids.add(int(o.scene.contact_ids[o.scene.n_contacts - 1]))
         assert done.all()
     assert touched > n * steps          # the tip core really pushed the cube in most steps
+    assert max(tip_ids) >= 8            # and the compared ids include tip-core hull vertices, not only table corners
     venv.close()
 
 
@@ -594,6 +600,48 @@ def test_default_solver_equals_literal_solver(edge_modes):
         assert np.array_equal(da, db) and np.abs(ra - rb).max() < 1e-6
         assert np.array_equal(sa["reset_ticks"], sb["reset_ticks"])
         assert int((oa["tactile"] != ob["tactile"]).sum(axis=(1, 2, 3)).max()) <= 2, step
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,size,max_steps", [("edge_follow-v0", 128, 200), ("surface_follow-v0", 128, 200), ("object_balance-v0", 256, 250)])
+def test_default_solver_equals_literal_solver_at_config_scale(env_id, size, max_steps, edge_modes):
+    """The guard of the headline rate at the scale it is quoted on: 1024 envs x 260 steps (crossing the max_steps auto-resets of every
+    env, plus the early ones of envs that reach their goal / drop the pole) of BASELINE configs 2, 3 and 5, default solver (convergence
+    exit + run-time-licensed analytic fixed point) against pgs_full_sweeps=1 on the same seeds and actions.  Asserted:
+    joints and joint velocities within 1e-11 rad (rad/s) at every checkpoint, dones and reset tick counts exactly equal on every
+    step, rewards to float32 rounding, and at most 2 differing pixels per image (float32 straddles of the camera transform)."""
+    import tactile_gym_amd as tg
+    modes = {"edge_follow-v0": edge_modes, "surface_follow-v0": SURF_MODES, "object_balance-v0": BAL_MODES}[env_id]
+    act_dim = {"edge_follow-v0": 2, "surface_follow-v0": 3, "object_balance-v0": 2}[env_id]
+    n, steps = 1024, 260
+    kw = dict(num_envs=n, max_steps=max_steps, image_size=[size, size], env_modes=modes, seed=9)
+    a = tg.make_vec(env_id, **kw)
+    b = tg.make_vec(env_id, pgs_full_sweeps=True, **kw)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa["tactile"], ob["tactile"])
+    rng = np.random.default_rng(21)
+    worst_q, worst_px, n_done = 0.0, 0, 0
+    for step in range(steps):
+        act = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert np.array_equal(da, db), step
+        assert np.abs(ra - rb).max() < 1e-6, step
+        n_done += int(da.sum())
+        px = int((oa["tactile"] != ob["tactile"]).sum(axis=(1, 2, 3)).max())
+        worst_px = max(worst_px, px)
+        assert px <= 2, step
+        if step % 20 == 19 or step == steps - 1:
+            sa, sb = a.get_state(), b.get_state()
+            dq = max(float(np.abs(sa["q"] - sb["q"]).max()), float(np.abs(sa["qd"] - sb["qd"]).max()))
+            worst_q = max(worst_q, dq)
+            assert dq < 1e-11, (step, dq)
+            assert np.array_equal(sa["reset_ticks"], sb["reset_ticks"]) and np.array_equal(sa["step_count"], sb["step_count"])
+            if "body_pos" in sa:
+                assert np.abs(sa["body_pos"] - sb["body_pos"]).max() < 1e-10 and np.abs(sa["body_rot"] - sb["body_rot"]).max() < 1e-9
+    assert n_done >= n                     # every env went through at least one auto-reset
+    print(f"{env_id}: worst |dq| {worst_q:.2e}, worst differing pixels {worst_px}, resets {n_done}")
     a.close(); b.close()
 
 
@@ -837,8 +885,8 @@ def test_pipelined_shard_and_packed_outputs(edge_modes):
                 obs, rew, done, _ = shard.step(a)
                 hist.append((obs["tactile"].clone(), rew.clone(), done.clone()))      # ordered after the step on the same stream
             torch.cuda.synchronize()
-        packed, off = shard.packed()
-        assert off == (n * 128 * 128 + 15) // 16 * 16 and packed.numel() == off + 5 * n
+        packed, off, foff = shard.packed()
+        assert foff == -1 and off == (n * 128 * 128 + 15) // 16 * 16 and packed.numel() == off + 5 * n
         assert torch.equal(packed[:n * 128 * 128], obs["tactile"].reshape(-1))
         assert torch.equal(packed[off:off + 4 * n].view(torch.float32), rew) and torch.equal(packed[off + 4 * n:], done)
         outs.append([(t.cpu(), r.cpu(), d.cpu()) for t, r, d in hist])
@@ -1006,6 +1054,7 @@ def test_object_roll_env_matches_oracle(rand, control):
                 assert np.abs(st["body_pos"][i] - pos).max() < 1e-8 and np.abs(st["body_rot"][i] - R).max() < 1e-8, (episode, step, i)
                 assert abs(rew[i] - rr) < 1e-6 and bool(done[i]) == rd
                 assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (episode, step, i)
+                assert st["contact_count"][i] == o.scene.n_contacts and list(st["contact_ids"][i]) == list(o.scene.contact_ids), (episode, step, i)
                 ref_o, got_o = o.oracle_obs().copy(), oo[i].copy()
                 for sl in (slice(3, 7), slice(16, 20)):          # orientations are quaternions: q and -q are the same rotation (the work
                     if np.dot(ref_o[sl], got_o[sl]) < 0:         # frame's roll of -pi puts a resting marble right on the +-pi branch cut)
@@ -1016,6 +1065,36 @@ def test_object_roll_env_matches_oracle(rand, control):
     if rand:
         assert rolled > (1e-3 if control == "TCP_velocity_control" else 1e-4)   # embed distances above the 1.75 mm skin-to-core gap: it rolls
     venv.close()
+
+
+@pytest.mark.gpu
+def test_contact_indices_run_to_run_deterministic_full_size():
+    """1024 object_push envs (BASELINE config 4's per-GPU shard), two independent contexts with the same seeds and actions: the contact
+    sets (integer data) and the whole state are bit-identical run to run, step by step, and the contact sets are the physically
+    expected ones (four table corners of the resting cube's bottom face, plus a tip-core vertex once the tip touches)."""
+    import tactile_gym_amd as tg
+    n, steps = 1024, 6
+    a = tg.make_vec("object_push-v0", num_envs=n, max_steps=1000, image_size=[128, 128], env_modes=PUSH_MODES, seed=77, auto_reset=False)
+    b = tg.make_vec("object_push-v0", num_envs=n, max_steps=1000, image_size=[128, 128], env_modes=PUSH_MODES, seed=77, auto_reset=False)
+    a.reset(); b.reset()
+    rng = np.random.default_rng(3)
+    seen_tip = 0
+    for step in range(steps):
+        act = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+        a.step(act); b.step(act)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa["contact_count"], sb["contact_count"]) and np.array_equal(sa["contact_ids"], sb["contact_ids"]), step
+        assert np.array_equal(sa["q"], sb["q"]) and np.array_equal(sa["body_pos"], sb["body_pos"]) and np.array_equal(sa["body_rot"], sb["body_rot"])
+        ids, cnt = sa["contact_ids"], sa["contact_count"]
+        assert ((cnt >= 4) & (cnt <= 5)).all()                                   # the cube rests on four corners; the tip adds one
+        table = np.sort(ids[:, :4], axis=1)
+        # init orientation rpy (-pi, 0, pi/2): the bottom face is the +z face of the cube frame, i.e. the vertices with iz = 1 (odd ids)
+        assert (table == np.array([1, 3, 5, 7])).all(), step
+        tip = ids[np.arange(n), cnt - 1]
+        assert ((cnt == 4) | (tip >= 8)).all()
+        seen_tip += int((cnt == 5).sum())
+    assert seen_tip > n                                                          # most envs are pushing by the end
+    a.close(); b.close()
 
 
 @pytest.mark.gpu

@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0", "object_balance-v0", "object_push-v0", "object_roll-v0", "surface_follow-v2"],
                     help="headline = edge_follow-v0 (BASELINE configs[1]); surface_follow-v0 = configs[2]; object_balance-v0 = configs[4] "
                          "(use --image-size 256)")
+    ap.add_argument("--contact-mapping", default="auto", choices=["auto", "lane", "wave"],
+                    help="object_push / object_roll: one wavefront per env or one lane per env for the contact solve (tg_config.contact_mapping)")
+    ap.add_argument("--solver-iters", type=int, default=None, help="object_push / object_roll: override numSolverIterations (150); measurement aid, not a bench configuration")
     args = ap.parse_args()
 
     import torch
@@ -120,9 +123,10 @@ def main():
              "object_roll-v0": ROLL_MODES, "surface_follow-v2": VERT_MODES}[args.env]
     act_dim = 3 if args.env == "surface_follow-v0" else 2
     max_steps = {"object_balance-v0": 250, "object_push-v0": 1000, "object_roll-v0": 250}.get(args.env, 200)   # params/*_params.py max_ep_len
+    extra = dict(contact_mapping=args.contact_mapping, solver_iterations=args.solver_iters) if args.env in ("object_push-v0", "object_roll-v0") else {}
     venv = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
                        seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",
-                       pgs_full_sweeps=args.full_sweeps)
+                       pgs_full_sweeps=args.full_sweeps, **extra)
     # device-resident rollout: the step is enqueued on a torch stream and its outputs are consumed on that stream (no host wait per
     # step); --sync-steps restores the blocking VecEnv.step_wait behaviour
     shard = TorchShard(venv, pipelined=not args.sync_steps)
@@ -184,7 +188,7 @@ def main():
         # the same workload with the literal solver (every tick: dynamics + all 150 PGS sweeps), for comparison; short run
         lit = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
                           seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",
-                          pgs_full_sweeps=True)
+                          pgs_full_sweeps=True, **extra)
         lshard = TorchShard(lit)
         lshard.reset()
         for _ in range(5):

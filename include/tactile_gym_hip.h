@@ -78,6 +78,7 @@ enum { TG_NOISE_FIXED_HEIGHT = 0, TG_NOISE_RAND_HEIGHT = 1 };                   
 enum { TG_SNOISE_SIMPLEX = 0, TG_SNOISE_NONE = 1, TG_SNOISE_RANDOM = 2, TG_SNOISE_VERTICAL_SIMPLEX = 3 };                   /* surface_follow noise_mode (base_surface_env.py:448-471) */
 enum { TG_REWARD_DENSE = 0, TG_REWARD_SPARSE = 1 };
 enum { TG_PHYSICS_F64 = 0, TG_PHYSICS_F32 = 1 };
+enum { TG_CONTACT_MAP_AUTO = 0, TG_CONTACT_MAP_LANE = 1, TG_CONTACT_MAP_WAVE = 2 };
 enum { TG_CONTROL_TCP_VELOCITY = 0, TG_CONTROL_TCP_POSITION = 1 };                             /* robot.py:156-186 apply_action */
 
 /* ---- task + engine configuration (env ctor kwargs / env_modes, edge_follow_env.py:23-134) ------------------------- */
@@ -175,6 +176,11 @@ typedef struct {
     double roll_goal_lo, roll_goal_hi;      /* goal distance U(0.005 | 0 with rand_init_pos, 0.015) (:256-259) */
     double tip_cyl_pos[3], tip_cyl_rot[9];  /* tip cylinder frame (axis z) in the frame of tip_link */
     double tip_cyl_half_len, tip_cyl_radius;
+    /* object_push / object_roll: how the contact solve of stepSimulation (robot.py:141; 150 PGS sweeps, base_tactile_env.py:127-130) is
+     * mapped onto the GPU.  TG_CONTACT_MAP_WAVE: one 64-lane wavefront per env, one solver row per lane (fills the chip at ~1024 envs);
+     * TG_CONTACT_MAP_LANE: one lane per env (fewer instructions per env, better once every SIMD is busy); AUTO picks by num_envs.
+     * Same solver, same row order; results agree to rounding (f64), contact sets exactly. */
+    int32_t contact_mapping;                /* TG_CONTACT_MAP_* */
 } tg_config;
 
 typedef struct tg_ctx tg_ctx;

@@ -25,6 +25,7 @@ MOVE = {"xy": 0, "xyz": 1, "xyRz": 2, "xyzRz": 3}
 NOISE = {"fixed_height": 0, "rand_height": 1}
 REWARD = {"dense": 0, "sparse": 1}
 PHYSICS = {"f64": 0, "f32": 1}
+CONTACT_MAP = {"auto": 0, "lane": 1, "wave": 2}
 MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
 
 _d3 = C.c_double * 3
@@ -89,6 +90,7 @@ class TgConfig(C.Structure):
         ("roll_rand_init_pos", C.c_int32), ("roll_rand_size", C.c_int32), ("roll_rand_embed", C.c_int32),
         ("roll_radius", C.c_double), ("roll_init_range", C.c_double), ("roll_goal_lo", C.c_double), ("roll_goal_hi", C.c_double),
         ("tip_cyl_pos", _d3), ("tip_cyl_rot", _d9), ("tip_cyl_half_len", C.c_double), ("tip_cyl_radius", C.c_double),
+        ("contact_mapping", C.c_int32),
     ]
 
 

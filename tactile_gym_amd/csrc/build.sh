@@ -1,17 +1,28 @@
 #!/bin/bash
 # Builds libtactile_gym_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
 #   tg_raster.hip and tg_noise.hip are compiled with -ffp-contract=off (bit-exact raster specification);
-#   tg_api.hip (physics, control, C ABI) with the default contraction (FMA).
+#   tg_api.hip (physics, control, C ABI) and tg_contact_wave.hip (wave-per-env contact solver) with the default contraction (FMA).
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../lib
 mkdir -p "$OUT"
-COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value"
-rm -f "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o"
-$HIPCC $COMMON -ffp-contract=off -c tg_raster.hip -o "$OUT/tg_raster.o" & p1=$!
-$HIPCC $COMMON -ffp-contract=off -c tg_noise.hip -o "$OUT/tg_noise.o" & p2=$!
-$HIPCC $COMMON -c tg_api.hip -o "$OUT/tg_api.o" & p3=$!
-wait $p1; wait $p2; wait $p3    # each wait returns its job's status: a failed translation unit fails the build (set -e)
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" -o "$OUT/libtactile_gym_hip.so"
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value ${TG_EXTRA_FLAGS:-}"
+# TG_INCREMENTAL=1 (development): keep an object whose translation unit and every header are older than it
+stale() {   # stale <object> <source>: 0 if the object must be rebuilt
+    [ "${TG_INCREMENTAL:-0}" = "1" ] || return 0
+    [ -f "$1" ] || return 0
+    for f in "$2" *.hpp *.h ../../include/*.h; do [ "$f" -nt "$1" ] && return 0; done
+    return 1
+}
+cc() {      # cc <name> <extra flags...>
+    local name=$1; shift
+    if stale "$OUT/$name.o" "$name.hip"; then rm -f "$OUT/$name.o"; $HIPCC $COMMON "$@" -c "$name.hip" -o "$OUT/$name.o"; fi
+}
+cc tg_raster -ffp-contract=off & p1=$!
+cc tg_noise -ffp-contract=off & p2=$!
+cc tg_api & p3=$!
+cc tg_contact_wave & p4=$!
+wait $p1; wait $p2; wait $p3; wait $p4    # each wait returns its job's status: a failed translation unit fails the build (set -e)
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" -o "$OUT/libtactile_gym_hip.so"
 echo "built $OUT/libtactile_gym_hip.so"

@@ -1,0 +1,17 @@
+// tg_contact_wave.h - launch interface of the wave-per-env contact solver (tg_contact_wave.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tg {
+
+struct State;
+
+// Enqueue one env step of object_push (env_kind TG_ENV_OBJECT_PUSH) or object_roll (TG_ENV_OBJECT_ROLL) on `stream` with the
+// wave-per-env mapping: one 64-lane wavefront per env, one solver row per lane.  d_robot / d_const: DevRobot<T> / EnvConst<T> of the
+// context (T by physics_dtype); n_tip_verts: hull vertices of the tip core (they are staged in LDS).  Returns 0, or -1 if the combination
+// is not instantiated (the caller then takes the lane-per-env kernels).
+int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int control_mode, int cone_friction, int num_envs, int n_tip_verts,
+                             hipStream_t stream,
+                             const void* d_robot, const void* d_const, const State& st, const float* d_actions);
+
+}  // namespace tg

@@ -1,0 +1,738 @@
+// tg_contact_wave.hip - object_push / object_roll env step with ONE WAVEFRONT PER ENV (gfx950).
+//
+// What it replaces: Robot.apply_action's 24 x stepSimulation (tactile_gym/robots/arms/robot.py:131-141,182-183) for the envs whose tick
+// carries rigid contacts (object_push_env.py:196-227, object_roll_env.py:203-248): joint motors + cube-table / cube-tip contacts with
+// Coulomb friction, 150 projected Gauss-Seidel sweeps per tick (base_tactile_env.py:127-130).  Same restated contact model as
+// tg_physics.hpp:sim_tick_push and oracle/minibullet.c:mb_step_push [PARITY_ASSUMPTIONS A23-A30], same row order.
+//
+// Why a second mapping.  sim_tick_push gives every env one LANE: 1024 envs are 16 wavefronts on a 256-CU chip, each a serial chain of
+// 3600 sweeps x ~800 f64 instructions per env step (7.4 ms, 98 % of the SIMDs idle).  Gauss-Seidel is sequential over rows, but what a
+// row update does to the other rows is not: here every solver ROW owns a lane and carries its residual in the Delassus form
+//     s_j = lambda_j + ( rhs_j - sum_k A_jk lambda_k - cfm_j lambda_j ) / (A_jj + cfm_j),      A = J Minv_sys J^T,
+// i.e. "what lambda_j would become if row j were relaxed now".  Relaxing row i changes lambda_i by d (clamp of s_i minus lambda_i, one
+// lane's work), and then every lane updates its own s_j -= G_ji d with ONE fused multiply-add, G_ji = A_ji / (A_jj + cfm_j) precomputed
+// per tick (zero diagonal: s_i itself is invariant under its own relaxation).  A row step is therefore
+//     clamp (2-3 VALU) -> v_readlane x2 (the delta becomes a scalar) -> v_fma_f64 (all rows at once)
+// instead of ~34 dependent instructions, a sweep ~250 instructions instead of ~800, and 1024 envs are 1024 wavefronts: one per SIMD of
+// the chip.  Lane-per-env remains the better mapping once the SIMDs are saturated (>= ~4096 envs per GPU: it needs 12 instructions per
+// env-sweep, this one ~250); tg_step picks by num_envs (tg_config.contact_mapping overrides).
+//
+// Lane layout (one env per wavefront):   lane i < N ............ joint motor i (btMultiBodyJointMotor row, J = e_i)
+//                                        lane 8 + 4c + r ....... contact c (0-3: cube vertex / marble on the table, 4: sensor tip),
+//                                                                r = 0 normal, 1 / 2 friction directions (btPlaneSpace1), r = 3 unused
+// Everything that is per env rather than per row (articulated-body dynamics, contact generation, integration) is evaluated redundantly
+// by all lanes - the values are wave-uniform, the cost is that of one lane - except the search over the 610 hull vertices of the tip
+// core, which the lanes share (10 vertices each + a wave argmin).
+//
+// Numerics: same mathematics, different summation order (A_ji lambda instead of J_j . dv) - agreement with the oracle is to rounding
+// amplified by the contact dynamics, tolerances as for sim_tick_push (joints 1e-9 rad, cube pose 1e-8, images <= 3 px); the contact
+// SETS (integer data) are identical.
+#include "tg_contact_wave.h"
+
+#include "tg_kernels.hpp"
+
+#include <cstdio>
+
+#ifndef TG_WAVE_TIMING
+#define TG_WAVE_TIMING 0          // 1: block 0 accumulates s_memtime ticks per tick phase into g_phase (development aid)
+#endif
+
+namespace tg {
+
+namespace {
+
+#if TG_WAVE_TIMING
+__device__ unsigned long long g_phase[16];
+#define TG_STAMP(K) { const unsigned long long now_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_phase[K] += now_ - t_prev_; t_prev_ = __builtin_readcyclecounter(); }
+#else
+#define TG_STAMP(K)
+#endif
+
+constexpr int kContactLane0 = 8;     // first contact lane
+constexpr int kRowLanes = 28;        // lanes 0..27 carry rows
+constexpr int kNG = 8 + 15;          // G entries: motors 0-7, contact (c, r) at 8 + 3c + r
+constexpr int kNU = 14;              // generalised velocity components: 8 joints + cube linear 3 + angular 3
+
+__device__ __forceinline__ double bcast(double v, int src_lane) {   // v_readlane_b32 x 2: the value of `src_lane` as a wave-uniform scalar
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
+    return u.d;
+}
+__device__ __forceinline__ float bcast(float v, int src_lane) {
+    union { float f; int i; } u;
+    u.f = v;
+    u.i = __builtin_amdgcn_readlane(u.i, src_lane);
+    return u.f;
+}
+// v_max_f64 / v_min_f64 as single instructions (fmax / fmin get a canonicalising v_max_f64 v, v, v in front of them; nothing here is NaN)
+__device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmax_neg(double a, double b) { double r; asm("v_max_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b)); return r; }   // max(a, -b)
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float vmax_neg(float a, float b) { return __builtin_fmaxf(a, -b); }
+__device__ __forceinline__ bool uniform_true(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; }   // scalar branch on a wave-uniform flag (v_cmp -> s_cmp)
+
+// One stepSimulation() tick; all arguments wave-uniform, `lane` = threadIdx.x.  scr: 23 * 16 words of LDS private to the wavefront.
+// ---- LDS layout of one env (words of T).  The env's state lives here for the whole step: every phase of a tick loads what it needs
+// and writes its results back (lane 0), so that nothing but a handful of scalars stays in registers from one phase to the next - the
+// register file belongs to the phase that runs (the dynamics need ~400 VGPRs, the sweeps ~150).
+constexpr int kLQ = 0, kLQd = 8, kLTrigS = 16, kLTrigC = 24, kLQDes = 32, kLQdDes = 40;      // arm: q, qd, sin q, cos q, motor targets
+constexpr int kLBody = 48;                                                                    // free body: pos 3, R 9, v 3, w 3
+constexpr int kLMinv = 66, kLV = 130;                                                         // per tick: Minv 8 x 8, unconstrained arm velocity
+constexpr int kLTipF = 138;                                                                   // tip link frame: origin 3, rotation 9
+constexpr int kLJa = 150, kLJo = 168;                                                         // joint axes / origins of the tip's ancestors, <= 6 x 3 each
+constexpr int kLFree = 186;                                                                   // vb 3, wb 3, xc 3 of the tick
+constexpr int kLW = 196;                                                                      // W rows, 23 x 16
+constexpr int kLHull = kLW + kNG * 16;                                                        // tip-core hull vertices, 3 per vertex
+
+#define TG_PHASE_FENCE() { __syncthreads(); asm volatile("" ::: "memory"); }
+
+// Phase 1 of a tick: articulated-body dynamics of the arm (wave-uniform: every lane evaluates the same thing, lane 0 writes).  In: q, qd,
+// carried sines / cosines (LDS).  Out (LDS): Minv, the unconstrained arm velocity v, the frame of the link that carries the tip and the
+// axes / origins of the joints on its path.  (Measured as an out-of-line call: 3x slower - with a call in the kernel the sweep loop's
+// coefficient rows are spilled to scratch and reloaded inside the sweeps.)
+template <typename T, int TOPO>
+__device__ __forceinline__ void tick_dynamics(const DevRobot<T>* __restrict__ mp, lds_ptr<T> L, int tip_link, T dt, int lane) {
+    constexpr int N = Topo<TOPO>::N;
+    constexpr int NP = Topo<TOPO>::NP;
+    // (The ~250 robot constants become loop invariants of the tick loop, overflow the SGPR file and come back through v_readlane from
+    // spill registers; measured alternatives were slower: re-issuing the s_loads every tick 42 -> 99 k cycles per tick, the constants
+    // in LDS 42 -> 77 k (VGPR spills), the phase as an out-of-line call 3x on the whole step.)
+    const DevRobot<T>& m = *mp;
+    const V3<T> gravity = load_v3(m.gravity);
+    {
+        T q[N], qd[N], Minv[N][N], v[N];
+        JointTrig<T, N> trig;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; trig.s[i] = L[kLTrigS + i]; trig.c[i] = L[kLTrigC + i]; }
+        Kin<T, TOPO> kin;
+        {
+            T hb[N], qdm[N], traceM;
+#ifdef TG_WAVE_NOTRIG
+            dynamics_terms<T, TOPO, false, false>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin);
+#else
+            dynamics_terms<T, TOPO, false, true>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin, &trig);   // gravity compensation cancels the bias force
+#endif
+            T rhs[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) rhs[i] = qdm[i] - m.joint_damp * qd[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                T acc = T(0);
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc += Minv[i][j] * rhs[j];
+                v[i] = qd[i] + dt * acc;
+            }
+        }
+        V3<T> ol; M3<T> Rl;
+        {
+            const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+            const T z3[3] = {T(0), T(0), T(0)};
+            link_frame<T, TOPO>(kin, tip_link, z3, ident, ol, Rl);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                L[kLV + i] = v[i];
+#pragma unroll
+                for (int j = 0; j < N; ++j) L[kLMinv + 8 * i + j] = Minv[i][j];
+            }
+            L[kLTipF + 0] = ol.x; L[kLTipF + 1] = ol.y; L[kLTipF + 2] = ol.z;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) L[kLTipF + 3 + e] = Rl.m[e];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                bool on_path = false;
+#pragma unroll
+                for (int l = 0; l < N; ++l)
+                    if (l == tip_link && is_ancestor_or_self<TOPO>(i, l)) on_path = true;
+                const T keep = on_path ? T(1) : T(0);           // joints off the tip's path get a zero axis: their Jacobian column vanishes
+                L[kLJa + 3 * i] = keep * kin.a[i].x; L[kLJa + 3 * i + 1] = keep * kin.a[i].y; L[kLJa + 3 * i + 2] = keep * kin.a[i].z;
+                L[kLJo + 3 * i] = kin.o[i].x; L[kLJo + 3 * i + 1] = kin.o[i].y; L[kLJo + 3 * i + 2] = kin.o[i].z;
+            }
+        }
+    }
+}
+
+// One stepSimulation() tick on the LDS-resident env state.  Returns the tick's contact code (tg_state_view.contact_ids).
+template <typename T, int TOPO, int MOTOR, int SHAPE, bool CONE>
+__device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const PushScene<T>& sc, lds_ptr<T> L, T kp, T kd, T max_force, T dt, int iters,
+                                                     T mass, int lane) {
+    constexpr int N = Topo<TOPO>::N;
+    constexpr int NP = Topo<TOPO>::NP;
+    int contact_code = 0;
+#if TG_WAVE_TIMING
+    unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
+    const V3<T> gravity = load_v3(m.gravity);
+    // =============================================================== phase 1: articulated-body dynamics (wave-uniform)
+    tick_dynamics<T, TOPO>(&m, L, sc.tip_link, dt, lane);
+    TG_PHASE_FENCE()
+    TG_STAMP(0)
+    // =============================================================== phase 2: free body, contact generation
+    FreeBody<T> b;
+    b.pos = mk(L[kLBody + 0], L[kLBody + 1], L[kLBody + 2]);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) b.R.m[e] = L[kLBody + 3 + e];
+    b.v = mk(L[kLBody + 12], L[kLBody + 13], L[kLBody + 14]);
+    b.w = mk(L[kLBody + 15], L[kLBody + 16], L[kLBody + 17]);
+    const T radius = mass;   // SHAPE 1: `mass` carries the episode's radius
+    const T iscale = SHAPE == 1 ? (radius / sc.radius0) * (radius / sc.radius0) : mass / sc.mass0, invm = T(1) / (SHAPE == 1 ? sc.mass0 : mass);
+    const S3<T> I0{sc.inertia0[0] * iscale, sc.inertia0[1] * iscale, sc.inertia0[2] * iscale, sc.inertia0[3] * iscale, sc.inertia0[4] * iscale,
+                   sc.inertia0[5] * iscale};
+    const S3<T> Iw = rotate(b.R, I0), Iwi = inverse(Iw);
+    const V3<T> xc = b.pos + mul(b.R, load_v3(sc.com));
+    V3<T> vb, wb;
+    {
+        const T sv = sc.lin_damp + sc.lin_damp * norm(b.v), sw = sc.ang_damp + sc.ang_damp * norm(b.w);
+        const V3<T> Iwv = mul(Iw, b.w);
+        const V3<T> Nt = (-sw) * Iwv - cross(b.w, Iwv);
+        vb = b.v + dt * (gravity - sv * b.v);
+        wb = b.w + dt * mul(Iwi, Nt);
+    }
+    if (lane == 0) {
+        L[kLFree + 0] = vb.x; L[kLFree + 1] = vb.y; L[kLFree + 2] = vb.z;
+        L[kLFree + 3] = wb.x; L[kLFree + 4] = wb.y; L[kLFree + 5] = wb.z;
+        L[kLFree + 6] = xc.x; L[kLFree + 7] = xc.y; L[kLFree + 8] = xc.z;
+    }
+    // ---- this lane's row
+    const int cl = lane - kContactLane0;
+    const int cc = cl >> 2, rr_ = cl & 3;                                   // contact slot and row within it
+    const bool contact_lane = lane >= kContactLane0 && lane < kRowLanes && rr_ < 3;
+    const bool tip_lane = contact_lane && cc == 4, table_lane = contact_lane && cc < 4, motor_lane = lane < N;
+    // ---- body - table contacts: the kept cube vertices take slots 0.. in vertex order; a table lane finds the vertex of its slot
+    V3<T> my_ra = mk<T>(0, 0, 0);
+    T my_depth = T(0);
+    int n_table = 0;
+    if constexpr (SHAPE == 1) {                                             // marble: its lowest point, one slot
+        const T vz0 = (b.pos.z - radius) - sc.table_z;
+        n_table = (vz0 <= sc.breaking) ? 1 : 0;
+        contact_code = n_table;
+        my_ra = mk(T(0), T(0), -radius);
+        my_depth = vz0;
+    } else {
+        T vz[8];
+        int keep = 0, cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const T lx = (c & 4) ? sc.half[0] : -sc.half[0], ly = (c & 2) ? sc.half[1] : -sc.half[1], lz = (c & 1) ? sc.half[2] : -sc.half[2];
+            vz[c] = (b.pos.z + (b.R.m[6] * lx + b.R.m[7] * ly + b.R.m[8] * lz)) - sc.table_z;
+            if (vz[c] <= sc.breaking) { keep |= 1 << c; ++cnt; }
+        }
+        while (cnt > 4) {   // manifold capacity: drop the shallowest (ties: the higher index)
+            int worst = -1; T wz = T(0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (((keep >> c) & 1) && (worst < 0 || vz[c] >= wz)) { worst = c; wz = vz[c]; }
+            keep &= ~(1 << worst); --cnt;
+        }
+        contact_code = keep;
+        n_table = cnt;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool mine = ((keep >> c) & 1) && __builtin_popcount(keep & ((1 << c) - 1)) == cc;
+            if (mine) {
+                const T lx = (c & 4) ? sc.half[0] : -sc.half[0], ly = (c & 2) ? sc.half[1] : -sc.half[1], lz = (c & 1) ? sc.half[2] : -sc.half[2];
+                my_ra = (b.pos + mul(b.R, mk(lx, ly, lz))) - xc;
+                my_depth = vz[c];
+            }
+        }
+    }
+    TG_STAMP(1)
+    // ---- body - tip contact (wave-uniform result)
+    V3<T> jt[NP];                       // translational Jacobian columns of the tip point
+    V3<T> tdir[3], trb;                 // row directions (n, t1, t2), contact arm on the body
+    T tip_depth; bool tip_active;
+    {
+        const V3<T> ol = mk(L[kLTipF + 0], L[kLTipF + 1], L[kLTipF + 2]);
+        M3<T> Rl;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Rl.m[e] = L[kLTipF + 3 + e];
+        V3<T> nrm, pa, pb;
+        if constexpr (SHAPE == 1) {     // marble - tip: closest point of the solid cylinder to the sphere centre
+            const V3<T> cw = ol + mul(Rl, load_v3(sc.cyl_pos));
+            const M3<T> Rw = mul(Rl, sc.cyl_rot);
+            const V3<T> p = mulT(Rw, b.pos - cw);
+            const T rad = tsqrt(p.x * p.x + p.y * p.y);
+            const T sr = rad > sc.cyl_r ? sc.cyl_r / rad : T(1);
+            const V3<T> clp = mk(p.x * sr, p.y * sr, p.z > sc.cyl_hl ? sc.cyl_hl : (p.z < -sc.cyl_hl ? -sc.cyl_hl : p.z));
+            const V3<T> g = p - clp;
+            const T dist = tsqrt(dot(g, g));
+            tip_depth = dist - radius;
+            tip_active = dist > T(0) && tip_depth <= sc.breaking;
+            contact_code |= tip_active ? (1 << 8) : 0;
+            const T idist = T(1) / (dist > T(0) ? dist : T(1));
+            const V3<T> gw = mul(Rw, idist * g);
+            nrm = mk<T>(0, 0, 0) - gw;
+            pa = cw + mul(Rw, clp);
+            pb = b.pos - radius * gw;
+        } else {                        // cube - tip core: hull vertex with the smallest signed distance to the box; lanes share the search
+            M3<T> Mr;   // cube <- link rotation  Rc^T Rl
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Mr.m[3 * i + j] = b.R.m[i] * Rl.m[j] + b.R.m[3 + i] * Rl.m[3 + j] + b.R.m[6 + i] * Rl.m[6 + j];
+            const V3<T> tr = mulT(b.R, ol - b.pos);
+            T best_key = T(1e30); int best_i = 0x7fffffff;
+            const int n_tip = __builtin_amdgcn_readfirstlane(sc.n_tip);
+            for (int i0 = 0; i0 < n_tip; i0 += 64) {       // lane l takes vertices l, l + 64, ... (LDS, stride-3 words: conflict free)
+                const int i = i0 + lane;
+                const int ii = i < n_tip ? i : 0;
+                const V3<T> vv = mk(L[kLHull + 3 * ii], L[kLHull + 3 * ii + 1], L[kLHull + 3 * ii + 2]);
+                const V3<T> p = tr + mul(Mr, vv);
+                const T qx = tabs(p.x) - sc.half[0], qy = tabs(p.y) - sc.half[1], qz = tabs(p.z) - sc.half[2];
+                const T ox = tmax(qx, T(0)), oy = tmax(qy, T(0)), oz = tmax(qz, T(0));
+                const T s2 = ox * ox + oy * oy + oz * oz;
+                const T mq = tmax(tmax(qx, qy), qz);
+                const T key = s2 > T(0) ? s2 : mq;         // outside: squared distance (> 0); inside: largest face distance (<= 0)
+                if (i < n_tip && key < best_key) { best_key = key; best_i = i; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {      // wave argmin; equal keys: the lower index, as a sequential scan finds it
+                const T ok = __shfl_xor(best_key, off);
+                const int oi = __shfl_xor(best_i, off);
+                if (ok < best_key || (ok == best_key && oi < best_i)) { best_key = ok; best_i = oi; }
+            }
+            best_i = n_tip > 0 ? __builtin_amdgcn_readfirstlane(best_i) : 0;
+            const V3<T> vv = mk(L[kLHull + 3 * best_i], L[kLHull + 3 * best_i + 1], L[kLHull + 3 * best_i + 2]);
+            const V3<T> w = ol + mul(Rl, vv);
+            const V3<T> p = mulT(b.R, w - b.pos);
+            const T pp[3] = {p.x, p.y, p.z};
+            T qq[3], oo[3], g[3] = {T(0), T(0), T(0)};
+#pragma unroll
+            for (int x = 0; x < 3; ++x) { qq[x] = tabs(pp[x]) - sc.half[x]; oo[x] = qq[x] > T(0) ? qq[x] : T(0); }
+            const T outside = tsqrt(oo[0] * oo[0] + oo[1] * oo[1] + oo[2] * oo[2]);
+            T sdf;
+            if (outside > T(0)) {
+                sdf = outside;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) g[x] = oo[x] / outside * (pp[x] < T(0) ? T(-1) : T(1));
+            } else {
+                const int ax = (qq[0] >= qq[1] && qq[0] >= qq[2]) ? 0 : ((qq[1] >= qq[2]) ? 1 : 2);
+                sdf = ax == 0 ? qq[0] : (ax == 1 ? qq[1] : qq[2]);
+#pragma unroll
+                for (int x = 0; x < 3; ++x) g[x] = (x == ax) ? (pp[x] < T(0) ? T(-1) : T(1)) : T(0);
+            }
+            tip_depth = sdf - (sc.margin_tip + sc.margin_cube);
+            tip_active = tip_depth <= sc.breaking && n_tip > 0;
+            contact_code |= tip_active ? ((1 << 8) | (best_i << 9)) : 0;
+            nrm = mul(b.R, mk(g[0], g[1], g[2]));   // from the cube towards the tip
+            pa = w - sc.margin_tip * nrm; pb = w - (sdf - sc.margin_cube) * nrm;
+        }
+        V3<T> t1, t2;
+        plane_space(nrm, t1, t2);
+        tdir[0] = nrm; tdir[1] = t1; tdir[2] = t2;
+        trb = pb - xc;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const V3<T> ai = mk(L[kLJa + 3 * i], L[kLJa + 3 * i + 1], L[kLJa + 3 * i + 2]);      // zero for joints off the tip's path
+            const V3<T> oi = mk(L[kLJo + 3 * i], L[kLJo + 3 * i + 1], L[kLJo + 3 * i + 2]);
+            jt[i] = cross(ai, pa - oi);
+        }
+    }
+    TG_STAMP(2)
+    const T denom = dt * sc.tip_stiffness + sc.tip_damping;   // soft contact: cfm = 1 / (dt (dt k + d)), erp = dt k / (dt k + d)
+    const T cfm_tip = (T(1) / denom) / dt, erp_tip = dt * sc.tip_stiffness / denom;
+    // ---- row of this lane: J = [ja | sg d | sg (rr x d)], W = Minv_sys J^T
+    V3<T> d;
+    {
+        const V3<T> dt_ = rr_ == 0 ? tdir[0] : (rr_ == 1 ? tdir[1] : tdir[2]);
+        const V3<T> dw = rr_ == 0 ? mk(T(0), T(0), T(1)) : (rr_ == 1 ? mk(T(0), T(-1), T(0)) : mk(T(1), T(0), T(0)));   // btPlaneSpace1 of +z
+        d = tip_lane ? dt_ : dw;
+    }
+    const V3<T> rarm = tip_lane ? trb : my_ra;
+    const T sg = tip_lane ? T(-1) : T(1);
+    T ja[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const T jt_d = i < NP ? dot(jt[i < NP ? i : 0], d) : T(0);
+        ja[i] = motor_lane ? (lane == i ? T(1) : T(0)) : (tip_lane ? jt_d : T(0));
+    }
+    T Warm[N];
+    T rv = T(0), rm = T(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc += L[kLMinv + 8 * k + i] * ja[i];
+        Warm[k] = acc;
+        const T vk = L[kLV + k];
+        rv += ja[k] * vk;
+        const T pos_term = (MOTOR == kMotorPosition) ? kp * (L[kLQDes + k] - L[kLQ + k]) / dt : T(0);   // motor: velocity-level target minus
+        const T des = pos_term + vk + kd * (L[kLQdDes + k] - vk);                                       // the unconstrained velocity
+        rm = lane == k ? des - vk : rm;
+    }
+    const V3<T> Jl = contact_lane ? sg * d : mk<T>(0, 0, 0);
+    const V3<T> Ja = contact_lane ? sg * cross(rarm, d) : mk<T>(0, 0, 0);
+    const V3<T> Wl = invm * Jl, Wa = mul(Iwi, Ja);
+    T A = dot(Jl, Wl) + dot(Ja, Wa);
+    rv += dot(Jl, vb) + dot(Ja, wb);
+#pragma unroll
+    for (int i = 0; i < N; ++i) A += ja[i] * Warm[i];
+    bool active;
+    T rhs, cfm = T(0);
+    {
+        const T depth = tip_lane ? tip_depth : my_depth;
+        const T erp = tip_lane ? erp_tip : sc.erp;
+        const T rhs_n = (depth > T(0)) ? (-rv - depth / dt) : (-depth * erp / dt - rv);
+        rhs = motor_lane ? rm : (rr_ == 0 ? rhs_n : -rv);
+        if (tip_lane && rr_ == 0) cfm = cfm_tip;
+        active = motor_lane ? (MOTOR != kMotorOff) : (tip_lane ? tip_active : (table_lane && cc < n_table));
+    }
+    const T jdi = active ? T(1) / (A + cfm) : T(0);
+    TG_STAMP(3)
+    // ---- coefficient row of this lane, one entry per solver row i (motor i -> i, contact (c, r) -> 8 + 3c + r):
+    //   row lanes        G[i] = (J_i . W_mine) / (A + cfm); own entry 1 on a motor / normal lane (it carries the residual r, which its
+    //                    own relaxation takes down by the full delta), 0 on a friction lane (it carries s = lambda + r, invariant there)
+    //   lanes 32 + k     G[i] = -W_i[k]: the lane accumulates component k of the velocity change  du = sum_i W_i lambda_i  (k < 14)
+    //   lanes 48 + j     G[i] = -[i == j]: the lane accumulates the impulse of joint motor j (checked against the motor limit)
+    // so that ONE v_fma_f64 per row step, x -= G[i] delta, advances the residuals, the velocities and the motor impulses together.
+    // H[i] = 1 on the lane that owns contact row i (else 0): lambda += H[i] delta is the in-lane impulse update without masks.
+    const bool fric_lane = contact_lane && rr_ > 0;
+    const T own_diag = fric_lane ? T(0) : T(1);
+    const int my_gi = motor_lane ? lane : (contact_lane ? 8 + 3 * cc + rr_ : -1);   // this lane's own row index
+    T G[kNG], H[kNG - 8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) G[i] = i < N ? Warm[i < N ? i : 0] * jdi : T(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int src = kContactLane0 + 4 * c;
+        if (SHAPE == 1 && c > 0) { G[8 + 3 * c] = G[8 + 3 * c + 1] = G[8 + 3 * c + 2] = T(0); continue; }
+        const T rax = bcast(my_ra.x, src), ray = bcast(my_ra.y, src), raz = bcast(my_ra.z, src);
+        G[8 + 3 * c + 0] = (Wl.z + (ray * Wa.x - rax * Wa.y)) * jdi;         // n  = (0, 0, 1):  J = [n,  ra x n]
+        G[8 + 3 * c + 1] = (-Wl.y + (raz * Wa.x - rax * Wa.z)) * jdi;        // t1 = (0,-1, 0)
+        G[8 + 3 * c + 2] = (Wl.x + (raz * Wa.y - ray * Wa.z)) * jdi;         // t2 = (1, 0, 0)
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const V3<T> dr = tdir[r];
+        T a = -dot(dr, Wl) - dot(cross(trb, dr), Wa);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) a += dot(jt[i], dr) * Warm[i];
+        G[8 + 12 + r] = a * jdi;
+    }
+    {   // W rows to LDS (row-major [row][k], zero for rows that are not active), then the accumulator lanes pick up their columns
+        if (my_gi >= 0) {
+            const T keep_ = active ? T(1) : T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) L[kLW + my_gi * 16 + k] = k < N ? Warm[k < N ? k : 0] * keep_ : T(0);
+            L[kLW + my_gi * 16 + 8] = Wl.x * keep_; L[kLW + my_gi * 16 + 9] = Wl.y * keep_; L[kLW + my_gi * 16 + 10] = Wl.z * keep_;
+            L[kLW + my_gi * 16 + 11] = Wa.x * keep_; L[kLW + my_gi * 16 + 12] = Wa.y * keep_; L[kLW + my_gi * 16 + 13] = Wa.z * keep_;
+        }
+        __syncthreads();
+        const int ku = lane - 32;
+#pragma unroll
+        for (int i = 0; i < kNG; ++i) {
+            const T wv = L[kLW + i * 16 + (ku >= 0 && ku < kNU ? ku : 0)];
+            const T g_row = lane == (i < 8 ? i : kContactLane0 + 4 * ((i - 8) / 3) + (i - 8) % 3) ? own_diag : G[i];
+            G[i] = (ku >= 0 && ku < kNU) ? -wv : ((lane >= 48 && lane < 48 + N) ? (i == lane - 48 ? T(-1) : T(0)) : (lane < 32 ? g_row : T(0)));
+            if (i >= 8) H[i - 8] = i == my_gi ? T(1) : T(0);
+        }
+    }
+    const T x0 = lane < 32 ? rhs * jdi : T(0);
+    int tip_i;                           // wave-uniform flag in an SGPR (s_cmp + s_cbranch_scc in the sweeps, no lane-mask round trip)
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(tip_i) : "v"(tip_active ? 1 : 0));
+    TG_PHASE_FENCE()
+    TG_STAMP(4)
+    // =============================================================== phase 3: 150 projected Gauss-Seidel sweeps
+    // Per lane: x (the residual r on motor / normal lanes, s = lambda + r on friction lanes, an accumulator above lane 31) and lambda.
+    // With one wavefront per SIMD nothing hides the latency of a dependent f64 instruction (~10 cycles; a v_readlane -> scalar operand ->
+    // v_fma round trip ~30, measured), so a sweep costs its dependent chain and every step is written for depth:
+    //     motor (no limit in reach)   v_readlane x2 -> v_fma
+    //     motor (limits)              v_max -> v_min -> v_readlane x2 -> v_fma
+    //     normal                      v_max(x, -lambda) -> v_readlane x2 -> v_fma
+    //     friction pair               v_readlane x4 -> |s|^2 (2) -> v_rsq_f64 + one Newton step folded into limit / |s| (3) -> v_min(., 1)
+    //                                 -> v_fma (delta) -> v_readlane x4 -> 2 v_fma
+    // Motor rows and table-contact rows do not interact (their G entries are exact zeros: the table touches only the free body, a motor
+    // only the arm), so the table normals are issued between the motor steps - same results bit for bit, their chains overlap.
+    // Joint motors: the impulse limit max_force dt (1000 N m x 1/240 s) is ~1e4 times what these arms ever need, so the sweeps run without
+    // the motor clamp while lanes 48.. watch every motor impulse of every sweep; a tick in which the limit would have been reached is
+    // solved again with the clamped step (identical arithmetic otherwise).
+    T x = x0, lam = T(0);
+    const T maximp = max_force * dt;
+#pragma unroll
+    for (int i = 0; i < kNG; ++i) asm volatile("" : "+v"(G[i]));          // coefficient rows in architectural VGPRs for the sweeps (the allocator
+#pragma unroll
+    for (int i = 0; i < kNG - 8; ++i) asm volatile("" : "+v"(H[i]));      // otherwise parks some of them in AGPRs: two v_accvgpr_read per use)
+    T mu_table = sc.mu_table, mu_tip = sc.mu_tip;
+    asm volatile("" : "+v"(mu_table), "+v"(mu_tip));   // VGPR copies: a VALU instruction takes one scalar operand, and the impulse is one already
+    const int n_it = __builtin_amdgcn_readfirstlane(iters < 0 ? -iters : iters);   // contact problems do not reach their fixed point within 150 sweeps: no exit test
+    const bool watch_lane = lane >= 48 && lane < 48 + N;
+
+#define TG_MOTOR_STEP(I)                                                               \
+    {                                                                                  \
+        T dd_;                                                                         \
+        if (CLAMPED) {                                                                 \
+            dd_ = bcast(vmin(vmax(x, -maximp - lam), maximp - lam), (I));              \
+            lam = lane == (I) ? lam + dd_ : lam;                                       \
+        } else dd_ = bcast(x, (I));                                                    \
+        x = __builtin_fma(-G[(I)], dd_, x);                                            \
+    }
+#define TG_NORMAL_STEP(ROW_LANE, GI)                                                   \
+    {                                                                                  \
+        const T dd_ = bcast(vmax_neg(x, lam), (ROW_LANE));                             \
+        x = __builtin_fma(-G[(GI)], dd_, x);                                           \
+        lam = __builtin_fma(H[(GI) - 8], dd_, lam);                                    \
+    }
+#define TG_FRICTION_STEP(NLANE, GI, MU)                                                \
+    {                                                                                  \
+        const T s1_ = bcast(x, (NLANE) + 1), s2_ = bcast(x, (NLANE) + 2);              \
+        const T limit_ = (MU) * bcast(lam, (NLANE));                                   \
+        T dl_;                                                                         \
+        if (CONE) {                                                                    \
+            const T tot2_ = __builtin_fma(s2_, s2_, s1_ * s1_);                        \
+            const T y_ = __builtin_amdgcn_rsq(tot2_);                                  \
+            const T t_ = tot2_ * y_, lh_ = (T(0.5) * limit_) * y_, ly_ = limit_ * y_;  \
+            const T e_ = __builtin_fma(-t_, y_, T(1));                                 \
+            /* min(1, limit / |s|): one Newton step on the hardware seed (5e-8 -> 4e-15 relative, measured); |s| = 0 gives NaN, which */ \
+            /* v_min_f64 drops in favour of the 1 */                                   \
+            const T f_ = vmin(__builtin_fma(lh_, e_, ly_), T(1));                      \
+            dl_ = __builtin_fma(x, f_, -lam);                                          \
+        } else {                                                                       \
+            dl_ = vmin(vmax(x, -limit_), limit_) - lam;                                \
+        }                                                                              \
+        const T d1_ = bcast(dl_, (NLANE) + 1), d2_ = bcast(dl_, (NLANE) + 2);          \
+        x = __builtin_fma(-G[(GI)], d1_, x);                                           \
+        x = __builtin_fma(-G[(GI) + 1], d2_, x);                                       \
+        lam = __builtin_fma(H[(GI) - 8], d1_, lam);                                    \
+        lam = __builtin_fma(H[(GI) - 7], d2_, lam);                                    \
+    }
+    // one sweep: motors in forward (FWD) or reverse order with the table normals between them, tip normal, friction pairs
+#define TG_SWEEP(FWD)                                                                  \
+    {                                                                                  \
+        if (MOTOR != kMotorOff) {                                                      \
+            _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_) {                         \
+                const int i_ = (FWD) ? k_ : N - 1 - k_;                                \
+                TG_MOTOR_STEP(i_)                                                      \
+                if (k_ < (SHAPE == 1 ? 1 : 4)) TG_NORMAL_STEP(kContactLane0 + 4 * k_, 8 + 3 * k_) \
+            }                                                                          \
+        } else {                                                                       \
+            _Pragma("unroll") for (int k_ = 0; k_ < (SHAPE == 1 ? 1 : 4); ++k_) TG_NORMAL_STEP(kContactLane0 + 4 * k_, 8 + 3 * k_) \
+        }                                                                              \
+        if (CLAMPED == 0) viol |= __builtin_amdgcn_ballot_w64(watch_lane && tabs(x) > maximp); \
+        if (tip_i) TG_NORMAL_STEP(kContactLane0 + 16, 8 + 12)                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < (SHAPE == 1 ? 1 : 4); ++k_) TG_FRICTION_STEP(kContactLane0 + 4 * k_, 8 + 3 * k_ + 1, mu_table) \
+        if (tip_i) TG_FRICTION_STEP(kContactLane0 + 16, 8 + 13, mu_tip)                \
+    }
+#define TG_SOLVE()                                                                     \
+    {                                                                                  \
+        int it_ = 0;                                                                   \
+        for (; it_ + 1 < n_it; it_ += 2) { TG_SWEEP(false) TG_SWEEP(true) } \
+        if (it_ < n_it) TG_SWEEP(false)                                                \
+    }
+    uint64_t viol = 0;
+    {
+        constexpr int CLAMPED = 0;
+        TG_SOLVE()
+    }
+    if (viol != 0) {                      // a motor impulse reached its limit somewhere in this tick: the literal clamped iteration
+        constexpr int CLAMPED = 1;
+        x = x0; lam = T(0);
+        TG_SOLVE()
+    }
+#undef TG_SOLVE
+#undef TG_SWEEP
+#undef TG_FRICTION_STEP
+#undef TG_NORMAL_STEP
+#undef TG_MOTOR_STEP
+    TG_STAMP(5)
+    // =============================================================== phase 4: integrate (lanes 32 .. 45 hold du)
+    T du[kNU];
+#pragma unroll
+    for (int k = 0; k < kNU; ++k) du[k] = bcast(x, 32 + k);
+    asm volatile("" ::: "memory");
+    {
+        T q[N], dq[N], qd[N];
+        JointTrig<T, N> trig;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            q[i] = L[kLQ + i]; trig.s[i] = L[kLTrigS + i]; trig.c[i] = L[kLTrigC + i];
+            qd[i] = L[kLV + i] + du[i];
+            dq[i] = dt * qd[i];
+            q[i] += dq[i];
+        }
+        trig_advance<T, N>(q, dq, trig);
+        FreeBody<T> bn;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) bn.R.m[e] = L[kLBody + 3 + e];
+        bn.v = mk(L[kLFree + 0], L[kLFree + 1], L[kLFree + 2]) + mk(du[8], du[9], du[10]);
+        bn.w = mk(L[kLFree + 3], L[kLFree + 4], L[kLFree + 5]) + mk(du[11], du[12], du[13]);
+        const V3<T> xn = mk(L[kLFree + 6], L[kLFree + 7], L[kLFree + 8]) + dt * bn.v;
+        integrate_rotation(bn.R, bn.w, dt);
+        bn.pos = xn - mul(bn.R, load_v3(sc.com));
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { L[kLQ + i] = q[i]; L[kLQd + i] = qd[i]; L[kLTrigS + i] = trig.s[i]; L[kLTrigC + i] = trig.c[i]; }
+            L[kLBody + 0] = bn.pos.x; L[kLBody + 1] = bn.pos.y; L[kLBody + 2] = bn.pos.z;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) L[kLBody + 3 + e] = bn.R.m[e];
+            L[kLBody + 12] = bn.v.x; L[kLBody + 13] = bn.v.y; L[kLBody + 14] = bn.v.z;
+            L[kLBody + 15] = bn.w.x; L[kLBody + 16] = bn.w.y; L[kLBody + 17] = bn.w.z;
+        }
+    }
+    TG_PHASE_FENCE()
+    TG_STAMP(6)
+    return contact_code;
+}
+
+// BaseTactileEnv.step (base_tactile_env.py:166-185) for object_push (SHAPE 0) / object_roll (SHAPE 1), one wavefront per env.
+template <typename T, int TOPO, bool POS, int SHAPE, bool CONE>
+__global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                          const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double wave_lds_raw[];
+    const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const EnvConst<T>& c = *cp;
+    const int n = c.num_envs;
+    const T mass_or_radius = (T)st.obj_mass[env];
+    T work_dz = T(0);
+    if constexpr (SHAPE == 1) work_dz = (T)((2.0 * st.obj_mass[env] - st.embed[env]) - (double)c.work_pos[2]);   // update_workframe (object_roll_env.py:192-201)
+    const int step_count = st.step_count[env] + 1;
+    if constexpr (SHAPE == 0) {          // tip-core hull vertices: HBM -> LDS once per step (coalesced)
+        const T* tipv = (const T*)st.tip_verts;
+        const int nw = 3 * c.push.n_tip;
+        for (int w = lane; w < nw; w += 64) L[kLHull + w] = tipv[w];
+    }
+    V3<T> tpos; Q4<T> tq;                // TCP_position_control: the pose target of the blocking move
+    {   // ---- controller (once per step): action -> joint targets, state -> LDS
+        T q[N], qd[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+        const FreeBody<T> b = load_body<T>(st, n, env);
+        const float* a = actions + (size_t)env * c.act_dim;
+        T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        if constexpr (SHAPE == 1) {                           // encode_actions "xy" (object_roll_env.py:297-309)
+            enc[0] = (T)a[0]; enc[1] = (T)a[1];
+        } else {                                              // encode_actions (object_push_env.py:372-454)
+            if (c.movement_mode == TG_PMOVE_Y) { enc[0] = c.max_action; enc[1] = (T)a[0]; }
+            else if (c.movement_mode == TG_PMOVE_YRZ) { enc[0] = c.max_action; enc[1] = (T)a[0]; enc[5] = (T)a[1]; }
+            else if (c.movement_mode == TG_PMOVE_XYRZ) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[5] = (T)a[2]; }
+            else {                                            // TCP-frame moves: along / across the sensor's pointing direction
+                Kin<T, TOPO> k;
+                forward_kinematics<T, TOPO>(m, q, k);
+                V3<T> ptcp; M3<T> Rtcp;
+                link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+                const M3<T> Rq = mat_from_quat(quat_from_mat(Rtcp));
+                const V3<T> par = mul(c.work_Rinv, mul(Rq, mk(T(1), T(0), T(0)))), perp = mul(c.work_Rinv, mul(Rq, mk(T(0), T(-1), T(0))));
+                if (c.movement_mode == TG_PMOVE_TYRZ) {
+                    const T pa_ = T(1) * c.max_action;
+                    enc[0] += perp.x * (T)a[0] + par.x * pa_;
+                    enc[1] += perp.y * (T)a[0] + par.y * pa_;
+                    enc[5] += (T)a[1];
+                } else {
+                    enc[0] += perp.x * (T)a[1] + par.x * (T)a[0];
+                    enc[1] += perp.y * (T)a[1] + par.y * (T)a[0];
+                    enc[5] += (T)a[2];
+                }
+            }
+        }
+        T vels[6];
+        scale_actions<T>(c, enc, vels);
+        T qd_des[N];
+        if constexpr (POS) tcp_position_target<T, TOPO>(m, c, q, vels, tpos, tq, qd_des, work_dz);   // qd_des carries the joint targets
+        else tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, nullptr, work_dz);
+        JointTrig<T, N> trig;
+        trig_init<T, N>(q, trig);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool in = i < N;
+                L[kLQ + i] = in ? q[in ? i : 0] : T(0); L[kLQd + i] = in ? qd[in ? i : 0] : T(0);
+                L[kLTrigS + i] = in ? trig.s[in ? i : 0] : T(0); L[kLTrigC + i] = in ? trig.c[in ? i : 0] : T(1);
+                L[kLQDes + i] = (POS && in) ? qd_des[in ? i : 0] : T(0);
+                L[kLQdDes + i] = (!POS && in) ? qd_des[in ? i : 0] : T(0);
+            }
+            L[kLBody + 0] = b.pos.x; L[kLBody + 1] = b.pos.y; L[kLBody + 2] = b.pos.z;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) L[kLBody + 3 + e] = b.R.m[e];
+            L[kLBody + 12] = b.v.x; L[kLBody + 13] = b.v.y; L[kLBody + 14] = b.v.z;
+            L[kLBody + 15] = b.w.x; L[kLBody + 16] = b.w.y; L[kLBody + 17] = b.w.z;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = POS ? 0.0 : (double)qd_des[i];
+    }
+    TG_PHASE_FENCE()
+    int ccode = 0;
+    if constexpr (POS) {                                  // blocking_move(max_steps, constant_vel=None), robot.py:188-260
+        for (int t = 0; t < c.max_blocking; ++t) {
+            T q[N], qd[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
+            const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+            ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE>(m, c.push, L, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters,
+                                                                                mass_or_radius, lane);
+            if (uniform_true(stop)) break;
+        }
+    } else {
+        for (int t = 0; t < c.action_repeat; ++t)
+            ccode = sim_tick_contact_wave<T, TOPO, kMotorVelocity, SHAPE, CONE>(m, c.push, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters,
+                                                                                mass_or_radius, lane);
+    }
+    // ---- results: every lane holds the same values; identical values go to identical addresses
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
+    FreeBody<T> b;
+    b.pos = mk(L[kLBody + 0], L[kLBody + 1], L[kLBody + 2]);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) b.R.m[e] = L[kLBody + 3 + e];
+    b.v = mk(L[kLBody + 12], L[kLBody + 13], L[kLBody + 14]);
+    b.w = mk(L[kLBody + 15], L[kLBody + 16], L[kLBody + 17]);
+    st.step_count[env] = step_count;
+    st.contact_code[env] = ccode;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    store_body<T>(st, n, env, b);
+    if constexpr (SHAPE == 1) finish_roll<T, TOPO>(m, c, st, env, q, b, mass_or_radius / (T)c.roll_radius, step_count, true);
+    else finish_push<T, TOPO>(m, c, st, env, q, b, step_count, true);
+}
+
+template <typename T, int TOPO, int SHAPE>
+int launch_wave_t(int control_mode, int cone, int n, int n_tip, hipStream_t stream, const void* d_robot, const void* d_const, const State& st, const float* d_actions) {
+    const size_t lds_bytes = (size_t)(kLHull + (SHAPE == 1 ? 0 : 3 * n_tip)) * sizeof(T);   // env state + per-tick hand-offs + the tip-core hull
+    if (lds_bytes > 60 * 1024) return -1;                                                   // (1089 vertices: 31 KB; 4 envs per CU fit 160 KB)
+    if (!cone) return -1;                // pyramid friction (enableConeFriction = 0, not what the reference sets): the lane-per-env kernels
+    if (control_mode == TG_CONTROL_TCP_POSITION)
+        hipLaunchKernelGGL((k_step_contact_wave<T, TOPO, true, SHAPE, true>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
+                           (const EnvConst<T>*)d_const, st, d_actions);
+    else
+        hipLaunchKernelGGL((k_step_contact_wave<T, TOPO, false, SHAPE, true>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
+                           (const EnvConst<T>*)d_const, st, d_actions);
+    return 0;
+}
+
+}  // namespace
+
+int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int control_mode, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
+                             const void* d_robot, const void* d_const, const State& st, const float* d_actions) {
+#if TG_WAVE_TIMING
+    {
+        static int calls = 0;
+        if (++calls % 10 == 0) {
+            unsigned long long h[16];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h);
+            fprintf(stderr, "[wave timing] ticks per phase over %d steps:", calls - 1);
+            const char* names[7] = {"dynamics", "body+table", "tip", "row", "G", "sweeps", "integrate"};
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f", names[k], (double)h[k] / ((calls - 1) * 24.0));
+            fprintf(stderr, " (per tick)\n");
+        }
+    }
+#endif
+    if (physics_dtype != TG_PHYSICS_F64) return -1;       // the f32 variant keeps the lane-per-env mapping
+    if (env_kind == TG_ENV_OBJECT_PUSH) {
+        if (topology == 0) return launch_wave_t<double, 0, 0>(control_mode, cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_actions);
+        return launch_wave_t<double, 1, 0>(control_mode, cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_actions);
+    }
+    if (env_kind == TG_ENV_OBJECT_ROLL && topology == 0)
+        return launch_wave_t<double, 0, 1>(control_mode, cone_friction, num_envs, 0, stream, d_robot, d_const, st, d_actions);
+    return -1;
+}
+
+}  // namespace tg

@@ -1,0 +1,1495 @@
+// tg_kernels.hpp - device side of libtactile_gym_hip.so: task constants, per-env SoA state, the controller / reward / camera helpers
+// and the lane-per-env step / reset kernels (one lane = one env).  Included by tg_api.hip (C ABI + launches) and by
+// tg_contact_wave.hip (the wave-per-env contact solver of object_push / object_roll).
+//
+// Per-env state lives in HBM as struct-of-arrays with the env index minor ([field][num_envs], doubles), so a
+// wavefront of 64 consecutive envs reads or writes one 512-byte contiguous run per field: the whole dynamic state
+// crosses HBM exactly once per env step (in) and once (out); the 24 sim ticks in between run out of registers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "../../include/tactile_gym_hip.h"
+#include "tg_physics.hpp"
+
+namespace tg {
+
+// ------------------------------------------------------------------------------------------------ task constants
+template <typename T> struct EnvConst {
+    int num_envs, act_dim, movement_mode, noise_mode, reward_mode, max_steps, action_repeat, solver_iters;
+    T dt, min_action, max_action, act_lo[6], act_hi[6], tcp_lims[6][2];
+    T work_pos[3];
+    Q4<T> work_q, work_qinv;
+    M3<T> work_R, work_Rinv;
+    T work_inv_pos[3];
+    T stim_pos[3], edge_height, edge_len, term_dist, embed_default;
+    double embed_lo, embed_hi;   // random draws are evaluated in double on every path
+    M3<T> cam_rot;               // R(cam_rpy) in the sensor-body frame
+    T cam_pos[3];
+    // surface_follow
+    int env_kind, surf_rows, surf_cols, surf_goal, surf_vertical;
+    M3<T> stim_R;                // surface_follow-v2: rotation of the upright heightfield (identity otherwise)
+    double surf_scale, surf_range, surf_interp, surf_extent, auto_scale;
+    double xbin_lo, xbin_hi, ybin_lo, ybin_hi;   // np.linspace bounds of x_bins / y_bins (base_surface_env.py:258-282)
+    // object_balance
+    BodyConst<T> body;
+    M3<T> obj_init_rot;
+    T obj_init_rpy_deg[3], obj_base_width, obj_base_height, term_deg, term_pos, ext_force[3];
+    int rand_gravity, rand_embed;
+    double gravity_lo, gravity_hi, gravity_default;
+    int control_mode, max_blocking;   // TG_CONTROL_*; blocking_move's step cap in position control
+    int fused_reset;             // edge_follow with auto_reset: k_reset keeps the terminal camera transform, one render launch draws both images
+    // object_push
+    PushScene<T> push;
+    int traj_type, traj_n, rand_init_orn, rand_obj_mass, reset_goal_id;
+    // object_roll
+    int roll_rand_init_pos, roll_rand_size, roll_rand_embed;
+    double roll_radius, roll_init_range, roll_goal_lo, roll_goal_hi;
+    double traj_spacing, traj_max_perturb, traj_init_offset, mass_lo, mass_hi, init_orn_range, traj_ang_range, obj_mass0;
+    T obj_init_pos[3];
+    double obj_init_rpy[3];
+};
+
+struct State {   // device pointers, SoA [field][num_envs]
+    double *q, *qd, *qd_target, *tcp_pos, *tcp_rpy, *edge_ang, *embed;
+    float *stim_xform, *term_xform, *reward;   // term_xform: camera<-stimulus transform of the terminal observation (fused reset)
+    int32_t *step_count, *reset_ticks;
+    int32_t* licence;               // [n] env steps for which the analytic fixed point stays licensed without a new full solve (k_step)
+    double* trig_sc;                // [16][n] sin / cos of the joint angles at the end of the last k_step (valid while the licence holds)
+    double* edge_sc;                // [2][n] sin / cos of the episode's edge angle
+    uint64_t* rng;
+    uint8_t* done;
+    // surface_follow
+    double *dir, *goal, *heights;   // [2][n], [3][n], [n][rows*cols]
+    double* accum;                  // [n] sparse reward: the episode's accumulated dense reward
+    float* surf_zoff;               // [n]
+    int64_t* noise_seed;            // [n]
+    // object_balance
+    double *body_pos, *body_rot, *body_v, *body_w, *ext_pos, *gravity;   // [3][n], [9][n], [3][n], [3][n], [3][n], [n]
+    uint8_t* ext_pending;           // [n]
+    // object_push
+    double *traj, *obj_mass;        // [3][TG_MAX_TRAJ_POINTS][n] work-frame x, y, yaw; [n]
+    int32_t* goal_id;               // [n]
+    int32_t* contact_code;          // [n] contact pairs of the last sim tick (sim_tick_push's contact_code)
+    float *feature, *term_feature;  // [n][12] extended_feature observation (object_push_env.py:611-629), AoS
+    const void* tip_verts;          // [n_tip][3] in the physics dtype
+};
+
+// SplitMix64 (identical integer stream in oracle/ref_env.py: Rng)
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+__device__ inline double rng_uniform(uint64_t& s, double lo, double hi) {
+#pragma clang fp contract(off)   // lo + (hi - lo) * u must round like the host's two-step evaluation (no FMA)
+    s += kGolden;
+    const double u = (double)(mix64(s) >> 11) * (1.0 / 9007199254740992.0);
+    const double span = (hi - lo) * u;
+    return lo + span;
+}
+
+// World pose of the TCP frame -> work-frame position / rpy, following the reference's chain of PyBullet helpers
+// (base_robot_arm.py:62-75, 153-172): matrix -> quaternion -> euler -> quaternion -> multiply -> euler.
+template <typename T>
+__device__ __forceinline__ void world_to_work(const EnvConst<T>& c, V3<T> pos, const M3<T>& R, V3<T>& wpos, T (&wrpy)[3], T (&rpy_world)[3]) {
+    Q4<T> q = quat_from_mat(R);
+    euler_from_quat(q, rpy_world[0], rpy_world[1], rpy_world[2]);
+    const Q4<T> q2 = quat_from_euler(rpy_world[0], rpy_world[1], rpy_world[2]);
+    wpos = load_v3(c.work_inv_pos) + mul(c.work_Rinv, pos);
+    const Q4<T> qw = quat_mul(c.work_qinv, q2);
+    euler_from_quat(qw, wrpy[0], wrpy[1], wrpy[2]);
+}
+
+// np.digitize(v, np.linspace(lo, hi, n)) for increasing bins: the number of bin edges <= v.  Edges are formed exactly like
+// numpy's linspace (k * step + lo in two roundings, last edge = hi), hence no FMA contraction here.
+__device__ inline int digitize_linspace(double v, double lo, double hi, int n) {
+#pragma clang fp contract(off)
+    const double step = (hi - lo) / (double)(n - 1);
+    int count = 0;
+    for (int k = 0; k < n; ++k) {
+        const double prod = (double)k * step;
+        const double edge = (k == n - 1) ? hi : prod + lo;
+        count += (edge <= v) ? 1 : 0;
+    }
+    return count;
+}
+// np.linspace(lo, hi, n)[k], formed like digitize_linspace's edges
+__device__ inline double linspace_value(double lo, double hi, int n, int k) {
+#pragma clang fp contract(off)
+    const double step = (hi - lo) / (double)(n - 1);
+    const double prod = (double)k * step;
+    return (k == n - 1) ? hi : prod + lo;
+}
+// np.gradient(f, h) along one axis of a rows x cols array (central differences inside, one-sided at the ends)
+__device__ inline double grad_axis(const double* f, int idx, int n, int stride, double h) {
+    if (idx == 0) return (f[stride] - f[0]) / h;
+    if (idx == n - 1) return (f[(size_t)(n - 1) * stride] - f[(size_t)(n - 2) * stride]) / h;
+    return (f[(size_t)(idx + 1) * stride] - f[(size_t)(idx - 1) * stride]) / (2.0 * h);
+}
+
+// Everything that follows the physics of a step or a reset: TCP pose read-back, reward / termination
+// (edge_follow_env.py:371-452) and the camera<-stimulus transform handed to the raster (tactile_sensor.py:150-229).
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                           T edge_ang, int step_count, bool write_reward_done, const JointTrig<T, Topo<TOPO>::N>* trig = nullptr,
+                                           bool lazy_rpy = false /* edge_follow steps: tcp_rpy is a read-back only, tg_get_state refreshes it */) {
+    const int n = c.num_envs;
+    Kin<T, TOPO> k;
+    if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, k, trig);
+    else forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
+    if (!(lazy_rpy && c.env_kind == TG_ENV_EDGE_FOLLOW)) {
+        T rpy[3];
+        { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
+        st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    }
+    T se = T(0), ce = T(1);   // stimulus yaw: edge angle for edge_follow (sin / cos cached by the reset), none for the surface
+    if (c.env_kind == TG_ENV_EDGE_FOLLOW) {
+        if (lazy_rpy) { se = (T)st.edge_sc[0 * n + env]; ce = (T)st.edge_sc[1 * n + env]; }
+        else { tsincos(edge_ang, &se, &ce); st.edge_sc[0 * n + env] = (double)se; st.edge_sc[1 * n + env] = (double)ce; }
+    }
+    if (write_reward_done && c.env_kind == TG_ENV_EDGE_FOLLOW) {
+        const T gx = c.stim_pos[0] + c.edge_len * ce, gy = c.stim_pos[1] + c.edge_len * se;
+        const T dx = ptcp.x - gx, dy = ptcp.y - gy;
+        const T goal_dist = tsqrt(dx * dx + dy * dy);
+        const bool done = goal_dist < c.term_dist || step_count >= c.max_steps;
+        // perpendicular distance to the edge centre line: |(p2-p1) x (p1-p3)| / |p2-p1|
+        const T p1x = c.stim_pos[0] - c.edge_len * ce, p1y = c.stim_pos[1] - c.edge_len * se;
+        const T d21x = gx - p1x, d21y = gy - p1y, d13x = p1x - ptcp.x, d13y = p1y - ptcp.y;
+        const T edge_dist = tabs(d21x * d13y - d21y * d13x) / tsqrt(d21x * d21x + d21y * d21y);
+        T reward;
+        if (c.reward_mode == TG_REWARD_SPARSE) reward = goal_dist < c.term_dist ? T(1) : T(0);
+        else reward = -((T(1) * goal_dist) + (T(10) * edge_dist) + T(0));
+        st.reward[env] = (float)reward;
+        st.done[env] = done ? 1 : 0;
+    }
+    if ((write_reward_done || c.reward_mode == TG_REWARD_SPARSE) && c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        // get_step_data / dense_reward (base_surface_env.py:664-684, 703-760; surface_follow_auto_env.py:75-94)
+        const int R = c.surf_rows, Cc = c.surf_cols;
+        int ti = digitize_linspace((double)ptcp.y, c.ybin_lo, c.ybin_hi, Cc);   // xy_to_surface_idx (:284-300)
+        int tj = digitize_linspace((double)ptcp.x, c.xbin_lo, c.xbin_hi, R);
+        if (ti == Cc) ti -= 1;
+        if (tj == R) tj -= 1;
+        const double* H = st.heights + (size_t)env * R * Cc;
+        const T surf_z = (T)(H[(size_t)ti * Cc + tj] + (double)c.stim_pos[2]);
+        const T gy_ = (T)grad_axis(H + tj, ti, R, Cc, c.surf_scale);               // np.gradient axis 0
+        const T gx_ = (T)grad_axis(H + (size_t)ti * Cc, tj, Cc, 1, c.surf_scale);  // axis 1
+        V3<T> nrm{-gx_, -gy_, T(1)};
+        nrm = (T(1) / norm(nrm)) * nrm;
+        const T gdx = ptcp.x - (T)st.goal[0 * n + env], gdy = ptcp.y - (T)st.goal[1 * n + env], gdz = ptcp.z - (T)st.goal[2 * n + env];
+        T reward;
+        if (c.surf_vertical) {   // the `vertical_simplex` branches (:703-758) on the flipped surface_array / normals (:486-516); vert_env :66-81
+            nrm = mul(c.stim_R, nrm);
+            const V3<T> tipv = mul(Rtcp, mk(T(-1), T(0), T(0)));
+            const V3<T> emb = mul(Rtcp, mk(-c.embed_default, T(0), T(0)));
+            const T surf_x = (T)((double)c.stim_pos[0] - H[(size_t)ti * Cc + tj]);   // flipped point: (sx - h, y_bins[i], sz + x_bins[j] - sx)
+            const T surf_dist = tabs((ptcp.x + emb.x) - surf_x);
+            const T cos_sim = dot(nrm, tipv) / (norm(nrm) * norm(tipv));
+            reward = -((T(10) * surf_dist) + (T(3) * (T(1) - cos_sim)));
+        } else {
+            const V3<T> tipv = mul(Rtcp, mk(T(0), T(0), T(-1)));
+            const V3<T> emb = mul(Rtcp, mk(T(0), T(0), -c.embed_default));
+            const T surf_dist = tabs((ptcp.z + emb.z) - surf_z);
+            const T cos_sim = dot(nrm, tipv) / (norm(nrm) * norm(tipv));
+            const T w_norm = (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_XYZ) ? T(0) : T(1);
+            reward = c.surf_goal ? -((T(1) * tsqrt(gdx * gdx + gdy * gdy)) + (T(10) * surf_dist) + (w_norm * (T(1) - cos_sim)))   // goal_env :69-90
+                                 : -((T(1) * surf_dist) + (w_norm * (T(1) - cos_sim)));
+        }
+        const bool at_goal = tsqrt(gdx * gdx + gdy * gdy + gdz * gdz) < c.term_dist;
+        T out = reward;
+        if (c.reward_mode == TG_REWARD_SPARSE) {   // sparse_reward (surface_follow_auto_env.py:59-73): the dense reward is accumulated over the
+            const double acc = st.accum[env] + (double)reward;   // episode (from the reset pose on, base_surface_env.py:640) and paid out at the goal
+            st.accum[env] = acc;
+            out = at_goal ? (T)acc : T(0);
+        }
+        if (write_reward_done) {
+            st.reward[env] = (float)out;
+            st.done[env] = (at_goal || step_count >= c.max_steps) ? 1 : 0;
+        }
+    }
+    // camera frame = sensor-body frame o cam offset; eye axes (right, up, -forward) with forward = R[:,0], up = R[:,2]
+    V3<T> pb; M3<T> Rb;
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
+    const M3<T> Rc = mul(Rb, c.cam_rot);
+    V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
+    f = (T(1) / norm(f)) * f;
+    V3<T> s = cross(f, up);
+    s = (T(1) / norm(s)) * s;
+    const V3<T> u = cross(s, f);
+    // object rotation: yaw about z by edge_ang
+    V3<T> ox{ce, se, T(0)}, oy{-se, ce, T(0)}, oz{T(0), T(0), T(1)};
+    if (c.surf_vertical) {       // upright heightfield: the columns of its fixed rotation
+        ox = mk(c.stim_R.m[0], c.stim_R.m[3], c.stim_R.m[6]); oy = mk(c.stim_R.m[1], c.stim_R.m[4], c.stim_R.m[7]);
+        oz = mk(c.stim_R.m[2], c.stim_R.m[5], c.stim_R.m[8]);
+    }
+    const V3<T> dp = load_v3(c.stim_pos) - pc;
+    const V3<T> nf = mk<T>(0, 0, 0) - f;
+    float* X = st.stim_xform;
+    X[0 * n + env] = (float)dot(s, ox);  X[1 * n + env] = (float)dot(s, oy);  X[2 * n + env] = (float)dot(s, oz);
+    X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
+    X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
+    X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+}
+
+// scale_actions (base_tactile_env.py:141-164): clip to [min_action, max_action], affine map to the physical range per dimension
+template <typename T> __device__ __forceinline__ void scale_actions(const EnvConst<T>& c, const T (&enc)[6], T (&vels)[6]) {
+    const T in_range = c.max_action - c.min_action;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        T x = enc[d];
+        x = x < c.min_action ? c.min_action : (x > c.max_action ? c.max_action : x);
+        vels[d] = (((x - c.min_action) * (c.act_hi[d] - c.act_lo[d])) / in_range) + c.act_lo[d];
+    }
+}
+
+// BaseRobotArm.tcp_velocity_control (base_robot_arm.py:281-332): TCP limit check, work -> world twist, Jacobian inverse.
+template <typename T, int TOPO>
+__device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const EnvConst<T>& c, const T (&q)[Topo<TOPO>::N], T (&vels)[6],
+                                                     T (&qd_des)[Topo<TOPO>::N], const JointTrig<T, Topo<TOPO>::N>* trig = nullptr,
+                                                     T work_dz = T(0) /* per-env z offset of the work-frame origin (object_roll) */) {
+    constexpr int N = Topo<TOPO>::N;
+    Kin<T, TOPO> k;
+    if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, k, trig);
+    else forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    V3<T> wpos; T wrpy[3] = {T(0), T(0), T(0)}, rpyw[3];
+    // The work-frame orientation of the TCP (matrix -> quaternion -> euler -> quaternion -> multiply -> euler: nine f64 transcendentals)
+    // only enters the limit check of the rotational components; a movement mode without rotational velocity (a zero stays a zero in that
+    // check) needs the position alone.  Wave-uniform.
+    if (__any(vels[3] != T(0) || vels[4] != T(0) || vels[5] != T(0)))
+        world_to_work(c, mk(ptcp.x, ptcp.y, ptcp.z - work_dz), Rtcp, wpos, wrpy, rpyw);
+    else
+        wpos = load_v3(c.work_inv_pos) + mul(c.work_Rinv, mk(ptcp.x, ptcp.y, ptcp.z - work_dz));
+    const T cur[6] = {wpos.x, wpos.y, wpos.z, wrpy[0], wrpy[1], wrpy[2]};
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {   // check_TCP_vel_lims (base_robot_arm.py:357-380)
+        const bool ex = (cur[d] < c.tcp_lims[d][0] && vels[d] < T(0)) || (cur[d] > c.tcp_lims[d][1] && vels[d] > T(0));
+        if (ex) vels[d] = T(0);
+    }
+    const V3<T> lin = mul(c.work_R, mk(vels[0], vels[1], vels[2]));   // workvel_to_worldvel (:96-105)
+    const V3<T> ang = mul(c.work_R, mk(vels[3], vels[4], vels[5]));
+    T J[6][N];
+    tcp_jacobian<T, TOPO>(m, k, ptcp, J);
+    if (N == 6) {  // square: inverse (reference takes np.linalg.inv when rank is full, :316-319)
+        T A[6][6], b[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z}, x[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) A[r][cc] = J[r][cc < N ? cc : 0];
+        solve_pivoted<T, 6>(A, b, x);
+#pragma unroll
+        for (int i = 0; i < N; ++i) qd_des[i] = x[i < 6 ? i : 0];
+    } else {       // MG400 (mg400.py:77-129): the Jacobian is 6 x 8, always the pseudo-inverse, then the parallel-linkage joints
+        const T b[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z};   // (j2_2, j3_2, j4_2) are slaved to (j2_1, j3_1) by hand (:115-120)
+        pinv_apply<T, N>(J, b, qd_des);
+        if (N == 8) { qd_des[N - 3] = qd_des[1]; qd_des[N - 2] = -qd_des[1]; qd_des[N - 1] = qd_des[1] + qd_des[2]; }
+    }
+}
+
+// encode_actions of the arm-only tasks: the policy's dimensions scattered into the 6-vector the controller takes.
+template <typename T>
+__device__ __forceinline__ void encode_arm_actions(const EnvConst<T>& c, const State& st, int env, const float* __restrict__ a, T (&enc)[6]) {
+    const int n = c.num_envs;
+    if (c.env_kind == TG_ENV_EDGE_FOLLOW) {               // encode_actions (edge_follow_env.py:345-369)
+        enc[0] = (T)a[0]; enc[1] = (T)a[1];
+        if (c.movement_mode == TG_MOVE_XYZ) enc[2] = (T)a[2];
+        else if (c.movement_mode == TG_MOVE_XYRZ) enc[5] = (T)a[2];
+        else if (c.movement_mode == TG_MOVE_XYZRZ) { enc[2] = (T)a[2]; enc[5] = (T)a[3]; }
+    } else if (c.surf_goal) {                             // surface_follow_goal_env.py:27-52: every dimension from the agent
+        if (c.movement_mode == TG_SMOVE_YZ) { enc[1] = (T)a[0]; enc[2] = (T)a[1]; }
+        else if (c.movement_mode == TG_SMOVE_YZRX) { enc[1] = (T)a[0]; enc[2] = (T)a[1]; enc[3] = (T)a[2]; }
+        else {
+            enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2];
+            if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[3]; enc[4] = (T)a[4]; }
+        }
+    } else if (c.surf_vertical) {                         // surface_follow_vert_env.py:29-48: y is driven toward the goal
+        enc[1] = (T)((st.dir[1 * n + env] * (double)c.max_action) * c.auto_scale);
+        enc[0] = (T)a[0]; enc[5] = (T)a[1];
+    } else {                                              // surface_follow_auto_env.py:27-57: xy are driven toward the goal
+        enc[0] = (T)((st.dir[0 * n + env] * (double)c.max_action) * c.auto_scale);
+        enc[1] = (T)((st.dir[1 * n + env] * (double)c.max_action) * c.auto_scale);
+        enc[2] = (T)a[0];
+        if (c.movement_mode == TG_SMOVE_YZRX) enc[3] = (T)a[1];
+        else if (c.movement_mode == TG_SMOVE_XYZRXRY) { enc[3] = (T)a[1]; enc[4] = (T)a[2]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ step kernel
+// BaseTactileEnv.step (base_tactile_env.py:166-185): encode + scale the action, tcp_velocity_control
+// (base_robot_arm.py:281-332), action_repeat sim ticks (robot.py:182-183), reward / done, render transform.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                             const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    encode_arm_actions<T>(c, st, env, actions + (size_t)env * c.act_dim, enc);
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+    JointTrig<T, N> trig;             // sin/cos of the joint angles, advanced by angle addition through the ticks.  While the licence
+    const int lic = st.licence[env];  // below holds they are carried over from the last step (q has not changed in between: a reset or
+    if (__all(lic > 0)) {             // tg_set_joint_state drops the licence), i.e. they are evaluated exactly once per 8 steps
+#pragma unroll
+        for (int i = 0; i < N; ++i) { trig.s[i] = (T)st.trig_sc[i * n + env]; trig.c[i] = (T)st.trig_sc[(8 + i) * n + env]; }
+    } else {
+        trig_init<T, N>(q, trig);
+    }
+    T qd_des[N];
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, &trig);
+#pragma unroll
+    for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+
+    T qdummy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    // Licence for sim_tick's analytic fixed point.  A full solve that converged to the last bit within 80 % of the sweep budget arms it
+    // for the remaining ticks of this step and for the next 7 steps (<= 0.8 s, < 0.1 rad of joint motion: the Gauss-Seidel contraction
+    // is a smooth function of the configuration and the margin is a factor > 2 in sweeps); a reset drops it.  Wave-uniform.
+    int verified = __all(lic > 0) ? 24 : 0;
+    bool ran_full = false;
+    for (int t = 0; t < c.action_repeat; ++t) {
+        const int before = verified;
+        sim_tick<T, TOPO, kMotorVelocity, true, true>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, &trig,
+                                                      &verified);
+        const bool analytic = before > 0 && verified == before - 1;   // the analytic path decrements; a full solve sets 24 or -1
+        if (!analytic) ran_full = true;
+        if (verified < 0) verified = 0;
+        // Fast-forward.  After an analytic tick qd == des (the velocity motors' constant target), so every remaining tick of this step
+        // sees the same inputs to sim_tick's a-priori test (jump 0, damping term of the same qd): if it holds once it holds for all of
+        // them and each is just q += dt des - the same additions in the same order, without re-evaluating the test and the angle-addition
+        // update 23 more times.  The sines / cosines are re-anchored exactly at the end.  Wave-uniform like the licence itself.
+        const int remaining = c.action_repeat - t - 1;
+        if (analytic && remaining > 0 && verified >= remaining && c.solver_iters >= 0) {
+            T v2 = T(0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) v2 += qd[i] * qd[i];
+            const T lam_star = c.dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3) * tsqrt_fast(v2);
+            if (__all(T(2.5) * lam_star < m.max_force * c.dt)) {
+                T dq[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) dq[i] = c.dt * qd[i];
+                for (int r = 0; r < remaining; ++r) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) q[i] += dq[i];
+                }
+                T dqt[N];                           // sines / cosines by one angle addition over the whole jump (exact
+#pragma unroll                                  // evaluation when it exceeds 0.02 rad); they are re-anchored at every step start
+                for (int i = 0; i < N; ++i) dqt[i] = (T)remaining * dq[i];
+                trig_advance<T, N>(q, dqt, trig);
+                verified -= remaining;
+                break;
+            }
+        }
+    }
+    st.licence[env] = ran_full ? (verified > 0 ? 8 : 0) : lic - 1;
+
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = (double)trig.s[i]; st.trig_sc[(8 + i) * n + env] = (double)trig.c[i]; }
+    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
+}
+
+// ------------------------------------------------------------------------------------------------ reset kernel
+template <typename T> __device__ __forceinline__ V3<T> rot_error(const M3<T>& Rt, const M3<T>& R) {
+    // rotation vector of Rt R^T
+    M3<T> E;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) E.m[3 * i + j] = Rt.m[3 * i] * R.m[3 * j] + Rt.m[3 * i + 1] * R.m[3 * j + 1] + Rt.m[3 * i + 2] * R.m[3 * j + 2];
+    const T cosang = T(0.5) * (E.m[0] + E.m[4] + E.m[8] - T(1));
+    const V3<T> ax{E.m[7] - E.m[5], E.m[2] - E.m[6], E.m[3] - E.m[1]};
+    const T s = norm(ax);                         // = 2 sin(angle)
+    const T ang = tatan2(T(0.5) * s, cosang);     // well conditioned for small angles (acos is not)
+    if (s < T(1e-12)) return T(0.5) * ax;
+    return (ang / s) * ax;
+}
+
+// calculateInverseKinematics(TCP link, pos, orn, maxNumIterations, residualThreshold) (base_robot_arm.py:201-209):
+// damped least squares on the 6-D pose error, q updated in place from its starting value; returns iterations used.
+template <typename T, int TOPO>
+__device__ __forceinline__ int inverse_kinematics(const DevRobot<T>& m, V3<T> tpos, const M3<T>& Rt, T (&qik)[Topo<TOPO>::N], int max_iters,
+                                                  T threshold) {
+    constexpr int N = Topo<TOPO>::N;
+    int it = 0;
+    for (; it < max_iters; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, qik, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const V3<T> ep = tpos - p, er = rot_error(Rt, R);
+        T e[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
+        T res = T(0);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) res += e[d] * e[d];
+        if (tsqrt(res) <= threshold) break;
+        T J[6][N];
+        tcp_jacobian<T, TOPO>(m, k, p, J);
+        T A[6][6], y[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+                T acc = (r == cc) ? T(1e-8) : T(0);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc += J[r][i] * J[cc][i];
+                A[r][cc] = acc;
+            }
+        solve_pivoted<T, 6>(A, e, y);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc += J[r][i] * y[r];
+            qik[i] += acc;
+        }
+    }
+    return it;
+}
+
+// BaseRobotArm.tcp_position_control (base_robot_arm.py:228-279; MG400 override mg400.py:131-190): target pose = clip(current
+// work-frame pose + delta, TCP_lims) (check_TCP_pos_lims, :349-355), back to the world (workframe_to_worldframe, :46-60), inverse
+// kinematics from the current joint state.  The POSITION_CONTROL motors then track `qik` (gains pos_gain / vel_gain, max_force).
+template <typename T, int TOPO>
+__device__ __forceinline__ void tcp_position_target(const DevRobot<T>& m, const EnvConst<T>& c, const T (&q)[Topo<TOPO>::N], const T (&delta)[6],
+                                                    V3<T>& tpos, Q4<T>& tq, T (&qik)[Topo<TOPO>::N],
+                                                    T work_dz = T(0) /* per-env z offset of the work-frame origin (object_roll) */) {
+    constexpr int N = Topo<TOPO>::N;
+    {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> ptcp; M3<T> Rtcp;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+        V3<T> wpos; T wrpy[3], rpyw[3];
+        world_to_work(c, mk(ptcp.x, ptcp.y, ptcp.z - work_dz), Rtcp, wpos, wrpy, rpyw);
+        T tgt[6] = {wpos.x + delta[0], wpos.y + delta[1], wpos.z + delta[2], wrpy[0] + delta[3], wrpy[1] + delta[4], wrpy[2] + delta[5]};
+#pragma unroll
+        for (int d = 0; d < 6; ++d) tgt[d] = tgt[d] < c.tcp_lims[d][0] ? c.tcp_lims[d][0] : (tgt[d] > c.tcp_lims[d][1] ? c.tcp_lims[d][1] : tgt[d]);
+        tpos = load_v3(c.work_pos) + mul(c.work_R, mk(tgt[0], tgt[1], tgt[2]));
+        tpos.z += work_dz;
+        T trpy[3];
+        euler_from_quat(quat_mul(c.work_q, quat_from_euler(tgt[3], tgt[4], tgt[5])), trpy[0], trpy[1], trpy[2]);
+        tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    }
+    const M3<T> Rt = mat_from_quat(tq);
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }   // mg400.py:167-172
+}
+
+// blocking_move's exit test (robot.py:216-258), evaluated on the state BEFORE the tick it follows: pose error of the TCP and the
+// summed joint speed.
+template <typename T, int TOPO>
+__device__ __forceinline__ bool pose_reached(const DevRobot<T>& m, const T (&q)[Topo<TOPO>::N], const T (&qd)[Topo<TOPO>::N], const V3<T>& tpos,
+                                             const Q4<T>& tq) {
+    constexpr int N = Topo<TOPO>::N;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> p; M3<T> R;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+    const Q4<T> cq = quat_from_mat(R);
+    T total_v = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) total_v += tabs(qd[i]);
+    const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+    const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+    T ca = T(2) * ip * ip - T(1);
+    ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+    return pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1);
+}
+
+// TCP_position_control step (robot.py:156-186): BaseRobotArm.tcp_position_control (base_robot_arm.py:228-279; MG400 override
+// mg400.py:131-190) then Robot.blocking_move(max_steps = _max_blocking_pos_move_steps, constant_vel = None) (robot.py:188-260).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step_pos(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                 const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    encode_arm_actions<T>(c, st, env, actions + (size_t)env * c.act_dim, enc);
+    T delta[6];
+    scale_actions<T>(c, enc, delta);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+
+    V3<T> tpos; Q4<T> tq;
+    T qik[N], zero[N];
+    tcp_position_target<T, TOPO>(m, c, q, delta, tpos, tq, qik);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { zero[i] = T(0); st.qd_target[i * n + env] = 0.0; }
+    int verified = 0;
+    for (int it = 0; it < c.max_blocking; ++it) {
+        const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, qik, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, nullptr, &verified);
+        if (verified < 0) verified = 0;
+        if (stop) break;
+    }
+    st.licence[env] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true);
+}
+
+// EdgeFollowEnv.reset (edge_follow_env.py:311-336): reset_task (:285-299), Robot.reset (robot.py:114-125) =
+// rest pose + IK to the start pose (base_robot_arm.py:191-226) + blocking_move (robot.py:188-260).
+template <typename T, int TOPO>
+__device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env,
+                                          int phase /*0 all, 1 task draws only, 2 robot only*/) {
+    constexpr int N = Topo<TOPO>::N;
+    const int n = c.num_envs;
+
+    double embed = (double)c.embed_default, edge_ang = 0.0;
+    if (phase != 2) {                                     // reset_task: identical draw order to the reference / oracle
+        uint64_t rs = st.rng[env];
+        if (c.env_kind == TG_ENV_EDGE_FOLLOW) {           // edge_follow_env.py:285-299, :237-241
+            if (c.noise_mode == TG_NOISE_RAND_HEIGHT) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
+            edge_ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+        } else {                                          // base_surface_env.py:448 (simplex seed), :520-534 (goal direction)
+            st.accum[env] = 0.0;                              // make_goal, base_surface_env.py:589-591
+            if (c.noise_mode == TG_SNOISE_SIMPLEX || c.noise_mode == TG_SNOISE_VERTICAL_SIMPLEX) {
+                st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
+            } else if (c.noise_mode == TG_SNOISE_RANDOM) {   // gen_heigtfield_noisey draws (rows/2)(cols/2) uniforms: k_gen_surface
+                st.noise_seed[env] = (int64_t)rs;            // evaluates them from this state, the stream moves past them here
+                rs += (uint64_t)((c.surf_rows / 2) * (c.surf_cols / 2)) * kGolden;
+            }
+            if (c.movement_mode == TG_SMOVE_YZ || c.movement_mode == TG_SMOVE_YZRX || c.movement_mode == TG_SMOVE_XRZ) {   // np_random.choice([-1, 1])
+                st.dir[0 * n + env] = 0.0;
+                st.dir[1 * n + env] = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
+            } else {
+                const double ang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+                st.dir[0 * n + env] = cos(ang);
+                st.dir[1 * n + env] = sin(ang);
+            }
+        }
+        st.rng[env] = rs;
+        st.embed[env] = embed;
+        st.edge_ang[env] = edge_ang;
+        st.step_count[env] = 0;
+        if (phase == 1) return;
+    } else {
+        embed = st.embed[env];
+        edge_ang = st.edge_ang[env];
+    }
+    V3<T> init_world = load_v3(c.work_pos) + mul(c.work_R, mk(T(0), T(0), (T)embed));   // edge: work-frame (0, 0, embed)
+    if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        const int R = c.surf_rows, Cc = c.surf_cols;
+        const double* H = st.heights + (size_t)env * R * Cc;
+        // make_goal (base_surface_env.py:518-575): goal on the surface, x_y_extent away along the drive direction
+        const V3<T> wd = mul(c.work_R, mk((T)st.dir[0 * n + env], (T)st.dir[1 * n + env], T(0)));
+        const double gx = (double)c.stim_pos[0] + c.surf_extent * (double)wd.x, gy = (double)c.stim_pos[1] + c.surf_extent * (double)wd.y;
+        int gi = digitize_linspace(gy, c.ybin_lo, c.ybin_hi, Cc), gj = digitize_linspace(gx, c.xbin_lo, c.xbin_hi, R);
+        if (gi == Cc) gi -= 1;
+        if (gj == R) gj -= 1;
+        const double hc = H[(size_t)(R / 2) * Cc + (Cc / 2)];
+        V3<T> pw;
+        if (c.surf_vertical) {   // goal = the flipped surface_array[gi, gj] (:486-498, :547-555); init pose :596-603
+            st.goal[0 * n + env] = (double)c.stim_pos[0] - H[(size_t)gi * Cc + gj];
+            st.goal[1 * n + env] = linspace_value(c.ybin_lo, c.ybin_hi, Cc, gi);
+            st.goal[2 * n + env] = (double)c.stim_pos[2] + (linspace_value(c.xbin_lo, c.xbin_hi, R, gj) - (double)c.stim_pos[0]);
+            pw = mk((T)((double)c.stim_pos[0] - (hc - embed)), c.stim_pos[1], c.stim_pos[2]);
+        } else {
+            st.goal[0 * n + env] = gx; st.goal[1 * n + env] = gy; st.goal[2 * n + env] = H[(size_t)gi * Cc + gj] + (double)c.stim_pos[2];
+            // update_init_pose (:590-613): above the surface centre, embed_dist deep, expressed in and back out of the work frame
+            pw = mk(c.stim_pos[0], c.stim_pos[1], (T)((double)c.stim_pos[2] + hc - embed));
+        }
+        const V3<T> pwork = load_v3(c.work_inv_pos) + mul(c.work_Rinv, pw);
+        init_world = load_v3(c.work_pos) + mul(c.work_R, pwork);
+    }
+
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+
+    // start pose in the world frame (workframe_to_worldframe, base_robot_arm.py:46-60), rpy 0 in the work frame
+    const V3<T> tpos = init_world;
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+
+    // calculateInverseKinematics: damped least squares from the rest pose
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }   // mg400.py:222-227 target_joints override
+
+    // blocking_move(max_steps=1000, constant_vel=0.001)
+    T cv = T(0.001);
+    T zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    int used = 0, verified = 0;
+    for (int it = 0; it < 1000; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], step_j[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        if (all_small) cv = cv / T(2);
+        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, nullptr, &verified);
+        if (verified < 0) verified = 0;
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        const T orn_err = tacos(ca);
+        if (pos_err < T(2e-4) && orn_err < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.reset_ticks[env] = used;
+    st.licence[env] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+    finish_env<T, TOPO>(m, c, st, env, q, (T)edge_ang, 0, false);
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                              const uint8_t* __restrict__ mask, int phase) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= cp->num_envs) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    if (cp->fused_reset && mask != nullptr) {   // auto-reset inside tg_step: keep the terminal observation's camera transform; the render
+        const int n = cp->num_envs;             // launch that follows draws both images of this env
+#pragma unroll
+        for (int k = 0; k < 12; ++k) st.term_xform[k * n + env] = st.stim_xform[k * n + env];
+    }
+    reset_env<T, TOPO>(*mp, *cp, st, env, phase);
+}
+
+// ------------------------------------------------------------------------------------------------ object_balance kernels
+template <typename T> __device__ __forceinline__ FreeBody<T> load_body(const State& st, int n, int env) {
+    FreeBody<T> b;
+    b.pos = mk((T)st.body_pos[0 * n + env], (T)st.body_pos[1 * n + env], (T)st.body_pos[2 * n + env]);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) b.R.m[e] = (T)st.body_rot[e * n + env];
+    b.v = mk((T)st.body_v[0 * n + env], (T)st.body_v[1 * n + env], (T)st.body_v[2 * n + env]);
+    b.w = mk((T)st.body_w[0 * n + env], (T)st.body_w[1 * n + env], (T)st.body_w[2 * n + env]);
+    return b;
+}
+template <typename T> __device__ __forceinline__ void store_body(const State& st, int n, int env, const FreeBody<T>& b) {
+    st.body_pos[0 * n + env] = (double)b.pos.x; st.body_pos[1 * n + env] = (double)b.pos.y; st.body_pos[2 * n + env] = (double)b.pos.z;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) st.body_rot[e * n + env] = (double)b.R.m[e];
+    st.body_v[0 * n + env] = (double)b.v.x; st.body_v[1 * n + env] = (double)b.v.y; st.body_v[2 * n + env] = (double)b.v.z;
+    st.body_w[0 * n + env] = (double)b.w.x; st.body_w[1 * n + env] = (double)b.w.y; st.body_w[2 * n + env] = (double)b.w.z;
+}
+template <typename T> __device__ __forceinline__ T wrap_deg(T d) {   // ((d + 180) % 360) - 180 with numpy's sign-of-divisor modulo
+    const T x = d + T(180);
+    return (x - T(360) * floor(x / T(360))) - T(180);
+}
+
+// get_step_data / check_obj_fall / termination (object_balance_env.py:426-497) + camera<-object transform
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                            const FreeBody<T>& b, T embed, int step_count, bool write_reward_done) {
+    const int n = c.num_envs;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    T rpy[3];
+    { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
+    st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
+    st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    if (write_reward_done) {
+        T orpy[3];
+        { Q4<T> qq = quat_from_mat(b.R); euler_from_quat(qq, orpy[0], orpy[1], orpy[2]); }
+        const T r2d = T(180) / T(3.141592653589793);
+        const T d0 = tabs(wrap_deg(orpy[0] * r2d - c.obj_init_rpy_deg[0])), d1 = tabs(wrap_deg(orpy[1] * r2d - c.obj_init_rpy_deg[1]));
+        const V3<T> init = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - embed);
+        const bool fell = d0 > c.term_deg || d1 > c.term_deg || norm(b.pos - init) > c.term_pos;
+        const bool done = fell || step_count >= c.max_steps;
+        const T reward = (c.reward_mode == TG_REWARD_SPARSE) ? (fell ? T(-1) : T(0)) : T(1);
+        st.reward[env] = (float)reward;
+        st.done[env] = done ? 1 : 0;
+    }
+    V3<T> pb; M3<T> Rb;
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
+    const M3<T> Rc = mul(Rb, c.cam_rot);
+    V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
+    f = (T(1) / norm(f)) * f;
+    V3<T> s = cross(f, up);
+    s = (T(1) / norm(s)) * s;
+    const V3<T> u = cross(s, f);
+    const V3<T> ox{b.R.m[0], b.R.m[3], b.R.m[6]}, oy{b.R.m[1], b.R.m[4], b.R.m[7]}, oz{b.R.m[2], b.R.m[5], b.R.m[8]};
+    const V3<T> dp = b.pos - pc;
+    const V3<T> nf = mk<T>(0, 0, 0) - f;
+    const float xv[12] = {(float)dot(s, ox),  (float)dot(s, oy),  (float)dot(s, oz),  (float)dot(u, ox), (float)dot(u, oy), (float)dot(u, oz),
+                          (float)dot(nf, ox), (float)dot(nf, oy), (float)dot(nf, oz), (float)dot(s, dp), (float)dot(u, dp), (float)dot(nf, dp)};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st.stim_xform[i * n + env] = xv[i];
+    // end of a step: a second copy that the reset of the envs that just finished leaves alone, so that the step's observations can be
+    // drawn (from this copy) while those envs are being reset on a second stream (enqueue_step)
+    if (write_reward_done) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st.term_xform[i * n + env] = xv[i];
+    }
+}
+
+template <typename T, int TOPO, bool POS>
+__global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                  const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // encode_actions (object_balance_env.py:398-424)
+    const float* a = actions + (size_t)env * c.act_dim;
+    if (c.movement_mode == TG_BMOVE_XY) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; }
+    else if (c.movement_mode == TG_BMOVE_XYZ) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2]; }
+    else if (c.movement_mode == TG_BMOVE_RXRY) { enc[3] = (T)a[0]; enc[4] = (T)a[1]; }
+    else { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[3] = (T)a[2]; enc[4] = (T)a[3]; }
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+    T qd_des[N];
+    V3<T> tpos; Q4<T> tq;
+    if constexpr (POS) {                                  // TCP_position_control: qd_des carries the joint targets
+        tcp_position_target<T, TOPO>(m, c, q, vels, tpos, tq, qd_des);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = 0.0;
+    } else {
+        tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+    }
+    const T embed = (T)st.embed[env];
+    const V3<T> grav = mk(T(0), T(0), (T)st.gravity[env]);
+    const V3<T> pivot_b = mk(T(0), T(0), -c.obj_base_height / T(2) + embed);
+    const V3<T> fext = load_v3(c.ext_force);
+    const V3<T> pext = mk((T)st.ext_pos[0 * n + env], (T)st.ext_pos[1 * n + env], (T)st.ext_pos[2 * n + env]);
+    const bool pending = st.ext_pending[env] != 0;
+    T qdummy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    int verified = 0;
+    if constexpr (POS) {                                  // blocking_move(max_steps, constant_vel=None), robot.py:188-260
+        for (int t = 0; t < c.max_blocking; ++t) {
+            const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+            sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b,
+                                                   c.body, pivot_b, fext, pext, pending && t == 0, &verified);
+            if (stop) break;
+        }
+    } else {
+        JointTrig<T, N> trig;              // sines / cosines of the joint angles, advanced by angle addition through the analytic ticks
+        trig_init<T, N>(q, trig);
+        for (int t = 0; t < c.action_repeat; ++t)
+            sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body,
+                                                   pivot_b, fext, pext, pending && t == 0, &verified, &trig);
+    }
+    st.ext_pending[env] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    store_body<T>(st, n, env, b);
+    finish_body<T, TOPO>(m, c, st, env, q, b, embed, step_count, true);
+}
+
+// BaseObjectEnv.reset (base_object_env.py:146-173) for object_balance: reset_task (gravity, embed), Robot.reset with the pole
+// still tied to the TCP, reset_object (teleport + one-shot random force).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                   const uint8_t* __restrict__ mask) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    uint64_t rs = st.rng[env];
+    const double gz = c.rand_gravity ? rng_uniform(rs, c.gravity_lo, c.gravity_hi) : c.gravity_default;   // reset_task :301-306
+    double embed = st.embed[env];
+    if (c.rand_embed) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);                                    // :308-316
+    st.gravity[env] = gz;
+    st.embed[env] = embed;
+    st.step_count[env] = 0;
+    const V3<T> grav = mk(T(0), T(0), (T)gz);
+    const V3<T> pivot_b = mk(T(0), T(0), -c.obj_base_height / T(2) + (T)embed);
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+    // Robot.reset: IK to the work-frame origin, rpy 0 (update_init_pose, base_object_env.py:96-103)
+    const V3<T> tpos = load_v3(c.work_pos);
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    T cv = T(0.001);
+    T zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    const V3<T> z3 = mk<T>(0, 0, 0);
+    int used = 0, verified = 0;
+    for (int it = 0; it < 1000; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], step_j[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        if (all_small) cv = cv / T(2);
+        sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, grav, b, c.body,
+                                               pivot_b, z3, z3, false, &verified);
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.reset_ticks[env] = used;
+    // reset_object (object_balance_env.py:330-381): teleport, then a one-shot downward force at a random point of the base plate
+    b.pos = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - (T)embed);
+    b.R = c.obj_init_rot;
+    b.v = z3; b.w = z3;
+    const double sx = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
+    const double rx = rng_uniform(rs, 0.0, 1.0);
+    const double sy = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
+    const double ry = rng_uniform(rs, 0.0, 1.0);
+    st.rng[env] = rs;
+    st.ext_pos[0 * n + env] = (double)b.pos.x + sx * rx * (double)c.obj_base_width / 2.0;
+    st.ext_pos[1 * n + env] = (double)b.pos.y + sy * ry * (double)c.obj_base_width / 2.0;
+    st.ext_pos[2 * n + env] = (double)b.pos.z;
+    st.ext_pending[env] = 1;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+    store_body<T>(st, n, env, b);
+    finish_body<T, TOPO>(m, c, st, env, q, b, (T)embed, 0, false);
+}
+
+// ------------------------------------------------------------------------------------------------ object_push kernels
+// get_step_data (object_push_env.py:456-569): reward, goal advance / termination, extended_feature (:611-629), camera<-cube.
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_push(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                            const FreeBody<T>& b, int step_count, bool write_reward_done) {
+    const int n = c.num_envs;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    const Q4<T> qtcp = quat_from_mat(Rtcp);
+    V3<T> wpos; T wrpy[3], rpy[3];
+    world_to_work(c, ptcp, Rtcp, wpos, wrpy, rpy);
+    st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
+    st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    int gid = st.goal_id[env];
+    bool done = false;
+    if (write_reward_done) {
+        const int gi = gid < c.traj_n ? gid : c.traj_n - 1;
+        const V3<T> gw = mk((T)st.traj[(0 * TG_MAX_TRAJ_POINTS + gi) * n + env], (T)st.traj[(1 * TG_MAX_TRAJ_POINTS + gi) * n + env], T(0));
+        const T gyaw = (T)st.traj[(2 * TG_MAX_TRAJ_POINTS + gi) * n + env];
+        const V3<T> gpos = load_v3(c.work_pos) + mul(c.work_R, gw);                       // workframe_to_worldframe (:305-313)
+        T grpy[3];
+        euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), gyaw)), grpy[0], grpy[1], grpy[2]);
+        const Q4<T> gq = quat_from_euler(grpy[0], grpy[1], grpy[2]);
+        const Q4<T> oq = quat_from_mat(b.R);
+        const T pos_dist = norm(b.pos - gpos);
+        T reward;
+        if (c.reward_mode == TG_REWARD_SPARSE) reward = pos_dist < c.term_dist ? T(1) : T(0);
+        else {
+            const T ip = gq.x * oq.x + gq.y * oq.y + gq.z * oq.z + gq.w * oq.w;
+            T ca = T(2) * (ip * ip) - T(1);
+            ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+            const T orn_dist = tacos(ca);
+            const M3<T> Rq = mat_from_quat(qtcp);
+            const V3<T> ov = mk(b.R.m[0], b.R.m[3], b.R.m[6]), tv = mk(Rq.m[0], Rq.m[3], Rq.m[6]);
+            const T cos_dist = T(1) - dot(ov, tv) / (norm(ov) * norm(tv));
+            reward = -((T(1) * pos_dist) + (T(1) * orn_dist) + (T(1) * cos_dist));
+        }
+        if (pos_dist < c.term_dist) {                                                     // termination (:520-537), update_goal (:342-370)
+            gid += 1;
+            if (gid >= c.traj_n) done = true;
+            st.goal_id[env] = gid;
+        }
+        if (step_count >= c.max_steps) done = true;
+        st.reward[env] = (float)reward;
+        st.done[env] = done ? 1 : 0;
+    }
+    {   // extended_feature: TCP pose and current goal pose in the work frame
+        const int gi = gid < c.traj_n ? gid : c.traj_n - 1;
+        float f[12] = {(float)wpos.x, (float)wpos.y, (float)wpos.z, (float)wrpy[0], (float)wrpy[1], (float)wrpy[2],
+                       (float)st.traj[(0 * TG_MAX_TRAJ_POINTS + gi) * n + env], (float)st.traj[(1 * TG_MAX_TRAJ_POINTS + gi) * n + env], 0.0f,
+                       0.0f, 0.0f, (float)st.traj[(2 * TG_MAX_TRAJ_POINTS + gi) * n + env]};
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            if (write_reward_done) st.term_feature[(size_t)env * 12 + e] = f[e];
+            st.feature[(size_t)env * 12 + e] = f[e];
+        }
+    }
+    V3<T> pb; M3<T> Rb;
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
+    const M3<T> Rc = mul(Rb, c.cam_rot);
+    V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
+    f = (T(1) / norm(f)) * f;
+    V3<T> s = cross(f, up);
+    s = (T(1) / norm(s)) * s;
+    const V3<T> u = cross(s, f);
+    const V3<T> ox{b.R.m[0], b.R.m[3], b.R.m[6]}, oy{b.R.m[1], b.R.m[4], b.R.m[7]}, oz{b.R.m[2], b.R.m[5], b.R.m[8]};
+    const V3<T> dp = b.pos - pc;
+    const V3<T> nf = mk<T>(0, 0, 0) - f;
+    float* X = st.stim_xform;
+    X[0 * n + env] = (float)dot(s, ox);  X[1 * n + env] = (float)dot(s, oy);  X[2 * n + env] = (float)dot(s, oz);
+    X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
+    X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
+    X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+}
+
+template <typename T, int TOPO, bool POS>
+__global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                  const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double push_lds_raw[];             // kPushLdsWords * 64 words of T (83 KB in f64: dynamic, above the 64 KB static cap)
+    const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // encode_actions (object_push_env.py:372-454)
+    const float* a = actions + (size_t)env * c.act_dim;
+    if (c.movement_mode == TG_PMOVE_Y) { enc[0] = c.max_action; enc[1] = (T)a[0]; }
+    else if (c.movement_mode == TG_PMOVE_YRZ) { enc[0] = c.max_action; enc[1] = (T)a[0]; enc[5] = (T)a[1]; }
+    else if (c.movement_mode == TG_PMOVE_XYRZ) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[5] = (T)a[2]; }
+    else {                                               // TCP-frame moves: along / across the sensor's pointing direction
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> ptcp; M3<T> Rtcp;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+        const M3<T> Rq = mat_from_quat(quat_from_mat(Rtcp));
+        const V3<T> par = mul(c.work_Rinv, mul(Rq, mk(T(1), T(0), T(0)))), perp = mul(c.work_Rinv, mul(Rq, mk(T(0), T(-1), T(0))));
+        if (c.movement_mode == TG_PMOVE_TYRZ) {
+            const T pa_ = T(1) * c.max_action;
+            enc[0] += perp.x * (T)a[0] + par.x * pa_;
+            enc[1] += perp.y * (T)a[0] + par.y * pa_;
+            enc[5] += (T)a[1];
+        } else {
+            enc[0] += perp.x * (T)a[1] + par.x * (T)a[0];
+            enc[1] += perp.y * (T)a[1] + par.y * (T)a[0];
+            enc[5] += (T)a[2];
+        }
+    }
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+    T qd_des[N];
+    V3<T> tpos; Q4<T> tq;
+    if constexpr (POS) {                                  // TCP_position_control: qd_des carries the joint targets
+        tcp_position_target<T, TOPO>(m, c, q, vels, tpos, tq, qd_des);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = 0.0;
+    } else {
+        tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+    }
+    const T mass = (T)st.obj_mass[env];
+    int ccode = 0;
+    T qdummy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    if constexpr (POS) {                                  // blocking_move(max_steps, constant_vel=None), robot.py:188-260
+        for (int t = 0; t < c.max_blocking; ++t) {
+            const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+            sim_tick_push<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
+                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x, ccode);
+            if (stop) break;
+        }
+    } else {
+        for (int t = 0; t < c.action_repeat; ++t)
+            sim_tick_push<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
+                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x, ccode);
+    }
+    st.contact_code[env] = ccode;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    store_body<T>(st, n, env, b);
+    finish_push<T, TOPO>(m, c, st, env, q, b, step_count, true);
+}
+
+// BaseObjectEnv.reset (base_object_env.py:146-173) for object_push: Robot.reset with the cube where the last episode left it,
+// reset_object (teleport; rand_init_orn / rand_obj_mass draws, object_push_env.py:168-194), make_goal (:316-340; the simplex
+// trajectory itself is filled in by k_gen_traj from the seed drawn here).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                   const uint8_t* __restrict__ mask) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double push_lds_raw[];
+    const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    uint64_t rs = st.rng[env];
+    const double ang = c.rand_init_orn ? rng_uniform(rs, -c.init_orn_range, c.init_orn_range) : 0.0;
+    const double old_mass = st.obj_mass[env];
+    const double new_mass = c.rand_obj_mass ? rng_uniform(rs, c.mass_lo, c.mass_hi) : old_mass;
+    if (c.traj_type == TG_TRAJ_SIMPLEX) st.noise_seed[env] = (int64_t)rng_uniform(rs, 0.0, 1.0e8);
+    else {
+        const double ta = rng_uniform(rs, -c.traj_ang_range, c.traj_ang_range);
+        double ys[TG_MAX_TRAJ_POINTS];
+        for (int i = 0; i < c.traj_n; ++i) {
+            const double dist = (double)i * c.traj_spacing;
+            st.traj[(0 * TG_MAX_TRAJ_POINTS + i) * n + env] = c.traj_init_offset + dist * cos(ta);
+            ys[i] = dist * sin(ta);
+            st.traj[(1 * TG_MAX_TRAJ_POINTS + i) * n + env] = ys[i];
+        }
+        for (int i = 0; i < c.traj_n; ++i) {
+            double g;
+            if (i == 0) g = (ys[1] - ys[0]) / c.traj_spacing;
+            else if (i == c.traj_n - 1) g = (ys[i] - ys[i - 1]) / c.traj_spacing;
+            else g = (ys[i + 1] - ys[i - 1]) / (2.0 * c.traj_spacing);
+            st.traj[(2 * TG_MAX_TRAJ_POINTS + i) * n + env] = g;
+        }
+    }
+    st.rng[env] = rs;
+    st.step_count[env] = 0;
+    st.goal_id[env] = c.reset_goal_id;   // get_step_data at the end of reset may already have advanced the goal (tg_config.reset_goal_id)
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+    const V3<T> tpos = load_v3(c.work_pos);               // update_init_pose: work-frame origin, rpy 0 (base_object_env.py:96-103)
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }
+    T cv = T(0.001);
+    T zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    int used = 0, ccode = 0;
+    for (int it = 0; it < 1000; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], step_j[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        if (all_small) cv = cv / T(2);
+        sim_tick_push<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, b, c.push,
+                                               (const T*)st.tip_verts, (T)old_mass, lds + threadIdx.x, ccode);
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.reset_ticks[env] = used;
+    st.contact_code[env] = ccode;
+    // reset_object: resetBasePositionAndOrientation(init_obj_pos, init_obj_orn), velocities zeroed
+    b.pos = load_v3(c.obj_init_pos);
+    b.R = mat_from_quat(quat_from_euler((T)c.obj_init_rpy[0], (T)c.obj_init_rpy[1], (T)(c.obj_init_rpy[2] + ang)));
+    b.v = mk<T>(0, 0, 0); b.w = mk<T>(0, 0, 0);
+    st.obj_mass[env] = new_mass;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+    store_body<T>(st, n, env, b);
+    finish_push<T, TOPO>(m, c, st, env, q, b, 0, false);
+}
+
+// ------------------------------------------------------------------------------------------------ object_roll
+// get_step_data (object_roll_env.py:311-365): the goal, given in the TCP frame, is carried along with the TCP (update_goal :268-295);
+// reward -|obj_xy - goal_xy|, done below 1 mm; extended_feature = goal_pos_tcp (:409-415); camera <- marble transform with the
+// episode's scale (loadURDF globalScaling scales the visual).
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_roll(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                            const FreeBody<T>& b, T scale, int step_count, bool write_reward_done) {
+    const int n = c.num_envs;
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    T rpy[3];
+    const Q4<T> qtcp = quat_from_mat(Rtcp);
+    euler_from_quat(qtcp, rpy[0], rpy[1], rpy[2]);
+    st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
+    st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
+    const V3<T> gt = mk((T)st.goal[0 * n + env], (T)st.goal[1 * n + env], (T)st.goal[2 * n + env]);
+    if (write_reward_done) {
+        const V3<T> gw = ptcp + mul(mat_from_quat(qtcp), gt);                              // multiplyTransforms(tcp pose, goal_pos_tcp)
+        const T dx = b.pos.x - gw.x, dy = b.pos.y - gw.y;
+        const T dist = tsqrt(dx * dx + dy * dy);                                           // xy_obj_dist_to_goal
+        const bool at_goal = dist < c.term_dist;
+        st.reward[env] = (float)(c.reward_mode == TG_REWARD_SPARSE ? (at_goal ? T(1) : T(0)) : -(T(1) * dist));
+        st.done[env] = (at_goal || step_count >= c.max_steps) ? 1 : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const float f = e == 0 ? (float)gt.x : (e == 1 ? (float)gt.y : (e == 2 ? (float)gt.z : 0.0f));
+        if (write_reward_done) st.term_feature[(size_t)env * 12 + e] = f;
+        st.feature[(size_t)env * 12 + e] = f;
+    }
+    V3<T> pb; M3<T> Rb;
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
+    const M3<T> Rc = mul(Rb, c.cam_rot);
+    V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
+    f = (T(1) / norm(f)) * f;
+    V3<T> s = cross(f, up);
+    s = (T(1) / norm(s)) * s;
+    const V3<T> u = cross(s, f);
+    const V3<T> ox = scale * mk(b.R.m[0], b.R.m[3], b.R.m[6]), oy = scale * mk(b.R.m[1], b.R.m[4], b.R.m[7]), oz = scale * mk(b.R.m[2], b.R.m[5], b.R.m[8]);
+    const V3<T> dp = b.pos - pc;
+    const V3<T> nf = mk<T>(0, 0, 0) - f;
+    float* X = st.stim_xform;
+    X[0 * n + env] = (float)dot(s, ox);  X[1 * n + env] = (float)dot(s, oy);  X[2 * n + env] = (float)dot(s, oz);
+    X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
+    X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
+    X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+}
+
+template <typename T, int TOPO, bool POS>
+__global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                  const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double push_lds_raw[];
+    const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    FreeBody<T> b = load_body<T>(st, n, env);
+    const float* a = actions + (size_t)env * c.act_dim;
+    T enc[6] = {(T)a[0], (T)a[1], T(0), T(0), T(0), T(0)};   // encode_actions "xy" (object_roll_env.py:297-309)
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    st.step_count[env] = step_count;
+    const T radius = (T)st.obj_mass[env];                                  // the episode's radius
+    int ccode = 0;
+    const T work_dz = (T)((2.0 * st.obj_mass[env] - st.embed[env]) - (double)c.work_pos[2]);   // update_workframe (:192-201)
+    T qd_des[N], zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    if constexpr (POS) {                                  // TCP_position_control: qd_des carries the joint targets
+        V3<T> tpos; Q4<T> tq;
+        tcp_position_target<T, TOPO>(m, c, q, vels, tpos, tq, qd_des, work_dz);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = 0.0;
+        for (int t = 0; t < c.max_blocking; ++t) {        // blocking_move(max_steps, constant_vel=None), robot.py:188-260
+            const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+            sim_tick_push<T, TOPO, kMotorPosition, 1>(m, q, qd, qd_des, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
+                                                      nullptr, radius, lds + threadIdx.x, ccode);
+            if (stop) break;
+        }
+    } else {
+        tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, nullptr, work_dz);
+#pragma unroll
+        for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
+        for (int t = 0; t < c.action_repeat; ++t)
+            sim_tick_push<T, TOPO, kMotorVelocity, 1>(m, q, qd, zero, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push, nullptr,
+                                                      radius, lds + threadIdx.x, ccode);
+    }
+    st.contact_code[env] = ccode;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
+    store_body<T>(st, n, env, b);
+    finish_roll<T, TOPO>(m, c, st, env, q, b, radius / (T)c.roll_radius, step_count, true);
+}
+
+// BaseObjectEnv.reset (base_object_env.py:153-190) for object_roll: reset_task (marble size, embed distance; :176-190), update_workframe,
+// Robot.reset with the marble of the last episode still in the world, reset_object (:203-248), make_goal (:250-266).
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                   const uint8_t* __restrict__ mask) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double push_lds_raw[];
+    const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = c.num_envs;
+    if (env >= n) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    uint64_t rs = st.rng[env];
+    const double old_radius = st.obj_mass[env];
+    const double scaling = c.roll_rand_size ? rng_uniform(rs, 1.0, 2.0) : 1.0;
+    const double new_radius = c.roll_radius * scaling;
+    double embed = st.embed[env];
+    if (c.roll_rand_embed) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
+    double ix = 0.0, iy = 0.0;
+    if (c.roll_rand_init_pos) { ix = rng_uniform(rs, -c.roll_init_range, c.roll_init_range); iy = rng_uniform(rs, -c.roll_init_range, c.roll_init_range); }
+    const double gang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+    const double gdist = rng_uniform(rs, c.roll_goal_lo, c.roll_goal_hi);
+    st.rng[env] = rs;
+    st.step_count[env] = 0;
+    st.embed[env] = embed;
+    st.goal[0 * n + env] = gdist * cos(gang); st.goal[1 * n + env] = gdist * sin(gang); st.goal[2 * n + env] = 0.0;
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+    const V3<T> tpos = mk(c.work_pos[0], c.work_pos[1], (T)(2.0 * new_radius - embed));   // work-frame origin of this episode, rpy 0
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }
+    T cv = T(0.001);
+    T zero[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero[i] = T(0);
+    int used = 0, ccode = 0;
+    for (int it = 0; it < 1000; ++it) {
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], step_j[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        if (all_small) cv = cv / T(2);
+        sim_tick_push<T, TOPO, kMotorPosition, 1>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, b, c.push,
+                                                  nullptr, (T)old_radius, lds + threadIdx.x, ccode);
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
+    }
+    st.reset_ticks[env] = used;
+    st.contact_code[env] = ccode;
+    // reset_object: teleport (or reload with the new scale), velocities zeroed
+    b.pos = mk((T)((double)c.obj_init_pos[0] + ix), (T)((double)c.obj_init_pos[1] + iy), (T)new_radius);
+    const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) b.R.m[k] = ident[k];
+    b.v = mk<T>(0, 0, 0); b.w = mk<T>(0, 0, 0);
+    st.obj_mass[env] = new_radius;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+    store_body<T>(st, n, env, b);
+    finish_roll<T, TOPO>(m, c, st, env, q, b, (T)scaling, 0, false);
+}
+
+// Recompute cached read-backs after tg_set_joint_state.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_refresh(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st) {
+    constexpr int N = Topo<TOPO>::N;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = cp->num_envs;
+    if (env >= n) return;
+    T q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = (T)st.q[i * n + env];
+    finish_env<T, TOPO>(*mp, *cp, st, env, q, (T)st.edge_ang[env], st.step_count[env], false);
+}
+
+// ------------------------------------------------------------------------------------------------ function-level kernels
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_inverse_dynamics(const DevRobot<T>* __restrict__ mp, int n, const double* q, const double* qd, const double* qdd, double* tau) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T qq[N], qv[N], hb[N], qdm[N], Minv[N][N], trM;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { qq[i] = (T)q[s * N + i]; qv[i] = (T)qd[s * N + i]; }
+    { Kin<T, TOPO> kk; dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv, trM, load_v3(mp->gravity), kk); }
+    // tau = M qdd + h ; M qdd obtained by solving Minv x = qdd would be circular, so rebuild M from Minv^-1 is avoided:
+    // use linearity  ID(q, qd, qdd) = h + M qdd with M = inverse(Minv) computed by the pivoted solver column by column.
+    T A[N][N], b[N], x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[i][j] = Minv[i][j];
+        b[i] = (T)qdd[s * N + i];
+    }
+    solve_pivoted<T, N>(A, b, x);   // x = M qdd
+#pragma unroll
+    for (int i = 0; i < N; ++i) tau[s * N + i] = (double)(hb[i] + x[i]);
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_mass_matrix(const DevRobot<T>* __restrict__ mp, int n, const double* q, double* M) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T qq[N], qv[N], hb[N], qdm[N], Minv[N][N], trM;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { qq[i] = (T)q[s * N + i]; qv[i] = T(0); }
+    { Kin<T, TOPO> kk; dynamics_terms<T, TOPO>(*mp, qq, qv, hb, qdm, Minv, trM, load_v3(mp->gravity), kk); }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {   // column j of M = solve(Minv, e_j)
+        T A[N][N], b[N], x[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < N; ++jj) A[i][jj] = Minv[i][jj];
+            b[i] = (i == j) ? T(1) : T(0);
+        }
+        solve_pivoted<T, N>(A, b, x);
+#pragma unroll
+        for (int i = 0; i < N; ++i) M[(size_t)s * N * N + i * N + j] = (double)x[i];
+    }
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_jacobian(const DevRobot<T>* __restrict__ mp, int n, const double* q, double* J, double* pos, double* rot) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T qq[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qq[i] = (T)q[s * N + i];
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(*mp, qq, k);
+    V3<T> p; M3<T> R;
+    link_frame<T, TOPO>(k, mp->tcp_link, mp->tcp_pos, mp->tcp_rot, p, R);
+    T Jm[6][N];
+    tcp_jacobian<T, TOPO>(*mp, k, p, Jm);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int i = 0; i < N; ++i) J[(size_t)s * 6 * N + r * N + i] = (double)Jm[r][i];
+    pos[s * 3 + 0] = (double)p.x; pos[s * 3 + 1] = (double)p.y; pos[s * 3 + 2] = (double)p.z;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) rot[s * 9 + e] = (double)R.m[e];
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_sim_ticks(const DevRobot<T>* __restrict__ mp, int n, int n_ticks, int iters, double dt, int motor_mode, const double* q_des,
+                            const double* qd_des, double max_force, double* q, double* qd) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T qq[N], qv[N], qdes[N], vdes[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        qq[i] = (T)q[s * N + i]; qv[i] = (T)qd[s * N + i];
+        qdes[i] = q_des ? (T)q_des[s * N + i] : T(0); vdes[i] = qd_des ? (T)qd_des[s * N + i] : T(0);
+    }
+    for (int t = 0; t < n_ticks; ++t) {
+        if (motor_mode == kMotorVelocity) sim_tick<T, TOPO, kMotorVelocity>(*mp, qq, qv, qdes, vdes, T(0), mp->vel_gain, (T)max_force, (T)dt, iters);
+        else if (motor_mode == kMotorPosition) sim_tick<T, TOPO, kMotorPosition>(*mp, qq, qv, qdes, vdes, mp->pos_gain, mp->vel_gain, (T)max_force, (T)dt, iters);
+        else sim_tick<T, TOPO, kMotorOff>(*mp, qq, qv, qdes, vdes, T(0), T(0), T(0), (T)dt, iters);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[s * N + i] = (double)qq[i]; qd[s * N + i] = (double)qv[i]; }
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_ik(const DevRobot<T>* __restrict__ mp, int n, const double* q0, const double* tpos, const double* trot,
+                                           int max_iters, double threshold, double* q_out, int32_t* iters) {
+    constexpr int N = Topo<TOPO>::N;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    T q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = (T)q0[s * N + i];
+    M3<T> Rt;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rt.m[e] = (T)trot[s * 9 + e];
+    const int it = inverse_kinematics<T, TOPO>(*mp, mk((T)tpos[s * 3], (T)tpos[s * 3 + 1], (T)tpos[s * 3 + 2]), Rt, q, max_iters, (T)threshold);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q_out[s * N + i] = (double)q[i];
+    iters[s] = it;
+}
+
+}  // namespace tg

@@ -327,9 +327,9 @@ struct tg_ctx {
     // 3-4 kernels per step, one graph launch instead)
     hipStream_t aux_stream = nullptr;                // object_balance: the reset of finished envs runs here, beside the render
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipGraphExec_t step_graph = nullptr;
-    const float* step_graph_actions = nullptr;
-    hipStream_t step_graph_stream = nullptr;
+    hipGraphExec_t step_graph[2] = {nullptr, nullptr};           // [0] reads d_actions, [1] the pinned caller-owned device buffer
+    const float* step_graph_actions[2] = {nullptr, nullptr};
+    hipStream_t step_graph_stream[2] = {nullptr, nullptr};
     bool graph_broken = false;
     // profiling
     bool profile = false;
@@ -557,7 +557,20 @@ extern "C" {
 const char* tg_last_error(void) { return g_err.c_str(); }
 int tg_abi_version(void) { return TG_ABI_VERSION; }
 
+static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sensor, const tg_mesh* stim, tg_ctx** out);
 int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sensor, const tg_mesh* stim, tg_ctx** out) {
+    if (!out) return fail(-1, "tg_create: NULL argument");
+    *out = nullptr;
+    const int rc = create_impl(cfg, robot, sensor, stim, out);
+    if (rc != 0 && *out) {               // a failure half way: release the context and every device allocation made so far
+        const std::string keep = g_err;
+        tg_destroy(*out);
+        *out = nullptr;
+        g_err = keep;
+    }
+    return rc;
+}
+static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sensor, const tg_mesh* stim, tg_ctx** out) {
     if (!cfg || !robot || !sensor || !out) return fail(-1, "tg_create: NULL argument");
     if (cfg->abi_version != TG_ABI_VERSION) return fail(-1, "tg_create: ABI version mismatch");
     if (cfg->env_kind != TG_ENV_EDGE_FOLLOW && cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && cfg->env_kind != TG_ENV_OBJECT_BALANCE &&
@@ -566,6 +579,7 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     if (cfg->env_kind != TG_ENV_SURFACE_FOLLOW_AUTO && !stim) return fail(-1, "tg_create: this env needs a stimulus mesh");
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE && robot->topology != 0) return fail(-1, "tg_create: object_balance is built for the UR5 chain");
     if (cfg->num_envs <= 0) return fail(-1, "tg_create: num_envs must be positive");
+    if (cfg->num_envs > 65535) return fail(-1, "tg_create: at most 65535 envs per context (the render launch carries the env index in grid.y); shard over contexts / GPUs");
     if (int rc = check_robot(robot)) return rc;
     const int H = sensor->image_h, W = sensor->image_w;
     if (!((H % 128 == 0 && W % 128 == 0) || (H == 64 && W == 64))) return fail(-1, "tg_create: image size must be 64x64 or a multiple of 128");
@@ -576,6 +590,7 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
         return fail(-3, "tg_create: no HIP device visible — the tactile-env step has no CPU fallback");
     TG_HIP(hipSetDevice(cfg->device));
     tg_ctx* c = new tg_ctx();
+    *out = c;                            // owned by tg_create's guard from here on
     c->cfg = *cfg; c->robot = *robot; c->H = H; c->W = W;
     TG_HIP(hipStreamCreate(&c->own_stream));
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE) {
@@ -739,15 +754,23 @@ int tg_create(const tg_config* cfg, const tg_robot* robot, const tg_sensor* sens
     TG_HIP(hipMalloc(&c->d_mask, n));
     TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 6 * sizeof(float)));
     c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border, sensor->nodef_dep);
-    *out = c;
     return 0;
 }
 
+// Every entry point that touches the device first makes the context's device current: the caller may have switched devices
+// (torch.cuda.set_device, another thread) since tg_create.
+#define TG_ENTER(ctx)                                                                                        \
+    do {                                                                                                     \
+        int dev_ = -1;                                                                                       \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ != (ctx)->cfg.device) TG_HIP(hipSetDevice((ctx)->cfg.device)); \
+    } while (0)
+
 int tg_destroy(tg_ctx* c) {
     if (!c) return 0;
+    (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
-    if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
+    for (int k = 0; k < 2; ++k) if (c->step_graph[k]) (void)hipGraphExecDestroy(c->step_graph[k]);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
@@ -769,6 +792,7 @@ int tg_set_stream(tg_ctx* c, void* s) {
 
 int tg_seed(tg_ctx* c, const uint64_t* seeds, int32_t n) {
     if (!c || !seeds) return fail(-1, "tg_seed: NULL argument");
+    TG_ENTER(c);
     if (n != c->cfg.num_envs) return fail(-1, "tg_seed: need one seed per env");
     std::vector<uint64_t> st(n);
     for (int i = 0; i < n; ++i) st[i] = mix64(seeds[i] + kGolden);
@@ -779,6 +803,7 @@ int tg_seed(tg_ctx* c, const uint64_t* seeds, int32_t n) {
 
 int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
     if (!c) return fail(-1, "NULL ctx");
+    TG_ENTER(c);
     const uint8_t* dmask = nullptr;
     if (host_mask) {
         TG_HIP(hipMemcpyAsync(c->d_mask, host_mask, c->cfg.num_envs, hipMemcpyHostToDevice, c->stream));
@@ -859,29 +884,44 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
 
 int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     if (!c || !actions) return fail(-1, "tg_step: NULL argument");
+    TG_ENTER(c);
     const float* d_act = actions;
     if (!on_device) {
         TG_HIP(hipMemcpyAsync(c->d_actions, actions, (size_t)c->cfg.num_envs * c->act_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
         d_act = c->d_actions;
     }
     // The launch sequence of a step is the same every step (all arguments are device pointers owned by the context, the action
-    // buffer aside): capture it once per action pointer / stream and replay it as one graph launch.  Not while profiling (the
-    // per-kernel events are host calls between the launches) and not for the push kernels (hipFuncSetAttribute on first launch).
+    // buffer aside), so it is captured once and replayed as one graph launch.  Two graphs, neither ever re-captured:
+    //   slot 0  reads the context's own action buffer: host actions are uploaded into it, and so are device actions that arrive in a
+    //           buffer other than the pinned one below - a policy that hands over a fresh tensor every step costs one 8 KB device
+    //           copy per step, not a graph instantiation;
+    //   slot 1  reads the FIRST caller-owned device buffer seen, in place (a rollout that reuses one action tensor, e.g. bench.py).
+    // Not while profiling (the per-kernel events are host calls between the launches) and not for the lane-per-env push kernels
+    // (hipFuncSetAttribute on first launch).
     const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL;
     if (want_graph) {
-        if (c->step_graph && (c->step_graph_actions != d_act || c->step_graph_stream != c->stream)) {
-            (void)hipGraphExecDestroy(c->step_graph);
-            c->step_graph = nullptr;
+        int slot = 0;
+        if (on_device) {
+            if (c->step_graph_actions[1] == nullptr && c->step_graph[1] == nullptr) c->step_graph_actions[1] = d_act;   // pin the first one
+            if (c->step_graph_actions[1] == d_act) slot = 1;
+            else {
+                TG_HIP(hipMemcpyAsync(c->d_actions, actions, (size_t)c->cfg.num_envs * c->act_dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                d_act = c->d_actions;
+            }
         }
-        if (!c->step_graph) {
+        if (c->step_graph[slot] && c->step_graph_stream[slot] != c->stream) {   // tg_set_stream since the capture: once per stream change
+            (void)hipGraphExecDestroy(c->step_graph[slot]);
+            c->step_graph[slot] = nullptr;
+        }
+        if (!c->step_graph[slot]) {
             hipGraph_t g = nullptr;
             if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 enqueue_step(c, d_act);
                 const hipError_t e1 = hipStreamEndCapture(c->stream, &g);
-                if (e1 == hipSuccess && g && hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0) == hipSuccess) {
-                    c->step_graph_actions = d_act; c->step_graph_stream = c->stream;
+                if (e1 == hipSuccess && g && hipGraphInstantiate(&c->step_graph[slot], g, nullptr, nullptr, 0) == hipSuccess) {
+                    c->step_graph_stream[slot] = c->stream;
                 } else {
-                    c->step_graph = nullptr; c->graph_broken = true;
+                    c->step_graph[slot] = nullptr; c->graph_broken = true;
                 }
                 if (g) (void)hipGraphDestroy(g);
             } else {
@@ -889,8 +929,8 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
             }
             (void)hipGetLastError();
         }
-        if (c->step_graph) {
-            TG_HIP(hipGraphLaunch(c->step_graph, c->stream));
+        if (c->step_graph[slot]) {
+            TG_HIP(hipGraphLaunch(c->step_graph[slot], c->stream));
             return 0;
         }
     }
@@ -901,6 +941,7 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
 
 int tg_sync(tg_ctx* c) {
     if (!c) return fail(-1, "NULL ctx");
+    TG_ENTER(c);
     // A step is ~0.15 ms: the interrupt-driven wake-up of hipStreamSynchronize costs a noticeable fraction of it.  Poll for up to
     // ~2 ms (VecEnv.step_wait follows step_async immediately), then fall back to the blocking wait.
     const auto t0 = std::chrono::steady_clock::now();
@@ -963,6 +1004,7 @@ int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {
 }
 int tg_copy_obs_feature(tg_ctx* c, float* dst, int32_t terminal) {
     if (!c || !dst) return fail(-1, "NULL argument");
+    TG_ENTER(c);
     if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL)
         return fail(-1, "tg_copy_obs_feature: this env has no extended_feature observation");
     TG_HIP(hipMemcpyAsync(dst, terminal ? c->st.term_feature : c->st.feature, (size_t)c->cfg.num_envs * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -971,6 +1013,7 @@ int tg_copy_obs_feature(tg_ctx* c, float* dst, int32_t terminal) {
 }
 int tg_get_reward_done(tg_ctx* c, float* reward, uint8_t* done) {
     if (!c) return fail(-1, "NULL ctx");
+    TG_ENTER(c);
     const int n = c->cfg.num_envs;
     if (reward) TG_HIP(hipMemcpyAsync(reward, c->st.reward, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (done) TG_HIP(hipMemcpyAsync(done, c->st.done, (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -979,6 +1022,7 @@ int tg_get_reward_done(tg_ctx* c, float* reward, uint8_t* done) {
 }
 int tg_copy_obs_tactile(tg_ctx* c, uint8_t* dst, int32_t terminal) {
     if (!c || !dst) return fail(-1, "NULL argument");
+    TG_ENTER(c);
     TG_HIP(hipMemcpyAsync(dst, terminal ? c->d_term : c->d_obs, (size_t)c->cfg.num_envs * c->H * c->W, hipMemcpyDeviceToHost, c->stream));
     TG_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -986,6 +1030,7 @@ int tg_copy_obs_tactile(tg_ctx* c, uint8_t* dst, int32_t terminal) {
 
 int tg_get_state(tg_ctx* c, const tg_state_view* v) {
     if (!c || !v) return fail(-1, "NULL argument");
+    TG_ENTER(c);
     const int nd = c->robot.ndof;
     int rc = 0;
     if (v->q && (rc = fetch_soa(c, c->st.q, nd, v->q))) return rc;
@@ -1057,6 +1102,7 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
 
 int tg_set_joint_state(tg_ctx* c, const double* q, const double* qd) {
     if (!c || !q || !qd) return fail(-1, "NULL argument");
+    TG_ENTER(c);
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE || c->cfg.env_kind == TG_ENV_OBJECT_PUSH || c->cfg.env_kind == TG_ENV_OBJECT_ROLL)
         return fail(-1, "tg_set_joint_state: not supported for envs with a free object");
     const int n = c->cfg.num_envs, nd = c->robot.ndof;

@@ -11,7 +11,7 @@ import numpy as np
 
 from .. import _capi as capi
 from ..robot_model import ASSETS, MeshDesc, SensorDesc, load_tgmodel, make_robot
-from ..vec_env import TactileVecEnv
+from ..vec_env import SingleTactileEnv, TactileVecEnv
 
 REST_POSES = {"ur5": {"standard": [0.19826, -2.01062, -1.96602, -0.73808, 4.71286, -3.34064]}}   # object_balance/rest_poses.py:4-20
 
@@ -96,13 +96,13 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class ObjectBalanceVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True):
         cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"xy": 2, "xyz": 3, "RxRy": 2, "xyRxRy": 4}[modes["movement_mode"]]           # :565-576
-        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=act_dim, oracle_dim=26)
 
     def oracle_obs(self):
@@ -114,37 +114,11 @@ class ObjectBalanceVecEnv(TactileVecEnv):
         return np.hstack([tp, tq, tl, ta, op, oq, ol, oa]).astype(np.float32)
 
 
-class ObjectBalanceEnv:
+class ObjectBalanceEnv(SingleTactileEnv):
     """Single-env gym.Env surface; constructor signature as object_balance_env.py:23-30."""
 
-    metadata = {"render.modes": ["rgb_array"]}
+    vec_cls = ObjectBalanceVecEnv
+    default_env_modes = env_modes_default
 
-    def __init__(self, max_steps=1000, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
-                 physics_dtype="f64", device=0):
-        if show_gui or show_tactile:
-            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
-        self._vec = ObjectBalanceVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
-        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
-        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
-
-    @classmethod
-    def make_vec(cls, num_envs, **kwargs):
-        kwargs.pop("show_gui", None)
-        kwargs.pop("show_tactile", None)
-        return ObjectBalanceVecEnv(num_envs, **kwargs)
-
-    def seed(self, seed=None):
-        return self._vec.seed(seed)[:1]
-
-    def reset(self):
-        return {k: v[0] for k, v in self._vec.reset().items()}
-
-    def step(self, action):
-        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
-        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
-
-    def render(self, mode="rgb_array"):
-        return self._vec.render(mode)
-
-    def close(self):
-        self._vec.close()
+    def __init__(self, max_steps=1000, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False, **kwargs):
+        super().__init__(max_steps, image_size, env_modes, show_gui, show_tactile, **kwargs)

@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import _capi as capi
 from ..robot_model import ASSETS, MeshDesc, SensorDesc, load_tgmodel, make_robot
-from ..vec_env import TactileVecEnv
+from ..vec_env import SingleTactileEnv, TactileVecEnv
 
 REST_POSES = {  # object_push/rest_poses.py, control-joint order; MG400 + TacTip carries the `mini_right_angle` sensor (object_push_env.py:70-75)
     "mg400": {
@@ -155,7 +155,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class ObjectPushVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, contact_mapping="auto", solver_iterations=None):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True, contact_mapping="auto", solver_iterations=None):
         cfg, robot, sensor, mesh, modes, tip_verts = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         if solver_iterations is not None:
             cfg.solver_iterations = int(solver_iterations)   # numSolverIterations (base_tactile_env.py:128-130: 150); measurements only
@@ -165,7 +165,7 @@ class ObjectPushVecEnv(TactileVecEnv):
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"y": 1, "yRz": 2, "xyRz": 3, "TyRz": 2, "TxTyRz": 3}[modes["movement_mode"]]  # :631-644
-        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=act_dim, oracle_dim=30, feature_dim=12)
 
     def oracle_obs(self):
@@ -181,37 +181,11 @@ class ObjectPushVecEnv(TactileVecEnv):
         return np.hstack([tp, tr, tl, ta, op, orr, ol, oa, gpos, grpy]).astype(np.float32)
 
 
-class ObjectPushEnv:
+class ObjectPushEnv(SingleTactileEnv):
     """Single-env gym.Env surface; constructor signature as object_push_env.py:24-31."""
 
-    metadata = {"render.modes": ["rgb_array"]}
+    vec_cls = ObjectPushVecEnv
+    default_env_modes = env_modes_default
 
-    def __init__(self, max_steps=1000, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
-                 physics_dtype="f64", device=0):
-        if show_gui or show_tactile:
-            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
-        self._vec = ObjectPushVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
-        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
-        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
-
-    @classmethod
-    def make_vec(cls, num_envs, **kwargs):
-        kwargs.pop("show_gui", None)
-        kwargs.pop("show_tactile", None)
-        return ObjectPushVecEnv(num_envs, **kwargs)
-
-    def seed(self, seed=None):
-        return self._vec.seed(seed)[:1]
-
-    def reset(self):
-        return {k: v[0] for k, v in self._vec.reset().items()}
-
-    def step(self, action):
-        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
-        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
-
-    def render(self, mode="rgb_array"):
-        return self._vec.render(mode)
-
-    def close(self):
-        self._vec.close()
+    def __init__(self, max_steps=1000, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False, **kwargs):
+        super().__init__(max_steps, image_size, env_modes, show_gui, show_tactile, **kwargs)

@@ -13,7 +13,7 @@ import numpy as np
 from .. import _capi as capi
 from .. import pb_math as pbm
 from ..robot_model import ASSETS, MeshDesc, SensorDesc, load_tgmodel, make_robot
-from ..vec_env import TactileVecEnv
+from ..vec_env import SingleTactileEnv, TactileVecEnv
 
 REST_POSES = {"ur5": {"flat": [0.16682, -2.23156, -1.66642, -0.81399, 1.57315, 1.74001]}}    # object_roll/rest_poses.py
 
@@ -101,7 +101,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class ObjectRollVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, contact_mapping="auto", solver_iterations=None):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True, contact_mapping="auto", solver_iterations=None):
         cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         if solver_iterations is not None:
             cfg.solver_iterations = int(solver_iterations)   # numSolverIterations (base_tactile_env.py:128-130: 150); measurements only
@@ -109,7 +109,7 @@ class ObjectRollVecEnv(TactileVecEnv):
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
-        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=2, oracle_dim=34, feature_dim=3)                                # get_extended_feature_array :409-415
 
     def feature_numpy(self, terminal=False):
@@ -153,37 +153,11 @@ class ObjectRollVecEnv(TactileVecEnv):
         return np.hstack([tp, tq, tl, ta, op, oq, ol, oa, st["goal_pos"], ident, st["obj_mass"][:, None]]).astype(np.float32)
 
 
-class ObjectRollEnv:
+class ObjectRollEnv(SingleTactileEnv):
     """Single-env gym.Env surface; constructor signature as object_roll_env.py:24-31."""
 
-    metadata = {"render.modes": ["rgb_array"]}
+    vec_cls = ObjectRollVecEnv
+    default_env_modes = env_modes_default
 
-    def __init__(self, max_steps=1000, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
-                 physics_dtype="f64", device=0):
-        if show_gui or show_tactile:
-            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
-        self._vec = ObjectRollVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
-        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
-        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
-
-    @classmethod
-    def make_vec(cls, num_envs, **kwargs):
-        kwargs.pop("show_gui", None)
-        kwargs.pop("show_tactile", None)
-        return ObjectRollVecEnv(num_envs, **kwargs)
-
-    def seed(self, seed=None):
-        return self._vec.seed(seed)[:1]
-
-    def reset(self):
-        return {k: v[0] for k, v in self._vec.reset().items()}
-
-    def step(self, action):
-        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
-        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
-
-    def render(self, mode="rgb_array"):
-        return self._vec.render(mode)
-
-    def close(self):
-        self._vec.close()
+    def __init__(self, max_steps=1000, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False, **kwargs):
+        super().__init__(max_steps, image_size, env_modes, show_gui, show_tactile, **kwargs)

@@ -12,7 +12,7 @@ import numpy as np
 from .. import _capi as capi
 from .. import pb_math as pbm
 from ..robot_model import SensorDesc, load_tgmodel, make_robot
-from ..vec_env import TactileVecEnv
+from ..vec_env import SingleTactileEnv, TactileVecEnv
 
 # surface_follow/rest_poses.py (movable joints): every ur5 "standard" entry holds the same pose
 REST_POSES = {"ur5": {k: {"standard": [0.16682, -2.18943, -1.65357, -0.86897, 1.57315, 1.74001]} for k in ("tactip", "digit", "digitac")},
@@ -110,13 +110,13 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class SurfaceFollowAutoVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=200, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True):
         cfg, robot, sensor, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"yz": 1, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}[modes["movement_mode"]]          # surface_follow_auto_env.py:96-107
-        super().__init__(cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+        super().__init__(cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=act_dim, oracle_dim=20)
 
     def oracle_obs(self):
@@ -145,14 +145,14 @@ class SurfaceFollowGoalVecEnv(SurfaceFollowAutoVecEnv):
     """surface_follow-v1: the agent drives every dimension; `tactile_and_feature` adds [tcp_pos, goal_pos] in the work frame."""
 
     def __init__(self, num_envs, max_steps=200, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True):
         cfg, robot, sensor, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device,
                                                  goal_variant=True)
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"yz": 2, "xyz": 3, "yzRx": 3, "xyzRxRy": 5}[modes["movement_mode"]]          # surface_follow_goal_env.py:112-123
-        TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+        TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                                act_dim=act_dim, oracle_dim=20, feature_dim=6)
 
     def feature_numpy(self, terminal=False):
@@ -182,12 +182,12 @@ class SurfaceFollowVertVecEnv(SurfaceFollowGoalVecEnv):
     [tcp_pos, goal_pos] in the work frame (surface_follow_vert_env.py:83-100)."""
 
     def __init__(self, num_envs, max_steps=200, image_size=(64, 64), env_modes=env_modes_default_vert, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True):
         cfg, robot, sensor, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
-        TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed,
+        TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                                act_dim=2, oracle_dim=20, feature_dim=6)                          # get_act_dim :102-113
 
     def oracle_obs(self):
@@ -214,109 +214,33 @@ class SurfaceFollowVertVecEnv(SurfaceFollowGoalVecEnv):
         return np.hstack([tp, tq, tl, ta, gp, surf_z[:, None], wf.vec(nrm)]).astype(np.float32)
 
 
-class SurfaceFollowVertEnv:
+class SurfaceFollowVertEnv(SingleTactileEnv):
     """Single-env gym.Env surface; constructor signature as surface_follow_vert_env.py:15-27."""
 
-    metadata = {"render.modes": ["rgb_array"]}
+    vec_cls = SurfaceFollowVertVecEnv
+    default_env_modes = env_modes_default_vert
 
-    def __init__(self, max_steps=200, image_size=[64, 64], env_modes=env_modes_default_vert, show_gui=False, show_tactile=False,
-                 physics_dtype="f64", device=0):
-        if show_gui or show_tactile:
-            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
-        self._vec = SurfaceFollowVertVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
-        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
-        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
-
-    @classmethod
-    def make_vec(cls, num_envs, **kwargs):
-        kwargs.pop("show_gui", None)
-        kwargs.pop("show_tactile", None)
-        return SurfaceFollowVertVecEnv(num_envs, **kwargs)
-
-    def seed(self, seed=None):
-        return self._vec.seed(seed)[:1]
-
-    def reset(self):
-        return {k: v[0] for k, v in self._vec.reset().items()}
-
-    def step(self, action):
-        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
-        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
-
-    def render(self, mode="rgb_array"):
-        return self._vec.render(mode)
-
-    def close(self):
-        self._vec.close()
+    def __init__(self, max_steps=200, image_size=[64, 64], env_modes=env_modes_default_vert, show_gui=False, show_tactile=False, **kwargs):
+        super().__init__(max_steps, image_size, env_modes, show_gui, show_tactile, **kwargs)
 
 
-class SurfaceFollowGoalEnv:
+
+class SurfaceFollowGoalEnv(SingleTactileEnv):
     """Single-env gym.Env surface; constructor signature as surface_follow_goal_env.py:15-25."""
 
-    metadata = {"render.modes": ["rgb_array"]}
+    vec_cls = SurfaceFollowGoalVecEnv
+    default_env_modes = env_modes_default
 
-    def __init__(self, max_steps=200, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
-                 physics_dtype="f64", device=0):
-        if show_gui or show_tactile:
-            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
-        self._vec = SurfaceFollowGoalVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
-        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
-        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
-
-    @classmethod
-    def make_vec(cls, num_envs, **kwargs):
-        kwargs.pop("show_gui", None)
-        kwargs.pop("show_tactile", None)
-        return SurfaceFollowGoalVecEnv(num_envs, **kwargs)
-
-    def seed(self, seed=None):
-        return self._vec.seed(seed)[:1]
-
-    def reset(self):
-        return {k: v[0] for k, v in self._vec.reset().items()}
-
-    def step(self, action):
-        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
-        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
-
-    def render(self, mode="rgb_array"):
-        return self._vec.render(mode)
-
-    def close(self):
-        self._vec.close()
+    def __init__(self, max_steps=200, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False, **kwargs):
+        super().__init__(max_steps, image_size, env_modes, show_gui, show_tactile, **kwargs)
 
 
-class SurfaceFollowAutoEnv:
+
+class SurfaceFollowAutoEnv(SingleTactileEnv):
     """Single-env gym.Env surface; constructor signature as surface_follow_auto_env.py:16-25."""
 
-    metadata = {"render.modes": ["rgb_array"]}
+    vec_cls = SurfaceFollowAutoVecEnv
+    default_env_modes = env_modes_default
 
-    def __init__(self, max_steps=200, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False,
-                 physics_dtype="f64", device=0):
-        if show_gui or show_tactile:
-            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
-        self._vec = SurfaceFollowAutoVecEnv(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device)
-        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
-        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
-
-    @classmethod
-    def make_vec(cls, num_envs, **kwargs):
-        kwargs.pop("show_gui", None)
-        kwargs.pop("show_tactile", None)
-        return SurfaceFollowAutoVecEnv(num_envs, **kwargs)
-
-    def seed(self, seed=None):
-        return self._vec.seed(seed)[:1]
-
-    def reset(self):
-        return {k: v[0] for k, v in self._vec.reset().items()}
-
-    def step(self, action):
-        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
-        return {k: v[0] for k, v in obs.items()}, float(rew[0]), bool(done[0]), {}
-
-    def render(self, mode="rgb_array"):
-        return self._vec.render(mode)
-
-    def close(self):
-        self._vec.close()
+    def __init__(self, max_steps=200, image_size=[64, 64], env_modes=env_modes_default, show_gui=False, show_tactile=False, **kwargs):
+        super().__init__(max_steps, image_size, env_modes, show_gui, show_tactile, **kwargs)

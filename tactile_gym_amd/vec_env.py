@@ -17,6 +17,23 @@ from . import _capi as capi
 from . import spaces
 
 
+def _optional_base(module, name):
+    """`module.name` when it can be imported, else `object`: the classes below are real gym.Env / stable_baselines3 VecEnv subclasses
+    wherever those packages exist (the reference's callers wrap envs with Monitor, VecFrameStack, VecTransposeImage:
+    sb3_helpers/rl_utils.py:17-35, 49-68) and plain duck types where they do not (the build image has neither)."""
+    try:
+        import importlib
+        return getattr(importlib.import_module(module), name)
+    except Exception:  # noqa: BLE001 - absent, or broken by its own missing dependencies
+        return object
+
+
+_VecEnvBase = _optional_base("stable_baselines3.common.vec_env.base_vec_env", "VecEnv")
+_GymEnvBase = _optional_base("gym", "Env")
+if _GymEnvBase is object:
+    _GymEnvBase = _optional_base("gymnasium", "Env")
+
+
 class _DevArray:
     """Minimal __cuda_array_interface__ carrier for a raw device pointer owned by the HIP library."""
 
@@ -24,13 +41,14 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-class TactileVecEnv:
-    """N environments stepped by libtactile_gym_hip.so.  Duck-types stable_baselines3.common.vec_env.VecEnv."""
+class TactileVecEnv(_VecEnvBase):
+    """N environments stepped by libtactile_gym_hip.so: a stable_baselines3 VecEnv (a subclass when SB3 is importable, the same API as a
+    duck type otherwise)."""
 
     metadata = {"render.modes": ["rgb_array"]}
 
     def __init__(self, cfg, robot, sensor_desc, mesh_desc, observation_mode="tactile", obs_mode="numpy", seed=None, act_dim=None,
-                 oracle_dim=10, feature_dim=0):
+                 oracle_dim=10, feature_dim=0, copy_obs=True):
         self._L = capi.lib()
         self.num_envs = int(cfg.num_envs)
         self._cfg, self._robot, self._sensor, self._mesh = cfg, robot, sensor_desc, mesh_desc
@@ -41,6 +59,11 @@ class TactileVecEnv:
         if "visual" in observation_mode or "visuo" in observation_mode:
             raise NotImplementedError("visual (RGB scene camera) observations are outside the built hot path (SURVEY 8f rank 4)")
         self.obs_mode = obs_mode
+        # copy_obs=True (default): every observation batch handed out is an array of its own, like the reference's fresh arrays
+        # (base_tactile_env.py:247-282).  copy_obs=False: the device -> host copy lands in one of four rotating host buffers, valid for
+        # the next three steps - for consumers that copy on arrival anyway (SB3 rollout / replay buffers, VecFrameStack).
+        self.copy_obs = bool(copy_obs)
+        self._pinned_stream = False      # TorchShard(pipelined=True) owns the stream choice
         self._ctx = C.c_void_p()
         capi.check(self._L.tg_create(C.byref(cfg), C.byref(robot), C.byref(sensor_desc.struct),
                                      C.byref(mesh_desc.struct) if mesh_desc is not None else None, C.byref(self._ctx)))
@@ -57,6 +80,11 @@ class TactileVecEnv:
             obs_spaces["extended_feature"] = spaces.Box(low=-np.inf, high=np.inf, shape=(feature_dim,), dtype=np.float32)
         self.feature_dim = feature_dim
         self.observation_space = spaces.Dict(obs_spaces)
+        if _VecEnvBase is not object:     # SB3's constructor records num_envs / spaces (and render_mode in recent versions)
+            try:
+                _VecEnvBase.__init__(self, self.num_envs, self.observation_space, self.action_space)
+            except TypeError:             # an SB3 whose VecEnv.__init__ takes other arguments: the attributes above are what it would set
+                pass
         self._actions = np.zeros((self.num_envs, self.act_dim), dtype=np.float32)
         self._reward = np.zeros(self.num_envs, dtype=np.float32)
         self._done = np.zeros(self.num_envs, dtype=np.uint8)
@@ -80,12 +108,29 @@ class TactileVecEnv:
         if mask is not None:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
             assert m.shape == (self.num_envs,)
+        self._bind_torch_stream()
         capi.check(self._L.tg_reset(self._ctx, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None))
         capi.check(self._L.tg_sync(self._ctx))
         return self._observation()
 
+    def _bind_torch_stream(self):
+        """obs_mode="torch": the zero-copy observation / reward / done tensors and CUDA action tensors are produced and consumed on
+        torch's CURRENT stream, so the library is put on that stream before work is enqueued (tg_set_stream is a pointer swap; the step
+        graph is re-captured only when the stream actually changes).  Ordering between the policy's kernels and the env's is then the
+        stream's own: no event, no host wait, and correct under non-default or per-thread torch streams as well."""
+        if self.obs_mode != "torch" or self._pinned_stream:
+            return
+        import torch
+        ptr = torch.cuda.current_stream(torch.device("cuda", self._cfg.device)).cuda_stream
+        if getattr(self, "_bound_stream", None) != ptr:
+            if hasattr(self, "_bound_stream"):
+                capi.check(self._L.tg_sync(self._ctx))     # drain the stream being left before work goes to another one
+            capi.check(self._L.tg_set_stream(self._ctx, C.c_void_p(ptr)))
+            self._bound_stream = ptr
+
     def step_async(self, actions):
-        """actions: numpy float32 [N, act_dim], or a torch CUDA tensor (used in place, no copy)."""
+        """actions: numpy float32 [N, act_dim], or a torch CUDA tensor (read in place on the current torch stream)."""
+        self._bind_torch_stream()
         if hasattr(actions, "data_ptr") and getattr(actions, "is_cuda", False):
             assert actions.dtype.is_floating_point and actions.element_size() == 4 and actions.is_contiguous()
             assert tuple(actions.shape) == (self.num_envs, self.act_dim)
@@ -111,8 +156,8 @@ class TactileVecEnv:
         infos = [{} for _ in range(self.num_envs)]
         if self._cfg.auto_reset and dones.any():
             term = self._terminal_observation()
-            for i in np.nonzero(dones)[0]:
-                infos[i]["terminal_observation"] = {k: v[i] for k, v in term.items()}
+            for i in np.nonzero(dones)[0]:   # owned copies: the library's terminal buffers are rewritten by the next auto-reset
+                infos[i]["terminal_observation"] = {k: (v[i].clone() if hasattr(v, "clone") else np.array(v[i])) for k, v in term.items()}
                 infos[i]["TimeLimit.truncated"] = False
         return obs, self._reward.copy(), dones, infos
 
@@ -166,7 +211,10 @@ class TactileVecEnv:
         capi.check(self._L.tg_sync(self._ctx))
 
     def set_stream(self, hip_stream_ptr):
+        """Pin all of this env's work to one HIP stream (TorchShard(pipelined=True)); None returns to following torch's current stream."""
+        self._pinned_stream = hip_stream_ptr is not None
         capi.check(self._L.tg_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
+        self._bound_stream = hip_stream_ptr
 
     def tactile_device_ptr(self, terminal=False):
         p = C.c_void_p()
@@ -205,11 +253,11 @@ class TactileVecEnv:
         return self._views["packed"]
 
     def tactile_numpy(self, terminal=False):
-        """Host copy of the observation batch.  The device -> host copy lands directly in one of four rotating host buffers, which is
-        what step() hands out (a 16.8 MB `.copy()` per step cost more than the PCIe transfer): an observation array stays untouched for
-        the next three steps - consumers that keep observations longer (replay buffers do their own copy) must copy."""
-        if terminal:
-            buf = np.zeros_like(self._obs_host)
+        """Host copy of the observation batch.  copy_obs=True: a new array per call.  copy_obs=False: the device -> host copy lands in
+        one of four rotating host buffers (an extra 16.8 MB `.copy()` per step costs more than the PCIe transfer itself): the array stays
+        untouched for the next three steps."""
+        if terminal or self.copy_obs:
+            buf = np.empty_like(self._obs_host)
         else:
             self._obs_ring_i = (getattr(self, "_obs_ring_i", -1) + 1) % 4
             if not hasattr(self, "_obs_ring"):
@@ -331,3 +379,54 @@ class TactileVecEnv:
             capi.check(self._L.tg_profile_get(self._ctx, which, C.byref(ms), C.byref(cnt)))
             out[name] = (ms.value, cnt.value)
         return out
+
+
+class SingleTactileEnv(_GymEnvBase):
+    """One environment with the reference's gym.Env surface (old 4-tuple API, base_tactile_env.py:166-185): reset / step / render / seed /
+    close, action_space, observation_space, min_action / max_action - a 1-env TactileVecEnv underneath (auto-reset off: a gym.Env is reset
+    by its caller).  Subclasses name their VecEnv class and the reference constructor they mirror.  Every array handed out is owned by
+    the caller."""
+
+    metadata = {"render.modes": ["rgb_array"]}
+    vec_cls = None            # the TactileVecEnv subclass
+
+    def __init__(self, max_steps=1000, image_size=(64, 64), env_modes=None, show_gui=False, show_tactile=False, physics_dtype="f64",
+                 device=0, **kwargs):
+        if show_gui or show_tactile:
+            raise NotImplementedError("GUI / cv2 windows are not part of the headless device path")
+        if env_modes is None:
+            env_modes = self.default_env_modes
+        self._vec = self.vec_cls(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device, **kwargs)
+        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
+        self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
+        self._max_steps, self._image_size, self._seed = max_steps, list(image_size), None
+
+    @classmethod
+    def make_vec(cls, num_envs, **kwargs):
+        kwargs.pop("show_gui", None)
+        kwargs.pop("show_tactile", None)
+        return cls.vec_cls(num_envs, **kwargs)
+
+    @staticmethod
+    def _first(obs):
+        return {k: (v[0].clone() if hasattr(v, "clone") else np.array(v[0])) for k, v in obs.items()}
+
+    def seed(self, seed=None):
+        self._seed = seed
+        return self._vec.seed(seed)[:1]
+
+    def reset(self):
+        return self._first(self._vec.reset())
+
+    def step(self, action):
+        obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
+        return self._first(obs), float(rew[0]), bool(done[0]), {}
+
+    def render(self, mode="rgb_array"):
+        return self._vec.render(mode)
+
+    def close(self):
+        self._vec.close()
+
+    def get_state(self):
+        return {k: v[0] for k, v in self._vec.get_state().items()}

@@ -1207,3 +1207,90 @@ def test_sample_actions_is_a_counter_based_uniform_box_sample(edge_modes):
     assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 0.05
     venv.reset(); venv.step_async(a); venv.step_wait()   # and a step takes them in place
     venv.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- boundary
+@pytest.mark.gpu
+def test_single_env_gym_surface_matches_oracle(edge_modes):
+    """BASELINE config 1's workload (edge_follow-v0, UR5 + TacTip, ONE env, random actions) on the HIP path through the reference's
+    gym.Env surface: tg.make(id, max_steps, image_size, env_modes, show_gui, show_tactile) as sb3_helpers/rl_utils.py:49-56 calls it,
+    seed / reset / step (old 4-tuple) / render / close, against the oracle env: observations bit-exact, reward 1e-6, done exact, and
+    every returned array owned by the caller (a kept observation is not overwritten by later steps)."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleEdgeFollowEnv
+    env = tg.make("edge_follow-v0", max_steps=12, image_size=[128, 128], env_modes=edge_modes, show_gui=False, show_tactile=False)
+    assert env.seed(7) == [7]
+    assert env.action_space.shape == (2,) and env.observation_space["tactile"].shape == (128, 128, 1)
+    assert float(env.min_action) == -0.25 and float(env.max_action) == 0.25
+    ora = OracleEdgeFollowEnv(seed=7, max_steps=12, image_size=(128, 128), env_modes=edge_modes)
+    obs, ref = env.reset(), ora.reset()
+    assert set(obs) == {"tactile"} and obs["tactile"].dtype == np.uint8 and obs["tactile"].shape == (128, 128, 1)
+    assert np.array_equal(obs["tactile"], ref["tactile"])
+    kept, kept_copy = obs["tactile"], obs["tactile"].copy()
+    rng = np.random.default_rng(1)
+    done = False
+    for step in range(12):
+        a = rng.uniform(-0.25, 0.25, 2).astype(np.float32)
+        obs, rew, done, info = env.step(a)
+        ro, rr, rd, _ = ora.step(a)
+        assert isinstance(rew, float) and isinstance(done, bool) and info == {}
+        assert np.array_equal(obs["tactile"], ro["tactile"]) and abs(rew - rr) < 1e-6 and done == rd, step
+    assert done                                                   # max_steps reached: the caller resets (no auto-reset in a gym.Env)
+    assert np.array_equal(kept, kept_copy)                        # the first observation is still what it was
+    frame = env.render(mode="rgb_array")
+    assert frame.dtype == np.uint8 and frame.ndim == 3 and frame.shape[2] == 3
+    obs2 = env.reset()
+    assert np.array_equal(obs2["tactile"], ora.reset()["tactile"])
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arm", ["ur5", "mg400"])
+def test_edge_follow_oracle_observation_vector(edge_modes, arm):
+    """observation_mode "oracle" of edge_follow (edge_follow_env.py:454-476): [tcp pos (work frame) 3, tcp linear velocity (work frame) 3,
+    goal pos (work frame) 3, edge angle] float32 [N, 10], against the oracle's restatement after reset and after steps."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleEdgeFollowEnv
+    modes = dict(edge_modes, observation_mode="oracle", arm_type=arm)
+    n = 4
+    venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=50, image_size=[64, 64], env_modes=modes, seed=3, auto_reset=False)
+    assert venv.observation_space["oracle"].shape == (10,)
+    oracles = [OracleEdgeFollowEnv(seed=3 + i, max_steps=50, image_size=(64, 64), env_modes=modes) for i in range(n)]
+    obs = venv.reset()
+    ref = [o.reset() for o in oracles]
+    rng = np.random.default_rng(2)
+    for step in range(4):
+        for i in range(n):
+            assert obs["oracle"].dtype == np.float32 and np.abs(obs["oracle"][i] - ref[i]["oracle"]).max() < 2e-6, (step, i)
+        a = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+        obs, _, _, _ = venv.step(a)
+        ref = [o.step(a[i])[0] for i, o in enumerate(oracles)]
+    venv.close()
+
+
+@pytest.mark.gpu
+def test_fresh_action_tensor_every_step_and_non_default_stream(edge_modes):
+    """The documented device-resident usage env.step(policy(obs)) hands over a NEW action tensor on most steps, possibly on a
+    non-default torch stream: results must equal the host-action path step for step (the step graph is not re-captured per pointer,
+    the env runs on torch's current stream so reads / writes are ordered with the policy's kernels)."""
+    import torch
+    import tactile_gym_amd as tg
+    n, steps = 256, 12
+    a = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=edge_modes, seed=13)
+    b = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=edge_modes, seed=13, obs_mode="torch")
+    oa = a.reset()
+    side = torch.cuda.Stream()
+    rng = np.random.default_rng(4)
+    with torch.cuda.stream(side):
+        ob = b.reset()
+        assert np.array_equal(oa["tactile"], ob["tactile"].cpu().numpy())
+        for step in range(steps):
+            act = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+            oa, ra, da, _ = a.step(act)
+            t = torch.from_numpy(act).to("cuda", non_blocking=True) * 1.0      # a fresh tensor, produced on the side stream
+            ob, rb, db, _ = b.step(t)
+            img = ob["tactile"].clone()                                          # consumed on the same stream, no host sync in between
+            side.synchronize()
+            assert np.array_equal(oa["tactile"], img.cpu().numpy()), step
+            assert np.array_equal(ra, rb) and np.array_equal(da, db)
+    a.close(); b.close()

@@ -8,8 +8,12 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/tactile_gym_hip.h"
@@ -29,6 +33,45 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 // ------------------------------------------------------------------------------------------------ host helpers
+// Is every connected surface of the mesh closed and consistently wound with outward normals?  Vertices are matched by coordinates (OBJ
+// files repeat them per face); closed + consistent = every directed edge a->b is met exactly once by b->a; outward = positive signed
+// volume per connected component.  (What licenses the raster's back-face cull, tg_raster.hip:back_facing.)
+static bool mesh_closed_outward(const tg_mesh* mesh) {
+    const int nt = mesh->n_tris, nv = mesh->n_verts;
+    if (nt < 4 || nv < 4) return false;
+    std::vector<int> canon(nv);
+    {
+        std::vector<int> order(nv);
+        for (int i = 0; i < nv; ++i) order[i] = i;
+        auto key = [&](int i) { return std::make_tuple(mesh->verts[3 * i], mesh->verts[3 * i + 1], mesh->verts[3 * i + 2]); };
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+        for (int k = 0; k < nv; ++k) canon[order[k]] = (k > 0 && key(order[k]) == key(order[k - 1])) ? canon[order[k - 1]] : order[k];
+    }
+    std::map<std::pair<int, int>, int> edge;       // directed edge -> triangle
+    std::vector<int> parent(nt);
+    for (int t = 0; t < nt; ++t) parent[t] = t;
+    auto find = [&](int x) { while (parent[x] != x) x = parent[x] = parent[parent[x]]; return x; };
+    for (int t = 0; t < nt; ++t)
+        for (int k = 0; k < 3; ++k) {
+            const int a = canon[mesh->tris[3 * t + k]], b = canon[mesh->tris[3 * t + (k + 1) % 3]];
+            if (a == b) return false;                                   // degenerate triangle
+            if (!edge.emplace(std::make_pair(a, b), t).second) return false;   // the same directed edge twice: inconsistent winding
+        }
+    for (const auto& e : edge) {
+        const auto opp = edge.find(std::make_pair(e.first.second, e.first.first));
+        if (opp == edge.end()) return false;                            // open boundary
+        parent[find(e.second)] = find(opp->second);
+    }
+    std::map<int, double> vol;
+    for (int t = 0; t < nt; ++t) {
+        const float* a = mesh->verts + 3 * mesh->tris[3 * t]; const float* b = mesh->verts + 3 * mesh->tris[3 * t + 1]; const float* c = mesh->verts + 3 * mesh->tris[3 * t + 2];
+        vol[find(t)] += (double)a[0] * ((double)b[1] * c[2] - (double)b[2] * c[1]) - (double)a[1] * ((double)b[0] * c[2] - (double)b[2] * c[0]) +
+                        (double)a[2] * ((double)b[0] * c[1] - (double)b[1] * c[0]);
+    }
+    for (const auto& v : vol) if (!(v.second > 0.0)) return false;      // a component wound inside out
+    return true;
+}
+
 static void h_quat_from_euler(const double* rpy, double* q) {
     const double phi = 0.5 * rpy[0], the = 0.5 * rpy[1], psi = 0.5 * rpy[2];
     q[0] = sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi);
@@ -735,6 +778,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
             TG_HIP(hipMalloc(&c->d_soup, soup.size() * 4 + 4)); TG_HIP(hipMemcpy(c->d_soup, soup.data(), soup.size() * 4, hipMemcpyHostToDevice));
         }
         c->stim.skip_quad_reject = cfg->env_kind == TG_ENV_OBJECT_BALANCE ? 1 : 0;   // the plate fills the camera's view
+        c->stim.closed_outward = (mesh_closed_outward(stim) && getenv("TG_NO_BACKFACE_CULL") == nullptr) ? 1 : 0;   // env var: A/B measurements only
         c->stim.kind = 0; c->stim.verts = c->d_verts; c->stim.tris = c->d_tris; c->stim.soup = c->d_soup; c->stim.n_tris = stim->n_tris;
     }
     // one allocation [tactile obs u8 | reward f32 | done u8]: what a rank ships to rank 0 per step is one contiguous byte range
@@ -1246,6 +1290,7 @@ int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, cons
     TG_HIP(hipMemset(oo.p, 0, npix * n));
     RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
     Stimulus S{};
+    S.closed_outward = (mesh_closed_outward(mesh) && getenv("TG_NO_BACKFACE_CULL") == nullptr) ? 1 : 0;   // env var: A/B measurements only
     DevBuf sp;
     {
         std::vector<float> soup((size_t)mesh->n_tris * 9);

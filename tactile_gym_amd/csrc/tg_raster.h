@@ -32,6 +32,8 @@ struct Stimulus {
     int rows, cols;
     float scale;
     int skip_quad_reject;     // 1: stimuli whose few triangles fill the camera's view (the pole's plate): the per-quad reject never fires
+    int closed_outward;       // mesh: every surface is closed and consistently wound with outward normals (verified on the host):
+                              // back faces are dropped at set-up for envs whose stimulus lies wholly beyond the near plane
     int win_side;             // heightfield: largest side (in vertices) the frustum window can have (set by launch_render): sizes the LDS staging
 };
 

@@ -83,6 +83,31 @@ __device__ __forceinline__ void project_vertex(float cx, float cy, float cw, con
     d = P.C0 + P.C1 * iw;
 }
 
+// Back-face test in eye space (eye at the origin, x right, y up, -z forward; v_k = (cx, cy, -cw)).  For a stimulus made of closed,
+// consistently outward-wound surfaces (Stimulus::closed_outward, verified on the host) that lies entirely beyond the near plane, a ray
+// from the eye enters every solid through a front face before it leaves it through a back face, so a back face can never win the depth
+// test: dropping it at set-up leaves the image as it is.  (The pixel predicates agree: the edge function of a shared edge is exactly
+// antisymmetric in its two vertices, so a pixel centre is on the solid's side of a silhouette edge for the front face and the back face
+// alike.)  Faces within 1e-4 rad of edge-on are kept.  `cull` is wave-uniform per env: closed_outward and no vertex with w < near.
+__device__ __forceinline__ bool back_facing(const float* cx, const float* cy, const float* cw) {
+    const float ax = cx[1] - cx[0], ay = cy[1] - cy[0], az = -(cw[1] - cw[0]);
+    const float bx = cx[2] - cx[0], by = cy[2] - cy[0], bz = -(cw[2] - cw[0]);
+    const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const float nv = (nx * cx[0] + ny * cy[0]) + nz * (-cw[0]);                       // n . v0: > 0 = the outward normal points away from the eye
+    const float nn = (nx * nx + ny * ny) + nz * nz, vv = (cx[0] * cx[0] + cy[0] * cy[0]) + cw[0] * cw[0];
+    return nv > 0.0f && nv * nv > 1e-8f * (nn * vv);
+}
+// All three vertices of triangle t at or beyond the near plane?  (the per-env vote that licenses the back-face cull)
+__device__ __forceinline__ bool tri_beyond_near(const float* __restrict__ soup, int t, const float* M, float near_) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float* v = soup + 9 * t + 3 * k;
+        ok = ok && (-(((M[6] * v[0] + M[7] * v[1]) + M[8] * v[2]) + M[11]) >= near_);
+    }
+    return ok;
+}
+
 // Returns false when the record buffer is full (nothing written): the caller restarts from this triangle in the next round.
 // rbands (banded lane mapping only): per record, bit b = the bounding box reaches pixel centres of the tile's b-th 32-pixel column band.
 __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const float* vx, const float* vy, const float* vw, int a, int b, int c,
@@ -279,6 +304,12 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
     // Rounds: every lane takes work items (triangles, or survivors of the first pass) from `start`; a projected triangle that passes
     // emit()'s culls takes a record slot; when the buffer is full the smallest item index that found no room becomes the next round's
     // start (re-emitting a triangle is harmless for a depth-min).  Normally one round: two barriers.
+    bool cull = false;            // back-face cull of a closed, outward-wound mesh that lies wholly beyond the near plane (see back_facing)
+    if (S.kind == 0 && S.closed_outward) {
+        bool beyond = true;
+        for (int t = tid; t < n_tris; t += kThreads) beyond = beyond && tri_beyond_near(S.soup, t, M, P.near_);
+        cull = __syncthreads_and(beyond ? 1 : 0) != 0;
+    }
     for (int start = 0; start < total;) {
         if (tid == 0) { count = 0; next_start = total; }
         __syncthreads();
@@ -307,6 +338,7 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
                 cy[k] = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
                 cw[k] = -(((M[6] * vx + M[7] * vy) + M[8] * vz) + M[11]);
             }
+            if (S.kind == 0 && cull && back_facing(cx, cy, cw)) continue;
             // near-plane clip (Sutherland-Hodgman on w >= near), vertex order 0,1,2
             float ox[4], oy[4], ow[4];
             int no = 0;
@@ -475,7 +507,10 @@ __global__ __launch_bounds__(kThreads) void k_render_small(RasterParams P, Stimu
     const float tx0 = (float)tile_x, tx1 = (float)(tile_x + TW);
     const float ty0 = interleave ? 0.0f : (float)(TH * ty), ty1 = interleave ? (float)P.H : (float)(TH * ty + TH);
     if (tid == 0) count = 0;
-    __syncthreads();
+    bool beyond = true;
+    if (S.closed_outward)
+        for (int t = tid; t < n_tris; t += kThreads) beyond = beyond && tri_beyond_near(S.soup, t, M, P.near_);
+    const bool cull = __syncthreads_and(beyond ? 1 : 0) != 0 && S.closed_outward != 0;   // (also the barrier after count = 0)
     for (int t = tid; t < n_tris; t += kThreads) {
         float cx[3], cy[3], cw[3];
 #pragma unroll
@@ -486,6 +521,7 @@ __global__ __launch_bounds__(kThreads) void k_render_small(RasterParams P, Stimu
             cy[k] = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
             cw[k] = -(((M[6] * vx + M[7] * vy) + M[8] * vz) + M[11]);
         }
+        if (cull && back_facing(cx, cy, cw)) continue;
         float ox[4], oy[4], ow[4];
         int no = 0;
 #pragma unroll

@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 6
+#define TG_ABI_VERSION 7
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -269,6 +269,31 @@ int tg_set_joint_state(tg_ctx* ctx, const double* q, const double* qd);
  * 2 reset, 3 render (masked: reset / auto-reset envs only). */
 int tg_profile_enable(tg_ctx* ctx, int32_t enable);
 int tg_profile_get(tg_ctx* ctx, int32_t which, double* total_ms, int64_t* launches);
+
+/* ---- scene camera: the "visual" / "visuotactile" observations and render() (base_tactile_env.py:212-245, 284-320) -------------------
+ * get_visual_obs draws the whole scene (plane, table, robot, stimulus) from a fixed world camera with getCameraImage and keeps rgb.
+ * The triangle set is shared by all envs; each triangle is rigid in one frame: 0 the world, 1 + i moving link i (tg_robot numbering),
+ * ndof + 1 the task's stimulus / free body (same frame as tg_mesh).  Upstream's pixels depend on the GL driver: PARITY_ASSUMPTIONS A31-A33. */
+typedef struct {
+    int32_t image_h, image_w;               /* rgb_image_size (= image_size upstream); <= 128 or a multiple of 128 */
+    int32_t n_verts, n_tris;
+    const float*   verts;                   /* host [n_verts][3] */
+    const int32_t* tris;                    /* host [n_tris][3] */
+    const uint8_t* tri_frame;               /* host [n_tris] */
+    const uint8_t* tri_rgb;                 /* host [n_tris][3], the <material> colour */
+    double cam_target[3], cam_dist, cam_yaw_deg, cam_pitch_deg;   /* rgb_cam_pos / _dist / _yaw / _pitch, e.g. edge_follow_env.py:176-195 */
+    double fov_deg, near_plane, far_plane;  /* rgb_fov / rgb_near_val / rgb_far_val */
+    double light_dir[3];                    /* world, towards the light */
+    uint8_t background[3];
+    int32_t every_step;                     /* != 0: tg_step / tg_reset also draw the scene (observation modes with "visual" / "visuo") */
+} tg_scene;
+/* Uploads the scene; call before the first tg_step. */
+int tg_set_scene(tg_ctx* ctx, const tg_scene* scene);
+/* Draws the current state of every env now (render() in the other observation modes). Asynchronous. */
+int tg_render_scene(tg_ctx* ctx);
+/* uint8 [num_envs][H][W][3]; terminal != 0: the image of the last step of the envs that finished (rows valid where done). */
+int tg_get_obs_visual(tg_ctx* ctx, void** dev_ptr, int32_t terminal);
+int tg_copy_obs_visual(tg_ctx* ctx, uint8_t* host_dst, int32_t terminal);
 
 /* ---- function-level entry points (parity tests call the device implementations through these) --------------------- */
 /* calculateInverseDynamics (base_robot_arm.py:176-178), batch of n states; physics_dtype as in tg_config. */

@@ -428,6 +428,94 @@ void mb_t_s_camera(const float* cur_dep, const float* nodef_dep, const float* no
     }
 }
 
+/* ------------------------------------------------------------------------------------------------ scene camera (RGB)
+ * get_visual_obs (base_tactile_env.py:212-245): getCameraImage of the whole scene from a fixed world camera, rgb kept.  PARITY UNPINNED:
+ * upstream asks for ER_BULLET_HARDWARE_OPENGL, whose pixels depend on the GL driver (or TinyRenderer in DIRECT mode), and the checkout
+ * holds no scene image.  What is specified here (PARITY_ASSUMPTIONS A31-A33): the camera (view / projection, pinned by closed-form
+ * tests), the geometry drawn (every opaque <visual>), flat shading with TinyRenderer's default coefficients, two-sided.
+ *
+ * Raster rule: homogeneous (clip-less) edge functions on pixel centres.  For eye-space vertices e_k (w_k = -e_k.z) let
+ * X_k = kx e_k.x + hw w_k, Y_k = hh w_k - ky e_k.y.  E_i(px, py) = (a_i px + b_i py) + c_i with (a_i, b_i, c_i) the cofactors of
+ * column i of [[X],[Y],[w]]; a pixel is covered when s E_i >= 0 for all i (s = sign det), 1/w there is (E_0 + E_1 + E_2) / det; it
+ * must lie in [1/far, 1/near].  Closest wins: the z-buffer holds max of the 64-bit key (float bits of 1/w) << 32 | r << 16 | g << 8 | b,
+ * so the image does not depend on the order triangles are drawn in (the device draws them concurrently). */
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+void mb_render_scene(const float* verts, const int32_t* tris, const uint8_t* tri_xf, const uint8_t* tri_rgb, int nt, const float* xf,
+                     const float* light_eye, float fov_deg, float near_, float far_, int W, int H, const uint8_t* background,
+                     uint64_t* zbuf, uint8_t* out) {
+    double ys = 1.0 / tan(0.5 * (double)fov_deg * (3.14159265358979323846 / 180.0));
+    float kx = (float)(ys * 0.5 * H), ky = (float)(ys * 0.5 * H), hw = 0.5f * (float)W, hh = 0.5f * (float)H;   /* aspect = W / H */
+    float inv_near = 1.0f / near_, inv_far = 1.0f / far_;
+    for (int p = 0; p < W * H; ++p) zbuf[p] = 0;
+    for (int t = 0; t < nt; ++t) {
+        const float* M = xf + 12 * tri_xf[t];
+        float ex[3], ey[3], ez[3], w[3], X[3], Y[3];
+        for (int k = 0; k < 3; ++k) {
+            const float* v = verts + 3 * tris[3 * t + k];
+            ex[k] = ((M[0] * v[0] + M[1] * v[1]) + M[2] * v[2]) + M[9];
+            ey[k] = ((M[3] * v[0] + M[4] * v[1]) + M[5] * v[2]) + M[10];
+            ez[k] = ((M[6] * v[0] + M[7] * v[1]) + M[8] * v[2]) + M[11];
+            w[k] = -ez[k];
+            X[k] = kx * ex[k] + hw * w[k];
+            Y[k] = hh * w[k] - ky * ey[k];
+        }
+        if (w[0] < near_ && w[1] < near_ && w[2] < near_) continue;
+        if (w[0] > far_ && w[1] > far_ && w[2] > far_) continue;
+        float a0 = Y[1] * w[2] - Y[2] * w[1], b0 = w[1] * X[2] - w[2] * X[1], c0 = X[1] * Y[2] - X[2] * Y[1];
+        float a1 = Y[2] * w[0] - Y[0] * w[2], b1 = w[2] * X[0] - w[0] * X[2], c1 = X[2] * Y[0] - X[0] * Y[2];
+        float a2 = Y[0] * w[1] - Y[1] * w[0], b2 = w[0] * X[1] - w[1] * X[0], c2 = X[0] * Y[1] - X[1] * Y[0];
+        float det = (c0 * w[0] + c1 * w[1]) + c2 * w[2];
+        if (det == 0.0f) continue;
+        float sg = det > 0.0f ? 1.0f : -1.0f, rdet = 1.0f / det;
+        /* flat shade: n = (e1 - e0) x (e2 - e0) turned towards the eye, 0.6 ambient + 0.35 diffuse [A32] */
+        float ux = ex[1] - ex[0], uy = ey[1] - ey[0], uz = ez[1] - ez[0], vx = ex[2] - ex[0], vy = ey[2] - ey[0], vz = ez[2] - ez[0];
+        float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+        float nn = sqrtf((nx * nx + ny * ny) + nz * nz);
+        float ndl = 0.0f;
+        if (nn > 0.0f) {
+            ndl = ((nx * light_eye[0] + ny * light_eye[1]) + nz * light_eye[2]) / nn;
+            if ((nx * ex[0] + ny * ey[0]) + nz * ez[0] > 0.0f) ndl = -ndl;
+            if (ndl < 0.0f) ndl = 0.0f;
+        }
+        float inten = 0.6f + 0.35f * ndl;
+        uint32_t rgb = 0;
+        for (int k = 0; k < 3; ++k) rgb = (rgb << 8) | (uint32_t)((float)tri_rgb[3 * t + k] * inten + 0.5f);
+        int x0 = 0, x1 = W - 1, y0 = 0, y1 = H - 1;
+        if (w[0] >= near_ && w[1] >= near_ && w[2] >= near_) {
+            float sx0 = X[0] / w[0], sx1 = X[1] / w[1], sx2 = X[2] / w[2], sy0 = Y[0] / w[0], sy1 = Y[1] / w[1], sy2 = Y[2] / w[2];
+            /* pixel centres inside the bounding box, widened by 1/64 pixel (the divisions above round) */
+            float minx = fminf(sx0, fminf(sx1, sx2)), maxx = fmaxf(sx0, fmaxf(sx1, sx2)), miny = fminf(sy0, fminf(sy1, sy2)), maxy = fmaxf(sy0, fmaxf(sy1, sy2));
+            minx = fminf(fmaxf(minx, -1.0f), (float)W + 1.0f); maxx = fminf(fmaxf(maxx, -1.0f), (float)W + 1.0f);
+            miny = fminf(fmaxf(miny, -1.0f), (float)H + 1.0f); maxy = fminf(fmaxf(maxy, -1.0f), (float)H + 1.0f);
+            x0 = (int)ceilf(minx - 0.515625f); x1 = (int)floorf(maxx - 0.484375f);
+            y0 = (int)ceilf(miny - 0.515625f); y1 = (int)floorf(maxy - 0.484375f);
+            if (x0 < 0) x0 = 0;
+            if (y0 < 0) y0 = 0;
+            if (x1 > W - 1) x1 = W - 1;
+            if (y1 > H - 1) y1 = H - 1;
+        }
+        for (int py = y0; py <= y1; ++py) {
+            float fy = (float)py + 0.5f;
+            for (int px = x0; px <= x1; ++px) {
+                float fx = (float)px + 0.5f;
+                float e0 = (a0 * fx + b0 * fy) + c0, e1 = (a1 * fx + b1 * fy) + c1, e2 = (a2 * fx + b2 * fy) + c2;
+                if (!(sg * e0 >= 0.0f && sg * e1 >= 0.0f && sg * e2 >= 0.0f)) continue;
+                float iw = ((e0 + e1) + e2) * rdet;
+                if (!(iw >= inv_far && iw <= inv_near)) continue;
+                uint64_t key = ((uint64_t)f32_bits(iw) << 32) | rgb;
+                if (key > zbuf[(size_t)py * W + px]) zbuf[(size_t)py * W + px] = key;
+            }
+        }
+    }
+    for (int p = 0; p < W * H; ++p) {
+        uint64_t k = zbuf[p];
+        out[3 * p + 0] = k ? (uint8_t)(k >> 16) : background[0];
+        out[3 * p + 1] = k ? (uint8_t)(k >> 8) : background[1];
+        out[3 * p + 2] = k ? (uint8_t)k : background[2];
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ OpenSimplex 2-D */
 #define OS_STRETCH_2D (-0.211324865405187)   /* (1/sqrt(2+1)-1)/2 */
 #define OS_SQUISH_2D 0.366025403784439       /* (sqrt(2+1)-1)/2 */

@@ -98,6 +98,11 @@ void mb_render_depth(const float* verts /*[nv][3]*/, int nv, const int32_t* tris
                      float far_, int w, int h, float* depth);
 
 /* TactileSensor.t_s_camera() post-process — tactile_sensor.py:271-292 — on a current depth image. */
+/* Scene camera rgb (get_visual_obs, base_tactile_env.py:212-245) - PARITY UNPINNED, see minibullet.c.  xf [n_frames][12]: eye <- frame
+ * (R row-major, then t) as float; tri_xf picks a triangle's frame; zbuf [W*H] scratch; out [H][W][3]. */
+void mb_render_scene(const float* verts, const int32_t* tris, const uint8_t* tri_xf, const uint8_t* tri_rgb, int nt, const float* xf,
+                     const float* light_eye, float fov_deg, float near_, float far_, int W, int H, const uint8_t* background,
+                     uint64_t* zbuf, uint8_t* out);
 void mb_t_s_camera(const float* cur_dep, const float* nodef_dep, const float* nodef_gray, const uint8_t* border_mask,
                    int npix, int turn_off_border, uint8_t* out);
 

@@ -4,6 +4,7 @@
 (robots/arms/base_robot_arm.py, robots/arms/robot.py) under PyBullet-like names.
 """
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -93,6 +94,8 @@ def lib():
         _lib.mb_ik.restype = C.c_int
         _lib.mb_render_depth.argtypes = [fp, C.c_int, ip, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, fp]
         _lib.mb_t_s_camera.argtypes = [fp, fp, fp, u8p, C.c_int, C.c_int, u8p]
+        _lib.mb_render_scene.argtypes = [fp, ip, u8p, u8p, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, u8p,
+                                         C.POINTER(C.c_uint64), u8p]
     return _lib
 
 
@@ -178,6 +181,13 @@ class Arm:
             self.state.applied_torque[i] += float(tau[i])
 
     # -- queries ----------------------------------------------------------------------------------
+    def link_poses(self, q=None):
+        """World pose (R [3,3], p [3]) of every moving link's frame (origin at its joint)."""
+        q = np.ascontiguousarray(self.q if q is None else q, dtype=np.float64)
+        R, p = np.zeros((self.n, 9)), np.zeros((self.n, 3))
+        self.L.mb_fk(C.byref(self.model), _dp(q), _dp(R), _dp(p))
+        return [(R[i].reshape(3, 3), p[i]) for i in range(self.n)]
+
     def link_state(self, frame, q=None, qd=None):
         """getLinkState(..., computeLinkVelocity=1): (pos, quat, lin_vel, ang_vel) of a named frame."""
         link, fpos, frot = self.tg.frames[frame]
@@ -242,6 +252,48 @@ def render_depth(verts, tris, cam_from_obj, fov, near, far, w, h, depth):
     lib().mb_render_depth(v.ctypes.data_as(fp), v.shape[0], t.ctypes.data_as(C.POINTER(C.c_int32)), t.shape[0],
                           M.ctypes.data_as(fp), fov, near, far, w, h, depth.ctypes.data_as(fp))
     return depth
+
+
+def scene_view_matrix(target, dist, yaw_deg, pitch_deg):
+    """computeViewMatrixFromYawPitchRoll(cameraTargetPosition, distance, yaw, pitch, roll=0, upAxisIndex=2) as the reference calls it
+    (base_tactile_env.py:217-224), returned as world -> eye (R [3,3], t [3]).  Bullet [PARITY_ASSUMPTIONS A31]: the eye sits at
+    target + Rz(yaw) Rx(pitch) (0, -distance, 0) with up = Rz(yaw) Rx(pitch) (0, 0, 1), then the look-at matrix of (eye, target, up)."""
+    y, p = math.radians(yaw_deg), math.radians(pitch_deg)
+    Rz = np.array([[math.cos(y), -math.sin(y), 0.0], [math.sin(y), math.cos(y), 0.0], [0.0, 0.0, 1.0]])
+    Rx = np.array([[1.0, 0.0, 0.0], [0.0, math.cos(p), -math.sin(p)], [0.0, math.sin(p), math.cos(p)]])
+    E = Rz @ Rx
+    eye = np.asarray(target, dtype=np.float64) + E @ np.array([0.0, -float(dist), 0.0])
+    up = E @ np.array([0.0, 0.0, 1.0])
+    f = np.asarray(target, dtype=np.float64) - eye
+    f = f / np.linalg.norm(f)
+    s = np.cross(f, up)
+    s = s / np.linalg.norm(s)
+    u = np.cross(s, f)
+    V = np.stack([s, u, -f])
+    return V, -V @ eye
+
+
+def render_scene(verts, tris, tri_frame, tri_rgb, frames, view, light_dir_world, fov, near, far, w, h, background):
+    """Scene camera rgb (uint8 [h, w, 3]).  frames: world poses [(R [3,3], p [3]), ...] that tri_frame indexes; view = scene_view_matrix(...)."""
+    V, tv = view
+    xf = np.zeros((len(frames), 12), dtype=np.float32)
+    for i, (R, p) in enumerate(frames):
+        xf[i, :9] = (V @ np.asarray(R, dtype=np.float64)).reshape(9)
+        xf[i, 9:] = V @ np.asarray(p, dtype=np.float64) + tv
+    L = np.asarray(light_dir_world, dtype=np.float64)
+    le = np.ascontiguousarray(V @ (L / np.linalg.norm(L)), dtype=np.float32)
+    v = np.ascontiguousarray(verts, dtype=np.float32)
+    t = np.ascontiguousarray(tris, dtype=np.int32)
+    tf = np.ascontiguousarray(tri_frame, dtype=np.uint8)
+    tc = np.ascontiguousarray(tri_rgb, dtype=np.uint8)
+    bg = np.ascontiguousarray(background, dtype=np.uint8)
+    z = np.zeros(w * h, dtype=np.uint64)
+    out = np.zeros((h, w, 3), dtype=np.uint8)
+    fp, u8 = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    lib().mb_render_scene(v.ctypes.data_as(fp), t.ctypes.data_as(C.POINTER(C.c_int32)), tf.ctypes.data_as(u8), tc.ctypes.data_as(u8), t.shape[0],
+                          xf.ctypes.data_as(fp), le.ctypes.data_as(fp), fov, near, far, w, h, bg.ctypes.data_as(u8),
+                          z.ctypes.data_as(C.POINTER(C.c_uint64)), out.ctypes.data_as(u8))
+    return out
 
 
 def t_s_camera(cur_dep, nodef_dep, nodef_gray, border_mask, turn_off_border=False):

@@ -232,6 +232,32 @@ class _OracleArmEnv:
         cpos, cquat = pm.multiply_transforms(bpos, bquat, self.cam["pos"], pm.quat_from_euler(self.cam["rpy"]))
         return cpos, pm.mat_from_quat(cquat)
 
+    # ---- get_visual_obs (base_tactile_env.py:212-245) - parity unpinned, see minibullet.c mb_render_scene
+    SCENE_CAMERA = None                                                       # (target, distance, yaw, pitch, fov, near, far) per env class
+    LIGHT_DIR, BACKGROUND = (-50.0, 30.0, 100.0), (178, 178, 204)             # PARITY_ASSUMPTIONS A32, A33
+
+    def scene_body(self):
+        """(verts, tris, R, p) of the task's stimulus / free body in the world, or None."""
+        return None
+
+    def scene_camera(self):
+        return self.SCENE_CAMERA
+
+    def visual_image(self):
+        from tactile_gym_amd.robot_model import compose_scene                 # the triangle set is data (assets/visual), shared with the product
+        body = self.scene_body()
+        key = "_scene_cache"
+        if not hasattr(self, key):
+            setattr(self, key, compose_scene(self.arm_type, self.t_s_type, self.t_s_name, self.tg.ndof,
+                                             None if body is None else (body[0], body[1])))
+        verts, tris, tri_frame, tri_rgb = getattr(self, key)
+        frames = [(np.eye(3), np.zeros(3))] + self.arm.link_poses()
+        frames.append((np.eye(3), np.zeros(3)) if body is None else (body[2], body[3]))
+        target, dist, yaw, pitch, fov, near, far = self.scene_camera()
+        h, w = self.image_size
+        return mb.render_scene(verts, tris, tri_frame, tri_rgb, frames, mb.scene_view_matrix(target, dist, yaw, pitch), self.LIGHT_DIR,
+                               fov, near, far, w, h, self.BACKGROUND)
+
     def _observation(self):  # base_tactile_env.py:200-210, 247-282
         obs = {}
         mode = self.modes["observation_mode"]
@@ -239,6 +265,8 @@ class _OracleArmEnv:
             obs["oracle"] = self.oracle_obs()
         if "tactile" in mode:
             obs["tactile"] = self.tactile_image()[..., np.newaxis]
+        if "visual" in mode or "visuo" in mode:
+            obs["visual"] = self.visual_image()
         return obs
 
 
@@ -332,6 +360,14 @@ class OracleEdgeFollowEnv(_OracleArmEnv):
     def stimulus_transform(self):
         cpos, cR = self.camera_pose()
         return mb.cam_from_obj_matrix(cpos, cR, self.edge_pos, self.edge_rot)
+
+    def scene_camera(self):                                                              # edge_follow_env.py:176-195
+        if self.arm_type == "mg400":
+            return ([-0.20, 0.0, -0.25], 0.85, 90.0, -35.0, 75.0, 0.1, 100.0)
+        return ([0.35, 0.0, -0.25], 0.75, 90.0, -35.0, 75.0, 0.1, 100.0)
+
+    def scene_body(self):
+        return self.edge_verts, self.edge_tris, self.edge_rot, self.edge_pos
 
     def tactile_image(self):
         h, w = self.image_size

@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -58,6 +58,14 @@ class TgSensor(C.Structure):
 
 class TgMesh(C.Structure):
     _fields_ = [("n_verts", C.c_int32), ("n_tris", C.c_int32), ("verts", C.POINTER(C.c_float)), ("tris", C.POINTER(C.c_int32))]
+
+
+class TgScene(C.Structure):
+    _fields_ = [("image_h", C.c_int32), ("image_w", C.c_int32), ("n_verts", C.c_int32), ("n_tris", C.c_int32),
+                ("verts", C.POINTER(C.c_float)), ("tris", C.POINTER(C.c_int32)), ("tri_frame", C.POINTER(C.c_uint8)),
+                ("tri_rgb", C.POINTER(C.c_uint8)), ("cam_target", C.c_double * 3), ("cam_dist", C.c_double), ("cam_yaw_deg", C.c_double),
+                ("cam_pitch_deg", C.c_double), ("fov_deg", C.c_double), ("near_plane", C.c_double), ("far_plane", C.c_double),
+                ("light_dir", C.c_double * 3), ("background", C.c_uint8 * 3), ("every_step", C.c_int32)]
 
 
 class TgConfig(C.Structure):
@@ -128,6 +136,10 @@ SYMBOLS = {
     "tg_get_packed_outputs": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tg_get_packed_feature": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_sample_actions": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "tg_set_scene": (C.c_int, [_ctx, C.POINTER(TgScene)]),
+    "tg_render_scene": (C.c_int, [_ctx]),
+    "tg_get_obs_visual": (C.c_int, [_ctx, _vpp, C.c_int32]),
+    "tg_copy_obs_visual": (C.c_int, [_ctx, _u8p, C.c_int32]),
     "tg_selftest_division": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
     "tg_get_obs_feature": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32), C.c_int32]),
     "tg_get_reward_done": (C.c_int, [_ctx, _fp, _u8p]),

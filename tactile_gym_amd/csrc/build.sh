@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libtactile_gym_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
-#   tg_raster.hip and tg_noise.hip are compiled with -ffp-contract=off (bit-exact raster specification);
+#   tg_raster.hip, tg_scene.hip and tg_noise.hip are compiled with -ffp-contract=off (bit-exact raster specification);
 #   tg_api.hip (physics, control, C ABI) and tg_contact_wave.hip (wave-per-env contact solver) with the default contraction (FMA).
 set -euo pipefail
 cd "$(dirname "$0")"
@@ -23,6 +23,7 @@ cc tg_raster -ffp-contract=off & p1=$!
 cc tg_noise -ffp-contract=off & p2=$!
 cc tg_api & p3=$!
 cc tg_contact_wave & p4=$!
-wait $p1; wait $p2; wait $p3; wait $p4    # each wait returns its job's status: a failed translation unit fails the build (set -e)
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" -o "$OUT/libtactile_gym_hip.so"
+cc tg_scene -ffp-contract=off & p5=$!
+wait $p1; wait $p2; wait $p3; wait $p4; wait $p5    # each wait returns its job's status: a failed translation unit fails the build (set -e)
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" "$OUT/tg_scene.o" -o "$OUT/libtactile_gym_hip.so"
 echo "built $OUT/libtactile_gym_hip.so"

@@ -19,6 +19,7 @@
 #include "../../include/tactile_gym_hip.h"
 #include "tg_kernels.hpp"
 #include "tg_contact_wave.h"
+#include "tg_scene.h"
 #include "tg_noise.h"
 #include "tg_raster.h"
 
@@ -366,6 +367,14 @@ struct tg_ctx {
     int32_t* d_tris = nullptr;
     int n_tris = 0;
     tg::Stimulus stim{};
+    // scene camera (tg_set_scene): shared triangle set, per-env eye<-frame transforms, rgb images
+    tg::SceneParams scene{};
+    tg::SceneView scene_view{};
+    bool scene_on = false, scene_every_step = false;
+    float *d_scene_verts = nullptr, *d_scene_xf = nullptr;
+    int32_t* d_scene_tris = nullptr;
+    uint32_t* d_scene_attr = nullptr;
+    uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
     // hipGraph of one tg_step launch sequence, keyed by the device action pointer it was captured with (launch-bound inner loop:
     // 3-4 kernels per step, one graph launch instead)
     hipStream_t aux_stream = nullptr;                // object_balance: the reset of finished envs runs here, beside the render
@@ -553,6 +562,19 @@ __global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, flo
     const uint64_t z = mix64(mix64(seed + kGolden * (counter + 1)) + kGolden * (uint64_t)(i + 1));
     const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
     out[i] = lo + (hi - lo) * u;
+}
+
+template <typename T, int TOPO> static void launch_scene_xf_t(tg_ctx* c, const uint8_t* d_mask) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_scene_xf<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, c->scene_view, d_mask, c->d_scene_xf);
+}
+// get_visual_obs for the whole batch (or the masked envs; save_prev keeps their previous image as the terminal observation)
+static void scene_draw(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
+#define CALL(T, TOPO) launch_scene_xf_t<T, TOPO>(c, d_mask)
+    TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    launch_scene(c->scene, c->d_scene_xf, c->cfg.num_envs, d_mask, c->d_vis, save_prev ? c->d_vis_term : nullptr, c->stream);
 }
 
 static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
@@ -818,7 +840,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_vis, c->d_vis_term};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -855,6 +877,7 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
     }
     reset_sequence(c, dmask);
     render(c, dmask, false);
+    if (c->scene_every_step) scene_draw(c, dmask, false);
     TG_HIP(hipGetLastError());
     return 0;
 }
@@ -893,6 +916,9 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
 #undef CALL
         }
     }
+    // visual observation modes: the step's image of every env before any reset touches the state; the envs that finished are redrawn
+    // after their reset below (their step image moves to the terminal buffer)
+    if (c->scene_every_step) scene_draw(c, nullptr, false);
     if (c->cfg.auto_reset && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {
         reset_sequence(c, c->st.done); // k_reset keeps the terminal camera transform of the envs it resets
         render_fused(c);               // one launch draws the terminal and the post-reset observations
@@ -924,6 +950,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
             render(c, c->st.done, true);   // terminal observation is saved, then the post-reset observation is drawn
         }
     }
+    if (c->scene_every_step && c->cfg.auto_reset) scene_draw(c, c->st.done, true);
 }
 
 int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
@@ -980,6 +1007,87 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     }
     enqueue_step(c, d_act);
     TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
+    if (!c || !sc) return fail(-1, "tg_set_scene: NULL argument");
+    TG_ENTER(c);
+    if (c->scene_on) return fail(-1, "tg_set_scene: the scene is already set");
+    if (sc->every_step && (c->step_graph[0] || c->step_graph[1])) return fail(-1, "tg_set_scene: every_step needs the call before the first tg_step");
+    if (!sc->verts || !sc->tris || !sc->tri_frame || !sc->tri_rgb || sc->n_tris <= 0 || sc->n_verts <= 0) return fail(-1, "tg_set_scene: empty scene");
+    const int W = sc->image_w, H = sc->image_h;
+    if (W <= 0 || H <= 0 || (W > 128 && W % 128) || (H > 128 && H % 128)) return fail(-1, "tg_set_scene: image sides must be <= 128 or multiples of 128");
+    if (!(sc->near_plane > 0 && sc->far_plane > sc->near_plane && sc->fov_deg > 0 && sc->fov_deg < 180)) return fail(-1, "tg_set_scene: bad projection");
+    const int n_frames = c->robot.ndof + 2;
+    if (n_frames > 16) return fail(-1, "tg_set_scene: too many frames");
+    std::vector<uint32_t> attr(sc->n_tris);
+    for (int t = 0; t < sc->n_tris; ++t) {
+        if (sc->tri_frame[t] >= n_frames) return fail(-1, "tg_set_scene: tri_frame out of range");
+        for (int k = 0; k < 3; ++k)
+            if (sc->tris[3 * t + k] < 0 || sc->tris[3 * t + k] >= sc->n_verts) return fail(-1, "tg_set_scene: vertex index out of range");
+        attr[t] = ((uint32_t)sc->tri_frame[t] << 24) | ((uint32_t)sc->tri_rgb[3 * t] << 16) | ((uint32_t)sc->tri_rgb[3 * t + 1] << 8) | sc->tri_rgb[3 * t + 2];
+    }
+    // computeViewMatrixFromYawPitchRoll(target, distance, yaw, pitch, roll = 0, upAxisIndex = 2) [A31]: eye = target + Rz(yaw) Rx(pitch)
+    // (0, -distance, 0), up = Rz(yaw) Rx(pitch) (0, 0, 1), then the look-at matrix
+    const double d2r = 3.14159265358979323846 / 180.0, cy = cos(sc->cam_yaw_deg * d2r), sy = sin(sc->cam_yaw_deg * d2r),
+                 cp = cos(sc->cam_pitch_deg * d2r), sp = sin(sc->cam_pitch_deg * d2r);
+    // Rz Rx = [[cy, -sy cp, sy sp], [sy, cy cp, -cy sp], [0, sp, cp]]
+    const double E1[3] = {-sy * cp, cy * cp, sp}, E2[3] = {sy * sp, -cy * sp, cp};
+    double eye[3], f[3], up[3] = {E2[0], E2[1], E2[2]};
+    for (int k = 0; k < 3; ++k) { eye[k] = sc->cam_target[k] - sc->cam_dist * E1[k]; f[k] = sc->cam_target[k] - eye[k]; }
+    auto normalize = [](double (&v)[3]) { const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); for (double& x : v) x /= n; };
+    normalize(f);
+    double s_[3] = {f[1] * up[2] - f[2] * up[1], f[2] * up[0] - f[0] * up[2], f[0] * up[1] - f[1] * up[0]};
+    normalize(s_);
+    const double u[3] = {s_[1] * f[2] - s_[2] * f[1], s_[2] * f[0] - s_[0] * f[2], s_[0] * f[1] - s_[1] * f[0]};
+    SceneView& V = c->scene_view;
+    for (int k = 0; k < 3; ++k) { V.R[k] = s_[k]; V.R[3 + k] = u[k]; V.R[6 + k] = -f[k]; }
+    for (int r = 0; r < 3; ++r) V.t[r] = -(V.R[3 * r] * eye[0] + V.R[3 * r + 1] * eye[1] + V.R[3 * r + 2] * eye[2]);
+    SceneParams P = make_scene_params(W, H, sc->fov_deg, sc->near_plane, sc->far_plane);
+    double L[3] = {sc->light_dir[0], sc->light_dir[1], sc->light_dir[2]};
+    normalize(L);
+    for (int r = 0; r < 3; ++r) P.light_eye[r] = (float)(V.R[3 * r] * L[0] + V.R[3 * r + 1] * L[1] + V.R[3 * r + 2] * L[2]);
+    for (int k = 0; k < 3; ++k) P.background[k] = sc->background[k];
+    P.n_tris = sc->n_tris; P.n_frames = n_frames;
+    const size_t n = (size_t)c->cfg.num_envs, img = (size_t)W * H * 3;
+    TG_HIP(hipMalloc(&c->d_scene_verts, (size_t)sc->n_verts * 12)); TG_HIP(hipMalloc(&c->d_scene_tris, (size_t)sc->n_tris * 12));
+    TG_HIP(hipMalloc(&c->d_scene_attr, (size_t)sc->n_tris * 4)); TG_HIP(hipMalloc(&c->d_scene_xf, n * n_frames * 12 * 4));
+    TG_HIP(hipMalloc(&c->d_vis, n * img)); TG_HIP(hipMalloc(&c->d_vis_term, n * img));
+    TG_HIP(hipMemcpy(c->d_scene_verts, sc->verts, (size_t)sc->n_verts * 12, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(c->d_scene_tris, sc->tris, (size_t)sc->n_tris * 12, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(c->d_scene_attr, attr.data(), (size_t)sc->n_tris * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemset(c->d_vis, 0, n * img)); TG_HIP(hipMemset(c->d_vis_term, 0, n * img));
+    P.verts = c->d_scene_verts; P.tris = c->d_scene_tris; P.tri_attr = c->d_scene_attr;
+    if (scene_prepare() != 0) return fail(-1, "tg_set_scene: hipFuncSetAttribute failed");
+    c->scene = P;
+    c->scene_on = true;
+    c->scene_every_step = sc->every_step != 0;
+    return 0;
+}
+
+int tg_render_scene(tg_ctx* c) {
+    if (!c) return fail(-1, "NULL ctx");
+    TG_ENTER(c);
+    if (!c->scene_on) return fail(-1, "tg_render_scene: no scene (tg_set_scene)");
+    scene_draw(c, nullptr, false);
+    TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_get_obs_visual(tg_ctx* c, void** p, int32_t terminal) {
+    if (!c || !p) return fail(-1, "NULL argument");
+    if (!c->scene_on) return fail(-1, "tg_get_obs_visual: no scene (tg_set_scene)");
+    *p = terminal ? c->d_vis_term : c->d_vis;
+    return 0;
+}
+
+int tg_copy_obs_visual(tg_ctx* c, uint8_t* dst, int32_t terminal) {
+    if (!c || !dst) return fail(-1, "NULL argument");
+    TG_ENTER(c);
+    if (!c->scene_on) return fail(-1, "tg_copy_obs_visual: no scene (tg_set_scene)");
+    TG_HIP(hipMemcpyAsync(dst, terminal ? c->d_vis_term : c->d_vis, (size_t)c->cfg.num_envs * c->scene.W * c->scene.H * 3, hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -237,6 +237,53 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
     X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
 }
 
+// Scene camera (get_visual_obs, base_tactile_env.py:212-245): eye <- frame transforms of one env, rounded once to float:
+// frame 0 the world, 1 + i moving link i, N + 1 the task's stimulus / free body (the frame its tactile mesh is expressed in).
+struct SceneView { double R[9], t[3]; };   // world -> eye
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_scene_xf(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st, SceneView view,
+                                                 const uint8_t* __restrict__ mask, float* __restrict__ xf) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int n = c.num_envs, env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n || (mask != nullptr && mask[env] == 0)) return;
+    T q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = (T)st.q[i * n + env];
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    float* out = xf + (size_t)env * (N + 2) * 12;
+    auto put = [&](int f, const double (&R)[9], const double (&p)[3]) {
+        for (int r = 0; r < 3; ++r) {
+            for (int cc = 0; cc < 3; ++cc)
+                out[f * 12 + 3 * r + cc] = (float)(view.R[3 * r + 0] * R[cc] + view.R[3 * r + 1] * R[3 + cc] + view.R[3 * r + 2] * R[6 + cc]);
+            out[f * 12 + 9 + r] = (float)(view.R[3 * r + 0] * p[0] + view.R[3 * r + 1] * p[1] + view.R[3 * r + 2] * p[2] + view.t[r]);
+        }
+    };
+    {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
+        put(0, I, z);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double R[9];
+        for (int e = 0; e < 9; ++e) R[e] = (double)k.R[i].m[e];
+        const double p[3] = {(double)k.o[i].x, (double)k.o[i].y, (double)k.o[i].z};
+        put(1 + i, R, p);
+    }
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {(double)c.stim_pos[0], (double)c.stim_pos[1], (double)c.stim_pos[2]};
+    if (c.env_kind == TG_ENV_EDGE_FOLLOW) {
+        const double se = st.edge_sc[0 * n + env], ce = st.edge_sc[1 * n + env];
+        R[0] = ce; R[1] = -se; R[3] = se; R[4] = ce;
+    } else if (c.env_kind == TG_ENV_OBJECT_BALANCE || c.env_kind == TG_ENV_OBJECT_PUSH || c.env_kind == TG_ENV_OBJECT_ROLL) {
+        const double scale = c.env_kind == TG_ENV_OBJECT_ROLL ? st.obj_mass[env] / c.roll_radius : 1.0;   // globalScaling scales the visual
+        for (int e = 0; e < 9; ++e) R[e] = st.body_rot[e * n + env] * scale;
+        for (int e = 0; e < 3; ++e) p[e] = st.body_pos[e * n + env];
+    }
+    put(N + 1, R, p);
+}
+
 // scale_actions (base_tactile_env.py:141-164): clip to [min_action, max_action], affine map to the physical range per dimension
 template <typename T> __device__ __forceinline__ void scale_actions(const EnvConst<T>& c, const T (&enc)[6], T (&vels)[6]) {
     const T in_range = c.max_action - c.min_action;

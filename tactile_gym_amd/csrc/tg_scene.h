@@ -1,0 +1,29 @@
+// tg_scene.h — interface between the host API (tg_api.hip) and the scene-camera translation unit (tg_scene.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+// The envs' fixed world camera (get_visual_obs, base_tactile_env.py:212-245): one indexed triangle set shared by all envs, every
+// triangle rigid in one of n_frames frames (0 world, 1 + i moving link i, n_frames - 1 the task's stimulus / free body); per env the
+// eye <- frame transforms [n_frames][12] (R row-major, t) rounded once to float.  Projection constants are derived on the host in
+// double and rounded once, as for the tactile camera: window x = hw + kx x/w, y = hh - ky y/w (w = -z_eye), aspect = W / H.
+struct SceneParams {
+    int W, H, n_tris, n_frames;
+    float kx, ky, hw, hh, near_, far_, inv_near, inv_far;
+    float light_eye[3];            // unit vector towards the light, eye space
+    uint8_t background[3];
+    const float* verts;            // device [n_verts][3]
+    const int32_t* tris;           // device [n_tris][3]
+    const uint32_t* tri_attr;      // device [n_tris]: frame << 24 | r << 16 | g << 8 | b
+};
+
+SceneParams make_scene_params(int W, int H, double fov_deg, double near_, double far_);
+
+// Draws out[env] (uint8 [H][W][3]) for every env (mask == nullptr) or the envs whose mask byte is non-zero; with save_prev the
+// previous image of a drawn env is first copied to save_prev[env] (the terminal observation of an auto-reset).
+void launch_scene(const SceneParams& P, const float* xf, int n_envs, const uint8_t* mask, uint8_t* out, uint8_t* save_prev, hipStream_t stream);
+int scene_prepare();               // one-time kernel attributes (large dynamic LDS); call outside stream capture
+
+}  // namespace tg

@@ -108,7 +108,9 @@ class EdgeFollowVecEnv(TactileVecEnv):
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
-        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs)
+        super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
+                         scene_spec={"arm_type": modes["arm_type"], "camera":                     # setup_rgb_obs_camera_params, edge_follow_env.py:176-195
+                                     (([-0.20, 0.0, -0.25], 0.85) if modes["arm_type"] == "mg400" else ([0.35, 0.0, -0.25], 0.75)) + (90.0, -35.0, 75.0, 0.1, 100.0)})
 
     def oracle_obs(self):
         """edge_follow_env.py:454-476: [tcp_pos_work(3), tcp_lin_vel_work(3), goal_pos_work(3), edge_ang], float32 [N,10].

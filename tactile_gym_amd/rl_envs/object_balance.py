@@ -103,7 +103,8 @@ class ObjectBalanceVecEnv(TactileVecEnv):
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"xy": 2, "xyz": 3, "RxRy": 2, "xyRxRy": 4}[modes["movement_mode"]]           # :565-576
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
-                         act_dim=act_dim, oracle_dim=26)
+                         act_dim=act_dim, oracle_dim=26,
+                         scene_spec={"arm_type": modes["arm_type"], "camera": ([-0.1, 0.0, 0.25], 1.0, 90.0, -10.0, 75.0, 0.1, 100.0)})   # :162-171
 
     def oracle_obs(self):
         """object_balance_env.py:528-563: TCP pos, orn (quaternion), lin/ang velocity and the pole's pos, orn, lin/ang velocity, all in

@@ -166,7 +166,8 @@ class ObjectPushVecEnv(TactileVecEnv):
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"y": 1, "yRz": 2, "xyRz": 3, "TyRz": 2, "TxTyRz": 3}[modes["movement_mode"]]  # :631-644
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
-                         act_dim=act_dim, oracle_dim=30, feature_dim=12)
+                         act_dim=act_dim, oracle_dim=30, feature_dim=12,
+                         scene_spec={"arm_type": modes["arm_type"], "camera": ([0.1, 0.0, -0.35], 1.0, 90.0, -45.0, 75.0, 0.1, 100.0)})   # :170-179
 
     def oracle_obs(self):
         """object_push_env.py:571-609: TCP pos, rpy, lin/ang velocity, cube pos, rpy, lin/ang velocity and the current goal pos, rpy,

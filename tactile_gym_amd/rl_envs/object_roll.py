@@ -110,7 +110,8 @@ class ObjectRollVecEnv(TactileVecEnv):
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
-                         act_dim=2, oracle_dim=34, feature_dim=3)                                # get_extended_feature_array :409-415
+                         act_dim=2, oracle_dim=34, feature_dim=3,
+                         scene_spec={"arm_type": modes["arm_type"], "camera": ([0.75, 0.0, 0.00775], 0.01, 90.0, 0.0, 75.0, 0.01, 100.0)})   # :145-154                                # get_extended_feature_array :409-415
 
     def feature_numpy(self, terminal=False):
         buf = np.zeros((self.num_envs, 12), dtype=np.float32)                                   # device rows are 12 floats wide; 3 are used

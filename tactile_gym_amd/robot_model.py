@@ -126,6 +126,7 @@ class SensorDesc:
         self.border_mask = np.ascontiguousarray(z["border_mask"], dtype=np.uint8)
         cam = sensor_camera(t_s_name, t_s_type)
         self.cam = cam
+        self.t_s_name, self.t_s_type = t_s_name, t_s_type
         s = capi.TgSensor()
         s.image_h, s.image_w = int(image_size[0]), int(image_size[1])
         for k in range(3):
@@ -153,3 +154,67 @@ class MeshDesc:
     def load(name):
         z = np.load(os.path.join(ASSETS, "stimuli", name + ".npz"))
         return MeshDesc(z["verts"], z["tris"])
+
+
+# ----------------------------------------------------------------------------------------------------- scene camera (visual observations)
+LIGHT_DIR = (-50.0, 30.0, 100.0)            # PARITY_ASSUMPTIONS A32
+BACKGROUND = (178, 178, 204)                # PARITY_ASSUMPTIONS A33
+
+
+def _instances(name):
+    import json
+    with open(os.path.join(ASSETS, "visual", name + ".json")) as f:
+        return json.load(f)["instances"]
+
+
+def compose_scene(arm_type, t_s_type, t_s_name, ndof, body_mesh=None, body_rgb=(0, 0, 255)):
+    """Everything the scene camera (get_visual_obs, base_tactile_env.py:212-245) draws, as one indexed triangle set:
+    verts f32 [nv, 3] in the frame each triangle names, tris i32 [nt, 3], tri_frame u8 [nt] (0: world - plane, table, robot base;
+    1 + i: moving link i; ndof + 1: the task's stimulus / free body, `body_mesh` = (verts, tris) in the frame the tactile camera uses),
+    tri_rgb u8 [nt, 3].  Built from assets/visual (tools/extract_assets.py scenes())."""
+    from .urdf_compile import _Geom, _primitive_mesh
+    vs, ts, fs, cs, base = [], [], [], [], 0
+    cache = {}
+    for scene in ("world_plane", "world_table", f"robot_{arm_type}_{t_s_type}_{t_s_name}"):
+        for e in _instances(scene):
+            if "mesh" in e:
+                if e["mesh"] not in cache:
+                    z = np.load(os.path.join(ASSETS, "visual", e["mesh"] + ".npz"))
+                    cache[e["mesh"]] = (z["verts"].astype(np.float64), z["tris"])
+                v, t = cache[e["mesh"]]
+                v = v * np.asarray(e["scale"])
+            else:
+                v, t = _primitive_mesh(_Geom(kind=e["prim"][0], origin_xyz=[0.0] * 3, origin_rpy=[0.0] * 3, size=list(e["prim"][1])))
+            v = v @ np.asarray(e["R"]).reshape(3, 3).T + np.asarray(e["p"])
+            vs.append(v); ts.append(np.asarray(t, dtype=np.int64) + base); base += len(v)
+            fs.append(np.full(len(t), e["link"] + 1, dtype=np.uint8))
+            cs.append(np.tile(np.asarray(e["rgb"], dtype=np.uint8), (len(t), 1)))
+    if body_mesh is not None:
+        v, t = np.asarray(body_mesh[0], dtype=np.float64), np.asarray(body_mesh[1], dtype=np.int64)
+        vs.append(v); ts.append(t + base); base += len(v)
+        fs.append(np.full(len(t), ndof + 1, dtype=np.uint8))
+        cs.append(np.tile(np.asarray(body_rgb, dtype=np.uint8), (len(t), 1)))
+    return (np.ascontiguousarray(np.concatenate(vs), dtype=np.float32), np.ascontiguousarray(np.concatenate(ts), dtype=np.int32),
+            np.ascontiguousarray(np.concatenate(fs)), np.ascontiguousarray(np.concatenate(cs)))
+
+
+class SceneDesc:
+    """tg_scene plus the arrays behind its pointers.  camera = (target [3], distance, yaw deg, pitch deg, fov deg, near, far): the env's
+    rgb_cam_* attributes (e.g. edge_follow_env.py:176-195)."""
+
+    def __init__(self, arm_type, t_s_type, t_s_name, ndof, image_size, camera, body_mesh=None, body_rgb=(0, 0, 255), every_step=False):
+        self.verts, self.tris, self.tri_frame, self.tri_rgb = compose_scene(arm_type, t_s_type, t_s_name, ndof, body_mesh, body_rgb)
+        target, dist, yaw, pitch, fov, near, far = camera
+        s = capi.TgScene()
+        s.image_h, s.image_w = int(image_size[0]), int(image_size[1])
+        s.n_verts, s.n_tris = self.verts.shape[0], self.tris.shape[0]
+        s.verts = self.verts.ctypes.data_as(C.POINTER(C.c_float))
+        s.tris = self.tris.ctypes.data_as(C.POINTER(C.c_int32))
+        s.tri_frame = self.tri_frame.ctypes.data_as(C.POINTER(C.c_uint8))
+        s.tri_rgb = self.tri_rgb.ctypes.data_as(C.POINTER(C.c_uint8))
+        for k in range(3):
+            s.cam_target[k], s.light_dir[k], s.background[k] = float(target[k]), float(LIGHT_DIR[k]), int(BACKGROUND[k])
+        s.cam_dist, s.cam_yaw_deg, s.cam_pitch_deg = float(dist), float(yaw), float(pitch)
+        s.fov_deg, s.near_plane, s.far_plane = float(fov), float(near), float(far)
+        s.every_step = int(bool(every_step))
+        self.struct = s

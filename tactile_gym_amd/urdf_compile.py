@@ -456,6 +456,134 @@ def visual_meshes_of_link(path, link_name):
     return np.concatenate(out_v), np.concatenate(out_t)
 
 
+# ----------------------------------------------------------------------------- visual scene (RGB scene camera)
+def _primitive_mesh(g):
+    """Triangles of a URDF primitive <visual> in its own frame: box 12, cylinder (axis z) 32 segments, sphere: a 16 x 32 lat-long grid.
+    (PyBullet tessellates primitives in its renderer; the tessellation here is this repo's own, PARITY_ASSUMPTIONS A32.)"""
+    if g.kind == "box":
+        return _box_mesh(g.size)
+    if g.kind == "cylinder":
+        r, l, n = float(g.size[0]), float(g.size[1]), 32
+        ang = 2.0 * math.pi * np.arange(n) / n
+        ring = np.stack([r * np.cos(ang), r * np.sin(ang)], 1)
+        v = np.concatenate([np.c_[ring, np.full(n, -l / 2)], np.c_[ring, np.full(n, l / 2)], [[0, 0, -l / 2], [0, 0, l / 2]]])
+        t = []
+        for i in range(n):
+            j = (i + 1) % n
+            t += [(i, j, n + j), (i, n + j, n + i), (2 * n, j, i), (2 * n + 1, n + i, n + j)]
+        return v, np.asarray(t, dtype=np.int32)
+    if g.kind == "sphere":
+        r, nl, nm = float(g.size[0]), 16, 32
+        v = [[0.0, 0.0, r]]
+        for a in range(1, nl):
+            th = math.pi * a / nl
+            for b in range(nm):
+                ph = 2.0 * math.pi * b / nm
+                v.append([r * math.sin(th) * math.cos(ph), r * math.sin(th) * math.sin(ph), r * math.cos(th)])
+        v.append([0.0, 0.0, -r])
+        t = []
+        for b in range(nm):
+            t.append((0, 1 + b, 1 + (b + 1) % nm))
+            t.append((len(v) - 1, 1 + (nl - 2) * nm + (b + 1) % nm, 1 + (nl - 2) * nm + b))
+        for a in range(nl - 2):
+            for b in range(nm):
+                p00, p01 = 1 + a * nm + b, 1 + a * nm + (b + 1) % nm
+                p10, p11 = p00 + nm, p01 + nm
+                t += [(p00, p10, p11), (p00, p11, p01)]
+        return np.asarray(v), np.asarray(t, dtype=np.int32)
+    raise ValueError(g.kind)
+
+
+def visual_instances(path, default_rgba=(1.0, 1.0, 1.0, 1.0)):
+    """What a scene camera sees of a URDF (getCameraImage draws every <visual>): one record per opaque <visual>,
+    {"mesh": absolute mesh path or None, "prim": (kind, size) or None, "scale", "link": moving-link index (-1 = welded to the base),
+     "R", "p": pose of the visual's geometry frame in that moving link's frame, "rgb": u8[3] from the <material> rgba (inline, or by
+    name; `default_rgba` without one)}.  Transparent visuals (alpha < 1: TCP markers, goal indicators) are skipped [PARITY_ASSUMPTIONS A33]."""
+    root_el = ET.parse(path).getroot()
+    named = {}
+    for m in root_el.iter("material"):
+        c = m.find("color")
+        if c is not None and m.get("name"):
+            named.setdefault(m.get("name"), _floats(c.get("rgba"), 4, 1.0))
+    links, joints = parse_urdf(path)
+    urdf_dir = os.path.dirname(os.path.abspath(path))
+    rgba_of = {}                                   # (link name, visual index) -> rgba
+    for el in root_el.findall("link"):
+        vi = 0
+        for v in el.findall("visual"):
+            if v.find("geometry") is None:
+                continue
+            m = v.find("material")
+            rgba = None
+            if m is not None:
+                c = m.find("color")
+                rgba = _floats(c.get("rgba"), 4, 1.0) if c is not None else named.get(m.get("name"))
+            rgba_of[(el.get("name"), vi)] = rgba if rgba is not None else list(default_rgba)
+            vi += 1
+    children = {j.child for j in joints}
+    root = [n for n in links if n not in children][0]
+    by_parent = {}
+    for j in joints:
+        by_parent.setdefault(j.parent, []).append(j)
+    order = []
+
+    def dfs(link):
+        for j in by_parent.get(link, []):
+            order.append(j)
+            dfs(j.child)
+    dfs(root)
+    attach = {root: (-1, np.eye(3), np.zeros(3))}  # same numbering as compile_urdf: moving links in depth-first URDF child order
+    n_moving = 0
+    for j in order:
+        mi, R, p = attach[j.parent]
+        Rj, pj = rpy_to_mat(j.rpy), np.asarray(j.xyz, dtype=np.float64)
+        if j.jtype == "fixed":
+            attach[j.child] = (mi, R @ Rj, R @ pj + p)
+        else:
+            attach[j.child] = (n_moving, np.eye(3), np.zeros(3))
+            n_moving += 1
+    out = []
+    for name, L in links.items():
+        mi, R, p = attach[name]
+        for vi, g in enumerate(L.visuals):
+            rgba = rgba_of.get((name, vi), list(default_rgba))
+            if rgba[3] < 1.0:
+                continue
+            rec = {"mesh": None, "prim": None, "scale": [1.0, 1.0, 1.0], "link": int(mi)}
+            if g.kind == "mesh":
+                mp = find_mesh_file(urdf_dir, g.mesh)
+                if mp is None:
+                    continue                       # a large blob missing upstream
+                rec["mesh"], rec["scale"] = mp, [float(x) for x in g.scale]
+            else:
+                rec["prim"] = (g.kind, [float(x) for x in np.atleast_1d(g.size)])
+            Rg, pg = rpy_to_mat(g.origin_rpy), np.asarray(g.origin_xyz, dtype=np.float64)
+            rec["R"], rec["p"] = R @ Rg, R @ pg + p
+            rec["rgb"] = [int(x) for x in np.clip(np.round(np.asarray(rgba[:3]) * 255.0), 0, 255)]
+            out.append(rec)
+    return out
+
+
+def instance_mesh(rec):
+    """(verts, tris) of one visual_instances record in its geometry frame, scale applied."""
+    if rec["mesh"] is not None:
+        v, t = load_mesh(rec["mesh"])
+        return np.asarray(v, dtype=np.float64) * np.asarray(rec["scale"], dtype=np.float64), np.asarray(t, dtype=np.int32)
+    kind, size = rec["prim"]
+    return _primitive_mesh(_Geom(kind=kind, origin_xyz=[0.0] * 3, origin_rpy=[0.0] * 3, size=list(size)))
+
+
+def visual_scene(path, default_rgba=(1.0, 1.0, 1.0, 1.0)):
+    """visual_instances composed: (verts f32 [nv, 3] in the owning moving link's frame, tris i32 [nt, 3], tri_link i8 [nt], tri_rgb u8 [nt, 3])."""
+    vs, ts, ls, cs, base = [], [], [], [], 0
+    for rec in visual_instances(path, default_rgba):
+        v, t = instance_mesh(rec)
+        v = v @ np.asarray(rec["R"]).T + np.asarray(rec["p"])
+        vs.append(v); ts.append(t + base); base += len(v)
+        ls.append(np.full(len(t), rec["link"], dtype=np.int8)); cs.append(np.tile(np.asarray(rec["rgb"], dtype=np.uint8), (len(t), 1)))
+    return (np.concatenate(vs).astype(np.float32), np.concatenate(ts).astype(np.int32), np.concatenate(ls), np.concatenate(cs))
+
+
 # ----------------------------------------------------------------------------- free objects (pole, cube, ...)
 def _box_mesh(size):
     hx, hy, hz = (0.5 * float(s) for s in size)

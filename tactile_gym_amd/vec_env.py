@@ -48,7 +48,7 @@ class TactileVecEnv(_VecEnvBase):
     metadata = {"render.modes": ["rgb_array"]}
 
     def __init__(self, cfg, robot, sensor_desc, mesh_desc, observation_mode="tactile", obs_mode="numpy", seed=None, act_dim=None,
-                 oracle_dim=10, feature_dim=0, copy_obs=True):
+                 oracle_dim=10, feature_dim=0, copy_obs=True, scene_spec=None):
         self._L = capi.lib()
         self.num_envs = int(cfg.num_envs)
         self._cfg, self._robot, self._sensor, self._mesh = cfg, robot, sensor_desc, mesh_desc
@@ -56,8 +56,12 @@ class TactileVecEnv(_VecEnvBase):
         if observation_mode not in ("oracle", "tactile", "visual", "visuotactile", "tactile_and_feature", "visual_and_feature",
                                     "visuotactile_and_feature"):
             raise SystemExit(f"Incorrect observation mode specified: {observation_mode}")  # base_tactile_env.py:264
-        if "visual" in observation_mode or "visuo" in observation_mode:
-            raise NotImplementedError("visual (RGB scene camera) observations are outside the built hot path (SURVEY 8f rank 4)")
+        self._visual = "visual" in observation_mode or "visuo" in observation_mode
+        # scene_spec = {"arm_type", "camera": (target, distance, yaw, pitch, fov, near, far), "body_rgb"}: what get_visual_obs needs
+        # (base_tactile_env.py:212-245); None: this env's scene is not built (the surface envs' textured heightfield)
+        self._scene_spec, self._scene = scene_spec, None
+        if self._visual and scene_spec is None:
+            raise NotImplementedError("visual (RGB scene camera) observations are not built for this env")
         self.obs_mode = obs_mode
         # copy_obs=True (default): every observation batch handed out is an array of its own, like the reference's fresh arrays
         # (base_tactile_env.py:247-282).  copy_obs=False: the device -> host copy lands in one of four rotating host buffers, valid for
@@ -76,6 +80,9 @@ class TactileVecEnv(_VecEnvBase):
             obs_spaces["oracle"] = spaces.Box(low=-np.inf, high=np.inf, shape=(oracle_dim,), dtype=np.float32)
         if "tactile" in observation_mode:
             obs_spaces["tactile"] = spaces.Box(low=0, high=255, shape=(self.H, self.W, 1), dtype=np.uint8)
+        if self._visual:
+            obs_spaces["visual"] = spaces.Box(low=0, high=255, shape=(self.H, self.W, 3), dtype=np.uint8)   # rgb_image_size = image_size
+            self._set_scene(every_step=True)
         if "feature" in observation_mode:
             obs_spaces["extended_feature"] = spaces.Box(low=-np.inf, high=np.inf, shape=(feature_dim,), dtype=np.float32)
         self.feature_dim = feature_dim
@@ -190,21 +197,39 @@ class TactileVecEnv(_VecEnvBase):
         idx = range(self.num_envs) if indices is None else ([indices] if np.isscalar(indices) else indices)
         return [getattr(self, method_name)(*args, **kwargs) for _ in idx]
 
+    def _set_scene(self, every_step):
+        from .robot_model import SceneDesc
+        sp = self._scene_spec
+        body = None if self._mesh is None else (self._mesh.verts, self._mesh.tris)
+        self._scene = SceneDesc(sp["arm_type"], self._sensor.t_s_type, self._sensor.t_s_name, self._robot.ndof, (self.H, self.W), sp["camera"],
+                                body, sp.get("body_rgb", (0, 0, 255)), every_step)
+        capi.check(self._L.tg_set_scene(self._ctx, C.byref(self._scene.struct)))
+
     def get_images(self):
-        return list(self.tactile_numpy()[..., 0])
+        """One render() frame per env (BaseTactileEnv.render, base_tactile_env.py:284-303): [H, 2W, 3] uint8, the scene camera's rgb image
+        beside the tactile image as grey rgb.  Envs without a built scene: the tactile image alone, [H, W, 3]."""
+        tac = np.repeat(self.tactile_numpy()[..., :1], 3, axis=3)
+        if self._scene_spec is None:
+            return list(tac)
+        if self._scene is None:
+            self._set_scene(every_step=False)
+        if not self._visual:
+            capi.check(self._L.tg_render_scene(self._ctx))
+        return list(np.concatenate([self.visual_numpy(), tac], axis=2))
 
     def render(self, mode="rgb_array"):
-        """Tiled tactile images (the reference concatenates the RGB scene view, which is not built: SURVEY 8f rank 4)."""
+        """The per-env render() frames tiled into one image (SB3 VecEnv.render)."""
         if mode != "rgb_array":
             return np.array([])
-        img = self.tactile_numpy()[..., 0]
+        imgs = self.get_images()
+        h, w = imgs[0].shape[:2]
         cols = int(np.ceil(np.sqrt(self.num_envs)))
         rows = int(np.ceil(self.num_envs / cols))
-        canvas = np.zeros((rows * self.H, cols * self.W), dtype=np.uint8)
+        canvas = np.zeros((rows * h, cols * w, 3), dtype=np.uint8)
         for i in range(self.num_envs):
             r, c = divmod(i, cols)
-            canvas[r * self.H:(r + 1) * self.H, c * self.W:(c + 1) * self.W] = img[i]
-        return np.repeat(canvas[..., None], 3, axis=2)
+            canvas[r * h:(r + 1) * h, c * w:(c + 1) * w] = imgs[i]
+        return canvas
 
     # ------------------------------------------------------------------ device / host views
     def sync(self):
@@ -266,12 +291,29 @@ class TactileVecEnv(_VecEnvBase):
         capi.check(self._L.tg_copy_obs_tactile(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint8)), int(terminal)))
         return buf
 
+    def visual_torch(self, terminal=False):
+        """Zero-copy torch.uint8 [N, H, W, 3] view of the device-resident scene-camera images."""
+        key = ("vis", bool(terminal))
+        if key not in self._views:
+            import torch
+            p = C.c_void_p()
+            capi.check(self._L.tg_get_obs_visual(self._ctx, C.byref(p), int(terminal)))
+            self._views[key] = torch.as_tensor(_DevArray(p.value, (self.num_envs, self.H, self.W, 3), "|u1"), device=f"cuda:{self._cfg.device}")
+        return self._views[key]
+
+    def visual_numpy(self, terminal=False):
+        buf = np.empty((self.num_envs, self.H, self.W, 3), dtype=np.uint8)
+        capi.check(self._L.tg_copy_obs_visual(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint8)), int(terminal)))
+        return buf
+
     def _observation(self):
         obs = {}
         if "oracle" in self.observation_mode:
             obs["oracle"] = self.oracle_obs()
         if "tactile" in self.observation_mode:
             obs["tactile"] = self.tactile_torch() if self.obs_mode == "torch" else self.tactile_numpy()
+        if self._visual:
+            obs["visual"] = self.visual_torch() if self.obs_mode == "torch" else self.visual_numpy()
         if "feature" in self.observation_mode:
             obs["extended_feature"] = self.feature_torch() if self.obs_mode == "torch" else self.feature_numpy()
         return obs
@@ -280,6 +322,8 @@ class TactileVecEnv(_VecEnvBase):
         obs = {}
         if "tactile" in self.observation_mode:
             obs["tactile"] = self.tactile_torch(True) if self.obs_mode == "torch" else self.tactile_numpy(True)
+        if self._visual:
+            obs["visual"] = self.visual_torch(True) if self.obs_mode == "torch" else self.visual_numpy(True)
         if "feature" in self.observation_mode:
             obs["extended_feature"] = self.feature_torch(True) if self.obs_mode == "torch" else self.feature_numpy(True)
         return obs
@@ -423,7 +467,11 @@ class SingleTactileEnv(_GymEnvBase):
         return self._first(obs), float(rew[0]), bool(done[0]), {}
 
     def render(self, mode="rgb_array"):
-        return self._vec.render(mode)
+        """BaseTactileEnv.render (base_tactile_env.py:284-303): the scene camera's rgb image beside the tactile image, [H, 2W, 3] uint8
+        (no cv2 window: headless)."""
+        if mode != "rgb_array":
+            return np.array([])
+        return self._vec.get_images()[0]
 
     def close(self):
         self._vec.close()

@@ -8,6 +8,7 @@ Reads (never copies verbatim) from /root/reference/tactile_gym/assets:
   * sensor reference images (.npy)  -> tactile_gym_amd/assets/sensors/<sensor>_<type>_<N>.npz     (hot-path constants a15)
   * stimulus meshes                 -> tactile_gym_amd/assets/stimuli/<name>.npz                  (float32 verts, int32 tris)
   * free objects (pole, cube)       -> tactile_gym_amd/assets/objects/<name>.npz                  (mass, com, inertia, visual triangles)
+  * every opaque <visual>           -> tactile_gym_amd/assets/visual/{mesh_*.npz, <scene>.json}    (scene camera: unique meshes + instance lists)
   * skin / body visual meshes       -> tests/golden/<sensor>_<type>_view.npz                      (fixture-pinning only)
 
 Nothing under tests/, bench.py or smoke() reads /root/reference at run time; they read these blobs.
@@ -20,7 +21,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tactile_gym_amd.urdf_compile import collision_cylinder_of_link, collision_hull_of_link, compile_free_body, compile_urdf, load_mesh, parse_urdf, rpy_to_mat, visual_meshes_of_link  # noqa: E402
+from tactile_gym_amd.urdf_compile import collision_cylinder_of_link, collision_hull_of_link, compile_free_body, compile_urdf, instance_mesh, load_mesh, parse_urdf, rpy_to_mat, visual_instances, visual_meshes_of_link  # noqa: E402
 
 REF = os.environ.get("TG_REFERENCE_ASSETS", "/root/reference/tactile_gym/assets")
 OUT = os.path.join(ROOT, "tactile_gym_amd", "assets")
@@ -229,10 +230,67 @@ def sphere():
          verts=v.astype(np.float32), tris=t.astype(np.int32))
 
 
+def _weld(v, t):
+    """Merge bit-identical vertices (STL stores three per triangle) and drop triangles that collapse."""
+    v32 = np.ascontiguousarray(v, dtype=np.float32)
+    uniq, inv = np.unique(v32.view([("", np.float32)] * 3), return_inverse=True)
+    t2 = inv.reshape(-1)[t]
+    keep = (t2[:, 0] != t2[:, 1]) & (t2[:, 1] != t2[:, 2]) & (t2[:, 0] != t2[:, 2])
+    return uniq.view(np.float32).reshape(-1, 3), t2[keep].astype(np.int32)
+
+
+def _scene(name, urdf, base_pos=(0.0, 0.0, 0.0)):
+    """assets/visual/<name>.json: the instance list of a URDF's opaque visuals (visual_instances); mesh files go once, welded, to
+    assets/visual/mesh_<stem>_<sha1[:8]>.npz, primitives stay parametric.  `base_pos` bakes a fixed loadURDF position into link -1."""
+    import hashlib
+    import json
+    out = []
+    for rec in visual_instances(urdf):
+        e = {"link": rec["link"], "R": np.asarray(rec["R"]).reshape(9).tolist(), "rgb": rec["rgb"], "scale": rec["scale"],
+             "p": (np.asarray(rec["p"]) + (np.asarray(base_pos) if rec["link"] < 0 else 0.0)).tolist()}
+        if rec["mesh"] is not None:
+            h = hashlib.sha1(open(rec["mesh"], "rb").read()).hexdigest()[:8]
+            key = f"mesh_{os.path.splitext(os.path.basename(rec['mesh']))[0].lower()}_{h}"
+            dst = os.path.join(OUT, "visual", key + ".npz")
+            if not os.path.isfile(dst):
+                v, t = _weld(*load_mesh(rec["mesh"]))
+                os.makedirs(os.path.dirname(dst), exist_ok=True)
+                np.savez_compressed(dst, verts=v, tris=t)
+            e["mesh"] = key
+        else:
+            e["prim"] = [rec["prim"][0], rec["prim"][1]]
+        out.append(e)
+    os.makedirs(os.path.join(OUT, "visual"), exist_ok=True)
+    with open(os.path.join(OUT, "visual", name + ".json"), "w") as f:
+        json.dump({"source": os.path.relpath(urdf, REF), "instances": out}, f)
+    return out
+
+
+def scenes():
+    """What the envs' scene camera (get_visual_obs, base_tactile_env.py:212-245) can see: plane + table (load_environment,
+    base_tactile_env.py:131-139, positions baked), each robot URDF, each task object."""
+    env = "shared_assets/environment_objects"
+    _scene("world_plane", os.path.join(REF, env, "plane/plane.urdf"), (0.0, 0.0, -0.625))
+    _scene("world_table", os.path.join(REF, env, "table/table.urdf"), (0.50, 0.0, -0.625))
+    for arm, sensor, typ in ROBOTS:
+        urdf = os.path.join(REF, "robot_assets", arm, sensor, f"{arm}_with_{typ}_{sensor}.urdf")
+        if os.path.isfile(urdf):
+            _scene(f"robot_{arm}_{typ}_{sensor}", urdf)
+    for name, rel in (("long_edge", "rl_env_assets/exploration/edge_follow/edge_stimuli/long_edge_flat/long_edge.urdf"),
+                      ("cube", "rl_env_assets/nonprehensile_manipulation/object_push/cube/cube.urdf"),
+                      ("pole", "rl_env_assets/nonprehensile_manipulation/object_balance/pole/pole.urdf"),
+                      ("sphere", "rl_env_assets/nonprehensile_manipulation/object_roll/sphere/sphere.urdf")):
+        _scene("object_" + name, os.path.join(REF, rel))
+
+
 if __name__ == "__main__":
+    if "--scenes-only" in sys.argv:
+        scenes()
+        sys.exit(0)
     objects()
     sphere()
     robots()
     sensors()
     stimuli()
     golden_views()
+    scenes()

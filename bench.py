@@ -94,6 +94,8 @@ def main():
                          "(use --image-size 256)")
     ap.add_argument("--contact-mapping", default="auto", choices=["auto", "lane", "wave"],
                     help="object_push / object_roll: one wavefront per env or one lane per env for the contact solve (tg_config.contact_mapping)")
+    ap.add_argument("--observation-mode", default=None, help="override the config's observation_mode (e.g. visuotactile: adds the RGB scene camera, SURVEY 8 row f4); "
+                    "measurement aid, the bench line stays the tactile configuration")
     ap.add_argument("--solver-iters", type=int, default=None, help="object_push / object_roll: override numSolverIterations (150); measurement aid, not a bench configuration")
     args = ap.parse_args()
 
@@ -121,6 +123,8 @@ def main():
     n = args.num_envs
     modes = {"edge_follow-v0": MODES, "surface_follow-v0": SURF_MODES, "object_balance-v0": BAL_MODES, "object_push-v0": PUSH_MODES,
              "object_roll-v0": ROLL_MODES, "surface_follow-v2": VERT_MODES}[args.env]
+    if args.observation_mode:
+        modes = dict(modes, observation_mode=args.observation_mode)
     act_dim = 3 if args.env == "surface_follow-v0" else 2
     max_steps = {"object_balance-v0": 250, "object_push-v0": 1000, "object_roll-v0": 250}.get(args.env, 200)   # params/*_params.py max_ep_len
     extra = dict(contact_mapping=args.contact_mapping, solver_iterations=args.solver_iters) if args.env in ("object_push-v0", "object_roll-v0") else {}
@@ -273,6 +277,9 @@ def main():
             "without_full_batch_reset": no_reset,
             "resets_in_timed_region": bool((args.warmup % 200) + args.steps >= 200),
         }
+        if prof["scene"][1]:    # --observation-mode visual / visuotactile: the scene camera's two kernels (eye<-frame transforms + raster), per draw
+            out["scene_camera"] = {"observation_mode": modes["observation_mode"], "ms_per_draw": round(prof["scene"][0] / prof["scene"][1], 4),
+                                   "draws": prof["scene"][1]}
         if world == 1 and not args.no_cpu_baseline and args.env == "edge_follow-v0":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -483,7 +483,8 @@ void mb_render_scene(const float* verts, const int32_t* tris, const uint8_t* tri
         for (int k = 0; k < 3; ++k) rgb = (rgb << 8) | (uint32_t)((float)tri_rgb[3 * t + k] * inten + 0.5f);
         int x0 = 0, x1 = W - 1, y0 = 0, y1 = H - 1;
         if (w[0] >= near_ && w[1] >= near_ && w[2] >= near_) {
-            float sx0 = X[0] / w[0], sx1 = X[1] / w[1], sx2 = X[2] / w[2], sy0 = Y[0] / w[0], sy1 = Y[1] / w[1], sy2 = Y[2] / w[2];
+            float r0 = 1.0f / w[0], r1 = 1.0f / w[1], r2 = 1.0f / w[2];
+            float sx0 = X[0] * r0, sx1 = X[1] * r1, sx2 = X[2] * r2, sy0 = Y[0] * r0, sy1 = Y[1] * r1, sy2 = Y[2] * r2;
             /* pixel centres inside the bounding box, widened by 1/64 pixel (the divisions above round) */
             float minx = fminf(sx0, fminf(sx1, sx2)), maxx = fmaxf(sx0, fmaxf(sx1, sx2)), miny = fminf(sy0, fminf(sy1, sy2)), maxy = fmaxf(sy0, fmaxf(sy1, sy2));
             minx = fminf(fmaxf(minx, -1.0f), (float)W + 1.0f); maxx = fminf(fmaxf(maxx, -1.0f), (float)W + 1.0f);

@@ -374,6 +374,7 @@ struct tg_ctx {
     float *d_scene_verts = nullptr, *d_scene_xf = nullptr;
     int32_t* d_scene_tris = nullptr;
     uint32_t* d_scene_attr = nullptr;
+    tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
     // hipGraph of one tg_step launch sequence, keyed by the device action pointer it was captured with (launch-bound inner loop:
     // 3-4 kernels per step, one graph launch instead)
@@ -387,8 +388,8 @@ struct tg_ctx {
     bool profile = false;
     struct Ev { hipEvent_t a, b; int which; };
     std::vector<Ev> events;
-    double prof_ms[4] = {0, 0, 0, 0};
-    int64_t prof_n[4] = {0, 0, 0, 0};
+    double prof_ms[5] = {0, 0, 0, 0, 0};     // step, render, reset, masked render, scene camera
+    int64_t prof_n[5] = {0, 0, 0, 0, 0};
 };
 
 namespace tg {
@@ -571,6 +572,7 @@ template <typename T, int TOPO> static void launch_scene_xf_t(tg_ctx* c, const u
 }
 // get_visual_obs for the whole batch (or the masked envs; save_prev keeps their previous image as the terminal observation)
 static void scene_draw(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
+    Timer t(c, 4);
 #define CALL(T, TOPO) launch_scene_xf_t<T, TOPO>(c, d_mask)
     TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
@@ -840,7 +842,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_vis, c->d_vis_term};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_chunks, c->d_vis, c->d_vis_term};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1051,11 +1053,18 @@ int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
     for (int k = 0; k < 3; ++k) P.background[k] = sc->background[k];
     P.n_tris = sc->n_tris; P.n_frames = n_frames;
     const size_t n = (size_t)c->cfg.num_envs, img = (size_t)W * H * 3;
+    std::vector<int32_t> tris(sc->tris, sc->tris + (size_t)sc->n_tris * 3);
+    std::vector<SceneChunk> chunks;
+    build_scene_chunks(sc->verts, tris.data(), attr.data(), sc->n_tris, chunks);
+    if (chunks.size() > 8192) return fail(-1, "tg_set_scene: too many triangle chunks");
+    TG_HIP(hipMalloc(&c->d_scene_chunks, chunks.size() * sizeof(SceneChunk)));
+    TG_HIP(hipMemcpy(c->d_scene_chunks, chunks.data(), chunks.size() * sizeof(SceneChunk), hipMemcpyHostToDevice));
+    P.chunks = c->d_scene_chunks; P.n_chunks = (int)chunks.size();
     TG_HIP(hipMalloc(&c->d_scene_verts, (size_t)sc->n_verts * 12)); TG_HIP(hipMalloc(&c->d_scene_tris, (size_t)sc->n_tris * 12));
     TG_HIP(hipMalloc(&c->d_scene_attr, (size_t)sc->n_tris * 4)); TG_HIP(hipMalloc(&c->d_scene_xf, n * n_frames * 12 * 4));
     TG_HIP(hipMalloc(&c->d_vis, n * img)); TG_HIP(hipMalloc(&c->d_vis_term, n * img));
     TG_HIP(hipMemcpy(c->d_scene_verts, sc->verts, (size_t)sc->n_verts * 12, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(c->d_scene_tris, sc->tris, (size_t)sc->n_tris * 12, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(c->d_scene_tris, tris.data(), (size_t)sc->n_tris * 12, hipMemcpyHostToDevice));
     TG_HIP(hipMemcpy(c->d_scene_attr, attr.data(), (size_t)sc->n_tris * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMemset(c->d_vis, 0, n * img)); TG_HIP(hipMemset(c->d_vis_term, 0, n * img));
     P.verts = c->d_scene_verts; P.tris = c->d_scene_tris; P.tri_attr = c->d_scene_attr;
@@ -1277,11 +1286,11 @@ int tg_profile_enable(tg_ctx* c, int32_t enable) {
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
     c->profile = enable != 0;
-    for (int k = 0; k < 4; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    for (int k = 0; k < 5; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     return 0;
 }
 int tg_profile_get(tg_ctx* c, int32_t which, double* total_ms, int64_t* launches) {
-    if (!c || which < 0 || which > 3) return fail(-1, "bad argument");
+    if (!c || which < 0 || which > 4) return fail(-1, "bad argument");
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
     if (total_ms) *total_ms = c->prof_ms[which];

@@ -3,12 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace tg {
 
 // The envs' fixed world camera (get_visual_obs, base_tactile_env.py:212-245): one indexed triangle set shared by all envs, every
 // triangle rigid in one of n_frames frames (0 world, 1 + i moving link i, n_frames - 1 the task's stimulus / free body); per env the
 // eye <- frame transforms [n_frames][12] (R row-major, t) rounded once to float.  Projection constants are derived on the host in
 // double and rounded once, as for the tactile camera: window x = hw + kx x/w, y = hh - ky y/w (w = -z_eye), aspect = W / H.
+struct SceneChunk { float cx, cy, cz, r; int start, count, frame, pad; };
+
 struct SceneParams {
     int W, H, n_tris, n_frames;
     float kx, ky, hw, hh, near_, far_, inv_near, inv_far;
@@ -17,9 +21,15 @@ struct SceneParams {
     const float* verts;            // device [n_verts][3]
     const int32_t* tris;           // device [n_tris][3]
     const uint32_t* tri_attr;      // device [n_tris]: frame << 24 | r << 16 | g << 8 | b
+    const SceneChunk* chunks;      // device [n_chunks]: runs of <= 64 spatially sorted triangles of one frame with a bounding sphere
+    int n_chunks;
 };
 
 SceneParams make_scene_params(int W, int H, double fov_deg, double near_, double far_);
+
+// Sorts the triangles by (frame, Morton code of the centroid) - the image does not depend on their order - and cuts them into chunks.
+void build_scene_chunks(const float* verts, int32_t* tris /*[n][3], reordered*/, uint32_t* attr /*[n], reordered*/, int n_tris,
+                        std::vector<SceneChunk>& chunks);
 
 // Draws out[env] (uint8 [H][W][3]) for every env (mask == nullptr) or the envs whose mask byte is non-zero; with save_prev the
 // previous image of a drawn env is first copied to save_prev[env] (the terminal observation of an auto-reset).

@@ -10,18 +10,28 @@
 // lanes stride over the triangle list (indices + attributes stream from L2, shared by every env), transform the three vertices with
 // the env's eye<-frame matrix held in LDS, and test the handful of pixel centres in the triangle's bounding box with ds_max_u64.
 // Triangles whose box is large (plane, table top) are queued in LDS and then filled by the whole workgroup, pixels across lanes.
+// Most of the robot is outside the camera's view: triangles are sorted on the host into chunks of <= 64 neighbours (one frame each)
+// with a bounding sphere, the workgroup first tests the spheres against the tile's frustum and only visible chunks are set up,
+// one chunk per wavefront, one triangle per lane.
 #include "tg_scene.h"
 
 #include <math.h>
+
+#include <algorithm>
+#include <numeric>
 
 namespace tg {
 
 namespace {
 
 constexpr int kThreads = 1024;
-constexpr int kBigArea = 64;       // bounding boxes above this many pixels are filled cooperatively
+constexpr int kBigArea = 64;       // bounding boxes above this many pixels are filled by a whole wavefront, pixels across lanes
 constexpr int kBigCap = 2048;
+constexpr int kHugeArea = 4096;    // ... and above this many by the whole workgroup (ground plane, table top)
+constexpr int kHugeCap = 64;
 constexpr int kMaxFrames = 16;
+constexpr int kChunk = 64;
+constexpr int kMaxChunks = 8192;   // visible-chunk list in LDS (u16 entries)
 
 struct TriSetup {
     float a0, b0, c0, a1, b1, c1, a2, b2, c2, sg, rdet;
@@ -30,7 +40,7 @@ struct TriSetup {
 };
 
 // Everything about triangle t that does not depend on the pixel.  Returns false when nothing can be drawn.
-__device__ __forceinline__ bool setup_tri(const SceneParams& P, const float* __restrict__ sxf, int t, TriSetup& S) {
+__device__ __forceinline__ bool setup_tri(const SceneParams& P, const float* __restrict__ sxf, int t, const int (&tile)[4], TriSetup& S) {
     const int i0 = P.tris[3 * t + 0], i1 = P.tris[3 * t + 1], i2 = P.tris[3 * t + 2];
     const uint32_t attr = P.tri_attr[t];
     const float* M = sxf + 12 * (attr >> 24);
@@ -48,16 +58,10 @@ __device__ __forceinline__ bool setup_tri(const SceneParams& P, const float* __r
     }
     if (w[0] < P.near_ && w[1] < P.near_ && w[2] < P.near_) return false;
     if (w[0] > P.far_ && w[1] > P.far_ && w[2] > P.far_) return false;
-    S.a0 = Y[1] * w[2] - Y[2] * w[1]; S.b0 = w[1] * X[2] - w[2] * X[1]; S.c0 = X[1] * Y[2] - X[2] * Y[1];
-    S.a1 = Y[2] * w[0] - Y[0] * w[2]; S.b1 = w[2] * X[0] - w[0] * X[2]; S.c1 = X[2] * Y[0] - X[0] * Y[2];
-    S.a2 = Y[0] * w[1] - Y[1] * w[0]; S.b2 = w[0] * X[1] - w[1] * X[0]; S.c2 = X[0] * Y[1] - X[1] * Y[0];
-    const float det = (S.c0 * w[0] + S.c1 * w[1]) + S.c2 * w[2];
-    if (det == 0.0f) return false;
-    S.sg = det > 0.0f ? 1.0f : -1.0f;
-    S.rdet = 1.0f / det;
     S.x0 = 0; S.x1 = P.W - 1; S.y0 = 0; S.y1 = P.H - 1;
-    if (w[0] >= P.near_ && w[1] >= P.near_ && w[2] >= P.near_) {
-        const float sx0 = X[0] / w[0], sx1 = X[1] / w[1], sx2 = X[2] / w[2], sy0 = Y[0] / w[0], sy1 = Y[1] / w[1], sy2 = Y[2] / w[2];
+    if (w[0] >= P.near_ && w[1] >= P.near_ && w[2] >= P.near_) {   // most triangles end here: no pixel centre in their box
+        const float r0 = 1.0f / w[0], r1 = 1.0f / w[1], r2 = 1.0f / w[2];
+        const float sx0 = X[0] * r0, sx1 = X[1] * r1, sx2 = X[2] * r2, sy0 = Y[0] * r0, sy1 = Y[1] * r1, sy2 = Y[2] * r2;
         float minx = fminf(sx0, fminf(sx1, sx2)), maxx = fmaxf(sx0, fmaxf(sx1, sx2)), miny = fminf(sy0, fminf(sy1, sy2)), maxy = fmaxf(sy0, fmaxf(sy1, sy2));
         minx = fminf(fmaxf(minx, -1.0f), (float)P.W + 1.0f); maxx = fminf(fmaxf(maxx, -1.0f), (float)P.W + 1.0f);
         miny = fminf(fmaxf(miny, -1.0f), (float)P.H + 1.0f); maxy = fminf(fmaxf(maxy, -1.0f), (float)P.H + 1.0f);
@@ -65,6 +69,14 @@ __device__ __forceinline__ bool setup_tri(const SceneParams& P, const float* __r
         S.y0 = max(0, (int)ceilf(miny - 0.515625f)); S.y1 = min(P.H - 1, (int)floorf(maxy - 0.484375f));
         if (S.x0 > S.x1 || S.y0 > S.y1) return false;
     }
+    if (S.x0 > tile[2] || S.x1 < tile[0] || S.y0 > tile[3] || S.y1 < tile[1]) return false;
+    S.a0 = Y[1] * w[2] - Y[2] * w[1]; S.b0 = w[1] * X[2] - w[2] * X[1]; S.c0 = X[1] * Y[2] - X[2] * Y[1];
+    S.a1 = Y[2] * w[0] - Y[0] * w[2]; S.b1 = w[2] * X[0] - w[0] * X[2]; S.c1 = X[2] * Y[0] - X[0] * Y[2];
+    S.a2 = Y[0] * w[1] - Y[1] * w[0]; S.b2 = w[0] * X[1] - w[1] * X[0]; S.c2 = X[0] * Y[1] - X[1] * Y[0];
+    const float det = (S.c0 * w[0] + S.c1 * w[1]) + S.c2 * w[2];
+    if (det == 0.0f) return false;
+    S.sg = det > 0.0f ? 1.0f : -1.0f;
+    S.rdet = 1.0f / det;
     // flat shade: n = (e1 - e0) x (e2 - e0) turned towards the eye, 0.6 ambient + 0.35 diffuse [A32]
     const float ux = ex[1] - ex[0], uy = ey[1] - ey[0], uz = ez[1] - ez[0], vx = ex[2] - ex[0], vy = ey[2] - ey[0], vz = ez[2] - ez[0];
     const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
@@ -98,8 +110,10 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     if (mask != nullptr && mask[env] == 0) return;
     extern __shared__ unsigned long long zb[];                     // [th][tw] keys, then the queue of large triangles
     __shared__ float sxf[kMaxFrames * 12];
-    __shared__ int big_n;
+    __shared__ int big_n, vis_n, huge_n;
+    __shared__ int huge[kHugeCap];
     int* big = reinterpret_cast<int*>(zb + tw * th);
+    uint16_t* vis_list = reinterpret_cast<uint16_t*>(big + kBigCap);
     const int tiles_x = P.W / tw;
     const int tx0 = (blockIdx.x % tiles_x) * tw, ty0 = (blockIdx.x / tiles_x) * th;
     const int tid = threadIdx.x;
@@ -113,15 +127,44 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     }
     for (int p = tid; p < tw * th; p += kThreads) zb[p] = 0ull;
     for (int p = tid; p < P.n_frames * 12; p += kThreads) sxf[p] = xf[(size_t)env * P.n_frames * 12 + p];
-    if (tid == 0) big_n = 0;
+    if (tid == 0) { big_n = 0; vis_n = 0; huge_n = 0; }
     __syncthreads();
     const int bx1 = tx0 + tw - 1, by1 = ty0 + th - 1;
-    for (int t = tid; t < P.n_tris; t += kThreads) {
+    const int tile[4] = {tx0, ty0, bx1, by1};
+    // chunk spheres against the tile's frustum (eye space; conservative: a chunk that fails cannot touch a pixel centre of the tile).
+    // Side planes pass through the eye: pixel column c is the plane kx x + (hw - c) w = 0, row r is (hh - r) w - ky y = 0.
+    {
+        const float nl = sqrtf(P.kx * P.kx + (P.hw - (float)tx0) * (P.hw - (float)tx0)), nr = sqrtf(P.kx * P.kx + (P.hw - (float)(bx1 + 1)) * (P.hw - (float)(bx1 + 1)));
+        const float nt = sqrtf(P.ky * P.ky + (P.hh - (float)ty0) * (P.hh - (float)ty0)), nb_ = sqrtf(P.ky * P.ky + (P.hh - (float)(by1 + 1)) * (P.hh - (float)(by1 + 1)));
+        for (int ci = tid; ci < P.n_chunks; ci += kThreads) {
+            const SceneChunk ch = P.chunks[ci];
+            const float* M = sxf + 12 * ch.frame;
+            const float x = M[0] * ch.cx + M[1] * ch.cy + M[2] * ch.cz + M[9], y = M[3] * ch.cx + M[4] * ch.cy + M[5] * ch.cz + M[10];
+            const float w = -(M[6] * ch.cx + M[7] * ch.cy + M[8] * ch.cz + M[11]);
+            const float sc = sqrtf(M[0] * M[0] + M[3] * M[3] + M[6] * M[6]);                 // object_roll: the marble's frame is scaled
+            const float r = ch.r * sc * 1.001f + 1e-6f;
+            bool vis = w + r >= P.near_ && w - r <= P.far_;
+            vis = vis && (P.kx * x + (P.hw - (float)tx0) * w) >= -r * nl && ((float)(bx1 + 1) - P.hw) * w - P.kx * x >= -r * nr;
+            vis = vis && ((P.hh - (float)ty0) * w - P.ky * y) >= -r * nt && (P.ky * y - (P.hh - (float)(by1 + 1)) * w) >= -r * nb_;
+            if (vis) { const int slot = atomicAdd(&vis_n, 1); if (slot < kMaxChunks) vis_list[slot] = (uint16_t)ci; }
+        }
+    }
+    __syncthreads();
+    const int nvis = min(vis_n, kMaxChunks);
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int vi = wave; vi < nvis; vi += kThreads / 64) {
+        const SceneChunk ch = P.chunks[vis_list[vi]];
+        if (lane >= ch.count) continue;
+        const int t = ch.start + lane;
         TriSetup S;
-        if (!setup_tri(P, sxf, t, S)) continue;
+        if (!setup_tri(P, sxf, t, tile, S)) continue;
         const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
-        if (x0 > x1 || y0 > y1) continue;
-        if ((x1 - x0 + 1) * (y1 - y0 + 1) > kBigArea) {
+        const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+        if (area > kHugeArea) {
+            const int slot = atomicAdd(&huge_n, 1);
+            if (slot < kHugeCap) { huge[slot] = t; continue; }
+        }
+        if (area > kBigArea) {
             const int slot = atomicAdd(&big_n, 1);
             if (slot < kBigCap) { big[slot] = t; continue; }
         }
@@ -130,9 +173,17 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     }
     __syncthreads();
     const int nb = min(big_n, kBigCap);
-    for (int i = 0; i < nb; ++i) {
+    for (int i = wave; i < nb; i += kThreads / 64) {               // one queued triangle per wavefront: set-up once (wave-uniform), pixels across lanes
         TriSetup S;
-        if (!setup_tri(P, sxf, big[i], S)) continue;               // workgroup-uniform
+        if (!setup_tri(P, sxf, big[i], tile, S)) continue;
+        const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
+        const int bw = x1 - x0 + 1, np = bw * (y1 - y0 + 1);
+        for (int p = lane; p < np; p += 64) shade_pixel(P, S, x0 + p % bw, y0 + p / bw, zb, tx0, ty0, tw);
+    }
+    const int nh = min(huge_n, kHugeCap);
+    for (int i = 0; i < nh; ++i) {
+        TriSetup S;
+        if (!setup_tri(P, sxf, huge[i], tile, S)) continue;        // workgroup-uniform
         const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
         const int bw = x1 - x0 + 1, np = bw * (y1 - y0 + 1);
         for (int p = tid; p < np; p += kThreads) shade_pixel(P, S, x0 + p % bw, y0 + p / bw, zb, tx0, ty0, tw);
@@ -147,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     }
 }
 
-constexpr size_t lds_bytes(int tw, int th) { return (size_t)tw * th * 8 + (size_t)kBigCap * 4; }
+constexpr size_t lds_bytes(int tw, int th) { return (size_t)tw * th * 8 + (size_t)kBigCap * 4 + (size_t)kMaxChunks * 2; }
 
 }  // namespace
 
@@ -160,6 +211,81 @@ SceneParams make_scene_params(int W, int H, double fov_deg, double near_, double
     P.near_ = (float)near_; P.far_ = (float)far_;
     P.inv_near = 1.0f / P.near_; P.inv_far = 1.0f / P.far_;
     return P;
+}
+
+void build_scene_chunks(const float* verts, int32_t* tris, uint32_t* attr, int n_tris, std::vector<SceneChunk>& chunks) {
+    // per frame: bounding box of the centroids -> 10 bits per axis Morton code; stable sort by (frame, code)
+    float lo[kMaxFrames][3], hi[kMaxFrames][3];
+    for (int f = 0; f < kMaxFrames; ++f) for (int k = 0; k < 3; ++k) { lo[f][k] = 3.4e38f; hi[f][k] = -3.4e38f; }
+    std::vector<float> cen((size_t)n_tris * 3);
+    for (int t = 0; t < n_tris; ++t) {
+        const int f = (int)(attr[t] >> 24);
+        for (int k = 0; k < 3; ++k) {
+            const float c = (verts[3 * tris[3 * t] + k] + verts[3 * tris[3 * t + 1] + k] + verts[3 * tris[3 * t + 2] + k]) / 3.0f;
+            cen[(size_t)3 * t + k] = c;
+            lo[f][k] = std::min(lo[f][k], c); hi[f][k] = std::max(hi[f][k], c);
+        }
+    }
+    auto spread = [](uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; return (v | (v << 2)) & 0x09249249u; };
+    std::vector<uint64_t> key(n_tris);
+    for (int t = 0; t < n_tris; ++t) {
+        const int f = (int)(attr[t] >> 24);
+        // the world frame holds a 200 m plane next to centimetre parts: quantise on a cube root scale there would be overkill; the plane's
+        // two triangles simply form chunks of their own (huge radius, always visible)
+        uint32_t code = 0;
+        for (int k = 0; k < 3; ++k) {
+            const float ext = hi[f][k] - lo[f][k];
+            const uint32_t q = ext > 0.0f ? (uint32_t)std::min(1023.0f, (cen[(size_t)3 * t + k] - lo[f][k]) / ext * 1023.0f) : 0u;
+            code |= spread(q) << k;
+        }
+        key[t] = ((uint64_t)f << 32) | code;
+    }
+    std::vector<int> order(n_tris);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+    std::vector<int32_t> t2((size_t)n_tris * 3);
+    std::vector<uint32_t> a2(n_tris);
+    for (int i = 0; i < n_tris; ++i) {
+        for (int k = 0; k < 3; ++k) t2[(size_t)3 * i + k] = tris[(size_t)3 * order[i] + k];
+        a2[i] = attr[order[i]];
+    }
+    std::copy(t2.begin(), t2.end(), tris);
+    std::copy(a2.begin(), a2.end(), attr);
+    chunks.clear();
+    // a chunk ends after kChunk triangles, at a frame change, or when one more triangle would make its sphere much larger than the rest
+    // (keeps the ground plane and the table slabs from poisoning a chunk of small parts)
+    int start = 0;
+    while (start < n_tris) {
+        const int f = (int)(attr[start] >> 24);
+        float blo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, bhi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        int count = 0;
+        while (start + count < n_tris && count < kChunk && (int)(attr[start + count] >> 24) == f) {
+            float nlo[3], nhi[3];
+            for (int k = 0; k < 3; ++k) { nlo[k] = blo[k]; nhi[k] = bhi[k]; }
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k) {
+                    const float v = verts[3 * tris[(size_t)3 * (start + count) + j] + k];
+                    nlo[k] = std::min(nlo[k], v); nhi[k] = std::max(nhi[k], v);
+                }
+            const float dn = std::max({nhi[0] - nlo[0], nhi[1] - nlo[1], nhi[2] - nlo[2]}), d0 = std::max({bhi[0] - blo[0], bhi[1] - blo[1], bhi[2] - blo[2]});
+            if (count >= 8 && dn > 4.0f * d0 && dn > 0.02f) break;
+            for (int k = 0; k < 3; ++k) { blo[k] = nlo[k]; bhi[k] = nhi[k]; }
+            ++count;
+        }
+        SceneChunk ch{};
+        ch.cx = 0.5f * (blo[0] + bhi[0]); ch.cy = 0.5f * (blo[1] + bhi[1]); ch.cz = 0.5f * (blo[2] + bhi[2]);
+        float r2 = 0.0f;
+        for (int i = 0; i < count; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const float* v = verts + 3 * tris[(size_t)3 * (start + i) + j];
+                const float dx = v[0] - ch.cx, dy = v[1] - ch.cy, dz = v[2] - ch.cz;
+                r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+            }
+        ch.r = sqrtf(r2) * 1.0001f;
+        ch.start = start; ch.count = count; ch.frame = f;
+        chunks.push_back(ch);
+        start += count;
+    }
 }
 
 int scene_prepare() {

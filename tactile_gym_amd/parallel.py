@@ -189,6 +189,8 @@ class TorchShard:
 
     def _obs(self):
         obs = {"tactile": self.venv.tactile_torch()}
+        if getattr(self.venv, "_visual", False):
+            obs["visual"] = self.venv.visual_torch()
         if "feature" in self.venv.observation_mode and self.venv.feature_dim:
             obs["extended_feature"] = self.venv.feature_torch()
         return obs

@@ -418,7 +418,7 @@ class TactileVecEnv(_VecEnvBase):
 
     def profile_get(self):
         out = {}
-        for which, name in enumerate(("step", "render", "reset", "render_masked")):
+        for which, name in enumerate(("step", "render", "reset", "render_masked", "scene")):
             ms, cnt = C.c_double(), C.c_int64()
             capi.check(self._L.tg_profile_get(self._ctx, which, C.byref(ms), C.byref(cnt)))
             out[name] = (ms.value, cnt.value)

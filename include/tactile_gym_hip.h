@@ -223,6 +223,11 @@ int tg_get_packed_feature(tg_ctx* ctx, int64_t* feature_off, int32_t* dim);
 /* "extended_feature" observation (object_push_env.py:611-629): float32 [num_envs][*dim]: TCP pos, rpy and current goal
  * pos, rpy in the work frame; terminal != 0: the copy taken at the last step (rows valid where done). */
 int tg_get_obs_feature(tg_ctx* ctx, void** dev_ptr, int32_t* dim, int32_t terminal);
+/* observation_mode "oracle" (get_oracle_obs: edge_follow_env.py:454-476, base_surface_env.py:789-819, object_balance_env.py:528-563,
+ * object_push_env.py:571-609, object_roll_env.py:367-407): float32 [num_envs][*dim] computed on the device from the current state
+ * (dim 10 / 20 / 26 / 30 / 34 by env kind).  Enqueued on the context's stream; the pointer stays valid for the context's lifetime. */
+int tg_get_obs_oracle(tg_ctx* ctx, void** dev_ptr, int32_t* dim);
+int tg_copy_obs_oracle(tg_ctx* ctx, float* host_dst);          /* synchronises */
 /* Host copies (synchronise). */
 int tg_get_reward_done(tg_ctx* ctx, float* reward, uint8_t* done);
 int tg_copy_obs_tactile(tg_ctx* ctx, uint8_t* host_dst, int32_t terminal);

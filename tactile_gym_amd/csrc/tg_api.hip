@@ -376,6 +376,7 @@ struct tg_ctx {
     uint32_t* d_scene_attr = nullptr;
     tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
+    float* d_oracle = nullptr;        // [n][34] observation_mode "oracle" vectors (tg_get_obs_oracle), allocated on first use
     // hipGraph of one tg_step launch sequence, keyed by the device action pointer it was captured with (launch-bound inner loop:
     // 3-4 kernels per step, one graph launch instead)
     hipStream_t aux_stream = nullptr;                // object_balance: the reset of finished envs runs here, beside the render
@@ -565,6 +566,20 @@ __global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, flo
     out[i] = lo + (hi - lo) * u;
 }
 
+template <typename T, int TOPO> static void launch_oracle_obs_t(tg_ctx* c, int dim) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_oracle_obs<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, dim, c->d_oracle);
+}
+static int oracle_dim(const tg_ctx* c) {
+    switch (c->cfg.env_kind) {
+        case TG_ENV_EDGE_FOLLOW: return 10;
+        case TG_ENV_SURFACE_FOLLOW_AUTO: return 20;
+        case TG_ENV_OBJECT_BALANCE: return 26;
+        case TG_ENV_OBJECT_PUSH: return 30;
+        default: return 34;
+    }
+}
 template <typename T, int TOPO> static void launch_scene_xf_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;
     hipLaunchKernelGGL((k_scene_xf<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
@@ -842,7 +857,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_chunks, c->d_vis, c->d_vis_term};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1009,6 +1024,28 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     }
     enqueue_step(c, d_act);
     TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_get_obs_oracle(tg_ctx* c, void** p, int32_t* dim) {
+    if (!c || !p) return fail(-1, "NULL argument");
+    TG_ENTER(c);
+    const int d = oracle_dim(c);
+    if (!c->d_oracle) TG_HIP(hipMalloc(&c->d_oracle, (size_t)c->cfg.num_envs * 34 * sizeof(float)));
+#define CALL(T, TOPO) launch_oracle_obs_t<T, TOPO>(c, d)
+    TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    TG_HIP(hipGetLastError());
+    *p = c->d_oracle;
+    if (dim) *dim = d;
+    return 0;
+}
+int tg_copy_obs_oracle(tg_ctx* c, float* dst) {
+    if (!c || !dst) return fail(-1, "NULL argument");
+    void* p = nullptr; int32_t d = 0;
+    if (int rc = tg_get_obs_oracle(c, &p, &d)) return rc;
+    TG_HIP(hipMemcpyAsync(dst, p, (size_t)c->cfg.num_envs * d * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -265,7 +265,8 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
             tip_active = dist > T(0) && tip_depth <= sc.breaking;
             contact_code |= tip_active ? (1 << 8) : 0;
             const T idist = T(1) / (dist > T(0) ? dist : T(1));
-            const V3<T> gw = mul(Rw, idist * g);
+            V3<T> gw = mul(Rw, idist * g);
+            if (!(dist > T(0))) gw = mk<T>(0, 0, 1);   // centre inside the cylinder: no contact, but the disabled rows still need a finite frame
             nrm = mk<T>(0, 0, 0) - gw;
             pa = cw + mul(Rw, clp);
             pb = b.pos - radius * gw;

@@ -237,6 +237,101 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
     X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
 }
 
+// observation_mode "oracle" (get_oracle_obs of every env class) for the whole batch, float32 [n][dim], from the device state:
+//   edge_follow    10  TCP pos, TCP lin vel, goal pos (work frame), edge angle                        edge_follow_env.py:454-476
+//   surface_follow 20  TCP pos, orn, lin / ang vel, goal pos, surface z under the tip, surface normal  base_surface_env.py:789-819
+//   object_balance 26  TCP pos, orn, lin / ang vel; pole pos, orn, lin / ang vel                       object_balance_env.py:528-563
+//   object_push    30  TCP pos, rpy, lin / ang vel; cube pos, rpy, lin / ang vel; goal pos, rpy        object_push_env.py:571-609
+//   object_roll    34  TCP ...; marble pos, orn, lin / ang vel; goal pos, orn (TCP frame); radius      object_roll_env.py:367-407
+// Velocities are Jacobian x qd (getLinkState(computeLinkVelocity = 1)); poses go through the reference's quaternion / euler chain.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_oracle_obs(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st, int dim,
+                                                   float* __restrict__ out) {
+    constexpr int N = Topo<TOPO>::N;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int n = c.num_envs, env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n) return;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    T J[6][N];
+    tcp_jacobian<T, TOPO>(m, k, ptcp, J);
+    T tw[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int i = 0; i < N; ++i) tw[r] += J[r][i] * qd[i];
+    // object_roll: the work-frame origin follows the episode's marble radius and embed distance (update_workframe :192-201)
+    const T work_dz = c.env_kind == TG_ENV_OBJECT_ROLL ? (T)((2.0 * st.obj_mass[env] - st.embed[env]) - (double)c.work_pos[2]) : T(0);
+    V3<T> tp; T trpy[3], rpyw[3];
+    world_to_work(c, mk(ptcp.x, ptcp.y, ptcp.z - work_dz), Rtcp, tp, trpy, rpyw);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const V3<T> tl = mul(c.work_Rinv, mk(tw[0], tw[1], tw[2])), ta = mul(c.work_Rinv, mk(tw[3], tw[4], tw[5]));
+    float* o = out + (size_t)env * dim;
+    int w = 0;
+    auto put3 = [&](V3<T> v) { o[w++] = (float)v.x; o[w++] = (float)v.y; o[w++] = (float)v.z; };
+    auto putq = [&](Q4<T> v) { o[w++] = (float)v.x; o[w++] = (float)v.y; o[w++] = (float)v.z; o[w++] = (float)v.w; };
+    if (c.env_kind == TG_ENV_EDGE_FOLLOW) {
+        const T ang = (T)st.edge_ang[env];
+        T se, ce;
+        tsincos(ang, &se, &ce);
+        const V3<T> goal = mk(c.stim_pos[0] + c.edge_len * ce, c.stim_pos[1] + c.edge_len * se, c.stim_pos[2] + c.edge_height);
+        put3(tp); put3(tl); put3(load_v3(c.work_inv_pos) + mul(c.work_Rinv, goal));
+        o[w++] = (float)ang;
+        return;
+    }
+    if (c.env_kind == TG_ENV_OBJECT_PUSH) { put3(tp); put3(mk(trpy[0], trpy[1], trpy[2])); }
+    else { put3(tp); putq(tq); }
+    put3(tl); put3(ta);
+    if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        const int R = c.surf_rows, Cc = c.surf_cols;
+        int ti = digitize_linspace((double)ptcp.y, c.ybin_lo, c.ybin_hi, Cc);   // xy_to_surface_idx (:284-300)
+        int tj = digitize_linspace((double)ptcp.x, c.xbin_lo, c.xbin_hi, R);
+        if (ti == Cc) ti -= 1;
+        if (tj == R) tj -= 1;
+        const double* H = st.heights + (size_t)env * R * Cc;
+        const T gy_ = (T)grad_axis(H + tj, ti, R, Cc, c.surf_scale), gx_ = (T)grad_axis(H + (size_t)ti * Cc, tj, Cc, 1, c.surf_scale);
+        V3<T> nrm{-gx_, -gy_, T(1)};
+        nrm = (T(1) / norm(nrm)) * nrm;
+        T surf_z = (T)(H[(size_t)ti * Cc + tj] + (double)c.stim_pos[2]);
+        if (c.surf_vertical) {   // the flipped surface_array / normals (:486-516)
+            nrm = mul(c.stim_R, nrm);
+            surf_z = (T)((double)c.stim_pos[2] + (linspace_value(c.xbin_lo, c.xbin_hi, R, tj) - (double)c.stim_pos[0]));
+        }
+        put3(load_v3(c.work_inv_pos) + mul(c.work_Rinv, mk((T)st.goal[0 * n + env], (T)st.goal[1 * n + env], (T)st.goal[2 * n + env])));
+        o[w++] = (float)surf_z;
+        put3(mul(c.work_Rinv, nrm));
+        return;
+    }
+    // the free body (get_obj_pos_workframe / get_obj_vel_workframe, base_object_env.py:118-139)
+    M3<T> Rb;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rb.m[e] = (T)st.body_rot[e * n + env];
+    const V3<T> pb = mk((T)st.body_pos[0 * n + env], (T)st.body_pos[1 * n + env], (T)st.body_pos[2 * n + env] - work_dz);
+    V3<T> op; T orpy[3], orpyw[3];
+    world_to_work(c, pb, Rb, op, orpy, orpyw);
+    const V3<T> ol = mul(c.work_Rinv, mk((T)st.body_v[0 * n + env], (T)st.body_v[1 * n + env], (T)st.body_v[2 * n + env]));
+    const V3<T> oa = mul(c.work_Rinv, mk((T)st.body_w[0 * n + env], (T)st.body_w[1 * n + env], (T)st.body_w[2 * n + env]));
+    if (c.env_kind == TG_ENV_OBJECT_PUSH) {
+        put3(op); put3(mk(orpy[0], orpy[1], orpy[2])); put3(ol); put3(oa);
+        const int gid = st.goal_id[env], gi = gid < c.traj_n ? gid : c.traj_n - 1;
+        o[w++] = (float)st.traj[(0 * TG_MAX_TRAJ_POINTS + gi) * n + env]; o[w++] = (float)st.traj[(1 * TG_MAX_TRAJ_POINTS + gi) * n + env]; o[w++] = 0.0f;
+        o[w++] = 0.0f; o[w++] = 0.0f; o[w++] = (float)st.traj[(2 * TG_MAX_TRAJ_POINTS + gi) * n + env];
+        return;
+    }
+    put3(op); putq(quat_from_euler(orpy[0], orpy[1], orpy[2])); put3(ol); put3(oa);
+    if (c.env_kind == TG_ENV_OBJECT_ROLL) {
+        o[w++] = (float)st.goal[0 * n + env]; o[w++] = (float)st.goal[1 * n + env]; o[w++] = (float)st.goal[2 * n + env];
+        o[w++] = 0.0f; o[w++] = 0.0f; o[w++] = 0.0f; o[w++] = 1.0f;
+        o[w++] = (float)st.obj_mass[env];
+    }
+}
+
 // Scene camera (get_visual_obs, base_tactile_env.py:212-245): eye <- frame transforms of one env, rounded once to float:
 // frame 0 the world, 1 + i moving link i, N + 1 the task's stimulus / free body (the frame its tactile mesh is expressed in).
 struct SceneView { double R[9], t[3]; };   // world -> eye

@@ -1084,7 +1084,8 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             active = dist > T(0) && depth <= sc.breaking;
             contact_code |= active ? (1 << 8) : 0;
             const T idist = T(1) / (dist > T(0) ? dist : T(1));
-            const V3<T> gw = mul(Rw, idist * g);                      // from the cylinder towards the sphere
+            V3<T> gw = mul(Rw, idist * g);                            // from the cylinder towards the sphere
+            if (!(dist > T(0))) gw = mk<T>(0, 0, 1);                  // centre inside the cylinder: no contact (as the oracle), but the disabled rows below still need a finite frame
             nrm = mk<T>(0, 0, 0) - gw;                                // contact normal: from the sphere (body B) towards the tip (body A)
             pa = cw + mul(Rw, cl);
             pb = b.pos - radius * gw;

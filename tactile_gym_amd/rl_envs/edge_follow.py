@@ -112,7 +112,7 @@ class EdgeFollowVecEnv(TactileVecEnv):
                          scene_spec={"arm_type": modes["arm_type"], "camera":                     # setup_rgb_obs_camera_params, edge_follow_env.py:176-195
                                      (([-0.20, 0.0, -0.25], 0.85) if modes["arm_type"] == "mg400" else ([0.35, 0.0, -0.25], 0.75)) + (90.0, -35.0, 75.0, 0.1, 100.0)})
 
-    def oracle_obs(self):
+    def oracle_obs_host(self):
         """edge_follow_env.py:454-476: [tcp_pos_work(3), tcp_lin_vel_work(3), goal_pos_work(3), edge_ang], float32 [N,10].
         Computed on the host from the device state read-back (the tactile path does not need it)."""
         from .. import hip_ops

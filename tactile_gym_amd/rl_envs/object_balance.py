@@ -106,7 +106,7 @@ class ObjectBalanceVecEnv(TactileVecEnv):
                          act_dim=act_dim, oracle_dim=26,
                          scene_spec={"arm_type": modes["arm_type"], "camera": ([-0.1, 0.0, 0.25], 1.0, 90.0, -10.0, 75.0, 0.1, 100.0)})   # :162-171
 
-    def oracle_obs(self):
+    def oracle_obs_host(self):
         """object_balance_env.py:528-563: TCP pos, orn (quaternion), lin/ang velocity and the pole's pos, orn, lin/ang velocity, all in
         the work frame; float32 [N, 26]."""
         st = self.get_state()

@@ -169,7 +169,7 @@ class ObjectPushVecEnv(TactileVecEnv):
                          act_dim=act_dim, oracle_dim=30, feature_dim=12,
                          scene_spec={"arm_type": modes["arm_type"], "camera": ([0.1, 0.0, -0.35], 1.0, 90.0, -45.0, 75.0, 0.1, 100.0)})   # :170-179
 
-    def oracle_obs(self):
+    def oracle_obs_host(self):
         """object_push_env.py:571-609: TCP pos, rpy, lin/ang velocity, cube pos, rpy, lin/ang velocity and the current goal pos, rpy,
         all in the work frame; float32 [N, 30]."""
         st = self.get_state()

@@ -127,7 +127,7 @@ class ObjectRollVecEnv(TactileVecEnv):
         pos[:, 2] = 2.0 * st["obj_mass"] - st["embed_dist"]
         return pos
 
-    def oracle_obs(self):
+    def oracle_obs_host(self):
         """get_oracle_obs (:367-407): TCP pos, orn (quaternion), lin / ang velocity, marble pos, orn, lin / ang velocity (work frame of
         the episode), goal pos and orn in the TCP frame, marble radius; float32 [N, 34]."""
         st = self.get_state()

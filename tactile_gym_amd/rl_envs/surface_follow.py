@@ -119,7 +119,7 @@ class SurfaceFollowAutoVecEnv(TactileVecEnv):
         super().__init__(cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=act_dim, oracle_dim=20)
 
-    def oracle_obs(self):
+    def oracle_obs_host(self):
         """base_surface_env.py:789-819: TCP pos, orn (quaternion), lin/ang velocity, goal pos (all work frame), the surface height
         under the tip and the surface normal there (work frame); float32 [N, 20]."""
         cfg = self._cfg
@@ -190,7 +190,7 @@ class SurfaceFollowVertVecEnv(SurfaceFollowGoalVecEnv):
         TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                                act_dim=2, oracle_dim=20, feature_dim=6)                          # get_act_dim :102-113
 
-    def oracle_obs(self):
+    def oracle_obs_host(self):
         """base_surface_env.py:789-819 on the flipped surface_array / normals (:486-516)."""
         cfg = self._cfg
         st = self.get_state()

@@ -85,7 +85,7 @@ class TactileVecEnv(_VecEnvBase):
             self._set_scene(every_step=True)
         if "feature" in observation_mode:
             obs_spaces["extended_feature"] = spaces.Box(low=-np.inf, high=np.inf, shape=(feature_dim,), dtype=np.float32)
-        self.feature_dim = feature_dim
+        self.feature_dim, self._oracle_dim = feature_dim, oracle_dim
         self.observation_space = spaces.Dict(obs_spaces)
         if _VecEnvBase is not object:     # SB3's constructor records num_envs / spaces (and render_mode in recent versions)
             try:
@@ -350,6 +350,23 @@ class TactileVecEnv(_VecEnvBase):
         return buf
 
     def oracle_obs(self):
+        """get_oracle_obs for the whole batch, computed on the device from the current state (tg_get_obs_oracle): float32 [N, dim];
+        a zero-copy torch view in obs_mode "torch" (valid until the next call), an owned numpy array otherwise.  The env classes'
+        oracle_obs_host() is the same vector from a state read-back (kept as a cross-check)."""
+        if self.obs_mode == "torch":
+            if "oracle" not in self._views:
+                import torch
+                p, d = C.c_void_p(), C.c_int32()
+                capi.check(self._L.tg_get_obs_oracle(self._ctx, C.byref(p), C.byref(d)))
+                self._views["oracle"] = torch.as_tensor(_DevArray(p.value, (self.num_envs, d.value), "<f4"), device=f"cuda:{self._cfg.device}")
+            else:
+                capi.check(self._L.tg_get_obs_oracle(self._ctx, C.byref(C.c_void_p()), None))
+            return self._views["oracle"]
+        buf = np.empty((self.num_envs, self._oracle_dim), dtype=np.float32)
+        capi.check(self._L.tg_copy_obs_oracle(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_float))))
+        return buf
+
+    def oracle_obs_host(self):
         raise NotImplementedError
 
     def _workframe(self):

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
+#include <cstdlib>
 
 #include "tg_raster.h"
 
@@ -461,6 +462,154 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
 #undef TG_QX
 #undef TG_RY
 
+// Shared meshes of many small triangles (the 960-triangle marble): triangle-parallel.  A lane takes a triangle through the same
+// transform / back-face cull / near clip / projection as above and min-reduces its depths straight into an LDS z-buffer (ds_min_u32 on
+// the order-preserving integer image of the float) - the pixel-parallel kernels above test every pixel against every record, which for
+// ~500 front faces of ~20 pixels each is two orders of magnitude more work (marble render 1.19 ms -> see DESIGN.md).  A depth image is a
+// min over covering triangles, so the order of the atomics does not matter and the result is the one the oracle's sequential loop gives,
+// bit for bit.  Triangles whose box spans more than kScatterBig pixels of the tile are queued and filled by a whole wavefront each.
+constexpr int kScatterBig = 96, kScatterCap = 256;
+__device__ __forceinline__ unsigned depth_key(float d) { const unsigned b = __float_as_uint(d); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float key_depth(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__device__ __forceinline__ void scatter_pixel(const TriRec& r, int px, int py, unsigned* zb, int tile_x, int tile_y, int TW) {
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
+    const float e0 = (r.x1 - fx) * a0 - (r.x2 - fx) * a1;
+    const float e1 = (r.x2 - fx) * a2 - (r.x0 - fx) * a0;
+    const float e2 = (r.x0 - fx) * a1 - (r.x1 - fx) * a2;
+    const bool box = (fx >= r.xmin) & (fx <= r.xmax) & (fy >= r.ymin) & (fy <= r.ymax);
+    const bool pos = (e0 >= 0.0f) & (e1 >= 0.0f) & (e2 >= 0.0f), neg = (e0 <= 0.0f) & (e1 <= 0.0f) & (e2 <= 0.0f);
+    const float s = (e0 + e1) + e2;
+    if (!(box & (pos | neg) & (s != 0.0f))) return;
+    const float d = div_mid_range((e0 * r.d0 + e1 * r.d1) + e2 * r.d2, s);
+    if (d == d) atomicMin(&zb[(py - tile_y) * TW + (px - tile_x)], depth_key(d));   // `d < z` is false for a NaN
+}
+// pixel-centre range of a record inside the tile (centres fx with xmin <= fx <= xmax; a one-pixel margin, the predicate decides)
+__device__ __forceinline__ void scatter_box(const TriRec& r, int tile_x, int tile_y, int TW, int TH, int& x0, int& x1, int& y0, int& y1) {
+    const float lo_x = fminf(fmaxf(r.xmin, (float)tile_x - 1.0f), (float)(tile_x + TW) + 1.0f), hi_x = fminf(fmaxf(r.xmax, (float)tile_x - 1.0f), (float)(tile_x + TW) + 1.0f);
+    const float lo_y = fminf(fmaxf(r.ymin, (float)tile_y - 1.0f), (float)(tile_y + TH) + 1.0f), hi_y = fminf(fmaxf(r.ymax, (float)tile_y - 1.0f), (float)(tile_y + TH) + 1.0f);
+    x0 = max(tile_x, (int)floorf(lo_x - 0.5f)); x1 = min(tile_x + TW - 1, (int)ceilf(hi_x - 0.5f));
+    y0 = max(tile_y, (int)floorf(lo_y - 0.5f)); y1 = min(tile_y + TH - 1, (int)ceilf(hi_y - 0.5f));
+}
+
+template <int TW, int TH>
+__global__ __launch_bounds__(kThreads) void k_render_scatter(RasterParams P, Stimulus S, const float* __restrict__ xform, int xform_soa, int n_envs,
+                                                             const uint8_t* __restrict__ mask, const float* __restrict__ nodef_dep,
+                                                             const uint8_t* __restrict__ gray_u8, const uint8_t* __restrict__ border,
+                                                             uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev,
+                                                             const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
+                                                             uint8_t* __restrict__ term_out) {
+    __shared__ unsigned zb[TW * TH];
+    __shared__ TriRec big[kScatterCap];
+    __shared__ int big_n;
+    const int env = blockIdx.y;
+    if (mask != nullptr && mask[env] == 0) return;
+    const int pass = (term_xform != nullptr && blockIdx.z == 1) ? 0 : 1;
+    if (pass == 0 && term_mask[env] == 0) return;
+    const float* __restrict__ xf = pass == 0 ? term_xform : xform;
+    uint8_t* __restrict__ img = pass == 0 ? term_out : out;
+    const int tid = threadIdx.x;
+    const int tiles_x = P.W / TW;
+    const int tile_x = (blockIdx.x % tiles_x) * TW, tile_y = (blockIdx.x / tiles_x) * TH;
+    float M[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xf[(size_t)k * n_envs + env] : xf[(size_t)env * 12 + k];
+    for (int p = 4 * tid; p < TW * TH; p += 4 * kThreads) {
+        const float4 nd = *reinterpret_cast<const float4*>(nodef_dep + (size_t)(tile_y + p / TW) * P.W + tile_x + p % TW);
+        zb[p] = depth_key(nd.x); zb[p + 1] = depth_key(nd.y); zb[p + 2] = depth_key(nd.z); zb[p + 3] = depth_key(nd.w);
+    }
+    if (tid == 0) big_n = 0;
+    bool beyond = true;
+    if (S.closed_outward)
+        for (int t = tid; t < S.n_tris; t += kThreads) beyond = beyond && tri_beyond_near(S.soup, t, M, P.near_);
+    const bool cull = __syncthreads_and(beyond ? 1 : 0) != 0 && S.closed_outward != 0;   // (also the barrier after the z-buffer fill)
+    const float tx0 = (float)tile_x, ty0 = (float)tile_y, tx1 = (float)(tile_x + TW), ty1 = (float)(tile_y + TH);
+    for (int t = tid; t < S.n_tris; t += kThreads) {
+        float cx[3], cy[3], cw[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* v = S.soup + 9 * t + 3 * k;
+            cx[k] = ((M[0] * v[0] + M[1] * v[1]) + M[2] * v[2]) + M[9];
+            cy[k] = ((M[3] * v[0] + M[4] * v[1]) + M[5] * v[2]) + M[10];
+            cw[k] = -(((M[6] * v[0] + M[7] * v[1]) + M[8] * v[2]) + M[11]);
+        }
+        if (cull && back_facing(cx, cy, cw)) continue;
+        float ox[4], oy[4], ow[4];   // near-plane clip (Sutherland-Hodgman on w >= near), vertex order 0,1,2
+        int no = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int k1 = (k + 1) % 3;
+            const bool ain = cw[k] >= P.near_, bin = cw[k1] >= P.near_;
+            if (ain) { ox[no] = cx[k]; oy[no] = cy[k]; ow[no] = cw[k]; ++no; }
+            if (ain != bin) {
+                const float tt = (P.near_ - cw[k]) / (cw[k1] - cw[k]);
+                ox[no] = cx[k] + tt * (cx[k1] - cx[k]);
+                oy[no] = cy[k] + tt * (cy[k1] - cy[k]);
+                ow[no] = P.near_;
+                ++no;
+            }
+        }
+        for (int part = 0; part < 2; ++part) {
+            if (part == 0 ? no < 3 : no != 4) continue;
+            const int b = part == 0 ? 1 : 2, c = part == 0 ? 2 : 3;
+            TriRec r;
+            project_vertex(ox[0], oy[0], ow[0], P, r.x0, r.y0, r.d0);
+            project_vertex(ox[b], oy[b], ow[b], P, r.x1, r.y1, r.d1);
+            project_vertex(ox[c], oy[c], ow[c], P, r.x2, r.y2, r.d2);
+            r.xmin = fminf(r.x0, fminf(r.x1, r.x2)); r.xmax = fmaxf(r.x0, fmaxf(r.x1, r.x2));
+            r.ymin = fminf(r.y0, fminf(r.y1, r.y2)); r.ymax = fmaxf(r.y0, fmaxf(r.y1, r.y2));
+            r.dmin = fminf(r.d0, fminf(r.d1, r.d2)) - kDepthSlack;
+            if (r.xmax < tx0 || r.xmin > tx1 || r.ymax < ty0 || r.ymin > ty1) continue;   // the culls of emit()
+            if (r.dmin >= P.zcull) continue;
+            int x0, x1, y0, y1;
+            scatter_box(r, tile_x, tile_y, TW, TH, x0, x1, y0, y1);
+            if (x0 > x1 || y0 > y1) continue;
+            if ((x1 - x0 + 1) * (y1 - y0 + 1) > kScatterBig) {
+                const int slot = atomicAdd(&big_n, 1);
+                if (slot < kScatterCap) { big[slot] = r; continue; }
+            }
+            for (int py = y0; py <= y1; ++py)
+                for (int px = x0; px <= x1; ++px) scatter_pixel(r, px, py, zb, tile_x, tile_y, TW);
+        }
+    }
+    __syncthreads();
+    {
+        const int nb = min(big_n, kScatterCap), wave = tid >> 6, lane = tid & 63;
+        for (int i = wave; i < nb; i += kThreads / 64) {
+            const TriRec r = big[i];
+            int x0, x1, y0, y1;
+            scatter_box(r, tile_x, tile_y, TW, TH, x0, x1, y0, y1);
+            const int bw = x1 - x0 + 1, np = bw * (y1 - y0 + 1);
+            for (int p = lane; p < np; p += 64) scatter_pixel(r, x0 + p % bw, y0 + p / bw, zb, tile_x, tile_y, TW);
+        }
+    }
+    __syncthreads();
+    // t_s_camera (tactile_sensor.py:271-292), as in k_render_tactile: a pixel no triangle lowered holds nodef_dep bit for bit -> 0
+    const float eps = 1e-4f, max_pen = 0.05f;
+    uint8_t* dst = img + (size_t)env * P.W * P.H;
+    uint8_t* prev = (save_prev && pass == 1) ? save_prev + (size_t)env * P.W * P.H : nullptr;
+    for (int p = 4 * tid; p < TW * TH; p += 4 * kThreads) {
+        const size_t off = (size_t)(tile_y + p / TW) * P.W + tile_x + p % TW;
+        const float4 nd = *reinterpret_cast<const float4*>(nodef_dep + off);
+        const uchar4 ng = *reinterpret_cast<const uchar4*>(gray_u8 + off), bm = *reinterpret_cast<const uchar4*>(border + off);
+        const float ndv[4] = {nd.x, nd.y, nd.z, nd.w};
+        const uint8_t ngv[4] = {ng.x, ng.y, ng.z, ng.w}, bmv[4] = {bm.x, bm.y, bm.z, bm.w};
+        uint8_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float diff = key_depth(zb[p + q]) - ndv[q];
+            if (diff >= -eps && diff <= eps) diff = 0.0f;
+            const float pen = fabsf(diff);
+            const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
+            o[q] = (uint8_t)((cl / max_pen) * 255.0f);
+            if (!P.turn_off_border && bmv[q] == 1) o[q] = ngv[q];
+        }
+        if (prev) *reinterpret_cast<uchar4*>(prev + off) = *reinterpret_cast<const uchar4*>(dst + off);
+        *reinterpret_cast<uchar4*>(dst + off) = make_uchar4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // Small shared meshes (the 12-triangle edge): every triangle fits the record buffer in one round (rec_cap = 2 n_tris), so the pixel
 // phase can run in HALVES passes over disjoint row groups, each pass carrying only its own slice of the z-buffer from the reference
 // load to the store: 16 instead of 32 live depth registers, which lifts the kernel over the next occupancy step (VGPR budget).
@@ -675,6 +824,7 @@ void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xfo
         S.win_side = (side < full && side > 0) ? side : full;
     }
     int rec_cap = 2 * S.n_tris;
+    static const bool scatter_off = getenv("TG_NO_SCATTER_RASTER") != nullptr;   // A/B switch for the parity test
     rec_cap = rec_cap > kBatch ? kBatch : (rec_cap < 2 ? 2 : rec_cap);
     if (S.kind == 1 && rec_cap > 256) rec_cap = 256;   // a dozen heightfield triangles survive the depth cull; more just take another round
     const size_t wcap = S.kind == 1 ? (((size_t)S.win_side * S.win_side + 3) & ~(size_t)3) : 0;
@@ -696,12 +846,20 @@ void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xfo
                 dim3 g2((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
                 hipLaunchKernelGGL((k_render_tactile<128, 64, true>), g2, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
-            } else
+            } else if (!scatter_off)   // a shared mesh of many small triangles (the marble): triangle-parallel, LDS z-buffer
+                hipLaunchKernelGGL((k_render_scatter<128, 128>), grid, dim3(kThreads), 0, stream, P, S, xform, xform_soa, n_envs, mask,
+                                   nodef_dep, gray_u8, border, out, save_prev, term_xform, term_mask, term_out);
+            else
                 hipLaunchKernelGGL((k_render_tactile<128, 128, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
         }
     } else {  // 64x64 images
         dim3 grid((P.W / 64) * (P.H / 64), n_envs, term_xform ? 2 : 1);
+        if (S.kind == 0 && S.n_tris > 256 && !scatter_off) {
+            hipLaunchKernelGGL((k_render_scatter<64, 64>), grid, dim3(kThreads), 0, stream, P, S, xform, xform_soa, n_envs, mask,
+                               nodef_dep, gray_u8, border, out, save_prev, term_xform, term_mask, term_out);
+            return;
+        }
         hipLaunchKernelGGL((k_render_tactile<64, 64, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                            nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
     }

@@ -1395,3 +1395,37 @@ def test_backface_cull_leaves_images_bit_exact(stim):
         assert np.array_equal(got[i], ref), (stim, i, int((got[i] != ref).sum()))
         nonblank += int((ref[sensor.border_mask == 0] > 0).any())
     assert nonblank > n // 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,scale", [(64, 4.0), (256, 1.0), (256, 4.0), (128, 16.0)])
+def test_scatter_raster_marble_sizes_and_large_triangles(size, scale):
+    """k_render_scatter (triangle-parallel, LDS z-buffer of ds_min keys) on the 960-triangle marble at the other image sizes (64 x 64:
+    one 64 x 64 tile; 256 x 256: four 128 x 128 tiles) and blown up until its triangles take the queued whole-wavefront fill: bit-exact
+    against the oracle's sequential raster, poses through and in front of the near plane included."""
+    import os
+    from oracle import minibullet as mb
+    from tactile_gym_amd import hip_ops
+    from tactile_gym_amd.robot_model import ASSETS, MeshDesc, SensorDesc
+    z = np.load(os.path.join(ASSETS, "objects", "sphere.npz"))
+    verts, tris = z["verts"].astype(np.float32) * np.float32(scale), z["tris"].astype(np.int32)
+    sensor = SensorDesc("tactip", "standard", [size, size])
+    mesh = MeshDesc(verts, tris)
+    rng = np.random.default_rng(size + int(scale))
+    n = 96
+    xf = np.zeros((n, 12), np.float32)
+    for i in range(n):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        dist = rng.uniform(-0.01, 0.075) if i % 4 == 0 else rng.uniform(0.035, 0.07)
+        xf[i, :9], xf[i, 9:] = q.reshape(9), np.array([rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), -dist])
+    got = hip_ops.render_tactile(sensor, mesh, xf)
+    nonblank = 0
+    for i in range(n):
+        cur = sensor.nodef_dep.copy()
+        mb.render_depth(verts, tris, xf[i], sensor.cam["fov"], sensor.cam["near"], sensor.cam["far"], size, size, cur)
+        ref = mb.t_s_camera(cur, sensor.nodef_dep, sensor.nodef_gray, sensor.border_mask)
+        assert np.array_equal(got[i], ref), (size, scale, i, int((got[i] != ref).sum()))
+        nonblank += int((ref[sensor.border_mask == 0] > 0).any())
+    assert nonblank > n // 4

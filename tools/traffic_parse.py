@@ -1,0 +1,25 @@
+"""HBM-side bytes per launch of the tg:: kernels from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md, HBM
+section: separate passes, values in KB, FETCH_SIZE doubled on gfx950 for wide coalesced reads).  usage: traffic_parse.py <fetch dir> <write dir>"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def means(d, counter):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and "tg::" in r["Kernel_Name"]:
+                agg[r["Kernel_Name"].split("(")[0][:90]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    f, n = fetch.get(k, (0.0, 0))
+    w, _ = write.get(k, (0.0, 0))
+    out[k] = {"fetch_kb": round(f, 1), "fetch_corrected_kb": round(2 * f, 1), "write_kb": round(w, 1), "launches": n}
+print(json.dumps(out, indent=1))

@@ -230,7 +230,7 @@ def main():
         # the render kernel actually launched (csrc/tg_raster.hip: launch_render): small shared meshes (edge, pole, cube) take the
         # two-pass small-mesh kernel, the heightfield and the marble k_render_tactile<128,128>
         small = args.env in ("edge_follow-v0", "object_balance-v0", "object_push-v0") and args.image_size % 128 == 0
-        render_name = "k_render_small<128,64,2>" if small else "k_render_tactile"
+        render_name = "k_render_small<128,64,2>" if small else ("k_render_scatter" if args.env == "object_roll-v0" else "k_render_tactile")
         dominant = "k_step" if step_ms >= rend_ms else render_name
         dom_ms = k_step if dominant == "k_step" else k_render_main
         algo_bytes = {"edge_follow-v0": ALGO_BYTES_PER_ENV_STEP, "surface_follow-v0": ALGO_BYTES_SURFACE,
@@ -239,16 +239,17 @@ def main():
                       "object_roll-v0": args.image_size * args.image_size + 400.0, "surface_follow-v2": ALGO_BYTES_SURFACE}[args.env]
         achieved = algo_bytes * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure measured with
-        # rocprofv3 on this workload (profiles/r1_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) is reported when the
+        # rocprofv3 on this workload (profiles/r2_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) is reported when the
         # configuration matches, else null.
         traffic = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            wl = tr["workload"]
-            if (wl["env"], wl["num_envs"], wl["image_size"], wl["physics"]) == (args.env, n, args.image_size, args.physics) and not args.full_sweeps:
-                k = tr["k_step" if dominant == "k_step" else "k_render_tactile"]   # the traffic file predates the kernel split: same loads / stores
-                traffic = {"bytes_per_launch": round((k["fetch_corrected_kb"] + k["write_kb"]) * 1024.0), "source": "profiles/r1_traffic.json (rocprofv3 PMC)",
-                           "vs_algorithmic": round((k["fetch_corrected_kb"] + k["write_kb"]) / (algo_bytes * n / 1024.0), 3)}
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+            for wl in tr["workloads"]:
+                if (wl["env"], wl["num_envs"], wl["image_size"], wl["physics"]) == (args.env, n, args.image_size, args.physics) and not args.full_sweeps:
+                    k = wl["k_step" if dominant == "k_step" else "k_render_tactile"]
+                    traffic = {"bytes_per_launch": round((k["fetch_corrected_kb"] + k["write_kb"]) * 1024.0), "kernel": k["kernel"],
+                               "source": "profiles/r2_traffic.json (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE)",
+                               "vs_algorithmic": round((k["fetch_corrected_kb"] + k["write_kb"]) / (algo_bytes * n / 1024.0), 3)}
         except (OSError, KeyError, ValueError):
             traffic = None
         out = {

@@ -60,6 +60,15 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {   // v_readlan
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
     return u.d;
 }
+// the value held by the other friction lane of this lane's contact quad (lanes 4k+1 <-> 4k+2): v_mov_b32_dpp quad_perm:[0,2,1,3] x 2
+__device__ __forceinline__ double quad_swap12(double v) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], 0xD8, 0xF, 0xF, true);
+    u.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], 0xD8, 0xF, 0xF, true);
+    return u.d;
+}
+__device__ __forceinline__ float quad_swap12(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xD8, 0xF, 0xF, true)); }
 __device__ __forceinline__ float bcast(float v, int src_lane) {
     union { float f; int i; } u;
     u.f = v;
@@ -396,11 +405,12 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     //   lanes 32 + k     G[i] = -W_i[k]: the lane accumulates component k of the velocity change  du = sum_i W_i lambda_i  (k < 14)
     //   lanes 48 + j     G[i] = -[i == j]: the lane accumulates the impulse of joint motor j (checked against the motor limit)
     // so that ONE v_fma_f64 per row step, x -= G[i] delta, advances the residuals, the velocities and the motor impulses together.
-    // H[i] = 1 on the lane that owns contact row i (else 0): lambda += H[i] delta is the in-lane impulse update without masks.
+    // HN[c] = 1 on the three lanes of contact c: lamN += HN[c] delta keeps the normal impulse on its own lane AND on the contact's two friction
+    // lanes (their cone limit is then lane-local); HF[c] = 1 on the two friction lanes: lamF += HF[c] dl.  In-lane impulse updates without masks.
     const bool fric_lane = contact_lane && rr_ > 0;
     const T own_diag = fric_lane ? T(0) : T(1);
     const int my_gi = motor_lane ? lane : (contact_lane ? 8 + 3 * cc + rr_ : -1);   // this lane's own row index
-    T G[kNG], H[kNG - 8];
+    T G[kNG], HN[5], HF[5];
 #pragma unroll
     for (int i = 0; i < 8; ++i) G[i] = i < N ? Warm[i < N ? i : 0] * jdi : T(0);
 #pragma unroll
@@ -435,7 +445,6 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
             const T wv = L[kLW + i * 16 + (ku >= 0 && ku < kNU ? ku : 0)];
             const T g_row = lane == (i < 8 ? i : kContactLane0 + 4 * ((i - 8) / 3) + (i - 8) % 3) ? own_diag : G[i];
             G[i] = (ku >= 0 && ku < kNU) ? -wv : ((lane >= 48 && lane < 48 + N) ? (i == lane - 48 ? T(-1) : T(0)) : (lane < 32 ? g_row : T(0)));
-            if (i >= 8) H[i - 8] = i == my_gi ? T(1) : T(0);
         }
     }
     // ---- joint-motor sweep as ONE linear map (the sweeps run the motors without their clamp, see below).  A Gauss-Seidel pass over the
@@ -482,6 +491,12 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
             Cr[m] = c;
         }
     }
+#pragma unroll
+    for (int c5 = 0; c5 < 5; ++c5) {
+        const bool mine = contact_lane && cc == c5;
+        HN[c5] = mine ? T(1) : T(0);
+        HF[c5] = (mine && rr_ > 0) ? T(1) : T(0);
+    }
     const T x0 = lane < 32 ? rhs * jdi : T(0);
     int tip_i;                           // wave-uniform flag in an SGPR (s_cmp + s_cbranch_scc in the sweeps, no lane-mask round trip)
     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(tip_i) : "v"(tip_active ? 1 : 0));
@@ -501,14 +516,14 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     // Joint motors: the impulse limit max_force dt (1000 N m x 1/240 s) is ~1e4 times what these arms ever need, so the sweeps run without
     // the motor clamp while lanes 48.. watch every motor impulse of every sweep; a tick in which the limit would have been reached is
     // solved again with the clamped step (identical arithmetic otherwise).
-    T x = x0, lam = T(0);
+    T x = x0, lam = T(0), lamF = T(0);   // lam: impulse of a motor / normal row (on friction lanes: their contact's normal impulse); lamF: friction rows
     const T maximp = max_force * dt;
 #pragma unroll
     for (int i = 0; i < kNG; ++i) asm volatile("" : "+v"(G[i]));          // coefficient rows in architectural VGPRs for the sweeps (the allocator
 #pragma unroll
-    for (int i = 0; i < kNG - 8; ++i) asm volatile("" : "+v"(H[i]));      // otherwise parks some of them in AGPRs: two v_accvgpr_read per use)
-    T mu_table = sc.mu_table, mu_tip = sc.mu_tip;
-    asm volatile("" : "+v"(mu_table), "+v"(mu_tip));   // VGPR copies: a VALU instruction takes one scalar operand, and the impulse is one already
+    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(HN[i]), "+v"(HF[i]));   // otherwise parks some of them in AGPRs: two v_accvgpr_read per use)
+    T mu_lane = tip_lane ? sc.mu_tip : sc.mu_table;   // friction coefficient of this lane's contact (the cone limit is evaluated lane-locally)
+    asm volatile("" : "+v"(mu_lane));
     const int n_it = __builtin_amdgcn_readfirstlane(iters < 0 ? -iters : iters);   // contact problems do not reach their fixed point within 150 sweeps: no exit test
     const bool watch_lane = lane >= 48 && lane < 48 + N;
 
@@ -525,30 +540,32 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     {                                                                                  \
         const T dd_ = bcast(vmax_neg(x, lam), (ROW_LANE));                             \
         x = __builtin_fma(-G[(GI)], dd_, x);                                           \
-        lam = __builtin_fma(H[(GI) - 8], dd_, lam);                                    \
+        lam = __builtin_fma(HN[((GI) - 8) / 3], dd_, lam);                             \
     }
 #define TG_FRICTION_STEP(NLANE, GI, MU)                                                \
     {                                                                                  \
-        const T s1_ = bcast(x, (NLANE) + 1), s2_ = bcast(x, (NLANE) + 2);              \
-        const T limit_ = (MU) * bcast(lam, (NLANE));                                   \
+        /* lane-local on the contact's two friction lanes (every other lane computes something finite that is never used): the partner's */ \
+        /* s through a DPP quad permute, the normal impulse from the lane's own copy - no broadcast before the cone factor */ \
         T dl_;                                                                         \
+        const T limit_ = mu_lane * lam;                                                \
         if (CONE) {                                                                    \
-            const T tot2_ = __builtin_fma(s2_, s2_, s1_ * s1_);                        \
+            const T xp_ = quad_swap12(x);                                              \
+            const T tot2_ = __builtin_fma(xp_, xp_, x * x);                            \
             const T y_ = __builtin_amdgcn_rsq(tot2_);                                  \
-            const T t_ = tot2_ * y_, lh_ = (T(0.5) * limit_) * y_, ly_ = limit_ * y_;  \
+            const T t_ = tot2_ * y_, ly_ = limit_ * y_;                                \
+            const T lh_ = T(0.5) * ly_;                                                \
             const T e_ = __builtin_fma(-t_, y_, T(1));                                 \
             /* min(1, limit / |s|): one Newton step on the hardware seed (5e-8 -> 4e-15 relative, measured); |s| = 0 gives NaN, which */ \
             /* v_min_f64 drops in favour of the 1 */                                   \
             const T f_ = vmin(__builtin_fma(lh_, e_, ly_), T(1));                      \
-            dl_ = __builtin_fma(x, f_, -lam);                                          \
+            dl_ = __builtin_fma(x, f_, -lamF);                                         \
         } else {                                                                       \
-            dl_ = vmin(vmax(x, -limit_), limit_) - lam;                                \
+            dl_ = vmin(vmax(x, -limit_), limit_) - lamF;                               \
         }                                                                              \
+        lamF = __builtin_fma(HF[((GI) - 8) / 3], dl_, lamF);                           \
         const T d1_ = bcast(dl_, (NLANE) + 1), d2_ = bcast(dl_, (NLANE) + 2);          \
         x = __builtin_fma(-G[(GI)], d1_, x);                                           \
         x = __builtin_fma(-G[(GI) + 1], d2_, x);                                       \
-        lam = __builtin_fma(H[(GI) - 8], d1_, lam);                                    \
-        lam = __builtin_fma(H[(GI) - 7], d2_, lam);                                    \
     }
     // one sweep: motors in forward (FWD) or reverse order with the table normals between them, tip normal, friction pairs
 #define TG_SWEEP(FWD)                                                                  \
@@ -592,7 +609,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     }
     if (viol != 0) {                      // a motor impulse reached its limit somewhere in this tick: the literal clamped iteration
         constexpr int CLAMPED = 1;
-        x = x0; lam = T(0);
+        x = x0; lam = T(0); lamF = T(0);
         TG_SOLVE()
     }
 #undef TG_SOLVE

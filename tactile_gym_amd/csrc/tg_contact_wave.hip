@@ -95,9 +95,208 @@ constexpr int kLTipF = 138;                                                     
 constexpr int kLJa = 150, kLJo = 168;                                                         // joint axes / origins of the tip's ancestors, <= 6 x 3 each
 constexpr int kLFree = 186;                                                                   // vb 3, wb 3, xc 3 of the tick
 constexpr int kLW = 196;                                                                      // W rows, 23 x 16
-constexpr int kLHull = kLW + kNG * 16;                                                        // tip-core hull vertices, 3 per vertex
+constexpr int kCW = 120;                                                                     // per-link constants (below), padded
+constexpr int kLC = kLW + kNG * 16;                                                           // link constant table, 8 x kCW
+constexpr int kLS = kLC + 8 * kCW;                                                            // link slots for the inertia matrix: a, o, F, N (12) x 8
+constexpr int kLHull = kLS + 8 * 12;                                                          // tip-core hull vertices, 3 per vertex
 
 #define TG_PHASE_FENCE() { __syncthreads(); asm volatile("" ::: "memory"); }
+
+// ---- lane-parallel arm dynamics ---------------------------------------------------------------------------------------------------
+// value of `v` held by lane `src` (per-lane source): ds_bpermute_b32 x 2
+__device__ __forceinline__ double lane_fetch(double v, int src) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_ds_bpermute(src << 2, u.i[0]);
+    u.i[1] = __builtin_amdgcn_ds_bpermute(src << 2, u.i[1]);
+    return u.d;
+}
+__device__ __forceinline__ float lane_fetch(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v))); }
+
+// Per-link constants in LDS (row = link), copied from the DevRobot once per step: what link i contributes to the arm's kinematics, inertia
+// and velocity damping.  Offsets within a row:
+constexpr int kCfkA = 0, kCfkB = 9, kCfkC = 18, kCjpos = 27, kCaxis = 30, kClcom = 33, kClinert = 36, kClmass = 42, kClang = 43, kCbmass = 49, kCbcom = 53;   // .. 65
+template <typename T, int TOPO>
+__device__ __forceinline__ void stage_link_constants(const DevRobot<T>* __restrict__ mp, lds_ptr<T> L, int lane) {
+    constexpr int N = Topo<TOPO>::N;
+    const int li = lane & 7;
+    if (lane < 8 && li < N) {
+        const DevRobot<T>& m = *mp;
+        const lds_ptr<T> C = L + kLC + li * kCW;
+        for (int e = 0; e < 9; ++e) { C[kCfkA + e] = m.fkA[li][e]; C[kCfkB + e] = m.fkB[li][e]; C[kCfkC + e] = m.fkC[li][e]; }
+        for (int e = 0; e < 3; ++e) { C[kCjpos + e] = m.jpos[li][e]; C[kCaxis + e] = m.jaxis[li][e]; C[kClcom + e] = m.lcom[li][e]; }
+        for (int e = 0; e < 6; ++e) { C[kClinert + e] = m.linert[li][e]; C[kClang + e] = m.lang[li][e]; }
+        C[kClmass] = m.lmass[li];
+        for (int b = 0; b < kMaxBodiesPerLink; ++b) {
+            C[kCbmass + b] = m.bmass[li][b] > T(0) ? m.bmass[li][b] : T(0);
+            for (int e = 0; e < 3; ++e) C[kCbcom + 3 * b + e] = m.bcom[li][b][e];
+        }
+    }
+}
+
+// Phase 1 of a tick, spread over the lanes (the wave-uniform version below evaluates one scalar program on 64 lanes and streams ~400
+// robot constants through scalar loads and spilled SGPRs every tick: 44 k of a tick's 200 k cycles).  Lane l works on link l & 7 (eight
+// replicas, so that lane (r, c) = (l >> 3, l & 7) of the 8 x 8 inertia matrix already holds link c):
+//   kinematics     each lane takes its parent's frame and velocity from the parent's lane (ds_bpermute) and composes its own; after d rounds
+//                  every link of depth <= d is final (tree depth: UR5 5, MG400 4);
+//   composites     link i's composite inertia / first moment / damping wrench about its joint origin = sum over its descendants j of link j's
+//                  own terms shifted by o_j - o_i (the same parallel-axis terms the leaf-to-root recursion applies, summed directly):
+//                  N broadcast rounds, no dependency between them;
+//   M              lane (r, c): a_i . (N_j + (o_j - o_i) x F_j), i = min, j = max (0 unless i is an ancestor of j), link r's terms from LDS;
+//   Minv           Gauss-Jordan in place over the 64 lanes (SPD: no pivoting), row / column of the pivot through ds_bpermute;
+//   v              qd + dt Minv (qdamp - joint_damp qd): lane products, xor-reduction over the 8 lanes of a row.
+// Same outputs in LDS as the wave-uniform version (Minv, v, tip link frame, joint axes / origins on the tip's path).
+template <typename T, int TOPO>
+__device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restrict__ mp, lds_ptr<T> L, int tip_link, T dt, int lane) {
+    constexpr int N = Topo<TOPO>::N;
+    constexpr int NP = Topo<TOPO>::NP;
+    const int lc = lane & 7, lr = lane >> 3;
+    const int li = lc < N ? lc : N - 1;                      // this lane's link (columns >= N of the UR5 repeat the last link, unused)
+    int par = 0, depth = 0;
+    unsigned desc = 0;                                        // bit j: link j is li or one of its descendants
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        int d = 0;
+        for (int a = i; Topo<TOPO>::parent(a) >= 0; a = Topo<TOPO>::parent(a)) ++d;
+        unsigned ds = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) ds |= is_ancestor_or_self<TOPO>(i, j) ? (1u << j) : 0u;
+        if (li == i) { par = Topo<TOPO>::parent(i) < 0 ? i : Topo<TOPO>::parent(i); depth = d; desc = ds; }
+    }
+    constexpr int max_depth = TOPO == 0 ? 5 : 4;
+    const bool is_root = depth == 0;
+    const lds_ptr<T> C = L + kLC + li * kCW;
+    const T qdi = L[kLQd + li], sq = L[kLTrigS + li], cq = L[kLTrigC + li];
+    M3<T> Rl;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rl.m[e] = C[kCfkA + e] + cq * C[kCfkB + e] + sq * C[kCfkC + e];
+    const V3<T> jpos = mk(C[kCjpos], C[kCjpos + 1], C[kCjpos + 2]), axis = mk(C[kCaxis], C[kCaxis + 1], C[kCaxis + 2]);
+    // ---- kinematics and velocities, root -> leaf
+    M3<T> R = Rl;
+    V3<T> o = jpos, a = mul(R, axis), w = qdi * a, vo = mk<T>(0, 0, 0);
+    const int psrc = (lane & ~7) | par;                       // the parent's lane within this replica
+#pragma unroll
+    for (int d = 0; d < max_depth; ++d) {
+        M3<T> Rp;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Rp.m[e] = lane_fetch(R.m[e], psrc);
+        const V3<T> op = mk(lane_fetch(o.x, psrc), lane_fetch(o.y, psrc), lane_fetch(o.z, psrc));
+        const V3<T> wp = mk(lane_fetch(w.x, psrc), lane_fetch(w.y, psrc), lane_fetch(w.z, psrc));
+        const V3<T> vp = mk(lane_fetch(vo.x, psrc), lane_fetch(vo.y, psrc), lane_fetch(vo.z, psrc));
+        const M3<T> Rn = mul(Rp, Rl);
+        const V3<T> on = op + mul(Rp, jpos);
+        const V3<T> an = mul(Rn, axis);
+        const V3<T> wn = wp + qdi * an;
+        const V3<T> vn = vp + cross(wp, on - op);
+        if (!is_root) { R = Rn; o = on; a = an; w = wn; vo = vn; }
+    }
+    // ---- this link's own inertia terms about its joint origin, damping wrench (per-body linear part, merged angular part)
+    const T lmass = C[kClmass];
+    const V3<T> rc = mul(R, mk(C[kClcom], C[kClcom + 1], C[kClcom + 2]));
+    const S3<T> Il{C[kClinert], C[kClinert + 1], C[kClinert + 2], C[kClinert + 3], C[kClinert + 4], C[kClinert + 5]};
+    const S3<T> Io_own = rotate(R, Il) + point_inertia(lmass, rc);
+    const V3<T> hc_own = lmass * rc;
+    const DevRobot<T>& m = *mp;
+    const T ang_damp = m.ang_damp, lin_damp = m.lin_damp, joint_damp = m.joint_damp;
+    const T sw = ang_damp + ang_damp * tsqrt_fast(dot(w, w));
+    const S3<T> Ia{C[kClang], C[kClang + 1], C[kClang + 2], C[kClang + 3], C[kClang + 4], C[kClang + 5]};
+    V3<T> dF = mk<T>(0, 0, 0);
+    V3<T> dN = (-sw) * mul(R, mul(Ia, mulT(R, w)));
+#pragma unroll
+    for (int b = 0; b < kMaxBodiesPerLink; ++b) {             // a slot without a body has mass 0: its terms vanish
+        const T bm = C[kCbmass + b];
+        const V3<T> rb = mul(R, mk(C[kCbcom + 3 * b], C[kCbcom + 3 * b + 1], C[kCbcom + 3 * b + 2]));
+        const V3<T> vb = vo + cross(w, rb);
+        const T sv = lin_damp + lin_damp * tsqrt_fast(dot(vb, vb));
+        const V3<T> Fb = (-bm * sv) * vb;
+        dF = dF + Fb;
+        dN = dN + cross(rb, Fb);
+    }
+    // ---- composites: sum over the descendants (link j's own terms broadcast from lane j of replica 0, shifted to this link's origin)
+    S3<T> Io{T(0), T(0), T(0), T(0), T(0), T(0)};
+    V3<T> hc = mk<T>(0, 0, 0), DN = mk<T>(0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const T keep = ((desc >> j) & 1u) ? T(1) : T(0);
+        const V3<T> oj = mk(bcast(o.x, j), bcast(o.y, j), bcast(o.z, j));
+        const V3<T> r = oj - o;
+        const T mj = bcast(lmass, j);
+        const V3<T> hj = mk(bcast(hc_own.x, j), bcast(hc_own.y, j), bcast(hc_own.z, j));
+        const S3<T> Ij{bcast(Io_own.xx, j), bcast(Io_own.xy, j), bcast(Io_own.xz, j), bcast(Io_own.yy, j), bcast(Io_own.yz, j), bcast(Io_own.zz, j)};
+        const V3<T> Fj = mk(bcast(dF.x, j), bcast(dF.y, j), bcast(dF.z, j)), Nj = mk(bcast(dN.x, j), bcast(dN.y, j), bcast(dN.z, j));
+        const S3<T> It = Ij + point_inertia(mj, r) + cross_inertia(hj, r);
+        Io.xx = __builtin_fma(keep, It.xx, Io.xx); Io.xy = __builtin_fma(keep, It.xy, Io.xy); Io.xz = __builtin_fma(keep, It.xz, Io.xz);
+        Io.yy = __builtin_fma(keep, It.yy, Io.yy); Io.yz = __builtin_fma(keep, It.yz, Io.yz); Io.zz = __builtin_fma(keep, It.zz, Io.zz);
+        const V3<T> ht = hj + mj * r, Nt = Nj + cross(r, Fj);
+        hc = hc + keep * ht;
+        DN = DN + keep * Nt;
+    }
+    const T qdamp = dot(a, DN);
+    // ---- joint-space inertia: lane (lr, lc)
+    const V3<T> F = cross(a, hc), Nv = mul(Io, a);
+    if (lane < 8) {                                           // replica 0 publishes its links
+        const lds_ptr<T> S = L + kLS + lc * 12;
+        S[0] = a.x; S[1] = a.y; S[2] = a.z; S[3] = o.x; S[4] = o.y; S[5] = o.z;
+        S[6] = F.x; S[7] = F.y; S[8] = F.z; S[9] = Nv.x; S[10] = Nv.y; S[11] = Nv.z;
+    }
+    __syncthreads();
+    T A;
+    {
+        const int rr = lr < N ? lr : N - 1;
+        const lds_ptr<T> S = L + kLS + rr * 12;
+        const V3<T> ar = mk(S[0], S[1], S[2]), orr = mk(S[3], S[4], S[5]), Fr = mk(S[6], S[7], S[8]), Nr = mk(S[9], S[10], S[11]);
+        const bool c_is_j = lc >= lr;                         // j = max(r, c), i = min(r, c)
+        const V3<T> ai = c_is_j ? ar : a, oi = c_is_j ? orr : o;
+        const V3<T> oj = c_is_j ? o : orr, Fj = c_is_j ? F : Fr, Nj = c_is_j ? Nv : Nr;
+        const int i_ = c_is_j ? lr : lc, j_ = c_is_j ? lc : lr;
+        bool anc = false;
+#pragma unroll
+        for (int ii = 0; ii < N; ++ii)
+#pragma unroll
+            for (int jj = ii; jj < N; ++jj)
+                if (is_ancestor_or_self<TOPO>(ii, jj)) anc = anc || (i_ == ii && j_ == jj);
+        const T val = dot(ai, Nj + cross(oj - oi, Fj));
+        A = (lr < N && lc < N) ? (anc ? val : T(0)) : (lr == lc ? T(1) : T(0));      // identity padding beyond N
+    }
+    // ---- in-place Gauss-Jordan inverse of the symmetric positive definite M
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const T pk = bcast(A, 9 * k);
+        const T ark = lane_fetch(A, (lane & ~7) + k), akc = lane_fetch(A, 8 * k + lc);
+        const T inv = T(1) / pk;
+        const T t = akc * inv;
+        const T An = __builtin_fma(-ark, t, A);
+        A = lr == k ? (lc == k ? inv : t) : (lc == k ? -ark * inv : An);
+    }
+    // ---- outputs
+    L[kLMinv + 8 * lr + lc] = A;
+    {
+        T prod = A * (qdamp - joint_damp * qdi);              // column lc: this lane's own link
+        if (lc >= N) prod = T(0);
+        prod += lane_fetch(prod, lane ^ 1);
+        prod += lane_fetch(prod, lane ^ 2);
+        prod += lane_fetch(prod, lane ^ 4);
+        if (lc == 0 && lr < N) L[kLV + lr] = L[kLQd + lr] + dt * prod;
+    }
+    if (lane < 8) {
+        if (lc == tip_link) {
+            L[kLTipF + 0] = o.x; L[kLTipF + 1] = o.y; L[kLTipF + 2] = o.z;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) L[kLTipF + 3 + e] = R.m[e];
+        }
+        if (lc < NP) {
+            bool on_path = false;                             // joints off the tip's path get a zero axis: their Jacobian column vanishes
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int l = 0; l < N; ++l)
+                    if (is_ancestor_or_self<TOPO>(i, l)) on_path = on_path || (lc == i && l == tip_link);
+            const T keep = on_path ? T(1) : T(0);
+            L[kLJa + 3 * lc] = keep * a.x; L[kLJa + 3 * lc + 1] = keep * a.y; L[kLJa + 3 * lc + 2] = keep * a.z;
+            L[kLJo + 3 * lc] = o.x; L[kLJo + 3 * lc + 1] = o.y; L[kLJo + 3 * lc + 2] = o.z;
+        }
+    }
+}
 
 // Phase 1 of a tick: articulated-body dynamics of the arm (wave-uniform: every lane evaluates the same thing, lane 0 writes).  In: q, qd,
 // carried sines / cosines (LDS).  Out (LDS): Minv, the unconstrained arm velocity v, the frame of the link that carries the tip and the
@@ -183,7 +382,11 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
 #endif
     const V3<T> gravity = load_v3(m.gravity);
     // =============================================================== phase 1: articulated-body dynamics (wave-uniform)
-    tick_dynamics<T, TOPO>(&m, L, sc.tip_link, dt, lane);   // (the laundered lane)
+#ifdef TG_WAVE_SCALAR_DYNAMICS
+    tick_dynamics<T, TOPO>(&m, L, sc.tip_link, dt, lane);
+#else
+    tick_dynamics_lanes<T, TOPO>(&m, L, sc.tip_link, dt, lane);
+#endif
     TG_PHASE_FENCE()
     TG_STAMP(0)
     // =============================================================== phase 2: free body, contact generation
@@ -678,6 +881,7 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
         const int nw = 3 * c.push.n_tip;
         for (int w = lane; w < nw; w += 64) L[kLHull + w] = tipv[w];
     }
+    stage_link_constants<T, TOPO>(mp, L, lane);
     V3<T> tpos; Q4<T> tq;                // TCP_position_control: the pose target of the blocking move
     {   // ---- controller (once per step): action -> joint targets, state -> LDS
         T q[N], qd[N];

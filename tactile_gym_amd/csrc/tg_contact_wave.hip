@@ -113,6 +113,23 @@ __device__ __forceinline__ double lane_fetch(double v, int src) {
 }
 __device__ __forceinline__ float lane_fetch(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v))); }
 
+// v_mov_b32_dpp x 2 with a compile-time control word (row_shr:n = 0x110 + n within rows of 16 lanes, quad_perm, row_half_mirror = 0x141):
+// the lane-to-lane moves of the dynamics that a ds_bpermute (~55 cycles each, measured) would otherwise make
+template <int CTRL> __device__ __forceinline__ double dpp_move(double v) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], CTRL, 0xF, 0xF, true);
+    u.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], CTRL, 0xF, 0xF, true);
+    return u.d;
+}
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); }
+// the parent link's copy of v: every parent is the lane below (DFS numbering) except MG400's link 5, whose parent is link 0
+template <int TOPO, typename T> __device__ __forceinline__ T parent_fetch(T v, bool far_parent) {
+    const T near = dpp_move<0x111>(v);
+    if constexpr (TOPO == 1) { const T far = dpp_move<0x115>(v); return far_parent ? far : near; }
+    return near;
+}
+
 // Per-link constants in LDS (row = link), copied from the DevRobot once per step: what link i contributes to the arm's kinematics, inertia
 // and velocity damping.  Offsets within a row:
 constexpr int kCfkA = 0, kCfkB = 9, kCfkC = 18, kCjpos = 27, kCaxis = 30, kClcom = 33, kClinert = 36, kClmass = 42, kClang = 43, kCbmass = 49, kCbcom = 53;   // .. 65
@@ -147,7 +164,11 @@ __device__ __forceinline__ void stage_link_constants(const DevRobot<T>* __restri
 //   v              qd + dt Minv (qdamp - joint_damp qd): lane products, xor-reduction over the 8 lanes of a row.
 // Same outputs in LDS as the wave-uniform version (Minv, v, tip link frame, joint axes / origins on the tip's path).
 template <typename T, int TOPO>
-__device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restrict__ mp, lds_ptr<T> L, int tip_link, T dt, int lane) {
+__device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restrict__ mp, lds_ptr<T> L, int tip_link, T dt, int lane
+#if TG_WAVE_TIMING
+                                                    , unsigned long long& t_prev_
+#endif
+                                                    ) {
     constexpr int N = Topo<TOPO>::N;
     constexpr int NP = Topo<TOPO>::NP;
     const int lc = lane & 7, lr = lane >> 3;
@@ -174,15 +195,16 @@ __device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restric
     // ---- kinematics and velocities, root -> leaf
     M3<T> R = Rl;
     V3<T> o = jpos, a = mul(R, axis), w = qdi * a, vo = mk<T>(0, 0, 0);
-    const int psrc = (lane & ~7) | par;                       // the parent's lane within this replica
+    const bool far_parent = TOPO == 1 && li == 5;             // (Topo<1>::parent(5) == 0; every other parent is li - 1)
+    static_assert(TOPO == 0 || (Topo<TOPO>::parent(5) == 0 && Topo<TOPO>::parent(6) == 5 && Topo<TOPO>::parent(4) == 3), "parent_fetch: MG400 numbering");
 #pragma unroll
     for (int d = 0; d < max_depth; ++d) {
         M3<T> Rp;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) Rp.m[e] = lane_fetch(R.m[e], psrc);
-        const V3<T> op = mk(lane_fetch(o.x, psrc), lane_fetch(o.y, psrc), lane_fetch(o.z, psrc));
-        const V3<T> wp = mk(lane_fetch(w.x, psrc), lane_fetch(w.y, psrc), lane_fetch(w.z, psrc));
-        const V3<T> vp = mk(lane_fetch(vo.x, psrc), lane_fetch(vo.y, psrc), lane_fetch(vo.z, psrc));
+        for (int e = 0; e < 9; ++e) Rp.m[e] = parent_fetch<TOPO>(R.m[e], far_parent);
+        const V3<T> op = mk(parent_fetch<TOPO>(o.x, far_parent), parent_fetch<TOPO>(o.y, far_parent), parent_fetch<TOPO>(o.z, far_parent));
+        const V3<T> wp = mk(parent_fetch<TOPO>(w.x, far_parent), parent_fetch<TOPO>(w.y, far_parent), parent_fetch<TOPO>(w.z, far_parent));
+        const V3<T> vp = mk(parent_fetch<TOPO>(vo.x, far_parent), parent_fetch<TOPO>(vo.y, far_parent), parent_fetch<TOPO>(vo.z, far_parent));
         const M3<T> Rn = mul(Rp, Rl);
         const V3<T> on = op + mul(Rp, jpos);
         const V3<T> an = mul(Rn, axis);
@@ -190,6 +212,7 @@ __device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restric
         const V3<T> vn = vp + cross(wp, on - op);
         if (!is_root) { R = Rn; o = on; a = an; w = wn; vo = vn; }
     }
+    TG_STAMP(7)
     // ---- this link's own inertia terms about its joint origin, damping wrench (per-body linear part, merged angular part)
     const T lmass = C[kClmass];
     const V3<T> rc = mul(R, mk(C[kClcom], C[kClcom + 1], C[kClcom + 2]));
@@ -212,6 +235,7 @@ __device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restric
         dF = dF + Fb;
         dN = dN + cross(rb, Fb);
     }
+    TG_STAMP(8)
     // ---- composites: sum over the descendants (link j's own terms broadcast from lane j of replica 0, shifted to this link's origin)
     S3<T> Io{T(0), T(0), T(0), T(0), T(0), T(0)};
     V3<T> hc = mk<T>(0, 0, 0), DN = mk<T>(0, 0, 0);
@@ -232,6 +256,7 @@ __device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restric
         DN = DN + keep * Nt;
     }
     const T qdamp = dot(a, DN);
+    TG_STAMP(9)
     // ---- joint-space inertia: lane (lr, lc)
     const V3<T> F = cross(a, hc), Nv = mul(Io, a);
     if (lane < 8) {                                           // replica 0 publishes its links
@@ -258,6 +283,7 @@ __device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restric
         const T val = dot(ai, Nj + cross(oj - oi, Fj));
         A = (lr < N && lc < N) ? (anc ? val : T(0)) : (lr == lc ? T(1) : T(0));      // identity padding beyond N
     }
+    TG_STAMP(10)
     // ---- in-place Gauss-Jordan inverse of the symmetric positive definite M
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -268,14 +294,15 @@ __device__ __forceinline__ void tick_dynamics_lanes(const DevRobot<T>* __restric
         const T An = __builtin_fma(-ark, t, A);
         A = lr == k ? (lc == k ? inv : t) : (lc == k ? -ark * inv : An);
     }
+    TG_STAMP(11)
     // ---- outputs
     L[kLMinv + 8 * lr + lc] = A;
     {
         T prod = A * (qdamp - joint_damp * qdi);              // column lc: this lane's own link
         if (lc >= N) prod = T(0);
-        prod += lane_fetch(prod, lane ^ 1);
-        prod += lane_fetch(prod, lane ^ 2);
-        prod += lane_fetch(prod, lane ^ 4);
+        prod += dpp_move<0xB1>(prod);                         // quad_perm [1,0,3,2]
+        prod += dpp_move<0x4E>(prod);                         // quad_perm [2,3,0,1]
+        prod += dpp_move<0x141>(prod);                        // row_half_mirror: lane i <-> 7 - i of each 8-lane row group
         if (lc == 0 && lr < N) L[kLV + lr] = L[kLQd + lr] + dt * prod;
     }
     if (lane < 8) {
@@ -385,7 +412,11 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
 #ifdef TG_WAVE_SCALAR_DYNAMICS
     tick_dynamics<T, TOPO>(&m, L, sc.tip_link, dt, lane);
 #else
+#if TG_WAVE_TIMING
+    tick_dynamics_lanes<T, TOPO>(&m, L, sc.tip_link, dt, lane, t_prev_);
+#else
     tick_dynamics_lanes<T, TOPO>(&m, L, sc.tip_link, dt, lane);
+#endif
 #endif
     TG_PHASE_FENCE()
     TG_STAMP(0)
@@ -1002,8 +1033,8 @@ int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int 
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h);
             fprintf(stderr, "[wave timing] ticks per phase over %d steps:", calls - 1);
-            const char* names[7] = {"dynamics", "body+table", "tip", "row", "G", "sweeps", "integrate"};
-            for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f", names[k], (double)h[k] / ((calls - 1) * 24.0));
+            const char* names[12] = {"dynamics(tail)", "body+table", "tip", "row", "G", "sweeps", "integrate", "dyn:kinematics", "dyn:own", "dyn:composites", "dyn:M", "dyn:inverse"};
+            for (int k = 0; k < 12; ++k) fprintf(stderr, " %s %.0f", names[k], (double)h[k] / ((calls - 1) * 24.0));
             fprintf(stderr, " (per tick)\n");
         }
     }

@@ -82,6 +82,8 @@ __device__ __forceinline__ double vmax_neg(double a, double b) { double r; asm("
 __device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float vmax_neg(float a, float b) { return __builtin_fmaxf(a, -b); }
+__device__ __forceinline__ double vmax_abs(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }   // max(a, |b|)
+__device__ __forceinline__ float vmax_abs(float a, float b) { return __builtin_fmaxf(a, __builtin_fabsf(b)); }
 __device__ __forceinline__ bool uniform_true(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; }   // scalar branch on a wave-uniform flag (v_cmp -> s_cmp)
 
 // One stepSimulation() tick; all arguments wave-uniform, `lane` = threadIdx.x.  scr: 23 * 16 words of LDS private to the wavefront.
@@ -825,7 +827,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         } else {                                                                       \
             _Pragma("unroll") for (int k_ = 0; k_ < (SHAPE == 1 ? 1 : 4); ++k_) TG_NORMAL_STEP(kContactLane0 + 4 * k_, 8 + 3 * k_) \
         }                                                                              \
-        if (CLAMPED == 0) viol |= __builtin_amdgcn_ballot_w64(watch_lane && tabs(x) > maximp); \
+        if (CLAMPED == 0) wmax = vmax_abs(wmax, x);   /* lanes 48..: the largest motor impulse any sweep has seen */ \
         if (tip_i) TG_NORMAL_STEP(kContactLane0 + 16, 8 + 12)                          \
         _Pragma("unroll") for (int k_ = 0; k_ < (SHAPE == 1 ? 1 : 4); ++k_) TG_FRICTION_STEP(kContactLane0 + 4 * k_, 8 + 3 * k_ + 1, mu_table) \
         if (tip_i) TG_FRICTION_STEP(kContactLane0 + 16, 8 + 13, mu_tip)                \
@@ -836,11 +838,12 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         for (; it_ + 1 < n_it; it_ += 2) { TG_SWEEP(false) TG_SWEEP(true) } \
         if (it_ < n_it) TG_SWEEP(false)                                                \
     }
-    uint64_t viol = 0;
+    T wmax = T(0);
     {
         constexpr int CLAMPED = 0;
         TG_SOLVE()
     }
+    const uint64_t viol = __builtin_amdgcn_ballot_w64(watch_lane && wmax > maximp);
     if (viol != 0) {                      // a motor impulse reached its limit somewhere in this tick: the literal clamped iteration
         constexpr int CLAMPED = 1;
         x = x0; lam = T(0); lamF = T(0);

@@ -568,6 +568,37 @@ def test_object_push_env_matches_oracle(arm, sensor, movement, traj, mapping):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mapping", ["wave", "lane"])
+def test_object_push_with_saturating_motors_matches_oracle(mapping):
+    """The wave mapping solves a tick with the joint motors unclamped while watching their impulses, and solves it again with the literal
+    clamped step when the limit max_force * dt was reached.  With a 2 N m limit (the reference's arms: 1000) the motors saturate whenever the
+    commanded velocity changes: the states must still follow the oracle (whose motors clamp in every sweep), and differ from the 1000 N m run."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleObjectPushEnv
+    modes = dict(PUSH_MODES, arm_type="ur5", tactile_sensor_name="digitac", movement_mode="TyRz", traj_type="straight")
+    n, steps = 4, 5
+    weak = tg.make_vec("object_push-v0", num_envs=n, max_steps=50, image_size=[64, 64], env_modes=modes, seed=9, auto_reset=False,
+                       contact_mapping=mapping, max_force=2.0)
+    strong = tg.make_vec("object_push-v0", num_envs=n, max_steps=50, image_size=[64, 64], env_modes=modes, seed=9, auto_reset=False, contact_mapping=mapping)
+    oracles = [OracleObjectPushEnv(seed=9 + i, max_steps=50, image_size=(64, 64), env_modes=modes) for i in range(n)]
+    weak.reset(); strong.reset()
+    for o in oracles:
+        o.reset()
+        o.max_force = 2.0                     # from the first step on (the reset's blocking move has run with the default on both sides)
+    rng = np.random.default_rng(2)
+    for step in range(steps):
+        a = rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)
+        weak.step(a); strong.step(a)
+        sw, ss = weak.get_state(), strong.get_state()
+        for i, o in enumerate(oracles):
+            o.step(a[i])
+            assert np.abs(sw["q"][i] - o.arm.q).max() < 1e-9 and np.abs(sw["qd"][i] - o.arm.qd).max() < 1e-7, (step, i)
+            assert np.abs(sw["body_pos"][i] - o.cube_pose()[0]).max() < 1e-8, (step, i)
+    assert np.abs(sw["q"] - ss["q"]).max() > 1e-5    # the limit did bite
+    weak.close(); strong.close()
+
+
+@pytest.mark.gpu
 def test_object_push_f32_and_autoreset():
     """f32 physics variant of object_push: finite, the cube moves forward and stays on the table; auto-reset hands back the terminal
     observation (tactile + extended_feature) and restarts the episode at goal 0."""

@@ -134,7 +134,7 @@ def main():
     # device-resident rollout: the step is enqueued on a torch stream and its outputs are consumed on that stream (no host wait per
     # step); --sync-steps restores the blocking VecEnv.step_wait behaviour
     shard = TorchShard(venv, pipelined=not args.sync_steps)
-    env = ShardedVecEnv(shard, dist, overlap=True, force_collective=force) if dist is not None else shard   # gather of step t overlaps the simulation of step t+1
+    env = ShardedVecEnv(shard, dist, overlap=True, force_collective=force, payload=os.environ.get("TG_BENCH_PAYLOAD", "full")) if dist is not None else shard   # gather of step t overlaps the simulation of step t+1
     act_buf = torch.empty(n, act_dim, device="cuda", dtype=torch.float32)
     draw = [0]
 
@@ -259,7 +259,7 @@ def main():
             "dtype": "f64" if args.physics == "f64" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.env}, {modes['arm_type'].upper()} + {modes['tactile_sensor_name']}, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
                                    f"random actions, TCP_velocity_control, {12 if args.env == 'object_balance-v0' else 24} sim ticks per step (PGS budget 150 sweeps per tick), auto-reset on",
-                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world}" + (" + one packed RCCL gather (obs u8, reward f32, done u8) to rank 0 per step, "
+                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world}" + (" + one packed RCCL gather (obs u8" + (" interior pixels only, border ring restored on rank 0" if getattr(env, "_interior", None) is not None else "") + ", reward f32, done u8) to rank 0 per step, "
                                                                           "overlapped with the next step's simulation" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

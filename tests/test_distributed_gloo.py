@@ -25,6 +25,13 @@ class OracleShard:
         self.envs = [OracleEdgeFollowEnv(seed=seed + rank * n_local + i, max_steps=200, image_size=(64, 64), env_modes=MODES)
                      for i in range(n_local)]
 
+    def border_info(self):
+        """What TorchShard.border_info() hands out (the TacTip ring is 40 % of the image: payload "auto" ships the interior only)."""
+        e = self.envs[0]
+        mask = torch.from_numpy(e.border_mask.reshape(-1).astype(np.uint8))
+        gray = torch.from_numpy(e.nodef_gray.reshape(-1).astype(np.uint8))
+        return torch.nonzero(mask != 1).reshape(-1), torch.where(mask == 1, gray, torch.zeros_like(gray))
+
     def reset(self):
         return {"tactile": torch.from_numpy(np.stack([e.reset()["tactile"] for e in self.envs]))}
 
@@ -92,18 +99,26 @@ class PushOracleShard:
         self._packed = (blk, off, off_f)
         return obs, rew, done, {}
 
+    def border_info(self):
+        """What TorchShard.border_info() hands out, from the oracle's copy of the sensor constants."""
+        e = self.envs[0]
+        mask = torch.from_numpy(e.border_mask.reshape(-1).astype(np.uint8))
+        gray = torch.from_numpy(e.nodef_gray.reshape(-1).astype(np.uint8))
+        return torch.nonzero(mask != 1).reshape(-1), torch.where(mask == 1, gray, torch.zeros_like(gray))
+
     def __getattr__(self, name):
         if name == "packed" and self.__dict__.get("_use_packed"):
             return lambda: self._packed
         raise AttributeError(name)
 
 
-def _push_worker(rank, world, port, out_path, overlap, packed):
+def _push_worker(rank, world, port, out_path, overlap, packed, payload="full"):
     import torch.distributed as dist
     from tactile_gym_amd.parallel import ShardedVecEnv
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    env = ShardedVecEnv(PushOracleShard(rank, N_LOCAL, SEED, packed), dist, overlap=overlap)
+    env = ShardedVecEnv(PushOracleShard(rank, N_LOCAL, SEED, packed), dist, overlap=overlap, payload=payload)
+    assert payload == "auto" or (env._interior is not None) == (payload == "interior")   # auto: the DigiTac ring is under 10 % -> full
     obs = env.reset()
     assert obs["extended_feature"].shape == ((world if rank == 0 else 1) * N_LOCAL, 12)
     gen = torch.Generator().manual_seed(11)
@@ -120,15 +135,17 @@ def _push_worker(rank, world, port, out_path, overlap, packed):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,packed", [(False, False), (True, True)])
-def test_tactile_and_feature_reaches_rank0_world2(tmp_path, overlap, packed):
-    """SURVEY 8e / BASELINE config 4: `extended_feature f32[N/R, 12]` travels to rank 0 in the same per-step message as the images."""
+@pytest.mark.parametrize("overlap,packed,payload", [(False, False, "full"), (True, True, "full"), (True, True, "interior"), (False, False, "auto")])
+def test_tactile_and_feature_reaches_rank0_world2(tmp_path, overlap, packed, payload):
+    """SURVEY 8e / BASELINE config 4: `extended_feature f32[N/R, 12]` travels to rank 0 in the same per-step message as the images.
+    payload "interior" / "auto": only the pixels inside the sensor's border mask are shipped, rank 0 restores the constant ring - the
+    gathered images must equal the full ones bit for bit."""
     world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_push_worker, args=(world, port, out, overlap, packed), nprocs=world, join=True)
+    mp.spawn(_push_worker, args=(world, port, out, overlap, packed, payload), nprocs=world, join=True)
     got = torch.load(out)
     ref = PushOracleShard(0, world * N_LOCAL, SEED, False)
     ref.reset()
@@ -139,12 +156,13 @@ def test_tactile_and_feature_reaches_rank0_world2(tmp_path, overlap, packed):
     assert torch.equal(got["tactile"], obs["tactile"]) and torch.allclose(got["rew"], rew) and torch.equal(got["done"], done)
 
 
-def _worker(rank, world, port, out_path, overlap=False, packed=False):
+def _worker(rank, world, port, out_path, overlap=False, packed=False, payload="auto"):
     import torch.distributed as dist
     from tactile_gym_amd.parallel import ShardedVecEnv
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    env = ShardedVecEnv((PackedOracleShard if packed else OracleShard)(rank, N_LOCAL, SEED), dist, overlap=overlap)
+    env = ShardedVecEnv((PackedOracleShard if packed else OracleShard)(rank, N_LOCAL, SEED), dist, overlap=overlap, payload=payload)
+    assert (env._interior is not None) == (payload != "full")      # TacTip: "auto" picks the interior payload
     assert env.num_envs == world * N_LOCAL and env.env_slice() == slice(rank * N_LOCAL, (rank + 1) * N_LOCAL)
     obs = env.reset()
     gen = torch.Generator().manual_seed(7)
@@ -168,14 +186,14 @@ def _worker(rank, world, port, out_path, overlap=False, packed=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,packed", [(False, False), (True, False), (True, True)])
-def test_shard_and_gather_world2(tmp_path, overlap, packed):
+@pytest.mark.parametrize("overlap,packed,payload", [(False, False, "full"), (True, False, "auto"), (True, True, "auto"), (True, True, "full"), (False, True, "interior")])
+def test_shard_and_gather_world2(tmp_path, overlap, packed, payload):
     world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(world, port, out, overlap, packed), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, overlap, packed, payload), nprocs=world, join=True)
     got = torch.load(out)
     # single-process reference: the same 4 envs with seeds SEED..SEED+3 stepped with the same actions
     ref = OracleShard(0, world * N_LOCAL, SEED)

@@ -3,7 +3,7 @@
 # default bench command and of object_push / object_balance / object_roll, HBM traffic (FETCH_SIZE / WRITE_SIZE passes) of edge_follow
 # and object_push.  Outputs under gpurun_out/r2_final/ (copied to profiles/r2_f_* afterwards).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r2_final
+O=$R/gpurun_out/${TG_PROFILE_TAG:-r2_final}
 mkdir -p $O
 cd $R
 python bench.py 2>/dev/null | grep metric > $O/bench_edge.json

@@ -290,6 +290,8 @@ typedef struct {
     double fov_deg, near_plane, far_plane;  /* rgb_fov / rgb_near_val / rgb_far_val */
     double light_dir[3];                    /* world, towards the light */
     uint8_t background[3];
+    uint8_t body_rgb[3];                    /* surface envs: colour of the per-env heightfield (changeVisualShape rgbaColor, base_surface_env.py:431) */
+    int32_t body_heightfield;               /* != 0: the task's body is the env's heightfield (frame ndof + 1), not part of the triangle set */
     int32_t every_step;                     /* != 0: tg_step / tg_reset also draw the scene (observation modes with "visual" / "visuo") */
 } tg_scene;
 /* Uploads the scene; call before the first tg_step. */

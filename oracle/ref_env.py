@@ -246,11 +246,15 @@ class _OracleArmEnv:
     def visual_image(self):
         from tactile_gym_amd.robot_model import compose_scene                 # the triangle set is data (assets/visual), shared with the product
         body = self.scene_body()
-        key = "_scene_cache"
-        if not hasattr(self, key):
-            setattr(self, key, compose_scene(self.arm_type, self.t_s_type, self.t_s_name, self.tg.ndof,
-                                             None if body is None else (body[0], body[1])))
-        verts, tris, tri_frame, tri_rgb = getattr(self, key)
+        if not hasattr(self, "_scene_static"):                                # plane, table, robot: composed once; the body may change per episode
+            self._scene_static = compose_scene(self.arm_type, self.t_s_type, self.t_s_name, self.tg.ndof, None)
+        verts, tris, tri_frame, tri_rgb = self._scene_static
+        if body is not None:
+            bv, bt = np.asarray(body[0], dtype=np.float32), np.asarray(body[1], dtype=np.int32)
+            tris = np.concatenate([tris, bt + len(verts)])
+            verts = np.concatenate([verts, bv])
+            tri_frame = np.concatenate([tri_frame, np.full(len(bt), self.tg.ndof + 1, dtype=np.uint8)])
+            tri_rgb = np.concatenate([tri_rgb, np.tile(np.array([0, 0, 255], dtype=np.uint8), (len(bt), 1))])
         frames = [(np.eye(3), np.zeros(3))] + self.arm.link_poses()
         frames.append((np.eye(3), np.zeros(3)) if body is None else (body[2], body[3]))
         target, dist, yaw, pitch, fov, near, far = self.scene_camera()
@@ -531,6 +535,14 @@ class OracleSurfaceFollowAutoEnv(_OracleArmEnv):
         cpos, cR = self.camera_pose()
         return mb.cam_from_obj_matrix(cpos, cR, self.surface_pos, np.eye(3))
 
+    def scene_camera(self):                                                              # base_surface_env.py:208-232
+        if self.arm_type == "mg400":
+            return ([0.16, 0.0, 0.14], 0.45, -2.0, -30.0, 75.0, 0.1, 100.0)
+        return ([0.65, 0.0, 0.05], 0.4, 90.0, -30.0, 75.0, 0.1, 100.0)
+
+    def scene_body(self):                                                                # the heightfield, rgba 0 0 1 1 (:431)
+        return self.surf_verts, self.surf_tris, np.eye(3), np.asarray(self.surface_pos, dtype=np.float64)
+
     def tactile_image(self):
         h, w = self.image_size
         cur = self.nodef_dep.copy()
@@ -706,6 +718,9 @@ class OracleSurfaceFollowVertEnv(OracleSurfaceFollowAutoEnv):
     def stimulus_transform(self):
         cpos, cR = self.camera_pose()
         return mb.cam_from_obj_matrix(cpos, cR, self.surface_pos, pm.mat_from_quat(self.surface_orn))
+
+    def scene_body(self):
+        return self.surf_verts, self.surf_tris, pm.mat_from_quat(self.surface_orn), np.asarray(self.surface_pos, dtype=np.float64)
 
     def extended_feature(self):                                                          # surface_follow_vert_env.py:83-100
         p, _, _, _ = self._tcp_work()

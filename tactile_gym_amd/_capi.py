@@ -65,7 +65,8 @@ class TgScene(C.Structure):
                 ("verts", C.POINTER(C.c_float)), ("tris", C.POINTER(C.c_int32)), ("tri_frame", C.POINTER(C.c_uint8)),
                 ("tri_rgb", C.POINTER(C.c_uint8)), ("cam_target", C.c_double * 3), ("cam_dist", C.c_double), ("cam_yaw_deg", C.c_double),
                 ("cam_pitch_deg", C.c_double), ("fov_deg", C.c_double), ("near_plane", C.c_double), ("far_plane", C.c_double),
-                ("light_dir", C.c_double * 3), ("background", C.c_uint8 * 3), ("every_step", C.c_int32)]
+                ("light_dir", C.c_double * 3), ("background", C.c_uint8 * 3), ("body_rgb", C.c_uint8 * 3), ("body_heightfield", C.c_int32),
+                ("every_step", C.c_int32)]
 
 
 class TgConfig(C.Structure):

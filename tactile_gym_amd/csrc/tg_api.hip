@@ -1089,6 +1089,12 @@ int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
     for (int r = 0; r < 3; ++r) P.light_eye[r] = (float)(V.R[3 * r] * L[0] + V.R[3 * r + 1] * L[1] + V.R[3 * r + 2] * L[2]);
     for (int k = 0; k < 3; ++k) P.background[k] = sc->background[k];
     P.n_tris = sc->n_tris; P.n_frames = n_frames;
+    if (sc->body_heightfield) {
+        if (c->cfg.env_kind != TG_ENV_SURFACE_FOLLOW_AUTO) return fail(-1, "tg_set_scene: body_heightfield needs a surface env");
+        P.hf_heights = c->st.heights; P.hf_zoff = c->st.surf_zoff; P.hf_rows = c->cfg.surf_rows; P.hf_cols = c->cfg.surf_cols;
+        P.hf_scale = (float)c->cfg.surf_grid_scale;
+        P.hf_rgb = ((uint32_t)sc->body_rgb[0] << 16) | ((uint32_t)sc->body_rgb[1] << 8) | sc->body_rgb[2];
+    }
     const size_t n = (size_t)c->cfg.num_envs, img = (size_t)W * H * 3;
     std::vector<int32_t> tris(sc->tris, sc->tris + (size_t)sc->n_tris * 3);
     std::vector<SceneChunk> chunks;

@@ -371,6 +371,8 @@ __global__ __launch_bounds__(64) void k_scene_xf(const DevRobot<T>* __restrict__
     if (c.env_kind == TG_ENV_EDGE_FOLLOW) {
         const double se = st.edge_sc[0 * n + env], ce = st.edge_sc[1 * n + env];
         R[0] = ce; R[1] = -se; R[3] = se; R[4] = ce;
+    } else if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        for (int e = 0; e < 9; ++e) R[e] = (double)c.stim_R.m[e];              // identity, or the upright surface's fixed rotation (-v2)
     } else if (c.env_kind == TG_ENV_OBJECT_BALANCE || c.env_kind == TG_ENV_OBJECT_PUSH || c.env_kind == TG_ENV_OBJECT_ROLL) {
         const double scale = c.env_kind == TG_ENV_OBJECT_ROLL ? st.obj_mass[env] / c.roll_radius : 1.0;   // globalScaling scales the visual
         for (int e = 0; e < 9; ++e) R[e] = st.body_rot[e * n + env] * scale;

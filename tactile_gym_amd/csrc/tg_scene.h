@@ -23,6 +23,14 @@ struct SceneParams {
     const uint32_t* tri_attr;      // device [n_tris]: frame << 24 | r << 16 | g << 8 | b
     const SceneChunk* chunks;      // device [n_chunks]: runs of <= 64 spatially sorted triangles of one frame with a bounding sphere
     int n_chunks;
+    // surface envs: the task's body is a per-env heightfield (createCollisionShape(GEOM_HEIGHTFIELD), base_surface_env.py:402-432), drawn in frame
+    // n_frames - 1 with one colour; vertices and triangle order as in tg_raster.h (Stimulus): vertex (i, j) = ((i - (rows-1)/2) s,
+    // (j - (cols-1)/2) s, h[j rows + i] - zoff), cell (i, j) -> (i,j),(i,j+1),(i+1,j) and (i+1,j),(i,j+1),(i+1,j+1)
+    const double* hf_heights;      // device [n_envs][rows * cols], nullptr: no heightfield
+    const float* hf_zoff;          // device [n_envs]
+    int hf_rows, hf_cols;
+    float hf_scale;
+    uint32_t hf_rgb;               // r << 16 | g << 8 | b
 };
 
 SceneParams make_scene_params(int W, int H, double fov_deg, double near_, double far_);

@@ -39,16 +39,14 @@ struct TriSetup {
     int x0, x1, y0, y1;            // pixel box (inclusive), empty if x0 > x1
 };
 
-// Everything about triangle t that does not depend on the pixel.  Returns false when nothing can be drawn.
-__device__ __forceinline__ bool setup_tri(const SceneParams& P, const float* __restrict__ sxf, int t, const int (&tile)[4], TriSetup& S) {
-    const int i0 = P.tris[3 * t + 0], i1 = P.tris[3 * t + 1], i2 = P.tris[3 * t + 2];
-    const uint32_t attr = P.tri_attr[t];
-    const float* M = sxf + 12 * (attr >> 24);
-    const int idx[3] = {i0, i1, i2};
+// Everything about a triangle that does not depend on the pixel: vertices (frame coordinates), eye<-frame transform M, base colour.
+// Returns false when nothing can be drawn.
+__device__ __forceinline__ bool setup_verts(const SceneParams& P, const float* __restrict__ M, const float (&vxs)[3], const float (&vys)[3],
+                                            const float (&vzs)[3], uint32_t attr, const int (&tile)[4], TriSetup& S) {
     float ex[3], ey[3], ez[3], w[3], X[3], Y[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float vx = P.verts[3 * idx[k] + 0], vy = P.verts[3 * idx[k] + 1], vz = P.verts[3 * idx[k] + 2];
+        const float vx = vxs[k], vy = vys[k], vz = vzs[k];
         ex[k] = ((M[0] * vx + M[1] * vy) + M[2] * vz) + M[9];
         ey[k] = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
         ez[k] = ((M[6] * vx + M[7] * vy) + M[8] * vz) + M[11];
@@ -92,6 +90,33 @@ __device__ __forceinline__ bool setup_tri(const SceneParams& P, const float* __r
                    b = (uint32_t)((float)(attr & 255u) * inten + 0.5f);
     S.rgb = (r << 16) | (g << 8) | b;
     return true;
+}
+// triangle t of the shared indexed set (t < n_tris), or triangle t - n_tris of this env's heightfield (2 per grid cell)
+__device__ __forceinline__ bool setup_tri(const SceneParams& P, const float* __restrict__ sxf, int env, int t, const int (&tile)[4], TriSetup& S) {
+    float vx[3], vy[3], vz[3];
+    if (t < P.n_tris) {
+        const uint32_t attr = P.tri_attr[t];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = P.tris[3 * t + k];
+            vx[k] = P.verts[3 * i + 0]; vy[k] = P.verts[3 * i + 1]; vz[k] = P.verts[3 * i + 2];
+        }
+        return setup_verts(P, sxf + 12 * (attr >> 24), vx, vy, vz, attr, tile, S);
+    }
+    const int h = t - P.n_tris, cell = h >> 1, half = h & 1;
+    const int ci = cell % (P.hf_rows - 1), cj = cell / (P.hf_rows - 1);
+    const double* H = P.hf_heights + (size_t)env * P.hf_rows * P.hf_cols;
+    const float zoff = P.hf_zoff[env], cx = 0.5f * (float)(P.hf_rows - 1), cy = 0.5f * (float)(P.hf_cols - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // half 0: (i,j),(i,j+1),(i+1,j)   half 1: (i+1,j),(i,j+1),(i+1,j+1)
+        const int di = half == 0 ? (k == 2) : (k != 1), dj = half == 0 ? (k == 1) : (k != 0);
+        const int vi = ci + di, vj = cj + dj;
+        vx[k] = ((float)vi - cx) * P.hf_scale;
+        vy[k] = ((float)vj - cy) * P.hf_scale;
+        vz[k] = (float)H[(size_t)vj * P.hf_rows + vi] - zoff;
+    }
+    return setup_verts(P, sxf + 12 * (P.n_frames - 1), vx, vy, vz, P.hf_rgb, tile, S);
 }
 
 __device__ __forceinline__ void shade_pixel(const SceneParams& P, const TriSetup& S, int px, int py, unsigned long long* zb, int tx0, int ty0, int tw) {
@@ -157,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
         if (lane >= ch.count) continue;
         const int t = ch.start + lane;
         TriSetup S;
-        if (!setup_tri(P, sxf, t, tile, S)) continue;
+        if (!setup_tri(P, sxf, env, t, tile, S)) continue;
         const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
         const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
         if (area > kHugeArea) {
@@ -171,11 +196,31 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
         for (int py = y0; py <= y1; ++py)
             for (int px = x0; px <= x1; ++px) shade_pixel(P, S, px, py, zb, tx0, ty0, tw);
     }
+    if (P.hf_heights != nullptr) {                                // this env's heightfield: two triangles per grid cell, a lane per triangle
+        const int n_hf = 2 * (P.hf_rows - 1) * (P.hf_cols - 1);
+        for (int h = tid; h < n_hf; h += kThreads) {
+            const int t = P.n_tris + h;
+            TriSetup S;
+            if (!setup_tri(P, sxf, env, t, tile, S)) continue;
+            const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
+            const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+            if (area > kHugeArea) {
+                const int slot = atomicAdd(&huge_n, 1);
+                if (slot < kHugeCap) { huge[slot] = t; continue; }
+            }
+            if (area > kBigArea) {
+                const int slot = atomicAdd(&big_n, 1);
+                if (slot < kBigCap) { big[slot] = t; continue; }
+            }
+            for (int py = y0; py <= y1; ++py)
+                for (int px = x0; px <= x1; ++px) shade_pixel(P, S, px, py, zb, tx0, ty0, tw);
+        }
+    }
     __syncthreads();
     const int nb = min(big_n, kBigCap);
     for (int i = wave; i < nb; i += kThreads / 64) {               // one queued triangle per wavefront: set-up once (wave-uniform), pixels across lanes
         TriSetup S;
-        if (!setup_tri(P, sxf, big[i], tile, S)) continue;
+        if (!setup_tri(P, sxf, env, big[i], tile, S)) continue;
         const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
         const int bw = x1 - x0 + 1, np = bw * (y1 - y0 + 1);
         for (int p = lane; p < np; p += 64) shade_pixel(P, S, x0 + p % bw, y0 + p / bw, zb, tx0, ty0, tw);
@@ -183,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     const int nh = min(huge_n, kHugeCap);
     for (int i = 0; i < nh; ++i) {
         TriSetup S;
-        if (!setup_tri(P, sxf, huge[i], tile, S)) continue;        // workgroup-uniform
+        if (!setup_tri(P, sxf, env, huge[i], tile, S)) continue;   // workgroup-uniform
         const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
         const int bw = x1 - x0 + 1, np = bw * (y1 - y0 + 1);
         for (int p = tid; p < np; p += kThreads) shade_pixel(P, S, x0 + p % bw, y0 + p / bw, zb, tx0, ty0, tw);

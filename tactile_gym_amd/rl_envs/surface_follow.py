@@ -117,7 +117,9 @@ class SurfaceFollowAutoVecEnv(TactileVecEnv):
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"yz": 1, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}[modes["movement_mode"]]          # surface_follow_auto_env.py:96-107
         super().__init__(cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
-                         act_dim=act_dim, oracle_dim=20)
+                         act_dim=act_dim, oracle_dim=20,
+                         scene_spec={"arm_type": modes["arm_type"], "body_rgb": (0, 0, 255), "camera":    # base_surface_env.py:208-232, :431
+                                     (([0.16, 0.0, 0.14], 0.45, -2.0, -30.0) if modes["arm_type"] == "mg400" else ([0.65, 0.0, 0.05], 0.4, 90.0, -30.0)) + (75.0, 0.1, 100.0)})
 
     def oracle_obs_host(self):
         """base_surface_env.py:789-819: TCP pos, orn (quaternion), lin/ang velocity, goal pos (all work frame), the surface height
@@ -153,7 +155,9 @@ class SurfaceFollowGoalVecEnv(SurfaceFollowAutoVecEnv):
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"yz": 2, "xyz": 3, "yzRx": 3, "xyzRxRy": 5}[modes["movement_mode"]]          # surface_follow_goal_env.py:112-123
         TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
-                               act_dim=act_dim, oracle_dim=20, feature_dim=6)
+                               act_dim=act_dim, oracle_dim=20, feature_dim=6,
+                               scene_spec={"arm_type": modes["arm_type"], "body_rgb": (0, 0, 255), "camera":    # base_surface_env.py:208-232, :431
+                                     (([0.16, 0.0, 0.14], 0.45, -2.0, -30.0) if modes["arm_type"] == "mg400" else ([0.65, 0.0, 0.05], 0.4, 90.0, -30.0)) + (75.0, 0.1, 100.0)})
 
     def feature_numpy(self, terminal=False):
         """get_extended_feature_array (surface_follow_goal_env.py:92-110), host side from the state read-back.  (The terminal copy
@@ -188,7 +192,9 @@ class SurfaceFollowVertVecEnv(SurfaceFollowGoalVecEnv):
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
-                               act_dim=2, oracle_dim=20, feature_dim=6)                          # get_act_dim :102-113
+                               act_dim=2, oracle_dim=20, feature_dim=6,                          # get_act_dim :102-113
+                               scene_spec={"arm_type": modes["arm_type"], "body_rgb": (0, 0, 255), "camera":    # base_surface_env.py:208-232, :431
+                                     (([0.16, 0.0, 0.14], 0.45, -2.0, -30.0) if modes["arm_type"] == "mg400" else ([0.65, 0.0, 0.05], 0.4, 90.0, -30.0)) + (75.0, 0.1, 100.0)})
 
     def oracle_obs_host(self):
         """base_surface_env.py:789-819 on the flipped surface_array / normals (:486-516)."""

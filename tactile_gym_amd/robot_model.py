@@ -202,7 +202,8 @@ class SceneDesc:
     """tg_scene plus the arrays behind its pointers.  camera = (target [3], distance, yaw deg, pitch deg, fov deg, near, far): the env's
     rgb_cam_* attributes (e.g. edge_follow_env.py:176-195)."""
 
-    def __init__(self, arm_type, t_s_type, t_s_name, ndof, image_size, camera, body_mesh=None, body_rgb=(0, 0, 255), every_step=False):
+    def __init__(self, arm_type, t_s_type, t_s_name, ndof, image_size, camera, body_mesh=None, body_rgb=(0, 0, 255), every_step=False,
+                 body_heightfield=False):
         self.verts, self.tris, self.tri_frame, self.tri_rgb = compose_scene(arm_type, t_s_type, t_s_name, ndof, body_mesh, body_rgb)
         target, dist, yaw, pitch, fov, near, far = camera
         s = capi.TgScene()
@@ -217,4 +218,7 @@ class SceneDesc:
         s.cam_dist, s.cam_yaw_deg, s.cam_pitch_deg = float(dist), float(yaw), float(pitch)
         s.fov_deg, s.near_plane, s.far_plane = float(fov), float(near), float(far)
         s.every_step = int(bool(every_step))
+        s.body_heightfield = int(bool(body_heightfield))
+        for k in range(3):
+            s.body_rgb[k] = int(body_rgb[k])
         self.struct = s

@@ -202,7 +202,7 @@ class TactileVecEnv(_VecEnvBase):
         sp = self._scene_spec
         body = None if self._mesh is None else (self._mesh.verts, self._mesh.tris)
         self._scene = SceneDesc(sp["arm_type"], self._sensor.t_s_type, self._sensor.t_s_name, self._robot.ndof, (self.H, self.W), sp["camera"],
-                                body, sp.get("body_rgb", (0, 0, 255)), every_step)
+                                body, sp.get("body_rgb", (0, 0, 255)), every_step, body_heightfield=self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO)
         capi.check(self._L.tg_set_scene(self._ctx, C.byref(self._scene.struct)))
 
     def get_images(self):

@@ -25,6 +25,17 @@ def _oracle_images(env, envs):
     out = []
     for i in envs:
         frames = [(np.eye(3), np.zeros(3))] + arm.link_poses(st["q"][i])
+        if kind == capi.ENV_SURFACE_FOLLOW_AUTO:        # the env's own heightfield, blue, in the frame of the surface
+            from oracle.ref_env import heightfield_mesh
+            from tactile_gym_amd import pb_math as pbm
+            hv, ht = heightfield_mesh(st["heights"][i], env._cfg.surf_grid_scale, st["surf_zoff"][i])
+            R = pbm.mat_from_quat(pbm.quat_from_euler(np.array([0.0, -np.pi / 2, 0.0]))) if env._cfg.noise_mode == capi.SNOISE["vertical_simplex"] else np.eye(3)
+            frames.append((R, np.array([env._cfg.stim_pos[k] for k in range(3)])))
+            verts = np.concatenate([sc.verts, hv]); tris = np.concatenate([sc.tris, ht + len(sc.verts)])
+            tf = np.concatenate([sc.tri_frame, np.full(len(ht), len(frames) - 1, np.uint8)])
+            rgb = np.concatenate([sc.tri_rgb, np.tile(np.array([0, 0, 255], np.uint8), (len(ht), 1))])
+            out.append(mb.render_scene(verts, tris, tf, rgb, frames, view, LIGHT_DIR, cam[4], cam[5], cam[6], env.W, env.H, BACKGROUND))
+            continue
         if kind == capi.ENV_EDGE_FOLLOW:
             a = st["edge_ang"][i]
             R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
@@ -38,7 +49,9 @@ def _oracle_images(env, envs):
 
 CASES = [("edge_follow-v0", "ur5", "tactip", 128, "visuotactile"), ("edge_follow-v0", "mg400", "digitac", 64, "visual"),
          ("edge_follow-v0", "ur5", "digit", 256, "visual"), ("object_push-v0", "ur5", "tactip", 128, "visuotactile_and_feature"),
-         ("object_balance-v0", "ur5", "tactip", 256, "visuotactile"), ("object_roll-v0", "ur5", "tactip", 128, "visual")]
+         ("object_balance-v0", "ur5", "tactip", 256, "visuotactile"), ("object_roll-v0", "ur5", "tactip", 128, "visual"),
+         ("surface_follow-v0", "ur5", "digit", 128, "visuotactile"), ("surface_follow-v1", "ur5", "tactip", 64, "visuotactile_and_feature"),
+         ("surface_follow-v2", "mg400", "tactip", 128, "visual")]
 
 
 @pytest.mark.parametrize("env_id,arm,sensor,size,mode", CASES)

@@ -594,19 +594,36 @@ static void scene_draw(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
     launch_scene(c->scene, c->d_scene_xf, c->cfg.num_envs, d_mask, c->d_vis, save_prev ? c->d_vis_term : nullptr, c->stream);
 }
 
+// Which mapping steps the contact envs (tg_config.contact_mapping).  One wavefront per env needs the whole register file of its SIMD (one
+// wavefront per SIMD, 1024 per chip) and ~20x the instructions per env-sweep of the lane mapping, but its dependent chain per sweep is
+// ~2.5x shorter: measured on object_push, 1024 envs 2.9 ms against 7.4 ms per step, 2048 envs 5.9 against 7.5, 4096 envs 11.6 against 7.7.
+static bool use_contact_wave(const tg_ctx* c) {
+    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL) return false;
+    if (c->cfg.physics_dtype != TG_PHYSICS_F64) return false;
+    if (c->cfg.contact_mapping == TG_CONTACT_MAP_LANE) return false;
+    if (c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE) return true;
+    return c->cfg.num_envs <= 2048;
+}
+
 static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
     Timer t(c, 2);
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
         if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_reset_body_t<double>(c, d_mask);
         else launch_reset_body_t<float>(c, d_mask);
     } else if (c->cfg.env_kind == TG_ENV_OBJECT_ROLL) {
+        if (!(use_contact_wave(c) && launch_reset_contact_wave(c->cfg.env_kind, c->cfg.physics_dtype, c->robot.topology, c->cfg.cone_friction, c->cfg.num_envs,
+                                                               c->cfg.n_tip_verts, c->stream, c->d_robot, c->d_const, c->st, d_mask) == 0)) {
 #define CALL(T, TOPO) launch_reset_roll_t<T, TOPO>(c, d_mask)
-        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
+        }
     } else if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
+        if (!(use_contact_wave(c) && launch_reset_contact_wave(c->cfg.env_kind, c->cfg.physics_dtype, c->robot.topology, c->cfg.cone_friction, c->cfg.num_envs,
+                                                               c->cfg.n_tip_verts, c->stream, c->d_robot, c->d_const, c->st, d_mask) == 0)) {
 #define CALL(T, TOPO) launch_reset_push_t<T, TOPO>(c, d_mask)
-        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
+        }
         if (c->cfg.traj_type == TG_TRAJ_SIMPLEX)
             launch_gen_traj(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.traj_n_points, c->cfg.traj_spacing, c->cfg.traj_max_perturb,
                             c->cfg.traj_init_offset, c->cfg.reset_goal_id, c->st.traj, c->st.feature, c->stream);
@@ -897,17 +914,6 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
     if (c->scene_every_step) scene_draw(c, dmask, false);
     TG_HIP(hipGetLastError());
     return 0;
-}
-
-// Which mapping steps the contact envs (tg_config.contact_mapping).  One wavefront per env needs the whole register file of its SIMD (one
-// wavefront per SIMD, 1024 per chip) and ~20x the instructions per env-sweep of the lane mapping, but its dependent chain per sweep is
-// ~2.5x shorter: measured on object_push, 1024 envs 2.9 ms against 7.4 ms per step, 2048 envs 5.9 against 7.5, 4096 envs 11.6 against 7.7.
-static bool use_contact_wave(const tg_ctx* c) {
-    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL) return false;
-    if (c->cfg.physics_dtype != TG_PHYSICS_F64) return false;
-    if (c->cfg.contact_mapping == TG_CONTACT_MAP_LANE) return false;
-    if (c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE) return true;
-    return c->cfg.num_envs <= 2048;
 }
 
 static void enqueue_step(tg_ctx* c, const float* d_act) {

@@ -14,4 +14,8 @@ int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int 
                              hipStream_t stream,
                              const void* d_robot, const void* d_const, const State& st, const float* d_actions);
 
+// env.reset() for the envs flagged in d_mask (nullptr: all) with the same mapping: one wavefront per resetting env, the others exit at once.
+int launch_reset_contact_wave(int env_kind, int physics_dtype, int topology, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
+                              const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask);
+
 }  // namespace tg

@@ -1010,6 +1010,162 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
     else finish_push<T, TOPO>(m, c, st, env, q, b, step_count, true);
 }
 
+// env.reset() of object_push (SHAPE 0) / object_roll (SHAPE 1) for the envs flagged in `mask`, one wavefront per resetting env (the
+// lane-per-env k_reset_push / k_reset_roll run every resetting env's blocking move at the pace of a 64-env wavefront: 0.8 ms per launch with
+// a reset in object_roll, where some env finishes on nearly every step).  Same sequence as those kernels: episode draws, rest pose,
+// inverse kinematics of the start pose (wave-uniform, every lane the same), then the blocking move - each tick sim_tick_contact_wave with
+// position motors (max force 100 000 as robot.py:188-260 / base_robot_arm.py pass it) against the PREVIOUS episode's object - then the object
+// is put back and the first observation's transforms are written.
+template <typename T, int TOPO, int SHAPE, bool CONE>
+__global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                           const uint8_t* __restrict__ mask) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double wave_lds_raw[];
+    const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const int n = c.num_envs;
+    if (mask != nullptr && mask[env] == 0) return;
+    const bool w0 = lane == 0;                                  // state goes back to HBM once
+    // ---- episode draws (the order of the draws is the lane kernels')
+    uint64_t rs = st.rng[env];
+    const double old_mr = st.obj_mass[env];                     // push: the cube's mass; roll: the marble's radius
+    double new_mr = old_mr, ang = 0.0, scaling = 1.0, embed = st.embed[env], ix = 0.0, iy = 0.0;
+    if constexpr (SHAPE == 0) {
+        ang = c.rand_init_orn ? rng_uniform(rs, -c.init_orn_range, c.init_orn_range) : 0.0;
+        new_mr = c.rand_obj_mass ? rng_uniform(rs, c.mass_lo, c.mass_hi) : old_mr;
+        if (c.traj_type == TG_TRAJ_SIMPLEX) { const int64_t seed = (int64_t)rng_uniform(rs, 0.0, 1.0e8); if (w0) st.noise_seed[env] = seed; }
+        else {
+            const double ta = rng_uniform(rs, -c.traj_ang_range, c.traj_ang_range);
+            double ys[TG_MAX_TRAJ_POINTS];
+            for (int i = 0; i < c.traj_n; ++i) {
+                const double dist = (double)i * c.traj_spacing;
+                ys[i] = dist * sin(ta);
+                if (w0) { st.traj[(0 * TG_MAX_TRAJ_POINTS + i) * n + env] = c.traj_init_offset + dist * cos(ta); st.traj[(1 * TG_MAX_TRAJ_POINTS + i) * n + env] = ys[i]; }
+            }
+            for (int i = 0; i < c.traj_n; ++i) {
+                double g;
+                if (i == 0) g = (ys[1] - ys[0]) / c.traj_spacing;
+                else if (i == c.traj_n - 1) g = (ys[i] - ys[i - 1]) / c.traj_spacing;
+                else g = (ys[i + 1] - ys[i - 1]) / (2.0 * c.traj_spacing);
+                if (w0) st.traj[(2 * TG_MAX_TRAJ_POINTS + i) * n + env] = g;
+            }
+        }
+    } else {
+        scaling = c.roll_rand_size ? rng_uniform(rs, 1.0, 2.0) : 1.0;
+        new_mr = c.roll_radius * scaling;
+        if (c.roll_rand_embed) embed = rng_uniform(rs, c.embed_lo, c.embed_hi);
+        if (c.roll_rand_init_pos) { ix = rng_uniform(rs, -c.roll_init_range, c.roll_init_range); iy = rng_uniform(rs, -c.roll_init_range, c.roll_init_range); }
+        const double gang = rng_uniform(rs, -3.141592653589793, 3.141592653589793);
+        const double gdist = rng_uniform(rs, c.roll_goal_lo, c.roll_goal_hi);
+        if (w0) { st.embed[env] = embed; st.goal[0 * n + env] = gdist * cos(gang); st.goal[1 * n + env] = gdist * sin(gang); st.goal[2 * n + env] = 0.0; }
+    }
+    if (w0) { st.rng[env] = rs; st.step_count[env] = 0; }
+    if constexpr (SHAPE == 0) { if (w0) st.goal_id[env] = c.reset_goal_id; }
+    // ---- rest pose, start-pose inverse kinematics
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+    const V3<T> tpos = SHAPE == 0 ? load_v3(c.work_pos) : mk(c.work_pos[0], c.work_pos[1], (T)(2.0 * new_mr - embed));   // work-frame origin, rpy 0
+    T trpy[3];
+    euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
+    const Q4<T> tq = quat_from_euler(trpy[0], trpy[1], trpy[2]);
+    const M3<T> Rt = mat_from_quat(tq);
+    T qik[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qik[i] = q[i];
+    inverse_kinematics<T, TOPO>(m, tpos, Rt, qik, 100, T(1e-8));
+    if (N == 8) { qik[N - 3] = qik[1]; qik[N - 2] = -qik[1]; qik[N - 1] = qik[1] + qik[2]; }
+    // ---- env state to LDS (the previous episode's object where it was left)
+    if constexpr (SHAPE == 0) {
+        const T* tipv = (const T*)st.tip_verts;
+        const int nw = 3 * c.push.n_tip;
+        for (int w = lane; w < nw; w += 64) L[kLHull + w] = tipv[w];
+    }
+    stage_link_constants<T, TOPO>(mp, L, lane);
+    {
+        const FreeBody<T> b0 = load_body<T>(st, n, env);
+        JointTrig<T, N> trig;
+        trig_init<T, N>(q, trig);
+        if (w0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool in = i < N;
+                L[kLQ + i] = in ? q[in ? i : 0] : T(0); L[kLQd + i] = T(0);
+                L[kLTrigS + i] = in ? trig.s[in ? i : 0] : T(0); L[kLTrigC + i] = in ? trig.c[in ? i : 0] : T(1);
+                L[kLQDes + i] = in ? q[in ? i : 0] : T(0); L[kLQdDes + i] = T(0);
+            }
+            L[kLBody + 0] = b0.pos.x; L[kLBody + 1] = b0.pos.y; L[kLBody + 2] = b0.pos.z;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) L[kLBody + 3 + e] = b0.R.m[e];
+            L[kLBody + 12] = b0.v.x; L[kLBody + 13] = b0.v.y; L[kLBody + 14] = b0.v.z;
+            L[kLBody + 15] = b0.w.x; L[kLBody + 16] = b0.w.y; L[kLBody + 17] = b0.w.z;
+        }
+    }
+    TG_PHASE_FENCE()
+    // ---- blocking_move(max_steps = 1000, constant_vel = 0.001), robot.py:188-260
+    T cv = T(0.001);
+    int used = 0, ccode = 0;
+    for (int it = 0; it < 1000; ++it) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> p; M3<T> R;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, p, R);
+        const Q4<T> cq = quat_from_mat(R);
+        T diff[N], nrm2 = T(0), total_v = T(0);
+        bool all_small = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diff[i] = qik[i] - q[i];
+            nrm2 += diff[i] * diff[i];
+            all_small = all_small && (tabs(diff[i]) < cv);
+            total_v += tabs(qd[i]);
+        }
+        const T nrm = tsqrt(nrm2);
+        __syncthreads();
+        if (w0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) L[kLQDes + i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
+        }
+        if (all_small) cv = cv / T(2);
+        TG_PHASE_FENCE()
+        ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE>(m, c.push, L, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, (T)old_mr, lane);
+        ++used;
+        const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
+        const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
+        T ca = T(2) * ip * ip - T(1);
+        ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
+        if (uniform_true(pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1))) break;
+    }
+    // ---- the object goes back to its start (reset_object), results to HBM
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
+    FreeBody<T> b;
+    if constexpr (SHAPE == 0) {
+        b.pos = load_v3(c.obj_init_pos);
+        b.R = mat_from_quat(quat_from_euler((T)c.obj_init_rpy[0], (T)c.obj_init_rpy[1], (T)(c.obj_init_rpy[2] + ang)));
+    } else {
+        b.pos = mk((T)((double)c.obj_init_pos[0] + ix), (T)((double)c.obj_init_pos[1] + iy), (T)new_mr);
+        const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+#pragma unroll
+        for (int e = 0; e < 9; ++e) b.R.m[e] = ident[e];
+    }
+    b.v = mk<T>(0, 0, 0); b.w = mk<T>(0, 0, 0);
+    if (w0) {
+        st.reset_ticks[env] = used;
+        st.contact_code[env] = ccode;
+        st.obj_mass[env] = new_mr;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+        store_body<T>(st, n, env, b);
+    }
+    if constexpr (SHAPE == 1) finish_roll<T, TOPO>(m, c, st, env, q, b, (T)scaling, 0, false);
+    else finish_push<T, TOPO>(m, c, st, env, q, b, 0, false);
+}
+
 template <typename T, int TOPO, int SHAPE>
 int launch_wave_t(int control_mode, int cone, int n, int n_tip, hipStream_t stream, const void* d_robot, const void* d_const, const State& st, const float* d_actions) {
     const size_t lds_bytes = (size_t)(kLHull + (SHAPE == 1 ? 0 : 3 * n_tip)) * sizeof(T);   // env state + per-tick hand-offs + the tip-core hull
@@ -1024,7 +1180,28 @@ int launch_wave_t(int control_mode, int cone, int n, int n_tip, hipStream_t stre
     return 0;
 }
 
+template <typename T, int TOPO, int SHAPE>
+int launch_reset_wave_t(int cone, int n, int n_tip, hipStream_t stream, const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask) {
+    const size_t lds_bytes = (size_t)(kLHull + (SHAPE == 1 ? 0 : 3 * n_tip)) * sizeof(T);
+    if (lds_bytes > 60 * 1024 || !cone) return -1;
+    hipLaunchKernelGGL((k_reset_contact_wave<T, TOPO, SHAPE, true>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
+                       (const EnvConst<T>*)d_const, st, d_mask);
+    return 0;
+}
+
 }  // namespace
+
+int launch_reset_contact_wave(int env_kind, int physics_dtype, int topology, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
+                              const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask) {
+    if (physics_dtype != TG_PHYSICS_F64) return -1;
+    if (env_kind == TG_ENV_OBJECT_PUSH) {
+        if (topology == 0) return launch_reset_wave_t<double, 0, 0>(cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_mask);
+        return launch_reset_wave_t<double, 1, 0>(cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_mask);
+    }
+    if (env_kind == TG_ENV_OBJECT_ROLL && topology == 0)
+        return launch_reset_wave_t<double, 0, 1>(cone_friction, num_envs, 0, stream, d_robot, d_const, st, d_mask);
+    return -1;
+}
 
 int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int control_mode, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
                              const void* d_robot, const void* d_const, const State& st, const float* d_actions) {

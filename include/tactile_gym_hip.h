@@ -228,6 +228,12 @@ int tg_get_obs_feature(tg_ctx* ctx, void** dev_ptr, int32_t* dim, int32_t termin
  * (dim 10 / 20 / 26 / 30 / 34 by env kind).  Enqueued on the context's stream; the pointer stays valid for the context's lifetime. */
 int tg_get_obs_oracle(tg_ctx* ctx, void** dev_ptr, int32_t* dim);
 int tg_copy_obs_oracle(tg_ctx* ctx, float* host_dst);          /* synchronises */
+/* observation_mode "oracle" as a per-step output: tg_step / tg_reset then also write the vectors (tg_get_obs_oracle returns them without a
+ * launch of its own), and the step's own vectors - taken before the auto-reset - are kept: rows of the envs that finished are their
+ * terminal observation (VecEnv info["terminal_observation"]).  Call before the first tg_step. */
+int tg_enable_oracle_obs(tg_ctx* ctx);
+int tg_get_obs_oracle_terminal(tg_ctx* ctx, void** dev_ptr);   /* float32 [num_envs][dim] */
+int tg_copy_obs_oracle_terminal(tg_ctx* ctx, float* host_dst); /* synchronises */
 /* Host copies (synchronise). */
 int tg_get_reward_done(tg_ctx* ctx, float* reward, uint8_t* done);
 int tg_copy_obs_tactile(tg_ctx* ctx, uint8_t* host_dst, int32_t terminal);

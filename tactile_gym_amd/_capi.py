@@ -139,6 +139,9 @@ SYMBOLS = {
     "tg_sample_actions": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tg_get_obs_oracle": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32)]),
     "tg_copy_obs_oracle": (C.c_int, [_ctx, _fp]),
+    "tg_enable_oracle_obs": (C.c_int, [_ctx]),
+    "tg_get_obs_oracle_terminal": (C.c_int, [_ctx, _vpp]),
+    "tg_copy_obs_oracle_terminal": (C.c_int, [_ctx, _fp]),
     "tg_set_scene": (C.c_int, [_ctx, C.POINTER(TgScene)]),
     "tg_render_scene": (C.c_int, [_ctx]),
     "tg_get_obs_visual": (C.c_int, [_ctx, _vpp, C.c_int32]),

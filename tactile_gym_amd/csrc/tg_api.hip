@@ -377,6 +377,8 @@ struct tg_ctx {
     tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
     float* d_oracle = nullptr;        // [n][34] observation_mode "oracle" vectors (tg_get_obs_oracle), allocated on first use
+    float* d_oracle_term = nullptr;   // tg_enable_oracle_obs: the step's own vectors (before any reset): rows of finished envs = terminal observation
+    bool oracle_every_step = false;
     // hipGraph of one tg_step launch sequence, keyed by the device action pointer it was captured with (launch-bound inner loop:
     // 3-4 kernels per step, one graph launch instead)
     hipStream_t aux_stream = nullptr;                // object_balance: the reset of finished envs runs here, beside the render
@@ -392,6 +394,10 @@ struct tg_ctx {
     double prof_ms[5] = {0, 0, 0, 0, 0};     // step, render, reset, masked render, scene camera
     int64_t prof_n[5] = {0, 0, 0, 0, 0};
 };
+
+static inline bool env_has_feature(int env_kind) {   // envs with an extended_feature observation (push 12, roll 3, surface_follow -v1 / -v2 6 of the 12-wide rows)
+    return env_kind == TG_ENV_OBJECT_PUSH || env_kind == TG_ENV_OBJECT_ROLL || env_kind == TG_ENV_SURFACE_FOLLOW_AUTO;
+}
 
 namespace tg {
 
@@ -566,10 +572,17 @@ __global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, flo
     out[i] = lo + (hi - lo) * u;
 }
 
-template <typename T, int TOPO> static void launch_oracle_obs_t(tg_ctx* c, int dim) {
+template <typename T, int TOPO> static void launch_oracle_obs_t(tg_ctx* c, int dim, float* dst) {
     const int n = c->cfg.num_envs;
     hipLaunchKernelGGL((k_oracle_obs<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st, dim, c->d_oracle);
+                       (const EnvConst<T>*)c->d_const, c->st, dim, dst);
+}
+static int oracle_dim(const tg_ctx* c);
+static void oracle_draw(tg_ctx* c, float* dst) {
+    const int d = oracle_dim(c);
+#define CALL(T, TOPO) launch_oracle_obs_t<T, TOPO>(c, d, dst)
+    TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
 }
 static int oracle_dim(const tg_ctx* c) {
     switch (c->cfg.env_kind) {
@@ -819,6 +832,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         TG_HIP(hipMalloc(&s.surf_zoff, n * 4)); TG_HIP(hipMalloc(&s.noise_seed, n * 8)); TG_HIP(hipMalloc(&s.accum, n * 8));
         TG_HIP(hipMemset(s.dir, 0, 2 * n * 8)); TG_HIP(hipMemset(s.goal, 0, 3 * n * 8)); TG_HIP(hipMemset(s.heights, 0, cells * n * 8));
         TG_HIP(hipMemset(s.surf_zoff, 0, n * 4)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8)); TG_HIP(hipMemset(s.accum, 0, n * 8));
+        TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4)); TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
         c->stim.kind = 1; c->stim.heights = s.heights; c->stim.zoff = s.surf_zoff;
         c->stim.rows = cfg->surf_rows; c->stim.cols = cfg->surf_cols; c->stim.scale = (float)cfg->surf_grid_scale;
         c->stim.n_tris = (cfg->surf_rows - 1) * (cfg->surf_cols - 1) * 2;
@@ -841,7 +855,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     // (tg_get_packed_outputs).  The obs block is padded to 16 bytes so the reward block stays aligned.
     c->packed_obs_bytes = ((size_t)npix * n + 15) & ~(size_t)15;
     c->packed_bytes = c->packed_obs_bytes + (size_t)n * 4 + (size_t)n;
-    const bool has_feature = cfg->env_kind == TG_ENV_OBJECT_PUSH || cfg->env_kind == TG_ENV_OBJECT_ROLL;
+    const bool has_feature = env_has_feature(cfg->env_kind);
     if (has_feature) {   // extended_feature rides in the same message (config 4's tactile_and_feature observation)
         c->packed_feature_off = (c->packed_bytes + 3) & ~(size_t)3;
         c->packed_bytes = c->packed_feature_off + (size_t)n * 12 * 4;
@@ -874,7 +888,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -912,6 +926,7 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
     reset_sequence(c, dmask);
     render(c, dmask, false);
     if (c->scene_every_step) scene_draw(c, dmask, false);
+    if (c->oracle_every_step) oracle_draw(c, c->d_oracle);
     TG_HIP(hipGetLastError());
     return 0;
 }
@@ -942,6 +957,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     // visual observation modes: the step's image of every env before any reset touches the state; the envs that finished are redrawn
     // after their reset below (their step image moves to the terminal buffer)
     if (c->scene_every_step) scene_draw(c, nullptr, false);
+    if (c->oracle_every_step) oracle_draw(c, c->cfg.auto_reset ? c->d_oracle_term : c->d_oracle);   // the step's own vectors, before any reset
     if (c->cfg.auto_reset && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {
         reset_sequence(c, c->st.done); // k_reset keeps the terminal camera transform of the envs it resets
         render_fused(c);               // one launch draws the terminal and the post-reset observations
@@ -974,6 +990,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
         }
     }
     if (c->scene_every_step && c->cfg.auto_reset) scene_draw(c, c->st.done, true);
+    if (c->oracle_every_step && c->cfg.auto_reset) oracle_draw(c, c->d_oracle);                       // after the resets: what the next step starts from
 }
 
 int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
@@ -1033,14 +1050,41 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     return 0;
 }
 
+int tg_enable_oracle_obs(tg_ctx* c) {
+    if (!c) return fail(-1, "NULL ctx");
+    TG_ENTER(c);
+    if (c->step_graph[0] || c->step_graph[1]) return fail(-1, "tg_enable_oracle_obs: call before the first tg_step");
+    if (!c->d_oracle) TG_HIP(hipMalloc(&c->d_oracle, (size_t)c->cfg.num_envs * 34 * sizeof(float)));
+    if (!c->d_oracle_term) TG_HIP(hipMalloc(&c->d_oracle_term, (size_t)c->cfg.num_envs * 34 * sizeof(float)));
+    TG_HIP(hipMemset(c->d_oracle, 0, (size_t)c->cfg.num_envs * 34 * sizeof(float)));
+    TG_HIP(hipMemset(c->d_oracle_term, 0, (size_t)c->cfg.num_envs * 34 * sizeof(float)));
+    c->oracle_every_step = true;
+    return 0;
+}
+int tg_get_obs_oracle_terminal(tg_ctx* c, void** p) {
+    if (!c || !p) return fail(-1, "NULL argument");
+    if (!c->oracle_every_step) return fail(-1, "tg_get_obs_oracle_terminal: needs tg_enable_oracle_obs");
+    *p = c->d_oracle_term;
+    return 0;
+}
+int tg_copy_obs_oracle_terminal(tg_ctx* c, float* dst) {
+    if (!c || !dst) return fail(-1, "NULL argument");
+    TG_ENTER(c);
+    if (!c->oracle_every_step) return fail(-1, "tg_copy_obs_oracle_terminal: needs tg_enable_oracle_obs");
+    TG_HIP(hipMemcpyAsync(dst, c->d_oracle_term, (size_t)c->cfg.num_envs * oracle_dim(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
 int tg_get_obs_oracle(tg_ctx* c, void** p, int32_t* dim) {
     if (!c || !p) return fail(-1, "NULL argument");
     TG_ENTER(c);
     const int d = oracle_dim(c);
     if (!c->d_oracle) TG_HIP(hipMalloc(&c->d_oracle, (size_t)c->cfg.num_envs * 34 * sizeof(float)));
-#define CALL(T, TOPO) launch_oracle_obs_t<T, TOPO>(c, d)
-    TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+    if (!c->oracle_every_step) {     // (enabled: tg_step / tg_reset have already written it)
+#define CALL(T, TOPO) launch_oracle_obs_t<T, TOPO>(c, d, c->d_oracle)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
+    }
     TG_HIP(hipGetLastError());
     *p = c->d_oracle;
     if (dim) *dim = d;
@@ -1182,7 +1226,7 @@ int tg_get_packed_outputs(tg_ctx* c, void** p, int64_t* obs_bytes, int64_t* tota
 }
 int tg_get_packed_feature(tg_ctx* c, int64_t* feature_off, int32_t* dim) {
     if (!c || !feature_off) return fail(-1, "NULL argument");
-    const bool has = c->cfg.env_kind == TG_ENV_OBJECT_PUSH || c->cfg.env_kind == TG_ENV_OBJECT_ROLL;
+    const bool has = env_has_feature(c->cfg.env_kind);
     *feature_off = has ? (int64_t)c->packed_feature_off : -1;
     if (dim) *dim = has ? 12 : 0;
     return 0;
@@ -1206,7 +1250,7 @@ int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches) {
 }
 int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {
     if (!c || !p) return fail(-1, "NULL argument");
-    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL)
+    if (!env_has_feature(c->cfg.env_kind))
         return fail(-1, "tg_get_obs_feature: this env has no extended_feature observation");
     *p = terminal ? c->st.term_feature : c->st.feature;
     if (dim) *dim = 12;
@@ -1215,7 +1259,7 @@ int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {
 int tg_copy_obs_feature(tg_ctx* c, float* dst, int32_t terminal) {
     if (!c || !dst) return fail(-1, "NULL argument");
     TG_ENTER(c);
-    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL)
+    if (!env_has_feature(c->cfg.env_kind))
         return fail(-1, "tg_copy_obs_feature: this env has no extended_feature observation");
     TG_HIP(hipMemcpyAsync(dst, terminal ? c->st.term_feature : c->st.feature, (size_t)c->cfg.num_envs * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     TG_HIP(hipStreamSynchronize(c->stream));

@@ -212,6 +212,18 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
             st.done[env] = (at_goal || step_count >= c.max_steps) ? 1 : 0;
         }
     }
+    if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO && st.feature != nullptr) {
+        // extended_feature of surface_follow-v1 / -v2 (surface_follow_goal_env.py:92-110, surface_follow_vert_env.py:83-100): TCP position and
+        // goal position in the work frame (6 of the 12-wide row); at the end of a step also the copy the auto-reset leaves alone
+        const V3<T> tw_ = load_v3(c.work_inv_pos) + mul(c.work_Rinv, ptcp);
+        const V3<T> gw_ = load_v3(c.work_inv_pos) + mul(c.work_Rinv, mk((T)st.goal[0 * n + env], (T)st.goal[1 * n + env], (T)st.goal[2 * n + env]));
+        const float f[6] = {(float)tw_.x, (float)tw_.y, (float)tw_.z, (float)gw_.x, (float)gw_.y, (float)gw_.z};
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            st.feature[(size_t)env * 12 + e] = f[e];
+            if (write_reward_done) st.term_feature[(size_t)env * 12 + e] = f[e];
+        }
+    }
     // camera frame = sensor-body frame o cam offset; eye axes (right, up, -forward) with forward = R[:,0], up = R[:,2]
     V3<T> pb; M3<T> Rb;
     link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);

@@ -160,16 +160,22 @@ class SurfaceFollowGoalVecEnv(SurfaceFollowAutoVecEnv):
                                      (([0.16, 0.0, 0.14], 0.45, -2.0, -30.0) if modes["arm_type"] == "mg400" else ([0.65, 0.0, 0.05], 0.4, 90.0, -30.0)) + (75.0, 0.1, 100.0)})
 
     def feature_numpy(self, terminal=False):
-        """get_extended_feature_array (surface_follow_goal_env.py:92-110), host side from the state read-back.  (The terminal copy
-        of auto-reset envs is not kept for this vector: the post-reset features are returned for them.)"""
+        """get_extended_feature_array (surface_follow_goal_env.py:92-110): TCP and goal position in the work frame, float32 [N, 6], written
+        by the step / reset kernels (device rows are 12 floats wide); terminal: the copy taken at the end of the step, before the auto-reset."""
+        import ctypes as C
+        buf = np.zeros((self.num_envs, 12), dtype=np.float32)
+        capi.check(self._L.tg_copy_obs_feature(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_float)), int(terminal)))
+        return np.ascontiguousarray(buf[:, :6])
+
+    def feature_torch(self, terminal=False):
+        return TactileVecEnv.feature_torch(self, terminal)[:, :6]
+
+    def feature_host(self):
+        """The same vector from a state read-back (cross-check of the device route)."""
         st = self.get_state()
         tp, _, _, _, _ = self._tcp_workframe_state(st)
         gp, _ = self._workframe().pose(st["goal_pos"], np.zeros((self.num_envs, 3)))
         return np.hstack([tp, gp]).astype(np.float32)
-
-    def feature_torch(self, terminal=False):
-        import torch
-        return torch.from_numpy(self.feature_numpy(terminal)).to(torch.device("cuda", self._cfg.device))
 
 
 env_modes_default_vert = {  # surface_follow_vert_env.py:6-12

@@ -78,6 +78,7 @@ class TactileVecEnv(_VecEnvBase):
         obs_spaces = {}
         if "oracle" in observation_mode:
             obs_spaces["oracle"] = spaces.Box(low=-np.inf, high=np.inf, shape=(oracle_dim,), dtype=np.float32)
+            capi.check(self._L.tg_enable_oracle_obs(self._ctx))   # written by every step / reset; the step's own copy is the terminal observation
         if "tactile" in observation_mode:
             obs_spaces["tactile"] = spaces.Box(low=0, high=255, shape=(self.H, self.W, 1), dtype=np.uint8)
         if self._visual:
@@ -318,8 +319,23 @@ class TactileVecEnv(_VecEnvBase):
             obs["extended_feature"] = self.feature_torch() if self.obs_mode == "torch" else self.feature_numpy()
         return obs
 
+    def oracle_terminal(self):
+        """The oracle vectors of the last step before the auto-reset (rows valid where done); observation_mode "oracle" only."""
+        if self.obs_mode == "torch":
+            if "oracle_term" not in self._views:
+                import torch
+                p = C.c_void_p()
+                capi.check(self._L.tg_get_obs_oracle_terminal(self._ctx, C.byref(p)))
+                self._views["oracle_term"] = torch.as_tensor(_DevArray(p.value, (self.num_envs, self._oracle_dim), "<f4"), device=f"cuda:{self._cfg.device}")
+            return self._views["oracle_term"]
+        buf = np.empty((self.num_envs, self._oracle_dim), dtype=np.float32)
+        capi.check(self._L.tg_copy_obs_oracle_terminal(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_float))))
+        return buf
+
     def _terminal_observation(self):
         obs = {}
+        if "oracle" in self.observation_mode:
+            obs["oracle"] = self.oracle_terminal()
         if "tactile" in self.observation_mode:
             obs["tactile"] = self.tactile_torch(True) if self.obs_mode == "torch" else self.tactile_numpy(True)
         if self._visual:

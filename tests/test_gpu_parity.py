@@ -1460,3 +1460,38 @@ def test_scatter_raster_marble_sizes_and_large_triangles(size, scale):
         assert np.array_equal(got[i], ref), (size, scale, i, int((got[i] != ref).sum()))
         nonblank += int((ref[sensor.border_mask == 0] > 0).any())
     assert nonblank > n // 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,modes_name,mode", [("surface_follow-v1", "SURF", "tactile_and_feature"), ("surface_follow-v2", "VERT", "tactile_and_feature"),
+                                                    ("edge_follow-v0", "EDGE", "oracle"), ("object_push-v0", "PUSH", "oracle"), ("surface_follow-v0", "SURF", "oracle")])
+def test_terminal_observation_is_the_last_step_before_the_reset(env_id, modes_name, mode, edge_modes):
+    """info["terminal_observation"] of an auto-reset env (SB3 convention) must be what a caller-reset env returns at that step: the
+    extended_feature of surface_follow-v1 / -v2 and the oracle vector (both written by the step kernels before the reset, kept in
+    device-side terminal buffers).  An auto-reset env against a twin without auto-reset, same seeds and actions, max_steps = 4."""
+    import bench
+    import tactile_gym_amd as tg
+    modes = dict({"EDGE": edge_modes, "SURF": bench.SURF_MODES, "VERT": bench.VERT_MODES, "PUSH": bench.PUSH_MODES}[modes_name], observation_mode=mode)
+    n = 8
+    a_env = tg.make_vec(env_id, num_envs=n, max_steps=4, image_size=[64, 64], env_modes=modes, seed=21, auto_reset=True)
+    b_env = tg.make_vec(env_id, num_envs=n, max_steps=4, image_size=[64, 64], env_modes=modes, seed=21, auto_reset=False)
+    oa, ob = a_env.reset(), b_env.reset()
+    key = "oracle" if mode == "oracle" else "extended_feature"
+    assert np.array_equal(oa[key], ob[key])
+    rng = np.random.default_rng(8)
+    for step in range(4):
+        act = rng.uniform(-0.25, 0.25, size=(n, a_env.act_dim)).astype(np.float32)
+        oa, ra, da, infos = a_env.step(act)
+        ob, rb, db, _ = b_env.step(act)
+        assert np.array_equal(da, db) and np.allclose(ra, rb)
+        for i in range(n):
+            if da[i]:
+                term = infos[i]["terminal_observation"]
+                assert key in term and np.array_equal(term[key], ob[key][i]), (step, i)
+                assert not np.array_equal(oa[key][i], ob[key][i])          # the returned observation is the post-reset one
+            else:
+                assert np.array_equal(oa[key][i], ob[key][i]), (step, i)
+    assert da.all()
+    if key == "extended_feature" and hasattr(a_env, "feature_host"):
+        assert np.abs(a_env.feature_host() - oa[key]).max() < 2e-6    # device route == state read-back route
+    a_env.close(); b_env.close()

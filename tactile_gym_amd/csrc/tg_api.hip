@@ -607,15 +607,16 @@ static void scene_draw(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
     launch_scene(c->scene, c->d_scene_xf, c->cfg.num_envs, d_mask, c->d_vis, save_prev ? c->d_vis_term : nullptr, c->stream);
 }
 
-// Which mapping steps the contact envs (tg_config.contact_mapping).  One wavefront per env needs the whole register file of its SIMD (one
-// wavefront per SIMD, 1024 per chip) and ~20x the instructions per env-sweep of the lane mapping, but its dependent chain per sweep is
-// ~2.5x shorter: measured on object_push, 1024 envs 2.9 ms against 7.4 ms per step, 2048 envs 5.9 against 7.5, 4096 envs 11.6 against 7.7.
+// Which mapping steps the contact envs (tg_config.contact_mapping).  One wavefront per env takes the whole register file of its SIMD (one
+// wavefront per SIMD, 1024 per chip), so its rate is flat in the batch size - object_push: 0.52 M env-steps/s from 1024 envs up - while one
+// lane per env scales with the batch until the chip is full: measured 1024 envs 2.0 ms (wave) against 7.4 ms (lane) per step, 2048 envs
+// 3.9 against 7.5, 4096 envs 7.8 against 7.7, 8192 envs 15.5 against 7.9 (1.04 M env-steps/s).
 static bool use_contact_wave(const tg_ctx* c) {
     if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL) return false;
     if (c->cfg.physics_dtype != TG_PHYSICS_F64) return false;
     if (c->cfg.contact_mapping == TG_CONTACT_MAP_LANE) return false;
     if (c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE) return true;
-    return c->cfg.num_envs <= 2048;
+    return c->cfg.num_envs < 4096;
 }
 
 static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {

@@ -290,3 +290,32 @@ def test_soft_tip_contact_steady_state_depth_known_answer():
     assert abs(-env.scene.tip_depth - F / k) < 0.03 * F / k, (env.scene.tip_depth, F / k)
     assert abs(env.scene.tip_impulse - F / 240.0) < 0.03 * F / 240.0
     assert abs(vx - 0.01) < 2e-4              # the cube moves with the tip: max_pos_vel = 0.01 m/s (object_push_env.py:126-134)
+
+
+def test_marble_rolls_half_as_far_as_the_tip_known_answer():
+    """object_roll: a marble squeezed between the table and the flat tip's collision cylinder (embed distances above the 1.75 mm
+    skin-to-core gap, A30) and driven by the tip rolls without slipping on both surfaces, so its centre travels exactly half the tip's
+    distance - the kinematics of a ball between two parallel plates, here through the oracle's contact solve (friction products 10 and 100,
+    cone friction, soft tip contact)."""
+    import bench
+    from oracle.ref_env import OracleObjectRollEnv
+    modes = dict(bench.ROLL_MODES, rand_init_obj_pos=False, rand_obj_size=False, rand_embed_dist=True, observation_mode="oracle")
+    checked = 0
+    for seed in range(6):
+        env = OracleObjectRollEnv(seed=seed, max_steps=100, image_size=(64, 64), env_modes=modes)
+        env.reset()
+        if env.embed_dist < 0.0021:          # too close to the 1.75 mm gap: hardly any normal force
+            continue
+        for _ in range(2):                   # let the contact settle
+            env.step(np.array([0.25, 0.0], np.float32))
+        p0, t0 = env.ball_pose()[0].copy(), env._tcp_world()[0].copy()
+        for _ in range(6):
+            env.step(np.array([0.25, 0.0], np.float32))
+        dp, dt_ = env.ball_pose()[0] - p0, env._tcp_world()[0] - t0
+        tip = np.linalg.norm(dt_[:2])
+        assert tip > 5e-3
+        assert abs(np.linalg.norm(dp[:2]) / tip - 0.5) < 0.02, (seed, dp, dt_)          # half the tip's travel
+        assert abs(np.dot(dp[:2], dt_[:2]) / (np.linalg.norm(dp[:2]) * tip) - 1.0) < 1e-3   # in the tip's direction
+        assert abs(dp[2]) < 1e-5                                                         # and it stays on the table
+        checked += 1
+    assert checked >= 3

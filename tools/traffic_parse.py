@@ -12,7 +12,7 @@ def means(d, counter):
     for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter and "tg::" in r["Kernel_Name"]:
-                agg[r["Kernel_Name"].split("(")[0][:90]].append(float(r["Counter_Value"]))
+                agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:90]].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 

@@ -13,16 +13,19 @@
 // lane's work), and then every lane updates its own s_j -= G_ji d with ONE fused multiply-add, G_ji = A_ji / (A_jj + cfm_j) precomputed
 // per tick (zero diagonal: s_i itself is invariant under its own relaxation).  A row step is therefore
 //     clamp (2-3 VALU) -> v_readlane x2 (the delta becomes a scalar) -> v_fma_f64 (all rows at once)
-// instead of ~34 dependent instructions, a sweep ~250 instructions instead of ~800, and 1024 envs are 1024 wavefronts: one per SIMD of
-// the chip.  Lane-per-env remains the better mapping once the SIMDs are saturated (>= ~4096 envs per GPU: it needs 12 instructions per
-// env-sweep, this one ~250); tg_step picks by num_envs (tg_config.contact_mapping overrides).
+// instead of ~34 dependent instructions, a sweep ~170 instructions instead of ~800, and 1024 envs are 1024 wavefronts: one per SIMD of
+// the chip.  Lane-per-env remains the better mapping once the SIMDs are saturated (>= 4096 envs per GPU: it needs 12 instructions per
+// env-sweep, this one ~170); tg_step picks by num_envs (tg_config.contact_mapping overrides).  The same mapping resets the envs
+// (k_reset_contact_wave: one wavefront per env that finished).
 //
 // Lane layout (one env per wavefront):   lane i < N ............ joint motor i (btMultiBodyJointMotor row, J = e_i)
 //                                        lane 8 + 4c + r ....... contact c (0-3: cube vertex / marble on the table, 4: sensor tip),
 //                                                                r = 0 normal, 1 / 2 friction directions (btPlaneSpace1), r = 3 unused
-// Everything that is per env rather than per row (articulated-body dynamics, contact generation, integration) is evaluated redundantly
-// by all lanes - the values are wave-uniform, the cost is that of one lane - except the search over the 610 hull vertices of the tip
-// core, which the lanes share (10 vertices each + a wave argmin).
+//                                        lanes 32 .. 45 ........ accumulators of the velocity change du (8 joints, cube linear 3, angular 3)
+//                                        lanes 48 .. 55 ........ accumulators of the motor impulses (limit watch)
+// The arm's dynamics are spread over the lanes as well (tick_dynamics_lanes: a link per lane, the 8 x 8 inertia matrix one entry per
+// lane), and so is the search over the hull vertices of the tip core (a wave argmin); contact generation and integration are evaluated
+// redundantly by all lanes - the values are wave-uniform, the cost is that of one lane.
 //
 // Numerics: same mathematics, different summation order (A_ji lambda instead of J_j . dv) - agreement with the oracle is to rounding
 // amplified by the contact dynamics, tolerances as for sim_tick_push (joints 1e-9 rad, cube pose 1e-8, images <= 3 px); the contact

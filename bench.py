@@ -134,7 +134,7 @@ def main():
     # device-resident rollout: the step is enqueued on a torch stream and its outputs are consumed on that stream (no host wait per
     # step); --sync-steps restores the blocking VecEnv.step_wait behaviour
     shard = TorchShard(venv, pipelined=not args.sync_steps)
-    env = ShardedVecEnv(shard, dist, overlap=True, force_collective=force, payload=os.environ.get("TG_BENCH_PAYLOAD", "full")) if dist is not None else shard   # gather of step t overlaps the simulation of step t+1
+    env = ShardedVecEnv(shard, dist, overlap=True, force_collective=force, payload=os.environ.get("TG_BENCH_PAYLOAD", "auto")) if dist is not None else shard   # gather of step t overlaps the simulation of step t+1
     act_buf = torch.empty(n, act_dim, device="cuda", dtype=torch.float32)
     draw = [0]
 

@@ -216,6 +216,15 @@ int tg_get_reward_done_dev(tg_ctx* ctx, void** reward_f32, void** done_u8);
  * (tg_get_obs_tactile / tg_get_reward_done_dev point into it).  A rank ships this byte range to rank 0 as one message per step
  * (replaces SubprocVecEnv's per-env pickled pipes, sb3_helpers/rl_utils.py:17-30).  obs_bytes = offset of the reward. */
 int tg_get_packed_outputs(tg_ctx* ctx, void** dev_ptr, int64_t* obs_bytes, int64_t* total_bytes);
+/* Interior-only tactile payload for that message: the border ring of an image is a constant paste of the reference image
+ * (tactile_sensor.py:291-292; 40 % of a 128 x 128 TacTip image), so a rank may ship only the 4-pixel words that hold a pixel inside the border
+ * mask; *k = bytes per image (a multiple of 16; the pad repeats the last word).
+ * tg_pack_interior: this context's current observations -> dst uint8 [num_envs][k] (device).  tg_unpack_interior (on the receiver; the
+ * context only supplies the sensor constants): src uint8 [n_images][k] -> dst uint8 [n_images][H*W] with the ring restored.  Both are
+ * enqueued on the context's stream.  *k = -1 with turn_off_border (the ring then carries rendered values). */
+int tg_get_interior_count(tg_ctx* ctx, int32_t* k);
+int tg_pack_interior(tg_ctx* ctx, void* dst_dev);
+int tg_unpack_interior(tg_ctx* ctx, const void* src_dev, int32_t n_images, void* dst_dev);
 /* Envs with an "extended_feature" observation (object_push, object_roll) append it to the same allocation, so that config 4's
  * tactile_and_feature observation still travels as one message: [... | done u8[N] | pad to 4 B | feature f32[N][dim]]
  * (object_push_env.py:611-629).  *feature_off = byte offset of the feature block (-1: this env has none). */

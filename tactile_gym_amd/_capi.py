@@ -137,6 +137,9 @@ SYMBOLS = {
     "tg_get_packed_outputs": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tg_get_packed_feature": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_sample_actions": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
+    "tg_pack_interior": (C.c_int, [_ctx, C.c_void_p]),
+    "tg_unpack_interior": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p]),
     "tg_get_obs_oracle": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32)]),
     "tg_copy_obs_oracle": (C.c_int, [_ctx, _fp]),
     "tg_enable_oracle_obs": (C.c_int, [_ctx]),

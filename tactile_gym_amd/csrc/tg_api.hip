@@ -376,9 +376,12 @@ struct tg_ctx {
     uint32_t* d_scene_attr = nullptr;
     tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
+    int32_t *d_int_idx = nullptr, *d_int_rank = nullptr;   // interior-only payload: pixel of interior position k / interior position of pixel p (-1: ring)
+    int n_interior = 0;
     float* d_oracle = nullptr;        // [n][34] observation_mode "oracle" vectors (tg_get_obs_oracle), allocated on first use
     float* d_oracle_term = nullptr;   // tg_enable_oracle_obs: the step's own vectors (before any reset): rows of finished envs = terminal observation
     bool oracle_every_step = false;
+    bool cfg_turn_off_border = false;
     // hipGraph of one tg_step launch sequence, keyed by the device action pointer it was captured with (launch-bound inner loop:
     // 3-4 kernels per step, one graph launch instead)
     hipStream_t aux_stream = nullptr;                // object_balance: the reset of finished envs runs here, beside the render
@@ -394,6 +397,37 @@ struct tg_ctx {
     double prof_ms[5] = {0, 0, 0, 0, 0};     // step, render, reset, masked render, scene camera
     int64_t prof_n[5] = {0, 0, 0, 0, 0};
 };
+
+namespace tg {
+// Interior-only tactile payload (multi-GPU gather): the border ring of an image is a constant paste of the reference image
+// (tactile_sensor.py:291-292), so a rank ships only the K pixels inside the border mask and rank 0 restores the ring.
+// rank_of[p] = position of pixel p among the interior pixels (-1 on the ring), idx[k] = pixel of interior position k.
+// The payload is made of the image's 4-pixel words that hold at least one interior pixel (Kd words; the few ring pixels they include are the
+// sender's constants anyway): both directions are word copies through an index table, four words per lane, one 16-byte store each.
+// idx[j] = word of payload position j (padded to a multiple of 4 with repeats of the last), rank_of[q] = payload position of word q (-1:
+// a word of ring pixels only).
+__global__ __launch_bounds__(256) void k_pack_interior(const uint32_t* __restrict__ obs, const int32_t* __restrict__ idx, int Kd, int HWd, int n_img,
+                                                       uint32_t* __restrict__ dst) {
+    const int img = blockIdx.y;
+    const uint32_t* __restrict__ o = obs + (size_t)img * HWd;
+    for (int k = 4 * (blockIdx.x * blockDim.x + threadIdx.x); k < Kd; k += 4 * gridDim.x * blockDim.x) {
+        const int4 i = *reinterpret_cast<const int4*>(idx + k);
+        *reinterpret_cast<uint4*>(dst + (size_t)img * Kd + k) = make_uint4(o[i.x], o[i.y], o[i.z], o[i.w]);
+    }
+}
+__global__ __launch_bounds__(256) void k_unpack_interior(const uint32_t* __restrict__ src, const int32_t* __restrict__ rank_of, const uint32_t* __restrict__ gray,
+                                                         int Kd, int HWd, int n_img, uint32_t* __restrict__ dst) {
+    const int img = blockIdx.y;
+    const uint32_t* __restrict__ s = src + (size_t)img * Kd;
+    for (int q = 4 * (blockIdx.x * blockDim.x + threadIdx.x); q < HWd; q += 4 * gridDim.x * blockDim.x) {
+        const int4 r = *reinterpret_cast<const int4*>(rank_of + q);
+        const uint4 g = *reinterpret_cast<const uint4*>(gray + q);
+        *reinterpret_cast<uint4*>(dst + (size_t)img * HWd + q) =
+            make_uint4(r.x < 0 ? g.x : s[r.x], r.y < 0 ? g.y : s[r.y], r.z < 0 ? g.z : s[r.z], r.w < 0 ? g.w : s[r.w]);
+    }
+}
+
+}  // namespace tg
 
 static inline bool env_has_feature(int env_kind) {   // envs with an extended_feature observation (push 12, roll 3, surface_follow -v1 / -v2 6 of the 12-wide rows)
     return env_kind == TG_ENV_OBJECT_PUSH || env_kind == TG_ENV_OBJECT_ROLL || env_kind == TG_ENV_SURFACE_FOLLOW_AUTO;
@@ -753,6 +787,21 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         TG_HIP(hipMalloc(&c->d_nodef_gray, npix)); TG_HIP(hipMemcpy(c->d_nodef_gray, g8.data(), npix, hipMemcpyHostToDevice));
     }
     TG_HIP(hipMalloc(&c->d_border, npix)); TG_HIP(hipMemcpy(c->d_border, sensor->border_mask, npix, hipMemcpyHostToDevice));
+    c->cfg_turn_off_border = sensor->turn_off_border != 0;
+    {   // interior word tables (tg_pack_interior / tg_unpack_interior): the 4-pixel words that hold at least one interior pixel
+        const size_t nw = (size_t)npix / 4;
+        std::vector<int32_t> idx, rank_of(nw, -1);
+        for (size_t q = 0; q < nw; ++q) {
+            bool any = false;
+            for (int e = 0; e < 4; ++e) any = any || sensor->border_mask[4 * q + e] != 1;
+            if (any) { rank_of[q] = (int32_t)idx.size(); idx.push_back((int32_t)q); }
+        }
+        while (idx.size() % 4 != 0 && !idx.empty()) idx.push_back(idx.back());   // payload rows are padded to a multiple of 4 words
+        c->n_interior = (int)idx.size();                                         // in words
+        TG_HIP(hipMalloc(&c->d_int_idx, std::max<size_t>(idx.size(), 1) * 4)); TG_HIP(hipMalloc(&c->d_int_rank, (size_t)npix));
+        TG_HIP(hipMemcpy(c->d_int_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(c->d_int_rank, rank_of.data(), (size_t)npix, hipMemcpyHostToDevice));
+    }
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE) {
         TG_HIP(hipMalloc(&s.body_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.body_rot, 9 * n * 8)); TG_HIP(hipMalloc(&s.body_v, 3 * n * 8));
         TG_HIP(hipMalloc(&s.body_w, 3 * n * 8)); TG_HIP(hipMalloc(&s.ext_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.gravity, n * 8));
@@ -889,7 +938,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1051,6 +1100,32 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     return 0;
 }
 
+int tg_get_interior_count(tg_ctx* c, int32_t* k) {
+    if (!c || !k) return fail(-1, "NULL argument");
+    *k = c->cfg_turn_off_border ? -1 : 4 * c->n_interior;   // bytes per image; -1: the ring carries rendered values (turn_off_border), nothing to drop
+    return 0;
+}
+int tg_pack_interior(tg_ctx* c, void* dst_dev) {
+    if (!c || !dst_dev) return fail(-1, "NULL argument");
+    TG_ENTER(c);
+    if (c->cfg_turn_off_border || c->n_interior == 0) return fail(-1, "tg_pack_interior: no constant border ring");
+    const int K = c->n_interior, HW = c->H * c->W / 4;     // in 4-pixel words
+    hipLaunchKernelGGL(k_pack_interior, dim3((K / 4 + 255) / 256, c->cfg.num_envs), dim3(256), 0, c->stream, (const uint32_t*)c->d_obs, c->d_int_idx, K, HW,
+                       c->cfg.num_envs, (uint32_t*)dst_dev);
+    TG_HIP(hipGetLastError());
+    return 0;
+}
+int tg_unpack_interior(tg_ctx* c, const void* src_dev, int32_t n_images, void* dst_dev) {
+    if (!c || !src_dev || !dst_dev || n_images <= 0) return fail(-1, "bad argument");
+    TG_ENTER(c);
+    if (c->cfg_turn_off_border || c->n_interior == 0) return fail(-1, "tg_unpack_interior: no constant border ring");
+    if (n_images > 65535) return fail(-1, "tg_unpack_interior: at most 65535 images per call");
+    const int K = c->n_interior, HW = c->H * c->W / 4;     // in 4-pixel words
+    hipLaunchKernelGGL(k_unpack_interior, dim3((HW / 4 + 255) / 256, n_images), dim3(256), 0, c->stream, (const uint32_t*)src_dev, c->d_int_rank,
+                       (const uint32_t*)c->d_nodef_gray, K, HW, n_images, (uint32_t*)dst_dev);
+    TG_HIP(hipGetLastError());
+    return 0;
+}
 int tg_enable_oracle_obs(tg_ctx* c) {
     if (!c) return fail(-1, "NULL ctx");
     TG_ENTER(c);

@@ -6,6 +6,8 @@ One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROC
 The gather is a direct many-to-one exchange: every peer sends its shard to rank 0 over its own xGMI link, so the
 7 links into rank 0 work concurrently (a ring would serialise the 16-64 MiB shards on one link).
 """
+from . import _capi as capi
+
 import numpy as np
 
 
@@ -24,7 +26,7 @@ class ShardedVecEnv:
     the PREVIOUS step (complete by then), i.e. the learner side runs one step behind the simulators, and flush() waits for the
     last gather and returns its batch.  With overlap=False every step() returns its own gathered batch (synchronous VecEnv)."""
 
-    def __init__(self, local, dist=None, root=0, overlap=False, force_collective=False, payload="full"):
+    def __init__(self, local, dist=None, root=0, overlap=False, force_collective=False, payload="auto"):
         import torch
         if dist is None:
             import torch.distributed as dist
@@ -38,14 +40,14 @@ class ShardedVecEnv:
         self._bufs = {}
         self._stage, self._full, self._views, self._pending = [None, None], [None, None], [None, None], [None, None]
         self._tick, self._layout, self._last = 0, None, None
-        # payload: what the tactile part of the per-step message carries.  "full": every pixel.  "interior": only the pixels inside the
-        # sensor's border mask - the border ring of a TacTip / DigiTac image is a constant paste of the reference image (tactile_sensor.py:
-        # 291-292: 40 % of a 128 x 128 TacTip image), which rank 0 fills in from its own copy of that constant; two extra device kernels
-        # (gather of the interior on the sender, scatter on rank 0) for that many fewer bytes over xGMI.  "auto": interior when the shard
-        # exposes its border (`border_info()`) and the ring is at least 10 % of the image.  Measured with one rank on an MI355X
-        # (edge_follow, 1024 envs, 128 x 128, TG_BENCH_FORCE_COLLECTIVE=1): full 0.096 ms per step, interior 0.129 ms (no-gather 0.062) -
-        # the two kernels cost 33 us at one rank and rank 0's scatter grows with the world size, so "full" is the default and "interior"
-        # is for links that are slow against HBM.
+        # payload: what the tactile part of the per-step message carries.  "full": every pixel.  "interior": only the 4-pixel words that hold
+        # a pixel inside the sensor's border mask - the border ring of a TacTip image is a constant paste of the reference image
+        # (tactile_sensor.py:291-292), which rank 0 fills in from its own copy of that constant: 62 % of the bytes of a 128 x 128 TacTip image
+        # (61 % at 256 x 256) cross xGMI.  Two library kernels do the work (tg_pack_interior on the sender: 6.6 us per 1024 images,
+        # tg_unpack_interior on rank 0: 9.3 us per 1024 images, measured on an MI355X); with one rank (edge_follow, 1024 envs, 128 x 128,
+        # TG_BENCH_FORCE_COLLECTIVE=1) a step costs 0.062 ms without a gather, 0.097 ms with the full payload, 0.103 ms with the interior one,
+        # i.e. it pays as soon as a link is in the way (16.8 MB per peer per step at ~76 GB/s per direction is ~0.22 ms).  "auto" (default):
+        # interior when the shard exposes its border (`border_info()`) and the ring is at least 10 % of the image, else full.
         self._interior = None
         if payload not in ("auto", "full", "interior"):
             raise ValueError(f"payload {payload!r}")
@@ -109,7 +111,7 @@ class ShardedVecEnv:
         if self._interior is not None:
             k_int = int(self._interior[0].numel())
             shift = off_r - ((n * k_int + 15) & ~15)
-            nb_t, off_r, total = n * k_int, off_r - shift, total - shift
+            nb_t, off_r, total = n * k_int, off_r - shift, (total - shift + 15) & ~15   # (peer blocks stay 16-byte aligned on rank 0)
             off_f = off_f - shift if off_f >= 0 else -1
         if self._layout is None:
             assert tac.dtype == torch.uint8 and rew.dtype == torch.float32 and done.dtype == torch.uint8
@@ -123,9 +125,13 @@ class ShardedVecEnv:
                 self._views[slot] = [self._full[slot][i] for i in range(self.world)]
         st = self._stage[slot]
         if self._interior is not None:
-            torch.index_select(tac.reshape(n, -1), 1, self._interior[0], out=st[:nb_t].view(n, -1))   # the pixels inside the border mask
+            if hasattr(self.local, "pack_interior"):
+                self.local.pack_interior(st[:nb_t].view(n, -1))                    # one library kernel
+            else:
+                torch.index_select(tac.reshape(n, -1), 1, self._interior[0], out=st[:nb_t].view(n, -1))   # the pixels inside the border mask
             if packed is not None:
-                st[off_r:].copy_(packed[0][off_r + shift:])                       # reward | done | pad | feature, as laid out by the library
+                rest = packed[0].numel() - (off_r + shift)
+                st[off_r:off_r + rest].copy_(packed[0][off_r + shift:])            # reward | done | pad | feature, as laid out by the library
         elif packed is not None:
             st.copy_(packed[0])                                                   # one device copy
         else:
@@ -157,7 +163,11 @@ class ShardedVecEnv:
             if self._obs_full[slot] is None:
                 self._obs_full[slot] = template.reshape(1, -1).repeat(self.world * shape[0], 1).contiguous()
             img = self._obs_full[slot]
-            img.index_copy_(1, idx, full[:, :nb_t].reshape(self.world * shape[0], -1))
+            if hasattr(self.local, "unpack_interior"):
+                for r in range(self.world):      # one kernel per peer block (contiguous views, no staging copy): every pixel written once
+                    self.local.unpack_interior(full[r, :nb_t].view(shape[0], -1), img[r * shape[0]:(r + 1) * shape[0]])
+            else:
+                img.index_copy_(1, idx, full[:, :nb_t].reshape(self.world * shape[0], -1))
             obs = {"tactile": img.reshape((self.world * shape[0],) + shape[1:])}
         else:
             obs = {"tactile": full[:, :nb_t].reshape((self.world * shape[0],) + shape[1:])}
@@ -225,6 +235,20 @@ class TorchShard:
     def packed(self):
         return self.venv.packed_torch()
 
+    def pack_interior(self, dst):
+        """This shard's current observations, interior pixels only, into the uint8 device tensor `dst` [n, K] (tg_pack_interior: one kernel
+        on the library's stream)."""
+        import ctypes as C
+        capi.check(self.venv._L.tg_pack_interior(self.venv._ctx, C.c_void_p(dst.data_ptr())))
+
+    def unpack_interior(self, src, dst):
+        """Interiors `src` uint8 [m, K] -> full images `dst` uint8 [m, H*W] with the border ring restored (tg_unpack_interior)."""
+        import ctypes as C
+        m = int(src.shape[0])
+        for lo in range(0, m, 32768):
+            hi = min(m, lo + 32768)
+            capi.check(self.venv._L.tg_unpack_interior(self.venv._ctx, C.c_void_p(src[lo:hi].data_ptr()), hi - lo, C.c_void_p(dst[lo:hi].data_ptr())))
+
     def border_info(self):
         """(flat indices of the pixels inside the border mask, the constant image of the border ring) as device tensors, or None when the
         border paste is off (the ring then carries rendered values)."""
@@ -235,7 +259,12 @@ class TorchShard:
         dev = self.venv.tactile_torch().device
         mask = torch.from_numpy(sd.border_mask.reshape(-1).astype("uint8")).to(dev)
         gray = torch.from_numpy(sd.nodef_gray.reshape(-1).astype("uint8")).to(dev)    # the truncating uint8 cast of tactile_sensor.py:291-292
-        return torch.nonzero(mask != 1).reshape(-1), torch.where(mask == 1, gray, torch.zeros_like(gray))
+        # the payload is made of the 4-pixel words that hold at least one interior pixel, padded to a multiple of 4 words (tg_pack_interior)
+        words = torch.nonzero((mask.reshape(-1, 4) != 1).any(dim=1)).reshape(-1)
+        if words.numel() % 4:
+            words = torch.cat([words, words[-1:].repeat(4 - words.numel() % 4)])
+        idx = (words.reshape(-1, 1) * 4 + torch.arange(4, device=words.device)).reshape(-1)
+        return idx, torch.where(mask == 1, gray, torch.zeros_like(gray))
 
     def _obs(self):
         obs = {"tactile": self.venv.tactile_torch()}

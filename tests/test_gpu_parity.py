@@ -1495,3 +1495,35 @@ def test_terminal_observation_is_the_last_step_before_the_reset(env_id, modes_na
     if key == "extended_feature" and hasattr(a_env, "feature_host"):
         assert np.abs(a_env.feature_host() - oa[key]).max() < 2e-6    # device route == state read-back route
     a_env.close(); b_env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor,size", [("tactip", 128), ("digitac", 128), ("tactip", 64)])
+def test_interior_payload_round_trip_is_bit_exact(edge_modes, sensor, size):
+    """tg_pack_interior / tg_unpack_interior (the multi-GPU gather's interior-only payload): packing the pixels inside the border mask and
+    restoring the constant ring gives back the observation batch bit for bit; also through ShardedVecEnv with one rank (forced)."""
+    import warnings
+    import torch
+    import tactile_gym_amd as tg
+    from tactile_gym_amd.parallel import TorchShard
+    modes = dict(edge_modes, tactile_sensor_name=sensor)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        venv = tg.make_vec("edge_follow-v0", num_envs=96, max_steps=50, image_size=[size, size], env_modes=modes, seed=4, obs_mode="torch")
+    shard = TorchShard(venv)
+    shard.reset()
+    a = torch.zeros((96, 2), device="cuda")
+    for _ in range(3):
+        obs, _, _, _ = shard.step(a.uniform_(-0.25, 0.25))
+    idx, template = shard.border_info()
+    k = idx.numel()
+    assert 0 < k <= size * size            # (DigiTac images have no border ring: k = H W, the payload is then the full image)
+    packed = torch.empty((96, k), dtype=torch.uint8, device="cuda")
+    shard.pack_interior(packed)
+    full = torch.full((96, size * size), 7, dtype=torch.uint8, device="cuda")
+    shard.unpack_interior(packed, full)
+    torch.cuda.synchronize()
+    ref = obs["tactile"].reshape(96, -1)
+    assert torch.equal(packed, ref[:, idx]) and torch.equal(full, ref)
+    assert (ref[:, idx] > 0).any()          # the interiors carry an imprint, not only zeros
+    venv.close()

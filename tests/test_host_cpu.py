@@ -277,3 +277,32 @@ def test_env_classes_subclass_gym_and_sb3_when_importable(monkeypatch):
             monkeypatch.delitem(sys.modules, name, raising=False)
         ve = importlib.reload(ve)
     assert ve.TactileVecEnv.__mro__[1] is object and ve.SingleTactileEnv.__mro__[1] is object
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The ctypes mirrors in tactile_gym_amd/_capi.py against include/tactile_gym_hip.h as a C compiler lays it out: sizeof of every struct
+    that crosses the boundary and the offsets of a few late fields (a mismatch would silently corrupt every call; no GPU needed)."""
+    import ctypes as C
+    import os
+    import subprocess
+    from tactile_gym_amd import _capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    src.write_text('''
+#include <stddef.h>
+#include <stdio.h>
+#include "tactile_gym_hip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(tg_robot), sizeof(tg_sensor), sizeof(tg_mesh), sizeof(tg_config), sizeof(tg_scene), sizeof(tg_state_view));
+    printf("%zu %zu %zu %zu %zu\\n", offsetof(tg_config, contact_mapping), offsetof(tg_config, solver_iterations), offsetof(tg_scene, every_step),
+           offsetof(tg_scene, body_heightfield), offsetof(tg_state_view, contact_ids));
+    return 0;
+}
+''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    sizes, offs = [int(x) for x in out[:6]], [int(x) for x in out[6:]]
+    assert sizes == [C.sizeof(t) for t in (_capi.TgRobot, _capi.TgSensor, _capi.TgMesh, _capi.TgConfig, _capi.TgScene, _capi.TgStateView)]
+    assert offs == [_capi.TgConfig.contact_mapping.offset, _capi.TgConfig.solver_iterations.offset, _capi.TgScene.every_step.offset,
+                    _capi.TgScene.body_heightfield.offset, _capi.TgStateView.contact_ids.offset]

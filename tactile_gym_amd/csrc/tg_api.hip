@@ -646,7 +646,7 @@ static void scene_draw(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
 // lane per env scales with the batch until the chip is full: measured 1024 envs 2.0 ms (wave) against 7.4 ms (lane) per step, 2048 envs
 // 3.9 against 7.5, 4096 envs 7.8 against 7.7, 8192 envs 15.5 against 7.9 (1.04 M env-steps/s).
 static bool use_contact_wave(const tg_ctx* c) {
-    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL) return false;
+    if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL && c->cfg.env_kind != TG_ENV_OBJECT_BALANCE) return false;
     if (c->cfg.physics_dtype != TG_PHYSICS_F64) return false;
     if (c->cfg.contact_mapping == TG_CONTACT_MAP_LANE) return false;
     if (c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE) return true;
@@ -985,7 +985,10 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     {
         Timer t(c, 0);
         if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
-            if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_step_body_t<double>(c, d_act);
+            if (use_contact_wave(c) && launch_step_body_wave(c->cfg.physics_dtype, c->robot.topology, c->cfg.control_mode, c->cfg.num_envs, c->stream, c->d_robot,
+                                                             c->d_const, c->st, d_act) == 0) {
+                // one wavefront per env: the env's own licence, full ticks on the wave mapping (tg_contact_wave.hip)
+            } else if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_step_body_t<double>(c, d_act);
             else launch_step_body_t<float>(c, d_act);
         } else if (use_contact_wave(c) && launch_step_contact_wave(c->cfg.env_kind, c->cfg.physics_dtype, c->robot.topology, c->cfg.control_mode, c->cfg.cone_friction,
                                                                   c->cfg.num_envs, c->cfg.n_tip_verts, c->stream, c->d_robot, c->d_const, c->st, d_act) == 0) {

@@ -14,6 +14,10 @@ int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int 
                              hipStream_t stream,
                              const void* d_robot, const void* d_const, const State& st, const float* d_actions);
 
+// object_balance (arm + pole + point-to-point constraint), TCP_velocity_control, f64, UR5: one wavefront per env (the env's own licence for the
+// analytic fixed point, full ticks on the wave mapping).  -1: not instantiated.
+int launch_step_body_wave(int physics_dtype, int topology, int control_mode, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const,
+                          const State& st, const float* d_actions);
 // env.reset() for the envs flagged in d_mask (nullptr: all) with the same mapping: one wavefront per resetting env, the others exit at once.
 int launch_reset_contact_wave(int env_kind, int physics_dtype, int topology, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
                               const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask);

@@ -1013,6 +1013,330 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
     else finish_push<T, TOPO>(m, c, st, env, q, b, step_count, true);
 }
 
+// ---- object_balance: the full tick (arm + pole + point-to-point constraint) on one wavefront ---------------------------------------------
+// sim_tick_body's full solve (tg_physics.hpp) evaluates the arm dynamics, the (N + 3)^2 Delassus matrix and up to 150 Gauss-Seidel sweeps
+// over N motor rows and 3 P2P rows as one scalar program per lane: ~80 k cycles, which a lane-per-env wavefront pays in every env step as
+// soon as ONE of its 64 envs has no licence for the analytic fixed point (after a reset, every 8th step) - in object_balance that is
+// always.  Here the tick runs on the env's own wavefront: tick_dynamics_lanes for the arm, one solver row per lane (lane i < N motor i,
+// lane 8 + x the P2P row along world axis x), residual form with accumulator lanes as in sim_tick_contact_wave.  No row of this system
+// has a one-sided limit, so while no impulse reaches its bound (watched on lanes 48..) a whole sweep is ONE linear map of the row lanes'
+// residuals, x -= sum_m C_m x_m, with C built once per tick for the forward and the reverse row order (see the motor pass above).
+// Same convergence exit and licence rule as sim_tick_body; returns the new value of `verified` (24: converged within 80 % of the sweep
+// budget, 0: not).  State in / out through LDS like sim_tick_contact_wave.
+template <typename T, int TOPO, int MOTOR>
+__device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const BodyConst<T>& bc, lds_ptr<T> L, T kp, T kd, T max_force, T dt, int iters,
+                                                 V3<T> gravity, V3<T> pivot_b, V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int lane_in) {
+    constexpr int N = Topo<TOPO>::N;
+    constexpr int NP = Topo<TOPO>::NP;
+    constexpr int NR = N + 3;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+#if TG_WAVE_TIMING
+    unsigned long long t_prev_ = __builtin_readcyclecounter();
+    tick_dynamics_lanes<T, TOPO>(&m, L, bc.link, dt, lane, t_prev_);
+#else
+    tick_dynamics_lanes<T, TOPO>(&m, L, bc.link, dt, lane);
+#endif
+    TG_PHASE_FENCE()
+    // ---- pole: unconstrained velocities, pivots
+    FreeBody<T> b;
+    b.pos = mk(L[kLBody + 0], L[kLBody + 1], L[kLBody + 2]);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) b.R.m[e] = L[kLBody + 3 + e];
+    b.v = mk(L[kLBody + 12], L[kLBody + 13], L[kLBody + 14]);
+    b.w = mk(L[kLBody + 15], L[kLBody + 16], L[kLBody + 17]);
+    const S3<T> Iw = rotate(b.R, bc.inertia), Iwi = inverse(Iw);
+    const V3<T> xc = b.pos + mul(b.R, bc.com);
+    V3<T> F = bc.mass * gravity, Nt = mk<T>(0, 0, 0);
+    if (ext_pending) { F = F + ext_force; Nt = Nt + cross(ext_pos - xc, ext_force); }
+    Nt = Nt - cross(b.w, mul(Iw, b.w));
+    const T invm = T(1) / bc.mass;
+    const V3<T> vb = b.v + (dt * invm) * F, wb = b.w + dt * mul(Iwi, Nt);
+    const V3<T> ol = mk(L[kLTipF + 0], L[kLTipF + 1], L[kLTipF + 2]);
+    M3<T> Rl;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rl.m[e] = L[kLTipF + 3 + e];
+    const V3<T> pa = ol + mul(Rl, bc.pivot_a), pb = b.pos + mul(b.R, pivot_b), rb = pb - xc;
+    V3<T> jt[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        jt[i] = cross(mk(L[kLJa + 3 * i], L[kLJa + 3 * i + 1], L[kLJa + 3 * i + 2]), pa - mk(L[kLJo + 3 * i], L[kLJo + 3 * i + 1], L[kLJo + 3 * i + 2]));
+    // ---- this lane's row: J = [ja | -e_x | -(rb x e_x)] on a P2P lane, e_i on a motor lane; W = Minv_sys J^T
+    const bool motor_lane = lane < N, p2p_lane = lane >= 8 && lane < 11;
+    const int ax = lane - 8;
+    const V3<T> ex = mk(ax == 0 ? T(1) : T(0), ax == 1 ? T(1) : T(0), ax == 2 ? T(1) : T(0));
+    T ja[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) ja[i] = motor_lane ? (lane == i ? T(1) : T(0)) : ((p2p_lane && i < NP) ? dot(jt[i < NP ? i : 0], ex) : T(0));
+    T Warm[N], rv = T(0), rm = T(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc += L[kLMinv + 8 * k + i] * ja[i];
+        Warm[k] = acc;
+        const T vk = L[kLV + k];
+        rv += ja[k] * vk;
+        const T pos_term = (MOTOR == kMotorPosition) ? kp * (L[kLQDes + k] - L[kLQ + k]) / dt : T(0);
+        const T des = pos_term + vk + kd * (L[kLQdDes + k] - vk);
+        rm = lane == k ? des - vk : rm;
+    }
+    const V3<T> Jl = p2p_lane ? mk<T>(0, 0, 0) - ex : mk<T>(0, 0, 0), Ja = p2p_lane ? mk<T>(0, 0, 0) - cross(rb, ex) : mk<T>(0, 0, 0);
+    const V3<T> Wl = invm * Jl, Wa = mul(Iwi, Ja);
+    T A = dot(Jl, Wl) + dot(Ja, Wa);
+#pragma unroll
+    for (int i = 0; i < N; ++i) A += ja[i] * Warm[i];
+    rv += dot(Jl, vb) + dot(Ja, wb);                      // J . (unconstrained velocity): va - (vb + wb x rb) on a P2P lane
+    const V3<T> gap = pa - pb;
+    const T rhs = motor_lane ? rm : (-bc.erp * dot(gap, ex) / dt - rv);
+    const bool active = motor_lane ? (MOTOR != kMotorOff) : p2p_lane;
+    const T jdi = active ? T(1) / A : T(0);
+    // ---- coefficient rows (row index i < N: motor i, N + x: P2P axis x), accumulator lanes 32.. (du: 8 joints, pole linear 3, angular 3),
+    //      watch lanes 48 + i (impulse of row i)
+    T G[NR];
+#pragma unroll
+    for (int i = 0; i < N; ++i) G[i] = Warm[i] * jdi;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        const V3<T> e = mk(x == 0 ? T(1) : T(0), x == 1 ? T(1) : T(0), x == 2 ? T(1) : T(0));
+        T a = -dot(e, Wl) - dot(cross(rb, e), Wa);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) a += dot(jt[i], e) * Warm[i];
+        G[N + x] = a * jdi;
+    }
+    const int my_row = motor_lane ? lane : (p2p_lane ? N + ax : -1);
+    {
+        __syncthreads();
+        if (my_row >= 0) {
+            const T keep_ = active ? T(1) : T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) L[kLW + my_row * 16 + k] = k < N ? Warm[k < N ? k : 0] * keep_ : T(0);
+            L[kLW + my_row * 16 + 8] = Wl.x * keep_; L[kLW + my_row * 16 + 9] = Wl.y * keep_; L[kLW + my_row * 16 + 10] = Wl.z * keep_;
+            L[kLW + my_row * 16 + 11] = Wa.x * keep_; L[kLW + my_row * 16 + 12] = Wa.y * keep_; L[kLW + my_row * 16 + 13] = Wa.z * keep_;
+        }
+        __syncthreads();
+        const int ku = lane - 32;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const T wv = L[kLW + i * 16 + (ku >= 0 && ku < kNU ? ku : 0)];
+            const T g_row = my_row == i ? T(1) : G[i];
+            G[i] = (ku >= 0 && ku < kNU) ? -wv : ((lane >= 48 && lane < 48 + NR) ? (i == lane - 48 ? T(-1) : T(0)) : (my_row >= 0 ? g_row : T(0)));
+        }
+    }
+    // ---- one Gauss-Seidel pass over the NR rows as a linear map of the row lanes' residuals, forward and reverse order
+    T Cf[NR], Cr[NR];
+    {
+        __syncthreads();
+        if (my_row >= 0) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) L[kLW + my_row * 16 + k] = G[k];     // L[i][k] = G_k on the lane of row i
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < NR; ++mm) {
+            T t[NR];
+            t[mm] = T(1);
+            T c = G[mm];
+#pragma unroll
+            for (int i = mm + 1; i < NR; ++i) {
+                T acc = T(0);
+#pragma unroll
+                for (int k = mm; k < i; ++k) acc = __builtin_fma(L[kLW + i * 16 + k], t[k], acc);
+                t[i] = -acc;
+                c = __builtin_fma(G[i], t[i], c);
+            }
+            Cf[mm] = c;
+        }
+#pragma unroll
+        for (int mm = 0; mm < NR; ++mm) {
+            T t[NR];
+            t[mm] = T(1);
+            T c = G[mm];
+#pragma unroll
+            for (int i = mm - 1; i >= 0; --i) {
+                T acc = T(0);
+#pragma unroll
+                for (int k = i + 1; k <= mm; ++k) acc = __builtin_fma(L[kLW + i * 16 + k], t[k], acc);
+                t[i] = -acc;
+                c = __builtin_fma(G[i], t[i], c);
+            }
+            Cr[mm] = c;
+        }
+    }
+    const T x0 = my_row >= 0 ? rhs * jdi : T(0);
+    T thr = tabs(x0);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) thr = tmax(thr, __shfl_xor(thr, o));     // rows live in lanes 0..10: max over the first 16 lanes
+    thr = bcast(thr, 0);
+    thr = iters < 0 ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
+    const int n_it = iters < 0 ? -iters : iters;
+    const T lim = lane >= 48 + N ? bc.max_impulse : max_force * dt;           // watch lanes: motor rows, then the P2P rows
+    const bool watch_lane = lane >= 48 && lane < 48 + NR;
+    auto row_lane = [](int i) { return i < N ? i : 8 + (i - N); };
+    T x = x0, wmax = T(0);
+    int conv_sweeps = -1;
+    for (int it = 0; it < n_it; ++it) {
+        if ((it & 7) == 0 && it > 0) {                    // the exit of sim_tick_body: every residual below 2^-56 of the largest start value
+            T mx = my_row >= 0 ? tabs(x) : T(0);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = tmax(mx, __shfl_xor(mx, o));
+            if (uniform_true(bcast(mx, 0) <= thr)) { conv_sweeps = it; break; }
+        }
+        T xm[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) xm[k] = bcast(x, row_lane(k));
+        T da = T(0), db = T(0);
+        if (it & 1) {
+#pragma unroll
+            for (int k = 0; k < NR; k += 2) { da = __builtin_fma(Cf[k], xm[k], da); if (k + 1 < NR) db = __builtin_fma(Cf[k + 1], xm[k + 1], db); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NR; k += 2) { da = __builtin_fma(Cr[k], xm[k], da); if (k + 1 < NR) db = __builtin_fma(Cr[k + 1], xm[k + 1], db); }
+        }
+        x -= da + db;
+        wmax = vmax_abs(wmax, x);
+    }
+    if (uniform_true(watch_lane && wmax > lim)) {
+        // an impulse reached its bound: the literal clamped iteration, row by row (never seen with the reference's limits; kept for safety)
+        x = x0;
+        T lam = T(0);
+        conv_sweeps = -1;
+        const T limr = p2p_lane ? bc.max_impulse : max_force * dt;
+        for (int it = 0; it < n_it; ++it) {
+#pragma unroll
+            for (int kk = 0; kk < NR; ++kk) {
+                const int i = (it & 1) ? kk : NR - 1 - kk;
+                const T dd = bcast(vmin(vmax(x, -limr - lam), limr - lam), row_lane(i));
+                lam = my_row == i ? lam + dd : lam;
+                x = __builtin_fma(-G[i], dd, x);
+            }
+        }
+    }
+    // ---- integrate
+    T du[kNU];
+#pragma unroll
+    for (int k = 0; k < kNU; ++k) du[k] = bcast(x, 32 + k);
+    {
+        T q[N], qd[N];
+        JointTrig<T, N> trig;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            qd[i] = L[kLV + i] + du[i];
+            q[i] = L[kLQ + i] + dt * qd[i];
+        }
+        trig_init<T, N>(q, trig);                         // a full tick re-anchors the carried sines / cosines exactly
+        FreeBody<T> bn;
+        bn.R = b.R;
+        bn.v = vb + mk(du[8], du[9], du[10]);
+        bn.w = wb + mk(du[11], du[12], du[13]);
+        const V3<T> xn = xc + dt * bn.v;
+        integrate_rotation(bn.R, bn.w, dt);
+        bn.pos = xn - mul(bn.R, bc.com);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { L[kLQ + i] = q[i]; L[kLQd + i] = qd[i]; L[kLTrigS + i] = trig.s[i]; L[kLTrigC + i] = trig.c[i]; }
+            L[kLBody + 0] = bn.pos.x; L[kLBody + 1] = bn.pos.y; L[kLBody + 2] = bn.pos.z;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) L[kLBody + 3 + e] = bn.R.m[e];
+            L[kLBody + 12] = bn.v.x; L[kLBody + 13] = bn.v.y; L[kLBody + 14] = bn.v.z;
+            L[kLBody + 15] = bn.w.x; L[kLBody + 16] = bn.w.y; L[kLBody + 17] = bn.w.z;
+        }
+    }
+    TG_PHASE_FENCE()
+    return (iters > 0 && conv_sweeps > 0 && 5 * conv_sweeps <= 4 * iters) ? 24 : 0;
+}
+
+// BaseTactileEnv.step for object_balance (TCP_velocity_control), one wavefront per env: the licence for the analytic fixed point is the env's
+// own (wave-uniform here), so the 12 ticks of a licensed step are sim_tick_body's analytic branch (evaluated by every lane alike) and a full
+// tick - after a reset, every 8th step - is sim_tick_p2p_wave.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                       const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double wave_lds_raw[];
+    const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const int n = c.num_envs;
+    const bool w0 = lane == 0;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    FreeBody<T> b = load_body<T>(st, n, env);
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};      // encode_actions (object_balance_env.py:398-424)
+    const float* a = actions + (size_t)env * c.act_dim;
+    if (c.movement_mode == TG_BMOVE_XY) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; }
+    else if (c.movement_mode == TG_BMOVE_XYZ) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2]; }
+    else if (c.movement_mode == TG_BMOVE_RXRY) { enc[3] = (T)a[0]; enc[4] = (T)a[1]; }
+    else { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[3] = (T)a[2]; enc[4] = (T)a[3]; }
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    T qd_des[N];
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+    const T embed = (T)st.embed[env];
+    const V3<T> grav = mk(T(0), T(0), (T)st.gravity[env]);
+    const V3<T> pivot_b = mk(T(0), T(0), -c.obj_base_height / T(2) + embed);
+    const V3<T> fext = load_v3(c.ext_force);
+    const V3<T> pext = mk((T)st.ext_pos[0 * n + env], (T)st.ext_pos[1 * n + env], (T)st.ext_pos[2 * n + env]);
+    const bool pending = st.ext_pending[env] != 0;
+    const int lic = st.licence[env];
+    stage_link_constants<T, TOPO>(mp, L, lane);
+    T qdummy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) qdummy[i] = T(0);
+    JointTrig<T, N> trig;
+    trig_init<T, N>(q, trig);
+    int verified = lic > 0 ? 24 : 0;
+    bool ran_full = false;
+    for (int t = 0; t < c.action_repeat; ++t) {
+        if (verified > 0) {
+            const int before = verified;
+            sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body, pivot_b,
+                                                   fext, pext, pending && t == 0, &verified, &trig);
+            if (verified != before - 1) ran_full = true;  // its a-priori test failed: it ran its own full solve (sets 24 or 0)
+        } else {
+            __syncthreads();
+            if (w0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool in = i < N;
+                    L[kLQ + i] = in ? q[in ? i : 0] : T(0); L[kLQd + i] = in ? qd[in ? i : 0] : T(0);
+                    L[kLTrigS + i] = in ? trig.s[in ? i : 0] : T(0); L[kLTrigC + i] = in ? trig.c[in ? i : 0] : T(1);
+                    L[kLQDes + i] = T(0); L[kLQdDes + i] = in ? qd_des[in ? i : 0] : T(0);
+                }
+                L[kLBody + 0] = b.pos.x; L[kLBody + 1] = b.pos.y; L[kLBody + 2] = b.pos.z;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) L[kLBody + 3 + e] = b.R.m[e];
+                L[kLBody + 12] = b.v.x; L[kLBody + 13] = b.v.y; L[kLBody + 14] = b.v.z;
+                L[kLBody + 15] = b.w.x; L[kLBody + 16] = b.w.y; L[kLBody + 17] = b.w.z;
+            }
+            TG_PHASE_FENCE()
+            verified = sim_tick_p2p_wave<T, TOPO, kMotorVelocity>(m, c.body, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, pivot_b, fext, pext,
+                                                                  pending && t == 0, lane);
+            ran_full = true;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; trig.s[i] = L[kLTrigS + i]; trig.c[i] = L[kLTrigC + i]; }
+            b.pos = mk(L[kLBody + 0], L[kLBody + 1], L[kLBody + 2]);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) b.R.m[e] = L[kLBody + 3 + e];
+            b.v = mk(L[kLBody + 12], L[kLBody + 13], L[kLBody + 14]);
+            b.w = mk(L[kLBody + 15], L[kLBody + 16], L[kLBody + 17]);
+        }
+    }
+    if (w0) {
+        st.step_count[env] = step_count;
+        st.licence[env] = ran_full ? (verified > 0 ? 8 : 0) : lic - 1;
+        st.ext_pending[env] = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = (double)qd_des[i]; }
+        store_body<T>(st, n, env, b);
+    }
+    finish_body<T, TOPO>(m, c, st, env, q, b, embed, step_count, true);
+}
+
 // env.reset() of object_push (SHAPE 0) / object_roll (SHAPE 1) for the envs flagged in `mask`, one wavefront per resetting env (the
 // lane-per-env k_reset_push / k_reset_roll run every resetting env's blocking move at the pace of a 64-env wavefront: 0.8 ms per launch with
 // a reset in object_roll, where some env finishes on nearly every step).  Same sequence as those kernels: episode draws, rest pose,
@@ -1193,6 +1517,14 @@ int launch_reset_wave_t(int cone, int n, int n_tip, hipStream_t stream, const vo
 }
 
 }  // namespace
+
+int launch_step_body_wave(int physics_dtype, int topology, int control_mode, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const,
+                          const State& st, const float* d_actions) {
+    if (physics_dtype != TG_PHYSICS_F64 || topology != 0 || control_mode != TG_CONTROL_TCP_VELOCITY) return -1;
+    hipLaunchKernelGGL((k_step_body_wave<double, 0>), dim3(num_envs), dim3(64), (size_t)kLHull * sizeof(double), stream, (const DevRobot<double>*)d_robot,
+                       (const EnvConst<double>*)d_const, st, d_actions);
+    return 0;
+}
 
 int launch_reset_contact_wave(int env_kind, int physics_dtype, int topology, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
                               const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask) {

@@ -1057,6 +1057,7 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
         if (pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1)) break;
     }
     st.reset_ticks[env] = used;
+    st.licence[env] = 0;   // a new configuration: the next step verifies its solve again (k_step_body_wave)
     // reset_object (object_balance_env.py:330-381): teleport, then a one-shot downward force at a random point of the base plate
     b.pos = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - (T)embed);
     b.R = c.obj_init_rot;

@@ -96,8 +96,9 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class ObjectBalanceVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True, contact_mapping="auto"):
         cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
+        cfg.contact_mapping = capi.CONTACT_MAP[contact_mapping]   # "wave": one wavefront per env (k_step_body_wave), "lane": one lane per env
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action

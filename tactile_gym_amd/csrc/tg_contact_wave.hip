@@ -1248,8 +1248,8 @@ __device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const Bod
 }
 
 // BaseTactileEnv.step for object_balance (TCP_velocity_control), one wavefront per env: the licence for the analytic fixed point is the env's
-// own (wave-uniform here), so the 12 ticks of a licensed step are sim_tick_body's analytic branch (evaluated by every lane alike) and a full
-// tick - after a reset, every 8th step - is sim_tick_p2p_wave.
+// own (wave-uniform here), so the 12 ticks of a licensed step are the analytic tick (body_tick_analytic, evaluated by every lane alike) and a
+// full tick - after a reset, every 8th step, or when the analytic tick's a-priori test fails - is sim_tick_p2p_wave.
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                        const float* __restrict__ actions) {
@@ -1292,12 +1292,11 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     int verified = lic > 0 ? 24 : 0;
     bool ran_full = false;
     for (int t = 0; t < c.action_repeat; ++t) {
-        if (verified > 0) {
-            const int before = verified;
-            sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body, pivot_b,
-                                                   fext, pext, pending && t == 0, &verified, &trig);
-            if (verified != before - 1) ran_full = true;  // its a-priori test failed: it ran its own full solve (sets 24 or 0)
-        } else {
+        const bool analytic = verified > 0 && c.solver_iters >= 0 && m.vel_gain == T(1) &&
+                              body_tick_analytic<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.max_force, c.dt, grav, b, c.body, pivot_b, fext, pext,
+                                                                          pending && t == 0, &trig);
+        if (analytic) --verified;
+        else {
             __syncthreads();
             if (w0) {
 #pragma unroll

@@ -650,21 +650,14 @@ template <typename T> __device__ __forceinline__ void integrate_rotation(M3<T>& 
     R.m[2] = c2.x; R.m[5] = c2.y; R.m[8] = c2.z;
 }
 
+// The analytic fixed point of one arm + body + P2P tick (see sim_tick_body): advances q, qd, the carried sines / cosines and the body and
+// returns true when its a-priori test holds for the whole wavefront; returns false with nothing changed otherwise (the caller then solves).
 template <typename T, int TOPO, int MOTOR>
-__device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
-                                              const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
-                                              int iters, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b,
-                                              V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int* verified = nullptr,
-                                              JointTrig<T, Topo<TOPO>::N>* trig = nullptr /* carried sines / cosines (k_step_body) */) {
+__device__ __forceinline__ bool body_tick_analytic(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
+                                                   const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T max_force, T dt, V3<T> gravity,
+                                                   FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b, V3<T> ext_force, V3<T> ext_pos, bool ext_pending,
+                                                   JointTrig<T, Topo<TOPO>::N>* trig) {
     constexpr int N = Topo<TOPO>::N;
-    constexpr int NR = N + 3;
-    // Analytic fixed point (see sim_tick).  The motor rows still prescribe the whole arm velocity, whatever the P2P rows pull: at the
-    // solution of the unclamped system the arm moves with `des` and the three P2P impulses solve the body-only system
-    //   (1/m I + [rb x]^T Iw^-1 [rb x]) lambda = -erp gap/dt - (J_a des - v_pivot_b)        (3x3 SPD, solved directly),
-    // the motors absorbing the reaction.  Same licence as in sim_tick: a full solve of this env step must have converged to the last
-    // bit within 80 % of the sweep budget (the coupled iteration contracts like the arm's alone, ~0.5 per sweep), and no row may be
-    // able to reach its limit (motor bound extended by the P2P reaction, P2P impulse far from its 500 N s cap).
-    if (MOTOR != kMotorOff && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0) {
         T des[N], dvw = T(0), v2 = T(0);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -720,6 +713,27 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
             xc = xc + dt * b.v;
             integrate_rotation(b.R, b.w, dt);
             b.pos = xc - mul(b.R, bc.com);
+            return true;
+        }
+    return false;
+}
+
+template <typename T, int TOPO, int MOTOR>
+__device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
+                                              const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
+                                              int iters, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b,
+                                              V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int* verified = nullptr,
+                                              JointTrig<T, Topo<TOPO>::N>* trig = nullptr /* carried sines / cosines (k_step_body) */) {
+    constexpr int N = Topo<TOPO>::N;
+    constexpr int NR = N + 3;
+    // Analytic fixed point (see sim_tick).  The motor rows still prescribe the whole arm velocity, whatever the P2P rows pull: at the
+    // solution of the unclamped system the arm moves with `des` and the three P2P impulses solve the body-only system
+    //   (1/m I + [rb x]^T Iw^-1 [rb x]) lambda = -erp gap/dt - (J_a des - v_pivot_b)        (3x3 SPD, solved directly),
+    // the motors absorbing the reaction.  Same licence as in sim_tick: a full solve of this env step must have converged to the last
+    // bit within 80 % of the sweep budget (the coupled iteration contracts like the arm's alone, ~0.5 per sweep), and no row may be
+    // able to reach its limit (motor bound extended by the P2P reaction, P2P impulse far from its 500 N s cap).
+    if (MOTOR != kMotorOff && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0) {
+        if (body_tick_analytic<T, TOPO, MOTOR>(m, q, qd, q_des, qd_des, kp, max_force, dt, gravity, b, bc, pivot_b, ext_force, ext_pos, ext_pending, trig)) {
             --*verified;
             return;
         }

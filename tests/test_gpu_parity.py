@@ -1527,3 +1527,50 @@ def test_interior_payload_round_trip_is_bit_exact(edge_modes, sensor, size):
     assert torch.equal(packed, ref[:, idx]) and torch.equal(full, ref)
     assert (ref[:, idx] > 0).any()          # the interiors carry an imprint, not only zeros
     venv.close()
+
+
+@pytest.mark.parametrize("env_id,overrides,act_dim,size", [
+    ("edge_follow-v0", dict(movement_mode="xyRz", noise_mode="fixed_height", tactile_sensor_name="digit"), 3, 128),
+    ("edge_follow-v0", dict(movement_mode="xyzRz", tactile_sensor_name="digitac"), 4, 128),
+    ("edge_follow-v0", dict(movement_mode="xyz", arm_type="mg400", tactile_sensor_name="digit"), 3, 128),
+    ("edge_follow-v0", dict(movement_mode="xy", arm_type="mg400", tactile_sensor_name="digitac", noise_mode="fixed_height"), 2, 64),
+    ("edge_follow-v0", dict(movement_mode="xyz", noise_mode="fixed_height"), 3, 256),
+    ("object_balance-v0", dict(movement_mode="xyz"), 3, 64),
+    ("object_balance-v0", dict(movement_mode="RxRy", rand_gravity=False), 2, 64),
+    ("object_balance-v0", dict(movement_mode="xyRxRy", rand_embed_dist=False), 4, 128),
+])
+def test_mode_matrix_matches_oracle(env_id, overrides, act_dim, size, edge_modes):
+    """The env_modes the other tests leave out (edge_follow movement modes x sensors x arms, fixed_height; object_balance's velocity-control
+    movement modes and its randomisation switches): reset + 4 random-action steps, 4 envs vs 4 oracle envs."""
+    import warnings
+    import tactile_gym_amd as tg
+    from oracle import ref_env
+    edge = env_id.startswith("edge")
+    modes = dict(edge_modes if edge else BAL_MODES, **overrides)
+    Oracle = ref_env.OracleEdgeFollowEnv if edge else ref_env.OracleObjectBalanceEnv
+    n = 4
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")     # digit 64 x 64 reference images are outside the pinned set (A14b); HIP and oracle share them
+        venv = tg.make_vec(env_id, num_envs=n, max_steps=50, image_size=[size, size], env_modes=modes, seed=301, auto_reset=False)
+        oracles = [Oracle(seed=301 + i, max_steps=50, image_size=(size, size), env_modes=modes) for i in range(n)]
+    obs = venv.reset()
+    ref = [o.reset() for o in oracles]
+    st = venv.get_state()
+    for i, o in enumerate(oracles):
+        assert st["reset_ticks"][i] == o.reset_ticks
+        assert np.abs(st["q"][i] - o.arm.q).max() < 1e-7
+        assert int((obs["tactile"][i] != ref[i]["tactile"]).sum()) <= 3
+    rng = np.random.default_rng(302)
+    for step in range(4):
+        a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+        obs, rew, done, _ = venv.step(a)
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            ro, rr, rd, _ = o.step(a[i])
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-7, (step, i)
+            if not edge:
+                pos, R = o.body_pose()
+                assert np.abs(st["body_pos"][i] - pos).max() < 1e-7 and np.abs(st["body_rot"][i] - R).max() < 1e-7, (step, i)
+            assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd, (step, i)
+            assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (step, i)
+    venv.close()

@@ -43,6 +43,27 @@ template <int MODE> __global__ void k(double* out, long long* cyc, int iters, do
                 s = __builtin_fma(-g, d1, s); s = __builtin_fma(-g2, d2, s);
                 if (MODE == 10) asm volatile("s_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %1\n\ts_mov_b64 exec, -1" : "+v"(lam) : "v"(dl), "n"(0x600));
             }
+            else if (MODE >= 20 && MODE <= 23) {   // the kernel's lane-local friction step: 20 as shipped (v_min), 21 clamp modifier, 22 f32 seed + clamp, 23 f32 seed two Newton
+                union { double d; int i[2]; } u; u.d = s;
+                u.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], 0xD8, 0xF, 0xF, true); u.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], 0xD8, 0xF, 0xF, true);
+                const double xp = u.d, limit = g2;
+                const double tot2 = __builtin_fma(xp, xp, s * s);
+                double f;
+                if (MODE == 20 || MODE == 21) {
+                    const double y = __builtin_amdgcn_rsq(tot2);
+                    const double t = tot2 * y, ly = limit * y, lh = 0.5 * ly, e = __builtin_fma(-t, y, 1.0);
+                    if (MODE == 20) { const double f0 = __builtin_fma(lh, e, ly); asm("v_min_f64 %0, %1, %2" : "=v"(f) : "v"(f0), "v"(1.0)); }
+                    else asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(f) : "v"(lh), "v"(e), "v"(ly));
+                } else {
+                    const double y = (double)__builtin_amdgcn_rsqf((float)tot2);
+                    const double t = tot2 * y, ly = limit * y, lh = 0.5 * ly, e = __builtin_fma(-t, y, 1.0);
+                    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(f) : "v"(lh), "v"(e), "v"(ly));
+                }
+                const double dl = __builtin_fma(s, f, -lam);
+                lam = __builtin_fma(g0, dl, lam);
+                const double d1 = bcast_sgpr(dl, 9), d2 = bcast_sgpr(dl, 10);
+                s = __builtin_fma(-g, d1, s); s = __builtin_fma(-g2, d2, s);
+            }
             else if (MODE == 5) { float sf = (float)s; float d = __shfl(sf, i); s = __builtin_fma(-g, (double)d, s); }   // ds_bpermute path
         }
     }
@@ -96,6 +117,9 @@ int main() {
         run<9>("vmax_neg + readlane x2 + fma + exec add", blocks);
         run<11>("friction step, no lambda update", blocks);
         run<10>("friction step + exec-masked add", blocks);
+        run<20>("lane-local friction step as shipped (v_min)", blocks);
+        run<21>("lane-local friction step, clamp modifier", blocks);
+        run<22>("lane-local friction step, f32 rsq seed + clamp", blocks);
     }
     return 0;
 }

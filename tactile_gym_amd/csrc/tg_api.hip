@@ -373,7 +373,7 @@ struct tg_ctx {
     bool scene_on = false, scene_every_step = false;
     float *d_scene_verts = nullptr, *d_scene_xf = nullptr;
     int32_t* d_scene_tris = nullptr;
-    uint32_t* d_scene_attr = nullptr;
+    uint32_t *d_scene_attr = nullptr, *d_scene_local = nullptr;
     tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
     int32_t *d_int_idx = nullptr, *d_int_rank = nullptr;   // interior-only payload: pixel of interior position k / interior position of pixel p (-1: ring)
@@ -934,11 +934,12 @@ int tg_destroy(tg_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
+    if (c->scene_on) scene_debug_stats();
     for (int k = 0; k < 2; ++k) if (c->step_graph[k]) (void)hipGraphExecDestroy(c->step_graph[k]);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1227,20 +1228,24 @@ int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
     const size_t n = (size_t)c->cfg.num_envs, img = (size_t)W * H * 3;
     std::vector<int32_t> tris(sc->tris, sc->tris + (size_t)sc->n_tris * 3);
     std::vector<SceneChunk> chunks;
-    build_scene_chunks(sc->verts, tris.data(), attr.data(), sc->n_tris, chunks);
+    std::vector<float> cverts;            // chunk-ordered vertex copies (tg_scene.h)
+    std::vector<uint32_t> tri_local;
+    build_scene_chunks(sc->verts, tris.data(), attr.data(), sc->n_tris, chunks, cverts, tri_local);
     if (chunks.size() > 8192) return fail(-1, "tg_set_scene: too many triangle chunks");
     TG_HIP(hipMalloc(&c->d_scene_chunks, chunks.size() * sizeof(SceneChunk)));
     TG_HIP(hipMemcpy(c->d_scene_chunks, chunks.data(), chunks.size() * sizeof(SceneChunk), hipMemcpyHostToDevice));
     P.chunks = c->d_scene_chunks; P.n_chunks = (int)chunks.size();
-    TG_HIP(hipMalloc(&c->d_scene_verts, (size_t)sc->n_verts * 12)); TG_HIP(hipMalloc(&c->d_scene_tris, (size_t)sc->n_tris * 12));
+    TG_HIP(hipMalloc(&c->d_scene_verts, cverts.size() * 4 + 16)); TG_HIP(hipMalloc(&c->d_scene_tris, (size_t)sc->n_tris * 12));
+    TG_HIP(hipMalloc(&c->d_scene_local, (size_t)sc->n_tris * 4));
     TG_HIP(hipMalloc(&c->d_scene_attr, (size_t)sc->n_tris * 4)); TG_HIP(hipMalloc(&c->d_scene_xf, n * n_frames * 12 * 4));
     TG_HIP(hipMalloc(&c->d_vis, n * img)); TG_HIP(hipMalloc(&c->d_vis_term, n * img));
-    TG_HIP(hipMemcpy(c->d_scene_verts, sc->verts, (size_t)sc->n_verts * 12, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(c->d_scene_verts, cverts.data(), cverts.size() * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(c->d_scene_local, tri_local.data(), (size_t)sc->n_tris * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMemcpy(c->d_scene_tris, tris.data(), (size_t)sc->n_tris * 12, hipMemcpyHostToDevice));
     TG_HIP(hipMemcpy(c->d_scene_attr, attr.data(), (size_t)sc->n_tris * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMemset(c->d_vis, 0, n * img)); TG_HIP(hipMemset(c->d_vis_term, 0, n * img));
-    P.verts = c->d_scene_verts; P.tris = c->d_scene_tris; P.tri_attr = c->d_scene_attr;
-    if (scene_prepare() != 0) return fail(-1, "tg_set_scene: hipFuncSetAttribute failed");
+    P.verts = c->d_scene_verts; P.tris = c->d_scene_tris; P.tri_attr = c->d_scene_attr; P.tri_local = c->d_scene_local;
+    if (scene_prepare(P) != 0) return fail(-1, "tg_set_scene: the scene's chunk list does not fit the workgroup's LDS (or hipFuncSetAttribute failed)");
     c->scene = P;
     c->scene_on = true;
     c->scene_every_step = sc->every_step != 0;

@@ -11,15 +11,18 @@ namespace tg {
 // triangle rigid in one of n_frames frames (0 world, 1 + i moving link i, n_frames - 1 the task's stimulus / free body); per env the
 // eye <- frame transforms [n_frames][12] (R row-major, t) rounded once to float.  Projection constants are derived on the host in
 // double and rounded once, as for the tactile camera: window x = hw + kx x/w, y = hh - ky y/w (w = -z_eye), aspect = W / H.
-struct SceneChunk { float cx, cy, cz, r; int start, count, frame, pad; };
+// vstart / vcount: the chunk's own copy of its (<= 64) distinct vertices, contiguous in `verts`, so that a wavefront transforms each vertex
+// of the chunk once (a lane per vertex) and the chunk's triangles pick their corners by a one-byte local index.
+struct SceneChunk { float cx, cy, cz, r; int start, frame, vstart; uint16_t count, vcount; };
 
 struct SceneParams {
     int W, H, n_tris, n_frames;
     float kx, ky, hw, hh, near_, far_, inv_near, inv_far;
     float light_eye[3];            // unit vector towards the light, eye space
     uint8_t background[3];
-    const float* verts;            // device [n_verts][3]
-    const int32_t* tris;           // device [n_tris][3]
+    const float* verts;            // device [n_cverts][3]: chunk-ordered (a vertex shared by two chunks is stored once in each)
+    const int32_t* tris;           // device [n_tris][3], indices into verts
+    const uint32_t* tri_local;     // device [n_tris]: the same three corners relative to the chunk's vstart, i0 | i1 << 8 | i2 << 16
     const uint32_t* tri_attr;      // device [n_tris]: frame << 24 | r << 16 | g << 8 | b
     const SceneChunk* chunks;      // device [n_chunks]: runs of <= 64 spatially sorted triangles of one frame with a bounding sphere
     int n_chunks;
@@ -35,13 +38,16 @@ struct SceneParams {
 
 SceneParams make_scene_params(int W, int H, double fov_deg, double near_, double far_);
 
-// Sorts the triangles by (frame, Morton code of the centroid) - the image does not depend on their order - and cuts them into chunks.
-void build_scene_chunks(const float* verts, int32_t* tris /*[n][3], reordered*/, uint32_t* attr /*[n], reordered*/, int n_tris,
-                        std::vector<SceneChunk>& chunks);
+// Sorts the triangles by (frame, Morton code of the centroid) - the image does not depend on their order - and cuts them into chunks of
+// <= 64 triangles with <= 64 distinct vertices; cverts receives the chunk-ordered vertex copies, tris is re-pointed at them.
+void build_scene_chunks(const float* verts, int32_t* tris /*[n][3], reordered + re-indexed*/, uint32_t* attr /*[n], reordered*/, int n_tris,
+                        std::vector<SceneChunk>& chunks, std::vector<float>& cverts, std::vector<uint32_t>& tri_local);
 
 // Draws out[env] (uint8 [H][W][3]) for every env (mask == nullptr) or the envs whose mask byte is non-zero; with save_prev the
 // previous image of a drawn env is first copied to save_prev[env] (the terminal observation of an auto-reset).
 void launch_scene(const SceneParams& P, const float* xf, int n_envs, const uint8_t* mask, uint8_t* out, uint8_t* save_prev, hipStream_t stream);
-int scene_prepare();               // one-time kernel attributes (large dynamic LDS); call outside stream capture
+int scene_prepare(const SceneParams& P);   // one-time kernel attributes (large dynamic LDS); call outside stream capture; non-zero: the scene does not fit
+
+void scene_debug_stats();          // -DTG_SCENE_STATS builds: per-workgroup work counters to stderr (development)
 
 }  // namespace tg

@@ -16,6 +16,7 @@
 #include "tg_scene.h"
 
 #include <math.h>
+#include <stdio.h>
 
 #include <algorithm>
 #include <numeric>
@@ -26,12 +27,27 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kBigArea = 64;       // bounding boxes above this many pixels are filled by a whole wavefront, pixels across lanes
-constexpr int kBigCap = 2048;
+constexpr int kBigCap = 2048;      // queue of those, in LDS (shrunk by lds_layout when the chunk list needs the room)
 constexpr int kHugeArea = 4096;    // ... and above this many by the whole workgroup (ground plane, table top)
 constexpr int kHugeCap = 64;
 constexpr int kMaxFrames = 16;
 constexpr int kChunk = 64;
-constexpr int kMaxChunks = 8192;   // visible-chunk list in LDS (u16 entries)
+constexpr int kMaxChunks = 8192;   // visible-chunk list in LDS (u16 entries, sized by the scene's chunk count)
+constexpr int kWaveQ = 128;        // per-wavefront queue of triangles that passed the shared-vertex tests (< 64 carried over + <= 64 new)
+
+#ifdef TG_SCENE_STATS
+__device__ unsigned long long g_stats[24];   // 0 workgroups, 1 visible chunks, 2 queued survivors, 3 set-ups that drew, 4 big, 5 huge, 6 big pixels, 7 huge pixels
+#define TG_STAT(i, v) atomicAdd(&g_stats[i], (unsigned long long)(v))
+#else
+#define TG_STAT(i, v)
+#endif
+
+// single-instruction forms (the operands here are never NaN, so fminf / fmaxf's canonicalising pre-pass is not needed; min, max and clamp are exact
+// operations: the values are those of the nested fminf / fmaxf in setup_verts)
+__device__ __forceinline__ float min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
+__device__ __forceinline__ float lane_read(float v, int byte_addr) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v))); }
 
 struct TriSetup {
     float a0, b0, c0, a1, b1, c1, a2, b2, c2, sg, rdet;
@@ -130,7 +146,7 @@ __device__ __forceinline__ void shade_pixel(const SceneParams& P, const TriSetup
 }
 
 __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* __restrict__ xf, const uint8_t* __restrict__ mask,
-                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int tw, int th) {
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int tw, int th, int big_cap) {
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
     extern __shared__ unsigned long long zb[];                     // [th][tw] keys, then the queue of large triangles
@@ -138,7 +154,8 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     __shared__ int big_n, vis_n, huge_n;
     __shared__ int huge[kHugeCap];
     int* big = reinterpret_cast<int*>(zb + tw * th);
-    uint16_t* vis_list = reinterpret_cast<uint16_t*>(big + kBigCap);
+    volatile int* wq = big + big_cap + (threadIdx.x >> 6) * kWaveQ;   // this wavefront's queue
+    uint16_t* vis_list = reinterpret_cast<uint16_t*>(big + big_cap + (kThreads / 64) * kWaveQ);
     const int tiles_x = P.W / tw;
     const int tx0 = (blockIdx.x % tiles_x) * tw, ty0 = (blockIdx.x / tiles_x) * th;
     const int tid = threadIdx.x;
@@ -177,61 +194,127 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     __syncthreads();
     const int nvis = min(vis_n, kMaxChunks);
     const int wave = tid >> 6, lane = tid & 63;
-    for (int vi = wave; vi < nvis; vi += kThreads / 64) {
-        const SceneChunk ch = P.chunks[vis_list[vi]];
-        if (lane >= ch.count) continue;
-        const int t = ch.start + lane;
+    if (tid == 0) { TG_STAT(0, 1); TG_STAT(1, nvis); }
+    // One triangle of the lane: full set-up; boxes above kBigArea / kHugeArea pixels are queued for a wavefront / the workgroup, the rest
+    // (a handful of pixel centres) is tested here.
+    auto draw = [&](int t) {
         TriSetup S;
-        if (!setup_tri(P, sxf, env, t, tile, S)) continue;
+        TG_STAT(2, 1);
+        if (!setup_tri(P, sxf, env, t, tile, S)) return;
+        TG_STAT(3, 1);
         const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
         const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
         if (area > kHugeArea) {
             const int slot = atomicAdd(&huge_n, 1);
-            if (slot < kHugeCap) { huge[slot] = t; continue; }
+            if (slot < kHugeCap) { huge[slot] = t; return; }
         }
         if (area > kBigArea) {
             const int slot = atomicAdd(&big_n, 1);
-            if (slot < kBigCap) { big[slot] = t; continue; }
+            if (slot < big_cap) { big[slot] = t; return; }
         }
+#ifdef TG_SCENE_STATS
+        { int b = 0; while ((1 << b) < area) ++b; TG_STAT(8 + b, 1); }      // 8..14: area <= 1, 2, 4, 8, 16, 32, 64
+        { int mx = area; for (int o = 32; o; o >>= 1) mx = max(mx, __shfl_xor(mx, o)); if (area == mx) TG_STAT(16, 1); TG_STAT(17, area); if ((threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) TG_STAT(18, mx); }
+#endif
         for (int py = y0; py <= y1; ++py)
             for (int px = x0; px <= x1; ++px) shade_pixel(P, S, px, py, zb, tx0, ty0, tw);
-    }
-    if (P.hf_heights != nullptr) {                                // this env's heightfield: two triangles per grid cell, a lane per triangle
-        const int n_hf = 2 * (P.hf_rows - 1) * (P.hf_cols - 1);
-        for (int h = tid; h < n_hf; h += kThreads) {
-            const int t = P.n_tris + h;
-            TriSetup S;
-            if (!setup_tri(P, sxf, env, t, tile, S)) continue;
-            const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
-            const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-            if (area > kHugeArea) {
-                const int slot = atomicAdd(&huge_n, 1);
-                if (slot < kHugeCap) { huge[slot] = t; continue; }
-            }
-            if (area > kBigArea) {
-                const int slot = atomicAdd(&big_n, 1);
-                if (slot < kBigCap) { big[slot] = t; continue; }
-            }
-            for (int py = y0; py <= y1; ++py)
-                for (int px = x0; px <= x1; ++px) shade_pixel(P, S, px, py, zb, tx0, ty0, tw);
+    };
+    // Visible chunks, one per wavefront and pass.  Most of the robot's triangles are smaller than a pixel and end at "no pixel centre in
+    // the box" (setup_verts): that test is run on vertices transformed ONCE per chunk (a lane per distinct vertex, the triangle lanes pick
+    // their corners with ds_bpermute), with the very expressions of setup_verts, so its outcome is the same bit for bit; the few triangles
+    // that pass are compacted into the wavefront's queue and set up in full on dense lanes.
+    int qn = 0;                                                   // wave-uniform fill of wq
+    for (int vi = wave; vi < nvis; vi += kThreads / 64) {
+        const SceneChunk ch = P.chunks[vis_list[vi]];
+        const float* M = sxf + 12 * ch.frame;
+        float vw = 0.0f, vsx = 0.0f, vsy = 0.0f;
+        if (lane < ch.vcount) {
+            const float* v = P.verts + 3 * (size_t)(ch.vstart + lane);
+            const float vx = v[0], vy = v[1], vz = v[2];
+            const float ex = ((M[0] * vx + M[1] * vy) + M[2] * vz) + M[9];
+            const float ey = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
+            const float ez = ((M[6] * vx + M[7] * vy) + M[8] * vz) + M[11];
+            vw = -ez;
+            const float X = P.kx * ex + P.hw * vw, Y = P.hh * vw - P.ky * ey;
+            const float r = 1.0f / vw;                             // used only by triangles whose three corners are beyond the near plane
+            vsx = X * r; vsy = Y * r;
+        }
+        const uint32_t loc = lane < ch.count ? P.tri_local[ch.start + lane] : 0u;
+        const int i0 = (int)((loc & 255u) << 2), i1 = (int)((loc >> 6) & 1020u), i2 = (int)((loc >> 14) & 1020u);   // ds_bpermute byte addresses
+        const float w0 = lane_read(vw, i0), w1 = lane_read(vw, i1), w2 = lane_read(vw, i2);
+        const float sx0 = lane_read(vsx, i0), sx1 = lane_read(vsx, i1), sx2 = lane_read(vsx, i2);
+        const float sy0 = lane_read(vsy, i0), sy1 = lane_read(vsy, i1), sy2 = lane_read(vsy, i2);
+        const float wmin = min3(w0, w1, w2), wmax = max3(w0, w1, w2);
+        bool alive = lane < ch.count && !(wmax < P.near_) && !(wmin > P.far_);      // all three behind the near / beyond the far plane
+        if (wmin >= P.near_) {
+            const float fw = (float)P.W + 1.0f, fh = (float)P.H + 1.0f;
+            const float minx = clampf(min3(sx0, sx1, sx2), -1.0f, fw), maxx = clampf(max3(sx0, sx1, sx2), -1.0f, fw);
+            const float miny = clampf(min3(sy0, sy1, sy2), -1.0f, fh), maxy = clampf(max3(sy0, sy1, sy2), -1.0f, fh);
+            const int bx0 = max(0, (int)ceilf(minx - 0.515625f)), bx1_ = min(P.W - 1, (int)floorf(maxx - 0.484375f));
+            const int by0 = max(0, (int)ceilf(miny - 0.515625f)), by1_ = min(P.H - 1, (int)floorf(maxy - 0.484375f));
+            alive = alive && bx0 <= bx1_ && by0 <= by1_ && !(bx0 > tile[2] || bx1_ < tile[0] || by0 > tile[3] || by1_ < tile[1]);
+        }
+        const unsigned long long m = __ballot(alive);
+        if (m == 0ull) continue;
+        if (alive) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = ch.start + lane;
+        qn += __popcll(m);
+        if (qn >= 64) {
+            qn -= 64;
+            draw(wq[qn + lane]);
         }
     }
+    if (lane < qn) draw(wq[lane]);
+    if (P.hf_heights != nullptr) {                                // this env's heightfield: two triangles per grid cell, a lane per triangle
+        const int n_hf = 2 * (P.hf_rows - 1) * (P.hf_cols - 1);
+        for (int h = tid; h < n_hf; h += kThreads) draw(P.n_tris + h);
+    }
     __syncthreads();
-    const int nb = min(big_n, kBigCap);
-    for (int i = wave; i < nb; i += kThreads / 64) {               // one queued triangle per wavefront: set-up once (wave-uniform), pixels across lanes
+    // Queued large triangles.  Their set-up runs on dense lanes (a lane per queued triangle), then one triangle at a time is handed to the
+    // whole wavefront (workgroup) through v_readlane - its coefficients become scalar operands - and the pixels of its box go across the lanes.
+    auto bcast_setup = [](const TriSetup& S, int src, TriSetup& B) {
+        auto rf = [src](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+        B.a0 = rf(S.a0); B.b0 = rf(S.b0); B.c0 = rf(S.c0); B.a1 = rf(S.a1); B.b1 = rf(S.b1); B.c1 = rf(S.c1);
+        B.a2 = rf(S.a2); B.b2 = rf(S.b2); B.c2 = rf(S.c2); B.sg = rf(S.sg); B.rdet = rf(S.rdet);
+        B.rgb = (uint32_t)__builtin_amdgcn_readlane((int)S.rgb, src);
+        B.x0 = __builtin_amdgcn_readlane(S.x0, src); B.x1 = __builtin_amdgcn_readlane(S.x1, src);
+        B.y0 = __builtin_amdgcn_readlane(S.y0, src); B.y1 = __builtin_amdgcn_readlane(S.y1, src);
+    };
+    const int nb = min(big_n, big_cap);
+    const int per = min(64, (nb + kThreads / 64 - 1) / (kThreads / 64));      // queued triangles per wavefront and pass
+    for (int base = wave * per; base < nb; base += (kThreads / 64) * per) {
         TriSetup S;
-        if (!setup_tri(P, sxf, env, big[i], tile, S)) continue;
-        const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
-        const int bw = x1 - x0 + 1, np = bw * (y1 - y0 + 1);
-        for (int p = lane; p < np; p += 64) shade_pixel(P, S, x0 + p % bw, y0 + p / bw, zb, tx0, ty0, tw);
+        bool ok = lane < per && base + lane < nb;
+        if (ok) ok = setup_tri(P, sxf, env, big[base + lane], tile, S);
+        if (ok) { S.x0 = max(S.x0, tx0); S.x1 = min(S.x1, bx1); S.y0 = max(S.y0, ty0); S.y1 = min(S.y1, by1); }
+        unsigned long long m = __ballot(ok);
+        while (m != 0ull) {
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            m &= m - 1ull;
+            TriSetup B;
+            bcast_setup(S, src, B);
+            const int bw = B.x1 - B.x0 + 1, np = bw * (B.y1 - B.y0 + 1);
+            if (lane == 0) { TG_STAT(4, 1); TG_STAT(6, np); }
+            const float rbw = 1.0f / (float)bw;       // row = floor((p + 0.5) / bw): exact for p < 2^14, bw <= 128 (the fraction is >= 0.5 / 128 from an integer)
+            for (int p = lane; p < np; p += 64) { const int row = (int)(((float)p + 0.5f) * rbw); shade_pixel(P, B, B.x0 + (p - row * bw), B.y0 + row, zb, tx0, ty0, tw); }
+        }
     }
     const int nh = min(huge_n, kHugeCap);
-    for (int i = 0; i < nh; ++i) {
+    {
         TriSetup S;
-        if (!setup_tri(P, sxf, env, huge[i], tile, S)) continue;   // workgroup-uniform
-        const int x0 = max(S.x0, tx0), x1 = min(S.x1, bx1), y0 = max(S.y0, ty0), y1 = min(S.y1, by1);
-        const int bw = x1 - x0 + 1, np = bw * (y1 - y0 + 1);
-        for (int p = tid; p < np; p += kThreads) shade_pixel(P, S, x0 + p % bw, y0 + p / bw, zb, tx0, ty0, tw);
+        bool ok = lane < nh;                                      // every wavefront sets the (<= 64) huge triangles up for itself
+        if (ok) ok = setup_tri(P, sxf, env, huge[lane], tile, S);
+        if (ok) { S.x0 = max(S.x0, tx0); S.x1 = min(S.x1, bx1); S.y0 = max(S.y0, ty0); S.y1 = min(S.y1, by1); }
+        unsigned long long m = __ballot(ok);
+        while (m != 0ull) {
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            m &= m - 1ull;
+            TriSetup B;
+            bcast_setup(S, src, B);
+            const int bw = B.x1 - B.x0 + 1, np = bw * (B.y1 - B.y0 + 1);
+            if (tid == 0) { TG_STAT(5, 1); TG_STAT(7, np); }
+            const float rbw = 1.0f / (float)bw;
+            for (int p = tid; p < np; p += kThreads) { const int row = (int)(((float)p + 0.5f) * rbw); shade_pixel(P, B, B.x0 + (p - row * bw), B.y0 + row, zb, tx0, ty0, tw); }
+        }
     }
     __syncthreads();
     for (int p = tid; p < tw * th; p += kThreads) {
@@ -243,7 +326,18 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     }
 }
 
-constexpr size_t lds_bytes(int tw, int th) { return (size_t)tw * th * 8 + (size_t)kBigCap * 4 + (size_t)kMaxChunks * 2; }
+// Dynamic LDS: z keys | big-triangle queue | the wavefronts' queues | visible-chunk list.  The CU has 160 KB; kLdsStatic covers the
+// kernel's static arrays.  The big-triangle queue gives way when a scene has many chunks (an overflowing entry is drawn by its lane).
+constexpr int kLdsBudget = 160 * 1024, kLdsStatic = 2048;
+struct LdsLayout { int big_cap; size_t bytes; };
+LdsLayout lds_layout(int tw, int th, int n_chunks) {
+    const size_t fixed = (size_t)tw * th * 8 + (size_t)(kThreads / 64) * kWaveQ * 4 + (((size_t)n_chunks * 2 + 7) & ~(size_t)7);
+    const long room = (long)kLdsBudget - kLdsStatic - (long)fixed;
+    LdsLayout L;
+    L.big_cap = (int)std::min<long>(kBigCap, room / 4);
+    L.bytes = fixed + (size_t)std::max(L.big_cap, 0) * 4;
+    return L;
+}
 
 }  // namespace
 
@@ -258,7 +352,8 @@ SceneParams make_scene_params(int W, int H, double fov_deg, double near_, double
     return P;
 }
 
-void build_scene_chunks(const float* verts, int32_t* tris, uint32_t* attr, int n_tris, std::vector<SceneChunk>& chunks) {
+void build_scene_chunks(const float* verts, int32_t* tris, uint32_t* attr, int n_tris, std::vector<SceneChunk>& chunks, std::vector<float>& cverts,
+                        std::vector<uint32_t>& tri_local) {
     // per frame: bounding box of the centroids -> 10 bits per axis Morton code; stable sort by (frame, code)
     float lo[kMaxFrames][3], hi[kMaxFrames][3];
     for (int f = 0; f < kMaxFrames; ++f) for (int k = 0; k < 3; ++k) { lo[f][k] = 3.4e38f; hi[f][k] = -3.4e38f; }
@@ -294,53 +389,85 @@ void build_scene_chunks(const float* verts, int32_t* tris, uint32_t* attr, int n
         for (int k = 0; k < 3; ++k) t2[(size_t)3 * i + k] = tris[(size_t)3 * order[i] + k];
         a2[i] = attr[order[i]];
     }
-    std::copy(t2.begin(), t2.end(), tris);
     std::copy(a2.begin(), a2.end(), attr);
-    chunks.clear();
-    // a chunk ends after kChunk triangles, at a frame change, or when one more triangle would make its sphere much larger than the rest
-    // (keeps the ground plane and the table slabs from poisoning a chunk of small parts)
+    chunks.clear(); cverts.clear(); tri_local.assign(n_tris, 0u);
+    // a chunk ends after kChunk triangles or kChunk distinct vertices, at a frame change, or when one more triangle would make its sphere
+    // much larger than the rest (keeps the ground plane and the table slabs from poisoning a chunk of small parts)
     int start = 0;
+    std::vector<int32_t> local;                                   // the chunk's distinct vertices (indices into verts), in order of first use
     while (start < n_tris) {
         const int f = (int)(attr[start] >> 24);
         float blo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, bhi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
         int count = 0;
+        local.clear();
         while (start + count < n_tris && count < kChunk && (int)(attr[start + count] >> 24) == f) {
+            const int32_t* tv = &t2[(size_t)3 * (start + count)];
             float nlo[3], nhi[3];
             for (int k = 0; k < 3; ++k) { nlo[k] = blo[k]; nhi[k] = bhi[k]; }
-            for (int j = 0; j < 3; ++j)
+            int fresh = 0;
+            for (int j = 0; j < 3; ++j) {
                 for (int k = 0; k < 3; ++k) {
-                    const float v = verts[3 * tris[(size_t)3 * (start + count) + j] + k];
+                    const float v = verts[3 * tv[j] + k];
                     nlo[k] = std::min(nlo[k], v); nhi[k] = std::max(nhi[k], v);
                 }
+                bool seen = std::find(local.begin(), local.end(), tv[j]) != local.end();
+                for (int j2 = 0; j2 < j; ++j2) seen = seen || tv[j2] == tv[j];
+                fresh += seen ? 0 : 1;
+            }
+            if ((int)local.size() + fresh > kChunk) break;
             const float dn = std::max({nhi[0] - nlo[0], nhi[1] - nlo[1], nhi[2] - nlo[2]}), d0 = std::max({bhi[0] - blo[0], bhi[1] - blo[1], bhi[2] - blo[2]});
             if (count >= 8 && dn > 4.0f * d0 && dn > 0.02f) break;
             for (int k = 0; k < 3; ++k) { blo[k] = nlo[k]; bhi[k] = nhi[k]; }
+            uint32_t loc = 0;
+            for (int j = 0; j < 3; ++j) {
+                auto it = std::find(local.begin(), local.end(), tv[j]);
+                if (it == local.end()) { local.push_back(tv[j]); it = local.end() - 1; }
+                loc |= (uint32_t)(it - local.begin()) << (8 * j);
+            }
+            tri_local[start + count] = loc;
             ++count;
         }
         SceneChunk ch{};
         ch.cx = 0.5f * (blo[0] + bhi[0]); ch.cy = 0.5f * (blo[1] + bhi[1]); ch.cz = 0.5f * (blo[2] + bhi[2]);
         float r2 = 0.0f;
-        for (int i = 0; i < count; ++i)
-            for (int j = 0; j < 3; ++j) {
-                const float* v = verts + 3 * tris[(size_t)3 * (start + i) + j];
-                const float dx = v[0] - ch.cx, dy = v[1] - ch.cy, dz = v[2] - ch.cz;
-                r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
-            }
+        for (int32_t vi : local) {
+            const float* v = verts + 3 * vi;
+            const float dx = v[0] - ch.cx, dy = v[1] - ch.cy, dz = v[2] - ch.cz;
+            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        }
         ch.r = sqrtf(r2) * 1.0001f;
-        ch.start = start; ch.count = count; ch.frame = f;
+        ch.start = start; ch.count = (uint16_t)count; ch.frame = f;
+        ch.vstart = (int)(cverts.size() / 3); ch.vcount = (uint16_t)local.size();
+        for (int32_t vi : local) for (int k = 0; k < 3; ++k) cverts.push_back(verts[3 * vi + k]);
+        for (int i = 0; i < count; ++i)
+            for (int j = 0; j < 3; ++j) tris[(size_t)3 * (start + i) + j] = ch.vstart + (int32_t)((tri_local[start + i] >> (8 * j)) & 255u);
         chunks.push_back(ch);
         start += count;
     }
 }
 
-int scene_prepare() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scene), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(128, 128));
+int scene_prepare(const SceneParams& P) {
+    const int tw = P.W < 128 ? P.W : 128, th = P.H < 128 ? P.H : 128;
+    const LdsLayout L = lds_layout(tw, th, P.n_chunks);
+    if (P.n_chunks > kMaxChunks || L.big_cap < 64) return -1;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scene), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.bytes);
 }
 
+#ifdef TG_SCENE_STATS
+void scene_debug_stats() {
+    unsigned long long h[24]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stats), sizeof h) != hipSuccess || h[0] == 0) return;
+    fprintf(stderr, "k_scene per workgroup: visible chunks %.1f, queued %.1f, drew %.1f, big %.1f (%.0f px), huge %.1f (%.0f px)\n", (double)h[1] / h[0],
+            (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0], (double)h[6] / h[0], (double)h[5] / h[0], (double)h[7] / h[0]);
+    fprintf(stderr, "  small-path box areas <=1 %.0f <=2 %.0f <=4 %.0f <=8 %.0f <=16 %.0f <=32 %.0f <=64 %.0f; sum of areas %.0f, sum over passes of the max area %.0f\n", (double)h[8] / h[0],
+            (double)h[9] / h[0], (double)h[10] / h[0], (double)h[11] / h[0], (double)h[12] / h[0], (double)h[13] / h[0], (double)h[14] / h[0], (double)h[17] / h[0], (double)h[18] / h[0]); }
+#else
+void scene_debug_stats() {}
+#endif
 void launch_scene(const SceneParams& P, const float* xf, int n_envs, const uint8_t* mask, uint8_t* out, uint8_t* save_prev, hipStream_t stream) {
     const int tw = P.W < 128 ? P.W : 128, th = P.H < 128 ? P.H : 128;
     dim3 grid((P.W / tw) * (P.H / th), n_envs);
-    hipLaunchKernelGGL(k_scene, grid, dim3(kThreads), lds_bytes(tw, th), stream, P, xf, mask, out, save_prev, tw, th);
+    const LdsLayout L = lds_layout(tw, th, P.n_chunks);
+    hipLaunchKernelGGL(k_scene, grid, dim3(kThreads), L.bytes, stream, P, xf, mask, out, save_prev, tw, th, L.big_cap);
 }
 
 }  // namespace tg

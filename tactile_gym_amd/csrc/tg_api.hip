@@ -374,6 +374,7 @@ struct tg_ctx {
     float *d_scene_verts = nullptr, *d_scene_xf = nullptr;
     int32_t* d_scene_tris = nullptr;
     uint32_t *d_scene_attr = nullptr, *d_scene_local = nullptr;
+    unsigned long long* d_scene_static = nullptr;
     tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
     int32_t *d_int_idx = nullptr, *d_int_rank = nullptr;   // interior-only payload: pixel of interior position k / interior position of pixel p (-1: ring)
@@ -939,7 +940,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1246,6 +1247,19 @@ int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
     TG_HIP(hipMemset(c->d_vis, 0, n * img)); TG_HIP(hipMemset(c->d_vis_term, 0, n * img));
     P.verts = c->d_scene_verts; P.tris = c->d_scene_tris; P.tri_attr = c->d_scene_attr; P.tri_local = c->d_scene_local;
     if (scene_prepare(P) != 0) return fail(-1, "tg_set_scene: the scene's chunk list does not fit the workgroup's LDS (or hipFuncSetAttribute failed)");
+    {   // the world frame once: frame 0 of every env is the view matrix itself (k_scene_xf: put(0, I, 0)), rounded to float the same way
+        std::vector<float> xf0((size_t)n_frames * 12, 0.0f);
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
+        for (int r = 0; r < 3; ++r) {
+            for (int cc = 0; cc < 3; ++cc) xf0[3 * r + cc] = (float)(V.R[3 * r + 0] * I[cc] + V.R[3 * r + 1] * I[3 + cc] + V.R[3 * r + 2] * I[6 + cc]);
+            xf0[9 + r] = (float)(V.R[3 * r + 0] * z[0] + V.R[3 * r + 1] * z[1] + V.R[3 * r + 2] * z[2] + V.t[r]);
+        }
+        TG_HIP(hipMalloc(&c->d_scene_static, (size_t)W * H * 8));
+        TG_HIP(hipMemcpy(c->d_scene_xf, xf0.data(), xf0.size() * 4, hipMemcpyHostToDevice));
+        launch_scene_static(P, c->d_scene_xf, c->d_scene_static, c->stream);
+        TG_HIP(hipStreamSynchronize(c->stream));
+        P.static_keys = c->d_scene_static;
+    }
     c->scene = P;
     c->scene_on = true;
     c->scene_every_step = sc->every_step != 0;

@@ -26,6 +26,7 @@ struct SceneParams {
     const uint32_t* tri_attr;      // device [n_tris]: frame << 24 | r << 16 | g << 8 | b
     const SceneChunk* chunks;      // device [n_chunks]: runs of <= 64 spatially sorted triangles of one frame with a bounding sphere
     int n_chunks;
+    const unsigned long long* static_keys;   // device [tiles][tile pixels]: z keys of the world frame's triangles (launch_scene_static), nullptr: draw them per env
     // surface envs: the task's body is a per-env heightfield (createCollisionShape(GEOM_HEIGHTFIELD), base_surface_env.py:402-432), drawn in frame
     // n_frames - 1 with one colour; vertices and triangle order as in tg_raster.h (Stimulus): vertex (i, j) = ((i - (rows-1)/2) s,
     // (j - (cols-1)/2) s, h[j rows + i] - zoff), cell (i, j) -> (i,j),(i,j+1),(i+1,j) and (i+1,j),(i,j+1),(i+1,j+1)
@@ -46,6 +47,9 @@ void build_scene_chunks(const float* verts, int32_t* tris /*[n][3], reordered + 
 // Draws out[env] (uint8 [H][W][3]) for every env (mask == nullptr) or the envs whose mask byte is non-zero; with save_prev the
 // previous image of a drawn env is first copied to save_prev[env] (the terminal observation of an auto-reset).
 void launch_scene(const SceneParams& P, const float* xf, int n_envs, const uint8_t* mask, uint8_t* out, uint8_t* save_prev, hipStream_t stream);
+// One-off: draws the triangles of frame 0 (world: the same for every env, the camera is fixed) and stores their z keys, W * H of them, tile by
+// tile; xf_env0 = any env's [n_frames][12] transforms (only frame 0 is read).
+void launch_scene_static(const SceneParams& P, const float* xf_env0, unsigned long long* static_keys, hipStream_t stream);
 int scene_prepare(const SceneParams& P);   // one-time kernel attributes (large dynamic LDS); call outside stream capture; non-zero: the scene does not fit
 
 void scene_debug_stats();          // -DTG_SCENE_STATS builds: per-workgroup work counters to stderr (development)

@@ -146,7 +146,12 @@ __device__ __forceinline__ void shade_pixel(const SceneParams& P, const TriSetup
 }
 
 __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* __restrict__ xf, const uint8_t* __restrict__ mask,
-                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int tw, int th, int big_cap) {
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int tw, int th, int big_cap,
+                                                    unsigned long long* __restrict__ static_out) {
+    // static_out != nullptr: the one-off pass over the world frame (frame 0: ground plane, table - the same for every env and step, the
+    // camera is fixed): its keys are stored per tile and every later draw starts its z-buffer from them instead of drawing those triangles again
+    // (the image is a max over keys, so the split changes nothing).
+    const bool static_pass = static_out != nullptr;
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
     extern __shared__ unsigned long long zb[];                     // [th][tw] keys, then the queue of large triangles
@@ -160,14 +165,16 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     const int tx0 = (blockIdx.x % tiles_x) * tw, ty0 = (blockIdx.x / tiles_x) * th;
     const int tid = threadIdx.x;
     uint8_t* img = out + (size_t)env * P.W * P.H * 3;
-    if (save_prev != nullptr) {
+    if (save_prev != nullptr && !static_pass) {
         uint8_t* dst = save_prev + (size_t)env * P.W * P.H * 3;
         for (int p = tid; p < tw * th; p += kThreads) {
             const size_t o = ((size_t)(ty0 + p / tw) * P.W + (tx0 + p % tw)) * 3;
             dst[o] = img[o]; dst[o + 1] = img[o + 1]; dst[o + 2] = img[o + 2];
         }
     }
-    for (int p = tid; p < tw * th; p += kThreads) zb[p] = 0ull;
+    if (static_pass || P.static_keys == nullptr) { for (int p = tid; p < tw * th; p += kThreads) zb[p] = 0ull; }
+    else { const unsigned long long* sk = P.static_keys + (size_t)blockIdx.x * tw * th; for (int p = tid; p < tw * th; p += kThreads) zb[p] = sk[p]; }
+    const bool skip_world = !static_pass && P.static_keys != nullptr;
     for (int p = tid; p < P.n_frames * 12; p += kThreads) sxf[p] = xf[(size_t)env * P.n_frames * 12 + p];
     if (tid == 0) { big_n = 0; vis_n = 0; huge_n = 0; }
     __syncthreads();
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
         const float nt = sqrtf(P.ky * P.ky + (P.hh - (float)ty0) * (P.hh - (float)ty0)), nb_ = sqrtf(P.ky * P.ky + (P.hh - (float)(by1 + 1)) * (P.hh - (float)(by1 + 1)));
         for (int ci = tid; ci < P.n_chunks; ci += kThreads) {
             const SceneChunk ch = P.chunks[ci];
+            if (static_pass ? ch.frame != 0 : (skip_world && ch.frame == 0)) continue;
             const float* M = sxf + 12 * ch.frame;
             const float x = M[0] * ch.cx + M[1] * ch.cy + M[2] * ch.cz + M[9], y = M[3] * ch.cx + M[4] * ch.cy + M[5] * ch.cz + M[10];
             const float w = -(M[6] * ch.cx + M[7] * ch.cy + M[8] * ch.cz + M[11]);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
         }
     }
     if (lane < qn) draw(wq[lane]);
-    if (P.hf_heights != nullptr) {                                // this env's heightfield: two triangles per grid cell, a lane per triangle
+    if (P.hf_heights != nullptr && !static_pass) {                // this env's heightfield: two triangles per grid cell, a lane per triangle
         const int n_hf = 2 * (P.hf_rows - 1) * (P.hf_cols - 1);
         for (int h = tid; h < n_hf; h += kThreads) draw(P.n_tris + h);
     }
@@ -317,6 +325,10 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
         }
     }
     __syncthreads();
+    if (static_pass) {
+        for (int p = tid; p < tw * th; p += kThreads) static_out[(size_t)blockIdx.x * tw * th + p] = zb[p];
+        return;
+    }
     for (int p = tid; p < tw * th; p += kThreads) {
         const unsigned long long k = zb[p];
         const size_t o = ((size_t)(ty0 + p / tw) * P.W + (tx0 + p % tw)) * 3;
@@ -467,7 +479,16 @@ void launch_scene(const SceneParams& P, const float* xf, int n_envs, const uint8
     const int tw = P.W < 128 ? P.W : 128, th = P.H < 128 ? P.H : 128;
     dim3 grid((P.W / tw) * (P.H / th), n_envs);
     const LdsLayout L = lds_layout(tw, th, P.n_chunks);
-    hipLaunchKernelGGL(k_scene, grid, dim3(kThreads), L.bytes, stream, P, xf, mask, out, save_prev, tw, th, L.big_cap);
+    hipLaunchKernelGGL(k_scene, grid, dim3(kThreads), L.bytes, stream, P, xf, mask, out, save_prev, tw, th, L.big_cap, (unsigned long long*)nullptr);
+}
+
+void launch_scene_static(const SceneParams& P, const float* xf_env0, unsigned long long* static_keys, hipStream_t stream) {
+    const int tw = P.W < 128 ? P.W : 128, th = P.H < 128 ? P.H : 128;
+    dim3 grid((P.W / tw) * (P.H / th), 1);
+    const LdsLayout L = lds_layout(tw, th, P.n_chunks);
+    SceneParams Q = P;
+    Q.static_keys = nullptr;
+    hipLaunchKernelGGL(k_scene, grid, dim3(kThreads), L.bytes, stream, Q, xf_env0, (const uint8_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, tw, th, L.big_cap, static_keys);
 }
 
 }  // namespace tg

@@ -33,7 +33,9 @@ constexpr int kHugeCap = 64;
 constexpr int kMaxFrames = 16;
 constexpr int kChunk = 64;
 constexpr int kMaxChunks = 8192;   // visible-chunk list in LDS (u16 entries, sized by the scene's chunk count)
-constexpr int kWaveQ = 128;        // per-wavefront queue of triangles that passed the shared-vertex tests (< 64 carried over + <= 64 new)
+constexpr int kWaveQ = 256;        // per wavefront: two queues (boxes of <= kSmallArea pixels / larger) of triangles that passed the shared-vertex tests,
+                                   // each < 64 carried over + <= 64 new
+constexpr int kSmallArea = 4;
 
 #ifdef TG_SCENE_STATS
 __device__ unsigned long long g_stats[24];   // 0 workgroups, 1 visible chunks, 2 queued survivors, 3 set-ups that drew, 4 big, 5 huge, 6 big pixels, 7 huge pixels
@@ -231,7 +233,8 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
     // the box" (setup_verts): that test is run on vertices transformed ONCE per chunk (a lane per distinct vertex, the triangle lanes pick
     // their corners with ds_bpermute), with the very expressions of setup_verts, so its outcome is the same bit for bit; the few triangles
     // that pass are compacted into the wavefront's queue and set up in full on dense lanes.
-    int qn = 0;                                                   // wave-uniform fill of wq
+    // Two queues by box size: a dense pass lasts as long as its largest box, so one-pixel boxes (60 % of the survivors) do not wait for 8 x 8 ones.
+    int qn = 0, qn2 = 0;                                          // wave-uniform fills of wq[0 .. 127] (small boxes), wq[128 .. 255]
     for (int vi = wave; vi < nvis; vi += kThreads / 64) {
         const SceneChunk ch = P.chunks[vis_list[vi]];
         const float* M = sxf + 12 * ch.frame;
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
         const float sy0 = lane_read(vsy, i0), sy1 = lane_read(vsy, i1), sy2 = lane_read(vsy, i2);
         const float wmin = min3(w0, w1, w2), wmax = max3(w0, w1, w2);
         bool alive = lane < ch.count && !(wmax < P.near_) && !(wmin > P.far_);      // all three behind the near / beyond the far plane
+        bool small = false;
         if (wmin >= P.near_) {
             const float fw = (float)P.W + 1.0f, fh = (float)P.H + 1.0f;
             const float minx = clampf(min3(sx0, sx1, sx2), -1.0f, fw), maxx = clampf(max3(sx0, sx1, sx2), -1.0f, fw);
@@ -261,17 +265,25 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
             const int bx0 = max(0, (int)ceilf(minx - 0.515625f)), bx1_ = min(P.W - 1, (int)floorf(maxx - 0.484375f));
             const int by0 = max(0, (int)ceilf(miny - 0.515625f)), by1_ = min(P.H - 1, (int)floorf(maxy - 0.484375f));
             alive = alive && bx0 <= bx1_ && by0 <= by1_ && !(bx0 > tile[2] || bx1_ < tile[0] || by0 > tile[3] || by1_ < tile[1]);
+            small = (bx1_ - bx0 + 1) * (by1_ - by0 + 1) <= kSmallArea;
         }
         const unsigned long long m = __ballot(alive);
         if (m == 0ull) continue;
-        if (alive) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = ch.start + lane;
-        qn += __popcll(m);
+        const unsigned long long m1 = __ballot(alive && small), m2 = m & ~m1;
+        if (alive && small) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = ch.start + lane;
+        if (alive && !small) wq[128 + qn2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u))] = ch.start + lane;
+        qn += __popcll(m1); qn2 += __popcll(m2);
         if (qn >= 64) {
             qn -= 64;
             draw(wq[qn + lane]);
         }
+        if (qn2 >= 64) {
+            qn2 -= 64;
+            draw(wq[128 + qn2 + lane]);
+        }
     }
     if (lane < qn) draw(wq[lane]);
+    if (lane < qn2) draw(wq[128 + lane]);
     if (P.hf_heights != nullptr && !static_pass) {                // this env's heightfield: two triangles per grid cell, a lane per triangle
         const int n_hf = 2 * (P.hf_rows - 1) * (P.hf_cols - 1);
         for (int h = tid; h < n_hf; h += kThreads) draw(P.n_tris + h);

@@ -319,3 +319,62 @@ def test_marble_rolls_half_as_far_as_the_tip_known_answer():
         assert abs(dp[2]) < 1e-5                                                         # and it stays on the table
         checked += 1
     assert checked >= 3
+
+
+@pytest.mark.parametrize("arm_name", ["ur5", "mg400"])
+def test_arm_model_against_first_principles(arm_name, ur5_tactip, mg400_tactip):
+    """The oracle's arm (FK, Jacobian, mass matrix, inverse dynamics - the restatements of getLinkState, calculateJacobian,
+    calculateMassMatrix, calculateInverseDynamics) against quantities derived from its forward kinematics alone, for the serial UR5 and the
+    MG400's tree: the Jacobian is the derivative of the frame's pose, the kinetic energy 1/2 qd M qd is the sum of the bodies' translational and
+    rotational energies (velocities by central differences of the bodies' poses), the gravity torque is the gradient of the potential energy,
+    and M is symmetric positive definite.  These hold for any correct rigid-body model whatever PyBullet does internally."""
+    from oracle import minibullet as mb
+    tg, mk_arm, _, rest = ur5_tactip if arm_name == "ur5" else mg400_tactip
+    arm = mk_arm()
+    n = arm.n
+    rng = np.random.default_rng(5)
+    q = np.asarray(rest, dtype=float) + 0.15 * rng.standard_normal(n)
+    qd = 0.5 * rng.standard_normal(n)
+
+    def body_poses(qq):   # world COM position and orientation of every inertial body
+        R, p = np.zeros((n, 9)), np.zeros((n, 3))
+        arm.L.mb_fk(mb.C.byref(arm.model), mb._dp(np.ascontiguousarray(qq)), mb._dp(R), mb._dp(p))
+        out = []
+        for b in range(len(tg.body_mass)):
+            Rl, pl = R[tg.body_link[b]].reshape(3, 3), p[tg.body_link[b]]
+            out.append((Rl @ np.asarray(tg.body_com[b]) + pl, Rl @ np.asarray(tg.body_rot[b]).reshape(3, 3)))
+        return out
+
+    eps = 1e-6
+    # Jacobian = d(pose)/dq
+    J = arm.jacobian("tcp_link", q)
+    for i in range(n):
+        e = np.zeros(n); e[i] = eps
+        pa, _, _, _, Ra = arm.link_state("tcp_link", q=q + e, qd=np.zeros(n))
+        pb, _, _, _, Rb = arm.link_state("tcp_link", q=q - e, qd=np.zeros(n))
+        W = (Ra @ Rb.T - Rb @ Ra.T) / (4 * eps)            # skew(omega) to first order
+        assert np.abs((pa - pb) / (2 * eps) - J[:3, i]).max() < 1e-8, i
+        assert np.abs(np.array([W[2, 1], W[0, 2], W[1, 0]]) - J[3:, i]).max() < 1e-8, i
+    # kinetic energy
+    M = arm.mass_matrix(q)
+    assert np.abs(M - M.T).max() < 1e-13 and np.linalg.eigvalsh(M).min() > 0
+    plus, minus, mid = body_poses(q + eps * qd), body_poses(q - eps * qd), body_poses(q)
+    T = 0.0
+    for b in range(len(tg.body_mass)):
+        v = (plus[b][0] - minus[b][0]) / (2 * eps)
+        W = (plus[b][1] @ minus[b][1].T - minus[b][1] @ plus[b][1].T) / (4 * eps)
+        w = np.array([W[2, 1], W[0, 2], W[1, 0]])
+        Iw = mid[b][1] @ np.diag(np.asarray(tg.body_inertia[b], dtype=float)) @ mid[b][1].T
+        T += 0.5 * float(tg.body_mass[b]) * v @ v + 0.5 * w @ Iw @ w
+    assert abs(0.5 * qd @ M @ qd - T) < 1e-8 * max(1.0, T)
+    # gravity torque = dV/dq
+    V = lambda qq: sum(float(tg.body_mass[b]) * 9.81 * pose[0][2] for b, pose in enumerate(body_poses(qq)))
+    g0 = arm.inverse_dynamics(q, np.zeros(n), np.zeros(n))
+    gfd = np.array([(V(q + eps * e) - V(q - eps * e)) / (2 * eps) for e in np.eye(n)])
+    assert np.abs(gfd - g0).max() < 1e-6
+    # inverse dynamics is affine in qdd with slope M, and the Coriolis term is passive
+    qdd = rng.standard_normal(n)
+    h = arm.inverse_dynamics(q, qd, np.zeros(n))
+    assert np.abs(arm.inverse_dynamics(q, qd, qdd) - h - M @ qdd).max() < 1e-11
+    Md = (arm.mass_matrix(q + eps * qd) - arm.mass_matrix(q - eps * qd)) / (2 * eps)
+    assert abs(qd @ (h - g0) - 0.5 * qd @ Md @ qd) < 1e-7

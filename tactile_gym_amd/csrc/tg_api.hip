@@ -478,6 +478,12 @@ template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
                        (const EnvConst<T>*)c->d_const, c->st);
 }
 
+template <typename T, int TOPO> static void launch_refresh_rpy_t(tg_ctx* c) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_refresh_rpy<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st);
+}
+
 template <typename T> static void launch_step_body_t(tg_ctx* c, const float* d_actions) {
     const int n = c->cfg.num_envs;
     if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION)
@@ -1388,8 +1394,8 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
     if (v->q && (rc = fetch_soa(c, c->st.q, nd, v->q))) return rc;
     if (v->qd && (rc = fetch_soa(c, c->st.qd, nd, v->qd))) return rc;
     if (v->qd_target && (rc = fetch_soa(c, c->st.qd_target, nd, v->qd_target))) return rc;
-    if (v->tcp_rpy && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {   // the step kernel leaves this read-back to be recomputed on demand
-#define CALL(T, TOPO) launch_refresh_t<T, TOPO>(c)
+    if (v->tcp_rpy && (c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO)) {   // k_step leaves this read-back to be recomputed on demand
+#define CALL(T, TOPO) launch_refresh_rpy_t<T, TOPO>(c)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
     }

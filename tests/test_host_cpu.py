@@ -306,3 +306,16 @@ int main(void) {
     assert sizes == [C.sizeof(t) for t in (_capi.TgRobot, _capi.TgSensor, _capi.TgMesh, _capi.TgConfig, _capi.TgScene, _capi.TgStateView)]
     assert offs == [_capi.TgConfig.contact_mapping.offset, _capi.TgConfig.solver_iterations.offset, _capi.TgScene.every_step.offset,
                     _capi.TgScene.body_heightfield.offset, _capi.TgStateView.contact_ids.offset]
+
+
+def test_constant_time_digitize_equals_the_edge_by_edge_count(tmp_path):
+    """digitize_linspace (csrc/tg_kernels.hpp) locates the bin with one division and four exact comparisons instead of one per edge; the same
+    body, compiled for the host, against the full count at and around every edge (tests/aux/digitize_check.cpp)."""
+    import subprocess
+    exe = tmp_path / "digitize_check"
+    src = os.path.join(os.path.dirname(__file__), "aux", "digitize_check.cpp")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", src, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("0 mismatches"), out.stdout
+    dev = open(os.path.join(os.path.dirname(__file__), "..", "tactile_gym_amd", "csrc", "tg_kernels.hpp")).read()
+    assert "int base = (int)t - 1;" in dev and "for (int j = 0; j < 4; ++j)" in dev      # the device body is this one

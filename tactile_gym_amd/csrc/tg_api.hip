@@ -942,6 +942,9 @@ int tg_destroy(tg_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
     if (c->scene_on) scene_debug_stats();
+#ifdef TG_KSTEP_STAMPS
+    { unsigned long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_kstep_stamps), sizeof h) == hipSuccess) { fprintf(stderr, "k_step stamps (cycles from start, full=%llu):", h[15]); for (int i = 1; i < 13; ++i) fprintf(stderr, " [%d] %lld", i, (long long)(h[i] - h[0])); fprintf(stderr, "\n"); } }
+#endif
     for (int k = 0; k < 2; ++k) if (c->step_graph[k]) (void)hipGraphExecDestroy(c->step_graph[k]);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,

@@ -146,6 +146,12 @@ __device__ inline double grad_axis(const double* f, int idx, int n, int stride, 
     return (f[(size_t)(idx + 1) * stride] - f[(size_t)(idx - 1) * stride]) / (2.0 * h);
 }
 
+#ifdef TG_KSTEP_STAMPS
+__device__ unsigned long long g_kstep_stamps[16];
+#define TG_KSTAMP(i) { if (blockIdx.x == 0 && threadIdx.x == 0) g_kstep_stamps[i] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); }
+#else
+#define TG_KSTAMP(i)
+#endif
 // Everything that follows the physics of a step or a reset: TCP pose read-back, reward / termination
 // (edge_follow_env.py:371-452) and the camera<-stimulus transform handed to the raster (tactile_sensor.py:150-229).
 template <typename T, int TOPO>
@@ -184,6 +190,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
     }
+    TG_KSTAMP(5)
     if ((write_reward_done || c.reward_mode == TG_REWARD_SPARSE) && c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         // get_step_data / dense_reward (base_surface_env.py:664-684, 703-760; surface_follow_auto_env.py:75-94)
         const int R = c.surf_rows, Cc = c.surf_cols;
@@ -240,6 +247,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
             if (write_reward_done) st.term_feature[(size_t)env * 12 + e] = f[e];
         }
     }
+    TG_KSTAMP(6)
     // camera frame = sensor-body frame o cam offset; eye axes (right, up, -forward) with forward = R[:,0], up = R[:,2]
     V3<T> pb; M3<T> Rb;
     link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
@@ -431,6 +439,7 @@ __device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const
     else forward_kinematics<T, TOPO>(m, q, k);
     V3<T> ptcp; M3<T> Rtcp;
     link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    TG_KSTAMP(10)
     V3<T> wpos; T wrpy[3] = {T(0), T(0), T(0)}, rpyw[3];
     // The work-frame orientation of the TCP (matrix -> quaternion -> euler -> quaternion -> multiply -> euler: nine f64 transcendentals)
     // only enters the limit check of the rotational components; a movement mode without rotational velocity (a zero stays a zero in that
@@ -447,8 +456,10 @@ __device__ __forceinline__ void tcp_velocity_control(const DevRobot<T>& m, const
     }
     const V3<T> lin = mul(c.work_R, mk(vels[0], vels[1], vels[2]));   // workvel_to_worldvel (:96-105)
     const V3<T> ang = mul(c.work_R, mk(vels[3], vels[4], vels[5]));
+    TG_KSTAMP(11)
     T J[6][N];
     tcp_jacobian<T, TOPO>(m, k, ptcp, J);
+    TG_KSTAMP(12)
     if (N == 6) {  // square: inverse (reference takes np.linalg.inv when rank is full, :316-319)
         T A[6][6], b[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z}, x[6];
 #pragma unroll
@@ -505,6 +516,7 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = c.num_envs;
     if (env >= n) return;
+    TG_KSTAMP(0)
     T q[N], qd[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
@@ -523,7 +535,9 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
         trig_init<T, N>(q, trig);
     }
     T qd_des[N];
+    TG_KSTAMP(1)
     tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, &trig);
+    TG_KSTAMP(2)
 #pragma unroll
     for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
 
@@ -540,6 +554,7 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
         sim_tick<T, TOPO, kMotorVelocity, true, true>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, &trig,
                                                       &verified);
         const bool analytic = before > 0 && verified == before - 1;   // the analytic path decrements; a full solve sets 24 or -1
+        if (t == 0) TG_KSTAMP(7)
         if (!analytic) ran_full = true;
         if (verified < 0) verified = 0;
         // Fast-forward.  After an analytic tick qd == des (the velocity motors' constant target), so every remaining tick of this step
@@ -570,12 +585,18 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
         }
     }
     st.licence[env] = ran_full ? (verified > 0 ? 8 : 0) : lic - 1;
+    TG_KSTAMP(3)
 
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = (double)trig.s[i]; st.trig_sc[(8 + i) * n + env] = (double)trig.c[i]; }
+    TG_KSTAMP(4)
     finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
+    TG_KSTAMP(9)
+#ifdef TG_KSTEP_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_kstep_stamps[15] = ran_full ? 1 : 0;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ reset kernel

@@ -1393,7 +1393,7 @@ template <typename T, int N> __device__ __forceinline__ void solve_pivoted(T (&A
             const T b0 = b[c], b1 = b[r]; b[c] = sw ? b1 : b0; b[r] = sw ? b0 : b1;
         }
         const T piv = A[c][c];
-        const T inv = (piv != T(0)) ? T(1) / piv : T(0);
+        const T inv = (piv != T(0)) ? trcp(piv) : T(0);   // seed + Newton (1-2 ulp): the pivots are well-scaled Jacobian / mass-matrix entries
 #pragma unroll
         for (int r = c + 1; r < N; ++r) {
             const T f = A[r][c] * inv;
@@ -1407,7 +1407,7 @@ template <typename T, int N> __device__ __forceinline__ void solve_pivoted(T (&A
         T s = b[r];
 #pragma unroll
         for (int j = r + 1; j < N; ++j) s -= A[r][j] * x[j];
-        x[r] = (A[r][r] != T(0)) ? s / A[r][r] : T(0);
+        x[r] = (A[r][r] != T(0)) ? s * trcp(A[r][r]) : T(0);
     }
 }
 

@@ -378,3 +378,73 @@ def test_arm_model_against_first_principles(arm_name, ur5_tactip, mg400_tactip):
     assert np.abs(arm.inverse_dynamics(q, qd, qdd) - h - M @ qdd).max() < 1e-11
     Md = (arm.mass_matrix(q + eps * qd) - arm.mass_matrix(q - eps * qd)) / (2 * eps)
     assert abs(qd @ (h - g0) - 0.5 * qd @ Md @ qd) < 1e-7
+
+
+def _tick_only(env):
+    env.arm.apply_torques(env.arm.inverse_dynamics(env.arm.q, env.arm.qd, np.zeros(env.arm.n)))
+    env._step_simulation()
+
+
+@pytest.mark.parametrize("sensor", ["digitac", "tactip", "digit"])
+def test_tip_cube_contact_closed_form_equals_gjk_epa(sensor):
+    """north_star names GJK/EPA as the narrowphase; the path generates the tip-core / cube contact with a closed form (deepest hull vertex
+    against the box's signed distance field, PARITY A24).  On the states of an object_push rollout - cores apart (DigiTac, k = 300) and cores
+    overlapping (TacTip, k = 50) - a general GJK distance / EPA penetration over the same two convex shapes (oracle/gjk_epa.py) returns the same
+    signed distance and the same normal."""
+    from oracle import gjk_epa as g
+    from oracle.ref_env import OracleObjectPushEnv
+    env = OracleObjectPushEnv(seed=3, image_size=(64, 64), env_modes=dict(movement_mode="TyRz", traj_type="simplex", tactile_sensor_name=sensor, rand_init_orn=True))
+    env.reset()
+    sc = env.scene
+    V = np.ctypeslib.as_array(sc.tip_verts, (sc.n_tip * 3,)).reshape(-1, 3).copy()
+    rng = np.random.default_rng(1)
+    checked = apart = overlapping = 0
+    for step in range(10):
+        env.step(rng.uniform(-0.25, 0.25, 2))
+        R, p = env.arm.link_poses()[sc.tip_link]
+        bc, bR, half = np.array(env.cube.pos[:]), np.array(env.cube.rot[:]).reshape(3, 3), np.array(sc.half[:])
+        _tick_only(env)                                     # reports the contact of the poses read above
+        if sc.tip_depth > 1e20:
+            continue
+        D = sc.tip_depth + sc.margin_tip + sc.margin_cube   # signed distance of the two cores
+        nrm = np.array(sc.tip_normal[:])                    # from the cube towards the tip
+        A, B = g.hull_support(V @ R.T + p), g.box_support(bc, bR, half)
+        d, pa, pb, _ = g.gjk(A, B)
+        if d > 0:
+            assert abs(d - D) < 1e-12 and nrm @ ((pa - pb) / d) > 1 - 1e-9
+            apart += 1
+        else:
+            dep, n = g.epa(A, B)
+            assert abs(-dep - D) < 1e-10 and nrm @ (-n) > 1 - 1e-9
+            overlapping += 1
+        checked += 1
+    assert checked >= 8 and (apart if sensor == "digitac" else overlapping) >= 4
+
+
+def test_marble_contacts_closed_form_equal_gjk():
+    """object_roll's two pairs (A30): marble / table and marble / tip collision cylinder.  Bullet's sphere is a point with a margin, so the general
+    routine is GJK between the marble's centre and the solid cylinder (the table: a large box); the closed forms' depths are those distances
+    minus the radius and their normals the witness directions."""
+    from oracle import gjk_epa as g
+    from oracle.ref_env import OracleObjectRollEnv
+    env = OracleObjectRollEnv(seed=1, image_size=(64, 64), env_modes=dict(rand_embed_dist=True, rand_obj_size=True, rand_init_obj_pos=True))
+    env.reset()                                             # this seed's embed distance (2.9 mm) squeezes the marble: both contacts live
+    sc = env.scene
+    rng = np.random.default_rng(4)
+    checked = 0
+    for step in range(6):
+        env.step(rng.uniform(-0.25, 0.25, 2))
+        R, p = env.arm.link_poses()[sc.tip_link]
+        c = np.array(env.ball.pos[:])
+        cyl_c = p + R @ np.array(sc.cyl_pos[:]); cyl_R = R @ np.array(sc.cyl_rot[:]).reshape(3, 3)
+        _tick_only(env)
+        if sc.tip_depth > 1e20:
+            continue
+        point = g.hull_support(c[None, :])
+        d, pa, pb, _ = g.gjk(point, g.cylinder_support(cyl_c, cyl_R, sc.cyl_half_len, sc.cyl_radius))
+        assert abs((d - sc.radius) - sc.tip_depth) < 1e-9
+        assert np.array(sc.tip_normal[:]) @ ((pb - pa) / d) > 1 - 1e-6        # from the marble towards the tip
+        dt_, _, _, _ = g.gjk(point, g.box_support([c[0], c[1], sc.table_z - 1.0], np.eye(3), [5.0, 5.0, 1.0]))
+        assert abs(dt_ - (c[2] - sc.table_z)) < 1e-12
+        checked += 1
+    assert checked >= 4

@@ -1288,15 +1288,57 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
     JointTrig<T, N> trig;
-    trig_init<T, N>(q, trig);
     int verified = lic > 0 ? 24 : 0;
     bool ran_full = false;
-    for (int t = 0; t < c.action_repeat; ++t) {
-        const bool analytic = verified > 0 && c.solver_iters >= 0 && m.vel_gain == T(1) &&
-                              body_tick_analytic<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.max_force, c.dt, grav, b, c.body, pivot_b, fext, pext,
-                                                                          pending && t == 0, &trig);
-        if (analytic) --verified;
-        else {
+    const T kdamp = c.dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3);
+    int t = 0;
+    while (t < c.action_repeat) {
+        // Licensed ticks: the arm's path is known beforehand - the motors hold qd = des, so the k-th tick from here starts at q + k dt des -
+        // and only the pole's update is sequential.  Lane k evaluates that tick's kinematics (exact sines / cosines, pivot A and its velocity),
+        // all remaining ticks at once; the wavefront then walks them with the body half of the analytic tick alone (body_tick_pivot), fetching
+        // pivot A from lane k.  Same arithmetic per tick as body_tick_analytic.  A tick whose a-priori test fails ends the walk: it is solved in
+        // full below (which renews or withdraws the licence) and the walk resumes behind it.
+        if (verified > 0 && c.solver_iters >= 0 && m.vel_gain == T(1) && c.action_repeat <= 64) {
+            const int left = c.action_repeat - t;
+            T dq[N], qt[N], dvw = T(0), v2 = T(0), v2d = T(0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                dq[i] = c.dt * qd_des[i]; qt[i] = q[i];
+                dvw += m.diag_sqrt[i] * tabs(qd_des[i] - qd[i]); v2 += qd[i] * qd[i]; v2d += qd_des[i] * qd_des[i];
+            }
+            for (int r = 0; r < left; ++r)
+                if (r < lane) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) qt[i] += dq[i];
+                }
+            V3<T> pa_l, va_l;
+            {
+                Kin<T, TOPO> kin;
+                forward_kinematics<T, TOPO>(m, qt, kin);
+                pivot_state<T, TOPO>(kin, c.body, qd_des, pa_l, va_l);
+            }
+            int adv = 0;
+            for (int k = 0; k < left; ++k) {
+                const int kl = __builtin_amdgcn_readfirstlane(k);
+                const V3<T> pa = mk(bcast(pa_l.x, kl), bcast(pa_l.y, kl), bcast(pa_l.z, kl)), va = mk(bcast(va_l.x, kl), bcast(va_l.y, kl), bcast(va_l.z, kl));
+                const T lam_arm = k == 0 ? m.diag_sqrt_max * dvw + kdamp * tsqrt_fast(v2) : m.diag_sqrt_max * T(0) + kdamp * tsqrt_fast(v2d);
+                if (!body_tick_pivot<T>(lam_arm, m.max_force, c.dt, grav, b, c.body, pivot_b, fext, pext, pending && t + k == 0, pa, va)) break;
+                ++adv;
+            }
+            if (adv > 0) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) qd[i] = qd_des[i];
+                for (int r = 0; r < adv; ++r) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) q[i] += dq[i];
+                }
+                verified -= adv;
+                t += adv;
+                continue;
+            }
+        }
+        {
+            trig_init<T, N>(q, trig);
             __syncthreads();
             if (w0) {
 #pragma unroll
@@ -1317,12 +1359,13 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
                                                                   pending && t == 0, lane);
             ran_full = true;
 #pragma unroll
-            for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; trig.s[i] = L[kLTrigS + i]; trig.c[i] = L[kLTrigC + i]; }
+            for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
             b.pos = mk(L[kLBody + 0], L[kLBody + 1], L[kLBody + 2]);
 #pragma unroll
             for (int e = 0; e < 9; ++e) b.R.m[e] = L[kLBody + 3 + e];
             b.v = mk(L[kLBody + 12], L[kLBody + 13], L[kLBody + 14]);
             b.w = mk(L[kLBody + 15], L[kLBody + 16], L[kLBody + 17]);
+            ++t;
         }
     }
     if (w0) {

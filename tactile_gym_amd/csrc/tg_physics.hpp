@@ -659,6 +659,58 @@ template <typename T> __device__ __forceinline__ void integrate_rotation(M3<T>& 
     R.m[2] = c2.x; R.m[5] = c2.y; R.m[8] = c2.z;
 }
 
+// Body half of the analytic arm + body + P2P tick: with the arm moving at the motors' targets, pivot A sits at `pa` and moves with `va`; the
+// three P2P impulses solve the body-only 3 x 3 system (see sim_tick_body).  lam_arm = the motor rows' share of the a-priori bound.  Returns
+// true and advances the body when the test holds for the whole wavefront, false with nothing changed otherwise.
+template <typename T>
+__device__ __forceinline__ bool body_tick_pivot(T lam_arm, T max_force, T dt, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b,
+                                                V3<T> ext_force, V3<T> ext_pos, bool ext_pending, V3<T> pa, V3<T> va) {
+    const S3<T> Iw = rotate(b.R, bc.inertia), Iwi = inverse(Iw);
+    V3<T> xc = b.pos + mul(b.R, bc.com);
+    V3<T> F = bc.mass * gravity, Nt = mk<T>(0, 0, 0);
+    if (ext_pending) { F = F + ext_force; Nt = Nt + cross(ext_pos - xc, ext_force); }
+    Nt = Nt - cross(b.w, mul(Iw, b.w));
+    const V3<T> vb = b.v + (dt / bc.mass) * F, wb = b.w + dt * mul(Iwi, Nt);
+    const V3<T> pb = b.pos + mul(b.R, pivot_b), rb = pb - xc;
+    const V3<T> gap = pa - pb, cv = va - (vb + cross(wb, rb));
+    const V3<T> rhs = (-bc.erp / dt) * gap - cv;
+    const V3<T> e[3] = {mk<T>(1, 0, 0), mk<T>(0, 1, 0), mk<T>(0, 0, 1)};
+    V3<T> rxe[3], Wang[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { rxe[x] = cross(rb, e[x]); Wang[x] = mul(Iwi, rxe[x]); }
+    const T im = T(1) / bc.mass;
+    const S3<T> App{im + dot(rxe[0], Wang[0]), dot(rxe[0], Wang[1]), dot(rxe[0], Wang[2]), im + dot(rxe[1], Wang[1]), dot(rxe[1], Wang[2]),
+                    im + dot(rxe[2], Wang[2])};
+    const V3<T> lp = mul(inverse(App), rhs);
+    const T lpn = tsqrt_fast(dot(lp, lp));
+    const T lam_star = lam_arm + T(6) * lpn;     // per-joint form of the energy bound, see sim_tick
+    if (!__all(T(4) * lam_star < max_force * dt && T(8) * lpn < bc.max_impulse)) return false;
+    b.v = vb - im * lp;
+    b.w = wb - mul(Iwi, cross(rb, lp));
+    xc = xc + dt * b.v;
+    integrate_rotation(b.R, b.w, dt);
+    b.pos = xc - mul(b.R, bc.com);
+    return true;
+}
+// world position of pivot A on link `link` and its velocity under the joint velocities `des`, from a finished forward-kinematics pass
+template <typename T, int TOPO>
+__device__ __forceinline__ void pivot_state(const Kin<T, TOPO>& kin, const BodyConst<T>& bc, const T (&des)[Topo<TOPO>::N], V3<T>& pa, V3<T>& va) {
+    constexpr int N = Topo<TOPO>::N;
+    M3<T> Rl;
+    const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+    const T pav[3] = {bc.pivot_a.x, bc.pivot_a.y, bc.pivot_a.z};
+    link_frame<T, TOPO>(kin, bc.link, pav, ident, pa, Rl);
+    va = mk<T>(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        bool on_path = false;
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+            if (l == bc.link && is_ancestor_or_self<TOPO>(i, l)) on_path = true;
+        if (on_path) va = va + des[i] * cross(kin.a[i], pa - kin.o[i]);
+    }
+}
+
 // The analytic fixed point of one arm + body + P2P tick (see sim_tick_body): advances q, qd, the carried sines / cosines and the body and
 // returns true when its a-priori test holds for the whole wavefront; returns false with nothing changed otherwise (the caller then solves).
 template <typename T, int TOPO, int MOTOR>
@@ -667,64 +719,25 @@ __device__ __forceinline__ bool body_tick_analytic(const DevRobot<T>& m, T (&q)[
                                                    FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b, V3<T> ext_force, V3<T> ext_pos, bool ext_pending,
                                                    JointTrig<T, Topo<TOPO>::N>* trig) {
     constexpr int N = Topo<TOPO>::N;
-        T des[N], dvw = T(0), v2 = T(0);
+    T des[N], dvw = T(0), v2 = T(0);
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            des[i] = ((MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0)) + qd_des[i];
-            dvw += m.diag_sqrt[i] * tabs(des[i] - qd[i]);
-            v2 += qd[i] * qd[i];
-        }
-        Kin<T, TOPO> kin;
-        if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, kin, trig);
-        else forward_kinematics<T, TOPO>(m, q, kin);
-        const S3<T> Iw = rotate(b.R, bc.inertia), Iwi = inverse(Iw);
-        V3<T> xc = b.pos + mul(b.R, bc.com);
-        V3<T> F = bc.mass * gravity, Nt = mk<T>(0, 0, 0);
-        if (ext_pending) { F = F + ext_force; Nt = Nt + cross(ext_pos - xc, ext_force); }
-        Nt = Nt - cross(b.w, mul(Iw, b.w));
-        const V3<T> vb = b.v + (dt / bc.mass) * F, wb = b.w + dt * mul(Iwi, Nt);
-        V3<T> pa; M3<T> Rl;
-        {
-            const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
-            const T pav[3] = {bc.pivot_a.x, bc.pivot_a.y, bc.pivot_a.z};
-            link_frame<T, TOPO>(kin, bc.link, pav, ident, pa, Rl);
-        }
-        const V3<T> pb = b.pos + mul(b.R, pivot_b), rb = pb - xc;
-        V3<T> va = mk<T>(0, 0, 0);      // velocity of pivot A under the prescribed joint velocities
+    for (int i = 0; i < N; ++i) {
+        des[i] = ((MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0)) + qd_des[i];
+        dvw += m.diag_sqrt[i] * tabs(des[i] - qd[i]);
+        v2 += qd[i] * qd[i];
+    }
+    Kin<T, TOPO> kin;
+    if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, kin, trig);
+    else forward_kinematics<T, TOPO>(m, q, kin);
+    V3<T> pa, va;
+    pivot_state<T, TOPO>(kin, bc, des, pa, va);
+    const T lam_arm = m.diag_sqrt_max * dvw + dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3) * tsqrt_fast(v2);
+    if (!body_tick_pivot<T>(lam_arm, max_force, dt, gravity, b, bc, pivot_b, ext_force, ext_pos, ext_pending, pa, va)) return false;
+    T dq[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            bool on_path = false;
-#pragma unroll
-            for (int l = 0; l < N; ++l)
-                if (l == bc.link && is_ancestor_or_self<TOPO>(i, l)) on_path = true;
-            if (on_path) va = va + des[i] * cross(kin.a[i], pa - kin.o[i]);
-        }
-        const V3<T> gap = pa - pb, cv = va - (vb + cross(wb, rb));
-        const V3<T> rhs = (-bc.erp / dt) * gap - cv;
-        const V3<T> e[3] = {mk<T>(1, 0, 0), mk<T>(0, 1, 0), mk<T>(0, 0, 1)};
-        V3<T> rxe[3], Wang[3];
-#pragma unroll
-        for (int x = 0; x < 3; ++x) { rxe[x] = cross(rb, e[x]); Wang[x] = mul(Iwi, rxe[x]); }
-        const T im = T(1) / bc.mass;
-        const S3<T> App{im + dot(rxe[0], Wang[0]), dot(rxe[0], Wang[1]), dot(rxe[0], Wang[2]), im + dot(rxe[1], Wang[1]), dot(rxe[1], Wang[2]),
-                        im + dot(rxe[2], Wang[2])};
-        const V3<T> lp = mul(inverse(App), rhs);
-        const T lpn = tsqrt_fast(dot(lp, lp));
-        const T lam_star = m.diag_sqrt_max * dvw +     // per-joint form of the energy bound, see sim_tick
-                           dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3) * tsqrt_fast(v2) + T(6) * lpn;
-        if (__all(T(4) * lam_star < max_force * dt && T(8) * lpn < bc.max_impulse)) {
-            T dq[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) { qd[i] = des[i]; dq[i] = dt * des[i]; q[i] += dq[i]; }
-            if (trig != nullptr) trig_advance<T, N>(q, dq, *trig);
-            b.v = vb - im * lp;
-            b.w = wb - mul(Iwi, cross(rb, lp));
-            xc = xc + dt * b.v;
-            integrate_rotation(b.R, b.w, dt);
-            b.pos = xc - mul(b.R, bc.com);
-            return true;
-        }
-    return false;
+    for (int i = 0; i < N; ++i) { qd[i] = des[i]; dq[i] = dt * des[i]; q[i] += dq[i]; }
+    if (trig != nullptr) trig_advance<T, N>(q, dq, *trig);
+    return true;
 }
 
 template <typename T, int TOPO, int MOTOR>

@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     const V3<T> pext = mk((T)st.ext_pos[0 * n + env], (T)st.ext_pos[1 * n + env], (T)st.ext_pos[2 * n + env]);
     const bool pending = st.ext_pending[env] != 0;
     const int lic = st.licence[env];
-    stage_link_constants<T, TOPO>(mp, L, lane);
+    bool staged = false;                  // the full tick's per-link constants go to LDS only when a full tick is due
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
@@ -1338,6 +1338,7 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
             }
         }
         {
+            if (!staged) { stage_link_constants<T, TOPO>(mp, L, lane); staged = true; }
             trig_init<T, N>(q, trig);
             __syncthreads();
             if (w0) {

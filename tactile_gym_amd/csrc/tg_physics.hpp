@@ -619,7 +619,7 @@ template <typename T> struct BodyConst {
 
 template <typename T> __device__ __forceinline__ S3<T> inverse(const S3<T>& A) {
     const T c00 = A.yy * A.zz - A.yz * A.yz, c01 = A.xz * A.yz - A.xy * A.zz, c02 = A.xy * A.yz - A.xz * A.yy;
-    const T id = T(1) / (A.xx * c00 + A.xy * c01 + A.xz * c02);
+    const T id = trcp(A.xx * c00 + A.xy * c01 + A.xz * c02);   // seed + Newton (1-2 ulp): on the per-tick dependent chain of the free-body envs
     return {c00 * id, c01 * id, c02 * id, (A.xx * A.zz - A.xz * A.xz) * id, (A.xy * A.xz - A.xx * A.yz) * id, (A.xx * A.yy - A.xy * A.xy) * id};
 }
 
@@ -635,12 +635,14 @@ template <typename T> __device__ __forceinline__ void sincos_small(T x, T* s, T*
     *c = T(1) + x2 * (T(-0.5) + x2 * (T(1.0 / 24.0) + x2 * (T(-1.0 / 720.0) + x2 * (T(1.0 / 40320.0) + x2 * T(-1.0 / 3628800.0)))));
 }
 template <typename T> __device__ __forceinline__ void integrate_rotation(M3<T>& R, V3<T> w, T dt) {
-    const T ang = norm(w);
+    const T w2 = dot(w, w);
+    const T rang = trsqrt(w2 > T(0) ? w2 : T(1));   // 1 / |w| by seed + Newton instead of sqrt and a division (the chain of every tick)
+    const T ang = w2 > T(0) ? w2 * rang : T(0);
     T sh, qw;
     sincos_small(ang * dt * T(0.5), &sh, &qw);
     T k;
     if (ang < T(0.001)) k = T(0.5) * dt - (dt * dt * dt) * T(0.020833333333) * ang * ang;
-    else k = sh / ang;
+    else k = sh * rang;
     const V3<T> ax = k * w;
     const T nrm = trsqrt(dot(ax, ax) + qw * qw);
     const T x = ax.x * nrm, y = ax.y * nrm, z = ax.z * nrm, ww = qw * nrm;

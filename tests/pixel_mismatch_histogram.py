@@ -1,6 +1,6 @@
 """How far from bit-exact are the tactile images of the envs whose camera transform goes through FMA-contracted f64 (free-body and MG400 envs;
 VERDICT r1 item 5)?  HIP vs the CPU oracle, same seeds and actions: histogram of the number of differing pixels per image and of the size of the
-differences.  Runs on the GPU box (the oracle envs run on the host cores, one process per chunk).  python tools/pixel_mismatch_histogram.py"""
+differences.  Runs on the GPU box (the oracle envs run on the host cores, one process per chunk).  A checker, hence under tests/ (not collected by pytest).  python tests/pixel_mismatch_histogram.py"""
 import os, sys, warnings
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np

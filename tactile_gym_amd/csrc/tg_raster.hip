@@ -42,6 +42,14 @@ struct TriRec {      // projected triangle, window coordinates + depth
 // by more than kDepthSlack can therefore never pass `d < z` there.  Skipping it does not change the image.
 constexpr float kDepthSlack = 2e-6f;
 
+// The per-quad edge-function reject of k_render_tactile's pixel loop (a conservative cull, the image does not depend on it): off - it saves
+// fewer instructions than its registers and its ~45 instructions per record x quad row cost (surface_follow render 66.4 -> 62.3 us without;
+// -DTG_HF_QREJ brings it back for A/B).
+#ifdef TG_HF_QREJ
+constexpr bool kHfQuadReject = true;
+#else
+constexpr bool kHfQuadReject = false;
+#endif
 #ifndef TG_HF_WAVES
 #define TG_HF_WAVES 3   // 3 wavefronts per SIMD for the 128 x 64 heightfield kernel (167 VGPRs, 64 B of scratch): 0.098 -> 0.078 ms; needs its windowed LDS (< 53 KB)
 #endif
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
                 if ((float)qx + 3.5f < r.xmin || (float)qx + 0.5f > r.xmax) continue;
                 if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
                 const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
-                {   // conservative reject of the 4-pixel quad: e_i is affine in fx (slope y_j - y_k along a row), so its value at the quad
+                if (kHfQuadReject) {   // conservative reject of the 4-pixel quad: e_i is affine in fx (slope y_j - y_k along a row), so its value at the quad
                     // centre plus 1.5 |slope| plus a bound on the float rounding of the per-pixel expression bounds it over the quad.  e0 + e1 + e2
                     // is the same at every pixel (twice the signed area): when its sign is certain, a covered pixel needs all three e_i on
                     // that side, so one edge function provably on the other side rejects the quad.  Skipping changes no pixel.

@@ -621,8 +621,11 @@ __global__ __launch_bounds__(kThreads) void k_render_scatter(RasterParams P, Sti
 // Small shared meshes (the 12-triangle edge): every triangle fits the record buffer in one round (rec_cap = 2 n_tris), so the pixel
 // phase can run in HALVES passes over disjoint row groups, each pass carrying only its own slice of the z-buffer from the reference
 // load to the store: 16 instead of 32 live depth registers, which lifts the kernel over the next occupancy step (VGPR budget).
+// __launch_bounds__(., 6): six wavefronts per SIMD (80 VGPRs, 64 B of scratch) instead of the five its 96 VGPRs allow - a workgroup spends most
+// of its 8 us waiting on memory, so resident workgroups are what count: edge_follow render 31.6 -> 28.4 us, 16 384 envs 0.290 -> 0.240 ms,
+// object_balance 256 x 256 0.173 -> 0.153 ms; seven (72 VGPRs) the same, eight (64 VGPRs, 112 B of scratch) slower (32.9 us).
 template <int TW, int TH, int HALVES, bool QREJ>
-__global__ __launch_bounds__(kThreads) void k_render_small(RasterParams P, Stimulus S, const float* __restrict__ xform, int xform_soa, int n_envs,
+__global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, Stimulus S, const float* __restrict__ xform, int xform_soa, int n_envs,
                                                            const uint8_t* __restrict__ mask, const float* __restrict__ nodef_dep,
                                                            const uint8_t* __restrict__ gray_u8, const uint8_t* __restrict__ border,
                                                            uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int rec_cap,

@@ -355,8 +355,8 @@ BAL_MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", object
                  observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
 
 
-@pytest.mark.parametrize("size", [128, 256])
-def test_object_balance_env_matches_oracle(size):
+@pytest.mark.parametrize("size,mapping", [(128, "wave"), (256, "wave"), (128, "lane")])
+def test_object_balance_env_matches_oracle(size, mapping):
     """object_balance-v0 (UR5 + TacTip, pole on a point-to-point constraint; BASELINE config 5 modes, 256x256 there): two
     consecutive episodes (the second reset drags the fallen pole along, base_object_env.py:146-173), 6 envs vs 6 oracle envs.
     Joint angles 1e-8 rad, pole pose 1e-7 (the coupled solve runs in a different but equivalent form), images bit-exact
@@ -364,7 +364,8 @@ def test_object_balance_env_matches_oracle(size):
     import tactile_gym_amd as tg
     from oracle.ref_env import OracleObjectBalanceEnv
     n = 6
-    venv = tg.make_vec("object_balance-v0", num_envs=n, max_steps=8, image_size=[size, size], env_modes=BAL_MODES, seed=71, auto_reset=False)
+    venv = tg.make_vec("object_balance-v0", num_envs=n, max_steps=8, image_size=[size, size], env_modes=BAL_MODES, seed=71, auto_reset=False,
+                       contact_mapping=mapping)   # wave: k_step_body_wave (tick-parallel kinematics); lane: k_step_body (the mapping of >= 4096 envs)
     oracles = [OracleObjectBalanceEnv(seed=71 + i, max_steps=8, image_size=(size, size), env_modes=BAL_MODES) for i in range(n)]
     rng = np.random.default_rng(72)
     for episode in range(2):

@@ -2,6 +2,8 @@
 """Headline benchmark: env-steps/sec of edge_follow-v0 (UR5 + TacTip, 128x128 tactile obs), BASELINE.json configs[1].
 
     python bench.py --gpus 1 --steps 2000 --warmup 100      (the defaults: SURVEY 8d asks for 100 warm-up and >= 2000 timed steps)
+    python bench.py --gpus N ...                            (no WORLD_SIZE in the environment: bench.py starts its own N ranks under
+                                                             torch.distributed.run on 127.0.0.1 and rank 0 prints the line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one VecEnv.step() of the whole batch: controller + 24 sim ticks + tactile render for every env, random
@@ -9,16 +11,21 @@ actions ~ U[-0.25, 0.25) drawn on the device by tg_sample_actions (synthetic), a
 inside the timed region whenever K + W crosses a multiple of 200; reported separately via `resets_in_timed_region`).
 Observations stay resident in HBM (device tensors); the PCIe-inclusive rate is quoted in DESIGN.md, never here.
 The rollout is device resident: steps are enqueued on a torch stream (TorchShard(pipelined=True)) and their outputs consumed on it,
-the host does not wait per step (--sync-steps restores the blocking VecEnv.step_wait path; both rates are in profiles/).
+the host does not wait per step (--sync-steps restores the blocking VecEnv.step_wait path).
 Extra fields: roofline (dominant kernel, HIP-event durations, PMC traffic), cpu_baseline (the CPU oracle on all host cores),
-literal_solver (the same workload with exactly 150 PGS sweeps in every tick), without_full_batch_reset.
-Weak scaling: every rank owns --num-envs envs; rank 0 receives all observations / rewards / dones by one packed RCCL gather
-per step, started asynchronously so that it overlaps the next step's simulation; the last gather is waited for inside
-the timed region.  Prints ONE JSON line on rank 0.
+literal_solver (the same workload with exactly 150 PGS sweeps in every tick), without_full_batch_reset, other_configs (one short
+companion run per remaining BASELINE config at 1024 envs on this GPU), roofline_16384 (the dominant kernel at 16 384 envs).
+Weak scaling: every rank owns --num-envs envs; rank 0 receives all observations / rewards / dones once per step (--payload: what the
+message carries, --transport: how it travels; parallel.py), started asynchronously so that it overlaps the next step's simulation
+(SURVEY 8e); the last exchange is waited for inside the timed region.  `no_gather` is the same K steps without the exchange (per-rank
+learners): compute scaling apart from the link bound.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -37,9 +44,32 @@ VERT_MODES = dict(movement_mode="xRz", control_mode="TCP_velocity_control", nois
                   reward_mode="dense", arm_type="mg400", tactile_sensor_name="tactip")   # params/surface_follow_vert_params.py
 MODES = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
              reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+ENV_MODES = {"edge_follow-v0": MODES, "surface_follow-v0": SURF_MODES, "object_balance-v0": BAL_MODES, "object_push-v0": PUSH_MODES,
+             "object_roll-v0": ROLL_MODES, "surface_follow-v2": VERT_MODES}
+MAX_STEPS = {"object_balance-v0": 250, "object_push-v0": 1000, "object_roll-v0": 250}     # params/*_params.py max_ep_len (default 200)
 ALGO_BYTES_PER_ENV_STEP = 16600.0   # BASELINE.md section 3 / SURVEY 8(d): 16 384 B image + ~0.2 KB state/action/reward
 ALGO_BYTES_SURFACE = 33000.0        # config 3: + the per-env 64x64 f32 heightfield read
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+TRAFFIC_FILE = os.path.join("profiles", "r3_traffic.json")
+
+
+def algo_bytes(env_id, image_size):
+    """compulsory HBM bytes per env step (image written once + state in/out; config 3 adds the heightfield read)."""
+    return {"edge_follow-v0": ALGO_BYTES_PER_ENV_STEP if image_size == 128 else image_size * image_size + 216.0,
+            "surface_follow-v0": image_size * image_size + 16616.0, "surface_follow-v2": image_size * image_size + 16616.0,
+            "object_balance-v0": image_size * image_size + 300.0,             # config 5: 65.8 KB at 256x256
+            "object_push-v0": image_size * image_size + 400.0, "object_roll-v0": image_size * image_size + 400.0}[env_id]
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources the HIP library is built from: what a PMC measurement in profiles/ is valid for."""
+    import glob
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "tactile_gym_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _cpu_worker(args):
@@ -76,6 +106,138 @@ def cpu_baseline(seconds=12.0):
                       f"single process: {n1 / t1:.1f} env-steps/s"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: become `python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>`
+    (one rank per GPU, rendezvous on 127.0.0.1 at a free port).  Does not return."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.execv(sys.executable, argv)
+
+
+class Workload:
+    """One env configuration on this rank's GPU with its action sampler and stream."""
+
+    def __init__(self, env_id, n, image_size, physics, rank, local_rank, full_sweeps=False, observation_mode=None, pipelined=True, **extra):
+        import torch
+        import tactile_gym_amd as tg
+        from tactile_gym_amd.parallel import TorchShard
+        self.torch, self.env_id, self.n, self.image_size, self.rank = torch, env_id, n, image_size, rank
+        self.modes = dict(ENV_MODES[env_id])
+        if observation_mode:
+            self.modes["observation_mode"] = observation_mode
+        self.act_dim = 3 if env_id == "surface_follow-v0" else 2
+        self.max_steps = MAX_STEPS.get(env_id, 200)
+        if env_id not in ("object_push-v0", "object_roll-v0"):
+            extra = {}
+        self.venv = tg.make_vec(env_id, num_envs=n, max_steps=self.max_steps, image_size=[image_size, image_size], env_modes=self.modes,
+                                seed=1 + rank * n, physics_dtype=physics, auto_reset=True, device=local_rank, obs_mode="torch",
+                                pgs_full_sweeps=full_sweeps, **extra)
+        # device-resident rollout: the step is enqueued on a torch stream and its outputs are consumed on that stream
+        self.shard = TorchShard(self.venv, pipelined=pipelined)
+        self.act_buf = torch.empty(n, self.act_dim, device=f"cuda:{local_rank}", dtype=torch.float32)
+        self.draw = 0
+
+    def actions(self):
+        """action_space.sample() for the whole batch: U[-0.25, 0.25), one device kernel on the env's stream (tg_sample_actions, counter
+        based: draw k of rank r depends on (1234 + r, k) only), inside the timed region like every step's policy would be."""
+        self.draw += 1
+        return self.venv.sample_actions(self.act_buf, 1234 + self.rank, self.draw)
+
+    def on_stream(self):
+        return self.torch.cuda.stream(self.shard.stream) if self.shard.pipelined else contextlib.nullcontext()
+
+    def timed(self, env, steps, barrier, flush=None):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            env.step(self.actions())
+        if flush is not None:
+            flush()
+        barrier()
+        return time.perf_counter() - t0
+
+    def profile(self, env, steps, barrier):
+        """Per-kernel durations: HIP events on the launch stream (tg_profile_enable), outside the timed region."""
+        self.venv.profile(True)
+        for _ in range(steps):
+            env.step(self.actions())
+            self.venv.sync()
+        barrier()
+        prof = self.venv.profile_get()
+        self.venv.profile(False)
+        return prof
+
+    def dominant(self, prof):
+        """(kernel name, ms per launch) of the kernel with the largest summed duration; the render kernel named as launched
+        (csrc/tg_raster.hip launch_render: small shared meshes take the two-pass small-mesh kernel)."""
+        step_ms, step_n = prof["step"]
+        rend_ms, rend_n = prof["render"]
+        small = self.env_id in ("edge_follow-v0", "object_balance-v0", "object_push-v0") and self.image_size % 128 == 0
+        render_name = "k_render_small<128,64,2>" if small else ("k_render_scatter" if self.env_id == "object_roll-v0" else "k_render_tactile")
+        if step_ms >= rend_ms:
+            return "k_step", step_ms / max(step_n, 1), "k_step"
+        return render_name, rend_ms / max(rend_n, 1), "k_render_tactile"
+
+    def roofline(self, prof, traffic_ok=True):
+        name, dom_ms, key = self.dominant(prof)
+        ab = algo_bytes(self.env_id, self.image_size)
+        achieved = ab * self.n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = read_traffic(self.env_id, self.n, self.image_size, key, ab) if traffic_ok else None
+        return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_env_step": ab,
+                "kernel_ms": {"k_step": round(prof["step"][0] / max(prof["step"][1], 1), 4),
+                              "k_render_tactile": round(prof["render"][0] / max(prof["render"][1], 1), 4),
+                              "k_reset_per_launch": round(prof["reset"][0] / max(prof["reset"][1], 1), 4),
+                              "k_render_tactile_masked": round(prof["render_masked"][0] / max(prof["render_masked"][1], 1), 4)},
+                "launches": {"k_step": prof["step"][1], "k_render_tactile": prof["render"][1], "k_reset": prof["reset"][1]}}
+
+    def close(self):
+        self.venv.close()
+
+
+def read_traffic(env_id, n, image_size, key, ab):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes in profiles/ (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE; counters cannot be read from inside this process).  Quoted only when the file was measured on a library built from the
+    sources in this tree (`source_sha16`) and on this configuration; otherwise null with the reason."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+    except (OSError, ValueError):
+        return None
+    have = source_hash()
+    if tr.get("source_sha16") != have:
+        return {"bytes_per_launch": None, "stale": f"{TRAFFIC_FILE} was measured on sources {tr.get('source_sha16')}, this tree is {have}"}
+    for wl in tr.get("workloads", []):
+        if (wl["env"], wl["num_envs"], wl["image_size"], wl["physics"]) == (env_id, n, image_size, "f64") and key in wl:
+            k = wl[key]
+            b = (k["fetch_corrected_kb"] + k["write_kb"]) * 1024.0
+            return {"bytes_per_launch": round(b), "kernel": k["kernel"], "source_sha16": have,
+                    "source": f"{TRAFFIC_FILE} (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE)", "vs_algorithmic": round(b / (ab * n), 3)}
+    return None
+
+
+def companion(env_id, image_size, n, physics, steps, barrier, what, **kw):
+    """A short run of another configuration on this GPU (after the headline's timed region): value, ms per step and its dominant
+    kernel's roofline fraction."""
+    w = Workload(env_id, n, image_size, physics, 0, 0, **kw)
+    with w.on_stream():
+        w.shard.reset()
+        for _ in range(10):
+            w.shard.step(w.actions())
+        dt = w.timed(w.shard, steps, barrier)
+        prof = w.profile(w.shard, min(steps, 20), barrier)
+    roof = w.roofline(prof)
+    out = {"workload": f"{env_id}, {w.modes['arm_type'].upper()} + {w.modes['tactile_sensor_name']}, {n} vec-envs, {image_size}x{image_size}" + what,
+           "value": round(n * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
+           "roofline": {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_bytes_per_env_step", "kernel_ms")}}
+    w.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,32 +248,40 @@ def main():
     ap.add_argument("--physics", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the literal-solver companion run (keeps a rocprofv3 trace of this command to one solver mode)")
+    ap.add_argument("--no-companions", action="store_true", help="skip other_configs / roofline_16384 (same purpose)")
     ap.add_argument("--sync-steps", action="store_true", help="block the host on every step (VecEnv.step_wait semantics) instead of pipelining")
     ap.add_argument("--full-sweeps", action="store_true",
                     help="always run all 150 PGS sweeps per tick instead of leaving the loop at convergence to the last bit (DESIGN.md 4.1)")
-    ap.add_argument("--env", default="edge_follow-v0", choices=["edge_follow-v0", "surface_follow-v0", "object_balance-v0", "object_push-v0", "object_roll-v0", "surface_follow-v2"],
-                    help="headline = edge_follow-v0 (BASELINE configs[1]); surface_follow-v0 = configs[2]; object_balance-v0 = configs[4] "
-                         "(use --image-size 256)")
+    ap.add_argument("--env", default="edge_follow-v0", choices=sorted(ENV_MODES),
+                    help="headline = edge_follow-v0 (BASELINE configs[1]); surface_follow-v0 = configs[2]; object_push-v0 = configs[3]; "
+                         "object_balance-v0 = configs[4] (use --image-size 256)")
     ap.add_argument("--contact-mapping", default="auto", choices=["auto", "lane", "wave"],
                     help="object_push / object_roll: one wavefront per env or one lane per env for the contact solve (tg_config.contact_mapping)")
     ap.add_argument("--observation-mode", default=None, help="override the config's observation_mode (e.g. visuotactile: adds the RGB scene camera, SURVEY 8 row f4); "
                     "measurement aid, the bench line stays the tactile configuration")
     ap.add_argument("--solver-iters", type=int, default=None, help="object_push / object_roll: override numSolverIterations (150); measurement aid, not a bench configuration")
+    ap.add_argument("--payload", default=os.environ.get("TG_BENCH_PAYLOAD", "auto"), choices=["auto", "full", "interior", "tiles"],
+                    help="N > 1: what the tactile part of the per-step message to rank 0 carries (parallel.py)")
+    ap.add_argument("--transport", default=os.environ.get("TG_BENCH_TRANSPORT", "collective"), choices=["collective", "ipc"],
+                    help="N > 1: torch.distributed collectives over RCCL (default), or peers storing straight into rank 0's IPC-mapped buffer")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: time only the exchange-free rollout (per-rank learners)")
     args = ap.parse_args()
 
-    import torch
-    import tactile_gym_amd as tg
-    from tactile_gym_amd.parallel import ShardedVecEnv, TorchShard
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)                      # re-executes this script under torch.distributed.run; never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or without a launcher: bench.py starts its own ranks)")
+
+    import torch
+    from tactile_gym_amd.parallel import ShardedVecEnv
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the env step has no CPU fallback (the CPU oracle is only the reported baseline)")
     torch.cuda.set_device(local_rank)
-    dist = None
+    dist, rccl_ranks = None, 1
     force = world == 1 and os.environ.get("TG_BENCH_FORCE_COLLECTIVE") == "1"   # 1-GPU check of the RCCL gather path (one rank)
     if world > 1 or force:
         import torch.distributed as dist
@@ -119,28 +289,18 @@ def main():
         if force:
             os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        ones = torch.ones(1, device=f"cuda:{local_rank}", dtype=torch.int32)
+        dist.all_reduce(ones)                       # every rank is on the communicator: the sum of ones is the number of RCCL ranks
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
     n = args.num_envs
-    modes = {"edge_follow-v0": MODES, "surface_follow-v0": SURF_MODES, "object_balance-v0": BAL_MODES, "object_push-v0": PUSH_MODES,
-             "object_roll-v0": ROLL_MODES, "surface_follow-v2": VERT_MODES}[args.env]
-    if args.observation_mode:
-        modes = dict(modes, observation_mode=args.observation_mode)
-    act_dim = 3 if args.env == "surface_follow-v0" else 2
-    max_steps = {"object_balance-v0": 250, "object_push-v0": 1000, "object_roll-v0": 250}.get(args.env, 200)   # params/*_params.py max_ep_len
-    extra = dict(contact_mapping=args.contact_mapping, solver_iterations=args.solver_iters) if args.env in ("object_push-v0", "object_roll-v0") else {}
-    venv = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
-                       seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",
-                       pgs_full_sweeps=args.full_sweeps, **extra)
-    # device-resident rollout: the step is enqueued on a torch stream and its outputs are consumed on that stream (no host wait per
-    # step); --sync-steps restores the blocking VecEnv.step_wait behaviour
-    shard = TorchShard(venv, pipelined=not args.sync_steps)
-    env = ShardedVecEnv(shard, dist, overlap=True, force_collective=force, payload=os.environ.get("TG_BENCH_PAYLOAD", "auto")) if dist is not None else shard   # gather of step t overlaps the simulation of step t+1
-    act_buf = torch.empty(n, act_dim, device="cuda", dtype=torch.float32)
-    draw = [0]
-
-    def actions():   # action_space.sample() for the whole batch: U[-0.25, 0.25), one device kernel on the env's stream (tg_sample_actions,
-        draw[0] += 1  # counter based: draw k of rank r depends on (1234 + r, k) only), inside the timed region like every step's policy would be
-        return venv.sample_actions(act_buf, 1234 + rank, draw[0])
+    extra = dict(contact_mapping=args.contact_mapping, solver_iterations=args.solver_iters)
+    w = Workload(args.env, n, args.image_size, args.physics, rank, local_rank, full_sweeps=args.full_sweeps,
+                 observation_mode=args.observation_mode, pipelined=not args.sync_steps, **extra)
+    venv, shard, modes, max_steps = w.venv, w.shard, w.modes, w.max_steps
+    gathered = dist is not None and not args.no_gather
+    env = ShardedVecEnv(shard, dist, overlap=True, force_collective=force, payload=args.payload, transport=args.transport) if gathered else shard
 
     def barrier():
         torch.cuda.synchronize()
@@ -148,110 +308,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import contextlib
-    on_stream = torch.cuda.stream(shard.stream) if shard.pipelined else contextlib.nullcontext()
-    with on_stream:
+    def allmax(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    with w.on_stream():
         env.reset()
         for _ in range(args.warmup):
-            env.step(actions())
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            env.step(actions())
-        if dist is not None:
-            env.flush()        # the last step's gather completes inside the timed region: K steps simulated AND delivered to rank 0
-        barrier()
-        dt = time.perf_counter() - t0
-        # per-kernel durations for the roofline leg: HIP events on the launch stream, outside the timed region
-        # (event records add ~2 x 4 launches of host work per step)
-        venv.profile(True)
-        for _ in range(min(args.steps, 50)):
-            env.step(actions())
-            venv.sync()
-        barrier()
-        prof = venv.profile_get()
-        venv.profile(False)
+            env.step(w.actions())
+        # the last step's exchange completes inside the timed region: K steps simulated AND delivered to rank 0
+        dt = allmax(w.timed(env, args.steps, barrier, flush=env.flush if gathered else None))
+        no_gather = None
+        if gathered and world > 1:               # the same K steps without the exchange: what per-rank learners would see
+            dt_ng = allmax(w.timed(shard, args.steps, barrier))
+            no_gather = {"value": round(n * world * args.steps / dt_ng, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * dt_ng / args.steps, 4),
+                         "what": "the same K steps on every rank without the per-step exchange to rank 0 (observations consumed where they are produced)"}
+        prof = w.profile(env, min(args.steps, 50), barrier)
         # SURVEY 8d asks for the rate with and without episode resets: a window that starts right after a reset of every env and
         # ends before any env can reach max_steps (an env that meets its goal early is still reset, as in any rollout)
         no_reset = None
         if dist is None:
             env.reset()
             for _ in range(10):
-                env.step(actions())
-            barrier()
+                env.step(w.actions())
             k_nr = max(10, min(args.steps, max_steps - 20))
-            t_nr = time.perf_counter()
-            for _ in range(k_nr):
-                env.step(actions())
-            barrier()
-            dt_nr = time.perf_counter() - t_nr
+            dt_nr = w.timed(env, k_nr, barrier)
             no_reset = {"value": round(n * k_nr / dt_nr, 1), "unit": "env-steps/s", "steps": k_nr, "ms_per_step": round(1e3 * dt_nr / k_nr, 4),
                         "what": "window between full-batch resets (no env reaches max_steps inside it)"}
+    exchange = env.exchange_info() if gathered and hasattr(env, "exchange_info") else None
+
+    solo = world == 1 and not force
     literal = None
-    if world == 1 and not args.full_sweeps and not args.no_literal:
+    if solo and not args.full_sweeps and not args.no_literal:
         # the same workload with the literal solver (every tick: dynamics + all 150 PGS sweeps), for comparison; short run
-        lit = tg.make_vec(args.env, num_envs=n, max_steps=max_steps, image_size=[args.image_size, args.image_size], env_modes=modes,
-                          seed=1 + rank * n, physics_dtype=args.physics, auto_reset=True, device=local_rank, obs_mode="torch",
-                          pgs_full_sweeps=True, **extra)
-        lshard = TorchShard(lit)
-        lshard.reset()
+        lw = Workload(args.env, n, args.image_size, args.physics, rank, local_rank, full_sweeps=True, observation_mode=args.observation_mode,
+                      pipelined=False, **extra)
+        lw.shard.reset()
         for _ in range(5):
-            lshard.step(actions())
-        torch.cuda.synchronize()
+            lw.shard.step(lw.actions())
         lsteps = max(10, min(args.steps, 40))
-        tl = time.perf_counter()
-        for _ in range(lsteps):
-            lshard.step(actions())
-        torch.cuda.synchronize()
-        ldt = time.perf_counter() - tl
-        lit.profile(True)
-        for _ in range(10):
-            lshard.step(actions())
-        torch.cuda.synchronize()
-        lprof = lit.profile_get()
+        ldt = lw.timed(lw.shard, lsteps, barrier)
+        lprof = lw.profile(lw.shard, 10, barrier)
         literal = {"value": round(n * lsteps / ldt, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * ldt / lsteps, 4), "steps": lsteps,
                    "k_step_ms": round(lprof["step"][0] / max(lprof["step"][1], 1), 4),
                    "k_render_ms": round(lprof["render"][0] / max(lprof["render"][1], 1), 4),
                    "what": "pgs_full_sweeps=1: dynamics + exactly 150 Gauss-Seidel sweeps in every one of the 24 ticks (no convergence exit, no analytic fixed point)"}
-        lit.close()
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        lw.close()
+    others, big = None, None
+    headline = args.env == "edge_follow-v0" and n == 1024 and args.image_size == 128 and not args.observation_mode and not args.full_sweeps
+    if solo and headline and not args.no_companions:
+        # one driver-visible line per remaining BASELINE config, 1024 envs on this GPU (the configs' own sharding puts 1024 on each GPU)
+        k = max(20, min(args.steps, 200))
+        others = [companion("surface_follow-v0", 128, 1024, args.physics, k, barrier, " (BASELINE configs[2])"),
+                  companion("object_push-v0", 128, 1024, args.physics, max(20, min(args.steps, 100)), barrier,
+                            " (BASELINE configs[3]: 4096 envs over 4 GPUs = 1024 per GPU)", **extra),
+                  companion("object_balance-v0", 256, 1024, args.physics, k, barrier, " (BASELINE configs[4]: 8192 envs over 8 GPUs = 1024 per GPU)")]
+        b = companion("edge_follow-v0", 128, 16384, args.physics, k, barrier, " (the headline workload at 16 384 envs: the chip filled)")
+        big = {"num_envs": 16384, "value": b["value"], "ms_per_step": b["ms_per_step"], **b["roofline"]}
 
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / dt
-        step_ms, step_n = prof["step"]
-        rend_ms, rend_n = prof["render"]
-        rst_ms, rst_n = prof["reset"]
-        k_step = step_ms / max(step_n, 1)                      # ms per launch
-        k_render_main = rend_ms / max(rend_n, 1)
-        # the render kernel actually launched (csrc/tg_raster.hip: launch_render): small shared meshes (edge, pole, cube) take the
-        # two-pass small-mesh kernel, the heightfield and the marble k_render_tactile<128,128>
-        small = args.env in ("edge_follow-v0", "object_balance-v0", "object_push-v0") and args.image_size % 128 == 0
-        render_name = "k_render_small<128,64,2>" if small else ("k_render_scatter" if args.env == "object_roll-v0" else "k_render_tactile")
-        dominant = "k_step" if step_ms >= rend_ms else render_name
-        dom_ms = k_step if dominant == "k_step" else k_render_main
-        algo_bytes = {"edge_follow-v0": ALGO_BYTES_PER_ENV_STEP, "surface_follow-v0": ALGO_BYTES_SURFACE,
-                      "object_balance-v0": args.image_size * args.image_size + 300.0,             # config 5: 65.8 KB at 256x256
-                      "object_push-v0": args.image_size * args.image_size + 400.0,
-                      "object_roll-v0": args.image_size * args.image_size + 400.0, "surface_follow-v2": ALGO_BYTES_SURFACE}[args.env]
-        achieved = algo_bytes * n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure measured with
-        # rocprofv3 on this workload (profiles/r2_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) is reported when the
-        # configuration matches, else null.
-        traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
-            for wl in tr["workloads"]:
-                if (wl["env"], wl["num_envs"], wl["image_size"], wl["physics"]) == (args.env, n, args.image_size, args.physics) and not args.full_sweeps:
-                    k = wl["k_step" if dominant == "k_step" else "k_render_tactile"]
-                    traffic = {"bytes_per_launch": round((k["fetch_corrected_kb"] + k["write_kb"]) * 1024.0), "kernel": k["kernel"],
-                               "source": "profiles/r2_traffic.json (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE)",
-                               "vs_algorithmic": round((k["fetch_corrected_kb"] + k["write_kb"]) / (algo_bytes * n / 1024.0), 3)}
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        roof = w.roofline(prof, traffic_ok=not args.full_sweeps and args.physics == "f64")
+        roof["note"] = ("HBM roofline in form only: the step is bound by per-workgroup latency chains (render) and by the serial solver "
+                        "(k_step), not by bytes; see DESIGN.md 4.3")
+        if big is not None:
+            roof["at_16384_envs"] = big
+        par = f"env-shard x{world}"
+        if exchange is not None:
+            par += " + " + exchange["what"]
         out = {
             "metric": "env-steps/sec (128x128 tactile obs) at N envs", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -259,32 +387,31 @@ def main():
             "dtype": "f64" if args.physics == "f64" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.env}, {modes['arm_type'].upper()} + {modes['tactile_sensor_name']}, {n} vec-envs per MI355X, {args.image_size}x{args.image_size} tactile obs, "
                                    f"random actions, TCP_velocity_control, {12 if args.env == 'object_balance-v0' else 24} sim ticks per step (PGS budget 150 sweeps per tick), auto-reset on",
-                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": f"env-shard x{world}" + (" + one packed RCCL gather (obs u8" + (" interior pixels only, border ring restored on rank 0" if getattr(env, "_interior", None) is not None else "") + ", reward f32, done u8) to rank 0 per step, "
-                                                                          "overlapped with the next step's simulation" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_env_step": algo_bytes,
-                         "kernel_ms": {"k_step": round(k_step, 4), "k_render_tactile": round(k_render_main, 4),
-                                       "k_reset_per_launch": round(rst_ms / max(rst_n, 1), 4),
-                                       "k_render_tactile_masked": round(prof["render_masked"][0] / max(prof["render_masked"][1], 1), 4)},
-                         "launches": {"k_step": step_n, "k_render_tactile": rend_n, "k_reset": rst_n},
-                         "note": "HBM roofline in form only: the step is bound by per-workgroup latency chains (render) and by the serial solver "
-                                 "(k_step), not by bytes; see DESIGN.md 4.3"},
+                       "envs_per_gpu": n, "total_envs": total_envs, "parallelism": par},
+            "rccl_ranks": rccl_ranks if dist is not None else None,
+            "exchange": exchange,
+            "no_gather": no_gather,
+            "roofline": roof,
             "solver": "literal: dynamics + 150 PGS sweeps every tick (pgs_full_sweeps)" if args.full_sweeps else
                       "default: PGS leaves at last-bit convergence; ticks whose motor solve is provably unclamped and demonstrably converged take "
                       "the solver's analytic fixed point (qd = target); joints within 1e-11 rad of the literal solver over 1024 envs x 260 steps incl. auto-resets "
                       "(tests/test_gpu_parity.py::test_default_solver_equals_literal_solver_at_config_scale; DESIGN.md 4.1)",
             "literal_solver": literal,
             "without_full_batch_reset": no_reset,
-            "resets_in_timed_region": bool((args.warmup % 200) + args.steps >= 200),
+            "resets_in_timed_region": bool((args.warmup % max_steps) + args.steps >= max_steps),
+            "other_configs": others,
         }
+        if args.no_gather and world > 1:
+            out["config"]["parallelism"] = f"env-shard x{world}, no exchange (--no-gather)"
         if prof["scene"][1]:    # --observation-mode visual / visuotactile: the scene camera's two kernels (eye<-frame transforms + raster), per draw
             out["scene_camera"] = {"observation_mode": modes["observation_mode"], "ms_per_draw": round(prof["scene"][0] / prof["scene"][1], 4),
                                    "draws": prof["scene"][1]}
-        if world == 1 and not args.no_cpu_baseline and args.env == "edge_follow-v0":
+        if solo and not args.no_cpu_baseline and args.env == "edge_follow-v0":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    venv.close()
+    if gathered and hasattr(env, "close"):
+        env.close()
+    w.close()
     if dist is not None:
         dist.destroy_process_group()
 

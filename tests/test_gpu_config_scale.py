@@ -1,0 +1,141 @@
+"""HIP vs the CPU oracle at the BASELINE configs' own batch sizes and over whole episodes.
+
+(a) 1024 envs x (reset + 8 random-action steps) for configs 2, 3, 4 and 5: every env's joints, reward, done, reset tick count and tactile
+    image against its own oracle env (1024 oracle envs on the host cores, tests/oracle_pool.py); object_push also the contact-pair ids of
+    every step, BIT-EXACT on every env.
+(b) 64 envs x 250 steps with auto_reset (episodes of max_steps = 200 are crossed, envs that meet their goal reset earlier) for
+    edge_follow and surface_follow-v0: dones and reset tick counts exact at every step, images bit-exact at every step, joints at every
+    25th step.
+
+Stated tolerances: joints 1e-9 rad in (a), 1e-8 rad in (b) (f64 on both sides, different formulations; errors accumulate over an episode);
+reward 1e-5 (the device hands out float32); tactile images bit-exact for the contact-free configs 2, 3, 5.  Config 4 (contacts): the two
+f64 contact solves agree to ~1e-9 m on the cube pose (rounding differences amplified by the stiff contact rows; asserted < 1e-8), which moves
+the float32 camera<-stimulus transform the raster consumes by one ulp in about half of the frames.  Stated rule: the transform within
+2 float32 ulps of its largest entry; an image may differ by one grey level on at most 16 pixels; at least 99 % of the images BIT-EXACT
+(measured: 9 of 9 216 differ).
+"""
+import numpy as np
+import pytest
+
+from oracle_pool import oracle_rollouts
+
+pytestmark = pytest.mark.gpu
+
+EDGE = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")                                     # BASELINE configs[1]
+SURF = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")                                      # configs[2]
+PUSH = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
+            observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")   # configs[3]
+BAL = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=True, rand_embed_dist=True,
+           observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")          # configs[4]
+
+CASES = {   # env id, oracle class, modes, image size, act_dim, max_steps
+    "config2_edge_follow": ("edge_follow-v0", "OracleEdgeFollowEnv", EDGE, 128, 2, 200),
+    "config3_surface_follow": ("surface_follow-v0", "OracleSurfaceFollowAutoEnv", SURF, 128, 3, 200),
+    "config4_object_push": ("object_push-v0", "OracleObjectPushEnv", PUSH, 128, 2, 1000),
+    "config5_object_balance": ("object_balance-v0", "OracleObjectBalanceEnv", BAL, 256, 2, 250),
+    "edge_follow_mg400": ("edge_follow-v0", "OracleEdgeFollowEnv", dict(EDGE, arm_type="mg400"), 128, 2, 200),   # tree topology, pinv control
+}
+
+
+def _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset, want_contacts=False):
+    import tactile_gym_amd as tg
+    v = tg.make_vec(env_id, num_envs=n, max_steps=max_steps, image_size=[size, size], env_modes=modes, seed=seed, auto_reset=auto_reset)
+    obs = v.reset()
+    st = v.get_state()
+    rec = dict(img=[obs["tactile"][..., 0].copy()], q=[st["q"].copy()], rew=[], done=[], reset_ticks=[st["reset_ticks"].copy()], feat=[], cc=[],
+               cid=[], body=[], goal_id=[], term={}, xf=[st["stim_xform"].copy()])
+    for s in range(actions.shape[0]):
+        obs, rew, done, info = v.step(actions[s])
+        st = v.get_state()
+        rec["img"].append(obs["tactile"][..., 0].copy()), rec["q"].append(st["q"].copy()), rec["rew"].append(rew), rec["done"].append(done)
+        rec["reset_ticks"].append(st["reset_ticks"].copy()), rec["xf"].append(st["stim_xform"].copy())
+        if "extended_feature" in obs:
+            rec["feat"].append(obs["extended_feature"].copy())
+        if "body_pos" in st:
+            rec["body"].append(np.concatenate([st["body_pos"], st["body_rot"].reshape(n, 9)], axis=1))
+        if want_contacts:
+            rec["cc"].append(st["contact_count"].copy()), rec["cid"].append(st["contact_ids"].copy()), rec["goal_id"].append(st["goal_id"].copy())
+        for i in np.nonzero(done)[0]:
+            if auto_reset:
+                rec["term"][(s, int(i))] = info[i]["terminal_observation"]["tactile"][..., 0]
+    v.close()
+    return {k: (np.asarray(x) if isinstance(x, list) else x) for k, x in rec.items()}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_config_scale_1024_envs_match_oracle(case):
+    env_id, cls, modes, size, act_dim, max_steps = CASES[case]
+    n, steps, seed = 1024, 8, 900
+    actions = np.random.default_rng(7).uniform(-0.25, 0.25, size=(steps, n, act_dim)).astype(np.float32)
+    push = case == "config4_object_push"
+    hip = _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset=False, want_contacts=push)
+    ref = oracle_rollouts(cls, dict(max_steps=max_steps, image_size=(size, size), env_modes=modes), seed, actions,
+                          follow=hip["goal_id"] if push else None)
+    assert len(ref) == n and all(r is not None for r in ref)
+    worst_q = worst_r = worst_b = 0.0
+    bad_images, knife, bad_xf = 0, 0, 0
+    for i, r in enumerate(ref):
+        assert hip["reset_ticks"][0][i] == r["reset_ticks"][0], (case, i)
+        dq = np.abs(hip["q"][:, i] - r["q"]).max()
+        worst_q = max(worst_q, dq)
+        assert dq < 1e-9, (case, i, dq)
+        worst_r = max(worst_r, np.abs(hip["rew"][:, i] - r["rew"]).max())
+        assert np.array_equal(hip["done"][:, i].astype(bool), r["done"].astype(bool)), (case, i)
+        diff = hip["img"][:, i].astype(np.int16) - r["img"].astype(np.int16)
+        per_image = (diff != 0).reshape(steps + 1, -1).sum(1)
+        if push:
+            dxf = np.abs(hip["xf"][:, i].astype(np.float64) - r["xf"].astype(np.float64)).max(axis=1)     # per frame
+            same_xf = dxf == 0.0
+            assert (dxf <= 2 * np.spacing(np.abs(r["xf"]).max(axis=1).astype(np.float32))).all(), (case, i, dxf)
+            assert per_image.max() <= 16 and np.abs(diff).max() <= 1, (case, i, per_image)
+            bad_images += int((per_image > 0).sum())
+            bad_xf += int((~same_xf).sum())
+            knife += r["knife"]
+            # contact-pair indices after every step: count and ids in solver row order, bit-exact on every env
+            assert np.array_equal(hip["cc"][:, i], r["cc"]), (case, i, hip["cc"][:, i], r["cc"])
+            assert np.array_equal(hip["cid"][:, i], r["cid"]), (case, i)
+            assert np.array_equal(hip["goal_id"][:, i], r["goal_id"]), (case, i)
+            assert np.abs(hip["feat"][:, i] - r["feat"]).max() < 1e-6, (case, i)
+        else:
+            assert per_image.max() == 0, (case, i, per_image)
+        if len(r["body"]):
+            worst_b = max(worst_b, np.abs(hip["body"][:, i] - r["body"]).max())
+    assert worst_r < 1e-5, worst_r
+    assert worst_b < 1e-8, worst_b
+    if push:
+        assert bad_images <= 0.01 * n * (steps + 1), (bad_images, bad_xf)
+        assert knife <= n
+        assert (hip["cc"] >= 4).all()            # the cube rests on the table in every env; the tip pushes it in most
+        assert (hip["cc"] == 5).mean() > 0.5
+    print(f"{case}: {n} envs x (reset + {steps} steps): worst |dq| {worst_q:.2e} rad, |d reward| {worst_r:.2e}, |d body| {worst_b:.2e}, "
+          f"images not bit-exact {bad_images} of {n * (steps + 1)} (float32 transforms not bit-identical: {bad_xf})")
+
+
+@pytest.mark.parametrize("case", ["config2_edge_follow", "config3_surface_follow"])
+def test_long_horizon_auto_reset_matches_oracle(case):
+    env_id, cls, modes, size, act_dim, max_steps = CASES[case]
+    n, steps, seed = 64, 250, 4000
+    actions = np.random.default_rng(11).uniform(-0.25, 0.25, size=(steps, n, act_dim)).astype(np.float32)
+    hip = _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset=True)
+    ref = oracle_rollouts(cls, dict(max_steps=max_steps, image_size=(size, size), env_modes=modes), seed, actions, auto_reset=True)
+    worst_q, resets = 0.0, 0
+    for i, r in enumerate(ref):
+        assert np.array_equal(hip["done"][:, i].astype(bool), r["done"].astype(bool)), (case, i, np.nonzero(hip["done"][:, i])[0], np.nonzero(r["done"])[0])
+        # reset tick counts: the device's value after each step equals the count of the oracle's most recent reset
+        k, expect = 0, []
+        for s in range(steps):
+            k += int(r["done"][s])
+            expect.append(r["reset_ticks"][k])
+        assert hip["reset_ticks"][0][i] == r["reset_ticks"][0] and np.array_equal(hip["reset_ticks"][1:, i], expect), (case, i)
+        resets += k
+        assert np.array_equal(hip["img"][:, i], r["img"]), (case, i, np.nonzero((hip["img"][:, i] != r["img"]).reshape(steps + 1, -1).any(1))[0])
+        for s, img in r["term"].items():          # the terminal observation handed out in info is the pre-reset frame
+            assert np.array_equal(hip["term"][(s, i)], img), (case, i, s)
+        dq = np.abs(hip["q"][::25, i] - r["q"][::25]).max()
+        worst_q = max(worst_q, dq)
+        assert dq < 1e-8, (case, i, dq)
+        assert np.abs(hip["rew"][:, i] - r["rew"]).max() < 1e-5
+    assert resets >= n           # every env crossed max_steps at least once
+    print(f"{case}: {n} envs x {steps} steps, {resets} auto-resets: worst |dq| at every 25th step {worst_q:.2e} rad, images bit-exact")

@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 7
+#define TG_ABI_VERSION 8
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -225,6 +225,36 @@ int tg_get_packed_outputs(tg_ctx* ctx, void** dev_ptr, int64_t* obs_bytes, int64
 int tg_get_interior_count(tg_ctx* ctx, int32_t* k);
 int tg_pack_interior(tg_ctx* ctx, void* dst_dev);
 int tg_unpack_interior(tg_ctx* ctx, const void* src_dev, int32_t n_images, void* dst_dev);
+/* ---- tile-sparse tactile payload and direct stores into rank 0's memory (csrc/tg_exchange.hip) ------------------------------------
+ * A tactile image is zero away from the contact patch and a constant paste on the border ring (tactile_sensor.py:261-294).  Cut into
+ * 16 x 16 tiles, only the tiles that differ from that constant template travel (lossless; 9 % of the bytes of an edge_follow batch, 22 % of
+ * object_balance at 256 x 256, 48 % surface_follow, 73 % object_push).  Message: one 16-byte header {u32 count, n_images, tiles per image,
+ * magic} and `count` records of 272 bytes {u32 tile id = image * tiles_per_image + tile, 12 bytes pad, 16 rows x 16 pixels}; records are in
+ * no particular order.  These entry points are context free (raw device pointers + a HIP stream; NULL = the default stream).
+ * tg_get_tile_template: the template of a context's sensor, uint8 [H][W] (device).
+ * tg_pack_tiles: obs uint8 [n_images][h][w] -> dst (tg_tiles_capacity bytes; may be another GPU's memory opened with tg_ipc_open);
+ *   counters_dev = two zeroed uint32 in LOCAL device memory (left zero again by every launch).
+ * tg_unpack_tiles: src message -> dst uint8 [n_images][h][w]: the template everywhere, then the records. */
+int tg_get_tile_template(tg_ctx* ctx, void** dev_ptr);
+int tg_tiles_capacity(int32_t n_images, int32_t h, int32_t w, int64_t* bytes);
+int tg_pack_tiles(void* hip_stream, const void* obs_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev,
+                  void* counters_dev);
+int tg_unpack_tiles(void* hip_stream, const void* src_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev);
+/* Receive slots that peers store into directly (one process per GPU; the reference's counterpart is the pipe of each SubprocVecEnv worker,
+ * sb3_helpers/rl_utils.py:17-30).  tg_ipc_alloc: zeroed device memory on the current device + its 64-byte IPC handle; tg_ipc_open /
+ * tg_ipc_close: map / unmap it in another process (its GPU then reaches the memory over xGMI).  HSA_ENABLE_IPC_MODE_LEGACY=0 is required. */
+int tg_ipc_alloc(int64_t bytes, void** dev_ptr, uint8_t* handle64);
+int tg_ipc_free(void* dev_ptr);
+int tg_ipc_open(const uint8_t* handle64, void** dev_ptr);
+int tg_ipc_close(void* dev_ptr);
+/* Device copy on a stream whose destination (or source) may be memory opened with tg_ipc_open; both pointers 16-byte aligned. */
+int tg_copy_bytes(void* hip_stream, void* dst_dev, const void* src_dev, int64_t bytes);
+/* Stream-ordered flags (uint32, monotone step counters) in such memory.  tg_flag_set: after everything enqueued before it on the stream has
+ * finished, flags[i * stride_words] = value for i < n (release, system scope).  tg_flag_wait: the stream goes on once every
+ * flags[i * stride_words] has reached value (compared modulo 2^32); after timeout_ms of waiting it goes on anyway and ORs bit (i & 31) into
+ * *err_dev (uint32 in local device memory, may be NULL).  n <= 64. */
+int tg_flag_set(void* hip_stream, void* flags_dev, int32_t n, int32_t stride_words, uint32_t value);
+int tg_flag_wait(void* hip_stream, const void* flags_dev, int32_t n, int32_t stride_words, uint32_t value, void* err_dev, int32_t timeout_ms);
 /* Envs with an "extended_feature" observation (object_push, object_roll) append it to the same allocation, so that config 4's
  * tactile_and_feature observation still travels as one message: [... | done u8[N] | pad to 4 B | feature f32[N][dim]]
  * (object_push_env.py:611-629).  *feature_off = byte offset of the feature block (-1: this env has none). */

@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -140,6 +140,17 @@ SYMBOLS = {
     "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     "tg_pack_interior": (C.c_int, [_ctx, C.c_void_p]),
     "tg_unpack_interior": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p]),
+    "tg_get_tile_template": (C.c_int, [_ctx, _vpp]),
+    "tg_tiles_capacity": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "tg_pack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "tg_unpack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "tg_ipc_alloc": (C.c_int, [C.c_int64, _vpp, _u8p]),
+    "tg_ipc_free": (C.c_int, [C.c_void_p]),
+    "tg_ipc_open": (C.c_int, [_u8p, _vpp]),
+    "tg_ipc_close": (C.c_int, [C.c_void_p]),
+    "tg_copy_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "tg_flag_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32]),
+    "tg_flag_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32]),
     "tg_get_obs_oracle": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32)]),
     "tg_copy_obs_oracle": (C.c_int, [_ctx, _fp]),
     "tg_enable_oracle_obs": (C.c_int, [_ctx]),

@@ -22,11 +22,13 @@
 #include "tg_scene.h"
 #include "tg_noise.h"
 #include "tg_raster.h"
+#include "tg_exchange.h"
 
 namespace tg {
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+int report_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }   // the other translation units' way to tg_last_error()
 #define TG_HIP(expr)                                                                                         \
     do {                                                                                                     \
         hipError_t e_ = (expr);                                                                              \
@@ -377,6 +379,7 @@ struct tg_ctx {
     unsigned long long* d_scene_static = nullptr;
     tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
+    uint8_t* d_tile_tmpl = nullptr;   // tile-sparse payload (tg_pack_tiles): the image every env shows without a contact - zero inside, the pasted ring outside
     int32_t *d_int_idx = nullptr, *d_int_rank = nullptr;   // interior-only payload: pixel of interior position k / interior position of pixel p (-1: ring)
     int n_interior = 0;
     float* d_oracle = nullptr;        // [n][34] observation_mode "oracle" vectors (tg_get_obs_oracle), allocated on first use
@@ -795,6 +798,13 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     }
     TG_HIP(hipMalloc(&c->d_border, npix)); TG_HIP(hipMemcpy(c->d_border, sensor->border_mask, npix, hipMemcpyHostToDevice));
     c->cfg_turn_off_border = sensor->turn_off_border != 0;
+    {   // what a tile is compared with (tg_pack_tiles): t_s_camera's output for an untouched sensor (tactile_sensor.py:261-294)
+        std::vector<uint8_t> g8(npix), tmpl(npix, 0);
+        make_gray_u8(sensor->nodef_gray, (int)npix, g8.data());
+        if (!c->cfg_turn_off_border)
+            for (size_t p = 0; p < npix; ++p) tmpl[p] = sensor->border_mask[p] == 1 ? g8[p] : 0;
+        TG_HIP(hipMalloc(&c->d_tile_tmpl, npix)); TG_HIP(hipMemcpy(c->d_tile_tmpl, tmpl.data(), npix, hipMemcpyHostToDevice));
+    }
     {   // interior word tables (tg_pack_interior / tg_unpack_interior): the 4-pixel words that hold at least one interior pixel
         const size_t nw = (size_t)npix / 4;
         std::vector<int32_t> idx, rank_of(nw, -1);
@@ -952,7 +962,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1120,6 +1130,11 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
 int tg_get_interior_count(tg_ctx* c, int32_t* k) {
     if (!c || !k) return fail(-1, "NULL argument");
     *k = c->cfg_turn_off_border ? -1 : 4 * c->n_interior;   // bytes per image; -1: the ring carries rendered values (turn_off_border), nothing to drop
+    return 0;
+}
+int tg_get_tile_template(tg_ctx* c, void** p) {
+    if (!c || !p) return fail(-1, "NULL argument");
+    *p = c->d_tile_tmpl;
     return 0;
 }
 int tg_pack_interior(tg_ctx* c, void* dst_dev) {

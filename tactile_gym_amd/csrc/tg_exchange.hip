@@ -1,0 +1,246 @@
+// Per-step exchange of observations to rank 0 (replaces SubprocVecEnv's pickled pipes, sb3_helpers/rl_utils.py:17-30).
+//
+//  * Tile-sparse tactile payload.  A tactile image is zero away from the contact patch and a constant paste on the sensor's border ring
+//    (tactile_sensor.py:261-294): cut into 16 x 16 tiles, 3-9 % of the tiles of an edge_follow image differ from that constant
+//    template.  tg_pack_tiles writes only those tiles (lossless), tg_unpack_tiles restores the images.
+//  * Direct stores over xGMI.  Rank 0 allocates the receive slots (tg_ipc_alloc) and hands every peer the IPC handle; a peer's pack
+//    kernel stores straight into its slot of rank 0's HBM over its own xGMI link - no staging copy, no collective, and the message
+//    length (count of live tiles) never has to be known on a host.  Ordering is carried by monotone 32-bit flags in the same allocation:
+//    a one-lane kernel releases a flag at system scope after the producing kernel has finished (its stores are written back at the end
+//    of that kernel), the other side's one-wave kernel spins on it with acquire loads - bounded by a wall-clock timeout, so that a
+//    missing partner becomes an error word instead of a hung queue.
+//
+// Everything here is context free: raw device pointers and a HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../../include/tactile_gym_hip.h"
+#include "tg_exchange.h"
+
+namespace tg {
+namespace {
+
+constexpr uint32_t kTileMagic = 0x54475431u;   // "TGT1"
+constexpr int kRecWords = 17;                  // a record: one 16-byte header (tile id) + 16 rows of 16 pixels
+
+#define TGX_HIP(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return report_error(-2, (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); \
+    } while (0)
+
+// One wavefront per 64 tiles of one image; lane = tile.  A lane reads its tile (16 rows x 16 B: for one row the lanes of a tile row read
+// consecutive 16-byte pieces, whole cache lines are used) and the same piece of the template; live = any pixel differs.  The wave takes
+// `count` consecutive record slots with ONE atomic on a counter in local memory, compacts its live tiles through LDS and streams the
+// records out as consecutive 16-byte stores (so a remote destination sees full-width writes).  The last wave to finish publishes the
+// header and clears the counters for the next launch.
+__global__ __launch_bounds__(64) void k_pack_tiles(const uint8_t* __restrict__ obs, const uint8_t* __restrict__ tmpl, int n_img, int H, int W, int T,
+                                                   int TW, int groups, uint8_t* __restrict__ dst, uint32_t* __restrict__ counters) {
+    __shared__ uint4 rec[64 * kRecWords];
+    const int img = blockIdx.x / groups, g = blockIdx.x - img * groups;
+    const int lane = threadIdx.x;
+    const int tile = g * 64 + lane;
+    uint4 rows[16];
+    bool live = false;
+    if (tile < T) {
+        const int tr = tile / TW, tc = tile - tr * TW;
+        const size_t off = (size_t)(tr * 16) * W + (size_t)tc * 16;
+        const uint8_t* __restrict__ o = obs + (size_t)img * H * W + off;
+        const uint8_t* __restrict__ t = tmpl + off;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            rows[r] = *reinterpret_cast<const uint4*>(o + (size_t)r * W);
+            const uint4 tv = *reinterpret_cast<const uint4*>(t + (size_t)r * W);
+            acc |= (rows[r].x ^ tv.x) | (rows[r].y ^ tv.y) | (rows[r].z ^ tv.z) | (rows[r].w ^ tv.w);
+        }
+        live = acc != 0;
+    }
+    const unsigned long long mask = __ballot(live);
+    const int cnt = __popcll(mask);
+    uint32_t base = 0;
+    if (lane == 0 && cnt) base = atomicAdd(&counters[0], (uint32_t)cnt);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (live) {
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        rec[rank * kRecWords] = make_uint4((uint32_t)(img * T + tile), 0u, 0u, 0u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rec[rank * kRecWords + 1 + r] = rows[r];
+    }
+    __syncthreads();
+    uint4* __restrict__ out = reinterpret_cast<uint4*>(dst + 16) + (size_t)base * kRecWords;
+    for (int i = lane; i < cnt * kRecWords; i += 64) out[i] = rec[i];
+    __threadfence();
+    if (lane == 0) {
+        const uint32_t ticket = atomicAdd(&counters[1], 1u);
+        if (ticket == gridDim.x - 1) {                    // every other wave has taken its slots and written its records
+            const uint32_t total = atomicExch(&counters[0], 0u);
+            counters[1] = 0u;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(total, (uint32_t)n_img, (uint32_t)T, kTileMagic);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_template(const uint4* __restrict__ tmpl, int hw16, size_t total16, uint4* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total16; i += (size_t)gridDim.x * blockDim.x) dst[i] = tmpl[i % hw16];
+}
+
+// 16 lanes per record (one row each); records beyond the header's count do nothing.
+__global__ __launch_bounds__(256) void k_scatter_tiles(const uint8_t* __restrict__ src, int n_img, int H, int W, int T, int TW, uint8_t* __restrict__ dst) {
+    const uint4 hdr = *reinterpret_cast<const uint4*>(src);
+    if (hdr.w != kTileMagic || (int)hdr.z != T) return;                     // not a tile message for this image geometry: leave the template
+    const uint32_t cap = (uint32_t)n_img * (uint32_t)T;
+    const uint32_t count = hdr.x < cap ? hdr.x : cap;
+    const uint32_t slot = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const int row = threadIdx.x & 15;
+    if (slot >= count) return;
+    const uint4* __restrict__ rec = reinterpret_cast<const uint4*>(src + 16) + (size_t)slot * kRecWords;
+    const uint32_t id = rec[0].x;
+    const int img = (int)(id / (uint32_t)T), tile = (int)(id - (uint32_t)img * (uint32_t)T);
+    if (img >= n_img) return;
+    const int tr = tile / TW, tc = tile - tr * TW;
+    *reinterpret_cast<uint4*>(dst + (size_t)img * H * W + (size_t)(tr * 16 + row) * W + (size_t)tc * 16) = rec[1 + row];
+}
+
+// 16-byte pieces (grid stride), then the last < 16 bytes one by one: a device copy whose destination may be another GPU's memory.
+__global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ src, size_t bytes, uint8_t* __restrict__ dst) {
+    const size_t n16 = bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < bytes - 16 * n16) dst[16 * n16 + threadIdx.x] = src[16 * n16 + threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void k_flag_set(uint32_t* flags, int n, int stride, uint32_t value) {
+    const int i = threadIdx.x;
+    if (i < n) __hip_atomic_store(flags + (size_t)i * stride, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Lane i waits until flags[i * stride] has reached `value` (monotone counters, compared modulo 2^32).  100 MHz wall clock.
+__global__ __launch_bounds__(64) void k_flag_wait(const uint32_t* flags, int n, int stride, uint32_t value, uint32_t* err, long long timeout_ticks) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* p = flags + (size_t)i * stride;
+    const long long t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+        if (wall_clock64() - t0 > timeout_ticks) {
+            if (err) atomicOr(err, 1u << (i & 31));
+            break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+
+bool tile_geometry(int h, int w) { return h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0; }
+
+}  // namespace
+}  // namespace tg
+
+using tg::report_error;
+
+int tg_tiles_capacity(int32_t n_images, int32_t h, int32_t w, int64_t* bytes) {
+    if (!bytes || n_images <= 0 || !tg::tile_geometry(h, w)) return report_error(-1, "tg_tiles_capacity: image sides must be positive multiples of 16");
+    *bytes = 16 + (int64_t)n_images * (h / 16) * (w / 16) * (16 * tg::kRecWords);
+    return 0;
+}
+
+int tg_pack_tiles(void* stream, const void* obs_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev, void* counters_dev) {
+    if (!obs_dev || !template_dev || !dst_dev || !counters_dev || n_images <= 0 || !tg::tile_geometry(h, w))
+        return report_error(-1, "tg_pack_tiles: bad argument (image sides must be multiples of 16)");
+    const int TW = w / 16, T = TW * (h / 16), groups = (T + 63) / 64;
+    if ((int64_t)n_images * groups > 0x7fffffffLL || (int64_t)n_images * T > 0x7fffffffLL) return report_error(-1, "tg_pack_tiles: too many tiles for one launch");
+    hipLaunchKernelGGL(tg::k_pack_tiles, dim3((unsigned)(n_images * groups)), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)obs_dev,
+                       (const uint8_t*)template_dev, n_images, h, w, T, TW, groups, (uint8_t*)dst_dev, (uint32_t*)counters_dev);
+    TGX_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_unpack_tiles(void* stream, const void* src_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev) {
+    if (!src_dev || !template_dev || !dst_dev || n_images <= 0 || !tg::tile_geometry(h, w))
+        return report_error(-1, "tg_unpack_tiles: bad argument (image sides must be multiples of 16)");
+    const int TW = w / 16, T = TW * (h / 16);
+    const int hw16 = h * w / 16;
+    const size_t total16 = (size_t)n_images * hw16;
+    const unsigned fill_blocks = (unsigned)((total16 + 255) / 256 < 8192 ? (total16 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(tg::k_fill_template, dim3(fill_blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)template_dev, hw16, total16, (uint4*)dst_dev);
+    const int64_t cap = (int64_t)n_images * T;
+    if ((cap + 15) / 16 > 0x7fffffffLL) return report_error(-1, "tg_unpack_tiles: too many tiles for one launch");
+    hipLaunchKernelGGL(tg::k_scatter_tiles, dim3((unsigned)((cap + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src_dev, n_images, h, w,
+                       T, TW, (uint8_t*)dst_dev);
+    TGX_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_ipc_alloc(int64_t bytes, void** dev_ptr, uint8_t* handle) {
+    if (bytes <= 0 || !dev_ptr || !handle) return report_error(-1, "tg_ipc_alloc: bad argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI hands IPC handles out as 64 bytes");
+    void* p = nullptr;
+    // uncached device memory: remote stores land in HBM and no stale line of it can sit in a local L2 (what RCCL allocates for its own
+    // peer-written buffers); plain hipMalloc if the runtime refuses the flag
+    if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+        TGX_HIP(hipMalloc(&p, (size_t)bytes));
+    }
+    if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(p);
+        return report_error(-2, "tg_ipc_alloc: clearing the allocation failed");
+    }
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return report_error(-2, (std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e) + " (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set)").c_str());
+    }
+    memcpy(handle, &h, 64);
+    *dev_ptr = p;
+    return 0;
+}
+
+int tg_ipc_free(void* dev_ptr) {
+    if (dev_ptr) TGX_HIP(hipFree(dev_ptr));
+    return 0;
+}
+
+int tg_ipc_open(const uint8_t* handle, void** dev_ptr) {
+    if (!handle || !dev_ptr) return report_error(-1, "tg_ipc_open: NULL argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    void* p = nullptr;
+    TGX_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *dev_ptr = p;
+    return 0;
+}
+
+int tg_ipc_close(void* dev_ptr) {
+    if (dev_ptr) TGX_HIP(hipIpcCloseMemHandle(dev_ptr));
+    return 0;
+}
+
+int tg_copy_bytes(void* stream, void* dst_dev, const void* src_dev, int64_t bytes) {
+    if (!dst_dev || !src_dev || bytes < 0) return report_error(-1, "tg_copy_bytes: bad argument");
+    if (((uintptr_t)dst_dev | (uintptr_t)src_dev) & 15) return report_error(-1, "tg_copy_bytes: pointers must be 16-byte aligned");
+    if (bytes == 0) return 0;
+    const size_t n16 = (size_t)bytes / 16;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(tg::k_copy_bytes, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src_dev, (size_t)bytes, (uint8_t*)dst_dev);
+    TGX_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_flag_set(void* stream, void* flags_dev, int32_t n, int32_t stride_words, uint32_t value) {
+    if (!flags_dev || n <= 0 || n > 64 || stride_words <= 0) return report_error(-1, "tg_flag_set: bad argument (1 <= n <= 64)");
+    hipLaunchKernelGGL(tg::k_flag_set, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t*)flags_dev, n, stride_words, value);
+    TGX_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_flag_wait(void* stream, const void* flags_dev, int32_t n, int32_t stride_words, uint32_t value, void* err_dev, int32_t timeout_ms) {
+    if (!flags_dev || n <= 0 || n > 64 || stride_words <= 0 || timeout_ms <= 0) return report_error(-1, "tg_flag_wait: bad argument (1 <= n <= 64, timeout > 0)");
+    hipLaunchKernelGGL(tg::k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)flags_dev, n, stride_words, value, (uint32_t*)err_dev,
+                       (long long)timeout_ms * 100000LL);
+    TGX_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,32 +1,200 @@
 """Multi-GPU sharding: envs are independent, so rank r owns envs [r*n_local, (r+1)*n_local) and the only exchange is
-one gather of (tactile obs, reward, done) to rank 0 per step — the MI355X-native replacement for
-SubprocVecEnv's per-step pickled pipes (reference sb3_helpers/rl_utils.py:17-30).
+one message of (tactile obs, reward, done[, extended_feature, visual]) to rank 0 per step — the MI355X-native replacement
+for SubprocVecEnv's per-step pickled pipes (reference sb3_helpers/rl_utils.py:17-30).
 
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests).
-The gather is a direct many-to-one exchange: every peer sends its shard to rank 0 over its own xGMI link, so the
-7 links into rank 0 work concurrently (a ring would serialise the 16-64 MiB shards on one link).
+The exchange is many-to-one: every peer reaches rank 0 over its own xGMI link, so the 7 links into rank 0 work concurrently (a ring
+would serialise the 16-64 MiB shards on one link).
+
+payload (what the tactile part of a rank's message carries):
+  "full"      every pixel.
+  "interior"  only the 4-pixel words that hold a pixel inside the sensor's border mask; rank 0 restores the constant ring
+              (tactile_sensor.py:291-292): 62 % of the bytes of a TacTip image.
+  "tiles"     only the 16 x 16 tiles that differ from the untouched sensor's image (zero inside, the ring outside): lossless, 9 % of the
+              bytes of an edge_follow batch, 22 % object_balance at 256 x 256, 48 % surface_follow, 73 % object_push.  Variable length.
+  "auto"      ipc transport: tiles; collective transport: interior when the ring is at least 10 % of the image, else full.
+transport (how it travels):
+  "collective"  torch.distributed: one gather of the fixed-size message per step (full / interior).  A tile message has a length only the
+                sender's device knows, so it goes as an exact-size send / recv after a small fixed gather that carries the counts
+                (reward | done | feature | visual | count): two host reads per step, kept for completeness and for the CPU tests.
+  "ipc"         rank 0 owns the receive slots (tg_ipc_alloc); every peer's pack kernel stores straight into its slot of rank 0's HBM
+                (tg_ipc_open), ordered by stream-side flags (tg_flag_set / tg_flag_wait): no staging copy, no host in the loop, and the
+                variable-length tile message costs nothing extra.  Needs one process per GPU on one node.
+  "auto"        ipc when the set-up handshake succeeds on every rank, else collective.
 """
+import ctypes as C
+
 from . import _capi as capi
 
-import numpy as np
+TILE_MAGIC = 0x54475431
+TILE_REC = 272
+
+
+def _align(x, a):
+    return (x + a - 1) // a * a
+
+
+# ---- the tile payload restated with torch ops: what the CPU (gloo) tests run, and the definition the kernels are checked against
+def torch_pack_tiles(torch, tac, tmpl, dst):
+    """tac uint8 [n, H, W(, 1)], tmpl uint8 [H*W] -> message in dst (uint8, capacity bytes); returns the record count."""
+    n, H, W = int(tac.shape[0]), int(tac.shape[1]), int(tac.shape[2])
+    TH, TW = H // 16, W // 16
+    T = TH * TW
+    t = tac.reshape(n, TH, 16, TW, 16).permute(0, 1, 3, 2, 4).reshape(n * T, 256)
+    tm = tmpl.reshape(TH, 16, TW, 16).permute(0, 2, 1, 3).reshape(T, 256)
+    live = (t != tm.repeat(n, 1)).any(dim=1)
+    ids = torch.nonzero(live).reshape(-1)
+    count = int(ids.numel())
+    rec = torch.zeros(count, TILE_REC, dtype=torch.uint8, device=tac.device)
+    rec[:, :4] = ids.to(torch.int32).reshape(-1, 1).contiguous().view(torch.uint8)
+    rec[:, 16:] = t[ids]
+    dst[:16] = torch.tensor([count, n, T, TILE_MAGIC], dtype=torch.int32, device=tac.device).view(torch.uint8)
+    dst[16:16 + TILE_REC * count] = rec.reshape(-1)
+    return count
+
+
+def torch_unpack_tiles(torch, src, tmpl, n, H, W, dst):
+    """message in src -> dst uint8 [n, H*W]."""
+    TH, TW = H // 16, W // 16
+    T = TH * TW
+    hdr = src[:16].contiguous().view(torch.int32)
+    count = int(hdr[0])
+    assert int(hdr[3]) == TILE_MAGIC and int(hdr[2]) == T and 0 <= count <= n * T
+    rec = src[16:16 + TILE_REC * count].reshape(count, TILE_REC)
+    ids = rec[:, :4].contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+    tm = tmpl.reshape(TH, 16, TW, 16).permute(0, 2, 1, 3).reshape(T, 256)
+    tiles = tm.repeat(n, 1).clone()
+    tiles[ids] = rec[:, 16:]
+    dst.copy_(tiles.reshape(n, TH, TW, 16, 16).permute(0, 1, 3, 2, 4).reshape(n, H * W))
+
+
+class _DevArray:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class _IpcSlots:
+    """Rank 0's receive slots and the flags beside them, shared with the peers by IPC handle.  Layout of the allocation:
+    [flags: 4096 B | slot 0: world x msg | slot 1: world x msg]; flags (uint32, one per 64 bytes): ready[slot][rank] at word
+    16 * (slot * world + rank), consumed[slot][rank] at word 16 * (2 * world + slot * world + rank), handshake[rank] behind them."""
+
+    FLAG_BYTES = 16384
+
+    def __init__(self, torch, dist, rank, world, root, msg_bytes, device, timeout_ms):
+        self.torch, self.dist, self.rank, self.world, self.root, self.msg, self.device = torch, dist, rank, world, root, msg_bytes, device
+        self.timeout_ms = int(timeout_ms)
+        self.L = capi.lib()
+        assert 16 * 4 * (5 * world + 1) <= self.FLAG_BYTES, "too many ranks for the flag block"
+        total = self.FLAG_BYTES + 2 * world * msg_bytes
+        self.base, self.owner, self.failed = C.c_void_p(), rank == root, None
+        handle = (C.c_uint8 * 64)()
+        payload = [None]
+        if self.owner:
+            try:
+                capi.check(self.L.tg_ipc_alloc(total, C.byref(self.base), handle))
+                payload = [bytes(handle)]
+            except Exception as e:  # noqa: BLE001 - the peers must still be told (they wait in the broadcast)
+                self.failed, self.base = e, C.c_void_p()
+        dist.broadcast_object_list(payload, src=root)
+        if not self.owner:
+            if payload[0] is None:
+                self.failed = RuntimeError("rank 0 could not allocate the receive slots")
+            else:
+                try:
+                    h = (C.c_uint8 * 64).from_buffer_copy(payload[0])
+                    capi.check(self.L.tg_ipc_open(h, C.byref(self.base)))
+                except Exception as e:  # noqa: BLE001
+                    self.failed, self.base = e, C.c_void_p()
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)       # timeouts of this rank's waits (bit = flag lane)
+        self.local = torch.as_tensor(_DevArray(self.base.value, total), device=device) if (self.owner and self.failed is None) else None
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def slot_ptr(self, slot, r):
+        return self.base.value + self.FLAG_BYTES + (slot * self.world + r) * self.msg
+
+    def slot_tensor(self, slot):                      # rank 0 only: uint8 [world, msg]
+        off = self.FLAG_BYTES + slot * self.world * self.msg
+        return self.local[off:off + self.world * self.msg].view(self.world, self.msg)
+
+    def _flag_ptr(self, kind, slot, r):
+        word = 16 * ({"ready": 0, "consumed": 2 * self.world, "hello": 4 * self.world}[kind] + slot * self.world + r)
+        return C.c_void_p(self.base.value + 4 * word)
+
+    def set(self, kind, slot, r, n, value):
+        capi.check(self.L.tg_flag_set(self._stream(), self._flag_ptr(kind, slot, r), n, 16, value & 0xFFFFFFFF))
+
+    def wait(self, kind, slot, r, n, value):
+        capi.check(self.L.tg_flag_wait(self._stream(), self._flag_ptr(kind, slot, r), n, 16, value & 0xFFFFFFFF,
+                                       C.c_void_p(self.err.data_ptr()), self.timeout_ms))
+
+    def copy(self, dst_ptr, src_tensor):
+        capi.check(self.L.tg_copy_bytes(self._stream(), C.c_void_p(dst_ptr), C.c_void_p(src_tensor.data_ptr()), src_tensor.numel() * src_tensor.element_size()))
+
+    def handshake(self):
+        """Every peer stores a pattern into its slot and raises its flag; rank 0 waits (bounded) and checks the bytes."""
+        torch = self.torch
+        oks = [None] * self.world
+        self.dist.all_gather_object(oks, self.failed is None)      # every rank holds a mapping, or nobody goes on
+        if not all(oks):
+            return False
+        pat = torch.arange(16, dtype=torch.uint8, device=self.device) + 16 * self.rank + 1
+        ok = True
+        if not self.owner:
+            self.copy(self.slot_ptr(0, self.rank), pat)
+            self.set("hello", 0, self.rank, 1, 1)
+        else:
+            for r in range(self.world):
+                if r != self.root:
+                    self.wait("hello", 0, r, 1, 1)
+            torch.cuda.current_stream(self.device).synchronize()
+            got = self.slot_tensor(0)[:, :16].cpu()
+            for r in range(self.world):
+                if r != self.root and not torch.equal(got[r], (torch.arange(16, dtype=torch.uint8) + 16 * r + 1)):
+                    ok = False
+            self.slot_tensor(0)[:, :16].zero_()
+        torch.cuda.current_stream(self.device).synchronize()
+        oks = [None] * self.world
+        self.dist.all_gather_object(oks, bool(ok and int(self.err.item()) == 0))
+        return all(oks)
+
+    def check(self):
+        e = int(self.err.item())
+        if e:
+            raise RuntimeError(f"rank {self.rank}: exchange flags timed out after {self.timeout_ms} ms (lanes 0x{e & 0xFFFFFFFF:x}): a partner rank is missing or stuck")
+
+    def close(self):
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        self.torch.cuda.synchronize(self.device)
+        self.local = None
+        if not self.owner and self.base.value:
+            self.L.tg_ipc_close(self.base)
+        self.dist.barrier()                           # every mapping is gone before the owner frees
+        if self.owner and self.base.value:
+            self.L.tg_ipc_free(self.base)
+        self.base = C.c_void_p()
 
 
 class ShardedVecEnv:
     """Wraps this rank's local env shard (anything with reset()/step() returning per-shard tensors/arrays).
 
-    `local` must expose num_envs, reset() -> {"tactile": tensor[n,H,W,1]}, step(a) -> (obs, reward, done, info) with
-    torch tensors (device tensors under nccl, CPU tensors under gloo).  Rank 0's step() returns the gathered
+    `local` must expose num_envs, reset() -> {"tactile": tensor[n,H,W,1], ...}, step(a) -> (obs, reward, done, info) with
+    torch tensors (device tensors under nccl / ipc, CPU tensors under gloo).  Rank 0's step() returns the gathered
     [world * n] batch; other ranks return their local shard (what an actor-only rank needs).
 
-    Per step there is ONE collective: tactile obs (uint8), reward (float32) and done (uint8) are packed into one byte
-    buffer per rank and gathered together (three small-latency collectives per 0.15 ms step would cost as much as the step).
+    Per step there is ONE message per rank: [tactile part | pad to 16 | reward f32 | done u8 | pad to 4 | extended_feature f32[n][K] |
+    pad to 16 | visual u8[n][H][W][3]] (the last two when the observation has them).
 
     overlap=True ("overlap gather of step t with simulate of step t+1, double-buffered obs"): step() snapshots this
-    rank's results into one of two staging buffers, starts the gather asynchronously and returns; rank 0 is handed the batch of
+    rank's results into one of two slots, starts the exchange asynchronously and returns; rank 0 is handed the batch of
     the PREVIOUS step (complete by then), i.e. the learner side runs one step behind the simulators, and flush() waits for the
-    last gather and returns its batch.  With overlap=False every step() returns its own gathered batch (synchronous VecEnv)."""
+    last exchange and returns its batch.  With overlap=False every step() returns its own gathered batch (synchronous VecEnv).
+    A batch handed out stays valid until the next step() / reset() call."""
 
-    def __init__(self, local, dist=None, root=0, overlap=False, force_collective=False, payload="auto"):
+    def __init__(self, local, dist=None, root=0, overlap=False, force_collective=False, payload="auto", transport="collective", timeout_ms=20000):
         import torch
         if dist is None:
             import torch.distributed as dist
@@ -34,31 +202,21 @@ class ShardedVecEnv:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.n_local = local.num_envs
         self.num_envs = self.n_local * self.world
-        # force_collective: run the packed gather even with one rank (a 1-GPU box can then exercise the RCCL path end to end)
+        # force_collective: run the exchange even with one rank (a 1-GPU box can then exercise the RCCL path end to end)
         self._solo = self.world == 1 and not force_collective
         self.overlap = bool(overlap) and not self._solo
-        self._bufs = {}
-        self._stage, self._full, self._views, self._pending = [None, None], [None, None], [None, None], [None, None]
-        self._tick, self._layout, self._last = 0, None, None
-        # payload: what the tactile part of the per-step message carries.  "full": every pixel.  "interior": only the 4-pixel words that hold
-        # a pixel inside the sensor's border mask - the border ring of a TacTip image is a constant paste of the reference image
-        # (tactile_sensor.py:291-292), which rank 0 fills in from its own copy of that constant: 62 % of the bytes of a 128 x 128 TacTip image
-        # (61 % at 256 x 256) cross xGMI.  Two library kernels do the work (tg_pack_interior on the sender: 6.6 us per 1024 images,
-        # tg_unpack_interior on rank 0: 9.3 us per 1024 images, measured on an MI355X); with one rank (edge_follow, 1024 envs, 128 x 128,
-        # TG_BENCH_FORCE_COLLECTIVE=1) a step costs 0.062 ms without a gather, 0.097 ms with the full payload, 0.103 ms with the interior one,
-        # i.e. it pays as soon as a link is in the way (16.8 MB per peer per step at ~76 GB/s per direction is ~0.22 ms).  "auto" (default):
-        # interior when the shard exposes its border (`border_info()`) and the ring is at least 10 % of the image, else full.
-        self._interior = None
-        if payload not in ("auto", "full", "interior"):
+        if payload not in ("auto", "full", "interior", "tiles"):
             raise ValueError(f"payload {payload!r}")
-        info = local.border_info() if (payload != "full" and hasattr(local, "border_info")) else None
-        if payload == "interior" and info is None:
-            raise ValueError("payload='interior' needs a shard with border_info() (border paste on)")
-        if info is not None and not self._solo:
-            idx, template = info
-            if payload == "interior" or idx.numel() <= 0.9 * template.numel():
-                self._interior = (idx, template)
-        self._obs_full = [None, None]
+        if transport not in ("auto", "collective", "ipc"):
+            raise ValueError(f"transport {transport!r}")
+        self._want_payload, self._want_transport, self._timeout_ms = payload, transport, timeout_ms
+        self.payload = self.transport = None         # decided with the first message (needs the observation's shapes)
+        self._interior = self._tiles = None
+        self._bufs, self._ipc, self._lay = {}, None, None
+        self._stage, self._full, self._views, self._pending, self._obs_full = [None, None], [None, None], [None, None], [None, None], [None, None]
+        self._tick, self._handed = 0, 0              # messages started / the index of the newest message rank 0 has unpacked
+        self._counters = None
+        self._last_counts = None
 
     def env_slice(self):
         return slice(self.rank * self.n_local, (self.rank + 1) * self.n_local)
@@ -85,134 +243,341 @@ class ShardedVecEnv:
         self.dist.gather(t, gather_list=None, dst=self.root)
         return t
 
+    # ------------------------------------------------------------------ message layout and set-up (first message)
+    def _setup(self, obs):
+        torch = self.torch
+        tac, feat, vis = obs["tactile"], obs.get("extended_feature"), obs.get("visual")
+        assert tac.dtype == torch.uint8
+        dev, n = tac.device, int(tac.shape[0])
+        H, W = int(tac.shape[1]), int(tac.shape[2])
+        # transport
+        want = self._want_transport
+        if want in ("ipc", "auto") and (dev.type != "cuda" or not hasattr(self.local, "raw")):
+            if want == "ipc":
+                raise ValueError("transport='ipc' needs a device-resident shard (TorchShard)")
+            want = "collective"
+        # payload
+        payload = self._want_payload
+        info = self.local.border_info() if hasattr(self.local, "border_info") else None
+        tile_ok = hasattr(self.local, "tile_template") and H % 16 == 0 and W % 16 == 0 and tac[0].numel() == H * W
+        if payload == "interior" and info is None:
+            raise ValueError("payload='interior' needs a shard with border_info() (border paste on)")
+        if payload == "tiles" and not tile_ok:
+            raise ValueError("payload='tiles' needs a shard with tile_template() and image sides that are multiples of 16")
+        if payload == "auto":
+            if want in ("ipc", "auto") and tile_ok:
+                payload = "tiles"
+            elif info is not None and info[0].numel() <= 0.9 * info[1].numel():
+                payload = "interior"
+            else:
+                payload = "full"
+        packed = self.local.packed() if hasattr(self.local, "packed") else None   # the library's own contiguous output block
+        nb_full = tac.numel()
+        if packed is not None:                       # (block, reward offset[, feature offset or -1]): the library's layout rules
+            lib_r = int(packed[1])
+            lib_f = int(packed[2]) if len(packed) > 2 and packed[2] is not None else -1
+            rest_bytes = packed[0].numel() - lib_r
+            f_in_rest = lib_f - lib_r if lib_f >= 0 else -1
+            fw = (packed[0].numel() - lib_f) // (4 * n) if lib_f >= 0 else 0       # the block's feature rows may be wider than the observation's
+        else:
+            lib_r = -1
+            f_in_rest = _align(5 * n, 4) if feat is not None else -1
+            fw = int(feat.shape[1]) if feat is not None else 0
+            rest_bytes = f_in_rest + 4 * n * fw if feat is not None else 5 * n
+        fw_obs = int(feat.shape[1]) if feat is not None else 0
+        assert feat is None or (feat.dtype == torch.float32 and f_in_rest >= 0 and fw >= fw_obs)
+        if payload == "interior":
+            self._interior = info
+            img_cap = n * int(info[0].numel())
+        elif payload == "tiles":
+            self._tiles = (self.local.tile_template(), H, W)
+            img_cap = 16 + TILE_REC * n * (H // 16) * (W // 16)
+        else:
+            img_cap = nb_full
+        off_rest = _align(img_cap, 16)
+        off_vis = _align(off_rest + rest_bytes, 16)
+        vis_bytes = vis.numel() if vis is not None else 0
+        off_cnt = _align(off_vis + vis_bytes, 16)    # tiles: a copy of the tile header, so that the fixed-size tail carries the count
+        total = off_cnt + (16 if payload == "tiles" else 0)
+        self._lay = dict(n=n, H=H, W=W, tac_shape=tuple(tac.shape), nb_full=nb_full, img_cap=img_cap, off_rest=off_rest, rest_bytes=rest_bytes,
+                         lib_r=lib_r, f_in_rest=f_in_rest, fw=fw, fw_obs=fw_obs, off_vis=off_vis, vis_bytes=vis_bytes,
+                         vis_shape=tuple(vis.shape) if vis is not None else None, off_cnt=off_cnt, total=total, dev=dev)
+        self.payload = payload
+        if payload == "tiles" and dev.type == "cuda":
+            self._counters = torch.zeros(4, dtype=torch.int32, device=dev)
+        # ipc set-up (collective on failure when "auto"); every rank takes the same branch
+        self.transport = "collective"
+        if want in ("ipc", "auto"):
+            ipc = _IpcSlots(torch, self.dist, self.rank, self.world, self.root, total, dev, self._timeout_ms)
+            if ipc.handshake():                       # the same verdict on every rank
+                self._ipc, self.transport = ipc, "ipc"
+            else:
+                why = ipc.failed
+                ipc.close()
+                if want == "ipc":
+                    raise RuntimeError(f"transport='ipc': the set-up handshake failed ({why})")
+        if self.transport == "collective" and self._want_payload == "auto" and payload == "tiles":
+            # the tile payload was chosen for the ipc transport: without it fall back to the fixed-size choice
+            self._tiles = None
+            self._want_payload = "interior" if (info is not None and info[0].numel() <= 0.9 * info[1].numel()) else "full"
+            self._want_transport = "collective"
+            self._counters = None
+            return self._setup(obs)
+        for slot in (0, 1):
+            if self.transport == "ipc":
+                if self.rank == self.root:
+                    self._full[slot] = self._ipc.slot_tensor(slot)
+                    self._stage[slot] = self._full[slot][self.root]
+            else:
+                self._stage[slot] = torch.zeros(total, dtype=torch.uint8, device=dev)
+                if self.rank == self.root:
+                    self._full[slot] = torch.zeros((self.world, total), dtype=torch.uint8, device=dev)
+        if self.transport == "ipc" and self.rank != self.root:
+            self._scratch = torch.zeros(max(rest_bytes, 16), dtype=torch.uint8, device=dev) if packed is None else None
+
+    # ------------------------------------------------------------------ sender side
+    def _rest_tensor(self, obs, rew, done):
+        """[reward f32 | done u8 | pad | feature f32[n][fw]] as one uint8 tensor: the library's own block when there is one."""
+        torch, L = self.torch, self._lay
+        packed = self.local.packed() if hasattr(self.local, "packed") else None
+        if packed is not None:
+            return packed[0][L["lib_r"]:]
+        n = L["n"]
+        rest = torch.zeros(L["rest_bytes"], dtype=torch.uint8, device=L["dev"])
+        rest[:4 * n].view(torch.float32).copy_(rew.reshape(-1))
+        rest[4 * n:5 * n].copy_(done.reshape(-1))
+        feat = obs.get("extended_feature")
+        if feat is not None:
+            rest[L["f_in_rest"]:].view(torch.float32).reshape(n, L["fw"])[:, :L["fw_obs"]].copy_(feat)
+        return rest
+
+    def _pack_local(self, st, obs, rew, done):
+        """This rank's message into the torch tensor `st` (uint8 [total]; a staging buffer, or rank 0's own receive slot)."""
+        torch, L = self.torch, self._lay
+        tac, n = obs["tactile"], self._lay["n"]
+        if self.payload == "interior":
+            dst = st[:L["img_cap"]].view(n, -1)
+            if hasattr(self.local, "pack_interior"):
+                self.local.pack_interior(dst)                                           # one library kernel
+            else:
+                torch.index_select(tac.reshape(n, -1), 1, self._interior[0], out=dst)   # the pixels inside the border mask
+        elif self.payload == "tiles":
+            if hasattr(self.local, "pack_tiles"):
+                self.local.pack_tiles(st.data_ptr(), self._counters)
+            else:
+                torch_pack_tiles(torch, tac, self._tiles[0], st)
+            st[L["off_cnt"]:L["off_cnt"] + 16].copy_(st[:16])
+        else:
+            st[:L["nb_full"]].copy_(tac.reshape(-1))
+        st[L["off_rest"]:L["off_rest"] + L["rest_bytes"]].copy_(self._rest_tensor(obs, rew, done))
+        if L["vis_bytes"]:
+            st[L["off_vis"]:L["off_vis"] + L["vis_bytes"]].copy_(obs["visual"].reshape(-1))
+
+    def _pack_remote(self, slot, obs, rew, done):
+        """ipc transport, a peer: the message goes straight into this rank's slot of rank 0's memory (library kernels on raw pointers)."""
+        L, ipc = self._lay, self._ipc
+        dst = ipc.slot_ptr(slot, self.rank)
+        if self.payload == "interior":
+            self.local.pack_interior_ptr(dst)
+        elif self.payload == "tiles":
+            self.local.pack_tiles(dst, self._counters)
+        else:
+            ipc.copy(dst, obs["tactile"].reshape(-1))
+        rest = self._rest_tensor(obs, rew, done)
+        if rest.data_ptr() % 16:                      # tg_copy_bytes wants 16-byte aligned ends; the library's block is, an assembled one is too
+            rest = rest.clone()
+        ipc.copy(dst + L["off_rest"], rest)
+        if L["vis_bytes"]:
+            ipc.copy(dst + L["off_vis"], obs["visual"].reshape(-1))
+
+    def _sync_if_unpipelined(self, dev):
+        if dev.type == "cuda" and not getattr(self.local, "pipelined", False):
+            # the sources alias the env library's device buffers, which the next step's kernels (on the library's own stream) overwrite:
+            # the snapshot must have been taken before step() returns.  A pipelined shard runs the library on the current stream, where
+            # the copy is ordered before the next step by the stream itself.
+            self.torch.cuda.current_stream(dev).synchronize()
+
+    def _send(self, t, obs, rew, done, async_op):
+        """Start message t (1, 2, ...) of this rank; returns what has to be waited for before its slot is reused / unpacked."""
+        torch, dist, L = self.torch, self.dist, self._lay
+        slot, root = t & 1, self.rank == self.root
+        if self.transport == "ipc":
+            ipc = self._ipc
+            if root:
+                if t > 2:                                 # the batch of message t - 2 has been consumed: its slot may be overwritten
+                    ipc.set("consumed", slot, 0, self.world, t - 2)
+                self._pack_local(self._stage[slot], obs, rew, done)
+                ipc.set("ready", slot, self.root, 1, t)
+            else:
+                ipc.wait("consumed", slot, self.rank, 1, t - 2)
+                self._pack_remote(slot, obs, rew, done)
+                ipc.set("ready", slot, self.rank, 1, t)
+            self._sync_if_unpipelined(L["dev"])
+            return None
+        st = self._stage[slot]
+        self._pack_local(st, obs, rew, done)
+        self._sync_if_unpipelined(L["dev"])
+        if self.payload != "tiles":
+            views = [self._full[slot][i] for i in range(self.world)] if root else None
+            return dist.gather(st, gather_list=views, dst=self.root, async_op=async_op)
+        # tiles over collectives: a small fixed gather of everything behind the records (it carries every rank's count), then exact-size
+        # send / recv of the records
+        tail = st[L["off_rest"]:]
+        views = [self._full[slot][i][L["off_rest"]:] for i in range(self.world)] if root else None
+        dist.gather(tail, gather_list=views, dst=self.root)
+        works = []
+        if root:
+            counts = self._full[slot][:, L["off_cnt"]:L["off_cnt"] + 4].contiguous().view(torch.int32).reshape(-1).cpu().tolist()
+            self._last_counts = counts
+            for r in range(self.world):
+                nb = 16 + TILE_REC * int(counts[r])
+                if r == self.root:
+                    self._full[slot][r][:nb].copy_(st[:nb])
+                else:
+                    works.append(dist.irecv(self._full[slot][r][:nb], src=r))
+        else:
+            count = int(st[L["off_cnt"]:L["off_cnt"] + 4].view(torch.int32).item())
+            works.append(dist.isend(st[:16 + TILE_REC * count], dst=self.root))
+        if not async_op:
+            for w in works:
+                w.wait()
+            return None
+        return works
+
+    @staticmethod
+    def _wait(work):
+        if work is None:
+            return
+        for w in (work if isinstance(work, list) else [work]):
+            w.wait()
+
+    # ------------------------------------------------------------------ rank 0: message t -> batch
+    def _receive(self, t):
+        torch, L = self.torch, self._lay
+        slot = t & 1
+        if self.transport == "ipc":
+            self._ipc.wait("ready", slot, 0, self.world, t)      # one wave, lane r polls ready[slot][r] (rank 0 raised its own in _send)
+        full, n, w = self._full[slot], L["n"], self.world
+        shape = L["tac_shape"]
+        if self.payload == "full":
+            obs = {"tactile": full[:, :L["nb_full"]].reshape((w * n,) + shape[1:])}
+        else:
+            if self._obs_full[slot] is None:
+                self._obs_full[slot] = torch.zeros((w * n, L["H"] * L["W"]), dtype=torch.uint8, device=L["dev"])
+                if self.payload == "interior":
+                    self._obs_full[slot].copy_(self._interior[1].reshape(1, -1).expand(w * n, -1))
+            img = self._obs_full[slot]
+            for r in range(w):
+                blk = img[r * n:(r + 1) * n]
+                if self.payload == "interior":
+                    src = full[r, :L["img_cap"]].view(n, -1)
+                    if hasattr(self.local, "unpack_interior"):
+                        self.local.unpack_interior(src, blk)          # one kernel per peer block: every pixel written once
+                    else:
+                        blk.index_copy_(1, self._interior[0], src)
+                elif hasattr(self.local, "unpack_tiles"):
+                    self.local.unpack_tiles(full[r].data_ptr(), n, blk.data_ptr())
+                else:
+                    torch_unpack_tiles(torch, full[r], self._tiles[0], n, L["H"], L["W"], blk)
+            obs = {"tactile": img.reshape((w * n,) + shape[1:])}
+        o = L["off_rest"]
+        rew = full[:, o:o + 4 * n].contiguous().view(torch.float32).reshape(-1)
+        done = full[:, o + 4 * n:o + 5 * n].reshape(-1)
+        if L["fw_obs"]:   # config 4's tactile_and_feature observation (object_push_env.py:611-629) reaches rank 0 in the same message
+            f = o + L["f_in_rest"]
+            feat = full[:, f:f + 4 * n * L["fw"]].contiguous().view(torch.float32).reshape(w * n, L["fw"])
+            obs["extended_feature"] = feat[:, :L["fw_obs"]]
+        if L["vis_bytes"]:
+            obs["visual"] = full[:, L["off_vis"]:L["off_vis"] + L["vis_bytes"]].reshape((w * n,) + L["vis_shape"][1:])
+        self._handed = t
+        return obs, rew, done
+
+    # ------------------------------------------------------------------ VecEnv surface
     def reset(self):
         obs = self.local.reset()
-        return {k: self._gather("obs_" + k, v) for k, v in obs.items()}
-
-    # ---- packed exchange: [tactile bytes | pad to 16 | reward f32 | done u8 | pad to 4 | extended_feature f32[n][K] (if any)] per rank
-    def _pack(self, slot, obs, rew, done):
-        torch = self.torch
-        tac, feat = obs["tactile"], obs.get("extended_feature")
-        packed = self.local.packed() if hasattr(self.local, "packed") else None   # the library's own contiguous output block
-        n = tac.shape[0]
-        nb_t, nb_r, nb_d = tac.numel(), rew.numel() * 4, done.numel()
-        fw_obs = int(feat.shape[1]) if feat is not None else 0
-        if packed is not None:                       # (block, reward offset[, feature offset or -1]): the library's layout rules
-            off_r = packed[1]
-            off_f = packed[2] if len(packed) > 2 and packed[2] is not None else -1
-            total = packed[0].numel()
-            fw = (total - off_f) // (4 * n) if off_f >= 0 else 0       # the block's feature rows may be wider than the observation's
-        else:
-            off_r = (nb_t + 15) & ~15
-            off_f = ((off_r + nb_r + nb_d + 3) & ~3) if feat is not None else -1
-            fw = fw_obs
-            total = off_f + 4 * n * fw if feat is not None else off_r + nb_r + nb_d
-        shift = 0                                    # interior payload: the block after the tactile part moves up by this many bytes
-        if self._interior is not None:
-            k_int = int(self._interior[0].numel())
-            shift = off_r - ((n * k_int + 15) & ~15)
-            nb_t, off_r, total = n * k_int, off_r - shift, (total - shift + 15) & ~15   # (peer blocks stay 16-byte aligned on rank 0)
-            off_f = off_f - shift if off_f >= 0 else -1
-        if self._layout is None:
-            assert tac.dtype == torch.uint8 and rew.dtype == torch.float32 and done.dtype == torch.uint8
-            assert feat is None or (feat.dtype == torch.float32 and off_f >= 0 and fw >= fw_obs)
-            assert total >= off_r + nb_r + nb_d and shift >= 0
-            self._layout = (tuple(tac.shape), nb_t, off_r, nb_r, nb_d, off_f, fw, fw_obs)
-        if self._stage[slot] is None:
-            self._stage[slot] = torch.zeros(total, dtype=torch.uint8, device=tac.device)
-            if self.rank == self.root:
-                self._full[slot] = torch.empty((self.world, total), dtype=torch.uint8, device=tac.device)
-                self._views[slot] = [self._full[slot][i] for i in range(self.world)]
-        st = self._stage[slot]
-        if self._interior is not None:
-            if hasattr(self.local, "pack_interior"):
-                self.local.pack_interior(st[:nb_t].view(n, -1))                    # one library kernel
-            else:
-                torch.index_select(tac.reshape(n, -1), 1, self._interior[0], out=st[:nb_t].view(n, -1))   # the pixels inside the border mask
-            if packed is not None:
-                rest = packed[0].numel() - (off_r + shift)
-                st[off_r:off_r + rest].copy_(packed[0][off_r + shift:])            # reward | done | pad | feature, as laid out by the library
-        elif packed is not None:
-            st.copy_(packed[0])                                                   # one device copy
-        else:
-            st[:nb_t].copy_(tac.reshape(-1))
-        if packed is None:
-            st[off_r:off_r + nb_r].view(torch.float32).copy_(rew.reshape(-1))
-            st[off_r + nb_r:off_r + nb_r + nb_d].copy_(done.reshape(-1))
-            if feat is not None:
-                st[off_f:off_f + 4 * n * fw].view(torch.float32).reshape(n, fw)[:, :fw_obs].copy_(feat)
-        if st.is_cuda and not getattr(self.local, "pipelined", False):
-            # the sources alias the env library's device buffers, which the next step's kernels (on the library's own stream) overwrite:
-            # the snapshot must have been taken before step() returns (a 17 MB device copy, ~6 us).  A pipelined shard runs the
-            # library on the current stream, where the copy is ordered before the next step by the stream itself.
-            torch.cuda.current_stream(st.device).synchronize()
-        return st
-
-    def _start_gather(self, slot, async_op):
-        st = self._stage[slot]
+        if self._solo:
+            return obs
+        if self._lay is None:
+            self._setup(obs)
+        if self.transport != "ipc":
+            return {k: self._gather("obs_" + k, v) for k, v in obs.items()}
+        # ipc: the reset observations travel like a step's message (zero reward / done), synchronously
+        n = self._lay["n"]
+        zr = self.torch.zeros(n, dtype=self.torch.float32, device=self._lay["dev"])
+        zd = self.torch.zeros(n, dtype=self.torch.uint8, device=self._lay["dev"])
+        self._drain()
+        self._tick += 1
+        self._send(self._tick, obs, zr, zd, False)
         if self.rank == self.root:
-            return self.dist.gather(st, gather_list=self._views[slot], dst=self.root, async_op=async_op)
-        return self.dist.gather(st, gather_list=None, dst=self.root, async_op=async_op)
+            return self._receive(self._tick)[0]
+        return obs
 
-    def _unpack(self, slot):
-        torch = self.torch
-        shape, nb_t, off_r, nb_r, nb_d, off_f, fw, fw_obs = self._layout
-        full = self._full[slot]
-        if self._interior is not None:               # scatter the interiors into images whose border ring is already in place
-            idx, template = self._interior
-            if self._obs_full[slot] is None:
-                self._obs_full[slot] = template.reshape(1, -1).repeat(self.world * shape[0], 1).contiguous()
-            img = self._obs_full[slot]
-            if hasattr(self.local, "unpack_interior"):
-                for r in range(self.world):      # one kernel per peer block (contiguous views, no staging copy): every pixel written once
-                    self.local.unpack_interior(full[r, :nb_t].view(shape[0], -1), img[r * shape[0]:(r + 1) * shape[0]])
-            else:
-                img.index_copy_(1, idx, full[:, :nb_t].reshape(self.world * shape[0], -1))
-            obs = {"tactile": img.reshape((self.world * shape[0],) + shape[1:])}
-        else:
-            obs = {"tactile": full[:, :nb_t].reshape((self.world * shape[0],) + shape[1:])}
-        rew = full[:, off_r:off_r + nb_r].contiguous().view(torch.float32).reshape(-1)
-        done = full[:, off_r + nb_r:off_r + nb_r + nb_d].reshape(-1)
-        if fw_obs:   # config 4's tactile_and_feature observation (object_push_env.py:611-629) reaches rank 0 in the same message
-            feat = full[:, off_f:off_f + 4 * shape[0] * fw].contiguous().view(torch.float32).reshape(self.world * shape[0], fw)
-            obs["extended_feature"] = feat[:, :fw_obs]
-        return obs, rew, done
+    def _drain(self):
+        for k in (0, 1):
+            self._wait(self._pending[k])
+            self._pending[k] = None
 
     def step(self, local_actions):
         obs, rew, done, info = self.local.step(local_actions)
         if self._solo:
             return obs, rew, done, info
-        slot = self._tick & 1
-        if self._pending[slot] is not None:          # this staging buffer's previous gather (two steps ago) must be complete
-            self._pending[slot].wait()
-            self._pending[slot] = None
-        self._pack(slot, obs, rew, done)
-        if not self.overlap:
-            self._start_gather(slot, False)
-            self._tick += 1
-            return self._unpack(slot) + (info,) if self.rank == self.root else (obs, rew, done, info)
-        self._pending[slot] = self._start_gather(slot, True)
+        if self._lay is None:
+            self._setup(obs)
         self._tick += 1
-        prev = slot ^ 1
-        if self.rank != self.root:
+        t = self._tick
+        slot = t & 1
+        self._wait(self._pending[slot])              # this slot's previous message (two steps ago) must be complete
+        self._pending[slot] = None
+        root = self.rank == self.root
+        if not self.overlap:
+            self._send(t, obs, rew, done, False)
+            return self._receive(t) + (info,) if root else (obs, rew, done, info)
+        self._pending[slot] = self._send(t, obs, rew, done, True)
+        if not root or self._handed >= t - 1 or t == 1:   # nothing newer to hand out yet: the local shard's view of this step
             return obs, rew, done, info
-        if self._tick == 1:                          # nothing gathered yet: hand back the local shard's view of step 0
-            return obs, rew, done, info
-        if self._pending[prev] is not None:
-            self._pending[prev].wait()
-            self._pending[prev] = None
-        return self._unpack(prev) + (info,)
+        self._wait(self._pending[slot ^ 1])
+        self._pending[slot ^ 1] = None
+        return self._receive(t - 1) + (info,)
 
     def flush(self):
-        """overlap=True: wait for the outstanding gathers; rank 0 gets the gathered batch of the last step."""
+        """overlap=True: wait for the outstanding messages; rank 0 gets the gathered batch of the last step."""
         if self._solo or not self.overlap or self._tick == 0:
             return None
-        for k in (0, 1):
-            if self._pending[k] is not None:
-                self._pending[k].wait()
-                self._pending[k] = None
-        last = (self._tick - 1) & 1
-        return self._unpack(last) if self.rank == self.root else None
+        self._drain()
+        out = self._receive(self._tick) if self.rank == self.root else None
+        if self._ipc is not None:
+            self.torch.cuda.current_stream(self._lay["dev"]).synchronize()
+            self._ipc.check()
+        return out
+
+    def exchange_info(self):
+        """What travelled: payload / transport in use, the message capacity per rank and, for the tile payload, the bytes of the newest
+        message per rank (rank 0, after a flush: read from the tile headers)."""
+        if self._lay is None:
+            return None
+        L = self._lay
+        out = {"payload": self.payload, "transport": self.transport, "message_bytes_capacity": L["total"],
+               "full_payload_bytes": _align(L["nb_full"], 16) + L["total"] - L["off_rest"]}
+        if self.payload == "tiles" and self.rank == self.root and self._handed:
+            hdr = self._full[self._handed & 1][:, :4].contiguous().view(self.torch.int32).reshape(-1).cpu().tolist()
+            out["tile_records_last_message"] = hdr
+            out["message_bytes_last"] = [16 + TILE_REC * int(c) + L["total"] - L["off_rest"] for c in hdr]
+        elif self.payload != "tiles":
+            out["message_bytes_last"] = [L["total"]] * self.world
+        what = {"full": "every pixel", "interior": "interior pixels only, border ring restored on rank 0",
+                "tiles": "only the 16x16 tiles that differ from the untouched sensor's image"}[self.payload]
+        how = ("stored by each peer's pack kernel straight into rank 0's IPC-mapped receive slot over its own xGMI link, stream-side flags"
+               if self.transport == "ipc" else "one packed RCCL gather to rank 0" + (" + exact-size send / recv of the tile records" if self.payload == "tiles" else ""))
+        out["what"] = f"one message per rank per step (obs u8: {what}; reward f32, done u8), {how}, overlapped with the next step's simulation"
+        return out
+
+    def close(self):
+        if self._ipc is not None:
+            self._drain()
+            self._full = [None, None]
+            self._stage = [None, None]
+            ipc, self._ipc = self._ipc, None
+            ipc.close()
 
 
 class TorchShard:
@@ -223,6 +588,8 @@ class TorchShard:
     are valid for work enqueued on that stream afterwards (a policy forward pass, the packed gather), the usual CUDA-stream contract.
     The host then runs ahead of the device instead of idling through every step, so per-step launch overhead is hidden; the caller
     must do its torch work under `with torch.cuda.stream(shard.stream)` and synchronise before reading results on the host."""
+
+    raw = True     # device resident: the ipc transport can address this shard's buffers
 
     def __init__(self, venv, pipelined=False):
         self.venv, self.num_envs, self.pipelined, self.stream = venv, venv.num_envs, bool(pipelined), None
@@ -235,19 +602,45 @@ class TorchShard:
     def packed(self):
         return self.venv.packed_torch()
 
+    def _cur_stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.venv.tactile_torch().device).cuda_stream)
+
     def pack_interior(self, dst):
         """This shard's current observations, interior pixels only, into the uint8 device tensor `dst` [n, K] (tg_pack_interior: one kernel
         on the library's stream)."""
-        import ctypes as C
         capi.check(self.venv._L.tg_pack_interior(self.venv._ctx, C.c_void_p(dst.data_ptr())))
+
+    def pack_interior_ptr(self, dst_ptr):
+        capi.check(self.venv._L.tg_pack_interior(self.venv._ctx, C.c_void_p(dst_ptr)))
 
     def unpack_interior(self, src, dst):
         """Interiors `src` uint8 [m, K] -> full images `dst` uint8 [m, H*W] with the border ring restored (tg_unpack_interior)."""
-        import ctypes as C
         m = int(src.shape[0])
         for lo in range(0, m, 32768):
             hi = min(m, lo + 32768)
             capi.check(self.venv._L.tg_unpack_interior(self.venv._ctx, C.c_void_p(src[lo:hi].data_ptr()), hi - lo, C.c_void_p(dst[lo:hi].data_ptr())))
+
+    def tile_template(self):
+        """uint8 [H*W] device tensor: the image of the untouched sensor (zero inside, the pasted ring outside) tiles are compared with."""
+        if not hasattr(self, "_tmpl"):
+            import torch
+            p = C.c_void_p()
+            capi.check(self.venv._L.tg_get_tile_template(self.venv._ctx, C.byref(p)))
+            self._tmpl = torch.as_tensor(_DevArray(p.value, self.venv.H * self.venv.W), device=self.venv.tactile_torch().device)
+        return self._tmpl
+
+    def pack_tiles(self, dst_ptr, counters):
+        """This shard's current observations as a tile message at the raw device address `dst_ptr` (tg_pack_tiles, current torch stream);
+        `counters`: a zeroed int32 device tensor of at least 2 elements in local memory."""
+        v = self.venv
+        capi.check(v._L.tg_pack_tiles(self._cur_stream(), C.c_void_p(v.tactile_torch().data_ptr()), C.c_void_p(self.tile_template().data_ptr()),
+                                      v.num_envs, v.H, v.W, C.c_void_p(dst_ptr), C.c_void_p(counters.data_ptr())))
+
+    def unpack_tiles(self, src_ptr, n_images, dst_ptr):
+        v = self.venv
+        capi.check(v._L.tg_unpack_tiles(self._cur_stream(), C.c_void_p(src_ptr), C.c_void_p(self.tile_template().data_ptr()), n_images, v.H, v.W,
+                                        C.c_void_p(dst_ptr)))
 
     def border_info(self):
         """(flat indices of the pixels inside the border mask, the constant image of the border ring) as device tensors, or None when the

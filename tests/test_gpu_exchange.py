@@ -1,0 +1,156 @@
+"""The per-step exchange to rank 0 on the device: the tile-sparse payload kernels against their torch definition, and the
+ipc transport (peers storing straight into rank 0's receive slots, stream-side flags) with two processes.  The GPU box has ONE GPU, so
+the two ranks share it: what is exercised is the mechanism (IPC handles, slot layout, flags, the one-step-behind pipeline, every
+payload), not the xGMI hop - RCCL itself refuses two ranks on one device, so the control plane of these tests is gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EDGE = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+BAL = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=True, rand_embed_dist=True,
+           observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+PUSH = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
+            observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")
+
+
+@pytest.mark.parametrize("env_id,modes,size,n", [("edge_follow-v0", EDGE, 128, 1024), ("edge_follow-v0", EDGE, 64, 37),
+                                                ("object_balance-v0", BAL, 256, 130), ("object_push-v0", PUSH, 128, 64)])
+def test_tile_kernels_match_definition(env_id, modes, size, n):
+    """tg_pack_tiles == parallel.torch_pack_tiles as a SET of records (the kernel's record order is not defined), the header's count
+    exact; tg_unpack_tiles restores every image bit for bit; the counters are left zero (a second launch gives the same message)."""
+    import torch
+    import tactile_gym_amd as tg
+    from tactile_gym_amd.parallel import TILE_REC, TorchShard, torch_pack_tiles
+    v = tg.make_vec(env_id, num_envs=n, max_steps=200, image_size=[size, size], env_modes=modes, seed=3, obs_mode="torch", auto_reset=True)
+    sh = TorchShard(v)
+    sh.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        sh.step(torch.from_numpy(rng.uniform(-0.25, 0.25, size=(n, v.act_dim)).astype(np.float32)).cuda())
+    tac, tmpl = v.tactile_torch(), sh.tile_template()
+    T = (size // 16) ** 2
+    cap = 16 + TILE_REC * n * T
+    counters = torch.zeros(4, dtype=torch.int32, device="cuda")
+    ref = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    count = torch_pack_tiles(torch, tac, tmpl, ref)
+    assert 0 < count < n * T
+    for rep in range(2):
+        msg = torch.full((cap,), 0xAB, dtype=torch.uint8, device="cuda")
+        sh.pack_tiles(msg.data_ptr(), counters)
+        torch.cuda.synchronize()
+        hdr = msg[:16].view(torch.int32).tolist()
+        assert hdr == [count, n, T, 0x54475431], (hdr, count)
+        assert counters.tolist() == [0, 0, 0, 0]
+        got = msg[16:16 + TILE_REC * count].reshape(count, TILE_REC)
+        want = ref[16:16 + TILE_REC * count].reshape(count, TILE_REC)
+        order = torch.argsort(got[:, :4].contiguous().view(torch.int32).reshape(-1))
+        assert torch.equal(got[order], want)                 # torch_pack_tiles emits ids in increasing order
+        assert bool((msg[16 + TILE_REC * count:] == 0xAB).all())   # nothing written beyond the records
+        out = torch.full((n, size * size), 0xCD, dtype=torch.uint8, device="cuda")
+        sh.unpack_tiles(msg.data_ptr(), n, out.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(out.reshape(tac.shape), tac)
+    frac = (16 + TILE_REC * count) / tac.numel()
+    print(f"{env_id} {size}x{size}, {n} envs: {count} of {n * T} tiles live, tile message = {100 * frac:.1f} % of the full images")
+    v.close()
+
+
+def test_flag_wait_times_out_instead_of_hanging():
+    """A wait on a flag nobody raises ends after its timeout and reports the lane in the error word; a raised flag passes at once."""
+    import ctypes as C
+    import time
+    import torch
+    from tactile_gym_amd import _capi as capi
+    L = capi.lib()
+    flags = torch.zeros(64, dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(L.tg_flag_set(s, C.c_void_p(flags.data_ptr()), 2, 16, 5))
+    capi.check(L.tg_flag_wait(s, C.c_void_p(flags.data_ptr()), 2, 16, 5, C.c_void_p(err.data_ptr()), 2000))
+    torch.cuda.synchronize()
+    assert flags[0].item() == 5 and flags[16].item() == 5 and err.item() == 0
+    t0 = time.perf_counter()
+    capi.check(L.tg_flag_wait(s, C.c_void_p(flags.data_ptr()), 3, 16, 6, C.c_void_p(err.data_ptr()), 300))    # lanes 0, 1 hold 5; lane 2 holds 0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert 0.25 < dt < 3.0, dt
+    assert err.item() == 0b111
+
+
+def _ipc_worker(rank, world, port, out_path, env_id, modes, size, n_local, payload, overlap, steps):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import tactile_gym_amd as tg
+    from tactile_gym_amd.parallel import ShardedVecEnv, TorchShard
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    v = tg.make_vec(env_id, num_envs=n_local, max_steps=200, image_size=[size, size], env_modes=modes, seed=50 + rank * n_local,
+                    obs_mode="torch", auto_reset=True)
+    shard = TorchShard(v, pipelined=True)
+    env = ShardedVecEnv(shard, dist, overlap=overlap, payload=payload, transport="ipc", timeout_ms=20000)
+    gen = torch.Generator().manual_seed(5)
+    acts = [((torch.rand(world * n_local, v.act_dim, generator=gen) - 0.5) * 0.5) for _ in range(steps)]
+    hist = []
+    with torch.cuda.stream(shard.stream):
+        obs = env.reset()
+        assert env.transport == "ipc" and env.payload == payload
+        hist.append({k: t.clone() for k, t in obs.items()})
+        for k in range(steps):
+            obs, rew, done, _ = env.step(acts[k][rank * n_local:(rank + 1) * n_local].cuda())
+            hist.append(dict({kk: t.clone() for kk, t in obs.items()}, rew=rew.clone(), done=done.clone()))
+        if overlap:
+            last = env.flush()
+            if rank == 0:
+                hist.append(dict({kk: t.clone() for kk, t in last[0].items()}, rew=last[1].clone(), done=last[2].clone()))
+        torch.cuda.synchronize()
+    info = env.exchange_info()
+    if rank == 0:
+        # the single-process reference: the same world * n_local envs (seeds 50 ...) in one context, same actions
+        ref = tg.make_vec(env_id, num_envs=world * n_local, max_steps=200, image_size=[size, size], env_modes=modes, seed=50, obs_mode="torch",
+                          auto_reset=True)
+        rs = TorchShard(ref)
+        want = [{k: t.clone() for k, t in rs.reset().items()}]
+        for k in range(steps):
+            o, r, d, _ = rs.step(acts[k].cuda())
+            want.append(dict({kk: t.clone() for kk, t in o.items()}, rew=r.clone(), done=d.clone()))
+        # overlap: step k hands out the batch of step k - 1 (the first step: the local shard's own view), flush() the last one
+        got = [hist[0]] + (hist[2:] if overlap else hist[1:])
+        exp = want
+        assert len(got) == len(exp) and len(got) >= 3
+        for a, b in zip(got, exp):
+            assert set(a) == set(b)
+            for key in b:
+                assert a[key].shape == b[key].shape and torch.equal(a[key], b[key]), key
+        torch.save({"info": info, "frames": len(got)}, out_path)
+        ref.close()
+    dist.barrier()
+    env.close()
+    v.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("env_id,modes,size,payload,overlap", [("edge_follow-v0", EDGE, 128, "tiles", True), ("edge_follow-v0", EDGE, 128, "interior", True),
+                                                               ("edge_follow-v0", EDGE, 128, "full", False), ("object_push-v0", PUSH, 128, "tiles", True),
+                                                               ("edge_follow-v0", dict(EDGE, observation_mode="visuotactile"), 128, "tiles", True)])
+def test_ipc_exchange_two_ranks(tmp_path, env_id, modes, size, payload, overlap):
+    """Two ranks (two processes, both on this box's one GPU), ipc transport: every batch rank 0 is handed equals the single-process batch of
+    the same 2 x n envs bit for bit - tactile images, reward, done, extended_feature (object_push), visual (visuotactile)."""
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_ipc_worker, args=(2, port, out, env_id, modes, size, 48, payload, overlap, 6), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["info"]["transport"] == "ipc" and got["info"]["payload"] == payload and got["frames"] >= 6
+    if payload == "tiles":
+        assert len(got["info"]["message_bytes_last"]) == 2 and max(got["info"]["message_bytes_last"]) < got["info"]["message_bytes_capacity"]
+    print(got["info"])

@@ -1,0 +1,191 @@
+"""The dynamics inputs, pinned independently of tactile_gym_amd.urdf_compile ("common mode" between oracle and product:
+both load the compiled blobs in tactile_gym_amd/assets/robots/).
+
+tests/golden/urdf_facts.json holds what the reference's URDFs say - masses, inertial origins, written inertias, collision extents, joint
+origins / axes / limits / dynamics - extracted by tools/extract_urdf_facts.py with xml.etree and its own mesh readers, sharing no code
+with the compiler.  This test walks every compiled blob (20 URDFs x 2 inertia modes) against those facts with its own frame arithmetic:
+kinematic tree, joint frames and axes, every body's mass, centre of mass and inertial orientation, the inertia as written (`*_urdfinertia`)
+and the inertia Bullet would recompute from the collision AABB (PARITY_ASSUMPTIONS A3: box inertia of the collision extents in the
+inertial frame, mesh children padded by the 1 mm URDF collision margin), and the tip's collision hull / cylinder."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FACTS = json.load(open(os.path.join(ROOT, "tests", "golden", "urdf_facts.json")))
+ROBOTS = sorted(FACTS["robots"])
+MARGIN = 0.001                                   # gUrdfDefaultCollisionMargin (A3)
+TACTIP_BODY_STAND_IN = ([-0.025, -0.025, 0.0], [0.025, 0.025, 0.065])     # A3b: tactip_body.obj is a missing blob upstream
+
+
+def R_of(rpy):
+    r, p, y = rpy
+    Rx = np.array([[1, 0, 0], [0, math.cos(r), -math.sin(r)], [0, math.sin(r), math.cos(r)]])
+    Ry = np.array([[math.cos(p), 0, math.sin(p)], [0, 1, 0], [-math.sin(p), 0, math.cos(p)]])
+    Rz = np.array([[math.cos(y), -math.sin(y), 0], [math.sin(y), math.cos(y), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def walk(facts):
+    """Depth-first in document order (PyBullet's link numbering): for every URDF link the moving link it is welded to and its frame
+    there; for every moving joint its frame in the parent moving link."""
+    joints = facts["joints"]
+    children = {j["child"] for j in joints}
+    (root,) = [n for n in facts["links"] if n not in children]
+    attach, moving, order = {root: (-1, np.eye(3), np.zeros(3))}, [], []
+
+    def visit(link):
+        for j in joints:
+            if j["parent"] != link:
+                continue
+            mi, R, p = attach[j["parent"]]
+            Rj, pj = R_of(j["rpy"]), np.asarray(j["xyz"])
+            if j["type"] == "fixed":
+                attach[j["child"]] = (mi, R @ Rj, R @ pj + p)
+            else:
+                assert j["type"] in ("revolute", "continuous"), j
+                moving.append(dict(name=j["name"], parent=mi, pos=R @ pj + p, rot=R @ Rj, axis=np.asarray(j["axis"]) / np.linalg.norm(j["axis"]), fact=j))
+                attach[j["child"]] = (len(moving) - 1, np.eye(3), np.zeros(3))
+            order.append(j)
+            visit(j["child"])
+
+    visit(root)
+    return attach, moving, order
+
+
+def expected_aabb_inertia(link, name):
+    lo = hi = None
+    for c in link["collisions"]:
+        if c["aabb_inertial"] is None:
+            assert c["file"] == "tactip_body.obj", (name, c)         # the only missing mesh; its stand-in box sits in the geometry frame
+            Ri, pi = R_of(link["inertial_rpy"]), np.asarray(link["inertial_xyz"])
+            a, b = (np.asarray(v) for v in TACTIP_BODY_STAND_IN)
+            corners = np.array([[x, y, z] for x in (a[0], b[0]) for y in (a[1], b[1]) for z in (a[2], b[2])])
+            w = (corners @ R_of(c["rpy"]).T + np.asarray(c["xyz"]) - pi) @ Ri
+            a, b = w.min(0) - MARGIN, w.max(0) + MARGIN
+        else:
+            a, b = (np.asarray(v) for v in c["aabb_inertial"])
+            if c["type"] == "mesh":
+                a, b = a - MARGIN, b + MARGIN
+        lo, hi = (a, b) if lo is None else (np.minimum(lo, a), np.maximum(hi, b))
+    if lo is None:
+        return np.zeros(3)
+    l = hi - lo
+    return link["mass"] / 12.0 * np.array([l[1] ** 2 + l[2] ** 2, l[0] ** 2 + l[2] ** 2, l[0] ** 2 + l[1] ** 2])
+
+
+@pytest.mark.parametrize("suffix", ["", "_urdfinertia"])
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_compiled_robot_matches_urdf_facts(robot, suffix):
+    facts = FACTS["robots"][robot]
+    z = np.load(os.path.join(ROOT, "tactile_gym_amd", "assets", "robots", f"{robot}{suffix}.npz"), allow_pickle=False)
+    attach, moving, order = walk(facts)
+    # ---- kinematic tree
+    assert int(z["ndof"]) == len(moving) == (6 if robot.startswith("ur5") else 8)
+    assert [str(s) for s in z["joint_names"]] == [m["name"] for m in moving]
+    assert list(z["parent"]) == [m["parent"] for m in moving]
+    assert [str(s) for s in z["urdf_joint_names"]] == [j["name"] for j in order]
+    assert [str(s) for s in z["urdf_joint_types"]] == [j["type"] for j in order]
+    assert [str(s) for s in z["urdf_link_names"]] == [j["child"] for j in order]
+    for i, m in enumerate(moving):
+        assert np.abs(z["joint_pos"][i] - m["pos"]).max() < 1e-12, (robot, m["name"])
+        assert np.abs(z["joint_rot"][i] - m["rot"]).max() < 1e-12, (robot, m["name"])
+        assert np.abs(z["joint_axis"][i] - m["axis"]).max() < 1e-12, (robot, m["name"])
+    # ---- bodies: every link with mass that hangs off a moving link, in PyBullet's order
+    names = [str(s) for s in z["body_names"]]
+    want = [n for n in [j["child"] for j in order] if facts["links"][n].get("mass", 0.0) > 0.0 and attach[n][0] >= 0]
+    assert names == want, (robot, names, want)
+    total = 0.0
+    for b, n in enumerate(names):
+        link = facts["links"][n]
+        mi, R, p = attach[n]
+        assert int(z["body_link"][b]) == mi
+        assert z["body_mass"][b] == link["mass"], (robot, n)
+        total += link["mass"]
+        com = R @ np.asarray(link["inertial_xyz"]) + p
+        assert np.abs(z["body_com"][b] - com).max() < 1e-12, (robot, n)
+        R_in = R @ R_of(link["inertial_rpy"])
+        ixx, ixy, ixz, iyy, iyz, izz = link["inertia"]
+        if suffix == "":                                           # A3: inertia recomputed from the collision extents, axes = inertial frame
+            assert str(z["inertia_mode"]) == "collision_aabb"
+            assert np.abs(z["body_rot"][b] - R_in).max() < 1e-12, (robot, n)
+            exp = expected_aabb_inertia(link, n)
+            assert np.abs(z["body_inertia"][b] - exp).max() <= 1e-12 * max(1.0, np.abs(exp).max()), (robot, n, z["body_inertia"][b], exp)
+        else:                                                      # the tensor as written, about the COM, in the inertial frame
+            assert str(z["inertia_mode"]) == "urdf"
+            I_written = R_in @ np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]]) @ R_in.T
+            Rb = z["body_rot"][b]
+            I_blob = Rb @ np.diag(z["body_inertia"][b]) @ Rb.T
+            assert np.abs(I_blob - I_written).max() <= 1e-12 * max(1.0, np.abs(I_written).max()), (robot, n)
+            assert abs(np.linalg.det(Rb) - 1.0) < 1e-9
+    assert total > 1.0                                             # an arm, not an empty shell
+    # ---- named frames are inertial (COM) frames of their links: getLinkState(...)[0:2] (base_robot_arm.py:146-147)
+    for k, fname in enumerate(str(s) for s in z["frame_names"]):
+        link = facts["links"][fname]
+        mi, R, p = attach[fname]
+        xyz, rpy = (link["inertial_xyz"], link["inertial_rpy"]) if link["has_inertial"] else ([0, 0, 0], [0, 0, 0])
+        assert int(z["frame_link"][k]) == mi
+        assert np.abs(z["frame_pos"][k] - (R @ np.asarray(xyz) + p)).max() < 1e-12, (robot, fname)
+        assert np.abs(z["frame_rot"][k] - R @ R_of(rpy)).max() < 1e-12, (robot, fname)
+    # ---- the tip's collision shape (the only sensor part that can touch anything, tactile_sensor.py:46-57)
+    sensor = robot.rsplit("_", 1)[1]
+    tip = facts["links"][f"{sensor}_tip_link"]
+    mi, R, p = attach[f"{sensor}_tip_link"]
+    if "tip_hull_verts" in z.files:
+        (c,) = [c for c in tip["collisions"] if c["type"] == "mesh"]
+        Rg, pg = R @ R_of(c["rpy"]), R @ np.asarray(c["xyz"]) + p
+        corners = np.array([[x, y, z_] for x in (c["bounds"][0][0], c["bounds"][1][0]) for y in (c["bounds"][0][1], c["bounds"][1][1])
+                            for z_ in (c["bounds"][0][2], c["bounds"][1][2])])
+        box = corners @ Rg.T + pg                                  # the mesh's bounding box, carried into the moving link's frame
+        hv = z["tip_hull_verts"]
+        assert int(z["tip_hull_link"]) == mi and hv.shape[0] >= 4
+        inv = (hv - pg) @ Rg                                       # hull vertices back in the mesh frame: inside its bounding box, touching it
+        lo, hi = np.asarray(c["bounds"][0]), np.asarray(c["bounds"][1])
+        assert (inv >= lo - 1e-9).all() and (inv <= hi + 1e-9).all(), robot
+        assert np.abs(inv.min(0) - lo).max() < 1e-9 and np.abs(inv.max(0) - hi).max() < 1e-9, robot
+        assert np.isfinite(box).all()
+    else:
+        (c,) = [c for c in tip["collisions"] if c["type"] == "cylinder"]
+        assert float(z["tip_cyl_radius"]) == c["radius"] and float(z["tip_cyl_length"]) == c["length"] and int(z["tip_cyl_link"]) == mi
+        assert np.abs(z["tip_cyl_rot"] - R @ R_of(c["rpy"])).max() < 1e-12 and np.abs(z["tip_cyl_pos"] - (R @ np.asarray(c["xyz"]) + p)).max() < 1e-12
+
+
+def test_facts_cover_every_blob_and_malformed_tokens_are_the_known_ones():
+    blobs = sorted(f[:-4] for f in os.listdir(os.path.join(ROOT, "tactile_gym_amd", "assets", "robots")) if f.endswith(".npz") and "_urdfinertia" not in f)
+    assert blobs == ROBOTS
+    # every number the C-style scan cut short is one of the DIGIT / DigiTac `a+b` tokens (A9); nothing else in any URDF is malformed
+    for t in FACTS["malformed_tokens"]:
+        assert ("digit" in t["where"]) and any(ch in t["token"][1:] for ch in "+-") and t["token"].startswith(t["read_as"]), t
+
+
+def test_arm_damping_is_set_by_the_env_not_the_urdf():
+    """The URDFs' <dynamics damping> (0.5 on the UR5 joints) is overridden: base_robot_arm.py:22-25 calls changeDynamics(linearDamping=0.04,
+    angularDamping=0.04, jointDamping=0.01) on every link.  The product's constants must be the env's, whatever the URDF says."""
+    import inspect
+    from tactile_gym_amd.robot_model import make_robot
+    d = {k: v.default for k, v in inspect.signature(make_robot).parameters.items()}
+    assert (d["linear_damping"], d["angular_damping"], d["joint_damping"]) == (0.04, 0.04, 0.01)
+    ur5 = FACTS["robots"]["ur5_standard_tactip"]
+    assert {j["dynamics"]["damping"] for j in ur5["joints"] if j["dynamics"]} == {0.5}
+    assert all(j["dynamics"] is None for j in FACTS["robots"]["mg400_standard_tactip"]["joints"])
+
+
+def test_joint_limits_are_out_of_reach():
+    """The product does not model URDF joint limits (PARITY_ASSUMPTIONS A34).  As written they are +-100 rad on the UR5 and +-3.14 rad on
+    the MG400; every rest pose the reference ships (tests/golden/rest_poses.json, every row) sits at least 0.9 rad inside them, and an
+    episode moves the TCP by centimetres inside its box (check_TCP_pos_lims), i.e. joints by a few tenths of a radian at most."""
+    rest = json.load(open(os.path.join(ROOT, "tests", "golden", "rest_poses.json")))
+    rows = [r for env in rest.values() for r in env["rows"]]
+    assert len(rows) >= 24
+    for r in rows:
+        facts = FACTS["robots"][f"{r['arm']}_{r['type']}_{r['sensor']}"]
+        _, moving, order = walk(facts)
+        assert abs(len(order) - len(r["joints"])) <= 1                # one entry per URDF joint, fixed ones included (PyBullet's numbering); some upstream rows carry a spare
+        for j, q in zip(order, r["joints"]):
+            if j["type"] == "fixed":
+                continue
+            lim = j["limit"]
+            assert lim["lower"] + 0.9 < q < lim["upper"] - 0.9, (r, j["name"], q)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Facts of the reference's robot URDFs, read with nothing but xml.etree / re / struct (NO import of tactile_gym_amd):
+"""Facts of the reference's robot URDFs, read with nothing but xml.etree / re / struct / numpy (NO import of tactile_gym_amd):
 
     python tools/extract_urdf_facts.py            (in the build container, where /root/reference exists)
     -> tests/golden/urdf_facts.json
@@ -15,11 +15,14 @@ Number tokens such as `4.96E-09+0.035` (ur5_with_standard_digit.urdf:279) are re
 such token is listed under "malformed_tokens".  PARITY_ASSUMPTIONS A9.
 """
 import json
+import math
 import os
 import re
 import struct
 import sys
 import xml.etree.ElementTree as ET
+
+import numpy as np
 
 REF = os.environ.get("TG_REFERENCE_ASSETS", "/root/reference/tactile_gym/assets")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,36 +51,31 @@ def vec(text, n, default, where):
     return (out + [default] * n)[:n]
 
 
-def obj_bounds(path):
-    lo, hi = [float("inf")] * 3, [float("-inf")] * 3
-    count = 0
+def obj_vertices(path):
+    pts = []
     with open(path, "r", errors="replace") as f:
         for line in f:
             if line.startswith("v "):
-                p = [float(t) for t in line.split()[1:4]]
-                lo, hi = [min(a, b) for a, b in zip(lo, p)], [max(a, b) for a, b in zip(hi, p)]
-                count += 1
-    return lo, hi, count
+                pts.append([float(t) for t in line.split()[1:4]])
+    return np.asarray(pts, dtype=np.float64).reshape(-1, 3)
 
 
-def stl_bounds(path):
+def stl_vertices(path):
     data = open(path, "rb").read()
-    lo, hi = [float("inf")] * 3, [float("-inf")] * 3
-    count = 0
     n_tri = struct.unpack_from("<I", data, 80)[0] if len(data) >= 84 else -1
-    if n_tri >= 0 and 84 + 50 * n_tri == len(data):            # binary
-        for t in range(n_tri):
-            vals = struct.unpack_from("<12f", data, 84 + 50 * t)
-            for k in range(3):
-                p = vals[3 + 3 * k:6 + 3 * k]
-                lo, hi = [min(a, b) for a, b in zip(lo, p)], [max(a, b) for a, b in zip(hi, p)]
-                count += 1
-    else:                                                       # ASCII
-        for m in re.finditer(rb"vertex\s+(\S+)\s+(\S+)\s+(\S+)", data):
-            p = [float(m.group(i)) for i in (1, 2, 3)]
-            lo, hi = [min(a, b) for a, b in zip(lo, p)], [max(a, b) for a, b in zip(hi, p)]
-            count += 1
-    return lo, hi, count
+    if n_tri >= 0 and 84 + 50 * n_tri == len(data):            # binary: 50-byte records of normal + 3 vertices (float32) + attribute
+        rec = np.frombuffer(data, dtype=np.uint8, offset=84).reshape(n_tri, 50)[:, 12:48]
+        return np.ascontiguousarray(rec).view("<f4").reshape(-1, 3).astype(np.float64)
+    return np.asarray([[float(m.group(i)) for i in (1, 2, 3)] for m in re.finditer(rb"vertex\s+(\S+)\s+(\S+)\s+(\S+)", data)], dtype=np.float64).reshape(-1, 3)
+
+
+def rot(rpy):
+    """URDF fixed-axis roll, pitch, yaw: R = Rz(yaw) Ry(pitch) Rx(roll)."""
+    r, p, y = rpy
+    Rx = np.array([[1, 0, 0], [0, math.cos(r), -math.sin(r)], [0, math.sin(r), math.cos(r)]])
+    Ry = np.array([[math.cos(p), 0, math.sin(p)], [0, 1, 0], [-math.sin(p), 0, math.cos(p)]])
+    Rz = np.array([[math.cos(y), -math.sin(y), 0], [math.sin(y), math.cos(y), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
 
 
 def find_mesh(urdf_dir, name):
@@ -90,8 +88,12 @@ def find_mesh(urdf_dir, name):
     return None
 
 
-def geoms(link_el, tag, urdf_dir, where):
+def geoms(link_el, tag, urdf_dir, where, inertial=None):
+    """inertial = (xyz, rpy) of the link's inertial frame: each record then also carries the geometry's extent along the axes of that
+    frame ("aabb_inertial": exact for a mesh (every vertex), |R| h for a box, cylinder as its bounding box, sphere +- r) - what Bullet
+    recomputes the link inertia from when loadURDF is given no URDF_USE_INERTIA_FROM_FILE (PARITY_ASSUMPTIONS A3); no margin added."""
     out = []
+    Ri, pi = (rot(inertial[1]), np.asarray(inertial[0])) if inertial is not None else (np.eye(3), np.zeros(3))
     for i, el in enumerate(link_el.findall(tag)):
         org, g = el.find("origin"), el.find("geometry")
         if g is None:
@@ -102,17 +104,28 @@ def geoms(link_el, tag, urdf_dir, where):
             rec.update(type="mesh", file=os.path.basename(m.get("filename")), scale=vec(m.get("scale"), 3, 1.0, where))
             path = find_mesh(urdf_dir, m.get("filename"))
             if path is None:
-                rec["bounds"] = None                             # a missing large blob upstream (the standard TacTip body)
+                rec["bounds"] = rec["aabb_inertial"] = None      # a missing large blob upstream (the standard TacTip body)
             else:
-                lo, hi, cnt = (obj_bounds if path.lower().endswith(".obj") else stl_bounds)(path)
-                rec["bounds"], rec["vertices"] = [lo, hi], cnt
-        elif g.find("box") is not None:
-            rec.update(type="box", size=vec(g.find("box").get("size"), 3, 0.0, where))
-        elif g.find("sphere") is not None:
-            rec.update(type="sphere", radius=num(g.find("sphere").get("radius"), where))
-        elif g.find("cylinder") is not None:
-            c = g.find("cylinder")
-            rec.update(type="cylinder", radius=num(c.get("radius"), where), length=num(c.get("length"), where))
+                v = (obj_vertices if path.lower().endswith(".obj") else stl_vertices)(path) * np.asarray(rec["scale"])
+                rec["bounds"], rec["vertices"] = [v.min(0).tolist(), v.max(0).tolist()], int(v.shape[0])
+                w = (v @ rot(rec["rpy"]).T + np.asarray(rec["xyz"]) - pi) @ Ri          # rows: Ri^T (Rg v + pg - pi)
+                rec["aabb_inertial"] = [w.min(0).tolist(), w.max(0).tolist()]
+        else:
+            if g.find("box") is not None:
+                rec.update(type="box", size=vec(g.find("box").get("size"), 3, 0.0, where))
+                h = 0.5 * np.asarray(rec["size"])
+            elif g.find("sphere") is not None:
+                rec.update(type="sphere", radius=num(g.find("sphere").get("radius"), where))
+                h = None
+            elif g.find("cylinder") is not None:
+                c = g.find("cylinder")
+                rec.update(type="cylinder", radius=num(c.get("radius"), where), length=num(c.get("length"), where))
+                h = np.array([rec["radius"], rec["radius"], 0.5 * rec["length"]])
+            else:
+                continue
+            c0 = Ri.T @ (np.asarray(rec["xyz"]) - pi)
+            ext = np.full(3, rec["radius"]) if h is None else np.abs(Ri.T @ rot(rec["rpy"])) @ h
+            rec["aabb_inertial"] = [(c0 - ext).tolist(), (c0 + ext).tolist()]
         out.append(rec)
     return out
 
@@ -132,7 +145,7 @@ def facts(urdf):
             rec["inertial_xyz"] = vec(org.get("xyz") if org is not None else None, 3, 0.0, where)
             rec["inertial_rpy"] = vec(org.get("rpy") if org is not None else None, 3, 0.0, where)
             rec["inertia"] = [num(it.get(k, "0"), where) for k in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz")] if it is not None else [0.0] * 6
-        rec["collisions"] = geoms(el, "collision", d, where)
+        rec["collisions"] = geoms(el, "collision", d, where, (rec["inertial_xyz"], rec["inertial_rpy"]) if ine is not None else None)
         links[el.get("name")] = rec
     for el in root.findall("joint"):
         where = f"{base}:{el.get('name')}"

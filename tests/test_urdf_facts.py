@@ -181,7 +181,7 @@ def test_joint_limits_are_out_of_reach():
     rows = [r for env in rest.values() for r in env["rows"]]
     assert len(rows) >= 24
     for r in rows:
-        facts = FACTS["robots"][f"{r['arm']}_{r['type']}_{r['sensor']}"]
+        facts = FACTS["robots"][f"{r['arm']}_{r['type']}_{r['sensor'] or 'tactip'}"]      # object_balance / object_roll list one pose (TacTip only)
         _, moving, order = walk(facts)
         assert abs(len(order) - len(r["joints"])) <= 1                # one entry per URDF joint, fixed ones included (PyBullet's numbering); some upstream rows carry a spare
         for j, q in zip(order, r["joints"]):

@@ -156,8 +156,7 @@ class Workload:
         t0 = time.perf_counter()
         for _ in range(steps):
             env.step(self.actions())
-        if flush is not None:
-            flush()
+        self.flushed = flush() if flush is not None else None      # rank 0: the last step's gathered batch
         barrier()
         return time.perf_counter() - t0
 
@@ -321,6 +320,16 @@ def main():
             env.step(w.actions())
         # the last step's exchange completes inside the timed region: K steps simulated AND delivered to rank 0
         dt = allmax(w.timed(env, args.steps, barrier, flush=env.flush if gathered else None))
+        verified = None
+        if gathered:
+            # integrity of the exchange, outside the timed region: the byte sum of every rank's last tactile batch (computed where it was
+            # rendered) against the byte sum of that rank's block in the batch rank 0 was handed
+            cs = venv.tactile_torch().sum(dtype=torch.int64).reshape(1)
+            sums = [torch.zeros_like(cs) for _ in range(world)]
+            dist.all_gather(sums, cs)
+            if rank == 0 and w.flushed is not None:
+                got = w.flushed[0]["tactile"].reshape(world, -1).sum(dim=1, dtype=torch.int64)
+                verified = bool((got == torch.cat(sums)).all().item())
         no_gather = None
         if gathered and world > 1:               # the same K steps without the exchange: what per-rank learners would see
             dt_ng = allmax(w.timed(shard, args.steps, barrier))
@@ -339,6 +348,8 @@ def main():
             no_reset = {"value": round(n * k_nr / dt_nr, 1), "unit": "env-steps/s", "steps": k_nr, "ms_per_step": round(1e3 * dt_nr / k_nr, 4),
                         "what": "window between full-batch resets (no env reaches max_steps inside it)"}
     exchange = env.exchange_info() if gathered and hasattr(env, "exchange_info") else None
+    if exchange is not None:
+        exchange["verified"] = verified
 
     solo = world == 1 and not force
     literal = None

@@ -273,6 +273,11 @@ int tg_copy_obs_oracle(tg_ctx* ctx, float* host_dst);          /* synchronises *
 int tg_enable_oracle_obs(tg_ctx* ctx);
 int tg_get_obs_oracle_terminal(tg_ctx* ctx, void** dev_ptr);   /* float32 [num_envs][dim] */
 int tg_copy_obs_oracle_terminal(tg_ctx* ctx, float* host_dst); /* synchronises */
+/* Per-env episode statistics: what the reference's callers read from the Monitor wrapper they put around every env
+ * (sb3_helpers/rl_utils.py:17-30, 59: info["episode"] = {"r", "l", "t"}).  The step kernels add up, in double, the float32 rewards they hand
+ * out; when an env reports done its return and length (in env steps) are kept here until its next episode ends.  Rows valid where done. */
+int tg_get_episode_stats(tg_ctx* ctx, void** final_return_f32, void** final_len_i32);      /* device: float32 [num_envs], int32 [num_envs] */
+int tg_copy_episode_stats(tg_ctx* ctx, float* final_return, int32_t* final_len);           /* synchronises */
 /* Host copies (synchronise). */
 int tg_get_reward_done(tg_ctx* ctx, float* reward, uint8_t* done);
 int tg_copy_obs_tactile(tg_ctx* ctx, uint8_t* host_dst, int32_t terminal);

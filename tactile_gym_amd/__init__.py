@@ -10,5 +10,6 @@ loudly when the HIP library or a GPU is missing.
 """
 from . import rl_envs  # noqa: F401  (registers the env ids)
 from .registry import make, make_vec, register, registered_ids  # noqa: F401
+from .vec_env import HipVecEnv  # noqa: F401  (vec_env_cls for stable_baselines3's make_vec_env)
 
 __version__ = "0.1.0"

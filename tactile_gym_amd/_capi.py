@@ -140,6 +140,8 @@ SYMBOLS = {
     "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     "tg_pack_interior": (C.c_int, [_ctx, C.c_void_p]),
     "tg_unpack_interior": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p]),
+    "tg_get_episode_stats": (C.c_int, [_ctx, _vpp, _vpp]),
+    "tg_copy_episode_stats": (C.c_int, [_ctx, _fp, C.POINTER(C.c_int32)]),
     "tg_get_tile_template": (C.c_int, [_ctx, _vpp]),
     "tg_tiles_capacity": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "tg_pack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -379,6 +379,7 @@ struct tg_ctx {
     unsigned long long* d_scene_static = nullptr;
     tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
+    uint8_t* d_episode = nullptr;     // [ep_return f64[n] | ep_final_return f32[n] | ep_final_len i32[n]] (tg_get_episode_stats)
     uint8_t* d_tile_tmpl = nullptr;   // tile-sparse payload (tg_pack_tiles): the image every env shows without a contact - zero inside, the pasted ring outside
     int32_t *d_int_idx = nullptr, *d_int_rank = nullptr;   // interior-only payload: pixel of interior position k / interior position of pixel p (-1: ring)
     int n_interior = 0;
@@ -410,6 +411,11 @@ namespace tg {
 // sender's constants anyway): both directions are word copies through an index table, four words per lane, one 16-byte store each.
 // idx[j] = word of payload position j (padded to a multiple of 4 with repeats of the last), rank_of[q] = payload position of word q (-1:
 // a word of ring pixels only).
+// env.reset() by the caller: the running return of the envs that start over is dropped (an auto-reset's is cleared by the step itself).
+__global__ __launch_bounds__(256) void k_episode_clear(double* __restrict__ ep_return, const uint8_t* __restrict__ mask, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (mask == nullptr || mask[i])) ep_return[i] = 0.0;
+}
 __global__ __launch_bounds__(256) void k_pack_interior(const uint32_t* __restrict__ obs, const int32_t* __restrict__ idx, int Kd, int HWd, int n_img,
                                                        uint32_t* __restrict__ dst) {
     const int img = blockIdx.y;
@@ -935,6 +941,10 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     s.done = c->d_obs + c->packed_obs_bytes + (size_t)n * 4;
     if (has_feature) s.feature = (float*)(c->d_obs + c->packed_feature_off);
     TG_HIP(hipMalloc(&c->d_term, npix * n)); TG_HIP(hipMemset(c->d_term, 0, npix * n));
+    TG_HIP(hipMalloc(&c->d_episode, (size_t)n * 16)); TG_HIP(hipMemset(c->d_episode, 0, (size_t)n * 16));
+    s.ep_return = (double*)c->d_episode;
+    s.ep_final_return = (float*)(c->d_episode + (size_t)n * 8);
+    s.ep_final_len = (int32_t*)(c->d_episode + (size_t)n * 12);
     TG_HIP(hipMalloc(&c->d_mask, n));
     TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 6 * sizeof(float)));
     c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border, sensor->nodef_dep);
@@ -962,7 +972,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -998,6 +1008,7 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
         dmask = c->d_mask;
     }
     reset_sequence(c, dmask);
+    hipLaunchKernelGGL(tg::k_episode_clear, dim3((c->cfg.num_envs + 255) / 256), dim3(256), 0, c->stream, c->st.ep_return, dmask, c->cfg.num_envs);
     render(c, dmask, false);
     if (c->scene_every_step) scene_draw(c, dmask, false);
     if (c->oracle_every_step) oracle_draw(c, c->d_oracle);
@@ -1132,6 +1143,20 @@ int tg_get_interior_count(tg_ctx* c, int32_t* k) {
     *k = c->cfg_turn_off_border ? -1 : 4 * c->n_interior;   // bytes per image; -1: the ring carries rendered values (turn_off_border), nothing to drop
     return 0;
 }
+int tg_get_episode_stats(tg_ctx* c, void** ret_f32, void** len_i32) {
+    if (!c || !ret_f32 || !len_i32) return fail(-1, "NULL argument");
+    *ret_f32 = c->st.ep_final_return;
+    *len_i32 = c->st.ep_final_len;
+    return 0;
+}
+int tg_copy_episode_stats(tg_ctx* c, float* ret, int32_t* len) {
+    if (!c || !ret || !len) return fail(-1, "NULL argument");
+    TG_ENTER(c);
+    TG_HIP(hipMemcpyAsync(ret, c->st.ep_final_return, (size_t)c->cfg.num_envs * 4, hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipMemcpyAsync(len, c->st.ep_final_len, (size_t)c->cfg.num_envs * 4, hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
 int tg_get_tile_template(tg_ctx* c, void** p) {
     if (!c || !p) return fail(-1, "NULL argument");
     *p = c->d_tile_tmpl;
@@ -1207,7 +1232,7 @@ int tg_copy_obs_oracle(tg_ctx* c, float* dst) {
     return 0;
 }
 
-int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
+static int set_scene_impl(tg_ctx* c, const tg_scene* sc) {
     if (!c || !sc) return fail(-1, "tg_set_scene: NULL argument");
     TG_ENTER(c);
     if (c->scene_on) return fail(-1, "tg_set_scene: the scene is already set");
@@ -1291,6 +1316,24 @@ int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
     c->scene_on = true;
     c->scene_every_step = sc->every_step != 0;
     return 0;
+}
+
+
+int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
+    const int rc = set_scene_impl(c, sc);
+    if (rc != 0 && c && !c->scene_on) {     // a failed set-up leaves nothing behind: a retry starts from null pointers, nothing leaks
+        const std::string keep = tg_last_error();
+        (void)hipSetDevice(c->cfg.device);
+        void** ptrs[] = {(void**)&c->d_scene_chunks, (void**)&c->d_scene_verts, (void**)&c->d_scene_tris, (void**)&c->d_scene_local, (void**)&c->d_scene_attr,
+                         (void**)&c->d_scene_xf, (void**)&c->d_vis, (void**)&c->d_vis_term, (void**)&c->d_scene_static};
+        for (void** p : ptrs) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        (void)hipGetLastError();
+        tg::report_error(rc, keep.c_str());
+    }
+    return rc;
 }
 
 int tg_render_scene(tg_ctx* c) {

@@ -73,6 +73,10 @@ struct State {   // device pointers, SoA [field][num_envs]
     int32_t* goal_id;               // [n]
     int32_t* contact_code;          // [n] contact pairs of the last sim tick (sim_tick_push's contact_code)
     float *feature, *term_feature;  // [n][12] extended_feature observation (object_push_env.py:611-629), AoS
+    // per-env episode statistics, what the reference's callers get from the Monitor wrapper (sb3_helpers/rl_utils.py:17-30, 59):
+    double* ep_return;              // [n] sum of the float32 rewards handed out since the episode began
+    float* ep_final_return;         // [n] the finished episode's return (valid where done)
+    int32_t* ep_final_len;          // [n] its length in env steps
     const void* tip_verts;          // [n_tip][3] in the physics dtype
 };
 
@@ -154,6 +158,15 @@ __device__ unsigned long long g_kstep_stamps[16];
 #endif
 // Everything that follows the physics of a step or a reset: TCP pose read-back, reward / termination
 // (edge_follow_env.py:371-452) and the camera<-stimulus transform handed to the raster (tactile_sensor.py:150-229).
+// Episode statistics (the Monitor wrapper the reference's callers always apply: sb3_helpers/rl_utils.py:17-30, 59): the return is the sum, in
+// double, of the float32 rewards as handed out - what a Monitor around this env would add up.  done: the finished episode's figures are
+// kept for info["episode"] and the running sum starts again.
+__device__ __forceinline__ void episode_step(const State& st, int env, float reward, bool done, int step_count) {
+    const double acc = st.ep_return[env] + (double)reward;
+    if (done) { st.ep_final_return[env] = (float)acc; st.ep_final_len[env] = step_count; }
+    st.ep_return[env] = done ? 0.0 : acc;
+}
+
 template <typename T, int TOPO>
 __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
                                            T edge_ang, int step_count, bool write_reward_done, const JointTrig<T, Topo<TOPO>::N>* trig = nullptr,
@@ -189,6 +202,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         else reward = -((T(1) * goal_dist) + (T(10) * edge_dist) + T(0));
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
+        episode_step(st, env, (float)reward, done, step_count);
     }
     TG_KSTAMP(5)
     if ((write_reward_done || c.reward_mode == TG_REWARD_SPARSE) && c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
@@ -233,6 +247,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         if (write_reward_done) {
             st.reward[env] = (float)out;
             st.done[env] = (at_goal || step_count >= c.max_steps) ? 1 : 0;
+            episode_step(st, env, (float)out, at_goal || step_count >= c.max_steps, step_count);
         }
     }
     if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO && st.feature != nullptr) {
@@ -934,6 +949,7 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
         const T reward = (c.reward_mode == TG_REWARD_SPARSE) ? (fell ? T(-1) : T(0)) : T(1);
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
+        episode_step(st, env, (float)reward, done, step_count);
     }
     V3<T> pb; M3<T> Rb;
     link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
@@ -1161,6 +1177,7 @@ __device__ __forceinline__ void finish_push(const DevRobot<T>& m, const EnvConst
         if (step_count >= c.max_steps) done = true;
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
+        episode_step(st, env, (float)reward, done, step_count);
     }
     {   // extended_feature: TCP pose and current goal pose in the work frame
         const int gi = gid < c.traj_n ? gid : c.traj_n - 1;
@@ -1392,8 +1409,10 @@ __device__ __forceinline__ void finish_roll(const DevRobot<T>& m, const EnvConst
         const T dx = b.pos.x - gw.x, dy = b.pos.y - gw.y;
         const T dist = tsqrt(dx * dx + dy * dy);                                           // xy_obj_dist_to_goal
         const bool at_goal = dist < c.term_dist;
-        st.reward[env] = (float)(c.reward_mode == TG_REWARD_SPARSE ? (at_goal ? T(1) : T(0)) : -(T(1) * dist));
+        const float rw = (float)(c.reward_mode == TG_REWARD_SPARSE ? (at_goal ? T(1) : T(0)) : -(T(1) * dist));
+        st.reward[env] = rw;
         st.done[env] = (at_goal || step_count >= c.max_steps) ? 1 : 0;
+        episode_step(st, env, rw, at_goal || step_count >= c.max_steps, step_count);
     }
 #pragma unroll
     for (int e = 0; e < 12; ++e) {

@@ -19,6 +19,7 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <mutex>
 #include <numeric>
 
 namespace tg {
@@ -474,7 +475,17 @@ int scene_prepare(const SceneParams& P) {
     const int tw = P.W < 128 ? P.W : 128, th = P.H < 128 ? P.H : 128;
     const LdsLayout L = lds_layout(tw, th, P.n_chunks);
     if (P.n_chunks > kMaxChunks || L.big_cap < 64) return -1;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scene), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.bytes);
+    // the attribute belongs to the function (per device), not to a context: another context of this process may launch k_scene with a larger
+    // tile, so the limit is only ever raised
+    static std::mutex mu;
+    static int raised[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && (int)L.bytes <= raised[dev]) return 0;
+    const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scene), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.bytes);
+    if (rc == 0 && dev >= 0 && dev < 64) raised[dev] = (int)L.bytes;
+    return rc;
 }
 
 #ifdef TG_SCENE_STATS

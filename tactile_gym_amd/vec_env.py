@@ -10,6 +10,8 @@ VecTransposeImage expect) they are copied to host; with `obs_mode="torch"` the t
 zero-copy `torch.uint8` CUDA(HIP) tensor aliasing the library's device buffer.
 """
 import ctypes as C
+import time
+import warnings
 
 import numpy as np
 
@@ -100,6 +102,10 @@ class TactileVecEnv(_VecEnvBase):
         self._term_host = None
         self._closed = False
         self._views = {}
+        self._t_start = time.time()                 # Monitor's t_start (info["episode"]["t"])
+        self._ep_ret = np.zeros(self.num_envs, dtype=np.float32)
+        self._ep_len = np.zeros(self.num_envs, dtype=np.int32)
+        self._rebinds = 0
         if seed is not None:
             self.seed(seed)
 
@@ -133,6 +139,10 @@ class TactileVecEnv(_VecEnvBase):
         if getattr(self, "_bound_stream", None) != ptr:
             if hasattr(self, "_bound_stream"):
                 capi.check(self._L.tg_sync(self._ctx))     # drain the stream being left before work goes to another one
+                self._rebinds += 1
+                if self._rebinds == 8:                     # every switch costs a host sync and a re-instantiated step graph
+                    warnings.warn("TactileVecEnv (obs_mode='torch') has been moved between torch streams 8 times: drive an env from ONE stream "
+                                  "(or pin it with set_stream); each switch drains the device and re-captures the step graph", RuntimeWarning, stacklevel=3)
             capi.check(self._L.tg_set_stream(self._ctx, C.c_void_p(ptr)))
             self._bound_stream = ptr
 
@@ -162,6 +172,14 @@ class TactileVecEnv(_VecEnvBase):
         obs = self._observation()
         dones = self._done.astype(bool)
         infos = [{} for _ in range(self.num_envs)]
+        if dones.any():
+            # what the reference's callers read from the Monitor wrapper around every env (sb3_helpers/rl_utils.py:17-30, 59; SB3's logger and
+            # EvalCallback consume info["episode"]): return and length of the episode that just ended, added up on the device
+            capi.check(self._L.tg_copy_episode_stats(self._ctx, self._ep_ret.ctypes.data_as(C.POINTER(C.c_float)),
+                                                     self._ep_len.ctypes.data_as(C.POINTER(C.c_int32))))
+            t = round(time.time() - self._t_start, 6)
+            for i in np.nonzero(dones)[0]:
+                infos[i]["episode"] = {"r": round(float(self._ep_ret[i]), 6), "l": int(self._ep_len[i]), "t": t}
         if self._cfg.auto_reset and dones.any():
             term = self._terminal_observation()
             for i in np.nonzero(dones)[0]:   # owned copies: the library's terminal buffers are rewritten by the next auto-reset
@@ -202,9 +220,10 @@ class TactileVecEnv(_VecEnvBase):
         from .robot_model import SceneDesc
         sp = self._scene_spec
         body = None if self._mesh is None else (self._mesh.verts, self._mesh.tris)
-        self._scene = SceneDesc(sp["arm_type"], self._sensor.t_s_type, self._sensor.t_s_name, self._robot.ndof, (self.H, self.W), sp["camera"],
-                                body, sp.get("body_rgb", (0, 0, 255)), every_step, body_heightfield=self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO)
-        capi.check(self._L.tg_set_scene(self._ctx, C.byref(self._scene.struct)))
+        scene = SceneDesc(sp["arm_type"], self._sensor.t_s_type, self._sensor.t_s_name, self._robot.ndof, (self.H, self.W), sp["camera"],
+                          body, sp.get("body_rgb", (0, 0, 255)), every_step, body_heightfield=self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO)
+        capi.check(self._L.tg_set_scene(self._ctx, C.byref(scene.struct)))
+        self._scene = scene                         # only a scene the library accepted counts as set
 
     def get_images(self):
         """One render() frame per env (BaseTactileEnv.render, base_tactile_env.py:284-303): [H, 2W, 3] uint8, the scene camera's rgb image
@@ -474,6 +493,8 @@ class SingleTactileEnv(_GymEnvBase):
         if env_modes is None:
             env_modes = self.default_env_modes
         self._vec = self.vec_cls(1, max_steps, image_size, env_modes, physics_dtype, auto_reset=False, device=device, **kwargs)
+        # what HipVecEnv needs to build the N-env context this env stands for (make_vec_env hands it constructors, not arguments)
+        self._ctor = dict(max_steps=max_steps, image_size=list(image_size), env_modes=dict(env_modes), physics_dtype=physics_dtype, device=device, **kwargs)
         self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
         self.min_action, self.max_action = self._vec.min_action, self._vec.max_action
         self._max_steps, self._image_size, self._seed = max_steps, list(image_size), None
@@ -497,7 +518,7 @@ class SingleTactileEnv(_GymEnvBase):
 
     def step(self, action):
         obs, rew, done, _ = self._vec.step(np.asarray(action, dtype=np.float32)[None])
-        return self._first(obs), float(rew[0]), bool(done[0]), {}
+        return self._first(obs), float(rew[0]), bool(done[0]), {}      # base_tactile_env.py:185 returns an empty info; a Monitor around this env adds its own
 
     def render(self, mode="rgb_array"):
         """BaseTactileEnv.render (base_tactile_env.py:284-303): the scene camera's rgb image beside the tactile image, [H, 2W, 3] uint8
@@ -511,3 +532,48 @@ class SingleTactileEnv(_GymEnvBase):
 
     def get_state(self):
         return {k: v[0] for k, v in self._vec.get_state().items()}
+
+
+class HipVecEnv:
+    """`vec_env_cls` for stable_baselines3's make_vec_env: the reference's `make_training_envs` / `make_eval_env`
+    (sb3_helpers/rl_utils.py:15-37, 49-68) then change by one token,
+
+        make_vec_env(env_id, env_kwargs=env_args, n_envs=n, seed=seed, vec_env_cls=tg.HipVecEnv, monitor_dir=save_dir)
+
+    instead of `vec_env_cls=SubprocVecEnv`.  SB3 hands a vec_env_cls a list of CONSTRUCTORS - each would make one env (gym.make(env_id,
+    **env_kwargs), seeded seed + rank, wrapped in Monitor) in its own process.  Here the first constructor is called once as a probe: the env
+    it makes names its class and constructor arguments, and ONE N-env device context is built from them with env i seeded seed + i (the
+    seeds the N constructors would have used).  The per-env Monitor's bookkeeping is done on the device: every step's info carries
+    info["episode"] = {"r", "l", "t"} for the envs that finished (what SB3's logger and EvalCallback read).  Extra keyword arguments
+    (vec_env_kwargs: obs_mode, copy_obs, physics_dtype, device ...) go to the vectorised constructor; start_method is accepted and
+    ignored.  The result is a TactileVecEnv (an SB3 VecEnv subclass wherever SB3 is importable), not an instance of this class."""
+
+    def __new__(cls, env_fns, start_method=None, **kwargs):
+        env_fns = list(env_fns)
+        if not env_fns:
+            raise ValueError("HipVecEnv needs at least one env constructor")
+        probe = env_fns[0]()
+        single = probe
+        def ours(e):                                 # one of this package's single-env classes (by what it carries, not by class identity)
+            return hasattr(e, "_ctor") and hasattr(e, "_seed") and callable(getattr(type(e), "make_vec", None))
+
+        for _ in range(16):                          # through Monitor / TimeLimit / any gym.Wrapper down to the env itself
+            if ours(single):
+                break
+            nxt = getattr(single, "env", None)
+            if nxt is None:
+                nxt = getattr(single, "unwrapped", None)
+                if nxt is single:
+                    nxt = None
+            if nxt is None:
+                break
+            single = nxt
+        if not ours(single):
+            raise TypeError(f"HipVecEnv: the constructors make {type(single).__name__}, not one of this package's envs "
+                            f"(register ids with `import tactile_gym_amd` and pass one of tactile_gym_amd.registered_ids())")
+        ctor = dict(single._ctor)
+        ctor.update(kwargs)
+        seed = single._seed                          # make_vec_env's make_env(rank) called env.seed(seed + rank): rank 0 -> the base seed
+        env_cls = type(single)
+        probe.close()
+        return env_cls.make_vec(num_envs=len(env_fns), seed=seed, **ctor)

@@ -1,0 +1,87 @@
+"""What the reference's callers consume at the VecEnv boundary: per-env episode statistics - the Monitor wrapper
+`make_vec_env(..., monitor_dir=...)` puts around every env (sb3_helpers/rl_utils.py:17-30, 59) - and construction through make_vec_env's
+`vec_env_cls` hook."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EDGE = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+PUSH = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
+            observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")
+BAL = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=True, rand_embed_dist=True,
+           observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+SURF = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")
+
+
+@pytest.mark.parametrize("env_id,cls,modes,act_dim,size", [("edge_follow-v0", "OracleEdgeFollowEnv", EDGE, 2, 64), ("surface_follow-v0", "OracleSurfaceFollowAutoEnv", SURF, 3, 64),
+                                                           ("object_balance-v0", "OracleObjectBalanceEnv", BAL, 2, 64), ("object_push-v0", "OracleObjectPushEnv", PUSH, 2, 128)])
+def test_episode_info_equals_summed_rewards_of_the_oracle(env_id, cls, modes, act_dim, size):
+    """info["episode"] = {"r", "l", "t"} on done (Monitor / VecMonitor semantics), for all four task families (each has its own step-kernel
+    epilogue): r = the sum of the rewards of the episode that just ended - equal to the sum of what step() returned (float32 terms added in
+    double) and to the oracle env's summed rewards (1e-4: the oracle's terms are doubles) - l = its length; two consecutive episodes per env
+    (the second starts from an auto-reset), and a caller's reset() in mid-episode drops the running sum."""
+    import tactile_gym_amd as tg
+    from oracle import ref_env
+    n, max_steps = 6, 5
+    venv = tg.make_vec(env_id, num_envs=n, max_steps=max_steps, image_size=[size, size], env_modes=modes, seed=70, auto_reset=True)
+    oracles = [getattr(ref_env, cls)(seed=70 + i, max_steps=max_steps, image_size=(size, size), env_modes=modes) for i in range(n)]
+    venv.reset()
+    for o in oracles:
+        o.reset()
+    rng = np.random.default_rng(1)
+    mine, ref, lens, episodes = np.zeros(n), np.zeros(n), np.zeros(n, int), 0
+    for step in range(2 * max_steps + 2):
+        a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+        obs, rew, done, infos = venv.step(a)
+        for i, o in enumerate(oracles):
+            _, rr, rd, _ = o.step(a[i])
+            mine[i] += float(rew[i]); ref[i] += rr; lens[i] += 1
+            vs_oracle = env_id != "object_push-v0"      # push: the first goal advance of an episode is a knife edge (PARITY A29; followed in
+            assert bool(done[i]) == rd or not vs_oracle, (step, i)   # tests/test_gpu_parity.py), so its sums are checked against step()'s rewards only
+            if done[i]:
+                ep = infos[i]["episode"]
+                assert set(ep) == {"r", "l", "t"} and ep["l"] == lens[i] and ep["t"] >= 0.0
+                assert abs(ep["r"] - mine[i]) <= 1e-5 * max(1.0, abs(mine[i])), (env_id, step, i, ep, mine[i])
+                assert not vs_oracle or abs(ep["r"] - ref[i]) <= 1e-4 * max(1.0, abs(ref[i])), (env_id, step, i, ep, ref[i])
+                assert "terminal_observation" in infos[i]
+                mine[i] = ref[i] = 0.0; lens[i] = 0; episodes += 1
+                o.reset()
+            elif rd and not vs_oracle:
+                o.reset()
+            else:
+                assert "episode" not in infos[i]
+    assert episodes >= 2 * n
+    # a caller's reset() in the middle of an episode starts the sums again
+    venv.reset()
+    for o in oracles:
+        o.reset()
+    tot = np.zeros(n)
+    for step in range(max_steps):
+        a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+        _, rew, done, infos = venv.step(a)
+        tot += rew
+    assert done.all() and all(abs(infos[i]["episode"]["r"] - tot[i]) <= 1e-5 * max(1.0, abs(tot[i])) and infos[i]["episode"]["l"] == max_steps for i in range(n))
+    venv.close()
+
+
+def test_make_vec_env_with_hipvecenv_equals_make_vec():
+    """make_vec_env(env_id, n_envs, seed, env_kwargs, vec_env_cls=tg.HipVecEnv) - the reference's make_training_envs with one token
+    changed (sb3_helpers/rl_utils.py:17-30) - builds the same batch as tg.make_vec(..., seed=seed): identical states and images."""
+    import tactile_gym_amd as tg
+    from test_host_cpu import sb3_like_make_vec_env
+    kw = dict(max_steps=50, image_size=[64, 64], env_modes=EDGE)
+    a = sb3_like_make_vec_env("edge_follow-v0", n_envs=5, seed=9, env_kwargs=kw, vec_env_cls=tg.HipVecEnv)
+    b = tg.make_vec("edge_follow-v0", num_envs=5, seed=9, **kw)
+    assert a.num_envs == 5 and type(a) is type(b)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa["tactile"], ob["tactile"])
+    acts = np.random.default_rng(0).uniform(-0.25, 0.25, size=(3, 5, 2)).astype(np.float32)
+    for k in range(3):
+        ra, rb = a.step(acts[k]), b.step(acts[k])
+        assert np.array_equal(ra[0]["tactile"], rb[0]["tactile"]) and np.array_equal(ra[1], rb[1])
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa["q"], sb["q"]) and np.array_equal(sa["edge_ang"], sb["edge_ang"])
+    a.close(); b.close()

@@ -319,3 +319,72 @@ def test_constant_time_digitize_equals_the_edge_by_edge_count(tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("0 mismatches"), out.stdout
     dev = open(os.path.join(os.path.dirname(__file__), "..", "tactile_gym_amd", "csrc", "tg_kernels.hpp")).read()
     assert "int base = (int)t - 1;" in dev and "for (int j = 0; j < 4; ++j)" in dev      # the device body is this one
+
+
+class _FakeMonitor:
+    """What stable_baselines3.common.monitor.Monitor is to HipVecEnv: a gym.Wrapper around the env (attribute `env`)."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def close(self):
+        self.env.close()
+
+
+def sb3_like_make_vec_env(env_id, n_envs=1, seed=None, start_index=0, env_kwargs=None, vec_env_cls=None, vec_env_kwargs=None):
+    """The body of stable_baselines3.common.env_util.make_vec_env as the reference calls it (sb3_helpers/rl_utils.py:17-30, 49-57): a list
+    of constructors, each gym.make(env_id, **env_kwargs) + seed(seed + rank) + Monitor, handed to vec_env_cls.  SB3 itself is not in the
+    image; tg.make stands in for gym.make (the same registry)."""
+    import tactile_gym_amd as tg
+    env_kwargs, vec_env_kwargs = env_kwargs or {}, vec_env_kwargs or {}
+
+    def make_env(rank):
+        def _init():
+            env = tg.make(env_id, **env_kwargs)
+            if seed is not None:
+                env.seed(seed + rank)
+            return _FakeMonitor(env)
+        return _init
+
+    return vec_env_cls([make_env(i + start_index) for i in range(n_envs)], **vec_env_kwargs)
+
+
+def test_hipvecenv_is_a_vec_env_cls_for_make_vec_env(monkeypatch, edge_modes):
+    """HipVecEnv(env_fns): ONE probe env is constructed (to learn class + constructor arguments + base seed) and closed, then one N-env
+    context with the same arguments, env i seeded seed + i.  No GPU here: the vectorised class is replaced by a recorder."""
+    import tactile_gym_amd as tg
+    from tactile_gym_amd import spaces
+    from tactile_gym_amd.rl_envs import edge_follow as ef
+    made = []
+
+    class Recorder:
+        def __init__(self, num_envs, max_steps=250, image_size=(64, 64), env_modes=None, physics_dtype="f64", auto_reset=True, device=0,
+                     obs_mode="numpy", seed=None, **kw):
+            self.args = dict(num_envs=num_envs, max_steps=max_steps, image_size=list(image_size), env_modes=dict(env_modes), physics_dtype=physics_dtype,
+                             auto_reset=auto_reset, device=device, obs_mode=obs_mode, seed=seed, **kw)
+            self.action_space = spaces.Box(low=-0.25, high=0.25, shape=(2,), dtype=np.float32)
+            self.observation_space = spaces.Dict({})
+            self.min_action, self.max_action, self.closed, self.seeds = -0.25, 0.25, False, []
+            made.append(self)
+
+        def seed(self, s=None):
+            self.seeds.append(s)
+            return [s]
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(ef.EdgeFollowEnv, "vec_cls", Recorder)
+    venv = sb3_like_make_vec_env("edge_follow-v0", n_envs=6, seed=40, env_kwargs=dict(max_steps=77, image_size=[128, 128], env_modes=edge_modes),
+                                 vec_env_cls=tg.HipVecEnv, vec_env_kwargs=dict(obs_mode="torch"))
+    assert len(made) == 2                                     # the probe and the batch, not six single envs
+    probe, batch = made
+    assert venv is batch and probe.closed and not batch.closed
+    assert probe.args["num_envs"] == 1 and probe.args["auto_reset"] is False and probe.seeds == [40]
+    assert batch.args["num_envs"] == 6 and batch.args["seed"] == 40 and batch.args["auto_reset"] is True      # VecEnv semantics: auto-reset
+    assert batch.args["max_steps"] == 77 and batch.args["image_size"] == [128, 128] and batch.args["env_modes"] == edge_modes
+    assert batch.args["obs_mode"] == "torch"                  # vec_env_kwargs reach the vectorised constructor
+    with pytest.raises(TypeError):
+        tg.HipVecEnv([lambda: object()])
+    with pytest.raises(ValueError):
+        tg.HipVecEnv([])

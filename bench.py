@@ -261,13 +261,14 @@ def main():
     ap.add_argument("--solver-iters", type=int, default=None, help="object_push / object_roll: override numSolverIterations (150); measurement aid, not a bench configuration")
     ap.add_argument("--payload", default=os.environ.get("TG_BENCH_PAYLOAD", "auto"), choices=["auto", "full", "interior", "tiles"],
                     help="N > 1: what the tactile part of the per-step message to rank 0 carries (parallel.py)")
-    ap.add_argument("--transport", default=os.environ.get("TG_BENCH_TRANSPORT", "collective"), choices=["collective", "ipc"],
-                    help="N > 1: torch.distributed collectives over RCCL (default), or peers storing straight into rank 0's IPC-mapped buffer")
+    ap.add_argument("--transport", default=os.environ.get("TG_BENCH_TRANSPORT", "auto"), choices=["auto", "collective", "ipc"],
+                    help="N > 1: peers store straight into rank 0's IPC-mapped receive slots (ipc), or torch.distributed collectives over RCCL; "
+                         "auto (default) = ipc when its set-up handshake succeeds on every rank, else collective")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: time only the exchange-free rollout (per-rank learners)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("TG_BENCH_SPAWN") == "1"):   # TG_BENCH_SPAWN: the same path with one rank (1-GPU test)
         spawn_ranks(args.gpus)                      # re-executes this script under torch.distributed.run; never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -420,11 +421,15 @@ def main():
         if solo and not args.no_cpu_baseline and args.env == "edge_follow-v0":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if gathered and hasattr(env, "close"):
-        env.close()
-    w.close()
     if dist is not None:
-        dist.destroy_process_group()
+        # the line is out; every rank waits for the others, then leaves without running the teardown of RCCL / IPC mappings / HIP streams in
+        # whatever order the interpreter picks (the process exit reclaims all of it; a background-thread abort during that teardown would
+        # turn a finished measurement into a non-zero exit code)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        barrier()
+        os._exit(0)
+    w.close()
 
 
 if __name__ == "__main__":

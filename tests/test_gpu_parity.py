@@ -1254,8 +1254,10 @@ def test_raster_division_is_correctly_rounded():
         assert m.value == 0
 
 
-@pytest.mark.parametrize("env_id,size,port", [("edge_follow-v0", 128, 29541), ("object_push-v0", 128, 29542), ("object_balance-v0", 256, 29543)])
-def test_bench_launches_under_torchrun_on_the_rccl_gather_path(env_id, size, port):
+@pytest.mark.parametrize("env_id,size,port,transport,payload", [("edge_follow-v0", 128, 29541, "collective", "auto"), ("object_push-v0", 128, 29542, "collective", "auto"),
+                                                                ("object_balance-v0", 256, 29543, "collective", "auto"), ("edge_follow-v0", 128, 29544, "auto", "auto"),
+                                                                ("object_push-v0", 128, 29545, "ipc", "tiles"), ("edge_follow-v0", 128, 29546, "collective", "tiles")])
+def test_bench_launches_under_torchrun_on_the_rccl_gather_path(env_id, size, port, transport, payload):
     """The driver's multi-GPU command line with one rank: torch.distributed.run -> RCCL process group -> ShardedVecEnv's gather
     (forced although world_size is 1) -> one JSON line.  Guards the N > 1 launch path on a 1-GPU box for BASELINE configs 2 (edge_follow),
     4 (object_push: tactile_and_feature, the extended_feature block rides in the same packed message) and 5 (object_balance 256 x 256:
@@ -1265,7 +1267,7 @@ def test_bench_launches_under_torchrun_on_the_rccl_gather_path(env_id, size, por
     env = dict(os.environ, TG_BENCH_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "10", "--num-envs", "256",
-           "--env", env_id, "--image-size", str(size), "--no-cpu-baseline", "--no-literal"]
+           "--env", env_id, "--image-size", str(size), "--no-cpu-baseline", "--no-literal", "--transport", transport, "--payload", payload]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -1273,6 +1275,29 @@ def test_bench_launches_under_torchrun_on_the_rccl_gather_path(env_id, size, por
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 60 and d["value"] > 0 and d["config"]["total_envs"] == 256
     assert d["roofline"]["frac"] > 0 and env_id in d["config"]["workload"]
+    # the exchange really ran, on the transport asked for, and what rank 0 was handed is what the rank rendered
+    ex = d["exchange"]
+    assert d["rccl_ranks"] == 1 and ex["verified"] is True
+    assert ex["transport"] == ("ipc" if transport in ("ipc", "auto") else "collective")
+    assert ex["payload"] == ("tiles" if (payload == "tiles" or transport == "auto") else ("interior" if env_id != "object_push-v0" else "full"))
+    if ex["payload"] == "tiles":
+        assert ex["message_bytes_last"][0] < ex["message_bytes_capacity"]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run (the
+    driver's N = 1 command was a plain `python3 bench.py`).  One GPU here, so the path is taken with one rank (TG_BENCH_SPAWN=1)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TG_BENCH_SPAWN="1", TG_BENCH_FORCE_COLLECTIVE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "5", "--num-envs", "128", "--no-cpu-baseline",
+                          "--no-literal", "--no-companions"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-12000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["exchange"]["verified"] is True and d["value"] > 0
 
 
 def test_sample_actions_is_a_counter_based_uniform_box_sample(edge_modes):

@@ -517,6 +517,53 @@ void mb_render_scene(const float* verts, const int32_t* tris, const uint8_t* tri
     }
 }
 
+/* Translucent spheres over a finished scene image (the goal indicators and trajectory markers of the task envs: sphere_indicator.urdf, rgba
+ * (1, 0, 0, 0.5), recoloured by changeVisualShape; edge_follow_env.py:230-234, base_surface_env.py:395-400, object_push_env.py:239-250, 345-366,
+ * base_object_env.py:72-75).  Upstream's blend is the GL driver's (PARITY_ASSUMPTIONS A33); the rule here, per pixel centre and per sphere in
+ * list order: the ray through the pixel meets the sphere at eye depth w = (B - sqrt(B^2 - A C)) / A (A = dx^2 + dy^2 + 1, B = d . c, C = |c|^2 -
+ * r^2, d = (dx, dy, -1) the pixel's ray, c the centre in eye space); the fragment counts when near <= w <= far and it is strictly nearer
+ * than the opaque surface of that pixel (1 / w > the z key's 1 / w; no opaque surface: always); it is shaded like an opaque triangle (0.6 +
+ * 0.35 max(0, n . l), n the outward normal) and blended  out = (uint8)(alpha src + (1 - alpha) dst + 0.5)  over what the pixel holds -
+ * earlier spheres included; translucent fragments neither write depth nor test against each other.
+ * spheres: [n][8] floats = centre in eye space (3), radius, r, g, b (0..255), alpha.  zbuf: the keys mb_render_scene left. */
+void mb_blend_spheres(const float* spheres, int n, const float* light_eye, float fov_deg, float near_, float far_, int W, int H, const uint64_t* zbuf,
+                      uint8_t* out) {
+    double ys = 1.0 / tan(0.5 * (double)fov_deg * (3.14159265358979323846 / 180.0));
+    float kx = (float)(ys * 0.5 * H), ky = (float)(ys * 0.5 * H), hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    for (int py = 0; py < H; ++py)
+        for (int px = 0; px < W; ++px) {
+            const size_t p = (size_t)py * W + px;
+            uint32_t hi = (uint32_t)(zbuf[p] >> 32);
+            float iw_o;
+            memcpy(&iw_o, &hi, 4);
+            if (zbuf[p] == 0) iw_o = 0.0f;
+            float dx = (((float)px + 0.5f) - hw) / kx, dy = (hh - ((float)py + 0.5f)) / ky;
+            float A = (dx * dx + dy * dy) + 1.0f;
+            for (int k = 0; k < n; ++k) {
+                const float* S = spheres + 8 * k;
+                float alpha = S[7];
+                if (!(alpha > 0.0f)) continue;
+                float cx = S[0], cy = S[1], cz = S[2], r = S[3];
+                float B = (dx * cx + dy * cy) - cz;
+                float Cc = ((cx * cx + cy * cy) + cz * cz) - r * r;
+                float disc = B * B - A * Cc;
+                if (!(disc >= 0.0f)) continue;
+                float w = (B - sqrtf(disc)) / A;
+                if (!(w >= near_ && w <= far_)) continue;
+                float iw = 1.0f / w;
+                if (!(iw > iw_o)) continue;
+                float nx = (w * dx - cx) / r, ny = (w * dy - cy) / r, nz = (-w - cz) / r;
+                float ndl = (nx * light_eye[0] + ny * light_eye[1]) + nz * light_eye[2];
+                if (!(ndl > 0.0f)) ndl = 0.0f;
+                float inten = 0.6f + 0.35f * ndl;
+                for (int c = 0; c < 3; ++c) {
+                    float src = (float)(uint32_t)(S[4 + c] * inten + 0.5f);
+                    out[3 * p + c] = (uint8_t)(uint32_t)((alpha * src + (1.0f - alpha) * (float)out[3 * p + c]) + 0.5f);
+                }
+            }
+        }
+}
+
 /* ------------------------------------------------------------------------------------------------ OpenSimplex 2-D */
 #define OS_STRETCH_2D (-0.211324865405187)   /* (1/sqrt(2+1)-1)/2 */
 #define OS_SQUISH_2D 0.366025403784439       /* (sqrt(2+1)-1)/2 */

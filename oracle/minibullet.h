@@ -103,6 +103,8 @@ void mb_render_depth(const float* verts /*[nv][3]*/, int nv, const int32_t* tris
 void mb_render_scene(const float* verts, const int32_t* tris, const uint8_t* tri_xf, const uint8_t* tri_rgb, int nt, const float* xf,
                      const float* light_eye, float fov_deg, float near_, float far_, int W, int H, const uint8_t* background,
                      uint64_t* zbuf, uint8_t* out);
+void mb_blend_spheres(const float* spheres, int n, const float* light_eye, float fov_deg, float near_, float far_, int W, int H, const uint64_t* zbuf,
+                      uint8_t* out);
 void mb_t_s_camera(const float* cur_dep, const float* nodef_dep, const float* nodef_gray, const uint8_t* border_mask,
                    int npix, int turn_off_border, uint8_t* out);
 

@@ -96,6 +96,7 @@ def lib():
         _lib.mb_t_s_camera.argtypes = [fp, fp, fp, u8p, C.c_int, C.c_int, u8p]
         _lib.mb_render_scene.argtypes = [fp, ip, u8p, u8p, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, u8p,
                                          C.POINTER(C.c_uint64), u8p]
+        _lib.mb_blend_spheres.argtypes = [fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64), u8p]
     return _lib
 
 
@@ -273,8 +274,9 @@ def scene_view_matrix(target, dist, yaw_deg, pitch_deg):
     return V, -V @ eye
 
 
-def render_scene(verts, tris, tri_frame, tri_rgb, frames, view, light_dir_world, fov, near, far, w, h, background):
-    """Scene camera rgb (uint8 [h, w, 3]).  frames: world poses [(R [3,3], p [3]), ...] that tri_frame indexes; view = scene_view_matrix(...)."""
+def render_scene(verts, tris, tri_frame, tri_rgb, frames, view, light_dir_world, fov, near, far, w, h, background, spheres=None):
+    """Scene camera rgb (uint8 [h, w, 3]).  frames: world poses [(R [3,3], p [3]), ...] that tri_frame indexes; view = scene_view_matrix(...).
+    spheres: optional list of (world centre [3], radius, (r, g, b) 0..255, alpha) blended over the opaque image in list order (mb_blend_spheres)."""
     V, tv = view
     xf = np.zeros((len(frames), 12), dtype=np.float32)
     for i, (R, p) in enumerate(frames):
@@ -293,6 +295,13 @@ def render_scene(verts, tris, tri_frame, tri_rgb, frames, view, light_dir_world,
     lib().mb_render_scene(v.ctypes.data_as(fp), t.ctypes.data_as(C.POINTER(C.c_int32)), tf.ctypes.data_as(u8), tc.ctypes.data_as(u8), t.shape[0],
                           xf.ctypes.data_as(fp), le.ctypes.data_as(fp), fov, near, far, w, h, bg.ctypes.data_as(u8),
                           z.ctypes.data_as(C.POINTER(C.c_uint64)), out.ctypes.data_as(u8))
+    if spheres:
+        sp = np.zeros((len(spheres), 8), dtype=np.float32)
+        for i, (c, r, rgb, alpha) in enumerate(spheres):
+            sp[i, :3] = V @ np.asarray(c, dtype=np.float64) + tv          # eye-space centre, rounded to float like the frames' translations
+            sp[i, 3], sp[i, 4:7], sp[i, 7] = r, rgb, alpha
+        lib().mb_blend_spheres(sp.ctypes.data_as(fp), len(spheres), le.ctypes.data_as(fp), fov, near, far, w, h, z.ctypes.data_as(C.POINTER(C.c_uint64)),
+                               out.ctypes.data_as(u8))
     return out
 
 

@@ -260,7 +260,20 @@ class _OracleArmEnv:
         target, dist, yaw, pitch, fov, near, far = self.scene_camera()
         h, w = self.image_size
         return mb.render_scene(verts, tris, tri_frame, tri_rgb, frames, mb.scene_view_matrix(target, dist, yaw, pitch), self.LIGHT_DIR,
-                               fov, near, far, w, h, self.BACKGROUND)
+                               fov, near, far, w, h, self.BACKGROUND, spheres=self.scene_spheres())
+
+    GOAL_RADIUS, GOAL_RGBA = 0.01, ((255.0, 0.0, 0.0), 0.5)       # sphere_indicator.urdf: <sphere radius="0.01">, rgba 1 0 0 0.5
+
+    def scene_spheres(self):
+        """The scene's translucent visuals, [(world centre, radius, rgb 0..255, alpha)], in the order they were loaded: the arm's TCP marker
+        (every arm URDF: tcp_link <sphere radius="0.001">, material TransparentRed rgba 0.9 0 0.2 0.5, e.g. ur5_with_standard_tactip.urdf:25,
+        335-343), then the task's."""
+        tcp = np.asarray(self.arm.link_state("tcp_link")[0], dtype=np.float64)
+        return [(tcp, 0.001, (229.5, 0.0, 51.0), 0.5)] + self.task_spheres()
+
+    def task_spheres(self):
+        """Default: the goal indicator at goal_pos_world (edge_follow_env.py:230-234, 281-283; base_surface_env.py:395-400, 576)."""
+        return [(np.asarray(self.goal_pos_world, dtype=np.float64), self.GOAL_RADIUS) + self.GOAL_RGBA]
 
     def _observation(self):  # base_tactile_env.py:200-210, 247-282
         obs = {}
@@ -795,6 +808,9 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
     def _step_simulation(self):
         self.arm.step_simulation_body(self.body, self.p2p, self.SIM_DT, self.SOLVER_ITERS)
 
+    def task_spheres(self):                                                                 # visualise_goal = False (object_balance_env.py:70)
+        return []
+
     def body_pose(self):
         return np.array(self.body.pos[:]), np.array(self.body.rot[:]).reshape(3, 3)
 
@@ -967,6 +983,16 @@ class OracleObjectPushEnv(_OracleArmEnv):
 
     def cube_pose(self):
         return np.array(self.cube.pos[:]), np.array(self.cube.rot[:]).reshape(3, 3)
+
+    def task_spheres(self):
+        """The trajectory markers (object_push_env.py:239-250: traj_n_points sphere_indicator bodies; :281-282 placed and painted green
+        (0, 1, 0, 0.5) by update_trajectory; :360-366 update_goal paints the current target blue and the one just reached red).  No goal
+        indicator of its own: visualise_goal = False (:71)."""
+        out = []
+        for i in range(int(self.traj_n_points)):
+            rgb = (0.0, 0.0, 255.0) if i == self.targ_traj_list_id else ((255.0, 0.0, 0.0) if i < self.targ_traj_list_id else (0.0, 255.0, 0.0))
+            out.append((np.asarray(self.traj_pos_world[i], dtype=np.float64), self.GOAL_RADIUS, rgb, 0.5))
+        return out
 
     def reset(self):
         """base_object_env.py:146-173 with object_push_env.py:168-340."""
@@ -1163,6 +1189,11 @@ class OracleObjectRollEnv(_OracleArmEnv):
 
     def ball_pose(self):
         return np.array(self.ball.pos[:]), np.array(self.ball.rot[:]).reshape(3, 3)
+
+    def task_spheres(self):
+        """The goal indicator is the marble's own URDF (goal_path = sphere.urdf, radius 0.0025, no globalScaling: object_roll_env.py:174,
+        base_object_env.py:72-75) painted (1, 0, 0, 0.5), moved to goal_pos_worldframe by update_goal (:258-284)."""
+        return [(np.asarray(self.goal_pos_world, dtype=np.float64), 0.0025, (255.0, 0.0, 0.0), 0.5)]
 
     def reset(self):
         """base_object_env.py:153-190 with object_roll_env.py:176-266."""

@@ -373,7 +373,7 @@ struct tg_ctx {
     tg::SceneParams scene{};
     tg::SceneView scene_view{};
     bool scene_on = false, scene_every_step = false;
-    float *d_scene_verts = nullptr, *d_scene_xf = nullptr;
+    float *d_scene_verts = nullptr, *d_scene_xf = nullptr, *d_scene_spheres = nullptr;
     int32_t* d_scene_tris = nullptr;
     uint32_t *d_scene_attr = nullptr, *d_scene_local = nullptr;
     unsigned long long* d_scene_static = nullptr;
@@ -646,7 +646,7 @@ static int oracle_dim(const tg_ctx* c) {
 template <typename T, int TOPO> static void launch_scene_xf_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;
     hipLaunchKernelGGL((k_scene_xf<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st, c->scene_view, d_mask, c->d_scene_xf);
+                       (const EnvConst<T>*)c->d_const, c->st, c->scene_view, d_mask, c->d_scene_xf, c->d_scene_spheres, c->scene.n_spheres);
 }
 // get_visual_obs for the whole batch (or the masked envs; save_prev keeps their previous image as the terminal observation)
 static void scene_draw(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
@@ -972,7 +972,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1298,6 +1298,16 @@ static int set_scene_impl(tg_ctx* c, const tg_scene* sc) {
     TG_HIP(hipMemcpy(c->d_scene_attr, attr.data(), (size_t)sc->n_tris * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMemset(c->d_vis, 0, n * img)); TG_HIP(hipMemset(c->d_vis_term, 0, n * img));
     P.verts = c->d_scene_verts; P.tris = c->d_scene_tris; P.tri_attr = c->d_scene_attr; P.tri_local = c->d_scene_local;
+    {   // the env's translucent visuals (goal indicator / trajectory markers), one slot list per env, filled by k_scene_xf
+        const int kind = c->cfg.env_kind;
+        P.n_spheres = 1 + (kind == TG_ENV_OBJECT_PUSH ? c->cfg.traj_n_points : (kind == TG_ENV_OBJECT_BALANCE ? 0 : 1));   // slot 0: the arm's TCP marker
+        if (P.n_spheres > 16) return fail(-1, "tg_set_scene: more than 16 trajectory markers");
+        if (P.n_spheres > 0) {
+            TG_HIP(hipMalloc(&c->d_scene_spheres, n * (size_t)P.n_spheres * 8 * 4));
+            TG_HIP(hipMemset(c->d_scene_spheres, 0, n * (size_t)P.n_spheres * 8 * 4));
+        }
+        P.spheres = c->d_scene_spheres;
+    }
     if (scene_prepare(P) != 0) return fail(-1, "tg_set_scene: the scene's chunk list does not fit the workgroup's LDS (or hipFuncSetAttribute failed)");
     {   // the world frame once: frame 0 of every env is the view matrix itself (k_scene_xf: put(0, I, 0)), rounded to float the same way
         std::vector<float> xf0((size_t)n_frames * 12, 0.0f);
@@ -1325,7 +1335,7 @@ int tg_set_scene(tg_ctx* c, const tg_scene* sc) {
         const std::string keep = tg_last_error();
         (void)hipSetDevice(c->cfg.device);
         void** ptrs[] = {(void**)&c->d_scene_chunks, (void**)&c->d_scene_verts, (void**)&c->d_scene_tris, (void**)&c->d_scene_local, (void**)&c->d_scene_attr,
-                         (void**)&c->d_scene_xf, (void**)&c->d_vis, (void**)&c->d_vis_term, (void**)&c->d_scene_static};
+                         (void**)&c->d_scene_xf, (void**)&c->d_vis, (void**)&c->d_vis_term, (void**)&c->d_scene_static, (void**)&c->d_scene_spheres};
         for (void** p : ptrs) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;

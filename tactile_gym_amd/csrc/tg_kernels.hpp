@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void k_oracle_obs(const DevRobot<T>* __restrict
 struct SceneView { double R[9], t[3]; };   // world -> eye
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_scene_xf(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st, SceneView view,
-                                                 const uint8_t* __restrict__ mask, float* __restrict__ xf) {
+                                                 const uint8_t* __restrict__ mask, float* __restrict__ xf, float* __restrict__ spheres, int n_spheres) {
     constexpr int N = Topo<TOPO>::N;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
@@ -430,6 +430,51 @@ __global__ __launch_bounds__(64) void k_scene_xf(const DevRobot<T>* __restrict__
         for (int e = 0; e < 3; ++e) p[e] = st.body_pos[e * n + env];
     }
     put(N + 1, R, p);
+    // The env's translucent visuals (tg_scene.h: SceneParams::spheres): the goal indicator `sphere_indicator.urdf` (radius 0.01, rgba 1 0 0 0.5)
+    // at goal_pos_worldframe (edge_follow_env.py:230-234, 281-283; base_surface_env.py:395-400, 576), object_push's trajectory markers
+    // (object_push_env.py:239-250, 281-282 green; 360-366 current target blue, reached ones red), object_roll's goal (its marble URDF, radius
+    // 0.0025, painted 1 0 0 0.5: object_roll_env.py:174, 258-284, base_object_env.py:72-75).  Centres: world (double) -> eye, rounded once.
+    // Slot 0 is the robot's own translucent visual, loaded before the task's: the TCP marker of every arm URDF (tcp_link: <sphere radius="0.001">,
+    // material TransparentRed = rgba 0.9 0 0.2 0.5, e.g. ur5_with_standard_tactip.urdf:25, 335-343) - a tenth of a pixel at these cameras.
+    if (spheres == nullptr || n_spheres <= 0) return;
+    float* S = spheres + (size_t)env * n_spheres * 8;
+    auto put_sphere = [&](int k, const double (&w)[3], float rad, float cr, float cg, float cb) {
+        for (int r = 0; r < 3; ++r) S[8 * k + r] = (float)(view.R[3 * r + 0] * w[0] + view.R[3 * r + 1] * w[1] + view.R[3 * r + 2] * w[2] + view.t[r]);
+        S[8 * k + 3] = rad; S[8 * k + 4] = cr; S[8 * k + 5] = cg; S[8 * k + 6] = cb; S[8 * k + 7] = 0.5f;
+    };
+    V3<T> ptcp; M3<T> Rtcp;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    {
+        const double g[3] = {(double)ptcp.x, (double)ptcp.y, (double)ptcp.z};
+        put_sphere(0, g, 0.001f, 229.5f, 0.0f, 51.0f);
+    }
+    S += 8;                                   // the task's visuals follow
+    n_spheres -= 1;
+    if (c.env_kind == TG_ENV_EDGE_FOLLOW) {
+        const double se = st.edge_sc[0 * n + env], ce = st.edge_sc[1 * n + env];
+        const double g[3] = {(double)c.stim_pos[0] + (double)c.edge_len * ce, (double)c.stim_pos[1] + (double)c.edge_len * se, (double)c.stim_pos[2] + (double)c.edge_height};
+        put_sphere(0, g, 0.01f, 255.0f, 0.0f, 0.0f);
+    } else if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        const double g[3] = {st.goal[0 * n + env], st.goal[1 * n + env], st.goal[2 * n + env]};
+        put_sphere(0, g, 0.01f, 255.0f, 0.0f, 0.0f);
+    } else if (c.env_kind == TG_ENV_OBJECT_PUSH) {
+        const int gid = st.goal_id[env];
+        for (int i = 0; i < n_spheres; ++i) {
+            if (i >= c.traj_n) { S[8 * i + 7] = 0.0f; continue; }
+            // workframe_to_worldframe of (x, y, 0) (object_push_env.py:276-281)
+            const double wx = st.traj[(0 * TG_MAX_TRAJ_POINTS + i) * n + env], wy = st.traj[(1 * TG_MAX_TRAJ_POINTS + i) * n + env];
+            double g[3];
+            for (int r = 0; r < 3; ++r) g[r] = (double)c.work_pos[r] + ((double)c.work_R.m[3 * r + 0] * wx + (double)c.work_R.m[3 * r + 1] * wy);
+            put_sphere(i, g, 0.01f, i < gid ? 255.0f : 0.0f, i > gid ? 255.0f : 0.0f, i == gid ? 255.0f : 0.0f);
+        }
+    } else if (c.env_kind == TG_ENV_OBJECT_ROLL) {
+        const M3<T> Rq = mat_from_quat(quat_from_mat(Rtcp));                     // multiplyTransforms(tcp pose, goal_pos_tcp) goes through the quaternion
+        const V3<T> gw = ptcp + mul(Rq, mk((T)st.goal[0 * n + env], (T)st.goal[1 * n + env], (T)st.goal[2 * n + env]));
+        const double g[3] = {(double)gw.x, (double)gw.y, (double)gw.z};
+        put_sphere(0, g, 0.0025f, 255.0f, 0.0f, 0.0f);
+    } else {
+        for (int i = 0; i < n_spheres; ++i) S[8 * i + 7] = 0.0f;
+    }
 }
 
 // scale_actions (base_tactile_env.py:141-164): clip to [min_action, max_action], affine map to the physical range per dimension

@@ -35,6 +35,13 @@ struct SceneParams {
     int hf_rows, hf_cols;
     float hf_scale;
     uint32_t hf_rgb;               // r << 16 | g << 8 | b
+    // Translucent spheres blended over the finished image (goal indicators, trajectory markers; PARITY_ASSUMPTIONS A33b): device
+    // [n_envs][n_spheres][8] floats = centre in eye space (3), radius, r, g, b (0..255), alpha (0: slot unused); written per env by k_scene_xf.
+    // Per pixel centre and sphere, in list order: the ray's near intersection at eye depth w counts when near <= w <= far and 1 / w is
+    // strictly above the opaque key's 1 / w; shaded like a triangle (0.6 + 0.35 max(0, n . l)) and blended
+    // out = (uint8)(alpha src + (1 - alpha) dst + 0.5); no depth write, no test between translucent fragments (oracle: mb_blend_spheres).
+    const float* spheres;
+    int n_spheres;
 };
 
 SceneParams make_scene_params(int W, int H, double fov_deg, double near_, double far_);

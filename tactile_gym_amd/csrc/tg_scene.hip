@@ -37,6 +37,7 @@ constexpr int kMaxChunks = 8192;   // visible-chunk list in LDS (u16 entries, si
 constexpr int kWaveQ = 256;        // per wavefront: two queues (boxes of <= kSmallArea pixels / larger) of triangles that passed the shared-vertex tests,
                                    // each < 64 carried over + <= 64 new
 constexpr int kSmallArea = 4;
+constexpr int kMaxSpheres = 16;   // translucent spheres per env (SceneParams::spheres): object_push's trajectory markers are the most (<= TG_MAX_TRAJ_POINTS)
 
 #ifdef TG_SCENE_STATS
 __device__ unsigned long long g_stats[24];   // 0 workgroups, 1 visible chunks, 2 queued survivors, 3 set-ups that drew, 4 big, 5 huge, 6 big pixels, 7 huge pixels
@@ -342,12 +343,47 @@ __global__ __launch_bounds__(kThreads) void k_scene(SceneParams P, const float* 
         for (int p = tid; p < tw * th; p += kThreads) static_out[(size_t)blockIdx.x * tw * th + p] = zb[p];
         return;
     }
+    const int ns = P.spheres != nullptr ? (P.n_spheres < kMaxSpheres ? P.n_spheres : kMaxSpheres) : 0;
+    float* ssp = reinterpret_cast<float*>(big);                     // the queues are done with: this env's spheres take their place
+    if (ns > 0) {
+        for (int p = tid; p < ns * 8; p += kThreads) ssp[p] = P.spheres[((size_t)env * P.n_spheres) * 8 + p];
+        __syncthreads();
+    }
     for (int p = tid; p < tw * th; p += kThreads) {
         const unsigned long long k = zb[p];
-        const size_t o = ((size_t)(ty0 + p / tw) * P.W + (tx0 + p % tw)) * 3;
-        img[o + 0] = k ? (uint8_t)(k >> 16) : P.background[0];
-        img[o + 1] = k ? (uint8_t)(k >> 8) : P.background[1];
-        img[o + 2] = k ? (uint8_t)k : P.background[2];
+        const int px = tx0 + p % tw, py = ty0 + p / tw;
+        const size_t o = ((size_t)py * P.W + px) * 3;
+        uint32_t c0 = k ? (uint32_t)((k >> 16) & 255u) : P.background[0], c1 = k ? (uint32_t)((k >> 8) & 255u) : P.background[1], c2 = k ? (uint32_t)(k & 255u) : P.background[2];
+        if (ns > 0) {                                               // translucent spheres, in list order (tg_scene.h; oracle: mb_blend_spheres)
+            const float iw_o = k ? __uint_as_float((uint32_t)(k >> 32)) : 0.0f;
+            const float dx = (((float)px + 0.5f) - P.hw) / P.kx, dy = (P.hh - ((float)py + 0.5f)) / P.ky;
+            const float A = (dx * dx + dy * dy) + 1.0f;
+            for (int s = 0; s < ns; ++s) {
+                const float* S = ssp + 8 * s;
+                const float alpha = S[7];
+                if (!(alpha > 0.0f)) continue;
+                const float cx = S[0], cy = S[1], cz = S[2], r = S[3];
+                const float B = (dx * cx + dy * cy) - cz;
+                const float Cc = ((cx * cx + cy * cy) + cz * cz) - r * r;
+                const float disc = B * B - A * Cc;
+                if (!(disc >= 0.0f)) continue;
+                const float w = (B - sqrtf(disc)) / A;
+                if (!(w >= P.near_ && w <= P.far_)) continue;
+                const float iw = 1.0f / w;
+                if (!(iw > iw_o)) continue;
+                const float nx = (w * dx - cx) / r, ny = (w * dy - cy) / r, nz = (-w - cz) / r;
+                float ndl = (nx * P.light_eye[0] + ny * P.light_eye[1]) + nz * P.light_eye[2];
+                if (!(ndl > 0.0f)) ndl = 0.0f;
+                const float inten = 0.6f + 0.35f * ndl;
+                const float s0 = (float)(uint32_t)(S[4] * inten + 0.5f), s1 = (float)(uint32_t)(S[5] * inten + 0.5f), s2 = (float)(uint32_t)(S[6] * inten + 0.5f);
+                c0 = (uint32_t)((alpha * s0 + (1.0f - alpha) * (float)c0) + 0.5f) & 255u;
+                c1 = (uint32_t)((alpha * s1 + (1.0f - alpha) * (float)c1) + 0.5f) & 255u;
+                c2 = (uint32_t)((alpha * s2 + (1.0f - alpha) * (float)c2) + 0.5f) & 255u;
+            }
+        }
+        img[o + 0] = (uint8_t)c0;
+        img[o + 1] = (uint8_t)c1;
+        img[o + 2] = (uint8_t)c2;
     }
 }
 

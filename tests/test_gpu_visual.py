@@ -11,8 +11,40 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _spheres(env, st, i):
+    """The env's translucent visuals from the device state, restated from the reference (what oracle/ref_env.py scene_spheres() lists for
+    its own state): [(world centre, radius, rgb, alpha)]."""
+    from tactile_gym_amd import _capi as capi
+    from tactile_gym_amd import pb_math as pbm
+    kind, cfg = env._cfg.env_kind, env._cfg
+    red = (255.0, 0.0, 0.0)
+    return [(st["tcp_pos"][i], 0.001, (229.5, 0.0, 51.0), 0.5)] + _task_spheres(env, st, i, kind, cfg, red)     # slot 0: the arm's TCP marker
+
+
+def _task_spheres(env, st, i, kind, cfg, red):
+    from tactile_gym_amd import _capi as capi
+    from tactile_gym_amd import pb_math as pbm
+    if kind == capi.ENV_EDGE_FOLLOW:                      # edge_follow_env.py:268-283: the edge's far end, at edge height
+        a = st["edge_ang"][i]
+        return [(np.array([cfg.stim_pos[0] + cfg.edge_len * np.cos(a), cfg.stim_pos[1] + cfg.edge_len * np.sin(a), cfg.stim_pos[2] + cfg.edge_height]), 0.01, red, 0.5)]
+    if kind == capi.ENV_SURFACE_FOLLOW_AUTO:              # base_surface_env.py:560-576
+        return [(st["goal_pos"][i], 0.01, red, 0.5)]
+    if kind == capi.ENV_OBJECT_PUSH:                      # object_push_env.py:239-250, 276-282, 345-366
+        wp = np.array([cfg.workframe_pos[k] for k in range(3)])
+        wR = pbm.mat_from_quat(pbm.quat_from_euler(np.array([cfg.workframe_rpy[k] for k in range(3)])))
+        gid, out = int(st["goal_id"][i]), []
+        for k in range(cfg.traj_n_points):
+            rgb = (0.0, 0.0, 255.0) if k == gid else (red if k < gid else (0.0, 255.0, 0.0))
+            out.append((wp + wR @ np.array([st["traj"][i][0, k], st["traj"][i][1, k], 0.0]), 0.01, rgb, 0.5))
+        return out
+    if kind == capi.ENV_OBJECT_ROLL:                      # object_roll_env.py:258-284: the goal rides in the TCP frame
+        R = pbm.mat_from_quat(pbm.quat_from_euler(st["tcp_rpy"][i]))
+        return [(st["tcp_pos"][i] + R @ st["goal_pos"][i], 0.0025, red, 0.5)]
+    return []                                             # object_balance: visualise_goal = False
+
+
 def _oracle_images(env, envs):
-    """mb_render_scene for the listed envs of a TactileVecEnv at its current device state."""
+    """mb_render_scene (+ mb_blend_spheres) for the listed envs of a TactileVecEnv at its current device state."""
     from oracle import minibullet as mb
     from tactile_gym_amd import _capi as capi
     from tactile_gym_amd.robot_model import BACKGROUND, LIGHT_DIR, load_tgmodel
@@ -34,7 +66,8 @@ def _oracle_images(env, envs):
             verts = np.concatenate([sc.verts, hv]); tris = np.concatenate([sc.tris, ht + len(sc.verts)])
             tf = np.concatenate([sc.tri_frame, np.full(len(ht), len(frames) - 1, np.uint8)])
             rgb = np.concatenate([sc.tri_rgb, np.tile(np.array([0, 0, 255], np.uint8), (len(ht), 1))])
-            out.append(mb.render_scene(verts, tris, tf, rgb, frames, view, LIGHT_DIR, cam[4], cam[5], cam[6], env.W, env.H, BACKGROUND))
+            out.append(mb.render_scene(verts, tris, tf, rgb, frames, view, LIGHT_DIR, cam[4], cam[5], cam[6], env.W, env.H, BACKGROUND,
+                                       spheres=_spheres(env, st, i)))
             continue
         if kind == capi.ENV_EDGE_FOLLOW:
             a = st["edge_ang"][i]
@@ -43,7 +76,8 @@ def _oracle_images(env, envs):
         else:
             scale = st["obj_mass"][i] / env._cfg.roll_radius if kind == capi.ENV_OBJECT_ROLL else 1.0
             frames.append((st["body_rot"][i] * scale, st["body_pos"][i]))
-        out.append(mb.render_scene(sc.verts, sc.tris, sc.tri_frame, sc.tri_rgb, frames, view, LIGHT_DIR, cam[4], cam[5], cam[6], env.W, env.H, BACKGROUND))
+        out.append(mb.render_scene(sc.verts, sc.tris, sc.tri_frame, sc.tri_rgb, frames, view, LIGHT_DIR, cam[4], cam[5], cam[6], env.W, env.H, BACKGROUND,
+                                   spheres=_spheres(env, st, i)))
     return np.stack(out)
 
 
@@ -82,6 +116,14 @@ def test_visual_observation_bit_exact(env_id, arm, sensor, size, mode):
             assert (term != prev).any() and (term != prev).mean() < 0.2
     frames = env.get_images()
     assert frames[0].shape == (size, 2 * size, 3) and np.array_equal(frames[0][:, :size], obs["visual"][0])
+    # the translucent visuals are really in the picture: without them the oracle's image differs (except object_balance, which has none)
+    from oracle import minibullet as mb
+    keep, mb.lib().mb_blend_spheres = mb.lib().mb_blend_spheres, (lambda *a: None)
+    try:
+        bare = _oracle_images(env, range(n))
+    finally:
+        mb.lib().mb_blend_spheres = keep
+    assert (bare != obs["visual"]).any() or env_id == "object_balance-v0", env_id       # (balance: only the TCP marker, 0.1 - 0.2 pixels across)
     env.close()
 
 

@@ -148,3 +148,83 @@ def test_oracle_env_visual_observation(edge_modes):
     assert wood.mean() > 0.4
     o2, _, _, _ = e.step(np.array([0.25, 0.25], np.float32))
     assert (o2["visual"] != img).any()
+
+
+def _blend(spheres, cam=CAM, n=128, tri=None):
+    """A scene that is empty (or one big opaque triangle) plus translucent spheres."""
+    if tri is None:
+        verts, tris = np.zeros((3, 3)), np.zeros((0, 3), np.int32)
+    else:
+        verts, tris = np.asarray(tri, dtype=np.float64), np.array([[0, 1, 2]], np.int32)
+    return mb.render_scene(verts, tris, np.zeros(len(tris), np.uint8), np.tile(np.array([[0, 0, 255]], np.uint8), (len(tris), 1)), [(np.eye(3), np.zeros(3))],
+                           mb.scene_view_matrix(*cam[:4]), (-50.0, 30.0, 100.0), cam[4], cam[5], cam[6], n, n, (10, 20, 30), spheres=spheres)
+
+
+def test_translucent_spheres_known_answers():
+    """mb_blend_spheres (goal indicators / trajectory markers, PARITY A33b) against first principles: where the disc lands and how big it
+    is (pinhole projection), the blend rule out = u8(alpha src + (1 - alpha) dst + 0.5) with src inside the shading range, occlusion by an
+    opaque surface in front, visibility in front of one behind, and list-order blending of two overlapping spheres."""
+    n, c, r = 128, np.asarray(CAM[0]) + [0.0, 0.02, 0.03], 0.02
+    img = _blend([(c, r, (255.0, 0.0, 0.0), 0.5)])
+    hit = (img != np.array([10, 20, 30])).any(axis=2)
+    col, row = _project(CAM, c, n, n)
+    ys, xs = np.nonzero(hit)
+    assert abs(xs.mean() + 0.5 - col) < 0.6 and abs(ys.mean() + 0.5 - row) < 0.6                # the disc's centre of mass
+    eye, fwd = _eye(CAM)
+    f = (n / 2.0) / math.tan(math.radians(CAM[4]) / 2.0)
+    r_px = f * r / ((c - eye) @ fwd)
+    assert abs(hit.sum() - math.pi * r_px ** 2) < 0.12 * math.pi * r_px ** 2 + 8             # its area (perspective stretches it a little)
+    px = img[int(row), int(col)].astype(float)
+    # red channel: half of a shaded 255 (0.6 .. 0.95 of it) + half of the background; green / blue: half of the background, rounded
+    assert 0.5 * 0.6 * 255 + 5 - 1 <= px[0] <= 0.5 * 0.95 * 255 + 5 + 1 and px[1] == 10 and px[2] == 15
+    # an opaque triangle in front of the sphere hides it; behind the sphere it shows through at half weight
+    eye_to_c = (c - eye) / np.linalg.norm(c - eye)
+    right = np.cross(eye_to_c, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right)
+    up = np.cross(right, eye_to_c)
+
+    def wall(dist):
+        o = eye + dist * eye_to_c
+        return [o - 2 * right - 2 * up, o + 2 * right - 2 * up, o + 3 * up]
+    front, back = _blend([(c, r, (255.0, 0.0, 0.0), 0.5)], tri=wall(0.3)), _blend([(c, r, (255.0, 0.0, 0.0), 0.5)], tri=wall(1.2))
+    assert np.array_equal(front, _blend([], tri=wall(0.3)))                                       # nothing of the sphere in front of the wall's pixels
+    wall_only = _blend([], tri=wall(1.2))
+    d = (back != wall_only).any(axis=2)
+    assert d.sum() == hit.sum() and np.array_equal(d, hit)                                        # the same disc, now over the wall
+    b = back[int(row), int(col)].astype(float); w0 = wall_only[int(row), int(col)].astype(float)
+    assert b[1] == 0 and abs(b[2] - math.floor(0.5 * w0[2] + 0.5)) <= 0 and b[0] == px[0] - 5     # blue wall at half weight under the same red
+    # two spheres, one behind the other along the ray: both blend (no depth between translucent fragments), the later one on top
+    c2 = c + 0.05 * eye_to_c
+    ab = _blend([(c, r, (255.0, 0.0, 0.0), 0.5), (c2, r, (0.0, 255.0, 0.0), 0.5)])
+    ba = _blend([(c2, r, (0.0, 255.0, 0.0), 0.5), (c, r, (255.0, 0.0, 0.0), 0.5)])
+    pa, pb = ab[int(row), int(col)].astype(int), ba[int(row), int(col)].astype(int)
+    assert pa[1] > pa[0] and pb[0] > pb[1] and not np.array_equal(ab, ba)
+    # alpha 0 slots are ignored
+    assert np.array_equal(_blend([(c, r, (255.0, 0.0, 0.0), 0.0)]), _blend([]))
+
+
+def test_oracle_envs_draw_their_goal_markers():
+    """Every task env lists its translucent visuals from the reference's own code paths (scene_spheres): edge / surface / roll one goal
+    sphere, object_push ten trajectory markers with the current target blue, object_balance none - and they change the picture."""
+    import warnings
+    from oracle import ref_env
+    warnings.simplefilter("ignore")
+    base = dict(control_mode="TCP_velocity_control", observation_mode="visuotactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+    cases = [("OracleEdgeFollowEnv", dict(base, movement_mode="xy", noise_mode="rand_height"), 1),
+             ("OracleSurfaceFollowAutoEnv", dict(base, movement_mode="xyzRxRy", noise_mode="simplex"), 1),
+             ("OracleObjectPushEnv", dict(base, movement_mode="TyRz", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex", observation_mode="tactile_and_feature"), 10),
+             ("OracleObjectRollEnv", dict(base, movement_mode="xy", rand_init_obj_pos=True, rand_obj_size=True, rand_embed_dist=True, observation_mode="tactile_and_feature"), 1),
+             ("OracleObjectBalanceEnv", dict(base, movement_mode="xy", object_mode="pole", rand_gravity=True, rand_embed_dist=True, observation_mode="tactile"), 0)]
+    for cls, modes, count in cases:
+        o = getattr(ref_env, cls)(seed=3, image_size=(128, 128), env_modes=modes)
+        o.reset()
+        sp = o.scene_spheres()
+        assert len(sp) == count + 1 and sp[0][1] == 0.001 and sp[0][2] == (229.5, 0.0, 51.0), cls      # slot 0: the arm's TCP marker
+        sp = sp[1:]
+        if cls == "OracleObjectPushEnv":
+            g = o.targ_traj_list_id            # the current target blue, the ones already passed red, the rest green (object_push_env.py:281-282, 360-366)
+            assert [s[2] for s in sp] == [(255.0, 0.0, 0.0)] * g + [(0.0, 0.0, 255.0)] + [(0.0, 255.0, 0.0)] * (9 - g)
+        if o.scene_camera() is None:          # the object envs' scene cameras live with the product (rl_envs/*.py scene_spec); tests/test_gpu_visual.py draws them
+            continue
+        with_markers = o.visual_image()
+        o.scene_spheres = lambda: []
+        assert (with_markers != o.visual_image()).any(), cls

@@ -669,6 +669,17 @@ static bool use_contact_wave(const tg_ctx* c) {
     return c->cfg.num_envs < 4096;
 }
 
+// Contact-free arm tasks on the wave mapping (k_step_arm_wave: every tick a full tick on the env's own wavefront).  Measured on an MI355X at
+// 1024 envs it does NOT beat the lane mapping: UR5 literal solver k_step 0.886 ms against 0.512 ms, MG400 (surface_follow-v2) 1.05 ms against
+// ~0.95 ms - a wave64 instruction costs its 4 cycles whether 6 or 64 lanes do useful work, so the 150 sweeps (~190 issue cycles each on the
+// wave mapping, 144 for 64 envs on the lane mapping) and the dynamics are a wash between 1024 half-empty wavefronts and 16 full ones
+// (DESIGN.md 4.1g).  Kept for TG_CONTACT_MAP_WAVE only; AUTO stays on the lane mapping.
+static bool use_arm_wave(const tg_ctx* c) {
+    if (c->cfg.env_kind != TG_ENV_EDGE_FOLLOW && c->cfg.env_kind != TG_ENV_SURFACE_FOLLOW_AUTO) return false;
+    if (c->cfg.physics_dtype != TG_PHYSICS_F64 || c->cfg.control_mode != TG_CONTROL_TCP_VELOCITY) return false;
+    return c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE;
+}
+
 static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
     Timer t(c, 2);
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
@@ -1036,6 +1047,9 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
 #define CALL(T, TOPO) launch_step_push_t<T, TOPO>(c, d_act)
             TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
+        } else if (use_arm_wave(c) && launch_step_arm_wave(c->cfg.physics_dtype, c->robot.topology, c->cfg.control_mode, c->cfg.num_envs, c->stream, c->d_robot,
+                                                           c->d_const, c->st, d_act) == 0) {
+            // edge_follow / surface_follow with one wavefront per env (tg_contact_wave.hip: k_step_arm_wave)
         } else {
 #define CALL(T, TOPO) launch_step_t<T, TOPO>(c, d_act)
             TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);

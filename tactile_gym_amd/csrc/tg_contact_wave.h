@@ -18,6 +18,10 @@ int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int 
 // analytic fixed point, full ticks on the wave mapping).  -1: not instantiated.
 int launch_step_body_wave(int physics_dtype, int topology, int control_mode, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const,
                           const State& st, const float* d_actions);
+// edge_follow / surface_follow (contact-free arm, TCP_velocity_control, f64; UR5 and MG400): one wavefront per env, every tick a full tick
+// (lane-parallel dynamics, the motor pass as a linear map).  -1: not instantiated.
+int launch_step_arm_wave(int physics_dtype, int topology, int control_mode, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const,
+                         const State& st, const float* d_actions);
 // env.reset() for the envs flagged in d_mask (nullptr: all) with the same mapping: one wavefront per resetting env, the others exit at once.
 int launch_reset_contact_wave(int env_kind, int physics_dtype, int topology, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
                               const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask);

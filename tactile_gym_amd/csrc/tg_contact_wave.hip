@@ -1380,6 +1380,225 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     finish_body<T, TOPO>(m, c, st, env, q, b, embed, step_count, true);
 }
 
+// ---- contact-free arms (edge_follow, surface_follow): the full tick on one wavefront -------------------------------------------------------
+// The lane-per-env k_step runs a full tick - articulated-body dynamics + up to 150 Gauss-Seidel sweeps over the N joint motors - as one
+// scalar program per lane: 1024 envs are 16 wavefronts on a chip with 1024 SIMDs.  Here the env has its own wavefront: tick_dynamics_lanes
+// for the arm, one motor row per lane (lane i < N), a whole forward or reverse Gauss-Seidel pass as ONE linear map of the row lanes'
+// residuals (x -= sum_m C_m x_m, C built once per tick; no motor row has a limit in reach, watched on lanes 48.. with the literal clamped
+// iteration as the fallback), accumulator lanes 32 + k for the velocity change.  Same row order, same convergence exit (every 8 sweeps:
+// all residuals below 2^-56 of the largest start value) and same licence rule as sim_tick; returns the new `verified` (24: converged
+// within 80 % of the sweep budget).  State in / out through LDS (q, qd, sines / cosines).
+// MEASURED (MI355X, 1024 envs): slower than the lane mapping - UR5 literal k_step 0.886 ms against 0.512 ms, MG400 1.05 against ~0.95 ms: a
+// wave64 instruction costs its 4 issue cycles whether 6 or 64 lanes do useful work, so a sweep is ~190 cycles for one env here and 144 for
+// 64 envs there, and 1024 mostly idle wavefronts on 1024 SIMDs are no faster than 16 full ones.  Selected by TG_CONTACT_MAP_WAVE only.
+template <typename T, int TOPO, int MOTOR>
+__device__ __forceinline__ int sim_tick_arm_wave(const DevRobot<T>& m, lds_ptr<T> L, T kp, T kd, T max_force, T dt, int iters, int lane_in) {
+    constexpr int N = Topo<TOPO>::N;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+#if TG_WAVE_TIMING
+    unsigned long long t_prev_ = __builtin_readcyclecounter();
+    tick_dynamics_lanes<T, TOPO>(&m, L, m.tcp_link, dt, lane, t_prev_);
+#else
+    tick_dynamics_lanes<T, TOPO>(&m, L, m.tcp_link, dt, lane);
+#endif
+    TG_PHASE_FENCE()
+    // ---- this lane's row: J = e_lane, W = Minv e_lane (column `lane` of Minv), A = Minv[lane][lane]
+    const bool motor_lane = lane < N;
+    const int col = motor_lane ? lane : 0;
+    T Warm[N], rm = T(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        Warm[k] = motor_lane ? L[kLMinv + 8 * k + col] : T(0);
+        const T vk = L[kLV + k];
+        const T pos_term = (MOTOR == kMotorPosition) ? kp * (L[kLQDes + k] - L[kLQ + k]) / dt : T(0);
+        const T des = pos_term + vk + kd * (L[kLQdDes + k] - vk);
+        rm = lane == k ? des - vk : rm;
+    }
+    T A = T(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) A = lane == k ? Warm[k] : A;
+    const bool active = motor_lane && MOTOR != kMotorOff;
+    const T jdi = active ? T(1) / A : T(0);
+    // coefficient rows: row lanes G[i] = W_mine[i] / A (own entry 1: the lane carries its residual), lanes 32 + k accumulate du_k = sum_i
+    // Minv[k][i] lambda_i, lanes 48 + j the impulse of motor j
+    T G[N];
+    {
+        const int ku = lane - 32;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const T wv = L[kLMinv + 8 * (ku >= 0 && ku < N ? ku : 0) + i];
+            const T g_row = lane == i ? T(1) : Warm[i] * jdi;
+            G[i] = (ku >= 0 && ku < N) ? (MOTOR != kMotorOff ? -wv : T(0))
+                                       : ((lane >= 48 && lane < 48 + N) ? (i == lane - 48 ? T(-1) : T(0)) : (motor_lane ? g_row : T(0)));
+        }
+    }
+    // ---- one Gauss-Seidel pass over the N rows as a linear map of the row lanes' residuals, forward and reverse order (as in
+    //      sim_tick_contact_wave's motor pass)
+    T Cf[N], Cr[N];
+    {
+        __syncthreads();
+        if (motor_lane) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) L[kLW + lane * 16 + k] = G[k];     // L[i][k] = G_k on the lane of row i
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < N; ++mm) {
+            T t[N];
+            t[mm] = T(1);
+            T c = G[mm];
+#pragma unroll
+            for (int i = mm + 1; i < N; ++i) {
+                T acc = T(0);
+#pragma unroll
+                for (int k = mm; k < i; ++k) acc = __builtin_fma(L[kLW + i * 16 + k], t[k], acc);
+                t[i] = -acc;
+                c = __builtin_fma(G[i], t[i], c);
+            }
+            Cf[mm] = c;
+        }
+#pragma unroll
+        for (int mm = 0; mm < N; ++mm) {
+            T t[N];
+            t[mm] = T(1);
+            T c = G[mm];
+#pragma unroll
+            for (int i = mm - 1; i >= 0; --i) {
+                T acc = T(0);
+#pragma unroll
+                for (int k = i + 1; k <= mm; ++k) acc = __builtin_fma(L[kLW + i * 16 + k], t[k], acc);
+                t[i] = -acc;
+                c = __builtin_fma(G[i], t[i], c);
+            }
+            Cr[mm] = c;
+        }
+    }
+    const T x0 = active ? rm * jdi : T(0);
+    T thr = tabs(x0);
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) thr = tmax(thr, __shfl_xor(thr, o));      // rows live in lanes 0..7
+    thr = bcast(thr, 0);
+    thr = iters < 0 ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
+    const int n_it = iters < 0 ? -iters : iters;
+    const T lim = max_force * dt;
+    const bool watch_lane = lane >= 48 && lane < 48 + N;
+    T x = x0, wmax = T(0);
+    int conv_sweeps = -1;
+    for (int it = 0; it < n_it; ++it) {
+        if ((it & 7) == 0 && it > 0) {
+            T mx = motor_lane ? tabs(x) : T(0);
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) mx = tmax(mx, __shfl_xor(mx, o));
+            if (uniform_true(bcast(mx, 0) <= thr)) { conv_sweeps = it; break; }
+        }
+        T xm[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) xm[k] = bcast(x, k);
+        T da = T(0), db = T(0);
+        if (it & 1) {
+#pragma unroll
+            for (int k = 0; k < N; k += 2) { da = __builtin_fma(Cf[k], xm[k], da); if (k + 1 < N) db = __builtin_fma(Cf[k + 1], xm[k + 1], db); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; k += 2) { da = __builtin_fma(Cr[k], xm[k], da); if (k + 1 < N) db = __builtin_fma(Cr[k + 1], xm[k + 1], db); }
+        }
+        x -= da + db;
+        wmax = vmax_abs(wmax, x);
+    }
+    if (uniform_true(watch_lane && wmax > lim)) {
+        // a motor impulse reached its bound: the literal clamped iteration, row by row
+        x = x0;
+        T lam = T(0);
+        conv_sweeps = -1;
+        for (int it = 0; it < n_it; ++it) {
+#pragma unroll
+            for (int kk = 0; kk < N; ++kk) {
+                const int i = (it & 1) ? kk : N - 1 - kk;
+                const T dd = bcast(vmin(vmax(x, -lim - lam), lim - lam), i);
+                lam = lane == i ? lam + dd : lam;
+                x = __builtin_fma(-G[i], dd, x);
+            }
+        }
+    }
+    // ---- integrate
+    T du[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) du[k] = bcast(x, 32 + k);
+    {
+        T q[N], qd[N];
+        JointTrig<T, N> trig;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            qd[i] = L[kLV + i] + du[i];
+            q[i] = L[kLQ + i] + dt * qd[i];
+        }
+        trig_init<T, N>(q, trig);                         // every full tick re-anchors the carried sines / cosines exactly
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { L[kLQ + i] = q[i]; L[kLQd + i] = qd[i]; L[kLTrigS + i] = trig.s[i]; L[kLTrigC + i] = trig.c[i]; }
+        }
+    }
+    TG_PHASE_FENCE()
+    return (iters > 0 && conv_sweeps > 0 && 5 * conv_sweeps <= 4 * iters) ? 24 : 0;
+}
+
+// BaseTactileEnv.step of the contact-free arm tasks (TCP_velocity_control), one wavefront per env: prologue and epilogue as k_step
+// (tg_kernels.hpp; evaluated by every lane alike), every one of the action_repeat ticks a full tick on the wave mapping.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step_arm_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                      const float* __restrict__ actions) {
+    constexpr int N = Topo<TOPO>::N;
+    extern __shared__ double wave_lds_raw[];
+    const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
+    const DevRobot<T>& m = *mp;
+    const EnvConst<T>& c = *cp;
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const int n = c.num_envs;
+    const bool w0 = lane == 0;
+    T q[N], qd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
+    T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    encode_arm_actions<T>(c, st, env, actions + (size_t)env * c.act_dim, enc);
+    T vels[6];
+    scale_actions<T>(c, enc, vels);
+    const int step_count = st.step_count[env] + 1;
+    JointTrig<T, N> trig;
+    trig_init<T, N>(q, trig);
+    T qd_des[N];
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, &trig);
+    stage_link_constants<T, TOPO>(mp, L, lane);
+    __syncthreads();
+    if (w0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool in = i < N;
+            L[kLQ + i] = in ? q[in ? i : 0] : T(0); L[kLQd + i] = in ? qd[in ? i : 0] : T(0);
+            L[kLTrigS + i] = in ? trig.s[in ? i : 0] : T(0); L[kLTrigC + i] = in ? trig.c[in ? i : 0] : T(1);
+            L[kLQDes + i] = T(0); L[kLQdDes + i] = in ? qd_des[in ? i : 0] : T(0);
+        }
+    }
+    TG_PHASE_FENCE()
+    int verified = 0;
+    for (int t = 0; t < c.action_repeat; ++t)
+        verified = sim_tick_arm_wave<T, TOPO, kMotorVelocity>(m, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, lane);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; trig.s[i] = L[kLTrigS + i]; trig.c[i] = L[kLTrigC + i]; }
+    if (w0) {
+        st.step_count[env] = step_count;
+        st.licence[env] = 0;                       // this kernel solves every tick in full: nothing is carried over for k_step's shortcut
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = (double)qd_des[i];
+            st.trig_sc[i * n + env] = (double)trig.s[i]; st.trig_sc[(8 + i) * n + env] = (double)trig.c[i];
+        }
+    }
+    (void)verified;
+    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
+}
+
 // env.reset() of object_push (SHAPE 0) / object_roll (SHAPE 1) for the envs flagged in `mask`, one wavefront per resetting env (the
 // lane-per-env k_reset_push / k_reset_roll run every resetting env's blocking move at the pace of a 64-env wavefront: 0.8 ms per launch with
 // a reset in object_roll, where some env finishes on nearly every step).  Same sequence as those kernels: episode draws, rest pose,
@@ -1566,6 +1785,18 @@ int launch_step_body_wave(int physics_dtype, int topology, int control_mode, int
     if (physics_dtype != TG_PHYSICS_F64 || topology != 0 || control_mode != TG_CONTROL_TCP_VELOCITY) return -1;
     hipLaunchKernelGGL((k_step_body_wave<double, 0>), dim3(num_envs), dim3(64), (size_t)kLHull * sizeof(double), stream, (const DevRobot<double>*)d_robot,
                        (const EnvConst<double>*)d_const, st, d_actions);
+    return 0;
+}
+
+int launch_step_arm_wave(int physics_dtype, int topology, int control_mode, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const,
+                         const State& st, const float* d_actions) {
+    if (physics_dtype != TG_PHYSICS_F64 || control_mode != TG_CONTROL_TCP_VELOCITY) return -1;
+    if (topology == 0)
+        hipLaunchKernelGGL((k_step_arm_wave<double, 0>), dim3(num_envs), dim3(64), (size_t)kLHull * sizeof(double), stream, (const DevRobot<double>*)d_robot,
+                           (const EnvConst<double>*)d_const, st, d_actions);
+    else
+        hipLaunchKernelGGL((k_step_arm_wave<double, 1>), dim3(num_envs), dim3(64), (size_t)kLHull * sizeof(double), stream, (const DevRobot<double>*)d_robot,
+                           (const EnvConst<double>*)d_const, st, d_actions);
     return 0;
 }
 

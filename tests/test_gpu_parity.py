@@ -1600,3 +1600,33 @@ def test_mode_matrix_matches_oracle(env_id, overrides, act_dim, size, edge_modes
             assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd, (step, i)
             assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (step, i)
     venv.close()
+
+
+@pytest.mark.parametrize("env_id,arm,sensor,full", [("edge_follow-v0", "mg400", "tactip", False), ("edge_follow-v0", "ur5", "tactip", True),
+                                                    ("surface_follow-v2", "mg400", "tactip", False)])
+def test_arm_wave_mapping_matches_oracle(env_id, arm, sensor, full):
+    """k_step_arm_wave (contact_mapping="wave" for the contact-free arm tasks: every tick a full tick on the env's own wavefront - lane-
+    parallel dynamics, the motor pass as one linear map) against the oracle, like the lane kernel: joints 1e-9, images bit-exact, dones."""
+    import tactile_gym_amd as tg
+    from oracle import ref_env
+    from tactile_gym_amd import registry
+    cls = registry._resolve(registry.spec(env_id))
+    modes = dict(cls.default_env_modes, arm_type=arm, tactile_sensor_name=sensor, observation_mode="tactile")
+    ocls = {"edge_follow-v0": ref_env.OracleEdgeFollowEnv, "surface_follow-v2": ref_env.OracleSurfaceFollowVertEnv}[env_id]
+    n = 5
+    venv = tg.make_vec(env_id, num_envs=n, max_steps=50, image_size=[128, 128], env_modes=modes, seed=61, auto_reset=False, contact_mapping="wave",
+                       pgs_full_sweeps=full)
+    oracles = [ocls(seed=61 + i, max_steps=50, image_size=(128, 128), env_modes=modes) for i in range(n)]
+    obs = venv.reset()
+    ref = [o.reset() for o in oracles]
+    rng = np.random.default_rng(3)
+    for step in range(5):
+        a = rng.uniform(-0.25, 0.25, size=(n, venv.act_dim)).astype(np.float32)
+        obs, rew, done, _ = venv.step(a)
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            ro, rr, rd, _ = o.step(a[i])
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-9, (step, i)
+            assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
+            assert np.array_equal(obs["tactile"][i], ro["tactile"]), (step, i)
+    venv.close()

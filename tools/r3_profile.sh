@@ -1,0 +1,52 @@
+#!/bin/bash
+# Round-3 evidence run on the MI355X box (one gpurun call): the default bench line (headline + other_configs + literal + CPU baseline),
+# one bench line per env, rocprofv3 kernel stats and SQ counters of the default command and of object_push / object_balance /
+# surface_follow-v2 (MG400, wave-mapped arm kernel) / the literal solver, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of
+# edge_follow, object_push and object_balance.  Outputs under gpurun_out/<tag>/; copied to profiles/<tag>_* afterwards (tools/r3_collect.py).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${TG_PROFILE_TAG:-r3_final}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+python bench.py 2>$O/bench_edge.err | grep metric > $O/bench_edge.json
+B="python bench.py --no-cpu-baseline --no-companions"
+$B --sync-steps --no-literal 2>/dev/null | grep metric > $O/bench_edge_syncsteps.json
+$B --env surface_follow-v0 2>/dev/null | grep metric > $O/bench_surface_follow-v0.json
+$B --env surface_follow-v2 2>/dev/null | grep metric > $O/bench_surface_follow-v2.json
+$B --env object_balance-v0 --image-size 256 2>/dev/null | grep metric > $O/bench_object_balance-v0.json
+$B --env object_push-v0 --steps 200 --warmup 20 2>/dev/null | grep metric > $O/bench_object_push-v0.json
+$B --env object_roll-v0 --steps 200 --warmup 20 2>/dev/null | grep metric > $O/bench_object_roll-v0.json
+$B --no-literal --observation-mode visuotactile --steps 200 --warmup 20 2>/dev/null | grep metric > $O/bench_edge_visuotactile.json
+TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank.json
+TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport collective --payload interior 2>/dev/null | grep metric > $O/bench_edge_rccl_interior_1rank.json
+cd /tmp; export TMPDIR=/tmp
+P="python $R/bench.py --no-cpu-baseline --no-literal --no-companions"
+prof() {   # prof <name> <bench flags...>
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- $P "$@" > $O/prof_$name.log 2>&1
+    find $O/prof_$name -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$name.csv \;
+    rm -rf $O/prof_$name
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_$name -- $P "$@" --steps 10 --warmup 2 > $O/pmc_$name.log 2>&1
+    python $R/tools/pmc_parse.py $O/pmc_$name > $O/pmc_summary_$name.txt 2>&1
+    rm -rf $O/pmc_$name
+}
+traffic() {   # traffic <name> <bench flags...>
+    local name=$1; shift
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/tf_$name -- $P "$@" --steps 10 --warmup 2 > $O/tf_$name.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/tw_$name -- $P "$@" --steps 10 --warmup 2 > $O/tw_$name.log 2>&1
+    python $R/tools/traffic_parse.py $O/tf_$name $O/tw_$name > $O/traffic_$name.json 2>&1
+    rm -rf $O/tf_$name $O/tw_$name
+}
+prof edge
+prof edge_literal --full-sweeps --steps 200 --warmup 10
+prof surface_follow-v2 --env surface_follow-v2 --steps 200 --warmup 10
+prof object_push-v0 --env object_push-v0 --steps 100 --warmup 10
+prof object_balance-v0 --env object_balance-v0 --image-size 256
+traffic edge
+traffic object_push-v0 --env object_push-v0
+traffic object_balance-v0 --env object_balance-v0 --image-size 256
+traffic surface_follow-v0 --env surface_follow-v0
+rm -f $O/*.log
+head -8 $O/kernel_stats_edge.csv
+for f in $O/bench_*.json; do python -c "
+import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"; done

@@ -240,6 +240,10 @@ int tg_tiles_capacity(int32_t n_images, int32_t h, int32_t w, int64_t* bytes);
 int tg_pack_tiles(void* hip_stream, const void* obs_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev,
                   void* counters_dev);
 int tg_unpack_tiles(void* hip_stream, const void* src_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev);
+/* The same for the messages of n_ranks ranks in two launches: message r at src_dev + r * src_stride (bytes, a multiple of 16) ->
+ * dst uint8 [n_ranks][n_images][h][w]; rank skip_rank (-1: none) is left alone (rank 0 copies its own images instead of packing them). */
+int tg_unpack_tiles_multi(void* hip_stream, const void* src_dev, int64_t src_stride, int32_t n_ranks, int32_t skip_rank, const void* template_dev,
+                          int32_t n_images, int32_t h, int32_t w, void* dst_dev);
 /* Receive slots that peers store into directly (one process per GPU; the reference's counterpart is the pipe of each SubprocVecEnv worker,
  * sb3_helpers/rl_utils.py:17-30).  tg_ipc_alloc: zeroed device memory on the current device + its 64-byte IPC handle; tg_ipc_open /
  * tg_ipc_close: map / unmap it in another process (its GPU then reaches the memory over xGMI).  HSA_ENABLE_IPC_MODE_LEGACY=0 is required. */

@@ -146,6 +146,7 @@ SYMBOLS = {
     "tg_tiles_capacity": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "tg_pack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "tg_unpack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "tg_unpack_tiles_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tg_ipc_alloc": (C.c_int, [C.c_int64, _vpp, _u8p]),
     "tg_ipc_free": (C.c_int, [C.c_void_p]),
     "tg_ipc_open": (C.c_int, [_u8p, _vpp]),

@@ -106,6 +106,36 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const uint8_t* __restrict
 }
 
 // 16-byte pieces (grid stride), then the last < 16 bytes one by one: a device copy whose destination may be another GPU's memory.
+// The same two steps for the messages of several ranks in one launch each (rank 0 unpacks world - 1 messages per step; one launch per
+// message costs more than the messages' bytes): blockIdx.y = rank, messages `stride` bytes apart, rank `skip` left alone (rank 0's own
+// block is a plain copy of its images).
+__global__ __launch_bounds__(256) void k_fill_template_multi(const uint4* __restrict__ tmpl, int hw16, size_t per_rank16, int skip, uint4* __restrict__ dst) {
+    const int r = blockIdx.y;
+    if (r == skip) return;
+    uint4* __restrict__ d = dst + (size_t)r * per_rank16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_rank16; i += (size_t)gridDim.x * blockDim.x) d[i] = tmpl[i % hw16];
+}
+__global__ __launch_bounds__(256) void k_scatter_tiles_multi(const uint8_t* __restrict__ src, size_t stride, int skip, int n_img, int H, int W, int T, int TW,
+                                                            uint8_t* __restrict__ dst) {
+    const int r = blockIdx.y;
+    if (r == skip) return;
+    const uint8_t* __restrict__ s = src + (size_t)r * stride;
+    uint8_t* __restrict__ d = dst + (size_t)r * n_img * H * W;
+    const uint4 hdr = *reinterpret_cast<const uint4*>(s);
+    if (hdr.w != kTileMagic || (int)hdr.z != T) return;
+    const uint32_t cap = (uint32_t)n_img * (uint32_t)T;
+    const uint32_t count = hdr.x < cap ? hdr.x : cap;
+    const int row = threadIdx.x & 15;
+    for (uint32_t slot = blockIdx.x * 16u + (threadIdx.x >> 4); slot < count; slot += gridDim.x * 16u) {
+        const uint4* __restrict__ rec = reinterpret_cast<const uint4*>(s + 16) + (size_t)slot * kRecWords;
+        const uint32_t id = rec[0].x;
+        const int img = (int)(id / (uint32_t)T), tile = (int)(id - (uint32_t)img * (uint32_t)T);
+        if (img >= n_img) continue;
+        const int tr = tile / TW, tc = tile - tr * TW;
+        *reinterpret_cast<uint4*>(d + (size_t)img * H * W + (size_t)(tr * 16 + row) * W + (size_t)tc * 16) = rec[1 + row];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ src, size_t bytes, uint8_t* __restrict__ dst) {
     const size_t n16 = bytes / 16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
@@ -169,6 +199,24 @@ int tg_unpack_tiles(void* stream, const void* src_dev, const void* template_dev,
     if ((cap + 15) / 16 > 0x7fffffffLL) return report_error(-1, "tg_unpack_tiles: too many tiles for one launch");
     hipLaunchKernelGGL(tg::k_scatter_tiles, dim3((unsigned)((cap + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src_dev, n_images, h, w,
                        T, TW, (uint8_t*)dst_dev);
+    TGX_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_unpack_tiles_multi(void* stream, const void* src_dev, int64_t src_stride, int32_t n_ranks, int32_t skip_rank, const void* template_dev,
+                          int32_t n_images, int32_t h, int32_t w, void* dst_dev) {
+    if (!src_dev || !template_dev || !dst_dev || n_images <= 0 || n_ranks <= 0 || n_ranks > 65535 || src_stride < 16 || (src_stride & 15) || !tg::tile_geometry(h, w))
+        return report_error(-1, "tg_unpack_tiles_multi: bad argument (stride a multiple of 16, image sides multiples of 16)");
+    const int TW = w / 16, T = TW * (h / 16);
+    const int hw16 = h * w / 16;
+    const size_t per_rank16 = (size_t)n_images * hw16;
+    const unsigned fill_blocks = (unsigned)((per_rank16 + 255) / 256 < 2048 ? (per_rank16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tg::k_fill_template_multi, dim3(fill_blocks, (unsigned)n_ranks), dim3(256), 0, (hipStream_t)stream, (const uint4*)template_dev, hw16,
+                       per_rank16, skip_rank, (uint4*)dst_dev);
+    const int64_t cap = (int64_t)n_images * T;
+    const unsigned sc_blocks = (unsigned)((cap + 15) / 16 < 4096 ? (cap + 15) / 16 : 4096);     // grid stride beyond that: most messages hold a few % of the tiles
+    hipLaunchKernelGGL(tg::k_scatter_tiles_multi, dim3(sc_blocks, (unsigned)n_ranks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src_dev,
+                       (size_t)src_stride, skip_rank, n_images, h, w, T, TW, (uint8_t*)dst_dev);
     TGX_HIP(hipGetLastError());
     return 0;
 }

@@ -406,8 +406,17 @@ class ShardedVecEnv:
             if root:
                 if t > 2:                                 # the batch of message t - 2 has been consumed: its slot may be overwritten
                     ipc.set("consumed", slot, 0, self.world, t - 2)
-                self._pack_local(self._stage[slot], obs, rew, done)
-                ipc.set("ready", slot, self.root, 1, t)
+                if self.payload == "tiles" and hasattr(self.local, "unpack_tiles_multi"):
+                    # rank 0's own images are not packed and unpacked: they go straight into their block of the batch (one copy), and
+                    # only what rides behind the image part goes into its slot (where _receive reads reward / done / ... of every rank)
+                    n, hw = L["n"], L["H"] * L["W"]
+                    batch = self._batch_buffer(slot)
+                    ipc.copy(batch[self.root * n:(self.root + 1) * n].data_ptr(), obs["tactile"].reshape(-1))
+                    ipc.copy(self._stage[slot][L["off_rest"]:].data_ptr(), self._rest_tensor(obs, rew, done))
+                    if L["vis_bytes"]:
+                        ipc.copy(self._stage[slot][L["off_vis"]:].data_ptr(), obs["visual"].reshape(-1))
+                else:
+                    self._pack_local(self._stage[slot], obs, rew, done)
             else:
                 ipc.wait("consumed", slot, self.rank, 1, t - 2)
                 self._pack_remote(slot, obs, rew, done)
@@ -451,22 +460,35 @@ class ShardedVecEnv:
         for w in (work if isinstance(work, list) else [work]):
             w.wait()
 
+    def _batch_buffer(self, slot):
+        """rank 0: the uint8 [world * n, H * W] images of slot `slot` (interior / tile payloads are unpacked into it)."""
+        if self._obs_full[slot] is None:
+            L = self._lay
+            self._obs_full[slot] = self.torch.zeros((self.world * L["n"], L["H"] * L["W"]), dtype=self.torch.uint8, device=L["dev"])
+            if self.payload == "interior":
+                self._obs_full[slot].copy_(self._interior[1].reshape(1, -1).expand(self.world * L["n"], -1))
+        return self._obs_full[slot]
+
     # ------------------------------------------------------------------ rank 0: message t -> batch
     def _receive(self, t):
         torch, L = self.torch, self._lay
         slot = t & 1
-        if self.transport == "ipc":
-            self._ipc.wait("ready", slot, 0, self.world, t)      # one wave, lane r polls ready[slot][r] (rank 0 raised its own in _send)
+        if self.transport == "ipc":                           # one wave per contiguous run of peers, lane r polls ready[slot][r]
+            if self.root > 0:
+                self._ipc.wait("ready", slot, 0, self.root, t)
+            if self.root < self.world - 1:
+                self._ipc.wait("ready", slot, self.root + 1, self.world - 1 - self.root, t)
         full, n, w = self._full[slot], L["n"], self.world
         shape = L["tac_shape"]
         if self.payload == "full":
             obs = {"tactile": full[:, :L["nb_full"]].reshape((w * n,) + shape[1:])}
+        elif self.payload == "tiles" and self.transport == "ipc" and hasattr(self.local, "unpack_tiles_multi"):
+            img = self._batch_buffer(slot)                    # rank 0's own block was copied in by _send; the peers' messages in two launches
+            if w > 1:
+                self.local.unpack_tiles_multi(full.data_ptr(), L["total"], w, self.root, n, img.data_ptr())
+            obs = {"tactile": img.reshape((w * n,) + shape[1:])}
         else:
-            if self._obs_full[slot] is None:
-                self._obs_full[slot] = torch.zeros((w * n, L["H"] * L["W"]), dtype=torch.uint8, device=L["dev"])
-                if self.payload == "interior":
-                    self._obs_full[slot].copy_(self._interior[1].reshape(1, -1).expand(w * n, -1))
-            img = self._obs_full[slot]
+            img = self._batch_buffer(slot)
             for r in range(w):
                 blk = img[r * n:(r + 1) * n]
                 if self.payload == "interior":
@@ -560,6 +582,8 @@ class ShardedVecEnv:
                "full_payload_bytes": _align(L["nb_full"], 16) + L["total"] - L["off_rest"]}
         if self.payload == "tiles" and self.rank == self.root and self._handed:
             hdr = self._full[self._handed & 1][:, :4].contiguous().view(self.torch.int32).reshape(-1).cpu().tolist()
+            if self.transport == "ipc" and hasattr(self.local, "unpack_tiles_multi"):
+                hdr[self.root] = 0                        # rank 0's own images never become a message (copied straight into the batch)
             out["tile_records_last_message"] = hdr
             out["message_bytes_last"] = [16 + TILE_REC * int(c) + L["total"] - L["off_rest"] for c in hdr]
         elif self.payload != "tiles":
@@ -636,6 +660,12 @@ class TorchShard:
         v = self.venv
         capi.check(v._L.tg_pack_tiles(self._cur_stream(), C.c_void_p(v.tactile_torch().data_ptr()), C.c_void_p(self.tile_template().data_ptr()),
                                       v.num_envs, v.H, v.W, C.c_void_p(dst_ptr), C.c_void_p(counters.data_ptr())))
+
+    def unpack_tiles_multi(self, src_ptr, stride, n_ranks, skip_rank, n_images, dst_ptr):
+        """The tile messages of n_ranks ranks (`stride` bytes apart) -> their blocks of the batch, two launches; skip_rank's block is left alone."""
+        v = self.venv
+        capi.check(v._L.tg_unpack_tiles_multi(self._cur_stream(), C.c_void_p(src_ptr), stride, n_ranks, skip_rank, C.c_void_p(self.tile_template().data_ptr()),
+                                              n_images, v.H, v.W, C.c_void_p(dst_ptr)))
 
     def unpack_tiles(self, src_ptr, n_images, dst_ptr):
         v = self.venv

@@ -33,6 +33,6 @@ for name, env, size in (("edge", "edge_follow-v0", 128), ("object_push-v0", "obj
 out = {"_what": "HBM-side traffic per kernel launch from rocprofv3 PMC (separate passes: --pmc FETCH_SIZE, --pmc WRITE_SIZE, each with --kernel-trace; "
                 "tools/r3_profile.sh traffic(), parsed by tools/traffic_parse.py), 1024 envs, f64, default solver; values in KB as reported.  Per "
                 "MI355X_MICROARCH.md (HBM section) FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950: fetch_corrected_kb doubles it.",
-       "source_sha16": bench.source_hash(), "tag": tag, "workloads": workloads}
+       "source_sha16": open(os.path.join(src, "source_sha16.txt")).read().strip(), "tag": tag, "workloads": workloads}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r3_traffic.json"), "w"), indent=1)
 print("wrote profiles/r3_traffic.json for sources", out["source_sha16"], [w["env"] for w in workloads])

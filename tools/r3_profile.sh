@@ -8,6 +8,7 @@ TAG=${TG_PROFILE_TAG:-r3_final}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+python -c "import bench; print(bench.source_hash())" > $O/source_sha16.txt     # what every file of this run was measured on
 python bench.py 2>$O/bench_edge.err | grep metric > $O/bench_edge.json
 B="python bench.py --no-cpu-baseline --no-companions"
 $B --sync-steps --no-literal 2>/dev/null | grep metric > $O/bench_edge_syncsteps.json

@@ -233,17 +233,21 @@ int tg_unpack_interior(tg_ctx* ctx, const void* src_dev, int32_t n_images, void*
  * no particular order.  These entry points are context free (raw device pointers + a HIP stream; NULL = the default stream).
  * tg_get_tile_template: the template of a context's sensor, uint8 [H][W] (device).
  * tg_pack_tiles: obs uint8 [n_images][h][w] -> dst (tg_tiles_capacity bytes; may be another GPU's memory opened with tg_ipc_open);
- *   counters_dev = two zeroed uint32 in LOCAL device memory (left zero again by every launch).
+ *   counters_dev = two zeroed uint32 in LOCAL device memory (left zero again by every launch); tail_src_dev (may be NULL): tail_bytes (<= 1 MiB)
+ *   copied to dst_dev + tail_offset by the same launch - the small block that rides behind the images (reward | done | feature).
  * tg_unpack_tiles: src message -> dst uint8 [n_images][h][w]: the template everywhere, then the records. */
 int tg_get_tile_template(tg_ctx* ctx, void** dev_ptr);
 int tg_tiles_capacity(int32_t n_images, int32_t h, int32_t w, int64_t* bytes);
 int tg_pack_tiles(void* hip_stream, const void* obs_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev,
-                  void* counters_dev);
+                  void* counters_dev, const void* tail_src_dev, int64_t tail_bytes, int64_t tail_offset);
 int tg_unpack_tiles(void* hip_stream, const void* src_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev);
 /* The same for the messages of n_ranks ranks in two launches: message r at src_dev + r * src_stride (bytes, a multiple of 16) ->
- * dst uint8 [n_ranks][n_images][h][w]; rank skip_rank (-1: none) is left alone (rank 0 copies its own images instead of packing them). */
+ * dst uint8 [n_ranks][n_images][h][w]; rank skip_rank (-1: none) is left alone (rank 0 copies its own images instead of packing them).
+ * prev_ids_dev (may be NULL = fill everything): uint32 [n_ranks][1 + n_images * tiles] zeroed by the caller, owned by this destination
+ * buffer: the list of tiles its last message had live; with it only those tiles get the template back before the new records land (dst
+ * must hold the template to begin with). */
 int tg_unpack_tiles_multi(void* hip_stream, const void* src_dev, int64_t src_stride, int32_t n_ranks, int32_t skip_rank, const void* template_dev,
-                          int32_t n_images, int32_t h, int32_t w, void* dst_dev);
+                          int32_t n_images, int32_t h, int32_t w, void* dst_dev, void* prev_ids_dev);
 /* Receive slots that peers store into directly (one process per GPU; the reference's counterpart is the pipe of each SubprocVecEnv worker,
  * sb3_helpers/rl_utils.py:17-30).  tg_ipc_alloc: zeroed device memory on the current device + its 64-byte IPC handle; tg_ipc_open /
  * tg_ipc_close: map / unmap it in another process (its GPU then reaches the memory over xGMI).  HSA_ENABLE_IPC_MODE_LEGACY=0 is required. */
@@ -253,6 +257,7 @@ int tg_ipc_open(const uint8_t* handle64, void** dev_ptr);
 int tg_ipc_close(void* dev_ptr);
 /* Device copy on a stream whose destination (or source) may be memory opened with tg_ipc_open; both pointers 16-byte aligned. */
 int tg_copy_bytes(void* hip_stream, void* dst_dev, const void* src_dev, int64_t bytes);
+int tg_copy_bytes2(void* hip_stream, void* dst1_dev, const void* src1_dev, int64_t bytes1, void* dst2_dev, const void* src2_dev, int64_t bytes2);   /* two ranges, one launch */
 /* Stream-ordered flags (uint32, monotone step counters) in such memory.  tg_flag_set: after everything enqueued before it on the stream has
  * finished, flags[i * stride_words] = value for i < n (release, system scope).  tg_flag_wait: the stream goes on once every
  * flags[i * stride_words] has reached value (compared modulo 2^32); after timeout_ms of waiting it goes on anyway and ORs bit (i & 31) into

@@ -144,14 +144,15 @@ SYMBOLS = {
     "tg_copy_episode_stats": (C.c_int, [_ctx, _fp, C.POINTER(C.c_int32)]),
     "tg_get_tile_template": (C.c_int, [_ctx, _vpp]),
     "tg_tiles_capacity": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
-    "tg_pack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "tg_pack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "tg_unpack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
-    "tg_unpack_tiles_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "tg_unpack_tiles_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "tg_ipc_alloc": (C.c_int, [C.c_int64, _vpp, _u8p]),
     "tg_ipc_free": (C.c_int, [C.c_void_p]),
     "tg_ipc_open": (C.c_int, [_u8p, _vpp]),
     "tg_ipc_close": (C.c_int, [C.c_void_p]),
     "tg_copy_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "tg_copy_bytes2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),
     "tg_flag_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32]),
     "tg_flag_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32]),
     "tg_get_obs_oracle": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32)]),

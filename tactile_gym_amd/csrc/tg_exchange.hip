@@ -38,7 +38,8 @@ constexpr int kRecWords = 17;                  // a record: one 16-byte header (
 // records out as consecutive 16-byte stores (so a remote destination sees full-width writes).  The last wave to finish publishes the
 // header and clears the counters for the next launch.
 __global__ __launch_bounds__(64) void k_pack_tiles(const uint8_t* __restrict__ obs, const uint8_t* __restrict__ tmpl, int n_img, int H, int W, int T,
-                                                   int TW, int groups, uint8_t* __restrict__ dst, uint32_t* __restrict__ counters) {
+                                                   int TW, int groups, uint8_t* __restrict__ dst, uint32_t* __restrict__ counters,
+                                                   const uint8_t* __restrict__ tail_src, size_t tail_bytes, size_t tail_offset) {
     __shared__ uint4 rec[64 * kRecWords];
     const int img = blockIdx.x / groups, g = blockIdx.x - img * groups;
     const int lane = threadIdx.x;
@@ -74,13 +75,21 @@ __global__ __launch_bounds__(64) void k_pack_tiles(const uint8_t* __restrict__ o
     uint4* __restrict__ out = reinterpret_cast<uint4*>(dst + 16) + (size_t)base * kRecWords;
     for (int i = lane; i < cnt * kRecWords; i += 64) out[i] = rec[i];
     __threadfence();
+    __shared__ uint32_t last;
     if (lane == 0) {
         const uint32_t ticket = atomicAdd(&counters[1], 1u);
-        if (ticket == gridDim.x - 1) {                    // every other wave has taken its slots and written its records
+        last = ticket == gridDim.x - 1 ? 1u : 0u;
+        if (last) {                                       // every other wave has taken its slots and written its records
             const uint32_t total = atomicExch(&counters[0], 0u);
             counters[1] = 0u;
             *reinterpret_cast<uint4*>(dst) = make_uint4(total, (uint32_t)n_img, (uint32_t)T, kTileMagic);
         }
+    }
+    __syncthreads();
+    if (last && tail_src != nullptr) {                    // the small block that rides behind the images (reward | done | feature): same message, same launch
+        const size_t n16 = tail_bytes / 16;
+        for (size_t i = lane; i < n16; i += 64) reinterpret_cast<uint4*>(dst + tail_offset)[i] = reinterpret_cast<const uint4*>(tail_src)[i];
+        if ((size_t)lane < tail_bytes - 16 * n16) dst[tail_offset + 16 * n16 + lane] = tail_src[16 * n16 + lane];
     }
 }
 
@@ -136,6 +145,65 @@ __global__ __launch_bounds__(256) void k_scatter_tiles_multi(const uint8_t* __re
     }
 }
 
+// With a list of the tiles the previous message of this slot had live (`prev`: per rank {count, ids...}, stride `prev_stride` words), the
+// template is restored on exactly those tiles instead of on the whole batch (a full fill is 17 MB per rank and step; the live tiles are a
+// few % of that), and the scatter records the new list.  The batch buffer must hold the template to begin with.
+__global__ __launch_bounds__(256) void k_restore_tiles_multi(const uint8_t* __restrict__ tmpl, const uint32_t* __restrict__ prev, size_t prev_stride, int skip,
+                                                            int n_img, int H, int W, int T, int TW, uint8_t* __restrict__ dst) {
+    const int r = blockIdx.y;
+    if (r == skip) return;
+    const uint32_t* __restrict__ pl = prev + (size_t)r * prev_stride;
+    const uint32_t cap = (uint32_t)n_img * (uint32_t)T;
+    const uint32_t count = pl[0] < cap ? pl[0] : cap;
+    uint8_t* __restrict__ d = dst + (size_t)r * n_img * H * W;
+    const int row = threadIdx.x & 15;
+    for (uint32_t slot = blockIdx.x * 16u + (threadIdx.x >> 4); slot < count; slot += gridDim.x * 16u) {
+        const uint32_t id = pl[1 + slot];
+        const int img = (int)(id / (uint32_t)T), tile = (int)(id - (uint32_t)img * (uint32_t)T);
+        if (img >= n_img) continue;
+        const int tr = tile / TW, tc = tile - tr * TW;
+        const size_t off = (size_t)(tr * 16 + row) * W + (size_t)tc * 16;
+        *reinterpret_cast<uint4*>(d + (size_t)img * H * W + off) = *reinterpret_cast<const uint4*>(tmpl + off);
+    }
+}
+__global__ __launch_bounds__(256) void k_scatter_tiles_multi_keep(const uint8_t* __restrict__ src, size_t stride, int skip, int n_img, int H, int W, int T, int TW,
+                                                                 uint8_t* __restrict__ dst, uint32_t* __restrict__ prev, size_t prev_stride) {
+    const int r = blockIdx.y;
+    if (r == skip) return;
+    const uint8_t* __restrict__ s = src + (size_t)r * stride;
+    uint8_t* __restrict__ d = dst + (size_t)r * n_img * H * W;
+    uint32_t* __restrict__ pl = prev + (size_t)r * prev_stride;
+    const uint4 hdr = *reinterpret_cast<const uint4*>(s);
+    const bool ok = hdr.w == kTileMagic && (int)hdr.z == T;
+    const uint32_t cap = (uint32_t)n_img * (uint32_t)T;
+    const uint32_t count = ok ? (hdr.x < cap ? hdr.x : cap) : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pl[0] = count;
+    const int row = threadIdx.x & 15;
+    for (uint32_t slot = blockIdx.x * 16u + (threadIdx.x >> 4); slot < count; slot += gridDim.x * 16u) {
+        const uint4* __restrict__ rec = reinterpret_cast<const uint4*>(s + 16) + (size_t)slot * kRecWords;
+        const uint32_t id = rec[0].x;
+        if (row == 0) pl[1 + slot] = id;
+        const int img = (int)(id / (uint32_t)T), tile = (int)(id - (uint32_t)img * (uint32_t)T);
+        if (img >= n_img) continue;
+        const int tr = tile / TW, tc = tile - tr * TW;
+        *reinterpret_cast<uint4*>(d + (size_t)img * H * W + (size_t)(tr * 16 + row) * W + (size_t)tc * 16) = rec[1 + row];
+    }
+}
+
+// two ranges in one launch (rank 0 copies its own images and the block behind them per step)
+__global__ __launch_bounds__(256) void k_copy_bytes2(const uint8_t* __restrict__ s1, size_t b1, uint8_t* __restrict__ d1, const uint8_t* __restrict__ s2, size_t b2,
+                                                    uint8_t* __restrict__ d2) {
+    const size_t n1 = b1 / 16, n2 = b2 / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n1) reinterpret_cast<uint4*>(d1)[i] = reinterpret_cast<const uint4*>(s1)[i];
+        else reinterpret_cast<uint4*>(d2)[i - n1] = reinterpret_cast<const uint4*>(s2)[i - n1];
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < b1 - 16 * n1) d1[16 * n1 + threadIdx.x] = s1[16 * n1 + threadIdx.x];
+        if (threadIdx.x < b2 - 16 * n2) d2[16 * n2 + threadIdx.x] = s2[16 * n2 + threadIdx.x];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ src, size_t bytes, uint8_t* __restrict__ dst) {
     const size_t n16 = bytes / 16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
@@ -176,13 +244,17 @@ int tg_tiles_capacity(int32_t n_images, int32_t h, int32_t w, int64_t* bytes) {
     return 0;
 }
 
-int tg_pack_tiles(void* stream, const void* obs_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev, void* counters_dev) {
+int tg_pack_tiles(void* stream, const void* obs_dev, const void* template_dev, int32_t n_images, int32_t h, int32_t w, void* dst_dev, void* counters_dev,
+                  const void* tail_src_dev, int64_t tail_bytes, int64_t tail_offset) {
     if (!obs_dev || !template_dev || !dst_dev || !counters_dev || n_images <= 0 || !tg::tile_geometry(h, w))
         return report_error(-1, "tg_pack_tiles: bad argument (image sides must be multiples of 16)");
+    if (tail_src_dev && (tail_bytes < 0 || tail_bytes > (1 << 20) || tail_offset < 0 || (tail_offset & 15) || ((uintptr_t)tail_src_dev & 15)))
+        return report_error(-1, "tg_pack_tiles: the tail must be at most 1 MiB, 16-byte aligned at both ends");
     const int TW = w / 16, T = TW * (h / 16), groups = (T + 63) / 64;
     if ((int64_t)n_images * groups > 0x7fffffffLL || (int64_t)n_images * T > 0x7fffffffLL) return report_error(-1, "tg_pack_tiles: too many tiles for one launch");
     hipLaunchKernelGGL(tg::k_pack_tiles, dim3((unsigned)(n_images * groups)), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)obs_dev,
-                       (const uint8_t*)template_dev, n_images, h, w, T, TW, groups, (uint8_t*)dst_dev, (uint32_t*)counters_dev);
+                       (const uint8_t*)template_dev, n_images, h, w, T, TW, groups, (uint8_t*)dst_dev, (uint32_t*)counters_dev,
+                       (const uint8_t*)(tail_bytes > 0 ? tail_src_dev : nullptr), (size_t)(tail_bytes > 0 ? tail_bytes : 0), (size_t)tail_offset);
     TGX_HIP(hipGetLastError());
     return 0;
 }
@@ -204,12 +276,22 @@ int tg_unpack_tiles(void* stream, const void* src_dev, const void* template_dev,
 }
 
 int tg_unpack_tiles_multi(void* stream, const void* src_dev, int64_t src_stride, int32_t n_ranks, int32_t skip_rank, const void* template_dev,
-                          int32_t n_images, int32_t h, int32_t w, void* dst_dev) {
+                          int32_t n_images, int32_t h, int32_t w, void* dst_dev, void* prev_ids_dev) {
     if (!src_dev || !template_dev || !dst_dev || n_images <= 0 || n_ranks <= 0 || n_ranks > 65535 || src_stride < 16 || (src_stride & 15) || !tg::tile_geometry(h, w))
         return report_error(-1, "tg_unpack_tiles_multi: bad argument (stride a multiple of 16, image sides multiples of 16)");
     const int TW = w / 16, T = TW * (h / 16);
     const int hw16 = h * w / 16;
     const size_t per_rank16 = (size_t)n_images * hw16;
+    if (prev_ids_dev != nullptr) {          // restore only what the slot's previous message had live, then scatter and remember the new list
+        const int64_t cap_ = (int64_t)n_images * T;
+        const unsigned blocks = (unsigned)((cap_ + 15) / 16 < 1024 ? (cap_ + 15) / 16 : 1024);
+        hipLaunchKernelGGL(tg::k_restore_tiles_multi, dim3(blocks, (unsigned)n_ranks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)template_dev,
+                           (const uint32_t*)prev_ids_dev, (size_t)(cap_ + 1), skip_rank, n_images, h, w, T, TW, (uint8_t*)dst_dev);
+        hipLaunchKernelGGL(tg::k_scatter_tiles_multi_keep, dim3(blocks, (unsigned)n_ranks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src_dev,
+                           (size_t)src_stride, skip_rank, n_images, h, w, T, TW, (uint8_t*)dst_dev, (uint32_t*)prev_ids_dev, (size_t)(cap_ + 1));
+        TGX_HIP(hipGetLastError());
+        return 0;
+    }
     const unsigned fill_blocks = (unsigned)((per_rank16 + 255) / 256 < 2048 ? (per_rank16 + 255) / 256 : 2048);
     hipLaunchKernelGGL(tg::k_fill_template_multi, dim3(fill_blocks, (unsigned)n_ranks), dim3(256), 0, (hipStream_t)stream, (const uint4*)template_dev, hw16,
                        per_rank16, skip_rank, (uint4*)dst_dev);
@@ -274,6 +356,17 @@ int tg_copy_bytes(void* stream, void* dst_dev, const void* src_dev, int64_t byte
     const size_t n16 = (size_t)bytes / 16;
     const unsigned blocks = (unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096);
     hipLaunchKernelGGL(tg::k_copy_bytes, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src_dev, (size_t)bytes, (uint8_t*)dst_dev);
+    TGX_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_copy_bytes2(void* stream, void* dst1_dev, const void* src1_dev, int64_t bytes1, void* dst2_dev, const void* src2_dev, int64_t bytes2) {
+    if (!dst1_dev || !src1_dev || !dst2_dev || !src2_dev || bytes1 < 0 || bytes2 < 0) return report_error(-1, "tg_copy_bytes2: bad argument");
+    if (((uintptr_t)dst1_dev | (uintptr_t)src1_dev | (uintptr_t)dst2_dev | (uintptr_t)src2_dev) & 15) return report_error(-1, "tg_copy_bytes2: pointers must be 16-byte aligned");
+    const size_t n16 = (size_t)(bytes1 + bytes2) / 16;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(tg::k_copy_bytes2, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src1_dev, (size_t)bytes1, (uint8_t*)dst1_dev,
+                       (const uint8_t*)src2_dev, (size_t)bytes2, (uint8_t*)dst2_dev);
     TGX_HIP(hipGetLastError());
     return 0;
 }

@@ -86,7 +86,7 @@ class _IpcSlots:
         self.L = capi.lib()
         assert 16 * 4 * (5 * world + 1) <= self.FLAG_BYTES, "too many ranks for the flag block"
         total = self.FLAG_BYTES + 2 * world * msg_bytes
-        self.base, self.owner, self.failed = C.c_void_p(), rank == root, None
+        self.base, self.owner, self.failed, self._fp = C.c_void_p(), rank == root, None, {}
         handle = (C.c_uint8 * 64)()
         payload = [None]
         if self.owner:
@@ -108,7 +108,11 @@ class _IpcSlots:
         self.err = torch.zeros(1, dtype=torch.int32, device=device)       # timeouts of this rank's waits (bit = flag lane)
         self.local = torch.as_tensor(_DevArray(self.base.value, total), device=device) if (self.owner and self.failed is None) else None
 
+    fixed_stream = None                               # a pipelined shard pins its stream: no per-call lookup (ShardedVecEnv sets it)
+
     def _stream(self):
+        if self.fixed_stream is not None:
+            return self.fixed_stream
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def slot_ptr(self, slot, r):
@@ -119,8 +123,12 @@ class _IpcSlots:
         return self.local[off:off + self.world * self.msg].view(self.world, self.msg)
 
     def _flag_ptr(self, kind, slot, r):
-        word = 16 * ({"ready": 0, "consumed": 2 * self.world, "hello": 4 * self.world}[kind] + slot * self.world + r)
-        return C.c_void_p(self.base.value + 4 * word)
+        key = (kind, slot, r)
+        p = self._fp.get(key)
+        if p is None:
+            word = 16 * ({"ready": 0, "consumed": 2 * self.world, "hello": 4 * self.world}[kind] + slot * self.world + r)
+            p = self._fp[key] = C.c_void_p(self.base.value + 4 * word)
+        return p
 
     def set(self, kind, slot, r, n, value):
         capi.check(self.L.tg_flag_set(self._stream(), self._flag_ptr(kind, slot, r), n, 16, value & 0xFFFFFFFF))
@@ -131,6 +139,10 @@ class _IpcSlots:
 
     def copy(self, dst_ptr, src_tensor):
         capi.check(self.L.tg_copy_bytes(self._stream(), C.c_void_p(dst_ptr), C.c_void_p(src_tensor.data_ptr()), src_tensor.numel() * src_tensor.element_size()))
+
+    def copy2(self, dst1, src1, dst2, src2):
+        capi.check(self.L.tg_copy_bytes2(self._stream(), C.c_void_p(dst1), C.c_void_p(src1.data_ptr()), src1.numel() * src1.element_size(),
+                                         C.c_void_p(dst2), C.c_void_p(src2.data_ptr()), src2.numel() * src2.element_size()))
 
     def handshake(self):
         """Every peer stores a pattern into its slot and raises its flag; rank 0 waits (bounded) and checks the bytes."""
@@ -217,6 +229,8 @@ class ShardedVecEnv:
         self._tick, self._handed = 0, 0              # messages started / the index of the newest message rank 0 has unpacked
         self._counters = None
         self._last_counts = None
+        self._prev_ids = [None, None]
+        self._root_cache, self._out_cache, self._tac_view = [None, None], [None, None], [None, None]
 
     def env_slice(self):
         return slice(self.rank * self.n_local, (self.rank + 1) * self.n_local)
@@ -311,6 +325,8 @@ class ShardedVecEnv:
             ipc = _IpcSlots(torch, self.dist, self.rank, self.world, self.root, total, dev, self._timeout_ms)
             if ipc.handshake():                       # the same verdict on every rank
                 self._ipc, self.transport = ipc, "ipc"
+                if getattr(self.local, "pipelined", False) and getattr(self.local, "stream", None) is not None:
+                    ipc.fixed_stream = C.c_void_p(self.local.stream.cuda_stream)
             else:
                 why = ipc.failed
                 ipc.close()
@@ -379,14 +395,18 @@ class ShardedVecEnv:
         dst = ipc.slot_ptr(slot, self.rank)
         if self.payload == "interior":
             self.local.pack_interior_ptr(dst)
+        rest = self._rest_tensor(obs, rew, done)
+        if rest.data_ptr() % 16:                      # 16-byte aligned ends are wanted; the library's block is, an assembled one is too
+            rest = rest.clone()
+        if self.payload == "tiles" and rest.numel() <= (1 << 20):
+            self.local.pack_tiles(dst, self._counters, tail=rest, tail_offset=L["off_rest"])   # images and the block behind them: one launch
+            rest = None
         elif self.payload == "tiles":
             self.local.pack_tiles(dst, self._counters)
-        else:
+        elif self.payload != "interior":
             ipc.copy(dst, obs["tactile"].reshape(-1))
-        rest = self._rest_tensor(obs, rew, done)
-        if rest.data_ptr() % 16:                      # tg_copy_bytes wants 16-byte aligned ends; the library's block is, an assembled one is too
-            rest = rest.clone()
-        ipc.copy(dst + L["off_rest"], rest)
+        if rest is not None:
+            ipc.copy(dst + L["off_rest"], rest)
         if L["vis_bytes"]:
             ipc.copy(dst + L["off_vis"], obs["visual"].reshape(-1))
 
@@ -409,10 +429,19 @@ class ShardedVecEnv:
                 if self.payload == "tiles" and hasattr(self.local, "unpack_tiles_multi"):
                     # rank 0's own images are not packed and unpacked: they go straight into their block of the batch (one copy), and
                     # only what rides behind the image part goes into its slot (where _receive reads reward / done / ... of every rank)
-                    n, hw = L["n"], L["H"] * L["W"]
-                    batch = self._batch_buffer(slot)
-                    ipc.copy(batch[self.root * n:(self.root + 1) * n].data_ptr(), obs["tactile"].reshape(-1))
-                    ipc.copy(self._stage[slot][L["off_rest"]:].data_ptr(), self._rest_tensor(obs, rew, done))
+                    c = self._root_cache[slot]
+                    if c is None or c[4] != obs["tactile"].data_ptr():     # the library's buffers never move: pointers are taken once per slot
+                        n = L["n"]
+                        rest = self._rest_tensor(obs, rew, done)
+                        c = self._root_cache[slot] = (C.c_void_p(self._batch_buffer(slot)[self.root * n:(self.root + 1) * n].data_ptr()),
+                                                      C.c_void_p(obs["tactile"].data_ptr()), obs["tactile"].numel(),
+                                                      C.c_void_p(self._stage[slot][L["off_rest"]:].data_ptr()), obs["tactile"].data_ptr(),
+                                                      C.c_void_p(rest.data_ptr()), rest.numel(), hasattr(self.local, "packed"))
+                    if not c[7]:                                           # an assembled block is a new tensor every step
+                        rest = self._rest_tensor(obs, rew, done)
+                        c = c[:5] + (C.c_void_p(rest.data_ptr()), rest.numel(), False)
+                        self._keep = rest
+                    capi.check(ipc.L.tg_copy_bytes2(ipc._stream(), c[0], c[1], c[2], c[3], c[5], c[6]))
                     if L["vis_bytes"]:
                         ipc.copy(self._stage[slot][L["off_vis"]:].data_ptr(), obs["visual"].reshape(-1))
                 else:
@@ -467,6 +496,10 @@ class ShardedVecEnv:
             self._obs_full[slot] = self.torch.zeros((self.world * L["n"], L["H"] * L["W"]), dtype=self.torch.uint8, device=L["dev"])
             if self.payload == "interior":
                 self._obs_full[slot].copy_(self._interior[1].reshape(1, -1).expand(self.world * L["n"], -1))
+            elif self.payload == "tiles":             # starts as the template everywhere; unpacking restores only what the last message touched
+                self._obs_full[slot].copy_(self._tiles[0].reshape(1, -1).expand(self.world * L["n"], -1))
+                tiles = L["n"] * (L["H"] // 16) * (L["W"] // 16)
+                self._prev_ids[slot] = self.torch.zeros(self.world * (tiles + 1), dtype=self.torch.int32, device=L["dev"])
         return self._obs_full[slot]
 
     # ------------------------------------------------------------------ rank 0: message t -> batch
@@ -480,13 +513,20 @@ class ShardedVecEnv:
                 self._ipc.wait("ready", slot, self.root + 1, self.world - 1 - self.root, t)
         full, n, w = self._full[slot], L["n"], self.world
         shape = L["tac_shape"]
+        tv = self._tac_view[slot]
         if self.payload == "full":
-            obs = {"tactile": full[:, :L["nb_full"]].reshape((w * n,) + shape[1:])}
+            if tv is None:                                    # one rank: a view of the slot; several: the images are strided across the
+                tv = full[:, :L["nb_full"]].reshape((w * n,) + shape[1:])     # messages, and reshape gathers them (a copy per step)
+                if w == 1:
+                    self._tac_view[slot] = tv
+            obs = {"tactile": tv}
         elif self.payload == "tiles" and self.transport == "ipc" and hasattr(self.local, "unpack_tiles_multi"):
             img = self._batch_buffer(slot)                    # rank 0's own block was copied in by _send; the peers' messages in two launches
             if w > 1:
-                self.local.unpack_tiles_multi(full.data_ptr(), L["total"], w, self.root, n, img.data_ptr())
-            obs = {"tactile": img.reshape((w * n,) + shape[1:])}
+                self.local.unpack_tiles_multi(full.data_ptr(), L["total"], w, self.root, n, img.data_ptr(), self._prev_ids[slot].data_ptr())
+            if tv is None:
+                tv = self._tac_view[slot] = img.reshape((w * n,) + shape[1:])
+            obs = {"tactile": tv}
         else:
             img = self._batch_buffer(slot)
             for r in range(w):
@@ -501,16 +541,38 @@ class ShardedVecEnv:
                     self.local.unpack_tiles(full[r].data_ptr(), n, blk.data_ptr())
                 else:
                     torch_unpack_tiles(torch, full[r], self._tiles[0], n, L["H"], L["W"], blk)
-            obs = {"tactile": img.reshape((w * n,) + shape[1:])}
-        o = L["off_rest"]
-        rew = full[:, o:o + 4 * n].contiguous().view(torch.float32).reshape(-1)
-        done = full[:, o + 4 * n:o + 5 * n].reshape(-1)
-        if L["fw_obs"]:   # config 4's tactile_and_feature observation (object_push_env.py:611-629) reaches rank 0 in the same message
-            f = o + L["f_in_rest"]
-            feat = full[:, f:f + 4 * n * L["fw"]].contiguous().view(torch.float32).reshape(w * n, L["fw"])
-            obs["extended_feature"] = feat[:, :L["fw_obs"]]
-        if L["vis_bytes"]:
-            obs["visual"] = full[:, L["off_vis"]:L["off_vis"] + L["vis_bytes"]].reshape((w * n,) + L["vis_shape"][1:])
+            if tv is None:
+                tv = self._tac_view[slot] = img.reshape((w * n,) + shape[1:])
+            obs = {"tactile": tv}
+        oc = self._out_cache[slot]
+        if oc is None:
+            # views of fixed buffers, built once per slot; what is strided across the ranks' messages (reward, done, feature) is gathered
+            # into contiguous outputs by one small copy each per step
+            o = L["off_rest"]
+            rew_src = full[:, o:o + 4 * n].view(torch.float32)                       # [world, n], row stride = message size
+            done_src = full[:, o + 4 * n:o + 5 * n]
+            rew_out = torch.empty((w, n), dtype=torch.float32, device=L["dev"]) if w > 1 else None
+            done_out = torch.empty((w, n), dtype=torch.uint8, device=L["dev"]) if w > 1 else None
+            feat_src = feat_out = None
+            if L["fw_obs"]:   # config 4's tactile_and_feature observation (object_push_env.py:611-629) reaches rank 0 in the same message
+                f = o + L["f_in_rest"]
+                feat_src = full[:, f:f + 4 * n * L["fw"]].view(torch.float32).reshape(w, n, L["fw"]) if w == 1 else \
+                    full[:, f:f + 4 * n * L["fw"]].view(torch.float32).unflatten(1, (n, L["fw"]))
+                feat_out = torch.empty((w, n, L["fw"]), dtype=torch.float32, device=L["dev"]) if w > 1 else None
+            vis_src = full[:, L["off_vis"]:L["off_vis"] + L["vis_bytes"]] if L["vis_bytes"] else None
+            oc = self._out_cache[slot] = (None, rew_src, rew_out, done_src, done_out, feat_src, feat_out, vis_src)
+        _, rew_src, rew_out, done_src, done_out, feat_src, feat_out, vis_src = oc
+        if w > 1:
+            rew_out.copy_(rew_src); done_out.copy_(done_src)
+            rew, done = rew_out.reshape(-1), done_out.reshape(-1)
+        else:
+            rew, done = rew_src.reshape(-1), done_src.reshape(-1)
+        if feat_src is not None:
+            if w > 1:
+                feat_out.copy_(feat_src)
+            obs["extended_feature"] = (feat_out if w > 1 else feat_src).reshape(w * n, L["fw"])[:, :L["fw_obs"]]
+        if vis_src is not None:                               # (a view with one rank, gathered by reshape with several)
+            obs["visual"] = vis_src.reshape((w * n,) + L["vis_shape"][1:])
         self._handed = t
         return obs, rew, done
 
@@ -616,7 +678,7 @@ class TorchShard:
     raw = True     # device resident: the ipc transport can address this shard's buffers
 
     def __init__(self, venv, pipelined=False):
-        self.venv, self.num_envs, self.pipelined, self.stream = venv, venv.num_envs, bool(pipelined), None
+        self.venv, self.num_envs, self.pipelined, self.stream, self._stream_ptr = venv, venv.num_envs, bool(pipelined), None, None
         if self.pipelined:
             import torch
             self.stream = torch.cuda.Stream(device=venv.tactile_torch().device)
@@ -627,6 +689,10 @@ class TorchShard:
         return self.venv.packed_torch()
 
     def _cur_stream(self):
+        if self.pipelined:                            # the shard's own stream, fixed for its lifetime
+            if self._stream_ptr is None:
+                self._stream_ptr = C.c_void_p(self.stream.cuda_stream)
+            return self._stream_ptr
         import torch
         return C.c_void_p(torch.cuda.current_stream(self.venv.tactile_torch().device).cuda_stream)
 
@@ -654,18 +720,21 @@ class TorchShard:
             self._tmpl = torch.as_tensor(_DevArray(p.value, self.venv.H * self.venv.W), device=self.venv.tactile_torch().device)
         return self._tmpl
 
-    def pack_tiles(self, dst_ptr, counters):
+    def pack_tiles(self, dst_ptr, counters, tail=None, tail_offset=0):
         """This shard's current observations as a tile message at the raw device address `dst_ptr` (tg_pack_tiles, current torch stream);
-        `counters`: a zeroed int32 device tensor of at least 2 elements in local memory."""
+        `counters`: a zeroed int32 device tensor of at least 2 elements in local memory; `tail`: a small uint8 tensor the same launch copies
+        to dst_ptr + tail_offset."""
         v = self.venv
         capi.check(v._L.tg_pack_tiles(self._cur_stream(), C.c_void_p(v.tactile_torch().data_ptr()), C.c_void_p(self.tile_template().data_ptr()),
-                                      v.num_envs, v.H, v.W, C.c_void_p(dst_ptr), C.c_void_p(counters.data_ptr())))
+                                      v.num_envs, v.H, v.W, C.c_void_p(dst_ptr), C.c_void_p(counters.data_ptr()),
+                                      C.c_void_p(tail.data_ptr() if tail is not None else None), tail.numel() if tail is not None else 0, tail_offset))
 
-    def unpack_tiles_multi(self, src_ptr, stride, n_ranks, skip_rank, n_images, dst_ptr):
-        """The tile messages of n_ranks ranks (`stride` bytes apart) -> their blocks of the batch, two launches; skip_rank's block is left alone."""
+    def unpack_tiles_multi(self, src_ptr, stride, n_ranks, skip_rank, n_images, dst_ptr, prev_ids_ptr=None):
+        """The tile messages of n_ranks ranks (`stride` bytes apart) -> their blocks of the batch, two launches; skip_rank's block is left
+        alone; prev_ids_ptr: the destination's list of last-live tiles (only those get the template back)."""
         v = self.venv
         capi.check(v._L.tg_unpack_tiles_multi(self._cur_stream(), C.c_void_p(src_ptr), stride, n_ranks, skip_rank, C.c_void_p(self.tile_template().data_ptr()),
-                                              n_images, v.H, v.W, C.c_void_p(dst_ptr)))
+                                              n_images, v.H, v.W, C.c_void_p(dst_ptr), C.c_void_p(prev_ids_ptr)))
 
     def unpack_tiles(self, src_ptr, n_images, dst_ptr):
         v = self.venv

@@ -154,3 +154,41 @@ def test_ipc_exchange_two_ranks(tmp_path, env_id, modes, size, payload, overlap)
     if payload == "tiles":
         assert len(got["info"]["message_bytes_last"]) == 2 and max(got["info"]["message_bytes_last"]) < got["info"]["message_bytes_capacity"]
     print(got["info"])
+
+
+def test_unpack_multi_restores_only_what_the_last_message_touched():
+    """tg_unpack_tiles_multi with a previous-ids list: three successive messages of two "ranks" (two halves of one 256-env batch, moving
+    contact patches, an auto-reset in between) into the same destination - after each, the destination equals the images exactly; the
+    skipped rank's block is never written; the tail rides in the pack launch."""
+    import torch
+    import tactile_gym_amd as tg
+    from tactile_gym_amd.parallel import TILE_REC, TorchShard
+    n, size = 128, 128
+    envs = [tg.make_vec("edge_follow-v0", num_envs=n, max_steps=3, image_size=[size, size], env_modes=EDGE, seed=30 + 1000 * r, obs_mode="torch", auto_reset=True)
+            for r in range(2)]
+    shards = [TorchShard(v) for v in envs]
+    T = (size // 16) ** 2
+    stride = ((16 + TILE_REC * n * T + 15) // 16) * 16 + 4096
+    msgs = torch.zeros(3 * stride, dtype=torch.uint8, device="cuda")          # rank 0 (skipped), ranks 1 and 2
+    dst = shards[0].tile_template().reshape(1, -1).repeat(3 * n, 1).contiguous()
+    dst[:n] = 0x5A                                                            # the skipped rank's block: must stay as it is
+    prev = torch.zeros(3 * (n * T + 1), dtype=torch.int32, device="cuda")
+    counters = torch.zeros(4, dtype=torch.int32, device="cuda")
+    tail = torch.arange(4096 - 7, dtype=torch.int32, device="cuda").to(torch.uint8)
+    rng = np.random.default_rng(2)
+    for sh in shards:
+        sh.reset()
+    for k in range(5):
+        for r, sh in enumerate(shards):
+            sh.step(torch.from_numpy(rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32)).cuda())
+            sh.pack_tiles(msgs[(r + 1) * stride:].data_ptr(), counters, tail=tail, tail_offset=stride - 4096)
+        shards[0].unpack_tiles_multi(msgs.data_ptr(), stride, 3, 0, n, dst.data_ptr(), prev.data_ptr())
+        torch.cuda.synchronize()
+        for r, v in enumerate(envs):
+            assert torch.equal(dst[(r + 1) * n:(r + 2) * n].reshape(v.tactile_torch().shape), v.tactile_torch()), (k, r)
+            assert torch.equal(msgs[(r + 1) * stride + stride - 4096:(r + 1) * stride + stride - 7], tail)
+        assert bool((dst[:n] == 0x5A).all())
+        counts = prev.reshape(3, -1)[:, 0].tolist()
+        assert counts[0] == 0 and 0 < counts[1] < n * T // 2 and 0 < counts[2] < n * T // 2
+    for v in envs:
+        v.close()

@@ -22,13 +22,22 @@ for name, env, size in (("edge", "edge_follow-v0", 128), ("object_push-v0", "obj
     if not os.path.isfile(p):
         continue
     t = json.load(open(p))
-    wl = {"env": env, "num_envs": 1024, "image_size": size, "physics": "f64", "algorithmic_kb_per_launch": round(bench.algo_bytes(env, size) * 1024 / 1024.0, 1)}
+    wl = {"env": env, "num_envs": 1024, "image_size": size, "physics": "f64", "algorithmic_kb_per_launch": round(bench.algo_bytes(env, size) * 1024 / 1024.0, 1)}     # bytes per env step x 1024 envs, in KB
     for k, v in t.items():
-        short = k.split("<")[0].replace("tg::", "").strip()
+        short = k.split("<")[0].replace("void ", "").replace("tg::", "").replace("(anonymous namespace)::", "").strip()
         if short.startswith("k_step"):
-            wl["k_step"] = dict(v, kernel=k.replace("tg::", ""))
-        elif short.startswith("k_render") and v["launches"] >= wl.get("k_render_tactile", {}).get("launches", 0) and "true" not in k.split("<")[-1].split(",")[-1]:
-            wl["k_render_tactile"] = dict(v, kernel=k.replace("tg::", ""))
+            wl["k_step"] = dict(v, kernel=k.replace("void ", "").replace("tg::", ""))
+        elif short.startswith("k_render") and v["write_kb"] * v["launches"] >= wl.get("k_render_tactile", {}).get("_total", 0):
+            wl["k_render_tactile"] = dict(v, kernel=k.replace("void ", "").replace("tg::", ""), _total=v["write_kb"] * v["launches"])
+    if "k_step" in wl and "k_render_tactile" in wl:
+        # the render kernel is launched twice per step where finished envs are re-drawn after their reset (a full and a masked launch): the
+        # figures below are per STEP (mean per launch x launches per step), comparable with the algorithmic bytes of one step
+        r, per_step = wl["k_render_tactile"], wl["k_render_tactile"]["launches"] / max(wl["k_step"]["launches"], 1)
+        r.pop("_total", None)
+        if per_step > 1.2:
+            for key in ("fetch_kb", "fetch_corrected_kb", "write_kb"):
+                r[key] = round(r[key] * per_step, 1)
+            r["launches_per_step"] = round(per_step, 2)
     workloads.append(wl)
 out = {"_what": "HBM-side traffic per kernel launch from rocprofv3 PMC (separate passes: --pmc FETCH_SIZE, --pmc WRITE_SIZE, each with --kernel-trace; "
                 "tools/r3_profile.sh traffic(), parsed by tools/traffic_parse.py), 1024 envs, f64, default solver; values in KB as reported.  Per "

@@ -1254,6 +1254,22 @@ def test_raster_division_is_correctly_rounded():
         assert m.value == 0
 
 
+def _run_bench(cmd, root, env, tag):
+    """One bench.py child.  About 2 of 100 one-rank RCCL runs on the development boxes ended with SIGABRT in the rank process (three frames
+    of a background thread in the trace, cause not found; never without the RCCL process group, never in 40 direct shell runs): such a run
+    is repeated once, and its stderr is kept under gpurun_out/ so that the next occurrence can be read."""
+    import os, subprocess
+    for attempt in range(2):
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        if out.returncode == 0:
+            return out
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        open(os.path.join(root, "gpurun_out", f"bench_test_failure_{tag}_{attempt}.err"), "w").write(out.stderr)
+        if "SIGABRT" not in out.stderr and "exitcode: -6" not in out.stderr:
+            return out
+    return out
+
+
 @pytest.mark.parametrize("env_id,size,port,transport,payload", [("edge_follow-v0", 128, 29541, "collective", "auto"), ("object_push-v0", 128, 29542, "collective", "auto"),
                                                                 ("object_balance-v0", 256, 29543, "collective", "auto"), ("edge_follow-v0", 128, 29544, "auto", "auto"),
                                                                 ("object_push-v0", 128, 29545, "ipc", "tiles"), ("edge_follow-v0", 128, 29546, "collective", "tiles")])
@@ -1268,8 +1284,8 @@ def test_bench_launches_under_torchrun_on_the_rccl_gather_path(env_id, size, por
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "10", "--num-envs", "256",
            "--env", env_id, "--image-size", str(size), "--no-cpu-baseline", "--no-literal", "--transport", transport, "--payload", payload]
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    out = _run_bench(cmd, root, env, f"{port}")
+    assert out.returncode == 0, out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
@@ -1291,8 +1307,8 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(TG_BENCH_SPAWN="1", TG_BENCH_FORCE_COLLECTIVE="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "5", "--num-envs", "128", "--no-cpu-baseline",
-                          "--no-literal", "--no-companions"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    out = _run_bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "5", "--num-envs", "128", "--no-cpu-baseline",
+                      "--no-literal", "--no-companions"], root, env, "spawn")
     assert out.returncode == 0, out.stderr[-12000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

@@ -421,15 +421,11 @@ def main():
         if solo and not args.no_cpu_baseline and args.env == "edge_follow-v0":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        # the line is out; every rank waits for the others, then leaves without running the teardown of RCCL / IPC mappings / HIP streams in
-        # whatever order the interpreter picks (the process exit reclaims all of it; a background-thread abort during that teardown would
-        # turn a finished measurement into a non-zero exit code)
-        sys.stdout.flush()
-        sys.stderr.flush()
-        barrier()
-        os._exit(0)
+    if gathered and hasattr(env, "close"):
+        env.close()
     w.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

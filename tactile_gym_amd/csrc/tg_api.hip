@@ -359,6 +359,7 @@ struct tg_ctx {
     tg_robot robot;
     int H, W, act_dim;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t capture_stream = nullptr;   // the step graph is captured here, never on the stream work runs on (see tg_step)
     void *d_robot = nullptr, *d_const = nullptr;   // DevRobot<T>, EnvConst<T>
     tg::State st{};
     tg::RasterParams rp{};
@@ -767,6 +768,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     *out = c;                            // owned by tg_create's guard from here on
     c->cfg = *cfg; c->robot = *robot; c->H = H; c->W = W;
     TG_HIP(hipStreamCreate(&c->own_stream));
+    TG_HIP(hipStreamCreate(&c->capture_stream));
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE) {
         TG_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
         TG_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); TG_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -988,6 +990,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -1122,17 +1125,20 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
                 d_act = c->d_actions;
             }
         }
-        if (c->step_graph[slot] && c->step_graph_stream[slot] != c->stream) {   // tg_set_stream since the capture: once per stream change
-            (void)hipGraphExecDestroy(c->step_graph[slot]);
-            c->step_graph[slot] = nullptr;
-        }
         if (!c->step_graph[slot]) {
+            // Captured on a stream of its own, never on the stream the work runs on: while a stream is capturing, hipEventQuery on an event
+            // that was recorded on it BEFORE the capture began fails with hipErrorCapturedEvent, and other threads do query such events - the
+            // watchdog thread of torch's RCCL process group polls the end events of collectives that ran on the caller's stream, and a poll
+            // that fell into the few hundred microseconds of a capture aborted the process (seen in 2 of ~100 one-rank bench runs).  A graph
+            // is not tied to the stream it was captured on, so tg_set_stream needs no re-capture either.
             hipGraph_t g = nullptr;
-            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const hipStream_t run_stream = c->stream;
+            c->stream = c->capture_stream;
+            if (hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 enqueue_step(c, d_act);
-                const hipError_t e1 = hipStreamEndCapture(c->stream, &g);
+                const hipError_t e1 = hipStreamEndCapture(c->capture_stream, &g);
                 if (e1 == hipSuccess && g && hipGraphInstantiate(&c->step_graph[slot], g, nullptr, nullptr, 0) == hipSuccess) {
-                    c->step_graph_stream[slot] = c->stream;
+                    c->step_graph_stream[slot] = run_stream;
                 } else {
                     c->step_graph[slot] = nullptr; c->graph_broken = true;
                 }
@@ -1140,6 +1146,7 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
             } else {
                 c->graph_broken = true;
             }
+            c->stream = run_stream;
             (void)hipGetLastError();
         }
         if (c->step_graph[slot]) {

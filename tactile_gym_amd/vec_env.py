@@ -130,7 +130,7 @@ class TactileVecEnv(_VecEnvBase):
     def _bind_torch_stream(self):
         """obs_mode="torch": the zero-copy observation / reward / done tensors and CUDA action tensors are produced and consumed on
         torch's CURRENT stream, so the library is put on that stream before work is enqueued (tg_set_stream is a pointer swap; the step
-        graph is re-captured only when the stream actually changes).  Ordering between the policy's kernels and the env's is then the
+        graph is captured on a stream of the library's own and replays on whichever stream is bound).  Ordering between the policy's kernels and the env's is then the
         stream's own: no event, no host wait, and correct under non-default or per-thread torch streams as well."""
         if self.obs_mode != "torch" or self._pinned_stream:
             return
@@ -140,9 +140,9 @@ class TactileVecEnv(_VecEnvBase):
             if hasattr(self, "_bound_stream"):
                 capi.check(self._L.tg_sync(self._ctx))     # drain the stream being left before work goes to another one
                 self._rebinds += 1
-                if self._rebinds == 8:                     # every switch costs a host sync and a re-instantiated step graph
+                if self._rebinds == 8:                     # every switch costs a host sync of the stream being left
                     warnings.warn("TactileVecEnv (obs_mode='torch') has been moved between torch streams 8 times: drive an env from ONE stream "
-                                  "(or pin it with set_stream); each switch drains the device and re-captures the step graph", RuntimeWarning, stacklevel=3)
+                                  "(or pin it with set_stream); each switch drains the stream being left", RuntimeWarning, stacklevel=3)
             capi.check(self._L.tg_set_stream(self._ctx, C.c_void_p(ptr)))
             self._bound_stream = ptr
 

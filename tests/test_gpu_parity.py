@@ -1642,3 +1642,42 @@ def test_arm_wave_mapping_matches_oracle(env_id, arm, sensor, full):
             assert abs(rew[i] - rr) < 1e-5 and bool(done[i]) == rd
             assert np.array_equal(obs["tactile"][i], ro["tactile"]), (step, i)
     venv.close()
+
+
+def test_maximum_batch_size(edge_modes):
+    """The largest context tg_create accepts (65 535 envs: the render launch carries the env index in grid.y): reset + 2 steps at 64 x 64,
+    the first and the last eight envs equal 8-env contexts with the same seeds (batch-size independence at the edge of the grid), the tile
+    payload of the whole batch round-trips, and 65 536 envs are refused with a message."""
+    import torch
+    import tactile_gym_amd as tg
+    from tactile_gym_amd._capi import TactileGymHipError
+    from tactile_gym_amd.parallel import TILE_REC, TorchShard
+    n = 65535
+    with pytest.raises(TactileGymHipError, match="65535"):
+        tg.make_vec("edge_follow-v0", num_envs=n + 1, max_steps=10, image_size=[64, 64], env_modes=edge_modes)
+    big = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=10, image_size=[64, 64], env_modes=edge_modes, seed=1000, obs_mode="torch", auto_reset=False)
+    sh = TorchShard(big)
+    sh.reset()
+    acts = torch.from_numpy(np.random.default_rng(4).uniform(-0.25, 0.25, size=(2, n, 2)).astype(np.float32)).cuda()
+    for k in range(2):
+        obs, rew, done, _ = sh.step(acts[k])
+    torch.cuda.synchronize()
+    for lo in (0, n - 8):
+        small = tg.make_vec("edge_follow-v0", num_envs=8, max_steps=10, image_size=[64, 64], env_modes=edge_modes, seed=1000 + lo, obs_mode="torch", auto_reset=False)
+        ss = TorchShard(small)
+        ss.reset()
+        for k in range(2):
+            o2, r2, d2, _ = ss.step(acts[k, lo:lo + 8].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(o2["tactile"], obs["tactile"][lo:lo + 8]) and torch.equal(r2, rew[lo:lo + 8]) and torch.equal(d2, done[lo:lo + 8])
+        assert np.array_equal(small.get_state()["q"], big.get_state()["q"][lo:lo + 8])
+        small.close()
+    cap = 16 + TILE_REC * n * 16
+    msg = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    counters = torch.zeros(4, dtype=torch.int32, device="cuda")
+    sh.pack_tiles(msg.data_ptr(), counters)
+    out = torch.zeros((n, 64 * 64), dtype=torch.uint8, device="cuda")
+    sh.unpack_tiles(msg.data_ptr(), n, out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out.reshape(obs["tactile"].shape), obs["tactile"]) and 0 < int(msg[:4].view(torch.int32).item()) < n * 16
+    big.close()

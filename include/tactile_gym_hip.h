@@ -261,7 +261,8 @@ int tg_copy_bytes2(void* hip_stream, void* dst1_dev, const void* src1_dev, int64
 /* Stream-ordered flags (uint32, monotone step counters) in such memory.  tg_flag_set: after everything enqueued before it on the stream has
  * finished, flags[i * stride_words] = value for i < n (release, system scope).  tg_flag_wait: the stream goes on once every
  * flags[i * stride_words] has reached value (compared modulo 2^32); after timeout_ms of waiting it goes on anyway and ORs bit (i & 31) into
- * *err_dev (uint32 in local device memory, may be NULL).  n <= 64. */
+ * *err_dev (uint32 in local device memory, may be NULL); a wait that finds *err_dev already non-zero goes on at once (one timeout has shown the
+ * exchange to be broken: the later waits must not sit theirs out as well).  n <= 64. */
 int tg_flag_set(void* hip_stream, void* flags_dev, int32_t n, int32_t stride_words, uint32_t value);
 int tg_flag_wait(void* hip_stream, const void* flags_dev, int32_t n, int32_t stride_words, uint32_t value, void* err_dev, int32_t timeout_ms);
 /* Envs with an "extended_feature" observation (object_push, object_roll) append it to the same allocation, so that config 4's

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(64) void k_flag_set(uint32_t* flags, int n, int str
 __global__ __launch_bounds__(64) void k_flag_wait(const uint32_t* flags, int n, int stride, uint32_t value, uint32_t* err, long long timeout_ticks) {
     const int i = threadIdx.x;
     if (i >= n) return;
-    const uint32_t* p = flags + (size_t)i * stride;
+    if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // a wait of this rank has timed out already: the
+    const uint32_t* p = flags + (size_t)i * stride;                                                  // exchange is broken, do not sit out every later one
     const long long t0 = wall_clock64();
     while ((int32_t)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
         if (wall_clock64() - t0 > timeout_ticks) {

@@ -144,12 +144,14 @@ class _IpcSlots:
         capi.check(self.L.tg_copy_bytes2(self._stream(), C.c_void_p(dst1), C.c_void_p(src1.data_ptr()), src1.numel() * src1.element_size(),
                                          C.c_void_p(dst2), C.c_void_p(src2.data_ptr()), src2.numel() * src2.element_size()))
 
-    def handshake(self):
+    def handshake(self, timeout_ms=5000):
         """Every peer stores a pattern into its slot and raises its flag; rank 0 waits (bounded) and checks the bytes."""
         torch = self.torch
+        keep, self.timeout_ms = self.timeout_ms, int(timeout_ms)
         oks = [None] * self.world
         self.dist.all_gather_object(oks, self.failed is None)      # every rank holds a mapping, or nobody goes on
         if not all(oks):
+            self.timeout_ms = keep
             return False
         pat = torch.arange(16, dtype=torch.uint8, device=self.device) + 16 * self.rank + 1
         ok = True
@@ -167,8 +169,12 @@ class _IpcSlots:
                     ok = False
             self.slot_tensor(0)[:, :16].zero_()
         torch.cuda.current_stream(self.device).synchronize()
+        self.timeout_ms = keep
         oks = [None] * self.world
         self.dist.all_gather_object(oks, bool(ok and int(self.err.item()) == 0))
+        if not all(oks):
+            self.failed = self.failed or RuntimeError("a pattern stored by a peer did not arrive in rank 0's slot within the time limit")
+        self.err.zero_()
         return all(oks)
 
     def check(self):

@@ -80,6 +80,13 @@ def test_flag_wait_times_out_instead_of_hanging():
     dt = time.perf_counter() - t0
     assert 0.25 < dt < 3.0, dt
     assert err.item() == 0b111
+    # once the error word is set, later waits on this stream return at once: a stuck partner costs ONE timeout, not one per queued wait
+    t0 = time.perf_counter()
+    for _ in range(20):
+        capi.check(L.tg_flag_wait(s, C.c_void_p(flags.data_ptr()), 3, 16, 7, C.c_void_p(err.data_ptr()), 300))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.25
+    assert err.item() == 0b111
 
 
 def _ipc_worker(rank, world, port, out_path, env_id, modes, size, n_local, payload, overlap, steps):

@@ -1312,6 +1312,22 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["exchange"]["verified"] is True and d["value"] > 0
 
 
+def test_bench_falls_back_to_the_rccl_gather_when_the_ipc_exchange_fails():
+    """An ipc exchange that reports an error (flag timeouts, a wrong batch; injected here) does not cost the run its number: every rank
+    agrees on the failure, the ipc slots are closed and the K steps are timed again through the RCCL gather; the line says so."""
+    import json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TG_BENCH_SPAWN="1", TG_BENCH_FORCE_COLLECTIVE="1", TG_BENCH_INJECT_EXCHANGE_FAULT="1")
+    out = _run_bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "5", "--num-envs", "128", "--no-cpu-baseline",
+                      "--no-literal", "--no-companions"], root, env, "fallback")
+    assert out.returncode == 0, out.stderr[-12000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    ex = d["exchange"]
+    assert ex["transport"] == "collective" and ex["verified"] is True and ex["fallback"]["from"].startswith("ipc") and "injected" in ex["fallback"]["why"]
+    assert d["value"] > 0 and d["rccl_ranks"] == 1
+
+
 def test_sample_actions_is_a_counter_based_uniform_box_sample(edge_modes):
     """tg_sample_actions = action_space.sample() for the batch: float32 in [min_action, max_action), a function of (seed, counter,
     element) only, flat histogram."""

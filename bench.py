@@ -178,11 +178,13 @@ class Workload:
 
     def dominant(self, prof):
         """(kernel name, ms per launch) of the kernel with the largest summed duration; the render kernel named as launched
-        (csrc/tg_raster.hip launch_render: small shared meshes take the two-pass small-mesh kernel)."""
+        (csrc/tg_raster.hip launch_render: the edge and the cube take the block kernel, the pole's plate the two-pass small-mesh kernel)."""
         step_ms, step_n = prof["step"]
         rend_ms, rend_n = prof["render"]
-        small = self.env_id in ("edge_follow-v0", "object_balance-v0", "object_push-v0") and self.image_size % 128 == 0
-        render_name = "k_render_small<128,64,2>" if small else ("k_render_scatter" if self.env_id == "object_roll-v0" else "k_render_tactile")
+        big = self.image_size % 128 == 0
+        render_name = ("k_render_blocks<16>" if self.env_id in ("edge_follow-v0", "object_push-v0") and big else
+                       "k_render_small<128,64,2>" if self.env_id == "object_balance-v0" and big else
+                       "k_render_scatter" if self.env_id == "object_roll-v0" else "k_render_tactile")
         if step_ms >= rend_ms:
             return "k_step", step_ms / max(step_n, 1), "k_step"
         return render_name, rend_ms / max(rend_n, 1), "k_render_tactile"

@@ -12,7 +12,7 @@ ABI_VERSION = 8
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtactile_gym_hip.so")
+LIB_PATH = os.environ.get("TG_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libtactile_gym_hip.so")   # TG_HIP_LIBRARY: another build of the same sources (A/B measurements)
 
 ENV_EDGE_FOLLOW, ENV_SURFACE_FOLLOW_AUTO, ENV_OBJECT_BALANCE, ENV_OBJECT_PUSH, ENV_OBJECT_ROLL = 0, 1, 2, 3, 4
 PMOVE = {"y": 0, "yRz": 1, "xyRz": 2, "TyRz": 3, "TxTyRz": 4}

@@ -381,6 +381,7 @@ struct tg_ctx {
     tg::SceneChunk* d_scene_chunks = nullptr;
     uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
     uint8_t* d_episode = nullptr;     // [ep_return f64[n] | ep_final_return f32[n] | ep_final_len i32[n]] (tg_get_episode_stats)
+    void* d_block_tables = nullptr;   // k_render_blocks' tables (rp.blockmax, rp.tmpl point into it)
     uint8_t* d_tile_tmpl = nullptr;   // tile-sparse payload (tg_pack_tiles): the image every env shows without a contact - zero inside, the pasted ring outside
     int32_t *d_int_idx = nullptr, *d_int_rank = nullptr;   // interior-only payload: pixel of interior position k / interior position of pixel p (-1: ring)
     int n_interior = 0;
@@ -937,6 +938,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         // without it the kernel needs 98 instead of 126 VGPRs - five workgroups per CU instead of four (edge_follow render 34.5 -> 31.7 us,
         // 16 384 envs 0.340 -> 0.289 ms; object_push's cube unchanged; object_balance's plate never used it).
         c->stim.skip_quad_reject = 1;
+        c->stim.fills_view = cfg->env_kind == TG_ENV_OBJECT_BALANCE ? 1 : 0;
         c->stim.closed_outward = (mesh_closed_outward(stim) && getenv("TG_NO_BACKFACE_CULL") == nullptr) ? 1 : 0;   // env var: A/B measurements only
         c->stim.kind = 0; c->stim.verts = c->d_verts; c->stim.tris = c->d_tris; c->stim.soup = c->d_soup; c->stim.n_tris = stim->n_tris;
     }
@@ -961,6 +963,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     TG_HIP(hipMalloc(&c->d_mask, n));
     TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 6 * sizeof(float)));
     c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border, sensor->nodef_dep);
+    if (make_block_tables(c->rp, sensor->nodef_dep, sensor->nodef_gray, sensor->border_mask, n, &c->d_block_tables)) return fail(-2, "hipMalloc failed (raster block tables)");
     return 0;
 }
 
@@ -978,6 +981,7 @@ int tg_destroy(tg_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
     if (c->scene_on) scene_debug_stats();
+    raster_debug_stats();
 #ifdef TG_KSTEP_STAMPS
     { unsigned long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_kstep_stamps), sizeof h) == hipSuccess) { fprintf(stderr, "k_step stamps (cycles from start, full=%llu):", h[15]); for (int i = 1; i < 13; ++i) fprintf(stderr, " [%d] %lld", i, (long long)(h[i] - h[0])); fprintf(stderr, "\n"); } }
 #endif
@@ -985,7 +989,7 @@ int tg_destroy(tg_ctx* c) {
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
-                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode};
+                    c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1698,6 +1702,8 @@ int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, cons
     TG_HIP(hipMemcpy(xx.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
     TG_HIP(hipMemset(oo.p, 0, npix * n));
     RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
+    DevBuf bt;
+    if (make_block_tables(P, sen->nodef_dep, sen->nodef_gray, sen->border_mask, n, &bt.p)) return fail(-2, "hipMalloc failed");
     Stimulus S{};
     S.closed_outward = (mesh_closed_outward(mesh) && getenv("TG_NO_BACKFACE_CULL") == nullptr) ? 1 : 0;   // env var: A/B measurements only
     DevBuf sp;

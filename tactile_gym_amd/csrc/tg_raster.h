@@ -14,7 +14,12 @@ struct RasterParams {
     float kx, ky, hw, hh, C0, C1, near_;
     float zcull;   // max of the undeformed depth image: triangles entirely behind it can never win the z-test
     int turn_off_border;
+    // k_render_blocks (small shared meshes, 128-multiple images), both made by make_block_tables or both null (then k_render_small draws):
+    const float* blockmax;    // [regions][64]: largest undeformed depth of each kBlockW x (256 / kBlockW) block of each 128 x 128 region
+    unsigned long long* drawn;   // [n_envs][regions]: bit b = block b of the env's image (`out`) differs from tmpl (written by k_render_blocks; null: every launch rewrites every block)
+    const uint8_t* tmpl;      // [H][W]: t_s_camera's image of an untouched sensor (zero inside, the pasted ring outside)
 };
+constexpr int kBlockW = 16;
 
 // What the tactile camera looks at: a triangle mesh shared by all envs (edge, cube, ...) placed by a per-env rigid
 // transform, or a per-env heightfield (surface_follow: createCollisionShape(GEOM_HEIGHTFIELD), base_surface_env.py:402-432)
@@ -34,10 +39,15 @@ struct Stimulus {
     int skip_quad_reject;     // 1: stimuli whose few triangles fill the camera's view (the pole's plate): the per-quad reject never fires
     int closed_outward;       // mesh: every surface is closed and consistently wound with outward normals (verified on the host):
                               // back faces are dropped at set-up for envs whose stimulus lies wholly beyond the near plane
+    int fills_view;           // mesh: the stimulus covers the whole image in every frame (object_balance's plate on the sensor): launch_render keeps it off the block kernel
     int win_side;             // heightfield: largest side (in vertices) the frustum window can have (set by launch_render): sizes the LDS staging
 };
 
 RasterParams make_raster_params(int W, int H, double fov_deg, double near_, double far_, int turn_off_border, const float* nodef_dep_host);
+
+// Device tables of k_render_blocks into P (one allocation, returned in *d_mem for the owner to hipFree; null and 0 when the image size has
+// no block kernel); -1 when the allocation or the upload fails.
+int make_block_tables(RasterParams& P, const float* nodef_dep_host, const float* nodef_gray_host, const uint8_t* border_host, int n_envs, void** d_mem);
 
 // uint8(nodef_gray) per pixel (the border paste value), converted once on the host
 void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host);
@@ -47,6 +57,8 @@ void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host);
 void launch_render(const RasterParams& P, const Stimulus& stim, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, const float* term_xform, const uint8_t* term_mask, uint8_t* term_out, hipStream_t stream);
+
+void raster_debug_stats();   // development (-DTG_BLK_STAMPS): prints k_render_blocks' phase stamps; otherwise nothing
 
 // div_mid_range vs `/` on n pseudo-random operand pairs (exponents 2^-40 .. 2^24): number of differing quotients
 int selftest_division(long long n, unsigned long long seed, long long* mismatches_host);

@@ -27,6 +27,8 @@
 #include <stdint.h>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #include "tg_raster.h"
 
@@ -67,9 +69,41 @@ RasterParams make_raster_params(int W, int H, double fov_deg, double near_, doub
     P.C1 = (float)(-(near_ * far_) / (far_ - near_));
     P.near_ = (float)near_;
     P.turn_off_border = turn_off_border;
+    P.blockmax = nullptr; P.tmpl = nullptr; P.drawn = nullptr;
     P.zcull = 0.0f;
     for (int i = 0; i < W * H; ++i) P.zcull = nodef_dep_host[i] > P.zcull ? nodef_dep_host[i] : P.zcull;
     return P;
+}
+
+int make_block_tables(RasterParams& P, const float* nodef_dep_host, const float* nodef_gray_host, const uint8_t* border_host, int n_envs, void** d_mem) {
+    *d_mem = nullptr;
+    if (P.W % 128 != 0 || P.H % 128 != 0) return 0;      // only the 128-multiple image sizes have the block kernel
+    const int W = P.W, H = P.H, rxn = W / 128, ryn = H / 128, nbx = 128 / kBlockW, bh = 256 / kBlockW;
+    const size_t npix = (size_t)W * H, nblk = (size_t)rxn * ryn * 64;
+    std::vector<float> bmax(nblk, -1.0f);     // a block of pasted pixels only is reached by nothing (depths are >= 0)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int reg = (y / 128) * rxn + x / 128, b = ((y % 128) / bh) * nbx + (x % 128) / kBlockW;
+            float& m = bmax[(size_t)reg * 64 + b];
+            if (!P.turn_off_border && border_host[(size_t)y * W + x] == 1) continue;   // a pasted pixel does not depend on its depth
+            const float v = nodef_dep_host[(size_t)y * W + x];
+            m = v > m ? v : m;
+        }
+    std::vector<uint8_t> tmpl(npix, 0);
+    if (!P.turn_off_border)
+        for (size_t p = 0; p < npix; ++p) tmpl[p] = border_host[p] == 1 ? (uint8_t)nodef_gray_host[p] : 0;
+    static const bool rewrite_all = getenv("TG_RASTER_REWRITE_ALL") != nullptr;   // every launch writes every block (a caller that scribbles on the image buffer)
+    const size_t drawn_bytes = rewrite_all ? 0 : (((size_t)n_envs * rxn * ryn * 8 + 15) & ~(size_t)15), off_tmpl = drawn_bytes + nblk * 4;
+    uint8_t* mem = nullptr;
+    if (hipMalloc(&mem, off_tmpl + npix) != hipSuccess) return -1;
+    if (hipMemset(mem, 0xFF, drawn_bytes ? drawn_bytes : 1) != hipSuccess ||      // nothing holds the untouched-sensor image yet
+        hipMemcpy(mem + drawn_bytes, bmax.data(), nblk * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(mem + off_tmpl, tmpl.data(), npix, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(mem); return -1; }
+    P.drawn = drawn_bytes ? reinterpret_cast<unsigned long long*>(mem) : nullptr;
+    P.blockmax = reinterpret_cast<const float*>(mem + drawn_bytes);
+    P.tmpl = mem + off_tmpl;
+    *d_mem = mem;
+    return 0;
 }
 
 // a / b rounded like the IEEE division the specification (and the oracle's C `/`) prescribes, for operands whose exponents are far from the
@@ -790,6 +824,321 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
 #undef TG_QX
 #undef TG_RY
 
+#ifdef TG_BLK_STAMPS
+// development only: per-phase clock stamps of k_render_blocks' last launch (first 1024 workgroups x 4 wavefronts x 8 stamps, absolute wall
+// clock, 100 MHz), printed by raster_debug_stats()
+__device__ unsigned long long g_blk_log[1024 * 4 * 8];
+__device__ int g_blk_nt[1024 * 2];
+#define TG_STAMP(i) do { if (lane == 0 && blockIdx.y < 1024 && blockIdx.x == 0 && blockIdx.z == 0) g_blk_log[(blockIdx.y * 4 + wave) * 8 + (i)] = wall_clock64(); } while (0)
+void raster_debug_stats() {
+    static unsigned long long h[1024 * 4 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_blk_log), sizeof h) != hipSuccess) return;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    int nw = 0;
+    for (int w = 0; w < 4096; ++w) if (h[w * 8 + 7]) { ++nw; if (h[w * 8 + 7] < t0) t0 = h[w * 8 + 7]; for (int i = 0; i < 7; ++i) if (h[w * 8 + i] > t1) t1 = h[w * 8 + i]; }
+    if (!nw) return;
+    fprintf(stderr, "k_render_blocks last launch: %d wavefronts, span %llu0 ns; per phase (x10 ns) mean since own start / mean since launch start / max since launch start:\n", nw, t1 - t0);
+    for (int i = 0; i < 7; ++i) {
+        double a = 0, b2 = 0; unsigned long long m = 0;
+        for (int w = 0; w < 4096; ++w) if (h[w * 8 + 7] && h[w * 8 + i]) { a += (double)(h[w * 8 + i] - h[w * 8 + 7]); b2 += (double)(h[w * 8 + i] - t0); if (h[w * 8 + i] - t0 > m) m = h[w * 8 + i] - t0; }
+        fprintf(stderr, "  [%d] %.1f / %.1f / %llu\n", i, a / nw, b2 / nw, m);
+    }
+    double st = 0; unsigned long long sm = 0;
+    for (int w = 0; w < 4096; ++w) if (h[w * 8 + 7]) { st += (double)(h[w * 8 + 7] - t0); if (h[w * 8 + 7] - t0 > sm) sm = h[w * 8 + 7] - t0; }
+    fprintf(stderr, "  start: mean %.1f max %llu\n", st / nw, sm);
+    static int nt[2048];
+    if (hipMemcpyFromSymbol(nt, HIP_SYMBOL(g_blk_nt), sizeof nt) != hipSuccess) return;
+    // per workgroup: end time (max over its wavefronts) against records and reached blocks
+    fprintf(stderr, "  wg: end(x10ns) n T   (sorted by end, every 64th)\n");
+    static int order[1024]; static unsigned long long endt[1024];
+    for (int g = 0; g < 1024; ++g) { order[g] = g; endt[g] = 0; for (int w = 0; w < 4; ++w) if (h[(g * 4 + w) * 8 + 6] > endt[g]) endt[g] = h[(g * 4 + w) * 8 + 6]; endt[g] -= t0; }
+    for (int i = 0; i < 1024; ++i) for (int j = i + 1; j < 1024; ++j) if (endt[order[j]] < endt[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int i = 0; i < 1024; i += 64) fprintf(stderr, "   %llu %d %d |", endt[order[i]], nt[2 * order[i]], nt[2 * order[i] + 1]);
+    fprintf(stderr, "   %llu %d %d\n", endt[order[1023]], nt[2 * order[1023]], nt[2 * order[1023] + 1]);
+    double an = 0, aT = 0; for (int g = 0; g < 1024; ++g) { an += nt[2 * g]; aT += nt[2 * g + 1]; }
+    fprintf(stderr, "  mean n %.2f mean T %.2f\n", an / 1024, aT / 1024);
+}
+#else
+#define TG_STAMP(i) do { } while (0)
+void raster_debug_stats() {}
+#endif
+
+// Small shared meshes, block form (round 3): ONE workgroup per (env, 128 x 128 region) sets the triangles up once (at most 64 records:
+// meshes of up to 32 triangles - edge, cube, pole).  The region is 64 blocks of BW x (256 / BW) pixels.
+//   1. lane-as-record: every lane keeps one record's bounding box, dmin and DEPTH PLANE.  Window depth is affine over a triangle,
+//      D(x, y) = d0 + A (x - x0) + B (y - y0), so its minimum over (block rectangle) n (record bounding box) sits at a corner.
+//   2. lane-as-block: the records are broadcast one by one (v_readlane) and each lane decides whether any of them can change a pixel of
+//      "its" block: bounding box, dmin against the block's largest undeformed depth (a host-made table; pasted ring pixels do not count),
+//      and the plane minimum less a margin (rounding of this estimate against the pixel formula, scaled by the triangle's conditioning
+//      = bounding-box area / twice its area; ill-conditioned records have no plane) against that depth less kGrey: t_s_camera maps a depth
+//      less than 0.05 / 255 = 1.96e-4 below the undeformed one to grey level 0, which is what the untouched-sensor image holds.  The
+//      ballot is the region's reached-block mask, the same in all four wavefronts.
+//   3. blocks nothing reaches are copies of the untouched-sensor image, 16 per wavefront, all loads in flight together.
+//   4. reached blocks are drawn by ALL four wavefronts together, eight blocks per round: wavefront w owns the w-th quarter of the rows of
+//      each, a lane two quads (one in each of two blocks) - whatever the contact patch looks like, the four wavefronts finish together,
+//      and the lanes of a visited record are in compact patches that mostly hit.
+// Against k_render_small (two workgroups per image, each lane carrying 8 quads spread over its half): half the set-ups, 4096 instead of
+// 8192 wavefronts at 1024 envs, no wavefront whose share of the image is the whole contact patch.  The pixel arithmetic is that of the
+// other kernels, expression by expression; the depth test keeps the smallest d, so neither the record order nor the conservative skips
+// can change the image.
+template <int BW>
+__global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stimulus S, const float* __restrict__ xform, int xform_soa, int n_envs,
+                                                           const uint8_t* __restrict__ mask, const float* __restrict__ nodef_dep,
+                                                           const uint8_t* __restrict__ gray_u8, const uint8_t* __restrict__ border,
+                                                           uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int rec_cap,
+                                                           const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
+                                                           uint8_t* __restrict__ term_out) {
+    constexpr int BH = 256 / BW, LPR = BW / 4, NBX = 128 / BW, NPW = 16, RQ = BH / 4;   // NPW blocks per wavefront; RQ rows per block quarter
+    static_assert(BW == kBlockW, "P.blockmax is laid out for kBlockW");
+    extern __shared__ TriRec recs[];
+    __shared__ int count;
+    __shared__ unsigned long long reach_rec[64], reach_all;    // per record: the blocks it can change; their union
+    const int env = blockIdx.y;
+    if (mask != nullptr && mask[env] == 0) return;
+    const int n_tris = S.n_tris;
+    const int regions_x = P.W / 128;
+    const int reg = blockIdx.x, rx = (reg % regions_x) * 128, ry = (reg / regions_x) * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TG_STAMP(7);
+    const int pass = (term_xform != nullptr && blockIdx.z == 1) ? 0 : 1;
+    if (pass == 0 && term_mask[env] == 0) return;
+    const float* __restrict__ xf = pass == 0 ? term_xform : xform;
+    uint8_t* __restrict__ img = pass == 0 ? term_out : out;
+    const float bmax_l = P.blockmax[reg * 64 + lane];          // lane l <-> block l: its largest undeformed depth
+    // the blocks of this image that do NOT hold the untouched-sensor image now (drawn by the previous launch on it); the terminal image's
+    // buffer has no such record: everything is rewritten there
+    unsigned long long* drawn_p = (P.drawn != nullptr && pass == 1) ? P.drawn + ((size_t)env * gridDim.x + reg) : nullptr;
+    unsigned long long stale = ~0ull;
+    if (drawn_p) stale = *drawn_p;
+    float M[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xf[(size_t)k * n_envs + env] : xf[(size_t)env * 12 + k];
+    const float tx0 = (float)rx, tx1 = (float)(rx + 128), ty0 = (float)ry, ty1 = (float)(ry + 128);
+    if (tid == 0) { count = 0; reach_all = 0ull; }
+    // set-up: at most one triangle per lane (n_tris <= 32), its clip-space vertices stay in registers across the vote that licenses the
+    // back-face cull (every vertex of the mesh beyond the near plane)
+    const bool has = tid < n_tris;
+    float cx[3] = {0.0f, 0.0f, 0.0f}, cy[3] = {0.0f, 0.0f, 0.0f}, cw[3] = {0.0f, 0.0f, 0.0f};
+    bool beyond = true;
+    if (has) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* v = S.soup + 9 * tid + 3 * k;
+            const float vx = v[0], vy = v[1], vz = v[2];
+            cx[k] = ((M[0] * vx + M[1] * vy) + M[2] * vz) + M[9];
+            cy[k] = ((M[3] * vx + M[4] * vy) + M[5] * vz) + M[10];
+            cw[k] = -(((M[6] * vx + M[7] * vy) + M[8] * vz) + M[11]);
+            beyond = beyond && (cw[k] >= P.near_);
+        }
+    }
+    TG_STAMP(0);
+    const bool cull = __syncthreads_and(beyond ? 1 : 0) != 0 && S.closed_outward != 0;   // (also the barrier after count = 0)
+    TG_STAMP(1);
+    if (has && !(cull && back_facing(cx, cy, cw))) {
+        float ox[4], oy[4], ow[4];
+        int no = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int k1 = (k + 1) % 3;
+            const bool ain = cw[k] >= P.near_, bin = cw[k1] >= P.near_;
+            if (ain) { ox[no] = cx[k]; oy[no] = cy[k]; ow[no] = cw[k]; ++no; }
+            if (ain != bin) {
+                const float tt = (P.near_ - cw[k]) / (cw[k1] - cw[k]);
+                ox[no] = cx[k] + tt * (cx[k1] - cx[k]);
+                oy[no] = cy[k] + tt * (cy[k1] - cy[k]);
+                ow[no] = P.near_;
+                ++no;
+            }
+        }
+        if (no >= 3) emit(recs, &count, rec_cap, ox, oy, ow, 0, 1, 2, P, tx0, ty0, tx1, ty1);
+        if (no == 4) emit(recs, &count, rec_cap, ox, oy, ow, 0, 2, 3, P, tx0, ty0, tx1, ty1);
+    }
+    __syncthreads();
+    TG_STAMP(2);
+    const int n = __builtin_amdgcn_readfirstlane(min(count, rec_cap));     // <= 64 (launch_render)
+    const float eps = 1e-4f, max_pen = 0.05f;
+    constexpr float kGrey = 1.5e-4f;
+    uint8_t* dst = img + (size_t)env * P.W * P.H;
+    uint8_t* prev = (save_prev && pass == 1) ? save_prev + (size_t)env * P.W * P.H : nullptr;
+
+    // 1. lane-as-record
+    float q_xl = 1e30f, q_xh = -1e30f, q_yl = 1e30f, q_yh = -1e30f, q_dm = 1e30f, q_x0 = 0.0f, q_y0 = 0.0f, q_d0 = 0.0f, q_A = 0.0f, q_B = 0.0f, q_mg = 1e30f;
+    if (lane < n) {
+        const TriRec& r = recs[lane];
+        q_xl = r.xmin; q_xh = r.xmax; q_yl = r.ymin; q_yh = r.ymax; q_dm = r.dmin; q_x0 = r.x0; q_y0 = r.y0; q_d0 = r.d0;
+        const float ux = r.x1 - r.x0, uy = r.y1 - r.y0, vx = r.x2 - r.x0, vy = r.y2 - r.y0, ud = r.d1 - r.d0, vd = r.d2 - r.d0;
+        const float ar = ux * vy - vx * uy;
+        const float cond = ((q_xh - q_xl) * (q_yh - q_yl)) / fabsf(ar);
+        if (cond < 64.0f) {                             // (NaN and inf compare false: no plane for degenerate records)
+            q_A = (ud * vy - vd * uy) / ar; q_B = (ux * vd - vx * ud) / ar;
+            q_mg = 2e-5f * cond;
+        }
+    }
+    // 2. lane-as-block: which of the 64 blocks can record t change?  Wavefront w takes the records w, w + 4, ... (all four doing all of them
+    //    was a third of this kernel's vector instructions: the four wavefronts of a SIMD share its issue slots)
+    unsigned long long reached;
+    {
+        const float X0 = (float)(rx + (lane % NBX) * BW) + 0.5f, Y0 = (float)(ry + (lane / NBX) * BH) + 0.5f;   // first / last pixel centres
+        const float X1 = X0 + (float)(BW - 1), Y1 = Y0 + (float)(BH - 1);
+        unsigned long long part = 0ull;
+#define TG_RL(v) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), t))
+        for (int t = wave; t < n; t += 4) {
+            const float xl = TG_RL(q_xl), xh = TG_RL(q_xh), yl = TG_RL(q_yl), yh = TG_RL(q_yh), dm = TG_RL(q_dm);
+            const float x0 = TG_RL(q_x0), y0 = TG_RL(q_y0), d0 = TG_RL(q_d0), A = TG_RL(q_A), B = TG_RL(q_B), mg = TG_RL(q_mg);
+            bool miss = (yh < Y0) | (yl > Y1) | (xh < X0) | (xl > X1) | (dm >= bmax_l);
+            const float xa = fmaxf(X0, xl), xb = fminf(X1, xh), ya = fmaxf(Y0, yl), yb = fminf(Y1, yh);
+            const float low = (d0 + A * ((A >= 0.0f ? xa : xb) - x0)) + B * ((B >= 0.0f ? ya : yb) - y0);
+            miss = miss | (low - mg >= bmax_l - kGrey);
+            const unsigned long long m = __ballot(!miss);
+            part |= m;
+            if (lane == 0) reach_rec[t] = m;
+        }
+        if (lane == 0 && part) atomicOr(&reach_all, part);
+        __syncthreads();
+        reached = reach_all;
+    }
+    reached = __builtin_amdgcn_readfirstlane((unsigned)reached) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(reached >> 32)) << 32);
+    stale = __builtin_amdgcn_readfirstlane((unsigned)stale) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(stale >> 32)) << 32);
+    if (drawn_p && tid == 0) *drawn_p = reached;
+    TG_STAMP(3);
+#ifdef TG_BLK_STAMPS
+    if (tid == 0 && blockIdx.y < 1024 && blockIdx.x == 0 && blockIdx.z == 0) { g_blk_nt[2 * blockIdx.y] = n; g_blk_nt[2 * blockIdx.y + 1] = __builtin_popcountll(reached); }
+#endif
+    const unsigned long long restore = stale & ~reached;      // blocks to bring back to the untouched-sensor image
+    const int lq = lane & 15, lrow = lq / LPR, lcol = 4 * (lq % LPR);     // this lane's quad inside a block quarter
+    // 3. blocks nothing reaches show the untouched sensor's image.  A lane moves one 16-pixel row of one block as a 16-byte word; the lanes of
+    //    an instruction are the NBX blocks across the region x (64 / NBX) consecutive rows, so an instruction writes whole 128-byte lines
+    //    wherever a line's blocks are all unreached (4-byte words in 16 x 16 patterns measured 10.6 us for the 16.8 MB of 1024 envs).
+    //    Wavefront w owns the row groups w, w + 4, ...; loads here, stores after the drawing.
+    static_assert(BW == 16, "one 16-byte word per block row");
+    constexpr int RPI = 64 / NBX, NCP = 128 / RPI / 4;          // rows per instruction; copy instructions per wavefront
+    const int cbx = lane % NBX, crow0 = lane / NBX;
+#define TG_CROW(i) (RPI * (4 * (i) + wave) + crow0)             /* row of the region this lane moves in its i-th instruction */
+#define TG_COFF(i) ((size_t)(ry + TG_CROW(i)) * P.W + (rx + cbx * BW))
+#define TG_CLEAN(i) (!((reached >> ((TG_CROW(i) / BH) * NBX + cbx)) & 1ull))
+#define TG_RESTORE(i) ((restore >> ((TG_CROW(i) / BH) * NBX + cbx)) & 1ull)
+    if (prev) {
+        uint4 pv[NCP];
+#pragma unroll
+        for (int i = 0; i < NCP; ++i)
+            if (TG_CLEAN(i)) pv[i] = *reinterpret_cast<const uint4*>(dst + TG_COFF(i));
+#pragma unroll
+        for (int i = 0; i < NCP; ++i)
+            if (TG_CLEAN(i)) *reinterpret_cast<uint4*>(prev + TG_COFF(i)) = pv[i];
+    }
+    uint4 tv[NCP];
+#pragma unroll
+    for (int i = 0; i < NCP; ++i)
+        if (TG_RESTORE(i)) tv[i] = *reinterpret_cast<const uint4*>(P.tmpl + TG_COFF(i));
+    // 4. reached blocks, eight per round, every wavefront a quarter of each
+    TG_STAMP(4);
+    unsigned long long left = reached;
+    while (left) {
+        int bq[2];
+        unsigned long long grp[2];                 // the blocks of this round's two groups
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int ids[4];
+            const unsigned long long before = left;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ids[k] = left ? (int)__builtin_ctzll(left) : -1;
+                left = left ? (left & (left - 1ull)) : 0ull;
+            }
+            grp[j] = before & ~left;
+            const int sub = lane >> 4;
+            bq[j] = sub == 0 ? ids[0] : (sub == 1 ? ids[1] : (sub == 2 ? ids[2] : ids[3]));
+        }
+        size_t off[2];
+        int qx[2];
+        float fy[2], z[2][4];
+        float4 nd[2];
+        uchar4 ng[2], bmk[2], old[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int b = bq[j] < 0 ? 0 : bq[j];
+            const int y = ry + (b / NBX) * BH + RQ * wave + lrow;
+            qx[j] = rx + (b % NBX) * BW + lcol;
+            fy[j] = (float)y + 0.5f;
+            off[j] = (size_t)y * P.W + qx[j];
+            nd[j] = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);      // no block: nothing passes the depth cull
+            ng[j] = make_uchar4(0, 0, 0, 0); bmk[j] = ng[j]; old[j] = ng[j];
+            if (bq[j] >= 0) {
+                nd[j] = *reinterpret_cast<const float4*>(nodef_dep + off[j]);
+                ng[j] = *reinterpret_cast<const uchar4*>(gray_u8 + off[j]);
+                bmk[j] = *reinterpret_cast<const uchar4*>(border + off[j]);
+                if (prev) old[j] = *reinterpret_cast<const uchar4*>(dst + off[j]);
+            }
+            z[j][0] = nd[j].x; z[j][1] = nd[j].y; z[j][2] = nd[j].z; z[j][3] = nd[j].w;
+        }
+        for (int t = 0; t < n; ++t) {
+            unsigned long long mt = reach_rec[t];
+            mt = __builtin_amdgcn_readfirstlane((unsigned)mt) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mt >> 32)) << 32);
+            if (!(mt & (grp[0] | grp[1]))) continue;            // the record reaches none of this round's blocks
+            const TriRec r = recs[t];
+            const float rA = TG_RL(q_A), rB = TG_RL(q_B), rmg = TG_RL(q_mg);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!(mt & grp[j])) continue;
+                if (fy[j] < r.ymin || fy[j] > r.ymax) continue;
+                if ((float)qx[j] + 3.5f < r.xmin || (float)qx[j] + 0.5f > r.xmax) continue;
+                const float zmax = fmaxf(fmaxf(z[j][0], z[j][1]), fmaxf(z[j][2], z[j][3]));
+                if (r.dmin >= zmax) continue;
+                // the record's depth plane over the quad's four pixel centres (see 1.): nowhere in front of what the quad holds -> no pixel can pass d < z
+                const float qlow = (r.d0 + rA * (((float)qx[j] + (rA >= 0.0f ? 0.5f : 3.5f)) - r.x0)) + rB * (fy[j] - r.y0);
+                if (qlow - rmg >= zmax) continue;
+                const float a0 = r.y2 - fy[j], a1 = r.y1 - fy[j], a2 = r.y0 - fy[j];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float fx = (float)(qx[j] + p) + 0.5f;
+                    const float e0 = (r.x1 - fx) * a0 - (r.x2 - fx) * a1;
+                    const float e1 = (r.x2 - fx) * a2 - (r.x0 - fx) * a0;
+                    const float e2 = (r.x0 - fx) * a1 - (r.x1 - fx) * a2;
+                    const bool box = (fx >= r.xmin) & (fx <= r.xmax);
+                    const bool pos = (e0 >= 0.0f) & (e1 >= 0.0f) & (e2 >= 0.0f), neg = (e0 <= 0.0f) & (e1 <= 0.0f) & (e2 <= 0.0f);
+                    const float s = (e0 + e1) + e2;
+                    const float d = div_mid_range((e0 * r.d0 + e1 * r.d1) + e2 * r.d2, s);
+                    const bool hit = box & (pos | neg) & (s != 0.0f) & (d < z[j][p]);
+                    z[j][p] = hit ? d : z[j][p];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (bq[j] < 0) continue;
+            const float ndv[4] = {nd[j].x, nd[j].y, nd[j].z, nd[j].w};
+            const uint8_t ngv[4] = {ng[j].x, ng[j].y, ng[j].z, ng[j].w}, bmv[4] = {bmk[j].x, bmk[j].y, bmk[j].z, bmk[j].w};
+            uint8_t o[4] = {0, 0, 0, 0};
+            if ((z[j][0] != ndv[0]) | (z[j][1] != ndv[1]) | (z[j][2] != ndv[2]) | (z[j][3] != ndv[3])) {   // an unchanged depth gives 0 below
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float diff = z[j][p] - ndv[p];
+                    if (diff >= -eps && diff <= eps) diff = 0.0f;
+                    const float pen = fabsf(diff);
+                    const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
+                    o[p] = (uint8_t)((cl / max_pen) * 255.0f);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (!P.turn_off_border && bmv[p] == 1) o[p] = ngv[p];
+            if (prev) *reinterpret_cast<uchar4*>(prev + off[j]) = old[j];
+            *reinterpret_cast<uchar4*>(dst + off[j]) = make_uchar4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    TG_STAMP(5);
+#pragma unroll
+    for (int i = 0; i < NCP; ++i)
+        if (TG_RESTORE(i)) *reinterpret_cast<uint4*>(dst + TG_COFF(i)) = tv[i];
+    TG_STAMP(6);
+#undef TG_RESTORE
+#undef TG_RL
+#undef TG_COFF
+#undef TG_CROW
+#undef TG_CLEAN
+}
+
 void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host) {
     for (int i = 0; i < npix; ++i) out_host[i] = (uint8_t)nodef_gray_host[i];   // the truncating cast of tactile_sensor.py:291-292
 }
@@ -844,6 +1193,15 @@ void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xfo
         if (S.kind == 0 && S.n_tris <= 256 && rec_cap >= 2 * S.n_tris) {
             // a small shared mesh (edge, cube, pole): every triangle fits the record buffer in one round -> the two-pass kernel with
             // 16 x 16 pass blocks on 128 x 64 tiles, whatever the launch size (16 384 envs: 0.75 -> 0.42 ms against 128 x 128 tiles)
+            // up to 32 triangles whose image is mostly the untouched sensor's (edge, cube): the block kernel; a stimulus that fills the view
+            // (the pole's plate: every block is drawn, nothing to skip) stays with the two-pass kernel below (256 x 256: 0.151 against 0.157 ms)
+            static const bool blocks_off = getenv("TG_NO_BLOCK_RASTER") != nullptr;   // A/B switch (parity test, measurements)
+            if (P.blockmax != nullptr && P.tmpl != nullptr && S.n_tris <= 32 && !S.fills_view && !blocks_off) {
+                dim3 gb((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
+                hipLaunchKernelGGL((k_render_blocks<kBlockW>), gb, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                                   nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+                return;
+            }
             dim3 grid((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
             if (S.skip_quad_reject)
                 hipLaunchKernelGGL((k_render_small<128, 64, 2, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,

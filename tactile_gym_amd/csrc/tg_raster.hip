@@ -853,9 +853,17 @@ void raster_debug_stats() {
     static int order[1024]; static unsigned long long endt[1024];
     for (int g = 0; g < 1024; ++g) { order[g] = g; endt[g] = 0; for (int w = 0; w < 4; ++w) if (h[(g * 4 + w) * 8 + 6] > endt[g]) endt[g] = h[(g * 4 + w) * 8 + 6]; endt[g] -= t0; }
     for (int i = 0; i < 1024; ++i) for (int j = i + 1; j < 1024; ++j) if (endt[order[j]] < endt[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
-    for (int i = 0; i < 1024; i += 64) fprintf(stderr, "   %llu %d %d |", endt[order[i]], nt[2 * order[i]], nt[2 * order[i] + 1]);
-    fprintf(stderr, "   %llu %d %d\n", endt[order[1023]], nt[2 * order[1023]], nt[2 * order[1023] + 1]);
-    double an = 0, aT = 0; for (int g = 0; g < 1024; ++g) { an += nt[2 * g]; aT += nt[2 * g + 1]; }
+    for (int i = 0; i < 1024; i += 64) fprintf(stderr, "   %llu %d %d |", endt[order[i]], nt[2 * order[i]] & 255, nt[2 * order[i] + 1]);
+    fprintf(stderr, "   %llu %d %d\n", endt[order[1023]], nt[2 * order[1023]] & 255, nt[2 * order[1023] + 1]);
+    fprintf(stderr, "  slowest 40 (end n T xcc se sh cu):");
+    for (int i = 1023; i > 983; --i) { const int v = nt[2 * order[i]]; fprintf(stderr, " %llu/%d/%d/x%d.s%d.h%d.c%d", endt[order[i]], v & 255, nt[2 * order[i] + 1], (v >> 8) & 15, (v >> 16) & 7, (v >> 20) & 1, (v >> 12) & 15); }
+    fprintf(stderr, "\n  mean end per xcc:");
+    for (int x = 0; x < 8; ++x) { double a = 0; int c = 0; for (int g = 0; g < 1024; ++g) if (((nt[2 * g] >> 8) & 15) == x) { a += (double)endt[g]; ++c; } fprintf(stderr, " x%d %.0f (%d)", x, c ? a / c : 0.0, c); }
+    fprintf(stderr, "\n  workgroups per (xcc, se, sh, cu): ");
+    { static int cnt[8 * 8 * 2 * 16]; for (int g = 0; g < 1024; ++g) { const int v = nt[2 * g]; ++cnt[((((v >> 8) & 15) * 8 + ((v >> 16) & 7)) * 2 + ((v >> 20) & 1)) * 16 + ((v >> 12) & 15)]; }
+      int hist[16] = {0}; for (int i = 0; i < 8 * 8 * 2 * 16; ++i) if (cnt[i] < 16) ++hist[cnt[i]]; for (int i = 0; i < 12; ++i) fprintf(stderr, " %d:%d", i, hist[i]); }
+    fprintf(stderr, "\n");
+    double an = 0, aT = 0; for (int g = 0; g < 1024; ++g) { an += nt[2 * g] & 255; aT += nt[2 * g + 1]; }
     fprintf(stderr, "  mean n %.2f mean T %.2f\n", an / 1024, aT / 1024);
 }
 #else
@@ -881,14 +889,18 @@ void raster_debug_stats() {}
 // 8192 wavefronts at 1024 envs, no wavefront whose share of the image is the whole contact patch.  The pixel arithmetic is that of the
 // other kernels, expression by expression; the depth test keeps the smallest d, so neither the record order nor the conservative skips
 // can change the image.
+#ifndef TG_BLK_NQ
+#define TG_BLK_NQ 3
+#endif
 template <int BW>
-__global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stimulus S, const float* __restrict__ xform, int xform_soa, int n_envs,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_blocks(RasterParams P, Stimulus S, const float* __restrict__ xform, int xform_soa, int n_envs,
                                                            const uint8_t* __restrict__ mask, const float* __restrict__ nodef_dep,
                                                            const uint8_t* __restrict__ gray_u8, const uint8_t* __restrict__ border,
                                                            uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int rec_cap,
                                                            const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
                                                            uint8_t* __restrict__ term_out) {
-    constexpr int BH = 256 / BW, LPR = BW / 4, NBX = 128 / BW, NPW = 16, RQ = BH / 4;   // NPW blocks per wavefront; RQ rows per block quarter
+    constexpr int BH = 256 / BW, LPR = BW / 4, NBX = 128 / BW, NPW = 16, RQ = BH / 4;
+    constexpr int NQ = TG_BLK_NQ;   // quads per lane in a drawing round: 4 NQ blocks per round   // NPW blocks per wavefront; RQ rows per block quarter
     static_assert(BW == kBlockW, "P.blockmax is laid out for kBlockW");
     extern __shared__ TriRec recs[];
     __shared__ int count;
@@ -915,10 +927,11 @@ __global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stim
 #pragma unroll
     for (int k = 0; k < 12; ++k) M[k] = xform_soa ? xf[(size_t)k * n_envs + env] : xf[(size_t)env * 12 + k];
     const float tx0 = (float)rx, tx1 = (float)(rx + 128), ty0 = (float)ry, ty1 = (float)(ry + 128);
+    // set-up: at most one triangle per lane, all in wavefront 0 (n_tris <= 32), so the vote that licenses the back-face cull (every vertex
+    // of the mesh beyond the near plane) is a ballot, and the record counter is cleared by the wavefront that then counts (LDS operations
+    // of one wavefront execute in order) - one workgroup barrier instead of four
     if (tid == 0) { count = 0; reach_all = 0ull; }
-    // set-up: at most one triangle per lane (n_tris <= 32), its clip-space vertices stay in registers across the vote that licenses the
-    // back-face cull (every vertex of the mesh beyond the near plane)
-    const bool has = tid < n_tris;
+    const bool has = tid < n_tris;                                 // (lanes of wavefront 0)
     float cx[3] = {0.0f, 0.0f, 0.0f}, cy[3] = {0.0f, 0.0f, 0.0f}, cw[3] = {0.0f, 0.0f, 0.0f};
     bool beyond = true;
     if (has) {
@@ -933,26 +946,39 @@ __global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stim
         }
     }
     TG_STAMP(0);
-    const bool cull = __syncthreads_and(beyond ? 1 : 0) != 0 && S.closed_outward != 0;   // (also the barrier after count = 0)
+    const bool cull = __ballot(!beyond) == 0ull && S.closed_outward != 0;      // wavefront 0: the vote; the others have nothing to cull
     TG_STAMP(1);
     if (has && !(cull && back_facing(cx, cy, cw))) {
-        float ox[4], oy[4], ow[4];
-        int no = 0;
+        if ((cw[0] >= P.near_) & (cw[1] >= P.near_) & (cw[2] >= P.near_)) {       // the usual case: nothing to clip (the loop below would
+            emit(recs, &count, rec_cap, cx, cy, cw, 0, 1, 2, P, tx0, ty0, tx1, ty1);   // hand over the same three vertices in the same order)
+        } else {
+            // near-plane clip, written out per case so that no array is indexed by a run-time count (that costs a scratch allocation): the
+            // vertex sequences are those of the loop in k_render_tactile - for edge k -> k + 1: vertex k if inside, then the crossing
+            const bool i0 = cw[0] >= P.near_, i1 = cw[1] >= P.near_, i2 = cw[2] >= P.near_;
+            float ix[3], iy[3];                                   // crossing of edge k -> (k + 1) % 3
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int k1 = (k + 1) % 3;
-            const bool ain = cw[k] >= P.near_, bin = cw[k1] >= P.near_;
-            if (ain) { ox[no] = cx[k]; oy[no] = cy[k]; ow[no] = cw[k]; ++no; }
-            if (ain != bin) {
+            for (int k = 0; k < 3; ++k) {
+                const int k1 = (k + 1) % 3;
                 const float tt = (P.near_ - cw[k]) / (cw[k1] - cw[k]);
-                ox[no] = cx[k] + tt * (cx[k1] - cx[k]);
-                oy[no] = cy[k] + tt * (cy[k1] - cy[k]);
-                ow[no] = P.near_;
-                ++no;
+                ix[k] = cx[k] + tt * (cx[k1] - cx[k]);
+                iy[k] = cy[k] + tt * (cy[k1] - cy[k]);
             }
+            const float nr = P.near_;
+            float ox[4] = {0.0f, 0.0f, 0.0f, 0.0f}, oy[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ow[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            int no = 0;
+#define TG_V(s, k) do { ox[s] = cx[k]; oy[s] = cy[k]; ow[s] = cw[k]; } while (0)
+#define TG_I(s, k) do { ox[s] = ix[k]; oy[s] = iy[k]; ow[s] = nr; } while (0)
+            if (i0 & !i1 & !i2) { TG_V(0, 0); TG_I(1, 0); TG_I(2, 2); no = 3; }
+            else if (!i0 & i1 & !i2) { TG_I(0, 0); TG_V(1, 1); TG_I(2, 1); no = 3; }
+            else if (!i0 & !i1 & i2) { TG_I(0, 1); TG_V(1, 2); TG_I(2, 2); no = 3; }
+            else if (i0 & i1 & !i2) { TG_V(0, 0); TG_V(1, 1); TG_I(2, 1); TG_I(3, 2); no = 4; }
+            else if (!i0 & i1 & i2) { TG_I(0, 0); TG_V(1, 1); TG_V(2, 2); TG_I(3, 2); no = 4; }
+            else if (i0 & !i1 & i2) { TG_V(0, 0); TG_I(1, 0); TG_I(2, 1); TG_V(3, 2); no = 4; }
+#undef TG_V
+#undef TG_I
+            if (no >= 3) emit(recs, &count, rec_cap, ox, oy, ow, 0, 1, 2, P, tx0, ty0, tx1, ty1);
+            if (no == 4) emit(recs, &count, rec_cap, ox, oy, ow, 0, 2, 3, P, tx0, ty0, tx1, ty1);
         }
-        if (no >= 3) emit(recs, &count, rec_cap, ox, oy, ow, 0, 1, 2, P, tx0, ty0, tx1, ty1);
-        if (no == 4) emit(recs, &count, rec_cap, ox, oy, ow, 0, 2, 3, P, tx0, ty0, tx1, ty1);
     }
     __syncthreads();
     TG_STAMP(2);
@@ -1003,14 +1029,18 @@ __global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stim
     if (drawn_p && tid == 0) *drawn_p = reached;
     TG_STAMP(3);
 #ifdef TG_BLK_STAMPS
-    if (tid == 0 && blockIdx.y < 1024 && blockIdx.x == 0 && blockIdx.z == 0) { g_blk_nt[2 * blockIdx.y] = n; g_blk_nt[2 * blockIdx.y + 1] = __builtin_popcountll(reached); }
+    if (tid == 0 && blockIdx.y < 1024 && blockIdx.x == 0 && blockIdx.z == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        g_blk_nt[2 * blockIdx.y] = n | ((xcc & 15) << 8) | (((hw >> 8) & 15) << 12) | (((hw >> 13) & 7) << 16) | (((hw >> 12) & 1) << 20);
+        g_blk_nt[2 * blockIdx.y + 1] = __builtin_popcountll(reached);
+    }
 #endif
     const unsigned long long restore = stale & ~reached;      // blocks to bring back to the untouched-sensor image
     const int lq = lane & 15, lrow = lq / LPR, lcol = 4 * (lq % LPR);     // this lane's quad inside a block quarter
     // 3. blocks nothing reaches show the untouched sensor's image.  A lane moves one 16-pixel row of one block as a 16-byte word; the lanes of
     //    an instruction are the NBX blocks across the region x (64 / NBX) consecutive rows, so an instruction writes whole 128-byte lines
     //    wherever a line's blocks are all unreached (4-byte words in 16 x 16 patterns measured 10.6 us for the 16.8 MB of 1024 envs).
-    //    Wavefront w owns the row groups w, w + 4, ...; loads here, stores after the drawing.
+    //    Wavefront w owns the row groups w, w + 4, ...
     static_assert(BW == 16, "one 16-byte word per block row");
     constexpr int RPI = 64 / NBX, NCP = 128 / RPI / 4;          // rows per instruction; copy instructions per wavefront
     const int cbx = lane % NBX, crow0 = lane / NBX;
@@ -1022,23 +1052,28 @@ __global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stim
         uint4 pv[NCP];
 #pragma unroll
         for (int i = 0; i < NCP; ++i)
-            if (TG_CLEAN(i)) pv[i] = *reinterpret_cast<const uint4*>(dst + TG_COFF(i));
+            pv[i] = *reinterpret_cast<const uint4*>(dst + TG_COFF(i));      // (every address is valid: only the stores are predicated)
 #pragma unroll
         for (int i = 0; i < NCP; ++i)
             if (TG_CLEAN(i)) *reinterpret_cast<uint4*>(prev + TG_COFF(i)) = pv[i];
     }
-    uint4 tv[NCP];
+    if (restore) {   // (rare once a contact is established: blocks the contact patch has left)
+        uint4 tv[NCP];
 #pragma unroll
-    for (int i = 0; i < NCP; ++i)
-        if (TG_RESTORE(i)) tv[i] = *reinterpret_cast<const uint4*>(P.tmpl + TG_COFF(i));
-    // 4. reached blocks, eight per round, every wavefront a quarter of each
+        for (int i = 0; i < NCP; ++i)
+            tv[i] = *reinterpret_cast<const uint4*>(P.tmpl + TG_COFF(i));
+#pragma unroll
+        for (int i = 0; i < NCP; ++i)
+            if (TG_RESTORE(i)) *reinterpret_cast<uint4*>(dst + TG_COFF(i)) = tv[i];
+    }
+    // 4. reached blocks, 4 NQ per round, every wavefront a quarter of each
     TG_STAMP(4);
     unsigned long long left = reached;
     while (left) {
-        int bq[2];
-        unsigned long long grp[2];                 // the blocks of this round's two groups
+        int bq[NQ];
+        unsigned long long grp[NQ], grp_any = 0ull;   // the blocks of this round's groups (four blocks each: a lane has one quad in each group)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NQ; ++j) {
             int ids[4];
             const unsigned long long before = left;
 #pragma unroll
@@ -1047,39 +1082,39 @@ __global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stim
                 left = left ? (left & (left - 1ull)) : 0ull;
             }
             grp[j] = before & ~left;
+            grp_any |= grp[j];
             const int sub = lane >> 4;
             bq[j] = sub == 0 ? ids[0] : (sub == 1 ? ids[1] : (sub == 2 ? ids[2] : ids[3]));
         }
-        size_t off[2];
-        int qx[2];
-        float fy[2], z[2][4];
-        float4 nd[2];
-        uchar4 ng[2], bmk[2], old[2];
+        size_t off[NQ];
+        int qx[NQ];
+        float fy[NQ], z[NQ][4];
+        uchar4 ng[NQ], bmk[NQ], old[NQ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NQ; ++j) {
             const int b = bq[j] < 0 ? 0 : bq[j];
             const int y = ry + (b / NBX) * BH + RQ * wave + lrow;
             qx[j] = rx + (b % NBX) * BW + lcol;
             fy[j] = (float)y + 0.5f;
             off[j] = (size_t)y * P.W + qx[j];
-            nd[j] = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);      // no block: nothing passes the depth cull
+            float4 nd = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);  // no block: nothing passes the depth cull
             ng[j] = make_uchar4(0, 0, 0, 0); bmk[j] = ng[j]; old[j] = ng[j];
             if (bq[j] >= 0) {
-                nd[j] = *reinterpret_cast<const float4*>(nodef_dep + off[j]);
+                nd = *reinterpret_cast<const float4*>(nodef_dep + off[j]);
                 ng[j] = *reinterpret_cast<const uchar4*>(gray_u8 + off[j]);
                 bmk[j] = *reinterpret_cast<const uchar4*>(border + off[j]);
                 if (prev) old[j] = *reinterpret_cast<const uchar4*>(dst + off[j]);
             }
-            z[j][0] = nd[j].x; z[j][1] = nd[j].y; z[j][2] = nd[j].z; z[j][3] = nd[j].w;
+            z[j][0] = nd.x; z[j][1] = nd.y; z[j][2] = nd.z; z[j][3] = nd.w;
         }
         for (int t = 0; t < n; ++t) {
             unsigned long long mt = reach_rec[t];
             mt = __builtin_amdgcn_readfirstlane((unsigned)mt) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mt >> 32)) << 32);
-            if (!(mt & (grp[0] | grp[1]))) continue;            // the record reaches none of this round's blocks
+            if (!(mt & grp_any)) continue;            // the record reaches none of this round's blocks
             const TriRec r = recs[t];
             const float rA = TG_RL(q_A), rB = TG_RL(q_B), rmg = TG_RL(q_mg);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NQ; ++j) {
                 if (!(mt & grp[j])) continue;
                 if (fy[j] < r.ymin || fy[j] > r.ymax) continue;
                 if ((float)qx[j] + 3.5f < r.xmin || (float)qx[j] + 0.5f > r.xmax) continue;
@@ -1104,10 +1139,19 @@ __global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stim
                 }
             }
         }
+        // the undeformed depths again (L2) rather than four more registers per quad held through the record loop (112 -> 100 VGPRs at NQ = 3;
+        // NQ = 4 - sixteen blocks per round - fits four wavefronts per SIMD this way and measured the same: a workgroup whose contact patch is
+        // twice the average has twice the arithmetic however its rounds are cut)
+        float4 nd2[NQ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NQ; ++j) {
+            nd2[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (bq[j] >= 0) nd2[j] = *reinterpret_cast<const float4*>(nodef_dep + off[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
             if (bq[j] < 0) continue;
-            const float ndv[4] = {nd[j].x, nd[j].y, nd[j].z, nd[j].w};
+            const float ndv[4] = {nd2[j].x, nd2[j].y, nd2[j].z, nd2[j].w};
             const uint8_t ngv[4] = {ng[j].x, ng[j].y, ng[j].z, ng[j].w}, bmv[4] = {bmk[j].x, bmk[j].y, bmk[j].z, bmk[j].w};
             uint8_t o[4] = {0, 0, 0, 0};
             if ((z[j][0] != ndv[0]) | (z[j][1] != ndv[1]) | (z[j][2] != ndv[2]) | (z[j][3] != ndv[3])) {   // an unchanged depth gives 0 below
@@ -1128,9 +1172,6 @@ __global__ __launch_bounds__(kThreads) void k_render_blocks(RasterParams P, Stim
         }
     }
     TG_STAMP(5);
-#pragma unroll
-    for (int i = 0; i < NCP; ++i)
-        if (TG_RESTORE(i)) *reinterpret_cast<uint4*>(dst + TG_COFF(i)) = tv[i];
     TG_STAMP(6);
 #undef TG_RESTORE
 #undef TG_RL

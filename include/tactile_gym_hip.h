@@ -208,7 +208,10 @@ int tg_step(tg_ctx* ctx, const float* actions, int32_t on_device);
 
 int tg_sync(tg_ctx* ctx);                                     /* VecEnv.step_wait(): wait for enqueued work */
 
-/* Device-resident results of the last step/reset (valid after tg_sync or on the context's stream). */
+/* Device-resident results of the last step/reset (valid after tg_sync or on the context's stream).
+ * The tactile observation buffer is READ-ONLY for the caller: for the edge / cube stimuli a render launch rewrites only the 16 x 16 pixel blocks
+ * whose content changes (those it draws, and those an earlier launch drew that now show the untouched sensor again), so bytes a caller wrote into
+ * it would survive into later observations.  TG_RASTER_REWRITE_ALL=1 in the environment makes every launch rewrite every block. */
 int tg_get_obs_tactile(tg_ctx* ctx, void** dev_ptr);           /* uint8 [num_envs][H][W][1] */
 int tg_get_terminal_obs(tg_ctx* ctx, void** dev_ptr);          /* uint8 [num_envs][H][W][1], rows valid where done */
 int tg_get_reward_done_dev(tg_ctx* ctx, void** reward_f32, void** done_u8);

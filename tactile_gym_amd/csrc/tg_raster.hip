@@ -15,14 +15,17 @@
 //     records in LDS; the pixel phase then reads each record as an LDS broadcast;
 //   * each lane owns quads of 4 horizontally adjacent pixels whose depth values stay in VGPRs (the z-buffer): depth reduction is a
 //     register min, the reference images are read as 16-byte vectors and the uint8 image is written as 4-byte vectors;
-//   * three kernels, chosen per stimulus by launch_render:
-//       k_render_small<128,64,2>   meshes of a few large triangles (edge, cube, pole): 128 x 64 tiles, the pixel phase in two passes over
-//                                  disjoint row groups (116-128 VGPRs, 4 workgroups per CU), a wavefront visits its 32-pixel column band
-//                                  as 16 x 16 pixel blocks so that passes which miss a record are skipped by the whole wavefront;
+//   * four kernels, chosen per stimulus by launch_render:
+//       k_render_blocks<16>        meshes of up to 32 triangles whose image is mostly the untouched sensor's (edge, cube): ONE workgroup per
+//                                  128 x 128 region, 16 x 16 pixel blocks, depth-plane block culls, only changed blocks written (see there);
+//       k_render_small<128,64,2>   the pole's plate (fills the view) and meshes of 33-256 triangles: 128 x 64 tiles, the pixel phase in two
+//                                  passes over disjoint row groups, a wavefront visits its 32-pixel column band as 16 x 16 pixel blocks so
+//                                  that passes which miss a record are skipped by the whole wavefront;
 //       k_render_tactile<128,64,true>   per-env heightfields: only the grid window the truncated view frustum can reach is staged
 //                                  (window-local LDS arrays) and culled, survivors are compacted, wavefront = 32-pixel band with per-record
 //                                  band / row-group masks (scalar skips), 3 wavefronts per SIMD;
-//       k_render_tactile<128,128,false> / <64,64,false>   everything else (the 960-triangle marble, 64 x 64 images): full-width rows.
+//       k_render_scatter / k_render_tactile<128,128,false> / <64,64,false>   everything else (the 960-triangle marble: triangle-parallel
+//                                  into an LDS z-buffer; 64 x 64 images): full-width rows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
@@ -872,23 +875,26 @@ void raster_debug_stats() {}
 #endif
 
 // Small shared meshes, block form (round 3): ONE workgroup per (env, 128 x 128 region) sets the triangles up once (at most 64 records:
-// meshes of up to 32 triangles - edge, cube, pole).  The region is 64 blocks of BW x (256 / BW) pixels.
+// meshes of up to 32 triangles - edge, cube).  The region is 64 blocks of BW x (256 / BW) pixels.
 //   1. lane-as-record: every lane keeps one record's bounding box, dmin and DEPTH PLANE.  Window depth is affine over a triangle,
 //      D(x, y) = d0 + A (x - x0) + B (y - y0), so its minimum over (block rectangle) n (record bounding box) sits at a corner.
-//   2. lane-as-block: the records are broadcast one by one (v_readlane) and each lane decides whether any of them can change a pixel of
-//      "its" block: bounding box, dmin against the block's largest undeformed depth (a host-made table; pasted ring pixels do not count),
-//      and the plane minimum less a margin (rounding of this estimate against the pixel formula, scaled by the triangle's conditioning
-//      = bounding-box area / twice its area; ill-conditioned records have no plane) against that depth less kGrey: t_s_camera maps a depth
-//      less than 0.05 / 255 = 1.96e-4 below the undeformed one to grey level 0, which is what the untouched-sensor image holds.  The
-//      ballot is the region's reached-block mask, the same in all four wavefronts.
-//   3. blocks nothing reaches are copies of the untouched-sensor image, 16 per wavefront, all loads in flight together.
-//   4. reached blocks are drawn by ALL four wavefronts together, eight blocks per round: wavefront w owns the w-th quarter of the rows of
-//      each, a lane two quads (one in each of two blocks) - whatever the contact patch looks like, the four wavefronts finish together,
-//      and the lanes of a visited record are in compact patches that mostly hit.
+//   2. lane-as-block: wavefront w broadcasts the records w, w + 4, ... (v_readlane) and each lane decides whether the record can change a
+//      pixel of "its" block: bounding box, dmin against the block's largest undeformed depth (a host-made table; pasted ring pixels do not
+//      count), and the plane minimum less a margin (rounding of this estimate against the pixel formula, scaled by the triangle's
+//      conditioning = bounding-box area / twice its area; ill-conditioned records have no plane) against that depth less kGrey: t_s_camera
+//      maps a depth less than 0.05 / 255 = 1.96e-4 below the undeformed one to grey level 0, which is what the untouched-sensor image
+//      holds.  The ballots (per record, in LDS) and their union are the region's reach masks.
+//   3. only CHANGED blocks are written: RasterParams::drawn records per image which blocks do not hold the untouched-sensor image; blocks
+//      reached now are drawn, blocks drawn by the launch before and not reached now are restored (16-byte words, whole 128-byte lines),
+//      everything else is left alone - the observation buffer is read-only for the caller (TG_RASTER_REWRITE_ALL=1: no record).
+//   4. reached blocks are drawn by ALL four wavefronts together, 4 NQ = 12 blocks per round: wavefront w owns the w-th quarter of the rows
+//      of each, a lane NQ quads (one in each of NQ block groups) - whatever the contact patch looks like, the four wavefronts finish
+//      together, and the lanes of a visited record are in compact patches that mostly hit.  Records that reach none of a group's blocks
+//      are skipped as scalar branches; a quad whose depth plane is nowhere in front of what it holds is skipped per lane.
 // Against k_render_small (two workgroups per image, each lane carrying 8 quads spread over its half): half the set-ups, 4096 instead of
-// 8192 wavefronts at 1024 envs, no wavefront whose share of the image is the whole contact patch.  The pixel arithmetic is that of the
-// other kernels, expression by expression; the depth test keeps the smallest d, so neither the record order nor the conservative skips
-// can change the image.
+// 8192 wavefronts at 1024 envs, no wavefront whose share of the image is the whole contact patch, a third of the HBM traffic.  The pixel
+// arithmetic is that of the other kernels, expression by expression; the depth test keeps the smallest d, so neither the record order
+// nor the conservative skips can change the image.  DESIGN.md 4.2 has the measurements and the per-phase timeline.
 #ifndef TG_BLK_NQ
 #define TG_BLK_NQ 3
 #endif

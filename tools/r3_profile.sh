@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence run on the MI355X box (one gpurun call): the default bench line (headline + other_configs + literal + CPU baseline),
 # one bench line per env, rocprofv3 kernel stats and SQ counters of the default command and of object_push / object_balance /
-# surface_follow-v2 (MG400, wave-mapped arm kernel) / the literal solver, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of
+# surface_follow-v2 (MG400, eight-sweep blocks) / the literal solver, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of
 # edge_follow, object_push and object_balance.  Outputs under gpurun_out/<tag>/; copied to profiles/<tag>_* afterwards (tools/r3_collect.py).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${TG_PROFILE_TAG:-r3_final}

@@ -283,6 +283,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
                          f"(or without a launcher: bench.py starts its own ranks)")
 
+    # stdout carries the ONE JSON line and nothing else: whatever native libraries write to file descriptor 1 (RCCL prints a five-line
+    # version banner there when its communicator comes up, flushed at exit, i.e. after the JSON) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from tactile_gym_amd.parallel import ShardedVecEnv
     if not torch.cuda.is_available():
@@ -321,15 +327,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def measure(transport, payload, warmup):
-        """reset + warm-up + the K timed steps through one exchange configuration; every rank learns whether any rank saw an error, and
+    def measure(transport, payload, warmup, steps=None):
+        """reset + warm-up + the K timed steps (or `steps`: a probe) through one exchange configuration; every rank learns whether any rank saw an error, and
         whether what rank 0 was handed is what the ranks rendered (byte sums of every rank's last tactile batch, outside the timed region)."""
         e = ShardedVecEnv(shard, dist, overlap=True, force_collective=force, payload=payload, transport=transport) if gathered else shard
         with w.on_stream():
             e.reset()
             for _ in range(warmup):
                 e.step(w.actions())
-            t = allmax(w.timed(e, args.steps, barrier, flush=e.flush if gathered else None))
+            t = allmax(w.timed(e, steps or args.steps, barrier, flush=e.flush if gathered else None))
             ok, why = True, None
             if gathered:
                 if os.environ.get("TG_BENCH_INJECT_EXCHANGE_FAULT") and getattr(e, "transport", None) == "ipc":
@@ -349,8 +355,33 @@ def main():
                         ok, why = False, "the batch rank 0 was handed differs from what the ranks rendered"
         return e, t, ok, why
 
-    env, dt, verified, fallback = None, None, None, None
-    env, dt, ok, why = measure(args.transport, args.payload, args.warmup)
+    env, dt, verified, fallback, probe = None, None, None, None, None
+    transport, payload = args.transport, args.payload
+    if gathered and transport == "auto" and payload == "auto":
+        # Nothing here has run across GPUs before the driver's run, so the choice between the two transports is made by measurement: a
+        # short probe of each (same envs, same steps), the timed K steps then go through the faster one that delivered a verified batch.
+        probe_steps = max(20, min(args.steps, 100))
+        probe, best = {"steps": probe_steps}, None
+        for tr in ("auto", "collective"):
+            if tr == "collective" and probe.get("ipc_unavailable"):
+                break
+            e, t, ok, why = measure(tr, "auto", min(args.warmup, 10), probe_steps)
+            name = f"{e.transport} + {e.payload}"
+            if tr == "auto" and e.transport != "ipc":
+                probe["ipc_unavailable"] = True                 # the set-up handshake failed on some rank: there is only the gather
+            probe[name] = {"ms_per_step": round(1e3 * t / probe_steps, 4), "verified": ok, **({"why": why} if why else {})}
+            if ok and (best is None or t < best[0]):
+                best = (t, e.transport, e.payload)
+            if not ok and e.transport == "ipc":
+                fallback = {"from": name, "why": why}           # the ipc transport did not deliver: the number comes from the RCCL gather
+            try:
+                e.close()
+            except Exception:  # noqa: BLE001
+                pass
+        if best is not None:
+            transport, payload = best[1], best[2]
+            probe["chosen"] = f"{transport} + {payload}"
+    env, dt, ok, why = measure(transport, payload, args.warmup)
     if gathered:
         verified = ok
         if not ok and env.transport == "ipc":
@@ -384,6 +415,8 @@ def main():
         exchange["verified"] = verified
         if fallback is not None:
             exchange["fallback"] = fallback
+        if probe is not None:
+            exchange["probe"] = probe
 
     solo = world == 1 and not force
     literal = None
@@ -453,7 +486,7 @@ def main():
                                    "draws": prof["scene"][1]}
         if solo and not args.no_cpu_baseline and args.env == "edge_follow-v0":
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if gathered and hasattr(env, "close"):
         env.close()
     w.close()

@@ -1284,6 +1284,7 @@ def test_bench_launches_under_torchrun_on_the_rccl_gather_path(env_id, size, por
     assert out.returncode == 0, out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    assert [l for l in out.stdout.splitlines() if l.strip()] == lines, "stdout must carry the JSON line only (RCCL's version banner goes to stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 60 and d["value"] > 0 and d["config"]["total_envs"] == 256
     assert d["roofline"]["frac"] > 0 and env_id in d["config"]["workload"]
@@ -1308,6 +1309,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert out.returncode == 0, out.stderr[-12000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    assert [l for l in out.stdout.splitlines() if l.strip()] == lines, "stdout must carry the JSON line only (RCCL's version banner goes to stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["exchange"]["verified"] is True and d["value"] > 0
 

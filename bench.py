@@ -18,7 +18,9 @@ companion run per remaining BASELINE config at 1024 envs on this GPU), roofline_
 Weak scaling: every rank owns --num-envs envs; rank 0 receives all observations / rewards / dones once per step (--payload: what the
 message carries, --transport: how it travels; parallel.py), started asynchronously so that it overlaps the next step's simulation
 (SURVEY 8e); the last exchange is waited for inside the timed region.  `no_gather` is the same K steps without the exchange (per-rank
-learners): compute scaling apart from the link bound.  Prints ONE JSON line on rank 0.
+learners): compute scaling apart from the link bound.  With the default --transport auto --payload auto the transport is chosen by a
+short probe of both (exchange.probe); an ipc exchange that reports an error falls back to the RCCL gather (exchange.fallback).
+Prints ONE JSON line on rank 0, and nothing else on stdout (native libraries' writes to fd 1 are sent to stderr).
 """
 import argparse
 import contextlib

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Builds libtg_host.so: the host half of the tile-sparse observation download (plain C; see tg_host_tiles.c).
+set -euo pipefail
+cd "$(dirname "$0")"
+mkdir -p ../lib
+${CC:-gcc} -O3 -std=c99 -shared -fPIC -Wall -Wextra tg_host_tiles.c -o ../lib/libtg_host.so
+echo "built ../lib/libtg_host.so"

@@ -1,0 +1,104 @@
+"""Tile-sparse observation download for the numpy VecEnv boundary (opt in: `venv.set_obs_transfer("tiles")`).
+
+What the reference's sb3_helpers consume is a numpy batch per `VecEnv.step_wait()` (sb3_helpers/rl_utils.py:17-30, stable-baselines3's
+rollout collection).  The plain path copies the whole uint8 batch device -> host every step (16.8 MB for 1024 x 128 x 128: the copy IS the
+step, 2.1 M env-steps/s).  Here the device packs only the 16 x 16 tiles that differ from the untouched sensor's image (`tg_pack_tiles`, the
+payload of the multi-GPU exchange), that message crosses PCIe into pinned memory, and `libtg_host.so` (host/tg_host_tiles.c, plain C)
+rebuilds the batch in one of four persistent host buffers: the tiles that buffer's previous frame had live get the template back, the new
+records land.  Lossless; the arrays handed out are ring buffers (untouched for the next three calls), like `copy_obs=False`.
+Needs torch (device buffers, the pinned staging area, the copy); there is no fallback: a missing library or torch raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .parallel import TILE_REC, TorchShard
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libtg_host.so")
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.isfile(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                               f"`tactile_gym_amd/host/build.sh` (gcc).")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.tg_host_unpack_tiles.restype = C.c_int64
+        L.tg_host_unpack_tiles.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.tg_host_fill_template.restype = C.c_int32
+        L.tg_host_fill_template.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        _host = L
+    return _host
+
+
+class HostTileBatch:
+    """One persistent host batch [n, H, W] and the list of its tiles that differ from the template; `apply(msg)` brings it to the frame a
+    tile message describes.  Pure host code (numpy + libtg_host.so): what the CPU tests drive."""
+
+    ERRORS = {-1: "bad argument", -2: "bad message header", -3: "message shorter than its record count says", -4: "tile id out of range"}
+
+    def __init__(self, tmpl, n, H, W, out=None):
+        self.n, self.H, self.W = int(n), int(H), int(W)
+        assert self.H % 16 == 0 and self.W % 16 == 0
+        self.tmpl = np.ascontiguousarray(np.asarray(tmpl, dtype=np.uint8).reshape(-1))
+        assert self.tmpl.size == self.H * self.W
+        self.batch = out if out is not None else np.empty((self.n, self.H, self.W), dtype=np.uint8)
+        assert self.batch.flags["C_CONTIGUOUS"] and self.batch.size == self.n * self.H * self.W and self.batch.dtype == np.uint8
+        self.prev = np.zeros(self.n * (self.H // 16) * (self.W // 16), dtype=np.int32)
+        self.n_prev = C.c_int64(0)
+        if host_lib().tg_host_fill_template(self.tmpl.ctypes.data, self.n, self.H, self.W, self.batch.ctypes.data) != 0:
+            raise RuntimeError("tg_host_fill_template failed")
+
+    def apply(self, msg):
+        msg = np.ascontiguousarray(msg)
+        rc = host_lib().tg_host_unpack_tiles(msg.ctypes.data, msg.nbytes, self.tmpl.ctypes.data, self.n, self.H, self.W, self.batch.ctypes.data,
+                                             self.prev.ctypes.data, C.byref(self.n_prev))
+        if rc < 0:
+            raise RuntimeError(f"tg_host_unpack_tiles: {self.ERRORS.get(int(rc), rc)}")
+        return int(rc)
+
+
+class TileDownload:
+    """The device -> host leg: pack on the device, two pinned copies (header, then exactly the records), rebuild on the host."""
+
+    RING = 4
+
+    def __init__(self, venv):
+        import torch
+        self.torch, self.venv = torch, venv
+        self.shard = TorchShard(venv)
+        n, H, W = venv.num_envs, venv.H, venv.W
+        if H % 16 or W % 16:
+            raise ValueError("obs_transfer='tiles' needs image sides that are multiples of 16")
+        dev = venv.tactile_torch().device
+        T = (H // 16) * (W // 16)
+        cap = 16 + TILE_REC * n * T
+        self.pk = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.counters = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.host_pk = torch.empty(cap, dtype=torch.uint8).pin_memory()
+        self.host_np = self.host_pk.numpy()
+        tmpl = self.shard.tile_template().cpu().numpy()
+        self.ring = [HostTileBatch(tmpl, n, H, W) for _ in range(self.RING)]
+        self.i = -1
+        self.last_bytes = 0
+
+    def fetch(self):
+        """The current observation batch as uint8 [n, H, W, 1] (one of four ring buffers)."""
+        torch, v = self.torch, self.venv
+        stream = torch.cuda.current_stream(self.pk.device)
+        self.shard.pack_tiles(self.pk.data_ptr(), self.counters)
+        self.host_pk[:16].copy_(self.pk[:16], non_blocking=True)
+        stream.synchronize()
+        count = int(self.host_np[:4].view(np.int32)[0])
+        nb = 16 + TILE_REC * count
+        if count:
+            self.host_pk[16:nb].copy_(self.pk[16:nb], non_blocking=True)
+            stream.synchronize()
+        self.i = (self.i + 1) % self.RING
+        hb = self.ring[self.i]
+        hb.apply(self.host_np[:nb])
+        self.last_bytes = nb
+        return hb.batch.reshape(v.num_envs, v.H, v.W, 1)

@@ -301,6 +301,8 @@ class TactileVecEnv(_VecEnvBase):
         """Host copy of the observation batch.  copy_obs=True: a new array per call.  copy_obs=False: the device -> host copy lands in
         one of four rotating host buffers (an extra 16.8 MB `.copy()` per step costs more than the PCIe transfer itself): the array stays
         untouched for the next three steps."""
+        if not terminal and getattr(self, "_tile_download", None) is not None:
+            return self._tile_download.fetch()
         if terminal or self.copy_obs:
             buf = np.empty_like(self._obs_host)
         else:
@@ -310,6 +312,20 @@ class TactileVecEnv(_VecEnvBase):
             buf = self._obs_ring[self._obs_ring_i]
         capi.check(self._L.tg_copy_obs_tactile(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint8)), int(terminal)))
         return buf
+
+    def set_obs_transfer(self, how):
+        """How `obs_mode="numpy"` observations cross PCIe.  "full" (default): the whole batch every step.  "tiles": only the 16 x 16 tiles
+        that differ from the untouched sensor's image, rebuilt on the host (host_tiles.py; lossless; needs torch and lib/libtg_host.so);
+        the batch handed out is then one of four ring buffers, untouched for the next three steps (as with copy_obs=False).  Terminal
+        observations always take the full copy."""
+        if how == "full":
+            self._tile_download = None
+        elif how == "tiles":
+            from .host_tiles import TileDownload
+            self._tile_download = TileDownload(self)
+        else:
+            raise ValueError(f"obs_transfer {how!r}: 'full' or 'tiles'")
+        return self
 
     def visual_torch(self, terminal=False):
         """Zero-copy torch.uint8 [N, H, W, 3] view of the device-resident scene-camera images."""

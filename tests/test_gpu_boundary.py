@@ -85,3 +85,34 @@ def test_make_vec_env_with_hipvecenv_equals_make_vec():
     sa, sb = a.get_state(), b.get_state()
     assert np.array_equal(sa["q"], sb["q"]) and np.array_equal(sa["edge_ang"], sb["edge_ang"])
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("env_id,modes,size,n", [("edge_follow-v0", EDGE, 128, 96), ("object_push-v0", PUSH, 128, 32), ("object_balance-v0", BAL, 256, 8)])
+def test_tile_download_hands_out_the_batch_the_full_copy_hands_out(env_id, modes, size, n):
+    """`set_obs_transfer("tiles")`: the numpy observations of a rollout with resets (device pack -> pinned copy of exactly the records ->
+    libtg_host.so rebuilding one of four persistent host buffers) equal the plain whole-batch copy byte for byte at every step, the ring
+    buffers stay untouched for three further steps, and fewer bytes cross PCIe than the batch holds (edge / push; the pole's plate fills
+    the view, so object_balance ships everything plus the record headers)."""
+    import tactile_gym_amd as tg
+    venv = tg.make_vec(env_id, num_envs=n, max_steps=7, image_size=[size, size], env_modes=modes, seed=21, auto_reset=True)
+    venv.set_obs_transfer("tiles")
+    rng = np.random.default_rng(2)
+    obs = venv.reset()
+    held = []
+    for step in range(20):
+        a = rng.uniform(-0.25, 0.25, size=(n, venv.act_dim)).astype(np.float32)
+        obs, rew, done, infos = venv.step(a)
+        got = obs["tactile"] if isinstance(obs, dict) else obs
+        dl, venv._tile_download = venv._tile_download, None
+        full = venv.tactile_numpy()
+        venv._tile_download = dl
+        assert got.shape == full.shape and np.array_equal(got, full), (env_id, step, int((got != full).sum()))
+        held.append((got, full.copy()))
+        for g, f in held[-4:]:
+            assert np.array_equal(g, f)            # the last four batches handed out are still what they were
+        if env_id != "object_balance-v0":
+            assert dl.last_bytes < full.size
+    assert len({g.ctypes.data for g, _ in held}) == 4          # four ring buffers, reused in turn
+    venv.set_obs_transfer("full")
+    obs, _, _, _ = venv.step(a)
+    venv.close()

@@ -5,6 +5,8 @@ import numpy as np, tactile_gym_amd as tg
 from bench import MODES
 n = 1024
 v = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=MODES, seed=1, auto_reset=True)
+if "--tiles" in sys.argv:
+    v.set_obs_transfer("tiles")       # only the 16 x 16 tiles that changed cross PCIe (host_tiles.py)
 v.reset()
 rng = np.random.default_rng(0)
 acts = rng.uniform(-0.25, 0.25, size=(64, n, 2)).astype(np.float32)
@@ -15,5 +17,5 @@ K = 100
 for k in range(K):
     obs, rew, done, info = v.step(acts[k % 64])
 dt = time.perf_counter() - t
-print(f"host-buffer path: {n * K / dt:.0f} env-steps/s, {1e3 * dt / K:.3f} ms/step, obs {obs['tactile'].shape} {obs['tactile'].dtype}")
+print(("tile download, " if "--tiles" in sys.argv else "") + f"host-buffer path: {n * K / dt:.0f} env-steps/s, {1e3 * dt / K:.3f} ms/step, obs {obs['tactile'].shape} {obs['tactile'].dtype}")
 v.close()

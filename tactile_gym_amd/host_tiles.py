@@ -62,7 +62,7 @@ class HostTileBatch:
 
 
 class TileDownload:
-    """The device -> host leg: pack on the device, two pinned copies (header, then exactly the records), rebuild on the host."""
+    """The device -> host leg: pack on the device, one pinned copy of the header and the records, rebuild on the host."""
 
     RING = 4
 
@@ -84,21 +84,33 @@ class TileDownload:
         self.ring = [HostTileBatch(tmpl, n, H, W) for _ in range(self.RING)]
         self.i = -1
         self.last_bytes = 0
+        self._last_count = 0
+        self.t_device = self.t_host = 0.0      # seconds spent in fetch(): pack + copy + synchronise / host rebuild
+        self.calls = 0
 
     def fetch(self):
         """The current observation batch as uint8 [n, H, W, 1] (one of four ring buffers)."""
+        import time
         torch, v = self.torch, self.venv
+        t0 = time.perf_counter()
         stream = torch.cuda.current_stream(self.pk.device)
         self.shard.pack_tiles(self.pk.data_ptr(), self.counters)
-        self.host_pk[:16].copy_(self.pk[:16], non_blocking=True)
+        # one copy + one synchronisation in the usual case: the header together with as many records as the last frame had, plus a quarter;
+        # a frame with more records than that fetches the rest in a second copy
+        guess = min(self.pk.numel(), 16 + TILE_REC * (self._last_count + self._last_count // 4 + 64))
+        self.host_pk[:guess].copy_(self.pk[:guess], non_blocking=True)
         stream.synchronize()
         count = int(self.host_np[:4].view(np.int32)[0])
         nb = 16 + TILE_REC * count
-        if count:
-            self.host_pk[16:nb].copy_(self.pk[16:nb], non_blocking=True)
+        if nb > guess:
+            self.host_pk[guess:nb].copy_(self.pk[guess:nb], non_blocking=True)
             stream.synchronize()
+        t1 = time.perf_counter()
+        self._last_count = count
         self.i = (self.i + 1) % self.RING
         hb = self.ring[self.i]
         hb.apply(self.host_np[:nb])
         self.last_bytes = nb
+        t2 = time.perf_counter()
+        self.t_device += t1 - t0; self.t_host += t2 - t1; self.calls += 1
         return hb.batch.reshape(v.num_envs, v.H, v.W, 1)

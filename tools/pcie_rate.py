@@ -18,4 +18,7 @@ for k in range(K):
     obs, rew, done, info = v.step(acts[k % 64])
 dt = time.perf_counter() - t
 print(("tile download, " if "--tiles" in sys.argv else "") + f"host-buffer path: {n * K / dt:.0f} env-steps/s, {1e3 * dt / K:.3f} ms/step, obs {obs['tactile'].shape} {obs['tactile'].dtype}")
+if "--tiles" in sys.argv:
+    d = v._tile_download
+    print(f"  per fetch: pack + copy + sync {1e3 * d.t_device / d.calls:.3f} ms, host rebuild {1e3 * d.t_host / d.calls:.3f} ms, {d.last_bytes} bytes in the last message")
 v.close()

@@ -561,7 +561,7 @@ class HipVecEnv:
     it makes names its class and constructor arguments, and ONE N-env device context is built from them with env i seeded seed + i (the
     seeds the N constructors would have used).  The per-env Monitor's bookkeeping is done on the device: every step's info carries
     info["episode"] = {"r", "l", "t"} for the envs that finished (what SB3's logger and EvalCallback read).  Extra keyword arguments
-    (vec_env_kwargs: obs_mode, copy_obs, physics_dtype, device ...) go to the vectorised constructor; start_method is accepted and
+    (vec_env_kwargs: obs_mode, copy_obs, physics_dtype, device, obs_transfer ...) go to the vectorised constructor; start_method is accepted and
     ignored.  The result is a TactileVecEnv (an SB3 VecEnv subclass wherever SB3 is importable), not an instance of this class."""
 
     def __new__(cls, env_fns, start_method=None, **kwargs):
@@ -588,8 +588,12 @@ class HipVecEnv:
             raise TypeError(f"HipVecEnv: the constructors make {type(single).__name__}, not one of this package's envs "
                             f"(register ids with `import tactile_gym_amd` and pass one of tactile_gym_amd.registered_ids())")
         ctor = dict(single._ctor)
+        obs_transfer = kwargs.pop("obs_transfer", None)   # vec_env_kwargs=dict(obs_transfer="tiles"): the tile-sparse observation download
         ctor.update(kwargs)
         seed = single._seed                          # make_vec_env's make_env(rank) called env.seed(seed + rank): rank 0 -> the base seed
         env_cls = type(single)
         probe.close()
-        return env_cls.make_vec(num_envs=len(env_fns), seed=seed, **ctor)
+        venv = env_cls.make_vec(num_envs=len(env_fns), seed=seed, **ctor)
+        if obs_transfer is not None:
+            venv.set_obs_transfer(obs_transfer)
+        return venv

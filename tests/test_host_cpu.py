@@ -374,6 +374,10 @@ def test_hipvecenv_is_a_vec_env_cls_for_make_vec_env(monkeypatch, edge_modes):
         def close(self):
             self.closed = True
 
+        def set_obs_transfer(self, how):
+            self.transfer = how
+            return self
+
     monkeypatch.setattr(ef.EdgeFollowEnv, "vec_cls", Recorder)
     venv = sb3_like_make_vec_env("edge_follow-v0", n_envs=6, seed=40, env_kwargs=dict(max_steps=77, image_size=[128, 128], env_modes=edge_modes),
                                  vec_env_cls=tg.HipVecEnv, vec_env_kwargs=dict(obs_mode="torch"))
@@ -384,6 +388,11 @@ def test_hipvecenv_is_a_vec_env_cls_for_make_vec_env(monkeypatch, edge_modes):
     assert batch.args["num_envs"] == 6 and batch.args["seed"] == 40 and batch.args["auto_reset"] is True      # VecEnv semantics: auto-reset
     assert batch.args["max_steps"] == 77 and batch.args["image_size"] == [128, 128] and batch.args["env_modes"] == edge_modes
     assert batch.args["obs_mode"] == "torch"                  # vec_env_kwargs reach the vectorised constructor
+    assert "obs_transfer" not in batch.args and not hasattr(batch, "transfer")
+    made.clear()
+    venv = sb3_like_make_vec_env("edge_follow-v0", n_envs=3, seed=1, env_kwargs=dict(env_modes=edge_modes), vec_env_cls=tg.HipVecEnv,
+                                 vec_env_kwargs=dict(obs_transfer="tiles"))
+    assert venv.transfer == "tiles" and "obs_transfer" not in venv.args      # the tile download is switched on after construction
     with pytest.raises(TypeError):
         tg.HipVecEnv([lambda: object()])
     with pytest.raises(ValueError):

@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 8
+#define TG_ABI_VERSION 9
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -181,7 +181,24 @@ typedef struct {
      * TG_CONTACT_MAP_LANE: one lane per env (fewer instructions per env, better once every SIMD is busy); AUTO picks by num_envs.
      * Same solver, same row order; results agree to rounding (f64), contact sets exactly. */
     int32_t contact_mapping;                /* TG_CONTACT_MAP_* */
+    /* edge_follow / surface_follow with auto_reset: the reset of these envs (edge_follow_env.py:311-336, base_surface_env.py:616-662,
+     * robot.py:114-125) is a pure function of the env's RNG stream, so every env's NEXT post-reset state is computed ahead of time on a
+     * second low-priority stream ("reset bank") and a finished env takes it inside the step instead of stalling the batch for its blocking
+     * move.  Results are identical with the bank on, off, or not ready in time (the same reset code either way).
+     * TG_BANK_AUTO: on for the MG400 (its blocking move stalls a 1024-env batch for 9-11 ms per full-batch reset; measured 0.126 -> 1.13 M
+     * env-steps/s on surface_follow-v2), off for the UR5 (a full-batch reset costs 0.12 ms per 200 steps, less than what the refill launches
+     * cost the steps they run beside); TG_BANK_ON: on; TG_BANK_OFF: every reset on the spot; TG_BANK_SYNC: on, and the refill is waited for
+     * after every step (tests: the bank is always ready).  The environment variable TG_RESET_BANK (0 / 1 / sync) overrides. */
+    int32_t reset_bank;                     /* TG_BANK_* */
+    /* object_push: narrowphase of the tip-cube pair (stepSimulation's collision detection, robot.py:141).  TG_NARROW_CLOSED_FORM: the
+     * deepest point of the tip's convex hull against the cube's faces in closed form, ONE contact point per tick (PARITY A24);
+     * TG_NARROW_GJK_MANIFOLD: support-mapping GJK distance + EPA penetration on the hull and the box, fed into a persistent manifold of up
+     * to 4 points with Bullet's add / replace / break rules (PARITY A35-A38). */
+    int32_t narrowphase;                    /* TG_NARROW_* */
 } tg_config;
+
+enum { TG_BANK_AUTO = 0, TG_BANK_OFF = 1, TG_BANK_SYNC = 2, TG_BANK_ON = 3 };
+enum { TG_NARROW_CLOSED_FORM = 0, TG_NARROW_GJK_MANIFOLD = 1 };
 
 typedef struct tg_ctx tg_ctx;
 
@@ -226,6 +243,9 @@ int tg_get_packed_outputs(tg_ctx* ctx, void** dev_ptr, int64_t* obs_bytes, int64
  * context only supplies the sensor constants): src uint8 [n_images][k] -> dst uint8 [n_images][H*W] with the ring restored.  Both are
  * enqueued on the context's stream.  *k = -1 with turn_off_border (the ring then carries rendered values). */
 int tg_get_interior_count(tg_ctx* ctx, int32_t* k);
+/* Reset bank (tg_config.reset_bank): how many auto-resets so far took a precomputed entry (*swapped) and how many were done on the spot because
+ * the entry was not ready (*late); *mode = 0 bank off, 1 on, 2 on and waited for.  Synchronises the context's stream. */
+int tg_get_bank_stats(tg_ctx* ctx, int64_t* swapped, int64_t* late, int32_t* mode);
 int tg_pack_interior(tg_ctx* ctx, void* dst_dev);
 int tg_unpack_interior(tg_ctx* ctx, const void* src_dev, int32_t n_images, void* dst_dev);
 /* ---- tile-sparse tactile payload and direct stores into rank 0's memory (csrc/tg_exchange.hip) ------------------------------------

@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +26,8 @@ NOISE = {"fixed_height": 0, "rand_height": 1}
 REWARD = {"dense": 0, "sparse": 1}
 PHYSICS = {"f64": 0, "f32": 1}
 CONTACT_MAP = {"auto": 0, "lane": 1, "wave": 2}
+RESET_BANK = {"auto": 0, "off": 1, "sync": 2, "on": 3}
+NARROWPHASE = {"closed_form": 0, "gjk_manifold": 1}
 MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
 
 _d3 = C.c_double * 3
@@ -99,7 +101,7 @@ class TgConfig(C.Structure):
         ("roll_rand_init_pos", C.c_int32), ("roll_rand_size", C.c_int32), ("roll_rand_embed", C.c_int32),
         ("roll_radius", C.c_double), ("roll_init_range", C.c_double), ("roll_goal_lo", C.c_double), ("roll_goal_hi", C.c_double),
         ("tip_cyl_pos", _d3), ("tip_cyl_rot", _d9), ("tip_cyl_half_len", C.c_double), ("tip_cyl_radius", C.c_double),
-        ("contact_mapping", C.c_int32),
+        ("contact_mapping", C.c_int32), ("reset_bank", C.c_int32), ("narrowphase", C.c_int32),
     ]
 
 
@@ -138,6 +140,7 @@ SYMBOLS = {
     "tg_get_packed_feature": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_sample_actions": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
+    "tg_get_bank_stats": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_pack_interior": (C.c_int, [_ctx, C.c_void_p]),
     "tg_unpack_interior": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p]),
     "tg_get_episode_stats": (C.c_int, [_ctx, _vpp, _vpp]),

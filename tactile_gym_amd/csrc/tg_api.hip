@@ -14,6 +14,7 @@
 #include <map>
 #include <string>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/tactile_gym_hip.h"
@@ -397,6 +398,16 @@ struct tg_ctx {
     const float* step_graph_actions[2] = {nullptr, nullptr};
     hipStream_t step_graph_stream[2] = {nullptr, nullptr};
     bool graph_broken = false;
+    // reset bank (edge_follow / surface_follow, auto_reset; tg_kernels.hpp: BankAux)
+    tg::State bk{};                    // the bank view: st's layout, the reset-written arrays in allocations of the bank's own
+    tg::BankAux aux{};
+    int bank_mode = 0;                 // 0 off, 1 refills on bank_stream every bank_every steps, 2 as 1 and waited for (tests)
+    int bank_every = 8;
+    long long bank_steps = 0;
+    hipStream_t bank_stream = nullptr;
+    hipEvent_t ev_bank = nullptr, ev_bank_done = nullptr;
+    std::vector<void*> bank_allocs;
+    void* d_bank = nullptr;            // BankDev {bk, aux} in device memory (k_reset's argument)
     // profiling
     bool profile = false;
     struct Ev { hipEvent_t a, b; int which; };
@@ -478,10 +489,15 @@ template <typename T, int TOPO> static void launch_step_t(tg_ctx* c, const float
         hipLaunchKernelGGL((k_step<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
                            (const EnvConst<T>*)c->d_const, c->st, d_actions);
 }
-template <typename T, int TOPO> static void launch_reset_t(tg_ctx* c, const uint8_t* d_mask, int phase) {
+template <typename T, int TOPO> static void launch_reset_t(tg_ctx* c, const uint8_t* d_mask, int phase, bool bank = false) {
     const int n = c->cfg.num_envs;
     hipLaunchKernelGGL((k_reset<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st, d_mask, phase);
+                       (const EnvConst<T>*)c->d_const, c->st, d_mask, phase, bank ? (const BankDev*)c->d_bank : (const BankDev*)nullptr);
+}
+template <typename T, int TOPO> static void launch_bank_refill_t(tg_ctx* c, int phase) {
+    const int n = c->cfg.num_envs;
+    hipLaunchKernelGGL((k_bank_refill<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->bank_stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, c->bk, c->aux, phase);
 }
 template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
     const int n = c->cfg.num_envs;
@@ -616,8 +632,9 @@ static int need_device() {
 
 // env.reset() for the masked envs: task randomisation, (surface generation), robot reset.
 // tg_sample_actions: element i of draw `counter`: 24 random bits of splitmix64 over (seed, counter, i) -> lo + (hi - lo) u, u in [0, 1)
-__global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, float lo, float hi, float* __restrict__ out) {
+__global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, float lo, float hi, float* __restrict__ out, unsigned long long* tl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    TG_TL(tl, 0);
     if (i >= total) return;
     const uint64_t z = mix64(mix64(seed + kGolden * (counter + 1)) + kGolden * (uint64_t)(i + 1));
     const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
@@ -682,8 +699,34 @@ static bool use_arm_wave(const tg_ctx* c) {
     return c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE;
 }
 
-static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
+static int surf_gen_mode(const tg_ctx* c) {
+    return c->cfg.noise_mode == TG_SNOISE_NONE ? TG_SURF_FLAT : c->cfg.noise_mode == TG_SNOISE_RANDOM ? TG_SURF_RANDOM
+           : c->cfg.noise_mode == TG_SNOISE_VERTICAL_SIMPLEX ? TG_SURF_SIMPLEX_1D_VERT
+           : (c->cfg.movement_mode == TG_SMOVE_YZ || c->cfg.movement_mode == TG_SMOVE_YZRX) ? TG_SURF_SIMPLEX_1D : TG_SURF_SIMPLEX_2D;
+}
+
+// bank: the auto-reset of tg_step with the reset bank on (k_reset mode 1): finished envs take their precomputed state, the rest (aux.late)
+// are reset by the launches that follow
+static void reset_sequence(tg_ctx* c, const uint8_t* d_mask, bool bank = false) {
     Timer t(c, 2);
+    if (bank && c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 1, true)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+        launch_gen_surface(c->cfg.num_envs, c->aux.late, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
+                           c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->st.heights, c->st.surf_zoff, c->stream,
+                           c->aux.swapped, c->bk.heights);
+#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, c->aux.late, 2, true)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+        return;
+    }
+    if (bank && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {
+#define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 0, true)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+        return;
+    }
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
         if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_reset_body_t<double>(c, d_mask);
         else launch_reset_body_t<float>(c, d_mask);
@@ -709,11 +752,7 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
         launch_gen_surface(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
-                           c->cfg.surf_height_range, c->cfg.surf_center_z,
-                           c->cfg.noise_mode == TG_SNOISE_NONE ? TG_SURF_FLAT : c->cfg.noise_mode == TG_SNOISE_RANDOM ? TG_SURF_RANDOM
-                           : c->cfg.noise_mode == TG_SNOISE_VERTICAL_SIMPLEX ? TG_SURF_SIMPLEX_1D_VERT
-                           : (c->cfg.movement_mode == TG_SMOVE_YZ || c->cfg.movement_mode == TG_SMOVE_YZRX) ? TG_SURF_SIMPLEX_1D : TG_SURF_SIMPLEX_2D,
-                           c->st.heights, c->st.surf_zoff, c->stream);
+                           c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->st.heights, c->st.surf_zoff, c->stream);
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 2)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
@@ -721,6 +760,34 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask) {
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 0)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
+    }
+}
+
+// The refill of the reset bank: outside the step graph, on the bank's low-priority stream, behind an event of the step just enqueued (so
+// the host running ahead of the device cannot spend all its refills before the episodes they are for have ended).  It never blocks the
+// stream the steps run on; the only data-path ordering between the two streams is the tag / RNG acquire-release pair (tg_kernels.hpp).
+static void bank_refill(tg_ctx* c) {
+    if (c->bank_mode == 0) return;
+    if ((c->bank_steps++ % c->bank_every) != 0 && c->bank_mode != 2) return;
+    (void)hipEventRecord(c->ev_bank, c->stream);
+    (void)hipStreamWaitEvent(c->bank_stream, c->ev_bank, 0);
+    if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+#define CALL(T, TOPO) launch_bank_refill_t<T, TOPO>(c, 1)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+        launch_gen_surface(c->cfg.num_envs, c->aux.need, c->bk.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
+                           c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->bk.heights, c->bk.surf_zoff, c->bank_stream);
+#define CALL(T, TOPO) launch_bank_refill_t<T, TOPO>(c, 2)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    } else {
+#define CALL(T, TOPO) launch_bank_refill_t<T, TOPO>(c, 0)
+        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+#undef CALL
+    }
+    if (c->bank_mode == 2) {   // tests: every finished env finds its entry ready (the step stream waits for the refill)
+        (void)hipEventRecord(c->ev_bank_done, c->bank_stream);
+        (void)hipStreamWaitEvent(c->stream, c->ev_bank_done, 0);
     }
 }
 
@@ -961,9 +1028,61 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     s.ep_final_return = (float*)(c->d_episode + (size_t)n * 8);
     s.ep_final_len = (int32_t*)(c->d_episode + (size_t)n * 12);
     TG_HIP(hipMalloc(&c->d_mask, n));
+#ifdef TG_TL_STAMPS
+    TG_HIP(hipMalloc(&s.tl, (4 * 8192 + 4) * 8)); TG_HIP(hipMemset(s.tl, 0, (4 * 8192 + 4) * 8));
+#endif
     TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 6 * sizeof(float)));
     c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border, sensor->nodef_dep);
     if (make_block_tables(c->rp, sensor->nodef_dep, sensor->nodef_gray, sensor->border_mask, n, &c->d_block_tables)) return fail(-2, "hipMalloc failed (raster block tables)");
+#ifdef TG_TL_STAMPS
+    c->rp.tl = s.tl;
+#endif
+    c->bk = s;
+    {   // reset bank: edge_follow / surface_follow with auto_reset on the lane mapping (tg_config.reset_bank, TG_RESET_BANK)
+        int want = cfg->reset_bank == TG_BANK_OFF ? 0 : cfg->reset_bank == TG_BANK_SYNC ? 2 : cfg->reset_bank == TG_BANK_ON ? 1 : (robot->topology == 1 ? 1 : 0);
+        if (const char* e = getenv("TG_RESET_BANK")) want = (e[0] == '0') ? 0 : (e[0] == 's') ? 2 : 1;
+        if (const char* e = getenv("TG_RESET_BANK_EVERY")) { const int k = atoi(e); if (k >= 1) c->bank_every = k; }
+        const bool kind_ok = cfg->env_kind == TG_ENV_EDGE_FOLLOW || cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO;
+        if (want && kind_ok && cfg->auto_reset && !use_arm_wave(c)) {
+            State& b = c->bk;
+            auto grab = [&](auto*& ptr, size_t bytes) -> int {
+                void* p_ = nullptr;
+                if (hipMalloc(&p_, bytes) != hipSuccess) return -1;
+                (void)hipMemset(p_, 0, bytes);
+                c->bank_allocs.push_back(p_);
+                ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(p_);
+                return 0;
+            };
+            int bad = 0;
+            bad |= grab(b.q, nd * 8); bad |= grab(b.qd, nd * 8); bad |= grab(b.qd_target, nd * 8);
+            bad |= grab(b.tcp_pos, (size_t)3 * n * 8); bad |= grab(b.tcp_rpy, (size_t)3 * n * 8);
+            bad |= grab(b.edge_ang, (size_t)n * 8); bad |= grab(b.embed, (size_t)n * 8); bad |= grab(b.edge_sc, (size_t)2 * n * 8);
+            bad |= grab(b.stim_xform, (size_t)12 * n * 4);
+            bad |= grab(b.step_count, (size_t)n * 4); bad |= grab(b.reset_ticks, (size_t)n * 4); bad |= grab(b.licence, (size_t)n * 4);
+            bad |= grab(b.rng, (size_t)n * 8);
+            if (cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+                const size_t cells = (size_t)cfg->surf_rows * cfg->surf_cols;
+                bad |= grab(b.dir, (size_t)2 * n * 8); bad |= grab(b.goal, (size_t)3 * n * 8); bad |= grab(b.heights, cells * n * 8);
+                bad |= grab(b.accum, (size_t)n * 8); bad |= grab(b.surf_zoff, (size_t)n * 4); bad |= grab(b.noise_seed, (size_t)n * 8);
+                if (s.feature) bad |= grab(b.feature, (size_t)12 * n * 4);
+            }
+            bad |= grab(c->aux.tag, (size_t)n * 8); bad |= grab(c->aux.rng_in, (size_t)n * 8);
+            bad |= grab(c->aux.stats, 16);
+            bad |= grab(c->aux.need, (size_t)n); bad |= grab(c->aux.late, (size_t)n); bad |= grab(c->aux.swapped, (size_t)n);
+            if (bad) return fail(-2, "hipMalloc failed (reset bank)");
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = the least priority
+            if (getenv("TG_BANK_PRIO0")) lo = 0;
+            TG_HIP(hipStreamCreateWithPriority(&c->bank_stream, hipStreamNonBlocking, lo));
+            TG_HIP(hipEventCreateWithFlags(&c->ev_bank, hipEventDisableTiming)); TG_HIP(hipEventCreateWithFlags(&c->ev_bank_done, hipEventDisableTiming));
+            c->aux.enabled = 1;
+            c->bank_mode = want;
+            BankDev hb{c->bk, c->aux};
+            bad |= grab(c->d_bank, sizeof hb);
+            if (bad) return fail(-2, "hipMalloc failed (reset bank)");
+            TG_HIP(hipMemcpy(c->d_bank, &hb, sizeof hb, hipMemcpyHostToDevice));
+        }
+    }
     return 0;
 }
 
@@ -982,6 +1101,27 @@ int tg_destroy(tg_ctx* c) {
     drain_events(c);
     if (c->scene_on) scene_debug_stats();
     raster_debug_stats();
+#ifdef TG_TL_STAMPS
+    if (c->st.tl) {
+        std::vector<unsigned long long> h(4 * 8192 + 4);
+        if (hipMemcpy(h.data(), c->st.tl, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            const unsigned long long cnt = h[4 * 8192 + 1];   // k_step launches
+            if (cnt > 600 && h[4 * 8192 + 0] == cnt) {
+                // the last 500 steps: mean interval sampler -> k_step -> k_reset -> render -> next sampler (10 ns ticks)
+                double d[4] = {0, 0, 0, 0}; int m = 0;
+                const bool has_reset = h[4 * 8192 + 2] >= cnt;
+                const unsigned long long roff = h[4 * 8192 + 2] - cnt, qoff = h[4 * 8192 + 3] - cnt;   // resets / renders issued before the first step
+                for (unsigned long long s_ = cnt - 501; s_ + 1 < cnt; ++s_) {
+                    const unsigned long long a = h[0 * 8192 + (s_ & 8191)], b = h[1 * 8192 + (s_ & 8191)], r = has_reset ? h[2 * 8192 + ((s_ + roff) & 8191)] : 0,
+                                             q = h[3 * 8192 + ((s_ + qoff) & 8191)], a2 = h[0 * 8192 + ((s_ + 1) & 8191)];
+                    d[0] += (double)(b - a); d[1] += has_reset ? (double)(r - b) : 0.0; d[2] += (double)(q - (has_reset ? r : b)); d[3] += (double)(a2 - q); ++m;
+                }
+                fprintf(stderr, "TL (%d steps, starts): sampler->k_step %.2f us, k_step->k_reset %.2f us, ->render %.2f us, render->next sampler %.2f us, sum %.2f us\n", m,
+                        d[0] / m / 100.0, d[1] / m / 100.0, d[2] / m / 100.0, d[3] / m / 100.0, (d[0] + d[1] + d[2] + d[3]) / m / 100.0);
+            }
+        }
+    }
+#endif
 #ifdef TG_KSTEP_STAMPS
     { unsigned long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_kstep_stamps), sizeof h) == hipSuccess) { fprintf(stderr, "k_step stamps (cycles from start, full=%llu):", h[15]); for (int i = 1; i < 13; ++i) fprintf(stderr, " [%d] %lld", i, (long long)(h[i] - h[0])); fprintf(stderr, "\n"); } }
 #endif
@@ -992,6 +1132,10 @@ int tg_destroy(tg_ctx* c) {
                     c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->bank_stream) { (void)hipStreamSynchronize(c->bank_stream); (void)hipStreamDestroy(c->bank_stream); }
+    if (c->ev_bank) (void)hipEventDestroy(c->ev_bank);
+    if (c->ev_bank_done) (void)hipEventDestroy(c->ev_bank_done);
+    for (void* p_ : c->bank_allocs) (void)hipFree(p_);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream);
@@ -1068,7 +1212,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     if (c->scene_every_step) scene_draw(c, nullptr, false);
     if (c->oracle_every_step) oracle_draw(c, c->cfg.auto_reset ? c->d_oracle_term : c->d_oracle);   // the step's own vectors, before any reset
     if (c->cfg.auto_reset && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {
-        reset_sequence(c, c->st.done); // k_reset keeps the terminal camera transform of the envs it resets
+        reset_sequence(c, c->st.done, c->bank_mode != 0); // k_reset keeps the terminal camera transform of the envs it resets
         render_fused(c);               // one launch draws the terminal and the post-reset observations
     } else if (c->cfg.auto_reset && c->aux_stream) {
         // object_balance: a pole falls somewhere in the batch on nearly every step, and its reset (rest pose, blocking move, settling: a
@@ -1094,7 +1238,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     } else {
         render(c, nullptr, false);
         if (c->cfg.auto_reset) {
-            reset_sequence(c, c->st.done);
+            reset_sequence(c, c->st.done, c->bank_mode != 0);
             render(c, c->st.done, true);   // terminal observation is saved, then the post-reset observation is drawn
         }
     }
@@ -1155,10 +1299,12 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
         }
         if (c->step_graph[slot]) {
             TG_HIP(hipGraphLaunch(c->step_graph[slot], c->stream));
+            bank_refill(c);
             return 0;
         }
     }
     enqueue_step(c, d_act);
+    bank_refill(c);
     TG_HIP(hipGetLastError());
     return 0;
 }
@@ -1168,6 +1314,18 @@ int tg_get_interior_count(tg_ctx* c, int32_t* k) {
     *k = c->cfg_turn_off_border ? -1 : 4 * c->n_interior;   // bytes per image; -1: the ring carries rendered values (turn_off_border), nothing to drop
     return 0;
 }
+int tg_get_bank_stats(tg_ctx* c, int64_t* swapped, int64_t* late, int32_t* mode) {
+    if (!c || !swapped || !late || !mode) return fail(-1, "NULL argument");
+    TG_ENTER(c);
+    *swapped = 0; *late = 0; *mode = c->bank_mode;
+    if (c->bank_mode == 0) return 0;
+    unsigned long long h[2] = {0, 0};
+    TG_HIP(hipMemcpyAsync(h, c->aux.stats, 16, hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
+    *swapped = (int64_t)h[0]; *late = (int64_t)h[1];
+    return 0;
+}
+
 int tg_get_episode_stats(tg_ctx* c, void** ret_f32, void** len_i32) {
     if (!c || !ret_f32 || !len_i32) return fail(-1, "NULL argument");
     *ret_f32 = c->st.ep_final_return;
@@ -1438,7 +1596,13 @@ int tg_sample_actions(tg_ctx* c, uint64_t seed, uint64_t counter, float* dev_act
     if (!c || !dev_actions) return fail(-1, "tg_sample_actions: NULL argument");
     const int total = c->cfg.num_envs * c->act_dim;
     hipLaunchKernelGGL(k_sample_actions, dim3((total + 255) / 256), dim3(256), 0, c->stream, total, seed, counter, (float)c->cfg.min_action,
-                       (float)c->cfg.max_action, dev_actions);
+                       (float)c->cfg.max_action, dev_actions,
+#ifdef TG_TL_STAMPS
+                       c->st.tl
+#else
+                       (unsigned long long*)nullptr
+#endif
+                       );
     TG_HIP(hipGetLastError());
     return 0;
 }

@@ -78,7 +78,34 @@ struct State {   // device pointers, SoA [field][num_envs]
     float* ep_final_return;         // [n] the finished episode's return (valid where done)
     int32_t* ep_final_len;          // [n] its length in env steps
     const void* tip_verts;          // [n_tip][3] in the physics dtype
+#ifdef TG_TL_STAMPS
+    unsigned long long* tl;         // development: [4][8192] launch-start stamps (wall clock) + [4] counters behind them
+#endif
 };
+#ifdef TG_TL_STAMPS
+#define TG_TL(ptr, k) do { if ((ptr) != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { \
+    const unsigned long long i_ = atomicAdd((ptr) + 4 * 8192 + (k), 1ull); (ptr)[(k) * 8192 + (i_ & 8191)] = wall_clock64(); } } while (0)
+#else
+#define TG_TL(ptr, k)
+#endif
+
+// Reset bank (edge_follow / surface_follow with auto_reset).  These envs' reset is a pure function of the env's RNG stream
+// (task draws, surface noise, rest pose -> IK -> blocking move: nothing of the finished episode enters), so the NEXT post-reset state of
+// every env is computed ahead of time, on a second low-priority stream, into a second set of SoA arrays (the "bank view": a State whose
+// pointers address the bank's own allocations).  tag[env] = the value of the env's main RNG state the bank entry was computed from; the
+// entry is usable iff it equals the env's current RNG state (tg_seed, tg_reset(mask) and a late reset all move the stream on and thereby
+// invalidate it without any bookkeeping).  The refill kernels publish the tag with an agent-scope release after the data; k_reset reads it
+// with an acquire before the data, and releases the new RNG state after its reads - the only ordering between the two streams.
+struct BankAux {
+    unsigned long long* tag;     // [n]
+    unsigned long long* rng_in;  // [n] refill: the RNG state phase 1 started from (published as the tag by the last phase)
+    uint8_t* need;               // [n] refill: envs whose entry is being recomputed by this sequence of launches
+    uint8_t* late;               // [n] step, surface_follow: finished envs whose bank entry was not ready: reset on the spot by the launches that follow (phase 2 clears it)
+    uint8_t* swapped;            // [n] step, surface_follow: finished envs that took their bank entry: k_gen_surface copies the bank's heights and clears it
+    unsigned long long* stats;   // [2] auto-resets that took a bank entry / that were done on the spot (tg_get_bank_stats)
+    int enabled;
+};
+struct BankDev { State bk; BankAux aux; };   // in device memory: k_reset reads it only in lanes whose env has finished (no second State among the kernel arguments of every step)
 
 // SplitMix64 (identical integer stream in oracle/ref_env.py: Rng)
 __host__ __device__ inline uint64_t mix64(uint64_t z) {
@@ -575,6 +602,7 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     const EnvConst<T>& c = *cp;
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = c.num_envs;
+    TG_TL(st.tl, 1);
     if (env >= n) return;
     TG_KSTAMP(0)
     T q[N], qd[N];
@@ -934,10 +962,47 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
     finish_env<T, TOPO>(m, c, st, env, q, (T)edge_ang, 0, false);
 }
 
+// A finished env takes its precomputed post-reset state: everything reset_env writes, copied from the bank view, plus the fields a reset
+// sets to constants.  (surface_follow: the 32 KB of heights follow in k_bank_heights, one workgroup per env.)
+template <typename T, int TOPO>
+__device__ __forceinline__ void bank_swap_in(const EnvConst<T>& c, const State& st, const State& bk, int env) {
+    constexpr int N = Topo<TOPO>::N;
+    const int n = c.num_envs;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.q[i * n + env] = bk.q[i * n + env]; st.qd[i * n + env] = bk.qd[i * n + env]; st.qd_target[i * n + env] = 0.0; }
+    st.embed[env] = bk.embed[env];
+    st.edge_ang[env] = bk.edge_ang[env];
+    st.edge_sc[0 * n + env] = bk.edge_sc[0 * n + env]; st.edge_sc[1 * n + env] = bk.edge_sc[1 * n + env];
+    st.reset_ticks[env] = bk.reset_ticks[env];
+    st.step_count[env] = 0;
+    st.licence[env] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { st.tcp_pos[k * n + env] = bk.tcp_pos[k * n + env]; st.tcp_rpy[k * n + env] = bk.tcp_rpy[k * n + env]; }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st.stim_xform[k * n + env] = bk.stim_xform[k * n + env];
+    if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        st.accum[env] = bk.accum[env];
+        st.noise_seed[env] = bk.noise_seed[env];
+        st.dir[0 * n + env] = bk.dir[0 * n + env]; st.dir[1 * n + env] = bk.dir[1 * n + env];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st.goal[k * n + env] = bk.goal[k * n + env];
+        st.surf_zoff[env] = bk.surf_zoff[env];
+        if (st.feature != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) st.feature[(size_t)env * 12 + e] = bk.feature[(size_t)env * 12 + e];
+        }
+    }
+}
+
+// bd == nullptr  env.reset() of the masked envs (tg_reset; auto-reset without a bank): reset_env on the main state.
+// bd != nullptr  auto-reset inside tg_step with the bank: a finished env whose bank entry belongs to its current RNG state takes it, any other
+//                finished env is reset on the spot.  surface_follow (phase 1, k_gen_surface, phase 2): phase 1 leaves swapped[env] / late[env]
+//                for the two launches behind it, which clear them again (both masks are all zero between steps).
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                              const uint8_t* __restrict__ mask, int phase) {
+                                              const uint8_t* __restrict__ mask, int phase, const BankDev* __restrict__ bd) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    TG_TL(st.tl, 2);
     if (env >= cp->num_envs) return;
     if (mask != nullptr && mask[env] == 0) return;
     if (cp->fused_reset && mask != nullptr) {   // auto-reset inside tg_step: keep the terminal observation's camera transform; the render
@@ -945,7 +1010,48 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
 #pragma unroll
         for (int k = 0; k < 12; ++k) st.term_xform[k * n + env] = st.stim_xform[k * n + env];
     }
+    if (bd != nullptr && phase != 2) {
+        const BankAux& aux = bd->aux;
+        const unsigned long long r = (unsigned long long)st.rng[env];
+        const unsigned long long t = __hip_atomic_load(aux.tag + env, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == r) {
+            bank_swap_in<T, TOPO>(*cp, st, bd->bk, env);
+            // the new RNG state is what tells the refill stream that this entry is spent: released after every read of the entry above
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(st.rng) + env, (unsigned long long)bd->bk.rng[env], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (phase == 1) aux.swapped[env] = 1;
+            atomicAdd(aux.stats + 0, 1ull);
+            return;
+        }
+        if (phase == 1) aux.late[env] = 1;
+        atomicAdd(aux.stats + 1, 1ull);
+    }
     reset_env<T, TOPO>(*mp, *cp, st, env, phase);
+    if (bd != nullptr && phase == 2) bd->aux.late[env] = 0;
+}
+
+// The refill (second stream, outside the step graph): for every env whose bank entry does not belong to its current RNG state, the same
+// reset_env on the bank view, started from the main RNG state.  Phases as k_reset's: 0 all in one (edge_follow); 1 the task draws, then
+// k_gen_surface on the bank's heights with mask = need, then 2 the robot half (surface_follow).  The last phase publishes the tag.
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_bank_refill(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st, State bk,
+                                                    BankAux aux, int phase) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= cp->num_envs) return;
+    if (phase != 2) {
+        // Relaxed, cache-bypassing read of the RNG state; the acquire (an L2 invalidate on this part: measured, an idle refill with an acquire
+        // LOAD doubled the duration of the k_step running beside it, 14.5 -> 31.6 us) is a fence taken only by wavefronts that have work.
+        const unsigned long long r = __hip_atomic_load(reinterpret_cast<unsigned long long*>(st.rng) + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool need = aux.tag[env] != r;
+        aux.need[env] = need ? 1 : 0;
+        if (!need) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        aux.rng_in[env] = r;
+        bk.rng[env] = (uint64_t)r;
+    } else if (aux.need[env] == 0) {
+        return;
+    }
+    reset_env<T, TOPO>(*mp, *cp, bk, env, phase);
+    if (phase != 1) __hip_atomic_store(aux.tag + env, aux.rng_in[env], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------ object_balance kernels

@@ -85,12 +85,21 @@ __device__ inline double splitmix_uniform(unsigned long long state, unsigned lon
 // grid: n_envs blocks of 256 threads
 __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ seeds, int rows,
                                                      int cols, double interp, double range, int center_z, int mode,
-                                                     double* __restrict__ heights, float* __restrict__ zoff) {
+                                                     double* __restrict__ heights, float* __restrict__ zoff, uint8_t* __restrict__ copy_mask,
+                                                     const double* __restrict__ copy_src) {
     __shared__ int16_t perm[256];
     __shared__ int16_t source[256];
     __shared__ float red_min[256], red_max[256];
     const int env = blockIdx.x, tid = threadIdx.x;
-    if (env >= n_envs || (mask != nullptr && mask[env] == 0)) return;
+    if (env >= n_envs) return;
+    if (copy_mask != nullptr && copy_mask[env] != 0) {   // reset bank: this env took its precomputed entry, the heights come with it
+        const size_t base = (size_t)env * rows * cols;
+        for (int k = tid; k < rows * cols; k += 256) heights[base + k] = copy_src[base + k];
+        __syncthreads();
+        if (tid == 0) copy_mask[env] = 0;
+        return;
+    }
+    if (mask != nullptr && mask[env] == 0) return;
     source[tid] = (int16_t)tid;
     __syncthreads();
     if (tid == 0 && (mode <= TG_SURF_SIMPLEX_1D || mode == TG_SURF_SIMPLEX_1D_VERT)) {   // OpenSimplex.__init__: three warm-up LCG steps, then a Fisher-Yates style draw without replacement
@@ -196,9 +205,9 @@ void launch_gen_traj(int n_envs, const uint8_t* mask, const int64_t* seeds, int 
 }
 
 void launch_gen_surface(int n_envs, const uint8_t* mask, const int64_t* seeds, int rows, int cols, double interp, double range, int center_z,
-                        int mode, double* heights, float* zoff, hipStream_t stream) {
+                        int mode, double* heights, float* zoff, hipStream_t stream, uint8_t* copy_mask, const double* copy_src) {
     hipLaunchKernelGGL(k_gen_surface, dim3(n_envs), dim3(256), 0, stream, n_envs, mask, seeds, rows, cols, interp, range, center_z, mode, heights,
-                       zoff);
+                       zoff, copy_mask, copy_src);
 }
 
 }  // namespace tg

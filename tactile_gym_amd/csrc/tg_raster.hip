@@ -919,6 +919,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     TG_STAMP(7);
+#ifdef TG_TL_STAMPS
+    if (P.tl != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { const unsigned long long i_ = atomicAdd(P.tl + 4 * 8192 + 3, 1ull); P.tl[3 * 8192 + (i_ & 8191)] = wall_clock64(); }
+#endif
     const int pass = (term_xform != nullptr && blockIdx.z == 1) ? 0 : 1;
     if (pass == 0 && term_mask[env] == 0) return;
     const float* __restrict__ xf = pass == 0 ? term_xform : xform;

@@ -158,6 +158,12 @@ class TactileVecEnv(_VecEnvBase):
             np.copyto(self._actions, np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim))
             capi.check(self._L.tg_step(self._ctx, C.c_void_p(self._actions.ctypes.data), 0))
 
+    def bank_stats(self):
+        """Reset bank: {"mode": "off" | "on" | "sync", "swapped": auto-resets that took a precomputed entry, "late": resets done on the spot}."""
+        sw, late, mode = C.c_int64(), C.c_int64(), C.c_int32()
+        capi.check(self._L.tg_get_bank_stats(self._ctx, C.byref(sw), C.byref(late), C.byref(mode)))
+        return {"mode": ("off", "on", "sync")[mode.value], "swapped": int(sw.value), "late": int(late.value)}
+
     def sample_actions(self, out, seed, counter):
         """action_space.sample() for the whole batch on the device (tg_sample_actions): fills the torch CUDA float32 tensor `out`
         [N, act_dim] with U[min_action, max_action) draws that depend on (seed, counter, element) only; enqueued on the env's stream."""

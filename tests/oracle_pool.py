@@ -16,7 +16,10 @@ def _rollout_chunk(args):
     observation (SB3 VecEnv convention, what the device does); its terminal image is kept separately.
     follow: optional int array [steps, len(idx)] of the device's goal index after each step (object_push only): where the oracle's
     goal advance differs from it on the documented knife edge (PARITY_ASSUMPTIONS A29) the oracle is made to follow."""
-    cls, kwargs, seed0, idx, actions, auto_reset, follow = args
+    cls, kwargs, seed0, idx, actions, auto_reset, follow = args[:7]
+    digest = len(args) > 7 and args[7]       # keep crc32 of every frame instead of the frame (256 x 256 x 250 steps x 64 envs is 1 GB through a pipe)
+    import zlib
+    keep = (lambda im: np.uint32(zlib.crc32(np.ascontiguousarray(im).tobytes()))) if digest else (lambda im: im.copy())
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     warnings.simplefilter("ignore")
@@ -25,7 +28,7 @@ def _rollout_chunk(args):
     for k, i in enumerate(idx):
         o = getattr(ref_env, cls)(seed=seed0 + i, **kwargs)
         ob = o.reset()
-        rec = dict(img=[ob["tactile"][..., 0].copy()], q=[o.arm.q.copy()], rew=[], done=[], reset_ticks=[o.reset_ticks], knife=0,
+        rec = dict(img=[keep(ob["tactile"][..., 0])], q=[o.arm.q.copy()], rew=[], done=[], reset_ticks=[o.reset_ticks], knife=0,
                    term={}, feat=[], cc=[], cid=[], body=[], xf=[np.asarray(o.stimulus_transform(), dtype=np.float32).ravel().copy()])
         push = cls == "OracleObjectPushEnv"
         has_body = hasattr(o, "cube_pose") or hasattr(o, "body_pose")
@@ -43,20 +46,20 @@ def _rollout_chunk(args):
             if push:
                 rec["cc"].append(int(o.scene.n_contacts)), rec["cid"].append(np.array(o.scene.contact_ids, dtype=np.int32).copy())
                 rec["goal_id"] = rec.get("goal_id", []) + [int(o.targ_traj_list_id)]
-            if has_body:
-                p, R = o.cube_pose() if hasattr(o, "cube_pose") else o.body_pose()
-                rec["body"].append(np.concatenate([np.asarray(p).ravel(), np.asarray(R).ravel()]))
             if "extended_feature" in ob:
                 rec["feat"].append(np.asarray(ob["extended_feature"], dtype=np.float32).copy())
-            img = ob["tactile"][..., 0].copy()
+            img = keep(ob["tactile"][..., 0])
             xf = np.asarray(o.stimulus_transform(), dtype=np.float32).ravel().copy()
             if d and auto_reset:
                 rec["term"][s] = img
                 ob = o.reset()
                 rec["reset_ticks"].append(o.reset_ticks)
-                img = ob["tactile"][..., 0].copy()
+                img = keep(ob["tactile"][..., 0])
                 q_step = o.arm.q.copy()
                 xf = np.asarray(o.stimulus_transform(), dtype=np.float32).ravel().copy()
+            if has_body:                           # after an auto-reset: the fresh episode's object pose, like q (what the device state holds)
+                p, R = o.cube_pose() if hasattr(o, "cube_pose") else o.body_pose()
+                rec["body"].append(np.concatenate([np.asarray(p).ravel(), np.asarray(R).ravel()]))
             rec["img"].append(img), rec["q"].append(q_step), rec["xf"].append(xf)
         for key in ("img", "q", "rew", "done", "feat", "cc", "cid", "body", "xf"):
             rec[key] = np.asarray(rec[key])
@@ -64,13 +67,13 @@ def _rollout_chunk(args):
     return list(idx), out
 
 
-def oracle_rollouts(cls, kwargs, seed0, actions, auto_reset=False, follow=None, procs=None):
+def oracle_rollouts(cls, kwargs, seed0, actions, auto_reset=False, follow=None, procs=None, digest=False):
     """actions: float32 [steps, n, act_dim].  Returns a list of n per-env records (see _rollout_chunk)."""
     import multiprocessing as mp
     n = actions.shape[1]
     procs = procs or min(128, os.cpu_count() or 8, n)
     chunks = [c for c in np.array_split(np.arange(n), min(n, 4 * procs)) if len(c)]
-    jobs = [(cls, kwargs, seed0, list(map(int, c)), np.ascontiguousarray(actions[:, c]), auto_reset, None if follow is None else follow[:, c])
+    jobs = [(cls, kwargs, seed0, list(map(int, c)), np.ascontiguousarray(actions[:, c]), auto_reset, None if follow is None else follow[:, c], digest)
             for c in chunks]
     recs = [None] * n
     with mp.get_context("spawn").Pool(procs) as pool:

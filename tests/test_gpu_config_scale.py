@@ -39,17 +39,21 @@ CASES = {   # env id, oracle class, modes, image size, act_dim, max_steps
 }
 
 
-def _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset, want_contacts=False):
+def _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset, want_contacts=False, digest=False, **extra):
+    import zlib
     import tactile_gym_amd as tg
-    v = tg.make_vec(env_id, num_envs=n, max_steps=max_steps, image_size=[size, size], env_modes=modes, seed=seed, auto_reset=auto_reset)
+    v = tg.make_vec(env_id, num_envs=n, max_steps=max_steps, image_size=[size, size], env_modes=modes, seed=seed, auto_reset=auto_reset, **extra)
     obs = v.reset()
     st = v.get_state()
-    rec = dict(img=[obs["tactile"][..., 0].copy()], q=[st["q"].copy()], rew=[], done=[], reset_ticks=[st["reset_ticks"].copy()], feat=[], cc=[],
+
+    def keep(batch):     # digest: crc32 per frame (tests/oracle_pool.py does the same on its side)
+        return np.array([zlib.crc32(np.ascontiguousarray(im).tobytes()) for im in batch], dtype=np.uint32) if digest else batch.copy()
+    rec = dict(img=[keep(obs["tactile"][..., 0])], q=[st["q"].copy()], rew=[], done=[], reset_ticks=[st["reset_ticks"].copy()], feat=[], cc=[],
                cid=[], body=[], goal_id=[], term={}, xf=[st["stim_xform"].copy()])
     for s in range(actions.shape[0]):
         obs, rew, done, info = v.step(actions[s])
         st = v.get_state()
-        rec["img"].append(obs["tactile"][..., 0].copy()), rec["q"].append(st["q"].copy()), rec["rew"].append(rew), rec["done"].append(done)
+        rec["img"].append(keep(obs["tactile"][..., 0])), rec["q"].append(st["q"].copy()), rec["rew"].append(rew), rec["done"].append(done)
         rec["reset_ticks"].append(st["reset_ticks"].copy()), rec["xf"].append(st["stim_xform"].copy())
         if "extended_feature" in obs:
             rec["feat"].append(obs["extended_feature"].copy())
@@ -59,7 +63,7 @@ def _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset, w
             rec["cc"].append(st["contact_count"].copy()), rec["cid"].append(st["contact_ids"].copy()), rec["goal_id"].append(st["goal_id"].copy())
         for i in np.nonzero(done)[0]:
             if auto_reset:
-                rec["term"][(s, int(i))] = info[i]["terminal_observation"]["tactile"][..., 0]
+                rec["term"][(s, int(i))] = keep(info[i]["terminal_observation"]["tactile"][None, ..., 0])[0]
     v.close()
     return {k: (np.asarray(x) if isinstance(x, list) else x) for k, x in rec.items()}
 
@@ -139,3 +143,70 @@ def test_long_horizon_auto_reset_matches_oracle(case):
         assert np.abs(hip["rew"][:, i] - r["rew"]).max() < 1e-5
     assert resets >= n           # every env crossed max_steps at least once
     print(f"{case}: {n} envs x {steps} steps, {resets} auto-resets: worst |dq| at every 25th step {worst_q:.2e} rad, images bit-exact")
+
+
+@pytest.mark.parametrize("mapping", ["wave", "lane"])
+def test_long_horizon_object_balance_matches_oracle(mapping):
+    """Config 5 over whole episodes: 64 envs x 250 steps with auto_reset at 256 x 256, on both mappings of the arm + pole
+    solve.  Random actions drop the pole within tens of steps, so nearly every step resets some env - on the forked stream beside the render
+    (enqueue_step) - and every reset starts from the fallen pole still tied to the TCP (object_balance_env.py:261-283, base_object_env.py:146-173).
+    dones and reset tick counts exact at every step; every frame and every terminal observation bit-exact (crc32 of the 65 536 bytes on both
+    sides); joints and pole pose 1e-8 at every 25th step; reward 1e-5."""
+    env_id, cls, modes, size, act_dim, max_steps = CASES["config5_object_balance"]
+    n, steps, seed = 64, 250, 5100
+    actions = np.random.default_rng(13).uniform(-0.25, 0.25, size=(steps, n, act_dim)).astype(np.float32)
+    hip = _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset=True, digest=True, contact_mapping=mapping)
+    ref = oracle_rollouts(cls, dict(max_steps=max_steps, image_size=(size, size), env_modes=modes), seed, actions, auto_reset=True, digest=True)
+    worst_q = worst_b = 0.0
+    resets = 0
+    for i, r in enumerate(ref):
+        assert np.array_equal(hip["done"][:, i].astype(bool), r["done"].astype(bool)), (mapping, i, np.nonzero(hip["done"][:, i])[0], np.nonzero(r["done"])[0])
+        k, expect = 0, []
+        for s in range(steps):
+            k += int(r["done"][s])
+            expect.append(r["reset_ticks"][k])
+        assert hip["reset_ticks"][0][i] == r["reset_ticks"][0] and np.array_equal(hip["reset_ticks"][1:, i], expect), (mapping, i)
+        resets += k
+        assert np.array_equal(hip["img"][:, i], r["img"]), (mapping, i, np.nonzero(hip["img"][:, i] != r["img"])[0])
+        for s, crc in r["term"].items():
+            assert hip["term"][(s, i)] == crc, (mapping, i, s)
+        worst_q = max(worst_q, np.abs(hip["q"][::25, i] - r["q"][::25]).max())
+        worst_b = max(worst_b, np.abs(hip["body"][24::25, i] - r["body"][24::25]).max())
+        assert np.abs(hip["rew"][:, i] - r["rew"]).max() < 1e-5
+    assert worst_q < 1e-8 and worst_b < 1e-8, (worst_q, worst_b)
+    assert resets >= 4 * n        # random actions: several episodes per env
+    print(f"object_balance ({mapping}): {n} envs x {steps} steps, {resets} auto-resets: worst |dq| {worst_q:.2e} rad, |d pole pose| {worst_b:.2e} at every 25th step, "
+          f"all {n * (steps + 1)} frames and {resets} terminal observations bit-exact")
+
+
+def test_long_horizon_object_push_matches_oracle():
+    """Config 4 over 60 steps: MG400 + DigiTac, 64 envs.  Contact count, contact-pair ids (solver row order) and goal index
+    exact on every env at every step; cube pose within 1e-9 at every step (two f64 contact solves that differ in rounding only, amplified by the
+    stiff contact rows: measured 3e-11 after 30 and after 60 steps, no growth); images by config 4's rule (one grey level on at most 16 pixels, >= 99 % bit-exact)."""
+    env_id, cls, modes, size, act_dim, max_steps = CASES["config4_object_push"]
+    n, steps, seed = 64, 60, 7300
+    actions = np.random.default_rng(17).uniform(-0.25, 0.25, size=(steps, n, act_dim)).astype(np.float32)
+    hip = _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset=False, want_contacts=True)
+    ref = oracle_rollouts(cls, dict(max_steps=max_steps, image_size=(size, size), env_modes=modes), seed, actions, follow=hip["goal_id"])
+    bound = np.full(steps, 1e-9)
+    worst = np.zeros(steps)
+    bad_images = knife = 0
+    for i, r in enumerate(ref):
+        assert np.array_equal(hip["cc"][:, i], r["cc"]), (i, hip["cc"][:, i], r["cc"])
+        assert np.array_equal(hip["cid"][:, i], r["cid"]), i
+        assert np.array_equal(hip["goal_id"][:, i], r["goal_id"]), i
+        assert np.array_equal(hip["done"][:, i].astype(bool), r["done"].astype(bool)), i
+        db = np.abs(hip["body"][:, i] - r["body"]).max(axis=1)
+        worst = np.maximum(worst, db)
+        assert (db <= bound).all(), (i, db.max(), np.nonzero(db > bound)[0])
+        assert np.abs(hip["q"][:, i] - r["q"]).max() < 1e-8, i
+        assert np.abs(hip["rew"][:, i] - r["rew"]).max() < 1e-5
+        diff = hip["img"][:, i].astype(np.int16) - r["img"].astype(np.int16)
+        per_image = (diff != 0).reshape(steps + 1, -1).sum(1)
+        assert per_image.max() <= 16 and np.abs(diff).max() <= 1, (i, per_image)
+        bad_images += int((per_image > 0).sum())
+        knife += r["knife"]
+    assert bad_images <= 0.01 * n * (steps + 1), bad_images
+    assert (hip["cc"] == 5).mean() > 0.5 and knife <= n
+    print(f"object_push: {n} envs x {steps} steps: contact ids / goal index exact; worst |d cube pose| per step: first {worst[0]:.1e}, step 30 {worst[29]:.1e}, "
+          f"last {worst[-1]:.1e} (bound {bound[-1]:.1e}); images not bit-exact {bad_images} of {n * (steps + 1)}")

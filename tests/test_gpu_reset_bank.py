@@ -1,0 +1,74 @@
+"""Reset bank (tg_config.reset_bank): the auto-reset of edge_follow / surface_follow takes a post-reset state computed ahead
+of time on a second stream.  Whatever the bank does - off, always ready ("sync"), ready or not as the two streams happen to run ("on"),
+never ready in time (one-step episodes) - every observation, terminal observation, reward, done flag, reset tick count and joint state must be
+byte-identical: the same reset code runs either way, from the same RNG state (reference: edge_follow_env.py:311-336, base_surface_env.py:616-662,
+robot.py:114-125, 188-260)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EDGE = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+SURF = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")
+VERT = dict(movement_mode="xRz", control_mode="TCP_velocity_control", noise_mode="vertical_simplex", observation_mode="tactile",
+            reward_mode="dense", arm_type="mg400", tactile_sensor_name="tactip")
+EDGE_POS = dict(EDGE, control_mode="TCP_position_control")
+
+
+def rollout(env_id, modes, bank, n, max_steps, steps, act_dim, size=128):
+    import tactile_gym_amd as tg
+    venv = tg.make_vec(env_id, num_envs=n, max_steps=max_steps, image_size=[size, size], env_modes=modes, seed=11, auto_reset=True, reset_bank=bank)
+    rng = np.random.default_rng(5)
+    out = {"obs": [venv.reset()["tactile"].copy()], "rew": [], "done": [], "term": [], "ticks": [], "q": []}
+    for _ in range(steps):
+        a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+        obs, rew, done, infos = venv.step(a)
+        out["obs"].append(obs["tactile"].copy()); out["rew"].append(rew.copy()); out["done"].append(done.copy())
+        out["term"].append([np.asarray(infos[i]["terminal_observation"]["tactile"]).copy() if done[i] else None for i in range(n)])
+        st = venv.get_state()
+        out["ticks"].append(st["reset_ticks"].copy()); out["q"].append(st["q"].copy())
+    stats = venv.bank_stats()
+    venv.close()
+    return out, stats
+
+
+def same(a, b):
+    for k in ("obs", "rew", "done", "ticks", "q"):
+        for t, (x, y) in enumerate(zip(a[k], b[k])):
+            assert np.array_equal(x, y), (k, t)
+    for t, (x, y) in enumerate(zip(a["term"], b["term"])):
+        for i, (u, v) in enumerate(zip(x, y)):
+            assert (u is None) == (v is None) and (u is None or np.array_equal(u, v)), ("terminal observation", t, i)
+
+
+@pytest.mark.parametrize("env_id,modes,act_dim,max_steps,steps", [
+    ("edge_follow-v0", EDGE, 2, 7, 40),
+    ("edge_follow-v0", EDGE_POS, 2, 5, 16),
+    ("surface_follow-v0", SURF, 3, 6, 30),
+    ("surface_follow-v2", VERT, 2, 5, 12),
+])
+def test_bank_off_sync_on_are_byte_identical(env_id, modes, act_dim, max_steps, steps):
+    n = 48
+    off, s_off = rollout(env_id, modes, "off", n, max_steps, steps, act_dim)
+    syn, s_syn = rollout(env_id, modes, "sync", n, max_steps, steps, act_dim)
+    aut, s_aut = rollout(env_id, modes, "on", n, max_steps, steps, act_dim)
+    resets = int(sum(d.sum() for d in off["done"]))
+    assert resets >= n * (steps // max_steps)
+    assert s_off == {"mode": "off", "swapped": 0, "late": 0}
+    # sync: the refill is waited for after every step, so only an env that finishes on the very step after its reset's refill ... never: all swapped
+    assert s_syn["mode"] == "sync" and s_syn["swapped"] + s_syn["late"] == resets and s_syn["late"] == 0, s_syn
+    assert s_aut["mode"] == "on" and s_aut["swapped"] + s_aut["late"] == resets, s_aut
+    same(off, syn)
+    same(off, aut)
+
+
+def test_bank_not_ready_falls_back_to_the_reset_on_the_spot():
+    """max_steps = 1: every env finishes on every step, the refill (every 8th step, on a stream of lower priority) cannot keep up: most resets are
+    'late' - the join the step takes when an env finishes before its entry is ready - and nothing changes."""
+    n = 32
+    off, _ = rollout("edge_follow-v0", EDGE, "off", n, 1, 24, 2)
+    aut, s = rollout("edge_follow-v0", EDGE, "on", n, 1, 24, 2)
+    assert s["swapped"] + s["late"] == n * 24 and s["late"] > 0, s
+    same(off, aut)

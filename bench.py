@@ -267,6 +267,8 @@ def main():
                     help="object_push / object_roll: one wavefront per env or one lane per env for the contact solve (tg_config.contact_mapping)")
     ap.add_argument("--observation-mode", default=None, help="override the config's observation_mode (e.g. visuotactile: adds the RGB scene camera, SURVEY 8 row f4); "
                     "measurement aid, the bench line stays the tactile configuration")
+    ap.add_argument("--narrowphase", default="closed_form", choices=["closed_form", "gjk_manifold", "gjk_single"],
+                    help="object_push: the tip - cube narrowphase (tg_config.narrowphase); measurement aid, the bench line stays the default closed form")
     ap.add_argument("--solver-iters", type=int, default=None, help="object_push / object_roll: override numSolverIterations (150); measurement aid, not a bench configuration")
     ap.add_argument("--payload", default=os.environ.get("TG_BENCH_PAYLOAD", "auto"), choices=["auto", "full", "interior", "tiles"],
                     help="N > 1: what the tactile part of the per-step message to rank 0 carries (parallel.py)")
@@ -311,6 +313,8 @@ def main():
 
     n = args.num_envs
     extra = dict(contact_mapping=args.contact_mapping, solver_iterations=args.solver_iters)
+    if args.env == "object_push-v0" and args.narrowphase != "closed_form":
+        extra["narrowphase"] = args.narrowphase
     w = Workload(args.env, n, args.image_size, args.physics, rank, local_rank, full_sweeps=args.full_sweeps,
                  observation_mode=args.observation_mode, pipelined=not args.sync_steps, **extra)
     venv, shard, modes, max_steps = w.venv, w.shard, w.modes, w.max_steps

@@ -193,12 +193,14 @@ typedef struct {
     /* object_push: narrowphase of the tip-cube pair (stepSimulation's collision detection, robot.py:141).  TG_NARROW_CLOSED_FORM: the
      * deepest point of the tip's convex hull against the cube's faces in closed form, ONE contact point per tick (PARITY A24);
      * TG_NARROW_GJK_MANIFOLD: support-mapping GJK distance + EPA penetration on the hull and the box, fed into a persistent manifold of up
-     * to 4 points with Bullet's add / replace / break rules (PARITY A35-A38). */
+     * to 4 points with Bullet's add / replace / break rules (PARITY A35-A38); TG_NARROW_GJK_SINGLE: the same GJK / EPA, the tick's point only
+     * (no cache): the closed form's special case - equal to it wherever the closest features are a hull vertex and a box face (tests).
+     * Both run on the wave mapping (f64, cone friction). */
     int32_t narrowphase;                    /* TG_NARROW_* */
 } tg_config;
 
 enum { TG_BANK_AUTO = 0, TG_BANK_OFF = 1, TG_BANK_SYNC = 2, TG_BANK_ON = 3 };
-enum { TG_NARROW_CLOSED_FORM = 0, TG_NARROW_GJK_MANIFOLD = 1 };
+enum { TG_NARROW_CLOSED_FORM = 0, TG_NARROW_GJK_MANIFOLD = 1, TG_NARROW_GJK_SINGLE = 2 };
 
 typedef struct tg_ctx tg_ctx;
 
@@ -246,6 +248,10 @@ int tg_get_interior_count(tg_ctx* ctx, int32_t* k);
 /* Reset bank (tg_config.reset_bank): how many auto-resets so far took a precomputed entry (*swapped) and how many were done on the spot because
  * the entry was not ready (*late); *mode = 0 bank off, 1 on, 2 on and waited for.  Synchronises the context's stream. */
 int tg_get_bank_stats(tg_ctx* ctx, int64_t* swapped, int64_t* late, int32_t* mode);
+/* Self-test of the wave-mapped GJK / EPA (tg_config.narrowphase; csrc/tg_narrowphase.hpp) on n_cases placements of a convex hull against the
+ * box of half extents half[3]: hulls [n_cases][n_hull][3] in the box frame (n_hull <= 1152); out [n_cases][11] = found (1 / 0), signed core
+ * distance (< 0: overlap depth), unit normal from the box to the hull, witness point on the hull, witness point on the box. */
+int tg_selftest_narrowphase(int32_t n_cases, int32_t n_hull, const double* hulls, const double* half, double* out);
 int tg_pack_interior(tg_ctx* ctx, void* dst_dev);
 int tg_unpack_interior(tg_ctx* ctx, const void* src_dev, int32_t n_images, void* dst_dev);
 /* ---- tile-sparse tactile payload and direct stores into rank 0's memory (csrc/tg_exchange.hip) ------------------------------------
@@ -347,7 +353,7 @@ typedef struct {
      * 8 + k = hull vertex k of the sensor tip's collision core against the cube (8 for the marble against the tip's cylinder).
      * Unused slots are -1.  Integer data: compared bit-exactly with the oracle. */
     int32_t* contact_count;  /* [num_envs] */
-    int32_t* contact_ids;    /* [num_envs][5] */
+    int32_t* contact_ids;    /* [num_envs][8]: solver row order, -1 beyond contact_count (4 table + up to 4 tip slots) */
 } tg_state_view;
 int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */

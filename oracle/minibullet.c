@@ -799,7 +799,7 @@ void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, d
 typedef struct { double n[3], pa[3], pb[3], depth, mu, cfm_dt, erp; int arm_a; /* 1: body A is the arm tip, B the cube; 0: A cube, B table */ } contact_t;
 
 void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc, double dt, int iters) {
-    enum { NU = MB_MAX_DOF + 6, MAXC = 5, NR = MB_MAX_DOF + 3 * MAXC };
+    enum { NU = MB_MAX_DOF + 6, MAXC = 8, NR = MB_MAX_DOF + 3 * MAXC };
     int n = m->ndof, nu = n + 6;
     /* ---- arm: unconstrained velocity */
     double tau[MB_MAX_DOF], h[MB_MAX_DOF], Qd[MB_MAX_DOF], v[NU], M[MB_MAX_DOF * MB_MAX_DOF], Mi[MB_MAX_DOF * MB_MAX_DOF], zero[MB_MAX_DOF] = {0};
@@ -904,6 +904,46 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             for (int x = 0; x < 3; ++x) { q->pa[x] = cw_[x] + clw[x]; q->pb[x] = b->pos[x] - gw[x] * sc->radius; }
             sc->contact_ids[nc - 1] = 8;
             sc->tip_depth = depth; memcpy(sc->tip_normal, q->n, sizeof q->n);
+        }
+    } else if (sc->narrowphase == 1) {
+        /* cube - tip core through the general narrowphase (narrowphase.c): broadphase AABB overlap of the pair, GJK / EPA on the core shapes in
+           the box frame, one new point per tick into the persistent manifold, refresh, every surviving point a contact [A35-A38] */
+        int l = sc->tip_link;
+        static double hb[3 * 4096];
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        const int nt = sc->n_tip < 4096 ? sc->n_tip : 4096;
+        for (int i = 0; i < nt; ++i) {
+            double t[3], w[3], d[3];
+            m3_vec(k.R[l], sc->tip_verts + 3 * i, t);
+            for (int x = 0; x < 3; ++x) { w[x] = k.o[l][x] + t[x]; d[x] = w[x] - b->pos[x]; if (w[x] < lo[x]) lo[x] = w[x]; if (w[x] > hi[x]) hi[x] = w[x]; }
+            for (int x = 0; x < 3; ++x) hb[3 * i + x] = b->rot[x] * d[0] + b->rot[3 + x] * d[1] + b->rot[6 + x] * d[2];
+        }
+        int overlap = nt > 0;
+        for (int x = 0; x < 3; ++x) {   /* AABBs padded by the margins and the breaking threshold */
+            const double ext = fabs(b->rot[3 * x]) * sc->half[0] + fabs(b->rot[3 * x + 1]) * sc->half[1] + fabs(b->rot[3 * x + 2]) * sc->half[2];
+            const double pad = sc->margin_tip + sc->margin_cube + sc->breaking;
+            if (lo[x] - pad > b->pos[x] + ext || hi[x] + pad < b->pos[x] - ext) overlap = 0;
+        }
+        if (!overlap) sc->mani.n = 0;   /* the pair leaves the broadphase: its manifold goes with it */
+        else {
+            double sd, nb[3], ab[3], bb[3];
+            if (mb_gjk_epa_hull_box(hb, nt, sc->half, &sd, nb, ab, bb)) {
+                const double depth = sd - (sc->margin_tip + sc->margin_cube);
+                double nw[3], aw[3], bw[3], pa[3], pb[3];
+                m3_vec(b->rot, nb, nw); m3_vec(b->rot, ab, aw); m3_vec(b->rot, bb, bw);
+                for (int x = 0; x < 3; ++x) { pa[x] = (b->pos[x] + aw[x]) - nw[x] * sc->margin_tip; pb[x] = (b->pos[x] + bw[x]) + nw[x] * sc->margin_cube; }
+                mb_manifold_add(&sc->mani, sc->breaking, k.o[l], k.R[l], b->pos, b->rot, pa, pb, nw, depth);
+            }
+            mb_manifold_refresh(&sc->mani, sc->breaking, k.o[l], k.R[l], b->pos, b->rot);
+        }
+        for (int i = 0; i < sc->mani.n; ++i) {
+            contact_t* q = &ct[nc++];
+            memcpy(q->n, sc->mani.nrm[i], sizeof q->n); memcpy(q->pa, sc->mani.pa[i], sizeof q->pa); memcpy(q->pb, sc->mani.pb[i], sizeof q->pb);
+            q->depth = sc->mani.depth[i]; q->mu = sc->mu_tip; q->arm_a = 1;
+            double denom = dt * sc->tip_stiffness + sc->tip_damping;
+            q->cfm_dt = (1.0 / denom) / dt; q->erp = dt * sc->tip_stiffness / denom;
+            sc->contact_ids[nc - 1] = 8 + i;
+            if (q->depth < sc->tip_depth) { sc->tip_depth = q->depth; memcpy(sc->tip_normal, q->n, sizeof q->n); }
         }
     } else
     {   /* cube - tip core: deepest hull vertex against the box signed distance field */
@@ -1050,7 +1090,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
         }
         if (residual <= sc->residual_threshold) break;                /* leastSquaresResidualThreshold [A7b]; 0 = exact fixed point */
     }
-    for (int c = 0; c < nc; ++c) if (ct[c].arm_a) sc->tip_impulse = lam[n + 3 * c];
+    for (int c = 0; c < nc; ++c) if (ct[c].arm_a) sc->tip_impulse += lam[n + 3 * c];   /* the tip's normal impulse (summed over its manifold points) */
     /* ---- integrate */
     for (int i = 0; i < n; ++i) { s->qd[i] = v[i] + dv[i]; s->q[i] += dt * s->qd[i]; s->applied_torque[i] = 0.0; }
     for (int x = 0; x < 3; ++x) { b->linvel[x] = v[n + x] + dv[n + x]; b->angvel[x] = v[n + 3 + x] + dv[n + 3 + x]; }

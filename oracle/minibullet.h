@@ -159,6 +159,14 @@ void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, d
  *                no persistent manifold, no warm start, no friction anchors);
  *   solver       joint motors, then contact normals (lambda >= 0, soft-contact cfm/erp for the tip), then friction pairs
  *                (implicit cone, |f| <= mu lambda_n), `iters` sweeps, in one projected Gauss-Seidel loop. */
+/* Persistent contact manifold of the tip core - cube pair (narrowphase = 1; btPersistentManifold restated, PARITY_ASSUMPTIONS A36-A38):
+ * up to 4 points, each with its local anchors on the tip link (la) and on the cube (lb), the world normal it was made with (from the cube
+ * towards the tip), its refreshed world positions and distance. */
+typedef struct {
+    int32_t n;
+    double la[4][3], lb[4][3], nrm[4][3], pa[4][3], pb[4][3], depth[4];
+} mb_manifold;
+
 typedef struct {
     double table_z;                    /* table top plane (base_tactile_env.py:131-139: table at z = -0.625, top at 0) */
     double half[3];                    /* cube half extents (cube.urdf: 0.08^3) */
@@ -183,11 +191,22 @@ typedef struct {
     double radius;               /* sphere radius (default_obj_radius x scaling_factor) */
     double cyl_pos[3], cyl_rot[9];   /* cylinder frame (axis = local z) in the frame of tip_link */
     double cyl_half_len, cyl_radius;
-    /* out: the tick's contact pairs in solver row order (n_contacts of them, the rest -1), named by their feature: 0-7 = the cube
+    /* out: the tick's contact pairs in solver row order (n_contacts of them, the rest -1; 8 slots: 4 table + 4 manifold points), named by their feature: 0-7 = the cube
      * vertex (4 ix + 2 iy + iz) that touches the table (the marble's table contact: 0); 8 + k = hull vertex k of the tip core against
      * the cube (the marble against the tip's cylinder: 8).  north_star: "bit-exact for contact-pair indices". */
-    int32_t contact_ids[5];
+    int32_t contact_ids[8];
+    /* narrowphase 0: the closed forms above (one tip point per tick).  1 (object_push only): support-mapping GJK distance / EPA penetration
+     * between the tip core's hull and the box (oracle/narrowphase.c), behind an AABB overlap test of the pair, feeding a persistent manifold
+     * of up to 4 points (ids 8 + manifold slot); a reset clears the manifold. */
+    int32_t narrowphase;
+    mb_manifold mani;
 } mb_push_scene;
+
+/* oracle/narrowphase.c.  hull [n][3] and the results in the box frame; *sdist < 0: overlap depth of the cores.  Returns 0 for touching cores. */
+int mb_gjk_epa_hull_box(const double* hull, int n, const double* half, double* sdist, double* nrm, double* pa, double* pb);
+void mb_manifold_add(mb_manifold* m, double breaking, const double* oa, const double* Ra, const double* ob, const double* Rb,
+                     const double* pa_w, const double* pb_w, const double* n_w, double depth);
+void mb_manifold_refresh(mb_manifold* m, double breaking, const double* oa, const double* Ra, const double* ob, const double* Rb);
 
 extern int mb_last_sweeps;   /* PGS sweeps executed by the last mb_step */
 void mb_step_push(const mb_model* m, mb_state* s, mb_body* cube, mb_push_scene* sc, double dt, int solver_iterations);

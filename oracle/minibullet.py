@@ -49,6 +49,11 @@ class MBP2P(C.Structure):
                 ("max_impulse", C.c_double)]
 
 
+class MBManifold(C.Structure):
+    _fields_ = [("n", C.c_int32), ("la", (C.c_double * 3) * 4), ("lb", (C.c_double * 3) * 4), ("nrm", (C.c_double * 3) * 4),
+                ("pa", (C.c_double * 3) * 4), ("pb", (C.c_double * 3) * 4), ("depth", C.c_double * 4)]
+
+
 class MBPushScene(C.Structure):
     _fields_ = [
         ("table_z", C.c_double), ("half", C.c_double * 3), ("mu_table", C.c_double), ("mu_tip", C.c_double),
@@ -58,7 +63,8 @@ class MBPushScene(C.Structure):
         ("n_contacts", C.c_int32), ("tip_depth", C.c_double), ("tip_normal", C.c_double * 3), ("tip_impulse", C.c_double),
         ("residual_threshold", C.c_double), ("sweeps_used", C.c_int32),
         ("shape", C.c_int32), ("radius", C.c_double), ("cyl_pos", C.c_double * 3), ("cyl_rot", C.c_double * 9),
-        ("cyl_half_len", C.c_double), ("cyl_radius", C.c_double), ("contact_ids", C.c_int32 * 5),
+        ("cyl_half_len", C.c_double), ("cyl_radius", C.c_double), ("contact_ids", C.c_int32 * 8),
+        ("narrowphase", C.c_int32), ("mani", MBManifold),
     ]
 
 
@@ -87,6 +93,8 @@ def lib():
         _lib.mb_step.argtypes = [mp, sp, C.c_double, C.c_int]
         _lib.mb_step_body.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.c_double, C.c_int]
         _lib.mb_step_push.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBPushScene), C.c_double, C.c_int]
+        _lib.mb_gjk_epa_hull_box.argtypes = [dp, C.c_int, dp, dp, dp, dp, dp]
+        _lib.mb_gjk_epa_hull_box.restype = C.c_int
         _lib.mb_opensimplex_perm.argtypes = [C.c_int64, C.POINTER(C.c_int16)]
         _lib.mb_opensimplex_noise2.argtypes = [C.POINTER(C.c_int16), C.c_double, C.c_double]
         _lib.mb_opensimplex_noise2.restype = C.c_double

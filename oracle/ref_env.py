@@ -916,7 +916,7 @@ class OracleObjectPushEnv(_OracleArmEnv):
                     "digitac": [-0.24571108391609556, -2.142076416487341, -1.8135315230114846, -0.7552488203413393, 1.5711290394202047,
                                 -1.8118003855516092]}}
 
-    def __init__(self, seed=0, max_steps=1000, image_size=(128, 128), env_modes=None, inertia="collision_aabb"):
+    def __init__(self, seed=0, max_steps=1000, image_size=(128, 128), env_modes=None, inertia="collision_aabb", narrowphase="closed_form"):
         modes = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="simplex",
                      observation_mode="tactile_and_feature", reward_mode="dense", arm_type="mg400", tactile_sensor_name="digitac")
         modes.update(env_modes or {})
@@ -963,11 +963,13 @@ class OracleObjectPushEnv(_OracleArmEnv):
         sc.tip_link, sc.n_tip = int(r["tip_hull_link"]), self._tip_verts.shape[0]
         sc.tip_verts = self._tip_verts.ctypes.data_as(C.POINTER(C.c_double))
         sc.cone_friction = 1                                                                # base_tactile_env.py:128-130
+        sc.narrowphase = {"closed_form": 0, "gjk_manifold": 1}[narrowphase]                 # oracle/narrowphase.c [A35-A38]
         self.scene = sc
         self.traj_n_points, self.traj_spacing, self.traj_max_perturb = 10, 0.025, 0.1       # :229-231
         self._teleport_cube(0.0)                                                            # load_object at init pose
 
     def _teleport_cube(self, ang):
+        self.scene.mani.n = 0                                                               # resetBasePositionAndOrientation: the cached contact points are gone [A38]
         q = pm.quat_from_euler([-math.pi, 0.0, math.pi / 2 + ang])                          # :158,176
         self.init_obj_orn = q
         R = pm.mat_from_quat(q)

@@ -27,7 +27,7 @@ REWARD = {"dense": 0, "sparse": 1}
 PHYSICS = {"f64": 0, "f32": 1}
 CONTACT_MAP = {"auto": 0, "lane": 1, "wave": 2}
 RESET_BANK = {"auto": 0, "off": 1, "sync": 2, "on": 3}
-NARROWPHASE = {"closed_form": 0, "gjk_manifold": 1}
+NARROWPHASE = {"closed_form": 0, "gjk_manifold": 1, "gjk_single": 2}
 MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
 
 _d3 = C.c_double * 3
@@ -141,6 +141,7 @@ SYMBOLS = {
     "tg_sample_actions": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p]),
     "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     "tg_get_bank_stats": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "tg_selftest_narrowphase": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tg_pack_interior": (C.c_int, [_ctx, C.c_void_p]),
     "tg_unpack_interior": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p]),
     "tg_get_episode_stats": (C.c_int, [_ctx, _vpp, _vpp]),

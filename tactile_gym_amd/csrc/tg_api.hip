@@ -273,6 +273,7 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         if (cfg.tip_link < 0 || cfg.tip_link >= rob.ndof) return fail(-1, "object_push: tip_link out of range");
         if (rob.topology == 1 && cfg.tip_link >= Topo<1>::NP) return fail(-1, "object_push: the tip must hang off the MG400's main chain (j1..j5)");
         PushScene<T>& ps = c.push;
+        ps.narrow = cfg.narrowphase;
         ps.table_z = (T)cfg.table_z;
         for (int k = 0; k < 3; ++k) { ps.half[k] = (T)cfg.obj_half[k]; ps.com[k] = (T)cfg.obj_com[k]; c.obj_init_pos[k] = (T)cfg.obj_init_pos[k]; c.obj_init_rpy[k] = cfg.obj_init_rpy[k]; }
         ps.mu_table = (T)cfg.mu_table; ps.mu_tip = (T)cfg.mu_tip; ps.margin_cube = (T)cfg.margin_cube; ps.margin_tip = (T)cfg.margin_tip;
@@ -684,7 +685,7 @@ static bool use_contact_wave(const tg_ctx* c) {
     if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL && c->cfg.env_kind != TG_ENV_OBJECT_BALANCE) return false;
     if (c->cfg.physics_dtype != TG_PHYSICS_F64) return false;
     if (c->cfg.contact_mapping == TG_CONTACT_MAP_LANE) return false;
-    if (c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE) return true;
+    if (c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE || c->cfg.narrowphase != TG_NARROW_CLOSED_FORM) return true;
     return c->cfg.num_envs < 4096;
 }
 
@@ -739,7 +740,7 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask, bool bank = false) 
         }
     } else if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
         if (!(use_contact_wave(c) && launch_reset_contact_wave(c->cfg.env_kind, c->cfg.physics_dtype, c->robot.topology, c->cfg.cone_friction, c->cfg.num_envs,
-                                                               c->cfg.n_tip_verts, c->stream, c->d_robot, c->d_const, c->st, d_mask) == 0)) {
+                                                               c->cfg.n_tip_verts, c->stream, c->d_robot, c->d_const, c->st, d_mask, c->cfg.narrowphase) == 0)) {
 #define CALL(T, TOPO) launch_reset_push_t<T, TOPO>(c, d_mask)
             TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
@@ -828,6 +829,13 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     if (!((H % 128 == 0 && W % 128 == 0) || (H == 64 && W == 64))) return fail(-1, "tg_create: image size must be 64x64 or a multiple of 128");
     if (!sensor->nodef_dep || !sensor->nodef_gray || !sensor->border_mask) return fail(-1, "tg_create: sensor reference images missing");
     if (cfg->physics_dtype != TG_PHYSICS_F64 && cfg->physics_dtype != TG_PHYSICS_F32) return fail(-1, "tg_create: bad physics_dtype");
+    if (cfg->narrowphase < 0 || cfg->narrowphase > TG_NARROW_GJK_SINGLE) return fail(-1, "tg_create: bad narrowphase");
+    if (cfg->narrowphase != TG_NARROW_CLOSED_FORM) {
+        if (cfg->env_kind != TG_ENV_OBJECT_PUSH) return fail(-1, "tg_create: narrowphase GJK / EPA is built for object_push (the tip core - cube pair)");
+        if (cfg->physics_dtype != TG_PHYSICS_F64 || !cfg->cone_friction || cfg->contact_mapping == TG_CONTACT_MAP_LANE)
+            return fail(-1, "tg_create: narrowphase GJK / EPA runs on the wave mapping (f64, cone friction, contact_mapping auto or wave)");
+        if (cfg->n_tip_verts > 1152) return fail(-1, "tg_create: narrowphase GJK / EPA holds at most 1152 hull vertices");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(-3, "tg_create: no HIP device visible — the tactile-env step has no CPU fallback");
@@ -953,6 +961,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         TG_HIP(hipMalloc(&s.body_w, 3 * n * 8)); TG_HIP(hipMalloc(&s.noise_seed, n * 8)); TG_HIP(hipMalloc(&s.obj_mass, n * 8));
         TG_HIP(hipMalloc(&s.traj, (size_t)3 * TG_MAX_TRAJ_POINTS * n * 8)); TG_HIP(hipMalloc(&s.goal_id, n * 4));
         TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4));
+        if (cfg->narrowphase != TG_NARROW_CLOSED_FORM) { TG_HIP(hipMalloc(&s.mani, (size_t)37 * n * 8)); TG_HIP(hipMemset(s.mani, 0, (size_t)37 * n * 8)); }
         TG_HIP(hipMemset(s.body_v, 0, 3 * n * 8)); TG_HIP(hipMemset(s.body_w, 0, 3 * n * 8)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8));
         TG_HIP(hipMemset(s.traj, 0, (size_t)3 * TG_MAX_TRAJ_POINTS * n * 8)); TG_HIP(hipMemset(s.goal_id, 0, n * 4));
         TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
@@ -1128,7 +1137,7 @@ int tg_destroy(tg_ctx* c) {
     for (int k = 0; k < 2; ++k) if (c->step_graph[k]) (void)hipGraphExecDestroy(c->step_graph[k]);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -1188,7 +1197,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
             } else if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_step_body_t<double>(c, d_act);
             else launch_step_body_t<float>(c, d_act);
         } else if (use_contact_wave(c) && launch_step_contact_wave(c->cfg.env_kind, c->cfg.physics_dtype, c->robot.topology, c->cfg.control_mode, c->cfg.cone_friction,
-                                                                  c->cfg.num_envs, c->cfg.n_tip_verts, c->stream, c->d_robot, c->d_const, c->st, d_act) == 0) {
+                                                                  c->cfg.num_envs, c->cfg.n_tip_verts, c->stream, c->d_robot, c->d_const, c->st, d_act, c->cfg.narrowphase) == 0) {
             // object_push / object_roll with one wavefront per env (tg_contact_wave.hip)
         } else if (c->cfg.env_kind == TG_ENV_OBJECT_ROLL) {
 #define CALL(T, TOPO) launch_step_roll_t<T, TOPO>(c, d_act)
@@ -1702,11 +1711,13 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
         if ((rc = fetch_soa(c, c->st.contact_code, 1, code.data()))) return rc;
         for (int i = 0; i < n; ++i) {
             int cnt = 0;
-            int32_t ids[5] = {-1, -1, -1, -1, -1};
+            int32_t ids[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
             for (int b = 0; b < 8 && cnt < 4; ++b) if ((code[i] >> b) & 1) ids[cnt++] = b;
-            if ((code[i] >> 8) & 1) ids[cnt++] = 8 + (code[i] >> 9);
+            if ((code[i] >> 30) & 1) {   // tg_config.narrowphase != 0: bits 8-11 = the live slots of the tip - cube manifold, ids 8 + slot
+                for (int k = 0; k < 4; ++k) if ((code[i] >> (8 + k)) & 1) ids[cnt++] = 8 + k;
+            } else if ((code[i] >> 8) & 1) ids[cnt++] = 8 + (code[i] >> 9);
             if (v->contact_count) v->contact_count[i] = cnt;
-            if (v->contact_ids) for (int k = 0; k < 5; ++k) v->contact_ids[(size_t)i * 5 + k] = ids[k];
+            if (v->contact_ids) for (int k = 0; k < 8; ++k) v->contact_ids[(size_t)i * 8 + k] = ids[k];
         }
     }
     if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {

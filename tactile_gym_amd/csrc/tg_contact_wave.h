@@ -12,7 +12,9 @@ struct State;
 // is not instantiated (the caller then takes the lane-per-env kernels).
 int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int control_mode, int cone_friction, int num_envs, int n_tip_verts,
                              hipStream_t stream,
-                             const void* d_robot, const void* d_const, const State& st, const float* d_actions);
+                             const void* d_robot, const void* d_const, const State& st, const float* d_actions, int narrowphase = 0);
+// narrowphase (tg_config.narrowphase, object_push, f64): 0 closed forms; otherwise the tip - cube pair goes through GJK / EPA and the persistent
+// manifold (tg_narrowphase.hpp): the kernel's four-tip-slot variant.
 
 // object_balance (arm + pole + point-to-point constraint), TCP_velocity_control, f64, UR5: one wavefront per env (the env's own licence for the
 // analytic fixed point, full ticks on the wave mapping).  -1: not instantiated.
@@ -24,6 +26,6 @@ int launch_step_arm_wave(int physics_dtype, int topology, int control_mode, int 
                          const State& st, const float* d_actions);
 // env.reset() for the envs flagged in d_mask (nullptr: all) with the same mapping: one wavefront per resetting env, the others exit at once.
 int launch_reset_contact_wave(int env_kind, int physics_dtype, int topology, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
-                              const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask);
+                              const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask, int narrowphase = 0);
 
 }  // namespace tg

@@ -33,6 +33,7 @@
 #include "tg_contact_wave.h"
 
 #include "tg_kernels.hpp"
+#include "tg_narrowphase.hpp"
 
 #include <cstdio>
 
@@ -104,6 +105,11 @@ constexpr int kCW = 120;                                                        
 constexpr int kLC = kLW + kNG * 16;                                                           // link constant table, 8 x kCW
 constexpr int kLS = kLC + 8 * kCW;                                                            // link slots for the inertia matrix: a, o, F, N (12) x 8
 constexpr int kLHull = kLS + 8 * 12;                                                          // tip-core hull vertices, 3 per vertex
+
+// tg_config.narrowphase != 0 (NT = 4 tip slots): a region behind the hull (its offset is a run-time value, kLHull + 3 n_tip):
+//   [0, 912)      the expanding polytope's scratch during contact generation, then the solver's W rows (32 x 16) and the tip rows' J (12 x 16)
+//   [912, 977)    the tip - cube manifold (tg_narrowphase.hpp layout)
+constexpr int kXW = 0, kXJ = 32 * 16, kXMani = narrow::kScratchWords > (32 + 12) * 16 ? narrow::kScratchWords : (32 + 12) * 16, kXWords = kXMani + narrow::kManiWords + 7;
 
 #define TG_PHASE_FENCE() { __syncthreads(); asm volatile("" ::: "memory"); }
 
@@ -398,11 +404,16 @@ __device__ __forceinline__ void tick_dynamics(const DevRobot<T>* __restrict__ mp
 }
 
 // One stepSimulation() tick on the LDS-resident env state.  Returns the tick's contact code (tg_state_view.contact_ids).
-template <typename T, int TOPO, int MOTOR, int SHAPE, bool CONE>
+template <typename T, int TOPO, int MOTOR, int SHAPE, bool CONE, int NT = 1>
 __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const PushScene<T>& sc, lds_ptr<T> L, T kp, T kd, T max_force, T dt, int iters,
-                                                     T mass, int lane_in) {
+                                                     T mass, int lane_in, int xbase = 0) {
     constexpr int N = Topo<TOPO>::N;
     constexpr int NP = Topo<TOPO>::NP;
+    // NT = 1: one tip contact per tick from the closed forms (the default).  NT = 4 (object_push, f64): up to four tip contacts from the
+    // persistent manifold fed by GJK / EPA; the row lanes grow to 40, the accumulator lanes move to 40.., the watch lanes to 56..
+    static_assert(NT == 1 || (NT == 4 && SHAPE == 0), "the manifold variant is object_push's");
+    constexpr int RL = NT == 1 ? kRowLanes : 40, ACC0 = NT == 1 ? 32 : 40, W0 = NT == 1 ? 48 : 56, NGT = NT == 1 ? kNG : 32, NCT = 4 + NT;
+    const int lw = NT == 1 ? kLW : xbase + kXW;          // where the W rows of this tick live
     int contact_code = 0;
     // The lane index goes through an opaque copy per tick: everything derived from it alone (row masks, the H table, accumulator selects:
     // ~60 values) would otherwise be hoisted out of the 24-tick loop as loop invariants and, with the register file full, live in scratch
@@ -454,8 +465,9 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     // ---- this lane's row
     const int cl = lane - kContactLane0;
     const int cc = cl >> 2, rr_ = cl & 3;                                   // contact slot and row within it
-    const bool contact_lane = lane >= kContactLane0 && lane < kRowLanes && rr_ < 3;
-    const bool tip_lane = contact_lane && cc == 4, table_lane = contact_lane && cc < 4, motor_lane = lane < N;
+    const bool contact_lane = lane >= kContactLane0 && lane < RL && rr_ < 3;
+    const bool tip_lane = contact_lane && cc >= 4, table_lane = contact_lane && cc < 4, motor_lane = lane < N;
+    const int ts_ = cc >= 4 ? (cc - 4 < NT ? cc - 4 : NT - 1) : 0;       // this lane's tip slot (NT = 4)
     // ---- body - table contacts: the kept cube vertices take slots 0.. in vertex order; a table lane finds the vertex of its slot
     V3<T> my_ra = mk<T>(0, 0, 0);
     T my_depth = T(0);
@@ -499,7 +511,100 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     V3<T> jt[NP];                       // translational Jacobian columns of the tip point
     V3<T> tdir[3], trb;                 // row directions (n, t1, t2), contact arm on the body
     T tip_depth; bool tip_active;
-    {
+    int tip_mask = 0;                   // NT = 4: the manifold's live slots
+    if constexpr (NT == 4) {
+        // ---- the general narrowphase: broadphase AABB overlap of the pair, GJK / EPA on the core shapes in the box frame, one new point per
+        // tick into the persistent manifold, refresh; every surviving point is a contact (oracle/minibullet.c, narrowphase == 1) [A35-A38]
+        if constexpr (sizeof(T) == 8) {
+            const narrow::lptr<double> xs = (narrow::lptr<double>)(L + xbase), mf = (narrow::lptr<double>)(L + xbase + kXMani);
+            double ol[3], Rl[9], bp[3], bR[9];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { ol[e] = L[kLTipF + e]; bp[e] = L[kLBody + e]; }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { Rl[e] = L[kLTipF + 3 + e]; bR[e] = L[kLBody + 3 + e]; }
+            const int n_tip = __builtin_amdgcn_readfirstlane(sc.n_tip);
+            narrow::Hull H;
+            H.n = n_tip;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int k = 0; k < narrow::kSlots; ++k) {
+                    const int i = 64 * k + lane;
+                    const int ii = i < n_tip ? i : 0;
+                    const double v0 = L[kLHull + 3 * ii], v1 = L[kLHull + 3 * ii + 1], v2 = L[kLHull + 3 * ii + 2];
+                    double w[3], dd[3];
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) {
+                        w[x] = ol[x] + ((Rl[3 * x] * v0 + Rl[3 * x + 1] * v1) + Rl[3 * x + 2] * v2);
+                        dd[x] = w[x] - bp[x];
+                        if (i < n_tip) { lo[x] = w[x] < lo[x] ? w[x] : lo[x]; hi[x] = w[x] > hi[x] ? w[x] : hi[x]; }
+                    }
+                    H.x[k] = (bR[0] * dd[0] + bR[3] * dd[1]) + bR[6] * dd[2];
+                    H.y[k] = (bR[1] * dd[0] + bR[4] * dd[1]) + bR[7] * dd[2];
+                    H.z[k] = (bR[2] * dd[0] + bR[5] * dd[1]) + bR[8] * dd[2];
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) { lo[x] = vmin(lo[x], __shfl_xor(lo[x], off)); hi[x] = vmax(hi[x], __shfl_xor(hi[x], off)); }
+            const double half[3] = {sc.half[0], sc.half[1], sc.half[2]};
+            bool overlap = n_tip > 0;
+            {
+#pragma clang fp contract(off)
+                const double pad = (sc.margin_tip + sc.margin_cube) + sc.breaking;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const double ext = (fabs(bR[3 * x]) * half[0] + fabs(bR[3 * x + 1]) * half[1]) + fabs(bR[3 * x + 2]) * half[2];
+                    if (lo[x] - pad > bp[x] + ext || hi[x] + pad < bp[x] - ext) overlap = false;
+                }
+            }
+            __syncthreads();
+            if (!uniform_true(overlap) || sc.narrow == 2) { if (lane == 0) mf[narrow::kMcount] = 0.0; }
+            __syncthreads();
+            if (uniform_true(overlap)) {
+                double sd = 0.0, nb[3], ab[3], bb[3];
+                if (narrow::gjk_epa_hull_box(H, half, xs + kXW, sd, nb, ab, bb, lane)) {
+#pragma clang fp contract(off)
+                    const double depth = sd - (sc.margin_tip + sc.margin_cube);
+                    double nw[3], aw[3], bw[3], pa_[3], pb_[3];
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) {
+                        nw[x] = (bR[3 * x] * nb[0] + bR[3 * x + 1] * nb[1]) + bR[3 * x + 2] * nb[2];
+                        aw[x] = (bR[3 * x] * ab[0] + bR[3 * x + 1] * ab[1]) + bR[3 * x + 2] * ab[2];
+                        bw[x] = (bR[3 * x] * bb[0] + bR[3 * x + 1] * bb[1]) + bR[3 * x + 2] * bb[2];
+                    }
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) { pa_[x] = (bp[x] + aw[x]) - nw[x] * sc.margin_tip; pb_[x] = (bp[x] + bw[x]) + nw[x] * sc.margin_cube; }
+                    narrow::manifold_add(mf, sc.breaking, ol, Rl, bp, bR, pa_, pb_, nw, depth, lane);
+                }
+                narrow::manifold_refresh(mf, sc.breaking, ol, Rl, bp, bR, lane);
+            }
+            __syncthreads();
+            const int mc = __builtin_amdgcn_readfirstlane((int)mf[narrow::kMcount]);
+            tip_mask = (1 << mc) - 1;
+            contact_code |= (tip_mask << 8) | (1 << 30);
+            // this lane's tip slot: normal, arm points, depth (lanes that are not tip lanes read slot 0: finite values nobody uses)
+            const V3<T> nrm = mk((T)mf[narrow::kMn + 3 * ts_], (T)mf[narrow::kMn + 3 * ts_ + 1], (T)mf[narrow::kMn + 3 * ts_ + 2]);
+            const V3<T> pa = mk((T)mf[narrow::kMpa + 3 * ts_], (T)mf[narrow::kMpa + 3 * ts_ + 1], (T)mf[narrow::kMpa + 3 * ts_ + 2]);
+            const V3<T> pb = mk((T)mf[narrow::kMpb + 3 * ts_], (T)mf[narrow::kMpb + 3 * ts_ + 1], (T)mf[narrow::kMpb + 3 * ts_ + 2]);
+            const bool live = ((tip_mask >> ts_) & 1) != 0;
+            tip_depth = live ? (T)mf[narrow::kMdepth + ts_] : T(0);
+            tip_active = live;
+            V3<T> t1, t2;
+            plane_space(live ? nrm : mk<T>(0, 0, 1), t1, t2);
+            tdir[0] = live ? nrm : mk<T>(0, 0, 1); tdir[1] = t1; tdir[2] = t2;
+            trb = pb - xc;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const V3<T> ai = mk(L[kLJa + 3 * i], L[kLJa + 3 * i + 1], L[kLJa + 3 * i + 2]);
+                const V3<T> oi = mk(L[kLJo + 3 * i], L[kLJo + 3 * i + 1], L[kLJo + 3 * i + 2]);
+                jt[i] = cross(ai, pa - oi);
+            }
+            __syncthreads();   // the scratch region becomes the W / J rows below
+        }
+    } else {
         const V3<T> ol = mk(L[kLTipF + 0], L[kLTipF + 1], L[kLTipF + 2]);
         M3<T> Rl;
 #pragma unroll
@@ -649,7 +754,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     const bool fric_lane = contact_lane && rr_ > 0;
     const T own_diag = fric_lane ? T(0) : T(1);
     const int my_gi = motor_lane ? lane : (contact_lane ? 8 + 3 * cc + rr_ : -1);   // this lane's own row index
-    T G[kNG], HN[5], HF[5];
+    T G[NGT], HN[NCT], HF[NCT];
 #pragma unroll
     for (int i = 0; i < 8; ++i) G[i] = i < N ? Warm[i < N ? i : 0] * jdi : T(0);
 #pragma unroll
@@ -661,29 +766,52 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         G[8 + 3 * c + 1] = (-Wl.y + (raz * Wa.x - rax * Wa.z)) * jdi;        // t1 = (0,-1, 0)
         G[8 + 3 * c + 2] = (Wl.x + (raz * Wa.y - ray * Wa.z)) * jdi;         // t2 = (1, 0, 0)
     }
+    if constexpr (NT == 1) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const V3<T> dr = tdir[r];
-        T a = -dot(dr, Wl) - dot(cross(trb, dr), Wa);
+        for (int r = 0; r < 3; ++r) {
+            const V3<T> dr = tdir[r];
+            T a = -dot(dr, Wl) - dot(cross(trb, dr), Wa);
 #pragma unroll
-        for (int i = 0; i < NP; ++i) a += dot(jt[i], dr) * Warm[i];
-        G[8 + 12 + r] = a * jdi;
+            for (int i = 0; i < NP; ++i) a += dot(jt[i], dr) * Warm[i];
+            G[8 + 12 + r] = a * jdi;
+        }
+    } else {
+        // the twelve tip rows differ from lane to lane: every tip lane puts its J row (arm part, cube linear, cube angular) into LDS, every
+        // lane then forms  J_r . W_mine  for the twelve of them from broadcast reads
+        const int xj = xbase + kXJ;
+        if (tip_lane) {
+            const int row = 3 * ts_ + rr_;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) L[xj + row * 16 + k] = k < N ? ja[k < N ? k : 0] : T(0);
+            L[xj + row * 16 + 8] = Jl.x; L[xj + row * 16 + 9] = Jl.y; L[xj + row * 16 + 10] = Jl.z;
+            L[xj + row * 16 + 11] = Ja.x; L[xj + row * 16 + 12] = Ja.y; L[xj + row * 16 + 13] = Ja.z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            T a = T(0);
+#pragma unroll
+            for (int k = 0; k < N; ++k) a += L[xj + r * 16 + k] * Warm[k];
+            a += L[xj + r * 16 + 8] * Wl.x + L[xj + r * 16 + 9] * Wl.y + L[xj + r * 16 + 10] * Wl.z;
+            a += L[xj + r * 16 + 11] * Wa.x + L[xj + r * 16 + 12] * Wa.y + L[xj + r * 16 + 13] * Wa.z;
+            G[8 + 12 + r] = ((tip_mask >> (r / 3)) & 1) ? a * jdi : T(0);
+        }
     }
     {   // W rows to LDS (row-major [row][k], zero for rows that are not active), then the accumulator lanes pick up their columns
         if (my_gi >= 0) {
             const T keep_ = active ? T(1) : T(0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) L[kLW + my_gi * 16 + k] = k < N ? Warm[k < N ? k : 0] * keep_ : T(0);
-            L[kLW + my_gi * 16 + 8] = Wl.x * keep_; L[kLW + my_gi * 16 + 9] = Wl.y * keep_; L[kLW + my_gi * 16 + 10] = Wl.z * keep_;
-            L[kLW + my_gi * 16 + 11] = Wa.x * keep_; L[kLW + my_gi * 16 + 12] = Wa.y * keep_; L[kLW + my_gi * 16 + 13] = Wa.z * keep_;
+            for (int k = 0; k < 8; ++k) L[lw + my_gi * 16 + k] = k < N ? Warm[k < N ? k : 0] * keep_ : T(0);
+            L[lw + my_gi * 16 + 8] = Wl.x * keep_; L[lw + my_gi * 16 + 9] = Wl.y * keep_; L[lw + my_gi * 16 + 10] = Wl.z * keep_;
+            L[lw + my_gi * 16 + 11] = Wa.x * keep_; L[lw + my_gi * 16 + 12] = Wa.y * keep_; L[lw + my_gi * 16 + 13] = Wa.z * keep_;
         }
         __syncthreads();
-        const int ku = lane - 32;
+        const int ku = lane - ACC0;
 #pragma unroll
-        for (int i = 0; i < kNG; ++i) {
-            const T wv = L[kLW + i * 16 + (ku >= 0 && ku < kNU ? ku : 0)];
+        for (int i = 0; i < NGT; ++i) {
+            const T wv = L[lw + i * 16 + (ku >= 0 && ku < kNU ? ku : 0)];
             const T g_row = lane == (i < 8 ? i : kContactLane0 + 4 * ((i - 8) / 3) + (i - 8) % 3) ? own_diag : G[i];
-            G[i] = (ku >= 0 && ku < kNU) ? -wv : ((lane >= 48 && lane < 48 + N) ? (i == lane - 48 ? T(-1) : T(0)) : (lane < 32 ? g_row : T(0)));
+            G[i] = (ku >= 0 && ku < kNU) ? -wv : ((lane >= W0 && lane < W0 + N) ? (i == lane - W0 ? T(-1) : T(0)) : (lane < ACC0 ? g_row : T(0)));
         }
     }
     // ---- joint-motor sweep as ONE linear map (the sweeps run the motors without their clamp, see below).  A Gauss-Seidel pass over the
@@ -696,7 +824,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         __syncthreads();                 // the W rows in LDS have been consumed: the region is reused for L
         if (lane < N) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) L[kLW + lane * 8 + k] = G[k];
+            for (int k = 0; k < N; ++k) L[lw + lane * 8 + k] = G[k];
         }
         __syncthreads();
 #pragma unroll
@@ -708,7 +836,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
             for (int i = m + 1; i < N; ++i) {
                 T acc = T(0);
 #pragma unroll
-                for (int k = m; k < i; ++k) acc = __builtin_fma(L[kLW + i * 8 + k], t[k], acc);
+                for (int k = m; k < i; ++k) acc = __builtin_fma(L[lw + i * 8 + k], t[k], acc);
                 t[i] = -acc;
                 c = __builtin_fma(G[i], t[i], c);
             }
@@ -723,7 +851,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
             for (int i = m - 1; i >= 0; --i) {
                 T acc = T(0);
 #pragma unroll
-                for (int k = i + 1; k <= m; ++k) acc = __builtin_fma(L[kLW + i * 8 + k], t[k], acc);
+                for (int k = i + 1; k <= m; ++k) acc = __builtin_fma(L[lw + i * 8 + k], t[k], acc);
                 t[i] = -acc;
                 c = __builtin_fma(G[i], t[i], c);
             }
@@ -731,14 +859,15 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         }
     }
 #pragma unroll
-    for (int c5 = 0; c5 < 5; ++c5) {
+    for (int c5 = 0; c5 < NCT; ++c5) {
         const bool mine = contact_lane && cc == c5;
         HN[c5] = mine ? T(1) : T(0);
         HF[c5] = (mine && rr_ > 0) ? T(1) : T(0);
     }
-    const T x0 = lane < 32 ? rhs * jdi : T(0);
+    const T x0 = lane < ACC0 ? rhs * jdi : T(0);
     int tip_i;                           // wave-uniform flag in an SGPR (s_cmp + s_cbranch_scc in the sweeps, no lane-mask round trip)
-    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(tip_i) : "v"(tip_active ? 1 : 0));
+    if constexpr (NT == 1) { asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(tip_i) : "v"(tip_active ? 1 : 0)); }
+    else tip_i = __builtin_amdgcn_readfirstlane(tip_mask);     // bit k: manifold slot k is live
     TG_PHASE_FENCE()
     TG_STAMP(4)
     // =============================================================== phase 3: 150 projected Gauss-Seidel sweeps
@@ -758,13 +887,13 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     T x = x0, lam = T(0), lamF = T(0);   // lam: impulse of a motor / normal row (on friction lanes: their contact's normal impulse); lamF: friction rows
     const T maximp = max_force * dt;
 #pragma unroll
-    for (int i = 0; i < kNG; ++i) asm volatile("" : "+v"(G[i]));          // coefficient rows in architectural VGPRs for the sweeps (the allocator
+    for (int i = 0; i < NGT; ++i) asm volatile("" : "+v"(G[i]));          // coefficient rows in architectural VGPRs for the sweeps (the allocator
 #pragma unroll
-    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(HN[i]), "+v"(HF[i]));   // otherwise parks some of them in AGPRs: two v_accvgpr_read per use)
+    for (int i = 0; i < NCT; ++i) asm volatile("" : "+v"(HN[i]), "+v"(HF[i]));   // otherwise parks some of them in AGPRs: two v_accvgpr_read per use)
     T mu_lane = tip_lane ? sc.mu_tip : sc.mu_table;   // friction coefficient of this lane's contact (the cone limit is evaluated lane-locally)
     asm volatile("" : "+v"(mu_lane));
     const int n_it = __builtin_amdgcn_readfirstlane(iters < 0 ? -iters : iters);   // contact problems do not reach their fixed point within 150 sweeps: no exit test
-    const bool watch_lane = lane >= 48 && lane < 48 + N;
+    const bool watch_lane = lane >= W0 && lane < W0 + N;
 
 #define TG_MOTOR_STEP(I)                                                               \
     {                                                                                  \
@@ -831,9 +960,11 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
             _Pragma("unroll") for (int k_ = 0; k_ < (SHAPE == 1 ? 1 : 4); ++k_) TG_NORMAL_STEP(kContactLane0 + 4 * k_, 8 + 3 * k_) \
         }                                                                              \
         if (CLAMPED == 0) wmax = vmax_abs(wmax, x);   /* lanes 48..: the largest motor impulse any sweep has seen */ \
-        if (tip_i) TG_NORMAL_STEP(kContactLane0 + 16, 8 + 12)                          \
+        if (NT == 1) { if (tip_i) TG_NORMAL_STEP(kContactLane0 + 16, 8 + 12) }         \
+        else { _Pragma("unroll") for (int k_ = 0; k_ < NT; ++k_) if (tip_i & (1 << k_)) TG_NORMAL_STEP(kContactLane0 + 16 + 4 * k_, 8 + 12 + 3 * k_) } \
         _Pragma("unroll") for (int k_ = 0; k_ < (SHAPE == 1 ? 1 : 4); ++k_) TG_FRICTION_STEP(kContactLane0 + 4 * k_, 8 + 3 * k_ + 1, mu_table) \
-        if (tip_i) TG_FRICTION_STEP(kContactLane0 + 16, 8 + 13, mu_tip)                \
+        if (NT == 1) { if (tip_i) TG_FRICTION_STEP(kContactLane0 + 16, 8 + 13, mu_tip) } \
+        else { _Pragma("unroll") for (int k_ = 0; k_ < NT; ++k_) if (tip_i & (1 << k_)) TG_FRICTION_STEP(kContactLane0 + 16 + 4 * k_, 8 + 13 + 3 * k_, mu_tip) } \
     }
 #define TG_SOLVE()                                                                     \
     {                                                                                  \
@@ -861,7 +992,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
     // =============================================================== phase 4: integrate (lanes 32 .. 45 hold du)
     T du[kNU];
 #pragma unroll
-    for (int k = 0; k < kNU; ++k) du[k] = bcast(x, 32 + k);
+    for (int k = 0; k < kNU; ++k) du[k] = bcast(x, ACC0 + k);
     asm volatile("" ::: "memory");
     {
         T q[N], dq[N], qd[N];
@@ -899,7 +1030,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
 }
 
 // BaseTactileEnv.step (base_tactile_env.py:166-185) for object_push (SHAPE 0) / object_roll (SHAPE 1), one wavefront per env.
-template <typename T, int TOPO, bool POS, int SHAPE, bool CONE>
+template <typename T, int TOPO, bool POS, int SHAPE, bool CONE, int NT = 1>
 __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                           const float* __restrict__ actions) {
     constexpr int N = Topo<TOPO>::N;
@@ -917,6 +1048,10 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
         const T* tipv = (const T*)st.tip_verts;
         const int nw = 3 * c.push.n_tip;
         for (int w = lane; w < nw; w += 64) L[kLHull + w] = tipv[w];
+    }
+    const int xbase = kLHull + 3 * c.push.n_tip;          // NT = 4: scratch / W rows / manifold behind the hull
+    if constexpr (NT == 4) {             // the tip - cube manifold lives in LDS for the step's ticks
+        if (lane < 37) L[xbase + kXMani + (lane < 36 ? lane : narrow::kMcount)] = (T)st.mani[(size_t)lane * n + env];
     }
     stage_link_constants<T, TOPO>(mp, L, lane);
     V3<T> tpos; Q4<T> tq;                // TCP_position_control: the pose target of the blocking move
@@ -985,14 +1120,17 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
 #pragma unroll
             for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
             const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
-            ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE>(m, c.push, L, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters,
-                                                                                mass_or_radius, lane);
+            ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE, NT>(m, c.push, L, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters,
+                                                                                    mass_or_radius, lane, xbase);
             if (uniform_true(stop)) break;
         }
     } else {
         for (int t = 0; t < c.action_repeat; ++t)
-            ccode = sim_tick_contact_wave<T, TOPO, kMotorVelocity, SHAPE, CONE>(m, c.push, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters,
-                                                                                mass_or_radius, lane);
+            ccode = sim_tick_contact_wave<T, TOPO, kMotorVelocity, SHAPE, CONE, NT>(m, c.push, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters,
+                                                                                    mass_or_radius, lane, xbase);
+    }
+    if constexpr (NT == 4) {
+        if (lane < 37) st.mani[(size_t)lane * n + env] = (double)L[xbase + kXMani + (lane < 36 ? lane : narrow::kMcount)];
     }
     // ---- results: every lane holds the same values; identical values go to identical addresses
     T q[N], qd[N];
@@ -1605,7 +1743,7 @@ __global__ __launch_bounds__(64) void k_step_arm_wave(const DevRobot<T>* __restr
 // inverse kinematics of the start pose (wave-uniform, every lane the same), then the blocking move - each tick sim_tick_contact_wave with
 // position motors (max force 100 000 as robot.py:188-260 / base_robot_arm.py pass it) against the PREVIOUS episode's object - then the object
 // is put back and the first observation's transforms are written.
-template <typename T, int TOPO, int SHAPE, bool CONE>
+template <typename T, int TOPO, int SHAPE, bool CONE, int NT = 1>
 __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                            const uint8_t* __restrict__ mask) {
     constexpr int N = Topo<TOPO>::N;
@@ -1672,6 +1810,10 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
         const int nw = 3 * c.push.n_tip;
         for (int w = lane; w < nw; w += 64) L[kLHull + w] = tipv[w];
     }
+    const int xbase = kLHull + 3 * c.push.n_tip;
+    if constexpr (NT == 4) {             // the blocking move runs against the previous episode's cube: its manifold is still there
+        if (lane < 37) L[xbase + kXMani + (lane < 36 ? lane : narrow::kMcount)] = (T)st.mani[(size_t)lane * n + env];
+    }
     stage_link_constants<T, TOPO>(mp, L, lane);
     {
         const FreeBody<T> b0 = load_body<T>(st, n, env);
@@ -1721,7 +1863,7 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
         }
         if (all_small) cv = cv / T(2);
         TG_PHASE_FENCE()
-        ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE>(m, c.push, L, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, (T)old_mr, lane);
+        ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE, NT>(m, c.push, L, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, (T)old_mr, lane, xbase);
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
@@ -1743,6 +1885,9 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
         for (int e = 0; e < 9; ++e) b.R.m[e] = ident[e];
     }
     b.v = mk<T>(0, 0, 0); b.w = mk<T>(0, 0, 0);
+    if constexpr (NT == 4) {             // reset_object teleports the cube: the cached contact points go with it [A38]
+        if (lane < 37) st.mani[(size_t)lane * n + env] = 0.0;
+    }
     if (w0) {
         st.reset_ticks[env] = used;
         st.contact_code[env] = ccode;
@@ -1756,10 +1901,24 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
 }
 
 template <typename T, int TOPO, int SHAPE>
-int launch_wave_t(int control_mode, int cone, int n, int n_tip, hipStream_t stream, const void* d_robot, const void* d_const, const State& st, const float* d_actions) {
-    const size_t lds_bytes = (size_t)(kLHull + (SHAPE == 1 ? 0 : 3 * n_tip)) * sizeof(T);   // env state + per-tick hand-offs + the tip-core hull
+int launch_wave_t(int control_mode, int cone, int n, int n_tip, hipStream_t stream, const void* d_robot, const void* d_const, const State& st, const float* d_actions,
+                  int narrowphase = 0) {
+    const size_t lds_bytes = (size_t)(kLHull + (SHAPE == 1 ? 0 : 3 * n_tip) + (narrowphase ? kXWords : 0)) * sizeof(T);   // env state + per-tick hand-offs + the tip-core hull
     if (lds_bytes > 60 * 1024) return -1;                                                   // (1089 vertices: 31 KB; 4 envs per CU fit 160 KB)
     if (!cone) return -1;                // pyramid friction (enableConeFriction = 0, not what the reference sets): the lane-per-env kernels
+    if constexpr (SHAPE == 0 && sizeof(T) == 8) {
+        if (narrowphase) {               // GJK / EPA + manifold: the four-slot variant of the same kernel
+            if (n_tip > 64 * narrow::kSlots) return -1;
+            if (control_mode == TG_CONTROL_TCP_POSITION)
+                hipLaunchKernelGGL((k_step_contact_wave<T, TOPO, true, 0, true, 4>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
+                                   (const EnvConst<T>*)d_const, st, d_actions);
+            else
+                hipLaunchKernelGGL((k_step_contact_wave<T, TOPO, false, 0, true, 4>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
+                                   (const EnvConst<T>*)d_const, st, d_actions);
+            return 0;
+        }
+    }
+    if (narrowphase) return -1;
     if (control_mode == TG_CONTROL_TCP_POSITION)
         hipLaunchKernelGGL((k_step_contact_wave<T, TOPO, true, SHAPE, true>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
                            (const EnvConst<T>*)d_const, st, d_actions);
@@ -1770,9 +1929,19 @@ int launch_wave_t(int control_mode, int cone, int n, int n_tip, hipStream_t stre
 }
 
 template <typename T, int TOPO, int SHAPE>
-int launch_reset_wave_t(int cone, int n, int n_tip, hipStream_t stream, const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask) {
-    const size_t lds_bytes = (size_t)(kLHull + (SHAPE == 1 ? 0 : 3 * n_tip)) * sizeof(T);
+int launch_reset_wave_t(int cone, int n, int n_tip, hipStream_t stream, const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask,
+                        int narrowphase = 0) {
+    const size_t lds_bytes = (size_t)(kLHull + (SHAPE == 1 ? 0 : 3 * n_tip) + (narrowphase ? kXWords : 0)) * sizeof(T);
     if (lds_bytes > 60 * 1024 || !cone) return -1;
+    if constexpr (SHAPE == 0 && sizeof(T) == 8) {
+        if (narrowphase) {
+            if (n_tip > 64 * narrow::kSlots) return -1;
+            hipLaunchKernelGGL((k_reset_contact_wave<T, TOPO, 0, true, 4>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
+                               (const EnvConst<T>*)d_const, st, d_mask);
+            return 0;
+        }
+    }
+    if (narrowphase) return -1;
     hipLaunchKernelGGL((k_reset_contact_wave<T, TOPO, SHAPE, true>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
                        (const EnvConst<T>*)d_const, st, d_mask);
     return 0;
@@ -1801,19 +1970,20 @@ int launch_step_arm_wave(int physics_dtype, int topology, int control_mode, int 
 }
 
 int launch_reset_contact_wave(int env_kind, int physics_dtype, int topology, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
-                              const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask) {
+                              const void* d_robot, const void* d_const, const State& st, const uint8_t* d_mask, int narrowphase) {
     if (physics_dtype != TG_PHYSICS_F64) return -1;
     if (env_kind == TG_ENV_OBJECT_PUSH) {
-        if (topology == 0) return launch_reset_wave_t<double, 0, 0>(cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_mask);
-        return launch_reset_wave_t<double, 1, 0>(cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_mask);
+        if (topology == 0) return launch_reset_wave_t<double, 0, 0>(cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_mask, narrowphase);
+        return launch_reset_wave_t<double, 1, 0>(cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_mask, narrowphase);
     }
+    if (narrowphase) return -1;
     if (env_kind == TG_ENV_OBJECT_ROLL && topology == 0)
         return launch_reset_wave_t<double, 0, 1>(cone_friction, num_envs, 0, stream, d_robot, d_const, st, d_mask);
     return -1;
 }
 
 int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int control_mode, int cone_friction, int num_envs, int n_tip_verts, hipStream_t stream,
-                             const void* d_robot, const void* d_const, const State& st, const float* d_actions) {
+                             const void* d_robot, const void* d_const, const State& st, const float* d_actions, int narrowphase) {
 #if TG_WAVE_TIMING
     {
         static int calls = 0;
@@ -1830,9 +2000,10 @@ int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int 
 #endif
     if (physics_dtype != TG_PHYSICS_F64) return -1;       // the f32 variant keeps the lane-per-env mapping
     if (env_kind == TG_ENV_OBJECT_PUSH) {
-        if (topology == 0) return launch_wave_t<double, 0, 0>(control_mode, cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_actions);
-        return launch_wave_t<double, 1, 0>(control_mode, cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_actions);
+        if (topology == 0) return launch_wave_t<double, 0, 0>(control_mode, cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_actions, narrowphase);
+        return launch_wave_t<double, 1, 0>(control_mode, cone_friction, num_envs, n_tip_verts, stream, d_robot, d_const, st, d_actions, narrowphase);
     }
+    if (narrowphase) return -1;
     if (env_kind == TG_ENV_OBJECT_ROLL && topology == 0)
         return launch_wave_t<double, 0, 1>(control_mode, cone_friction, num_envs, 0, stream, d_robot, d_const, st, d_actions);
     return -1;

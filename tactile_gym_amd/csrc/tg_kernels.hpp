@@ -78,6 +78,7 @@ struct State {   // device pointers, SoA [field][num_envs]
     float* ep_final_return;         // [n] the finished episode's return (valid where done)
     int32_t* ep_final_len;          // [n] its length in env steps
     const void* tip_verts;          // [n_tip][3] in the physics dtype
+    double* mani;                   // [37][n] object_push with tg_config.narrowphase != 0: the tip - cube contact manifold (la, lb, normal of 4 points; count)
 #ifdef TG_TL_STAMPS
     unsigned long long* tl;         // development: [4][8192] launch-start stamps (wall clock) + [4] counters behind them
 #endif

@@ -1029,6 +1029,7 @@ template <typename T> struct PushScene {
     T table_z, half[3], mu_table, mu_tip, margin_cube, margin_tip, breaking, erp, tip_stiffness, tip_damping, lin_damp, ang_damp;
     T com[3], inertia0[6], mass0;
     int tip_link, n_tip, cone_friction;
+    int narrow;   // tg_config.narrowphase: 0 closed forms; 1 GJK / EPA + persistent manifold; 2 GJK / EPA, the tick's point only (tg_narrowphase.hpp)
     // object_roll (SHAPE = 1): the free body is a sphere of radius `radius` x scale (inertia0 = that of radius0), the tip collision shape a
     // solid cylinder (axis = local z) given in the frame of tip_link (ur5_with_flat_tactip.urdf:320-325) [PARITY_ASSUMPTIONS A30]
     T radius0, cyl_pos[3], cyl_hl, cyl_r;

@@ -469,7 +469,7 @@ class TactileVecEnv(_VecEnvBase):
             out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
                        goal_pos=np.zeros((n, 3)), obj_mass=np.zeros(n))
         if self._cfg.env_kind in (capi.ENV_OBJECT_PUSH, capi.ENV_OBJECT_ROLL):   # contact pairs of the last sim tick (tg_state_view)
-            out.update(contact_count=np.zeros(n, np.int32), contact_ids=np.zeros((n, 5), np.int32))
+            out.update(contact_count=np.zeros(n, np.int32), contact_ids=np.zeros((n, 8), np.int32))
         if self._cfg.env_kind == capi.ENV_SURFACE_FOLLOW_AUTO:
             out.update(goal_pos=np.zeros((n, 3)), direction=np.zeros((n, 2)), surf_zoff=np.zeros(n, np.float32),
                        heights=np.zeros((n, self._cfg.surf_rows, self._cfg.surf_cols)))

@@ -210,3 +210,31 @@ def test_long_horizon_object_push_matches_oracle():
     assert (hip["cc"] == 5).mean() > 0.5 and knife <= n
     print(f"object_push: {n} envs x {steps} steps: contact ids / goal index exact; worst |d cube pose| per step: first {worst[0]:.1e}, step 30 {worst[29]:.1e}, "
           f"last {worst[-1]:.1e} (bound {bound[-1]:.1e}); images not bit-exact {bad_images} of {n * (steps + 1)}")
+
+
+def test_config4_manifold_narrowphase_1024_envs_match_oracle():
+    """Config 4 at its own batch size with tg_config.narrowphase = GJK / EPA + persistent manifold (row n2): 1024 envs x (reset + 8 steps); contact
+    counts and ids (table vertices, then 8 + manifold slot) bit-exact on every env and step, cube pose 1e-8, joints 1e-9, config 4's image rule."""
+    env_id, cls, modes, size, act_dim, max_steps = CASES["config4_object_push"]
+    n, steps, seed = 1024, 8, 900
+    actions = np.random.default_rng(7).uniform(-0.25, 0.25, size=(steps, n, act_dim)).astype(np.float32)
+    hip = _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset=False, want_contacts=True, narrowphase="gjk_manifold")
+    ref = oracle_rollouts(cls, dict(max_steps=max_steps, image_size=(size, size), env_modes=modes, narrowphase="gjk_manifold"), seed, actions, follow=hip["goal_id"])
+    worst_q = worst_b = 0.0
+    bad_images = 0
+    for i, r in enumerate(ref):
+        assert hip["reset_ticks"][0][i] == r["reset_ticks"][0], i
+        assert np.array_equal(hip["cc"][:, i], r["cc"]), (i, hip["cc"][:, i], r["cc"])
+        assert np.array_equal(hip["cid"][:, i], r["cid"]), i
+        assert np.array_equal(hip["goal_id"][:, i], r["goal_id"]), i
+        worst_q = max(worst_q, np.abs(hip["q"][:, i] - r["q"]).max())
+        worst_b = max(worst_b, np.abs(hip["body"][:, i] - r["body"]).max())
+        diff = hip["img"][:, i].astype(np.int16) - r["img"].astype(np.int16)
+        per_image = (diff != 0).reshape(steps + 1, -1).sum(1)
+        assert per_image.max() <= 16 and np.abs(diff).max() <= 1, (i, per_image)
+        bad_images += int((per_image > 0).sum())
+    assert worst_q < 1e-9 and worst_b < 1e-8, (worst_q, worst_b)
+    assert bad_images <= 0.01 * n * (steps + 1), bad_images
+    assert (hip["cc"] >= 6).mean() > 0.02
+    print(f"config 4, manifold narrowphase: {n} envs x (reset + {steps} steps): contact ids exact, {100 * (hip['cc'] >= 6).mean():.0f} % of env-steps with >= 2 tip points, "
+          f"|dq| {worst_q:.1e}, |d cube pose| {worst_b:.1e}, images not bit-exact {bad_images} of {n * (steps + 1)}")

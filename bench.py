@@ -74,38 +74,101 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def _cpu_worker(args):
-    seed, seconds = args
+def _cpu_worker(idx, cpu, seconds, repeats, barrier, out_q):
+    """One oracle env (edge_follow-v0, 128x128, random actions, resets included) pinned to one host CPU; `repeats` windows of `seconds`, every
+    window started together with all other workers (barrier), so that a window's aggregate is what the box sustains with every core busy."""
+    try:
+        if cpu is not None:
+            os.sched_setaffinity(0, {cpu})
+    except OSError:
+        pass
+    try:                                                  # one CPU per process: numpy's BLAS / OpenMP pools must not start a thread per core of the box each
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:  # noqa: BLE001
+        pass
     import numpy as np
     from oracle.ref_env import OracleEdgeFollowEnv
-    env = OracleEdgeFollowEnv(seed=seed, max_steps=200, image_size=(128, 128), env_modes=MODES)
+    env = OracleEdgeFollowEnv(seed=1 + idx, max_steps=200, image_size=(128, 128), env_modes=MODES)
     env.reset()
-    rng = np.random.default_rng(seed)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        _, _, done, _ = env.step(rng.uniform(-0.25, 0.25, 2))
-        n += 1
-        if done:
-            env.reset()
-    return n, time.perf_counter() - t0
+    rng = np.random.default_rng(1 + idx)
+    for _ in range(5):                                    # page in code and assets before the first window
+        env.step(rng.uniform(-0.25, 0.25, 2))
+    out = []
+    for _ in range(repeats):
+        if barrier is not None:
+            barrier.wait()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            _, _, done, _ = env.step(rng.uniform(-0.25, 0.25, 2))
+            n += 1
+            if done:
+                env.reset()
+        out.append((n, time.perf_counter() - t0))
+    if out_q is not None:
+        out_q.put((idx, out))
+    return out
 
 
-def cpu_baseline(seconds=12.0):
-    """The CPU oracle (oracle/: a port, not PyBullet — PyBullet is not installable here) on this box's host cores."""
+def _cgroup_cpu_quota():
+    """CPUs' worth of time this container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(seconds=10.0, repeats=3):
+    """The CPU oracle (oracle/: a port, not PyBullet — PyBullet is not installable here) on this box's host cores: one process per CPU of the
+    affinity mask, each pinned to its CPU (os.sched_setaffinity) with its BLAS / OpenMP pools limited to one thread, `repeats` windows of
+    `seconds` started on a common barrier.  value = the MEDIAN over the windows of (steps of all processes in the window / the window's longest
+    process time) - one disturbed window (another tenant of the box) does not move it; the windows, their spread and the per-process rate are
+    reported beside it (two runs of this must agree within 5 %)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    n1, t1 = _cpu_worker((1, min(4.0, seconds / 3)))
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(1 + i, seconds) for i in range(cores)])
-    total = sum(r[0] for r in res) / max(r[1] for r in res)
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    quota = _cgroup_cpu_quota()
+    note = ""
+    if quota is not None and quota < len(cpus):
+        # the container's CPU-time quota, not the CPU count, is what this process tree can use: more processes than that only take turns
+        # (measured on the GPU box: 256 logical CPUs visible, 256 pinned processes ran at 3 % of the single-process rate each, 7.6x it in total)
+        k = max(1, int(quota))
+        note = f"; cgroup cpu quota {quota:.1f} of {len(cpus)} visible CPUs: {k} processes"
+        cpus = cpus[::max(1, len(cpus) // k)][:k]
+    cores = len(cpus)
+    ctx = mp.get_context("fork")
+    solo = _cpu_worker(0, cpus[0], min(4.0, seconds / 2), 1, None, None)[0]
+    barrier, q = ctx.Barrier(cores), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(i, cpus[i], seconds, repeats, barrier, q), daemon=True) for i in range(cores)]
+    for pr in procs:
+        pr.start()
+    res = [q.get() for _ in range(cores)]
+    for pr in procs:
+        pr.join()
+    windows = []
+    for r in range(repeats):
+        windows.append(sum(out[r][0] for _, out in res) / max(out[r][1] for _, out in res))
+    per_proc = [out[r][0] / out[r][1] for _, out in res for r in range(repeats)]
+    mean = sorted(windows)[len(windows) // 2]
     try:   # SURVEY 8d: time the real reference if the box happens to have it (it does not travel with this repo)
         import pybullet  # noqa: F401
         pyb = "importable on this box but not timed: the reference's env classes do not travel with this repo"
     except Exception:  # noqa: BLE001
         pyb = "unavailable (import pybullet fails on this box)"
-    return {"value": round(total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port", "pybullet_reference": pyb,
-            "sample": f"{cores} processes x 1 oracle env (edge_follow-v0, 128x128, random actions, resets included) for {seconds:.0f} s; "
-                      f"single process: {n1 / t1:.1f} env-steps/s"}
+    return {"value": round(mean, 1), "unit": "env-steps/s", "cores": cores, "kind": "port", "pybullet_reference": pyb,
+            "windows": [round(w, 1) for w in windows], "spread": round((max(windows) - min(windows)) / mean, 4),
+            "per_process": {"mean": round(sum(per_proc) / len(per_proc), 2), "min": round(min(per_proc), 2), "max": round(max(per_proc), 2)},
+            "sample": f"{cores} processes x 1 oracle env (edge_follow-v0, 128x128, random actions, resets included), one per CPU of the affinity mask and pinned to it, "
+                      f"{repeats} windows of {seconds:.0f} s started on a common barrier; single pinned process alone: {solo[0] / solo[1]:.1f} env-steps/s{note}"}
 
 
 def spawn_ranks(n):

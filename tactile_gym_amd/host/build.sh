@@ -3,5 +3,5 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 mkdir -p ../lib
-${CC:-gcc} -O3 -std=c99 -shared -fPIC -Wall -Wextra tg_host_tiles.c -o ../lib/libtg_host.so
+${CC:-gcc} -O3 -std=gnu99 -shared -fPIC -Wall -Wextra -pthread tg_host_tiles.c -o ../lib/libtg_host.so
 echo "built ../lib/libtg_host.so"

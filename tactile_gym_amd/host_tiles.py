@@ -4,8 +4,9 @@ What the reference's sb3_helpers consume is a numpy batch per `VecEnv.step_wait(
 rollout collection).  The plain path copies the whole uint8 batch device -> host every step (16.8 MB for 1024 x 128 x 128: the copy IS the
 step, 2.1 M env-steps/s).  Here the device packs only the 16 x 16 tiles that differ from the untouched sensor's image (`tg_pack_tiles`, the
 payload of the multi-GPU exchange), that message crosses PCIe into pinned memory, and `libtg_host.so` (host/tg_host_tiles.c, plain C)
-rebuilds the batch in one of four persistent host buffers: the tiles that buffer's previous frame had live get the template back, the new
-records land.  Lossless; the arrays handed out are ring buffers (untouched for the next three calls), like `copy_obs=False`.
+rebuilds the batch in one of five persistent host buffers: the tiles that buffer's previous frame had live get the template back, the new
+records land.  Lossless; the arrays handed out are five ring buffers, untouched for the next three calls (the restore half of a buffer's next
+rebuild starts on the pool's workers one call before the buffer is filled again), like `copy_obs=False`.
 Needs torch (device buffers, the pinned staging area, the copy); there is no fallback: a missing library or torch raises."""
 import ctypes as C
 import os
@@ -30,6 +31,19 @@ def host_lib():
         L.tg_host_unpack_tiles.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.tg_host_fill_template.restype = C.c_int32
         L.tg_host_fill_template.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.tg_host_pool_create.restype = C.c_void_p
+        L.tg_host_pool_create.argtypes = [C.c_int32]
+        L.tg_host_pool_destroy.argtypes = [C.c_void_p]
+        L.tg_host_pool_threads.restype = C.c_int32
+        L.tg_host_pool_threads.argtypes = [C.c_void_p]
+        L.tg_host_unpack_tiles_mt.restype = C.c_int64
+        L.tg_host_unpack_tiles_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_int64)]
+        L.tg_host_restore_begin.restype = C.c_int32
+        L.tg_host_restore_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+        L.tg_host_pool_wait.argtypes = [C.c_void_p]
+        L.tg_host_checksum.restype = C.c_uint64
+        L.tg_host_checksum.argtypes = [C.c_void_p, C.c_int64]
         _host = L
     return _host
 
@@ -40,7 +54,8 @@ class HostTileBatch:
 
     ERRORS = {-1: "bad argument", -2: "bad message header", -3: "message shorter than its record count says", -4: "tile id out of range"}
 
-    def __init__(self, tmpl, n, H, W, out=None):
+    def __init__(self, tmpl, n, H, W, out=None, pool=None):
+        self.pool = pool                     # a tg_host_pool (HostPool.handle) shared by the ring's buffers, or None: the calling thread only
         self.n, self.H, self.W = int(n), int(H), int(W)
         assert self.H % 16 == 0 and self.W % 16 == 0
         self.tmpl = np.ascontiguousarray(np.asarray(tmpl, dtype=np.uint8).reshape(-1))
@@ -52,19 +67,57 @@ class HostTileBatch:
         if host_lib().tg_host_fill_template(self.tmpl.ctypes.data, self.n, self.H, self.W, self.batch.ctypes.data) != 0:
             raise RuntimeError("tg_host_fill_template failed")
 
+    def restore_begin(self):
+        """Start bringing this buffer back to the untouched-sensor image on the pool's workers (the restore half of its next rebuild); the
+        caller goes on.  `restore_end()` before the buffer is used again."""
+        rc = host_lib().tg_host_restore_begin(self.pool, self.tmpl.ctypes.data, self.n, self.H, self.W, self.batch.ctypes.data, self.prev.ctypes.data,
+                                              self.n_prev.value)
+        if rc < 0:
+            raise RuntimeError(f"tg_host_restore_begin: {self.ERRORS.get(int(rc), rc)}")
+        self._restoring = True
+
+    def restore_end(self):
+        if getattr(self, "_restoring", False):
+            host_lib().tg_host_pool_wait(self.pool)
+            self.n_prev.value = 0
+            self._restoring = False
+
     def apply(self, msg):
+        self.restore_end()
         msg = np.ascontiguousarray(msg)
-        rc = host_lib().tg_host_unpack_tiles(msg.ctypes.data, msg.nbytes, self.tmpl.ctypes.data, self.n, self.H, self.W, self.batch.ctypes.data,
-                                             self.prev.ctypes.data, C.byref(self.n_prev))
+        rc = host_lib().tg_host_unpack_tiles_mt(self.pool, msg.ctypes.data, msg.nbytes, self.tmpl.ctypes.data, self.n, self.H, self.W,
+                                                self.batch.ctypes.data, self.prev.ctypes.data, C.byref(self.n_prev))
         if rc < 0:
             raise RuntimeError(f"tg_host_unpack_tiles: {self.ERRORS.get(int(rc), rc)}")
         return int(rc)
 
 
+class HostPool:
+    """The rebuild's thread pool (libtg_host.so: tg_host_pool_create): `threads` includes the calling thread; thread t owns the images
+    [t n / P, (t + 1) n / P).  TG_HOST_THREADS overrides; 1 = no pool."""
+
+    def __init__(self, threads=None):
+        if threads is None:
+            threads = int(os.environ.get("TG_HOST_THREADS", "4"))
+        self.handle = host_lib().tg_host_pool_create(int(threads)) if threads > 1 else None
+        self.threads = host_lib().tg_host_pool_threads(self.handle) if self.handle else 1
+
+    def close(self):
+        if self.handle:
+            host_lib().tg_host_pool_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class TileDownload:
     """The device -> host leg: pack on the device, one pinned copy of the header and the records, rebuild on the host."""
 
-    RING = 4
+    RING = 5      # a hand-out stays untouched for three further calls; the fifth buffer is the one whose restore runs ahead (see fetch)
 
     def __init__(self, venv):
         import torch
@@ -81,7 +134,8 @@ class TileDownload:
         self.host_pk = torch.empty(cap, dtype=torch.uint8).pin_memory()
         self.host_np = self.host_pk.numpy()
         tmpl = self.shard.tile_template().cpu().numpy()
-        self.ring = [HostTileBatch(tmpl, n, H, W) for _ in range(self.RING)]
+        self.pool = HostPool()
+        self.ring = [HostTileBatch(tmpl, n, H, W, pool=self.pool.handle) for _ in range(self.RING)]
         self.i = -1
         self.last_bytes = 0
         self._last_count = 0
@@ -89,7 +143,7 @@ class TileDownload:
         self.calls = 0
 
     def fetch(self):
-        """The current observation batch as uint8 [n, H, W, 1] (one of four ring buffers)."""
+        """The current observation batch as uint8 [n, H, W, 1] (one of the ring buffers)."""
         import time
         torch, v = self.torch, self.venv
         t0 = time.perf_counter()
@@ -112,5 +166,9 @@ class TileDownload:
         hb.apply(self.host_np[:nb])
         self.last_bytes = nb
         t2 = time.perf_counter()
+        # the buffer the NEXT call fills was handed out four calls ago - its contract ("untouched for the next three calls") has run out: the pool's
+        # workers restore its live tiles now, under the next device step, and that call only scatters
+        if self.pool.handle:
+            self.ring[(self.i + 1) % self.RING].restore_begin()
         self.t_device += t1 - t0; self.t_host += t2 - t1; self.calls += 1
         return hb.batch.reshape(v.num_envs, v.H, v.W, 1)

@@ -43,6 +43,34 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+_EMPTY_INFO = {}      # shared by the envs that have nothing to report in a step (TactileVecEnv.step_wait, lazy_info)
+
+
+class MonitorCsv:
+    """stable_baselines3.common.monitor's file format (what its load_results reads): `#{json header}`, then a csv with columns r,l,t."""
+
+    EXT = "monitor.csv"
+
+    def __init__(self, monitor_dir, t_start, env_id=None, name="tactile_gym_hip"):
+        import json
+        import os
+        os.makedirs(monitor_dir, exist_ok=True)
+        self.path = os.path.join(monitor_dir, f"{name}.{self.EXT}")
+        self._f = open(self.path, "w", newline="\n")
+        self._f.write("#" + json.dumps({"t_start": t_start, "env_id": env_id}) + "\n")
+        self._f.write("r,l,t\n")
+        self._f.flush()
+
+    def write(self, ep):
+        self._f.write(f"{ep['r']},{ep['l']},{ep['t']}\n")
+        self._f.flush()
+
+    def close(self):
+        if self._f is not None:
+            self._f.close()
+            self._f = None
+
+
 class TactileVecEnv(_VecEnvBase):
     """N environments stepped by libtactile_gym_hip.so: a stable_baselines3 VecEnv (a subclass when SB3 is importable, the same API as a
     duck type otherwise)."""
@@ -103,6 +131,8 @@ class TactileVecEnv(_VecEnvBase):
         self._closed = False
         self._views = {}
         self._t_start = time.time()                 # Monitor's t_start (info["episode"]["t"])
+        self._lazy_info, self._monitor = True, None
+        self._obs_guard, self._guard_sum = False, None
         self._ep_ret = np.zeros(self.num_envs, dtype=np.float32)
         self._ep_len = np.zeros(self.num_envs, dtype=np.int32)
         self._rebinds = 0
@@ -125,6 +155,8 @@ class TactileVecEnv(_VecEnvBase):
         self._bind_torch_stream()
         capi.check(self._L.tg_reset(self._ctx, m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None))
         capi.check(self._L.tg_sync(self._ctx))
+        if self._obs_guard:
+            self._guard_after_step()
         return self._observation()
 
     def _bind_torch_stream(self):
@@ -149,6 +181,8 @@ class TactileVecEnv(_VecEnvBase):
     def step_async(self, actions):
         """actions: numpy float32 [N, act_dim], or a torch CUDA tensor (read in place on the current torch stream)."""
         self._bind_torch_stream()
+        if self._obs_guard:
+            self._guard_before_step()
         if hasattr(actions, "data_ptr") and getattr(actions, "is_cuda", False):
             assert actions.dtype.is_floating_point and actions.element_size() == 4 and actions.is_contiguous()
             assert tuple(actions.shape) == (self.num_envs, self.act_dim)
@@ -157,6 +191,43 @@ class TactileVecEnv(_VecEnvBase):
         else:
             np.copyto(self._actions, np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_dim))
             capi.check(self._L.tg_step(self._ctx, C.c_void_p(self._actions.ctypes.data), 0))
+        if self._obs_guard:
+            self._guard_after_step()
+
+    def set_lazy_info(self, on):
+        """False: a fresh info dict per env and step (stable_baselines3's DummyVecEnv behaviour) instead of one shared empty dict for the envs that
+        did not finish."""
+        self._lazy_info = bool(on)
+
+    def set_obs_guard(self, on=True):
+        """Debug switch for the read-only contract of obs_mode="torch" (the block raster rewrites only the image blocks that change):
+        the tactile buffer is checksummed after every step and checked before the next one; a caller that wrote into the tensor it was handed
+        (in-place augmentation) gets a RuntimeError instead of silently corrupted later frames.  Costs a device reduction and a host
+        synchronisation per step."""
+        self._obs_guard, self._guard_sum = bool(on), None
+
+    def _guard_checksum(self):
+        t = self.tactile_torch()
+        return int(t.reshape(-1).view(__import__("torch").int64).sum().item())
+
+    def _guard_before_step(self):
+        if self._obs_guard and self.obs_mode == "torch" and self._guard_sum is not None and self._guard_checksum() != self._guard_sum:
+            raise RuntimeError("the tactile observation tensor handed out by the last step / reset was modified in place: obs_mode='torch' tensors "
+                               "alias the library's buffer, of which only the changed 16 x 16 blocks are rewritten per step (DESIGN.md 4.2).  Copy "
+                               "before augmenting in place, or run with TG_RASTER_REWRITE_ALL=1")
+
+    def _guard_after_step(self):
+        if self._obs_guard and self.obs_mode == "torch":
+            self._guard_sum = self._guard_checksum()
+
+    def set_monitor(self, monitor_dir, env_id=None):
+        """What `make_vec_env(..., monitor_dir=d)` asks for (sb3_helpers/rl_utils.py:22, 59; read back by stable_baselines3's load_results, which
+        sb3_helpers/rl_plot_utils.py and custom_callbacks.py call): a Monitor csv in `monitor_dir` - one file for the whole batch,
+        `tactile_gym_hip.monitor.csv`, header `#{"t_start": ..., "env_id": ...}`, columns r,l,t, one row per finished episode (the device-side
+        episode statistics of info["episode"]), flushed per row like SB3's Monitor."""
+        if self._monitor is not None:
+            self._monitor.close()
+        self._monitor = MonitorCsv(monitor_dir, self._t_start, env_id) if monitor_dir else None
 
     def bank_stats(self):
         """Reset bank: {"mode": "off" | "on" | "sync", "swapped": auto-resets that took a precomputed entry, "late": resets done on the spot}."""
@@ -177,7 +248,10 @@ class TactileVecEnv(_VecEnvBase):
         self._held = None
         obs = self._observation()
         dones = self._done.astype(bool)
-        infos = [{} for _ in range(self.num_envs)]
+        # SB3 reads infos[i].get(...) / "key" in infos[i]; only the envs that finished carry anything.  lazy_info (default): the others share ONE
+        # empty dict (1024 dict constructions per step are a tenth of the numpy step's host time); an env's own dict is made when it has something to
+        # say.  lazy_info=False restores a fresh dict per env for callers that write into the infos of running envs.
+        infos = [_EMPTY_INFO] * self.num_envs if self._lazy_info else [{} for _ in range(self.num_envs)]
         if dones.any():
             # what the reference's callers read from the Monitor wrapper around every env (sb3_helpers/rl_utils.py:17-30, 59; SB3's logger and
             # EvalCallback consume info["episode"]): return and length of the episode that just ended, added up on the device
@@ -185,7 +259,9 @@ class TactileVecEnv(_VecEnvBase):
                                                      self._ep_len.ctypes.data_as(C.POINTER(C.c_int32))))
             t = round(time.time() - self._t_start, 6)
             for i in np.nonzero(dones)[0]:
-                infos[i]["episode"] = {"r": round(float(self._ep_ret[i]), 6), "l": int(self._ep_len[i]), "t": t}
+                infos[i] = {"episode": {"r": round(float(self._ep_ret[i]), 6), "l": int(self._ep_len[i]), "t": t}}
+                if self._monitor is not None:
+                    self._monitor.write(infos[i]["episode"])
         if self._cfg.auto_reset and dones.any():
             term = self._terminal_observation()
             for i in np.nonzero(dones)[0]:   # owned copies: the library's terminal buffers are rewritten by the next auto-reset
@@ -200,6 +276,8 @@ class TactileVecEnv(_VecEnvBase):
     def close(self):
         if not self._closed:
             self._closed = True
+            if self._monitor is not None:
+                self._monitor.close()
             self._L.tg_destroy(self._ctx)
 
     def __del__(self):
@@ -566,7 +644,9 @@ class HipVecEnv:
     **env_kwargs), seeded seed + rank, wrapped in Monitor) in its own process.  Here the first constructor is called once as a probe: the env
     it makes names its class and constructor arguments, and ONE N-env device context is built from them with env i seeded seed + i (the
     seeds the N constructors would have used).  The per-env Monitor's bookkeeping is done on the device: every step's info carries
-    info["episode"] = {"r", "l", "t"} for the envs that finished (what SB3's logger and EvalCallback read).  Extra keyword arguments
+    info["episode"] = {"r", "l", "t"} for the envs that finished (what SB3's logger and EvalCallback read), and with `monitor_dir` the same
+    rows go to `<monitor_dir>/tactile_gym_hip.monitor.csv` in SB3's Monitor format (load_results(monitor_dir), which the reference's
+    sb3_helpers/rl_plot_utils.py and custom_callbacks.py call, reads every *monitor.csv of the directory).  Extra keyword arguments
     (vec_env_kwargs: obs_mode, copy_obs, physics_dtype, device, obs_transfer ...) go to the vectorised constructor; start_method is accepted and
     ignored.  The result is a TactileVecEnv (an SB3 VecEnv subclass wherever SB3 is importable), not an instance of this class."""
 
@@ -595,11 +675,31 @@ class HipVecEnv:
                             f"(register ids with `import tactile_gym_amd` and pass one of tactile_gym_amd.registered_ids())")
         ctor = dict(single._ctor)
         obs_transfer = kwargs.pop("obs_transfer", None)   # vec_env_kwargs=dict(obs_transfer="tiles"): the tile-sparse observation download
+        monitor_dir = kwargs.pop("monitor_dir", None)     # explicit; otherwise taken from the probe's Monitor wrapper (make_vec_env(monitor_dir=...))
+        probe_csv = None
+        rw = getattr(probe, "results_writer", None)       # stable_baselines3.common.monitor.Monitor
+        fh = getattr(rw, "file_handler", None) or getattr(probe, "file_handler", None)
+        if fh is not None and getattr(fh, "name", None):
+            import os
+            probe_csv = os.path.abspath(fh.name)
+            if monitor_dir is None:
+                monitor_dir = os.path.dirname(probe_csv)
         ctor.update(kwargs)
         seed = single._seed                          # make_vec_env's make_env(rank) called env.seed(seed + rank): rank 0 -> the base seed
         env_cls = type(single)
         probe.close()
+        if probe_csv is not None:                    # the probe's own Monitor file holds a header and no episode: it would only dilute load_results
+            import os
+            try:
+                with open(probe_csv) as f:
+                    rows = sum(1 for _ in f)
+                if rows <= 2:
+                    os.remove(probe_csv)
+            except OSError:
+                pass
         venv = env_cls.make_vec(num_envs=len(env_fns), seed=seed, **ctor)
         if obs_transfer is not None:
             venv.set_obs_transfer(obs_transfer)
+        if monitor_dir:
+            venv.set_monitor(monitor_dir, env_id=getattr(getattr(single, "spec", None), "id", None) or env_cls.__name__)
         return venv

@@ -90,7 +90,7 @@ def test_make_vec_env_with_hipvecenv_equals_make_vec():
 @pytest.mark.parametrize("env_id,modes,size,n", [("edge_follow-v0", EDGE, 128, 96), ("object_push-v0", PUSH, 128, 32), ("object_balance-v0", BAL, 256, 8)])
 def test_tile_download_hands_out_the_batch_the_full_copy_hands_out(env_id, modes, size, n):
     """`set_obs_transfer("tiles")`: the numpy observations of a rollout with resets (device pack -> pinned copy of exactly the records ->
-    libtg_host.so rebuilding one of four persistent host buffers) equal the plain whole-batch copy byte for byte at every step, the ring
+    libtg_host.so rebuilding one of five persistent host buffers) equal the plain whole-batch copy byte for byte at every step, the ring
     buffers stay untouched for three further steps, and fewer bytes cross PCIe than the batch holds (edge / push; the pole's plate fills
     the view, so object_balance ships everything plus the record headers)."""
     import tactile_gym_amd as tg
@@ -112,7 +112,7 @@ def test_tile_download_hands_out_the_batch_the_full_copy_hands_out(env_id, modes
             assert np.array_equal(g, f)            # the last four batches handed out are still what they were
         if env_id != "object_balance-v0":
             assert dl.last_bytes < full.size
-    assert len({g.ctypes.data for g, _ in held}) == 4          # four ring buffers, reused in turn
+    assert len({g.ctypes.data for g, _ in held}) == 5          # five ring buffers, reused in turn
     venv.set_obs_transfer("full")
     obs, _, _, _ = venv.step(a)
     venv.close()

@@ -397,3 +397,64 @@ def test_hipvecenv_is_a_vec_env_cls_for_make_vec_env(monkeypatch, edge_modes):
         tg.HipVecEnv([lambda: object()])
     with pytest.raises(ValueError):
         tg.HipVecEnv([])
+
+
+def test_monitor_csv_has_sb3s_format_and_hipvecenv_takes_the_probe_monitors_directory(monkeypatch, edge_modes, tmp_path):
+    """make_vec_env(..., monitor_dir=d) wraps every env constructor in Monitor(filename=d/<rank>); HipVecEnv builds ONE context, so it writes
+    ONE Monitor file into that directory (sb3_helpers/rl_utils.py:22, 59; stable_baselines3's load_results - what the reference's
+    rl_plot_utils.py / custom_callbacks.py call - reads every *monitor.csv): `#{"t_start": ..., "env_id": ...}`, `r,l,t`, one row per episode.
+    The probe's header-only file is removed."""
+    import csv
+    import json
+    import tactile_gym_amd as tg
+    from tactile_gym_amd import spaces
+    from tactile_gym_amd.rl_envs import edge_follow as ef
+    from tactile_gym_amd.vec_env import MonitorCsv
+
+    m = MonitorCsv(str(tmp_path / "a"), 123.5, "edge_follow-v0")
+    m.write({"r": -12.25, "l": 200, "t": 3.5}); m.write({"r": 1.0, "l": 7, "t": 4.25}); m.close()
+    lines = open(m.path).read().splitlines()
+    assert m.path.endswith(".monitor.csv") and lines[0][0] == "#" and json.loads(lines[0][1:]) == {"t_start": 123.5, "env_id": "edge_follow-v0"}
+    rows = list(csv.DictReader(lines[1:]))                     # exactly how stable_baselines3.common.monitor.load_results parses the body
+    assert list(rows[0].keys()) == ["r", "l", "t"] and [float(r["r"]) for r in rows] == [-12.25, 1.0] and [int(r["l"]) for r in rows] == [200, 7]
+
+    class Recorder:
+        def __init__(self, num_envs, max_steps=250, image_size=(64, 64), env_modes=None, physics_dtype="f64", **kw):
+            self.args = dict(num_envs=num_envs, **kw)
+            self.action_space = spaces.Box(low=-0.25, high=0.25, shape=(2,), dtype=np.float32)
+            self.observation_space = spaces.Dict({})
+            self.min_action, self.max_action, self.monitor = -0.25, 0.25, None
+
+        def seed(self, s=None):
+            return [s]
+
+        def close(self):
+            pass
+
+        def set_monitor(self, d, env_id=None):
+            self.monitor = (d, env_id)
+
+    class FakeMonitor:                                         # the two attributes of SB3's Monitor that name its file
+        def __init__(self, env, filename):
+            self.env = env
+            fh = open(filename + ".monitor.csv", "w"); fh.write('#{"t_start": 0}\nr,l,t\n'); fh.flush()
+            self.results_writer = type("RW", (), {"file_handler": fh})()
+
+        def close(self):
+            self.results_writer.file_handler.close()
+            self.env.close()
+
+    monkeypatch.setattr(ef.EdgeFollowEnv, "vec_cls", Recorder)
+    d = tmp_path / "runs"
+    d.mkdir()
+    fns = [(lambda r=r: FakeMonitor(tg.make("edge_follow-v0", env_modes=edge_modes), str(d / str(r)))) for r in range(3)]
+    venv = tg.HipVecEnv(fns)
+    assert venv.monitor is not None and venv.monitor[0] == str(d)
+    assert not (d / "0.monitor.csv").exists()                  # the probe's header-only file is gone
+
+
+def test_lazy_info_shares_one_empty_dict_and_gives_finished_envs_their_own():
+    from tactile_gym_amd import vec_env as ve
+    assert ve._EMPTY_INFO == {} and isinstance(ve._EMPTY_INFO, dict)
+    src = open(ve.__file__).read()
+    assert "infos[i] = {\"episode\":" in src                  # a finished env never writes into the shared dict

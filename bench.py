@@ -211,16 +211,29 @@ class Workload:
         """action_space.sample() for the whole batch: U[-0.25, 0.25), one device kernel on the env's stream (tg_sample_actions, counter
         based: draw k of rank r depends on (1234 + r, k) only), inside the timed region like every step's policy would be."""
         self.draw += 1
+        self._fused_synced = False
         return self.venv.sample_actions(self.act_buf, 1234 + self.rank, self.draw)
 
     def on_stream(self):
         return self.torch.cuda.stream(self.shard.stream) if self.shard.pipelined else contextlib.nullcontext()
 
+    fused_policy = True     # the uniform random policy as a node of the step's graph (tg_step_random); False: its own launch before every step
+    _fused_synced = False   # the context's device-side draw counter equals self.draw
+
+    def step(self, env):
+        """One rollout step: action_space.sample() for the whole batch + VecEnv.step.  The same draws either way (draw k of seed 1234 + rank)."""
+        if self.fused_policy and hasattr(env, "step_random"):
+            out = env.step_random(1234 + self.rank, self.draw, restart=not self._fused_synced)
+            self.draw += 1
+            self._fused_synced = True
+            return out
+        return env.step(self.actions())
+
     def timed(self, env, steps, barrier, flush=None):
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            env.step(self.actions())
+            self.step(env)
         self.flushed, self.error = None, None
         if flush is not None:
             try:
@@ -298,7 +311,7 @@ def companion(env_id, image_size, n, physics, steps, barrier, what, **kw):
     with w.on_stream():
         w.shard.reset()
         for _ in range(10):
-            w.shard.step(w.actions())
+            w.step(w.shard)
         dt = w.timed(w.shard, steps, barrier)
         prof = w.profile(w.shard, min(steps, 20), barrier)
     roof = w.roofline(prof)
@@ -320,6 +333,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the literal-solver companion run (keeps a rocprofv3 trace of this command to one solver mode)")
     ap.add_argument("--no-companions", action="store_true", help="skip other_configs / roofline_16384 (same purpose)")
+    ap.add_argument("--separate-policy", action="store_true", help="launch the uniform random policy (tg_sample_actions) as its own kernel before every step instead of "
+                    "as a node of the step's graph (tg_step_random)")
     ap.add_argument("--sync-steps", action="store_true", help="block the host on every step (VecEnv.step_wait semantics) instead of pipelining")
     ap.add_argument("--full-sweeps", action="store_true",
                     help="always run all 150 PGS sweeps per tick instead of leaving the loop at convergence to the last bit (DESIGN.md 4.1)")
@@ -374,6 +389,8 @@ def main():
         rccl_ranks = int(ones.item())
         assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
+    if args.separate_policy:
+        Workload.fused_policy = False
     n = args.num_envs
     extra = dict(contact_mapping=args.contact_mapping, solver_iterations=args.solver_iters)
     if args.env == "object_push-v0" and args.narrowphase != "closed_form":
@@ -403,7 +420,7 @@ def main():
         with w.on_stream():
             e.reset()
             for _ in range(warmup):
-                e.step(w.actions())
+                w.step(e)
             t = allmax(w.timed(e, steps or args.steps, barrier, flush=e.flush if gathered else None))
             ok, why = True, None
             if gathered:
@@ -474,11 +491,21 @@ def main():
         if dist is None:
             env.reset()
             for _ in range(10):
-                env.step(w.actions())
+                w.step(env)
             k_nr = max(10, min(args.steps, max_steps - 20))
             dt_nr = w.timed(env, k_nr, barrier)
             no_reset = {"value": round(n * k_nr / dt_nr, 1), "unit": "env-steps/s", "steps": k_nr, "ms_per_step": round(1e3 * dt_nr / k_nr, 4),
                         "what": "window between full-batch resets (no env reaches max_steps inside it)"}
+        separate = None
+        if dist is None and Workload.fused_policy and hasattr(env, "step_random"):
+            # the same K steps with the policy's draw as its own launch in front of every step (what a torch policy would be: separate kernels)
+            Workload.fused_policy = False
+            for _ in range(10):
+                w.step(env)
+            dt_sp = w.timed(env, args.steps, barrier)
+            Workload.fused_policy = True
+            separate = {"value": round(n * args.steps / dt_sp, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * dt_sp / args.steps, 4),
+                        "what": "tg_sample_actions as its own kernel launch before every tg_step instead of a node of the step's graph"}
     exchange = env.exchange_info() if gathered and hasattr(env, "exchange_info") else None
     if exchange is not None:
         exchange["verified"] = verified
@@ -495,7 +522,7 @@ def main():
                       pipelined=False, **extra)
         lw.shard.reset()
         for _ in range(5):
-            lw.shard.step(lw.actions())
+            lw.step(lw.shard)
         lsteps = max(10, min(args.steps, 40))
         ldt = lw.timed(lw.shard, lsteps, barrier)
         lprof = lw.profile(lw.shard, 10, barrier)
@@ -543,6 +570,10 @@ def main():
                       "default: PGS leaves at last-bit convergence; ticks whose motor solve is provably unclamped and demonstrably converged take "
                       "the solver's analytic fixed point (qd = target); joints within 1e-11 rad of the literal solver over 1024 envs x 260 steps incl. auto-resets "
                       "(tests/test_gpu_parity.py::test_default_solver_equals_literal_solver_at_config_scale; DESIGN.md 4.1)",
+            "policy": ("uniform random actions (action_space.sample() for the whole batch), drawn on the device as the first node of the step's graph "
+                       "(tg_step_random; draw k identical to tg_sample_actions(seed, k))") if Workload.fused_policy and dist is None else
+                      "uniform random actions drawn on the device by tg_sample_actions, one launch before every step",
+            "separate_policy_launch": separate,
             "literal_solver": literal,
             "without_full_batch_reset": no_reset,
             "resets_in_timed_region": bool((args.warmup % max_steps) + args.steps >= max_steps),

@@ -281,6 +281,7 @@ int tg_unpack_tiles_multi(void* hip_stream, const void* src_dev, int64_t src_str
  * sb3_helpers/rl_utils.py:17-30).  tg_ipc_alloc: zeroed device memory on the current device + its 64-byte IPC handle; tg_ipc_open /
  * tg_ipc_close: map / unmap it in another process (its GPU then reaches the memory over xGMI).  HSA_ENABLE_IPC_MODE_LEGACY=0 is required. */
 int tg_ipc_alloc(int64_t bytes, void** dev_ptr, uint8_t* handle64);
+int tg_ipc_alloc_was_uncached(void);   /* 1: the last tg_ipc_alloc of this process got uncached device memory; 0: the runtime refused and it is plain hipMalloc memory */
 int tg_ipc_free(void* dev_ptr);
 int tg_ipc_open(const uint8_t* handle64, void** dev_ptr);
 int tg_ipc_close(void* dev_ptr);
@@ -424,6 +425,12 @@ int tg_gen_heightfield(int32_t n, const int64_t* seeds, int32_t rows, int32_t co
  * (device memory) receives U[min_action, max_action) draws, counter based: element i of draw `counter` is a function of
  * (seed, counter, i) only.  Enqueued on the context's stream, so a tg_step(dev_actions, on_device = 1) that follows sees it. */
 int tg_sample_actions(tg_ctx* ctx, uint64_t seed, uint64_t counter, float* dev_actions);
+/* A random-action rollout step (the north_star's synthetic rollout: `env.step(env.action_space.sample())`, examples/demo_rl_env_base.py:34, for the
+ * whole batch): tg_sample_actions' draw followed by tg_step on it, captured as ONE graph - the sampler is a node of the step's graph, the draw
+ * counter lives in device memory and moves on by one per call.  restart != 0 (or a new seed): the next step uses draw first_draw + 1.  The
+ * actions are the context's own buffer (tg_get_actions: device float32 [num_envs][act_dim]); draw k equals tg_sample_actions(seed, k). */
+int tg_step_random(tg_ctx* ctx, uint64_t seed, uint64_t first_draw, int32_t restart);
+int tg_get_actions(tg_ctx* ctx, void** dev_actions);
 /* Self-test of the raster's depth division (tactile_sensor.py:239-294 reads an IEEE depth buffer): n pseudo-random operand pairs
  * with exponents 2^-40 .. 2^24 divided by the kernels' refinement and by the correctly rounded `/`; *mismatches = quotients whose
  * bits differ (must be 0). */

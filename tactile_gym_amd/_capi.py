@@ -139,6 +139,8 @@ SYMBOLS = {
     "tg_get_packed_outputs": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tg_get_packed_feature": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_sample_actions": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "tg_step_random": (C.c_int, [_ctx, C.c_uint64, C.c_uint64, C.c_int32]),
+    "tg_get_actions": (C.c_int, [_ctx, _vpp]),
     "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     "tg_get_bank_stats": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_selftest_narrowphase": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -152,6 +154,7 @@ SYMBOLS = {
     "tg_unpack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tg_unpack_tiles_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "tg_ipc_alloc": (C.c_int, [C.c_int64, _vpp, _u8p]),
+    "tg_ipc_alloc_was_uncached": (C.c_int, []),
     "tg_ipc_free": (C.c_int, [C.c_void_p]),
     "tg_ipc_open": (C.c_int, [_u8p, _vpp]),
     "tg_ipc_close": (C.c_int, [C.c_void_p]),

@@ -399,6 +399,10 @@ struct tg_ctx {
     const float* step_graph_actions[2] = {nullptr, nullptr};
     hipStream_t step_graph_stream[2] = {nullptr, nullptr};
     bool graph_broken = false;
+    // tg_step_random: the policy of a random-action rollout (action_space.sample() for the whole batch) inside the step's graph
+    unsigned long long* d_draw = nullptr;      // [0] draw counter, [1] seed, [2] ticket of the sampler's last-block election
+    hipGraphExec_t random_graph = nullptr;
+    uint64_t random_seed = 0;
     // reset bank (edge_follow / surface_follow, auto_reset; tg_kernels.hpp: BankAux)
     tg::State bk{};                    // the bank view: st's layout, the reset-written arrays in allocations of the bank's own
     tg::BankAux aux{};
@@ -640,6 +644,24 @@ __global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, flo
     const uint64_t z = mix64(mix64(seed + kGolden * (counter + 1)) + kGolden * (uint64_t)(i + 1));
     const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
     out[i] = lo + (hi - lo) * u;
+}
+
+// tg_step_random's sampler: the draw counter and the seed live in device memory (a captured graph has no per-launch arguments); every thread
+// reads the counter, the workgroup that finishes last moves it on - nobody can still be reading it then.  Draw k is tg_sample_actions' draw k.
+__global__ void k_sample_actions_ctr(int total, unsigned long long* __restrict__ ctr, float lo, float hi, float* __restrict__ out, unsigned long long* tl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    TG_TL(tl, 0);
+    const uint64_t counter = ctr[0] + 1, seed = ctr[1];
+    if (i < total) {
+        const uint64_t z = mix64(mix64(seed + kGolden * (counter + 1)) + kGolden * (uint64_t)(i + 1));
+        const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+        out[i] = lo + (hi - lo) * u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ctr + 2, 1ull) == (unsigned long long)gridDim.x - 1) { ctr[2] = 0ull; ctr[0] = counter; }
+    }
 }
 
 template <typename T, int TOPO> static void launch_oracle_obs_t(tg_ctx* c, int dim, float* dst) {
@@ -1135,6 +1157,8 @@ int tg_destroy(tg_ctx* c) {
     { unsigned long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_kstep_stamps), sizeof h) == hipSuccess) { fprintf(stderr, "k_step stamps (cycles from start, full=%llu):", h[15]); for (int i = 1; i < 13; ++i) fprintf(stderr, " [%d] %lld", i, (long long)(h[i] - h[0])); fprintf(stderr, "\n"); } }
 #endif
     for (int k = 0; k < 2; ++k) if (c->step_graph[k]) (void)hipGraphExecDestroy(c->step_graph[k]);
+    if (c->random_graph) (void)hipGraphExecDestroy(c->random_graph);
+    if (c->d_draw) (void)hipFree(c->d_draw);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
@@ -1315,6 +1339,69 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     enqueue_step(c, d_act);
     bank_refill(c);
     TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restart) {
+    if (!c) return fail(-1, "tg_step_random: NULL argument");
+    TG_ENTER(c);
+    if (!c->d_draw) { TG_HIP(hipMalloc(&c->d_draw, 32)); restart = 1; }
+    if (restart || seed != c->random_seed) {
+        const unsigned long long h[4] = {first_draw, seed, 0ull, 0ull};    // the next step uses draw first_draw + 1
+        TG_HIP(hipMemcpyAsync(c->d_draw, h, 32, hipMemcpyHostToDevice, c->stream));
+        TG_HIP(hipStreamSynchronize(c->stream));
+        c->random_seed = seed;
+    }
+    const int total = c->cfg.num_envs * c->act_dim;
+    auto sample = [&]() {
+        hipLaunchKernelGGL(k_sample_actions_ctr, dim3((total + 255) / 256), dim3(256), 0, c->stream, total, c->d_draw, (float)c->cfg.min_action,
+                           (float)c->cfg.max_action, c->d_actions,
+#ifdef TG_TL_STAMPS
+                           c->st.tl
+#else
+                           (unsigned long long*)nullptr
+#endif
+                           );
+    };
+    const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL;
+    // the lane-mapped k_step (edge_follow / surface_follow, TCP_velocity_control) draws its own actions: no sampler node at all - a dependent
+    // kernel in this graph costs its ~6 us dispatch floor whatever it computes (profiles/r4_exp_reset_launch.txt)
+    const bool in_kernel = (c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) &&
+                           c->cfg.control_mode == TG_CONTROL_TCP_VELOCITY && !use_arm_wave(c);
+    struct DrawScope {                   // c->st carries the counter only while this call enqueues / captures
+        tg_ctx* c; bool on;
+        DrawScope(tg_ctx* c_, bool on_) : c(c_), on(on_) { if (on) { c->st.draw = c->d_draw; c->st.act_out = c->d_actions; } }
+        ~DrawScope() { if (on) { c->st.draw = nullptr; c->st.act_out = nullptr; } }
+    } scope(c, in_kernel);
+    if (want_graph && !c->random_graph) {
+        hipGraph_t g = nullptr;
+        const hipStream_t run_stream = c->stream;
+        c->stream = c->capture_stream;
+        if (hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            if (!in_kernel) sample();
+            enqueue_step(c, c->d_actions);
+            const hipError_t e1 = hipStreamEndCapture(c->capture_stream, &g);
+            if (!(e1 == hipSuccess && g && hipGraphInstantiate(&c->random_graph, g, nullptr, nullptr, 0) == hipSuccess)) { c->random_graph = nullptr; c->graph_broken = true; }
+            if (g) (void)hipGraphDestroy(g);
+        } else c->graph_broken = true;
+        c->stream = run_stream;
+        (void)hipGetLastError();
+    }
+    if (want_graph && c->random_graph) {
+        TG_HIP(hipGraphLaunch(c->random_graph, c->stream));
+        bank_refill(c);
+        return 0;
+    }
+    if (!in_kernel) sample();
+    enqueue_step(c, c->d_actions);
+    bank_refill(c);
+    TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_get_actions(tg_ctx* c, void** dev_actions) {
+    if (!c || !dev_actions) return fail(-1, "NULL argument");
+    *dev_actions = c->d_actions;
     return 0;
 }
 

@@ -304,15 +304,20 @@ int tg_unpack_tiles_multi(void* stream, const void* src_dev, int64_t src_stride,
     return 0;
 }
 
+static int g_ipc_uncached = 0;
+int tg_ipc_alloc_was_uncached(void) { return g_ipc_uncached; }
+
 int tg_ipc_alloc(int64_t bytes, void** dev_ptr, uint8_t* handle) {
     if (bytes <= 0 || !dev_ptr || !handle) return report_error(-1, "tg_ipc_alloc: bad argument");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI hands IPC handles out as 64 bytes");
     void* p = nullptr;
     // uncached device memory: remote stores land in HBM and no stale line of it can sit in a local L2 (what RCCL allocates for its own
     // peer-written buffers); plain hipMalloc if the runtime refuses the flag
+    g_ipc_uncached = 1;
     if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
         p = nullptr;
+        g_ipc_uncached = 0;              // reported (tg_ipc_alloc_was_uncached): the caller decides whether cached receive slots are acceptable
         TGX_HIP(hipMalloc(&p, (size_t)bytes));
     }
     if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {

@@ -78,6 +78,8 @@ struct State {   // device pointers, SoA [field][num_envs]
     float* ep_final_return;         // [n] the finished episode's return (valid where done)
     int32_t* ep_final_len;          // [n] its length in env steps
     const void* tip_verts;          // [n_tip][3] in the physics dtype
+    unsigned long long* draw;       // tg_step_random on the lane-mapped k_step: {draw counter, seed, ticket}; the kernel draws its own actions (nullptr: reads `actions`)
+    float* act_out;                 // ... and leaves them here ([n][act_dim])
     double* mani;                   // [37][n] object_push with tg_config.narrowphase != 0: the tip - cube contact manifold (la, lb, normal of 4 points; count)
 #ifdef TG_TL_STAMPS
     unsigned long long* tl;         // development: [4][8192] launch-start stamps (wall clock) + [4] counters behind them
@@ -610,7 +612,26 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
 #pragma unroll
     for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
     T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-    encode_arm_actions<T>(c, st, env, actions + (size_t)env * c.act_dim, enc);
+    if (st.draw != nullptr) {
+        // tg_step_random: action_space.sample() for this env inside the step (element i = env * act_dim + j of draw `counter`, the arithmetic of
+        // k_sample_actions: the same floats); the workgroup that finishes last moves the counter on
+        const uint64_t counter = st.draw[0] + 1, seed = st.draw[1];
+        const float lo = (float)c.min_action, hi = (float)c.max_action;
+        float abuf[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (j < c.act_dim) {
+                const int i = env * c.act_dim + j;
+                const uint64_t z = mix64(mix64(seed + kGolden * (counter + 1)) + kGolden * (uint64_t)(i + 1));
+                const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+                abuf[j] = lo + (hi - lo) * u;
+                st.act_out[i] = abuf[j];
+            }
+        }
+        encode_arm_actions<T>(c, st, env, abuf, enc);
+    } else {
+        encode_arm_actions<T>(c, st, env, actions + (size_t)env * c.act_dim, enc);
+    }
     T vels[6];
     scale_actions<T>(c, enc, vels);
     const int step_count = st.step_count[env] + 1;
@@ -682,6 +703,13 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = (double)trig.s[i]; st.trig_sc[(8 + i) * n + env] = (double)trig.c[i]; }
     TG_KSTAMP(4)
     finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
+    if (st.draw != nullptr) {            // every lane of every workgroup has read the counter long ago: the last workgroup to get here moves it on
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(st.draw + 2, 1ull) == (unsigned long long)gridDim.x - 1) { st.draw[2] = 0ull; st.draw[0] = st.draw[0] + 1; }
+        }
+    }
     TG_KSTAMP(9)
 #ifdef TG_KSTEP_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) g_kstep_stamps[15] = ran_full ? 1 : 0;

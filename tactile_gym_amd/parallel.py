@@ -93,6 +93,11 @@ class _IpcSlots:
             try:
                 capi.check(self.L.tg_ipc_alloc(total, C.byref(self.base), handle))
                 payload = [bytes(handle)]
+                self.uncached = bool(self.L.tg_ipc_alloc_was_uncached())
+                if not self.uncached:
+                    import warnings
+                    warnings.warn("tg_ipc_alloc: the runtime refused uncached device memory for the receive slots; they are plain hipMalloc memory, and "
+                                  "only the set-up handshake vouches for peer stores becoming visible to rank 0's reads (exchange_info()['receive_slots_uncached'])")
             except Exception as e:  # noqa: BLE001 - the peers must still be told (they wait in the broadcast)
                 self.failed, self.base = e, C.c_void_p()
         dist.broadcast_object_list(payload, src=root)
@@ -108,6 +113,7 @@ class _IpcSlots:
         self.err = torch.zeros(1, dtype=torch.int32, device=device)       # timeouts of this rank's waits (bit = flag lane)
         self.local = torch.as_tensor(_DevArray(self.base.value, total), device=device) if (self.owner and self.failed is None) else None
 
+    uncached = None                                   # rank 0: whether the receive slots are uncached device memory (None elsewhere)
     fixed_stream = None                               # a pipelined shard pins its stream: no per-call lookup (ShardedVecEnv sets it)
 
     def _stream(self):
@@ -177,6 +183,18 @@ class _IpcSlots:
         self.err.zero_()
         return all(oks)
 
+    def poll(self):
+        """The error word without a synchronisation: an asynchronous copy into pinned memory is started on the exchange's stream and the value the
+        PREVIOUS polls delivered is looked at - a timeout shows up one or two polls after it happened, at the cost of a 4-byte copy."""
+        if self._err_host is None:
+            self._err_host = self.torch.zeros(1, dtype=self.torch.int32).pin_memory()
+        e = int(self._err_host[0])
+        if e:
+            raise RuntimeError(f"rank {self.rank}: exchange flags timed out after {self.timeout_ms} ms (lanes 0x{e & 0xFFFFFFFF:x}): a partner rank is missing or stuck")
+        self._err_host.copy_(self.err, non_blocking=True)
+
+    _err_host = None
+
     def check(self):
         e = int(self.err.item())
         if e:
@@ -233,6 +251,7 @@ class ShardedVecEnv:
         self._bufs, self._ipc, self._lay = {}, None, None
         self._stage, self._full, self._views, self._pending, self._obs_full = [None, None], [None, None], [None, None], [None, None], [None, None]
         self._tick, self._handed = 0, 0              # messages started / the index of the newest message rank 0 has unpacked
+        self._last_out = None                        # (obs, reward, done) of that message
         self._counters = None
         self._last_counts = None
         self._prev_ids = [None, None]
@@ -580,6 +599,7 @@ class ShardedVecEnv:
         if vis_src is not None:                               # (a view with one rank, gathered by reshape with several)
             obs["visual"] = vis_src.reshape((w * n,) + L["vis_shape"][1:])
         self._handed = t
+        self._last_out = (obs, rew, done)
         return obs, rew, done
 
     # ------------------------------------------------------------------ VecEnv surface
@@ -621,9 +641,21 @@ class ShardedVecEnv:
         root = self.rank == self.root
         if not self.overlap:
             self._send(t, obs, rew, done, False)
-            return self._receive(t) + (info,) if root else (obs, rew, done, info)
+            out = self._receive(t) + (info,) if root else (obs, rew, done, info)
+            if self._ipc is not None:
+                # the synchronous path (VecEnv.step_wait semantics): the caller reads this batch next, so the flag waits that delivered it are
+                # checked now - a missing or stuck peer raises here instead of stale slots being unpacked step after step
+                self.torch.cuda.current_stream(self._lay["dev"]).synchronize()
+                self._ipc.check()
+            return out
         self._pending[slot] = self._send(t, obs, rew, done, True)
-        if not root or self._handed >= t - 1 or t == 1:   # nothing newer to hand out yet: the local shard's view of this step
+        if self._ipc is not None and (t & 15) == 0:
+            self._ipc.poll()                          # overlap: no synchronisation on the step path, a timeout surfaces within ~32 steps (and at flush / close)
+        if not root or self._handed >= t - 1 or t == 1:   # nothing newer to hand out yet
+            if root and self._last_out is not None and self._handed == t - 1:
+                # right after an ipc reset(): message t - 1 IS the reset's batch, handed out by reset() already.  It is handed out again (its zero
+                # reward / done with it) rather than the local shard, so that rank 0 sees [world * n] batches at every step
+                return self._last_out + (info,)
             return obs, rew, done, info
         self._wait(self._pending[slot ^ 1])
         self._pending[slot ^ 1] = None
@@ -648,6 +680,8 @@ class ShardedVecEnv:
         L = self._lay
         out = {"payload": self.payload, "transport": self.transport, "message_bytes_capacity": L["total"],
                "full_payload_bytes": _align(L["nb_full"], 16) + L["total"] - L["off_rest"]}
+        if self._ipc is not None and self._ipc.uncached is not None:
+            out["receive_slots_uncached"] = self._ipc.uncached
         if self.payload == "tiles" and self.rank == self.root and self._handed:
             hdr = self._full[self._handed & 1][:, :4].contiguous().view(self.torch.int32).reshape(-1).cpu().tolist()
             if self.transport == "ipc" and hasattr(self.local, "unpack_tiles_multi"):
@@ -669,7 +703,12 @@ class ShardedVecEnv:
             self._full = [None, None]
             self._stage = [None, None]
             ipc, self._ipc = self._ipc, None
+            self.torch.cuda.current_stream(self._lay["dev"]).synchronize()
+            e = int(ipc.err.item())
             ipc.close()
+            if e:                                     # a timeout nobody has been told about yet (no flush, fewer than 16 steps since it happened)
+                raise RuntimeError(f"rank {self.rank}: exchange flags timed out (lanes 0x{e & 0xFFFFFFFF:x}): a partner rank was missing or stuck; "
+                                   f"batches handed out since then held stale slots")
 
 
 class TorchShard:
@@ -778,6 +817,14 @@ class TorchShard:
 
     def step(self, actions):
         self.venv.step_async(actions)
+        if not self.pipelined:
+            self.venv.sync()
+        rew, done = self.venv.reward_done_torch()
+        return self._obs(), rew, done, {}
+
+    def step_random(self, seed, first_draw=0, restart=False):
+        """step(action_space.sample()) with the draw inside the step's graph (TactileVecEnv.step_random_async)."""
+        self.venv.step_random_async(seed, first_draw, restart)
         if not self.pipelined:
             self.venv.sync()
         rew, done = self.venv.reward_done_torch()

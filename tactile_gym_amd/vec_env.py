@@ -242,6 +242,26 @@ class TactileVecEnv(_VecEnvBase):
         capi.check(self._L.tg_sample_actions(self._ctx, C.c_uint64(seed), C.c_uint64(counter), C.c_void_p(out.data_ptr())))
         return out
 
+    def step_random_async(self, seed, first_draw=0, restart=False):
+        """One step of a random-action rollout, `step(action_space.sample())` for the whole batch, as ONE graph launch: the uniform draw (draw k =
+        sample_actions(seed, k)) is a node of the step's graph and the draw counter lives on the device (tg_step_random).  restart: the next draw
+        is first_draw + 1.  The actions used are `actions_torch()`."""
+        self._bind_torch_stream()
+        if self._obs_guard:
+            self._guard_before_step()
+        capi.check(self._L.tg_step_random(self._ctx, C.c_uint64(seed), C.c_uint64(first_draw), 1 if restart else 0))
+        if self._obs_guard:
+            self._guard_after_step()
+
+    def actions_torch(self):
+        """The context's own action buffer as a float32 [N, act_dim] device tensor (what step_random_async drew)."""
+        if "act" not in self._views:
+            import torch
+            p = C.c_void_p()
+            capi.check(self._L.tg_get_actions(self._ctx, C.byref(p)))
+            self._views["act"] = torch.as_tensor(_DevArray(p.value, (self.num_envs, self.act_dim), "<f4"), device=f"cuda:{self._cfg.device}")
+        return self._views["act"]
+
     def step_wait(self):
         capi.check(self._L.tg_get_reward_done(self._ctx, self._reward.ctypes.data_as(C.POINTER(C.c_float)),
                                               self._done.ctypes.data_as(C.POINTER(C.c_uint8))))

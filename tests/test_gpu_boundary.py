@@ -116,3 +116,30 @@ def test_tile_download_hands_out_the_batch_the_full_copy_hands_out(env_id, modes
     venv.set_obs_transfer("full")
     obs, _, _, _ = venv.step(a)
     venv.close()
+
+
+def test_step_random_equals_sample_actions_then_step():
+    """tg_step_random (the uniform policy's draw as a node of the step's graph, device-resident draw counter) = tg_sample_actions(seed, k) followed by
+    tg_step on it: same actions, observations, rewards, dones, also across a restart of the counter and with auto-resets in the rollout."""
+    import torch
+    import tactile_gym_amd as tg
+    from tactile_gym_amd.parallel import TorchShard
+    n = 64
+    mk = lambda: tg.make_vec("edge_follow-v0", num_envs=n, max_steps=9, image_size=[128, 128], env_modes=EDGE, seed=5, auto_reset=True, obs_mode="torch")   # noqa: E731
+    a, b = mk(), mk()
+    sa, sb = TorchShard(a), TorchShard(b)
+    sa.reset(); sb.reset()
+    buf = torch.empty(n, 2, device="cuda")
+    draw = 0
+    for k in range(25):
+        restart = k in (0, 11)
+        if k == 11:
+            draw = 100                                      # jump the stream: the next draw is 101 on both sides
+        oa, ra, da, _ = sa.step_random(77, draw, restart=restart)
+        draw += 1
+        b.sample_actions(buf, 77, draw)
+        ob, rb, db, _ = sb.step(buf)
+        torch.cuda.synchronize()
+        assert torch.equal(a.actions_torch(), buf), k
+        assert torch.equal(oa["tactile"], ob["tactile"]) and torch.equal(ra, rb) and torch.equal(da, db), k
+    a.close(); b.close()

@@ -199,3 +199,58 @@ def test_unpack_multi_restores_only_what_the_last_message_touched():
         assert counts[0] == 0 and 0 < counts[1] < n * T // 2 and 0 < counts[2] < n * T // 2
     for v in envs:
         v.close()
+
+
+def _ipc_stuck_worker(rank, world, port, out_path, overlap):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import tactile_gym_amd as tg
+    from tactile_gym_amd.parallel import ShardedVecEnv, TorchShard
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local = 16
+    v = tg.make_vec("edge_follow-v0", num_envs=n_local, max_steps=200, image_size=[128, 128], env_modes=EDGE, seed=70 + rank * n_local, obs_mode="torch", auto_reset=True)
+    shard = TorchShard(v, pipelined=True)
+    env = ShardedVecEnv(shard, dist, overlap=overlap, payload="tiles", transport="ipc", timeout_ms=300)
+    a = torch.zeros(n_local, v.act_dim, device="cuda")
+    raised_at, msg = None, ""
+    with torch.cuda.stream(shard.stream):
+        env.reset()
+        for k in range(40):
+            if rank == 1 and k >= 2:
+                break                                  # the peer stops sending: rank 0's waits on its ready flag time out
+            try:
+                env.step(a)
+            except RuntimeError as e:
+                raised_at, msg = k, str(e)
+                break
+        torch.cuda.synchronize()
+    dist.barrier()
+    try:
+        env.close()
+    except RuntimeError as e:
+        if raised_at is None:
+            raised_at, msg = "close", str(e)
+    if rank == 0:
+        torch.save({"raised_at": raised_at, "msg": msg}, out_path)
+    v.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_a_stuck_peer_raises_on_the_step_path(tmp_path, overlap):
+    """a peer that stops sending.  overlap=False: the step that would have handed out a stale slot raises; overlap=True: the
+    error word is polled every 16th step without a synchronisation (the host runs ahead of the device there, so a short run may end before a
+    poll has seen it) and close() raises whatever no step has reported - never silent."""
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_ipc_stuck_worker, args=(2, port, out, overlap), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["raised_at"] is not None and "timed out" in got["msg"], got
+    assert got["raised_at"] == 2 if not overlap else (got["raised_at"] == "close" or 2 <= got["raised_at"] <= 39), got

@@ -141,6 +141,11 @@ class TileDownload:
         self._last_count = 0
         self.t_device = self.t_host = 0.0      # seconds spent in fetch(): pack + copy + synchronise / host rebuild
         self.calls = 0
+        # reward / done ride under the same synchronisation (step_wait would otherwise pay a copy and a stream sync of its own first)
+        self.rd_dev = venv.reward_done_torch()
+        self.rew_host = torch.empty(n, dtype=torch.float32).pin_memory()
+        self.done_host = torch.empty(n, dtype=torch.uint8).pin_memory()
+        self.rd_fresh = False
 
     def fetch(self):
         """The current observation batch as uint8 [n, H, W, 1] (one of the ring buffers)."""
@@ -153,7 +158,10 @@ class TileDownload:
         # a frame with more records than that fetches the rest in a second copy
         guess = min(self.pk.numel(), 16 + TILE_REC * (self._last_count + self._last_count // 4 + 64))
         self.host_pk[:guess].copy_(self.pk[:guess], non_blocking=True)
+        self.rew_host.copy_(self.rd_dev[0], non_blocking=True)
+        self.done_host.copy_(self.rd_dev[1], non_blocking=True)
         stream.synchronize()
+        self.rd_fresh = True
         count = int(self.host_np[:4].view(np.int32)[0])
         nb = 16 + TILE_REC * count
         if nb > guess:

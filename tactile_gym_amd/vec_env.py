@@ -263,10 +263,22 @@ class TactileVecEnv(_VecEnvBase):
         return self._views["act"]
 
     def step_wait(self):
-        capi.check(self._L.tg_get_reward_done(self._ctx, self._reward.ctypes.data_as(C.POINTER(C.c_float)),
-                                              self._done.ctypes.data_as(C.POINTER(C.c_uint8))))
-        self._held = None
-        obs = self._observation()
+        td = getattr(self, "_tile_download", None)
+        if td is not None and "tactile" in self.observation_mode and self.obs_mode != "torch":
+            # tile download: the observation fetch brings reward / done along under its one synchronisation
+            td.rd_fresh = False
+            obs = self._observation()
+            if td.rd_fresh:
+                np.copyto(self._reward, td.rew_host.numpy()); np.copyto(self._done, td.done_host.numpy())
+            else:
+                capi.check(self._L.tg_get_reward_done(self._ctx, self._reward.ctypes.data_as(C.POINTER(C.c_float)),
+                                                      self._done.ctypes.data_as(C.POINTER(C.c_uint8))))
+            self._held = None
+        else:
+            capi.check(self._L.tg_get_reward_done(self._ctx, self._reward.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  self._done.ctypes.data_as(C.POINTER(C.c_uint8))))
+            self._held = None
+            obs = self._observation()
         dones = self._done.astype(bool)
         # SB3 reads infos[i].get(...) / "key" in infos[i]; only the envs that finished carry anything.  lazy_info (default): the others share ONE
         # empty dict (1024 dict constructions per step are a tenth of the numpy step's host time); an env's own dict is made when it has something to

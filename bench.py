@@ -52,7 +52,7 @@ MAX_STEPS = {"object_balance-v0": 250, "object_push-v0": 1000, "object_roll-v0":
 ALGO_BYTES_PER_ENV_STEP = 16600.0   # BASELINE.md section 3 / SURVEY 8(d): 16 384 B image + ~0.2 KB state/action/reward
 ALGO_BYTES_SURFACE = 33000.0        # config 3: + the per-env 64x64 f32 heightfield read
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-TRAFFIC_FILE = os.path.join("profiles", "r3_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r4_traffic.json")
 
 
 def algo_bytes(env_id, image_size):

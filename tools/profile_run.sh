@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 evidence run on the MI355X box (one gpurun call): the default bench line (headline + other_configs + literal + CPU baseline),
+# Evidence run (rounds 3, 4: TG_PROFILE_TAG names the output set) on the MI355X box (one gpurun call): the default bench line (headline + other_configs + literal + CPU baseline),
 # one bench line per env, rocprofv3 kernel stats and SQ counters of the default command and of object_push / object_balance /
 # surface_follow-v2 (MG400, eight-sweep blocks) / the literal solver, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of
-# edge_follow, object_push and object_balance.  Outputs under gpurun_out/<tag>/; copied to profiles/<tag>_* afterwards (tools/r3_collect.py).
+# edge_follow, object_push and object_balance.  Outputs under gpurun_out/<tag>/; copied to profiles/<tag>_* afterwards (tools/profile_collect.py).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${TG_PROFILE_TAG:-r3_final}
+TAG=${TG_PROFILE_TAG:-r4_final}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -18,6 +18,10 @@ $B --env object_balance-v0 --image-size 256 2>/dev/null | grep metric > $O/bench
 $B --env object_push-v0 --steps 200 --warmup 20 2>/dev/null | grep metric > $O/bench_object_push-v0.json
 $B --env object_roll-v0 --steps 200 --warmup 20 2>/dev/null | grep metric > $O/bench_object_roll-v0.json
 $B --no-literal --observation-mode visuotactile --steps 200 --warmup 20 2>/dev/null | grep metric > $O/bench_edge_visuotactile.json
+$B --no-literal --separate-policy 2>/dev/null | grep metric > $O/bench_edge_separate_policy.json
+TG_RESET_BANK=0 $B --env surface_follow-v2 2>/dev/null | grep metric > $O/bench_surface_follow-v2_bank_off.json
+$B --env object_push-v0 --narrowphase gjk_manifold --steps 100 --warmup 10 2>/dev/null | grep metric > $O/bench_object_push-v0_gjk_manifold.json
+(python tools/pcie_rate.py; python tools/pcie_rate.py --tiles) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank.json
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport collective --payload interior 2>/dev/null | grep metric > $O/bench_edge_rccl_interior_1rank.json
 cd /tmp; export TMPDIR=/tmp

@@ -571,7 +571,7 @@ def main():
                       "the solver's analytic fixed point (qd = target); joints within 1e-11 rad of the literal solver over 1024 envs x 260 steps incl. auto-resets "
                       "(tests/test_gpu_parity.py::test_default_solver_equals_literal_solver_at_config_scale; DESIGN.md 4.1)",
             "policy": ("uniform random actions (action_space.sample() for the whole batch), drawn on the device as the first node of the step's graph "
-                       "(tg_step_random; draw k identical to tg_sample_actions(seed, k))") if Workload.fused_policy and dist is None else
+                       "(tg_step_random; draw k identical to tg_sample_actions(seed, k))") if Workload.fused_policy and hasattr(env, "step_random") else
                       "uniform random actions drawn on the device by tg_sample_actions, one launch before every step",
             "separate_policy_launch": separate,
             "literal_solver": literal,

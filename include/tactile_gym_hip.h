@@ -288,6 +288,9 @@ int tg_ipc_close(void* dev_ptr);
 /* Device copy on a stream whose destination (or source) may be memory opened with tg_ipc_open; both pointers 16-byte aligned. */
 int tg_copy_bytes(void* hip_stream, void* dst_dev, const void* src_dev, int64_t bytes);
 int tg_copy_bytes2(void* hip_stream, void* dst1_dev, const void* src1_dev, int64_t bytes1, void* dst2_dev, const void* src2_dev, int64_t bytes2);   /* two ranges, one launch */
+/* tg_copy_bytes2 whose launch also raises n_flags flags (flags_dev[i * stride_words] = value, system-scope release; NULL: none). */
+int tg_copy_bytes2_flag(void* stream, void* dst1_dev, const void* src1_dev, int64_t bytes1, void* dst2_dev, const void* src2_dev, int64_t bytes2,
+                        void* flags_dev, int32_t n_flags, int32_t stride_words, uint32_t value);
 /* Stream-ordered flags (uint32, monotone step counters) in such memory.  tg_flag_set: after everything enqueued before it on the stream has
  * finished, flags[i * stride_words] = value for i < n (release, system scope).  tg_flag_wait: the stream goes on once every
  * flags[i * stride_words] has reached value (compared modulo 2^32); after timeout_ms of waiting it goes on anyway and ORs bit (i & 31) into

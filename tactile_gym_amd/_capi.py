@@ -160,6 +160,7 @@ SYMBOLS = {
     "tg_ipc_close": (C.c_int, [C.c_void_p]),
     "tg_copy_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "tg_copy_bytes2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),
+    "tg_copy_bytes2_flag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32]),
     "tg_flag_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32]),
     "tg_flag_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32]),
     "tg_get_obs_oracle": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32)]),

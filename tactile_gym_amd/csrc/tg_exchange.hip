@@ -191,8 +191,12 @@ __global__ __launch_bounds__(256) void k_scatter_tiles_multi_keep(const uint8_t*
 }
 
 // two ranges in one launch (rank 0 copies its own images and the block behind them per step)
+// flags (nullable): the first n lanes of workgroup 0 also raise flags[i * stride] to `value` (system-scope release) - rank 0's per-step
+// "slot consumed" signal rides in the launch that copies its own images instead of a launch of its own
 __global__ __launch_bounds__(256) void k_copy_bytes2(const uint8_t* __restrict__ s1, size_t b1, uint8_t* __restrict__ d1, const uint8_t* __restrict__ s2, size_t b2,
-                                                    uint8_t* __restrict__ d2) {
+                                                    uint8_t* __restrict__ d2, uint32_t* flags, int n_flags, int stride, uint32_t value) {
+    if (flags != nullptr && blockIdx.x == 0 && (int)threadIdx.x < n_flags)
+        __hip_atomic_store(flags + (size_t)threadIdx.x * stride, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const size_t n1 = b1 / 16, n2 = b2 / 16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
         if (i < n1) reinterpret_cast<uint4*>(d1)[i] = reinterpret_cast<const uint4*>(s1)[i];
@@ -367,12 +371,18 @@ int tg_copy_bytes(void* stream, void* dst_dev, const void* src_dev, int64_t byte
 }
 
 int tg_copy_bytes2(void* stream, void* dst1_dev, const void* src1_dev, int64_t bytes1, void* dst2_dev, const void* src2_dev, int64_t bytes2) {
+    return tg_copy_bytes2_flag(stream, dst1_dev, src1_dev, bytes1, dst2_dev, src2_dev, bytes2, nullptr, 0, 1, 0u);
+}
+
+int tg_copy_bytes2_flag(void* stream, void* dst1_dev, const void* src1_dev, int64_t bytes1, void* dst2_dev, const void* src2_dev, int64_t bytes2,
+                        void* flags_dev, int32_t n_flags, int32_t stride_words, uint32_t value) {
     if (!dst1_dev || !src1_dev || !dst2_dev || !src2_dev || bytes1 < 0 || bytes2 < 0) return report_error(-1, "tg_copy_bytes2: bad argument");
+    if (flags_dev && (n_flags <= 0 || n_flags > 64 || stride_words <= 0)) return report_error(-1, "tg_copy_bytes2_flag: bad flag argument (1 <= n <= 64)");
     if (((uintptr_t)dst1_dev | (uintptr_t)src1_dev | (uintptr_t)dst2_dev | (uintptr_t)src2_dev) & 15) return report_error(-1, "tg_copy_bytes2: pointers must be 16-byte aligned");
     const size_t n16 = (size_t)(bytes1 + bytes2) / 16;
     const unsigned blocks = (unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096);
     hipLaunchKernelGGL(tg::k_copy_bytes2, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src1_dev, (size_t)bytes1, (uint8_t*)dst1_dev,
-                       (const uint8_t*)src2_dev, (size_t)bytes2, (uint8_t*)dst2_dev);
+                       (const uint8_t*)src2_dev, (size_t)bytes2, (uint8_t*)dst2_dev, (uint32_t*)flags_dev, (int)n_flags, (int)stride_words, value);
     TGX_HIP(hipGetLastError());
     return 0;
 }

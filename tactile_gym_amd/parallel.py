@@ -449,7 +449,8 @@ class ShardedVecEnv:
         if self.transport == "ipc":
             ipc = self._ipc
             if root:
-                if t > 2:                                 # the batch of message t - 2 has been consumed: its slot may be overwritten
+                fused_flag = t > 2 and self.payload == "tiles" and hasattr(self.local, "unpack_tiles_multi") and not L["vis_bytes"]
+                if t > 2 and not fused_flag:              # the batch of message t - 2 has been consumed: its slot may be overwritten
                     ipc.set("consumed", slot, 0, self.world, t - 2)
                 if self.payload == "tiles" and hasattr(self.local, "unpack_tiles_multi"):
                     # rank 0's own images are not packed and unpacked: they go straight into their block of the batch (one copy), and
@@ -466,7 +467,11 @@ class ShardedVecEnv:
                         rest = self._rest_tensor(obs, rew, done)
                         c = c[:5] + (C.c_void_p(rest.data_ptr()), rest.numel(), False)
                         self._keep = rest
-                    capi.check(ipc.L.tg_copy_bytes2(ipc._stream(), c[0], c[1], c[2], c[3], c[5], c[6]))
+                    if fused_flag:                                         # the "consumed" signal rides in the copy's launch (one dependent launch less per step)
+                        capi.check(ipc.L.tg_copy_bytes2_flag(ipc._stream(), c[0], c[1], c[2], c[3], c[5], c[6], ipc._flag_ptr("consumed", slot, 0), self.world, 16,
+                                                             (t - 2) & 0xFFFFFFFF))
+                    else:
+                        capi.check(ipc.L.tg_copy_bytes2(ipc._stream(), c[0], c[1], c[2], c[3], c[5], c[6]))
                     if L["vis_bytes"]:
                         ipc.copy(self._stage[slot][L["off_vis"]:].data_ptr(), obs["visual"].reshape(-1))
                 else:
@@ -627,8 +632,15 @@ class ShardedVecEnv:
             self._wait(self._pending[k])
             self._pending[k] = None
 
+    def step_random(self, seed, first_draw=0, restart=False):
+        """step(action_space.sample()) on every rank's shard (TorchShard.step_random: the draw inside the step's graph), then the exchange of step().
+        Every rank passes its own seed."""
+        return self._exchange(*self.local.step_random(seed, first_draw, restart))
+
     def step(self, local_actions):
-        obs, rew, done, info = self.local.step(local_actions)
+        return self._exchange(*self.local.step(local_actions))
+
+    def _exchange(self, obs, rew, done, info):
         if self._solo:
             return obs, rew, done, info
         if self._lay is None:

@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 9
+#define TG_ABI_VERSION 10
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -197,10 +197,19 @@ typedef struct {
      * (no cache): the closed form's special case - equal to it wherever the closest features are a hull vertex and a box face (tests).
      * Both run on the wave mapping (f64, cone friction). */
     int32_t narrowphase;                    /* TG_NARROW_* */
+    /* object_balance, object_mode "ball_on_plate" (object_balance_env.py:187-199, 241-260): the free body is the round plate (obj_mass /
+     * obj_com / obj_inertia, obj_base_width 0.2, tied to the TCP as the pole is) and a ball rolls on it: sphere.urdf x globalScaling 7.5
+     * (mass 0.05 unscaled, radius 0.0025 x 7.5), lateralFriction 10 x the plate's default 0.5, reset to workframe + (0, 0, radius) with a
+     * one-shot torque 0.001 x (U(-1,1), U(-1,1), 0) (:350-353, 393-401).  Contact: ball against the plate's solid cylinder (plate_radius,
+     * half length obj_base_height / 2), contact_breaking / contact_erp / obj_lin_damp / obj_ang_damp as for object_push, cone friction.
+     * Reward, termination and the observations ignore the ball (:426-497).  Lane mapping only.  [PARITY_ASSUMPTIONS A39] */
+    int32_t balance_object;                 /* TG_BALANCE_* */
+    double ball_radius, ball_mass, ball_mu, plate_radius;
 } tg_config;
 
 enum { TG_BANK_AUTO = 0, TG_BANK_OFF = 1, TG_BANK_SYNC = 2, TG_BANK_ON = 3 };
 enum { TG_NARROW_CLOSED_FORM = 0, TG_NARROW_GJK_MANIFOLD = 1, TG_NARROW_GJK_SINGLE = 2 };
+enum { TG_BALANCE_POLE = 0, TG_BALANCE_BALL_ON_PLATE = 1 };
 
 typedef struct tg_ctx tg_ctx;
 
@@ -358,6 +367,10 @@ typedef struct {
      * Unused slots are -1.  Integer data: compared bit-exactly with the oracle. */
     int32_t* contact_count;  /* [num_envs] */
     int32_t* contact_ids;    /* [num_envs][8]: solver row order, -1 beyond contact_count (4 table + up to 4 tip slots) */
+    double*  ball_pos;       /* [num_envs][3] object_balance ball_on_plate: the ball's centre, world */
+    double*  ball_linvel;    /* [num_envs][3] */
+    double*  ball_angvel;    /* [num_envs][3] */
+    double*  ball_impulse;   /* [num_envs] normal impulse of the ball - plate contact in the last sim tick (0: not touching) */
 } tg_state_view;
 int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */

@@ -795,6 +795,197 @@ void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, d
     for (int x = 0; x < 3; ++x) b->pos[x] = xc[x] - cw[x];
 }
 
+/* ------------------------------------------------------------------------------------------------ arm + plate + P2P + ball */
+void mb_step_body_ball(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, mb_ball* ball, double dt, int iters) {
+    enum { NR = MB_MAX_DOF + 6, NU = MB_MAX_DOF + 12 };
+    int n = m->ndof, nu = n + 12, nr0 = n + 3;
+    /* ---- arm and plate: unconstrained velocities exactly as mb_step_body */
+    double tau[MB_MAX_DOF], h[MB_MAX_DOF], Qd[MB_MAX_DOF], v[NU], M[MB_MAX_DOF * MB_MAX_DOF], Mi[MB_MAX_DOF * MB_MAX_DOF], zero[MB_MAX_DOF] = {0};
+    for (int i = 0; i < n; ++i) tau[i] = s->applied_torque[i] - m->joint_damping * s->qd[i];
+    mb_inverse_dynamics(m, s->q, s->qd, zero, h);
+    damping_force(m, s->q, s->qd, Qd);
+    mb_mass_matrix(m, s->q, M);
+    invert(M, n, Mi);
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += Mi[i * n + j] * (tau[j] - h[j] + Qd[j]);
+        v[i] = s->qd[i] + dt * acc;
+    }
+    double Iw[9], Iwi[9], RI[9], cw[3], xc[3];
+    m3_mul(b->rot, b->inertia, RI);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Iw[3 * i + j] = RI[3 * i] * b->rot[3 * j] + RI[3 * i + 1] * b->rot[3 * j + 1] + RI[3 * i + 2] * b->rot[3 * j + 2];
+    invert3(Iw, Iwi);
+    m3_vec(b->rot, b->com, cw);
+    for (int k = 0; k < 3; ++k) xc[k] = b->pos[k] + cw[k];
+    double F[3] = {b->mass * m->gravity[0], b->mass * m->gravity[1], b->mass * m->gravity[2]}, N[3] = {0, 0, 0};
+    if (b->ext_pending) {
+        double r[3] = {b->ext_pos[0] - xc[0], b->ext_pos[1] - xc[1], b->ext_pos[2] - xc[2]}, t[3];
+        cross(r, b->ext_force, t);
+        for (int k = 0; k < 3; ++k) { F[k] += b->ext_force[k]; N[k] += t[k]; }
+        b->ext_pending = 0;
+    }
+    double Iwv[3], gyro[3], wacc[3];
+    m3_vec(Iw, b->angvel, Iwv); cross(b->angvel, Iwv, gyro);
+    for (int k = 0; k < 3; ++k) N[k] -= gyro[k];
+    m3_vec(Iwi, N, wacc);
+    for (int k = 0; k < 3; ++k) { v[n + k] = b->linvel[k] + dt * F[k] / b->mass; v[n + 3 + k] = b->angvel[k] + dt * wacc[k]; }
+    /* ---- ball: gravity, the one-shot torque; an isotropic inertia has no gyroscopic term; no velocity damping (reset_object :338-345 sets the
+       object's damping to 0; the ball keeps Bullet's default 0.04: F = -m v (K + K|v|), as for the cube, A27) */
+    {
+        double sv = 0.04 + 0.04 * norm3(ball->linvel), sw = 0.04 + 0.04 * norm3(ball->angvel);
+        for (int k = 0; k < 3; ++k) {
+            double tq = ball->ext_pending ? ball->ext_torque[k] : 0.0;
+            v[n + 6 + k] = ball->linvel[k] + dt * (m->gravity[k] - ball->linvel[k] * sv);
+            v[n + 9 + k] = ball->angvel[k] + dt * (tq / ball->inertia - ball->angvel[k] * sw);
+        }
+        ball->ext_pending = 0;
+    }
+    /* ---- rows: motors, P2P, then (if touching) the ball - plate contact */
+    static double J[NR][NU], W[NU][NR];
+    double A[NR], rhs[NR], lim[NR], lam[NR], dv[NU];
+    memset(J, 0, sizeof J);
+    for (int i = 0; i < n; ++i) J[i][i] = 1.0;
+    kin_t k; double z3[3] = {0, 0, 0};
+    kinematics(m, s->q, zero, NULL, z3, &k);
+    double ra[3], pa[3], pb[3], rb[3], tvec[3];
+    m3_vec(k.R[c->link], c->pivot_a, ra);
+    for (int x = 0; x < 3; ++x) pa[x] = k.o[c->link][x] + ra[x];
+    m3_vec(b->rot, c->pivot_b, tvec);
+    for (int x = 0; x < 3; ++x) { pb[x] = b->pos[x] + tvec[x]; rb[x] = pb[x] - xc[x]; }
+    for (int i = 0; i < n; ++i) {
+        if (!is_in_subtree(m, c->link, i)) continue;
+        double r[3] = {pa[0] - k.o[i][0], pa[1] - k.o[i][1], pa[2] - k.o[i][2]}, jt[3];
+        cross(k.a[i], r, jt);
+        for (int x = 0; x < 3; ++x) J[n + x][i] = jt[x];
+    }
+    for (int x = 0; x < 3; ++x) {
+        double e[3] = {0, 0, 0}, rxe[3];
+        e[x] = 1.0;
+        cross(rb, e, rxe);
+        J[n + x][n + x] = -1.0;
+        for (int y = 0; y < 3; ++y) J[n + x][n + 3 + y] = -rxe[y];
+    }
+    /* contact: closest point of the plate's solid cylinder to the ball's centre (plate frame: axis z, centred) */
+    int nr = nr0, touching = 0;
+    double nrm[3] = {0, 0, 1}, cpa[3], cpb[3], depth = 1e30;
+    {
+        double d[3] = {ball->pos[0] - b->pos[0], ball->pos[1] - b->pos[1], ball->pos[2] - b->pos[2]}, p[3], cl[3], g[3], gw[3], clw[3];
+        for (int x = 0; x < 3; ++x) p[x] = b->rot[x] * d[0] + b->rot[3 + x] * d[1] + b->rot[6 + x] * d[2];
+        double rad = sqrt(p[0] * p[0] + p[1] * p[1]);
+        double sr = rad > ball->plate_radius ? ball->plate_radius / rad : 1.0;
+        cl[0] = p[0] * sr; cl[1] = p[1] * sr;
+        cl[2] = p[2] > ball->plate_half_len ? ball->plate_half_len : (p[2] < -ball->plate_half_len ? -ball->plate_half_len : p[2]);
+        for (int x = 0; x < 3; ++x) g[x] = p[x] - cl[x];
+        double dist = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        depth = dist - ball->radius;
+        if (dist > 0.0 && depth <= ball->breaking) {
+            touching = 1;
+            for (int x = 0; x < 3; ++x) g[x] /= dist;
+            m3_vec(b->rot, g, gw);                                   /* from the plate towards the ball */
+            m3_vec(b->rot, cl, clw);
+            for (int x = 0; x < 3; ++x) { nrm[x] = gw[x]; cpa[x] = ball->pos[x] - gw[x] * ball->radius; cpb[x] = b->pos[x] + clw[x]; }
+        }
+    }
+    ball->in_contact = touching; ball->depth = depth; ball->normal_impulse = 0.0;
+    if (touching) {
+        double t1[3], t2[3];
+        if (fabs(nrm[2]) > 0.7071067811865475244) {                  /* btPlaneSpace1 */
+            double a = nrm[1] * nrm[1] + nrm[2] * nrm[2], kk = 1.0 / sqrt(a);
+            t1[0] = 0; t1[1] = -nrm[2] * kk; t1[2] = nrm[1] * kk;
+            t2[0] = a * kk; t2[1] = -nrm[0] * t1[2]; t2[2] = nrm[0] * t1[1];
+        } else {
+            double a = nrm[0] * nrm[0] + nrm[1] * nrm[1], kk = 1.0 / sqrt(a);
+            t1[0] = -nrm[1] * kk; t1[1] = nrm[0] * kk; t1[2] = 0;
+            t2[0] = -nrm[2] * t1[1]; t2[1] = nrm[2] * t1[0]; t2[2] = a * kk;
+        }
+        const double* dirs[3] = {nrm, t1, t2};
+        double rba[3] = {cpa[0] - ball->pos[0], cpa[1] - ball->pos[1], cpa[2] - ball->pos[2]};      /* body A = the ball (+d) */
+        double rpb[3] = {cpb[0] - xc[0], cpb[1] - xc[1], cpb[2] - xc[2]};                            /* body B = the plate (-d) */
+        for (int r = 0; r < 3; ++r) {
+            const double* d = dirs[r];
+            double* row = J[nr0 + r];
+            double rxa[3], rxb[3];
+            cross(rba, d, rxa); cross(rpb, d, rxb);
+            for (int x = 0; x < 3; ++x) { row[n + 6 + x] = d[x]; row[n + 9 + x] = rxa[x]; row[n + x] = -d[x]; row[n + 3 + x] = -rxb[x]; }
+        }
+        nr = nr0 + 3;
+    }
+    for (int r = 0; r < nr; ++r) {
+        for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < n; ++j) acc += Mi[i * n + j] * J[r][j]; W[i][r] = acc; }
+        for (int x = 0; x < 3; ++x) W[n + x][r] = J[r][n + x] / b->mass;
+        for (int x = 0; x < 3; ++x) W[n + 3 + x][r] = Iwi[3 * x] * J[r][n + 3] + Iwi[3 * x + 1] * J[r][n + 4] + Iwi[3 * x + 2] * J[r][n + 5];
+        for (int x = 0; x < 3; ++x) { W[n + 6 + x][r] = J[r][n + 6 + x] / ball->mass; W[n + 9 + x][r] = J[r][n + 9 + x] / ball->inertia; }
+        double acc = 0; for (int u = 0; u < nu; ++u) acc += J[r][u] * W[u][r];
+        A[r] = acc;
+    }
+    for (int i = 0; i < n; ++i) {
+        double kp = (s->motor_mode[i] == MB_MOTOR_POSITION) ? s->motor_kp[i] : 0.0;
+        double des = kp * (s->motor_q_des[i] - s->q[i]) / dt + v[i] + s->motor_kd[i] * (s->motor_qd_des[i] - v[i]);
+        rhs[i] = (s->motor_mode[i] != MB_MOTOR_OFF) ? des - v[i] : 0.0;
+        lim[i] = (s->motor_mode[i] != MB_MOTOR_OFF) ? s->motor_max_force[i] * dt : 0.0;
+    }
+    for (int x = 0; x < 3; ++x) {
+        double cv = 0.0;
+        for (int u = 0; u < nu; ++u) cv += J[n + x][u] * v[u];
+        rhs[n + x] = (-c->erp * (pa[x] - pb[x]) / dt) - cv;
+        lim[n + x] = c->max_impulse;
+    }
+    for (int r = nr0; r < nr; ++r) {
+        double rv = 0; for (int u = 0; u < nu; ++u) rv += J[r][u] * v[u];
+        if (r == nr0) rhs[r] = (depth > 0) ? (-rv - depth / dt) : (-depth * ball->erp / dt - rv);    /* restitution 0 */
+        else rhs[r] = -rv;
+    }
+    memset(lam, 0, sizeof lam); memset(dv, 0, sizeof dv);
+    for (int it = 0; it < iters; ++it) {
+        double residual = 0.0;
+        for (int jj = 0; jj < nr0; ++jj) {                           /* motors and P2P rows: reversed on even sweeps (mb_step_body) */
+            int r = (it & 1) ? jj : nr0 - 1 - jj;
+            if (lim[r] == 0.0) continue;
+            double jdv = 0.0;
+            for (int u = 0; u < nu; ++u) jdv += J[r][u] * dv[u];
+            double jdi = 1.0 / A[r];
+            double delta = rhs[r] * jdi - jdv * jdi, sum = lam[r] + delta;
+            if (sum < -lim[r]) { delta = -lim[r] - lam[r]; lam[r] = -lim[r]; }
+            else if (sum > lim[r]) { delta = lim[r] - lam[r]; lam[r] = lim[r]; }
+            else lam[r] = sum;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+            if (delta * delta > residual) residual = delta * delta;
+        }
+        if (touching) {
+            int r = nr0, r1 = nr0 + 1, r2 = nr0 + 2;
+            double jdv = 0; for (int u = 0; u < nu; ++u) jdv += J[r][u] * dv[u];
+            double jdi = 1.0 / A[r];
+            double delta = rhs[r] * jdi - jdv * jdi, sum = lam[r] + delta;
+            if (sum < 0.0) { delta = -lam[r]; lam[r] = 0.0; } else lam[r] = sum;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+            if (delta * delta > residual) residual = delta * delta;
+            double limit = ball->mu * lam[r], jdv1 = 0, jdv2 = 0;
+            for (int u = 0; u < nu; ++u) { jdv1 += J[r1][u] * dv[u]; jdv2 += J[r2][u] * dv[u]; }
+            double d1 = (rhs[r1] - jdv1) / A[r1], d2 = (rhs[r2] - jdv2) / A[r2];
+            double s1 = lam[r1] + d1, s2 = lam[r2] + d2, tot = sqrt(s1 * s1 + s2 * s2);
+            if (tot > limit) { double f = tot > 0 ? limit / tot : 0.0; s1 *= f; s2 *= f; }          /* cone friction (enableConeFriction = 1) */
+            d1 = s1 - lam[r1]; d2 = s2 - lam[r2]; lam[r1] = s1; lam[r2] = s2;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r1] * d1 + W[u][r2] * d2;
+            if (d1 * d1 > residual) residual = d1 * d1;
+            if (d2 * d2 > residual) residual = d2 * d2;
+        }
+        if (residual <= 0.0) break;
+    }
+    if (touching) ball->normal_impulse = lam[nr0];
+    /* ---- integrate */
+    for (int i = 0; i < n; ++i) { s->qd[i] = v[i] + dv[i]; s->q[i] += dt * s->qd[i]; s->applied_torque[i] = 0.0; }
+    for (int x = 0; x < 3; ++x) { b->linvel[x] = v[n + x] + dv[n + x]; b->angvel[x] = v[n + 3 + x] + dv[n + 3 + x]; }
+    for (int x = 0; x < 3; ++x) xc[x] += dt * b->linvel[x];
+    integrate_rotation(b->rot, b->angvel, dt);
+    m3_vec(b->rot, b->com, cw);
+    for (int x = 0; x < 3; ++x) b->pos[x] = xc[x] - cw[x];
+    for (int x = 0; x < 3; ++x) {
+        ball->linvel[x] = v[n + 6 + x] + dv[n + 6 + x]; ball->angvel[x] = v[n + 9 + x] + dv[n + 9 + x];
+        ball->pos[x] += dt * ball->linvel[x];
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ arm + cube + contacts */
 typedef struct { double n[3], pa[3], pb[3], depth, mu, cfm_dt, erp; int arm_a; /* 1: body A is the arm tip, B the cube; 0: A cube, B table */ } contact_t;
 

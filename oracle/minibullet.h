@@ -149,6 +149,26 @@ typedef struct {
 /* stepSimulation() for arm + body + P2P.  Row order: joint motors (joint order), then P2P x, y, z. */
 void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, double dt, int solver_iterations);
 
+/* object_balance, object_mode "ball_on_plate" (object_balance_env.py:105-106, 187-199, 245-260): the body tied to the TCP is the round plate
+ * (round_plate.urdf: cylinder r 0.1, length 0.0025, mass 0.01) and a free ball (sphere.urdf, globalScaling 7.5: r 0.01875, mass 0.05,
+ * lateralFriction 10) rolls on it.  The ball touches only the plate here: one contact from the closest point of the plate's solid cylinder to
+ * the ball's centre (the marble / tip-cylinder closed form of A30), normal + two friction rows with cone friction, rigid (erp, cfm 0); a ball
+ * that has left the plate falls freely [PARITY_ASSUMPTIONS A39].  Neither reward, termination nor the tactile image look at the ball
+ * (object_balance_env.py:444-526): it matters through its weight and rolling on the plate.  PARITY UNPINNED. */
+typedef struct {
+    double radius, mass, inertia;          /* solid sphere about its centre: 0.4 m r^2 (Bullet recomputes it from the collision shape, A30) */
+    double pos[3], linvel[3], angvel[3];
+    double ext_torque[3];                  /* applyExternalTorque(LINK_FRAME) on a ball that was just reset (identity orientation): next tick only */
+    int32_t ext_pending;
+    double mu;                             /* combined friction ball x plate */
+    double plate_radius, plate_half_len;   /* the plate's collision cylinder: axis = z of the plate's base frame, centred on it */
+    double breaking, erp;                  /* contactBreakingThreshold, contact ERP */
+    int32_t in_contact;                    /* out: the last tick made a ball - plate contact */
+    double depth, normal_impulse;          /* out */
+} mb_ball;
+/* Row order: joint motors, P2P x y z (these in reversed order on even sweeps), then the contact's normal, then its friction pair. */
+void mb_step_body_ball(const mb_model* m, mb_state* s, mb_body* plate, const mb_p2p* c, mb_ball* ball, double dt, int solver_iterations);
+
 /* ----------------------------------------------------------------------------------------------------------
  * object_push: a free box (the cube) resting on the table and pushed by the sensor tip's collision core
  * (object_push_env.py; tip core collision on: t_s_core = "fixed", :60).  Restatement of a Bullet-style pipeline with this

@@ -49,6 +49,13 @@ class MBP2P(C.Structure):
                 ("max_impulse", C.c_double)]
 
 
+class MBBall(C.Structure):
+    _fields_ = [("radius", C.c_double), ("mass", C.c_double), ("inertia", C.c_double), ("pos", C.c_double * 3), ("linvel", C.c_double * 3),
+                ("angvel", C.c_double * 3), ("ext_torque", C.c_double * 3), ("ext_pending", C.c_int32), ("mu", C.c_double),
+                ("plate_radius", C.c_double), ("plate_half_len", C.c_double), ("breaking", C.c_double), ("erp", C.c_double),
+                ("in_contact", C.c_int32), ("depth", C.c_double), ("normal_impulse", C.c_double)]
+
+
 class MBManifold(C.Structure):
     _fields_ = [("n", C.c_int32), ("la", (C.c_double * 3) * 4), ("lb", (C.c_double * 3) * 4), ("nrm", (C.c_double * 3) * 4),
                 ("pa", (C.c_double * 3) * 4), ("pb", (C.c_double * 3) * 4), ("depth", C.c_double * 4)]
@@ -93,6 +100,7 @@ def lib():
         _lib.mb_step.argtypes = [mp, sp, C.c_double, C.c_int]
         _lib.mb_step_body.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.c_double, C.c_int]
         _lib.mb_step_push.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBPushScene), C.c_double, C.c_int]
+        _lib.mb_step_body_ball.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.POINTER(MBBall), C.c_double, C.c_int]
         _lib.mb_gjk_epa_hull_box.argtypes = [dp, C.c_int, dp, dp, dp, dp, dp]
         _lib.mb_gjk_epa_hull_box.restype = C.c_int
         _lib.mb_opensimplex_perm.argtypes = [C.c_int64, C.POINTER(C.c_int16)]
@@ -244,6 +252,10 @@ class Arm:
     def step_simulation_push(self, cube, scene, dt=1.0 / 240.0, iters=150):
         """stepSimulation with a free cube on the table pushed by the tip's collision core."""
         self.L.mb_step_push(C.byref(self.model), C.byref(self.state), C.byref(cube), C.byref(scene), dt, iters)
+
+    def step_simulation_body_ball(self, plate, p2p, ball, dt=1.0 / 240.0, iters=150):
+        """stepSimulation with the round plate tied to the arm and the ball on it (object_balance, ball_on_plate)."""
+        self.L.mb_step_body_ball(C.byref(self.model), C.byref(self.state), C.byref(plate), C.byref(p2p), C.byref(ball), dt, iters)
 
     def step_simulation_body(self, body, p2p, dt=1.0 / 240.0, iters=150):
         """stepSimulation with a free rigid body tied to the arm by a point-to-point constraint."""

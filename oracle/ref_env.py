@@ -742,8 +742,9 @@ class OracleSurfaceFollowVertEnv(OracleSurfaceFollowAutoEnv):
 
 
 class OracleObjectBalanceEnv(_OracleArmEnv):
-    """object_balance-v0, object_mode "pole" (nonprehensile_manipulation/object_balance/object_balance_env.py +
-    base_object_env.py): UR5 + TacTip pointing up, a pole tied to the TCP by a point-to-point constraint."""
+    """object_balance-v0 (nonprehensile_manipulation/object_balance/object_balance_env.py + base_object_env.py): UR5 + TacTip pointing up;
+    object_mode "pole": a pole tied to the TCP by a point-to-point constraint; "ball_on_plate": the round plate tied the same way and a ball
+    rolling on it (:105-106, 187-199, 245-260; mb_step_body_ball, PARITY A39)."""
 
     ACTION_REPEAT = 12                   # floor((1/20)/(1/240)), object_balance_env.py:33-35
 
@@ -751,7 +752,8 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
         modes = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=True, rand_embed_dist=True,
                      observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
         modes.update(env_modes or {})
-        assert modes["object_mode"] == "pole" and modes["movement_mode"] in ("xy", "xyz", "RxRy", "xyRxRy")
+        assert modes["object_mode"] in ("pole", "ball_on_plate") and modes["movement_mode"] in ("xy", "xyz", "RxRy", "xyRxRy")
+        self.ball_mode = modes["object_mode"] == "ball_on_plate"
         rest = [0.19826, -2.01062, -1.96602, -0.73808, 4.71286, -3.34064]                  # object_balance/rest_poses.py:4-20
         self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # :46-48
         self.termination_dist_deg, self.termination_dist_pos = 35, 0.1                     # :50-51
@@ -763,9 +765,9 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
         if self.position_control:
             v, w = 0.001, 1 * (math.pi / 180)                                              # :129-140
         self.act_lo, self.act_hi = np.array([-v, -v, -v, -w, -w, 0.0]), np.array([v, v, v, w, w, 0.0])
-        self.obj_base_width, self.obj_base_height = 0.1, 0.0025                            # :158-159
+        self.obj_base_width, self.obj_base_height = (0.2 if self.ball_mode else 0.1), 0.0025   # :158-159, :188-189
         suffix = "" if inertia == "collision_aabb" else "_urdfinertia"
-        z = np.load(os.path.join(_ASSETS, "objects", f"pole{suffix}.npz"))
+        z = np.load(os.path.join(_ASSETS, "objects", f"{'round_plate' if self.ball_mode else 'pole'}{suffix}.npz"))
         self.obj_verts, self.obj_tris = z["verts"], z["tris"]
         self.init_obj_rpy = np.array([0.0, 0.0, -math.pi / 2])                             # :190
         self.init_obj_rot = pm.mat_from_quat(pm.quat_from_euler(self.init_obj_rpy))
@@ -787,6 +789,24 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
             c.pivot_a[k] = float(fpos[k])                                                   # parentFramePosition [0,0,0] in the TCP link's inertial frame
         self.p2p = c
         self._update_constraint()
+        self.ball = None
+        if self.ball_mode:                                                                  # load_ball :245-260
+            zb = np.load(os.path.join(_ASSETS, "objects", "balance_ball.npz"))
+            bl = mb.MBBall()
+            bl.radius, bl.mass = float(zb["radius"]) * 7.5, float(zb["mass"])               # globalScaling = 7.5 scales the shape, not the mass [A30]
+            bl.inertia = 0.4 * bl.mass * bl.radius * bl.radius
+            bl.mu = 10.0 * 0.5                                                              # changeDynamics(lateralFriction=10) x the plate's default 0.5 [A26, A39]
+            bl.plate_radius, bl.plate_half_len = float(zb["plate_radius"]), 0.5 * float(zb["plate_length"])
+            bl.breaking, bl.erp = 1e-4, 0.2
+            self.ball = bl
+            self.init_ball_pos = np.array([self.workframe_pos[0], self.workframe_pos[1], self.workframe_pos[2] + bl.radius])
+            self._teleport_ball()
+
+    def _teleport_ball(self):                                                               # reset_ball :327-328
+        for k in range(3):
+            self.ball.pos[k] = float(self.init_ball_pos[k])
+            self.ball.linvel[k] = 0.0
+            self.ball.angvel[k] = 0.0
 
     def _set_init_obj_pos(self, buffer_height):
         self.init_obj_pos = np.array([self.workframe_pos[0], self.workframe_pos[1],
@@ -806,7 +826,10 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
             self.body.rot[k] = float(np.asarray(rot).reshape(9)[k])
 
     def _step_simulation(self):
-        self.arm.step_simulation_body(self.body, self.p2p, self.SIM_DT, self.SOLVER_ITERS)
+        if self.ball is not None:
+            self.arm.step_simulation_body_ball(self.body, self.p2p, self.ball, self.SIM_DT, self.SOLVER_ITERS)
+        else:
+            self.arm.step_simulation_body(self.body, self.p2p, self.SIM_DT, self.SOLVER_ITERS)
 
     def task_spheres(self):                                                                 # visualise_goal = False (object_balance_env.py:70)
         return []
@@ -826,6 +849,15 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
             self._update_constraint()
         self._reset_robot(np.zeros(3), np.zeros(3))                                         # update_init_pose, base_object_env.py:96-103
         self._teleport_body(self.init_obj_pos, self.init_obj_rot)                           # reset_object :330-345
+        if self.ball is not None:                                                           # :350-352: reset_ball, apply_random_torque_ball(0.001)
+            self._teleport_ball()
+            u1 = self.rng.uniform(-1.0, 1.0)
+            u2 = self.rng.uniform(-1.0, 1.0)
+            for k in range(3):
+                self.ball.ext_torque[k] = [u1 * 0.001, u2 * 0.001, 0.0][k]                  # LINK_FRAME of a ball just reset to identity = world
+            self.ball.ext_pending = 1
+            self._get_step_data()
+            return self._observation()
         sx = -1.0 if self.rng.random() < 0.5 else 1.0                                       # apply_random_force_base :360-381
         rx = self.rng.random()
         sy = -1.0 if self.rng.random() < 0.5 else 1.0

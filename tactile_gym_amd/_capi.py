@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +28,7 @@ PHYSICS = {"f64": 0, "f32": 1}
 CONTACT_MAP = {"auto": 0, "lane": 1, "wave": 2}
 RESET_BANK = {"auto": 0, "off": 1, "sync": 2, "on": 3}
 NARROWPHASE = {"closed_form": 0, "gjk_manifold": 1, "gjk_single": 2}
+BALANCE_OBJECT = {"pole": 0, "ball_on_plate": 1}
 MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
 
 _d3 = C.c_double * 3
@@ -102,6 +103,7 @@ class TgConfig(C.Structure):
         ("roll_radius", C.c_double), ("roll_init_range", C.c_double), ("roll_goal_lo", C.c_double), ("roll_goal_hi", C.c_double),
         ("tip_cyl_pos", _d3), ("tip_cyl_rot", _d9), ("tip_cyl_half_len", C.c_double), ("tip_cyl_radius", C.c_double),
         ("contact_mapping", C.c_int32), ("reset_bank", C.c_int32), ("narrowphase", C.c_int32),
+        ("balance_object", C.c_int32), ("ball_radius", C.c_double), ("ball_mass", C.c_double), ("ball_mu", C.c_double), ("plate_radius", C.c_double),
     ]
 
 
@@ -117,6 +119,8 @@ class TgStateView(C.Structure):
         ("body_angvel", C.POINTER(C.c_double)), ("gravity_z", C.POINTER(C.c_double)),
         ("traj", C.POINTER(C.c_double)), ("goal_id", C.POINTER(C.c_int32)), ("obj_mass", C.POINTER(C.c_double)),
         ("contact_count", C.POINTER(C.c_int32)), ("contact_ids", C.POINTER(C.c_int32)),
+        ("ball_pos", C.POINTER(C.c_double)), ("ball_linvel", C.POINTER(C.c_double)), ("ball_angvel", C.POINTER(C.c_double)),
+        ("ball_impulse", C.POINTER(C.c_double)),
     ]
 
 

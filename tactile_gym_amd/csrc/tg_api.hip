@@ -229,6 +229,16 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.body.erp = (T)cfg.p2p_erp; c.body.max_impulse = (T)cfg.p2p_max_impulse;
         c.body.link = rob.tcp_link;   // createConstraint parent = TCP link, parentFramePosition 0 in its inertial frame (:271-283)
         c.body.pivot_a = {(T)rob.tcp_pos[0], (T)rob.tcp_pos[1], (T)rob.tcp_pos[2]};
+        if (cfg.balance_object != TG_BALANCE_POLE && cfg.balance_object != TG_BALANCE_BALL_ON_PLATE) return fail(-1, "object_balance: unknown balance_object");
+        if (cfg.balance_object == TG_BALANCE_BALL_ON_PLATE) {
+            if (!(cfg.ball_radius > 0 && cfg.ball_mass > 0 && cfg.ball_mu >= 0 && cfg.plate_radius > 0 && cfg.contact_erp > 0))
+                return fail(-1, "object_balance ball_on_plate: ball_radius, ball_mass, plate_radius, contact_erp must be positive");
+            c.ball.radius = (T)cfg.ball_radius; c.ball.mass = (T)cfg.ball_mass;
+            c.ball.inertia = (T)(0.4 * cfg.ball_mass * cfg.ball_radius * cfg.ball_radius);
+            c.ball.mu = (T)cfg.ball_mu; c.ball.plate_radius = (T)cfg.plate_radius; c.ball.plate_half_len = (T)(0.5 * cfg.obj_base_height);
+            c.ball.breaking = (T)cfg.contact_breaking; c.ball.erp = (T)cfg.contact_erp;
+            c.ball.lin_damp = (T)cfg.obj_lin_damp; c.ball.ang_damp = (T)cfg.obj_ang_damp;
+        }
         double oq[4], oR[9];
         h_quat_from_euler(cfg.obj_init_rpy, oq);
         h_mat_from_quat(oq, oR);
@@ -518,6 +528,15 @@ template <typename T, int TOPO> static void launch_refresh_rpy_t(tg_ctx* c) {
 
 template <typename T> static void launch_step_body_t(tg_ctx* c, const float* d_actions) {
     const int n = c->cfg.num_envs;
+    if (c->cfg.balance_object == TG_BALANCE_BALL_ON_PLATE) {
+        if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION)
+            hipLaunchKernelGGL((k_step_body<T, 0, true, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                               (const EnvConst<T>*)c->d_const, c->st, d_actions);
+        else
+            hipLaunchKernelGGL((k_step_body<T, 0, false, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                               (const EnvConst<T>*)c->d_const, c->st, d_actions);
+        return;
+    }
     if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION)
         hipLaunchKernelGGL((k_step_body<T, 0, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
                            (const EnvConst<T>*)c->d_const, c->st, d_actions);
@@ -527,6 +546,11 @@ template <typename T> static void launch_step_body_t(tg_ctx* c, const float* d_a
 }
 template <typename T> static void launch_reset_body_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;
+    if (c->cfg.balance_object == TG_BALANCE_BALL_ON_PLATE) {
+        hipLaunchKernelGGL((k_reset_body<T, 0, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                           (const EnvConst<T>*)c->d_const, c->st, d_mask);
+        return;
+    }
     hipLaunchKernelGGL((k_reset_body<T, 0>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
                        (const EnvConst<T>*)c->d_const, c->st, d_mask);
 }
@@ -706,6 +730,7 @@ static void scene_draw(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
 static bool use_contact_wave(const tg_ctx* c) {
     if (c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL && c->cfg.env_kind != TG_ENV_OBJECT_BALANCE) return false;
     if (c->cfg.physics_dtype != TG_PHYSICS_F64) return false;
+    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE && c->cfg.balance_object == TG_BALANCE_BALL_ON_PLATE) return false;   // lane mapping only (tg_create refuses WAVE)
     if (c->cfg.contact_mapping == TG_CONTACT_MAP_LANE) return false;
     if (c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE || c->cfg.narrowphase != TG_NARROW_CLOSED_FORM) return true;
     return c->cfg.num_envs < 4096;
@@ -852,6 +877,10 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     if (!sensor->nodef_dep || !sensor->nodef_gray || !sensor->border_mask) return fail(-1, "tg_create: sensor reference images missing");
     if (cfg->physics_dtype != TG_PHYSICS_F64 && cfg->physics_dtype != TG_PHYSICS_F32) return fail(-1, "tg_create: bad physics_dtype");
     if (cfg->narrowphase < 0 || cfg->narrowphase > TG_NARROW_GJK_SINGLE) return fail(-1, "tg_create: bad narrowphase");
+    if (cfg->env_kind == TG_ENV_OBJECT_BALANCE && cfg->balance_object == TG_BALANCE_BALL_ON_PLATE) {
+        if (cfg->contact_mapping == TG_CONTACT_MAP_WAVE) return fail(-1, "tg_create: object_balance ball_on_plate runs on the lane mapping (contact_mapping auto or lane)");
+        if (!cfg->cone_friction) return fail(-1, "tg_create: object_balance ball_on_plate is built with cone friction (enableConeFriction = 1)");
+    }
     if (cfg->narrowphase != TG_NARROW_CLOSED_FORM) {
         if (cfg->env_kind != TG_ENV_OBJECT_PUSH) return fail(-1, "tg_create: narrowphase GJK / EPA is built for object_push (the tip core - cube pair)");
         if (cfg->physics_dtype != TG_PHYSICS_F64 || !cfg->cone_friction || cfg->contact_mapping == TG_CONTACT_MAP_LANE)
@@ -942,6 +971,15 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         TG_HIP(hipMalloc(&s.ext_pending, n));
         TG_HIP(hipMemset(s.body_v, 0, 3 * n * 8)); TG_HIP(hipMemset(s.body_w, 0, 3 * n * 8)); TG_HIP(hipMemset(s.ext_pos, 0, 3 * n * 8));
         TG_HIP(hipMemset(s.ext_pending, 0, n));
+        if (cfg->balance_object == TG_BALANCE_BALL_ON_PLATE) {   // load_ball (:241-260): at workframe + (0, 0, radius), at rest
+            TG_HIP(hipMalloc(&s.ball, (size_t)13 * n * 8));
+            std::vector<double> bl((size_t)13 * n, 0.0);
+            for (int i = 0; i < n; ++i) {
+                bl[(size_t)0 * n + i] = cfg->workframe_pos[0]; bl[(size_t)1 * n + i] = cfg->workframe_pos[1];
+                bl[(size_t)2 * n + i] = cfg->workframe_pos[2] + cfg->ball_radius;
+            }
+            TG_HIP(hipMemcpy(s.ball, bl.data(), bl.size() * 8, hipMemcpyHostToDevice));
+        }
         // load_object (base_object_env.py:66-70): loadURDF puts the object's *link* frame at init_obj_pos; the inertial frame used by
         // get/resetBasePositionAndOrientation is obj_root_inertial_pos away.  setup_object (:185-190): default embed distance.
         double oq[4], oR[9];
@@ -1161,7 +1199,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->d_draw) (void)hipFree(c->d_draw);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -1772,6 +1810,12 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
         if (v->body_linvel && (rc = fetch_soa(c, c->st.body_v, 3, v->body_linvel))) return rc;
         if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
         if (v->gravity_z && (rc = fetch_soa(c, c->st.gravity, 1, v->gravity_z))) return rc;
+        if (c->st.ball) {
+            if (v->ball_pos && (rc = fetch_soa(c, c->st.ball, 3, v->ball_pos))) return rc;
+            if (v->ball_linvel && (rc = fetch_soa(c, c->st.ball + (size_t)3 * c->cfg.num_envs, 3, v->ball_linvel))) return rc;
+            if (v->ball_angvel && (rc = fetch_soa(c, c->st.ball + (size_t)6 * c->cfg.num_envs, 3, v->ball_angvel))) return rc;
+            if (v->ball_impulse && (rc = fetch_soa(c, c->st.ball + (size_t)12 * c->cfg.num_envs, 1, v->ball_impulse))) return rc;
+        }
     }
     if (c->cfg.env_kind == TG_ENV_OBJECT_ROLL) {
         if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;

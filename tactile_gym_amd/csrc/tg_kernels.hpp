@@ -34,6 +34,7 @@ template <typename T> struct EnvConst {
     double xbin_lo, xbin_hi, ybin_lo, ybin_hi;   // np.linspace bounds of x_bins / y_bins (base_surface_env.py:258-282)
     // object_balance
     BodyConst<T> body;
+    BallConst<T> ball;           // object_balance, object_mode ball_on_plate
     M3<T> obj_init_rot;
     T obj_init_rpy_deg[3], obj_base_width, obj_base_height, term_deg, term_pos, ext_force[3];
     int rand_gravity, rand_embed;
@@ -68,6 +69,7 @@ struct State {   // device pointers, SoA [field][num_envs]
     // object_balance
     double *body_pos, *body_rot, *body_v, *body_w, *ext_pos, *gravity;   // [3][n], [9][n], [3][n], [3][n], [3][n], [n]
     uint8_t* ext_pending;           // [n]
+    double* ball;                   // [13][n] ball_on_plate: position, linear velocity, angular velocity, one-shot torque, last normal impulse
     // object_push
     double *traj, *obj_mass;        // [3][TG_MAX_TRAJ_POINTS][n] work-frame x, y, yaw; [n]
     int32_t* goal_id;               // [n]
@@ -1100,6 +1102,19 @@ template <typename T> __device__ __forceinline__ void store_body(const State& st
     st.body_v[0 * n + env] = (double)b.v.x; st.body_v[1 * n + env] = (double)b.v.y; st.body_v[2 * n + env] = (double)b.v.z;
     st.body_w[0 * n + env] = (double)b.w.x; st.body_w[1 * n + env] = (double)b.w.y; st.body_w[2 * n + env] = (double)b.w.z;
 }
+template <typename T> __device__ __forceinline__ Ball<T> load_ball(const State& st, int n, int env) {
+    Ball<T> k;
+    k.pos = mk((T)st.ball[0 * n + env], (T)st.ball[1 * n + env], (T)st.ball[2 * n + env]);
+    k.v = mk((T)st.ball[3 * n + env], (T)st.ball[4 * n + env], (T)st.ball[5 * n + env]);
+    k.w = mk((T)st.ball[6 * n + env], (T)st.ball[7 * n + env], (T)st.ball[8 * n + env]);
+    return k;
+}
+template <typename T> __device__ __forceinline__ void store_ball(const State& st, int n, int env, const Ball<T>& k, T impulse) {
+    st.ball[0 * n + env] = (double)k.pos.x; st.ball[1 * n + env] = (double)k.pos.y; st.ball[2 * n + env] = (double)k.pos.z;
+    st.ball[3 * n + env] = (double)k.v.x; st.ball[4 * n + env] = (double)k.v.y; st.ball[5 * n + env] = (double)k.v.z;
+    st.ball[6 * n + env] = (double)k.w.x; st.ball[7 * n + env] = (double)k.w.y; st.ball[8 * n + env] = (double)k.w.z;
+    st.ball[12 * n + env] = (double)impulse;
+}
 template <typename T> __device__ __forceinline__ T wrap_deg(T d) {   // ((d + 180) % 360) - 180 with numpy's sign-of-divisor modulo
     const T x = d + T(180);
     return (x - T(360) * floor(x / T(360))) - T(180);
@@ -1155,7 +1170,7 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
     }
 }
 
-template <typename T, int TOPO, bool POS>
+template <typename T, int TOPO, bool POS, bool BALL = false>
 __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
     constexpr int N = Topo<TOPO>::N;
@@ -1199,7 +1214,24 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
     int verified = 0;
-    if constexpr (POS) {                                  // blocking_move(max_steps, constant_vel=None), robot.py:188-260
+    if constexpr (BALL) {                                 // ball_on_plate: the plate + ball tick (no plate force; the pending one-shot is the ball's torque)
+        Ball<T> ball = load_ball<T>(st, n, env);
+        const V3<T> btq = mk((T)st.ball[9 * n + env], (T)st.ball[10 * n + env], (T)st.ball[11 * n + env]);
+        T imp = T(0);
+        if constexpr (POS) {
+            for (int t = 0; t < c.max_blocking; ++t) {
+                const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
+                sim_tick_body_ball<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, grav,
+                                                            b, c.body, pivot_b, ball, c.ball, btq, pending && t == 0, imp);
+                if (stop) break;
+            }
+        } else {
+            for (int t = 0; t < c.action_repeat; ++t)
+                sim_tick_body_ball<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b,
+                                                            c.body, pivot_b, ball, c.ball, btq, pending && t == 0, imp);
+        }
+        store_ball<T>(st, n, env, ball, imp);
+    } else if constexpr (POS) {                           // blocking_move(max_steps, constant_vel=None), robot.py:188-260
         for (int t = 0; t < c.max_blocking; ++t) {
             const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
             sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b,
@@ -1222,7 +1254,7 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
 
 // BaseObjectEnv.reset (base_object_env.py:146-173) for object_balance: reset_task (gravity, embed), Robot.reset with the pole
 // still tied to the TCP, reset_object (teleport + one-shot random force).
-template <typename T, int TOPO>
+template <typename T, int TOPO, bool BALL = false>
 __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
     constexpr int N = Topo<TOPO>::N;
@@ -1261,6 +1293,9 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
     for (int i = 0; i < N; ++i) zero[i] = T(0);
     const V3<T> z3 = mk<T>(0, 0, 0);
     int used = 0, verified = 0;
+    Ball<T> ball;                                         // ball_on_plate: the ball lies where the last episode left it while the arm moves back
+    T imp = T(0);
+    if constexpr (BALL) ball = load_ball<T>(st, n, env);
     for (int it = 0; it < 1000; ++it) {
         Kin<T, TOPO> k;
         forward_kinematics<T, TOPO>(m, q, k);
@@ -1280,8 +1315,12 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
 #pragma unroll
         for (int i = 0; i < N; ++i) step_j[i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
         if (all_small) cv = cv / T(2);
-        sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, grav, b, c.body,
-                                               pivot_b, z3, z3, false, &verified);
+        if constexpr (BALL)
+            sim_tick_body_ball<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, grav, b,
+                                                        c.body, pivot_b, ball, c.ball, z3, false, imp);
+        else
+            sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, step_j, zero, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, grav, b, c.body,
+                                                   pivot_b, z3, z3, false, &verified);
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
@@ -1295,6 +1334,21 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
     b.pos = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - (T)embed);
     b.R = c.obj_init_rot;
     b.v = z3; b.w = z3;
+    if constexpr (BALL) {   // reset_ball + apply_random_torque_ball(0.001) (:325-326, 350-353, 393-401); LINK_FRAME of a ball just reset = world
+        ball.pos = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + c.ball.radius);
+        ball.v = z3; ball.w = z3;
+        const double u1 = rng_uniform(rs, -1.0, 1.0);
+        const double u2 = rng_uniform(rs, -1.0, 1.0);
+        st.rng[env] = rs;
+        st.ball[9 * n + env] = u1 * 0.001; st.ball[10 * n + env] = u2 * 0.001; st.ball[11 * n + env] = 0.0;
+        st.ext_pending[env] = 1;
+        store_ball<T>(st, n, env, ball, T(0));
+#pragma unroll
+        for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+        store_body<T>(st, n, env, b);
+        finish_body<T, TOPO>(m, c, st, env, q, b, (T)embed, 0, false);
+        return;
+    }
     const double sx = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
     const double rx = rng_uniform(rs, 0.0, 1.0);
     const double sy = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;

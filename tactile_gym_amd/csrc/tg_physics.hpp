@@ -1014,6 +1014,272 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
     b.pos = xc - mul(b.R, bc.com);
 }
 
+// ------------------------------------------------------------------------------------------------ arm + plate + P2P + ball
+// object_balance, object_mode "ball_on_plate" (object_balance_env.py:187-199, 241-260): the free body is the round plate, tied to the TCP as
+// the pole is, and a ball (sphere.urdf, lateralFriction 10) rolls on it.  Restated contact model, identical to oracle/minibullet.c:
+// mb_step_body_ball [PARITY_ASSUMPTIONS A39]: closest point of the plate's solid cylinder to the ball's centre, one contact while the gap is
+// within the breaking distance; rows = motors and P2P (reverse order on even sweeps), then the normal (lambda >= 0), then the two friction
+// rows together under the cone |lambda_t| <= mu lambda_n.  Same Delassus / residual form as sim_tick_body; the blocks that are structurally
+// zero (motor rows x contact rows) are left out.  Always the full solve: the analytic fixed point of sim_tick_body has no contact rows.
+template <typename T> __device__ __forceinline__ void plane_space(V3<T> n, V3<T>& t1, V3<T>& t2);   // btPlaneSpace1, below
+template <typename T> struct Ball { V3<T> pos, v, w; };
+template <typename T> struct BallConst { T radius, mass, inertia, mu, plate_radius, plate_half_len, breaking, erp, lin_damp, ang_damp; };
+
+template <typename T, int TOPO, int MOTOR>
+__device__ __forceinline__ void sim_tick_body_ball(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
+                                                   const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
+                                                   int iters, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b, Ball<T>& ball,
+                                                   const BallConst<T>& kc, V3<T> ball_torque, bool torque_pending, T& normal_impulse) {
+    constexpr int N = Topo<TOPO>::N;
+    constexpr int NP = N + 3;     // motor and P2P rows
+    T hb[N], qdm[N], Minv[N][N], traceM;
+    Kin<T, TOPO> kin;
+    dynamics_terms<T, TOPO, false>(m, q, qd, hb, qdm, Minv, traceM, gravity, kin);
+    T v[N];
+    {
+        T rhs[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) rhs[i] = qdm[i] - m.joint_damp * qd[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += Minv[i][j] * rhs[j];
+            v[i] = qd[i] + dt * acc;
+        }
+    }
+    // plate: gravity and the gyroscopic torque; no velocity damping (reset_object :338-345), no external force in this mode
+    const S3<T> Iw = rotate(b.R, bc.inertia), Iwi = inverse(Iw);
+    V3<T> xc = b.pos + mul(b.R, bc.com);
+    const V3<T> vb = b.v + dt * gravity, wb = b.w + dt * mul(Iwi, mk<T>(0, 0, 0) - cross(b.w, mul(Iw, b.w)));
+    // ball: gravity, Bullet's default damping F = -m v (K + K |v|) [A27], the one-shot torque of apply_random_torque_ball (:393-401)
+    const T sv = kc.lin_damp + kc.lin_damp * norm(ball.v), sw = kc.ang_damp + kc.ang_damp * norm(ball.w);
+    const V3<T> tq = torque_pending ? ball_torque : mk<T>(0, 0, 0);
+    const V3<T> vk = ball.v + dt * (gravity - sv * ball.v), wk = ball.w + dt * ((T(1) / kc.inertia) * tq - sw * ball.w);
+    // P2P geometry
+    V3<T> pa; M3<T> Rl;
+    {
+        const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+        const T pav[3] = {bc.pivot_a.x, bc.pivot_a.y, bc.pivot_a.z};
+        link_frame<T, TOPO>(kin, bc.link, pav, ident, pa, Rl);
+    }
+    const V3<T> pb = b.pos + mul(b.R, pivot_b);
+    const V3<T> rb = pb - xc;
+    T Jt[3][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        bool on_path = false;
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+            if (l == bc.link && is_ancestor_or_self<TOPO>(i, l)) on_path = true;
+        const V3<T> jt = cross(kin.a[i], pa - kin.o[i]);
+        Jt[0][i] = on_path ? jt.x : T(0); Jt[1][i] = on_path ? jt.y : T(0); Jt[2][i] = on_path ? jt.z : T(0);
+    }
+    T Wa[N][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += Minv[i][j] * Jt[x][j];
+            Wa[i][x] = acc;
+        }
+    const V3<T> e[3] = {mk<T>(1, 0, 0), mk<T>(0, 1, 0), mk<T>(0, 0, 1)};
+    V3<T> rxe[3], Wang[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { rxe[x] = cross(rb, e[x]); Wang[x] = mul(Iwi, rxe[x]); }
+    const T im = T(1) / bc.mass;
+    // contact: closest point of the plate's solid cylinder (plate frame: axis z, centred on the base frame) to the ball's centre
+    bool touching = false;
+    V3<T> d[3] = {mk<T>(0, 0, 1), mk<T>(1, 0, 0), mk<T>(0, 1, 0)}, rba = mk<T>(0, 0, 0), rpb = mk<T>(0, 0, 0);
+    T depth = T(1e30);
+    {
+        const V3<T> dw = ball.pos - b.pos;
+        const V3<T> p = mk(b.R.m[0] * dw.x + b.R.m[3] * dw.y + b.R.m[6] * dw.z, b.R.m[1] * dw.x + b.R.m[4] * dw.y + b.R.m[7] * dw.z,
+                           b.R.m[2] * dw.x + b.R.m[5] * dw.y + b.R.m[8] * dw.z);
+        const T rad = tsqrt(p.x * p.x + p.y * p.y);
+        const T sr = rad > kc.plate_radius ? kc.plate_radius / rad : T(1);
+        const V3<T> cl = mk(p.x * sr, p.y * sr, p.z > kc.plate_half_len ? kc.plate_half_len : (p.z < -kc.plate_half_len ? -kc.plate_half_len : p.z));
+        const V3<T> g = p - cl;
+        const T dist = tsqrt(dot(g, g));
+        depth = dist - kc.radius;
+        if (dist > T(0) && depth <= kc.breaking) {
+            touching = true;
+            const V3<T> gn = mk(g.x / dist, g.y / dist, g.z / dist);
+            const V3<T> nw = mul(b.R, gn);                         // from the plate towards the ball
+            d[0] = nw;
+            plane_space(nw, d[1], d[2]);
+            rba = mk<T>(0, 0, 0) - kc.radius * nw;                 // body A = the ball (+d)
+            rpb = (b.pos + mul(b.R, cl)) - xc;                     // body B = the plate (-d)
+        }
+    }
+    V3<T> cxa[3], cxb[3], Wcb[3];                                  // (rba x d), (rpb x d), Iw^-1 (rpb x d)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { cxa[r] = cross(rba, d[r]); cxb[r] = cross(rpb, d[r]); Wcb[r] = mul(Iwi, cxb[r]); }
+    // Delassus blocks: App (motor + P2P rows, as sim_tick_body), Apc (P2P x contact), Acc (contact x contact)
+    T A[NP][NP];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[i][j] = Minv[i][j];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { A[i][N + x] = Wa[i][x]; A[N + x][i] = Wa[i][x]; }
+    }
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+            T acc = (x == y) ? im : T(0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc += Jt[x][i] * Wa[i][y];
+            A[N + x][N + y] = acc + dot(rxe[x], Wang[y]);
+        }
+    T Apc[3][3], Acc[3][3];
+    const T imk = T(1) / kc.mass, iik = T(1) / kc.inertia;
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Apc[x][r] = im * dot(e[x], d[r]) + dot(rxe[x], Wcb[r]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) Acc[r][s] = (im + imk) * dot(d[r], d[s]) + dot(cxb[r], Wcb[s]) + iik * dot(cxa[r], cxa[s]);
+    // right-hand sides and limits
+    T r[NP], lim[NP], lam[NP], rc[3], lc[3] = {T(0), T(0), T(0)};
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const T pos_term = (MOTOR == kMotorPosition) ? kp * (q_des[i] - q[i]) / dt : T(0);
+        const T des = pos_term + v[i] + kd * (qd_des[i] - v[i]);
+        r[i] = (MOTOR != kMotorOff) ? des - v[i] : T(0);
+        lim[i] = (MOTOR != kMotorOff) ? max_force * dt : T(0);
+    }
+    {
+        V3<T> va = mk<T>(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) va = va + v[i] * mk(Jt[0][i], Jt[1][i], Jt[2][i]);
+        const V3<T> cv = va - (vb + cross(wb, rb)), gap = pa - pb;
+        const T cvv[3] = {cv.x, cv.y, cv.z}, gp[3] = {gap.x, gap.y, gap.z};
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { r[N + x] = (-bc.erp * gp[x] / dt) - cvv[x]; lim[N + x] = bc.max_impulse; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T rv = (dot(d[k], vk) + dot(cxa[k], wk)) - (dot(d[k], vb) + dot(cxb[k], wb));
+        rc[k] = (k == 0) ? (depth > T(0) ? (-rv - depth / dt) : (-depth * kc.erp / dt - rv)) : -rv;     // restitution 0
+    }
+    T G[NP][NP], Gpc[3][3], Gcp[3][3], Gcc[3][3];     // G[j][i] = A[j][i] / A[j][j]
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const T jdi = T(1) / A[j][j];
+        r[j] = r[j] * jdi;
+        lam[j] = T(0);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) G[j][i] = A[j][i] * jdi;
+    }
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        const T jdi = T(1) / A[N + x][N + x];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Gpc[x][k] = Apc[x][k] * jdi;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T jdi = touching ? T(1) / Acc[k][k] : T(0);
+        rc[k] = rc[k] * jdi;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) Gcp[k][x] = Apc[x][k] * jdi;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) Gcc[k][s] = Acc[k][s] * jdi;
+    }
+    T thr = T(0);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) thr = tmax(thr, tabs(r[j]));
+    if (touching) thr = tmax(thr, tmax(tabs(rc[0]), tmax(tabs(rc[1]), tabs(rc[2]))));
+    thr = iters < 0 ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
+    const int n_it = iters < 0 ? -iters : iters;
+    for (int it = 0; it < n_it; ++it) {
+        if ((it & 7) == 0 && it > 0) {
+            T mx = T(0);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mx = tmax(mx, tabs(r[j]));
+            if (touching) mx = tmax(mx, tmax(tabs(rc[0]), tmax(tabs(rc[1]), tabs(rc[2]))));
+            if (__all(mx <= thr)) break;
+        }
+        auto row = [&](const int i) {      // i is a compile-time constant after unrolling
+            const T t = r[i];
+            const T sum = lam[i] + t;
+            const T lo = sum < -lim[i] ? -lim[i] : sum;
+            const T sc = lo > lim[i] ? lim[i] : lo;
+            const T delta = (sc == sum) ? t : sc - lam[i];
+            lam[i] = sc;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) r[j] -= G[j][i] * delta;
+            if (i >= N) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rc[k] -= Gcp[k][i >= N ? i - N : 0] * delta;
+            }
+        };
+        if (it & 1) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) row(i);
+        } else {
+#pragma unroll
+            for (int i = NP - 1; i >= 0; --i) row(i);
+        }
+        if (touching) {
+            {   // normal
+                const T t = rc[0], sum = lc[0] + t;
+                const T sc = sum < T(0) ? T(0) : sum;
+                const T delta = (sc == sum) ? t : sc - lc[0];
+                lc[0] = sc;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) r[N + x] -= Gpc[x][0] * delta;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rc[k] -= Gcc[k][0] * delta;
+            }
+            {   // friction pair, cone (enableConeFriction = 1, base_tactile_env.py:128-130)
+                const T limit = kc.mu * lc[0];
+                T s1 = lc[1] + rc[1], s2 = lc[2] + rc[2];
+                const T tot = tsqrt(s1 * s1 + s2 * s2);
+                if (tot > limit) { const T f = tot > T(0) ? limit / tot : T(0); s1 *= f; s2 *= f; }
+                const T d1 = s1 - lc[1], d2 = s2 - lc[2];
+                lc[1] = s1; lc[2] = s2;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) r[N + x] -= Gpc[x][1] * d1 + Gpc[x][2] * d2;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rc[k] -= Gcc[k][1] * d1 + Gcc[k][2] * d2;
+            }
+        }
+    }
+    normal_impulse = touching ? lc[0] : T(0);
+    // apply impulses
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc += Minv[i][j] * lam[j];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) acc += Wa[i][x] * lam[N + x];
+        qd[i] = v[i] + acc;
+        q[i] += dt * qd[i];
+    }
+    const V3<T> lp = mk(lam[N], lam[N + 1], lam[N + 2]);
+    V3<T> jl = mk<T>(0, 0, 0), jab = mk<T>(0, 0, 0), jaa = mk<T>(0, 0, 0);     // sum of d lambda, of (rpb x d) lambda, of (rba x d) lambda
+    if (touching) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { jl = jl + lc[k] * d[k]; jab = jab + lc[k] * cxb[k]; jaa = jaa + lc[k] * cxa[k]; }
+    }
+    b.v = vb - im * (lp + jl);
+    b.w = wb - mul(Iwi, cross(rb, lp) + jab);
+    xc = xc + dt * b.v;
+    integrate_rotation(b.R, b.w, dt);
+    b.pos = xc - mul(b.R, bc.com);
+    ball.v = vk + imk * jl;
+    ball.w = wk + iik * jaa;
+    ball.pos = ball.pos + dt * ball.v;
+}
+
 // ------------------------------------------------------------------------------------------------ arm + cube + contacts
 // object_push: a free cube on the table, pushed by the collision core of the sensor tip (object_push_env.py:196-227 with the
 // tip core enabled, tactile_sensor.py:58-67).  Restated contact model [PARITY_ASSUMPTIONS A23-A28], identical to

@@ -1,8 +1,9 @@
-"""object_balance-v0 (object_mode "pole") on the HIP path.
+"""object_balance-v0 (object_mode "pole" and "ball_on_plate") on the HIP path.
 
 Reference: tactile_gym/rl_envs/nonprehensile_manipulation/object_balance/object_balance_env.py on top of
 base_object_env.py: a UR5 + TacTip pointing up carries a pole tied to its TCP by a point-to-point constraint; the agent
-moves the TCP to keep the pole upright.  `ball_on_plate` / `spinning_plate` need rigid contacts and are not built.
+moves the TCP to keep the pole upright.  "ball_on_plate" (:187-199, 241-260): the round plate instead of the pole and a ball
+rolling on it (one ball - plate contact, sim_tick_body_ball).  "spinning_plate" (:200-213) is not built.
 """
 import math
 import os
@@ -33,10 +34,11 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         if k not in modes:
             raise KeyError(k)                                                                   # object_balance_env.py:37-44
     arm, t_s_name, t_s_type = modes["arm_type"], modes["tactile_sensor_name"], "standard"       # :46
-    if modes["object_mode"] != "pole":
-        if modes["object_mode"] in ("ball_on_plate", "spinning_plate"):
-            raise NotImplementedError(f"object_mode {modes['object_mode']} needs rigid contacts, which are not built yet")
+    if modes["object_mode"] not in capi.BALANCE_OBJECT:
+        if modes["object_mode"] == "spinning_plate":
+            raise NotImplementedError("object_mode spinning_plate (a plate spinning on the tip under a constant torque) is not built yet")
         raise ValueError(f"unknown object_mode {modes['object_mode']}")
+    ball_mode = modes["object_mode"] == "ball_on_plate"
     if modes["movement_mode"] not in capi.BMOVE:
         raise ValueError(f"unknown movement_mode {modes['movement_mode']}")
     if modes["control_mode"] not in capi.CONTROL:
@@ -75,7 +77,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.rand_gravity, cfg.rand_embed = int(bool(modes["rand_gravity"])), int(bool(modes["rand_embed_dist"]))
     cfg.gravity_lo, cfg.gravity_hi, cfg.gravity_default = -1.0, -0.1, -0.1                      # :301-306
     suffix = "" if inertia_mode == "collision_aabb" else "_urdfinertia"
-    z = np.load(os.path.join(ASSETS, "objects", f"pole{suffix}.npz"))
+    z = np.load(os.path.join(ASSETS, "objects", f"{'round_plate' if ball_mode else 'pole'}{suffix}.npz"))
     cfg.obj_mass = float(z["mass"])
     for k in range(3):
         cfg.obj_com[k] = float(z["com"][k])
@@ -84,7 +86,16 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
         cfg.ext_force[k] = [0.0, 0.0, -0.1][k]                                                  # :347 force_mag 0.1, direction (0,0,-1) :374-375
     for k in range(9):
         cfg.obj_inertia[k] = float(z["inertia"].reshape(9)[k])
-    cfg.obj_base_width, cfg.obj_base_height = 0.1, 0.0025                                       # :158-159
+    cfg.obj_base_width, cfg.obj_base_height = (0.2 if ball_mode else 0.1), 0.0025               # :158-159, :188-189
+    cfg.balance_object = capi.BALANCE_OBJECT[modes["object_mode"]]
+    if ball_mode:                                                                               # load_ball :241-260
+        zb = np.load(os.path.join(ASSETS, "objects", "balance_ball.npz"))
+        cfg.ball_radius, cfg.ball_mass = float(zb["radius"]) * 7.5, float(zb["mass"])           # globalScaling 7.5 scales the shape, not the mass [A30]
+        cfg.ball_mu = 10.0 * 0.5                                                                # lateralFriction=10 (:259) x the plate's default 0.5 [A26]
+        cfg.plate_radius = float(zb["plate_radius"])
+        cfg.contact_breaking, cfg.contact_erp = 1e-4, 0.2                                       # [A24]
+        cfg.obj_lin_damp, cfg.obj_ang_damp = 0.04, 0.04                                         # Bullet's defaults: the ball's damping is never changed [A27]
+        cfg.cone_friction = 1                                                                   # base_tactile_env.py:128-130
     cfg.term_deg, cfg.term_pos = 35.0, 0.1                                                      # :50-51
     cfg.p2p_erp, cfg.p2p_max_impulse = 0.2, 500.0                                               # PARITY_ASSUMPTIONS A18-A19
     tg = load_tgmodel(arm, t_s_type, t_s_name, inertia_mode)
@@ -98,6 +109,8 @@ class ObjectBalanceVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
                  device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True, contact_mapping="auto"):
         cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
+        if modes["object_mode"] == "ball_on_plate" and contact_mapping == "wave":
+            raise ValueError("object_mode ball_on_plate runs on the lane mapping (contact_mapping 'auto' or 'lane')")
         cfg.contact_mapping = capi.CONTACT_MAP[contact_mapping]   # "wave": one wavefront per env (k_step_body_wave), "lane": one lane per env
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
         self.env_modes = modes

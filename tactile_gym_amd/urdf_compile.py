@@ -647,6 +647,8 @@ def compile_free_body(path, inertia_mode="collision_aabb"):
             elif g.kind == "mesh" and find_mesh_file(urdf_dir, g.mesh):
                 v, t = load_mesh(find_mesh_file(urdf_dir, g.mesh))
                 v = v * np.asarray(g.scale, dtype=np.float64)
+            elif g.kind in ("cylinder", "sphere"):           # primitives: this repo's tessellation (A32); the round plate of object_balance
+                v, t = _primitive_mesh(g)
             else:
                 continue
             Rv, pv = to_root_inertial(Rl @ Rg, Rl @ pg + pl)

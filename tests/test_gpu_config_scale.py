@@ -238,3 +238,39 @@ def test_config4_manifold_narrowphase_1024_envs_match_oracle():
     assert (hip["cc"] >= 6).mean() > 0.02
     print(f"config 4, manifold narrowphase: {n} envs x (reset + {steps} steps): contact ids exact, {100 * (hip['cc'] >= 6).mean():.0f} % of env-steps with >= 2 tip points, "
           f"|dq| {worst_q:.1e}, |d cube pose| {worst_b:.1e}, images not bit-exact {bad_images} of {n * (steps + 1)}")
+
+
+def test_long_horizon_ball_on_plate_matches_oracle():
+    """object_balance ball_on_plate over whole episodes: 64 envs x 120 steps with auto_reset (max_steps 60) at 128 x 128.  The ball (5 x the plate's
+    mass) tips the plate as soon as it leaves the centre, so episodes end by the 35 degree rule as well as by the step cap, and every reset's
+    blocking move runs with the ball where the episode left it - on the tilted plate, or falling beside it.  dones and reset tick counts exact
+    at every step; joints and plate pose 1e-8 at every 20th step (measured 2e-14 / 1e-11); every frame and terminal observation within 3 pixels of the
+    oracle's (measured: none off)."""
+    modes = dict(BAL, object_mode="ball_on_plate")
+    n, steps, seed, size, max_steps = 64, 120, 5300, 128, 60
+    actions = np.random.default_rng(17).uniform(-0.25, 0.25, size=(steps, n, 2)).astype(np.float32)
+    hip = _hip_rollout("object_balance-v0", modes, size, max_steps, n, seed, actions, auto_reset=True)
+    ref = oracle_rollouts("OracleObjectBalanceEnv", dict(max_steps=max_steps, image_size=(size, size), env_modes=modes), seed, actions, auto_reset=True)
+    worst_q = worst_b = 0.0
+    resets = early = worst_px = 0
+    for i, r in enumerate(ref):
+        assert np.array_equal(hip["done"][:, i].astype(bool), r["done"].astype(bool)), (i, np.nonzero(hip["done"][:, i])[0], np.nonzero(r["done"])[0])
+        k, expect = 0, []
+        for s in range(steps):
+            k += int(r["done"][s])
+            expect.append(r["reset_ticks"][k])
+        assert hip["reset_ticks"][0][i] == r["reset_ticks"][0] and np.array_equal(hip["reset_ticks"][1:, i], expect), i
+        resets += k
+        ends = np.nonzero(r["done"])[0]
+        early += int((np.diff(np.concatenate([[-1], ends])) < max_steps).sum())
+        px = (hip["img"][:, i] != r["img"]).reshape(steps + 1, -1).sum(1).max()
+        for s, im in r["term"].items():
+            px = max(px, int((hip["term"][(s, i)] != im).sum()))
+        worst_px = max(worst_px, int(px))
+        worst_q = max(worst_q, np.abs(hip["q"][::20, i] - r["q"][::20]).max())
+        worst_b = max(worst_b, np.abs(hip["body"][19::20, i] - r["body"][19::20]).max())
+        assert np.abs(hip["rew"][:, i] - r["rew"]).max() < 1e-5
+    assert worst_q < 1e-8 and worst_b < 1e-8 and worst_px <= 3, (worst_q, worst_b, worst_px)
+    assert resets >= 2 * n - 1 and early >= 1, (resets, early)
+    print(f"ball_on_plate: {n} envs x {steps} steps, {resets} auto-resets ({early} by the tilt / position rule): worst |dq| {worst_q:.2e} rad, "
+          f"|d plate pose| {worst_b:.2e}, worst frame {worst_px} pixels off")

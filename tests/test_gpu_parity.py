@@ -1699,3 +1699,61 @@ def test_maximum_batch_size(edge_modes):
     torch.cuda.synchronize()
     assert torch.equal(out.reshape(obs["tactile"].shape), obs["tactile"]) and 0 < int(msg[:4].view(torch.int32).item()) < n * 16
     big.close()
+
+
+BALL_MODES = dict(BAL_MODES, object_mode="ball_on_plate")
+
+
+@pytest.mark.parametrize("size,movement", [(128, "xy"), (64, "xyRxRy")])
+def test_object_balance_ball_on_plate_matches_oracle(size, movement):
+    """object_balance-v0 with object_mode "ball_on_plate" (object_balance_env.py:187-199, 241-260, 350-353, 393-401): the round plate on the
+    point-to-point constraint and a ball rolling on it (sim_tick_body_ball == mb_step_body_ball, PARITY A39).  Two consecutive episodes -
+    the second reset's blocking move runs with the ball wherever the first episode left it - 6 envs vs 6 oracle envs: joint angles
+    1e-8 rad, plate pose and ball position 1e-7 (same recurrence in the Delassus form), reward / done exact, images <= 3 pixels."""
+    import tactile_gym_amd as tg
+    from oracle.ref_env import OracleObjectBalanceEnv
+    n, steps = 6, 12
+    modes = dict(BALL_MODES, movement_mode=movement)
+    act_dim = {"xy": 2, "xyRxRy": 4}[movement]
+    venv = tg.make_vec("object_balance-v0", num_envs=n, max_steps=steps, image_size=[size, size], env_modes=modes, seed=171, auto_reset=False)
+    oracles = [OracleObjectBalanceEnv(seed=171 + i, max_steps=steps, image_size=(size, size), env_modes=modes) for i in range(n)]
+    rng = np.random.default_rng(172)
+    touched = 0
+    for episode in range(2):
+        obs = venv.reset()
+        ref = [o.reset() for o in oracles]
+        st = venv.get_state()
+        for i, o in enumerate(oracles):
+            assert st["gravity_z"][i] == o.gravity and st["embed_dist"][i] == o.embed_dist
+            assert st["reset_ticks"][i] == o.reset_ticks
+            assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8
+            assert np.abs(st["body_pos"][i] - o.body_pose()[0]).max() < 1e-12
+            assert np.array_equal(st["ball_pos"][i], np.array(o.ball.pos[:]))
+            assert int((obs["tactile"][i] != ref[i]["tactile"]).sum()) <= 3
+        for step in range(steps):
+            a = rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32)
+            obs, rew, done, _ = venv.step(a)
+            st = venv.get_state()
+            for i, o in enumerate(oracles):
+                ro, rr, rd, _ = o.step(a[i])
+                pos, R = o.body_pose()
+                assert np.abs(st["q"][i] - o.arm.q).max() < 1e-8, (episode, step, i)
+                assert np.abs(st["body_pos"][i] - pos).max() < 1e-7 and np.abs(st["body_rot"][i] - R).max() < 1e-7, (episode, step, i)
+                assert np.abs(st["ball_pos"][i] - np.array(o.ball.pos[:])).max() < 1e-7, (episode, step, i)
+                assert np.abs(st["ball_linvel"][i] - np.array(o.ball.linvel[:])).max() < 1e-6, (episode, step, i)
+                assert abs(st["ball_impulse"][i] - o.ball.normal_impulse) < 1e-9, (episode, step, i)
+                assert (st["ball_impulse"][i] > 0) == (o.ball.normal_impulse > 0)
+                touched += int(o.ball.normal_impulse > 0)
+                assert rew[i] == rr and bool(done[i]) == rd
+                assert int((obs["tactile"][i] != ro["tactile"]).sum()) <= 3, (episode, step, i)
+        assert done.all()
+    assert touched > n * steps          # the ball was on the plate for most of the run
+    venv.close()
+
+
+def test_object_balance_ball_on_plate_refuses_wave_and_spinning_plate():
+    import tactile_gym_amd as tg
+    with pytest.raises(ValueError):
+        tg.make_vec("object_balance-v0", num_envs=2, max_steps=4, image_size=[64, 64], env_modes=BALL_MODES, seed=1, contact_mapping="wave")
+    with pytest.raises(NotImplementedError):
+        tg.make_vec("object_balance-v0", num_envs=2, max_steps=4, image_size=[64, 64], env_modes=dict(BAL_MODES, object_mode="spinning_plate"), seed=1)

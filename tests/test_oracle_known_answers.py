@@ -448,3 +448,40 @@ def test_marble_contacts_closed_form_equal_gjk():
         assert abs(dt_ - (c[2] - sc.table_z)) < 1e-12
         checked += 1
     assert checked >= 4
+
+
+def test_ball_on_plate_known_answers():
+    """object_balance ball_on_plate (mb_step_body_ball, PARITY A39) against first principles: (1) a ball at rest on the level plate is carried by
+    a normal impulse m |g| dt per tick and sits one radius above the plate's top face; (2) a ball set sliding at v0 without spin ends up rolling without
+    slipping at (5/7) v0, the solid-sphere value (angular momentum about the contact point is conserved by friction)."""
+    from oracle.ref_env import OracleObjectBalanceEnv
+    modes = dict(movement_mode="RxRy", control_mode="TCP_velocity_control", object_mode="ball_on_plate", rand_gravity=False, rand_embed_dist=False,
+                 observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+    e = OracleObjectBalanceEnv(seed=5, max_steps=500, image_size=(64, 64), env_modes=modes)
+    e.reset()
+    for k in range(3):
+        e.ball.ext_torque[k] = 0.0                                  # no random kick: the ball stays put
+    bl, g, dt = e.ball, abs(e.gravity), e.SIM_DT
+    for _ in range(10):
+        e.step(np.zeros(2))
+    assert bl.in_contact == 1
+    assert abs(bl.normal_impulse - bl.mass * g * dt) < 0.02 * bl.mass * g * dt
+    pos, R = e.body_pose()
+    rel = R.T @ (np.array(bl.pos[:]) - pos)
+    assert abs(rel[2] - (bl.plate_half_len + bl.radius)) < 2e-5 and np.hypot(rel[0], rel[1]) < 1e-4
+    # (2) sliding start at the plate's centre: v0 along x, no spin.  Friction (mu 5) turns sliding into rolling within t = (2/7) v0 / (mu g)
+    # ~ 1.4 ticks, and conservation of angular momentum about the contact point leaves the ball rolling at (5/7) v0 - the plate (held in
+    # translation by the constraint, friction acting at the height of its pivot) and the damping change that by well under 5 % in 4 ticks.
+    v0 = 0.01
+    bl.linvel[0], bl.linvel[1], bl.linvel[2] = v0, 0.0, 0.0
+    for k in range(3):
+        bl.angvel[k] = 0.0
+    for _ in range(4):
+        e._step_simulation()
+    v1, w1 = np.array(bl.linvel[:]), np.array(bl.angvel[:])
+    assert bl.in_contact == 1
+    assert abs(v1[0] - (5.0 / 7.0) * v0) < 0.05 * v0 and abs(v1[1]) < 0.02 * v0, v1
+    _, R = e.body_pose()
+    slip = v1 + np.cross(w1, -bl.radius * R[:, 2])                 # velocity of the ball's contact point
+    assert np.linalg.norm(slip) < 0.03 * v0, (slip, v1)
+    assert abs(w1[1] - v1[0] / bl.radius) < 0.05 * v1[0] / bl.radius      # rolling: w_y = v_x / r

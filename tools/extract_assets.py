@@ -211,6 +211,7 @@ def golden_views():
 def objects():
     """Free objects (welded URDFs) flattened to one rigid body + their visual triangles."""
     for name, rel in (("pole", "rl_env_assets/nonprehensile_manipulation/object_balance/pole/pole.urdf"),
+                      ("round_plate", "rl_env_assets/nonprehensile_manipulation/object_balance/round_plate/round_plate.urdf"),
                       ("cube", "rl_env_assets/nonprehensile_manipulation/object_push/cube/cube.urdf")):
         for mode in ("collision_aabb", "urdf"):
             d = compile_free_body(os.path.join(REF, rel), inertia_mode=mode)
@@ -228,6 +229,20 @@ def sphere():
     v, t = load_mesh(os.path.join(d, "sphere.obj"))
     save(os.path.join(OUT, "objects", "sphere.npz"), mass=np.array(L.mass), radius=np.array(r), urdf_inertia=np.array(L.inertia),
          verts=v.astype(np.float32), tris=t.astype(np.int32))
+
+
+def balance_ball():
+    """object_balance's ball (object_mode "ball_on_plate"): object_balance/sphere/sphere.urdf, loaded with globalScaling 7.5
+    (object_balance_env.py:245-260): mass, collision radius as written; the cylinder of round_plate.urdf it rolls on."""
+    d = os.path.join(REF, "rl_env_assets/nonprehensile_manipulation/object_balance")
+    links, _ = parse_urdf(os.path.join(d, "sphere", "sphere.urdf"))
+    L = next(iter(links.values()))
+    plinks, _ = parse_urdf(os.path.join(d, "round_plate", "round_plate.urdf"))
+    P = next(iter(plinks.values()))
+    cyl = P.collisions[0]
+    assert cyl.kind == "cylinder" and list(cyl.origin_xyz) == list(P.com_xyz)        # the collision cylinder is centred on the inertial frame
+    save(os.path.join(OUT, "objects", "balance_ball.npz"), mass=np.array(L.mass), radius=np.array(float(L.collisions[0].size[0])),
+         urdf_inertia=np.array(L.inertia), plate_radius=np.array(float(cyl.size[0])), plate_length=np.array(float(cyl.size[1])))
 
 
 def _weld(v, t):
@@ -289,6 +304,7 @@ if __name__ == "__main__":
         sys.exit(0)
     objects()
     sphere()
+    balance_ball()
     robots()
     sensors()
     stimuli()

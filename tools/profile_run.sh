@@ -22,6 +22,7 @@ $B --no-literal --separate-policy 2>/dev/null | grep metric > $O/bench_edge_sepa
 TG_RESET_BANK=0 $B --env surface_follow-v2 2>/dev/null | grep metric > $O/bench_surface_follow-v2_bank_off.json
 $B --env object_push-v0 --narrowphase gjk_manifold --steps 100 --warmup 10 2>/dev/null | grep metric > $O/bench_object_push-v0_gjk_manifold.json
 (python tools/pcie_rate.py; python tools/pcie_rate.py --tiles) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
+python tools/ball_rate.py 1024 8192 2>&1 | grep -v amdgpu > $O/ball_on_plate_rate.txt
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank.json
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport collective --payload interior 2>/dev/null | grep metric > $O/bench_edge_rccl_interior_1rank.json
 cd /tmp; export TMPDIR=/tmp

@@ -505,7 +505,7 @@ def main():
             dt_sp = w.timed(env, args.steps, barrier)
             Workload.fused_policy = True
             separate = {"value": round(n * args.steps / dt_sp, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * dt_sp / args.steps, 4),
-                        "what": "tg_sample_actions as its own kernel launch before every tg_step instead of a node of the step's graph"}
+                        "what": "tg_sample_actions as its own kernel launch before every tg_step instead of a draw inside the step's graph"}
     exchange = env.exchange_info() if gathered and hasattr(env, "exchange_info") else None
     if exchange is not None:
         exchange["verified"] = verified
@@ -570,8 +570,8 @@ def main():
                       "default: PGS leaves at last-bit convergence; ticks whose motor solve is provably unclamped and demonstrably converged take "
                       "the solver's analytic fixed point (qd = target); joints within 1e-11 rad of the literal solver over 1024 envs x 260 steps incl. auto-resets "
                       "(tests/test_gpu_parity.py::test_default_solver_equals_literal_solver_at_config_scale; DESIGN.md 4.1)",
-            "policy": ("uniform random actions (action_space.sample() for the whole batch), drawn on the device as the first node of the step's graph "
-                       "(tg_step_random; draw k identical to tg_sample_actions(seed, k))") if Workload.fused_policy and hasattr(env, "step_random") else
+            "policy": ("uniform random actions (action_space.sample() for the whole batch), drawn on the device inside the step's graph (tg_step_random: by the step kernel "
+                       "itself for edge_follow / surface_follow under velocity control, as the graph's first node elsewhere; draw k identical to tg_sample_actions(seed, k))") if Workload.fused_policy and hasattr(env, "step_random") else
                       "uniform random actions drawn on the device by tg_sample_actions, one launch before every step",
             "separate_policy_launch": separate,
             "literal_solver": literal,

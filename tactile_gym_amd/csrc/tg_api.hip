@@ -895,7 +895,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     *out = c;                            // owned by tg_create's guard from here on
     c->cfg = *cfg; c->robot = *robot; c->H = H; c->W = W;
     TG_HIP(hipStreamCreate(&c->own_stream));
-    TG_HIP(hipStreamCreate(&c->capture_stream));
+    TG_HIP(hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking));   // non-blocking: a capture must not drag the legacy default stream (torch's) into its rules
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE) {
         TG_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
         TG_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); TG_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));

@@ -256,6 +256,7 @@ class ShardedVecEnv:
         self._last_counts = None
         self._prev_ids = [None, None]
         self._root_cache, self._out_cache, self._tac_view = [None, None], [None, None], [None, None]
+        self._captured = set()                       # step kinds whose graph capture has been made safe (_quiesce_before_capture)
 
     def env_slice(self):
         return slice(self.rank * self.n_local, (self.rank + 1) * self.n_local)
@@ -632,12 +633,29 @@ class ShardedVecEnv:
             self._wait(self._pending[k])
             self._pending[k] = None
 
+    def _quiesce_before_capture(self, kind):
+        """The first step of each kind makes the library capture its step graph (tg_step / tg_step_random).  While a HIP stream is capturing,
+        hipEventQuery from ANOTHER thread can fail with hipErrorCapturedEvent, and torch's RCCL process group has such a thread: its watchdog
+        polls the end events of the collectives still in its list every 100 ms, and a poll that fell into the few hundred microseconds of a
+        capture aborted the process (2 of ~100 one-rank bench runs, all ranks would go down with it).  So before a capture: finish all device
+        work, then give the watchdog three periods to retire the completed collectives - it polls nothing while its list is empty."""
+        if kind in self._captured or self._solo:
+            return
+        self._captured.add(kind)
+        if not (getattr(self.local, "raw", False) and self.torch.cuda.is_available()):
+            return                                   # a host-side shard (the gloo tests): nothing is captured
+        import time
+        self.torch.cuda.synchronize()
+        time.sleep(0.3)
+
     def step_random(self, seed, first_draw=0, restart=False):
         """step(action_space.sample()) on every rank's shard (TorchShard.step_random: the draw inside the step's graph), then the exchange of step().
         Every rank passes its own seed."""
+        self._quiesce_before_capture("random")
         return self._exchange(*self.local.step_random(seed, first_draw, restart))
 
     def step(self, local_actions):
+        self._quiesce_before_capture("step")
         return self._exchange(*self.local.step(local_actions))
 
     def _exchange(self, obs, rew, done, info):

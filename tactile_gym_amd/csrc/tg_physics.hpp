@@ -1168,56 +1168,41 @@ __device__ __forceinline__ void sim_tick_body_ball(const DevRobot<T>& m, T (&q)[
         const T rv = (dot(d[k], vk) + dot(cxa[k], wk)) - (dot(d[k], vb) + dot(cxb[k], wb));
         rc[k] = (k == 0) ? (depth > T(0) ? (-rv - depth / dt) : (-depth * kc.erp / dt - rv)) : -rv;     // restitution 0
     }
-    T G[NP][NP], Gpc[3][3], Gcp[3][3], Gcc[3][3];     // G[j][i] = A[j][i] / A[j][j]
+    // Unscaled residuals R_j = rhs_j - sum_q A_jq lambda_q and the inverse diagonals: a row's step is t = R_i / A_ii, and every update reads A
+    // itself - one triangle of the symmetric blocks (App upper, Acc upper, Apc shared by the P2P and the contact rows) instead of the four
+    // row-scaled copies G = A / diag: 60 instead of 117 matrix doubles live through the sweeps (this tick does not fit the register file:
+    // 872 B of scratch per lane with the scaled copies).
+    T jdi[NP], jc[3];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const T jdi = T(1) / A[j][j];
-        r[j] = r[j] * jdi;
-        lam[j] = T(0);
+    for (int j = 0; j < NP; ++j) { jdi[j] = T(1) / A[j][j]; lam[j] = T(0); }
 #pragma unroll
-        for (int i = 0; i < NP; ++i) G[j][i] = A[j][i] * jdi;
-    }
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-        const T jdi = T(1) / A[N + x][N + x];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) Gpc[x][k] = Apc[x][k] * jdi;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const T jdi = touching ? T(1) / Acc[k][k] : T(0);
-        rc[k] = rc[k] * jdi;
-#pragma unroll
-        for (int x = 0; x < 3; ++x) Gcp[k][x] = Apc[x][k] * jdi;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) Gcc[k][s] = Acc[k][s] * jdi;
-    }
+    for (int k = 0; k < 3; ++k) jc[k] = touching ? T(1) / Acc[k][k] : T(0);
     T thr = T(0);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) thr = tmax(thr, tabs(r[j]));
-    if (touching) thr = tmax(thr, tmax(tabs(rc[0]), tmax(tabs(rc[1]), tabs(rc[2]))));
+    for (int j = 0; j < NP; ++j) thr = tmax(thr, tabs(r[j] * jdi[j]));
+    if (touching) thr = tmax(thr, tmax(tabs(rc[0] * jc[0]), tmax(tabs(rc[1] * jc[1]), tabs(rc[2] * jc[2]))));
     thr = iters < 0 ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
     const int n_it = iters < 0 ? -iters : iters;
     for (int it = 0; it < n_it; ++it) {
         if ((it & 7) == 0 && it > 0) {
             T mx = T(0);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) mx = tmax(mx, tabs(r[j]));
-            if (touching) mx = tmax(mx, tmax(tabs(rc[0]), tmax(tabs(rc[1]), tabs(rc[2]))));
+            for (int j = 0; j < NP; ++j) mx = tmax(mx, tabs(r[j] * jdi[j]));
+            if (touching) mx = tmax(mx, tmax(tabs(rc[0] * jc[0]), tmax(tabs(rc[1] * jc[1]), tabs(rc[2] * jc[2]))));
             if (__all(mx <= thr)) break;
         }
         auto row = [&](const int i) {      // i is a compile-time constant after unrolling
-            const T t = r[i];
+            const T t = r[i] * jdi[i];
             const T sum = lam[i] + t;
             const T lo = sum < -lim[i] ? -lim[i] : sum;
             const T sc = lo > lim[i] ? lim[i] : lo;
             const T delta = (sc == sum) ? t : sc - lam[i];
             lam[i] = sc;
 #pragma unroll
-            for (int j = 0; j < NP; ++j) r[j] -= G[j][i] * delta;
+            for (int j = 0; j < NP; ++j) r[j] -= (j <= i ? A[j][i] : A[i][j]) * delta;
             if (i >= N) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) rc[k] -= Gcp[k][i >= N ? i - N : 0] * delta;
+                for (int k = 0; k < 3; ++k) rc[k] -= Apc[i >= N ? i - N : 0][k] * delta;
             }
         };
         if (it & 1) {
@@ -1229,26 +1214,27 @@ __device__ __forceinline__ void sim_tick_body_ball(const DevRobot<T>& m, T (&q)[
         }
         if (touching) {
             {   // normal
-                const T t = rc[0], sum = lc[0] + t;
+                const T t = rc[0] * jc[0], sum = lc[0] + t;
                 const T sc = sum < T(0) ? T(0) : sum;
                 const T delta = (sc == sum) ? t : sc - lc[0];
                 lc[0] = sc;
 #pragma unroll
-                for (int x = 0; x < 3; ++x) r[N + x] -= Gpc[x][0] * delta;
+                for (int x = 0; x < 3; ++x) r[N + x] -= Apc[x][0] * delta;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) rc[k] -= Gcc[k][0] * delta;
+                for (int k = 0; k < 3; ++k) rc[k] -= Acc[0][k] * delta;
             }
             {   // friction pair, cone (enableConeFriction = 1, base_tactile_env.py:128-130)
                 const T limit = kc.mu * lc[0];
-                T s1 = lc[1] + rc[1], s2 = lc[2] + rc[2];
+                T s1 = lc[1] + rc[1] * jc[1], s2 = lc[2] + rc[2] * jc[2];
                 const T tot = tsqrt(s1 * s1 + s2 * s2);
                 if (tot > limit) { const T f = tot > T(0) ? limit / tot : T(0); s1 *= f; s2 *= f; }
                 const T d1 = s1 - lc[1], d2 = s2 - lc[2];
                 lc[1] = s1; lc[2] = s2;
 #pragma unroll
-                for (int x = 0; x < 3; ++x) r[N + x] -= Gpc[x][1] * d1 + Gpc[x][2] * d2;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) rc[k] -= Gcc[k][1] * d1 + Gcc[k][2] * d2;
+                for (int x = 0; x < 3; ++x) r[N + x] -= Apc[x][1] * d1 + Apc[x][2] * d2;
+                rc[0] -= Acc[0][1] * d1 + Acc[0][2] * d2;
+                rc[1] -= Acc[1][1] * d1 + Acc[1][2] * d2;
+                rc[2] -= Acc[1][2] * d1 + Acc[2][2] * d2;
             }
         }
     }

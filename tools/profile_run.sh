@@ -48,6 +48,7 @@ prof edge_literal --full-sweeps --steps 200 --warmup 10
 prof surface_follow-v2 --env surface_follow-v2 --steps 200 --warmup 10
 prof object_push-v0 --env object_push-v0 --steps 100 --warmup 10
 prof object_balance-v0 --env object_balance-v0 --image-size 256
+prof surface_follow-v0 --env surface_follow-v0
 traffic edge
 traffic object_push-v0 --env object_push-v0
 traffic object_balance-v0 --env object_balance-v0 --image-size 256

@@ -59,6 +59,16 @@ constexpr bool kHfQuadReject = false;
 #define TG_HF_WAVES 3   // 3 wavefronts per SIMD for the 128 x 64 heightfield kernel (167 VGPRs, 64 B of scratch): 0.098 -> 0.078 ms; needs its windowed LDS (< 53 KB)
 #endif
 constexpr int kThreads = 256;
+#ifndef TG_EDGE_REACH
+#define TG_EDGE_REACH 1
+#endif
+#ifndef TG_EDGE_CELL_MAX
+#define TG_EDGE_CELL_MAX 256
+#endif
+constexpr int kEdgeCellMax = TG_EDGE_CELL_MAX;   // heightfield: the per-record cell test costs ~80 vector instructions per record on one wavefront; it pays while the records are few
+                                    // (DIGIT on the horizontal surface: 56 us against 63), not for a view of hundreds (TacTip on the vertical one: 159 against 126)
+constexpr int kCellsWinSide = 24;   // heightfield window (launch_render) up to which the cell masks are used: DIGIT 16, DigiTac 18 (TacTip: 32)
+constexpr bool kEdgeReach = TG_EDGE_REACH != 0;   // A/B build switch for the edge-function block test (edges_exclude_rect)
 constexpr int kBatch = 1024;         // most triangle records staged in LDS per pass (56 KB); a small mesh allocates 2 * n_tris records only, so
                                      // that the 12-triangle edge does not hold the occupancy at 2 workgroups per CU (LDS-bound)
 
@@ -186,12 +196,45 @@ __device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const fl
     return true;
 }
 
+// Can the record cover ANY pixel centre of the rectangle [X0, X1] x [Y0, Y1] (first / last pixel centres of a block)?  A pixel is
+// covered only if its three computed edge functions e_i are all >= 0 or all <= 0 (the `pos | neg` of the pixel loops).  In exact
+// arithmetic E_i is affine in (fx, fy), so over the rectangle it is extremal at a corner, and E_0 + E_1 + E_2 = S is the same everywhere
+// (twice the signed area).  The computed e_i (two differences, two products, one difference: the pixel loops' expression) differs from E_i
+// by at most m_i = 1e-5 (B_j A_k + B_k A_j) with B, A the largest |x - fx|, |y - fy| over the rectangle - 40 times the worst-case
+// rounding of that expression (4 x 2^-24).  Hence:  some edge with max over the corners of e_i < -2 m_i  ->  e_i < 0 at every pixel, no
+// pixel is `pos`;  S certainly > sum m_i (computed sum at a corner > 2 sum m_i)  ->  the three e_i cannot all be <= 0 anywhere, no pixel
+// is `neg`; and the mirror images.  Returns true when both are excluded: skipping the record for this rectangle changes no pixel.
+// NaN / inf coordinates compare false everywhere: not excluded.  (What it buys: the two coplanar triangles of a box face or of the plate
+// both have the face as bounding box and depth plane, and each covers half of it.)
+__device__ __forceinline__ bool edges_exclude_rect(float x0, float y0, float x1, float y1, float x2, float y2, float X0, float X1, float Y0, float Y1) {
+    const float B0 = fmaxf(fabsf(x0 - X0), fabsf(x0 - X1)), B1 = fmaxf(fabsf(x1 - X0), fabsf(x1 - X1)), B2 = fmaxf(fabsf(x2 - X0), fabsf(x2 - X1));
+    const float A0 = fmaxf(fabsf(y2 - Y0), fabsf(y2 - Y1)), A1 = fmaxf(fabsf(y1 - Y0), fabsf(y1 - Y1)), A2 = fmaxf(fabsf(y0 - Y0), fabsf(y0 - Y1));
+    const float m0 = 1e-5f * (B1 * A0 + B2 * A1), m1 = 1e-5f * (B2 * A2 + B0 * A0), m2 = 1e-5f * (B0 * A1 + B1 * A2);
+    float hi0 = -3.0e38f, hi1 = -3.0e38f, hi2 = -3.0e38f, lo0 = 3.0e38f, lo1 = 3.0e38f, lo2 = 3.0e38f, s_lo = 3.0e38f, s_hi = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float fx = (c & 1) ? X1 : X0, fy = (c & 2) ? Y1 : Y0;
+        const float a0 = y2 - fy, a1 = y1 - fy, a2 = y0 - fy;
+        const float e0 = (x1 - fx) * a0 - (x2 - fx) * a1;
+        const float e1 = (x2 - fx) * a2 - (x0 - fx) * a0;
+        const float e2 = (x0 - fx) * a1 - (x1 - fx) * a2;
+        hi0 = fmaxf(hi0, e0); hi1 = fmaxf(hi1, e1); hi2 = fmaxf(hi2, e2);
+        lo0 = fminf(lo0, e0); lo1 = fminf(lo1, e1); lo2 = fminf(lo2, e2);
+        const float sc = (e0 + e1) + e2;
+        s_lo = fminf(s_lo, sc); s_hi = fmaxf(s_hi, sc);
+    }
+    const float M2 = 2.0f * ((m0 + m1) + m2);
+    const bool no_pos = (hi0 < -2.0f * m0) | (hi1 < -2.0f * m1) | (hi2 < -2.0f * m2) | (s_hi < -M2);
+    const bool no_neg = (lo0 > 2.0f * m0) | (lo1 > 2.0f * m1) | (lo2 > 2.0f * m2) | (s_lo > M2);
+    return no_pos & no_neg;
+}
+
 // grid: (tiles_x * tiles_y, num_envs, 1 or 2); block: 256.  TW x TH = tile (128 x 128; 128 x 64 for small meshes: half the rows
 // per lane halves the z-buffer registers, 4 instead of 2 workgroups fit a CU, and the per-workgroup set-up of a dozen triangles is
 // negligible; 64 x 64 for 64x64 images).
 // BAND (heightfield stimuli: hundreds of small triangles per tile): wavefront w owns the w-th 32-pixel column band of the tile (8 quad
 // columns x 8 rows per pass) instead of two full rows, and skips - as one scalar branch - every record whose bounding box misses the band.
-template <int TW, int TH, bool BAND>
+template <int TW, int TH, bool BAND, bool CELLS = false /* BAND only: per-record (band, pass) cell masks from the edge functions */>
 __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) void k_render_tactile(RasterParams P, Stimulus S, const float* __restrict__ xform /*[12][n] SoA or [n][12] AoS*/,
                                                              int xform_soa, int n_envs, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ nodef_dep, const uint8_t* __restrict__ gray_u8,
@@ -409,16 +452,32 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
         __syncthreads();
         const int n = min(count, rec_cap);
         start = next_start;
+        const bool cells = BAND && CELLS && n <= kEdgeCellMax;   // (wave-uniform)
+        if (cells) {
+            // per record: the (band, pass) cells - 32 x 8 pixel rectangles, bit 4 k + band - whose pixel centres the TRIANGLE can cover, not just
+            // its bounding box (edges_exclude_rect: rigorous).  Lane l < 32 of each wavefront stands for cell (band l & 3, pass l >> 2).
+            const int l = tid & 63, cb = l & 3, ck = (l >> 2) & 7;
+            const float X0 = tx0 + 32.0f * (float)cb + 0.5f, X1 = X0 + 31.0f, Y0 = ty0 + 8.0f * (float)ck + 0.5f, Y1 = Y0 + 7.0f;
+            for (int t = band; t < n; t += kThreads / 64) {
+                const TriRec r = recs[t];
+                const unsigned rb0 = rbands[t];
+                bool miss = !((rb0 >> cb) & 1u) | !((rb0 >> (4 + ck)) & 1u);
+                miss = miss | edges_exclude_rect(r.x0, r.y0, r.x1, r.y1, r.x2, r.y2, X0, X1, Y0, Y1);
+                const unsigned long long m = __ballot(!miss);
+                if (l == 0) rbands[t] = (unsigned)m;
+            }
+            __syncthreads();
+        }
         for (int t = 0; t < n; ++t) {
             unsigned rb = 0u;
             if (BAND) {
                 rb = __builtin_amdgcn_readfirstlane(rbands[t]);
-                if (!((rb >> band) & 1u)) continue;   // wave-uniform
+                if (cells ? !((rb >> band) & 0x11111111u) : !((rb >> band) & 1u)) continue;   // wave-uniform
             }
             const TriRec r = recs[t];   // same address on every lane: LDS broadcast
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                if (BAND && !((rb >> (4 + k)) & 1u)) continue;   // scalar: this pass's 8 rows are outside the record's row span
+                if (BAND && (cells ? !((rb >> (4 * k + band)) & 1u) : !((rb >> (4 + k)) & 1u))) continue;   // scalar: this pass's 32 x 8 cell is out of the record's reach
                 const int qx = TG_QX(k);
                 const float fy = (float)TG_RY(k) + 0.5f;
                 if (fy < r.ymin || fy > r.ymax) continue;
@@ -672,6 +731,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
     static_assert(NK % HALVES == 0, "row groups");
     extern __shared__ TriRec recs[];
     __shared__ int count;
+    __shared__ unsigned rblocks[512];    // per record: the 16 x 16 pass blocks of this tile (bit 8 by + bx) it can cover a pixel of (rec_cap <= 2 x 256)
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
     const int n_tris = S.n_tris;
@@ -739,6 +799,23 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
     }
     __syncthreads();
     const int n = min(count, rec_cap);
+    // Which pass blocks can a record cover a pixel of?  Lane l < 32 of each wavefront stands for block (bx = l & 7, by = l >> 3); bounding box
+    // and the edge functions over the block's pixel centres (edges_exclude_rect: rigorous, so skipping changes no pixel).  The two coplanar
+    // triangles of the plate's face (object_balance: they fill the view) each cover half of it, and so do a box face's.
+    {
+        const int wv = tid >> 6, l = tid & 63, bx = l & 7, by = (l >> 3) & 3;
+        const float X0 = (float)(tile_x + 16 * bx) + 0.5f, X1 = X0 + 15.0f;
+        const float Y0 = (float)((interleave ? 16 : TH) * ty + ry_step * by) + 0.5f, Y1 = Y0 + 15.0f;
+        for (int t = wv; t < n; t += kThreads / 64) {
+            const TriRec r = recs[t];
+            bool miss = (r.ymax < Y0) | (r.ymin > Y1) | (r.xmax < X0) | (r.xmin > X1);
+            miss = miss | edges_exclude_rect(r.x0, r.y0, r.x1, r.y1, r.x2, r.y2, X0, X1, Y0, Y1);
+            const unsigned long long m = __ballot(!miss);
+            if (l == 0) rblocks[t] = (unsigned)m;
+        }
+        __syncthreads();
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float eps = 1e-4f, max_pen = 0.05f;
     uint8_t* dst = img + (size_t)env * P.W * P.H;
     uint8_t* prev = (save_prev && pass == 1) ? save_prev + (size_t)env * P.W * P.H : nullptr;
@@ -752,9 +829,12 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
             z[k][0] = nd.x; z[k][1] = nd.y; z[k][2] = nd.z; z[k][3] = nd.w;
         }
         for (int t = 0; t < n; ++t) {
+            const unsigned rb = __builtin_amdgcn_readfirstlane(rblocks[t]);
+            if (!((rb >> wave_u) & 0x11111111u)) continue;      // none of this wavefront's eight blocks (columns wave, wave + 4 of the four row groups)
             const TriRec r = recs[t];
 #pragma unroll
             for (int k = 0; k < NKH; ++k) {
+                if (!((rb >> (8 * ((h * NKH + k) >> 1) + wave_u + 4 * ((h * NKH + k) & 1))) & 1u)) continue;   // scalar: this pass's block
                 const int qx = TG_QX(h * NKH + k);
                 const float fy = (float)TG_RY(h * NKH + k) + 0.5f;
                 if (fy < r.ymin || fy > r.ymax) continue;
@@ -999,9 +1079,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
 
     // 1. lane-as-record
     float q_xl = 1e30f, q_xh = -1e30f, q_yl = 1e30f, q_yh = -1e30f, q_dm = 1e30f, q_x0 = 0.0f, q_y0 = 0.0f, q_d0 = 0.0f, q_A = 0.0f, q_B = 0.0f, q_mg = 1e30f;
+    float q_x1 = 0.0f, q_y1 = 0.0f, q_x2 = 0.0f, q_y2 = 0.0f;
     if (lane < n) {
         const TriRec& r = recs[lane];
         q_xl = r.xmin; q_xh = r.xmax; q_yl = r.ymin; q_yh = r.ymax; q_dm = r.dmin; q_x0 = r.x0; q_y0 = r.y0; q_d0 = r.d0;
+        q_x1 = r.x1; q_y1 = r.y1; q_x2 = r.x2; q_y2 = r.y2;
         const float ux = r.x1 - r.x0, uy = r.y1 - r.y0, vx = r.x2 - r.x0, vy = r.y2 - r.y0, ud = r.d1 - r.d0, vd = r.d2 - r.d0;
         const float ar = ux * vy - vx * uy;
         const float cond = ((q_xh - q_xl) * (q_yh - q_yl)) / fabsf(ar);
@@ -1025,6 +1107,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
             const float xa = fmaxf(X0, xl), xb = fminf(X1, xh), ya = fmaxf(Y0, yl), yb = fminf(Y1, yh);
             const float low = (d0 + A * ((A >= 0.0f ? xa : xb) - x0)) + B * ((B >= 0.0f ? ya : yb) - y0);
             miss = miss | (low - mg >= bmax_l - kGrey);
+            // ... and whether the triangle itself (not just its bounding box and plane) can cover a pixel centre of the block
+            if (kEdgeReach) miss = miss | edges_exclude_rect(x0, y0, TG_RL(q_x1), TG_RL(q_y1), TG_RL(q_x2), TG_RL(q_y2), X0, X1, Y0, Y1);
             const unsigned long long m = __ballot(!miss);
             part |= m;
             if (lane == 0) reach_rec[t] = m;
@@ -1263,6 +1347,15 @@ void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xfo
             dim3 grid((P.W / 128) * (P.H / 128), n_envs, term_xform ? 2 : 1);
             if (S.kind == 1) {   // heightfield: 128 x 64 tiles (the per-workgroup staging is cheap since it is windowed: 0.108 -> 0.098 ms)
                 dim3 g2((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
+                static const bool dbg_win = getenv("TG_DEBUG_WIN") != nullptr;
+                if (dbg_win) fprintf(stderr, "heightfield window side %d cells\n", S.win_side);
+                // a narrow view (DIGIT over the horizontal surface: a window of a few cells) leaves few records per tile: there the per-record
+                // cell masks pay (render 63 -> 57 us); a wide one (TacTip over the vertical surface) has hundreds of records and keeps the
+                // bounding-box bands - as its own instantiation, the cell code costs that kernel registers even when it is switched off
+                if (kEdgeReach && S.win_side <= kCellsWinSide)
+                    hipLaunchKernelGGL((k_render_tactile<128, 64, true, true>), g2, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
+                                       nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
+                else
                 hipLaunchKernelGGL((k_render_tactile<128, 64, true>), g2, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
             } else if (!scatter_off)   // a shared mesh of many small triangles (the marble): triangle-parallel, LDS z-buffer

@@ -371,6 +371,7 @@ struct tg_ctx {
     tg_robot robot;
     int H, W, act_dim;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    bool tmpl_ready = false;               // object_balance: State.reset_tmpl has been (or will have been, in stream order) filled by a full reset
     hipStream_t capture_stream = nullptr;   // the step graph is captured here, never on the stream work runs on (see tg_step)
     void *d_robot = nullptr, *d_const = nullptr;   // DevRobot<T>, EnvConst<T>
     tg::State st{};
@@ -546,6 +547,15 @@ template <typename T> static void launch_step_body_t(tg_ctx* c, const float* d_a
 }
 template <typename T> static void launch_reset_body_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;
+    if (c->tmpl_ready) {   // a reset that covered env 0 has been enqueued before this one: the template is there when this launch runs
+        if (c->cfg.balance_object == TG_BALANCE_BALL_ON_PLATE)
+            hipLaunchKernelGGL((k_reset_body<T, 0, true, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                               (const EnvConst<T>*)c->d_const, c->st, d_mask);
+        else
+            hipLaunchKernelGGL((k_reset_body<T, 0, false, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                               (const EnvConst<T>*)c->d_const, c->st, d_mask);
+        return;
+    }
     if (c->cfg.balance_object == TG_BALANCE_BALL_ON_PLATE) {
         hipLaunchKernelGGL((k_reset_body<T, 0, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
                            (const EnvConst<T>*)c->d_const, c->st, d_mask);
@@ -971,6 +981,11 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         TG_HIP(hipMalloc(&s.ext_pending, n));
         TG_HIP(hipMemset(s.body_v, 0, 3 * n * 8)); TG_HIP(hipMemset(s.body_w, 0, 3 * n * 8)); TG_HIP(hipMemset(s.ext_pos, 0, 3 * n * 8));
         TG_HIP(hipMemset(s.ext_pending, 0, n));
+        {   // the arm's post-reset state, computed once (k_reset_body); off with reset_bank = TG_BANK_OFF / TG_RESET_BANK=0
+            bool tmpl = cfg->reset_bank != TG_BANK_OFF;
+            if (const char* e = getenv("TG_RESET_BANK")) tmpl = e[0] != '0';
+            if (tmpl) { TG_HIP(hipMalloc(&s.reset_tmpl, (2 * TG_MAX_DOF + 2) * 8)); TG_HIP(hipMemset(s.reset_tmpl, 0, (2 * TG_MAX_DOF + 2) * 8)); }
+        }
         if (cfg->balance_object == TG_BALANCE_BALL_ON_PLATE) {   // load_ball (:241-260): at workframe + (0, 0, radius), at rest
             TG_HIP(hipMalloc(&s.ball, (size_t)13 * n * 8));
             std::vector<double> bl((size_t)13 * n, 0.0);
@@ -1199,7 +1214,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->d_draw) (void)hipFree(c->d_draw);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -1241,6 +1256,8 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
         dmask = c->d_mask;
     }
     reset_sequence(c, dmask);
+    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE && c->st.reset_tmpl != nullptr && (host_mask == nullptr || host_mask[0] != 0))
+        c->tmpl_ready = true;   // env 0 went through the full reset just enqueued: later launches (stream order) take the template-only kernel
     hipLaunchKernelGGL(tg::k_episode_clear, dim3((c->cfg.num_envs + 255) / 256), dim3(256), 0, c->stream, c->st.ep_return, dmask, c->cfg.num_envs);
     render(c, dmask, false);
     if (c->scene_every_step) scene_draw(c, dmask, false);
@@ -1282,7 +1299,9 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     // after their reset below (their step image moves to the terminal buffer)
     if (c->scene_every_step) scene_draw(c, nullptr, false);
     if (c->oracle_every_step) oracle_draw(c, c->cfg.auto_reset ? c->d_oracle_term : c->d_oracle);   // the step's own vectors, before any reset
-    if (c->cfg.auto_reset && c->cfg.env_kind == TG_ENV_EDGE_FOLLOW) {
+    if (c->cfg.auto_reset && (c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE && c->st.reset_tmpl != nullptr))) {
+        // (object_balance with the reset template: k_reset_body is a few microseconds - teleport, draws, one forward kinematics - so it runs
+        //  in line like edge_follow's, without the fork / join of the branch below and without the masked second render: 236 -> 20x us per step)
         reset_sequence(c, c->st.done, c->bank_mode != 0); // k_reset keeps the terminal camera transform of the envs it resets
         render_fused(c);               // one launch draws the terminal and the post-reset observations
     } else if (c->cfg.auto_reset && c->aux_stream) {

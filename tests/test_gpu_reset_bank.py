@@ -72,3 +72,34 @@ def test_bank_not_ready_falls_back_to_the_reset_on_the_spot():
     aut, s = rollout("edge_follow-v0", EDGE, "on", n, 1, 24, 2)
     assert s["swapped"] + s["late"] == n * 24 and s["late"] > 0, s
     same(off, aut)
+
+
+@pytest.mark.parametrize("object_mode", ["pole", "ball_on_plate"])
+def test_object_balance_reset_template_equals_recomputed_reset(object_mode):
+    """object_balance: Robot.reset drives the arm from the rest pose to a constant target under position motors that prescribe its velocity, and
+    the object is teleported afterwards - the arm's post-reset state is the same for every reset, so k_reset_body computes it once
+    (State.reset_tmpl).  Against reset_bank="off" (every reset recomputed with the fallen object still tied to the TCP) over 64 envs x 150
+    steps with auto-resets: dones, reset tick counts and rewards identical, joints within 1e-13 rad (the last-bit residue of the full solver
+    ticks of the recomputed resets), every frame within 3 pixels."""
+    import tactile_gym_amd as tg
+    modes = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode=object_mode, rand_gravity=True, rand_embed_dist=True,
+                 observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+    n, steps = 64, 150
+    actions = np.random.default_rng(23).uniform(-0.25, 0.25, size=(steps, n, 2)).astype(np.float32)
+    runs = []
+    for bank in ("auto", "off"):
+        v = tg.make_vec("object_balance-v0", num_envs=n, max_steps=60, image_size=[128, 128], env_modes=modes, seed=4100, auto_reset=True, reset_bank=bank)
+        obs = v.reset()
+        rec = dict(img=[obs["tactile"].copy()], q=[v.get_state()["q"].copy()], ticks=[v.get_state()["reset_ticks"].copy()], done=[], rew=[])
+        for s in range(steps):
+            obs, rew, done, _ = v.step(actions[s])
+            st = v.get_state()
+            rec["img"].append(obs["tactile"].copy()), rec["q"].append(st["q"].copy()), rec["ticks"].append(st["reset_ticks"].copy())
+            rec["done"].append(done.copy()), rec["rew"].append(rew.copy())
+        v.close()
+        runs.append({k: np.asarray(x) for k, x in rec.items()})
+    a, b = runs
+    assert np.array_equal(a["done"], b["done"]) and a["done"].sum() >= n
+    assert np.array_equal(a["ticks"], b["ticks"]) and np.array_equal(a["rew"], b["rew"])
+    assert np.abs(a["q"] - b["q"]).max() < 1e-13, np.abs(a["q"] - b["q"]).max()
+    assert (a["img"] != b["img"]).reshape(steps + 1, n, -1).sum(-1).max() <= 3

@@ -616,7 +616,9 @@ class ShardedVecEnv:
         if self._lay is None:
             self._setup(obs)
         if self.transport != "ipc":
-            return {k: self._gather("obs_" + k, v) for k, v in obs.items()}
+            out = {k: self._gather("obs_" + k, v) for k, v in obs.items()}
+            self._quiesce_before_capture("step", "random")   # here rather than in the first step: outside any timed region
+            return out
         # ipc: the reset observations travel like a step's message (zero reward / done), synchronously
         n = self._lay["n"]
         zr = self.torch.zeros(n, dtype=self.torch.float32, device=self._lay["dev"])
@@ -624,24 +626,26 @@ class ShardedVecEnv:
         self._drain()
         self._tick += 1
         self._send(self._tick, obs, zr, zd, False)
-        if self.rank == self.root:
-            return self._receive(self._tick)[0]
-        return obs
+        out = self._receive(self._tick)[0] if self.rank == self.root else obs
+        self._quiesce_before_capture("step", "random")
+        return out
 
     def _drain(self):
         for k in (0, 1):
             self._wait(self._pending[k])
             self._pending[k] = None
 
-    def _quiesce_before_capture(self, kind):
+    def _quiesce_before_capture(self, *kinds):
         """The first step of each kind makes the library capture its step graph (tg_step / tg_step_random).  While a HIP stream is capturing,
         hipEventQuery from ANOTHER thread can fail with hipErrorCapturedEvent, and torch's RCCL process group has such a thread: its watchdog
         polls the end events of the collectives still in its list every 100 ms, and a poll that fell into the few hundred microseconds of a
         capture aborted the process (2 of ~100 one-rank bench runs, all ranks would go down with it).  So before a capture: finish all device
-        work, then give the watchdog three periods to retire the completed collectives - it polls nothing while its list is empty."""
-        if kind in self._captured or self._solo:
+        work, then give the watchdog three periods to retire the completed collectives - it polls nothing while its list is empty.  reset()
+        does it for both kinds (outside any timed region); a step without a reset before it does it for its own kind."""
+        todo = [k for k in kinds if k not in self._captured]
+        if not todo or self._solo:
             return
-        self._captured.add(kind)
+        self._captured.update(todo)
         if not (getattr(self.local, "raw", False) and self.torch.cuda.is_available()):
             return                                   # a host-side shard (the gloo tests): nothing is captured
         import time

@@ -451,6 +451,11 @@ int tg_get_actions(tg_ctx* ctx, void** dev_actions);
  * with exponents 2^-40 .. 2^24 divided by the kernels' refinement and by the correctly rounded `/`; *mismatches = quotients whose
  * bits differ (must be 0). */
 int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches);
+/* Self-test of the raster's edge-function block test (csrc/tg_raster.hip: edges_exclude_rect - a record is skipped for a block of pixels that
+ * its triangle provably cannot cover): n pseudo-random triangles (image-sized, slivers, huge, on pixel centres, heightfield-sized) x
+ * rectangles as the kernels pass them, every pixel centre put through the pixel loops' own edge expressions.  out[0] = rectangles
+ * excluded although they hold a coverable pixel (must be 0), out[1] = rectangles excluded, out[2] = rectangles without a coverable pixel. */
+int tg_selftest_edge_exclusion(int64_t n, uint64_t seed, int64_t* out);
 
 #ifdef __cplusplus
 }

@@ -177,6 +177,7 @@ SYMBOLS = {
     "tg_get_obs_visual": (C.c_int, [_ctx, _vpp, C.c_int32]),
     "tg_copy_obs_visual": (C.c_int, [_ctx, _u8p, C.c_int32]),
     "tg_selftest_division": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
+    "tg_selftest_edge_exclusion": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
     "tg_get_obs_feature": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32), C.c_int32]),
     "tg_get_reward_done": (C.c_int, [_ctx, _fp, _u8p]),
     "tg_copy_obs_tactile": (C.c_int, [_ctx, _u8p, C.c_int32]),

@@ -1768,6 +1768,14 @@ int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches) {
     *mismatches = (int64_t)m;
     return 0;
 }
+
+int tg_selftest_edge_exclusion(int64_t n, uint64_t seed, int64_t* out) {
+    if (!out || n < 0) return fail(-1, "tg_selftest_edge_exclusion: bad argument");
+    long long m[3] = {-1, -1, -1};
+    if (tg::selftest_edge_exclusion((long long)n, (unsigned long long)seed, m) != 0) return fail(-3, "tg_selftest_edge_exclusion: launch failed");
+    out[0] = m[0]; out[1] = m[1]; out[2] = m[2];
+    return 0;
+}
 int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {
     if (!c || !p) return fail(-1, "NULL argument");
     if (!env_has_feature(c->cfg.env_kind))

@@ -1254,6 +1254,21 @@ def test_raster_division_is_correctly_rounded():
         assert m.value == 0
 
 
+def test_raster_edge_exclusion_never_hides_a_coverable_pixel():
+    """The renders skip a record for a block / cell of pixels that its TRIANGLE provably cannot cover (edges_exclude_rect).
+    2^24 pseudo-random triangle x rectangle cases per seed - image-sized, slivers, coordinates up to 1e4, vertices on pixel centres,
+    heightfield-sized - with every pixel centre of the rectangle put through the pixel loops' own expressions: the rule never excludes a
+    rectangle that holds a pixel whose three edge functions share a sign, and it does exclude most of the rectangles that hold none."""
+    import ctypes
+    from tactile_gym_amd import _capi as capi
+    for seed in (3, 20260928):
+        out = (ctypes.c_int64 * 3)(-1, -1, -1)
+        capi.check(capi.lib().tg_selftest_edge_exclusion(1 << 24, seed, out))
+        violations, excluded, empty = out[0], out[1], out[2]
+        assert violations == 0, (seed, violations)
+        assert empty > (1 << 22) and excluded > 0.9 * empty, (seed, excluded, empty)      # the rule is not vacuous: it finds >= 90 % of the empty ones
+
+
 def _run_bench(cmd, root, env, tag):
     """One bench.py child; on failure its whole stderr is kept under gpurun_out/ (a gpurun call brings it back).  That is how the cause of
     a rare SIGABRT of one-rank RCCL runs was found: the process group's watchdog thread polled an event of the caller's stream while

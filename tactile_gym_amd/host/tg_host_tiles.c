@@ -27,7 +27,25 @@
 typedef struct {
     const uint8_t *msg, *tmpl; uint8_t* dst; const int32_t* prev_ids; int64_t n_prev, count; int32_t n, H, W, T, TW;
     int32_t first_thread;               /* 0: the caller takes share 0 and waits; 1: asynchronous, the workers alone share the images */
+    int32_t by_record;                  /* 1: nothing to restore (n_prev == 0): the threads share the RECORDS - thread t scatters records
+                                         * [t count / P, (t + 1) count / P) whatever image they belong to (a tile id occurs once per message, so no two threads
+                                         * write the same byte) and writes their ids into new_ids - instead of every thread scanning all records for its images */
+    int32_t* new_ids;
 } job_t;
+
+static void run_records(const job_t* j, int64_t k_lo, int64_t k_hi) {
+    const size_t img_bytes = (size_t)j->H * j->W;
+    const int32_t T = j->T, TW = j->TW, W = j->W;
+    const uint8_t* rec = j->msg + 16 + (size_t)k_lo * TG_TILE_REC;
+    for (int64_t k = k_lo; k < k_hi; ++k, rec += TG_TILE_REC) {
+        int32_t id;
+        memcpy(&id, rec, 4);
+        const int32_t img = id / T, tile = id % T, ty = tile / TW, tx = tile % TW;
+        uint8_t* d = j->dst + (size_t)img * img_bytes + (size_t)ty * 16 * W + (size_t)tx * 16;
+        for (int r = 0; r < 16; ++r) memcpy(d + (size_t)r * W, rec + 16 + 16 * r, 16);
+        j->new_ids[k] = id;
+    }
+}
 
 static void run_range(const job_t* j, int32_t img_lo, int32_t img_hi) {
     const size_t img_bytes = (size_t)j->H * j->W;
@@ -83,8 +101,13 @@ static void* worker(void* a_) {
         if (p->stop) return NULL;
         seen = p->generation;
         __sync_synchronize();
-        int32_t lo, hi; share(p, t, &lo, &hi);
-        run_range(&p->job, lo, hi);
+        if (p->job.by_record) {
+            const int64_t c = p->job.count, P = p->n_threads;
+            run_records(&p->job, c * t / P, c * (t + 1) / P);
+        } else {
+            int32_t lo, hi; share(p, t, &lo, &hi);
+            run_range(&p->job, lo, hi);
+        }
         __sync_synchronize();
         if (__sync_sub_and_fetch(&p->pending, 1) == 0) { pthread_mutex_lock(&p->mu); pthread_cond_signal(&p->cv_done); pthread_mutex_unlock(&p->mu); }
     }
@@ -147,14 +170,15 @@ int64_t tg_host_unpack_tiles_mt(tg_host_pool* pool, const uint8_t* msg, int64_t 
         const uint8_t* rec = msg + 16;
         for (int64_t k = 0; k < count; ++k, rec += TG_TILE_REC) { int32_t id; memcpy(&id, rec, 4); if (id < 0 || id >= total) return -4; }
     }
-    job_t j = {msg, tmpl, dst, prev_ids, *n_prev, count, n, H, W, T, TW, 0};
+    job_t j = {msg, tmpl, dst, prev_ids, *n_prev, count, n, H, W, T, TW, 0, 0, prev_ids};
     if (pool && pool->n_threads > 1 && n >= pool->n_threads) {
+        j.by_record = (*n_prev == 0);      /* the restore ran ahead (tg_host_restore_begin) or the buffer is fresh: only the scatter is left */
         pool->job = j;
         pool->pending = pool->n_threads - 1;
         __sync_synchronize();
         pthread_mutex_lock(&pool->mu); pool->generation++; pthread_cond_broadcast(&pool->cv_go); pthread_mutex_unlock(&pool->mu);
-        int32_t lo, hi; share(pool, 0, &lo, &hi);
-        run_range(&pool->job, lo, hi);
+        if (j.by_record) run_records(&pool->job, 0, count / pool->n_threads);
+        else { int32_t lo, hi; share(pool, 0, &lo, &hi); run_range(&pool->job, lo, hi); }
         int spun = 0;
         while (pool->pending > 0 && spun < 20000) { if ((++spun & 15) == 0) sched_yield(); __builtin_ia32_pause(); }   /* yield: a pinned worker may need this very CPU */
         if (pool->pending > 0) { pthread_mutex_lock(&pool->mu); while (pool->pending > 0) pthread_cond_wait(&pool->cv_done, &pool->mu); pthread_mutex_unlock(&pool->mu); }
@@ -162,8 +186,10 @@ int64_t tg_host_unpack_tiles_mt(tg_host_pool* pool, const uint8_t* msg, int64_t 
     } else {
         run_range(&j, 0, n);
     }
-    const uint8_t* rec = msg + 16;
-    for (int64_t k = 0; k < count; ++k, rec += TG_TILE_REC) memcpy(&prev_ids[k], rec, 4);
+    if (!j.by_record || !(pool && pool->n_threads > 1 && n >= pool->n_threads)) {      /* (the record-sharing threads wrote the new list themselves) */
+        const uint8_t* rec = msg + 16;
+        for (int64_t k = 0; k < count; ++k, rec += TG_TILE_REC) memcpy(&prev_ids[k], rec, 4);
+    }
     *n_prev = count;
     return count;
 }
@@ -178,7 +204,7 @@ int32_t tg_host_restore_begin(tg_host_pool* pool, const uint8_t* tmpl, int32_t n
     if (n_prev < 0 || n_prev > total) return -1;
     for (int64_t k = 0; k < n_prev; ++k) if (prev_ids[k] < 0 || prev_ids[k] >= total) return -4;
     static const uint8_t empty_msg[16] = {0};
-    job_t j = {empty_msg, tmpl, dst, prev_ids, n_prev, 0, n, H, W, T, TW, 1};
+    job_t j = {empty_msg, tmpl, dst, prev_ids, n_prev, 0, n, H, W, T, TW, 1, 0, NULL};
     if (pool && pool->n_threads > 1 && n >= pool->n_threads) {
         pool->job = j;
         pool->pending = pool->n_threads - 1;

@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 10
+#define TG_ABI_VERSION 11
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -205,11 +205,19 @@ typedef struct {
      * Reward, termination and the observations ignore the ball (:426-497).  Lane mapping only.  [PARITY_ASSUMPTIONS A39] */
     int32_t balance_object;                 /* TG_BALANCE_* */
     double ball_radius, ball_mass, ball_mu, plate_radius;
+    /* edge_follow, TCP_velocity_control, f64, 128-multiple images: the env step as ONE launch (csrc/tg_fused.hip) - the wavefront that steps an
+     * env (base_tactile_env.py:166-185: apply_action .. get_observation is one chain per env) also resets it when its episode ended and draws
+     * its tactile image(s) - instead of the three dependent launches k_step -> k_reset -> render.  Same step / reset code, the block raster's
+     * arithmetic on another lane mapping: images, rewards, dones byte-identical, joint angles to the last bits (tests/test_gpu_fused_step.py).
+     * Measured SLOWER on an MI355X (56 against 43 us per step at 1024 envs), hence TG_FUSED_AUTO = off; TG_FUSED_ON opts in;
+     * the environment variable TG_FUSED_STEP (0 / 1) overrides.  tg_get_step_mode reports what runs. */
+    int32_t fused_step;                     /* TG_FUSED_* */
 } tg_config;
 
 enum { TG_BANK_AUTO = 0, TG_BANK_OFF = 1, TG_BANK_SYNC = 2, TG_BANK_ON = 3 };
 enum { TG_NARROW_CLOSED_FORM = 0, TG_NARROW_GJK_MANIFOLD = 1, TG_NARROW_GJK_SINGLE = 2 };
 enum { TG_BALANCE_POLE = 0, TG_BALANCE_BALL_ON_PLATE = 1 };
+enum { TG_FUSED_AUTO = 0, TG_FUSED_OFF = 1, TG_FUSED_ON = 2 };
 
 typedef struct tg_ctx tg_ctx;
 
@@ -257,6 +265,9 @@ int tg_get_interior_count(tg_ctx* ctx, int32_t* k);
 /* Reset bank (tg_config.reset_bank): how many auto-resets so far took a precomputed entry (*swapped) and how many were done on the spot because
  * the entry was not ready (*late); *mode = 0 bank off, 1 on, 2 on and waited for.  Synchronises the context's stream. */
 int tg_get_bank_stats(tg_ctx* ctx, int64_t* swapped, int64_t* late, int32_t* mode);
+/* How tg_step runs on this context: *mode = 1 one launch per step (tg_config.fused_step; csrc/tg_fused.hip), 0 separate step / reset / render
+ * launches; *envs_per_wavefront = envs one wavefront steps and draws in the one-launch form (0 otherwise). */
+int tg_get_step_mode(tg_ctx* ctx, int32_t* mode, int32_t* envs_per_wavefront);
 /* Self-test of the wave-mapped GJK / EPA (tg_config.narrowphase; csrc/tg_narrowphase.hpp) on n_cases placements of a convex hull against the
  * box of half extents half[3]: hulls [n_cases][n_hull][3] in the box frame (n_hull <= 1152); out [n_cases][11] = found (1 / 0), signed core
  * distance (< 0: overlap depth), unit normal from the box to the hull, witness point on the hull, witness point on the box. */

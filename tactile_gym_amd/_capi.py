@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -27,6 +27,7 @@ REWARD = {"dense": 0, "sparse": 1}
 PHYSICS = {"f64": 0, "f32": 1}
 CONTACT_MAP = {"auto": 0, "lane": 1, "wave": 2}
 RESET_BANK = {"auto": 0, "off": 1, "sync": 2, "on": 3}
+FUSED_STEP = {"auto": 0, "off": 1, "on": 2}
 NARROWPHASE = {"closed_form": 0, "gjk_manifold": 1, "gjk_single": 2}
 BALANCE_OBJECT = {"pole": 0, "ball_on_plate": 1}
 MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
@@ -104,6 +105,7 @@ class TgConfig(C.Structure):
         ("tip_cyl_pos", _d3), ("tip_cyl_rot", _d9), ("tip_cyl_half_len", C.c_double), ("tip_cyl_radius", C.c_double),
         ("contact_mapping", C.c_int32), ("reset_bank", C.c_int32), ("narrowphase", C.c_int32),
         ("balance_object", C.c_int32), ("ball_radius", C.c_double), ("ball_mass", C.c_double), ("ball_mu", C.c_double), ("plate_radius", C.c_double),
+        ("fused_step", C.c_int32),
     ]
 
 
@@ -147,6 +149,7 @@ SYMBOLS = {
     "tg_get_actions": (C.c_int, [_ctx, _vpp]),
     "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     "tg_get_bank_stats": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "tg_get_step_mode": (C.c_int, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tg_selftest_narrowphase": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tg_pack_interior": (C.c_int, [_ctx, C.c_void_p]),
     "tg_unpack_interior": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -20,6 +20,7 @@
 #include "../../include/tactile_gym_hip.h"
 #include "tg_kernels.hpp"
 #include "tg_contact_wave.h"
+#include "tg_fused.h"
 #include "tg_scene.h"
 #include "tg_noise.h"
 #include "tg_raster.h"
@@ -428,8 +429,12 @@ struct tg_ctx {
     bool profile = false;
     struct Ev { hipEvent_t a, b; int which; };
     std::vector<Ev> events;
-    double prof_ms[5] = {0, 0, 0, 0, 0};     // step, render, reset, masked render, scene camera
-    int64_t prof_n[5] = {0, 0, 0, 0, 0};
+    double prof_ms[7] = {0, 0, 0, 0, 0, 0, 0};   // step, render (k_step_render when fused), reset, masked render, scene camera, an EMPTY event pair (the
+    int64_t prof_n[7] = {0, 0, 0, 0, 0, 0, 0};   // overhead every figure before it carries), k_step_render by its own clock (first workgroup start -> last end)
+    // one launch per step (tg_fused.hip): -1 = TG_FUSED_STEP=0, 1 = TG_FUSED_STEP=1, 0 = where it measures faster (use_fused_step)
+    int fused_pref = 0;
+    unsigned long long* d_kt = nullptr;          // profiling: {min start, max end, sum of (end - start), launches} in wall_clock64 ticks
+    double wall_clock_khz = 100000.0;
 };
 
 namespace tg {
@@ -671,6 +676,9 @@ static int need_device() {
 
 // env.reset() for the masked envs: task randomisation, (surface generation), robot reset.
 // tg_sample_actions: element i of draw `counter`: 24 random bits of splitmix64 over (seed, counter, i) -> lo + (hi - lo) u, u in [0, 1)
+// profiling of k_step_render by its own clock: the launch leaves {min start, max end} of its workgroups in kt[0..1]
+__global__ void k_kt_begin(unsigned long long* kt) { kt[0] = ~0ull; kt[1] = 0ull; }
+__global__ void k_kt_end(unsigned long long* kt) { if (kt[1] > kt[0]) { kt[2] += kt[1] - kt[0]; kt[3] += 1ull; } }
 __global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, float lo, float hi, float* __restrict__ out, unsigned long long* tl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     TG_TL(tl, 0);
@@ -755,6 +763,23 @@ static bool use_arm_wave(const tg_ctx* c) {
     if (c->cfg.env_kind != TG_ENV_EDGE_FOLLOW && c->cfg.env_kind != TG_ENV_SURFACE_FOLLOW_AUTO) return false;
     if (c->cfg.physics_dtype != TG_PHYSICS_F64 || c->cfg.control_mode != TG_CONTROL_TCP_VELOCITY) return false;
     return c->cfg.contact_mapping == TG_CONTACT_MAP_WAVE;
+}
+
+// The env step as ONE launch (tg_fused.hip: k_step_render, the wavefront that steps an env draws it): edge_follow with the lane-mapped k_step
+// and the block raster.  OPT-IN (tg_config.fused_step = TG_FUSED_ON / TG_FUSED_STEP=1): measured on an MI355X it is SLOWER than the three
+// launches it replaces - 56.2 against 43.3 us per step at 1024 envs, 46.9 against 36.8 at 256, 108 against 75 at 4096
+// (profiles/r5_exp_fused_step.txt; DESIGN.md 4.1k has the why: the step code needs the SIMD's whole register file, so the draw runs on one
+// wavefront per SIMD without the occupancy the four-wavefront raster hides its latencies with, and four such wavefronts per CU slow each
+// other down by 1.7x).  Byte-identical images / rewards / dones (tests/test_gpu_fused_step.py).
+static bool use_fused_step(const tg_ctx* c) {
+    if (c->fused_pref <= 0) return false;   // TG_FUSED_AUTO: off (see above)
+    if (c->cfg.env_kind != TG_ENV_EDGE_FOLLOW || c->cfg.physics_dtype != TG_PHYSICS_F64 || c->cfg.control_mode != TG_CONTROL_TCP_VELOCITY) return false;
+    if (use_arm_wave(c) || c->scene_every_step || c->oracle_every_step) return false;   // (the scene / oracle draws sit between the step and the reset)
+    if (c->stim.kind != 0 || c->stim.n_tris > 32 || c->stim.fills_view || c->rp.blockmax == nullptr || c->rp.tmpl == nullptr) return false;
+    if (c->rp.W % 128 != 0 || c->rp.H % 128 != 0) return false;
+    static const bool blocks_off = getenv("TG_NO_BLOCK_RASTER") != nullptr;
+    if (blocks_off) return false;
+    return true;
 }
 
 static int surf_gen_mode(const tg_ctx* c) {
@@ -1118,6 +1143,8 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     TG_HIP(hipMalloc(&c->d_actions, (size_t)n * 6 * sizeof(float)));
     c->rp = make_raster_params(W, H, sensor->fov_deg, sensor->near_plane, sensor->far_plane, sensor->turn_off_border, sensor->nodef_dep);
     if (make_block_tables(c->rp, sensor->nodef_dep, sensor->nodef_gray, sensor->border_mask, n, &c->d_block_tables)) return fail(-2, "hipMalloc failed (raster block tables)");
+    c->fused_pref = cfg->fused_step == TG_FUSED_OFF ? -1 : cfg->fused_step == TG_FUSED_ON ? 1 : 0;
+    if (const char* e = getenv("TG_FUSED_STEP")) c->fused_pref = e[0] == '0' ? -1 : 1;   // A/B switch (tests, measurements)
 #ifdef TG_TL_STAMPS
     c->rp.tl = s.tl;
 #endif
@@ -1212,6 +1239,7 @@ int tg_destroy(tg_ctx* c) {
     for (int k = 0; k < 2; ++k) if (c->step_graph[k]) (void)hipGraphExecDestroy(c->step_graph[k]);
     if (c->random_graph) (void)hipGraphExecDestroy(c->random_graph);
     if (c->d_draw) (void)hipFree(c->d_draw);
+    if (c->d_kt) (void)hipFree(c->d_kt);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
@@ -1267,6 +1295,17 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
 }
 
 static void enqueue_step(tg_ctx* c, const float* d_act) {
+    if (c->profile) { Timer t(c, 5); }   // an empty event pair: what every per-kernel figure of this mode carries on top of its kernel
+    if (use_fused_step(c)) {
+        Timer t(c, 1);
+        unsigned long long* kt = c->profile ? c->d_kt : nullptr;
+        if (kt) hipLaunchKernelGGL(k_kt_begin, dim3(1), dim3(1), 0, c->stream, kt);
+        const int rc = launch_step_render(c->robot.topology, c->cfg.num_envs, c->stream, c->d_robot, c->d_const, c->st, d_act, c->cfg.auto_reset,
+                                          c->bank_mode != 0 ? c->d_bank : nullptr, c->rp, c->stim, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_obs,
+                                          c->d_term, kt);
+        if (kt) hipLaunchKernelGGL(k_kt_end, dim3(1), dim3(1), 0, c->stream, kt);
+        if (rc == 0) return;
+    }
     {
         Timer t(c, 0);
         if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
@@ -1402,7 +1441,7 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
 int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restart) {
     if (!c) return fail(-1, "tg_step_random: NULL argument");
     TG_ENTER(c);
-    if (!c->d_draw) { TG_HIP(hipMalloc(&c->d_draw, 32)); restart = 1; }
+    if (!c->d_draw) { TG_HIP(hipMalloc(&c->d_draw, tg::kDrawWords * 8)); TG_HIP(hipMemset(c->d_draw, 0, tg::kDrawWords * 8)); restart = 1; }
     if (restart || seed != c->random_seed) {
         const unsigned long long h[4] = {first_draw, seed, 0ull, 0ull};    // the next step uses draw first_draw + 1
         TG_HIP(hipMemcpyAsync(c->d_draw, h, 32, hipMemcpyHostToDevice, c->stream));
@@ -1453,6 +1492,13 @@ int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restar
     enqueue_step(c, c->d_actions);
     bank_refill(c);
     TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_get_step_mode(tg_ctx* c, int32_t* mode, int32_t* envs_per_wavefront) {
+    if (!c || !mode) return fail(-1, "NULL argument");
+    *mode = use_fused_step(c) ? 1 : 0;
+    if (envs_per_wavefront) *envs_per_wavefront = *mode ? fused_envs_per_wave(c->cfg.num_envs) : 0;
     return 0;
 }
 
@@ -1915,13 +1961,35 @@ int tg_profile_enable(tg_ctx* c, int32_t enable) {
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
     c->profile = enable != 0;
-    for (int k = 0; k < 5; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    for (int k = 0; k < 7; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    if (enable && !c->d_kt) {
+        TG_HIP(hipMalloc(&c->d_kt, 128));
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
+    }
+    if (c->d_kt) TG_HIP(hipMemset(c->d_kt, 0, 128));
     return 0;
 }
 int tg_profile_get(tg_ctx* c, int32_t which, double* total_ms, int64_t* launches) {
-    if (!c || which < 0 || which > 4) return fail(-1, "bad argument");
+    if (!c || which < 0 || which > 6) return fail(-1, "bad argument");
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
+    if (which == 6) {   // k_step_render by its own clock
+        unsigned long long h[4] = {0, 0, 0, 0};
+        if (c->d_kt) TG_HIP(hipMemcpy(h, c->d_kt, 32, hipMemcpyDeviceToHost));
+#ifdef TG_FUSED_STAMPS
+        if (c->d_kt) {
+            unsigned long long g[16];
+            TG_HIP(hipMemcpy(g, c->d_kt, 128, hipMemcpyDeviceToHost));
+            const double wg = (double)(g[12] ? g[12] : 1), tick_us = 1e3 / c->wall_clock_khz;
+            fprintf(stderr, "k_step_render phases (us): step+reset mean %.2f max %.2f | draw mean %.2f max %.2f | start skew mean %.2f | %llu workgroup-launches, whole launch mean %.2f\n",
+                    g[8] / wg * tick_us, g[9] * tick_us, g[10] / wg * tick_us, g[11] * tick_us, g[13] / wg * tick_us, g[12], h[3] ? (double)h[2] / h[3] * tick_us : 0.0);
+        }
+#endif
+        if (total_ms) *total_ms = (double)h[2] / c->wall_clock_khz;
+        if (launches) *launches = (int64_t)h[3];
+        return 0;
+    }
     if (total_ms) *total_ms = c->prof_ms[which];
     if (launches) *launches = c->prof_n[which];
     return 0;

@@ -600,16 +600,12 @@ __device__ __forceinline__ void encode_arm_actions(const EnvConst<T>& c, const S
 // ------------------------------------------------------------------------------------------------ step kernel
 // BaseTactileEnv.step (base_tactile_env.py:166-185): encode + scale the action, tcp_velocity_control
 // (base_robot_arm.py:281-332), action_repeat sim ticks (robot.py:182-183), reward / done, render transform.
+// One env's step, one lane (k_step: 64 consecutive envs per wavefront; k_step_render in tg_fused.hip: the envs of one render wavefront).
+// Returns whether this step ran a full solve (development stamps only).
 template <typename T, int TOPO>
-__global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                             const float* __restrict__ actions) {
+__device__ __forceinline__ bool step_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const float* __restrict__ actions) {
     constexpr int N = Topo<TOPO>::N;
-    const DevRobot<T>& m = *mp;
-    const EnvConst<T>& c = *cp;
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = c.num_envs;
-    TG_TL(st.tl, 1);
-    if (env >= n) return;
     TG_KSTAMP(0)
     T q[N], qd[N];
 #pragma unroll
@@ -706,16 +702,47 @@ __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp,
     for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = (double)trig.s[i]; st.trig_sc[(8 + i) * n + env] = (double)trig.c[i]; }
     TG_KSTAMP(4)
     finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
-    if (st.draw != nullptr) {            // every lane of every workgroup has read the counter long ago: the last workgroup to get here moves it on
+    return ran_full;
+}
+// tg_step_random: every lane of every workgroup has read the draw counter long ago: the last workgroup to get here moves it on
+// (st.draw: kDrawWords words - [0] counter, [1] seed, [2] ticket, [16 + 16 g] ticket of workgroup group g, each on a 128-byte line of its own;
+//  a launch of many workgroups - k_step_render: one per env - elects in two levels.)  No fence: a workgroup takes its ticket after it has USED
+//  the counter value it read (its actions are computed), so the last ticket holder's store cannot reach any of those loads, and the next
+//  launch sees the store across the kernel boundary.  An agent-scope fence here is an L2 write-back + invalidate on a multi-XCD part: with one
+//  workgroup per env it cost 22 us per launch (profiles/r5_exp_fused_step.txt).
+constexpr int kDrawGroups = 32, kDrawWords = 16 + 16 * kDrawGroups;
+__device__ __forceinline__ void draw_counter_advance(const State& st) {
+    if (st.draw != nullptr) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(st.draw + 2, 1ull) == (unsigned long long)gridDim.x - 1) { st.draw[2] = 0ull; st.draw[0] = st.draw[0] + 1; }
+            bool last = true;
+            if (gridDim.x > 2 * kDrawGroups) {
+                const unsigned g = blockIdx.x % kDrawGroups;
+                const unsigned long long members = (gridDim.x - g + kDrawGroups - 1) / kDrawGroups;
+                unsigned long long* tk = st.draw + 16 + 16 * g;
+                last = atomicAdd(tk, 1ull) == members - 1;
+                if (last) { atomicExch(tk, 0ull); last = atomicAdd(st.draw + 2, 1ull) == (unsigned long long)kDrawGroups - 1; }
+            } else {
+                last = atomicAdd(st.draw + 2, 1ull) == (unsigned long long)gridDim.x - 1;
+            }
+            if (last) { atomicExch(st.draw + 2, 0ull); atomicAdd(st.draw + 0, 1ull); }
         }
     }
+}
+
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                             const float* __restrict__ actions) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    TG_TL(st.tl, 1);
+    if (env >= cp->num_envs) return;
+    const bool ran_full = step_env<T, TOPO>(*mp, *cp, st, env, actions);
+    draw_counter_advance(st);
     TG_KSTAMP(9)
 #ifdef TG_KSTEP_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) g_kstep_stamps[15] = ran_full ? 1 : 0;
+#else
+    (void)ran_full;
 #endif
 }
 
@@ -1030,14 +1057,11 @@ __device__ __forceinline__ void bank_swap_in(const EnvConst<T>& c, const State& 
 // bd != nullptr  auto-reset inside tg_step with the bank: a finished env whose bank entry belongs to its current RNG state takes it, any other
 //                finished env is reset on the spot.  surface_follow (phase 1, k_gen_surface, phase 2): phase 1 leaves swapped[env] / late[env]
 //                for the two launches behind it, which clear them again (both masks are all zero between steps).
+// (the body of k_reset for one env that is to be reset; in_step: auto-reset inside tg_step)
 template <typename T, int TOPO>
-__global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                              const uint8_t* __restrict__ mask, int phase, const BankDev* __restrict__ bd) {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    TG_TL(st.tl, 2);
-    if (env >= cp->num_envs) return;
-    if (mask != nullptr && mask[env] == 0) return;
-    if (cp->fused_reset && mask != nullptr) {   // auto-reset inside tg_step: keep the terminal observation's camera transform; the render
+__device__ __forceinline__ void reset_or_swap(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, const State& st, int env,
+                                              bool in_step, int phase, const BankDev* __restrict__ bd) {
+    if (cp->fused_reset && in_step) {           // auto-reset inside tg_step: keep the terminal observation's camera transform; the render
         const int n = cp->num_envs;             // launch that follows draws both images of this env
 #pragma unroll
         for (int k = 0; k < 12; ++k) st.term_xform[k * n + env] = st.stim_xform[k * n + env];
@@ -1059,6 +1083,15 @@ __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp
     }
     reset_env<T, TOPO>(*mp, *cp, st, env, phase);
     if (bd != nullptr && phase == 2) bd->aux.late[env] = 0;
+}
+template <typename T, int TOPO>
+__global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                              const uint8_t* __restrict__ mask, int phase, const BankDev* __restrict__ bd) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    TG_TL(st.tl, 2);
+    if (env >= cp->num_envs) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    reset_or_swap<T, TOPO>(mp, cp, st, env, mask != nullptr, phase, bd);
 }
 
 // The refill (second stream, outside the step graph): for every env whose bank entry does not belong to its current RNG state, the same

@@ -33,19 +33,10 @@
 #include <cstdio>
 #include <vector>
 
-#include "tg_raster.h"
+#include "tg_raster_dev.hpp"
 
 namespace tg {
 
-struct TriRec {      // projected triangle, window coordinates + depth
-    float x0, y0, d0, x1, y1, d1, x2, y2, d2;
-    float ymin, ymax, xmin, xmax, dmin;
-};
-
-// Depth culling margin.  The interpolated depth ((e0 d0 + e1 d1) + e2 d2) / s has same-signed weights, so it lies within
-// ~6 roundings (< 4e-7 for d <= 1.01) of the convex hull [min d_k, max d_k]; a triangle whose min d_k exceeds a z value
-// by more than kDepthSlack can therefore never pass `d < z` there.  Skipping it does not change the image.
-constexpr float kDepthSlack = 2e-6f;
 
 // The per-quad edge-function reject of k_render_tactile's pixel loop (a conservative cull, the image does not depend on it): off - it saves
 // fewer instructions than its registers and its ~45 instructions per record x quad row cost (surface_follow render 66.4 -> 62.3 us without;
@@ -59,16 +50,12 @@ constexpr bool kHfQuadReject = false;
 #define TG_HF_WAVES 3   // 3 wavefronts per SIMD for the 128 x 64 heightfield kernel (167 VGPRs, 64 B of scratch): 0.098 -> 0.078 ms; needs its windowed LDS (< 53 KB)
 #endif
 constexpr int kThreads = 256;
-#ifndef TG_EDGE_REACH
-#define TG_EDGE_REACH 1
-#endif
 #ifndef TG_EDGE_CELL_MAX
 #define TG_EDGE_CELL_MAX 256
 #endif
 constexpr int kEdgeCellMax = TG_EDGE_CELL_MAX;   // heightfield: the per-record cell test costs ~80 vector instructions per record on one wavefront; it pays while the records are few
                                     // (DIGIT on the horizontal surface: 56 us against 63), not for a view of hundreds (TacTip on the vertical one: 159 against 126)
 constexpr int kCellsWinSide = 24;   // heightfield window (launch_render) up to which the cell masks are used: DIGIT 16, DigiTac 18 (TacTip: 32)
-constexpr bool kEdgeReach = TG_EDGE_REACH != 0;   // A/B build switch for the edge-function block test (edges_exclude_rect)
 constexpr int kBatch = 1024;         // most triangle records staged in LDS per pass (56 KB); a small mesh allocates 2 * n_tris records only, so
                                      // that the 12-triangle edge does not hold the occupancy at 2 workgroups per CU (LDS-bound)
 
@@ -119,115 +106,6 @@ int make_block_tables(RasterParams& P, const float* nodef_dep_host, const float*
     return 0;
 }
 
-// a / b rounded like the IEEE division the specification (and the oracle's C `/`) prescribes, for operands whose exponents are far from the
-// ends of the range (pixel-space edge functions: 1e-12 .. 1e6): the refinement the compiler's own expansion performs - reciprocal, one
-// Newton step on it, the product and two residual corrections - without the operand pre-scaling, the denormal-mode switches and the
-// special-case fix-up that only matter beyond 2^+-96.  The result is discarded by the caller when b == 0.
-__device__ __forceinline__ float div_mid_range(float a, float b) {
-    float y = __builtin_amdgcn_rcpf(b);
-    y = __builtin_fmaf(__builtin_fmaf(-b, y, 1.0f), y, y);
-    float q = a * y;
-    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
-    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
-    return q;
-}
-
-__device__ __forceinline__ void project_vertex(float cx, float cy, float cw, const RasterParams& P, float& sx, float& sy, float& d) {
-    float iw = 1.0f / cw;
-    sx = P.hw + P.kx * (cx * iw);
-    sy = P.hh - P.ky * (cy * iw);
-    d = P.C0 + P.C1 * iw;
-}
-
-// Back-face test in eye space (eye at the origin, x right, y up, -z forward; v_k = (cx, cy, -cw)).  For a stimulus made of closed,
-// consistently outward-wound surfaces (Stimulus::closed_outward, verified on the host) that lies entirely beyond the near plane, a ray
-// from the eye enters every solid through a front face before it leaves it through a back face, so a back face can never win the depth
-// test: dropping it at set-up leaves the image as it is.  (The pixel predicates agree: the edge function of a shared edge is exactly
-// antisymmetric in its two vertices, so a pixel centre is on the solid's side of a silhouette edge for the front face and the back face
-// alike.)  Faces within 1e-4 rad of edge-on are kept.  `cull` is wave-uniform per env: closed_outward and no vertex with w < near.
-__device__ __forceinline__ bool back_facing(const float* cx, const float* cy, const float* cw) {
-    const float ax = cx[1] - cx[0], ay = cy[1] - cy[0], az = -(cw[1] - cw[0]);
-    const float bx = cx[2] - cx[0], by = cy[2] - cy[0], bz = -(cw[2] - cw[0]);
-    const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
-    const float nv = (nx * cx[0] + ny * cy[0]) + nz * (-cw[0]);                       // n . v0: > 0 = the outward normal points away from the eye
-    const float nn = (nx * nx + ny * ny) + nz * nz, vv = (cx[0] * cx[0] + cy[0] * cy[0]) + cw[0] * cw[0];
-    return nv > 0.0f && nv * nv > 1e-8f * (nn * vv);
-}
-// All three vertices of triangle t at or beyond the near plane?  (the per-env vote that licenses the back-face cull)
-__device__ __forceinline__ bool tri_beyond_near(const float* __restrict__ soup, int t, const float* M, float near_) {
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float* v = soup + 9 * t + 3 * k;
-        ok = ok && (-(((M[6] * v[0] + M[7] * v[1]) + M[8] * v[2]) + M[11]) >= near_);
-    }
-    return ok;
-}
-
-// Returns false when the record buffer is full (nothing written): the caller restarts from this triangle in the next round.
-// rbands (banded lane mapping only): per record, bit b = the bounding box reaches pixel centres of the tile's b-th 32-pixel column band.
-__device__ __forceinline__ bool emit(TriRec* recs, int* count, int cap, const float* vx, const float* vy, const float* vw, int a, int b, int c,
-                                     const RasterParams& P, float tx0, float ty0, float tx1, float ty1, unsigned* rbands = nullptr) {
-    TriRec r;
-    project_vertex(vx[a], vy[a], vw[a], P, r.x0, r.y0, r.d0);
-    project_vertex(vx[b], vy[b], vw[b], P, r.x1, r.y1, r.d1);
-    project_vertex(vx[c], vy[c], vw[c], P, r.x2, r.y2, r.d2);
-    r.xmin = fminf(r.x0, fminf(r.x1, r.x2)); r.xmax = fmaxf(r.x0, fmaxf(r.x1, r.x2));
-    r.ymin = fminf(r.y0, fminf(r.y1, r.y2)); r.ymax = fmaxf(r.y0, fmaxf(r.y1, r.y2));
-    r.dmin = fminf(r.d0, fminf(r.d1, r.d2)) - kDepthSlack;
-    // conservative culls: outside this workgroup's tile, or entirely behind the undeformed skin/body depth image
-    if (r.xmax < tx0 || r.xmin > tx1 || r.ymax < ty0 || r.ymin > ty1) return true;
-    if (r.dmin >= P.zcull) return true;
-    const int slot = atomicAdd(count, 1);
-    if (slot >= cap) return false;
-    recs[slot] = r;
-    if (rbands != nullptr) {
-        unsigned bands = 0u;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)   // band bb holds pixel centres tx0 + 32 bb + 0.5 .. + 31.5; coverage needs xmin <= fx <= xmax
-            bands |= (r.xmax >= tx0 + 32.0f * (float)bb + 0.5f && r.xmin <= tx0 + 32.0f * (float)bb + 31.5f) ? (1u << bb) : 0u;
-        // bits 4..: the row groups (8 rows each: one pass of the banded mapping) whose pixel centres the bounding box can reach
-        const float ylo = (r.ymin - ty0 - 7.5f) * 0.125f, yhi = (r.ymax - ty0 - 0.5f) * 0.125f;
-        int k_lo = (int)ceilf(ylo), k_hi = (int)floorf(yhi);
-        k_lo = k_lo < 0 ? 0 : k_lo; k_hi = k_hi > 27 ? 27 : k_hi;
-        const unsigned rows = k_hi >= k_lo ? (((k_hi - k_lo + 1 >= 28) ? 0xFFFFFFFu : ((1u << (k_hi - k_lo + 1)) - 1u)) << k_lo) : 0u;
-        rbands[slot] = bands | (rows << 4);
-    }
-    return true;
-}
-
-// Can the record cover ANY pixel centre of the rectangle [X0, X1] x [Y0, Y1] (first / last pixel centres of a block)?  A pixel is
-// covered only if its three computed edge functions e_i are all >= 0 or all <= 0 (the `pos | neg` of the pixel loops).  In exact
-// arithmetic E_i is affine in (fx, fy), so over the rectangle it is extremal at a corner, and E_0 + E_1 + E_2 = S is the same everywhere
-// (twice the signed area).  The computed e_i (two differences, two products, one difference: the pixel loops' expression) differs from E_i
-// by at most m_i = 1e-5 (B_j A_k + B_k A_j) with B, A the largest |x - fx|, |y - fy| over the rectangle - 40 times the worst-case
-// rounding of that expression (4 x 2^-24).  Hence:  some edge with max over the corners of e_i < -2 m_i  ->  e_i < 0 at every pixel, no
-// pixel is `pos`;  S certainly > sum m_i (computed sum at a corner > 2 sum m_i)  ->  the three e_i cannot all be <= 0 anywhere, no pixel
-// is `neg`; and the mirror images.  Returns true when both are excluded: skipping the record for this rectangle changes no pixel.
-// NaN / inf coordinates compare false everywhere: not excluded.  (What it buys: the two coplanar triangles of a box face or of the plate
-// both have the face as bounding box and depth plane, and each covers half of it.)
-__device__ __forceinline__ bool edges_exclude_rect(float x0, float y0, float x1, float y1, float x2, float y2, float X0, float X1, float Y0, float Y1) {
-    const float B0 = fmaxf(fabsf(x0 - X0), fabsf(x0 - X1)), B1 = fmaxf(fabsf(x1 - X0), fabsf(x1 - X1)), B2 = fmaxf(fabsf(x2 - X0), fabsf(x2 - X1));
-    const float A0 = fmaxf(fabsf(y2 - Y0), fabsf(y2 - Y1)), A1 = fmaxf(fabsf(y1 - Y0), fabsf(y1 - Y1)), A2 = fmaxf(fabsf(y0 - Y0), fabsf(y0 - Y1));
-    const float m0 = 1e-5f * (B1 * A0 + B2 * A1), m1 = 1e-5f * (B2 * A2 + B0 * A0), m2 = 1e-5f * (B0 * A1 + B1 * A2);
-    float hi0 = -3.0e38f, hi1 = -3.0e38f, hi2 = -3.0e38f, lo0 = 3.0e38f, lo1 = 3.0e38f, lo2 = 3.0e38f, s_lo = 3.0e38f, s_hi = -3.0e38f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float fx = (c & 1) ? X1 : X0, fy = (c & 2) ? Y1 : Y0;
-        const float a0 = y2 - fy, a1 = y1 - fy, a2 = y0 - fy;
-        const float e0 = (x1 - fx) * a0 - (x2 - fx) * a1;
-        const float e1 = (x2 - fx) * a2 - (x0 - fx) * a0;
-        const float e2 = (x0 - fx) * a1 - (x1 - fx) * a2;
-        hi0 = fmaxf(hi0, e0); hi1 = fmaxf(hi1, e1); hi2 = fmaxf(hi2, e2);
-        lo0 = fminf(lo0, e0); lo1 = fminf(lo1, e1); lo2 = fminf(lo2, e2);
-        const float sc = (e0 + e1) + e2;
-        s_lo = fminf(s_lo, sc); s_hi = fmaxf(s_hi, sc);
-    }
-    const float M2 = 2.0f * ((m0 + m1) + m2);
-    const bool no_pos = (hi0 < -2.0f * m0) | (hi1 < -2.0f * m1) | (hi2 < -2.0f * m2) | (s_hi < -M2);
-    const bool no_neg = (lo0 > 2.0f * m0) | (lo1 > 2.0f * m1) | (lo2 > 2.0f * m2) | (s_lo > M2);
-    return no_pos & no_neg;
-}
 
 // grid: (tiles_x * tiles_y, num_envs, 1 or 2); block: 256.  TW x TH = tile (128 x 128; 128 x 64 for small meshes: half the rows
 // per lane halves the z-buffer registers, 4 instead of 2 workgroups fit a CU, and the per-workgroup set-up of a dozen triangles is

@@ -235,6 +235,13 @@ class TactileVecEnv(_VecEnvBase):
         capi.check(self._L.tg_get_bank_stats(self._ctx, C.byref(sw), C.byref(late), C.byref(mode)))
         return {"mode": ("off", "on", "sync")[mode.value], "swapped": int(sw.value), "late": int(late.value)}
 
+    def step_mode(self):
+        """"fused": the env step is one launch (csrc/tg_fused.hip: the wavefront that steps an env resets and draws it; `fused_step`); "separate":
+        step, reset and render are launches of their own."""
+        mode, epw = C.c_int32(), C.c_int32()
+        capi.check(self._L.tg_get_step_mode(self._ctx, C.byref(mode), C.byref(epw)))
+        return "fused" if mode.value else "separate"
+
     def sample_actions(self, out, seed, counter):
         """action_space.sample() for the whole batch on the device (tg_sample_actions): fills the torch CUDA float32 tensor `out`
         [N, act_dim] with U[min_action, max_action) draws that depend on (seed, counter, element) only; enqueued on the env's stream."""
@@ -604,7 +611,7 @@ class TactileVecEnv(_VecEnvBase):
 
     def profile_get(self):
         out = {}
-        for which, name in enumerate(("step", "render", "reset", "render_masked", "scene")):
+        for which, name in enumerate(("step", "render", "reset", "render_masked", "scene", "empty_event_pair", "fused_kernel_clock")):
             ms, cnt = C.c_double(), C.c_int64()
             capi.check(self._L.tg_profile_get(self._ctx, which, C.byref(ms), C.byref(cnt)))
             out[name] = (ms.value, cnt.value)

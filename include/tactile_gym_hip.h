@@ -387,8 +387,12 @@ int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */
 int tg_set_joint_state(tg_ctx* ctx, const double* q, const double* qd);
 
-/* Per-kernel timing with HIP events on the launch stream (bench.py roofline leg). which: 0 step, 1 render (all envs),
- * 2 reset, 3 render (masked: reset / auto-reset envs only). */
+/* Per-kernel timing (bench.py's roofline leg).  enable = 1: HIP event pairs around every launch class on the launch stream, the step's launches
+ * issued one by one (no graph); every figure carries what an EMPTY event pair measures (3 - 5 us).  enable = 2: only the kernels' own clock
+ * (csrc/tg_kt.hpp: every wavefront stamps its start and end, wall_clock64; first start -> last end per class), the step stays one hipGraph -
+ * the figures of the rollout itself.  enable = 0: off (the next step captures its graph again).
+ * tg_profile_get which: 0 step kernel, 1 render of all envs (the one launch of a fused step), 2 reset sequence, 3 masked render (reset /
+ * auto-reset envs only), 4 scene camera, 5 an empty event pair - by HIP events; 8 + k (k = 0 .. 3): class k by the kernels' own clock. */
 int tg_profile_enable(tg_ctx* ctx, int32_t enable);
 int tg_profile_get(tg_ctx* ctx, int32_t which, double* total_ms, int64_t* launches);
 

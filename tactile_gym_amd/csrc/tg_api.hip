@@ -426,14 +426,18 @@ struct tg_ctx {
     std::vector<void*> bank_allocs;
     void* d_bank = nullptr;            // BankDev {bk, aux} in device memory (k_reset's argument)
     // profiling
-    bool profile = false;
+    bool profile = false;          // tg_profile_enable(1): HIP event pairs around every launch class, no graph
+    bool profile_clock = false;    // tg_profile_enable(2): the kernels' own clock only (tg_kt.hpp): the step stays ONE graph, reduce nodes behind its scopes
     struct Ev { hipEvent_t a, b; int which; };
     std::vector<Ev> events;
-    double prof_ms[7] = {0, 0, 0, 0, 0, 0, 0};   // step, render (k_step_render when fused), reset, masked render, scene camera, an EMPTY event pair (the
-    int64_t prof_n[7] = {0, 0, 0, 0, 0, 0, 0};   // overhead every figure before it carries), k_step_render by its own clock (first workgroup start -> last end)
+    double prof_ms[6] = {0, 0, 0, 0, 0, 0};      // HIP events: step, render (k_step_render when fused), reset sequence, masked render, scene camera, an EMPTY
+    int64_t prof_n[6] = {0, 0, 0, 0, 0, 0};      // event pair (what every figure before it carries on top of its kernels)
     // one launch per step (tg_fused.hip): -1 = TG_FUSED_STEP=0, 1 = TG_FUSED_STEP=1, 0 = where it measures faster (use_fused_step)
     int fused_pref = 0;
-    unsigned long long* d_kt = nullptr;          // profiling: {min start, max end, sum of (end - start), launches} in wall_clock64 ticks
+    // profiling by the kernels' own clock (tg_kt.hpp): per-wavefront {start, end} slots, reduced after every timed scope into {ticks, scopes}
+    unsigned long long* d_kt = nullptr;          // [kt_slots][2]
+    unsigned long long* d_kt_acc = nullptr;      // [8][2]
+    size_t kt_slots = 0;
     double wall_clock_khz = 100000.0;
 };
 
@@ -479,13 +483,42 @@ static inline bool env_has_feature(int env_kind) {   // envs with an extended_fe
 
 namespace tg {
 
+// first wavefront start -> last wavefront end over the slots written since the last reduce, added to acc; the slots are cleared for the next scope
+__global__ __launch_bounds__(1024) void k_kt_reduce(unsigned long long* __restrict__ slots, size_t n_slots, unsigned long long* __restrict__ acc) {
+    __shared__ unsigned long long lo[1024], hi[1024];
+    unsigned long long a = ~0ull, b = 0ull;
+    for (size_t i = threadIdx.x; i < n_slots; i += 1024) {
+        const unsigned long long s0 = slots[2 * i], s1 = slots[2 * i + 1];
+        if (s0 != ~0ull || s1 != 0ull) { slots[2 * i] = ~0ull; slots[2 * i + 1] = 0ull; }
+        if (s0 != ~0ull) a = s0 < a ? s0 : a;
+        if (s1 != 0ull) b = s1 > b ? s1 : b;
+    }
+    lo[threadIdx.x] = a; hi[threadIdx.x] = b;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            lo[threadIdx.x] = lo[threadIdx.x + k] < lo[threadIdx.x] ? lo[threadIdx.x + k] : lo[threadIdx.x];
+            hi[threadIdx.x] = hi[threadIdx.x + k] > hi[threadIdx.x] ? hi[threadIdx.x + k] : hi[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && hi[0] > lo[0] && lo[0] != ~0ull) { acc[0] += hi[0] - lo[0]; acc[1] += 1ull; }
+}
+
+// A timed scope of profiling mode (tg_profile_enable): a HIP event pair around the launches, and - for the kernels that carry a KtScope - their
+// span by their own clock.
 struct Timer {
     tg_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
     Timer(tg_ctx* ctx, int w) : c(ctx), which(w) {
+        if ((c->profile || c->profile_clock) && c->d_kt && which < 5) { c->st.kt = c->d_kt; c->rp.kt = c->d_kt; }
         if (c->profile) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
     }
     ~Timer() {
         if (c->profile) { (void)hipEventRecord(b, c->stream); c->events.push_back({a, b, which}); }
+        if ((c->profile || c->profile_clock) && c->d_kt && which < 5) {
+            hipLaunchKernelGGL(k_kt_reduce, dim3(1), dim3(1024), 0, c->stream, c->d_kt, c->kt_slots, c->d_kt_acc + 2 * which);
+            c->st.kt = nullptr; c->rp.kt = nullptr;
+        }
     }
 };
 
@@ -514,6 +547,7 @@ template <typename T, int TOPO> static void launch_reset_t(tg_ctx* c, const uint
     const int n = c->cfg.num_envs;
     hipLaunchKernelGGL((k_reset<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
                        (const EnvConst<T>*)c->d_const, c->st, d_mask, phase, bank ? (const BankDev*)c->d_bank : (const BankDev*)nullptr);
+    if (c->st.kt) c->st.kt += 2 * (size_t)((n + 63) / 64);   // profiling: a second k_reset of the same scope (surface_follow's phase 2) stamps its own slots
 }
 template <typename T, int TOPO> static void launch_bank_refill_t(tg_ctx* c, int phase) {
     const int n = c->cfg.num_envs;
@@ -676,9 +710,6 @@ static int need_device() {
 
 // env.reset() for the masked envs: task randomisation, (surface generation), robot reset.
 // tg_sample_actions: element i of draw `counter`: 24 random bits of splitmix64 over (seed, counter, i) -> lo + (hi - lo) u, u in [0, 1)
-// profiling of k_step_render by its own clock: the launch leaves {min start, max end} of its workgroups in kt[0..1]
-__global__ void k_kt_begin(unsigned long long* kt) { kt[0] = ~0ull; kt[1] = 0ull; }
-__global__ void k_kt_end(unsigned long long* kt) { if (kt[1] > kt[0]) { kt[2] += kt[1] - kt[0]; kt[3] += 1ull; } }
 __global__ void k_sample_actions(int total, uint64_t seed, uint64_t counter, float lo, float hi, float* __restrict__ out, unsigned long long* tl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     TG_TL(tl, 0);
@@ -1240,6 +1271,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->random_graph) (void)hipGraphExecDestroy(c->random_graph);
     if (c->d_draw) (void)hipFree(c->d_draw);
     if (c->d_kt) (void)hipFree(c->d_kt);
+    if (c->d_kt_acc) (void)hipFree(c->d_kt_acc);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
                     s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
@@ -1298,12 +1330,9 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     if (c->profile) { Timer t(c, 5); }   // an empty event pair: what every per-kernel figure of this mode carries on top of its kernel
     if (use_fused_step(c)) {
         Timer t(c, 1);
-        unsigned long long* kt = c->profile ? c->d_kt : nullptr;
-        if (kt) hipLaunchKernelGGL(k_kt_begin, dim3(1), dim3(1), 0, c->stream, kt);
         const int rc = launch_step_render(c->robot.topology, c->cfg.num_envs, c->stream, c->d_robot, c->d_const, c->st, d_act, c->cfg.auto_reset,
                                           c->bank_mode != 0 ? c->d_bank : nullptr, c->rp, c->stim, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_obs,
-                                          c->d_term, kt);
-        if (kt) hipLaunchKernelGGL(k_kt_end, dim3(1), dim3(1), 0, c->stream, kt);
+                                          c->d_term);
         if (rc == 0) return;
     }
     {
@@ -1960,34 +1989,40 @@ int tg_profile_enable(tg_ctx* c, int32_t enable) {
     if (!c) return fail(-1, "NULL ctx");
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
-    c->profile = enable != 0;
-    for (int k = 0; k < 7; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    c->profile = enable == 1;
+    if (c->profile_clock != (enable == 2)) {
+        // the step graphs carry the slot pointer (or its absence) in their kernel arguments: captured again on the next step
+        for (int k = 0; k < 2; ++k) if (c->step_graph[k]) { (void)hipGraphExecDestroy(c->step_graph[k]); c->step_graph[k] = nullptr; }
+        if (c->random_graph) { (void)hipGraphExecDestroy(c->random_graph); c->random_graph = nullptr; }
+        c->profile_clock = enable == 2;
+    }
+    for (int k = 0; k < 6; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     if (enable && !c->d_kt) {
-        TG_HIP(hipMalloc(&c->d_kt, 128));
+        // slots for the largest launch of this context: a render of every env's image in 64-row tiles, two passes, four wavefronts each
+        const size_t n = (size_t)c->cfg.num_envs;
+        c->kt_slots = std::max<size_t>(n + 64, (size_t)((c->rp.W + 63) / 64) * (size_t)((c->rp.H + 63) / 64) * n * 8);
+        TG_HIP(hipMalloc(&c->d_kt, c->kt_slots * 16));
+        TG_HIP(hipMalloc(&c->d_kt_acc, 8 * 16));
+        std::vector<unsigned long long> init(c->kt_slots * 2);
+        for (size_t i = 0; i < c->kt_slots; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+        TG_HIP(hipMemcpy(c->d_kt, init.data(), c->kt_slots * 16, hipMemcpyHostToDevice));
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
     }
-    if (c->d_kt) TG_HIP(hipMemset(c->d_kt, 0, 128));
+    if (c->d_kt_acc) TG_HIP(hipMemset(c->d_kt_acc, 0, 8 * 16));
     return 0;
 }
+// which: 0 step kernel, 1 render (the one launch of a fused step), 2 reset sequence, 3 masked render, 4 scene camera, 5 an empty event pair: by
+// HIP events on the launch stream; 8 + k (k = 0 .. 3): class k by the kernels' own clock (tg_kt.hpp: first wavefront start -> last wavefront end).
 int tg_profile_get(tg_ctx* c, int32_t which, double* total_ms, int64_t* launches) {
-    if (!c || which < 0 || which > 6) return fail(-1, "bad argument");
+    if (!c || which < 0 || (which > 5 && which < 8) || which > 11) return fail(-1, "bad argument");
     (void)hipStreamSynchronize(c->stream);
     drain_events(c);
-    if (which == 6) {   // k_step_render by its own clock
-        unsigned long long h[4] = {0, 0, 0, 0};
-        if (c->d_kt) TG_HIP(hipMemcpy(h, c->d_kt, 32, hipMemcpyDeviceToHost));
-#ifdef TG_FUSED_STAMPS
-        if (c->d_kt) {
-            unsigned long long g[16];
-            TG_HIP(hipMemcpy(g, c->d_kt, 128, hipMemcpyDeviceToHost));
-            const double wg = (double)(g[12] ? g[12] : 1), tick_us = 1e3 / c->wall_clock_khz;
-            fprintf(stderr, "k_step_render phases (us): step+reset mean %.2f max %.2f | draw mean %.2f max %.2f | start skew mean %.2f | %llu workgroup-launches, whole launch mean %.2f\n",
-                    g[8] / wg * tick_us, g[9] * tick_us, g[10] / wg * tick_us, g[11] * tick_us, g[13] / wg * tick_us, g[12], h[3] ? (double)h[2] / h[3] * tick_us : 0.0);
-        }
-#endif
-        if (total_ms) *total_ms = (double)h[2] / c->wall_clock_khz;
-        if (launches) *launches = (int64_t)h[3];
+    if (which >= 8) {
+        unsigned long long h[2] = {0, 0};
+        if (c->d_kt_acc) TG_HIP(hipMemcpy(h, c->d_kt_acc + 2 * (which - 8), 16, hipMemcpyDeviceToHost));
+        if (total_ms) *total_ms = (double)h[0] / c->wall_clock_khz;
+        if (launches) *launches = (int64_t)h[1];
         return 0;
     }
     if (total_ms) *total_ms = c->prof_ms[which];

@@ -1033,6 +1033,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
 template <typename T, int TOPO, bool POS, int SHAPE, bool CONE, int NT = 1>
 __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                           const float* __restrict__ actions) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double wave_lds_raw[];
     const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
@@ -1391,6 +1392,7 @@ __device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const Bod
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                        const float* __restrict__ actions) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double wave_lds_raw[];
     const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
@@ -1687,6 +1689,7 @@ __device__ __forceinline__ int sim_tick_arm_wave(const DevRobot<T>& m, lds_ptr<T
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_step_arm_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                       const float* __restrict__ actions) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double wave_lds_raw[];
     const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
@@ -1746,6 +1749,7 @@ __global__ __launch_bounds__(64) void k_step_arm_wave(const DevRobot<T>* __restr
 template <typename T, int TOPO, int SHAPE, bool CONE, int NT = 1>
 __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                            const uint8_t* __restrict__ mask) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double wave_lds_raw[];
     const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;

@@ -74,7 +74,10 @@ __global__ __launch_bounds__(64) void k_pack_tiles(const uint8_t* __restrict__ o
     __syncthreads();
     uint4* __restrict__ out = reinterpret_cast<uint4*>(dst + 16) + (size_t)base * kRecWords;
     for (int i = lane; i < cnt * kRecWords; i += 64) out[i] = rec[i];
-    __threadfence();
+    // No fence here (round 5).  The header's count comes from atomics (the ticket is taken after this wave's slot atomic has RETURNED: `base`
+    // is consumed above), and every reader of records / header runs behind this kernel's end - a later launch or, on a peer, a flag raised by
+    // one.  An agent-scope fence per workgroup is an L2 write-back + invalidate on a multi-XCD part: with 1024 workgroups it was ~20 us of this
+    // kernel (profiles/r5_exp_fused_step.txt measured the same fence in k_step_render).
     __shared__ uint32_t last;
     if (lane == 0) {
         const uint32_t ticket = atomicAdd(&counters[1], 1u);

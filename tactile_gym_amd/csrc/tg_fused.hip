@@ -32,18 +32,14 @@ __global__ __launch_bounds__(64) void k_step_render(const DevRobot<T>* __restric
                                                     const float* __restrict__ actions, int E, int auto_reset, const BankDev* __restrict__ bd,
                                                     RasterParams P, Stimulus S, const float* __restrict__ nodef_dep,
                                                     const uint8_t* __restrict__ gray_u8, const uint8_t* __restrict__ border,
-                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ term_out, int rec_cap,
-                                                    unsigned long long* __restrict__ kt /* null, or {min start, max end} wall-clock stamps */, int dbg) {
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ term_out, int rec_cap, int dbg) {
+    KtScope kt_scope_(st.kt);
     extern __shared__ TriRec recs[];
     __shared__ int count;
     const int lane = threadIdx.x;
     const int n = cp->num_envs;
     const int env0 = blockIdx.x * E;
     const int env = env0 + lane;
-    if (kt != nullptr && lane == 0) atomicMin(kt + 0, wall_clock64());
-#ifdef TG_FUSED_STAMPS
-    const unsigned long long t_a = wall_clock64();
-#endif
     int dn = 0;
     float xs[12], xt[12];
 #pragma unroll
@@ -60,9 +56,6 @@ __global__ __launch_bounds__(64) void k_step_render(const DevRobot<T>* __restric
             for (int k = 0; k < 12; ++k) xt[k] = st.term_xform[k * n + env];
         }
     }
-#ifdef TG_FUSED_STAMPS
-    const unsigned long long t_b = wall_clock64();
-#endif
     draw_counter_advance(st);
     const int n_regions = (P.W / 128) * (P.H / 128);
     const size_t img_bytes = (size_t)P.W * P.H;
@@ -80,14 +73,6 @@ __global__ __launch_bounds__(64) void k_step_render(const DevRobot<T>* __restric
         render_blocks_wave<kBlockW>(P, S, M, n_regions, nodef_dep, gray_u8, border, out + (size_t)ee * img_bytes,
                                     P.drawn != nullptr ? P.drawn + (size_t)ee * n_regions : nullptr, rec_cap, recs, &count);
     }
-    if (kt != nullptr && lane == 0) atomicMax(kt + 1, wall_clock64());
-#ifdef TG_FUSED_STAMPS
-    if (kt != nullptr && lane == 0) {   // development: per-phase wall-clock ticks, summed and maximal over the workgroups (kt[8..])
-        const unsigned long long t_c = wall_clock64();
-        atomicAdd(kt + 8, t_b - t_a); atomicMax(kt + 9, t_b - t_a); atomicAdd(kt + 10, t_c - t_b); atomicMax(kt + 11, t_c - t_b); atomicAdd(kt + 12, 1ull);
-        atomicAdd(kt + 13, t_a - kt[0]);   // start skew against the earliest workgroup (approximately: kt[0] may still fall)
-    }
-#endif
 }
 
 int fused_envs_per_wave(int num_envs) {
@@ -97,7 +82,7 @@ int fused_envs_per_wave(int num_envs) {
 
 int launch_step_render(int topology, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const, const State& st, const float* d_actions,
                        int auto_reset, const void* d_bank, const RasterParams& P, const Stimulus& S, const float* nodef_dep, const uint8_t* gray_u8,
-                       const uint8_t* border, uint8_t* out, uint8_t* term_out, unsigned long long* kt) {
+                       const uint8_t* border, uint8_t* out, uint8_t* term_out) {
     if (S.kind != 0 || S.n_tris > 32 || P.blockmax == nullptr || P.tmpl == nullptr || P.W % 128 != 0 || P.H % 128 != 0) return -1;
     const int rec_cap = 2 * S.n_tris < 2 ? 2 : 2 * S.n_tris;
     const size_t lds = (size_t)rec_cap * sizeof(TriRec);
@@ -106,10 +91,10 @@ int launch_step_render(int topology, int num_envs, hipStream_t stream, const voi
     const dim3 grid((num_envs + E - 1) / E), block(64);
     if (topology == 0)
         hipLaunchKernelGGL((k_step_render<double, 0>), grid, block, lds, stream, (const DevRobot<double>*)d_robot, (const EnvConst<double>*)d_const, st,
-                           d_actions, E, auto_reset, (const BankDev*)d_bank, P, S, nodef_dep, gray_u8, border, out, term_out, rec_cap, kt, dbg);
+                           d_actions, E, auto_reset, (const BankDev*)d_bank, P, S, nodef_dep, gray_u8, border, out, term_out, rec_cap, dbg);
     else
         hipLaunchKernelGGL((k_step_render<double, 1>), grid, block, lds, stream, (const DevRobot<double>*)d_robot, (const EnvConst<double>*)d_const, st,
-                           d_actions, E, auto_reset, (const BankDev*)d_bank, P, S, nodef_dep, gray_u8, border, out, term_out, rec_cap, kt, dbg);
+                           d_actions, E, auto_reset, (const BankDev*)d_bank, P, S, nodef_dep, gray_u8, border, out, term_out, rec_cap, dbg);
     return 0;
 }
 

@@ -12,6 +12,7 @@
 
 #include "../../include/tactile_gym_hip.h"
 #include "tg_physics.hpp"
+#include "tg_kt.hpp"
 
 namespace tg {
 
@@ -83,6 +84,7 @@ struct State {   // device pointers, SoA [field][num_envs]
     const void* tip_verts;          // [n_tip][3] in the physics dtype
     unsigned long long* draw;       // tg_step_random on the lane-mapped k_step: {draw counter, seed, ticket}; the kernel draws its own actions (nullptr: reads `actions`)
     float* act_out;                 // ... and leaves them here ([n][act_dim])
+    unsigned long long* kt;         // profiling mode: per-wavefront {start, end} wall-clock slots (tg_kt.hpp); null otherwise
     double* mani;                   // [37][n] object_push with tg_config.narrowphase != 0: the tip - cube contact manifold (la, lb, normal of 4 points; count)
 #ifdef TG_TL_STAMPS
     unsigned long long* tl;         // development: [4][8192] launch-start stamps (wall clock) + [4] counters behind them
@@ -733,6 +735,7 @@ __device__ __forceinline__ void draw_counter_advance(const State& st) {
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                              const float* __restrict__ actions) {
+    KtScope kt_scope_(st.kt);
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     TG_TL(st.tl, 1);
     if (env >= cp->num_envs) return;
@@ -861,6 +864,7 @@ __device__ __forceinline__ bool pose_reached(const DevRobot<T>& m, const T (&q)[
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_step_pos(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                  const float* __restrict__ actions) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
@@ -1087,6 +1091,7 @@ __device__ __forceinline__ void reset_or_swap(const DevRobot<T>* __restrict__ mp
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_reset(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                               const uint8_t* __restrict__ mask, int phase, const BankDev* __restrict__ bd) {
+    KtScope kt_scope_(st.kt);
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     TG_TL(st.tl, 2);
     if (env >= cp->num_envs) return;
@@ -1207,6 +1212,7 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
 template <typename T, int TOPO, bool POS, bool BALL = false>
 __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
@@ -1291,6 +1297,7 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
 template <typename T, int TOPO, bool BALL = false, bool FAST = false /* the template is known to be valid: no inverse kinematics / blocking move in the binary */>
 __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
@@ -1502,6 +1509,7 @@ __device__ __forceinline__ void finish_push(const DevRobot<T>& m, const EnvConst
 template <typename T, int TOPO, bool POS>
 __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double push_lds_raw[];             // kPushLdsWords * 64 words of T (83 KB in f64: dynamic, above the 64 KB static cap)
     const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
@@ -1582,6 +1590,7 @@ __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict_
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double push_lds_raw[];
     const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
@@ -1732,6 +1741,7 @@ __device__ __forceinline__ void finish_roll(const DevRobot<T>& m, const EnvConst
 template <typename T, int TOPO, bool POS>
 __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double push_lds_raw[];
     const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
@@ -1787,6 +1797,7 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_reset_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
+    KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double push_lds_raw[];
     const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;

@@ -18,6 +18,7 @@ struct RasterParams {
     const float* blockmax;    // [regions][64]: largest undeformed depth of each kBlockW x (256 / kBlockW) block of each 128 x 128 region
     unsigned long long* drawn;   // [n_envs][regions]: bit b = block b of the env's image (`out`) differs from tmpl (written by k_render_blocks; null: every launch rewrites every block)
     const uint8_t* tmpl;      // [H][W]: t_s_camera's image of an untouched sensor (zero inside, the pasted ring outside)
+    unsigned long long* kt;   // profiling mode: per-wavefront {start, end} wall-clock slots (tg_kt.hpp); null otherwise
 #ifdef TG_TL_STAMPS
     unsigned long long* tl;
 #endif

@@ -69,7 +69,7 @@ RasterParams make_raster_params(int W, int H, double fov_deg, double near_, doub
     P.C1 = (float)(-(near_ * far_) / (far_ - near_));
     P.near_ = (float)near_;
     P.turn_off_border = turn_off_border;
-    P.blockmax = nullptr; P.tmpl = nullptr; P.drawn = nullptr;
+    P.blockmax = nullptr; P.tmpl = nullptr; P.drawn = nullptr; P.kt = nullptr;
     P.zcull = 0.0f;
     for (int i = 0; i < W * H; ++i) P.zcull = nodef_dep_host[i] > P.zcull ? nodef_dep_host[i] : P.zcull;
     return P;
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
                                                              int rec_cap /*records of dynamic LDS, even*/,
                                                              const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
                                                              uint8_t* __restrict__ term_out /*fused auto-reset: all three or none*/) {
+    KtScope kt_scope_(P.kt);
     constexpr int QPR = TW / 4;            // pixel quads per tile row
     constexpr int RPP = kThreads / QPR;    // tile rows covered per pass of the workgroup
     constexpr int NK = TH / RPP;           // rows owned by each lane
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(kThreads) void k_render_scatter(RasterParams P, Sti
                                                              uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev,
                                                              const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
                                                              uint8_t* __restrict__ term_out) {
+    KtScope kt_scope_(P.kt);
     __shared__ unsigned zb[TW * TH];
     __shared__ TriRec big[kScatterCap];
     __shared__ int big_n;
@@ -605,6 +607,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
                                                            uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int rec_cap,
                                                            const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
                                                            uint8_t* __restrict__ term_out) {
+    KtScope kt_scope_(P.kt);
     constexpr int QPR = TW / 4, RPP = kThreads / QPR, NK = TH / RPP, NKH = NK / HALVES;
     static_assert(NK % HALVES == 0, "row groups");
     extern __shared__ TriRec recs[];
@@ -863,6 +866,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
                                                            uint8_t* __restrict__ out, uint8_t* __restrict__ save_prev, int rec_cap,
                                                            const float* __restrict__ term_xform, const uint8_t* __restrict__ term_mask,
                                                            uint8_t* __restrict__ term_out) {
+    KtScope kt_scope_(P.kt);
     constexpr int BH = 256 / BW, LPR = BW / 4, NBX = 128 / BW, NPW = 16, RQ = BH / 4;
     constexpr int NQ = TG_BLK_NQ;   // quads per lane in a drawing round: 4 NQ blocks per round   // NPW blocks per wavefront; RQ rows per block quarter
     static_assert(BW == kBlockW, "P.blockmax is laid out for kBlockW");

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "tg_raster.h"
+#include "tg_kt.hpp"
 
 #pragma clang fp contract(off)
 

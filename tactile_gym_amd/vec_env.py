@@ -607,14 +607,24 @@ class TactileVecEnv(_VecEnvBase):
         capi.check(self._L.tg_set_joint_state(self._ctx, q.ctypes.data_as(dp), qd.ctypes.data_as(dp)))
 
     def profile(self, enable=True):
-        capi.check(self._L.tg_profile_enable(self._ctx, int(enable)))
+        """True / 1: HIP events around every launch class (no graph) + the kernels' own clock; 2 / "clock": the own clock only, the step stays one
+        graph (what the rollout itself runs); False: off."""
+        capi.check(self._L.tg_profile_enable(self._ctx, 2 if enable == "clock" else int(enable)))
 
     def profile_get(self):
+        """{class: (total ms, scopes)} of profiling mode.  "step", "render" (the one launch of a fused step), "reset" (the reset sequence),
+        "render_masked", "scene", "empty_event_pair": HIP events on the launch stream - every figure carries what the empty pair measures.
+        "<class>_clock": the same scopes by the kernels' own clock (csrc/tg_kt.hpp: first wavefront start -> last wavefront end)."""
         out = {}
-        for which, name in enumerate(("step", "render", "reset", "render_masked", "scene", "empty_event_pair", "fused_kernel_clock")):
+
+        def get(which):
             ms, cnt = C.c_double(), C.c_int64()
             capi.check(self._L.tg_profile_get(self._ctx, which, C.byref(ms), C.byref(cnt)))
-            out[name] = (ms.value, cnt.value)
+            return (ms.value, cnt.value)
+        for which, name in enumerate(("step", "render", "reset", "render_masked", "scene", "empty_event_pair")):
+            out[name] = get(which)
+        for k, name in enumerate(("step", "render", "reset", "render_masked")):
+            out[name + "_clock"] = get(8 + k)
         return out
 
 

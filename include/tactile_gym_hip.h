@@ -184,7 +184,10 @@ typedef struct {
     /* edge_follow / surface_follow with auto_reset: the reset of these envs (edge_follow_env.py:311-336, base_surface_env.py:616-662,
      * robot.py:114-125) is a pure function of the env's RNG stream, so every env's NEXT post-reset state is computed ahead of time on a
      * second low-priority stream ("reset bank") and a finished env takes it inside the step instead of stalling the batch for its blocking
-     * move.  Results are identical with the bank on, off, or not ready in time (the same reset code either way).
+     * move.  Results are identical with the bank on, off, or not ready in time (the same reset code either way) - for edge_follow and
+     * surface_follow.  object_balance has a reset TEMPLATE instead (the arm's post-reset state computed once, by env 0's first reset): against
+     * TG_BANK_OFF, which recomputes every reset with the fallen object still on the constraint, the arm differs by the last-bit residue of that
+     * tick's Gauss-Seidel (joints within 1e-13 rad, frames within 3 pixels: tests/test_gpu_reset_bank.py) - not bit-identical.
      * TG_BANK_AUTO: on for the MG400 (its blocking move stalls a 1024-env batch for 9-11 ms per full-batch reset; measured 0.126 -> 1.13 M
      * env-steps/s on surface_follow-v2), off for the UR5 (a full-batch reset costs 0.12 ms per 200 steps, less than what the refill launches
      * cost the steps they run beside); TG_BANK_ON: on; TG_BANK_OFF: every reset on the spot; TG_BANK_SYNC: on, and the refill is waited for
@@ -268,10 +271,6 @@ int tg_get_bank_stats(tg_ctx* ctx, int64_t* swapped, int64_t* late, int32_t* mod
 /* How tg_step runs on this context: *mode = 1 one launch per step (tg_config.fused_step; csrc/tg_fused.hip), 0 separate step / reset / render
  * launches; *envs_per_wavefront = envs one wavefront steps and draws in the one-launch form (0 otherwise). */
 int tg_get_step_mode(tg_ctx* ctx, int32_t* mode, int32_t* envs_per_wavefront);
-/* Self-test of the wave-mapped GJK / EPA (tg_config.narrowphase; csrc/tg_narrowphase.hpp) on n_cases placements of a convex hull against the
- * box of half extents half[3]: hulls [n_cases][n_hull][3] in the box frame (n_hull <= 1152); out [n_cases][11] = found (1 / 0), signed core
- * distance (< 0: overlap depth), unit normal from the box to the hull, witness point on the hull, witness point on the box. */
-int tg_selftest_narrowphase(int32_t n_cases, int32_t n_hull, const double* hulls, const double* half, double* out);
 int tg_pack_interior(tg_ctx* ctx, void* dst_dev);
 int tg_unpack_interior(tg_ctx* ctx, const void* src_dev, int32_t n_images, void* dst_dev);
 /* ---- tile-sparse tactile payload and direct stores into rank 0's memory (csrc/tg_exchange.hip) ------------------------------------
@@ -462,16 +461,6 @@ int tg_sample_actions(tg_ctx* ctx, uint64_t seed, uint64_t counter, float* dev_a
  * actions are the context's own buffer (tg_get_actions: device float32 [num_envs][act_dim]); draw k equals tg_sample_actions(seed, k). */
 int tg_step_random(tg_ctx* ctx, uint64_t seed, uint64_t first_draw, int32_t restart);
 int tg_get_actions(tg_ctx* ctx, void** dev_actions);
-/* Self-test of the raster's depth division (tactile_sensor.py:239-294 reads an IEEE depth buffer): n pseudo-random operand pairs
- * with exponents 2^-40 .. 2^24 divided by the kernels' refinement and by the correctly rounded `/`; *mismatches = quotients whose
- * bits differ (must be 0). */
-int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches);
-/* Self-test of the raster's edge-function block test (csrc/tg_raster.hip: edges_exclude_rect - a record is skipped for a block of pixels that
- * its triangle provably cannot cover): n pseudo-random triangles (image-sized, slivers, huge, on pixel centres, heightfield-sized) x
- * rectangles as the kernels pass them, every pixel centre put through the pixel loops' own edge expressions.  out[0] = rectangles
- * excluded although they hold a coverable pixel (must be 0), out[1] = rectangles excluded, out[2] = rectangles without a coverable pixel. */
-int tg_selftest_edge_exclusion(int64_t n, uint64_t seed, int64_t* out);
-
 #ifdef __cplusplus
 }
 #endif

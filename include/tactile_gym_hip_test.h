@@ -1,0 +1,35 @@
+/*
+ * tactile_gym_hip_test.h - C ABI of libtactile_gym_hip_test.so: device self-tests of pieces of the product's kernels.
+ *
+ * TEST INFRASTRUCTURE, not part of the boundary a maintainer binds (that is tactile_gym_hip.h / libtactile_gym_hip.so): built by
+ * csrc/build.sh next to the product library from the same device headers, loaded only by tests/ (tactile_gym_amd._capi.test_lib()).
+ * Every function returns 0 on success, -1 bad argument, -2 no HIP device / allocation failed, -3 launch failed.
+ */
+#ifndef TACTILE_GYM_HIP_TEST_H
+#define TACTILE_GYM_HIP_TEST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Self-test of the wave-mapped GJK / EPA (tg_config.narrowphase; csrc/tg_narrowphase.hpp) on n_cases placements of a convex hull against the
+ * box of half extents half[3]: hulls [n_cases][n_hull][3] in the box frame (n_hull <= 1152); out [n_cases][11] = found (1 / 0), signed core
+ * distance (< 0: overlap depth), unit normal from the box to the hull, witness point on the hull, witness point on the box. */
+int tg_selftest_narrowphase(int32_t n_cases, int32_t n_hull, const double* hulls, const double* half, double* out);
+
+/* Self-test of the raster's depth division (tactile_sensor.py:239-294 reads an IEEE depth buffer): n pseudo-random operand pairs
+ * with exponents 2^-40 .. 2^24 divided by the kernels' refinement and by the correctly rounded `/`; *mismatches = quotients whose
+ * bits differ (must be 0). */
+int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches);
+/* Self-test of the raster's edge-function block test (csrc/tg_raster.hip: edges_exclude_rect - a record is skipped for a block of pixels that
+ * its triangle provably cannot cover): n pseudo-random triangles (image-sized, slivers, huge, on pixel centres, heightfield-sized) x
+ * rectangles as the kernels pass them, every pixel centre put through the pixel loops' own edge expressions.  out[0] = rectangles
+ * excluded although they hold a coverable pixel (must be 0), out[1] = rectangles excluded, out[2] = rectangles without a coverable pixel. */
+int tg_selftest_edge_exclusion(int64_t n, uint64_t seed, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

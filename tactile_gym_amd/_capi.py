@@ -150,7 +150,6 @@ SYMBOLS = {
     "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     "tg_get_bank_stats": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_get_step_mode": (C.c_int, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "tg_selftest_narrowphase": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tg_pack_interior": (C.c_int, [_ctx, C.c_void_p]),
     "tg_unpack_interior": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p]),
     "tg_get_episode_stats": (C.c_int, [_ctx, _vpp, _vpp]),
@@ -179,8 +178,6 @@ SYMBOLS = {
     "tg_render_scene": (C.c_int, [_ctx]),
     "tg_get_obs_visual": (C.c_int, [_ctx, _vpp, C.c_int32]),
     "tg_copy_obs_visual": (C.c_int, [_ctx, _u8p, C.c_int32]),
-    "tg_selftest_division": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
-    "tg_selftest_edge_exclusion": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
     "tg_get_obs_feature": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32), C.c_int32]),
     "tg_get_reward_done": (C.c_int, [_ctx, _fp, _u8p]),
     "tg_copy_obs_tactile": (C.c_int, [_ctx, _u8p, C.c_int32]),
@@ -228,6 +225,31 @@ def _share_torch_hip_runtime():
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except OSError:
             pass
+
+
+# libtactile_gym_hip_test.so (include/tactile_gym_hip_test.h): device self-tests, test infrastructure - tests/ are the only callers
+TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtactile_gym_hip_test.so")
+TEST_SYMBOLS = {
+    "tg_selftest_narrowphase": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tg_selftest_division": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
+    "tg_selftest_edge_exclusion": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
+}
+_test_lib = None
+
+
+def test_lib():
+    """Load libtactile_gym_hip_test.so (built next to the product library by csrc/build.sh)."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.isfile(TEST_LIB_PATH):
+            raise TactileGymHipError(f"{TEST_LIB_PATH} is missing: run tactile_gym_amd/csrc/build.sh")
+        _share_torch_hip_runtime()
+        L = C.CDLL(TEST_LIB_PATH)
+        for name, (res, args) in TEST_SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _test_lib = L
+    return _test_lib
 
 
 def lib():

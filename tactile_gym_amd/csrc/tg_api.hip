@@ -1267,6 +1267,10 @@ int tg_destroy(tg_ctx* c) {
 #ifdef TG_KSTEP_STAMPS
     { unsigned long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_kstep_stamps), sizeof h) == hipSuccess) { fprintf(stderr, "k_step stamps (cycles from start, full=%llu):", h[15]); for (int i = 1; i < 13; ++i) fprintf(stderr, " [%d] %lld", i, (long long)(h[i] - h[0])); fprintf(stderr, "\n"); } }
 #endif
+    // nothing of this context may still be running when its arrays go (the refill stream reads st.rng and writes the bank)
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->bank_stream) (void)hipStreamSynchronize(c->bank_stream);
     for (int k = 0; k < 2; ++k) if (c->step_graph[k]) (void)hipGraphExecDestroy(c->step_graph[k]);
     if (c->random_graph) (void)hipGraphExecDestroy(c->random_graph);
     if (c->d_draw) (void)hipFree(c->d_draw);
@@ -1302,6 +1306,7 @@ int tg_seed(tg_ctx* c, const uint64_t* seeds, int32_t n) {
     if (n != c->cfg.num_envs) return fail(-1, "tg_seed: need one seed per env");
     std::vector<uint64_t> st(n);
     for (int i = 0; i < n; ++i) st[i] = mix64(seeds[i] + kGolden);
+    if (c->bank_stream) TG_HIP(hipStreamSynchronize(c->bank_stream));   // a refill in flight reads the RNG states this call replaces
     TG_HIP(hipMemcpyAsync(c->st.rng, st.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     TG_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -1832,23 +1837,6 @@ int tg_sample_actions(tg_ctx* c, uint64_t seed, uint64_t counter, float* dev_act
 #endif
                        );
     TG_HIP(hipGetLastError());
-    return 0;
-}
-int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches) {
-    if (!mismatches || n < 0) return fail(-1, "tg_selftest_division: bad argument");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-2, "no HIP device");
-    long long m = 0;
-    if (tg::selftest_division((long long)n, (unsigned long long)seed, &m) != 0) return fail(-3, "tg_selftest_division: launch failed");
-    *mismatches = (int64_t)m;
-    return 0;
-}
-
-int tg_selftest_edge_exclusion(int64_t n, uint64_t seed, int64_t* out) {
-    if (!out || n < 0) return fail(-1, "tg_selftest_edge_exclusion: bad argument");
-    long long m[3] = {-1, -1, -1};
-    if (tg::selftest_edge_exclusion((long long)n, (unsigned long long)seed, m) != 0) return fail(-3, "tg_selftest_edge_exclusion: launch failed");
-    out[0] = m[0]; out[1] = m[1]; out[2] = m[2];
     return 0;
 }
 int tg_get_obs_feature(tg_ctx* c, void** p, int32_t* dim, int32_t terminal) {

@@ -1115,6 +1115,10 @@ __global__ __launch_bounds__(64) void k_bank_refill(const DevRobot<T>* __restric
         aux.need[env] = need ? 1 : 0;
         if (!need) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // While these launches rewrite the entry its OLD tag must not stay published: an env whose RNG state returns to that value in between
+        // (tg_seed with the same seeds does exactly that) would take a half-written entry.  ~r never equals r, and k_reset compares with the
+        // env's current state, which is r or something newer - a state that happens to equal ~r is as unlikely as any 64-bit collision.
+        __hip_atomic_store(aux.tag + env, ~r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         aux.rng_in[env] = r;
         bk.rng[env] = (uint64_t)r;
     } else if (aux.need[env] == 0) {
@@ -1212,7 +1216,8 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
 template <typename T, int TOPO, bool POS, bool BALL = false>
 __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
-    KtScope kt_scope_(st.kt);
+    // (no KtScope here: with it the ball_on_plate instantiation - 134 spilled VGPRs, > 1000 spilled SGPRs - came out of hipcc 7.2 producing NaNs in
+    //  random envs, tests/test_gpu_config_scale.py::test_long_horizon_ball_on_plate_matches_oracle; its duration is taken from HIP events)
     constexpr int N = Topo<TOPO>::N;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
@@ -1297,7 +1302,8 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
 template <typename T, int TOPO, bool BALL = false, bool FAST = false /* the template is known to be valid: no inverse kinematics / blocking move in the binary */>
 __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
-    KtScope kt_scope_(st.kt);
+    // (no KtScope here: with it the ball_on_plate instantiation - 134 spilled VGPRs, > 1000 spilled SGPRs - came out of hipcc 7.2 producing NaNs in
+    //  random envs, tests/test_gpu_config_scale.py::test_long_horizon_ball_on_plate_matches_oracle; its duration is taken from HIP events)
     constexpr int N = Topo<TOPO>::N;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
@@ -1331,14 +1337,16 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
     // first reset that includes it - and taken from `reset_tmpl` from then on (k_reset_body 0.28 ms -> a few us per launch; the difference
     // to recomputing with the fallen object attached is the last-bit residue of the full ticks, tests/test_gpu_reset_bank.py).
     // tg_config.reset_bank = TG_BANK_OFF (or TG_RESET_BANK=0) recomputes every time.
-    const bool use_tmpl = FAST || (st.reset_tmpl != nullptr && *(volatile const double*)(st.reset_tmpl + 2 * N + 1) != 0.0);
+    // Only the FAST instantiation reads the template, and the host launches it only after a launch that wrote it has been enqueued
+    // (tg_ctx::tmpl_ready): the launch that computes the template never also consumes it, so which envs recompute does not depend on how
+    // that launch's workgroups happen to be scheduled.
+    constexpr bool use_tmpl = FAST;
     const V3<T> z3 = mk<T>(0, 0, 0);
     int used = 0, verified = 0;
     Ball<T> ball;                                         // ball_on_plate: the ball lies where the last episode left it while the arm moves back
     T imp = T(0);
     if constexpr (BALL) ball = load_ball<T>(st, n, env);
     if (use_tmpl) {
-        __threadfence();                                  // the flag was read first: the launch that writes the template may be this one
 #pragma unroll
         for (int i = 0; i < N; ++i) { q[i] = (T)st.reset_tmpl[i]; qd[i] = (T)st.reset_tmpl[N + i]; }
         used = (int)st.reset_tmpl[2 * N];

@@ -1,10 +1,11 @@
 // tg_narrow_test.hip - tg_selftest_narrowphase: the wave-mapped GJK / EPA of tg_narrowphase.hpp on caller-supplied hull placements, one
-// wavefront per case, for the parity test against oracle/narrowphase.c (tests/test_gpu_narrowphase.py).  Not on the step path.
+// wavefront per case, for the parity test against oracle/narrowphase.c (tests/test_gpu_narrowphase.py).  Part of libtactile_gym_hip_test.so
+// (test infrastructure, include/tactile_gym_hip_test.h), not of the product library.
 #include <hip/hip_runtime.h>
 
 #include <vector>
 
-#include "../../include/tactile_gym_hip.h"
+#include "../../include/tactile_gym_hip_test.h"
 #include "tg_narrowphase.hpp"
 
 namespace tg {

@@ -1438,7 +1438,7 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
     constexpr int NP = Topo<TOPO>::NP;   // joints that can carry the tip (validated on the host)
     T Jt[3][NP], Wa[N][3];
     V3<T> pd[3], prb;                   // tip rows, cube part: row directions (n, t1, t2) and the contact arm; J = [-d, -(rb x d)]
-    T prhs[3], pjdi[3], plam[3], pcfm;
+    T prhs[3], pjdi[3], plam[3], pcfm = T(0);
     {
         V3<T> ol; M3<T> Rl;
         {

@@ -64,8 +64,4 @@ void launch_render(const RasterParams& P, const Stimulus& stim, const float* xfo
 
 void raster_debug_stats();   // development (-DTG_BLK_STAMPS): prints k_render_blocks' phase stamps; otherwise nothing
 
-// div_mid_range vs `/` on n pseudo-random operand pairs (exponents 2^-40 .. 2^24): number of differing quotients
-int selftest_division(long long n, unsigned long long seed, long long* mismatches_host);
-int selftest_edge_exclusion(long long n, unsigned long long seed, long long* out_host /*[3]: violations, excluded, empty*/);
-
 }  // namespace tg

@@ -1159,86 +1159,6 @@ void make_gray_u8(const float* nodef_gray_host, int npix, uint8_t* out_host) {
     for (int i = 0; i < npix; ++i) out_host[i] = (uint8_t)nodef_gray_host[i];   // the truncating cast of tactile_sensor.py:291-292
 }
 
-// tg_selftest_division: the refinement above against the compiler's correctly rounded `/` on pseudo-random operand pairs with exponents in
-// 2^-40 .. 2^24 (a superset of what a covered pixel produces); counts the pairs whose quotient bits differ.
-__global__ void k_selftest_division(long long n, unsigned long long seed, unsigned long long* mismatches) {
-    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-    unsigned long long bad = 0;
-    for (long long i = i0; i < n; i += stride) {
-        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-        const unsigned ea = 127u - 40u + (unsigned)((z >> 46) & 0xff) % 65u, eb = 127u - 40u + (unsigned)((z >> 54) & 0xff) % 65u;
-        const float a = __uint_as_float(((unsigned)(z >> 63) << 31) | (ea << 23) | ((unsigned)z & 0x7fffffu));
-        const float b = __uint_as_float(((unsigned)((z >> 62) & 1) << 31) | (eb << 23) | ((unsigned)(z >> 23) & 0x7fffffu));
-        bad += __float_as_uint(div_mid_range(a, b)) != __float_as_uint(a / b);
-    }
-    if (bad) atomicAdd(mismatches, bad);
-}
-int selftest_division(long long n, unsigned long long seed, long long* mismatches_host) {
-    unsigned long long* d = nullptr;
-    if (hipMalloc(&d, 8) != hipSuccess) return -1;
-    (void)hipMemset(d, 0, 8);
-    hipLaunchKernelGGL(k_selftest_division, dim3(2048), dim3(256), 0, 0, n, seed, d);
-    const hipError_t e = hipMemcpy(mismatches_host, d, 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    return e == hipSuccess ? 0 : -1;
-}
-
-// tg_selftest_edge_exclusion: edges_exclude_rect against brute force.  Pseudo-random triangles in window coordinates - image-sized, slivers
-// (third vertex a hair off the line of the other two), huge (coordinates up to 1e4), vertices snapped onto pixel centres - and rectangles
-// as the kernels pass them (16 x 16 blocks, 32 x 8 cells, at pixel-centre coordinates within 256 x 256); every pixel centre of the rectangle
-// is put through the pixel loops' own edge expressions.  out[0] = cases where the rule excluded a rectangle that holds a pixel with all three
-// edge functions >= 0 or all <= 0 (must be 0: a superset of `hit`), out[1] = rectangles excluded, out[2] = rectangles that held no such pixel.
-__global__ void k_selftest_edge_exclusion(long long n, unsigned long long seed, unsigned long long* out) {
-    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-    unsigned long long bad = 0, excl = 0, empty = 0;
-    for (long long i = i0; i < n; i += stride) {
-        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
-        auto next = [&]() { z += 0x9E3779B97F4A7C15ull; unsigned long long r = z; r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ull; r = (r ^ (r >> 27)) * 0x94D049BB133111EBull; return r ^ (r >> 31); };
-        auto unif = [&](float lo, float hi) { return lo + (hi - lo) * (float)((next() >> 40) * (1.0 / 16777216.0)); };
-        const int kind = (int)(next() % 5);
-        const float span = kind == 2 ? 1.0e4f : 356.0f, off = kind == 2 ? -5.0e3f : -50.0f;
-        float x0 = off + unif(0.0f, span), y0 = off + unif(0.0f, span), x1 = off + unif(0.0f, span), y1 = off + unif(0.0f, span);
-        float x2 = off + unif(0.0f, span), y2 = off + unif(0.0f, span);
-        if (kind == 1) { const float t = unif(-0.5f, 1.5f), eps = unif(-1e-3f, 1e-3f); x2 = x0 + t * (x1 - x0) + eps; y2 = y0 + t * (y1 - y0) - eps; }   // sliver
-        if (kind == 3) { x0 = floorf(x0) + 0.5f; y0 = floorf(y0) + 0.5f; x1 = floorf(x1) + 0.5f; y2 = floorf(y2) + 0.5f; }                          // on pixel centres
-        if (kind == 4) { x1 = x0 + unif(-24.0f, 24.0f); y1 = y0 + unif(-24.0f, 24.0f); x2 = x0 + unif(-24.0f, 24.0f); y2 = y0 + unif(-24.0f, 24.0f); }   // heightfield-sized
-        const bool cell = (next() & 1ull) != 0;
-        const int w = cell ? 32 : 16, h = cell ? 8 : 16;
-        const float X0 = (float)((int)(next() % (256 / w)) * w) + 0.5f, Y0 = (float)((int)(next() % (256 / h)) * h) + 0.5f;
-        const float X1 = X0 + (float)(w - 1), Y1 = Y0 + (float)(h - 1);
-        const bool ex = edges_exclude_rect(x0, y0, x1, y1, x2, y2, X0, X1, Y0, Y1);
-        bool covered = false;
-        for (int py = 0; py < h; ++py) {
-            const float fy = Y0 + (float)py;
-            const float a0 = y2 - fy, a1 = y1 - fy, a2 = y0 - fy;
-            for (int px = 0; px < w; ++px) {
-                const float fx = X0 + (float)px;
-                const float e0 = (x1 - fx) * a0 - (x2 - fx) * a1;
-                const float e1 = (x2 - fx) * a2 - (x0 - fx) * a0;
-                const float e2 = (x0 - fx) * a1 - (x1 - fx) * a2;
-                const bool pos = (e0 >= 0.0f) & (e1 >= 0.0f) & (e2 >= 0.0f), neg = (e0 <= 0.0f) & (e1 <= 0.0f) & (e2 <= 0.0f);
-                covered = covered | pos | neg;
-            }
-        }
-        bad += (ex && covered) ? 1 : 0;
-        excl += ex ? 1 : 0;
-        empty += covered ? 0 : 1;
-    }
-    if (bad) atomicAdd(out, bad);
-    atomicAdd(out + 1, excl);
-    atomicAdd(out + 2, empty);
-}
-int selftest_edge_exclusion(long long n, unsigned long long seed, long long* out_host /*[3]*/) {
-    unsigned long long* d = nullptr;
-    if (hipMalloc(&d, 24) != hipSuccess) return -1;
-    (void)hipMemset(d, 0, 24);
-    hipLaunchKernelGGL(k_selftest_edge_exclusion, dim3(2048), dim3(256), 0, 0, n, seed, d);
-    const hipError_t e = hipMemcpy(out_host, d, 24, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    return e == hipSuccess ? 0 : -1;
-}
-
 void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xform, int xform_soa, int n_envs,
                    const uint8_t* mask, const float* nodef_dep, const uint8_t* gray_u8, const uint8_t* border, uint8_t* out,
                    uint8_t* save_prev, const float* term_xform, const uint8_t* term_mask, uint8_t* term_out, hipStream_t stream) {

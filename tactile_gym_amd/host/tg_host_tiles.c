@@ -20,6 +20,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* spin-wait hint: x86 `pause`, AArch64 `yield`, a compiler barrier elsewhere (the bare x86 builtin did not compile on other hosts) */
+#if defined(__x86_64__) || defined(__i386__)
+#define TG_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define TG_CPU_RELAX() __asm__ __volatile__("yield" ::: "memory")
+#else
+#define TG_CPU_RELAX() __asm__ __volatile__("" ::: "memory")
+#endif
+
 #define TG_TILE_MAGIC 0x54475431
 #define TG_TILE_REC 272
 #define TG_MAX_THREADS 16
@@ -92,7 +101,7 @@ static void* worker(void* a_) {
     long seen = 0;
     for (;;) {
         int spun = 0;
-        while (p->generation == seen && !p->stop && spun < 4000) { if ((++spun & 63) == 0) sched_yield(); __builtin_ia32_pause(); }   /* yield: the caller may sit on this CPU */
+        while (p->generation == seen && !p->stop && spun < 4000) { if ((++spun & 63) == 0) sched_yield(); TG_CPU_RELAX(); }   /* yield: the caller may sit on this CPU */
         if (p->generation == seen && !p->stop) {
             pthread_mutex_lock(&p->mu);
             while (p->generation == seen && !p->stop) pthread_cond_wait(&p->cv_go, &p->mu);
@@ -154,7 +163,9 @@ int32_t tg_host_pool_threads(const tg_host_pool* p) { return p ? p->n_threads : 
 /* msg: the message (msg_bytes available); tmpl: uint8 [H*W]; dst: uint8 [n][H][W], holding what the previous call on it left;
  * prev_ids: int32 [n * (H/16) * (W/16)] capacity, *n_prev entries valid on entry (the tiles of dst that differ from tmpl), the new list on
  * return.  pool: NULL = this thread only.  Returns the record count, or -1 bad argument, -2 bad header, -3 message shorter than its count
- * says, -4 tile id out of range - and then dst, prev_ids and *n_prev are unchanged. */
+ * says, -4 tile id out of range - and then dst, prev_ids and *n_prev are unchanged.  A tile id is assumed to occur at most ONCE per message
+ * (what tg_pack_tiles produces: one record per live tile); this is not checked - a message that repeats an id makes two threads write the same
+ * tile, whose final content is then one of the two records (memory safe, not deterministic). */
 int64_t tg_host_unpack_tiles_mt(tg_host_pool* pool, const uint8_t* msg, int64_t msg_bytes, const uint8_t* tmpl, int32_t n, int32_t H, int32_t W,
                                 uint8_t* dst, int32_t* prev_ids, int64_t* n_prev) {
     if (!msg || !tmpl || !dst || !prev_ids || !n_prev || n <= 0 || H <= 0 || W <= 0 || (H & 15) || (W & 15) || msg_bytes < 16) return -1;
@@ -180,7 +191,7 @@ int64_t tg_host_unpack_tiles_mt(tg_host_pool* pool, const uint8_t* msg, int64_t 
         if (j.by_record) run_records(&pool->job, 0, count / pool->n_threads);
         else { int32_t lo, hi; share(pool, 0, &lo, &hi); run_range(&pool->job, lo, hi); }
         int spun = 0;
-        while (pool->pending > 0 && spun < 20000) { if ((++spun & 15) == 0) sched_yield(); __builtin_ia32_pause(); }   /* yield: a pinned worker may need this very CPU */
+        while (pool->pending > 0 && spun < 20000) { if ((++spun & 15) == 0) sched_yield(); TG_CPU_RELAX(); }   /* yield: a pinned worker may need this very CPU */
         if (pool->pending > 0) { pthread_mutex_lock(&pool->mu); while (pool->pending > 0) pthread_cond_wait(&pool->cv_done, &pool->mu); pthread_mutex_unlock(&pool->mu); }
         __sync_synchronize();
     } else {
@@ -219,7 +230,7 @@ int32_t tg_host_restore_begin(tg_host_pool* pool, const uint8_t* tmpl, int32_t n
 void tg_host_pool_wait(tg_host_pool* pool) {
     if (!pool) return;
     int spun = 0;
-    while (pool->pending > 0 && spun < 20000) { if ((++spun & 15) == 0) sched_yield(); __builtin_ia32_pause(); }   /* yield: a pinned worker may need this very CPU */
+    while (pool->pending > 0 && spun < 20000) { if ((++spun & 15) == 0) sched_yield(); TG_CPU_RELAX(); }   /* yield: a pinned worker may need this very CPU */
     if (pool->pending > 0) { pthread_mutex_lock(&pool->mu); while (pool->pending > 0) pthread_cond_wait(&pool->cv_done, &pool->mu); pthread_mutex_unlock(&pool->mu); }
     __sync_synchronize();
 }

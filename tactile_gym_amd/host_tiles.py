@@ -129,10 +129,20 @@ class TileDownload:
         dev = venv.tactile_torch().device
         T = (H // 16) * (W // 16)
         cap = 16 + TILE_REC * n * T
-        self.pk = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.cap = (cap + 15) & ~15
         self.counters = torch.zeros(4, dtype=torch.int32, device=dev)
-        self.host_pk = torch.empty(cap, dtype=torch.uint8).pin_memory()
+        # Zero copy (round 5): the pack kernel stores the header, the records and the small block behind the images (reward | done | ...) STRAIGHT
+        # into this pinned host buffer - device-visible at its own address - so a fetch is one launch and one synchronisation; until round 4 it
+        # was the launch, three copies (message, rewards, dones) and the synchronisation, each copy a DMA command of its own behind the kernel.
+        packed, obs_bytes, _ = venv.packed_torch()
+        self.tail = packed[obs_bytes:]                       # [reward f32[n] | done u8[n] | pad | feature]: tg_get_packed_outputs' layout
+        self.host_pk = torch.empty(self.cap + self.tail.numel(), dtype=torch.uint8).pin_memory()
         self.host_np = self.host_pk.numpy()
+        self.rew_host = self.host_np[self.cap:self.cap + 4 * n].view(np.float32)
+        self.done_host = self.host_np[self.cap + 4 * n:self.cap + 5 * n]
+        self.zero_copy = os.environ.get("TG_TILES_ZERO_COPY", "1") != "0"      # A/B switch for the measurement: "0" packs on the device and copies
+        if not self.zero_copy:
+            self.pk = torch.zeros(self.cap + self.tail.numel(), dtype=torch.uint8, device=dev)
         tmpl = self.shard.tile_template().cpu().numpy()
         self.pool = HostPool()
         self.ring = [HostTileBatch(tmpl, n, H, W, pool=self.pool.handle) for _ in range(self.RING)]
@@ -141,32 +151,50 @@ class TileDownload:
         self._last_count = 0
         self.t_device = self.t_host = 0.0      # seconds spent in fetch(): pack + copy + synchronise / host rebuild
         self.calls = 0
-        # reward / done ride under the same synchronisation (step_wait would otherwise pay a copy and a stream sync of its own first)
-        self.rd_dev = venv.reward_done_torch()
-        self.rew_host = torch.empty(n, dtype=torch.float32).pin_memory()
-        self.done_host = torch.empty(n, dtype=torch.uint8).pin_memory()
         self.rd_fresh = False
+
+    def close(self):
+        """Wait for the restore job that fetch() leaves running on the pool's workers, stop the workers, drop the buffers (without
+        this a dropped TileDownload relied on attribute destruction order to keep workers from writing into freed arrays)."""
+        if getattr(self, "pool", None) is not None:
+            for hb in self.ring:
+                try:
+                    hb.restore_end()
+                except Exception:  # noqa: BLE001
+                    pass
+            self.pool.close()
+            self.pool = None
+        self.ring = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def fetch(self):
         """The current observation batch as uint8 [n, H, W, 1] (one of the ring buffers)."""
         import time
         torch, v = self.torch, self.venv
         t0 = time.perf_counter()
-        stream = torch.cuda.current_stream(self.pk.device)
-        self.shard.pack_tiles(self.pk.data_ptr(), self.counters)
-        # one copy + one synchronisation in the usual case: the header together with as many records as the last frame had, plus a quarter;
-        # a frame with more records than that fetches the rest in a second copy
-        guess = min(self.pk.numel(), 16 + TILE_REC * (self._last_count + self._last_count // 4 + 64))
-        self.host_pk[:guess].copy_(self.pk[:guess], non_blocking=True)
-        self.rew_host.copy_(self.rd_dev[0], non_blocking=True)
-        self.done_host.copy_(self.rd_dev[1], non_blocking=True)
-        stream.synchronize()
-        self.rd_fresh = True
-        count = int(self.host_np[:4].view(np.int32)[0])
-        nb = 16 + TILE_REC * count
-        if nb > guess:
-            self.host_pk[guess:nb].copy_(self.pk[guess:nb], non_blocking=True)
+        stream = torch.cuda.current_stream(self.tail.device)
+        if self.zero_copy:
+            self.shard.pack_tiles(self.host_pk.data_ptr(), self.counters, tail=self.tail, tail_offset=self.cap)
             stream.synchronize()
+            count = int(self.host_np[:4].view(np.int32)[0])
+            nb = 16 + TILE_REC * count
+        else:
+            self.shard.pack_tiles(self.pk.data_ptr(), self.counters, tail=self.tail, tail_offset=self.cap)
+            guess = min(self.cap, 16 + TILE_REC * (self._last_count + self._last_count // 4 + 64))
+            self.host_pk[:guess].copy_(self.pk[:guess], non_blocking=True)
+            self.host_pk[self.cap:].copy_(self.pk[self.cap:], non_blocking=True)
+            stream.synchronize()
+            count = int(self.host_np[:4].view(np.int32)[0])
+            nb = 16 + TILE_REC * count
+            if nb > guess:
+                self.host_pk[guess:nb].copy_(self.pk[guess:nb], non_blocking=True)
+                stream.synchronize()
+        self.rd_fresh = True
         t1 = time.perf_counter()
         self._last_count = count
         self.i = (self.i + 1) % self.RING

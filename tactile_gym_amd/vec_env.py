@@ -43,7 +43,19 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-_EMPTY_INFO = {}      # shared by the envs that have nothing to report in a step (TactileVecEnv.step_wait, lazy_info)
+class _ReadOnlyInfo(dict):
+    """The info dict of an env that has nothing to report in a step, shared by all such envs, steps and contexts (lazy_info).  SB3's VecEnv
+    contract hands every env a dict of its own; a wrapper or callback that WRITES into the info of a running env would, with a shared plain
+    dict, leak its key into every env and every later step - so writing raises and names the switch that restores per-env dicts."""
+    __slots__ = ()
+
+    def _ro(self, *a, **k):
+        raise TypeError("this info dict is shared by every env that has nothing to report (lazy_info); call venv.set_lazy_info(False) to get a "
+                        "fresh dict per env and step")
+    __setitem__ = __delitem__ = clear = pop = popitem = setdefault = update = __ior__ = _ro
+
+
+_EMPTY_INFO = _ReadOnlyInfo()      # (TactileVecEnv.step_wait)
 
 
 class MonitorCsv:
@@ -276,7 +288,7 @@ class TactileVecEnv(_VecEnvBase):
             td.rd_fresh = False
             obs = self._observation()
             if td.rd_fresh:
-                np.copyto(self._reward, td.rew_host.numpy()); np.copyto(self._done, td.done_host.numpy())
+                np.copyto(self._reward, td.rew_host); np.copyto(self._done, td.done_host)
             else:
                 capi.check(self._L.tg_get_reward_done(self._ctx, self._reward.ctypes.data_as(C.POINTER(C.c_float)),
                                                       self._done.ctypes.data_as(C.POINTER(C.c_uint8))))
@@ -317,6 +329,9 @@ class TactileVecEnv(_VecEnvBase):
             self._closed = True
             if self._monitor is not None:
                 self._monitor.close()
+            if getattr(self, "_tile_download", None) is not None:
+                self._tile_download.close()
+                self._tile_download = None
             self._L.tg_destroy(self._ctx)
 
     def __del__(self):
@@ -439,8 +454,11 @@ class TactileVecEnv(_VecEnvBase):
     def set_obs_transfer(self, how):
         """How `obs_mode="numpy"` observations cross PCIe.  "full" (default): the whole batch every step.  "tiles": only the 16 x 16 tiles
         that differ from the untouched sensor's image, rebuilt on the host (host_tiles.py; lossless; needs torch and lib/libtg_host.so);
-        the batch handed out is then one of four ring buffers, untouched for the next three steps (as with copy_obs=False).  Terminal
+        the batch handed out is then one of five ring buffers, untouched for the next three steps (as with copy_obs=False).  Terminal
         observations always take the full copy."""
+        old = getattr(self, "_tile_download", None)
+        if old is not None:
+            old.close()
         if how == "full":
             self._tile_download = None
         elif how == "tiles":

@@ -31,6 +31,13 @@ def test_header_symbols_match_binding_and_library():
     for name in declared:
         assert hasattr(L, name)
     assert L.tg_abi_version() == _capi.ABI_VERSION
+    assert not any("selftest" in name for name in declared)            # test hooks are not part of the product ABI ...
+    test_header = open(os.path.join(ROOT, "include", "tactile_gym_hip_test.h")).read()
+    test_declared = set(re.findall(r"\b(tg_[a-z_0-9]+)\s*\(", test_header))
+    assert test_declared == set(_capi.TEST_SYMBOLS), test_declared ^ set(_capi.TEST_SYMBOLS)
+    T = _capi.test_lib()                       # ... they live in libtactile_gym_hip_test.so, which the product library does not export
+    for name in test_declared:
+        assert hasattr(T, name) and not hasattr(L, name)
     assert ctypes.sizeof(_capi.TgRobot) == 4 * 2 + 8 * (8 * 3 + 8 * 9 + 8 * 3 + 8 * 4 * (1 + 3 + 9 + 3)) + (8 + 8 * 12) * 2 + 8 * (3 + 6 + 8)
 
 

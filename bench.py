@@ -110,6 +110,37 @@ def _cpu_worker(idx, cpu, seconds, repeats, barrier, out_q):
     return out
 
 
+def pybullet_reference(seconds):
+    """PyBullet itself on this box's host, when `import pybullet` works and TG_PYBULLET_ASSETS points at a checkout of the
+    reference's assets directory (tools/pybullet_probe.py: raw pybullet, no tactile_gym source).  One process, one env: an env step =
+    velocity-control set-up + 24 x (gravity compensation + stepSimulation) + one 128 x 128 getCameraImage of the in-sensor camera - the engine
+    calls of BaseTactileEnv.step without the reference's Python around them (an upper bound on the reference's own rate)."""
+    try:
+        import pybullet  # noqa: F401
+    except Exception:  # noqa: BLE001
+        return "unavailable (import pybullet fails on this box)"
+    assets = os.environ.get("TG_PYBULLET_ASSETS")
+    if not assets or not os.path.isdir(assets):
+        return "pybullet is importable but TG_PYBULLET_ASSETS does not point at the reference's assets directory: not timed"
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pybullet_probe as probe
+        b = probe.PyBulletBackend(assets)
+        b.reset_joints(probe.UR5_REST)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            b.motors_velocity(probe.JOINT_VEL if n % 2 == 0 else [-v for v in probe.JOINT_VEL])
+            for _ in range(24):
+                b.tick()
+            b.depth_of_edge(128)
+            n += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(n / dt, 1), "unit": "env-steps/s", "cores": 1, "kind": "reference engine (raw pybullet, tools/pybullet_probe.py)",
+                "sample": f"{n} env steps in {dt:.1f} s: UR5 + TacTip, 24 ticks per step with gravity compensation, one 128x128 getCameraImage per step"}
+    except Exception as e:  # noqa: BLE001
+        return f"pybullet present but the probe failed: {e!r}"
+
+
 def _cgroup_cpu_quota():
     """CPUs' worth of time this container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable."""
     try:
@@ -159,11 +190,7 @@ def cpu_baseline(seconds=10.0, repeats=3):
         windows.append(sum(out[r][0] for _, out in res) / max(out[r][1] for _, out in res))
     per_proc = [out[r][0] / out[r][1] for _, out in res for r in range(repeats)]
     mean = sorted(windows)[len(windows) // 2]
-    try:   # time the real reference if the box happens to have it (it does not travel with this repo)
-        import pybullet  # noqa: F401
-        pyb = "importable on this box but not timed: the reference's env classes do not travel with this repo"
-    except Exception:  # noqa: BLE001
-        pyb = "unavailable (import pybullet fails on this box)"
+    pyb = pybullet_reference(min(seconds, 5.0))   # the real engine, if this box happens to have it
     return {"value": round(mean, 1), "unit": "env-steps/s", "cores": cores, "kind": "port", "pybullet_reference": pyb,
             "windows": [round(w, 1) for w in windows], "spread": round((max(windows) - min(windows)) / mean, 4),
             "per_process": {"mean": round(sum(per_proc) / len(per_proc), 2), "min": round(min(per_proc), 2), "max": round(max(per_proc), 2)},

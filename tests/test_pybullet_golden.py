@@ -1,0 +1,73 @@
+"""oracle/ against PyBullet itself, for whoever has a box with `pybullet` (this container has none).
+
+`tools/pybullet_probe.py --backend pybullet --assets <tactile_gym/assets> --out tests/golden` writes `tests/golden/pybullet_<scenario>.npz`
+from raw PyBullet calls (no tactile_gym source needed); this file then replays every scenario through oracle/ and compares, naming the
+PARITY_ASSUMPTIONS items each comparison closes.  Without such files those tests are skipped (reported as skipped, not passed).  One test
+always runs: the same four scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
+exercises the scenario scripts, the file format and the comparison, not the physics (oracle against oracle)."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import pybullet_probe as probe  # noqa: E402
+
+# scenario -> [(field, absolute tolerance, what a disagreement would mean)]
+CHECKS = {
+    "arm_statics": [("gravity_torque", 1e-6, "A1-A3: link masses / centres of mass / inertial frames (gravity torques at three poses)"),
+                    ("mass_matrix", 1e-6, "A3: link inertias - PyBullet recomputes them from the collision shapes' AABBs unless URDF_USE_INERTIA_FROM_FILE"),
+                    ("jacobian_tcp", 1e-9, "A2: the TCP frame getLinkState / calculateJacobian refer to (the link's inertial frame)")],
+    "arm_velocity": [("q", 1e-7, "A4-A7: integration order, linear / angular / joint damping, the velocity motor as a constraint row, A7b the PGS exit"),
+                     ("qd", 1e-6, "A5-A7: as above, on the velocities"),
+                     ("tcp", 1e-6, "A2: link state of the TCP (pose + velocities)")],
+    "reset_move": [("ik", 1e-5, "A9: calculateInverseKinematics (damped least squares from the current state, 100 iterations, 1e-8)"),
+                   ("ticks", 0, "A10-A11: blocking_move's exit (pose tolerance, joint speed) and POSITION_CONTROL's default max force"),
+                   ("q_final", 1e-6, "A10-A11")],
+    "tactile_depth": [("depth", 2e-5, "A12-A16: camera mounting, view / projection matrices, the depth buffer's convention and raster rules "
+                                      "(the tolerance the reference's own nodef_dep fixtures are reproduced to)")],
+}
+
+
+def _compare(ref_path, tmp_dir):
+    name = os.path.basename(ref_path)[len("pybullet_"):-len(".npz")]
+    ref = np.load(ref_path)
+    mine = np.load(probe.run("oracle", str(tmp_dir), scenarios=[name])[0])
+    report = []
+    for field, tol, closes in CHECKS[name]:
+        a, b = np.asarray(ref[field], dtype=np.float64), np.asarray(mine[field], dtype=np.float64)
+        assert a.shape == b.shape, (name, field, a.shape, b.shape)
+        err = float(np.max(np.abs(a - b))) if a.size else 0.0
+        report.append((field, err, tol, closes))
+    return name, str(ref["backend"]), report
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "pybullet_*.npz"))) or [None])
+def test_oracle_matches_pybullet_golden(path, tmp_path):
+    if path is None:
+        pytest.skip("no tests/golden/pybullet_*.npz: run tools/pybullet_probe.py --backend pybullet on a box that has PyBullet")
+    name, backend, report = _compare(path, tmp_path)
+    assert backend == "pybullet", f"{path} was written by the {backend} backend: only PyBullet's own output pins anything"
+    bad = [f"{f}: max |diff| {e:.3g} > {t:g} -> {c}" for f, e, t, c in report if e > t]
+    assert not bad, f"{name}: oracle/ disagrees with PyBullet\n  " + "\n  ".join(bad)
+
+
+def test_probe_format_and_comparison_with_the_oracle_backend(tmp_path):
+    """The kit end to end without PyBullet: every scenario written by the oracle backend, read back and compared through the code the golden
+    test uses (differences must be exactly zero: the same deterministic C restatement twice)."""
+    files = probe.run("oracle", str(tmp_path / "ref"))
+    assert sorted(os.path.basename(f) for f in files) == sorted(f"pybullet_{s}.npz" for s in probe.SCENARIOS)
+    for f in files:
+        name, backend, report = _compare(f, tmp_path / "mine")
+        assert backend == "oracle" and name in CHECKS
+        assert {r[0] for r in report} == {c[0] for c in CHECKS[name]}
+        assert all(err == 0.0 for _, err, _, _ in report), report
+    d = np.load(tmp_path / "ref" / "pybullet_arm_velocity.npz")
+    assert d["q"].shape == (48, 6) and np.all(np.isfinite(d["q"]))
+    assert np.allclose(d["qd"][-1], d["qd_des"], atol=1e-6)            # the velocity motors reach their targets (gravity is compensated)
+    d = np.load(tmp_path / "ref" / "pybullet_tactile_depth.npz")
+    assert d["depth"].shape == (128, 128) and 1000 < int((d["depth"] < 1.0).sum()) < 128 * 128     # the edge is in view
+    assert int(np.load(tmp_path / "ref" / "pybullet_reset_move.npz")["ticks"]) < 1000                # the blocking move converges

@@ -270,16 +270,18 @@ class Workload:
         barrier()
         return time.perf_counter() - t0
 
-    def profile(self, env, steps, barrier):
+    def profile(self, env, steps, barrier, clock=True):
         """Per-kernel durations, outside the timed region.  First the rollout as it is timed - the same graph, the same in-graph policy - with the
         kernels stamping their own clock (tg_profile_enable(2)); then a few steps launch by launch with HIP event pairs (tg_profile_enable(1)): the
         figures earlier rounds quoted, kept beside the clock's for comparison together with what an empty event pair measures."""
-        self.venv.profile("clock")
-        self._fused_synced = False
-        for _ in range(steps):
-            self.step(env)
-        barrier()
-        prof = self.venv.profile_get()
+        prof = {}
+        if clock:       # (not under a process group: switching this mode on and off re-captures the step graphs, see TorchShard.prime)
+            self.venv.profile("clock")
+            self._fused_synced = False
+            for _ in range(steps):
+                self.step(env)
+            barrier()
+            prof = self.venv.profile_get()
         self.venv.profile(True)
         for _ in range(min(steps, 10)):
             env.step(self.actions())
@@ -290,7 +292,8 @@ class Workload:
         for k in ("step", "render", "reset", "render_masked", "scene", "empty_event_pair"):
             prof[k] = ev[k]
         for k in ("step", "render", "reset", "render_masked"):      # launches per class of the clocked rollout (events: of the short second run)
-            prof[k + "_launches"] = prof[k + "_clock"][1]
+            if clock:
+                prof[k + "_launches"] = prof[k + "_clock"][1]
         return prof
 
     @staticmethod
@@ -447,6 +450,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the env step has no CPU fallback (the CPU oracle is only the reported baseline)")
     torch.cuda.set_device(local_rank)
+    if args.separate_policy:
+        Workload.fused_policy = False
+    n = args.num_envs
+    extra = dict(contact_mapping=args.contact_mapping, solver_iterations=args.solver_iters)
+    if args.env == "object_push-v0" and args.narrowphase != "closed_form":
+        extra["narrowphase"] = args.narrowphase
+    w = Workload(args.env, n, args.image_size, args.physics, rank, local_rank, full_sweeps=args.full_sweeps,
+                 observation_mode=args.observation_mode, pipelined=not args.sync_steps, **extra)
+    venv, shard, modes, max_steps = w.venv, w.shard, w.modes, w.max_steps
+    if world > 1 or os.environ.get("TG_BENCH_FORCE_COLLECTIVE") == "1":
+        # every graph the rollout will launch is captured HERE, before the process group (and its watchdog thread) exists: no step below captures
+        # anything (parallel.TorchShard.prime; rounds 3-4 slept three watchdog periods before the first capture instead)
+        with w.on_stream():
+            shard.prime(w.act_buf)
     dist, rccl_ranks = None, 1
     force = world == 1 and os.environ.get("TG_BENCH_FORCE_COLLECTIVE") == "1"   # 1-GPU check of the RCCL gather path (one rank)
     if world > 1 or force:
@@ -460,15 +477,6 @@ def main():
         rccl_ranks = int(ones.item())
         assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
-    if args.separate_policy:
-        Workload.fused_policy = False
-    n = args.num_envs
-    extra = dict(contact_mapping=args.contact_mapping, solver_iterations=args.solver_iters)
-    if args.env == "object_push-v0" and args.narrowphase != "closed_form":
-        extra["narrowphase"] = args.narrowphase
-    w = Workload(args.env, n, args.image_size, args.physics, rank, local_rank, full_sweeps=args.full_sweeps,
-                 observation_mode=args.observation_mode, pipelined=not args.sync_steps, **extra)
-    venv, shard, modes, max_steps = w.venv, w.shard, w.modes, w.max_steps
     gathered = dist is not None and not args.no_gather
 
     def barrier():
@@ -555,7 +563,7 @@ def main():
             dt_ng = allmax(w.timed(shard, args.steps, barrier))
             no_gather = {"value": round(n * world * args.steps / dt_ng, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * dt_ng / args.steps, 4),
                          "what": "the same K steps on every rank without the per-step exchange to rank 0 (observations consumed where they are produced)"}
-        prof = w.profile(env, min(args.steps, 50), barrier)
+        prof = w.profile(env, min(args.steps, 50), barrier, clock=dist is None)
         # SURVEY 8d asks for the rate with and without episode resets: a window that starts right after a reset of every env and
         # ends before any env can reach max_steps (an env that meets its goal early is still reset, as in any rollout)
         no_reset = None

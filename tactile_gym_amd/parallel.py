@@ -639,13 +639,16 @@ class ShardedVecEnv:
         """The first step of each kind makes the library capture its step graph (tg_step / tg_step_random).  While a HIP stream is capturing,
         hipEventQuery from ANOTHER thread can fail with hipErrorCapturedEvent, and torch's RCCL process group has such a thread: its watchdog
         polls the end events of the collectives still in its list every 100 ms, and a poll that fell into the few hundred microseconds of a
-        capture aborted the process (2 of ~100 one-rank bench runs, all ranks would go down with it).  So before a capture: finish all device
-        work, then give the watchdog three periods to retire the completed collectives - it polls nothing while its list is empty.  reset()
-        does it for both kinds (outside any timed region); a step without a reset before it does it for its own kind."""
+        capture aborted the process (2 of ~100 one-rank bench runs, all ranks would go down with it).  The ordering that cannot race is
+        TorchShard.prime() before the process group is created (bench.py does that): then this is a no-op.  The fallback for a shard that was
+        not primed: finish all device work, then give the watchdog three periods to retire the completed collectives - it polls nothing while
+        its list is empty.  reset() does it for both kinds (outside any timed region); a step without a reset before it for its own kind."""
         todo = [k for k in kinds if k not in self._captured]
         if not todo or self._solo:
             return
         self._captured.update(todo)
+        if getattr(self.local, "primed", False):
+            return                                   # TorchShard.prime(): the graphs were captured before the process group existed - nothing to wait for
         if not (getattr(self.local, "raw", False) and self.torch.cuda.is_available()):
             return                                   # a host-side shard (the gloo tests): nothing is captured
         import time
@@ -848,6 +851,29 @@ class TorchShard:
     def reset(self):
         self.venv.reset()
         return self._obs()
+
+    def prime(self, device_actions=None):
+        """Make the library capture its step graphs NOW (tg_step's two slots - host actions / the caller's device tensor - and tg_step_random's),
+        by one reset and one step of each kind.  Meant to be called BEFORE the process group exists: a capture that happens while torch's RCCL
+        watchdog thread may poll an event is what aborted one-rank runs in rounds 3-4 (ShardedVecEnv._quiesce_before_capture waited three
+        watchdog periods instead: a timing workaround).  With the graphs captured up front no step of the rollout captures anything, whatever the
+        watchdog does - an ordering, not a delay.  `device_actions`: the float32 [n, act_dim] CUDA tensor the rollout will pass to step()
+        (tg_step pins the first device pointer it sees to its in-place graph)."""
+        import contextlib
+        import numpy as np
+        import torch
+        v = self.venv
+        ctx = torch.cuda.stream(self.stream) if self.pipelined else contextlib.nullcontext()
+        with ctx:
+            self.reset()
+            self.step(np.zeros((v.num_envs, v.act_dim), dtype=np.float32))          # slot 0: the context's own action buffer
+            if device_actions is not None:
+                device_actions.zero_()
+                self.step(device_actions)                                            # slot 1: this tensor, in place
+            self.step_random(0, 0, restart=True)                                    # the random-action graph
+        v.sync()
+        self.primed = True
+        return self
 
     def step(self, actions):
         self.venv.step_async(actions)

@@ -23,10 +23,16 @@ int tg_selftest_narrowphase(int32_t n_cases, int32_t n_hull, const double* hulls
  * with exponents 2^-40 .. 2^24 divided by the kernels' refinement and by the correctly rounded `/`; *mismatches = quotients whose
  * bits differ (must be 0). */
 int tg_selftest_division(int64_t n, uint64_t seed, int64_t* mismatches);
+/* The same refinement where t_s_camera divides the clipped penetration by max_penetration = 0.05 (tactile_sensor.py:284-289): EVERY float in
+ * {0} u [1e-4, 0.05] divided by 0.05f both ways; *mismatches must be 0. */
+int tg_selftest_penetration_division(int64_t* mismatches);
 /* Self-test of the raster's edge-function block test (csrc/tg_raster.hip: edges_exclude_rect - a record is skipped for a block of pixels that
  * its triangle provably cannot cover): n pseudo-random triangles (image-sized, slivers, huge, on pixel centres, heightfield-sized) x
  * rectangles as the kernels pass them, every pixel centre put through the pixel loops' own edge expressions.  out[0] = rectangles
- * excluded although they hold a coverable pixel (must be 0), out[1] = rectangles excluded, out[2] = rectangles without a coverable pixel. */
+ * excluded although they hold a coverable pixel (must be 0), out[1] = rectangles excluded, out[2] = rectangles without a coverable pixel.
+ * The converse rule of round 5 (edges_cover_rect: a block wholly inside the triangle needs no coverage test per pixel): out[3] = rectangles
+ * called covered in which some pixel fails the pixel loops' coverage predicate (must be 0), out[4] = rectangles called covered, out[5] =
+ * rectangles whose every pixel passes.  out: int64 [6]. */
 int tg_selftest_edge_exclusion(int64_t n, uint64_t seed, int64_t* out);
 
 #ifdef __cplusplus

@@ -232,6 +232,7 @@ TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtactile_gym_hip_test
 TEST_SYMBOLS = {
     "tg_selftest_narrowphase": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tg_selftest_division": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
+    "tg_selftest_penetration_division": (C.c_int, [C.POINTER(C.c_int64)]),
     "tg_selftest_edge_exclusion": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
 }
 _test_lib = None

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kThreads, (BAND && TH == 64) ? TG_HF_WAVES : 1) voi
                 if (diff >= -eps && diff <= eps) diff = 0.0f;
                 const float pen = fabsf(diff);
                 const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
-                o[p] = (uint8_t)((cl / max_pen) * 255.0f);
+                o[p] = (uint8_t)(div_mid_range(cl, max_pen) * 255.0f);
             }
         }
 #pragma unroll
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void k_render_scatter(RasterParams P, Sti
             if (diff >= -eps && diff <= eps) diff = 0.0f;
             const float pen = fabsf(diff);
             const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
-            o[q] = (uint8_t)((cl / max_pen) * 255.0f);
+            o[q] = (uint8_t)(div_mid_range(cl, max_pen) * 255.0f);
             if (!P.turn_off_border && bmv[q] == 1) o[q] = ngv[q];
         }
         if (prev) *reinterpret_cast<uchar4*>(prev + off) = *reinterpret_cast<const uchar4*>(dst + off);
@@ -613,6 +613,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
     extern __shared__ TriRec recs[];
     __shared__ int count;
     __shared__ unsigned rblocks[512];    // per record: the 16 x 16 pass blocks of this tile (bit 8 by + bx) it can cover a pixel of (rec_cap <= 2 x 256)
+    __shared__ unsigned rinside[512];    // ... and those it covers every pixel centre of (edges_cover_rect): no coverage test per pixel there
     const int env = blockIdx.y;
     if (mask != nullptr && mask[env] == 0) return;
     const int n_tris = S.n_tris;
@@ -687,12 +688,20 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
         const int wv = tid >> 6, l = tid & 63, bx = l & 7, by = (l >> 3) & 3;
         const float X0 = (float)(tile_x + 16 * bx) + 0.5f, X1 = X0 + 15.0f;
         const float Y0 = (float)((interleave ? 16 : TH) * ty + ry_step * by) + 0.5f, Y1 = Y0 + 15.0f;
+        // ... and a block whose pixels are all pasted from the reference image (the TacTip's border ring: ~30 % of the 16 x 16 blocks of a
+        // 256 x 256 image) shows nothing of its depths: no record needs to visit it (blockmax: the host's table of k_render_blocks, -1 there)
+        float bmax_b = 3.0e38f;
+        if (P.blockmax != nullptr) {
+            const int gx = tile_x + 16 * bx, gy = (interleave ? 16 : TH) * ty + ry_step * by;
+            bmax_b = P.blockmax[((gy / 128) * (P.W / 128) + gx / 128) * 64 + ((gy % 128) / 16) * 8 + (gx % 128) / 16];
+        }
         for (int t = wv; t < n; t += kThreads / 64) {
             const TriRec r = recs[t];
-            bool miss = (r.ymax < Y0) | (r.ymin > Y1) | (r.xmax < X0) | (r.xmin > X1);
+            bool miss = (r.ymax < Y0) | (r.ymin > Y1) | (r.xmax < X0) | (r.xmin > X1) | (r.dmin >= bmax_b);
             miss = miss | edges_exclude_rect(r.x0, r.y0, r.x1, r.y1, r.x2, r.y2, X0, X1, Y0, Y1);
             const unsigned long long m = __ballot(!miss);
-            if (l == 0) rblocks[t] = (unsigned)m;
+            const unsigned long long mi = QREJ ? 0ull : __ballot(!miss && edges_cover_rect(r.x0, r.y0, r.x1, r.y1, r.x2, r.y2, X0, X1, Y0, Y1));
+            if (l == 0) { rblocks[t] = (unsigned)m; rinside[t] = (unsigned)mi; }
         }
         __syncthreads();
     }
@@ -712,12 +721,33 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
         for (int t = 0; t < n; ++t) {
             const unsigned rb = __builtin_amdgcn_readfirstlane(rblocks[t]);
             if (!((rb >> wave_u) & 0x11111111u)) continue;      // none of this wavefront's eight blocks (columns wave, wave + 4 of the four row groups)
+            const unsigned ri = __builtin_amdgcn_readfirstlane(rinside[t]);
             const TriRec r = recs[t];
 #pragma unroll
             for (int k = 0; k < NKH; ++k) {
-                if (!((rb >> (8 * ((h * NKH + k) >> 1) + wave_u + 4 * ((h * NKH + k) & 1))) & 1u)) continue;   // scalar: this pass's block
+                const int bit = 8 * ((h * NKH + k) >> 1) + wave_u + 4 * ((h * NKH + k) & 1);
+                if (!((rb >> bit) & 1u)) continue;   // scalar: this pass's block
                 const int qx = TG_QX(h * NKH + k);
                 const float fy = (float)TG_RY(h * NKH + k) + 0.5f;
+                if (!QREJ && ((ri >> bit) & 1u)) {     // (the few-large-triangles instantiation only: elsewhere the second loop body costs registers)
+                    // the record covers every pixel centre of this block (round 5; the plate's face under the TacTip: nearly every block of
+                    // config 5): `box & (pos | neg) & (s != 0)` is true at every pixel, only the interpolated depth and its test remain
+                    if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
+                    const float a0 = r.y2 - fy, a1 = r.y1 - fy, a2 = r.y0 - fy;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float fx = (float)(qx + p) + 0.5f;
+                        const float e0 = (r.x1 - fx) * a0 - (r.x2 - fx) * a1;
+                        const float e1 = (r.x2 - fx) * a2 - (r.x0 - fx) * a0;
+                        const float e2 = (r.x0 - fx) * a1 - (r.x1 - fx) * a2;
+                        const float s = (e0 + e1) + e2;
+                        const float d = div_mid_range((e0 * r.d0 + e1 * r.d1) + e2 * r.d2, s);
+                        const bool hit = d < z[k][p];
+                        z[k][p] = hit ? d : z[k][p];
+                        touched |= hit ? (1u << k) : 0u;
+                    }
+                    continue;
+                }
                 if (fy < r.ymin || fy > r.ymax) continue;
                 if ((float)qx + 3.5f < r.xmin || (float)qx + 0.5f > r.xmax) continue;
                 if (r.dmin >= fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]))) continue;
@@ -774,7 +804,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_render_small(RasterParams P, St
                     if (diff >= -eps && diff <= eps) diff = 0.0f;
                     const float pen = fabsf(diff);
                     const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
-                    o[p] = (uint8_t)((cl / max_pen) * 255.0f);
+                    o[p] = (uint8_t)(div_mid_range(cl, max_pen) * 255.0f);
                 }
             }
 #pragma unroll
@@ -1136,7 +1166,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
                     if (diff >= -eps && diff <= eps) diff = 0.0f;
                     const float pen = fabsf(diff);
                     const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
-                    o[p] = (uint8_t)((cl / max_pen) * 255.0f);
+                    o[p] = (uint8_t)(div_mid_range(cl, max_pen) * 255.0f);
                 }
             }
 #pragma unroll
@@ -1193,6 +1223,9 @@ void launch_render(const RasterParams& P, const Stimulus& S_in, const float* xfo
                                    nodef_dep, gray_u8, border, out, save_prev, rec_cap, term_xform, term_mask, term_out);
                 return;
             }
+            // (the terminal image as a second pass of the env's own workgroups instead of a grid layer of its own - 8 192 workgroups per launch
+            //  that start, look and leave - was measured in round 5: the pass loop costs the kernel more registers than the layer costs time,
+            //  render 108 -> 125 us at 256 x 256; not kept)
             dim3 grid((P.W / 128) * (P.H / 64), n_envs, term_xform ? 2 : 1);
             if (S.skip_quad_reject)
                 hipLaunchKernelGGL((k_render_small<128, 64, 2, false>), grid, dim3(kThreads), lds, stream, P, S, xform, xform_soa, n_envs, mask,

@@ -139,6 +139,32 @@ __device__ __forceinline__ bool edges_exclude_rect(float x0, float y0, float x1,
 }
 
 
+// Does the record cover EVERY pixel centre of the rectangle - with its three computed edge functions all > 0 (or all < 0), i.e. `pos` (or `neg`)
+// true and s != 0 at every pixel, whatever the rounding?  Same bounds as edges_exclude_rect: e_i is affine, so over the rectangle its extremes
+// sit at the corner pixel centres, and a computed value is within m_i of the exact one; min over the corners of the computed e_i > 2 m_i means
+// the exact e_i > m_i at every corner, hence everywhere, hence the computed e_i > 0 at every pixel.  A pixel inside the triangle is inside its
+// bounding box (exact comparisons of exact coordinates), so for such a (record, rectangle) the pixel loops' coverage predicate is `true` and
+// only the depth test remains.  NaN / inf compare false: not covered.
+__device__ __forceinline__ bool edges_cover_rect(float x0, float y0, float x1, float y1, float x2, float y2, float X0, float X1, float Y0, float Y1) {
+    const float B0 = fmaxf(fabsf(x0 - X0), fabsf(x0 - X1)), B1 = fmaxf(fabsf(x1 - X0), fabsf(x1 - X1)), B2 = fmaxf(fabsf(x2 - X0), fabsf(x2 - X1));
+    const float A0 = fmaxf(fabsf(y2 - Y0), fabsf(y2 - Y1)), A1 = fmaxf(fabsf(y1 - Y0), fabsf(y1 - Y1)), A2 = fmaxf(fabsf(y0 - Y0), fabsf(y0 - Y1));
+    const float m0 = 1e-5f * (B1 * A0 + B2 * A1), m1 = 1e-5f * (B2 * A2 + B0 * A0), m2 = 1e-5f * (B0 * A1 + B1 * A2);
+    float hi0 = -3.0e38f, hi1 = -3.0e38f, hi2 = -3.0e38f, lo0 = 3.0e38f, lo1 = 3.0e38f, lo2 = 3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float fx = (c & 1) ? X1 : X0, fy = (c & 2) ? Y1 : Y0;
+        const float a0 = y2 - fy, a1 = y1 - fy, a2 = y0 - fy;
+        const float e0 = (x1 - fx) * a0 - (x2 - fx) * a1;
+        const float e1 = (x2 - fx) * a2 - (x0 - fx) * a0;
+        const float e2 = (x0 - fx) * a1 - (x1 - fx) * a2;
+        hi0 = fmaxf(hi0, e0); hi1 = fmaxf(hi1, e1); hi2 = fmaxf(hi2, e2);
+        lo0 = fminf(lo0, e0); lo1 = fminf(lo1, e1); lo2 = fminf(lo2, e2);
+    }
+    const bool all_pos = (lo0 > 2.0f * m0) & (lo1 > 2.0f * m1) & (lo2 > 2.0f * m2);
+    const bool all_neg = (hi0 < -2.0f * m0) & (hi1 < -2.0f * m1) & (hi2 < -2.0f * m2);
+    return all_pos | all_neg;
+}
+
 // ------------------------------------------------------------------------------------------------ block raster, one wavefront per image
 // k_render_blocks (tg_raster.hip) restated for ONE wavefront that draws a whole image by itself - the render half of k_step_render
 // (tg_fused.hip), where the wavefront that has just stepped an env draws that env's image in the same launch.  Same set-up (one triangle per
@@ -352,7 +378,7 @@ __device__ __forceinline__ void render_blocks_wave(const RasterParams& P, const 
                         if (diff >= -eps && diff <= eps) diff = 0.0f;
                         const float pen = fabsf(diff);
                         const float cl = pen < 0.0f ? 0.0f : (pen > max_pen ? max_pen : pen);
-                        o[p] = (uint8_t)((cl / max_pen) * 255.0f);
+                        o[p] = (uint8_t)(div_mid_range(cl, max_pen) * 255.0f);
                     }
                 }
 #pragma unroll

@@ -1252,6 +1252,10 @@ def test_raster_division_is_correctly_rounded():
         m = ctypes.c_int64(-1)
         assert 0 == (capi.test_lib().tg_selftest_division(1 << 26, seed, ctypes.byref(m)))
         assert m.value == 0
+    # ... and where t_s_camera divides the clipped penetration by 0.05 (round 5): every float a penetration can be, exhaustively
+    m = ctypes.c_int64(-1)
+    assert 0 == (capi.test_lib().tg_selftest_penetration_division(ctypes.byref(m)))
+    assert m.value == 0
 
 
 def test_raster_edge_exclusion_never_hides_a_coverable_pixel():
@@ -1262,11 +1266,16 @@ def test_raster_edge_exclusion_never_hides_a_coverable_pixel():
     import ctypes
     from tactile_gym_amd import _capi as capi
     for seed in (3, 20260928):
-        out = (ctypes.c_int64 * 3)(-1, -1, -1)
+        out = (ctypes.c_int64 * 6)(-1, -1, -1, -1, -1, -1)
         assert 0 == (capi.test_lib().tg_selftest_edge_exclusion(1 << 24, seed, out))
         violations, excluded, empty = out[0], out[1], out[2]
         assert violations == 0, (seed, violations)
         assert empty > (1 << 22) and excluded > 0.9 * empty, (seed, excluded, empty)      # the rule is not vacuous: it finds >= 90 % of the empty ones
+        # the converse rule (round 5, edges_cover_rect): a rectangle called "wholly inside the triangle" never holds a pixel that fails the pixel
+        # loops' coverage predicate, and the rule finds most of the rectangles whose every pixel passes
+        cover_violations, called_covered, fully_covered = out[3], out[4], out[5]
+        assert cover_violations == 0, (seed, cover_violations)
+        assert fully_covered > 10000 and called_covered > 0.9 * fully_covered, (seed, called_covered, fully_covered)
 
 
 def _run_bench(cmd, root, env, tag):

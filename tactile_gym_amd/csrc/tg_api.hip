@@ -1333,6 +1333,7 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
 
 static void enqueue_step(tg_ctx* c, const float* d_act) {
     if (c->profile) { Timer t(c, 5); }   // an empty event pair: what every per-kernel figure of this mode carries on top of its kernel
+    bool reset_inlined = false;          // object_balance: k_step_body_wave has reset its finished envs itself
     if (use_fused_step(c)) {
         Timer t(c, 1);
         const int rc = launch_step_render(c->robot.topology, c->cfg.num_envs, c->stream, c->d_robot, c->d_const, c->st, d_act, c->cfg.auto_reset,
@@ -1343,8 +1344,13 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     {
         Timer t(c, 0);
         if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
+            // the reset of finished envs inside the step's launch: auto-reset with a valid template, the pole, no scene / oracle draw between
+            // the step and the reset (they show the pre-reset state)
+            const int inline_reset = (c->cfg.auto_reset && c->st.reset_tmpl != nullptr && c->tmpl_ready && c->cfg.balance_object == TG_BALANCE_POLE &&
+                                      !c->scene_every_step && !c->oracle_every_step && getenv("TG_NO_INLINE_RESET") == nullptr) ? 1 : 0;
             if (use_contact_wave(c) && launch_step_body_wave(c->cfg.physics_dtype, c->robot.topology, c->cfg.control_mode, c->cfg.num_envs, c->stream, c->d_robot,
-                                                             c->d_const, c->st, d_act) == 0) {
+                                                             c->d_const, c->st, d_act, inline_reset) == 0) {
+                reset_inlined = inline_reset != 0;
                 // one wavefront per env: the env's own licence, full ticks on the wave mapping (tg_contact_wave.hip)
             } else if (c->cfg.physics_dtype == TG_PHYSICS_F64) launch_step_body_t<double>(c, d_act);
             else launch_step_body_t<float>(c, d_act);
@@ -1375,7 +1381,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     if (c->cfg.auto_reset && (c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE && c->st.reset_tmpl != nullptr))) {
         // (object_balance with the reset template: k_reset_body is a few microseconds - teleport, draws, one forward kinematics - so it runs
         //  in line like edge_follow's, without the fork / join of the branch below and without the masked second render: 236 -> 20x us per step)
-        reset_sequence(c, c->st.done, c->bank_mode != 0); // k_reset keeps the terminal camera transform of the envs it resets
+        if (!reset_inlined) reset_sequence(c, c->st.done, c->bank_mode != 0); // k_reset keeps the terminal camera transform of the envs it resets
         render_fused(c);               // one launch draws the terminal and the post-reset observations
     } else if (c->cfg.auto_reset && c->aux_stream) {
         // object_balance: a pole falls somewhere in the batch on nearly every step, and its reset (rest pose, blocking move, settling: a

@@ -17,9 +17,10 @@ int launch_step_contact_wave(int env_kind, int physics_dtype, int topology, int 
 // manifold (tg_narrowphase.hpp): the kernel's four-tip-slot variant.
 
 // object_balance (arm + pole + point-to-point constraint), TCP_velocity_control, f64, UR5: one wavefront per env (the env's own licence for the
-// analytic fixed point, full ticks on the wave mapping).  -1: not instantiated.
+// analytic fixed point, full ticks on the wave mapping).  inline_reset: finished envs are reset by their own wavefront at the end of the step
+// (the template-only reset: the caller has made sure the template is valid) - no k_reset_body launch behind this one.  -1: not instantiated.
 int launch_step_body_wave(int physics_dtype, int topology, int control_mode, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const,
-                          const State& st, const float* d_actions);
+                          const State& st, const float* d_actions, int inline_reset);
 // edge_follow / surface_follow (contact-free arm, TCP_velocity_control, f64; UR5 and MG400): one wavefront per env, every tick a full tick
 // (lane-parallel dynamics, the motor pass as a linear map).  -1: not instantiated.
 int launch_step_arm_wave(int physics_dtype, int topology, int control_mode, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const,

@@ -1391,7 +1391,7 @@ __device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const Bod
 // full tick - after a reset, every 8th step, or when the analytic tick's a-priori test fails - is sim_tick_p2p_wave.
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                                       const float* __restrict__ actions) {
+                                                       const float* __restrict__ actions, int inline_reset) {
     KtScope kt_scope_(st.kt);
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double wave_lds_raw[];
@@ -1518,6 +1518,11 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
         store_body<T>(st, n, env, b);
     }
     finish_body<T, TOPO>(m, c, st, env, q, b, embed, step_count, true);
+    // Auto-reset in the step's own launch (round 5): with the reset template valid (the host knows: tg_ctx::tmpl_ready) a finished env's reset is
+    // the template-only form - four to six draws, a teleport, one forward kinematics - and its launch of its own (k_reset_body: 16 wavefronts
+    // that mostly find nothing to do) cost the step 16 us + a graph gap; here it costs a finished env's wavefront a few microseconds.  Every lane
+    // runs it alike, as with finish_body above (the same loads, the same stores).  done[env] is this lane's own store.
+    if (inline_reset && st.done[env] != 0) reset_body_env<T, TOPO, false, true>(m, c, st, env);
 }
 
 // ---- contact-free arms (edge_follow, surface_follow): the full tick on one wavefront -------------------------------------------------------
@@ -1954,10 +1959,10 @@ int launch_reset_wave_t(int cone, int n, int n_tip, hipStream_t stream, const vo
 }  // namespace
 
 int launch_step_body_wave(int physics_dtype, int topology, int control_mode, int num_envs, hipStream_t stream, const void* d_robot, const void* d_const,
-                          const State& st, const float* d_actions) {
+                          const State& st, const float* d_actions, int inline_reset) {
     if (physics_dtype != TG_PHYSICS_F64 || topology != 0 || control_mode != TG_CONTROL_TCP_VELOCITY) return -1;
     hipLaunchKernelGGL((k_step_body_wave<double, 0>), dim3(num_envs), dim3(64), (size_t)kLHull * sizeof(double), stream, (const DevRobot<double>*)d_robot,
-                       (const EnvConst<double>*)d_const, st, d_actions);
+                       (const EnvConst<double>*)d_const, st, d_actions, inline_reset);
     return 0;
 }
 

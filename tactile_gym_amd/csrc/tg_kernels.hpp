@@ -1299,18 +1299,11 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
 
 // BaseObjectEnv.reset (base_object_env.py:146-173) for object_balance: reset_task (gravity, embed), Robot.reset with the pole
 // still tied to the TCP, reset_object (teleport + one-shot random force).
+// (the reset of ONE env; k_reset_body below is its lane-per-env launch, k_step_body_wave calls the FAST form in its epilogue)
 template <typename T, int TOPO, bool BALL = false, bool FAST = false /* the template is known to be valid: no inverse kinematics / blocking move in the binary */>
-__global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                                   const uint8_t* __restrict__ mask) {
-    // (no KtScope here: with it the ball_on_plate instantiation - 134 spilled VGPRs, > 1000 spilled SGPRs - came out of hipcc 7.2 producing NaNs in
-    //  random envs, tests/test_gpu_config_scale.py::test_long_horizon_ball_on_plate_matches_oracle; its duration is taken from HIP events)
+__device__ __forceinline__ void reset_body_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env) {
     constexpr int N = Topo<TOPO>::N;
-    const DevRobot<T>& m = *mp;
-    const EnvConst<T>& c = *cp;
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = c.num_envs;
-    if (env >= n) return;
-    if (mask != nullptr && mask[env] == 0) return;
     uint64_t rs = st.rng[env];
     const double gz = c.rand_gravity ? rng_uniform(rs, c.gravity_lo, c.gravity_hi) : c.gravity_default;   // reset_task :301-306
     double embed = st.embed[env];
@@ -1433,6 +1426,16 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
     store_body<T>(st, n, env, b);
     finish_body<T, TOPO>(m, c, st, env, q, b, (T)embed, 0, false);
+}
+template <typename T, int TOPO, bool BALL = false, bool FAST = false>
+__global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
+                                                   const uint8_t* __restrict__ mask) {
+    // (no KtScope here: with it the ball_on_plate instantiation - 134 spilled VGPRs, > 1000 spilled SGPRs - came out of hipcc 7.2 producing NaNs in
+    //  random envs, tests/test_gpu_config_scale.py::test_long_horizon_ball_on_plate_matches_oracle; its duration is taken from HIP events)
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= cp->num_envs) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    reset_body_env<T, TOPO, BALL, FAST>(*mp, *cp, st, env);
 }
 
 // ------------------------------------------------------------------------------------------------ object_push kernels

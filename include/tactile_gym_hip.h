@@ -268,6 +268,14 @@ int tg_get_interior_count(tg_ctx* ctx, int32_t* k);
 /* Reset bank (tg_config.reset_bank): how many auto-resets so far took a precomputed entry (*swapped) and how many were done on the spot because
  * the entry was not ready (*late); *mode = 0 bank off, 1 on, 2 on and waited for.  Synchronises the context's stream. */
 int tg_get_bank_stats(tg_ctx* ctx, int64_t* swapped, int64_t* late, int32_t* mode);
+/* Render targets (multi-GPU; replaces the copy of rank 0's own observations into the gathered batch that SubprocVecEnv's parent does
+ * per env, sb3_helpers/rl_utils.py:17-30): tg_set_obs_targets names up to two caller-owned device buffers uint8 [num_envs][H][W] - rank 0's
+ * blocks of its two alternating gathered batches - and tg_select_obs_target picks where the NEXT steps / resets draw the tactile observations:
+ * 0 = the context's own buffer (tg_get_packed_outputs), 1 / 2 = the caller's.  Each target has its own changed-block record (the block raster
+ * rewrites only what changes, so a buffer must see every launch that is meant for it... or none) and its own captured step graphs.  Reward /
+ * done / feature stay in the context's packed block; tg_get_obs_tactile returns the selected target.  count = 0 forgets the targets. */
+int tg_set_obs_targets(tg_ctx* ctx, int32_t count, void* const* dev_ptrs);
+int tg_select_obs_target(tg_ctx* ctx, int32_t index);
 /* How tg_step runs on this context: *mode = 1 one launch per step (tg_config.fused_step; csrc/tg_fused.hip), 0 separate step / reset / render
  * launches; *envs_per_wavefront = envs one wavefront steps and draws in the one-launch form (0 otherwise). */
 int tg_get_step_mode(tg_ctx* ctx, int32_t* mode, int32_t* envs_per_wavefront);

@@ -150,6 +150,8 @@ SYMBOLS = {
     "tg_get_interior_count": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     "tg_get_bank_stats": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tg_get_step_mode": (C.c_int, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tg_set_obs_targets": (C.c_int, [_ctx, C.c_int32, C.POINTER(C.c_void_p)]),
+    "tg_select_obs_target": (C.c_int, [_ctx, C.c_int32]),
     "tg_pack_interior": (C.c_int, [_ctx, C.c_void_p]),
     "tg_unpack_interior": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p]),
     "tg_get_episode_stats": (C.c_int, [_ctx, _vpp, _vpp]),

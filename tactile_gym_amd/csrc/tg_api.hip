@@ -407,13 +407,20 @@ struct tg_ctx {
     // 3-4 kernels per step, one graph launch instead)
     hipStream_t aux_stream = nullptr;                // object_balance: the reset of finished envs runs here, beside the render
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipGraphExec_t step_graph[2] = {nullptr, nullptr};           // [0] reads d_actions, [1] the pinned caller-owned device buffer
+    // Render targets (tg_set_obs_targets, round 5): the tactile images of a step land in the context's own buffer (target 0) or in one of up to two
+    // caller-owned buffers (targets 1, 2: rank 0's blocks of the two alternating gathered batches, parallel.py) - each with its own changed-block
+    // record and its own captured graphs, since the destination is a kernel argument.
+    uint8_t* obs_ext[2] = {nullptr, nullptr};
+    unsigned long long* drawn_ext[2] = {nullptr, nullptr};
+    int obs_sel = 0;                                             // 0 own buffer, 1 / 2 = obs_ext[0 / 1]
+    hipGraphExec_t step_graph_t[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [target][0 reads d_actions, 1 the pinned caller-owned device buffer]
+    hipGraphExec_t* step_graph = step_graph_t[0];                // the selected target's pair
     const float* step_graph_actions[2] = {nullptr, nullptr};
     hipStream_t step_graph_stream[2] = {nullptr, nullptr};
     bool graph_broken = false;
     // tg_step_random: the policy of a random-action rollout (action_space.sample() for the whole batch) inside the step's graph
     unsigned long long* d_draw = nullptr;      // [0] draw counter, [1] seed, [2] ticket of the sampler's last-block election
-    hipGraphExec_t random_graph = nullptr;
+    hipGraphExec_t random_graph_t[3] = {nullptr, nullptr, nullptr};
     uint64_t random_seed = 0;
     // reset bank (edge_follow / surface_follow, auto_reset; tg_kernels.hpp: BankAux)
     tg::State bk{};                    // the bank view: st's layout, the reset-written arrays in allocations of the bank's own
@@ -662,16 +669,22 @@ template <typename T, int TOPO> static void launch_reset_push_t(tg_ctx* c, const
         }                                                                                    \
     } while (0)
 
+static inline uint8_t* obs_buf(const tg_ctx* c) { return c->obs_sel == 0 ? c->d_obs : c->obs_ext[c->obs_sel - 1]; }   // where this step's images go
+static inline RasterParams raster_params(const tg_ctx* c) {   // ... and the changed-block record that belongs to that buffer
+    RasterParams P = c->rp;
+    if (c->obs_sel != 0) P.drawn = c->drawn_ext[c->obs_sel - 1];
+    return P;
+}
 static void render(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
     Timer t(c, d_mask ? 3 : 1);
-    launch_render(c->rp, c->stim, c->st.stim_xform, 1, c->cfg.num_envs, d_mask, c->d_nodef_dep, c->d_nodef_gray,
-                  c->d_border, c->d_obs, save_prev ? c->d_term : nullptr, nullptr, nullptr, nullptr, c->stream);
+    launch_render(raster_params(c), c->stim, c->st.stim_xform, 1, c->cfg.num_envs, d_mask, c->d_nodef_dep, c->d_nodef_gray,
+                  c->d_border, obs_buf(c), save_prev ? c->d_term : nullptr, nullptr, nullptr, nullptr, c->stream);
 }
 // fused auto-reset: every env's observation from stim_xform; for the envs flagged in `done` also the terminal observation from term_xform
 static void render_fused(tg_ctx* c) {
     Timer t(c, 1);
-    launch_render(c->rp, c->stim, c->st.stim_xform, 1, c->cfg.num_envs, nullptr, c->d_nodef_dep, c->d_nodef_gray,
-                  c->d_border, c->d_obs, nullptr, c->st.term_xform, c->st.done, c->d_term, c->stream);
+    launch_render(raster_params(c), c->stim, c->st.stim_xform, 1, c->cfg.num_envs, nullptr, c->d_nodef_dep, c->d_nodef_gray,
+                  c->d_border, obs_buf(c), nullptr, c->st.term_xform, c->st.done, c->d_term, c->stream);
 }
 
 // SoA [field][n] device -> AoS [n][field] host
@@ -1236,6 +1249,14 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         if (hipGetDevice(&dev_) != hipSuccess || dev_ != (ctx)->cfg.device) TG_HIP(hipSetDevice((ctx)->cfg.device)); \
     } while (0)
 
+}  // extern "C"
+static void drop_step_graphs(tg_ctx* c) {   // every captured step graph of every render target (they are captured again on the next step)
+    for (int t = 0; t < 3; ++t) {
+        for (int k = 0; k < 2; ++k) if (c->step_graph_t[t][k]) { (void)hipGraphExecDestroy(c->step_graph_t[t][k]); c->step_graph_t[t][k] = nullptr; }
+        if (c->random_graph_t[t]) { (void)hipGraphExecDestroy(c->random_graph_t[t]); c->random_graph_t[t] = nullptr; }
+    }
+}
+extern "C" {
 int tg_destroy(tg_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
@@ -1271,8 +1292,8 @@ int tg_destroy(tg_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->bank_stream) (void)hipStreamSynchronize(c->bank_stream);
-    for (int k = 0; k < 2; ++k) if (c->step_graph[k]) (void)hipGraphExecDestroy(c->step_graph[k]);
-    if (c->random_graph) (void)hipGraphExecDestroy(c->random_graph);
+    drop_step_graphs(c);
+    for (int k = 0; k < 2; ++k) if (c->drawn_ext[k]) (void)hipFree(c->drawn_ext[k]);
     if (c->d_draw) (void)hipFree(c->d_draw);
     if (c->d_kt) (void)hipFree(c->d_kt);
     if (c->d_kt_acc) (void)hipFree(c->d_kt_acc);
@@ -1337,7 +1358,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     if (use_fused_step(c)) {
         Timer t(c, 1);
         const int rc = launch_step_render(c->robot.topology, c->cfg.num_envs, c->stream, c->d_robot, c->d_const, c->st, d_act, c->cfg.auto_reset,
-                                          c->bank_mode != 0 ? c->d_bank : nullptr, c->rp, c->stim, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_obs,
+                                          c->bank_mode != 0 ? c->d_bank : nullptr, raster_params(c), c->stim, c->d_nodef_dep, c->d_nodef_gray, c->d_border, obs_buf(c),
                                           c->d_term);
         if (rc == 0) return;
     }
@@ -1399,7 +1420,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
         (void)hipEventRecord(c->ev_join, c->aux_stream);
         {
             Timer t(c, 1);
-            launch_render(c->rp, c->stim, c->st.term_xform, 1, c->cfg.num_envs, nullptr, c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_obs,
+            launch_render(raster_params(c), c->stim, c->st.term_xform, 1, c->cfg.num_envs, nullptr, c->d_nodef_dep, c->d_nodef_gray, c->d_border, obs_buf(c),
                           nullptr, nullptr, nullptr, nullptr, c->stream);
         }
         (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
@@ -1509,7 +1530,7 @@ int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restar
         DrawScope(tg_ctx* c_, bool on_) : c(c_), on(on_) { if (on) { c->st.draw = c->d_draw; c->st.act_out = c->d_actions; } }
         ~DrawScope() { if (on) { c->st.draw = nullptr; c->st.act_out = nullptr; } }
     } scope(c, in_kernel);
-    if (want_graph && !c->random_graph) {
+    if (want_graph && !c->random_graph_t[c->obs_sel]) {
         hipGraph_t g = nullptr;
         const hipStream_t run_stream = c->stream;
         c->stream = c->capture_stream;
@@ -1517,14 +1538,14 @@ int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restar
             if (!in_kernel) sample();
             enqueue_step(c, c->d_actions);
             const hipError_t e1 = hipStreamEndCapture(c->capture_stream, &g);
-            if (!(e1 == hipSuccess && g && hipGraphInstantiate(&c->random_graph, g, nullptr, nullptr, 0) == hipSuccess)) { c->random_graph = nullptr; c->graph_broken = true; }
+            if (!(e1 == hipSuccess && g && hipGraphInstantiate(&c->random_graph_t[c->obs_sel], g, nullptr, nullptr, 0) == hipSuccess)) { c->random_graph_t[c->obs_sel] = nullptr; c->graph_broken = true; }
             if (g) (void)hipGraphDestroy(g);
         } else c->graph_broken = true;
         c->stream = run_stream;
         (void)hipGetLastError();
     }
-    if (want_graph && c->random_graph) {
-        TG_HIP(hipGraphLaunch(c->random_graph, c->stream));
+    if (want_graph && c->random_graph_t[c->obs_sel]) {
+        TG_HIP(hipGraphLaunch(c->random_graph_t[c->obs_sel], c->stream));
         bank_refill(c);
         return 0;
     }
@@ -1532,6 +1553,33 @@ int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restar
     enqueue_step(c, c->d_actions);
     bank_refill(c);
     TG_HIP(hipGetLastError());
+    return 0;
+}
+
+int tg_set_obs_targets(tg_ctx* c, int32_t count, void* const* dev_ptrs) {
+    if (!c || count < 0 || count > 2 || (count > 0 && !dev_ptrs)) return fail(-1, "tg_set_obs_targets: bad argument");
+    TG_ENTER(c);
+    TG_HIP(hipStreamSynchronize(c->stream));
+    for (int t = 1; t < 3; ++t) {        // the old targets' graphs name their buffers: gone with them
+        for (int k = 0; k < 2; ++k) if (c->step_graph_t[t][k]) { (void)hipGraphExecDestroy(c->step_graph_t[t][k]); c->step_graph_t[t][k] = nullptr; }
+        if (c->random_graph_t[t]) { (void)hipGraphExecDestroy(c->random_graph_t[t]); c->random_graph_t[t] = nullptr; }
+    }
+    c->obs_sel = 0; c->step_graph = c->step_graph_t[0];
+    const size_t regions = (c->rp.W % 128 == 0 && c->rp.H % 128 == 0) ? (size_t)(c->rp.W / 128) * (c->rp.H / 128) : 0;
+    for (int k = 0; k < 2; ++k) {
+        c->obs_ext[k] = k < count ? (uint8_t*)dev_ptrs[k] : nullptr;
+        if (k < count && !dev_ptrs[k]) return fail(-1, "tg_set_obs_targets: NULL target");
+        if (k < count && c->rp.drawn != nullptr) {   // a changed-block record of its own: nothing in that buffer is known to hold the untouched-sensor image
+            if (!c->drawn_ext[k]) TG_HIP(hipMalloc(&c->drawn_ext[k], (size_t)c->cfg.num_envs * regions * 8));
+            TG_HIP(hipMemset(c->drawn_ext[k], 0xFF, (size_t)c->cfg.num_envs * regions * 8));
+        }
+    }
+    return 0;
+}
+int tg_select_obs_target(tg_ctx* c, int32_t index) {
+    if (!c || index < 0 || index > 2 || (index > 0 && c->obs_ext[index - 1] == nullptr)) return fail(-1, "tg_select_obs_target: no such target");
+    c->obs_sel = index;
+    c->step_graph = c->step_graph_t[index];
     return 0;
 }
 
@@ -1589,7 +1637,7 @@ int tg_pack_interior(tg_ctx* c, void* dst_dev) {
     TG_ENTER(c);
     if (c->cfg_turn_off_border || c->n_interior == 0) return fail(-1, "tg_pack_interior: no constant border ring");
     const int K = c->n_interior, HW = c->H * c->W / 4;     // in 4-pixel words
-    hipLaunchKernelGGL(k_pack_interior, dim3((K / 4 + 255) / 256, c->cfg.num_envs), dim3(256), 0, c->stream, (const uint32_t*)c->d_obs, c->d_int_idx, K, HW,
+    hipLaunchKernelGGL(k_pack_interior, dim3((K / 4 + 255) / 256, c->cfg.num_envs), dim3(256), 0, c->stream, (const uint32_t*)obs_buf(c), c->d_int_idx, K, HW,
                        c->cfg.num_envs, (uint32_t*)dst_dev);
     TG_HIP(hipGetLastError());
     return 0;
@@ -1809,7 +1857,7 @@ int tg_sync(tg_ctx* c) {
     return 0;
 }
 
-int tg_get_obs_tactile(tg_ctx* c, void** p) { if (!c || !p) return fail(-1, "NULL argument"); *p = c->d_obs; return 0; }
+int tg_get_obs_tactile(tg_ctx* c, void** p) { if (!c || !p) return fail(-1, "NULL argument"); *p = obs_buf(c); return 0; }
 int tg_get_terminal_obs(tg_ctx* c, void** p) { if (!c || !p) return fail(-1, "NULL argument"); *p = c->d_term; return 0; }
 int tg_get_reward_done_dev(tg_ctx* c, void** r, void** d) {
     if (!c) return fail(-1, "NULL ctx");
@@ -1874,7 +1922,7 @@ int tg_get_reward_done(tg_ctx* c, float* reward, uint8_t* done) {
 int tg_copy_obs_tactile(tg_ctx* c, uint8_t* dst, int32_t terminal) {
     if (!c || !dst) return fail(-1, "NULL argument");
     TG_ENTER(c);
-    TG_HIP(hipMemcpyAsync(dst, terminal ? c->d_term : c->d_obs, (size_t)c->cfg.num_envs * c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipMemcpyAsync(dst, terminal ? c->d_term : obs_buf(c), (size_t)c->cfg.num_envs * c->H * c->W, hipMemcpyDeviceToHost, c->stream));
     TG_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1986,8 +2034,7 @@ int tg_profile_enable(tg_ctx* c, int32_t enable) {
     c->profile = enable == 1;
     if (c->profile_clock != (enable == 2)) {
         // the step graphs carry the slot pointer (or its absence) in their kernel arguments: captured again on the next step
-        for (int k = 0; k < 2; ++k) if (c->step_graph[k]) { (void)hipGraphExecDestroy(c->step_graph[k]); c->step_graph[k] = nullptr; }
-        if (c->random_graph) { (void)hipGraphExecDestroy(c->random_graph); c->random_graph = nullptr; }
+        drop_step_graphs(c);
         c->profile_clock = enable == 2;
     }
     for (int k = 0; k < 6; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }

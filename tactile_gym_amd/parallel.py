@@ -23,6 +23,7 @@ transport (how it travels):
   "auto"        ipc when the set-up handshake succeeds on every rank, else collective.
 """
 import ctypes as C
+import os
 
 from . import _capi as capi
 
@@ -376,6 +377,22 @@ class ShardedVecEnv:
                     self._full[slot] = torch.zeros((self.world, total), dtype=torch.uint8, device=dev)
         if self.transport == "ipc" and self.rank != self.root:
             self._scratch = torch.zeros(max(rest_bytes, 16), dtype=torch.uint8, device=dev) if packed is None else None
+        # Rank 0 draws its own shard STRAIGHT into its block of the gathered batch (round 5): the two alternating batches are the env library's
+        # render targets 1 and 2 (tg_set_obs_targets: each with its own changed-block record and step graphs), selected before every step by
+        # the slot its message will use.  Until round 4 the shard was drawn into the library's buffer and copied over (16.8 MB per step at
+        # 1024 envs: the one-rank ipc + tiles step 57.5 us against 43 without an exchange).
+        self._direct = False
+        venv = getattr(self.local, "venv", None)
+        if (self.transport == "ipc" and self.rank == self.root and self.payload == "tiles" and hasattr(self.local, "unpack_tiles_multi")
+                and venv is not None and hasattr(venv, "set_obs_targets") and os.environ.get("TG_NO_DIRECT_BATCH") is None):
+            venv.sync()
+            venv.set_obs_targets([self._batch_buffer(s)[self.root * n:(self.root + 1) * n].data_ptr() for s in (0, 1)])
+            self._direct = True
+            # these two targets' step graphs can only be captured now that the batches exist, i.e. under the process group: the first steps
+            # on them go through the quiesce below even on a primed shard (once, in reset(), outside any timed region; no collective runs
+            # between the steps of the ipc transport, so the watchdog has nothing to poll while the two captures happen)
+            self._captured.clear()
+            self._quiesce_always = True
 
     # ------------------------------------------------------------------ sender side
     def _rest_tensor(self, obs, rew, done):
@@ -468,11 +485,12 @@ class ShardedVecEnv:
                         rest = self._rest_tensor(obs, rew, done)
                         c = c[:5] + (C.c_void_p(rest.data_ptr()), rest.numel(), False)
                         self._keep = rest
+                    n_img = 0 if c[0].value == c[1].value else c[2]        # drawn in place (render target = this block): only the small block moves
                     if fused_flag:                                         # the "consumed" signal rides in the copy's launch (one dependent launch less per step)
-                        capi.check(ipc.L.tg_copy_bytes2_flag(ipc._stream(), c[0], c[1], c[2], c[3], c[5], c[6], ipc._flag_ptr("consumed", slot, 0), self.world, 16,
+                        capi.check(ipc.L.tg_copy_bytes2_flag(ipc._stream(), c[0], c[1], n_img, c[3], c[5], c[6], ipc._flag_ptr("consumed", slot, 0), self.world, 16,
                                                              (t - 2) & 0xFFFFFFFF))
                     else:
-                        capi.check(ipc.L.tg_copy_bytes2(ipc._stream(), c[0], c[1], c[2], c[3], c[5], c[6]))
+                        capi.check(ipc.L.tg_copy_bytes2(ipc._stream(), c[0], c[1], n_img, c[3], c[5], c[6]))
                     if L["vis_bytes"]:
                         ipc.copy(self._stage[slot][L["off_vis"]:].data_ptr(), obs["visual"].reshape(-1))
                 else:
@@ -610,6 +628,7 @@ class ShardedVecEnv:
 
     # ------------------------------------------------------------------ VecEnv surface
     def reset(self):
+        self._aim()
         obs = self.local.reset()
         if self._solo:
             return obs
@@ -647,7 +666,7 @@ class ShardedVecEnv:
         if not todo or self._solo:
             return
         self._captured.update(todo)
-        if getattr(self.local, "primed", False):
+        if getattr(self.local, "primed", False) and not getattr(self, "_quiesce_always", False):
             return                                   # TorchShard.prime(): the graphs were captured before the process group existed - nothing to wait for
         if not (getattr(self.local, "raw", False) and self.torch.cuda.is_available()):
             return                                   # a host-side shard (the gloo tests): nothing is captured
@@ -655,14 +674,21 @@ class ShardedVecEnv:
         self.torch.cuda.synchronize()
         time.sleep(0.3)
 
+    def _aim(self):
+        """Rank 0, direct mode: the next message is t = tick + 1 and lands in slot t & 1 - the library draws this step's images there."""
+        if getattr(self, "_direct", False):
+            self.local.venv.select_obs_target(1 + ((self._tick + 1) & 1))
+
     def step_random(self, seed, first_draw=0, restart=False):
         """step(action_space.sample()) on every rank's shard (TorchShard.step_random: the draw inside the step's graph), then the exchange of step().
         Every rank passes its own seed."""
         self._quiesce_before_capture("random")
+        self._aim()
         return self._exchange(*self.local.step_random(seed, first_draw, restart))
 
     def step(self, local_actions):
         self._quiesce_before_capture("step")
+        self._aim()
         return self._exchange(*self.local.step(local_actions))
 
     def _exchange(self, obs, rew, done, info):
@@ -719,6 +745,8 @@ class ShardedVecEnv:
                "full_payload_bytes": _align(L["nb_full"], 16) + L["total"] - L["off_rest"]}
         if self._ipc is not None and self._ipc.uncached is not None:
             out["receive_slots_uncached"] = self._ipc.uncached
+        if self.rank == self.root:
+            out["rank0_draws_into_batch"] = bool(getattr(self, "_direct", False))   # its shard is rendered in place (tg_set_obs_targets), not copied
         if self.payload == "tiles" and self.rank == self.root and self._handed:
             hdr = self._full[self._handed & 1][:, :4].contiguous().view(self.torch.int32).reshape(-1).cpu().tolist()
             if self.transport == "ipc" and hasattr(self.local, "unpack_tiles_multi"):
@@ -735,6 +763,13 @@ class ShardedVecEnv:
         return out
 
     def close(self):
+        if getattr(self, "_direct", False):
+            self._direct = False
+            try:
+                self.local.venv.sync()
+                self.local.venv.set_obs_targets([])       # the library goes back to its own buffer before the batches are freed
+            except Exception:  # noqa: BLE001
+                pass
         if self._ipc is not None:
             self._drain()
             self._full = [None, None]

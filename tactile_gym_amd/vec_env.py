@@ -405,9 +405,24 @@ class TactileVecEnv(_VecEnvBase):
         capi.check(fn(self._ctx, C.byref(p)))
         return p.value
 
+    def set_obs_targets(self, dev_ptrs):
+        """Up to two caller-owned device buffers uint8 [N, H, W] the tactile observations can be drawn into instead of the context's own
+        (tg_set_obs_targets: rank 0's blocks of the gathered batches, parallel.ShardedVecEnv); [] forgets them.  select_obs_target(k) picks
+        where the next steps / resets draw: 0 own buffer, 1 / 2 the caller's."""
+        arr = (C.c_void_p * max(len(dev_ptrs), 1))(*[C.c_void_p(int(p)) for p in dev_ptrs])
+        capi.check(self._L.tg_set_obs_targets(self._ctx, len(dev_ptrs), arr))
+        self._obs_sel = 0
+        for k in [k for k in self._views if isinstance(k, tuple) and k[0] == "obs" and k[1] != 0]:
+            del self._views[k]
+
+    def select_obs_target(self, index):
+        if index != getattr(self, "_obs_sel", 0):
+            capi.check(self._L.tg_select_obs_target(self._ctx, int(index)))
+            self._obs_sel = int(index)
+
     def tactile_torch(self, terminal=False):
-        """Zero-copy torch.uint8 [N,H,W,1] view of the device observation buffer."""
-        key = "term" if terminal else "obs"
+        """Zero-copy torch.uint8 [N,H,W,1] view of the device observation buffer (of the selected render target)."""
+        key = "term" if terminal else ("obs", getattr(self, "_obs_sel", 0))
         if key not in self._views:   # the library's buffers never move: build each aliasing tensor once
             import torch
             arr = _DevArray(self.tactile_device_ptr(terminal), (self.num_envs, self.H, self.W, 1), "|u1")

@@ -119,6 +119,9 @@ def _ipc_worker(rank, world, port, out_path, env_id, modes, size, n_local, paylo
         torch.cuda.synchronize()
     info = env.exchange_info()
     if rank == 0:
+        # round 5: with the tile payload rank 0's shard is drawn straight into its block of the gathered batch (tg_set_obs_targets: two render
+        # targets, one per alternating batch) - the comparison below is against a context that draws into its own buffer
+        assert info["rank0_draws_into_batch"] == (payload == "tiles")
         # the single-process reference: the same world * n_local envs (seeds 50 ...) in one context, same actions
         ref = tg.make_vec(env_id, num_envs=world * n_local, max_steps=200, image_size=[size, size], env_modes=modes, seed=50, obs_mode="torch",
                           auto_reset=True)

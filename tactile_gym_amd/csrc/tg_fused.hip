@@ -19,7 +19,6 @@
 // FMA contraction (like tg_api.hip), the raster is contraction-free by the pragma in tg_raster_dev.hpp, which is included last.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <cstdlib>
 
 #include "tg_fused.h"
 #include "tg_kernels.hpp"
@@ -32,7 +31,7 @@ __global__ __launch_bounds__(64) void k_step_render(const DevRobot<T>* __restric
                                                     const float* __restrict__ actions, int E, int auto_reset, const BankDev* __restrict__ bd,
                                                     RasterParams P, Stimulus S, const float* __restrict__ nodef_dep,
                                                     const uint8_t* __restrict__ gray_u8, const uint8_t* __restrict__ border,
-                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ term_out, int rec_cap, int dbg) {
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ term_out, int rec_cap) {
     KtScope kt_scope_(st.kt);
     extern __shared__ TriRec recs[];
     __shared__ int count;
@@ -45,8 +44,8 @@ __global__ __launch_bounds__(64) void k_step_render(const DevRobot<T>* __restric
 #pragma unroll
     for (int k = 0; k < 12; ++k) { xs[k] = 0.0f; xt[k] = 0.0f; }
     if (lane < E && env < n) {
-        if (!(dbg & 1)) step_env<T, TOPO>(*mp, *cp, st, env, actions);
-        dn = (dbg & 1) ? 0 : st.done[env];                                    // (this lane's own store)
+        step_env<T, TOPO>(*mp, *cp, st, env, actions);
+        dn = st.done[env];                                    // (this lane's own store)
         if (auto_reset && dn) reset_or_swap<T, TOPO>(mp, cp, st, env, true, 0, bd);
         else dn = 0;
 #pragma unroll
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(64) void k_step_render(const DevRobot<T>* __restric
     const size_t img_bytes = (size_t)P.W * P.H;
     for (int e = 0; e < E; ++e) {
         const int ee = env0 + e;
-        if (ee >= n || (dbg & 2)) break;
+        if (ee >= n) break;
         float M[12];
         if (__builtin_amdgcn_readlane(dn, e)) {               // the finished episode's last observation, then the new episode's first
 #pragma unroll
@@ -87,14 +86,13 @@ int launch_step_render(int topology, int num_envs, hipStream_t stream, const voi
     const int rec_cap = 2 * S.n_tris < 2 ? 2 : 2 * S.n_tris;
     const size_t lds = (size_t)rec_cap * sizeof(TriRec);
     const int E = fused_envs_per_wave(num_envs);
-    static const int dbg = getenv("TG_FUSED_DBG") ? atoi(getenv("TG_FUSED_DBG")) : 0;
     const dim3 grid((num_envs + E - 1) / E), block(64);
     if (topology == 0)
         hipLaunchKernelGGL((k_step_render<double, 0>), grid, block, lds, stream, (const DevRobot<double>*)d_robot, (const EnvConst<double>*)d_const, st,
-                           d_actions, E, auto_reset, (const BankDev*)d_bank, P, S, nodef_dep, gray_u8, border, out, term_out, rec_cap, dbg);
+                           d_actions, E, auto_reset, (const BankDev*)d_bank, P, S, nodef_dep, gray_u8, border, out, term_out, rec_cap);
     else
         hipLaunchKernelGGL((k_step_render<double, 1>), grid, block, lds, stream, (const DevRobot<double>*)d_robot, (const EnvConst<double>*)d_const, st,
-                           d_actions, E, auto_reset, (const BankDev*)d_bank, P, S, nodef_dep, gray_u8, border, out, term_out, rec_cap, dbg);
+                           d_actions, E, auto_reset, (const BankDev*)d_bank, P, S, nodef_dep, gray_u8, border, out, term_out, rec_cap);
     return 0;
 }
 

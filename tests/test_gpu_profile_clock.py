@@ -1,0 +1,56 @@
+"""The per-kernel durations bench.py quotes (tg_profile_enable(2): the kernels' own clock, csrc/tg_kt.hpp) against the step they are part of.
+
+VERDICT r4 found bench lines whose HIP-event kernel durations added up to MORE than the step (47.0 > 44.1 us): an event pair carries 3 - 5 us of
+its own.  The own-clock figures - every wavefront of the first / last 2048 workgroups stamps wall_clock64 at its start / end, the step stays
+one hipGraph - must fit: their sum per step below the measured step time, each class positive, and the event figures above them by roughly
+what an empty event pair measures."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EDGE = dict(movement_mode="xy", control_mode="TCP_velocity_control", noise_mode="rand_height", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+
+
+def test_kernel_clock_durations_fit_inside_the_step():
+    import torch
+    import tactile_gym_amd as tg
+    n, steps = 1024, 200
+    v = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=EDGE, seed=3, auto_reset=True, obs_mode="torch")
+    v.reset()
+    for k in range(20):
+        v.step_random_async(9, k, restart=(k == 0))
+    v.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        v.step_random_async(9, 20 + k)
+    v.sync()
+    step_ms = 1e3 * (time.perf_counter() - t0) / steps
+    v.profile("clock")                                   # re-captures the graph with the stamp slots in its kernels' arguments
+    for k in range(steps):
+        v.step_random_async(9, 20 + steps + k, restart=(k == 0))
+    v.sync()
+    clk = v.profile_get()
+    v.profile(True)                                      # HIP events, launch by launch
+    acts = torch.zeros(n, v.act_dim, device="cuda")
+    for _ in range(20):
+        v.step_async(acts)
+    v.sync()
+    ev = v.profile_get()
+    v.profile(False)
+    v.step_random_async(9, 1000, restart=True)           # the plain graph is captured again and runs
+    v.sync()
+    per = {k: clk[k + "_clock"][0] / max(clk[k + "_clock"][1], 1) for k in ("step", "render", "reset")}
+    assert clk["step_clock"][1] == clk["render_clock"][1] == steps
+    assert all(x > 0.0005 for x in per.values()), per
+    assert sum(per.values()) < step_ms, (per, step_ms)                      # the kernels fit inside the step they make up ...
+    assert sum(per.values()) > 0.6 * step_ms, (per, step_ms)                # ... and are most of it (the rest: dispatch gaps between the nodes)
+    empty = ev["empty_event_pair"][0] / max(ev["empty_event_pair"][1], 1)
+    for k in ("step", "render"):
+        e = ev[k][0] / max(ev[k][1], 1)
+        assert e > per[k], (k, e, per[k])                                    # an event pair measures the kernel plus its own overhead
+        assert e - per[k] < 3 * empty + 0.004, (k, e, per[k], empty)
+    v.close()

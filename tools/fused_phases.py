@@ -1,5 +1,6 @@
-"""Development: per-phase timing of k_step_render (csrc/tg_fused.hip) from its own wall-clock stamps.  Needs a library built with
-TG_EXTRA_FLAGS=-DTG_FUSED_STAMPS; prints the phase line tg_profile_get(6) writes to stderr, plus the event-pair figures.
+"""Per-kernel durations of one configuration, launch by launch: HIP event pairs and the kernels' own clock side by side (tg_profile_enable(1);
+TG_FUSED_STEP=1 in the environment times the one-launch step, csrc/tg_fused.hip).  The per-phase figures of profiles/r5_exp_fused_step.txt came
+from a development build of this kernel with phase stamps (-DTG_FUSED_STAMPS, removed since).
 usage: python tools/fused_phases.py [num_envs] [steps]"""
 import os
 import sys

@@ -323,7 +323,9 @@ class Workload:
                        "k_render_scatter" if self.env_id == "object_roll-v0" else "k_render_tactile")
         if prof["step"][1] == 0 and prof["render"][1] > 0:            # fused_step: the one launch (csrc/tg_fused.hip)
             return "k_step_render", km["k_render_tactile"], "k_render_tactile"
-        if km["k_step"] * prof["step"][1] >= km["k_render_tactile"] * prof["render"][1]:
+        # (within 5 % the render counts as the dominant one: it is the kernel that moves the algorithmic bytes - on the headline the two are a
+        #  coin flip from run to run, 16.6 against 16.1 us, and the line should not change its kernel with the box)
+        if km["k_step"] * prof["step"][1] > 1.05 * km["k_render_tactile"] * prof["render"][1]:
             return "k_step", km["k_step"], "k_step"
         return render_name, km["k_render_tactile"], "k_render_tactile"
 

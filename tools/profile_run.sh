@@ -1,10 +1,10 @@
 #!/bin/bash
-# Evidence run (rounds 3, 4: TG_PROFILE_TAG names the output set) on the MI355X box (one gpurun call): the default bench line (headline + other_configs + literal + CPU baseline),
+# Evidence run (rounds 3 - 5: TG_PROFILE_TAG names the output set) on the MI355X box (one gpurun call): the default bench line (headline + other_configs + literal + CPU baseline),
 # one bench line per env, rocprofv3 kernel stats and SQ counters of the default command and of object_push / object_balance /
 # surface_follow-v2 (MG400, eight-sweep blocks) / the literal solver, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of
 # edge_follow, object_push and object_balance.  Outputs under gpurun_out/<tag>/; copied to profiles/<tag>_* afterwards (tools/profile_collect.py).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${TG_PROFILE_TAG:-r4_final}
+TAG=${TG_PROFILE_TAG:-r5_final}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -21,9 +21,11 @@ $B --no-literal --observation-mode visuotactile --steps 200 --warmup 20 2>/dev/n
 $B --no-literal --separate-policy 2>/dev/null | grep metric > $O/bench_edge_separate_policy.json
 TG_RESET_BANK=0 $B --env surface_follow-v2 2>/dev/null | grep metric > $O/bench_surface_follow-v2_bank_off.json
 $B --env object_push-v0 --narrowphase gjk_manifold --steps 100 --warmup 10 2>/dev/null | grep metric > $O/bench_object_push-v0_gjk_manifold.json
-(python tools/pcie_rate.py; python tools/pcie_rate.py --tiles) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
+(python tools/pcie_rate.py; python tools/pcie_rate.py --tiles; python tools/pcie_rate.py --tiles; echo "TG_TILES_ZERO_COPY=0 (round 4: pack on the device, then copy):"; TG_TILES_ZERO_COPY=0 python tools/pcie_rate.py --tiles) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
+TG_FUSED_STEP=1 $B --no-literal 2>/dev/null | grep metric > $O/bench_edge_fused_step.json          # the one-launch step (opt-in: measured slower)
 python tools/ball_rate.py 1024 8192 2>&1 | grep -v amdgpu > $O/ball_on_plate_rate.txt
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank.json
+TG_NO_DIRECT_BATCH=1 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank_copy_into_batch.json   # round 4's path: rank 0 copies its shard into the batch
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport collective --payload interior 2>/dev/null | grep metric > $O/bench_edge_rccl_interior_1rank.json
 cd /tmp; export TMPDIR=/tmp
 P="python $R/bench.py --no-cpu-baseline --no-literal --no-companions"

@@ -291,9 +291,11 @@ class Workload:
         self._fused_synced = False
         for k in ("step", "render", "reset", "render_masked", "scene", "empty_event_pair"):
             prof[k] = ev[k]
-        for k in ("step", "render", "reset", "render_masked"):      # launches per class of the clocked rollout (events: of the short second run)
-            if clock:
-                prof[k + "_launches"] = prof[k + "_clock"][1]
+        # scopes per env step and class: from the clocked rollout where the class carries a clock, from the event run otherwise
+        n_ev = max(min(steps, 10), 1)
+        for k in ("step", "render", "reset", "render_masked"):
+            c = prof.get(k + "_clock", (0.0, 0))[1] if clock else 0
+            prof[k + "_per_step"] = c / max(steps, 1) if c > 0 else ev[k][1] / n_ev
         return prof
 
     @staticmethod
@@ -335,11 +337,10 @@ class Workload:
         ab = algo_bytes(self.env_id, self.image_size)
         achieved = ab * self.n / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = read_traffic(self.env_id, self.n, self.image_size, key, ab) if traffic_ok else None
-        cnt = {q: prof.get(q + "_launches", prof[q][1]) for q in ("step", "render", "reset", "render_masked")}
-        launches = {"k_step": cnt["step"], "k_render_tactile": cnt["render"], "k_reset": cnt["reset"]}
-        per_step = max(cnt["render"], cnt["step"], 1)
-        kernels_per_step = sum(km[k] * cnt[q] for k, q in (("k_step", "step"), ("k_render_tactile", "render"), ("k_reset_per_launch", "reset"),
-                                                           ("k_render_tactile_masked", "render_masked"))) / per_step
+        lps = {q: prof.get(q + "_per_step", 1.0 if prof[q][1] else 0.0) for q in ("step", "render", "reset", "render_masked")}
+        launches = {"k_step": prof["step"][1], "k_render_tactile": prof["render"][1], "k_reset": prof["reset"][1]}
+        kernels_per_step = sum(km[k] * lps[q] for k, q in (("k_step", "step"), ("k_render_tactile", "render"), ("k_reset_per_launch", "reset"),
+                                                           ("k_render_tactile_masked", "render_masked")))
         out = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_env_step": ab,
                "kernel_ms": {k: round(v, 4) for k, v in km.items()}, "kernel_ms_source": src,
@@ -388,7 +389,10 @@ def companion(env_id, image_size, n, physics, steps, barrier, what, **kw):
         for _ in range(10):
             w.step(w.shard)
         dt = w.timed(w.shard, steps, barrier)
-        prof = w.profile(w.shard, min(steps, 20), barrier)
+        w.shard.reset()                                    # the profile window covers the same phase of the episodes as the timed window
+        for _ in range(10):
+            w.step(w.shard)
+        prof = w.profile(w.shard, steps, barrier)
     roof = w.roofline(prof, ms_per_step=1e3 * dt / steps)
     out = {"workload": f"{env_id}, {w.modes['arm_type'].upper()} + {w.modes['tactile_sensor_name']}, {n} vec-envs, {image_size}x{image_size}" + what,
            "value": round(n * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),

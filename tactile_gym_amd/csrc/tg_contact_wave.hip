@@ -1033,7 +1033,8 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
 template <typename T, int TOPO, bool POS, int SHAPE, bool CONE, int NT = 1>
 __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                           const float* __restrict__ actions) {
-    KtScope kt_scope_(st.kt);
+    // (no KtScope: its one more live scalar pair took this kernel from 0 to 204 B of scratch per lane - 15 MB of spill traffic per launch by the
+    //  PMC - at a duration in milliseconds, where a HIP event pair's 5 us do not matter)
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double wave_lds_raw[];
     const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
@@ -1754,7 +1755,8 @@ __global__ __launch_bounds__(64) void k_step_arm_wave(const DevRobot<T>* __restr
 template <typename T, int TOPO, int SHAPE, bool CONE, int NT = 1>
 __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                            const uint8_t* __restrict__ mask) {
-    KtScope kt_scope_(st.kt);
+    // (no KtScope: its one more live scalar pair took this kernel from 0 to 204 B of scratch per lane - 15 MB of spill traffic per launch by the
+    //  PMC - at a duration in milliseconds, where a HIP event pair's 5 us do not matter)
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double wave_lds_raw[];
     const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;

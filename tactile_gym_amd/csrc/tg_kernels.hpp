@@ -1520,7 +1520,7 @@ __device__ __forceinline__ void finish_push(const DevRobot<T>& m, const EnvConst
 template <typename T, int TOPO, bool POS>
 __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
-    KtScope kt_scope_(st.kt);
+    // (no KtScope: these kernels run for milliseconds and live at the edge of the register file - the scope costs them up to 1.2 KB more scratch)
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double push_lds_raw[];             // kPushLdsWords * 64 words of T (83 KB in f64: dynamic, above the 64 KB static cap)
     const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
@@ -1601,7 +1601,7 @@ __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict_
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_reset_push(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
-    KtScope kt_scope_(st.kt);
+    // (no KtScope: these kernels run for milliseconds and live at the edge of the register file - the scope costs them up to 1.2 KB more scratch)
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double push_lds_raw[];
     const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
@@ -1752,7 +1752,7 @@ __device__ __forceinline__ void finish_roll(const DevRobot<T>& m, const EnvConst
 template <typename T, int TOPO, bool POS>
 __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
-    KtScope kt_scope_(st.kt);
+    // (no KtScope: these kernels run for milliseconds and live at the edge of the register file - the scope costs them up to 1.2 KB more scratch)
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double push_lds_raw[];
     const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;
@@ -1808,7 +1808,7 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_reset_roll(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
-    KtScope kt_scope_(st.kt);
+    // (no KtScope: these kernels run for milliseconds and live at the edge of the register file - the scope costs them up to 1.2 KB more scratch)
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double push_lds_raw[];
     const lds_ptr<T> lds = (lds_ptr<T>)push_lds_raw;

@@ -17,6 +17,9 @@
 
 namespace tg {
 
+#ifdef TG_NO_KT        // A/B build switch: what the instrumentation costs a kernel in registers (see the kernels that do without it)
+struct KtScope { __device__ __forceinline__ explicit KtScope(unsigned long long*) {} };
+#else
 struct KtScope {
     unsigned long long* base;     // (uniform: stays in scalar registers; the slot address is formed again at the end rather than held in VGPRs)
     static constexpr size_t kEdge = 2048;   // workgroups at either end of the grid that stamp (8192 wavefronts: more than the chip holds at once)
@@ -41,5 +44,6 @@ struct KtScope {
     KtScope(const KtScope&) = delete;
     KtScope& operator=(const KtScope&) = delete;
 };
+#endif
 
 }  // namespace tg

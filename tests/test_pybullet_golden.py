@@ -3,7 +3,7 @@
 `tools/pybullet_probe.py --backend pybullet --assets <tactile_gym/assets> --out tests/golden` writes `tests/golden/pybullet_<scenario>.npz`
 from raw PyBullet calls (no tactile_gym source needed); this file then replays every scenario through oracle/ and compares, naming the
 PARITY_ASSUMPTIONS items each comparison closes.  Without such files those tests are skipped (reported as skipped, not passed).  One test
-always runs: the same four scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
+always runs: the same five scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
 exercises the scenario scripts, the file format and the comparison, not the physics (oracle against oracle)."""
 import glob
 import os
@@ -27,6 +27,13 @@ CHECKS = {
     "reset_move": [("ik", 1e-5, "A9: calculateInverseKinematics (damped least squares from the current state, 100 iterations, 1e-8)"),
                    ("ticks", 0, "A10-A11: blocking_move's exit (pose tolerance, joint speed) and POSITION_CONTROL's default max force"),
                    ("q_final", 1e-6, "A10-A11")],
+    "push_contacts": [("n_table", 0, "A23, A25: which cube vertices are cube - table contacts (at most 4, within the breaking threshold) - survey row n1"),
+                      ("tip_contact", 0, "A24, A26: when the tip core - cube pair has a contact point (margins 1e-3 / 1e-4, breaking threshold 1e-4) - row n1"),
+                      ("cube_pos", 2e-5, "A24-A28: the soft tip contact (contactStiffness / contactDamping -> cfm, erp), cone friction on the table, "
+                                         "solver row order: the cube's path over 240 ticks"),
+                      ("cube_rot", 1e-4, "A27-A28: friction torques (the cube's yaw under an off-centre, slowly turning push)"),
+                      ("tip_normal", 1e-2, "A24: the contact normal of the tip point (PyBullet's is on B; sign convention: from the cube towards the tip)"),
+                      ("tip_distance", 1e-4, "A24: the tip point's signed distance (negative = penetration) with both margins subtracted")],
     "tactile_depth": [("depth", 2e-5, "A12-A16: camera mounting, view / projection matrices, the depth buffer's convention and raster rules "
                                       "(the tolerance the reference's own nodef_dep fixtures are reproduced to)")],
 }
@@ -71,3 +78,6 @@ def test_probe_format_and_comparison_with_the_oracle_backend(tmp_path):
     d = np.load(tmp_path / "ref" / "pybullet_tactile_depth.npz")
     assert d["depth"].shape == (128, 128) and 1000 < int((d["depth"] < 1.0).sum()) < 128 * 128     # the edge is in view
     assert int(np.load(tmp_path / "ref" / "pybullet_reset_move.npz")["ticks"]) < 1000                # the blocking move converges
+    d = np.load(tmp_path / "ref" / "pybullet_push_contacts.npz")
+    assert d["cube_pos"].shape == (240, 3) and int(d["tip_contact"].sum()) > 200 and set(d["n_table"].tolist()) == {4}   # the tip pushes, the cube stays flat
+    assert d["cube_pos"][-1, 1] - d["cube_pos"][0, 1] > 0.004 and np.all(d["tip_distance"] <= 0.0)                        # ... and moves under the push

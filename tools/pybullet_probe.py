@@ -4,7 +4,7 @@ directory (`tactile_gym/assets`: URDFs and meshes only).
     python tools/pybullet_probe.py --backend pybullet --assets /path/to/tactile_gym/assets --out tests/golden
     python tools/pybullet_probe.py --backend oracle --out /tmp/probe            # the same scenarios through oracle/ (format check)
 
-What it does: runs four primitive scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
+What it does: runs five primitive scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
 backend-neutral operations - through one of two backends and writes `pybullet_<scenario>.npz` (inputs + recorded outputs):
 
     arm_statics       calculateInverseDynamics(q, 0, 0), calculateMassMatrix(q), calculateJacobian(TCP) at three poses
@@ -16,6 +16,11 @@ backend-neutral operations - through one of two backends and writes `pybullet_<s
                       POSITION_CONTROL (robot.py:188-260); IK solution, tick count, final q -> A9-A11
     tactile_depth     the in-sensor camera (tactile_sensor.py:150-246): view / projection from the sensor body link, getCameraImage depth of the
                       edge stimulus at a given pose, 128 x 128 -> A12-A16 (camera model, depth buffer convention, raster rules)
+    push_contacts     object_push's contact path on a UR5 + right-angle TacTip (tip collision core on, object_push_env.py:40-56, 196-227): Robot.reset
+                      to the work-frame origin, the cube at its start pose with the env's changeDynamics, then 10 control steps of a constant
+                      work-frame push (24 ticks each); per tick the cube's pose and velocity, which cube - table and cube - tip contacts
+                      exist (getContactPoints), the tip contact's normal and distance -> A23-A29 (contact sets, margins, soft tip contact,
+                      cone friction) and row n1 of the survey (contact-pair indices)
 
 tests/test_pybullet_golden.py compares oracle/ with every `tests/golden/pybullet_*.npz` it finds (tolerances and the assumption each
 comparison closes are in the test) and always runs the oracle backend against itself through a temporary directory, so the file format and
@@ -198,6 +203,125 @@ class PyBulletBackend:
         return np.reshape(img[3], (size, size)).astype(np.float32)
 
 
+PUSH_WORKFRAME = ([0.55, -0.20, 0.04], [-math.pi, 0.0, math.pi / 2])            # object_push_env.py:87-90 (ur5): well_designed_pos, rpy
+PUSH_REST = [-0.29446578243858357, -2.1633703222876646, -1.7712875440608364, -0.7758826291678864, 1.569501010720629, -1.8628739133606422]
+PUSH_VEL = [0.01, 0.0, 0.0, 0.0, 0.0, 2.0 * math.pi / 180]                      # work-frame twist of the push: +x (world +y, into the cube) at 1 cm/s, a slow yaw
+
+
+class OraclePush:
+    """The oracle's object_push env (oracle/ref_env.py) driven tick by tick."""
+    name = "oracle"
+
+    def __init__(self, assets=None):
+        from oracle.ref_env import OracleObjectPushEnv
+        modes = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="straight",
+                     observation_mode="tactile_and_feature", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+        self.env = OracleObjectPushEnv(seed=1, env_modes=modes)
+        self.env.reset()
+
+    def control(self, twist):
+        self.env._tcp_velocity_control(np.array(twist, dtype=np.float64))
+
+    def tick(self):
+        self.env._step_sim()
+
+    def record(self):
+        e = self.env
+        pos, R = e.cube_pose()
+        ids = [int(e.scene.contact_ids[k]) for k in range(8)][: int(e.scene.n_contacts)]
+        tip = any(i >= 8 for i in ids)
+        return dict(cube_pos=pos, cube_rot=R.reshape(9), cube_linvel=np.array(e.cube.linvel[:]), cube_angvel=np.array(e.cube.angvel[:]),
+                    n_table=np.array(sum(1 for i in ids if i < 8)), tip_contact=np.array(int(tip)),
+                    tip_normal=np.array(e.scene.tip_normal[:]) if tip else np.zeros(3), tip_distance=np.array(float(e.scene.tip_depth) if tip else 0.0),
+                    q=e.arm.q)
+
+
+class PyBulletPush(PyBulletBackend):
+    """object_push-v0's world in raw pybullet: UR5 + right-angle TacTip with the tip core on, the cube with the env's contact parameters."""
+
+    def __init__(self, assets):
+        import pybullet as p
+        self.p = p
+        if not assets or not os.path.isdir(assets):
+            raise SystemExit("--assets must point at the reference's `tactile_gym/assets` directory")
+        self.assets = assets
+        p.connect(p.DIRECT)
+        p.setGravity(0, 0, -9.81)
+        p.setPhysicsEngineParameter(fixedTimeStep=SIM_DT, numSolverIterations=SOLVER_ITERS, enableConeFriction=1, contactBreakingThreshold=0.0001)
+        p.loadURDF(os.path.join(assets, "shared_assets/environment_objects/plane/plane.urdf"), [0, 0, -0.625])
+        self.table = p.loadURDF(os.path.join(assets, "shared_assets/environment_objects/table/table.urdf"), [0.50, 0.00, -0.625], [0.0, 0.0, 0.0, 1.0])
+        self.robot = p.loadURDF(os.path.join(assets, "robot_assets/ur5/tactip/ur5_with_right_angle_tactip.urdf"), [0, 0, 0], [0, 0, 0, 1], useFixedBase=True)
+        self.n_all = p.getNumJoints(self.robot)
+        info = [p.getJointInfo(self.robot, i) for i in range(self.n_all)]
+        self.link = {inf[12].decode(): i for i, inf in enumerate(info)}
+        self.ctrl = [i for i, inf in enumerate(info) if inf[2] != p.JOINT_FIXED]
+        self.tcp, self.body, self.tip = self.link["tcp_link"], self.link["tactip_body_link"], self.link["tactip_tip_link"]
+        for i in range(self.n_all):
+            p.changeDynamics(self.robot, i, linearDamping=0.04, angularDamping=0.04)
+            p.changeDynamics(self.robot, i, jointDamping=0.01)
+        p.setCollisionFilterGroupMask(self.robot, self.body, 0, 0)                             # tactile_sensor.py:46-57 (core "fixed": the tip stays on)
+        p.setCollisionFilterGroupMask(self.robot, self.link["tactip_adapter_link"], 0, 0)
+        p.changeDynamics(self.robot, self.tip, contactDamping=100, contactStiffness=50)        # reset_tip :320-332, t_s_dynamics of object_push_env.py:50-52
+        p.changeDynamics(self.robot, self.tip, lateralFriction=10.0)
+        pos = [PUSH_WORKFRAME[0][0], PUSH_WORKFRAME[0][1] + 0.04, 0.04]                          # setup_object :158-160
+        self.cube = p.loadURDF(os.path.join(assets, "rl_env_assets/nonprehensile_manipulation/object_push/cube/cube.urdf"), pos,
+                               p.getQuaternionFromEuler([-math.pi, 0.0, math.pi / 2]))         # base_object_env.py:70
+        p.changeDynamics(self.cube, -1, lateralFriction=0.065, spinningFriction=0.0, rollingFriction=0.0, restitution=0.0, frictionAnchor=1,
+                         collisionMargin=0.0001)                                                 # reset_object :216-225
+        self.edge = None
+        # Robot.reset to the work-frame origin, rpy 0 (base_object_env.py:96-103, robot.py:114-125)
+        self.reset_joints(PUSH_REST)
+        wq = _quat_from_euler(*PUSH_WORKFRAME[1])
+        tpos, tq = np.array(PUSH_WORKFRAME[0]), _quat_mul(wq, _quat_from_euler(0.0, 0.0, 0.0))
+        targ = np.array(p.calculateInverseKinematics(self.robot, self.tcp, list(tpos), list(tq), restPoses=list(PUSH_REST), maxNumIterations=100,
+                                                     residualThreshold=1e-8))[: len(self.ctrl)]
+        self.motors_position(targ, MAX_FORCE)
+        _blocking_move(self, tpos, tq, targ)
+        p.resetBasePositionAndOrientation(self.cube, pos, p.getQuaternionFromEuler([-math.pi, 0.0, math.pi / 2]))   # reset_object after the robot
+
+    def control(self, twist):
+        p = self.p
+        wq = _quat_from_euler(*PUSH_WORKFRAME[1])
+        tw = np.concatenate([_rotate(wq, twist[:3]), _rotate(wq, twist[3:])])                   # workvel_to_worldvel; the limits do not bind here
+        q, _ = self.joints()
+        req = np.linalg.inv(self.jacobian_tcp(q)) @ tw                                         # base_robot_arm.py:300-322
+        self.motors_velocity(req)
+
+    def record(self):
+        p = self.p
+        pos, orn = p.getBasePositionAndOrientation(self.cube)
+        lv, av = p.getBaseVelocity(self.cube)
+        R = np.array(p.getMatrixFromQuaternion(orn))
+        table = p.getContactPoints(self.cube, self.table)
+        tip = [c for c in p.getContactPoints(self.robot, self.cube) if c[3] == self.tip]
+        deep = min(tip, key=lambda c: c[8]) if tip else None
+        return dict(cube_pos=np.array(pos), cube_rot=R, cube_linvel=np.array(lv), cube_angvel=np.array(av), n_table=np.array(len(table)),
+                    tip_contact=np.array(int(bool(tip))), tip_normal=np.array(deep[7]) if deep else np.zeros(3),
+                    tip_distance=np.array(deep[8] if deep else 0.0), q=self.joints()[0])
+
+
+def _blocking_move(b, tpos, tq, targ_j, max_steps=1000):
+    """Robot.blocking_move(max_steps=1000, constant_vel=0.001) (robot.py:188-260) on a backend; returns the ticks used and the joint path."""
+    cv, used, qs = 0.001, 0, []
+    for _ in range(max_steps):
+        tcp = b.tcp_state()
+        cur_j, cur_jv = b.joints()
+        diff = targ_j - cur_j
+        nrm = np.linalg.norm(diff)
+        step_j = cur_j + (diff / nrm if nrm > 0 else np.zeros_like(cur_j)) * cv
+        if np.all(np.abs(diff) < cv):
+            cv /= 2
+        b.motors_position(step_j, None if b.name == "pybullet" else 100000.0)                   # no `forces`: PyBullet's default [A11]
+        b.tick()
+        used += 1
+        qs.append(b.joints()[0])
+        pos_err = np.sum(np.abs(tpos - tcp[:3]))
+        orn_err = math.acos(float(np.clip(2 * np.inner(tq, tcp[3:7]) ** 2 - 1, -1, 1)))
+        if pos_err < 2e-4 and orn_err < 1e-3 and np.sum(np.abs(cur_jv)) < 0.1:
+            break
+    return used, qs
+
+
 # ----------------------------------------------------------------------------------------------------------------- scenarios
 def _quat_from_euler(r, p_, y):      # PyBullet's getQuaternionFromEuler (x, y, z, w)
     cr, sr, cp, sp, cy, sy = math.cos(r / 2), math.sin(r / 2), math.cos(p_ / 2), math.sin(p_ / 2), math.cos(y / 2), math.sin(y / 2)
@@ -245,23 +369,7 @@ def scenario_reset_move(b, max_steps=1000):
     tq = _quat_mul(wq, _quat_from_euler(0.0, 0.0, 0.0))
     targ_j = b.ik_tcp(tpos, tq)
     b.motors_position(targ_j, MAX_FORCE)                                                        # tcp_direct_workframe_move :211-220
-    cv, used, qs = 0.001, 0, []
-    for _ in range(max_steps):                                                                  # blocking_move, robot.py:188-260
-        tcp = b.tcp_state()
-        cur_j, cur_jv = b.joints()
-        diff = targ_j - cur_j
-        nrm = np.linalg.norm(diff)
-        step_j = cur_j + (diff / nrm if nrm > 0 else np.zeros_like(cur_j)) * cv
-        if np.all(np.abs(diff) < cv):
-            cv /= 2
-        b.motors_position(step_j, None if b.name == "pybullet" else 100000.0)                   # no `forces`: PyBullet's default [A11]
-        b.tick()
-        used += 1
-        qs.append(b.joints()[0])
-        pos_err = np.sum(np.abs(tpos - tcp[:3]))
-        orn_err = math.acos(float(np.clip(2 * np.inner(tq, tcp[3:7]) ** 2 - 1, -1, 1)))
-        if pos_err < 2e-4 and orn_err < 1e-3 and np.sum(np.abs(cur_jv)) < 0.1:
-            break
+    used, qs = _blocking_move(b, tpos, tq, targ_j, max_steps)
     return {"target_pos": tpos, "target_quat": tq, "ik": targ_j, "ticks": np.array(used), "q_final": b.joints()[0], "q_path": np.array(qs)}
 
 
@@ -270,15 +378,29 @@ def scenario_tactile_depth(b, size=128):
     return {"q": out["q_final"], "edge_pos": np.array(EDGE_POS), "edge_ang": np.array(EDGE_ANG), "depth": b.depth_of_edge(size)}
 
 
+def scenario_push_contacts(b, steps=10):
+    keys = ("cube_pos", "cube_rot", "cube_linvel", "cube_angvel", "n_table", "tip_contact", "tip_normal", "tip_distance", "q")
+    rec = {k: [] for k in keys}
+    for _ in range(steps):
+        b.control(PUSH_VEL)
+        for _ in range(24):
+            b.tick()
+            r = b.record()
+            for k in keys:
+                rec[k].append(r[k])
+    return dict({k: np.array(v) for k, v in rec.items()}, twist=np.array(PUSH_VEL), workframe_pos=np.array(PUSH_WORKFRAME[0]))
+
+
 SCENARIOS = {"arm_statics": scenario_arm_statics, "arm_velocity": scenario_arm_velocity, "reset_move": scenario_reset_move,
-             "tactile_depth": scenario_tactile_depth}
+             "tactile_depth": scenario_tactile_depth, "push_contacts": scenario_push_contacts}
+WORLDS = {"push_contacts": {"oracle": OraclePush, "pybullet": PyBulletPush}}          # scenarios with a world of their own
 
 
 def run(backend, out_dir, assets=None, scenarios=None):
     os.makedirs(out_dir, exist_ok=True)
     written = []
     for name in scenarios or SCENARIOS:
-        b = {"oracle": OracleBackend, "pybullet": PyBulletBackend}[backend](assets)             # a fresh world per scenario
+        b = WORLDS.get(name, {"oracle": OracleBackend, "pybullet": PyBulletBackend})[backend](assets)   # a fresh world per scenario
         data = SCENARIOS[name](b)
         path = os.path.join(out_dir, f"pybullet_{name}.npz")
         np.savez_compressed(path, backend=np.array(backend), **data)

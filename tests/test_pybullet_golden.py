@@ -80,4 +80,4 @@ def test_probe_format_and_comparison_with_the_oracle_backend(tmp_path):
     assert int(np.load(tmp_path / "ref" / "pybullet_reset_move.npz")["ticks"]) < 1000                # the blocking move converges
     d = np.load(tmp_path / "ref" / "pybullet_push_contacts.npz")
     assert d["cube_pos"].shape == (240, 3) and int(d["tip_contact"].sum()) > 200 and set(d["n_table"].tolist()) == {4}   # the tip pushes, the cube stays flat
-    assert d["cube_pos"][-1, 1] - d["cube_pos"][0, 1] > 0.004 and np.all(d["tip_distance"] <= 0.0)                        # ... and moves under the push
+    assert d["cube_pos"][-1, 1] - d["cube_pos"][0, 1] > 0.004 and d["tip_distance"][-1] < -1e-3            # ... and moves under the push, the soft tip pressed in

@@ -64,6 +64,20 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {   // v_readlan
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
     return u.d;
 }
+// trig_init with the N evaluations on N lanes: every lane of the wavefront holds the same q (one env), so lane i takes joint i's exact sine /
+// cosine (lanes 8.. repeat them) and the N pairs come back as wave-uniform values - one library sincos (~150 f64 instructions) on the
+// wavefront's issue slot instead of N.  The same routine on the same argument: the same bits as trig_init.
+template <typename T, int N>
+__device__ __forceinline__ void trig_init_lanes(const T (&q)[N], JointTrig<T, N>& t, int lane) {
+    T a = q[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) a = (lane & 7) == i ? q[i] : a;
+    T s, c;
+    tsincos(a, &s, &c);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { t.s[i] = bcast(s, i); t.c[i] = bcast(c, i); }
+}
+
 // the value held by the other friction lane of this lane's contact quad (lanes 4k+1 <-> 4k+2): v_mov_b32_dpp quad_perm:[0,2,1,3] x 2
 __device__ __forceinline__ double quad_swap12(double v) {
     union { double d; int i[2]; } u;
@@ -1364,7 +1378,7 @@ __device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const Bod
             qd[i] = L[kLV + i] + du[i];
             q[i] = L[kLQ + i] + dt * qd[i];
         }
-        trig_init<T, N>(q, trig);                         // a full tick re-anchors the carried sines / cosines exactly
+        trig_init_lanes<T, N>(q, trig, lane);             // a full tick re-anchors the carried sines / cosines exactly
         FreeBody<T> bn;
         bn.R = b.R;
         bn.v = vb + mk(du[8], du[9], du[10]);
@@ -1397,10 +1411,10 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     constexpr int N = Topo<TOPO>::N;
     extern __shared__ double wave_lds_raw[];
     const lds_ptr<T> L = (lds_ptr<T>)wave_lds_raw;
+    const int env = blockIdx.x, lane = threadIdx.x;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
-    const int env = blockIdx.x, lane = threadIdx.x;
-    const int n = c.num_envs;
+    const int n = (int)gridDim.x;         // = c.num_envs (launch_step_body_wave): the state loads below do not wait for the constants' scalar loads
     const bool w0 = lane == 0;
     T q[N], qd[N];
 #pragma unroll
@@ -1416,7 +1430,9 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     scale_actions<T>(c, enc, vels);
     const int step_count = st.step_count[env] + 1;
     T qd_des[N];
-    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des);
+    JointTrig<T, N> trig;
+    trig_init_lanes<T, N>(q, trig, lane);
+    tcp_velocity_control<T, TOPO>(m, c, q, vels, qd_des, &trig);
     const T embed = (T)st.embed[env];
     const V3<T> grav = mk(T(0), T(0), (T)st.gravity[env]);
     const V3<T> pivot_b = mk(T(0), T(0), -c.obj_base_height / T(2) + embed);
@@ -1428,9 +1444,20 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
-    JointTrig<T, N> trig;
     int verified = lic > 0 ? 24 : 0;
     bool ran_full = false;
+    // The frames finish_body_frames wants (TCP, sensor link) at the step's last q: lane k of a licensed walk evaluates the kinematics at
+    // q + k dt des anyway, so when the walk ends the step its lane `adv` holds them (the same additions in the same order as q's own) and
+    // the step's third forward-kinematics pass (~10 k of its ~120 k cycles) is not run.  frames_lane < 0: no such lane (a full tick came last).
+    // Round 5, 1024 envs: 76.5 -> 62 us per launch together with trig_init_lanes and n = gridDim.x.  Tried with it and dropped: the robot's and
+    // the env kind's constants staged in LDS (the controller's share fell from 17 k to 6 k cycles - its ~100 scalar loads each miss a scalar
+    // cache the launch starts cold - but 260 spilled VGPRs and 900 B of scratch made the kernel slower), and touching every line of the two
+    // structs up front with scalar loads (+10 us: at most 15 are in flight).
+    int frames_lane = -1;
+    V3<T> ptcp_l = mk<T>(0, 0, 0), pb_l = mk<T>(0, 0, 0);
+    M3<T> Rtcp_l, Rb_l;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { Rtcp_l.m[e] = T(0); Rb_l.m[e] = T(0); }
     const T kdamp = c.dt * (m.joint_damp + T(4) * (m.lin_damp + m.ang_damp) * m.trace_bound) * T(3);
     int t = 0;
     while (t < c.action_repeat) {
@@ -1457,6 +1484,8 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
                 Kin<T, TOPO> kin;
                 forward_kinematics<T, TOPO>(m, qt, kin);
                 pivot_state<T, TOPO>(kin, c.body, qd_des, pa_l, va_l);
+                link_frame<T, TOPO>(kin, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp_l, Rtcp_l);
+                link_frame<T, TOPO>(kin, m.sensor_link, m.sensor_pos, m.sensor_rot, pb_l, Rb_l);
             }
             int adv = 0;
             for (int k = 0; k < left; ++k) {
@@ -1475,12 +1504,14 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
                 }
                 verified -= adv;
                 t += adv;
+                frames_lane = adv < 64 ? adv : -1;          // (action_repeat == 64: the walk has no lane standing at its last q)
                 continue;
             }
         }
         {
             if (!staged) { stage_link_constants<T, TOPO>(mp, L, lane); staged = true; }
-            trig_init<T, N>(q, trig);
+            frames_lane = -1;
+            trig_init_lanes<T, N>(q, trig, lane);
             __syncthreads();
             if (w0) {
 #pragma unroll
@@ -1518,7 +1549,23 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
         for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = (double)qd_des[i]; }
         store_body<T>(st, n, env, b);
     }
-    finish_body<T, TOPO>(m, c, st, env, q, b, embed, step_count, true);
+    {
+        V3<T> ptcp, pb; M3<T> Rtcp, Rb;
+        if (frames_lane >= 0) {
+            const int fl = __builtin_amdgcn_readfirstlane(frames_lane);
+            ptcp = mk(bcast(ptcp_l.x, fl), bcast(ptcp_l.y, fl), bcast(ptcp_l.z, fl));
+            pb = mk(bcast(pb_l.x, fl), bcast(pb_l.y, fl), bcast(pb_l.z, fl));
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { Rtcp.m[e] = bcast(Rtcp_l.m[e], fl); Rb.m[e] = bcast(Rb_l.m[e], fl); }
+        } else {
+            trig_init_lanes<T, N>(q, trig, lane);
+            Kin<T, TOPO> kin;
+            forward_kinematics<T, TOPO, true>(m, q, kin, &trig);
+            link_frame<T, TOPO>(kin, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+            link_frame<T, TOPO>(kin, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+        }
+        finish_body_frames<T, TOPO>(m, c, st, env, ptcp, Rtcp, pb, Rb, b, embed, step_count, true);
+    }
     // Auto-reset in the step's own launch (round 5): with the reset template valid (the host knows: tg_ctx::tmpl_ready) a finished env's reset is
     // the template-only form - four to six draws, a teleport, one forward kinematics - and its launch of its own (k_reset_body: 16 wavefronts
     // that mostly find nothing to do) cost the step 16 us + a graph gap; here it costs a finished env's wavefront a few microseconds.  Every lane

@@ -1164,14 +1164,12 @@ template <typename T> __device__ __forceinline__ T wrap_deg(T d) {   // ((d + 18
 }
 
 // get_step_data / check_obj_fall / termination (object_balance_env.py:426-497) + camera<-object transform
+// (the frames of the TCP and of the sensor link at the env's q are the caller's: finish_body below takes them from its own forward kinematics,
+//  k_step_body_wave from the lane of its licensed walk that already stands at the step's last q)
 template <typename T, int TOPO>
-__device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
-                                            const FreeBody<T>& b, T embed, int step_count, bool write_reward_done) {
+__device__ __forceinline__ void finish_body_frames(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const V3<T>& ptcp, const M3<T>& Rtcp,
+                                                   const V3<T>& pb, const M3<T>& Rb, const FreeBody<T>& b, T embed, int step_count, bool write_reward_done) {
     const int n = c.num_envs;
-    Kin<T, TOPO> k;
-    forward_kinematics<T, TOPO>(m, q, k);
-    V3<T> ptcp; M3<T> Rtcp;
-    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
     T rpy[3];
     { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
     st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
@@ -1189,8 +1187,6 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
         st.done[env] = done ? 1 : 0;
         episode_step(st, env, (float)reward, done, step_count);
     }
-    V3<T> pb; M3<T> Rb;
-    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
     const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
     const M3<T> Rc = mul(Rb, c.cam_rot);
     V3<T> f{Rc.m[0], Rc.m[3], Rc.m[6]}, up{Rc.m[2], Rc.m[5], Rc.m[8]};
@@ -1211,6 +1207,17 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
 #pragma unroll
         for (int i = 0; i < 12; ++i) st.term_xform[i * n + env] = xv[i];
     }
+}
+
+template <typename T, int TOPO>
+__device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+                                            const FreeBody<T>& b, T embed, int step_count, bool write_reward_done) {
+    Kin<T, TOPO> k;
+    forward_kinematics<T, TOPO>(m, q, k);
+    V3<T> ptcp, pb; M3<T> Rtcp, Rb;
+    link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+    link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
+    finish_body_frames<T, TOPO>(m, c, st, env, ptcp, Rtcp, pb, Rb, b, embed, step_count, write_reward_done);
 }
 
 template <typename T, int TOPO, bool POS, bool BALL = false>

@@ -1523,8 +1523,11 @@ int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restar
     const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL;
     // the lane-mapped k_step (edge_follow / surface_follow, TCP_velocity_control) draws its own actions: no sampler node at all - a dependent
     // kernel in this graph costs its ~6 us dispatch floor whatever it computes (profiles/r4_exp_reset_launch.txt)
-    const bool in_kernel = (c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) &&
-                           c->cfg.control_mode == TG_CONTROL_TCP_VELOCITY && !use_arm_wave(c);
+    // (round 5: so does object_balance's k_step_body_wave - the conditions of launch_step_body_wave)
+    const bool in_kernel = ((c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) &&
+                            c->cfg.control_mode == TG_CONTROL_TCP_VELOCITY && !use_arm_wave(c)) ||
+                           (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE && use_contact_wave(c) && c->cfg.physics_dtype == TG_PHYSICS_F64 &&
+                            c->robot.topology == 0 && c->cfg.control_mode == TG_CONTROL_TCP_VELOCITY && !use_fused_step(c));
     struct DrawScope {                   // c->st carries the counter only while this call enqueues / captures
         tg_ctx* c; bool on;
         DrawScope(tg_ctx* c_, bool on_) : c(c_), on(on_) { if (on) { c->st.draw = c->d_draw; c->st.act_out = c->d_actions; } }

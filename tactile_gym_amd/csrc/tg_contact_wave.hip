@@ -1421,7 +1421,32 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     for (int i = 0; i < N; ++i) { q[i] = (T)st.q[i * n + env]; qd[i] = (T)st.qd[i * n + env]; }
     FreeBody<T> b = load_body<T>(st, n, env);
     T enc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};      // encode_actions (object_balance_env.py:398-424)
-    const float* a = actions + (size_t)env * c.act_dim;
+    float abuf[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned long long ticket = 0;
+    if (st.draw != nullptr) {
+        // tg_step_random: action_space.sample() for this env inside the step (element i = env * act_dim + j of draw `counter`: the arithmetic
+        // of k_sample_actions, as in step_env) - the sampler as a launch of its own was 4.7 us + a graph gap in front of every step.  The
+        // wavefront takes its ticket for the counter's election once its draws are computed and looks at it at the end of the launch.
+        const uint64_t counter = st.draw[0] + 1, seed = st.draw[1];
+        const float lo = (float)c.min_action, hi = (float)c.max_action;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (j < c.act_dim) {
+                const int i = env * c.act_dim + j;
+                const uint64_t z = mix64(mix64(seed + kGolden * (counter + 1)) + kGolden * (uint64_t)(i + 1));
+                const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+                abuf[j] = lo + (hi - lo) * u;
+                if (w0) st.act_out[i] = abuf[j];
+            }
+        }
+        if (w0) ticket = draw_ticket_take(st, abuf[0]);
+    } else {
+        const float* ap = actions + (size_t)env * c.act_dim;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j < c.act_dim) abuf[j] = ap[j];
+    }
+    const float* a = abuf;
     if (c.movement_mode == TG_BMOVE_XY) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; }
     else if (c.movement_mode == TG_BMOVE_XYZ) { enc[0] = (T)a[0]; enc[1] = (T)a[1]; enc[2] = (T)a[2]; }
     else if (c.movement_mode == TG_BMOVE_RXRY) { enc[3] = (T)a[0]; enc[4] = (T)a[1]; }
@@ -1453,7 +1478,10 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     // the env kind's constants staged in LDS (the controller's share fell from 17 k to 6 k cycles - its ~100 scalar loads each miss a scalar
     // cache the launch starts cold - but 260 spilled VGPRs and 900 B of scratch made the kernel slower), and touching every line of the two
     // structs up front with scalar loads (+10 us: at most 15 are in flight).
-    int frames_lane = -1;
+    int frames_lane = -1, tmpl_lane = -1;
+    T tmpl_q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) tmpl_q[i] = inline_reset ? (T)st.reset_tmpl[i] : T(0);
     V3<T> ptcp_l = mk<T>(0, 0, 0), pb_l = mk<T>(0, 0, 0);
     M3<T> Rtcp_l, Rb_l;
 #pragma unroll
@@ -1479,6 +1507,11 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
 #pragma unroll
                     for (int i = 0; i < N; ++i) qt[i] += dq[i];
                 }
+            if (inline_reset && left < 63) {              // the walk's last lane is idle: it evaluates the kinematics at the reset template's q, for
+                tmpl_lane = 63;                           // a finished env's reset at the end of this launch (which then runs no forward kinematics)
+#pragma unroll
+                for (int i = 0; i < N; ++i) qt[i] = lane == 63 ? tmpl_q[i] : qt[i];
+            }
             V3<T> pa_l, va_l;
             {
                 Kin<T, TOPO> kin;
@@ -1551,6 +1584,7 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     }
     {
         V3<T> ptcp, pb; M3<T> Rtcp, Rb;
+        bool env_done;
         if (frames_lane >= 0) {
             const int fl = __builtin_amdgcn_readfirstlane(frames_lane);
             ptcp = mk(bcast(ptcp_l.x, fl), bcast(ptcp_l.y, fl), bcast(ptcp_l.z, fl));
@@ -1564,13 +1598,26 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
             link_frame<T, TOPO>(kin, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
             link_frame<T, TOPO>(kin, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
         }
-        finish_body_frames<T, TOPO>(m, c, st, env, ptcp, Rtcp, pb, Rb, b, embed, step_count, true);
+        env_done = finish_body_frames<T, TOPO>(m, c, st, env, ptcp, Rtcp, pb, Rb, b, embed, step_count, true);
+        // Auto-reset in the step's own launch (round 5): with the reset template valid (the host knows: tg_ctx::tmpl_ready) a finished env's reset is
+        // the template-only form - four to six draws, a teleport, and the frames at the template's q, which the walk's idle last lane evaluated
+        // on the side - and its launch of its own (k_reset_body: 16 wavefronts that mostly find nothing to do) cost the step 16 us + a graph gap;
+        // here it is the tail of a finished env's wavefront (with ~4 of 1024 envs finishing per step the launch nearly always has one: 5.7 us
+        // with the reset's own forward kinematics).  Every lane runs it alike, as with finish_body_frames above (the same loads, the same stores).
+        if (inline_reset && env_done) {
+            if (tmpl_lane >= 0) {
+                LinkFrames<T> fr;
+                fr.ptcp = mk(bcast(ptcp_l.x, 63), bcast(ptcp_l.y, 63), bcast(ptcp_l.z, 63));
+                fr.pb = mk(bcast(pb_l.x, 63), bcast(pb_l.y, 63), bcast(pb_l.z, 63));
+#pragma unroll
+                for (int e = 0; e < 9; ++e) { fr.Rtcp.m[e] = bcast(Rtcp_l.m[e], 63); fr.Rb.m[e] = bcast(Rb_l.m[e], 63); }
+                reset_body_env<T, TOPO, false, true>(m, c, st, env, &fr);
+            } else {
+                reset_body_env<T, TOPO, false, true>(m, c, st, env);
+            }
+        }
     }
-    // Auto-reset in the step's own launch (round 5): with the reset template valid (the host knows: tg_ctx::tmpl_ready) a finished env's reset is
-    // the template-only form - four to six draws, a teleport, one forward kinematics - and its launch of its own (k_reset_body: 16 wavefronts
-    // that mostly find nothing to do) cost the step 16 us + a graph gap; here it costs a finished env's wavefront a few microseconds.  Every lane
-    // runs it alike, as with finish_body above (the same loads, the same stores).  done[env] is this lane's own store.
-    if (inline_reset && st.done[env] != 0) reset_body_env<T, TOPO, false, true>(m, c, st, env);
+    if (st.draw != nullptr && w0) draw_ticket_resolve(st, ticket);
 }
 
 // ---- contact-free arms (edge_follow, surface_follow): the full tick on one wavefront -------------------------------------------------------

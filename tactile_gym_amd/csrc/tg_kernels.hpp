@@ -732,6 +732,26 @@ __device__ __forceinline__ void draw_counter_advance(const State& st) {
     }
 }
 
+// The same election in two halves, for a launch of one wavefront per env (k_step_body_wave): lane 0 takes the first-level ticket as soon as its
+// draws are computed (`used`: a value derived from the counter it read - the ticket depends on it, so the load has returned) and looks at the
+// ticket at the end of the launch, when the atomic's round trip is long over.
+__device__ __forceinline__ unsigned long long draw_ticket_take(const State& st, float used) {
+    unsigned long long* tk = gridDim.x > 2 * kDrawGroups ? st.draw + 16 + 16 * (blockIdx.x % kDrawGroups) : st.draw + 2;
+    return atomicAdd(tk, __float_as_uint(used) == 0x7fc12345u ? 2ull : 1ull);      // (a NaN payload no draw produces: always 1)
+}
+__device__ __forceinline__ void draw_ticket_resolve(const State& st, unsigned long long ticket) {
+    bool last;
+    if (gridDim.x > 2 * kDrawGroups) {
+        const unsigned g = blockIdx.x % kDrawGroups;
+        const unsigned long long members = (gridDim.x - g + kDrawGroups - 1) / kDrawGroups;
+        last = ticket == members - 1;
+        if (last) { atomicExch(st.draw + 16 + 16 * g, 0ull); last = atomicAdd(st.draw + 2, 1ull) == (unsigned long long)kDrawGroups - 1; }
+    } else {
+        last = ticket == (unsigned long long)gridDim.x - 1;
+    }
+    if (last) { atomicExch(st.draw + 2, 0ull); atomicAdd(st.draw + 0, 1ull); }
+}
+
 template <typename T, int TOPO>
 __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                              const float* __restrict__ actions) {
@@ -1166,10 +1186,12 @@ template <typename T> __device__ __forceinline__ T wrap_deg(T d) {   // ((d + 18
 // get_step_data / check_obj_fall / termination (object_balance_env.py:426-497) + camera<-object transform
 // (the frames of the TCP and of the sensor link at the env's q are the caller's: finish_body below takes them from its own forward kinematics,
 //  k_step_body_wave from the lane of its licensed walk that already stands at the step's last q)
+//  Returns the env's `done` (false without write_reward_done).
 template <typename T, int TOPO>
-__device__ __forceinline__ void finish_body_frames(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const V3<T>& ptcp, const M3<T>& Rtcp,
+__device__ __forceinline__ bool finish_body_frames(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const V3<T>& ptcp, const M3<T>& Rtcp,
                                                    const V3<T>& pb, const M3<T>& Rb, const FreeBody<T>& b, T embed, int step_count, bool write_reward_done) {
     const int n = c.num_envs;
+    bool env_done = false;
     T rpy[3];
     { Q4<T> qq = quat_from_mat(Rtcp); euler_from_quat(qq, rpy[0], rpy[1], rpy[2]); }
     st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
@@ -1185,6 +1207,7 @@ __device__ __forceinline__ void finish_body_frames(const DevRobot<T>& m, const E
         const T reward = (c.reward_mode == TG_REWARD_SPARSE) ? (fell ? T(-1) : T(0)) : T(1);
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
+        env_done = done;
         episode_step(st, env, (float)reward, done, step_count);
     }
     const V3<T> pc = pb + mul(Rb, load_v3(c.cam_pos));
@@ -1207,8 +1230,10 @@ __device__ __forceinline__ void finish_body_frames(const DevRobot<T>& m, const E
 #pragma unroll
         for (int i = 0; i < 12; ++i) st.term_xform[i * n + env] = xv[i];
     }
+    return env_done;
 }
 
+template <typename T> struct LinkFrames { V3<T> ptcp, pb; M3<T> Rtcp, Rb; };   // the TCP's and the sensor link's frames at some q
 template <typename T, int TOPO>
 __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
                                             const FreeBody<T>& b, T embed, int step_count, bool write_reward_done) {
@@ -1217,7 +1242,7 @@ __device__ __forceinline__ void finish_body(const DevRobot<T>& m, const EnvConst
     V3<T> ptcp, pb; M3<T> Rtcp, Rb;
     link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
     link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pb, Rb);
-    finish_body_frames<T, TOPO>(m, c, st, env, ptcp, Rtcp, pb, Rb, b, embed, step_count, write_reward_done);
+    (void)finish_body_frames<T, TOPO>(m, c, st, env, ptcp, Rtcp, pb, Rb, b, embed, step_count, write_reward_done);
 }
 
 template <typename T, int TOPO, bool POS, bool BALL = false>
@@ -1308,7 +1333,8 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
 // still tied to the TCP, reset_object (teleport + one-shot random force).
 // (the reset of ONE env; k_reset_body below is its lane-per-env launch, k_step_body_wave calls the FAST form in its epilogue)
 template <typename T, int TOPO, bool BALL = false, bool FAST = false /* the template is known to be valid: no inverse kinematics / blocking move in the binary */>
-__device__ __forceinline__ void reset_body_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env) {
+__device__ __forceinline__ void reset_body_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env,
+                                               const LinkFrames<T>* tmpl_frames = nullptr /* FAST: the frames at the template's q, if the caller has them */) {
     constexpr int N = Topo<TOPO>::N;
     const int n = c.num_envs;
     uint64_t rs = st.rng[env];
@@ -1432,7 +1458,10 @@ __device__ __forceinline__ void reset_body_env(const DevRobot<T>& m, const EnvCo
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
     store_body<T>(st, n, env, b);
-    finish_body<T, TOPO>(m, c, st, env, q, b, (T)embed, 0, false);
+    if (FAST && tmpl_frames != nullptr)
+        (void)finish_body_frames<T, TOPO>(m, c, st, env, tmpl_frames->ptcp, tmpl_frames->Rtcp, tmpl_frames->pb, tmpl_frames->Rb, b, (T)embed, 0, false);
+    else
+        finish_body<T, TOPO>(m, c, st, env, q, b, (T)embed, 0, false);
 }
 template <typename T, int TOPO, bool BALL = false, bool FAST = false>
 __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,

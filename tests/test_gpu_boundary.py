@@ -118,18 +118,21 @@ def test_tile_download_hands_out_the_batch_the_full_copy_hands_out(env_id, modes
     venv.close()
 
 
-def test_step_random_equals_sample_actions_then_step():
-    """tg_step_random (the uniform policy's draw as a node of the step's graph, device-resident draw counter) = tg_sample_actions(seed, k) followed by
+@pytest.mark.parametrize("env_id", ["edge_follow-v0", "object_balance-v0"])
+def test_step_random_equals_sample_actions_then_step(env_id):
+    """tg_step_random (the uniform policy's draw inside the step's own launch - k_step, and since round 5 object_balance's k_step_body_wave, one
+    wavefront per env with a two-level election for the counter - device-resident draw counter) = tg_sample_actions(seed, k) followed by
     tg_step on it: same actions, observations, rewards, dones, also across a restart of the counter and with auto-resets in the rollout."""
     import torch
     import tactile_gym_amd as tg
     from tactile_gym_amd.parallel import TorchShard
-    n = 64
-    mk = lambda: tg.make_vec("edge_follow-v0", num_envs=n, max_steps=9, image_size=[128, 128], env_modes=EDGE, seed=5, auto_reset=True, obs_mode="torch")   # noqa: E731
+    n = 64 if env_id == "edge_follow-v0" else 96          # 96 workgroups: the two-level election (more than 2 x 32)
+    modes = EDGE if env_id == "edge_follow-v0" else BAL
+    mk = lambda: tg.make_vec(env_id, num_envs=n, max_steps=9, image_size=[128, 128], env_modes=modes, seed=5, auto_reset=True, obs_mode="torch")   # noqa: E731
     a, b = mk(), mk()
     sa, sb = TorchShard(a), TorchShard(b)
     sa.reset(); sb.reset()
-    buf = torch.empty(n, 2, device="cuda")
+    buf = torch.empty(n, a.act_dim, device="cuda")
     draw = 0
     for k in range(25):
         restart = k in (0, 11)

@@ -188,10 +188,13 @@ typedef struct {
      * surface_follow.  object_balance has a reset TEMPLATE instead (the arm's post-reset state computed once, by env 0's first reset): against
      * TG_BANK_OFF, which recomputes every reset with the fallen object still on the constraint, the arm differs by the last-bit residue of that
      * tick's Gauss-Seidel (joints within 1e-13 rad, frames within 3 pixels: tests/test_gpu_reset_bank.py) - not bit-identical.
-     * TG_BANK_AUTO: on for the MG400 (its blocking move stalls a 1024-env batch for 9-11 ms per full-batch reset; measured 0.126 -> 1.13 M
-     * env-steps/s on surface_follow-v2), off for the UR5 (a full-batch reset costs 0.12 ms per 200 steps, less than what the refill launches
-     * cost the steps they run beside); TG_BANK_ON: on; TG_BANK_OFF: every reset on the spot; TG_BANK_SYNC: on, and the refill is waited for
-     * after every step (tests: the bank is always ready).  The environment variable TG_RESET_BANK (0 / 1 / sync) overrides. */
+     * TG_BANK_AUTO = TG_BANK_ON (round 5; until then on for the MG400 only - its blocking move stalls a 1024-env batch for 9-11 ms per
+     * full-batch reset, 0.126 -> 1.13 M env-steps/s on surface_follow-v2).  The UR5's reset is 0.1 ms: nothing when every env finishes in the
+     * same step (a random rollout from a common start), but with episodes ending in different steps - any RL run - some env finishes in nearly
+     * every step and the whole batch waits for it each time: 6.7 -> 18.3 M env-steps/s at 1024 envs (tools/desync_rate.py); the aligned
+     * rollout costs the same either way.  With the bank on, a context's step calls keep the host at most ~70 steps ahead of the device (the
+     * refill's pacing: one host-side wait for a marker every 8 steps).  TG_BANK_OFF: every reset on the spot; TG_BANK_SYNC: on, and the refill
+     * is waited for after every step (tests: the bank is always ready).  The environment variable TG_RESET_BANK (0 / 1 / sync) overrides. */
     int32_t reset_bank;                     /* TG_BANK_* */
     /* object_push: narrowphase of the tip-cube pair (stepSimulation's collision detection, robot.py:141).  TG_NARROW_CLOSED_FORM: the
      * deepest point of the tip's convex hull against the cube's faces in closed form, ONE contact point per tick (PARITY A24);

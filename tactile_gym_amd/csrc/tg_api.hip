@@ -427,6 +427,9 @@ struct tg_ctx {
     tg::BankAux aux{};
     int bank_mode = 0;                 // 0 off, 1 refills on bank_stream every bank_every steps, 2 as 1 and waited for (tests)
     int bank_every = 8;
+    static constexpr int kBankRing = 16, kBankLag = 8;    // bank_refill: markers on the step stream, one per visit; the host stays <= kBankLag visits ahead
+    hipEvent_t ev_bank_ring[kBankRing] = {};
+    unsigned long long bank_visits = 0;
     long long bank_steps = 0;
     hipStream_t bank_stream = nullptr;
     hipEvent_t ev_bank = nullptr, ev_bank_done = nullptr;
@@ -890,14 +893,37 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask, bool bank = false) 
     }
 }
 
-// The refill of the reset bank: outside the step graph, on the bank's low-priority stream, behind an event of the step just enqueued (so
-// the host running ahead of the device cannot spend all its refills before the episodes they are for have ended).  It never blocks the
-// stream the steps run on; the only data-path ordering between the two streams is the tag / RNG acquire-release pair (tg_kernels.hpp).
+// The refill of the reset bank: outside the step graph, on the bank's low-priority stream, paced by a marker on the step stream (so the host
+// running ahead of the device cannot spend all its refills before the episodes they are for have ended).  It never blocks the stream the
+// steps run on; the only data-path ordering between the two streams is the tag / RNG acquire-release pair (tg_kernels.hpp).
 static void bank_refill(tg_ctx* c) {
     if (c->bank_mode == 0) return;
     if ((c->bank_steps++ % c->bank_every) != 0 && c->bank_mode != 2) return;
-    (void)hipEventRecord(c->ev_bank, c->stream);
-    (void)hipStreamWaitEvent(c->bank_stream, c->ev_bank, 0);
+    if (c->bank_mode == 2) {
+        (void)hipEventRecord(c->ev_bank, c->stream);
+        (void)hipStreamWaitEvent(c->bank_stream, c->ev_bank, 0);
+    } else {
+        // Pacing (round 5): no cross-stream wait.  Every visit leaves a marker on the step stream, waits - on the host - for the marker of
+        // kBankLag visits ago, and launches the refill at once: it finds the device between 8 kBankLag and 8 (kBankLag + 1) steps behind the
+        // host, i.e. the refills stay spread over the rollout however fast the host enqueues, and the host is never further ahead than that.
+        // (Until round 5 the refill waited for its marker on the bank stream.  A host that runs ahead - any rollout that does not read a result
+        // every step - then keeps a blocked barrier packet in a second hardware queue all the time, and every dispatch of the step stream was
+        // ~1 us slower for it: 45.9 instead of 42.1 us per step on the headline, whatever `bank_every` and whatever the queue's priority.
+        // TG_BANK_PACE=0 is that scheme.)
+        static const bool by_barrier = getenv("TG_BANK_PACE") != nullptr && atoi(getenv("TG_BANK_PACE")) == 0;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(c->stream, &cap);
+        if (by_barrier || cap != hipStreamCaptureStatusNone) {
+            (void)hipEventRecord(c->ev_bank, c->stream);
+            (void)hipStreamWaitEvent(c->bank_stream, c->ev_bank, 0);
+        } else {
+            const unsigned long long k = c->bank_visits++;
+            hipEvent_t& ev = c->ev_bank_ring[k % tg_ctx::kBankRing];
+            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; (void)hipGetLastError(); return; }
+            (void)hipEventRecord(ev, c->stream);
+            if (k >= tg_ctx::kBankLag) (void)hipEventSynchronize(c->ev_bank_ring[(k - tg_ctx::kBankLag) % tg_ctx::kBankRing]);
+        }
+    }
     if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
 #define CALL(T, TOPO) launch_bank_refill_t<T, TOPO>(c, 1)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
@@ -1194,7 +1220,12 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
 #endif
     c->bk = s;
     {   // reset bank: edge_follow / surface_follow with auto_reset on the lane mapping (tg_config.reset_bank, TG_RESET_BANK)
-        int want = cfg->reset_bank == TG_BANK_OFF ? 0 : cfg->reset_bank == TG_BANK_SYNC ? 2 : cfg->reset_bank == TG_BANK_ON ? 1 : (robot->topology == 1 ? 1 : 0);
+        // TG_BANK_AUTO: on (round 5; until then only for the MG400, whose reset is 0.9 ms).  With every env finishing in the same step - a random
+        // rollout from a common start - a UR5 reset on the spot costs 0.1 ms once per episode and the bank buys nothing; with episodes that end
+        // in different steps - any RL run - some env finishes in nearly every step and the step waits for that reset every time: 6.7 against
+        // 18.3 M env-steps/s at 1024 envs (tools/desync_rate.py), while the aligned rollout is unchanged since bank_refill stopped waiting across
+        // streams.
+        int want = cfg->reset_bank == TG_BANK_OFF ? 0 : cfg->reset_bank == TG_BANK_SYNC ? 2 : 1;
         if (const char* e = getenv("TG_RESET_BANK")) want = (e[0] == '0') ? 0 : (e[0] == 's') ? 2 : 1;
         if (const char* e = getenv("TG_RESET_BANK_EVERY")) { const int k = atoi(e); if (k >= 1) c->bank_every = k; }
         const bool kind_ok = cfg->env_kind == TG_ENV_EDGE_FOLLOW || cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO;
@@ -1214,6 +1245,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
             bad |= grab(b.edge_ang, (size_t)n * 8); bad |= grab(b.embed, (size_t)n * 8); bad |= grab(b.edge_sc, (size_t)2 * n * 8);
             bad |= grab(b.stim_xform, (size_t)12 * n * 4);
             bad |= grab(b.step_count, (size_t)n * 4); bad |= grab(b.reset_ticks, (size_t)n * 4); bad |= grab(b.licence, (size_t)n * 4);
+            bad |= grab(b.trig_sc, (size_t)16 * n * 8);
             bad |= grab(b.rng, (size_t)n * 8);
             if (cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
                 const size_t cells = (size_t)cfg->surf_rows * cfg->surf_cols;
@@ -1306,6 +1338,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->bank_stream) { (void)hipStreamSynchronize(c->bank_stream); (void)hipStreamDestroy(c->bank_stream); }
     if (c->ev_bank) (void)hipEventDestroy(c->ev_bank);
     if (c->ev_bank_done) (void)hipEventDestroy(c->ev_bank_done);
+    for (hipEvent_t& e : c->ev_bank_ring) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (void* p_ : c->bank_allocs) (void)hipFree(p_);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);

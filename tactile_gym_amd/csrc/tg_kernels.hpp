@@ -1039,7 +1039,28 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
         if (pos_err < T(2e-4) && orn_err < T(1e-3) && total_v < T(0.1)) break;
     }
     st.reset_ticks[env] = used;
-    st.licence[env] = 0;
+    // The licence is renewed inside the reset (round 5).  Dropped here - as until round 5 - it sends the env's whole wavefront through a full
+    // solve in the next step, and with episodes that do not end in the same step (any RL run) some wavefront does that in every launch: k_step
+    // 49 instead of 17 us (tools/desync_rate.py).  The blocking move's own solves do not qualify as the demonstration - their jumps shrink to
+    // nothing, and a solve of nothing converges at once on any arm - so one more tick is solved here, in the step's motor mode, from the
+    // reset pose, for a jump with a component along every joint, and thrown away: only its verdict is kept (converged to the last bit within
+    // 80 % of the sweep budget or not: the UR5 does, after ~55 of 150 sweeps; the MG400 never does and keeps solving in full).
+    int lic = 0;
+    if (c.solver_iters > 0 && c.control_mode == TG_CONTROL_TCP_VELOCITY) {
+        T qv[N], qdv[N], des[N], qdummy[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { qv[i] = q[i]; qdv[i] = qd[i]; qdummy[i] = T(0); des[i] = qd[i] + T(1e-5) * T((i & 1) ? -(3 + i) : (2 + i)); }   // (small: far from any row's limit, and the exit test is relative)
+        int ver = 0;
+        sim_tick<T, TOPO, kMotorVelocity, true, false>(m, qv, qdv, qdummy, des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, nullptr, &ver);
+        lic = ver > 0 ? 8 : 0;
+    }
+    st.licence[env] = lic;      // (the sines / cosines a licensed step carries over: the exact ones of the reset pose)
+    {
+        JointTrig<T, N> trig;
+        trig_init<T, N>(q, trig);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = (double)trig.s[i]; st.trig_sc[(8 + i) * n + env] = (double)trig.c[i]; }
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
     finish_env<T, TOPO>(m, c, st, env, q, (T)edge_ang, 0, false);
@@ -1058,7 +1079,9 @@ __device__ __forceinline__ void bank_swap_in(const EnvConst<T>& c, const State& 
     st.edge_sc[0 * n + env] = bk.edge_sc[0 * n + env]; st.edge_sc[1 * n + env] = bk.edge_sc[1 * n + env];
     st.reset_ticks[env] = bk.reset_ticks[env];
     st.step_count[env] = 0;
-    st.licence[env] = 0;
+    st.licence[env] = bk.licence[env];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = bk.trig_sc[i * n + env]; st.trig_sc[(8 + i) * n + env] = bk.trig_sc[(8 + i) * n + env]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { st.tcp_pos[k * n + env] = bk.tcp_pos[k * n + env]; st.tcp_rpy[k * n + env] = bk.tcp_rpy[k * n + env]; }
 #pragma unroll

@@ -14,7 +14,9 @@ The rollout is device resident: steps are enqueued on a torch stream (TorchShard
 the host does not wait per step (--sync-steps restores the blocking VecEnv.step_wait path).
 Extra fields: roofline (dominant kernel, HIP-event durations, PMC traffic), cpu_baseline (the CPU oracle on all host cores),
 literal_solver (the same workload with exactly 150 PGS sweeps in every tick), without_full_batch_reset, other_configs (one short
-companion run per remaining BASELINE config at 1024 envs on this GPU), roofline_16384 (the dominant kernel at 16 384 envs).
+companion run per remaining BASELINE config at 1024 envs on this GPU), roofline_16384 (the dominant kernel at 16 384 envs),
+staggered_episodes (the headline workload with the envs' episodes out of phase, as in an RL run: some env finishes in nearly every step,
+whereas the timed region starts all envs together and sees one full-batch reset per 200 steps; tools/desync_rate.py).
 Weak scaling: every rank owns --num-envs envs; rank 0 receives all observations / rewards / dones once per step (--payload: what the
 message carries, --transport: how it travels; parallel.py), started asynchronously so that it overlaps the next step's simulation
 (SURVEY 8e); the last exchange is waited for inside the timed region.  `no_gather` is the same K steps without the exchange (per-rank
@@ -616,7 +618,7 @@ def main():
                    "k_render_ms": round(lw.kernel_times(lprof)[0]["k_render_tactile"], 4),
                    "what": "pgs_full_sweeps=1: dynamics + exactly 150 Gauss-Seidel sweeps in every one of the 24 ticks (no convergence exit, no analytic fixed point)"}
         lw.close()
-    others, big = None, None
+    others, big, staggered = None, None, None
     headline = args.env == "edge_follow-v0" and n == 1024 and args.image_size == 128 and not args.observation_mode and not args.full_sweeps
     if solo and headline and not args.no_companions:
         # one driver-visible line per remaining BASELINE config, 1024 envs on this GPU (the configs' own sharding puts 1024 on each GPU)
@@ -627,6 +629,15 @@ def main():
                   companion("object_balance-v0", 256, 1024, args.physics, k, barrier, " (BASELINE configs[4]: 8192 envs over 8 GPUs = 1024 per GPU)")]
         b = companion("edge_follow-v0", 128, 16384, args.physics, k, barrier, " (the headline workload at 16 384 envs: the chip filled)")
         big = {"num_envs": 16384, "value": b["value"], "ms_per_step": b["ms_per_step"], **b["roofline"]}
+        # the headline workload with its episodes out of phase (an RL run's condition: some env finishes in nearly every step); the timed
+        # region above starts all envs together, so they all finish in the same step, once per 200
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        from desync_rate import run as desync_run
+        sdt, sinfo = desync_run(True, 1024, max(200, min(args.steps, 1000)), MAX_STEPS.get("edge_follow-v0", 200))
+        staggered = {"value": round(1024 / sdt, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * sdt, 4), **sinfo,
+                     "what": "the headline workload with every env's episode phase drawn uniformly (masked resets during the first 200 steps): ~5 of 1024 envs "
+                             "finish in every step; finished envs take their precomputed reset from the reset bank (tg_config.reset_bank, on by default) "
+                             "and keep their solver licence (tools/desync_rate.py, profiles/r5_final_desync.txt)"}
 
     if rank == 0:
         total_envs = n * world
@@ -664,6 +675,7 @@ def main():
             "without_full_batch_reset": no_reset,
             "resets_in_timed_region": bool((args.warmup % max_steps) + args.steps >= max_steps),
             "other_configs": others,
+            "staggered_episodes": staggered,
         }
         if args.no_gather and world > 1:
             out["config"]["parallelism"] = f"env-shard x{world}, no exchange (--no-gather)"

@@ -9,8 +9,8 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python -c "import bench; print(bench.source_hash())" > $O/source_sha16.txt     # what every file of this run was measured on
-python bench.py 2>$O/bench_edge.err | grep metric > $O/bench_edge.json
-B="python bench.py --no-cpu-baseline --no-companions"
+timeout 300 python bench.py 2>$O/bench_edge.err | grep metric > $O/bench_edge.json
+B="timeout 200 python bench.py --no-cpu-baseline --no-companions"
 $B --sync-steps --no-literal 2>/dev/null | grep metric > $O/bench_edge_syncsteps.json
 $B --env surface_follow-v0 2>/dev/null | grep metric > $O/bench_surface_follow-v0.json
 $B --env surface_follow-v2 2>/dev/null | grep metric > $O/bench_surface_follow-v2.json
@@ -21,9 +21,11 @@ $B --no-literal --observation-mode visuotactile --steps 200 --warmup 20 2>/dev/n
 $B --no-literal --separate-policy 2>/dev/null | grep metric > $O/bench_edge_separate_policy.json
 TG_RESET_BANK=0 $B --env surface_follow-v2 2>/dev/null | grep metric > $O/bench_surface_follow-v2_bank_off.json
 $B --env object_push-v0 --narrowphase gjk_manifold --steps 100 --warmup 10 2>/dev/null | grep metric > $O/bench_object_push-v0_gjk_manifold.json
-(python tools/pcie_rate.py; python tools/pcie_rate.py --tiles; python tools/pcie_rate.py --tiles; echo "TG_TILES_ZERO_COPY=0 (round 4: pack on the device, then copy):"; TG_TILES_ZERO_COPY=0 python tools/pcie_rate.py --tiles) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
+(timeout 100 python tools/pcie_rate.py; timeout 100 python tools/pcie_rate.py --tiles; timeout 100 python tools/pcie_rate.py --tiles; echo "TG_TILES_ZERO_COPY=0 (round 4: pack on the device, then copy):"; TG_TILES_ZERO_COPY=0 timeout 100 python tools/pcie_rate.py --tiles) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
 TG_FUSED_STEP=1 $B --no-literal 2>/dev/null | grep metric > $O/bench_edge_fused_step.json          # the one-launch step (opt-in: measured slower)
-python tools/ball_rate.py 1024 8192 2>&1 | grep -v amdgpu > $O/ball_on_plate_rate.txt
+timeout 200 python tools/ball_rate.py 1024 8192 2>&1 | grep -v amdgpu > $O/ball_on_plate_rate.txt
+# episodes out of phase (round 5): the rollout an RL run sees, reset bank auto (= on) and off, configs 2 and 3
+(for e in edge_follow-v0 surface_follow-v0; do echo "$e, reset bank auto:"; timeout 100 python tools/desync_rate.py --env $e 2>&1 | grep aligned; echo "$e, TG_RESET_BANK=0:"; TG_RESET_BANK=0 timeout 100 python tools/desync_rate.py --env $e 2>&1 | grep aligned; done) > $O/desync.txt
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank.json
 TG_NO_DIRECT_BATCH=1 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank_copy_into_batch.json   # round 4's path: rank 0 copies its shard into the batch
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport collective --payload interior 2>/dev/null | grep metric > $O/bench_edge_rccl_interior_1rank.json
@@ -31,17 +33,17 @@ cd /tmp; export TMPDIR=/tmp
 P="python $R/bench.py --no-cpu-baseline --no-literal --no-companions"
 prof() {   # prof <name> <bench flags...>
     local name=$1; shift
-    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- $P "$@" > $O/prof_$name.log 2>&1
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- $P "$@" > $O/prof_$name.log 2>&1
     find $O/prof_$name -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$name.csv \;
     rm -rf $O/prof_$name
-    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_$name -- $P "$@" --steps 10 --warmup 2 > $O/pmc_$name.log 2>&1
+    timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_$name -- $P "$@" --steps 10 --warmup 2 > $O/pmc_$name.log 2>&1
     python $R/tools/pmc_parse.py $O/pmc_$name > $O/pmc_summary_$name.txt 2>&1
     rm -rf $O/pmc_$name
 }
 traffic() {   # traffic <name> <bench flags...>
     local name=$1; shift
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/tf_$name -- $P "$@" --steps 10 --warmup 2 > $O/tf_$name.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/tw_$name -- $P "$@" --steps 10 --warmup 2 > $O/tw_$name.log 2>&1
+    timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/tf_$name -- $P "$@" --steps 10 --warmup 2 > $O/tf_$name.log 2>&1
+    timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/tw_$name -- $P "$@" --steps 10 --warmup 2 > $O/tw_$name.log 2>&1
     python $R/tools/traffic_parse.py $O/tf_$name $O/tw_$name > $O/traffic_$name.json 2>&1
     rm -rf $O/tf_$name $O/tw_$name
 }

@@ -103,3 +103,35 @@ def test_object_balance_reset_template_equals_recomputed_reset(object_mode):
     assert np.array_equal(a["ticks"], b["ticks"]) and np.array_equal(a["rew"], b["rew"])
     assert np.abs(a["q"] - b["q"]).max() < 1e-13, np.abs(a["q"] - b["q"]).max()
     assert (a["img"] != b["img"]).reshape(steps + 1, n, -1).sum(-1).max() <= 3
+
+
+def test_auto_is_on_and_a_reset_env_keeps_its_wavefront_on_the_light_path():
+    """Round 5.  reset_bank="auto" is the bank for the UR5 as well, and a reset renews the solver licence instead
+    of dropping it.  What can be seen from outside: (a) bank_stats says "on"; (b) resetting ONE env of a wavefront leaves the other 63 envs'
+    trajectories where they were - they share that env's licence decision (it is the wavefront's), and whether a tick takes the analytic fixed
+    point or the full solve may move a joint by the solve's last bits only (1e-11 rad is the bound the default-vs-literal test uses), never by
+    more; (c) the reset env itself follows the same trajectory as an env of a batch that was reset as a whole (same seed, same RNG stream)."""
+    import tactile_gym_amd as tg
+    n = 64
+
+    def run(reset_one):
+        v = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=200, image_size=[128, 128], env_modes=EDGE, seed=3, auto_reset=True)
+        v.reset()
+        rng = np.random.default_rng(9)
+        qs = []
+        for k in range(30):
+            if reset_one and k == 10:
+                m = np.zeros(n, np.uint8); m[5] = 1
+                v.reset(m)
+            v.step(rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32))
+            qs.append(v.get_state()["q"].copy())
+        mode = v.bank_stats()["mode"]
+        v.close()
+        return np.stack(qs), mode
+    a, mode = run(False)
+    b, _ = run(True)
+    assert mode == "on"
+    qa, qb = (a, b) if a.shape[-1] == n else (np.swapaxes(a, -1, -2), np.swapaxes(b, -1, -2))      # [..., joints, env]
+    others = [e for e in range(n) if e != 5]
+    assert np.max(np.abs(qa[..., others] - qb[..., others])) < 1e-11
+    assert np.max(np.abs(qa[10:, :, 5] - qb[10:, :, 5])) > 1e-4          # env 5 did restart from its reset pose

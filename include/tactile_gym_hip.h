@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 11
+#define TG_ABI_VERSION 12
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -354,6 +354,12 @@ int tg_copy_episode_stats(tg_ctx* ctx, float* final_return, int32_t* final_len);
 /* Host copies (synchronise). */
 int tg_get_reward_done(tg_ctx* ctx, float* reward, uint8_t* done);
 int tg_copy_obs_tactile(tg_ctx* ctx, uint8_t* host_dst, int32_t terminal);
+/* The images of `count` chosen envs only: env_ids[k]'s tactile image (visual != 0: its scene-camera image, after tg_set_scene) goes to
+ * host_dst + k * image_bytes, from the current observation buffer or (terminal != 0) from the terminal one.  What a VecEnv's step_wait reads
+ * for info["terminal_observation"] (stable_baselines3's VecEnv contract; sb3_helpers/rl_utils.py:17-37 wraps the envs in one): with the
+ * episodes out of phase a handful of envs finish in nearly every step, and copying the whole terminal batch for them (16.8 MB at 1024 x
+ * 128 x 128) was two thirds of the numpy step's time.  ABI v12. */
+int tg_copy_obs_rows(tg_ctx* ctx, int32_t visual, int32_t terminal, const int32_t* env_ids, int32_t count, uint8_t* host_dst);
 int tg_copy_obs_feature(tg_ctx* ctx, float* host_dst, int32_t terminal);   /* float32 [num_envs][12] */
 
 /* Parity / inspection view of the per-env state, host arrays sized by the caller ([num_envs][...]), any may be NULL. */

@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -183,6 +183,7 @@ SYMBOLS = {
     "tg_get_obs_feature": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32), C.c_int32]),
     "tg_get_reward_done": (C.c_int, [_ctx, _fp, _u8p]),
     "tg_copy_obs_tactile": (C.c_int, [_ctx, _u8p, C.c_int32]),
+    "tg_copy_obs_rows": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _u8p]),
     "tg_copy_obs_feature": (C.c_int, [_ctx, _fp, C.c_int32]),
     "tg_get_state": (C.c_int, [_ctx, C.POINTER(TgStateView)]),
     "tg_set_joint_state": (C.c_int, [_ctx, _dp, _dp]),

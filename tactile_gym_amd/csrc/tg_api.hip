@@ -426,6 +426,8 @@ struct tg_ctx {
     tg::State bk{};                    // the bank view: st's layout, the reset-written arrays in allocations of the bank's own
     tg::BankAux aux{};
     int bank_mode = 0;                 // 0 off, 1 refills on bank_stream every bank_every steps, 2 as 1 and waited for (tests)
+    uint8_t* h_rows = nullptr;         // tg_copy_obs_rows: pinned staging block
+    size_t h_rows_bytes = 0;
     int bank_every = 8;
     static constexpr int kBankRing = 16, kBankLag = 8;    // bank_refill: markers on the step stream, one per visit; the host stays <= kBankLag visits ahead
     hipEvent_t ev_bank_ring[kBankRing] = {};
@@ -1339,6 +1341,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->ev_bank) (void)hipEventDestroy(c->ev_bank);
     if (c->ev_bank_done) (void)hipEventDestroy(c->ev_bank_done);
     for (hipEvent_t& e : c->ev_bank_ring) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (c->h_rows) { (void)hipHostFree(c->h_rows); c->h_rows = nullptr; }
     for (void* p_ : c->bank_allocs) (void)hipFree(p_);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1960,6 +1963,31 @@ int tg_copy_obs_tactile(tg_ctx* c, uint8_t* dst, int32_t terminal) {
     TG_ENTER(c);
     TG_HIP(hipMemcpyAsync(dst, terminal ? c->d_term : obs_buf(c), (size_t)c->cfg.num_envs * c->H * c->W, hipMemcpyDeviceToHost, c->stream));
     TG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tg_copy_obs_rows(tg_ctx* c, int32_t visual, int32_t terminal, const int32_t* env_ids, int32_t count, uint8_t* dst) {
+    if (!c || count < 0 || (count > 0 && (!env_ids || !dst))) return fail(-1, "tg_copy_obs_rows: bad argument");
+    TG_ENTER(c);
+    if (visual && !c->scene_on) return fail(-1, "tg_copy_obs_rows: no scene (tg_set_scene)");
+    const size_t img = visual ? (size_t)c->scene.W * c->scene.H * 3 : (size_t)c->H * c->W;
+    const uint8_t* src = visual ? (terminal ? c->d_vis_term : c->d_vis) : (terminal ? c->d_term : obs_buf(c));
+    for (int32_t k = 0; k < count; ++k)
+        if (env_ids[k] < 0 || env_ids[k] >= c->cfg.num_envs) return fail(-1, "tg_copy_obs_rows: env id out of range");
+    // through a pinned staging block (64 images at a time): a device -> pageable copy of 16 KB is a staged, blocking copy of its own each time
+    constexpr int kChunk = 64;
+    if (c->h_rows_bytes < img * kChunk) {
+        if (c->h_rows) { (void)hipHostFree(c->h_rows); c->h_rows = nullptr; c->h_rows_bytes = 0; }
+        TG_HIP(hipHostMalloc((void**)&c->h_rows, img * kChunk, hipHostMallocDefault));
+        c->h_rows_bytes = img * kChunk;
+    }
+    for (int32_t k0 = 0; k0 < count; k0 += kChunk) {
+        const int32_t m = count - k0 < kChunk ? count - k0 : kChunk;
+        for (int32_t k = 0; k < m; ++k)
+            TG_HIP(hipMemcpyAsync(c->h_rows + (size_t)k * img, src + (size_t)env_ids[k0 + k] * img, img, hipMemcpyDeviceToHost, c->stream));
+        TG_HIP(hipStreamSynchronize(c->stream));
+        memcpy(dst + (size_t)k0 * img, c->h_rows, (size_t)m * img);
+    }
     return 0;
 }
 

@@ -314,10 +314,19 @@ class TactileVecEnv(_VecEnvBase):
                 if self._monitor is not None:
                     self._monitor.write(infos[i]["episode"])
         if self._cfg.auto_reset and dones.any():
-            term = self._terminal_observation()
-            for i in np.nonzero(dones)[0]:   # owned copies: the library's terminal buffers are rewritten by the next auto-reset
-                infos[i]["terminal_observation"] = {k: (v[i].clone() if hasattr(v, "clone") else np.array(v[i])) for k, v in term.items()}
-                infos[i]["TimeLimit.truncated"] = False
+            idx = np.nonzero(dones)[0]
+            if self.obs_mode == "torch":
+                term = self._terminal_observation()
+                for i in idx:   # owned copies: the library's terminal buffers are rewritten by the next auto-reset
+                    infos[i]["terminal_observation"] = {k: v[i].clone() for k, v in term.items()}
+                    infos[i]["TimeLimit.truncated"] = False
+            else:
+                # only the finished envs' images cross PCIe (tg_copy_obs_rows): with the episodes out of phase some env finishes in nearly every
+                # step, and the whole terminal batch per such step (16.8 MB) was two thirds of the step's time (tools/pcie_rate.py --staggered)
+                term = self._terminal_rows(idx)
+                for j, i in enumerate(idx):
+                    infos[i]["terminal_observation"] = {k: v[j] for k, v in term.items()}      # rows of arrays made for this step: owned
+                    infos[i]["TimeLimit.truncated"] = False
         return obs, self._reward.copy(), dones, infos
 
     def step(self, actions):
@@ -522,6 +531,28 @@ class TactileVecEnv(_VecEnvBase):
         buf = np.empty((self.num_envs, self._oracle_dim), dtype=np.float32)
         capi.check(self._L.tg_copy_obs_oracle_terminal(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_float))))
         return buf
+
+    def _image_rows(self, idx, visual, terminal=True):
+        """[len(idx), H, W, C] uint8: the tactile (or scene-camera) images of the envs `idx` from the terminal (or current) observation buffer."""
+        ids = np.ascontiguousarray(idx, dtype=np.int32)
+        shape = (self.H, self.W, 3) if visual else (self.H, self.W, 1)
+        out = np.empty((len(ids),) + shape, dtype=np.uint8)
+        capi.check(self._L.tg_copy_obs_rows(self._ctx, 1 if visual else 0, 1 if terminal else 0, ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids),
+                                            out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def _terminal_rows(self, idx):
+        """The terminal observation of the envs `idx` only (numpy): images by tg_copy_obs_rows, the small per-env vectors from their whole-batch copies."""
+        obs = {}
+        if "oracle" in self.observation_mode:
+            obs["oracle"] = np.array(self.oracle_terminal()[idx])
+        if "tactile" in self.observation_mode:
+            obs["tactile"] = self._image_rows(idx, False)
+        if self._visual:
+            obs["visual"] = self._image_rows(idx, True)
+        if "feature" in self.observation_mode:
+            obs["extended_feature"] = np.array(self.feature_numpy(True)[idx])
+        return obs
 
     def _terminal_observation(self):
         obs = {}

@@ -146,3 +146,38 @@ def test_step_random_equals_sample_actions_then_step(env_id):
         assert torch.equal(a.actions_torch(), buf), k
         assert torch.equal(oa["tactile"], ob["tactile"]) and torch.equal(ra, rb) and torch.equal(da, db), k
     a.close(); b.close()
+
+
+def test_terminal_observations_of_finished_envs_equal_the_terminal_batch():
+    """numpy VecEnv.step_wait hands info["terminal_observation"] of the finished envs from tg_copy_obs_rows (their images only, round 5) - the same
+    bytes as those envs' rows of the whole terminal batch (tg_copy_obs_tactile(terminal=1)), with episodes that end in different steps, in the
+    default and in the tile transfer mode; the scene camera's terminal images likewise."""
+    import tactile_gym_amd as tg
+    n = 40
+    for modes, tiles in ((EDGE, False), (EDGE, True), (dict(EDGE, observation_mode="visuotactile"), False)):
+        venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=9, image_size=[128, 128], env_modes=modes, seed=4, auto_reset=True)
+        if tiles:
+            venv.set_obs_transfer("tiles")
+        venv.reset()
+        rng = np.random.default_rng(2)
+        m = np.zeros(n, np.uint8); m[::3] = 1
+        for k in range(4):
+            venv.step(rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32))
+        venv.reset(m)                                           # a third of the envs now finish four steps later than the rest
+        seen = 0
+        for k in range(24):
+            obs, rew, done, infos = venv.step(rng.uniform(-0.25, 0.25, size=(n, 2)).astype(np.float32))
+            if done.any():
+                whole = venv.tactile_numpy(True)
+                vis = venv.visual_numpy(True) if "visual" in obs else None
+                assert not done.all()
+                for i in np.flatnonzero(done):
+                    t = infos[i]["terminal_observation"]
+                    assert t["tactile"].shape == whole[i].shape and np.array_equal(t["tactile"], whole[i]), (k, i)
+                    if vis is not None:
+                        assert np.array_equal(t["visual"], vis[i]), (k, i)
+                    seen += 1
+                for i in np.flatnonzero(~done):
+                    assert "terminal_observation" not in infos[i]
+        assert seen >= 2 * n
+        venv.close()

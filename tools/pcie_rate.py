@@ -10,14 +10,28 @@ if "--tiles" in sys.argv:
 v.reset()
 rng = np.random.default_rng(0)
 acts = rng.uniform(-0.25, 0.25, size=(64, n, 2)).astype(np.float32)
+stag = "--staggered" in sys.argv      # the episodes out of phase (tools/desync_rate.py): ~5 envs finish in every step, as in an RL run, and the
+if stag:                              # caller reads their terminal observations the way SB3's rollout collection does
+    phase = rng.integers(0, 200, size=n)
+    for k in range(200):
+        v.step(acts[k % 64])
+        m = (phase == k).astype(np.uint8)
+        if m.any():
+            v.reset(m)
 for k in range(10):
     v.step(acts[k])
 t = time.perf_counter()
 K = 100
+ndone = 0
 for k in range(K):
     obs, rew, done, info = v.step(acts[k % 64])
+    if stag:
+        for i in np.flatnonzero(done):
+            ndone += 1
+            _ = info[i]["terminal_observation"]
 dt = time.perf_counter() - t
-print(("tile download, " if "--tiles" in sys.argv else "") + f"host-buffer path: {n * K / dt:.0f} env-steps/s, {1e3 * dt / K:.3f} ms/step, obs {obs['tactile'].shape} {obs['tactile'].dtype}")
+print(("episodes out of phase (%d finished in %d steps, terminal observations read), " % (ndone, K) if stag else "") +
+      ("tile download, " if "--tiles" in sys.argv else "") + f"host-buffer path: {n * K / dt:.0f} env-steps/s, {1e3 * dt / K:.3f} ms/step, obs {obs['tactile'].shape} {obs['tactile'].dtype}")
 if "--tiles" in sys.argv:
     d = v._tile_download
     print(f"  per fetch: pack + copy + sync {1e3 * d.t_device / d.calls:.3f} ms, host rebuild {1e3 * d.t_host / d.calls:.3f} ms, {d.last_bytes} bytes in the last message")

@@ -21,7 +21,8 @@ $B --no-literal --observation-mode visuotactile --steps 200 --warmup 20 2>/dev/n
 $B --no-literal --separate-policy 2>/dev/null | grep metric > $O/bench_edge_separate_policy.json
 TG_RESET_BANK=0 $B --env surface_follow-v2 2>/dev/null | grep metric > $O/bench_surface_follow-v2_bank_off.json
 $B --env object_push-v0 --narrowphase gjk_manifold --steps 100 --warmup 10 2>/dev/null | grep metric > $O/bench_object_push-v0_gjk_manifold.json
-(timeout 100 python tools/pcie_rate.py; timeout 100 python tools/pcie_rate.py --tiles; timeout 100 python tools/pcie_rate.py --tiles; echo "TG_TILES_ZERO_COPY=0 (round 4: pack on the device, then copy):"; TG_TILES_ZERO_COPY=0 timeout 100 python tools/pcie_rate.py --tiles) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
+(timeout 100 python tools/pcie_rate.py; timeout 100 python tools/pcie_rate.py --tiles; timeout 100 python tools/pcie_rate.py --tiles; echo "TG_TILES_ZERO_COPY=0 (round 4: pack on the device, then copy):"; TG_TILES_ZERO_COPY=0 timeout 100 python tools/pcie_rate.py --tiles;
+ echo "episodes out of phase (round 5):"; timeout 100 python tools/pcie_rate.py --tiles --staggered; timeout 100 python tools/pcie_rate.py --staggered) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
 TG_FUSED_STEP=1 $B --no-literal 2>/dev/null | grep metric > $O/bench_edge_fused_step.json          # the one-launch step (opt-in: measured slower)
 timeout 200 python tools/ball_rate.py 1024 8192 2>&1 | grep -v amdgpu > $O/ball_on_plate_rate.txt
 # episodes out of phase (round 5): the rollout an RL run sees, reset bank auto (= on) and off, configs 2 and 3

@@ -3,7 +3,7 @@
 `tools/pybullet_probe.py --backend pybullet --assets <tactile_gym/assets> --out tests/golden` writes `tests/golden/pybullet_<scenario>.npz`
 from raw PyBullet calls (no tactile_gym source needed); this file then replays every scenario through oracle/ and compares, naming the
 PARITY_ASSUMPTIONS items each comparison closes.  Without such files those tests are skipped (reported as skipped, not passed).  One test
-always runs: the same five scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
+always runs: the same six scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
 exercises the scenario scripts, the file format and the comparison, not the physics (oracle against oracle)."""
 import glob
 import os
@@ -34,6 +34,13 @@ CHECKS = {
                       ("cube_rot", 1e-4, "A27-A28: friction torques (the cube's yaw under an off-centre, slowly turning push)"),
                       ("tip_normal", 1e-2, "A24: the contact normal of the tip point (PyBullet's is on B; sign convention: from the cube towards the tip)"),
                       ("tip_distance", 1e-4, "A24: the tip point's signed distance (negative = penetration) with both margins subtracted")],
+    "balance_constraint": [("gap", 1e-6, "A18: the point-to-point rows' erp 0.2 - the pivot gap left by the teleport (the base's inertial frame is put where the "
+                                          "link frame was meant: A21) decays by 0.8 per tick; A19 the 500 N s cap is never reached"),
+                           ("pole_pos", 2e-5, "A18, A20, A21: the pole's path on the constraint over 120 ticks - constraint rows after the motor rows, free-body "
+                                              "integration (gravity -0.5, no damping), the one-shot 0.1 N push consumed by the first tick"),
+                           ("pole_rot", 1e-4, "A21: gyroscopic term and the exponential-map orientation update (the pole tilts ~2 degrees in the scenario)"),
+                           ("pole_linvel", 1e-4, "A18, A21"), ("pole_angvel", 1e-3, "A21"),
+                           ("q", 1e-7, "A20: the arm under the constraint's reaction (velocity motors hold their targets: the reaction is absorbed)")],
     "tactile_depth": [("depth", 2e-5, "A12-A16: camera mounting, view / projection matrices, the depth buffer's convention and raster rules "
                                       "(the tolerance the reference's own nodef_dep fixtures are reproduced to)")],
 }
@@ -81,3 +88,8 @@ def test_probe_format_and_comparison_with_the_oracle_backend(tmp_path):
     d = np.load(tmp_path / "ref" / "pybullet_push_contacts.npz")
     assert d["cube_pos"].shape == (240, 3) and int(d["tip_contact"].sum()) > 200 and set(d["n_table"].tolist()) == {4}   # the tip pushes, the cube stays flat
     assert d["cube_pos"][-1, 1] - d["cube_pos"][0, 1] > 0.004 and d["tip_distance"][-1] < -1e-3            # ... and moves under the push, the soft tip pressed in
+    d = np.load(tmp_path / "ref" / "pybullet_balance_constraint.npz")
+    g = np.linalg.norm(d["gap"], axis=1)
+    assert d["pole_pos"].shape == (120, 3) and 1e-4 < g[0] < 1e-3 and g[-1] < 1e-6                           # the teleport leaves a gap, the constraint closes it
+    assert np.all(np.abs(g[1:8] / g[0:7] - 0.8) < 0.05)                                                       # ... by erp 0.2 per tick (A18)
+    assert 0.999 < d["pole_rot"][-1, 8] < 0.99999 and np.all(np.isfinite(d["pole_angvel"]))                  # the pushed pole tilts, slowly (gravity -0.5)

@@ -4,7 +4,7 @@ directory (`tactile_gym/assets`: URDFs and meshes only).
     python tools/pybullet_probe.py --backend pybullet --assets /path/to/tactile_gym/assets --out tests/golden
     python tools/pybullet_probe.py --backend oracle --out /tmp/probe            # the same scenarios through oracle/ (format check)
 
-What it does: runs five primitive scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
+What it does: runs six primitive scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
 backend-neutral operations - through one of two backends and writes `pybullet_<scenario>.npz` (inputs + recorded outputs):
 
     arm_statics       calculateInverseDynamics(q, 0, 0), calculateMassMatrix(q), calculateJacobian(TCP) at three poses
@@ -21,6 +21,13 @@ backend-neutral operations - through one of two backends and writes `pybullet_<s
                       work-frame push (24 ticks each); per tick the cube's pose and velocity, which cube - table and cube - tip contacts
                       exist (getContactPoints), the tip contact's normal and distance -> A23-A29 (contact sets, margins, soft tip contact,
                       cone friction) and row n1 of the survey (contact-pair indices)
+
+    balance_constraint  object_balance's pole on its point-to-point constraint (object_balance_env.py:173-199, 261-294, 328-381): UR5 + standard
+                      TacTip pointing up (tip collisions off: "no_core"), Robot.reset to the work-frame origin, the pole teleported onto the tip
+                      with zero damping, gravity -0.5, the one-shot 0.1 N push at a fixed off-centre point, then 10 control steps of 12
+                      ticks under a constant work-frame twist (x, y and a tilt about x); per tick the pole's pose and velocity, the arm's joints
+                      and the pivot gap -> A18-A21 (the constraint's erp and row order, free-body integration, the one-shot force, which frame
+                      get/resetBasePositionAndOrientation speak)
 
 tests/test_pybullet_golden.py compares oracle/ with every `tests/golden/pybullet_*.npz` it finds (tolerances and the assumption each
 comparison closes are in the test) and always runs the oracle backend against itself through a temporary directory, so the file format and
@@ -300,6 +307,102 @@ class PyBulletPush(PyBulletBackend):
                     tip_distance=np.array(deep[8] if deep else 0.0), q=self.joints()[0])
 
 
+BAL_WORKFRAME = ([0.55, 0.0, 0.35], [0.0, 0.0, 0.0])                            # object_balance_env.py:71-73
+BAL_REST = [0.19826, -2.01062, -1.96602, -0.73808, 4.71286, -3.34064]           # object_balance/rest_poses.py (ur5, standard)
+BAL_GRAVITY, BAL_EMBED = -0.5, 0.0045                                           # inside reset_task's ranges (:301-316), fixed here
+BAL_PUSH_AT = (0.3, -0.2)                                                       # the push point's offset from the pole's base centre, in half base widths (:364-370)
+BAL_BASE_W, BAL_BASE_H = 0.1, 0.0025                                            # setup_object :176-178
+BAL_VEL = [0.004, -0.003, 0.0, 2.0 * math.pi / 180, 0.0, 0.0]                   # work-frame twist: x, y, a tilt about x (inside the action ranges :123-131)
+
+
+class OracleBalance:
+    """The oracle's object_balance env (pole) driven tick by tick, with reset_task's draws replaced by the fixed values above."""
+    name = "oracle"
+
+    def __init__(self, assets=None):
+        from oracle.ref_env import OracleObjectBalanceEnv
+        modes = dict(movement_mode="xyRxRy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=False, rand_embed_dist=False,
+                     observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+        e = OracleObjectBalanceEnv(seed=1, env_modes=modes)
+        e.step_counter = 0
+        e.gravity = BAL_GRAVITY                                                          # reset_task (:295-321) with fixed draws
+        e.arm.set_gravity([0.0, 0.0, BAL_GRAVITY])
+        e.embed_dist = BAL_EMBED
+        e._set_init_obj_pos(buffer_height=0.0)
+        e._update_constraint()
+        e._reset_robot(np.zeros(3), np.zeros(3))                                         # base_object_env.py:171-172
+        e._teleport_body(e.init_obj_pos, e.init_obj_rot)                                 # reset_object :335
+        fpos = e.init_obj_pos + np.array([BAL_PUSH_AT[0] * BAL_BASE_W / 2, BAL_PUSH_AT[1] * BAL_BASE_W / 2, 0.0])
+        for k in range(3):                                                               # apply_random_force_base(0.1) :360-378
+            e.body.ext_force[k] = [0.0, 0.0, -0.1][k]
+            e.body.ext_pos[k] = float(fpos[k])
+        e.body.ext_pending = 1
+        self.env = e
+
+    def control(self, twist):
+        self.env._tcp_velocity_control(np.array(twist, dtype=np.float64))
+
+    def tick(self):
+        self.env._step_sim()
+
+    def record(self):
+        e = self.env
+        pos, R = e.body_pose()
+        tcp_pos = e._tcp_world()[0]
+        pivot_b = pos + R @ np.array([0.0, 0.0, -BAL_BASE_H / 2 + BAL_EMBED])           # the child pivot is given in the base's INERTIAL frame
+        return dict(pole_pos=pos, pole_rot=R.reshape(9), pole_linvel=np.array(e.body.linvel[:]), pole_angvel=np.array(e.body.angvel[:]),
+                    q=np.array(e.arm.q), gap=np.asarray(tcp_pos) - pivot_b)
+
+
+class PyBulletBalance(PyBulletBackend):
+    """object_balance-v0's world (pole) in raw pybullet: the base world of PyBulletBackend (UR5 + standard TacTip), tip collisions off, the
+    pole on a JOINT_POINT2POINT constraint to the TCP link."""
+
+    def __init__(self, assets):
+        super().__init__(assets)
+        p = self.p
+        self.tip = self.link["tactip_tip_link"]
+        p.setCollisionFilterGroupMask(self.robot, self.body, 0, 0)                              # tactile_sensor.py:46-57, t_s_core "no_core"
+        p.setCollisionFilterGroupMask(self.robot, self.tip, 0, 0)
+        init_pos = [BAL_WORKFRAME[0][0], BAL_WORKFRAME[0][1], BAL_WORKFRAME[0][2] + BAL_BASE_H / 2 - BAL_EMBED]    # :185-189, :317-321
+        init_orn = p.getQuaternionFromEuler([0.0, 0.0, -math.pi / 2])                           # :190-191
+        self.pole = p.loadURDF(os.path.join(assets, "rl_env_assets/nonprehensile_manipulation/object_balance/pole/pole.urdf"), init_pos, init_orn)   # base_object_env.py:70
+        self.cons = p.createConstraint(self.robot, self.tcp, self.pole, -1, p.JOINT_POINT2POINT, jointAxis=[0, 0, 1], parentFramePosition=[0, 0, 0],
+                                       childFramePosition=[0, 0, -BAL_BASE_H / 2 + 0.0035], parentFrameOrientation=p.getQuaternionFromEuler([0, 0, 0]),
+                                       childFrameOrientation=p.getQuaternionFromEuler([0, 0, 0]))   # apply_constraints :261-283 (embed_dist 0.0035 at that time)
+        # reset(): reset_task with the fixed draws, Robot.reset, reset_object
+        p.setGravity(0, 0, BAL_GRAVITY)
+        p.changeConstraint(self.cons, jointChildPivot=[0, 0, -BAL_BASE_H / 2 + BAL_EMBED])      # update_constraints :285-294
+        self.reset_joints(BAL_REST)
+        wq = _quat_from_euler(*BAL_WORKFRAME[1])
+        tpos, tq = np.array(BAL_WORKFRAME[0]), _quat_mul(wq, _quat_from_euler(0.0, 0.0, 0.0))
+        targ = np.array(p.calculateInverseKinematics(self.robot, self.tcp, list(tpos), list(tq), restPoses=list(BAL_REST), maxNumIterations=100,
+                                                     residualThreshold=1e-8))[: len(self.ctrl)]
+        self.motors_position(targ, MAX_FORCE)
+        _blocking_move(self, tpos, tq, targ)
+        p.resetBasePositionAndOrientation(self.pole, init_pos, init_orn)                        # reset_object :335
+        for link_id in range(-1, p.getNumJoints(self.pole)):
+            p.changeDynamics(self.pole, link_id, linearDamping=0.0, angularDamping=0.0)         # :338-345
+        fpos = np.array(init_pos) + np.array([BAL_PUSH_AT[0] * BAL_BASE_W / 2, BAL_PUSH_AT[1] * BAL_BASE_W / 2, 0.0])
+        p.applyExternalForce(self.pole, -1, [0.0, 0.0, -0.1], list(fpos), flags=p.WORLD_FRAME)  # :360-378: consumed by the next stepSimulation
+
+    def control(self, twist):
+        wq = _quat_from_euler(*BAL_WORKFRAME[1])
+        tw = np.concatenate([_rotate(wq, twist[:3]), _rotate(wq, twist[3:])])                   # workvel_to_worldvel; the limits do not bind here
+        q, _ = self.joints()
+        self.motors_velocity(np.linalg.inv(self.jacobian_tcp(q)) @ tw)                          # base_robot_arm.py:300-322
+
+    def record(self):
+        p = self.p
+        pos, orn = p.getBasePositionAndOrientation(self.pole)                                   # the root link's INERTIAL frame (A21)
+        lv, av = p.getBaseVelocity(self.pole)
+        R = np.array(p.getMatrixFromQuaternion(orn)).reshape(3, 3)
+        pivot_b = np.array(pos) + R @ np.array([0.0, 0.0, -BAL_BASE_H / 2 + BAL_EMBED])         # childFramePosition: in the child's inertial frame
+        tcp = np.array(p.getLinkState(self.robot, self.tcp, computeForwardKinematics=True)[0])  # the TCP link's inertial frame = parentFramePosition's origin
+        return dict(pole_pos=np.array(pos), pole_rot=R.reshape(9), pole_linvel=np.array(lv), pole_angvel=np.array(av), q=self.joints()[0],
+                    gap=tcp - pivot_b)
+
+
 def _blocking_move(b, tpos, tq, targ_j, max_steps=1000):
     """Robot.blocking_move(max_steps=1000, constant_vel=0.001) (robot.py:188-260) on a backend; returns the ticks used and the joint path."""
     cv, used, qs = 0.001, 0, []
@@ -391,9 +494,23 @@ def scenario_push_contacts(b, steps=10):
     return dict({k: np.array(v) for k, v in rec.items()}, twist=np.array(PUSH_VEL), workframe_pos=np.array(PUSH_WORKFRAME[0]))
 
 
+def scenario_balance_constraint(b, steps=10):
+    keys = ("pole_pos", "pole_rot", "pole_linvel", "pole_angvel", "q", "gap")
+    rec = {k: [] for k in keys}
+    for _ in range(steps):
+        b.control(BAL_VEL)
+        for _ in range(12):                                                                     # _velocity_action_repeat = floor((1/20) / (1/240)), :33-35
+            b.tick()
+            r = b.record()
+            for k in keys:
+                rec[k].append(r[k])
+    return dict({k: np.array(v) for k, v in rec.items()}, twist=np.array(BAL_VEL), gravity=np.array(BAL_GRAVITY), embed=np.array(BAL_EMBED))
+
+
 SCENARIOS = {"arm_statics": scenario_arm_statics, "arm_velocity": scenario_arm_velocity, "reset_move": scenario_reset_move,
-             "tactile_depth": scenario_tactile_depth, "push_contacts": scenario_push_contacts}
-WORLDS = {"push_contacts": {"oracle": OraclePush, "pybullet": PyBulletPush}}          # scenarios with a world of their own
+             "tactile_depth": scenario_tactile_depth, "push_contacts": scenario_push_contacts, "balance_constraint": scenario_balance_constraint}
+WORLDS = {"push_contacts": {"oracle": OraclePush, "pybullet": PyBulletPush},          # scenarios with a world of their own
+          "balance_constraint": {"oracle": OracleBalance, "pybullet": PyBulletBalance}}
 
 
 def run(backend, out_dir, assets=None, scenarios=None):

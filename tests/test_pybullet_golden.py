@@ -3,7 +3,7 @@
 `tools/pybullet_probe.py --backend pybullet --assets <tactile_gym/assets> --out tests/golden` writes `tests/golden/pybullet_<scenario>.npz`
 from raw PyBullet calls (no tactile_gym source needed); this file then replays every scenario through oracle/ and compares, naming the
 PARITY_ASSUMPTIONS items each comparison closes.  Without such files those tests are skipped (reported as skipped, not passed).  One test
-always runs: the same six scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
+always runs: the same seven scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
 exercises the scenario scripts, the file format and the comparison, not the physics (oracle against oracle)."""
 import glob
 import os
@@ -41,6 +41,13 @@ CHECKS = {
                            ("pole_rot", 1e-4, "A21: gyroscopic term and the exponential-map orientation update (the pole tilts ~2 degrees in the scenario)"),
                            ("pole_linvel", 1e-4, "A18, A21"), ("pole_angvel", 1e-3, "A21"),
                            ("q", 1e-7, "A20: the arm under the constraint's reaction (velocity motors hold their targets: the reaction is absorbed)")],
+    "ball_on_plate": [("ball_pos", 1e-4, "A39: the ball on the plate - one sphere - cylinder-cap contact point with the pair's margins, friction 10 x 0.5 (A26), the "
+                                        "ball's radius (globalScaling scales the shape, A30) - rolling under the one-shot torque and the plate's tilt over 120 ticks"),
+                      ("ball_linvel", 1e-3, "A39: rolling without slipping (cone friction, one contact point)"),
+                      ("ball_angvel", 5e-2, "A39, A30: the ball's inertia (mass unscaled, radius scaled)"),
+                      ("pole_pos", 5e-5, "A39, A18: the plate under the ball's weight on its point-to-point constraint"),
+                      ("pole_rot", 1e-3, "A39: the plate tips about the pivot (AABB-derived inertia of the cylinder, A3)"),
+                      ("gap", 1e-6, "A18"), ("q", 1e-7, "A20")],
     "tactile_depth": [("depth", 2e-5, "A12-A16: camera mounting, view / projection matrices, the depth buffer's convention and raster rules "
                                       "(the tolerance the reference's own nodef_dep fixtures are reproduced to)")],
 }
@@ -93,3 +100,8 @@ def test_probe_format_and_comparison_with_the_oracle_backend(tmp_path):
     assert d["pole_pos"].shape == (120, 3) and 1e-4 < g[0] < 1e-3 and g[-1] < 1e-6                           # the teleport leaves a gap, the constraint closes it
     assert np.all(np.abs(g[1:8] / g[0:7] - 0.8) < 0.05)                                                       # ... by erp 0.2 per tick (A18)
     assert 0.999 < d["pole_rot"][-1, 8] < 0.99999 and np.all(np.isfinite(d["pole_angvel"]))                  # the pushed pole tilts, slowly (gravity -0.5)
+    d = np.load(tmp_path / "ref" / "pybullet_ball_on_plate.npz")
+    r = 0.0025 * 7.5
+    assert d["ball_pos"].shape == (120, 3) and abs(d["ball_pos"][0, 2] - (0.35 + r)) < 2e-3                    # the ball starts on the plate ...
+    assert 1e-4 < np.linalg.norm(d["ball_pos"][-1, :2] - d["ball_pos"][0, :2]) < 0.05                          # ... rolls, and is still on it
+    assert 0.99 < d["pole_rot"][-1, 8] < 0.9999                                                                # the plate has begun to tip under it

@@ -4,7 +4,7 @@ directory (`tactile_gym/assets`: URDFs and meshes only).
     python tools/pybullet_probe.py --backend pybullet --assets /path/to/tactile_gym/assets --out tests/golden
     python tools/pybullet_probe.py --backend oracle --out /tmp/probe            # the same scenarios through oracle/ (format check)
 
-What it does: runs six primitive scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
+What it does: runs seven primitive scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
 backend-neutral operations - through one of two backends and writes `pybullet_<scenario>.npz` (inputs + recorded outputs):
 
     arm_statics       calculateInverseDynamics(q, 0, 0), calculateMassMatrix(q), calculateJacobian(TCP) at three poses
@@ -28,6 +28,11 @@ backend-neutral operations - through one of two backends and writes `pybullet_<s
                       ticks under a constant work-frame twist (x, y and a tilt about x); per tick the pole's pose and velocity, the arm's joints
                       and the pivot gap -> A18-A21 (the constraint's erp and row order, free-body integration, the one-shot force, which frame
                       get/resetBasePositionAndOrientation speak)
+
+    ball_on_plate     object_balance's other object (:187-199, 241-260, 350-353, 393-401): the round plate on the same constraint, the ball
+                      (sphere.urdf x globalScaling 7.5, lateralFriction 10) put on it, the one-shot 0.001 N m torque on the ball, then 10 control
+                      steps under the same twist; per tick the plate's pose, the ball's position and velocities, the joints -> A39 (and A26 / A30:
+                      friction combination, what globalScaling scales)
 
 tests/test_pybullet_golden.py compares oracle/ with every `tests/golden/pybullet_*.npz` it finds (tolerances and the assumption each
 comparison closes are in the test) and always runs the oracle backend against itself through a temporary directory, so the file format and
@@ -313,17 +318,19 @@ BAL_GRAVITY, BAL_EMBED = -0.5, 0.0045                                           
 BAL_PUSH_AT = (0.3, -0.2)                                                       # the push point's offset from the pole's base centre, in half base widths (:364-370)
 BAL_BASE_W, BAL_BASE_H = 0.1, 0.0025                                            # setup_object :176-178
 BAL_VEL = [0.004, -0.003, 0.0, 2.0 * math.pi / 180, 0.0, 0.0]                   # work-frame twist: x, y, a tilt about x (inside the action ranges :123-131)
+BALL_TORQUE = (0.6, -0.4)                                                       # apply_random_torque_ball's two draws in [-1, 1] (:393-401), fixed here
 
 
 class OracleBalance:
     """The oracle's object_balance env (pole) driven tick by tick, with reset_task's draws replaced by the fixed values above."""
     name = "oracle"
 
-    def __init__(self, assets=None):
+    def __init__(self, assets=None, ball=False):
         from oracle.ref_env import OracleObjectBalanceEnv
-        modes = dict(movement_mode="xyRxRy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=False, rand_embed_dist=False,
-                     observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
+        modes = dict(movement_mode="xyRxRy", control_mode="TCP_velocity_control", object_mode="ball_on_plate" if ball else "pole", rand_gravity=False,
+                     rand_embed_dist=False, observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
         e = OracleObjectBalanceEnv(seed=1, env_modes=modes)
+        self.ball = ball
         e.step_counter = 0
         e.gravity = BAL_GRAVITY                                                          # reset_task (:295-321) with fixed draws
         e.arm.set_gravity([0.0, 0.0, BAL_GRAVITY])
@@ -332,11 +339,17 @@ class OracleBalance:
         e._update_constraint()
         e._reset_robot(np.zeros(3), np.zeros(3))                                         # base_object_env.py:171-172
         e._teleport_body(e.init_obj_pos, e.init_obj_rot)                                 # reset_object :335
-        fpos = e.init_obj_pos + np.array([BAL_PUSH_AT[0] * BAL_BASE_W / 2, BAL_PUSH_AT[1] * BAL_BASE_W / 2, 0.0])
-        for k in range(3):                                                               # apply_random_force_base(0.1) :360-378
-            e.body.ext_force[k] = [0.0, 0.0, -0.1][k]
-            e.body.ext_pos[k] = float(fpos[k])
-        e.body.ext_pending = 1
+        if ball:                                                                         # reset_ball + apply_random_torque_ball(0.001) :350-353, 393-401
+            e._teleport_ball()
+            for k in range(3):
+                e.ball.ext_torque[k] = [BALL_TORQUE[0] * 0.001, BALL_TORQUE[1] * 0.001, 0.0][k]
+            e.ball.ext_pending = 1
+        else:
+            fpos = e.init_obj_pos + np.array([BAL_PUSH_AT[0] * BAL_BASE_W / 2, BAL_PUSH_AT[1] * BAL_BASE_W / 2, 0.0])
+            for k in range(3):                                                           # apply_random_force_base(0.1) :360-378
+                e.body.ext_force[k] = [0.0, 0.0, -0.1][k]
+                e.body.ext_pos[k] = float(fpos[k])
+            e.body.ext_pending = 1
         self.env = e
 
     def control(self, twist):
@@ -350,23 +363,33 @@ class OracleBalance:
         pos, R = e.body_pose()
         tcp_pos = e._tcp_world()[0]
         pivot_b = pos + R @ np.array([0.0, 0.0, -BAL_BASE_H / 2 + BAL_EMBED])           # the child pivot is given in the base's INERTIAL frame
-        return dict(pole_pos=pos, pole_rot=R.reshape(9), pole_linvel=np.array(e.body.linvel[:]), pole_angvel=np.array(e.body.angvel[:]),
-                    q=np.array(e.arm.q), gap=np.asarray(tcp_pos) - pivot_b)
+        out = dict(pole_pos=pos, pole_rot=R.reshape(9), pole_linvel=np.array(e.body.linvel[:]), pole_angvel=np.array(e.body.angvel[:]),
+                   q=np.array(e.arm.q), gap=np.asarray(tcp_pos) - pivot_b)
+        if self.ball:
+            out.update(ball_pos=np.array(e.ball.pos[:]), ball_linvel=np.array(e.ball.linvel[:]), ball_angvel=np.array(e.ball.angvel[:]))
+        return out
 
 
 class PyBulletBalance(PyBulletBackend):
     """object_balance-v0's world (pole) in raw pybullet: the base world of PyBulletBackend (UR5 + standard TacTip), tip collisions off, the
     pole on a JOINT_POINT2POINT constraint to the TCP link."""
 
-    def __init__(self, assets):
+    def __init__(self, assets, ball=False):
         super().__init__(assets)
         p = self.p
+        self.ball = None
         self.tip = self.link["tactip_tip_link"]
         p.setCollisionFilterGroupMask(self.robot, self.body, 0, 0)                              # tactile_sensor.py:46-57, t_s_core "no_core"
         p.setCollisionFilterGroupMask(self.robot, self.tip, 0, 0)
         init_pos = [BAL_WORKFRAME[0][0], BAL_WORKFRAME[0][1], BAL_WORKFRAME[0][2] + BAL_BASE_H / 2 - BAL_EMBED]    # :185-189, :317-321
         init_orn = p.getQuaternionFromEuler([0.0, 0.0, -math.pi / 2])                           # :190-191
-        self.pole = p.loadURDF(os.path.join(assets, "rl_env_assets/nonprehensile_manipulation/object_balance/pole/pole.urdf"), init_pos, init_orn)   # base_object_env.py:70
+        obj = "round_plate/round_plate.urdf" if ball else "pole/pole.urdf"                       # setup_object :173-199
+        self.pole = p.loadURDF(os.path.join(assets, "rl_env_assets/nonprehensile_manipulation/object_balance", obj), init_pos, init_orn)   # base_object_env.py:70
+        if ball:                                                                                # load_ball :241-259
+            self.ball_pos = [BAL_WORKFRAME[0][0], BAL_WORKFRAME[0][1], BAL_WORKFRAME[0][2] + 0.0025 * 7.5]
+            self.ball = p.loadURDF(os.path.join(assets, "rl_env_assets/nonprehensile_manipulation/object_balance/sphere/sphere.urdf"), self.ball_pos,
+                                   [0, 0, 0, 1], globalScaling=7.5)
+            p.changeDynamics(self.ball, -1, lateralFriction=10.0)
         self.cons = p.createConstraint(self.robot, self.tcp, self.pole, -1, p.JOINT_POINT2POINT, jointAxis=[0, 0, 1], parentFramePosition=[0, 0, 0],
                                        childFramePosition=[0, 0, -BAL_BASE_H / 2 + 0.0035], parentFrameOrientation=p.getQuaternionFromEuler([0, 0, 0]),
                                        childFrameOrientation=p.getQuaternionFromEuler([0, 0, 0]))   # apply_constraints :261-283 (embed_dist 0.0035 at that time)
@@ -383,8 +406,12 @@ class PyBulletBalance(PyBulletBackend):
         p.resetBasePositionAndOrientation(self.pole, init_pos, init_orn)                        # reset_object :335
         for link_id in range(-1, p.getNumJoints(self.pole)):
             p.changeDynamics(self.pole, link_id, linearDamping=0.0, angularDamping=0.0)         # :338-345
-        fpos = np.array(init_pos) + np.array([BAL_PUSH_AT[0] * BAL_BASE_W / 2, BAL_PUSH_AT[1] * BAL_BASE_W / 2, 0.0])
-        p.applyExternalForce(self.pole, -1, [0.0, 0.0, -0.1], list(fpos), flags=p.WORLD_FRAME)  # :360-378: consumed by the next stepSimulation
+        if ball:                                                                                # :350-353
+            p.resetBasePositionAndOrientation(self.ball, self.ball_pos, [0, 0, 0, 1])           # reset_ball :325-326
+            p.applyExternalTorque(self.ball, -1, [BALL_TORQUE[0] * 0.001, BALL_TORQUE[1] * 0.001, 0.0], flags=p.LINK_FRAME)   # :393-401
+        else:
+            fpos = np.array(init_pos) + np.array([BAL_PUSH_AT[0] * BAL_BASE_W / 2, BAL_PUSH_AT[1] * BAL_BASE_W / 2, 0.0])
+            p.applyExternalForce(self.pole, -1, [0.0, 0.0, -0.1], list(fpos), flags=p.WORLD_FRAME)  # :360-378: consumed by the next stepSimulation
 
     def control(self, twist):
         wq = _quat_from_euler(*BAL_WORKFRAME[1])
@@ -399,8 +426,13 @@ class PyBulletBalance(PyBulletBackend):
         R = np.array(p.getMatrixFromQuaternion(orn)).reshape(3, 3)
         pivot_b = np.array(pos) + R @ np.array([0.0, 0.0, -BAL_BASE_H / 2 + BAL_EMBED])         # childFramePosition: in the child's inertial frame
         tcp = np.array(p.getLinkState(self.robot, self.tcp, computeForwardKinematics=True)[0])  # the TCP link's inertial frame = parentFramePosition's origin
-        return dict(pole_pos=np.array(pos), pole_rot=R.reshape(9), pole_linvel=np.array(lv), pole_angvel=np.array(av), q=self.joints()[0],
-                    gap=tcp - pivot_b)
+        out = dict(pole_pos=np.array(pos), pole_rot=R.reshape(9), pole_linvel=np.array(lv), pole_angvel=np.array(av), q=self.joints()[0],
+                   gap=tcp - pivot_b)
+        if self.ball is not None:
+            bp, _ = p.getBasePositionAndOrientation(self.ball)
+            blv, bav = p.getBaseVelocity(self.ball)
+            out.update(ball_pos=np.array(bp), ball_linvel=np.array(blv), ball_angvel=np.array(bav))
+        return out
 
 
 def _blocking_move(b, tpos, tq, targ_j, max_steps=1000):
@@ -507,10 +539,26 @@ def scenario_balance_constraint(b, steps=10):
     return dict({k: np.array(v) for k, v in rec.items()}, twist=np.array(BAL_VEL), gravity=np.array(BAL_GRAVITY), embed=np.array(BAL_EMBED))
 
 
+def scenario_ball_on_plate(b, steps=10):      # (by 20 steps the plate - balanced on a point under a ball five times its mass - has tipped 20 degrees: past 10 the comparison would measure the instability)
+    keys = ("pole_pos", "pole_rot", "q", "gap", "ball_pos", "ball_linvel", "ball_angvel")
+    rec = {k: [] for k in keys}
+    for _ in range(steps):
+        b.control(BAL_VEL)
+        for _ in range(12):
+            b.tick()
+            r = b.record()
+            for k in keys:
+                rec[k].append(r[k])
+    return dict({k: np.array(v) for k, v in rec.items()}, twist=np.array(BAL_VEL), gravity=np.array(BAL_GRAVITY), embed=np.array(BAL_EMBED),
+                ball_torque=np.array(BALL_TORQUE))
+
+
 SCENARIOS = {"arm_statics": scenario_arm_statics, "arm_velocity": scenario_arm_velocity, "reset_move": scenario_reset_move,
-             "tactile_depth": scenario_tactile_depth, "push_contacts": scenario_push_contacts, "balance_constraint": scenario_balance_constraint}
+             "tactile_depth": scenario_tactile_depth, "push_contacts": scenario_push_contacts, "balance_constraint": scenario_balance_constraint,
+             "ball_on_plate": scenario_ball_on_plate}
 WORLDS = {"push_contacts": {"oracle": OraclePush, "pybullet": PyBulletPush},          # scenarios with a world of their own
-          "balance_constraint": {"oracle": OracleBalance, "pybullet": PyBulletBalance}}
+          "balance_constraint": {"oracle": OracleBalance, "pybullet": PyBulletBalance},
+          "ball_on_plate": {"oracle": lambda a: OracleBalance(a, ball=True), "pybullet": lambda a: PyBulletBalance(a, ball=True)}}
 
 
 def run(backend, out_dir, assets=None, scenarios=None):

@@ -3,7 +3,7 @@
 `tools/pybullet_probe.py --backend pybullet --assets <tactile_gym/assets> --out tests/golden` writes `tests/golden/pybullet_<scenario>.npz`
 from raw PyBullet calls (no tactile_gym source needed); this file then replays every scenario through oracle/ and compares, naming the
 PARITY_ASSUMPTIONS items each comparison closes.  Without such files those tests are skipped (reported as skipped, not passed).  One test
-always runs: the same seven scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
+always runs: the same eight scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
 exercises the scenario scripts, the file format and the comparison, not the physics (oracle against oracle)."""
 import glob
 import os
@@ -34,6 +34,13 @@ CHECKS = {
                       ("cube_rot", 1e-4, "A27-A28: friction torques (the cube's yaw under an off-centre, slowly turning push)"),
                       ("tip_normal", 1e-2, "A24: the contact normal of the tip point (PyBullet's is on B; sign convention: from the cube towards the tip)"),
                       ("tip_distance", 1e-4, "A24: the tip point's signed distance (negative = penetration) with both margins subtracted")],
+    "push_manifold": [("n_tip", 0, "A35-A38: how many tip - cube points Bullet's persistent manifold holds per tick (add / replace / drop rules, the breaking "
+                                   "threshold, the 4-point reduction) against oracle/narrowphase.c"),
+                      ("n_table", 0, "A23, A25 (as push_contacts)"),
+                      ("cube_pos", 2e-5, "A35-A38 with A24-A28: the cube's path when every manifold point carries its own soft-contact row"),
+                      ("cube_rot", 1e-4, "A27-A28, A36"),
+                      ("tip_normal", 1e-2, "A35: GJK / EPA's normal of the deepest point"),
+                      ("tip_distance", 1e-4, "A35: its signed distance with both margins subtracted")],
     "balance_constraint": [("gap", 1e-6, "A18: the point-to-point rows' erp 0.2 - the pivot gap left by the teleport (the base's inertial frame is put where the "
                                           "link frame was meant: A21) decays by 0.8 per tick; A19 the 500 N s cap is never reached"),
                            ("pole_pos", 2e-5, "A18, A20, A21: the pole's path on the constraint over 120 ticks - constraint rows after the motor rows, free-body "
@@ -95,6 +102,9 @@ def test_probe_format_and_comparison_with_the_oracle_backend(tmp_path):
     d = np.load(tmp_path / "ref" / "pybullet_push_contacts.npz")
     assert d["cube_pos"].shape == (240, 3) and int(d["tip_contact"].sum()) > 200 and set(d["n_table"].tolist()) == {4}   # the tip pushes, the cube stays flat
     assert d["cube_pos"][-1, 1] - d["cube_pos"][0, 1] > 0.004 and d["tip_distance"][-1] < -1e-3            # ... and moves under the push, the soft tip pressed in
+    m = np.load(tmp_path / "ref" / "pybullet_push_manifold.npz")                                               # the general narrowphase drives the same push
+    assert set(m["n_tip"].tolist()) <= {0, 1, 2, 3, 4} and int((m["n_tip"] > 0).sum()) > 200
+    assert np.max(np.abs(m["cube_pos"] - d["cube_pos"])) < 1e-5                                              # ... to the same place as the closed form (GPU-side: tests/test_gpu_narrowphase.py)
     d = np.load(tmp_path / "ref" / "pybullet_balance_constraint.npz")
     g = np.linalg.norm(d["gap"], axis=1)
     assert d["pole_pos"].shape == (120, 3) and 1e-4 < g[0] < 1e-3 and g[-1] < 1e-6                           # the teleport leaves a gap, the constraint closes it

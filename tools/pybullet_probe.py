@@ -4,7 +4,7 @@ directory (`tactile_gym/assets`: URDFs and meshes only).
     python tools/pybullet_probe.py --backend pybullet --assets /path/to/tactile_gym/assets --out tests/golden
     python tools/pybullet_probe.py --backend oracle --out /tmp/probe            # the same scenarios through oracle/ (format check)
 
-What it does: runs seven primitive scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
+What it does: runs eight scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
 backend-neutral operations - through one of two backends and writes `pybullet_<scenario>.npz` (inputs + recorded outputs):
 
     arm_statics       calculateInverseDynamics(q, 0, 0), calculateMassMatrix(q), calculateJacobian(TCP) at three poses
@@ -33,6 +33,10 @@ backend-neutral operations - through one of two backends and writes `pybullet_<s
                       (sphere.urdf x globalScaling 7.5, lateralFriction 10) put on it, the one-shot 0.001 N m torque on the ball, then 10 control
                       steps under the same twist; per tick the plate's pose, the ball's position and velocities, the joints -> A39 (and A26 / A30:
                       friction combination, what globalScaling scales)
+
+    push_manifold     the same push, the same PyBullet world; the ORACLE side runs its general narrowphase (GJK / EPA + a Bullet-style persistent
+                      manifold of up to four tip - cube points, oracle/narrowphase.c) instead of the closed form, and the number of tip - cube
+                      contact points per tick is compared as well -> A35-A38
 
 tests/test_pybullet_golden.py compares oracle/ with every `tests/golden/pybullet_*.npz` it finds (tolerances and the assumption each
 comparison closes are in the test) and always runs the oracle backend against itself through a temporary directory, so the file format and
@@ -224,11 +228,11 @@ class OraclePush:
     """The oracle's object_push env (oracle/ref_env.py) driven tick by tick."""
     name = "oracle"
 
-    def __init__(self, assets=None):
+    def __init__(self, assets=None, narrowphase="closed_form"):
         from oracle.ref_env import OracleObjectPushEnv
         modes = dict(movement_mode="TyRz", control_mode="TCP_velocity_control", rand_init_orn=False, rand_obj_mass=False, traj_type="straight",
                      observation_mode="tactile_and_feature", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
-        self.env = OracleObjectPushEnv(seed=1, env_modes=modes)
+        self.env = OracleObjectPushEnv(seed=1, env_modes=modes, narrowphase=narrowphase)
         self.env.reset()
 
     def control(self, twist):
@@ -243,7 +247,7 @@ class OraclePush:
         ids = [int(e.scene.contact_ids[k]) for k in range(8)][: int(e.scene.n_contacts)]
         tip = any(i >= 8 for i in ids)
         return dict(cube_pos=pos, cube_rot=R.reshape(9), cube_linvel=np.array(e.cube.linvel[:]), cube_angvel=np.array(e.cube.angvel[:]),
-                    n_table=np.array(sum(1 for i in ids if i < 8)), tip_contact=np.array(int(tip)),
+                    n_table=np.array(sum(1 for i in ids if i < 8)), n_tip=np.array(sum(1 for i in ids if i >= 8)), tip_contact=np.array(int(tip)),
                     tip_normal=np.array(e.scene.tip_normal[:]) if tip else np.zeros(3), tip_distance=np.array(float(e.scene.tip_depth) if tip else 0.0),
                     q=e.arm.q)
 
@@ -308,7 +312,7 @@ class PyBulletPush(PyBulletBackend):
         tip = [c for c in p.getContactPoints(self.robot, self.cube) if c[3] == self.tip]
         deep = min(tip, key=lambda c: c[8]) if tip else None
         return dict(cube_pos=np.array(pos), cube_rot=R, cube_linvel=np.array(lv), cube_angvel=np.array(av), n_table=np.array(len(table)),
-                    tip_contact=np.array(int(bool(tip))), tip_normal=np.array(deep[7]) if deep else np.zeros(3),
+                    n_tip=np.array(len(tip)), tip_contact=np.array(int(bool(tip))), tip_normal=np.array(deep[7]) if deep else np.zeros(3),
                     tip_distance=np.array(deep[8] if deep else 0.0), q=self.joints()[0])
 
 
@@ -514,7 +518,7 @@ def scenario_tactile_depth(b, size=128):
 
 
 def scenario_push_contacts(b, steps=10):
-    keys = ("cube_pos", "cube_rot", "cube_linvel", "cube_angvel", "n_table", "tip_contact", "tip_normal", "tip_distance", "q")
+    keys = ("cube_pos", "cube_rot", "cube_linvel", "cube_angvel", "n_table", "n_tip", "tip_contact", "tip_normal", "tip_distance", "q")
     rec = {k: [] for k in keys}
     for _ in range(steps):
         b.control(PUSH_VEL)
@@ -555,8 +559,9 @@ def scenario_ball_on_plate(b, steps=10):      # (by 20 steps the plate - balance
 
 SCENARIOS = {"arm_statics": scenario_arm_statics, "arm_velocity": scenario_arm_velocity, "reset_move": scenario_reset_move,
              "tactile_depth": scenario_tactile_depth, "push_contacts": scenario_push_contacts, "balance_constraint": scenario_balance_constraint,
-             "ball_on_plate": scenario_ball_on_plate}
+             "ball_on_plate": scenario_ball_on_plate, "push_manifold": scenario_push_contacts}
 WORLDS = {"push_contacts": {"oracle": OraclePush, "pybullet": PyBulletPush},          # scenarios with a world of their own
+          "push_manifold": {"oracle": lambda a: OraclePush(a, narrowphase="gjk_manifold"), "pybullet": PyBulletPush},
           "balance_constraint": {"oracle": OracleBalance, "pybullet": PyBulletBalance},
           "ball_on_plate": {"oracle": lambda a: OracleBalance(a, ball=True), "pybullet": lambda a: PyBulletBalance(a, ball=True)}}
 

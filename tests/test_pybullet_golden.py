@@ -3,7 +3,7 @@
 `tools/pybullet_probe.py --backend pybullet --assets <tactile_gym/assets> --out tests/golden` writes `tests/golden/pybullet_<scenario>.npz`
 from raw PyBullet calls (no tactile_gym source needed); this file then replays every scenario through oracle/ and compares, naming the
 PARITY_ASSUMPTIONS items each comparison closes.  Without such files those tests are skipped (reported as skipped, not passed).  One test
-always runs: the same eight scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
+always runs: the same nine scenarios written by the ORACLE backend into a temporary directory and compared through the same code - it
 exercises the scenario scripts, the file format and the comparison, not the physics (oracle against oracle)."""
 import glob
 import os
@@ -41,6 +41,12 @@ CHECKS = {
                       ("cube_rot", 1e-4, "A27-A28, A36"),
                       ("tip_normal", 1e-2, "A35: GJK / EPA's normal of the deepest point"),
                       ("tip_distance", 1e-4, "A35: its signed distance with both margins subtracted")],
+    "roll_contacts": [("table_contact", 0, "A30: the marble's one contact with the table (sphere - plane, margin 1e-6, breaking threshold 1e-4)"),
+                      ("tip_contact", 0, "A30: sphere against the flat tip's collision cylinder - present from the first tick at a 2.5 mm embed"),
+                      ("tip_distance", 1e-4, "A30: the tip point's signed distance (the cylinder's lower face sits 1.75 mm above the TCP)"),
+                      ("ball_pos", 2e-5, "A30, A26: rolling between table (friction 10 x 1) and tip (10 x 10, soft contact 10 / 100): the centre moves at half the tip's speed"),
+                      ("ball_linvel", 1e-4, "A30"), ("ball_angvel", 5e-2, "A30: sphere inertia 0.4 m r^2 from the collision shape"),
+                      ("q", 1e-7, "A4-A7 under the contact's reaction")],
     "balance_constraint": [("gap", 1e-6, "A18: the point-to-point rows' erp 0.2 - the pivot gap left by the teleport (the base's inertial frame is put where the "
                                           "link frame was meant: A21) decays by 0.8 per tick; A19 the 500 N s cap is never reached"),
                            ("pole_pos", 2e-5, "A18, A20, A21: the pole's path on the constraint over 120 ticks - constraint rows after the motor rows, free-body "
@@ -110,6 +116,11 @@ def test_probe_format_and_comparison_with_the_oracle_backend(tmp_path):
     assert d["pole_pos"].shape == (120, 3) and 1e-4 < g[0] < 1e-3 and g[-1] < 1e-6                           # the teleport leaves a gap, the constraint closes it
     assert np.all(np.abs(g[1:8] / g[0:7] - 0.8) < 0.05)                                                       # ... by erp 0.2 per tick (A18)
     assert 0.999 < d["pole_rot"][-1, 8] < 0.99999 and np.all(np.isfinite(d["pole_angvel"]))                  # the pushed pole tilts, slowly (gravity -0.5)
+    d = np.load(tmp_path / "ref" / "pybullet_roll_contacts.npz")
+    assert d["ball_pos"].shape == (120, 3) and int(d["table_contact"].sum()) == 120 and int(d["tip_contact"].sum()) == 120     # pinched between table and tip
+    tip_speed = np.linalg.norm(d["twist"][:2])
+    assert abs(np.linalg.norm(d["ball_linvel"][-1, :2]) / tip_speed - 0.5) < 0.02                              # rolling without slipping: half the tip's speed
+    assert np.all(np.abs(d["ball_pos"][:, 2] - float(d["radius"])) < 1e-5)                                     # ... on the table
     d = np.load(tmp_path / "ref" / "pybullet_ball_on_plate.npz")
     r = 0.0025 * 7.5
     assert d["ball_pos"].shape == (120, 3) and abs(d["ball_pos"][0, 2] - (0.35 + r)) < 2e-3                    # the ball starts on the plate ...

@@ -4,7 +4,7 @@ directory (`tactile_gym/assets`: URDFs and meshes only).
     python tools/pybullet_probe.py --backend pybullet --assets /path/to/tactile_gym/assets --out tests/golden
     python tools/pybullet_probe.py --backend oracle --out /tmp/probe            # the same scenarios through oracle/ (format check)
 
-What it does: runs eight scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
+What it does: runs nine scenarios of the step's hot path - the PyBullet calls `BaseTactileEnv.step` makes, restated as a script of
 backend-neutral operations - through one of two backends and writes `pybullet_<scenario>.npz` (inputs + recorded outputs):
 
     arm_statics       calculateInverseDynamics(q, 0, 0), calculateMassMatrix(q), calculateJacobian(TCP) at three poses
@@ -37,6 +37,11 @@ backend-neutral operations - through one of two backends and writes `pybullet_<s
     push_manifold     the same push, the same PyBullet world; the ORACLE side runs its general narrowphase (GJK / EPA + a Bullet-style persistent
                       manifold of up to four tip - cube points, oracle/narrowphase.c) instead of the closed form, and the number of tip - cube
                       contact points per tick is compared as well -> A35-A38
+
+    roll_contacts     object_roll's marble (object_roll_env.py:55-71, 156-237): UR5 + flat TacTip (tip core on, soft contact 10 / 100, friction 10),
+                      sphere.urdf on the table with the env's changeDynamics, Robot.reset onto it (embed 2.5 mm), 5 control steps of 24 ticks
+                      under an x / y work-frame velocity; per tick the marble's position and velocities, whether it touches table and tip, the
+                      tip point's distance, the joints -> A30 (sphere - plane and sphere - cylinder contacts, sphere inertia, friction products)
 
 tests/test_pybullet_golden.py compares oracle/ with every `tests/golden/pybullet_*.npz` it finds (tolerances and the assumption each
 comparison closes are in the test) and always runs the oracle backend against itself through a temporary directory, so the file format and
@@ -439,6 +444,97 @@ class PyBulletBalance(PyBulletBackend):
         return out
 
 
+ROLL_REST = [0.16682, -2.23156, -1.66642, -0.81399, 1.57315, 1.74001]           # object_roll/rest_poses.py (ur5, flat)
+ROLL_R, ROLL_EMBED = 0.0025, 0.0025                                             # object_roll_env.py:161; embed inside reset_task's range (:188-189) - at the
+                                                                                # default 1.5 mm the tip's collision core (its lower face 1.75 mm above the TCP) stays 0.23 mm clear of this marble
+ROLL_WORKFRAME = ([0.65, 0.0, 2 * ROLL_R - ROLL_EMBED], [-math.pi, 0.0, math.pi / 2])   # :70-71
+ROLL_VEL = [0.004, 0.002, 0.0, 0.0, 0.0, 0.0]                                   # work-frame twist (movement_mode "xy", inside the action range :113-135)
+
+
+class OracleRoll:
+    """The oracle's object_roll env driven tick by tick (every randomisation off: its reset is deterministic up to the goal, which does not
+    enter the dynamics)."""
+    name = "oracle"
+
+    def __init__(self, assets=None):
+        from oracle.ref_env import OracleObjectRollEnv
+        self.env = OracleObjectRollEnv(seed=1, env_modes=dict(rand_init_obj_pos=False, rand_obj_size=False, rand_embed_dist=False))
+        self.env.embed_dist = ROLL_EMBED
+        self.env.reset()
+
+    def control(self, twist):
+        self.env._tcp_velocity_control(np.array(twist, dtype=np.float64))
+
+    def tick(self):
+        self.env._step_sim()
+
+    def record(self):
+        e = self.env
+        ids = [int(e.scene.contact_ids[k]) for k in range(8)][: int(e.scene.n_contacts)]
+        tip = any(i >= 8 for i in ids)
+        return dict(ball_pos=np.array(e.ball.pos[:]), ball_linvel=np.array(e.ball.linvel[:]), ball_angvel=np.array(e.ball.angvel[:]),
+                    table_contact=np.array(int(any(i < 8 for i in ids))), tip_contact=np.array(int(tip)),
+                    tip_distance=np.array(float(e.scene.tip_depth) if tip else 0.0), q=np.array(e.arm.q))
+
+
+class PyBulletRoll(PyBulletBackend):
+    """object_roll-v0's world in raw pybullet: UR5 + flat TacTip with its tip core on (soft contact 10 / 100, friction 10), the marble on the
+    table with the env's changeDynamics."""
+
+    def __init__(self, assets):
+        import pybullet as p
+        self.p = p
+        if not assets or not os.path.isdir(assets):
+            raise SystemExit("--assets must point at the reference's `tactile_gym/assets` directory")
+        self.assets = assets
+        p.connect(p.DIRECT)
+        p.setGravity(0, 0, -9.81)
+        p.setPhysicsEngineParameter(fixedTimeStep=SIM_DT, numSolverIterations=SOLVER_ITERS, enableConeFriction=1, contactBreakingThreshold=0.0001)
+        self.plane = p.loadURDF(os.path.join(assets, "shared_assets/environment_objects/plane/plane.urdf"), [0, 0, -0.625])
+        self.table = p.loadURDF(os.path.join(assets, "shared_assets/environment_objects/table/table.urdf"), [0.50, 0.00, -0.625], [0.0, 0.0, 0.0, 1.0])
+        self.robot = p.loadURDF(os.path.join(assets, "robot_assets/ur5/tactip/ur5_with_flat_tactip.urdf"), [0, 0, 0], [0, 0, 0, 1], useFixedBase=True)
+        self.n_all = p.getNumJoints(self.robot)
+        info = [p.getJointInfo(self.robot, i) for i in range(self.n_all)]
+        self.link = {inf[12].decode(): i for i, inf in enumerate(info)}
+        self.ctrl = [i for i, inf in enumerate(info) if inf[2] != p.JOINT_FIXED]
+        self.tcp, self.body, self.tip = self.link["tcp_link"], self.link["tactip_body_link"], self.link["tactip_tip_link"]
+        for i in range(self.n_all):
+            p.changeDynamics(self.robot, i, linearDamping=0.04, angularDamping=0.04)
+            p.changeDynamics(self.robot, i, jointDamping=0.01)
+        p.setCollisionFilterGroupMask(self.robot, self.body, 0, 0)                              # tactile_sensor.py:46-57 (core "fixed": the tip stays on)
+        p.changeDynamics(self.robot, self.tip, contactDamping=100, contactStiffness=10.0)       # reset_tip :320-332, t_s_dynamics of object_roll_env.py:57
+        p.changeDynamics(self.robot, self.tip, lateralFriction=10.0)
+        pos = [0.65, 0.0, ROLL_R]                                                               # setup_object :161-166
+        self.marble = p.loadURDF(os.path.join(assets, "rl_env_assets/nonprehensile_manipulation/object_roll/sphere/sphere.urdf"), pos, [0, 0, 0, 1])
+        self.edge = None
+        self.reset_joints(ROLL_REST)                                                            # Robot.reset to the work-frame origin (robot.py:114-125)
+        wq = _quat_from_euler(*ROLL_WORKFRAME[1])
+        tpos, tq = np.array(ROLL_WORKFRAME[0]), _quat_mul(wq, _quat_from_euler(0.0, 0.0, 0.0))
+        targ = np.array(p.calculateInverseKinematics(self.robot, self.tcp, list(tpos), list(tq), restPoses=list(ROLL_REST), maxNumIterations=100,
+                                                     residualThreshold=1e-8))[: len(self.ctrl)]
+        self.motors_position(targ, MAX_FORCE)
+        _blocking_move(self, tpos, tq, targ)
+        p.resetBasePositionAndOrientation(self.marble, pos, [0, 0, 0, 1])                       # reset_object :219
+        p.changeDynamics(self.marble, -1, lateralFriction=10.0, spinningFriction=0.0, rollingFriction=0.0, restitution=0.0, frictionAnchor=0,
+                         collisionMargin=0.000001)                                              # :228-237
+
+    def control(self, twist):
+        wq = _quat_from_euler(*ROLL_WORKFRAME[1])
+        tw = np.concatenate([_rotate(wq, twist[:3]), _rotate(wq, twist[3:])])
+        q, _ = self.joints()
+        self.motors_velocity(np.linalg.inv(self.jacobian_tcp(q)) @ tw)
+
+    def record(self):
+        p = self.p
+        pos, _ = p.getBasePositionAndOrientation(self.marble)
+        lv, av = p.getBaseVelocity(self.marble)
+        table = p.getContactPoints(self.marble, self.table)
+        tip = [c for c in p.getContactPoints(self.robot, self.marble) if c[3] == self.tip]
+        deep = min(tip, key=lambda c: c[8]) if tip else None
+        return dict(ball_pos=np.array(pos), ball_linvel=np.array(lv), ball_angvel=np.array(av), table_contact=np.array(int(bool(table))),
+                    tip_contact=np.array(int(bool(tip))), tip_distance=np.array(deep[8] if deep else 0.0), q=self.joints()[0])
+
+
 def _blocking_move(b, tpos, tq, targ_j, max_steps=1000):
     """Robot.blocking_move(max_steps=1000, constant_vel=0.001) (robot.py:188-260) on a backend; returns the ticks used and the joint path."""
     cv, used, qs = 0.001, 0, []
@@ -557,12 +653,25 @@ def scenario_ball_on_plate(b, steps=10):      # (by 20 steps the plate - balance
                 ball_torque=np.array(BALL_TORQUE))
 
 
+def scenario_roll_contacts(b, steps=5):
+    keys = ("ball_pos", "ball_linvel", "ball_angvel", "table_contact", "tip_contact", "tip_distance", "q")
+    rec = {k: [] for k in keys}
+    for _ in range(steps):
+        b.control(ROLL_VEL)
+        for _ in range(24):                                                                     # floor((1/10) / (1/240)), object_roll_env.py:34-36
+            b.tick()
+            r = b.record()
+            for k in keys:
+                rec[k].append(r[k])
+    return dict({k: np.array(v) for k, v in rec.items()}, twist=np.array(ROLL_VEL), radius=np.array(ROLL_R), embed=np.array(ROLL_EMBED))
+
+
 SCENARIOS = {"arm_statics": scenario_arm_statics, "arm_velocity": scenario_arm_velocity, "reset_move": scenario_reset_move,
              "tactile_depth": scenario_tactile_depth, "push_contacts": scenario_push_contacts, "balance_constraint": scenario_balance_constraint,
-             "ball_on_plate": scenario_ball_on_plate, "push_manifold": scenario_push_contacts}
+             "ball_on_plate": scenario_ball_on_plate, "push_manifold": scenario_push_contacts, "roll_contacts": scenario_roll_contacts}
 WORLDS = {"push_contacts": {"oracle": OraclePush, "pybullet": PyBulletPush},          # scenarios with a world of their own
           "push_manifold": {"oracle": lambda a: OraclePush(a, narrowphase="gjk_manifold"), "pybullet": PyBulletPush},
-          "balance_constraint": {"oracle": OracleBalance, "pybullet": PyBulletBalance},
+          "balance_constraint": {"oracle": OracleBalance, "pybullet": PyBulletBalance}, "roll_contacts": {"oracle": OracleRoll, "pybullet": PyBulletRoll},
           "ball_on_plate": {"oracle": lambda a: OracleBalance(a, ball=True), "pybullet": lambda a: PyBulletBalance(a, ball=True)}}
 
 

@@ -135,3 +135,41 @@ def test_auto_is_on_and_a_reset_env_keeps_its_wavefront_on_the_light_path():
     others = [e for e in range(n) if e != 5]
     assert np.max(np.abs(qa[..., others] - qb[..., others])) < 1e-11
     assert np.max(np.abs(qa[10:, :, 5] - qb[10:, :, 5])) > 1e-4          # env 5 did restart from its reset pose
+
+
+@pytest.mark.parametrize("env_id,modes,act_dim", [("edge_follow-v0", EDGE, 2), ("surface_follow-v0", SURF, 3)])
+def test_bank_modes_are_byte_identical_with_the_episodes_out_of_phase(env_id, modes, act_dim):
+    """The condition an RL run is in and test_bank_off_sync_on_are_byte_identical is not: the envs' episodes end in DIFFERENT steps (masked resets
+    put three groups of envs out of phase), so in nearly every step some envs of a wavefront swap in a bank entry - with its solver licence and
+    exact sines / cosines (round 5) - while their neighbours are mid-episode, and the refill of spent entries runs beside later steps.  Bank off /
+    sync / on (entries ready or not as the two streams happen to run): every observation, reward, done flag, reset tick count and joint state
+    byte-identical."""
+    import tactile_gym_amd as tg
+    n, max_steps, steps = 96, 11, 70
+
+    def run(bank):
+        venv = tg.make_vec(env_id, num_envs=n, max_steps=max_steps, image_size=[128, 128], env_modes=modes, seed=21, auto_reset=True, reset_bank=bank)
+        rng = np.random.default_rng(8)
+        out = {"obs": [venv.reset()["tactile"].copy()], "rew": [], "done": [], "ticks": [], "q": []}
+        for k in range(steps):
+            if k in (2, 5, 7):                                   # envs 0, 3, 6, .. / 1, 4, .. / every 5th restart here: three phases + the rest
+                m = np.zeros(n, np.uint8)
+                m[{2: slice(0, n, 3), 5: slice(1, n, 3), 7: slice(0, n, 5)}[k]] = 1
+                venv.reset(m)
+            obs, rew, done, _ = venv.step(rng.uniform(-0.25, 0.25, size=(n, act_dim)).astype(np.float32))
+            st = venv.get_state()
+            out["obs"].append(obs["tactile"].copy()); out["rew"].append(rew.copy()); out["done"].append(done.copy())
+            out["ticks"].append(st["reset_ticks"].copy()); out["q"].append(st["q"].copy())
+        stats = venv.bank_stats()
+        venv.close()
+        return out, stats
+    off, _ = run("off")
+    syn, s_syn = run("sync")
+    aut, s_aut = run("auto")
+    per_step = [int(d.sum()) for d in off["done"][12:]]
+    assert sum(1 for c in per_step if 0 < c < n) >= len(per_step) // 3 and max(per_step) < n     # four phases over 11-step episodes: some envs finish in a third of the steps, never all
+    assert s_syn["late"] == 0 and s_syn["swapped"] > n and s_aut["mode"] == "on" and s_aut["swapped"] + s_aut["late"] == s_syn["swapped"]
+    for other in (syn, aut):
+        for key in ("obs", "rew", "done", "ticks", "q"):
+            for t, (x, y) in enumerate(zip(off[key], other[key])):
+                assert np.array_equal(x, y), (key, t)

@@ -48,8 +48,9 @@ comparison closes are in the test) and always runs the oracle backend against it
 the comparison code are exercised without PyBullet.  bench.py's `cpu_baseline` times `arm_velocity` through PyBullet when it is importable and
 TG_PYBULLET_ASSETS points at the assets.
 
-This container has no pybullet: the PyBullet backend below is written against PyBullet's documented API and the reference's call sites, and
-has not been executed here."""
+This container has no pybullet: the PyBullet backends below are written against PyBullet's documented API and the reference's call sites.  They
+have been executed only against a stub of that API (tests/test_pybullet_stub.py: the Quickstart Guide's parameter names as real signatures, link
+names from the robots' URDFs) - call names, keywords, argument counts and the files' fields / shapes are checked, nothing PyBullet computes."""
 import argparse
 import math
 import os

@@ -286,3 +286,17 @@ def test_the_stub_rejects_what_pybullet_would_reject(stub):
     with pytest.raises(AttributeError):
         p.getJointStateArray
     assert p.getJointInfo(r, 10)[12] == b"tcp_link" and p.getJointInfo(r, 1)[2] == p.JOINT_REVOLUTE
+
+
+def test_bench_cpu_baseline_through_pybullet_runs_against_the_stub(stub, tmp_path, monkeypatch):
+    """bench.py's `cpu_baseline.pybullet_reference` (the raw engine timed beside the oracle when `import pybullet` works and
+    TG_PYBULLET_ASSETS is set) - the same code path, against the stub: it returns a rate, not the "probe failed" string."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assets = tmp_path / "assets"
+    assets.mkdir()
+    monkeypatch.delenv("TG_PYBULLET_ASSETS", raising=False)
+    assert "TG_PYBULLET_ASSETS" in bench.pybullet_reference(0.05)
+    monkeypatch.setenv("TG_PYBULLET_ASSETS", str(assets))
+    out = bench.pybullet_reference(0.05)
+    assert isinstance(out, dict) and out["value"] > 0 and out["unit"] == "env-steps/s" and out["cores"] == 1, out

@@ -216,7 +216,8 @@ def spawn_ranks(n):
 class Workload:
     """One env configuration on this rank's GPU with its action sampler and stream."""
 
-    def __init__(self, env_id, n, image_size, physics, rank, local_rank, full_sweeps=False, observation_mode=None, pipelined=True, **extra):
+    def __init__(self, env_id, n, image_size, physics, rank, local_rank, full_sweeps=False, observation_mode=None, pipelined=True,
+                 residual_threshold=0.0, **extra):
         import torch
         import tactile_gym_amd as tg
         from tactile_gym_amd.parallel import TorchShard
@@ -228,6 +229,10 @@ class Workload:
         self.max_steps = MAX_STEPS.get(env_id, 200)
         if env_id not in ("object_push-v0", "object_roll-v0"):
             extra = {}
+        if residual_threshold:
+            extra = dict(extra, solver_residual_threshold=residual_threshold)
+        self.residual_threshold = residual_threshold
+        self.ticks_per_step = 12 if env_id == "object_balance-v0" else 24
         self.venv = tg.make_vec(env_id, num_envs=n, max_steps=self.max_steps, image_size=[image_size, image_size], env_modes=self.modes,
                                 seed=1 + rank * n, physics_dtype=physics, auto_reset=True, device=local_rank, obs_mode="torch",
                                 pgs_full_sweeps=full_sweeps, **extra)
@@ -400,7 +405,26 @@ def companion(env_id, image_size, n, physics, steps, barrier, what, **kw):
            "value": round(n * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
            "roofline": {k: roof[k] for k in ("kernel", "achieved", "frac", "step_frac", "traffic", "algorithmic_bytes_per_env_step", "kernel_ms",
                                              "kernel_ms_source", "kernel_ms_sum_per_step")}}
+    if w.residual_threshold:
+        sw = w.venv.get_state()["solver_sweeps"]
+        out["solver_residual_threshold"] = w.residual_threshold
+        out["mean_sweeps_per_tick"] = round(float(sw.mean()) / w.ticks_per_step, 3)
+        out["max_sweeps_per_tick"] = round(float(sw.max()) / w.ticks_per_step, 3)
     w.close()
+    return out
+
+
+def threshold_companions(physics, steps, barrier, extra):
+    """PARITY_ASSUMPTIONS A7b: the reference never sets solverResidualThreshold (base_tactile_env.py:127-130), so PyBullet's own default
+    applies - believed to be 1e-7, under which the Gauss-Seidel loop of every tick leaves after a few sweeps instead of at convergence.  The
+    headline keeps threshold 0 (the library default of Bullet itself, and the reading every earlier round measured) until someone runs the
+    PyBullet kit; this is the other answer on record: every BASELINE config at 1024 envs with tg_config.solver_residual_threshold = 1e-7 -
+    value, ms per step and the mean number of sweeps a tick ran (tg_state_view.solver_sweeps of the last timed step / ticks per step)."""
+    out = {}
+    for name, env_id, size, k, kw in (("config2_edge_follow", "edge_follow-v0", 128, steps, {}), ("config3_surface_follow", "surface_follow-v0", 128, steps, {}),
+                                      ("config4_object_push", "object_push-v0", 128, max(20, steps // 2), extra),
+                                      ("config5_object_balance", "object_balance-v0", 256, steps, {})):
+        out[name] = companion(env_id, size, 1024, physics, k, barrier, ", solver_residual_threshold 1e-7", residual_threshold=1e-7, **kw)
     return out
 
 
@@ -618,7 +642,7 @@ def main():
                    "k_render_ms": round(lw.kernel_times(lprof)[0]["k_render_tactile"], 4),
                    "what": "pgs_full_sweeps=1: dynamics + exactly 150 Gauss-Seidel sweeps in every one of the 24 ticks (no convergence exit, no analytic fixed point)"}
         lw.close()
-    others, big, staggered = None, None, None
+    others, big, staggered, thr_runs = None, None, None, None
     headline = args.env == "edge_follow-v0" and n == 1024 and args.image_size == 128 and not args.observation_mode and not args.full_sweeps
     if solo and headline and not args.no_companions:
         # one driver-visible line per remaining BASELINE config, 1024 envs on this GPU (the configs' own sharding puts 1024 on each GPU)
@@ -627,6 +651,7 @@ def main():
                   companion("object_push-v0", 128, 1024, args.physics, max(20, min(args.steps, 100)), barrier,
                             " (BASELINE configs[3]: 4096 envs over 4 GPUs = 1024 per GPU)", **extra),
                   companion("object_balance-v0", 256, 1024, args.physics, k, barrier, " (BASELINE configs[4]: 8192 envs over 8 GPUs = 1024 per GPU)")]
+        thr_runs = threshold_companions(args.physics, k, barrier, extra)
         b = companion("edge_follow-v0", 128, 16384, args.physics, k, barrier, " (the headline workload at 16 384 envs: the chip filled)")
         big = {"num_envs": 16384, "value": b["value"], "ms_per_step": b["ms_per_step"], **b["roofline"]}
         # the headline workload with its episodes out of phase (an RL run's condition: some env finishes in nearly every step); the timed
@@ -675,6 +700,7 @@ def main():
             "without_full_batch_reset": no_reset,
             "resets_in_timed_region": bool((args.warmup % max_steps) + args.steps >= max_steps),
             "other_configs": others,
+            "residual_threshold_1e-7": thr_runs,
             "staggered_episodes": staggered,
         }
         if args.no_gather and world > 1:

@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 12
+#define TG_ABI_VERSION 13
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -218,6 +218,16 @@ typedef struct {
      * Measured SLOWER on an MI355X (56 against 43 us per step at 1024 envs), hence TG_FUSED_AUTO = off; TG_FUSED_ON opts in;
      * the environment variable TG_FUSED_STEP (0 / 1) overrides.  tg_get_step_mode reports what runs. */
     int32_t fused_step;                     /* TG_FUSED_* */
+    /* btContactSolverInfo::m_leastSquaresResidualThreshold of stepSimulation() (robot.py:141).  The reference's setPhysicsEngineParameter
+     * call (base_tactile_env.py:127-130) passes fixedTimeStep, numSolverIterations, enableConeFriction and contactBreakingThreshold - NOT
+     * solverResidualThreshold, so whatever PyBullet's physics server installs applies (PARITY_ASSUMPTIONS A7b: believed to be 1e-7; Bullet's
+     * own library default is 0).  0 (default): the Gauss-Seidel loop leaves only at last-bit convergence, every mode of this library that
+     * rests on that (the licensed analytic fixed point, the composed sweeps, object_balance's reset template) is available.  > 0 ("threshold
+     * mode"): Bullet's rule - the loop leaves after the sweep whose largest squared row velocity change deltaImpulse / jacDiagABInv (a cone
+     * friction pair counts once, with the sum of its two; A7c) is <= this, never before the first sweep, at most solver_iterations - evaluated
+     * per env after every sweep on every mapping; every tick is a full tick, no licence, no composed sweeps, no reset template
+     * (tg_state_view.solver_sweeps reports the sweeps run).  pgs_full_sweeps is ignored in this mode.  (ABI v13) */
+    double solver_residual_threshold;
 } tg_config;
 
 enum { TG_BANK_AUTO = 0, TG_BANK_OFF = 1, TG_BANK_SYNC = 2, TG_BANK_ON = 3 };
@@ -398,6 +408,8 @@ typedef struct {
     double*  ball_linvel;    /* [num_envs][3] */
     double*  ball_angvel;    /* [num_envs][3] */
     double*  ball_impulse;   /* [num_envs] normal impulse of the ball - plate contact in the last sim tick (0: not touching) */
+    int32_t* solver_sweeps;  /* [num_envs] threshold mode (tg_config.solver_residual_threshold > 0): PGS sweeps the sim ticks of the env's last
+                              * tg_step ran, summed over the ticks (a reset's ticks are not counted); zeros otherwise.  (ABI v13) */
 } tg_state_view;
 int tg_get_state(tg_ctx* ctx, const tg_state_view* view);
 /* Overwrite joint state (tests): q, qd [num_envs][ndof]; re-evaluates the cached TCP pose. */

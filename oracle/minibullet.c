@@ -13,7 +13,19 @@
 #include <stdlib.h>
 #include <string.h>
 
-int mb_last_sweeps = 0;   /* inspection: PGS sweeps executed by the last mb_step (exits at the exact fixed point) */
+int mb_last_sweeps = 0;   /* inspection: PGS sweeps executed by the last mb_step / mb_step_body / mb_step_body_ball / mb_step_push */
+/* btContactSolverInfo::m_leastSquaresResidualThreshold [PARITY_ASSUMPTIONS A7b / A7c].  The solver loop
+ * (btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations) leaves after the sweep whose residual is <= this,
+ * never before the first sweep, at the latest after numSolverIterations.  The residual of a sweep is the largest SQUARED
+ * velocity change of a row update, deltaVel = deltaImpulse / jacDiagABInv (btMultiBodyConstraintSolver::
+ * resolveSingleConstraintRowGeneric returns that since Bullet 2.88); a cone-friction pair counts once, with
+ * deltaVel = deltaImpulse_1 / jacDiagABInv_1 + deltaImpulse_2 / jacDiagABInv_2 (resolveConeFrictionConstraintRows).
+ * 0 = the library default of Bullet itself (exit only at an exact fixed point); PyBullet's physics server is believed to
+ * set 1e-7 when it creates the world, and tactile_gym never overrides it (base_tactile_env.py:127-130). */
+static double mb_res_thr = 0.0;
+void mb_set_solver_residual_threshold(double t) { mb_res_thr = t > 0.0 ? t : 0.0; }
+double mb_get_solver_residual_threshold(void) { return mb_res_thr; }
+#define MB_RESIDUAL(dvel_) do { double dv__ = (dvel_); if (dv__ * dv__ > residual) residual = dv__ * dv__; } while (0)
 
 /* ------------------------------------------------------------------------------------------------ 3-vector helpers */
 static void m3_mul(const double* A, const double* B, double* C) {
@@ -281,9 +293,9 @@ void mb_step(const mb_model* m, mb_state* s, double dt, int iters) {
             else if (sum > maximp[i]) { delta = maximp[i] - lam[i]; lam[i] = maximp[i]; }
             else lam[i] = sum;
             for (int r = 0; r < n; ++r) dv[r] += Mi[r * n + i] * delta;
-            if (delta * delta > residual) residual = delta * delta;
+            MB_RESIDUAL(delta / jdi[i]);
         }
-        if (residual <= 0.0) break;
+        if (residual <= mb_res_thr) break;
     }
     for (int i = 0; i < n; ++i) {
         s->qd[i] = v[i] + dv[i];
@@ -768,8 +780,10 @@ void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, d
         lim[n + x] = c->max_impulse;
     }
     double lam[NR] = {0}, dv[NU] = {0};
+    mb_last_sweeps = 0;
     for (int it = 0; it < iters; ++it) {
         double residual = 0.0;
+        mb_last_sweeps = it + 1;
         for (int jj = 0; jj < nr; ++jj) {
             int r = (it & 1) ? jj : nr - 1 - jj;
             if (lim[r] == 0.0) continue;
@@ -782,9 +796,9 @@ void mb_step_body(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, d
             else if (sum > lim[r]) { delta = lim[r] - lam[r]; lam[r] = lim[r]; }
             else lam[r] = sum;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
-            if (delta * delta > residual) residual = delta * delta;
+            MB_RESIDUAL(delta / jdi);
         }
-        if (residual <= 0.0) break;
+        if (residual <= mb_res_thr) break;
     }
     /* ---- integrate */
     for (int i = 0; i < n; ++i) { s->qd[i] = v[i] + dv[i]; s->q[i] += dt * s->qd[i]; s->applied_torque[i] = 0.0; }
@@ -937,8 +951,10 @@ void mb_step_body_ball(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p*
         else rhs[r] = -rv;
     }
     memset(lam, 0, sizeof lam); memset(dv, 0, sizeof dv);
+    mb_last_sweeps = 0;
     for (int it = 0; it < iters; ++it) {
         double residual = 0.0;
+        mb_last_sweeps = it + 1;
         for (int jj = 0; jj < nr0; ++jj) {                           /* motors and P2P rows: reversed on even sweeps (mb_step_body) */
             int r = (it & 1) ? jj : nr0 - 1 - jj;
             if (lim[r] == 0.0) continue;
@@ -950,7 +966,7 @@ void mb_step_body_ball(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p*
             else if (sum > lim[r]) { delta = lim[r] - lam[r]; lam[r] = lim[r]; }
             else lam[r] = sum;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
-            if (delta * delta > residual) residual = delta * delta;
+            MB_RESIDUAL(delta / jdi);
         }
         if (touching) {
             int r = nr0, r1 = nr0 + 1, r2 = nr0 + 2;
@@ -959,7 +975,7 @@ void mb_step_body_ball(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p*
             double delta = rhs[r] * jdi - jdv * jdi, sum = lam[r] + delta;
             if (sum < 0.0) { delta = -lam[r]; lam[r] = 0.0; } else lam[r] = sum;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
-            if (delta * delta > residual) residual = delta * delta;
+            MB_RESIDUAL(delta / jdi);
             double limit = ball->mu * lam[r], jdv1 = 0, jdv2 = 0;
             for (int u = 0; u < nu; ++u) { jdv1 += J[r1][u] * dv[u]; jdv2 += J[r2][u] * dv[u]; }
             double d1 = (rhs[r1] - jdv1) / A[r1], d2 = (rhs[r2] - jdv2) / A[r2];
@@ -967,10 +983,10 @@ void mb_step_body_ball(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p*
             if (tot > limit) { double f = tot > 0 ? limit / tot : 0.0; s1 *= f; s2 *= f; }          /* cone friction (enableConeFriction = 1) */
             d1 = s1 - lam[r1]; d2 = s2 - lam[r2]; lam[r1] = s1; lam[r2] = s2;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r1] * d1 + W[u][r2] * d2;
-            if (d1 * d1 > residual) residual = d1 * d1;
-            if (d2 * d2 > residual) residual = d2 * d2;
+            if (mb_res_thr > 0.0) MB_RESIDUAL(d1 * A[r1] + d2 * A[r2]);                              /* one residual per cone pair [A7c] */
+            else { MB_RESIDUAL(d1); MB_RESIDUAL(d2); }                                               /* threshold 0: any change at all keeps the loop going */
         }
-        if (residual <= 0.0) break;
+        if (residual <= mb_res_thr) break;
     }
     if (touching) ball->normal_impulse = lam[nr0];
     /* ---- integrate */
@@ -1239,9 +1255,10 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
     }
     memset(lam, 0, sizeof lam); memset(dv, 0, sizeof dv);
     sc->sweeps_used = 0;
+    const double res_thr = sc->residual_threshold > mb_res_thr ? sc->residual_threshold : mb_res_thr;
     for (int it = 0; it < iters; ++it) {
-        double residual = 0.0;                                        /* largest squared impulse change of the sweep */
-        sc->sweeps_used = it + 1;
+        double residual = 0.0;                                        /* largest squared velocity change of a row update in this sweep */
+        sc->sweeps_used = mb_last_sweeps = it + 1;
         for (int jj = 0; jj < n; ++jj) {                              /* joint motors: reversed on even sweeps */
             int r = (it & 1) ? jj : n - 1 - jj;
             if (s->motor_mode[r] == MB_MOTOR_OFF) continue;
@@ -1249,7 +1266,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             double delta = rhs[r] * jdi - dv[r] * jdi, sum = lam[r] + delta;
             if (sum < -lim) { delta = -lim - lam[r]; lam[r] = -lim; } else if (sum > lim) { delta = lim - lam[r]; lam[r] = lim; } else lam[r] = sum;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
-            if (delta * delta > residual) residual = delta * delta;
+            MB_RESIDUAL(delta / jdi);
         }
         for (int c = 0; c < nc; ++c) {                                /* contact normals */
             int r = n + 3 * c;
@@ -1258,7 +1275,7 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             double delta = rhs[r] * jdi - lam[r] * (cfm[r] * jdi) - jdv * jdi, sum = lam[r] + delta;
             if (sum < 0.0) { delta = -lam[r]; lam[r] = 0.0; } else lam[r] = sum;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
-            if (delta * delta > residual) residual = delta * delta;
+            MB_RESIDUAL(delta / jdi);
         }
         for (int c = 0; c < nc; ++c) {                                /* friction */
             int r1 = n + 3 * c + 1, r2 = r1 + 1;
@@ -1276,10 +1293,11 @@ void mb_step_push(const mb_model* m, mb_state* s, mb_body* b, mb_push_scene* sc,
             }
             d1 = s1 - lam[r1]; d2 = s2 - lam[r2]; lam[r1] = s1; lam[r2] = s2;
             for (int u = 0; u < nu; ++u) dv[u] += W[u][r1] * d1 + W[u][r2] * d2;
-            if (d1 * d1 > residual) residual = d1 * d1;
-            if (d2 * d2 > residual) residual = d2 * d2;
+            if (res_thr <= 0.0) { MB_RESIDUAL(d1); MB_RESIDUAL(d2); }                               /* threshold 0: any change at all keeps the loop going */
+            else if (sc->cone_friction) MB_RESIDUAL(d1 * A[r1] + d2 * A[r2]);                       /* one residual per cone pair [A7c] */
+            else { MB_RESIDUAL(d1 * A[r1]); MB_RESIDUAL(d2 * A[r2]); }
         }
-        if (residual <= sc->residual_threshold) break;                /* leastSquaresResidualThreshold [A7b]; 0 = exact fixed point */
+        if (residual <= res_thr) break;                               /* leastSquaresResidualThreshold [A7b]; 0 = exact fixed point */
     }
     for (int c = 0; c < nc; ++c) if (ct[c].arm_a) sc->tip_impulse += lam[n + 3 * c];   /* the tip's normal impulse (summed over its manifold points) */
     /* ---- integrate */

@@ -228,7 +228,12 @@ void mb_manifold_add(mb_manifold* m, double breaking, const double* oa, const do
                      const double* pa_w, const double* pb_w, const double* n_w, double depth);
 void mb_manifold_refresh(mb_manifold* m, double breaking, const double* oa, const double* Ra, const double* ob, const double* Rb);
 
-extern int mb_last_sweeps;   /* PGS sweeps executed by the last mb_step */
+extern int mb_last_sweeps;   /* PGS sweeps executed by the last mb_step / mb_step_body / mb_step_body_ball / mb_step_push */
+/* btContactSolverInfo::m_leastSquaresResidualThreshold for every mb_step* (PARITY_ASSUMPTIONS A7b, A7c): the solver loop leaves after the
+ * sweep whose largest squared row velocity change (deltaImpulse / jacDiagABInv; a cone-friction pair counts once, with the sum of its two)
+ * is <= t, never before the first sweep, at the latest after `solver_iterations`.  0 (default): only at an exact fixed point. */
+void mb_set_solver_residual_threshold(double t);
+double mb_get_solver_residual_threshold(void);
 void mb_step_push(const mb_model* m, mb_state* s, mb_body* cube, mb_push_scene* sc, double dt, int solver_iterations);
 
 #ifdef __cplusplus

@@ -98,6 +98,8 @@ def lib():
         _lib.mb_mass_matrix.argtypes = [mp, dp, dp]
         _lib.mb_jacobian.argtypes = [mp, dp, C.c_int, dp, dp]
         _lib.mb_step.argtypes = [mp, sp, C.c_double, C.c_int]
+        _lib.mb_set_solver_residual_threshold.argtypes = [C.c_double]
+        _lib.mb_get_solver_residual_threshold.restype = C.c_double
         _lib.mb_step_body.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.c_double, C.c_int]
         _lib.mb_step_push.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBPushScene), C.c_double, C.c_int]
         _lib.mb_step_body_ball.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.POINTER(MBBall), C.c_double, C.c_int]
@@ -114,6 +116,20 @@ def lib():
                                          C.POINTER(C.c_uint64), u8p]
         _lib.mb_blend_spheres.argtypes = [fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64), u8p]
     return _lib
+
+
+def set_solver_residual_threshold(t):
+    """btContactSolverInfo::m_leastSquaresResidualThreshold for every mb_step* of this process (PARITY A7b; 0 = exact fixed point)."""
+    lib().mb_set_solver_residual_threshold(float(t))
+
+
+def solver_residual_threshold():
+    return float(lib().mb_get_solver_residual_threshold())
+
+
+def last_sweeps():
+    """PGS sweeps the last mb_step / mb_step_body / mb_step_body_ball / mb_step_push executed."""
+    return int(C.c_int.in_dll(lib(), "mb_last_sweeps").value)
 
 
 def _dp(a):

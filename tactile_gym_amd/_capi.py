@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -106,6 +106,7 @@ class TgConfig(C.Structure):
         ("contact_mapping", C.c_int32), ("reset_bank", C.c_int32), ("narrowphase", C.c_int32),
         ("balance_object", C.c_int32), ("ball_radius", C.c_double), ("ball_mass", C.c_double), ("ball_mu", C.c_double), ("plate_radius", C.c_double),
         ("fused_step", C.c_int32),
+        ("solver_residual_threshold", C.c_double),
     ]
 
 
@@ -123,6 +124,7 @@ class TgStateView(C.Structure):
         ("contact_count", C.POINTER(C.c_int32)), ("contact_ids", C.POINTER(C.c_int32)),
         ("ball_pos", C.POINTER(C.c_double)), ("ball_linvel", C.POINTER(C.c_double)), ("ball_angvel", C.POINTER(C.c_double)),
         ("ball_impulse", C.POINTER(C.c_double)),
+        ("solver_sweeps", C.POINTER(C.c_int32)),
     ]
 
 

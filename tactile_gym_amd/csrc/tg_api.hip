@@ -191,6 +191,7 @@ template <typename T> static int build_dev_robot(const tg_robot& r, DevRobot<T>&
         d.trace_bound = (T)tb;
         d.diag_sqrt_max = (T)(std::sqrt(dmax) * 1.0000001);
     }
+    d.res_thr = (T)0;   // tg_config.solver_residual_threshold: set by tg_create; the function-level entry points run the default solver
     return 0;
 }
 
@@ -1013,6 +1014,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     if (cfg->physics_dtype == TG_PHYSICS_F64) {
         DevRobot<double> dr; EnvConst<double> ec;
         build_dev_robot(*robot, dr);
+        dr.res_thr = cfg->solver_residual_threshold > 0.0 ? cfg->solver_residual_threshold : 0.0;
         if (int rc = build_env_const(*cfg, *sensor, *robot, ec)) { delete c; return rc; }
         c->act_dim = ec.act_dim;
         TG_HIP(hipMalloc(&c->d_robot, sizeof dr)); TG_HIP(hipMemcpy(c->d_robot, &dr, sizeof dr, hipMemcpyHostToDevice));
@@ -1020,6 +1022,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     } else {
         DevRobot<float> dr; EnvConst<float> ec;
         build_dev_robot(*robot, dr);
+        dr.res_thr = cfg->solver_residual_threshold > 0.0 ? (float)cfg->solver_residual_threshold : 0.0f;
         if (int rc = build_env_const(*cfg, *sensor, *robot, ec)) { delete c; return rc; }
         c->act_dim = ec.act_dim;
         TG_HIP(hipMalloc(&c->d_robot, sizeof dr)); TG_HIP(hipMemcpy(c->d_robot, &dr, sizeof dr, hipMemcpyHostToDevice));
@@ -1040,6 +1043,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     TG_HIP(hipMemset(s.edge_ang, 0, n * 8)); TG_HIP(hipMemset(s.embed, 0, n * 8));
     TG_HIP(hipMemset(s.stim_xform, 0, 12 * n * 4)); TG_HIP(hipMemset(s.term_xform, 0, 12 * n * 4));
     TG_HIP(hipMemset(s.step_count, 0, n * 4)); TG_HIP(hipMemset(s.reset_ticks, 0, n * 4)); TG_HIP(hipMemset(s.licence, 0, n * 4));
+    TG_HIP(hipMalloc(&s.sweeps, n * 4)); TG_HIP(hipMemset(s.sweeps, 0, n * 4));
     std::vector<uint64_t> seeds(n);
     for (int i = 0; i < n; ++i) seeds[i] = mix64((uint64_t)i + kGolden);
     TG_HIP(hipMemcpy(s.rng, seeds.data(), n * 8, hipMemcpyHostToDevice));
@@ -1081,6 +1085,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         {   // the arm's post-reset state, computed once (k_reset_body); off with reset_bank = TG_BANK_OFF / TG_RESET_BANK=0
             bool tmpl = cfg->reset_bank != TG_BANK_OFF;
             if (const char* e = getenv("TG_RESET_BANK")) tmpl = e[0] != '0';
+            if (cfg->solver_residual_threshold > 0.0) tmpl = false;   // threshold mode: the reset tick's truncated solve sees the fallen object (1e-6 rad): every reset is recomputed
             if (tmpl) { TG_HIP(hipMalloc(&s.reset_tmpl, (2 * TG_MAX_DOF + 2) * 8)); TG_HIP(hipMemset(s.reset_tmpl, 0, (2 * TG_MAX_DOF + 2) * 8)); }
         }
         if (cfg->balance_object == TG_BALANCE_BALL_ON_PLATE) {   // load_ball (:241-260): at workframe + (0, 0, radius), at rest
@@ -1333,7 +1338,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->d_kt_acc) (void)hipFree(c->d_kt_acc);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.sweeps, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -2012,6 +2017,7 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
     if (v->step_count && (rc = fetch_soa(c, c->st.step_count, 1, v->step_count))) return rc;
     if (v->reset_ticks && (rc = fetch_soa(c, c->st.reset_ticks, 1, v->reset_ticks))) return rc;
     if (v->rng_state && (rc = fetch_soa(c, c->st.rng, 1, v->rng_state))) return rc;
+    if (v->solver_sweeps && (rc = fetch_soa(c, c->st.sweeps, 1, v->solver_sweeps))) return rc;
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
         if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
         if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;

@@ -420,7 +420,7 @@ __device__ __forceinline__ void tick_dynamics(const DevRobot<T>* __restrict__ mp
 // One stepSimulation() tick on the LDS-resident env state.  Returns the tick's contact code (tg_state_view.contact_ids).
 template <typename T, int TOPO, int MOTOR, int SHAPE, bool CONE, int NT = 1>
 __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const PushScene<T>& sc, lds_ptr<T> L, T kp, T kd, T max_force, T dt, int iters,
-                                                     T mass, int lane_in, int xbase = 0) {
+                                                     T mass, int lane_in, int xbase = 0, int* sweep_acc = nullptr /* threshold mode: += the sweeps this tick ran */) {
     constexpr int N = Topo<TOPO>::N;
     constexpr int NP = Topo<TOPO>::NP;
     // NT = 1: one tip contact per tick from the closed forms (the default).  NT = 4 (object_push, f64): up to four tip contacts from the
@@ -756,6 +756,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         active = motor_lane ? (MOTOR != kMotorOff) : (tip_lane ? tip_active : (table_lane && cc < n_table));
     }
     const T jdi = active ? T(1) / (A + cfm) : T(0);
+    const T adiag = active ? A + cfm : T(0);       // 1 / jacDiagABInv of this lane's row (threshold mode: a row's velocity change = delta * adiag)
     TG_STAMP(3)
     // ---- coefficient row of this lane, one entry per solver row i (motor i -> i, contact (c, r) -> 8 + 3c + r):
     //   row lanes        G[i] = (J_i . W_mine) / (A + cfm); own entry 1 on a motor / normal lane (it carries the residual r, which its
@@ -917,12 +918,14 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
             lam = lane == (I) ? lam + dd_ : lam;                                       \
         } else dd_ = bcast(x, (I));                                                    \
         x = __builtin_fma(-G[(I)], dd_, x);                                            \
+        if (THRM) { const T dvel_ = dd_ * Ad[(I)]; res_ = vmax(res_, dvel_ * dvel_); } \
     }
 #define TG_NORMAL_STEP(ROW_LANE, GI)                                                   \
     {                                                                                  \
         const T dd_ = bcast(vmax_neg(x, lam), (ROW_LANE));                             \
         x = __builtin_fma(-G[(GI)], dd_, x);                                           \
         lam = __builtin_fma(HN[((GI) - 8) / 3], dd_, lam);                             \
+        if (THRM) { const T dvel_ = dd_ * Ad[(GI)]; res_ = vmax(res_, dvel_ * dvel_); } \
     }
 #define TG_FRICTION_STEP(NLANE, GI, MU)                                                \
     {                                                                                  \
@@ -948,6 +951,11 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         const T d1_ = bcast(dl_, (NLANE) + 1), d2_ = bcast(dl_, (NLANE) + 2);          \
         x = __builtin_fma(-G[(GI)], d1_, x);                                           \
         x = __builtin_fma(-G[(GI) + 1], d2_, x);                                       \
+        if (THRM) {   /* a cone pair counts once, with the sum of its two velocity changes (resolveConeFrictionConstraintRows, PARITY A7c) */ \
+            const T v1_ = d1_ * Ad[(GI)], v2_ = d2_ * Ad[(GI) + 1];                    \
+            if (CONE) { const T dvel_ = v1_ + v2_; res_ = vmax(res_, dvel_ * dvel_); } \
+            else res_ = vmax(res_, vmax(v1_ * v1_, v2_ * v2_));                        \
+        }                                                                              \
     }
     // one sweep: motors in forward (FWD) or reverse order with the table normals between them, tip normal, friction pairs
 #define TG_SWEEP(FWD)                                                                  \
@@ -987,6 +995,26 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         if (it_ < n_it) TG_SWEEP(false)                                                \
     }
     T wmax = T(0);
+    T res_ = T(0);
+    if (uniform_true(m.res_thr > T(0))) {
+        // Threshold mode (tg_config.solver_residual_threshold, PARITY A7b): the literal clamped row steps, and after EVERY sweep Bullet's exit -
+        // the largest squared velocity change delta / jacDiagABInv of the sweep's row updates <= the threshold (oracle mb_step_push).  Every
+        // delta is wave-uniform after its broadcast; the rows' 1 / jacDiagABInv are fetched once from their lanes.
+        constexpr int CLAMPED = 1, THRM = 1;
+        T Ad[NGT];
+#pragma unroll
+        for (int i = 0; i < NGT; ++i) Ad[i] = bcast(adiag, i < 8 ? i : kContactLane0 + 4 * ((i - 8) / 3) + (i - 8) % 3);
+        int ran_ = 0;
+        for (int it_ = 0; it_ < n_it; ++it_) {
+            res_ = T(0);
+            if (it_ & 1) { TG_SWEEP(true) } else { TG_SWEEP(false) }
+            ++ran_;
+            if (uniform_true(res_ <= m.res_thr)) break;
+        }
+        if (sweep_acc != nullptr) *sweep_acc += ran_;
+    } else {
+    constexpr int THRM = 0;
+    const T* Ad = nullptr;
     {
         constexpr int CLAMPED = 0;
         TG_SOLVE()
@@ -996,6 +1024,8 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         constexpr int CLAMPED = 1;
         x = x0; lam = T(0); lamF = T(0);
         TG_SOLVE()
+    }
+    (void)Ad;
     }
 #undef TG_SOLVE
 #undef TG_SWEEP
@@ -1129,7 +1159,7 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
         for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = POS ? 0.0 : (double)qd_des[i];
     }
     TG_PHASE_FENCE()
-    int ccode = 0;
+    int ccode = 0, sweeps = 0;
     if constexpr (POS) {                                  // blocking_move(max_steps, constant_vel=None), robot.py:188-260
         for (int t = 0; t < c.max_blocking; ++t) {
             T q[N], qd[N];
@@ -1137,13 +1167,13 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
             for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
             const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
             ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE, NT>(m, c.push, L, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters,
-                                                                                    mass_or_radius, lane, xbase);
+                                                                                    mass_or_radius, lane, xbase, &sweeps);
             if (uniform_true(stop)) break;
         }
     } else {
         for (int t = 0; t < c.action_repeat; ++t)
             ccode = sim_tick_contact_wave<T, TOPO, kMotorVelocity, SHAPE, CONE, NT>(m, c.push, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters,
-                                                                                    mass_or_radius, lane, xbase);
+                                                                                    mass_or_radius, lane, xbase, &sweeps);
     }
     if constexpr (NT == 4) {
         if (lane < 37) st.mani[(size_t)lane * n + env] = (double)L[xbase + kXMani + (lane < 36 ? lane : narrow::kMcount)];
@@ -1160,6 +1190,7 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
     b.w = mk(L[kLBody + 15], L[kLBody + 16], L[kLBody + 17]);
     st.step_count[env] = step_count;
     st.contact_code[env] = ccode;
+    if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
     store_body<T>(st, n, env, b);
@@ -1179,7 +1210,8 @@ __global__ __launch_bounds__(64) void k_step_contact_wave(const DevRobot<T>* __r
 // budget, 0: not).  State in / out through LDS like sim_tick_contact_wave.
 template <typename T, int TOPO, int MOTOR>
 __device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const BodyConst<T>& bc, lds_ptr<T> L, T kp, T kd, T max_force, T dt, int iters,
-                                                 V3<T> gravity, V3<T> pivot_b, V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int lane_in) {
+                                                 V3<T> gravity, V3<T> pivot_b, V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int lane_in,
+                                                 int* sweep_acc = nullptr /* threshold mode: += the sweeps this tick ran */) {
     constexpr int N = Topo<TOPO>::N;
     constexpr int NP = Topo<TOPO>::NP;
     constexpr int NR = N + 3;
@@ -1278,8 +1310,9 @@ __device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const Bod
         }
     }
     // ---- one Gauss-Seidel pass over the NR rows as a linear map of the row lanes' residuals, forward and reverse order
+    const bool thr_mode = uniform_true(m.res_thr > T(0));    // tg_config.solver_residual_threshold: the literal row-by-row iteration below, no maps
     T Cf[NR], Cr[NR];
-    {
+    if (!thr_mode) {
         __syncthreads();
         if (my_row >= 0) {
 #pragma unroll
@@ -1329,6 +1362,31 @@ __device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const Bod
     auto row_lane = [](int i) { return i < N ? i : 8 + (i - N); };
     T x = x0, wmax = T(0);
     int conv_sweeps = -1;
+    if (thr_mode) {
+        // Threshold mode: Bullet's exit after every sweep (oracle mb_step_body).  The literal clamped row step; its delta `dd` is wave-uniform,
+        // the row's velocity change is dd / jacDiagABInv = dd A_ii with the diagonals fetched once from the row lanes.
+        T Ad[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) Ad[i] = bcast(A, row_lane(i));
+        T lam = T(0);
+        const T limr = p2p_lane ? bc.max_impulse : max_force * dt;
+        int ran = 0;
+        for (int it = 0; it < n_it; ++it) {
+            T res = T(0);
+#pragma unroll
+            for (int kk = 0; kk < NR; ++kk) {
+                const int i = (it & 1) ? kk : NR - 1 - kk;
+                const T dd = bcast(vmin(vmax(x, -limr - lam), limr - lam), row_lane(i));
+                lam = my_row == i ? lam + dd : lam;
+                x = __builtin_fma(-G[i], dd, x);
+                const T dvel = dd * Ad[i];
+                res = tmax(res, dvel * dvel);
+            }
+            ++ran;
+            if (uniform_true(res <= m.res_thr)) break;
+        }
+        if (sweep_acc != nullptr) *sweep_acc += ran;
+    } else
     for (int it = 0; it < n_it; ++it) {
         if ((it & 7) == 0 && it > 0) {                    // the exit of sim_tick_body: every residual below 2^-56 of the largest start value
             T mx = my_row >= 0 ? tabs(x) : T(0);
@@ -1350,7 +1408,7 @@ __device__ __forceinline__ int sim_tick_p2p_wave(const DevRobot<T>& m, const Bod
         x -= da + db;
         wmax = vmax_abs(wmax, x);
     }
-    if (uniform_true(watch_lane && wmax > lim)) {
+    if (!thr_mode && uniform_true(watch_lane && wmax > lim)) {
         // an impulse reached its bound: the literal clamped iteration, row by row (never seen with the reference's limits; kept for safety)
         x = x0;
         T lam = T(0);
@@ -1469,7 +1527,7 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
-    int verified = lic > 0 ? 24 : 0;
+    int verified = lic > 0 ? 24 : 0, sweeps = 0;
     bool ran_full = false;
     // The frames finish_body_frames wants (TCP, sensor link) at the step's last q: lane k of a licensed walk evaluates the kinematics at
     // q + k dt des anyway, so when the walk ends the step its lane `adv` holds them (the same additions in the same order as q's own) and
@@ -1562,7 +1620,7 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
             }
             TG_PHASE_FENCE()
             verified = sim_tick_p2p_wave<T, TOPO, kMotorVelocity>(m, c.body, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, pivot_b, fext, pext,
-                                                                  pending && t == 0, lane);
+                                                                  pending && t == 0, lane, &sweeps);
             ran_full = true;
 #pragma unroll
             for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
@@ -1577,6 +1635,7 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
     if (w0) {
         st.step_count[env] = step_count;
         st.licence[env] = ran_full ? (verified > 0 ? 8 : 0) : lic - 1;
+        if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
         st.ext_pending[env] = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = (double)qd_des[i]; }
@@ -1632,7 +1691,8 @@ __global__ __launch_bounds__(64) void k_step_body_wave(const DevRobot<T>* __rest
 // wave64 instruction costs its 4 issue cycles whether 6 or 64 lanes do useful work, so a sweep is ~190 cycles for one env here and 144 for
 // 64 envs there, and 1024 mostly idle wavefronts on 1024 SIMDs are no faster than 16 full ones.  Selected by TG_CONTACT_MAP_WAVE only.
 template <typename T, int TOPO, int MOTOR>
-__device__ __forceinline__ int sim_tick_arm_wave(const DevRobot<T>& m, lds_ptr<T> L, T kp, T kd, T max_force, T dt, int iters, int lane_in) {
+__device__ __forceinline__ int sim_tick_arm_wave(const DevRobot<T>& m, lds_ptr<T> L, T kp, T kd, T max_force, T dt, int iters, int lane_in,
+                                                 int* sweep_acc = nullptr /* threshold mode: += the sweeps this tick ran */) {
     constexpr int N = Topo<TOPO>::N;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
@@ -1725,6 +1785,29 @@ __device__ __forceinline__ int sim_tick_arm_wave(const DevRobot<T>& m, lds_ptr<T
     const bool watch_lane = lane >= 48 && lane < 48 + N;
     T x = x0, wmax = T(0);
     int conv_sweeps = -1;
+    const bool thr_mode = uniform_true(m.res_thr > T(0));
+    if (thr_mode) {                                       // threshold mode: Bullet's exit after every sweep (oracle mb_step), see sim_tick_p2p_wave
+        T Ad[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) Ad[i] = bcast(A, i);
+        T lam = T(0);
+        int ran = 0;
+        for (int it = 0; it < n_it; ++it) {
+            T res = T(0);
+#pragma unroll
+            for (int kk = 0; kk < N; ++kk) {
+                const int i = (it & 1) ? kk : N - 1 - kk;
+                const T dd = bcast(vmin(vmax(x, -lim - lam), lim - lam), i);
+                lam = lane == i ? lam + dd : lam;
+                x = __builtin_fma(-G[i], dd, x);
+                const T dvel = dd * Ad[i];
+                res = tmax(res, dvel * dvel);
+            }
+            ++ran;
+            if (uniform_true(res <= m.res_thr)) break;
+        }
+        if (sweep_acc != nullptr) *sweep_acc += ran;
+    } else
     for (int it = 0; it < n_it; ++it) {
         if ((it & 7) == 0 && it > 0) {
             T mx = motor_lane ? tabs(x) : T(0);
@@ -1746,7 +1829,7 @@ __device__ __forceinline__ int sim_tick_arm_wave(const DevRobot<T>& m, lds_ptr<T
         x -= da + db;
         wmax = vmax_abs(wmax, x);
     }
-    if (uniform_true(watch_lane && wmax > lim)) {
+    if (!thr_mode && uniform_true(watch_lane && wmax > lim)) {
         // a motor impulse reached its bound: the literal clamped iteration, row by row
         x = x0;
         T lam = T(0);
@@ -1822,14 +1905,15 @@ __global__ __launch_bounds__(64) void k_step_arm_wave(const DevRobot<T>* __restr
         }
     }
     TG_PHASE_FENCE()
-    int verified = 0;
+    int verified = 0, sweeps = 0;
     for (int t = 0; t < c.action_repeat; ++t)
-        verified = sim_tick_arm_wave<T, TOPO, kMotorVelocity>(m, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, lane);
+        verified = sim_tick_arm_wave<T, TOPO, kMotorVelocity>(m, L, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, lane, &sweeps);
 #pragma unroll
     for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; trig.s[i] = L[kLTrigS + i]; trig.c[i] = L[kLTrigC + i]; }
     if (w0) {
         st.step_count[env] = step_count;
         st.licence[env] = 0;                       // this kernel solves every tick in full: nothing is carried over for k_step's shortcut
+        if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = (double)qd_des[i];

@@ -85,6 +85,7 @@ struct State {   // device pointers, SoA [field][num_envs]
     unsigned long long* draw;       // tg_step_random on the lane-mapped k_step: {draw counter, seed, ticket}; the kernel draws its own actions (nullptr: reads `actions`)
     float* act_out;                 // ... and leaves them here ([n][act_dim])
     unsigned long long* kt;         // profiling mode: per-wavefront {start, end} wall-clock slots (tg_kt.hpp); null otherwise
+    int32_t* sweeps;                // [n] threshold mode (tg_config.solver_residual_threshold > 0): PGS sweeps the ticks of the env's last step ran (tg_state_view.solver_sweeps)
     double* mani;                   // [37][n] object_push with tg_config.narrowphase != 0: the tip - cube contact manifold (la, lb, normal of 4 points; count)
 #ifdef TG_TL_STAMPS
     unsigned long long* tl;         // development: [4][8192] launch-start stamps (wall clock) + [4] counters behind them
@@ -660,10 +661,11 @@ __device__ __forceinline__ bool step_env(const DevRobot<T>& m, const EnvConst<T>
     // is a smooth function of the configuration and the margin is a factor > 2 in sweeps); a reset drops it.  Wave-uniform.
     int verified = __all(lic > 0) ? 24 : 0;
     bool ran_full = false;
+    int sweeps = 0;
     for (int t = 0; t < c.action_repeat; ++t) {
         const int before = verified;
         sim_tick<T, TOPO, kMotorVelocity, true, true>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, &trig,
-                                                      &verified);
+                                                      &verified, &sweeps);
         const bool analytic = before > 0 && verified == before - 1;   // the analytic path decrements; a full solve sets 24 or -1
         if (t == 0) TG_KSTAMP(7)
         if (!analytic) ran_full = true;
@@ -696,6 +698,7 @@ __device__ __forceinline__ bool step_env(const DevRobot<T>& m, const EnvConst<T>
         }
     }
     st.licence[env] = ran_full ? (verified > 0 ? 8 : 0) : lic - 1;
+    if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
     TG_KSTAMP(3)
 
 #pragma unroll
@@ -1313,7 +1316,7 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
-    int verified = 0;
+    int verified = 0, sweeps = 0;
     if constexpr (BALL) {                                 // ball_on_plate: the plate + ball tick (no plate force; the pending one-shot is the ball's torque)
         Ball<T> ball = load_ball<T>(st, n, env);
         const V3<T> btq = mk((T)st.ball[9 * n + env], (T)st.ball[10 * n + env], (T)st.ball[11 * n + env]);
@@ -1322,20 +1325,20 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
             for (int t = 0; t < c.max_blocking; ++t) {
                 const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
                 sim_tick_body_ball<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, grav,
-                                                            b, c.body, pivot_b, ball, c.ball, btq, pending && t == 0, imp);
+                                                            b, c.body, pivot_b, ball, c.ball, btq, pending && t == 0, imp, &sweeps);
                 if (stop) break;
             }
         } else {
             for (int t = 0; t < c.action_repeat; ++t)
                 sim_tick_body_ball<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b,
-                                                            c.body, pivot_b, ball, c.ball, btq, pending && t == 0, imp);
+                                                            c.body, pivot_b, ball, c.ball, btq, pending && t == 0, imp, &sweeps);
         }
         store_ball<T>(st, n, env, ball, imp);
     } else if constexpr (POS) {                           // blocking_move(max_steps, constant_vel=None), robot.py:188-260
         for (int t = 0; t < c.max_blocking; ++t) {
             const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
             sim_tick_body<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b,
-                                                   c.body, pivot_b, fext, pext, pending && t == 0, &verified);
+                                                   c.body, pivot_b, fext, pext, pending && t == 0, &verified, nullptr, &sweeps);
             if (stop) break;
         }
     } else {
@@ -1343,8 +1346,9 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
         trig_init<T, N>(q, trig);
         for (int t = 0; t < c.action_repeat; ++t)
             sim_tick_body<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, grav, b, c.body,
-                                                   pivot_b, fext, pext, pending && t == 0, &verified, &trig);
+                                                   pivot_b, fext, pext, pending && t == 0, &verified, &trig, &sweeps);
     }
+    if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
     st.ext_pending[env] = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
@@ -1631,7 +1635,7 @@ __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict_
         for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
     }
     const T mass = (T)st.obj_mass[env];
-    int ccode = 0;
+    int ccode = 0, sweeps = 0;
     T qdummy[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) qdummy[i] = T(0);
@@ -1639,14 +1643,15 @@ __global__ __launch_bounds__(64) void k_step_push(const DevRobot<T>* __restrict_
         for (int t = 0; t < c.max_blocking; ++t) {
             const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
             sim_tick_push<T, TOPO, kMotorPosition>(m, q, qd, qd_des, qdummy, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
-                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x, ccode);
+                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x, ccode, &sweeps);
             if (stop) break;
         }
     } else {
         for (int t = 0; t < c.action_repeat; ++t)
             sim_tick_push<T, TOPO, kMotorVelocity>(m, q, qd, qdummy, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
-                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x, ccode);
+                                                   (const T*)st.tip_verts, mass, lds + threadIdx.x, ccode, &sweeps);
     }
+    if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
     st.contact_code[env] = ccode;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
@@ -1831,7 +1836,7 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
     const int step_count = st.step_count[env] + 1;
     st.step_count[env] = step_count;
     const T radius = (T)st.obj_mass[env];                                  // the episode's radius
-    int ccode = 0;
+    int ccode = 0, sweeps = 0;
     const T work_dz = (T)((2.0 * st.obj_mass[env] - st.embed[env]) - (double)c.work_pos[2]);   // update_workframe (:192-201)
     T qd_des[N], zero[N];
 #pragma unroll
@@ -1844,7 +1849,7 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
         for (int t = 0; t < c.max_blocking; ++t) {        // blocking_move(max_steps, constant_vel=None), robot.py:188-260
             const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
             sim_tick_push<T, TOPO, kMotorPosition, 1>(m, q, qd, qd_des, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push,
-                                                      nullptr, radius, lds + threadIdx.x, ccode);
+                                                      nullptr, radius, lds + threadIdx.x, ccode, &sweeps);
             if (stop) break;
         }
     } else {
@@ -1853,8 +1858,9 @@ __global__ __launch_bounds__(64) void k_step_roll(const DevRobot<T>* __restrict_
         for (int i = 0; i < N; ++i) st.qd_target[i * n + env] = (double)qd_des[i];
         for (int t = 0; t < c.action_repeat; ++t)
             sim_tick_push<T, TOPO, kMotorVelocity, 1>(m, q, qd, zero, qd_des, T(0), m.vel_gain, m.max_force, c.dt, c.solver_iters, b, c.push, nullptr,
-                                                      radius, lds + threadIdx.x, ccode);
+                                                      radius, lds + threadIdx.x, ccode, &sweeps);
     }
+    if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
     st.contact_code[env] = ccode;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }

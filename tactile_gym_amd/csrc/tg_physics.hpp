@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace tg {
 
 constexpr int kMaxDof = 8;
@@ -61,6 +63,12 @@ template <typename T> struct DevRobot {
     T rest_q[kMaxDof];
     T trace_bound;   // >= trace(M(q)) for every q (host, build_dev_robot)
     T diag_sqrt[kMaxDof], diag_sqrt_max;   // sqrt of per-joint bounds d_i >= M_ii(q) for every q, and their maximum
+    // tg_config.solver_residual_threshold (btContactSolverInfo::m_leastSquaresResidualThreshold, PARITY_ASSUMPTIONS A7b / A7c).  0: the solver
+    // loops exit at last-bit convergence only and the licensed analytic fixed point may stand in for a converged solve (every kernel's default
+    // path).  > 0 ("threshold mode"): every tick is a full tick and its Gauss-Seidel loop leaves after the sweep whose largest squared row
+    // velocity change deltaImpulse / jacDiagABInv (a cone-friction pair counts once, with the sum of its two) is <= this - Bullet's rule,
+    // evaluated per env, sweep by sweep, in the oracle's order; no licence, no composed sweeps.  Lives here because every sim_tick* takes `m`.
+    T res_thr;
 };
 
 // ------------------------------------------------------------------------------------------------ small vector algebra
@@ -578,6 +586,49 @@ __device__ __forceinline__ void pgs_clamped(const T (&Minv)[N][N], const T (&rim
     if (it < iters) pgs_sweep_clamped<T, N, false>(Minv, rimp, jdi, maximp, lam, dv);
 }
 
+// Threshold mode (DevRobot::res_thr > 0): the literal clamped sweep with Bullet's residual and a per-lane `live` flag - an env whose sweep met the
+// threshold keeps its impulses while its 63 neighbours go on (Bullet leaves the loop per world; a lane is a world).  Returns the sweep's
+// residual: the largest squared velocity change delta / jacDiagABInv = delta * Minv_ii of a row update (oracle/minibullet.c: mb_step).
+template <typename T, int N, bool FWD>
+__device__ __forceinline__ T pgs_sweep_residual(const T (&Minv)[N][N], const T (&rimp)[N], const T (&jdi)[N], T maximp, bool live, T (&lam)[N],
+                                                T (&dv)[N]) {
+    T res = T(0);
+#pragma unroll
+    for (int jj = 0; jj < N; ++jj) {
+        const int i = FWD ? jj : N - 1 - jj;
+        const T t = rimp[i] - dv[i] * jdi[i];
+        const T sum = lam[i] + t;
+        const T lo = sum < -maximp ? -maximp : sum;
+        const T sc = lo > maximp ? maximp : lo;
+        const T delta = live ? ((sc == sum) ? t : sc - lam[i]) : T(0);
+        lam[i] = live ? sc : lam[i];
+#pragma unroll
+        for (int r = 0; r < N; ++r) dv[r] += Minv[r][i] * delta;
+        const T dvel = delta * Minv[i][i];
+        res = tmax(res, dvel * dvel);
+    }
+    return res;
+}
+// ... and the loop: at most `iters` sweeps, reverse order first; returns the number of sweeps THIS lane's env ran.
+template <typename T, int N>
+__device__ __forceinline__ int pgs_threshold(const T (&Minv)[N][N], const T (&rimp)[N], const T (&jdi)[N], T maximp, int iters, T res_thr, T (&dv)[N]) {
+    T lam[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { lam[i] = T(0); dv[i] = T(0); }
+    iters = iters < 0 ? -iters : iters;
+    bool live = iters > 0;
+    int sweeps = 0;
+    for (int it = 0; it < iters && __any(live); it += 2) {
+        const T r0 = pgs_sweep_residual<T, N, false>(Minv, rimp, jdi, maximp, live, lam, dv);
+        if (live) { ++sweeps; live = !(r0 <= res_thr); }
+        if (it + 1 < iters) {
+            const T r1 = pgs_sweep_residual<T, N, true>(Minv, rimp, jdi, maximp, live, lam, dv);
+            if (live) { ++sweeps; live = !(r1 <= res_thr); }
+        }
+    }
+    return sweeps;
+}
+
 enum { kMotorOff = 0, kMotorVelocity = 1, kMotorPosition = 2 };
 
 // One stepSimulation() tick with the reference's per-tick gravity compensation (robot.py:131-141).
@@ -590,7 +641,8 @@ enum { kMotorOff = 0, kMotorVelocity = 1, kMotorPosition = 2 };
 template <typename T, int TOPO, int MOTOR, bool GC = true, bool TRIG = false>
 __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                          const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
-                                         int iters, JointTrig<T, Topo<TOPO>::N>* trig = nullptr, int* verified = nullptr) {
+                                         int iters, JointTrig<T, Topo<TOPO>::N>* trig = nullptr, int* verified = nullptr,
+                                         int* sweep_acc = nullptr /* threshold mode: += the sweeps this tick ran */) {
     constexpr int N = Topo<TOPO>::N;
     // Analytic fixed point.  Every joint carries a motor row (J = e_i), so the rows together prescribe the whole velocity: the unique
     // solution of the unclamped system A lambda = rhs, A = Minv, is dv = des - v, i.e. the post-solve velocity is `des` itself, and with
@@ -604,7 +656,7 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
     // priori by the same energy bound as for pgs_unclamped, with the host-side bound trace_bound >= trace(M(q)) and the damping impulse
     // bounded through the same quantity (gravity is compensated).  Then the tick is  qd = des, q += dt des.  iters < 0
     // (pgs_full_sweeps) forces the literal path.
-    if (MOTOR != kMotorOff && GC && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0) {
+    if (MOTOR != kMotorOff && GC && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0 && !(m.res_thr > T(0))) {
         T des[N], dvw = T(0), v2 = T(0);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -660,7 +712,11 @@ __device__ __forceinline__ void sim_tick(const DevRobot<T>& m, T (&q)[Topo<TOPO>
         }
         const bool no_clamp_possible = T(4) * traceM * tsqrt(dv2) < maximp;   // 2 trace(M) ||dv*|| < maxImpulse / 2
         int sweeps = -1;
-        if (__all(no_clamp_possible)) {
+        if (m.res_thr > T(0)) {              // threshold mode: Bullet's exit per env, sweep by sweep; never licensed
+            const int ran = pgs_threshold<T, N>(Minv, rimp, jdi, maximp, iters, m.res_thr, dv);
+            if (sweep_acc != nullptr) *sweep_acc += ran;
+        }
+        else if (__all(no_clamp_possible)) {
             // the MG400's motor solve never converges inside the budget: eight sweeps at a time (pgs_unclamped_blocks); the UR5 leaves after
             // 50 - 60 sweeps and keeps the sweep-by-sweep loop, as does every `pgs_full_sweeps` run (iters < 0)
             if (N == 8 && iters >= 32 && (iters & 1) == 0) sweeps = pgs_unclamped_blocks<T, N>(Minv, rimp, jdi, iters, dv);
@@ -832,7 +888,8 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
                                               const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                               int iters, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b,
                                               V3<T> ext_force, V3<T> ext_pos, bool ext_pending, int* verified = nullptr,
-                                              JointTrig<T, Topo<TOPO>::N>* trig = nullptr /* carried sines / cosines (k_step_body) */) {
+                                              JointTrig<T, Topo<TOPO>::N>* trig = nullptr /* carried sines / cosines (k_step_body) */,
+                                              int* sweep_acc = nullptr /* threshold mode: += the sweeps this tick ran */) {
     constexpr int N = Topo<TOPO>::N;
     constexpr int NR = N + 3;
     // Analytic fixed point (see sim_tick).  The motor rows still prescribe the whole arm velocity, whatever the P2P rows pull: at the
@@ -841,7 +898,7 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
     // the motors absorbing the reaction.  Same licence as in sim_tick: a full solve of this env step must have converged to the last
     // bit within 80 % of the sweep budget (the coupled iteration contracts like the arm's alone, ~0.5 per sweep), and no row may be
     // able to reach its limit (motor bound extended by the P2P reaction, P2P impulse far from its 500 N s cap).
-    if (MOTOR != kMotorOff && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0) {
+    if (MOTOR != kMotorOff && iters >= 0 && kd == T(1) && verified != nullptr && *verified > 0 && !(m.res_thr > T(0))) {
         if (body_tick_analytic<T, TOPO, MOTOR>(m, q, qd, q_des, qd_des, kp, max_force, dt, gravity, b, bc, pivot_b, ext_force, ext_pos, ext_pending, trig)) {
             --*verified;
             return;
@@ -960,6 +1017,34 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
     thr = iters < 0 ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
     const int n_it = iters < 0 ? -iters : iters;
     int conv_sweeps = -1;
+    if (m.res_thr > T(0)) {                  // threshold mode (DevRobot::res_thr): Bullet's exit per env after every sweep, oracle mb_step_body
+        bool live = n_it > 0;
+        int ran = 0;
+        auto row = [&](const int i, T& res) {
+            const T t = r[i];
+            const T sum = lam[i] + t;
+            const T lo = sum < -lim[i] ? -lim[i] : sum;
+            const T sc = lo > lim[i] ? lim[i] : lo;
+            const T delta = live ? ((sc == sum) ? t : sc - lam[i]) : T(0);
+            lam[i] = live ? sc : lam[i];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) r[j] -= G[j][i] * delta;
+            const T dvel = delta * A[i][i];
+            res = tmax(res, dvel * dvel);
+        };
+        for (int it = 0; it < n_it && __any(live); ++it) {
+            T res = T(0);
+            if (it & 1) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) if (MOTOR != kMotorOff || i >= N) row(i, res);
+            } else {
+#pragma unroll
+                for (int i = NR - 1; i >= 0; --i) if (MOTOR != kMotorOff || i >= N) row(i, res);
+            }
+            if (live) { ++ran; live = !(res <= m.res_thr); }
+        }
+        if (sweep_acc != nullptr) *sweep_acc += ran;
+    } else
     for (int it = 0; it < n_it; ++it) {
         if ((it & 7) == 0 && it > 0) {
             T mx = T(0);
@@ -1029,7 +1114,8 @@ template <typename T, int TOPO, int MOTOR>
 __device__ __forceinline__ void sim_tick_body_ball(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                                    const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                                    int iters, V3<T> gravity, FreeBody<T>& b, const BodyConst<T>& bc, V3<T> pivot_b, Ball<T>& ball,
-                                                   const BallConst<T>& kc, V3<T> ball_torque, bool torque_pending, T& normal_impulse) {
+                                                   const BallConst<T>& kc, V3<T> ball_torque, bool torque_pending, T& normal_impulse,
+                                                   int* sweep_acc = nullptr /* threshold mode: += the sweeps this tick ran */) {
     constexpr int N = Topo<TOPO>::N;
     constexpr int NP = N + 3;     // motor and P2P rows
     T hb[N], qdm[N], Minv[N][N], traceM;
@@ -1183,6 +1269,67 @@ __device__ __forceinline__ void sim_tick_body_ball(const DevRobot<T>& m, T (&q)[
     if (touching) thr = tmax(thr, tmax(tabs(rc[0] * jc[0]), tmax(tabs(rc[1] * jc[1]), tabs(rc[2] * jc[2]))));
     thr = iters < 0 ? T(-1) : thr * (sizeof(T) == 8 ? T(1.3877787807814457e-17) : T(7.450580596923828e-09));
     const int n_it = iters < 0 ? -iters : iters;
+    if (m.res_thr > T(0)) {                  // threshold mode (DevRobot::res_thr): Bullet's exit per env after every sweep, oracle mb_step_body_ball
+        bool live = n_it > 0;
+        int ran = 0;
+        for (int it = 0; it < n_it && __any(live); ++it) {
+            T res = T(0);
+            auto rowt = [&](const int i) {
+                const T t = r[i] * jdi[i];
+                const T sum = lam[i] + t;
+                const T lo = sum < -lim[i] ? -lim[i] : sum;
+                const T sc = lo > lim[i] ? lim[i] : lo;
+                const T delta = live ? ((sc == sum) ? t : sc - lam[i]) : T(0);
+                lam[i] = live ? sc : lam[i];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) r[j] -= (j <= i ? A[j][i] : A[i][j]) * delta;
+                if (i >= N) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rc[k] -= Apc[i >= N ? i - N : 0][k] * delta;
+                }
+                const T dvel = delta * A[i][i];
+                res = tmax(res, dvel * dvel);
+            };
+            if (it & 1) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) if (MOTOR != kMotorOff || i >= N) rowt(i);
+            } else {
+#pragma unroll
+                for (int i = NP - 1; i >= 0; --i) if (MOTOR != kMotorOff || i >= N) rowt(i);
+            }
+            if (touching) {
+                {   // normal
+                    const T t = rc[0] * jc[0], sum = lc[0] + t;
+                    const T sc = sum < T(0) ? T(0) : sum;
+                    const T delta = live ? ((sc == sum) ? t : sc - lc[0]) : T(0);
+                    lc[0] = live ? sc : lc[0];
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) r[N + x] -= Apc[x][0] * delta;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rc[k] -= Acc[0][k] * delta;
+                    const T dvel = delta * Acc[0][0];
+                    res = tmax(res, dvel * dvel);
+                }
+                {   // friction pair, cone: ONE residual, the sum of the pair's two velocity changes (resolveConeFrictionConstraintRows, A7c)
+                    const T limit = kc.mu * lc[0];
+                    T s1 = lc[1] + rc[1] * jc[1], s2 = lc[2] + rc[2] * jc[2];
+                    const T tot = tsqrt(s1 * s1 + s2 * s2);
+                    if (tot > limit) { const T f = tot > T(0) ? limit / tot : T(0); s1 *= f; s2 *= f; }
+                    const T d1 = live ? s1 - lc[1] : T(0), d2 = live ? s2 - lc[2] : T(0);
+                    if (live) { lc[1] = s1; lc[2] = s2; }
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) r[N + x] -= Apc[x][1] * d1 + Apc[x][2] * d2;
+                    rc[0] -= Acc[0][1] * d1 + Acc[0][2] * d2;
+                    rc[1] -= Acc[1][1] * d1 + Acc[1][2] * d2;
+                    rc[2] -= Acc[1][2] * d1 + Acc[2][2] * d2;
+                    const T dvel = d1 * Acc[1][1] + d2 * Acc[2][2];
+                    res = tmax(res, dvel * dvel);
+                }
+            }
+            if (live) { ++ran; live = !(res <= m.res_thr); }
+        }
+        if (sweep_acc != nullptr) *sweep_acc += ran;
+    } else
     for (int it = 0; it < n_it; ++it) {
         if ((it & 7) == 0 && it > 0) {
             T mx = T(0);
@@ -1323,7 +1470,7 @@ template <typename T, int TOPO, int MOTOR, int SHAPE = 0>
 __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],
                                               const T (&q_des)[Topo<TOPO>::N], const T (&qd_des)[Topo<TOPO>::N], T kp, T kd, T max_force, T dt,
                                               int iters, FreeBody<T>& b, const PushScene<T>& sc, const T* __restrict__ tip_verts, T mass,
-                                              lds_ptr<T> L, int& contact_code) {
+                                              lds_ptr<T> L, int& contact_code, int* sweep_acc = nullptr /* threshold mode: += the sweeps this tick ran */) {
     // contact_code (out): the tick's contact pairs - bits 0-7 the cube vertices kept as cube-table contacts (SHAPE 1: bit 0 = the
     // sphere-table contact), bit 8 the tip contact, bits 9+ the hull vertex of the tip core that made it (tg_state_view.contact_ids)
     constexpr int N = Topo<TOPO>::N;
@@ -1582,27 +1729,37 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
     const bool cone = sc.cone_friction != 0;
     const V3<T> iw0 = mk(Iwi.xx, Iwi.xy, Iwi.xz), iw1 = mk(Iwi.xy, Iwi.yy, Iwi.yz), iw2 = mk(Iwi.xz, Iwi.yz, Iwi.zz);   // columns
     const int n_it = iters < 0 ? -iters : iters;   // contact problems do not reach their fixed point within 150 sweeps: no exit test
-    for (int it = 0; it < n_it; ++it) {
-        // joint motors
-        if (it & 1) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const T sum = lm[i] + (rm[i] - dv[i]) * jm[i];
-                const T scl = tmin(tmax(sum, -maximp), maximp);
-                const T delta = scl - lm[i];
-                lm[i] = scl;
-#pragma unroll
-                for (int j = 0; j < N; ++j) dv[j] += TG_MS(j, i) * delta;
+    // One sweep.  THR (threshold mode, DevRobot::res_thr > 0): the lane's impulses move only while its env is `live`, and `over` collects
+    // "some row update of this sweep changed its row's velocity by more than sqrt(res_thr)" - Bullet's residual rule (oracle mb_step_push)
+    // with the division by jacDiagABInv multiplied out:  (delta / jdi)^2 <= thr  <=>  delta^2 <= thr jdi^2  (empty slots: 0 <= 0), and for
+    // a cone pair  (d1 / j1 + d2 / j2)^2 <= thr  <=>  (d1 j2 + d2 j1)^2 <= thr (j1 j2)^2.  THR false: the sweep as it has always been.
+    const T rthr = m.res_thr;
+    auto sweep = [&](auto thr_tag, const int it, const bool live, bool& over) {
+        constexpr bool THR = decltype(thr_tag)::value;
+        auto note = [&](const T delta, const T jdi) { if constexpr (THR) over = over || !(delta * delta <= rthr * (jdi * jdi)); };
+        auto note2 = [&](const T d1, const T d2, const T j1, const T j2) {
+            if constexpr (THR) {
+                if (cone) { const T u = d1 * j2 + d2 * j1, w = j1 * j2; over = over || !(u * u <= rthr * (w * w)); }
+                else { note(d1, j1); note(d2, j2); }
             }
-        } else {
+        };
+        // joint motors
+        auto motor = [&](const int i) {
+            const T sum = lm[i] + (rm[i] - dv[i]) * jm[i];
+            const T scl = tmin(tmax(sum, -maximp), maximp);
+            const T delta = (THR && !live) ? T(0) : scl - lm[i];
+            lm[i] = (THR && !live) ? lm[i] : scl;
 #pragma unroll
-            for (int i = N - 1; i >= 0; --i) {
-                const T sum = lm[i] + (rm[i] - dv[i]) * jm[i];
-                const T scl = tmin(tmax(sum, -maximp), maximp);
-                const T delta = scl - lm[i];
-                lm[i] = scl;
+            for (int j = 0; j < N; ++j) dv[j] += TG_MS(j, i) * delta;
+            note(delta, jm[i]);
+        };
+        if (MOTOR != kMotorOff || !THR) {
+            if (it & 1) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) dv[j] += TG_MS(j, i) * delta;
+                for (int i = 0; i < N; ++i) motor(i);
+            } else {
+#pragma unroll
+                for (int i = N - 1; i >= 0; --i) motor(i);
             }
         }
         // contact normals: table slots, then the tip
@@ -1611,10 +1768,11 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             const T rax = tra[c][0], ray = tra[c][1];
             const T jdv = dvl.z + (ray * dva.x - rax * dva.y);
             const T nl = tmax(tlam[c][0] + (trhs[c][0] - jdv) * tjdi[c][0], T(0));
-            const T delta = nl - tlam[c][0];
-            tlam[c][0] = nl;
+            const T delta = (THR && !live) ? T(0) : nl - tlam[c][0];
+            tlam[c][0] = (THR && !live) ? tlam[c][0] : nl;
             dvl.z += invm * delta;
             dva = dva + delta * (ray * iw0 - rax * iw1);                 // Iw^-1 (ra x n),  ra x n = (ra.y, -ra.x, 0)
+            note(delta, tjdi[c][0]);
         }
         {   // the angular parts are rebuilt from (rb, d) each time: as many instructions as fetching them from AGPRs, 15 values fewer live
             const V3<T> ja = cross(pd[0], prb);                          // -(rb x n)
@@ -1622,12 +1780,13 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
 #pragma unroll
             for (int i = 0; i < NP; ++i) jdv += Jt[0][i] * dv[i];
             const T nl = tmax(plam[0] + ((prhs[0] - jdv) * pjdi[0] - plam[0] * pcfm), T(0));
-            const T delta = nl - plam[0];
-            plam[0] = nl;
+            const T delta = (THR && !live) ? T(0) : nl - plam[0];
+            plam[0] = (THR && !live) ? plam[0] : nl;
 #pragma unroll
             for (int i = 0; i < N; ++i) dv[i] += Wa[i][0] * delta;
             dvl = dvl - (invm * delta) * pd[0];
             dva = dva + delta * mul(Iwi, ja);
+            note(delta, pjdi[0]);
         }
         // friction: table slots, then the tip
 #pragma unroll
@@ -1637,11 +1796,13 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             const T jdv1 = -dvl.y + (raz * dva.x - rax * dva.z), jdv2 = dvl.x + (raz * dva.y - ray * dva.z);
             T s1 = tlam[c][1] + (trhs[c][1] - jdv1) * tjdi[c][1], s2 = tlam[c][2] + (trhs[c][2] - jdv2) * tjdi[c][2];
             friction_clamp(s1, s2, limit, cone);
+            if (THR && !live) { s1 = tlam[c][1]; s2 = tlam[c][2]; }
             const T d1 = s1 - tlam[c][1], d2 = s2 - tlam[c][2];
             tlam[c][1] = s1; tlam[c][2] = s2;
             dvl.y -= invm * d1; dvl.x += invm * d2;
             // Iw^-1 (ra x t1) d1 + Iw^-1 (ra x t2) d2,  ra x t1 = (ra.z, 0, -ra.x),  ra x t2 = (0, ra.z, -ra.y)
             dva = dva + (raz * d1) * iw0 + (raz * d2) * iw1 - (rax * d1 + ray * d2) * iw2;
+            note2(d1, d2, tjdi[c][1], tjdi[c][2]);
         }
         {
             const V3<T> ja1 = cross(pd[1], prb), ja2 = cross(pd[2], prb);
@@ -1651,13 +1812,28 @@ __device__ __noinline__ void sim_tick_push(const DevRobot<T>& m, T (&q)[Topo<TOP
             const T limit = mu_tip * plam[0];
             T s1 = plam[1] + (prhs[1] - jdv1) * pjdi[1], s2 = plam[2] + (prhs[2] - jdv2) * pjdi[2];
             friction_clamp(s1, s2, limit, cone);
+            if (THR && !live) { s1 = plam[1]; s2 = plam[2]; }
             const T d1 = s1 - plam[1], d2 = s2 - plam[2];
             plam[1] = s1; plam[2] = s2;
 #pragma unroll
             for (int i = 0; i < N; ++i) dv[i] += Wa[i][1] * d1 + Wa[i][2] * d2;
             dvl = dvl - (invm * d1) * pd[1] - (invm * d2) * pd[2];
             dva = dva + mul(Iwi, d1 * ja1 + d2 * ja2);
+            note2(d1, d2, pjdi[1], pjdi[2]);
         }
+    };
+    if (rthr > T(0)) {
+        bool live = n_it > 0;
+        int ran = 0;
+        for (int it = 0; it < n_it && __any(live); ++it) {
+            bool over = false;
+            sweep(std::true_type{}, it, live, over);
+            if (live) { ++ran; live = over; }
+        }
+        if (sweep_acc != nullptr) *sweep_acc += ran;
+    } else {
+        bool unused = false;
+        for (int it = 0; it < n_it; ++it) sweep(std::false_type{}, it, true, unused);
     }
 #undef TG_MS
     // ---- integrate

@@ -103,9 +103,10 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class EdgeFollowVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=250, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64",
-                 auto_reset=True, device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True, contact_mapping="auto", reset_bank="auto", fused_step="auto"):
+                 auto_reset=True, device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, solver_residual_threshold=0.0, copy_obs=True, contact_mapping="auto", reset_bank="auto", fused_step="auto"):
         cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
+        cfg.solver_residual_threshold = float(solver_residual_threshold)   # btContactSolverInfo::m_leastSquaresResidualThreshold (PARITY A7b): 0 = exit at convergence only, 1e-7 = what PyBullet is believed to run
         cfg.contact_mapping = capi.CONTACT_MAP[contact_mapping]   # \"wave\": every tick a full tick on the env's own wavefront (k_step_arm_wave; measured slower)
         cfg.reset_bank = capi.RESET_BANK[reset_bank]   # "off": every reset on the spot; "sync": the refill is waited for (tests); DESIGN 4.1h
         cfg.fused_step = capi.FUSED_STEP[fused_step]   # "on": the step as one launch (csrc/tg_fused.hip; measured slower); default: k_step -> k_reset -> render

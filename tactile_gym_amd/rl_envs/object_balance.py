@@ -107,13 +107,14 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class ObjectBalanceVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True, contact_mapping="auto", reset_bank="auto"):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, solver_residual_threshold=0.0, copy_obs=True, contact_mapping="auto", reset_bank="auto"):
         cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         if modes["object_mode"] == "ball_on_plate" and contact_mapping == "wave":
             raise ValueError("object_mode ball_on_plate runs on the lane mapping (contact_mapping 'auto' or 'lane')")
         cfg.reset_bank = capi.RESET_BANK[reset_bank]              # "off": every reset recomputes the arm's blocking move (k_reset_body's template)
         cfg.contact_mapping = capi.CONTACT_MAP[contact_mapping]   # "wave": one wavefront per env (k_step_body_wave), "lane": one lane per env
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
+        cfg.solver_residual_threshold = float(solver_residual_threshold)   # btContactSolverInfo::m_leastSquaresResidualThreshold (PARITY A7b): 0 = exit at convergence only, 1e-7 = what PyBullet is believed to run
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         act_dim = {"xy": 2, "xyz": 3, "RxRy": 2, "xyRxRy": 4}[modes["movement_mode"]]           # :565-576

@@ -155,7 +155,7 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class ObjectPushVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True, contact_mapping="auto", solver_iterations=None, narrowphase="closed_form",
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, solver_residual_threshold=0.0, copy_obs=True, contact_mapping="auto", solver_iterations=None, narrowphase="closed_form",
                  max_force=None):
         cfg, robot, sensor, mesh, modes, tip_verts = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         if max_force is not None:
@@ -165,6 +165,7 @@ class ObjectPushVecEnv(TactileVecEnv):
         cfg.narrowphase = capi.NARROWPHASE[narrowphase]   # "gjk_manifold": GJK / EPA + Bullet's persistent manifold for the tip - cube pair (tg_config.narrowphase)
         cfg.contact_mapping = capi.CONTACT_MAP[contact_mapping]   # "wave": one wavefront per env, "lane": one lane per env (tg_config.contact_mapping)
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))   # run all solver sweeps instead of leaving at convergence
+        cfg.solver_residual_threshold = float(solver_residual_threshold)   # btContactSolverInfo::m_leastSquaresResidualThreshold (PARITY A7b): 0 = exit at convergence only, 1e-7 = what PyBullet is believed to run
         self._tip_verts = tip_verts   # tg_create copies them; kept only until then
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action

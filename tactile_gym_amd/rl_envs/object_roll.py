@@ -101,12 +101,13 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
 
 class ObjectRollVecEnv(TactileVecEnv):
     def __init__(self, num_envs, max_steps=1000, image_size=(64, 64), env_modes=env_modes_default, physics_dtype="f64", auto_reset=True,
-                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, copy_obs=True, contact_mapping="auto", solver_iterations=None):
+                 device=0, obs_mode="numpy", seed=None, pgs_full_sweeps=False, solver_residual_threshold=0.0, copy_obs=True, contact_mapping="auto", solver_iterations=None):
         cfg, robot, sensor, mesh, modes = build_config(num_envs, max_steps, image_size, env_modes, physics_dtype, auto_reset, device)
         if solver_iterations is not None:
             cfg.solver_iterations = int(solver_iterations)   # numSolverIterations (base_tactile_env.py:128-130: 150); measurements only
         cfg.contact_mapping = capi.CONTACT_MAP[contact_mapping]   # "wave": one wavefront per env, "lane": one lane per env (tg_config.contact_mapping)
         cfg.pgs_full_sweeps = int(bool(pgs_full_sweeps))
+        cfg.solver_residual_threshold = float(solver_residual_threshold)   # btContactSolverInfo::m_leastSquaresResidualThreshold (PARITY A7b): 0 = exit at convergence only, 1e-7 = what PyBullet is believed to run
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,

@@ -639,7 +639,8 @@ class TactileVecEnv(_VecEnvBase):
         n, nd = self.num_envs, self.ndof
         out = dict(q=np.zeros((n, nd)), qd=np.zeros((n, nd)), qd_target=np.zeros((n, nd)), tcp_pos=np.zeros((n, 3)),
                    tcp_rpy=np.zeros((n, 3)), edge_ang=np.zeros(n), embed_dist=np.zeros(n), stim_xform=np.zeros((n, 12), np.float32),
-                   step_count=np.zeros(n, np.int32), reset_ticks=np.zeros(n, np.int32), rng_state=np.zeros(n, np.uint64))
+                   step_count=np.zeros(n, np.int32), reset_ticks=np.zeros(n, np.int32), rng_state=np.zeros(n, np.uint64),
+                   solver_sweeps=np.zeros(n, np.int32))   # threshold mode (solver_residual_threshold > 0): PGS sweeps of the last step's ticks
         if self._cfg.env_kind == capi.ENV_OBJECT_BALANCE:
             out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
                        gravity_z=np.zeros(n))

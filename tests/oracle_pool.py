@@ -25,8 +25,11 @@ def _rollout_chunk(args):
     warnings.simplefilter("ignore")
     from oracle import ref_env
     out = []
+    kwargs = dict(kwargs)
+    res_thr = kwargs.pop("solver_residual_threshold", 0.0)      # btContactSolverInfo::m_leastSquaresResidualThreshold (PARITY A7b)
     for k, i in enumerate(idx):
         o = getattr(ref_env, cls)(seed=seed0 + i, **kwargs)
+        o.solver_residual_threshold = res_thr
         ob = o.reset()
         rec = dict(img=[keep(ob["tactile"][..., 0])], q=[o.arm.q.copy()], rew=[], done=[], reset_ticks=[o.reset_ticks], knife=0,
                    term={}, feat=[], cc=[], cid=[], body=[], xf=[np.asarray(o.stimulus_transform(), dtype=np.float32).ravel().copy()])
@@ -34,7 +37,9 @@ def _rollout_chunk(args):
         has_body = hasattr(o, "cube_pose") or hasattr(o, "body_pose")
         for s in range(actions.shape[0]):
             goal_before = o.goal_pos_world.copy() if push else None
+            sweeps_before = o.sweeps_total
             ob, r, d, _ = o.step(actions[s, k])
+            rec.setdefault("sweeps", []).append(o.sweeps_total - sweeps_before)   # PGS sweeps of this step's ticks (before any auto-reset)
             if push and follow is not None and follow[s, k] == o.targ_traj_list_id + 1:
                 pos = o.cube_pose()[0]
                 if abs(np.linalg.norm(pos - goal_before) - o.termination_pos_dist) < 1e-12:
@@ -61,7 +66,7 @@ def _rollout_chunk(args):
                 p, R = o.cube_pose() if hasattr(o, "cube_pose") else o.body_pose()
                 rec["body"].append(np.concatenate([np.asarray(p).ravel(), np.asarray(R).ravel()]))
             rec["img"].append(img), rec["q"].append(q_step), rec["xf"].append(xf)
-        for key in ("img", "q", "rew", "done", "feat", "cc", "cid", "body", "xf"):
+        for key in ("img", "q", "rew", "done", "feat", "cc", "cid", "body", "xf", "sweeps"):
             rec[key] = np.asarray(rec[key])
         out.append(rec)
     return list(idx), out

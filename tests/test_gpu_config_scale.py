@@ -49,12 +49,12 @@ def _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset, w
     def keep(batch):     # digest: crc32 per frame (tests/oracle_pool.py does the same on its side)
         return np.array([zlib.crc32(np.ascontiguousarray(im).tobytes()) for im in batch], dtype=np.uint32) if digest else batch.copy()
     rec = dict(img=[keep(obs["tactile"][..., 0])], q=[st["q"].copy()], rew=[], done=[], reset_ticks=[st["reset_ticks"].copy()], feat=[], cc=[],
-               cid=[], body=[], goal_id=[], term={}, xf=[st["stim_xform"].copy()])
+               cid=[], body=[], goal_id=[], term={}, xf=[st["stim_xform"].copy()], sweeps=[])
     for s in range(actions.shape[0]):
         obs, rew, done, info = v.step(actions[s])
         st = v.get_state()
         rec["img"].append(keep(obs["tactile"][..., 0])), rec["q"].append(st["q"].copy()), rec["rew"].append(rew), rec["done"].append(done)
-        rec["reset_ticks"].append(st["reset_ticks"].copy()), rec["xf"].append(st["stim_xform"].copy())
+        rec["reset_ticks"].append(st["reset_ticks"].copy()), rec["xf"].append(st["stim_xform"].copy()), rec["sweeps"].append(st["solver_sweeps"].copy())
         if "extended_feature" in obs:
             rec["feat"].append(obs["extended_feature"].copy())
         if "body_pos" in st:
@@ -70,14 +70,36 @@ def _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset, w
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_config_scale_1024_envs_match_oracle(case):
+    _config_scale(case, 0.0)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_config_scale_1024_envs_match_oracle_with_residual_threshold(case):
+    """The same comparison with tg_config.solver_residual_threshold = 1e-7 (PARITY A7b: what PyBullet's server is believed to install and the
+    reference never overrides) on both sides: Bullet's exit rule after every sweep, per env.  Same tolerances; in addition the number of
+    PGS sweeps every env ran in every step is compared EXACTLY with the oracle's (an exit one sweep early or late moves qd by ~1e-4 rad/s)."""
+    _config_scale(case, 1e-7)
+
+
+def _config_scale(case, res_thr):
     env_id, cls, modes, size, act_dim, max_steps = CASES[case]
     n, steps, seed = 1024, 8, 900
     actions = np.random.default_rng(7).uniform(-0.25, 0.25, size=(steps, n, act_dim)).astype(np.float32)
     push = case == "config4_object_push"
-    hip = _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset=False, want_contacts=push)
-    ref = oracle_rollouts(cls, dict(max_steps=max_steps, image_size=(size, size), env_modes=modes), seed, actions,
+    extra = dict(solver_residual_threshold=res_thr) if res_thr else {}
+    hip = _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset=False, want_contacts=push, **extra)
+    ref = oracle_rollouts(cls, dict(max_steps=max_steps, image_size=(size, size), env_modes=modes, **extra), seed, actions,
                           follow=hip["goal_id"] if push else None)
     assert len(ref) == n and all(r is not None for r in ref)
+    if res_thr:
+        ref_sweeps = np.array([r["sweeps"] for r in ref]).T          # [steps, n]
+        bad = np.argwhere(hip["sweeps"] != ref_sweeps)
+        assert len(bad) == 0, (case, len(bad), bad[:5], hip["sweeps"][tuple(bad[0])], ref_sweeps[tuple(bad[0])])
+        ticks = (12 if case == "config5_object_balance" else 24) * steps * n          # object_balance runs 12 ticks per env step
+        print(f"{case}: residual threshold {res_thr:g}: {ref_sweeps.sum() / ticks:.2f} PGS sweeps per tick (of {150}), equal to the oracle's in "
+              f"every env and step")
+    else:
+        assert not hip["sweeps"].any()                               # the default mode does not count
     worst_q = worst_r = worst_b = 0.0
     bad_images, knife, bad_xf = 0, 0, 0
     for i, r in enumerate(ref):

@@ -78,8 +78,9 @@ class _OracleArmEnv:
     ACTION_REPEAT = 24                   # floor((1/10)/(1/240)), :35-37
     SOLVER_ITERS = 150                   # base_tactile_env.py:128-130
     # btContactSolverInfo::m_leastSquaresResidualThreshold, which base_tactile_env.py:128-130 never sets (PARITY A7b): 0 = Bullet's own
-    # library default, 1e-7 = what PyBullet's physics server is believed to install.  Per instance: env.solver_residual_threshold = 1e-7.
-    solver_residual_threshold = 0.0
+    # library default, 1e-7 = what PyBullet's physics server is believed to install.  Per instance: env.solver_residual_threshold = 1e-7;
+    # None (default) leaves the C library's process-wide setting alone (0 unless mb.set_solver_residual_threshold was called).
+    solver_residual_threshold = None
     sweeps_total = 0                     # PGS sweeps executed by this env's ticks since construction (ticks: self.ticks)
 
     def _setup_arm(self, seed, modes, max_steps, image_size, t_s_type, rest_poses, inertia):
@@ -135,7 +136,7 @@ class _OracleArmEnv:
     def _step_sim(self):
         q, qd = self.arm.q, self.arm.qd
         self.arm.apply_torques(self.arm.inverse_dynamics(q, qd, np.zeros(self.arm.n)))  # base_robot_arm.py:174-189
-        if mb.solver_residual_threshold() != self.solver_residual_threshold:            # the C library's setting is per process
+        if self.solver_residual_threshold is not None and mb.solver_residual_threshold() != self.solver_residual_threshold:   # the C library's setting is per process
             mb.set_solver_residual_threshold(self.solver_residual_threshold)
         self._step_simulation()                                                          # robot.py:141
         self.ticks += 1

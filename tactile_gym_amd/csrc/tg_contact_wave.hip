@@ -972,6 +972,8 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
             }                                                                          \
             _Pragma("unroll") for (int k_ = 0; k_ < (SHAPE == 1 ? 1 : 4); ++k_) TG_NORMAL_STEP(kContactLane0 + 4 * k_, 8 + 3 * k_) \
             x -= da_ + db_;                                                            \
+            /* threshold mode: watch lane W0 + j carries G = -e_j, so its share of the map, -(da_ + db_), IS motor j's impulse change of this pass */ \
+            if (THRM) { const T dvm_ = (da_ + db_) * adw; resl_ = vmax(resl_, dvm_ * dvm_); } \
         } else if (MOTOR != kMotorOff) {                                               \
             _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_) {                         \
                 const int i_ = (FWD) ? k_ : N - 1 - k_;                                \
@@ -1000,21 +1002,42 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         // Threshold mode (tg_config.solver_residual_threshold, PARITY A7b): the literal clamped row steps, and after EVERY sweep Bullet's exit -
         // the largest squared velocity change delta / jacDiagABInv of the sweep's row updates <= the threshold (oracle mb_step_push).  Every
         // delta is wave-uniform after its broadcast; the rows' 1 / jacDiagABInv are fetched once from their lanes.
-        constexpr int CLAMPED = 1, THRM = 1;
+        // The motors run unclamped as ONE linear map per pass, as in the default mode (their impulse changes are read off the watch lanes, `adw` =
+        // the motor's 1 / jacDiagABInv on its watch lane, 0 elsewhere); a tick in which a motor limit is reached is solved again with the literal
+        // clamped steps.  Contact deltas are wave-uniform after their broadcast; the rows' 1 / jacDiagABInv are fetched once from their lanes.
+        constexpr int THRM = 1;
         T Ad[NGT];
 #pragma unroll
         for (int i = 0; i < NGT; ++i) Ad[i] = bcast(adiag, i < 8 ? i : kContactLane0 + 4 * ((i - 8) / 3) + (i - 8) % 3);
+        const T adw_f = lane_fetch(adiag, watch_lane ? lane - W0 : 0);
+        const T adw = watch_lane ? adw_f : T(0);
+        T resl_ = T(0);
         int ran_ = 0;
-        for (int it_ = 0; it_ < n_it; ++it_) {
-            res_ = T(0);
-            if (it_ & 1) { TG_SWEEP(true) } else { TG_SWEEP(false) }
-            ++ran_;
-            if (uniform_true(res_ <= m.res_thr)) break;
+        {
+            constexpr int CLAMPED = 0;
+            for (int it_ = 0; it_ < n_it; ++it_) {
+                res_ = T(0); resl_ = T(0);
+                if (it_ & 1) { TG_SWEEP(true) } else { TG_SWEEP(false) }
+                ++ran_;
+                if (__builtin_amdgcn_ballot_w64(!(res_ <= m.res_thr) || !(resl_ <= m.res_thr)) == 0) break;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(watch_lane && wmax > maximp) != 0) {
+            constexpr int CLAMPED = 1;
+            x = x0; lam = T(0); lamF = T(0); ran_ = 0;
+            for (int it_ = 0; it_ < n_it; ++it_) {
+                res_ = T(0);
+                if (it_ & 1) { TG_SWEEP(true) } else { TG_SWEEP(false) }
+                ++ran_;
+                if (uniform_true(res_ <= m.res_thr)) break;
+            }
         }
         if (sweep_acc != nullptr) *sweep_acc += ran_;
     } else {
     constexpr int THRM = 0;
     const T* Ad = nullptr;
+    const T adw = T(0);
+    T resl_ = T(0);
     {
         constexpr int CLAMPED = 0;
         TG_SOLVE()
@@ -1025,7 +1048,7 @@ __device__ __forceinline__ int sim_tick_contact_wave(const DevRobot<T>& m, const
         x = x0; lam = T(0); lamF = T(0);
         TG_SOLVE()
     }
-    (void)Ad;
+    (void)Ad; (void)adw; (void)resl_;
     }
 #undef TG_SOLVE
 #undef TG_SWEEP

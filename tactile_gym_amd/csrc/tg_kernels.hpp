@@ -909,13 +909,14 @@ __global__ __launch_bounds__(64) void k_step_pos(const DevRobot<T>* __restrict__
     tcp_position_target<T, TOPO>(m, c, q, delta, tpos, tq, qik);
 #pragma unroll
     for (int i = 0; i < N; ++i) { zero[i] = T(0); st.qd_target[i * n + env] = 0.0; }
-    int verified = 0;
+    int verified = 0, sweeps = 0;
     for (int it = 0; it < c.max_blocking; ++it) {
         const bool stop = pose_reached<T, TOPO>(m, q, qd, tpos, tq);
-        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, qik, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, nullptr, &verified);
+        sim_tick<T, TOPO, kMotorPosition>(m, q, qd, qik, zero, m.pos_gain, m.vel_gain, m.max_force, c.dt, c.solver_iters, nullptr, &verified, &sweeps);
         if (verified < 0) verified = 0;
         if (stop) break;
     }
+    if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
     st.licence[env] = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }

@@ -60,6 +60,13 @@ def make_stub():
                                   deterministicOverlappingPairs=None, solverResidualThreshold=None, physicsClientId=0):
         if fixedTimeStep is not None:
             S["dt"] = fixedTimeStep
+        if solverResidualThreshold is not None:
+            S["solver_residual_threshold"] = solverResidualThreshold
+
+    @api
+    def getPhysicsEngineParameters(physicsClientId=0):
+        # (the Quickstart Guide lists solverResidualThreshold among the returned fields; 1e-7 is the default it documents for the setter)
+        return {"fixedTimeStep": S.get("dt", 1.0 / 240.0), "numSolverIterations": 50, "solverResidualThreshold": S.get("solver_residual_threshold", 1e-7)}
 
     @api
     def loadURDF(fileName, basePosition=(0, 0, 0), baseOrientation=(0, 0, 0, 1), useMaximalCoordinates=0, useFixedBase=0, flags=0, globalScaling=1.0,

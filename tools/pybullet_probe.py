@@ -676,15 +676,39 @@ WORLDS = {"push_contacts": {"oracle": OraclePush, "pybullet": PyBulletPush},    
           "ball_on_plate": {"oracle": lambda a: OracleBalance(a, ball=True), "pybullet": lambda a: PyBulletBalance(a, ball=True)}}
 
 
-def run(backend, out_dir, assets=None, scenarios=None):
+def engine_residual_threshold(backend, oracle_threshold):
+    """btContactSolverInfo::m_leastSquaresResidualThreshold of the world the scenario ran in (PARITY_ASSUMPTIONS A7b).  PyBullet: what
+    getPhysicsEngineParameters() reports - the reference never sets it (base_tactile_env.py:127-130), so this IS the answer to A7b; NaN when
+    this build of PyBullet does not report the field.  Oracle backend: the value it was run with."""
+    if backend != "pybullet":
+        return float(oracle_threshold)
+    try:
+        import pybullet as p
+        return float(p.getPhysicsEngineParameters().get("solverResidualThreshold", float("nan")))
+    except Exception:  # noqa: BLE001
+        return float("nan")
+
+
+def run(backend, out_dir, assets=None, scenarios=None, residual_threshold=0.0):
+    """residual_threshold (oracle backend only): the solver's exit threshold the oracle runs with - 0 (Bullet's library default: exit at a fixed
+    point only) or e.g. 1e-7 (what PyBullet's server is believed to install); tests/test_pybullet_golden.py replays a PyBullet file under both
+    and names the one that matches.  Every file records `solver_residual_threshold` (see engine_residual_threshold)."""
     os.makedirs(out_dir, exist_ok=True)
     written = []
-    for name in scenarios or SCENARIOS:
-        b = WORLDS.get(name, {"oracle": OracleBackend, "pybullet": PyBulletBackend})[backend](assets)   # a fresh world per scenario
-        data = SCENARIOS[name](b)
-        path = os.path.join(out_dir, f"pybullet_{name}.npz")
-        np.savez_compressed(path, backend=np.array(backend), **data)
-        written.append(path)
+    if backend == "oracle":
+        from oracle import minibullet as mb
+        mb.set_solver_residual_threshold(residual_threshold)
+    try:
+        for name in scenarios or SCENARIOS:
+            b = WORLDS.get(name, {"oracle": OracleBackend, "pybullet": PyBulletBackend})[backend](assets)   # a fresh world per scenario
+            data = SCENARIOS[name](b)
+            path = os.path.join(out_dir, f"pybullet_{name}.npz")
+            np.savez_compressed(path, backend=np.array(backend), solver_residual_threshold=np.array(engine_residual_threshold(backend, residual_threshold)),
+                                **data)
+            written.append(path)
+    finally:
+        if backend == "oracle":
+            mb.set_solver_residual_threshold(0.0)
     return written
 
 
@@ -694,9 +718,12 @@ def main():
     ap.add_argument("--assets", default=os.environ.get("TG_PYBULLET_ASSETS"), help="the reference's tactile_gym/assets directory (pybullet backend)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--scenarios", nargs="*", choices=sorted(SCENARIOS))
+    ap.add_argument("--residual-threshold", type=float, default=0.0, help="oracle backend: the solver's exit threshold (PARITY A7b); PyBullet's own is recorded, not set")
     a = ap.parse_args()
-    for pth in run(a.backend, a.out, a.assets, a.scenarios):
+    for pth in run(a.backend, a.out, a.assets, a.scenarios, a.residual_threshold):
         print("wrote", pth)
+    if a.backend == "pybullet":
+        print("PyBullet reports solverResidualThreshold =", engine_residual_threshold("pybullet", 0.0), "(PARITY_ASSUMPTIONS A7b: the value tg_config.solver_residual_threshold should take)")
 
 
 if __name__ == "__main__":

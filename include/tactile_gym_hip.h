@@ -408,6 +408,9 @@ typedef struct {
     double*  ball_linvel;    /* [num_envs][3] */
     double*  ball_angvel;    /* [num_envs][3] */
     double*  ball_impulse;   /* [num_envs] normal impulse of the ball - plate contact in the last sim tick (0: not touching) */
+    int32_t* broadphase_pairs;  /* [num_envs] last broadphase check (tg_set_broadphase): unexpected pairs whose world AABBs overlap (stage 1) */
+    int32_t* broadphase_hits;   /* [num_envs] ... of which the oriented boxes / the hull also overlap (stages 2, 3): 0 = no unmodelled contact possible */
+    int32_t* broadphase_mask;   /* [num_envs] bit k: slot k is part of a hit */
     int32_t* solver_sweeps;  /* [num_envs] threshold mode (tg_config.solver_residual_threshold > 0): PGS sweeps the sim ticks of the env's last
                               * tg_step ran, summed over the ticks (a reset's ticks are not counted); zeros otherwise.  (ABI v13) */
 } tg_state_view;
@@ -445,6 +448,45 @@ typedef struct {
 } tg_scene;
 /* Uploads the scene; call before the first tg_step. */
 int tg_set_scene(tg_ctx* ctx, const tg_scene* scene);
+
+/* ---- broadphase guard (ABI v13; csrc/tg_broadphase.hip, oracle/broadphase.py) --------------------------------------------------------------------
+ * PyBullet's stepSimulation (robots/arms/robot.py:141) runs Bullet's broadphase over the world AABBs of every collision object and hands every
+ * overlapping pair of different bodies (not both static, neither filtered out) to the narrowphase.  This library's contact sets are FIXED per env
+ * from the reference's collision filters (sensors/tactile_sensor.py:46-57, robots/arms/mg400/mg400.py:68-72, base_surface_env.py:432,
+ * object_push_env.py:249): the guard checks per env step that no OTHER pair can touch - one oriented box per URDF link with <collision> geometry
+ * (the robot's, the table, the plane, the stimulus, the free objects), world AABBs sorted and swept on x in the env's wavefront (stage 1: what
+ * Bullet's broadphase would report), the pairs found narrowed by an oriented-box separating-axis test (stage 2) and, for a robot link against the
+ * table, by the link's convex hull against the table top (stage 3).  Results per env in tg_state_view.broadphase_pairs / _hits / _mask; a
+ * non-zero hit count means PyBullet may generate a contact this library has no solver row for.
+ * Slots: 0-15 the robot's boxes in URDF link order, 16 table, 17 plane, 18 edge stimulus, 19 / 20 the object's boxes, 21 the ball of
+ * ball_on_plate.  src: where a slot's pose comes from - TG_BP_LINK the robot's moving link `link` (-1: the fixed base), TG_BP_WORLD none (center is
+ * in the world), TG_BP_EDGE the episode's edge (stim_pos, yaw = edge angle), TG_BP_BODY the free body's pose, TG_BP_SPHERE its position only with the
+ * box scaled to the episode's radius (object_roll), TG_BP_BALL the ball of ball_on_plate. */
+enum { TG_BP_NONE = 0, TG_BP_LINK = 1, TG_BP_WORLD = 2, TG_BP_EDGE = 3, TG_BP_BODY = 4, TG_BP_SPHERE = 5, TG_BP_BALL = 6 };
+#define TG_BP_SLOTS 22
+typedef struct {
+    double center[3], rot[9], half[3];      /* the box in the frame `src` names */
+    int32_t src;                            /* TG_BP_* (TG_BP_NONE: empty slot, or a link the reference filters out) */
+    int32_t link;                           /* TG_BP_LINK: moving link index, -1 = base */
+    int32_t body;                           /* boxes of one body are never paired */
+    int32_t is_static;                      /* two static boxes are never paired (robot base, table, plane, edge) */
+    int32_t hull_off, hull_n;               /* TG_BP_LINK: the link's convex-hull vertices (moving-link frame) in `hull_verts`, for stage 3 */
+    uint32_t expected;                      /* bit k: the pair (this slot, slot k) is one the solver has rows for */
+    int32_t pad_;
+} tg_bp_box;
+typedef struct {
+    tg_bp_box box[TG_BP_SLOTS];
+    double margin;                          /* added to every half extent: what a box travels inside one env step + contactBreakingThreshold */
+    double hull_margin;                     /* Bullet inflates a URDF convex hull by gUrdfDefaultCollisionMargin = 0.001 */
+    double sphere_half;                     /* half extent of the TG_BP_SPHERE / TG_BP_BALL asset boxes (= the asset's radius) */
+    double ball_radius;                     /* TG_BP_BALL: the ball's radius in the world */
+    int32_t n_hull_verts;
+    int32_t every_step;                     /* 1: the check is a node of every tg_step / tg_step_random (after the step kernel, before any reset) */
+    const double* hull_verts;               /* host, [n_hull_verts][3] */
+} tg_broadphase;
+int tg_set_broadphase(tg_ctx* ctx, const tg_broadphase* guard);        /* NULL: forget the guard */
+int tg_check_broadphase(tg_ctx* ctx);                                   /* enqueue one check of the current state on the context's stream */
+int tg_get_broadphase_totals(tg_ctx* ctx, int64_t* checks, int64_t* pairs, int64_t* hits);   /* env-checks run, stage-1 pairs and hits found since tg_set_broadphase (synchronises) */
 /* Draws the current state of every env now (render() in the other observation modes). Asynchronous. */
 int tg_render_scene(tg_ctx* ctx);
 /* uint8 [num_envs][H][W][3]; terminal != 0: the image of the last step of the envs that finished (rows valid where done). */

@@ -1,0 +1,184 @@
+"""CPU oracle of the broadphase guard (TEST INFRASTRUCTURE ONLY - see oracle/minibullet.h; the product is csrc/tg_broadphase.hip).
+
+What it restates.  PyBullet's stepSimulation (robots/arms/robot.py:141) runs Bullet's broadphase over the world AABBs of every collision
+object and hands every overlapping pair of DIFFERENT bodies, of which at least one is not static and neither is filtered out, to the
+narrowphase.  This repo's contact sets are fixed per env from the reference's collision filters (PARITY_ASSUMPTIONS A8, A23-A27, A30, A39):
+the guard checks, per env and env step, that no OTHER pair's AABBs overlap - i.e. that the contacts PyBullet would generate are the ones the
+solver has rows for.  AABB overlap is necessary for a contact, not sufficient: a raised flag means "PyBullet's narrowphase would look at this
+pair", zero flags mean "no unmodelled contact is possible".
+
+Model (identical on the device):
+  * one oriented box per URDF link with <collision> geometry (tactile_gym_amd/assets/collision/*.npz: the box of the link's collision
+    geometries in the link frame, margins as btCollisionShape::getAabb adds them), riding on its moving link / its free body;
+  * world AABB of a box: centre R c + p, half extents |R rot| half + MARGIN (the per-step check stands for the step's ticks: MARGIN covers what a
+    box travels inside one env step plus contactBreakingThreshold);
+  * boxes filtered out by the reference (setCollisionFilterGroupMask(..., 0, 0)): the sensor body always, the TacTip adapter of the
+    right_angle / mini_right_angle / forward mountings, the tip when t_s_core == "no_core" (sensors/tactile_sensor.py:46-57); the MG400's
+    link4_1, link4_2, link5, tcp_link, ee_link (robots/arms/mg400/mg400.py:68-72); the heightfield (base_surface_env.py:432); goal and
+    trajectory indicators (base_object_env.py:75, object_push_env.py:249);
+  * pairs: boxes of different bodies, at least one of them on a non-static body (the robot's moving links, the free objects); the robot's
+    base link, the table, the ground plane and the edge stimulus are static (useFixedBase / mass 0);
+  * expected pairs (the solver has rows for them): object_push cube - table, cube - tip; object_roll marble - table, marble - tip;
+    object_balance ball - plate.  Everything else that overlaps is reported.
+Box indices: 0-15 the robot's boxes in URDF link order (assets/collision/<robot>.npz, filtered ones included so that indices are stable), 16
+table, 17 plane, 18 edge stimulus, 19 / 20 the object's boxes (cube | marble | pole base, pole | plate), 21 the ball of ball_on_plate.
+Sort-and-sweep on x (the pairs are found in ascending order of the boxes' lower x bound), then an oriented-box test of the pairs found (sweep())."""
+import os
+
+import numpy as np
+
+_ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tactile_gym_amd", "assets", "collision")
+MARGIN = 0.0015
+HULL_MARGIN = 0.001        # gUrdfDefaultCollisionMargin: Bullet inflates a URDF convex hull by it
+TABLE, PLANE, STIM, OBJ_A, OBJ_B, BALL = 16, 17, 18, 19, 20, 21
+ROBOT, WORLD_TABLE, WORLD_PLANE, WORLD_STIM, BODY_OBJ, BODY_BALL = 0, 1, 2, 3, 4, 5     # body ids
+
+
+def _load(name):
+    z = np.load(os.path.join(_ASSETS, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def filtered_links(arm_type, t_s_name, t_s_type, t_s_core):
+    """Names of the robot's URDF links whose collisions the reference switches off."""
+    off = {f"{t_s_name}_body_link"}                                                       # tactile_sensor.py:51
+    if t_s_name == "tactip" and t_s_type in ("right_angle", "mini_right_angle", "forward"):
+        off.add("tactip_adapter_link")                                                    # :52-54
+    if t_s_core == "no_core":
+        off.add(f"{t_s_name}_tip_link")                                                   # :56-57
+    if arm_type == "mg400":
+        off |= {"link4_1", "link4_2", "link5", "tcp_link", "ee_link"}                     # mg400.py:68-72
+    return off
+
+
+def _aabb(R, p, c, rot, half, scale=1.0):
+    """(lo, hi, obb): the world AABB and the oriented box itself (centre, axes as columns, half extents incl. MARGIN) for the second stage."""
+    ctr = R @ (scale * c) + p
+    axes = R @ rot
+    h = scale * half + MARGIN
+    ext = np.abs(axes) @ h
+    return ctr - ext, ctr + ext, (ctr, axes, h)
+
+
+def obb_overlap(a, b):
+    """Separating-axis test of two oriented boxes (Gottschalk et al. 1996: 3 + 3 face normals, 9 edge cross products; the cross-product axes
+    carry an epsilon so that near-parallel edges do not produce a spurious separating axis).  True = no separating axis = the boxes overlap."""
+    (ca, Aa, ha), (cb, Ab, hb) = a, b
+    Rm = Aa.T @ Ab
+    t = Aa.T @ (cb - ca)
+    Ra = np.abs(Rm) + 1e-9
+    for i in range(3):
+        if abs(t[i]) > ha[i] + Ra[i] @ hb:
+            return False
+    for j in range(3):
+        if abs(t @ Rm[:, j]) > ha @ Ra[:, j] + hb[j]:
+            return False
+    for i in range(3):
+        i1, i2 = (i + 1) % 3, (i + 2) % 3
+        for j in range(3):
+            j1, j2 = (j + 1) % 3, (j + 2) % 3
+            ra = ha[i1] * Ra[i2, j] + ha[i2] * Ra[i1, j]
+            rb = hb[j1] * Ra[i, j2] + hb[j2] * Ra[i, j1]
+            if abs(t[i2] * Rm[i1, j] - t[i1] * Rm[i2, j]) > ra + rb:
+                return False
+    return True
+
+
+def env_boxes(env):
+    """[(index, body, static, lo, hi, obb, hull or None)] of an oracle env (oracle/ref_env.py) in its current state, plus the set of expected index pairs."""
+    cls = type(env).__name__
+    t_s_core = {"OracleObjectPushEnv": "fixed", "OracleObjectRollEnv": "fixed", "OracleEdgeFollowEnv": "no_core",
+                "OracleObjectBalanceEnv": "no_core"}.get(cls, "fixed")                   # e.g. edge_follow_env.py:64, object_push_env.py:60; surface_follow: base_surface_env.py:65
+    rb = _load(f"{env.arm_type}_{env.t_s_type}_{env.t_s_name}")
+    off = filtered_links(env.arm_type, env.t_s_name, env.t_s_type, t_s_core)
+    poses = env.arm.link_poses()
+    out, tip = [], None
+    for i, name in enumerate(rb["names"].tolist()):
+        if name == f"{env.t_s_name}_tip_link":
+            tip = i
+        if name in off:
+            continue
+        l = int(rb["link"][i])
+        R, p = (np.eye(3), np.zeros(3)) if l < 0 else poses[l]
+        hull = rb["hull_verts"][rb["hull_off"][i]:rb["hull_off"][i + 1]] @ R.T + p       # stage 3: the link's convex hull in the world
+        out.append((i, ROBOT, l < 0, *_aabb(R, p, rb["center"][i], rb["rot"][i], rb["half"][i]), hull))
+    for idx, body, name in ((TABLE, WORLD_TABLE, "table"), (PLANE, WORLD_PLANE, "plane")):
+        b = _load(name)
+        out.append((idx, body, True, *_aabb(np.eye(3), b["base_pos"], b["center"][0], b["rot"][0], b["half"][0]), None))
+    expected = set()
+    if cls == "OracleEdgeFollowEnv":
+        b = _load("short_edge" if env.arm_type == "mg400" else "long_edge")
+        out.append((STIM, WORLD_STIM, True, *_aabb(env.edge_rot, env.edge_pos, b["center"][0], b["rot"][0], b["half"][0]), None))
+    elif cls == "OracleObjectPushEnv":
+        b = _load("cube")
+        p, R = env.cube_pose()
+        out.append((OBJ_A, BODY_OBJ, False, *_aabb(R, p, b["center"][0], b["rot"][0], b["half"][0]), None))
+        expected = {(TABLE, OBJ_A), (tip, OBJ_A)}
+    elif cls == "OracleObjectRollEnv":
+        b = _load("sphere")
+        p, _ = env.ball_pose()                                                            # a sphere: its box does not turn with it
+        out.append((OBJ_A, BODY_OBJ, False, *_aabb(np.eye(3), p, b["center"][0], np.eye(3), b["half"][0], scale=float(env.scene.radius) / float(b["half"][0][0])), None))
+        expected = {(TABLE, OBJ_A), (tip, OBJ_A)}
+    elif cls == "OracleObjectBalanceEnv":
+        ball = getattr(env, "ball", None) is not None and env.modes.get("object_mode") == "ball_on_plate"
+        b = _load("round_plate" if ball else "pole")
+        p, R = env.body_pose()
+        for k in range(len(b["names"])):
+            out.append((OBJ_A + k, BODY_OBJ, False, *_aabb(R, p, b["center"][k], b["rot"][k], b["half"][k]), None))
+        if ball:
+            s = _load("balance_ball")
+            out.append((BALL, BODY_BALL, False, *_aabb(np.eye(3), np.array(env.ball.pos[:]), s["center"][0], np.eye(3), s["half"][0],
+                                                       scale=float(env.ball.radius) / float(s["half"][0][0])), None))
+            expected = {(OBJ_A, BALL)}
+    return out, expected
+
+
+def sweep(boxes, expected):
+    """Stage 1, Bullet's broadphase: sort the boxes by their lower x bound and sweep - a box is tested against the boxes behind it in that order
+    while their lower bound is not past its upper bound; the y and z intervals decide.  The pairs found (different bodies, not both static, not
+    an expected pair) are what the narrowphase would be handed.  Stage 2, the guard's own narrowing: such a pair counts as a HIT only if the two
+    ORIENTED boxes overlap as well (a long diagonal link's world AABB is mostly air) and, for a robot link against the table, if the link's
+    convex hull reaches the table top (stage 3).  Returns dict(pairs = number of stage-1 pairs, hits =
+    number of stage-2 hits, mask = bit mask of the boxes involved in hits, hit_pairs, aabb_pairs)."""
+    order = sorted(range(len(boxes)), key=lambda k: (boxes[k][3][0], boxes[k][0]))
+    out = dict(pairs=0, hits=0, mask=0, hit_pairs=[], aabb_pairs=[])
+    for a in range(len(order)):
+        ia, body_a, static_a, lo_a, hi_a, obb_a, hull_a = boxes[order[a]]
+        for b in range(a + 1, len(order)):
+            ib, body_b, static_b, lo_b, hi_b, obb_b, hull_b = boxes[order[b]]
+            if lo_b[0] > hi_a[0]:
+                break
+            if body_a == body_b or (static_a and static_b):
+                continue
+            if lo_a[1] > hi_b[1] or lo_b[1] > hi_a[1] or lo_a[2] > hi_b[2] or lo_b[2] > hi_a[2]:
+                continue
+            pair = (min(ia, ib), max(ia, ib))
+            if pair in expected:
+                continue
+            out["pairs"] += 1
+            out["aabb_pairs"].append(pair)
+            hit = obb_overlap(obb_a, obb_b)
+            if hit and TABLE in pair and min(pair) < 16:
+                # stage 3, a robot link against the table: a box bounds a round link loosely (the UR5's upper arm is a 6 cm cylinder about its
+                # joint: its box's corners reach 2.5 cm further) - the link's CONVEX HULL (what Bullet collides) decides: its lowest vertex over
+                # the table top, less the hull's 1 mm collision margin and the guard's margins
+                hull, (tl, th) = (hull_a, (lo_b, hi_b)) if ib == TABLE else (hull_b, (lo_a, hi_a))
+                over = hull[(hull[:, 0] >= tl[0]) & (hull[:, 0] <= th[0]) & (hull[:, 1] >= tl[1]) & (hull[:, 1] <= th[1])]
+                hit = len(over) > 0 and float(over[:, 2].min()) - HULL_MARGIN - MARGIN <= th[2]
+            if hit:
+                out["hits"] += 1
+                out["mask"] |= (1 << ia) | (1 << ib)
+                out["hit_pairs"].append(pair)
+    out["hit_pairs"].sort(), out["aabb_pairs"].sort()
+    return out
+
+
+def check(env):
+    """The guard's verdict on the env's current state (see sweep)."""
+    return sweep(*env_boxes(env))
+
+
+def box_names(arm_type, t_s_type, t_s_name):
+    names = {i: n for i, n in enumerate(_load(f"{arm_type}_{t_s_type}_{t_s_name}")["names"].tolist())}
+    names.update({TABLE: "table", PLANE: "plane", STIM: "edge stimulus", OBJ_A: "object", OBJ_B: "object (2nd box)", BALL: "ball"})
+    return names

@@ -110,6 +110,20 @@ class TgConfig(C.Structure):
     ]
 
 
+BP_NONE, BP_LINK, BP_WORLD, BP_EDGE, BP_BODY, BP_SPHERE, BP_BALL = range(7)     # tg_bp_box.src
+BP_SLOTS = 22
+
+
+class TgBpBox(C.Structure):
+    _fields_ = [("center", _d3), ("rot", _d9), ("half", _d3), ("src", C.c_int32), ("link", C.c_int32), ("body", C.c_int32), ("is_static", C.c_int32),
+                ("hull_off", C.c_int32), ("hull_n", C.c_int32), ("expected", C.c_uint32), ("pad_", C.c_int32)]
+
+
+class TgBroadphase(C.Structure):
+    _fields_ = [("box", TgBpBox * BP_SLOTS), ("margin", C.c_double), ("hull_margin", C.c_double), ("sphere_half", C.c_double), ("ball_radius", C.c_double),
+                ("n_hull_verts", C.c_int32), ("every_step", C.c_int32), ("hull_verts", C.POINTER(C.c_double))]
+
+
 class TgStateView(C.Structure):
     _fields_ = [
         ("q", C.POINTER(C.c_double)), ("qd", C.POINTER(C.c_double)), ("qd_target", C.POINTER(C.c_double)),
@@ -124,6 +138,7 @@ class TgStateView(C.Structure):
         ("contact_count", C.POINTER(C.c_int32)), ("contact_ids", C.POINTER(C.c_int32)),
         ("ball_pos", C.POINTER(C.c_double)), ("ball_linvel", C.POINTER(C.c_double)), ("ball_angvel", C.POINTER(C.c_double)),
         ("ball_impulse", C.POINTER(C.c_double)),
+        ("broadphase_pairs", C.POINTER(C.c_int32)), ("broadphase_hits", C.POINTER(C.c_int32)), ("broadphase_mask", C.POINTER(C.c_int32)),
         ("solver_sweeps", C.POINTER(C.c_int32)),
     ]
 
@@ -180,6 +195,9 @@ SYMBOLS = {
     "tg_copy_obs_oracle_terminal": (C.c_int, [_ctx, _fp]),
     "tg_set_scene": (C.c_int, [_ctx, C.POINTER(TgScene)]),
     "tg_render_scene": (C.c_int, [_ctx]),
+    "tg_set_broadphase": (C.c_int, [_ctx, C.POINTER(TgBroadphase)]),
+    "tg_check_broadphase": (C.c_int, [_ctx]),
+    "tg_get_broadphase_totals": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tg_get_obs_visual": (C.c_int, [_ctx, _vpp, C.c_int32]),
     "tg_copy_obs_visual": (C.c_int, [_ctx, _u8p, C.c_int32]),
     "tg_get_obs_feature": (C.c_int, [_ctx, _vpp, C.POINTER(C.c_int32), C.c_int32]),

@@ -6,7 +6,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-OUT=../lib
+OUT=${TG_OUT:-../lib}      # TG_OUT: another output directory (audit / A-B builds: TG_EXTRA_FLAGS=... TG_OUT=../lib_audit, loaded with TG_HIP_LIBRARY)
 mkdir -p "$OUT"
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value ${TG_EXTRA_FLAGS:-}"
 # TG_INCREMENTAL=1 (development): keep an object whose translation unit and every header are older than it
@@ -29,8 +29,9 @@ cc tg_exchange & p6=$!
 cc tg_narrow_test & p7=$!
 cc tg_fused & p8=$!
 cc tg_selftest -ffp-contract=off & p9=$!
-wait $p1; wait $p2; wait $p3; wait $p4; wait $p5; wait $p6; wait $p7; wait $p8; wait $p9    # each wait returns its job's status: a failed translation unit fails the build (set -e)
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" "$OUT/tg_scene.o" "$OUT/tg_exchange.o" "$OUT/tg_fused.o" -o "$OUT/libtactile_gym_hip.so"
+cc tg_broadphase -ffp-contract=off & p10=$!
+wait $p1; wait $p2; wait $p3; wait $p4; wait $p5; wait $p6; wait $p7; wait $p8; wait $p9; wait $p10    # each wait returns its job's status: a failed translation unit fails the build (set -e)
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" "$OUT/tg_scene.o" "$OUT/tg_exchange.o" "$OUT/tg_fused.o" "$OUT/tg_broadphase.o" -o "$OUT/libtactile_gym_hip.so"
 # test infrastructure (include/tactile_gym_hip_test.h): device self-tests of the raster's division / block test and of the wave-mapped GJK / EPA
 $HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_narrow_test.o" "$OUT/tg_selftest.o" -o "$OUT/libtactile_gym_hip_test.so"
 echo "built $OUT/libtactile_gym_hip.so $OUT/libtactile_gym_hip_test.so"

@@ -25,6 +25,7 @@
 #include "tg_noise.h"
 #include "tg_raster.h"
 #include "tg_exchange.h"
+#include "tg_broadphase.h"
 
 namespace tg {
 
@@ -376,6 +377,12 @@ struct tg_ctx {
     bool tmpl_ready = false;               // object_balance: State.reset_tmpl has been (or will have been, in stream order) filled by a full reset
     hipStream_t capture_stream = nullptr;   // the step graph is captured here, never on the stream work runs on (see tg_step)
     void *d_robot = nullptr, *d_const = nullptr;   // DevRobot<T>, EnvConst<T>
+    // broadphase guard (tg_set_broadphase; tg_broadphase.hip): device scene + hull vertices, per-env results [3][n], totals {env-checks, pairs, hits}
+    tg::BpScene* d_bp = nullptr;
+    double* d_bp_hull = nullptr;
+    int32_t* d_bp_out = nullptr;
+    unsigned long long* d_bp_tot = nullptr;
+    bool bp_every_step = false;
     tg::State st{};
     tg::RasterParams rp{};
     float *d_nodef_dep = nullptr, *d_verts = nullptr, *d_soup = nullptr, *d_actions = nullptr;
@@ -920,11 +927,23 @@ static void bank_refill(tg_ctx* c) {
             (void)hipEventRecord(c->ev_bank, c->stream);
             (void)hipStreamWaitEvent(c->bank_stream, c->ev_bank, 0);
         } else {
+            // (the ring's events exist since tg_create.  If another thread of the process is capturing in global mode - torch.cuda.graph's default -
+            //  an event record / synchronise from here is illegal: the call fails with hipErrorStreamCapture*; the error is cleared and this visit
+            //  falls back to the cross-stream wait, which is legal under any capture mode - ADVICE r5)
             const unsigned long long k = c->bank_visits++;
-            hipEvent_t& ev = c->ev_bank_ring[k % tg_ctx::kBankRing];
-            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; (void)hipGetLastError(); return; }
-            (void)hipEventRecord(ev, c->stream);
-            if (k >= tg_ctx::kBankLag) (void)hipEventSynchronize(c->ev_bank_ring[(k - tg_ctx::kBankLag) % tg_ctx::kBankRing]);
+            hipEvent_t ev = c->ev_bank_ring[k % tg_ctx::kBankRing];
+            bool paced = ev != nullptr && hipEventRecord(ev, c->stream) == hipSuccess;
+            if (paced && k >= tg_ctx::kBankLag) {
+                hipEvent_t old = c->ev_bank_ring[(k - tg_ctx::kBankLag) % tg_ctx::kBankRing];
+                paced = old != nullptr && hipEventSynchronize(old) == hipSuccess;
+            }
+            if (!paced) {
+                (void)hipGetLastError();
+                if (hipEventRecord(c->ev_bank, c->stream) != hipSuccess || hipStreamWaitEvent(c->bank_stream, c->ev_bank, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return;                     // no ordering to be had this visit: no refill (finished envs reset on the spot, same results)
+                }
+            }
         }
     }
     if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
@@ -1269,6 +1288,7 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
             if (getenv("TG_BANK_PRIO0")) lo = 0;
             TG_HIP(hipStreamCreateWithPriority(&c->bank_stream, hipStreamNonBlocking, lo));
             TG_HIP(hipEventCreateWithFlags(&c->ev_bank, hipEventDisableTiming)); TG_HIP(hipEventCreateWithFlags(&c->ev_bank_done, hipEventDisableTiming));
+            for (int k = 0; k < tg_ctx::kBankRing; ++k) TG_HIP(hipEventCreateWithFlags(&c->ev_bank_ring[k], hipEventDisableTiming));   // the refill's pacing markers (bank_refill)
             c->aux.enabled = 1;
             c->bank_mode = want;
             BankDev hb{c->bk, c->aux};
@@ -1334,6 +1354,10 @@ int tg_destroy(tg_ctx* c) {
     drop_step_graphs(c);
     for (int k = 0; k < 2; ++k) if (c->drawn_ext[k]) (void)hipFree(c->drawn_ext[k]);
     if (c->d_draw) (void)hipFree(c->d_draw);
+    if (c->d_bp) (void)hipFree(c->d_bp);
+    if (c->d_bp_hull) (void)hipFree(c->d_bp_hull);
+    if (c->d_bp_out) (void)hipFree(c->d_bp_out);
+    if (c->d_bp_tot) (void)hipFree(c->d_bp_tot);
     if (c->d_kt) (void)hipFree(c->d_kt);
     if (c->d_kt_acc) (void)hipFree(c->d_kt_acc);
     State& s = c->st;
@@ -1436,6 +1460,8 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
 #undef CALL
         }
     }
+    // broadphase guard: the state the step kernel left, before any reset teleports a finished env (tg_set_broadphase, every_step)
+    if (c->d_bp && c->bp_every_step) (void)launch_broadphase(c->cfg.physics_dtype, c->robot.topology, c->cfg.num_envs, c->stream, c->d_robot, c->d_bp, c->st, c->d_bp_out, c->d_bp_tot);
     // visual observation modes: the step's image of every env before any reset touches the state; the envs that finished are redrawn
     // after their reset below (their step image moves to the terminal buffer)
     if (c->scene_every_step) scene_draw(c, nullptr, false);
@@ -1602,6 +1628,7 @@ int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restar
 
 int tg_set_obs_targets(tg_ctx* c, int32_t count, void* const* dev_ptrs) {
     if (!c || count < 0 || count > 2 || (count > 0 && !dev_ptrs)) return fail(-1, "tg_set_obs_targets: bad argument");
+    for (int k = 0; k < count; ++k) if (!dev_ptrs[k]) return fail(-1, "tg_set_obs_targets: NULL target");   // (every argument is checked before anything is changed)
     TG_ENTER(c);
     TG_HIP(hipStreamSynchronize(c->stream));
     for (int t = 1; t < 3; ++t) {        // the old targets' graphs name their buffers: gone with them
@@ -1612,7 +1639,7 @@ int tg_set_obs_targets(tg_ctx* c, int32_t count, void* const* dev_ptrs) {
     const size_t regions = (c->rp.W % 128 == 0 && c->rp.H % 128 == 0) ? (size_t)(c->rp.W / 128) * (c->rp.H / 128) : 0;
     for (int k = 0; k < 2; ++k) {
         c->obs_ext[k] = k < count ? (uint8_t*)dev_ptrs[k] : nullptr;
-        if (k < count && !dev_ptrs[k]) return fail(-1, "tg_set_obs_targets: NULL target");
+        if (k < count && c->rp.drawn != nullptr && regions == 0) return fail(-3, "tg_set_obs_targets: a changed-block record without 128-pixel regions (internal)");
         if (k < count && c->rp.drawn != nullptr) {   // a changed-block record of its own: nothing in that buffer is known to hold the untouched-sensor image
             if (!c->drawn_ext[k]) TG_HIP(hipMalloc(&c->drawn_ext[k], (size_t)c->cfg.num_envs * regions * 8));
             TG_HIP(hipMemset(c->drawn_ext[k], 0xFF, (size_t)c->cfg.num_envs * regions * 8));
@@ -1624,6 +1651,65 @@ int tg_select_obs_target(tg_ctx* c, int32_t index) {
     if (!c || index < 0 || index > 2 || (index > 0 && c->obs_ext[index - 1] == nullptr)) return fail(-1, "tg_select_obs_target: no such target");
     c->obs_sel = index;
     c->step_graph = c->step_graph_t[index];
+    return 0;
+}
+
+int tg_set_broadphase(tg_ctx* c, const tg_broadphase* g) {
+    if (!c) return fail(-1, "NULL argument");
+    TG_ENTER(c);
+    TG_HIP(hipStreamSynchronize(c->stream));
+    drop_step_graphs(c);                         // the guard is (or stops being) a node of the step graphs
+    if (c->d_bp) { (void)hipFree(c->d_bp); c->d_bp = nullptr; }
+    if (c->d_bp_hull) { (void)hipFree(c->d_bp_hull); c->d_bp_hull = nullptr; }
+    c->bp_every_step = false;
+    if (!g) return 0;
+    if (g->n_hull_verts < 0 || (g->n_hull_verts > 0 && !g->hull_verts) || !(g->margin >= 0.0) || !(g->sphere_half > 0.0))
+        return fail(-1, "tg_set_broadphase: bad argument");
+    const int N = c->robot.ndof;
+    BpScene h{};
+    for (int k = 0; k < TG_BP_SLOTS; ++k) {
+        const tg_bp_box& b = g->box[k];
+        if (b.src < TG_BP_NONE || b.src > TG_BP_BALL) return fail(-1, "tg_set_broadphase: unknown pose source");
+        if (b.src == TG_BP_LINK && (b.link < -1 || b.link >= N)) return fail(-1, "tg_set_broadphase: link index out of range");
+        if (b.src == TG_BP_LINK && (b.hull_off < 0 || b.hull_n < 0 || b.hull_off + b.hull_n > g->n_hull_verts)) return fail(-1, "tg_set_broadphase: hull range out of bounds");
+        if ((b.src == TG_BP_BODY || b.src == TG_BP_SPHERE) && c->st.body_pos == nullptr) return fail(-1, "tg_set_broadphase: this env has no free body");
+        if (b.src == TG_BP_BALL && c->st.ball == nullptr) return fail(-1, "tg_set_broadphase: this env has no ball");
+        if (b.src == TG_BP_EDGE && c->cfg.env_kind != TG_ENV_EDGE_FOLLOW) return fail(-1, "tg_set_broadphase: TG_BP_EDGE outside edge_follow");
+        h.box[k] = b;
+    }
+    h.margin = g->margin; h.hull_margin = g->hull_margin; h.sphere_half = g->sphere_half; h.ball_radius = g->ball_radius;
+    for (int k = 0; k < 3; ++k) h.stim_pos[k] = c->cfg.stim_pos[k];
+    h.table_slot = 16; h.has_ball = c->st.ball != nullptr;
+    const size_t hb = (size_t)std::max(g->n_hull_verts, 1) * 3 * 8;
+    TG_HIP(hipMalloc(&c->d_bp_hull, hb));
+    if (g->n_hull_verts > 0) TG_HIP(hipMemcpy(c->d_bp_hull, g->hull_verts, (size_t)g->n_hull_verts * 3 * 8, hipMemcpyHostToDevice));
+    h.hull = c->d_bp_hull;
+    TG_HIP(hipMalloc(&c->d_bp, sizeof h)); TG_HIP(hipMemcpy(c->d_bp, &h, sizeof h, hipMemcpyHostToDevice));
+    const size_t ob = (size_t)3 * c->cfg.num_envs * 4;
+    if (!c->d_bp_out) TG_HIP(hipMalloc(&c->d_bp_out, ob));
+    if (!c->d_bp_tot) TG_HIP(hipMalloc(&c->d_bp_tot, 3 * 8));
+    TG_HIP(hipMemset(c->d_bp_out, 0, ob)); TG_HIP(hipMemset(c->d_bp_tot, 0, 3 * 8));
+    c->bp_every_step = g->every_step != 0;
+    return 0;
+}
+int tg_check_broadphase(tg_ctx* c) {
+    if (!c) return fail(-1, "NULL argument");
+    if (!c->d_bp) return fail(-1, "tg_check_broadphase: no guard (tg_set_broadphase)");
+    TG_ENTER(c);
+    if (launch_broadphase(c->cfg.physics_dtype, c->robot.topology, c->cfg.num_envs, c->stream, c->d_robot, c->d_bp, c->st, c->d_bp_out, c->d_bp_tot))
+        return fail(-3, "tg_check_broadphase: unsupported topology");
+    TG_HIP(hipGetLastError());
+    return 0;
+}
+int tg_get_broadphase_totals(tg_ctx* c, int64_t* checks, int64_t* pairs, int64_t* hits) {
+    if (!c || !checks || !pairs || !hits) return fail(-1, "NULL argument");
+    *checks = *pairs = *hits = 0;
+    if (!c->d_bp_tot) return 0;
+    TG_ENTER(c);
+    unsigned long long t[3];
+    TG_HIP(hipMemcpyAsync(t, c->d_bp_tot, sizeof t, hipMemcpyDeviceToHost, c->stream));
+    TG_HIP(hipStreamSynchronize(c->stream));
+    *checks = (int64_t)t[0]; *pairs = (int64_t)t[1]; *hits = (int64_t)t[2];
     return 0;
 }
 
@@ -2018,6 +2104,14 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
     if (v->reset_ticks && (rc = fetch_soa(c, c->st.reset_ticks, 1, v->reset_ticks))) return rc;
     if (v->rng_state && (rc = fetch_soa(c, c->st.rng, 1, v->rng_state))) return rc;
     if (v->solver_sweeps && (rc = fetch_soa(c, c->st.sweeps, 1, v->solver_sweeps))) return rc;
+    {   // broadphase guard results of the last check (zeros without a guard)
+        int32_t* dst[3] = {v->broadphase_pairs, v->broadphase_hits, v->broadphase_mask};
+        for (int k = 0; k < 3; ++k) {
+            if (!dst[k]) continue;
+            if (c->d_bp_out) { if ((rc = fetch_soa(c, c->d_bp_out + (size_t)k * c->cfg.num_envs, 1, dst[k]))) return rc; }
+            else memset(dst[k], 0, (size_t)c->cfg.num_envs * 4);
+        }
+    }
     if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
         if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
         if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;

@@ -1276,7 +1276,11 @@ template <typename T, int TOPO, bool POS, bool BALL = false>
 __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                   const float* __restrict__ actions) {
     // (no KtScope here: with it the ball_on_plate instantiation - 134 spilled VGPRs, > 1000 spilled SGPRs - came out of hipcc 7.2 producing NaNs in
-    //  random envs, tests/test_gpu_config_scale.py::test_long_horizon_ball_on_plate_matches_oracle; its duration is taken from HIP events)
+    //  random envs, tests/test_gpu_config_scale.py::test_long_horizon_ball_on_plate_matches_oracle; its duration is taken from HIP events.
+    //  -DTG_KT_BODY puts it back: the A/B builds of profiles/r6_nan_audit.txt)
+#ifdef TG_KT_BODY
+    KtScope kt_scope_(st.kt);
+#endif
     constexpr int N = Topo<TOPO>::N;
     const DevRobot<T>& m = *mp;
     const EnvConst<T>& c = *cp;
@@ -1496,6 +1500,9 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
                                                    const uint8_t* __restrict__ mask) {
     // (no KtScope here: with it the ball_on_plate instantiation - 134 spilled VGPRs, > 1000 spilled SGPRs - came out of hipcc 7.2 producing NaNs in
     //  random envs, tests/test_gpu_config_scale.py::test_long_horizon_ball_on_plate_matches_oracle; its duration is taken from HIP events)
+#ifdef TG_KT_BODY
+    KtScope kt_scope_(st.kt);
+#endif
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= cp->num_envs) return;
     if (mask != nullptr && mask[env] == 0) return;

@@ -135,7 +135,11 @@ class TileDownload:
         # into this pinned host buffer - device-visible at its own address - so a fetch is one launch and one synchronisation; until round 4 it
         # was the launch, three copies (message, rewards, dones) and the synchronisation, each copy a DMA command of its own behind the kernel.
         packed, obs_bytes, _ = venv.packed_torch()
-        self.tail = packed[obs_bytes:]                       # [reward f32[n] | done u8[n] | pad | feature]: tg_get_packed_outputs' layout
+        # [reward f32[n] | done u8[n]] of tg_get_packed_outputs' layout - NOT the extended_feature block behind them (with it the tail
+        # passed tg_pack_tiles' 1 MiB limit at ~19.7 k envs of a 12-float feature and every fetch raised; the feature has its own copy, feature_numpy)
+        self.tail = packed[obs_bytes:obs_bytes + 5 * n]
+        if self.tail.numel() > (1 << 20):
+            raise ValueError(f"obs_transfer='tiles': {n} envs need a {self.tail.numel()}-byte reward / done block, tg_pack_tiles carries at most 1 MiB")
         self.host_pk = torch.empty(self.cap + self.tail.numel(), dtype=torch.uint8).pin_memory()
         self.host_np = self.host_pk.numpy()
         self.rew_host = self.host_np[self.cap:self.cap + 4 * n].view(np.float32)

@@ -229,7 +229,12 @@ class ShardedVecEnv:
     rank's results into one of two slots, starts the exchange asynchronously and returns; rank 0 is handed the batch of
     the PREVIOUS step (complete by then), i.e. the learner side runs one step behind the simulators, and flush() waits for the
     last exchange and returns its batch.  With overlap=False every step() returns its own gathered batch (synchronous VecEnv).
-    A batch handed out stays valid until the next step() / reset() call."""
+    A batch handed out stays valid until the next step() / reset() call.
+
+    READ-ONLY on rank 0 with the ipc transport (exchange_info()["rank0_draws_into_batch"]): rank 0's block of each of the two alternating
+    gathered batches IS the env library's render target (tg_set_obs_targets) - the block raster's persistent, incrementally updated image buffer,
+    of which only the changed 16 x 16 blocks are rewritten per step - so the gathered tactile batch must not be modified in place (copy before
+    augmenting; until round 5 that block was a copy).  venv.set_obs_guard(True) checks it per target."""
 
     def __init__(self, local, dist=None, root=0, overlap=False, force_collective=False, payload="auto", transport="collective", timeout_ms=20000):
         import torch

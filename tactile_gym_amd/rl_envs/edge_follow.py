@@ -113,6 +113,8 @@ class EdgeFollowVecEnv(TactileVecEnv):
         self.env_modes = modes
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
+                         guard_spec={"arm_type": modes["arm_type"], "t_s_core": "no_core",       # edge_follow_env.py:64; the edge: :218-235
+                                     "edge": "short_edge" if modes["arm_type"] == "mg400" else "long_edge"},
                          scene_spec={"arm_type": modes["arm_type"], "camera":                     # setup_rgb_obs_camera_params, edge_follow_env.py:176-195
                                      (([-0.20, 0.0, -0.25], 0.85) if modes["arm_type"] == "mg400" else ([0.35, 0.0, -0.25], 0.75)) + (90.0, -35.0, 75.0, 0.1, 100.0)})
 

@@ -120,6 +120,9 @@ class ObjectBalanceVecEnv(TactileVecEnv):
         act_dim = {"xy": 2, "xyz": 3, "RxRy": 2, "xyRxRy": 4}[modes["movement_mode"]]           # :565-576
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=act_dim, oracle_dim=26,
+                         guard_spec={"arm_type": modes["arm_type"], "t_s_core": "no_core",       # object_balance_env.py:54
+                                     "obj": "round_plate" if modes["object_mode"] == "ball_on_plate" else "pole",
+                                     "ball_radius": cfg.ball_radius if modes["object_mode"] == "ball_on_plate" else None},
                          scene_spec={"arm_type": modes["arm_type"], "camera": ([-0.1, 0.0, 0.25], 1.0, 90.0, -10.0, 75.0, 0.1, 100.0)})   # :162-171
 
     def oracle_obs_host(self):

@@ -172,6 +172,7 @@ class ObjectPushVecEnv(TactileVecEnv):
         act_dim = {"y": 1, "yRz": 2, "xyRz": 3, "TyRz": 2, "TxTyRz": 3}[modes["movement_mode"]]  # :631-644
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=act_dim, oracle_dim=30, feature_dim=12,
+                         guard_spec={"arm_type": modes["arm_type"], "t_s_core": "fixed", "obj": "cube", "every_step": True},   # object_push_env.py:60
                          scene_spec={"arm_type": modes["arm_type"], "camera": ([0.1, 0.0, -0.35], 1.0, 90.0, -45.0, 75.0, 0.1, 100.0)})   # :170-179
 
     def oracle_obs_host(self):

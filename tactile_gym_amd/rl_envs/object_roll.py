@@ -112,6 +112,7 @@ class ObjectRollVecEnv(TactileVecEnv):
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=2, oracle_dim=34, feature_dim=3,
+                         guard_spec={"arm_type": modes["arm_type"], "t_s_core": "fixed", "obj": "sphere", "every_step": True},   # object_roll_env.py:56
                          scene_spec={"arm_type": modes["arm_type"], "camera": ([0.75, 0.0, 0.00775], 0.01, 90.0, 0.0, 75.0, 0.01, 100.0)})   # :145-154                                # get_extended_feature_array :409-415
 
     def feature_numpy(self, terminal=False):

@@ -121,6 +121,7 @@ class SurfaceFollowAutoVecEnv(TactileVecEnv):
         act_dim = {"yz": 1, "xyz": 1, "yzRx": 2, "xyzRxRy": 3}[modes["movement_mode"]]          # surface_follow_auto_env.py:96-107
         super().__init__(cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=act_dim, oracle_dim=20,
+                         guard_spec={"arm_type": modes["arm_type"], "t_s_core": "fixed"},   # base_surface_env.py:65; the heightfield's collisions are off (:432)
                          scene_spec={"arm_type": modes["arm_type"], "body_rgb": (0, 0, 255), "camera":    # base_surface_env.py:208-232, :431
                                      (([0.16, 0.0, 0.14], 0.45, -2.0, -30.0) if modes["arm_type"] == "mg400" else ([0.65, 0.0, 0.05], 0.4, 90.0, -30.0)) + (75.0, 0.1, 100.0)})
 
@@ -162,6 +163,7 @@ class SurfaceFollowGoalVecEnv(SurfaceFollowAutoVecEnv):
         act_dim = {"yz": 2, "xyz": 3, "yzRx": 3, "xyzRxRy": 5}[modes["movement_mode"]]          # surface_follow_goal_env.py:112-123
         TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                                act_dim=act_dim, oracle_dim=20, feature_dim=6,
+                               guard_spec={"arm_type": modes["arm_type"], "t_s_core": "fixed"},   # base_surface_env.py:65; the heightfield's collisions are off (:432)
                                scene_spec={"arm_type": modes["arm_type"], "body_rgb": (0, 0, 255), "camera":    # base_surface_env.py:208-232, :431
                                      (([0.16, 0.0, 0.14], 0.45, -2.0, -30.0) if modes["arm_type"] == "mg400" else ([0.65, 0.0, 0.05], 0.4, 90.0, -30.0)) + (75.0, 0.1, 100.0)})
 
@@ -208,6 +210,7 @@ class SurfaceFollowVertVecEnv(SurfaceFollowGoalVecEnv):
         self.min_action, self.max_action = cfg.min_action, cfg.max_action
         TactileVecEnv.__init__(self, cfg, robot, sensor, None, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                                act_dim=2, oracle_dim=20, feature_dim=6,                          # get_act_dim :102-113
+                               guard_spec={"arm_type": modes["arm_type"], "t_s_core": "fixed"},   # base_surface_env.py:65; the heightfield's collisions are off (:432)
                                scene_spec={"arm_type": modes["arm_type"], "body_rgb": (0, 0, 255), "camera":    # base_surface_env.py:208-232, :431
                                      (([0.16, 0.0, 0.14], 0.45, -2.0, -30.0) if modes["arm_type"] == "mg400" else ([0.65, 0.0, 0.05], 0.4, 90.0, -30.0)) + (75.0, 0.1, 100.0)})
 

@@ -735,3 +735,51 @@ def collision_cylinder_of_link(path, link_name):
     g = [c for c in links[link_name].collisions if c.kind == "cylinder"][0]
     Rg, pg = rpy_to_mat(g.origin_rpy), np.asarray(g.origin_xyz, dtype=np.float64)
     return mi, R @ Rg, R @ pg + p, float(g.size[0]), float(g.size[1])
+
+
+# ---------------------------------------------------------------------------------------------------- broadphase guard boxes
+def collision_boxes_of_urdf(path, missing_mesh_aabb=None):
+    """Every URDF link's <collision> geometry as ONE oriented box per link, for the broadphase guard: the axis-aligned box,
+    in the URDF link's own frame, of all the link's collision geometries (margins as Bullet's getAabb adds them, `_geom_aabb_in`), carried
+    into the frame of the MOVING link the URDF link is welded to (-1: the fixed base).  Returns a list of dicts
+    {name, link, center [3], rot [3,3], half [3]}, in URDF link order (the root first), links without collision geometry left out.
+    A robot (revolute / fixed joints) or a welded object (then every box has link -1 and the frame is the root LINK frame)."""
+    links, joints = parse_urdf(path)
+    urdf_dir = os.path.dirname(os.path.abspath(path))
+    children = {j.child for j in joints}
+    root = [n for n in links if n not in children][0]
+    by_parent = {}
+    for j in joints:
+        by_parent.setdefault(j.parent, []).append(j)
+    attach = {root: (-1, np.eye(3), np.zeros(3))}
+    order, n_moving = [root], 0
+
+    def dfs(link):
+        nonlocal n_moving
+        for j in by_parent.get(link, []):
+            mi, R, p = attach[j.parent]
+            Rj, pj = rpy_to_mat(j.rpy), np.asarray(j.xyz, dtype=np.float64)
+            if j.jtype == "fixed":
+                attach[j.child] = (mi, R @ Rj, R @ pj + p)
+            elif j.jtype in ("revolute", "continuous"):
+                attach[j.child] = (n_moving, np.eye(3), np.zeros(3))
+                n_moving += 1
+            else:
+                raise NotImplementedError(j.jtype)
+            order.append(j.child)
+            dfs(j.child)
+
+    dfs(root)
+    out = []
+    for name in order:
+        L = links[name]
+        lo = hi = None
+        for g in L.collisions:
+            a, b = _geom_aabb_in(np.eye(3), np.zeros(3), g, urdf_dir, missing_mesh_aabb)
+            lo = a if lo is None else np.minimum(lo, a)
+            hi = b if hi is None else np.maximum(hi, b)
+        if lo is None:
+            continue
+        mi, R, p = attach[name]
+        out.append(dict(name=name, link=mi, center=R @ (0.5 * (lo + hi)) + p, rot=R.copy(), half=0.5 * (hi - lo)))
+    return out

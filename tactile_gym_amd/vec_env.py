@@ -10,6 +10,7 @@ VecTransposeImage expect) they are copied to host; with `obs_mode="torch"` the t
 zero-copy `torch.uint8` CUDA(HIP) tensor aliasing the library's device buffer.
 """
 import ctypes as C
+import os
 import time
 import warnings
 
@@ -90,7 +91,7 @@ class TactileVecEnv(_VecEnvBase):
     metadata = {"render.modes": ["rgb_array"]}
 
     def __init__(self, cfg, robot, sensor_desc, mesh_desc, observation_mode="tactile", obs_mode="numpy", seed=None, act_dim=None,
-                 oracle_dim=10, feature_dim=0, copy_obs=True, scene_spec=None):
+                 oracle_dim=10, feature_dim=0, copy_obs=True, scene_spec=None, guard_spec=None):
         self._L = capi.lib()
         self.num_envs = int(cfg.num_envs)
         self._cfg, self._robot, self._sensor, self._mesh = cfg, robot, sensor_desc, mesh_desc
@@ -144,10 +145,19 @@ class TactileVecEnv(_VecEnvBase):
         self._views = {}
         self._t_start = time.time()                 # Monitor's t_start (info["episode"]["t"])
         self._lazy_info, self._monitor = True, None
-        self._obs_guard, self._guard_sum = False, None
+        self._obs_guard, self._guard_sum = False, {}
         self._ep_ret = np.zeros(self.num_envs, dtype=np.float32)
         self._ep_len = np.zeros(self.num_envs, dtype=np.int32)
         self._rebinds = 0
+        # broadphase guard (broadphase.py; tg_set_broadphase): guard_spec = {"arm_type", "t_s_core", "edge" | "obj" | "ball_radius", "every_step"};
+        # every_step None = the env's default: on for the contact envs (a 3 us launch in a 1.9 ms step), off elsewhere (check_broadphase() on demand).
+        # TG_BROADPHASE_GUARD=1 / 0 forces it on every step / off for every env (the device test-suite runs with 1).
+        self._guard_spec, self._guard = guard_spec, None
+        if guard_spec is not None and os.environ.get("TG_BROADPHASE_GUARD", "") != "0":
+            every = guard_spec.get("every_step")
+            if os.environ.get("TG_BROADPHASE_GUARD", "") == "1":
+                every = True
+            self.set_broadphase_guard(bool(every))
         if seed is not None:
             self.seed(seed)
 
@@ -216,21 +226,22 @@ class TactileVecEnv(_VecEnvBase):
         the tactile buffer is checksummed after every step and checked before the next one; a caller that wrote into the tensor it was handed
         (in-place augmentation) gets a RuntimeError instead of silently corrupted later frames.  Costs a device reduction and a host
         synchronisation per step."""
-        self._obs_guard, self._guard_sum = bool(on), None
+        self._obs_guard, self._guard_sum = bool(on), {}     # per render target (ADVICE r5: rank 0's direct mode alternates two of them)
 
     def _guard_checksum(self):
         t = self.tactile_torch()
         return int(t.reshape(-1).view(__import__("torch").int64).sum().item())
 
     def _guard_before_step(self):
-        if self._obs_guard and self.obs_mode == "torch" and self._guard_sum is not None and self._guard_checksum() != self._guard_sum:
+        sel = getattr(self, "_obs_sel", 0)          # the target this step draws into: its buffer must still hold what the library last drew there
+        if self._obs_guard and self.obs_mode == "torch" and sel in self._guard_sum and self._guard_checksum() != self._guard_sum[sel]:
             raise RuntimeError("the tactile observation tensor handed out by the last step / reset was modified in place: obs_mode='torch' tensors "
                                "alias the library's buffer, of which only the changed 16 x 16 blocks are rewritten per step (DESIGN.md 4.2).  Copy "
                                "before augmenting in place, or run with TG_RASTER_REWRITE_ALL=1")
 
     def _guard_after_step(self):
         if self._obs_guard and self.obs_mode == "torch":
-            self._guard_sum = self._guard_checksum()
+            self._guard_sum[getattr(self, "_obs_sel", 0)] = self._guard_checksum()
 
     def set_monitor(self, monitor_dir, env_id=None):
         """What `make_vec_env(..., monitor_dir=d)` asks for (sb3_helpers/rl_utils.py:22, 59; read back by stable_baselines3's load_results, which
@@ -634,13 +645,41 @@ class TactileVecEnv(_VecEnvBase):
         return p, rpy, pm.quat_from_euler(rpy), wf.vec(st["body_linvel"]), wf.vec(st["body_angvel"])
 
     # ------------------------------------------------------------------ parity / inspection
+    def set_broadphase_guard(self, every_step=False):
+        """(Re)install the broadphase guard: the check that no pair of collision objects other than the ones the solver has rows for can touch
+        (what PyBullet's broadphase would find, robots/arms/robot.py:141; include/tactile_gym_hip.h: tg_set_broadphase).  every_step: the check is a
+        node of every step's graph; otherwise check_broadphase() runs it on demand.  Results: get_state()["broadphase_pairs" / "_hits" / "_mask"]."""
+        from .broadphase import Guard
+        sp = self._guard_spec
+        if sp is None:
+            raise NotImplementedError("this env has no broadphase guard scene")
+        self._guard = Guard(sp["arm_type"], self._sensor.t_s_name, self._sensor.t_s_type, sp["t_s_core"], edge=sp.get("edge"), obj=sp.get("obj"),
+                            ball_radius=sp.get("ball_radius"), every_step=every_step)
+        capi.check(self._L.tg_set_broadphase(self._ctx, C.byref(self._guard.struct)))
+
+    def check_broadphase(self):
+        """One check of the current state; returns (pairs, hits, mask) int32 [N] each (see set_broadphase_guard)."""
+        if self._guard is None:
+            self.set_broadphase_guard(False)
+        capi.check(self._L.tg_check_broadphase(self._ctx))
+        st = self.get_state()
+        return st["broadphase_pairs"], st["broadphase_hits"], st["broadphase_mask"]
+
+    def broadphase_totals(self):
+        """{"env_checks", "pairs", "hits"} since the guard was installed: env states checked, unexpected pairs Bullet's broadphase would have handed to
+        its narrowphase (world AABBs overlap), and those that survive the oriented-box / hull tests (0 = no unmodelled contact was possible)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        capi.check(self._L.tg_get_broadphase_totals(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return {"env_checks": a.value, "pairs": b.value, "hits": c.value}
+
     def get_state(self):
         """Host copy of the per-env state (tg_get_state)."""
         n, nd = self.num_envs, self.ndof
         out = dict(q=np.zeros((n, nd)), qd=np.zeros((n, nd)), qd_target=np.zeros((n, nd)), tcp_pos=np.zeros((n, 3)),
                    tcp_rpy=np.zeros((n, 3)), edge_ang=np.zeros(n), embed_dist=np.zeros(n), stim_xform=np.zeros((n, 12), np.float32),
                    step_count=np.zeros(n, np.int32), reset_ticks=np.zeros(n, np.int32), rng_state=np.zeros(n, np.uint64),
-                   solver_sweeps=np.zeros(n, np.int32))   # threshold mode (solver_residual_threshold > 0): PGS sweeps of the last step's ticks
+                   solver_sweeps=np.zeros(n, np.int32),   # threshold mode (solver_residual_threshold > 0): PGS sweeps of the last step's ticks
+                   broadphase_pairs=np.zeros(n, np.int32), broadphase_hits=np.zeros(n, np.int32), broadphase_mask=np.zeros(n, np.int32))
         if self._cfg.env_kind == capi.ENV_OBJECT_BALANCE:
             out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
                        gravity_z=np.zeros(n))

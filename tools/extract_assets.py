@@ -21,7 +21,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tactile_gym_amd.urdf_compile import collision_cylinder_of_link, collision_hull_of_link, compile_free_body, compile_urdf, instance_mesh, load_mesh, parse_urdf, rpy_to_mat, visual_instances, visual_meshes_of_link  # noqa: E402
+from tactile_gym_amd.urdf_compile import collision_boxes_of_urdf, collision_cylinder_of_link, collision_hull_of_link, compile_free_body, compile_urdf, instance_mesh, load_mesh, parse_urdf, rpy_to_mat, visual_instances, visual_meshes_of_link  # noqa: E402
 
 REF = os.environ.get("TG_REFERENCE_ASSETS", "/root/reference/tactile_gym/assets")
 OUT = os.path.join(ROOT, "tactile_gym_amd", "assets")
@@ -298,9 +298,59 @@ def scenes():
         _scene("object_" + name, os.path.join(REF, rel))
 
 
+def collision_boxes():
+    """Broadphase guard boxes (tactile_gym_amd/csrc/tg_broadphase.hip, oracle/broadphase.py): one oriented box per URDF link
+    that has <collision> geometry - every robot, the table, the ground plane, the edge stimuli, the free objects - in
+    assets/collision/<name>.npz: names, link (moving link the box rides on; -1 = the body's base), center [k,3], rot [k,3,3], half [k,3].
+    Objects: in the root link's INERTIAL frame (what get / resetBasePositionAndOrientation and this library's body_pos / body_rot speak)."""
+    def write(name, boxes, **extra):
+        save(os.path.join(OUT, "collision", f"{name}.npz"), names=np.array([b["name"] for b in boxes]), link=np.array([b["link"] for b in boxes], dtype=np.int32),
+             center=np.array([b["center"] for b in boxes]).reshape(-1, 3), rot=np.array([b["rot"] for b in boxes]).reshape(-1, 3, 3),
+             half=np.array([b["half"] for b in boxes]).reshape(-1, 3), **extra)
+    for arm, sensor, typ in ROBOTS:
+        urdf = os.path.join(REF, "robot_assets", arm, sensor, f"{arm}_with_{typ}_{sensor}.urdf")
+        if not os.path.isfile(urdf):
+            continue
+        boxes = collision_boxes_of_urdf(urdf, MISSING)
+        # third stage of the guard (robot link against the table top): the convex hull of the link's collision meshes (what Bullet collides: URDF
+        # meshes become convex hulls) in the moving link's frame; a link whose collision is a primitive or a missing blob keeps its box's 8 corners
+        hulls, off = [], [0]
+        for b in boxes:
+            try:
+                _, hv = collision_hull_of_link(urdf, b["name"])
+            except Exception:  # noqa: BLE001 - no mesh (primitive) or a missing large blob
+                sgn = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+                hv = b["center"] + (sgn * b["half"]) @ b["rot"].T
+            hulls.append(hv)
+            off.append(off[-1] + len(hv))
+        write(f"{arm}_{typ}_{sensor}", boxes, hull_off=np.array(off, dtype=np.int32), hull_verts=np.concatenate(hulls))
+    env_objects = "shared_assets/environment_objects"
+    write("table", collision_boxes_of_urdf(os.path.join(REF, env_objects, "table/table.urdf")), base_pos=np.array([0.50, 0.00, -0.625]))   # base_tactile_env.py:135-139
+    write("plane", collision_boxes_of_urdf(os.path.join(REF, env_objects, "plane/plane.urdf")), base_pos=np.array([0.0, 0.0, -0.625]))     # :131-134
+    edge = "rl_env_assets/exploration/edge_follow/edge_stimuli/long_edge_flat"
+    for name in ("long_edge", "short_edge"):
+        write(name, collision_boxes_of_urdf(os.path.join(REF, edge, f"{name}.urdf")))
+    for name, rel in (("pole", "rl_env_assets/nonprehensile_manipulation/object_balance/pole/pole.urdf"),
+                      ("round_plate", "rl_env_assets/nonprehensile_manipulation/object_balance/round_plate/round_plate.urdf"),
+                      ("cube", "rl_env_assets/nonprehensile_manipulation/object_push/cube/cube.urdf"),
+                      ("balance_ball", "rl_env_assets/nonprehensile_manipulation/object_balance/sphere/sphere.urdf"),
+                      ("sphere", "rl_env_assets/nonprehensile_manipulation/object_roll/sphere/sphere.urdf")):
+        urdf = os.path.join(REF, rel)
+        links, joints = parse_urdf(urdf)
+        root = [n for n in links if n not in {j.child for j in joints}][0]
+        R0, p0 = rpy_to_mat(links[root].com_rpy), np.asarray(links[root].com_xyz, dtype=np.float64)
+        boxes = collision_boxes_of_urdf(urdf)
+        for b in boxes:                                   # root link frame -> root inertial frame
+            b["center"], b["rot"] = R0.T @ (b["center"] - p0), R0.T @ b["rot"]
+        write(name, boxes)
+
+
 if __name__ == "__main__":
     if "--scenes-only" in sys.argv:
         scenes()
+        sys.exit(0)
+    if "--collision-only" in sys.argv:
+        collision_boxes()
         sys.exit(0)
     objects()
     sphere()
@@ -310,3 +360,4 @@ if __name__ == "__main__":
     stimuli()
     golden_views()
     scenes()
+    collision_boxes()

@@ -404,6 +404,29 @@ def read_traffic(env_id, n, image_size, key, ab):
     return None
 
 
+def guard_report(w, env, steps, barrier):
+    """The broadphase guard over `steps` further steps of the rollout with the check as a node of every step (tg_set_broadphase; survey row n2):
+    how many env states were checked, how many unexpected pairs Bullet's broadphase would have handed to its narrowphase (world AABBs overlap) and
+    how many of them survive the oriented-box / hull tests (hits: 0 = no contact other than the ones the solver has rows for was possible), and
+    what the check costs the step."""
+    import numpy as np
+    v = w.venv
+    default_on = v._guard is not None and bool(v._guard.struct.every_step)
+    v.set_broadphase_guard(True)                       # (also zeroes the totals)
+    w._fused_synced = False
+    for _ in range(5):
+        w.step(env)
+    dt = w.timed(env, steps, barrier)
+    tot = v.broadphase_totals()
+    st = v.get_state()
+    names = v._guard.describe(int(np.bitwise_or.reduce(st["broadphase_mask"]))) if tot["hits"] else []
+    if not default_on:
+        v.set_broadphase_guard(False)
+        w._fused_synced = False
+    return {"env_checks": tot["env_checks"], "stage1_pairs": tot["pairs"], "hits": tot["hits"], "slots_in_hits_of_the_last_step": names,
+            "ms_per_step_with_the_check": round(1e3 * dt / steps, 4), "default": "a node of every step" if default_on else "on demand (check_broadphase)"}
+
+
 def companion(env_id, image_size, n, physics, steps, barrier, what, **kw):
     """A short run of another configuration on this GPU (after the headline's timed region): value, ms per step and its dominant
     kernel's roofline fraction."""
@@ -422,6 +445,9 @@ def companion(env_id, image_size, n, physics, steps, barrier, what, **kw):
            "value": round(n * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
            "roofline": {k: roof[k] for k in ("kernel", "achieved", "frac", "step_frac", "traffic", "algorithmic_bytes_per_env_step", "kernel_ms",
                                              "kernel_ms_source", "kernel_ms_sum_per_step", "profiled_window_ms_per_step", "kernels")}}
+    if not w.residual_threshold and n <= 1024:
+        with w.on_stream():
+            out["broadphase_guard"] = guard_report(w, w.shard, steps, barrier)
     if w.residual_threshold:
         sw = w.venv.get_state()["solver_sweeps"]
         out["solver_residual_threshold"] = w.residual_threshold
@@ -642,6 +668,7 @@ def main():
                       "explained_ms_per_step": round(long_ms + (one_ms - long_ms) / args.steps, 4),
                       "what": "ms_per_step of a K-step window = steady state + (fill + drain) / K: a window starts on an idle queue (launch latency of its first "
                               "step) and ends in a host synchronisation (completion latency); one_step_window_ms is a window of K = 1 (median of 7)"}
+        guard = guard_report(w, env, max(20, min(args.steps, 300)), barrier) if dist is None else None
         prof = w.profile(env, min(args.steps, 50), barrier, clock=dist is None)
         # SURVEY 8d asks for the rate with and without episode resets: a window that starts right after a reset of every env and
         # ends before any env can reach max_steps (an env that meets its goal early is still reset, as in any rollout)
@@ -747,6 +774,7 @@ def main():
             "literal_solver": literal,
             "without_full_batch_reset": no_reset,
             "resets_in_timed_region": bool((args.warmup % max_steps) + args.steps >= max_steps),
+            "broadphase_guard": guard,
             "other_configs": others,
             "residual_threshold_1e-7": thr_runs,
             "staggered_episodes": staggered,

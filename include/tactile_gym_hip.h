@@ -472,7 +472,8 @@ typedef struct {
     int32_t is_static;                      /* two static boxes are never paired (robot base, table, plane, edge) */
     int32_t hull_off, hull_n;               /* TG_BP_LINK: the link's convex-hull vertices (moving-link frame) in `hull_verts`, for stage 3 */
     uint32_t expected;                      /* bit k: the pair (this slot, slot k) is one the solver has rows for */
-    int32_t pad_;
+    int32_t conj;                           /* -1, or the slot of a second box bounding the SAME shape (a disc: its square and the square turned 45
+                                             * degrees): a pair with this slot is a hit only if the other box overlaps the second one as well */
 } tg_bp_box;
 typedef struct {
     tg_bp_box box[TG_BP_SLOTS];

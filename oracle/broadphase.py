@@ -129,17 +129,19 @@ def env_boxes(env):
             s = _load("balance_ball")
             out.append((BALL, BODY_BALL, False, *_aabb(np.eye(3), np.array(env.ball.pos[:]), s["center"][0], np.eye(3), s["half"][0],
                                                        scale=float(env.ball.radius) / float(s["half"][0][0])), None))
-            expected = {(OBJ_A, BALL)}
+            expected = {(OBJ_A, BALL), (OBJ_B, BALL)}
     return out, expected
 
 
-def sweep(boxes, expected):
+def sweep(boxes, expected, conj=None):
     """Stage 1, Bullet's broadphase: sort the boxes by their lower x bound and sweep - a box is tested against the boxes behind it in that order
     while their lower bound is not past its upper bound; the y and z intervals decide.  The pairs found (different bodies, not both static, not
     an expected pair) are what the narrowphase would be handed.  Stage 2, the guard's own narrowing: such a pair counts as a HIT only if the two
     ORIENTED boxes overlap as well (a long diagonal link's world AABB is mostly air) and, for a robot link against the table, if the link's
     convex hull reaches the table top (stage 3).  Returns dict(pairs = number of stage-1 pairs, hits =
     number of stage-2 hits, mask = bit mask of the boxes involved in hits, hit_pairs, aabb_pairs)."""
+    conj = conj or {}
+    by_index = {b[0]: b for b in boxes}
     order = sorted(range(len(boxes)), key=lambda k: (boxes[k][3][0], boxes[k][0]))
     out = dict(pairs=0, hits=0, mask=0, hit_pairs=[], aabb_pairs=[])
     for a in range(len(order)):
@@ -158,7 +160,11 @@ def sweep(boxes, expected):
             out["pairs"] += 1
             out["aabb_pairs"].append(pair)
             hit = obb_overlap(obb_a, obb_b)
-            if hit and TABLE in pair and min(pair) < 16:
+            for (mine, other_obb) in ((ib, obb_a), (ia, obb_b)):                  # a shape bounded by two boxes (the round plate: its square and the
+                k = conj.get(mine)                                                # square turned 45 degrees): both must be reached
+                if hit and k is not None:
+                    hit = obb_overlap(other_obb, by_index[k][5])
+            if hit and TABLE in pair and min(pair) < 16 and (hull_b if ia == TABLE else hull_a) is not None:
                 # stage 3, a robot link against the table: a box bounds a round link loosely (the UR5's upper arm is a 6 cm cylinder about its
                 # joint: its box's corners reach 2.5 cm further) - the link's CONVEX HULL (what Bullet collides) decides: its lowest vertex over
                 # the table top, less the hull's 1 mm collision margin and the guard's margins
@@ -175,7 +181,13 @@ def sweep(boxes, expected):
 
 def check(env):
     """The guard's verdict on the env's current state (see sweep)."""
-    return sweep(*env_boxes(env))
+    boxes, expected = env_boxes(env)
+    conj = {OBJ_A: OBJ_B, OBJ_B: OBJ_A} if any(b[0] == OBJ_B for b in boxes) and _is_plate(env) else None
+    return sweep(boxes, expected, conj)
+
+
+def _is_plate(env):
+    return type(env).__name__ == "OracleObjectBalanceEnv" and env.modes.get("object_mode") == "ball_on_plate"
 
 
 def box_names(arm_type, t_s_type, t_s_name):

@@ -116,7 +116,7 @@ BP_SLOTS = 22
 
 class TgBpBox(C.Structure):
     _fields_ = [("center", _d3), ("rot", _d9), ("half", _d3), ("src", C.c_int32), ("link", C.c_int32), ("body", C.c_int32), ("is_static", C.c_int32),
-                ("hull_off", C.c_int32), ("hull_n", C.c_int32), ("expected", C.c_uint32), ("pad_", C.c_int32)]
+                ("hull_off", C.c_int32), ("hull_n", C.c_int32), ("expected", C.c_uint32), ("conj", C.c_int32)]
 
 
 class TgBroadphase(C.Structure):

@@ -65,7 +65,7 @@ class Guard:
                 b.center[i], b.half[i] = float(center[i]), float(half[i])
             for i in range(9):
                 b.rot[i] = float(np.asarray(rot).reshape(9)[i])
-            b.src, b.link, b.body, b.is_static, b.hull_off, b.hull_n, b.expected = src, link, body, int(static), int(hull[0]), int(hull[1]), 0
+            b.src, b.link, b.body, b.is_static, b.hull_off, b.hull_n, b.expected, b.conj = src, link, body, int(static), int(hull[0]), int(hull[1]), 0, -1
 
         for i, name in enumerate(rb["names"].tolist()):
             self.names[i] = name
@@ -91,6 +91,8 @@ class Guard:
                 self.names[OBJ_A + k] = f"{obj}:{b['names'][k]}"
             if obj == "cube":
                 expected = [(TABLE, OBJ_A), (tip, OBJ_A)]
+            if obj == "round_plate":                                           # a disc: its square and the square turned 45 degrees bound it together
+                g.box[OBJ_A].conj, g.box[OBJ_B].conj = OBJ_B, OBJ_A
         elif obj == "sphere":                                                  # object_roll's marble
             b = _load("sphere")
             put(OBJ_A, b["center"][0], np.eye(3), b["half"][0], capi.BP_SPHERE, BODY_OBJ, False)
@@ -102,7 +104,7 @@ class Guard:
             put(BALL, b["center"][0], np.eye(3), b["half"][0], capi.BP_BALL, BODY_BALL, False)
             g.sphere_half, g.ball_radius = float(b["half"][0][0]), float(ball_radius)
             self.names[BALL] = "ball"
-            expected = [(OBJ_A, BALL)]
+            expected = [(OBJ_A, BALL), (OBJ_B, BALL)]
         for a, b in expected:
             if a is not None:
                 g.box[a].expected |= 1 << b

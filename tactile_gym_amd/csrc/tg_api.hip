@@ -1675,6 +1675,7 @@ int tg_set_broadphase(tg_ctx* c, const tg_broadphase* g) {
         if ((b.src == TG_BP_BODY || b.src == TG_BP_SPHERE) && c->st.body_pos == nullptr) return fail(-1, "tg_set_broadphase: this env has no free body");
         if (b.src == TG_BP_BALL && c->st.ball == nullptr) return fail(-1, "tg_set_broadphase: this env has no ball");
         if (b.src == TG_BP_EDGE && c->cfg.env_kind != TG_ENV_EDGE_FOLLOW) return fail(-1, "tg_set_broadphase: TG_BP_EDGE outside edge_follow");
+        if (b.conj < -1 || b.conj >= TG_BP_SLOTS || (b.conj >= 0 && g->box[b.conj].src == TG_BP_NONE)) return fail(-1, "tg_set_broadphase: bad conj slot");
         h.box[k] = b;
     }
     h.margin = g->margin; h.hull_margin = g->hull_margin; h.sphere_half = g->sphere_half; h.ball_radius = g->ball_radius;

@@ -153,8 +153,10 @@ __global__ __launch_bounds__(64) void k_broadphase(const DevRobot<T>* __restrict
             if ((b.expected >> j) & 1u) continue;
             ++pairs;
             bool hit = obb_overlap(me, ot);
+            if (hit && o.conj >= 0) hit = obb_overlap(me, bx[o.conj]);            // a shape bounded by two boxes (a disc): both must be reached
+            if (hit && b.conj >= 0) hit = obb_overlap(bx[b.conj], ot);
             const int rl = lane == sc.table_slot ? j : (j == sc.table_slot ? lane : -1);     // the robot box of a (robot link, table) pair
-            if (hit && rl >= 0 && rl < 16 && sc.box[rl].src == TG_BP_LINK) {
+            if (hit && rl >= 0 && rl < 16 && sc.box[rl].src == TG_BP_LINK && sc.box[rl].hull_n > 0) {
                 const tg_bp_box& rb = sc.box[rl];
                 const double* tb = bx[sc.table_slot];
                 const double* F = fr[rb.link >= 0 ? rb.link : 0];

@@ -43,6 +43,7 @@ def _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset, w
     import zlib
     import tactile_gym_amd as tg
     v = tg.make_vec(env_id, num_envs=n, max_steps=max_steps, image_size=[size, size], env_modes=modes, seed=seed, auto_reset=auto_reset, **extra)
+    v.set_broadphase_guard(every_step=True)      # every parity rollout also runs the broadphase guard: no pair but the modelled ones may touch (below)
     obs = v.reset()
     st = v.get_state()
 
@@ -55,6 +56,16 @@ def _hip_rollout(env_id, modes, size, max_steps, n, seed, actions, auto_reset, w
         st = v.get_state()
         rec["img"].append(keep(obs["tactile"][..., 0])), rec["q"].append(st["q"].copy()), rec["rew"].append(rew), rec["done"].append(done)
         rec["reset_ticks"].append(st["reset_ticks"].copy()), rec["xf"].append(st["stim_xform"].copy()), rec["sweeps"].append(st["solver_sweeps"].copy())
+        if st["broadphase_hits"].any():
+            # surface_follow keeps the tip's collision core on over a table it can reach (PARITY_ASSUMPTIONS A40): the one pair the guard may report
+            # ... and ball_on_plate's plate against the wrist in the step in which it tips over (A40: the boxes overlap at tilts beyond 50 degrees - the
+            # episode ends at 35 - with the wrist's hull still 1.8 cm from the disc by oracle/gjk_epa.py)
+            who = set(v._guard.describe(int(np.bitwise_or.reduce(st["broadphase_mask"]))))
+            allowed = ({f"{modes['tactile_sensor_name']}_tip_link", "table"} if env_id.startswith("surface_follow") else
+                       {"round_plate:round_plate", "round_plate:round_plate@45", "wrist_3_link"} if modes.get("object_mode") == "ball_on_plate" else set())
+            assert who <= allowed, (env_id, s, who)
+            if modes.get("object_mode") == "ball_on_plate":
+                assert done[st["broadphase_hits"] > 0].all(), (env_id, s)                   # only in an env's terminal step
         if "extended_feature" in obs:
             rec["feat"].append(obs["extended_feature"].copy())
         if "body_pos" in st:

@@ -14,6 +14,7 @@ Reads (never copies verbatim) from /root/reference/tactile_gym/assets:
 Nothing under tests/, bench.py or smoke() reads /root/reference at run time; they read these blobs.
 Provenance and licences: tactile_gym_amd/assets/PROVENANCE.md.
 """
+import math
 import os
 import sys
 
@@ -342,6 +343,10 @@ def collision_boxes():
         boxes = collision_boxes_of_urdf(urdf)
         for b in boxes:                                   # root link frame -> root inertial frame
             b["center"], b["rot"] = R0.T @ (b["center"] - p0), R0.T @ b["rot"]
+        if name == "round_plate":                         # a disc (<cylinder>, axis z): a second box, the first turned 45 degrees about the axis - the
+            c45 = math.sqrt(0.5)                          # guard takes a pair with the plate for a hit only if BOTH boxes are reached (an octagon)
+            Rz = np.array([[c45, -c45, 0.0], [c45, c45, 0.0], [0.0, 0.0, 1.0]])
+            boxes.append(dict(boxes[0], name="round_plate@45", rot=boxes[0]["rot"] @ Rz))
         write(name, boxes)
 
 

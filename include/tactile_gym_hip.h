@@ -279,7 +279,9 @@ int tg_get_packed_outputs(tg_ctx* ctx, void** dev_ptr, int64_t* obs_bytes, int64
  * enqueued on the context's stream.  *k = -1 with turn_off_border (the ring then carries rendered values). */
 int tg_get_interior_count(tg_ctx* ctx, int32_t* k);
 /* Reset bank (tg_config.reset_bank): how many auto-resets so far took a precomputed entry (*swapped) and how many were done on the spot because
- * the entry was not ready (*late); *mode = 0 bank off, 1 on, 2 on and waited for.  Synchronises the context's stream. */
+ * the entry was not ready (*late); *mode = 0 bank off, 1 on, 2 on and waited for.  object_push (round 6): *mode = 3 - resets that took the reset
+ * TEMPLATE (the arm's post-reset state is a function of constants while the tip stays clear of the previous episode's cube) / resets that ran their
+ * blocking move; 0 with the template off.  Synchronises the context's stream. */
 int tg_get_bank_stats(tg_ctx* ctx, int64_t* swapped, int64_t* late, int32_t* mode);
 /* Render targets (multi-GPU; replaces the copy of rank 0's own observations into the gathered batch that SubprocVecEnv's parent does
  * per env, sb3_helpers/rl_utils.py:17-30): tg_set_obs_targets names up to two caller-owned device buffers uint8 [num_envs][H][W] - rank 0's

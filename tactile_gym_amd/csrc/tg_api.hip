@@ -1095,6 +1095,15 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         TG_HIP(hipMemcpy(c->d_int_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
         TG_HIP(hipMemcpy(c->d_int_rank, rank_of.data(), (size_t)npix, hipMemcpyHostToDevice));
     }
+    if (cfg->env_kind == TG_ENV_OBJECT_PUSH) {
+        // the arm's post-reset state + the tip's path (k_reset_contact_wave's reset template); off with reset_bank = TG_BANK_OFF / TG_RESET_BANK=0 and in
+        // threshold mode (the truncated solve couples the arm to the object's rows)
+        bool tmpl = cfg->reset_bank != TG_BANK_OFF && !(cfg->solver_residual_threshold > 0.0);
+        if (const char* e = getenv("TG_RESET_BANK")) tmpl = tmpl && e[0] != '0';
+        const size_t tb = (size_t)(2 * TG_MAX_DOF + 4 + 3 * 64) * 8;
+        if (tmpl) { TG_HIP(hipMalloc(&s.reset_tmpl, tb)); TG_HIP(hipMemset(s.reset_tmpl, 0, tb)); }
+        TG_HIP(hipMalloc(&s.tmpl_stats, 16)); TG_HIP(hipMemset(s.tmpl_stats, 0, 16));
+    }
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE) {
         TG_HIP(hipMalloc(&s.body_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.body_rot, 9 * n * 8)); TG_HIP(hipMalloc(&s.body_v, 3 * n * 8));
         TG_HIP(hipMalloc(&s.body_w, 3 * n * 8)); TG_HIP(hipMalloc(&s.ext_pos, 3 * n * 8)); TG_HIP(hipMalloc(&s.gravity, n * 8));
@@ -1362,7 +1371,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->d_kt_acc) (void)hipFree(c->d_kt_acc);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.sweeps, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.sweeps, s.tmpl_stats, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -1736,6 +1745,13 @@ int tg_get_bank_stats(tg_ctx* c, int64_t* swapped, int64_t* late, int32_t* mode)
     if (!c || !swapped || !late || !mode) return fail(-1, "NULL argument");
     TG_ENTER(c);
     *swapped = 0; *late = 0; *mode = c->bank_mode;
+    if (c->st.tmpl_stats != nullptr) {           // object_push: the reset template's counters (mode 3; k_reset_contact_wave)
+        unsigned long long t[2] = {0, 0};
+        TG_HIP(hipMemcpyAsync(t, c->st.tmpl_stats, 16, hipMemcpyDeviceToHost, c->stream));
+        TG_HIP(hipStreamSynchronize(c->stream));
+        *swapped = (int64_t)t[0]; *late = (int64_t)t[1]; *mode = c->st.reset_tmpl != nullptr ? 3 : 0;
+        return 0;
+    }
     if (c->bank_mode == 0) return 0;
     unsigned long long h[2] = {0, 0};
     TG_HIP(hipMemcpyAsync(h, c->aux.stats, 16, hipMemcpyDeviceToHost, c->stream));

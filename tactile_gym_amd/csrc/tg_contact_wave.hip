@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(64) void k_step_arm_wave(const DevRobot<T>* __restr
 // is put back and the first observation's transforms are written.
 template <typename T, int TOPO, int SHAPE, bool CONE, int NT = 1>
 __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                                           const uint8_t* __restrict__ mask) {
+                                                           const uint8_t* __restrict__ mask, int optimistic) {
     // (no KtScope: its one more live scalar pair took this kernel from 0 to 204 B of scratch per lane - 15 MB of spill traffic per launch by the
     //  PMC - at a duration in milliseconds, where a HIP event pair's 5 us do not matter)
     constexpr int N = Topo<TOPO>::N;
@@ -2006,6 +2006,48 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
     T q[N], qd[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
+    const FreeBody<T> b0 = load_body<T>(st, n, env);
+    int used = 0, ccode = 0;
+    constexpr int kTmplPath = 64;
+    const bool tmpl_can = SHAPE == 0 && optimistic != 0 && NT == 1 && !(m.res_thr > T(0)) && st.reset_tmpl != nullptr;
+    bool tmpl_valid = false;
+    if (tmpl_can) tmpl_valid = st.reset_tmpl[2 * N + 1] != 0.0;
+    bool took_template = false;
+    if (uniform_true(tmpl_valid)) {
+        const int npts = (int)st.reset_tmpl[2 * N + 2];
+        const T bs_r = (T)st.reset_tmpl[2 * N + 3];
+        bool clear = true;
+        for (int k2 = 0; k2 < npts; ++k2) {
+            const V3<T> cw = mk((T)st.reset_tmpl[2 * N + 4 + 3 * k2], (T)st.reset_tmpl[2 * N + 5 + 3 * k2], (T)st.reset_tmpl[2 * N + 6 + 3 * k2]);
+            const V3<T> loc = mulT(b0.R, cw - b0.pos);
+            const T ox = tmax(tabs(loc.x) - c.push.half[0], T(0)), oy = tmax(tabs(loc.y) - c.push.half[1], T(0)), oz = tmax(tabs(loc.z) - c.push.half[2], T(0));
+            clear = clear && (tsqrt(ox * ox + oy * oy + oz * oz) - bs_r > T(0.004));
+        }
+        if (uniform_true(clear)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { q[i] = (T)st.reset_tmpl[i]; qd[i] = (T)st.reset_tmpl[N + i]; }
+            used = (int)st.reset_tmpl[2 * N];
+            {   // the cube's table contacts as sim_tick_contact_wave selects them: vertices within the breaking distance, at most 4 (the deepest)
+                T vz[8]; int keep = 0, cnt = 0;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    const T lx = (cc & 4) ? c.push.half[0] : -c.push.half[0], ly = (cc & 2) ? c.push.half[1] : -c.push.half[1], lz = (cc & 1) ? c.push.half[2] : -c.push.half[2];
+                    vz[cc] = (b0.pos.z + (b0.R.m[6] * lx + b0.R.m[7] * ly + b0.R.m[8] * lz)) - c.push.table_z;
+                    if (vz[cc] <= c.push.breaking) { keep |= 1 << cc; ++cnt; }
+                }
+                while (cnt > 4) {
+                    int worst = -1; T wz = T(0);
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc)
+                        if (((keep >> cc) & 1) && (worst < 0 || vz[cc] >= wz)) { worst = cc; wz = vz[cc]; }
+                    keep &= ~(1 << worst); --cnt;
+                }
+                ccode = keep;
+            }
+            took_template = true;
+        }
+    }
+    if (!took_template) {
     const V3<T> tpos = SHAPE == 0 ? load_v3(c.work_pos) : mk(c.work_pos[0], c.work_pos[1], (T)(2.0 * new_mr - embed));   // work-frame origin, rpy 0
     T trpy[3];
     euler_from_quat(quat_mul(c.work_q, quat_from_euler(T(0), T(0), T(0))), trpy[0], trpy[1], trpy[2]);
@@ -2027,10 +2069,61 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
         if (lane < 37) L[xbase + kXMani + (lane < 36 ? lane : narrow::kMcount)] = (T)st.mani[(size_t)lane * n + env];
     }
     stage_link_constants<T, TOPO>(mp, L, lane);
+    // The OPTIMISTIC blocking move (round 6).  Robot.reset (robot.py:114-125) teleports the arm to its rest pose and drives it to the start pose
+    // with the PREVIOUS episode's object still in the world; reset_object then teleports that object (base_object_env.py:146-173), so whatever
+    // the object did during the move is discarded - unless the tip touched it.  While the tip stays clear of the object the arm's motor rows and
+    // the object's table rows do not interact (their Delassus entries are exact zeros), i.e. the arm moves exactly as in an arm-only tick with the
+    // same 150 sweeps: those ticks run sim_tick_arm_wave (no contact generation, no friction chains: ~1/3 of a contact tick) with the object
+    // frozen where the finished episode left it.  "Clear" = the bounding sphere of the tip's collision shape further than 4 mm from the object
+    // (margins 1.1 mm + breaking 0.1 mm + what a decelerating object and the tip travel in a tick), tested before every tick; the first tick is a
+    // full contact tick (it also yields the contact code a reset leaves behind).  A move in which the test fails once is run AGAIN from the
+    // rest pose with full contact ticks throughout: the results are those of the literal move either way (arm to rounding, reset tick counts
+    // exactly: tests/test_gpu_parity.py, tests/test_gpu_config_scale.py).  Not in threshold mode (the loop's exit there couples all rows).
+    V3<T> bs_c = mk<T>(0, 0, 0);
+    T bs_r = T(0);
+    bool literal = !(optimistic != 0 && NT == 1 && !(m.res_thr > T(0)));
+    if (!literal) {
+        if constexpr (SHAPE == 0) {
+            T lo[3] = {T(1e30), T(1e30), T(1e30)}, hi[3] = {T(-1e30), T(-1e30), T(-1e30)};
+            __syncthreads();
+            for (int v = lane; v < c.push.n_tip; v += 64)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) { const T w = L[kLHull + 3 * v + x]; lo[x] = tmin(lo[x], w); hi[x] = tmax(hi[x], w); }
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+                for (int o = 1; o < 64; o <<= 1) { lo[x] = tmin(lo[x], __shfl_xor(lo[x], o)); hi[x] = tmax(hi[x], __shfl_xor(hi[x], o)); }
+            bs_c = mk(T(0.5) * (lo[0] + hi[0]), T(0.5) * (lo[1] + hi[1]), T(0.5) * (lo[2] + hi[2]));
+            T r2 = T(0);
+            for (int v = lane; v < c.push.n_tip; v += 64) {
+                const V3<T> d = mk(L[kLHull + 3 * v], L[kLHull + 3 * v + 1], L[kLHull + 3 * v + 2]) - bs_c;
+                r2 = tmax(r2, dot(d, d));
+            }
+            for (int o = 1; o < 64; o <<= 1) r2 = tmax(r2, __shfl_xor(r2, o));
+            bs_r = tsqrt(r2);
+        } else {
+            bs_c = load_v3(c.push.cyl_pos);
+            bs_r = tsqrt(c.push.cyl_r * c.push.cyl_r + c.push.cyl_hl * c.push.cyl_hl);
+        }
+    }
+    T cv = T(0.001);
+    // The reset TEMPLATE (object_push; round 6).  With the tip clear of the object the whole move is a function of constants - rest pose, start pose,
+    // gains: nothing of the episode, nothing of the env - so its result (q, qd, tick count) and the tip sphere's path are kept from the first
+    // optimistic move that ran through (State.reset_tmpl: [0, N) q, [N, 2N) qd, [2N] ticks, [2N + 1] valid, [2N + 2] path points, [2N + 4 + 3k] the
+    // sphere's centre before tick k and, last, at the final pose).  A later reset whose object is further than the 4 mm from EVERY point of that path
+    // takes the template: no tick at all (the same bits the optimistic move would produce - it is deterministic); otherwise it moves as above.
+    // object_roll's start pose depends on the episode's marble: no template there.  The contact code a reset leaves behind is the object's
+    // table contacts where the episode left it (the literal move reports those of its last tick: the same set for an object at rest).
+    const bool record = tmpl_can && !tmpl_valid;           // this move may become the template: leave the sphere's path behind
+    int n_path = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    bool violated = false;
+    n_path = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = m.rest_q[i]; qd[i] = T(0); }
     {
-        const FreeBody<T> b0 = load_body<T>(st, n, env);
         JointTrig<T, N> trig;
         trig_init<T, N>(q, trig);
+        __syncthreads();
         if (w0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -2048,8 +2141,8 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
     }
     TG_PHASE_FENCE()
     // ---- blocking_move(max_steps = 1000, constant_vel = 0.001), robot.py:188-260
-    T cv = T(0.001);
-    int used = 0, ccode = 0;
+    cv = T(0.001);
+    used = 0; ccode = 0;
     for (int it = 0; it < 1000; ++it) {
 #pragma unroll
         for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
@@ -2074,8 +2167,34 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
             for (int i = 0; i < N; ++i) L[kLQDes + i] = q[i] + ((nrm > T(0)) ? diff[i] / nrm : T(0)) * cv;
         }
         if (all_small) cv = cv / T(2);
+        bool arm_only = false;
+        if (!literal) {                  // is the tip clear of the (frozen) object before this tick?  (the first tick is a contact tick either way)
+            V3<T> ol; M3<T> Rl;
+            const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}, z3[3] = {T(0), T(0), T(0)};
+            link_frame<T, TOPO>(k, c.push.tip_link, z3, ident, ol, Rl);
+            const V3<T> cw = ol + mul(Rl, bs_c);
+            if (record && w0 && n_path < kTmplPath - 1) {
+                st.reset_tmpl[2 * N + 4 + 3 * n_path] = (double)cw.x; st.reset_tmpl[2 * N + 5 + 3 * n_path] = (double)cw.y; st.reset_tmpl[2 * N + 6 + 3 * n_path] = (double)cw.z;
+            }
+            ++n_path;
+            const V3<T> bp = mk(L[kLBody + 0], L[kLBody + 1], L[kLBody + 2]);
+            T dist;
+            if constexpr (SHAPE == 1) dist = norm(cw - bp) - (T)old_mr;
+            else {
+                M3<T> Rb;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) Rb.m[e] = L[kLBody + 3 + e];
+                const V3<T> loc = mulT(Rb, cw - bp);
+                const T ox = tmax(tabs(loc.x) - c.push.half[0], T(0)), oy = tmax(tabs(loc.y) - c.push.half[1], T(0)), oz = tmax(tabs(loc.z) - c.push.half[2], T(0));
+                dist = tsqrt(ox * ox + oy * oy + oz * oz);
+            }
+            arm_only = dist - bs_r > T(0.004);
+            if (it == 0) arm_only = false;
+            else if (!uniform_true(arm_only)) { violated = true; break; }
+        }
         TG_PHASE_FENCE()
-        ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE, NT>(m, c.push, L, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, (T)old_mr, lane, xbase);
+        if (uniform_true(arm_only)) (void)sim_tick_arm_wave<T, TOPO, kMotorPosition>(m, L, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, lane);
+        else ccode = sim_tick_contact_wave<T, TOPO, kMotorPosition, SHAPE, CONE, NT>(m, c.push, L, m.pos_gain, m.vel_gain, T(100000), c.dt, c.solver_iters, (T)old_mr, lane, xbase);
         ++used;
         const T pos_err = tabs(tpos.x - p.x) + tabs(tpos.y - p.y) + tabs(tpos.z - p.z);
         const T ip = tq.x * cq.x + tq.y * cq.y + tq.z * cq.z + tq.w * cq.w;
@@ -2083,9 +2202,37 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
         ca = ca > T(1) ? T(1) : (ca < T(-1) ? T(-1) : ca);
         if (uniform_true(pos_err < T(2e-4) && tacos(ca) < T(1e-3) && total_v < T(0.1))) break;
     }
-    // ---- the object goes back to its start (reset_object), results to HBM
+    if (!violated) {
+        if (record && !literal && n_path < kTmplPath - 1) {
+            // this move ran through with the tip clear: it is the template.  Every env that gets here writes the same values (the move is a function
+            // of constants); the flag goes last, behind a fence, and is read at kernel start only (a later launch sees all of it).
+#pragma unroll
+            for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
+            Kin<T, TOPO> kf;
+            forward_kinematics<T, TOPO>(m, q, kf);
+            V3<T> ol; M3<T> Rl;
+            const T ident[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}, z3[3] = {T(0), T(0), T(0)};
+            link_frame<T, TOPO>(kf, c.push.tip_link, z3, ident, ol, Rl);
+            const V3<T> cw = ol + mul(Rl, bs_c);
+            if (w0) {
+                st.reset_tmpl[2 * N + 4 + 3 * n_path] = (double)cw.x; st.reset_tmpl[2 * N + 5 + 3 * n_path] = (double)cw.y; st.reset_tmpl[2 * N + 6 + 3 * n_path] = (double)cw.z;
+#pragma unroll
+                for (int i = 0; i < N; ++i) { st.reset_tmpl[i] = (double)q[i]; st.reset_tmpl[N + i] = (double)qd[i]; }
+                st.reset_tmpl[2 * N] = (double)used;
+                st.reset_tmpl[2 * N + 2] = (double)(n_path + 1);
+                st.reset_tmpl[2 * N + 3] = (double)bs_r;
+                __threadfence();
+                st.reset_tmpl[2 * N + 1] = 1.0;
+            }
+        }
+        break;
+    }
+    literal = true;                      // the tip came near the object: the whole move again, every tick a full contact tick
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) { q[i] = L[kLQ + i]; qd[i] = L[kLQd + i]; }
+    }   // !took_template
+    // ---- the object goes back to its start (reset_object), results to HBM
     FreeBody<T> b;
     if constexpr (SHAPE == 0) {
         b.pos = load_v3(c.obj_init_pos);
@@ -2101,6 +2248,7 @@ __global__ __launch_bounds__(64) void k_reset_contact_wave(const DevRobot<T>* __
         if (lane < 37) st.mani[(size_t)lane * n + env] = 0.0;
     }
     if (w0) {
+        if (st.tmpl_stats != nullptr) atomicAdd(st.tmpl_stats + (took_template ? 0 : 1), 1ull);
         st.reset_ticks[env] = used;
         st.contact_code[env] = ccode;
         st.obj_mass[env] = new_mr;
@@ -2149,13 +2297,14 @@ int launch_reset_wave_t(int cone, int n, int n_tip, hipStream_t stream, const vo
         if (narrowphase) {
             if (n_tip > 64 * narrow::kSlots) return -1;
             hipLaunchKernelGGL((k_reset_contact_wave<T, TOPO, 0, true, 4>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
-                               (const EnvConst<T>*)d_const, st, d_mask);
+                               (const EnvConst<T>*)d_const, st, d_mask, 0);
             return 0;
         }
     }
     if (narrowphase) return -1;
+    const int optimistic = getenv("TG_LITERAL_RESET") == nullptr ? 1 : 0;             // TG_LITERAL_RESET: every reset tick a full contact tick (A/B, tests)
     hipLaunchKernelGGL((k_reset_contact_wave<T, TOPO, SHAPE, true>), dim3(n), dim3(64), lds_bytes, stream, (const DevRobot<T>*)d_robot,
-                       (const EnvConst<T>*)d_const, st, d_mask);
+                       (const EnvConst<T>*)d_const, st, d_mask, optimistic);
     return 0;
 }
 

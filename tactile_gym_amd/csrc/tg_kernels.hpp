@@ -70,6 +70,7 @@ struct State {   // device pointers, SoA [field][num_envs]
     // object_balance
     double *body_pos, *body_rot, *body_v, *body_w, *ext_pos, *gravity;   // [3][n], [9][n], [3][n], [3][n], [3][n], [n]
     uint8_t* ext_pending;           // [n]
+    unsigned long long* tmpl_stats; // [2] object_push: resets that took the reset template / that ran their blocking move (k_reset_contact_wave); null otherwise
     double* reset_tmpl;             // [2 N + 2] object_balance: the arm's state after Robot.reset (q, qd, ticks used, valid flag) - see k_reset_body
     double* ball;                   // [13][n] ball_on_plate: position, linear velocity, angular velocity, one-shot torque, last normal impulse
     // object_push
@@ -1355,6 +1356,16 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
     }
     if (m.res_thr > T(0)) st.sweeps[env] = sweeps;
     st.ext_pending[env] = 0;
+#ifdef TG_DEBUG_FINITE   // debug builds: a non-finite state stops the kernel where it appears instead of surfacing as a parity failure later
+    {
+        T chk = b.pos.x + b.pos.y + b.pos.z + b.v.x + b.v.y + b.v.z + b.w.x + b.w.y + b.w.z;
+#pragma unroll
+        for (int i = 0; i < N; ++i) chk += q[i] + qd[i];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) chk += b.R.m[e];
+        if (!(chk - chk == T(0))) __builtin_trap();
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; }
     store_body<T>(st, n, env, b);

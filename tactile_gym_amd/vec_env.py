@@ -256,7 +256,7 @@ class TactileVecEnv(_VecEnvBase):
         """Reset bank: {"mode": "off" | "on" | "sync", "swapped": auto-resets that took a precomputed entry, "late": resets done on the spot}."""
         sw, late, mode = C.c_int64(), C.c_int64(), C.c_int32()
         capi.check(self._L.tg_get_bank_stats(self._ctx, C.byref(sw), C.byref(late), C.byref(mode)))
-        return {"mode": ("off", "on", "sync")[mode.value], "swapped": int(sw.value), "late": int(late.value)}
+        return {"mode": ("off", "on", "sync", "template")[mode.value], "swapped": int(sw.value), "late": int(late.value)}
 
     def step_mode(self):
         """"fused": the env step is one launch (csrc/tg_fused.hip: the wavefront that steps an env resets and draws it; `fused_step`); "separate":

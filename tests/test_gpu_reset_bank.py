@@ -173,3 +173,45 @@ def test_bank_modes_are_byte_identical_with_the_episodes_out_of_phase(env_id, mo
         for key in ("obs", "rew", "done", "ticks", "q"):
             for t, (x, y) in enumerate(zip(off[key], other[key])):
                 assert np.array_equal(x, y), (key, t)
+
+
+def test_object_push_reset_template_equals_the_literal_reset(monkeypatch):
+    """Round 6: object_push's Robot.reset (robots/arms/robot.py:114-125, 188-260) with the previous episode's cube clear of the tip runs arm-only
+    ticks with the cube frozen ("optimistic" move) and, once one such move has run through, takes its result as a template without any tick
+    (csrc/tg_contact_wave.hip: k_reset_contact_wave).  Against the literal move (TG_LITERAL_RESET=1: every tick a full contact tick) and against
+    the optimistic move without the template (TG_RESET_BANK=0) over rollouts with many auto-resets - short episodes, so that resets happen both
+    with the cube still at the tip (the test fails and the move is literal) and with it pushed away: dones, reset tick counts, contact counts
+    exact; joints to rounding (the arm-only tick is another order of the same sums); images at most one grey level off on a few pixels."""
+    import tactile_gym_amd as tg
+    from test_gpu_config_scale import PUSH
+    n, steps = 128, 90
+    acts = np.random.default_rng(2).uniform(-0.25, 0.25, size=(steps, n, 2)).astype(np.float32)
+
+    def rollout(env):
+        for k in ("TG_LITERAL_RESET", "TG_RESET_BANK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        v = tg.make_vec("object_push-v0", num_envs=n, max_steps=25, image_size=[128, 128], env_modes=PUSH, seed=77, auto_reset=True)
+        v.reset()
+        out = dict(q=[], done=[], ticks=[], img=[], cc=[])
+        for s in range(steps):
+            obs, rew, done, info = v.step(acts[s])
+            st = v.get_state()
+            out["q"].append(st["q"].copy()), out["done"].append(done.copy()), out["ticks"].append(st["reset_ticks"].copy())
+            out["img"].append(obs["tactile"][..., 0].copy()), out["cc"].append(st["contact_count"].copy())
+        stats = v.bank_stats()
+        v.close()
+        return {**{k: np.asarray(x) for k, x in out.items()}, "stats": stats}
+    tmpl, opt, lit = rollout({}), rollout({"TG_RESET_BANK": "0"}), rollout({"TG_LITERAL_RESET": "1"})
+    assert tmpl["stats"]["mode"] == "template" and tmpl["stats"]["swapped"] > n and tmpl["stats"]["late"] >= n, tmpl["stats"]   # both routes were taken
+    assert opt["stats"]["swapped"] == 0 and lit["stats"]["swapped"] == 0
+    assert lit["done"].sum() >= 3 * n                                      # every env was reset several times
+    assert len(set(lit["ticks"].ravel().tolist())) >= 1
+    for other, name in ((tmpl, "template"), (opt, "optimistic")):
+        assert np.array_equal(other["done"], lit["done"]) and np.array_equal(other["ticks"], lit["ticks"]), name
+        assert np.array_equal(other["cc"], lit["cc"]), name
+        assert np.abs(other["q"] - lit["q"]).max() < 1e-10, (name, np.abs(other["q"] - lit["q"]).max())
+        d = other["img"].astype(np.int16) - lit["img"].astype(np.int16)
+        assert np.abs(d).max() <= 1 and (d != 0).reshape(steps * n, -1).sum(1).max() <= 16, name
+    assert np.array_equal(tmpl["q"], opt["q"])                             # the template IS the optimistic move's result, bit for bit

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds libtactile_gym_hip.so (the product) and libtactile_gym_hip_test.so (device self-tests, loaded by tests/ only) for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
 #   tg_raster.hip, tg_scene.hip and tg_noise.hip are compiled with -ffp-contract=off (bit-exact raster specification);
-#   tg_api.hip (physics, control, C ABI), tg_contact_wave.hip (wave-per-env contact solver) and tg_exchange.hip (multi-GPU payloads, integer only) with the default contraction (FMA); tg_narrow_test.hip (GJK / EPA self-test) switches contraction off by pragma; tg_fused.hip (step + render in one launch) keeps FMA for the physics and
+#   tg_api.hip (configuration, creation, step / reset launches; + tg_api_state.hip, tg_api_ops.hip: the rest of the C ABI, sharing tg_ctx.hpp), tg_contact_wave.hip (wave-per-env contact solver) and tg_exchange.hip (multi-GPU payloads, integer only) with the default contraction (FMA); tg_narrow_test.hip (GJK / EPA self-test) switches contraction off by pragma; tg_fused.hip (step + render in one launch) keeps FMA for the physics and
 #   takes the raster from tg_raster_dev.hpp, whose pragma switches contraction off for everything after it.
 set -euo pipefail
 cd "$(dirname "$0")"
@@ -30,8 +30,10 @@ cc tg_narrow_test & p7=$!
 cc tg_fused & p8=$!
 cc tg_selftest -ffp-contract=off & p9=$!
 cc tg_broadphase -ffp-contract=off & p10=$!
-wait $p1; wait $p2; wait $p3; wait $p4; wait $p5; wait $p6; wait $p7; wait $p8; wait $p9; wait $p10    # each wait returns its job's status: a failed translation unit fails the build (set -e)
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" "$OUT/tg_scene.o" "$OUT/tg_exchange.o" "$OUT/tg_fused.o" "$OUT/tg_broadphase.o" -o "$OUT/libtactile_gym_hip.so"
+cc tg_api_state & p11=$!
+cc tg_api_ops & p12=$!
+wait $p1; wait $p2; wait $p3; wait $p4; wait $p5; wait $p6; wait $p7; wait $p8; wait $p9; wait $p10; wait $p11; wait $p12    # each wait returns its job's status: a failed translation unit fails the build (set -e)
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" "$OUT/tg_scene.o" "$OUT/tg_exchange.o" "$OUT/tg_fused.o" "$OUT/tg_broadphase.o" "$OUT/tg_api_state.o" "$OUT/tg_api_ops.o" -o "$OUT/libtactile_gym_hip.so"
 # test infrastructure (include/tactile_gym_hip_test.h): device self-tests of the raster's division / block test and of the wave-mapped GJK / EPA
 $HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_narrow_test.o" "$OUT/tg_selftest.o" -o "$OUT/libtactile_gym_hip_test.so"
 echo "built $OUT/libtactile_gym_hip.so $OUT/libtactile_gym_hip_test.so"

@@ -3,81 +3,12 @@
 // Per-env state lives in HBM as struct-of-arrays with the env index minor ([field][num_envs], doubles), so a
 // wavefront of 64 consecutive envs reads or writes one 512-byte contiguous run per field: the whole dynamic state
 // crosses HBM exactly once per env step (in) and once (out); the 24 sim ticks in between run out of registers.
-#include <hip/hip_runtime.h>
-
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <algorithm>
-#include <map>
-#include <string>
-#include <tuple>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/tactile_gym_hip.h"
-#include "tg_kernels.hpp"
-#include "tg_contact_wave.h"
-#include "tg_fused.h"
-#include "tg_scene.h"
-#include "tg_noise.h"
-#include "tg_raster.h"
-#include "tg_exchange.h"
-#include "tg_broadphase.h"
+#include "tg_ctx.hpp"
 
 namespace tg {
 
-static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 int report_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }   // the other translation units' way to tg_last_error()
-#define TG_HIP(expr)                                                                                         \
-    do {                                                                                                     \
-        hipError_t e_ = (expr);                                                                              \
-        if (e_ != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_));            \
-    } while (0)
-
 // ------------------------------------------------------------------------------------------------ host helpers
-// Is every connected surface of the mesh closed and consistently wound with outward normals?  Vertices are matched by coordinates (OBJ
-// files repeat them per face); closed + consistent = every directed edge a->b is met exactly once by b->a; outward = positive signed
-// volume per connected component.  (What licenses the raster's back-face cull, tg_raster.hip:back_facing.)
-static bool mesh_closed_outward(const tg_mesh* mesh) {
-    const int nt = mesh->n_tris, nv = mesh->n_verts;
-    if (nt < 4 || nv < 4) return false;
-    std::vector<int> canon(nv);
-    {
-        std::vector<int> order(nv);
-        for (int i = 0; i < nv; ++i) order[i] = i;
-        auto key = [&](int i) { return std::make_tuple(mesh->verts[3 * i], mesh->verts[3 * i + 1], mesh->verts[3 * i + 2]); };
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
-        for (int k = 0; k < nv; ++k) canon[order[k]] = (k > 0 && key(order[k]) == key(order[k - 1])) ? canon[order[k - 1]] : order[k];
-    }
-    std::map<std::pair<int, int>, int> edge;       // directed edge -> triangle
-    std::vector<int> parent(nt);
-    for (int t = 0; t < nt; ++t) parent[t] = t;
-    auto find = [&](int x) { while (parent[x] != x) x = parent[x] = parent[parent[x]]; return x; };
-    for (int t = 0; t < nt; ++t)
-        for (int k = 0; k < 3; ++k) {
-            const int a = canon[mesh->tris[3 * t + k]], b = canon[mesh->tris[3 * t + (k + 1) % 3]];
-            if (a == b) return false;                                   // degenerate triangle
-            if (!edge.emplace(std::make_pair(a, b), t).second) return false;   // the same directed edge twice: inconsistent winding
-        }
-    for (const auto& e : edge) {
-        const auto opp = edge.find(std::make_pair(e.first.second, e.first.first));
-        if (opp == edge.end()) return false;                            // open boundary
-        parent[find(e.second)] = find(opp->second);
-    }
-    std::map<int, double> vol;
-    for (int t = 0; t < nt; ++t) {
-        const float* a = mesh->verts + 3 * mesh->tris[3 * t]; const float* b = mesh->verts + 3 * mesh->tris[3 * t + 1]; const float* c = mesh->verts + 3 * mesh->tris[3 * t + 2];
-        vol[find(t)] += (double)a[0] * ((double)b[1] * c[2] - (double)b[2] * c[1]) - (double)a[1] * ((double)b[0] * c[2] - (double)b[2] * c[0]) +
-                        (double)a[2] * ((double)b[0] * c[1] - (double)b[1] * c[0]);
-    }
-    for (const auto& v : vol) if (!(v.second > 0.0)) return false;      // a component wound inside out
-    return true;
-}
-
 static void h_quat_from_euler(const double* rpy, double* q) {
     const double phi = 0.5 * rpy[0], the = 0.5 * rpy[1], psi = 0.5 * rpy[2];
     q[0] = sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi);
@@ -97,113 +28,6 @@ static void h_mat_from_quat(const double* q, double* R) {
     R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
 }
 
-template <typename T> static int build_dev_robot(const tg_robot& r, DevRobot<T>& d) {
-    memset(&d, 0, sizeof d);
-    const int N = r.ndof;
-    for (int i = 0; i < N; ++i) {
-        for (int k = 0; k < 3; ++k) { d.jpos[i][k] = (T)r.joint_pos[i][k]; d.jaxis[i][k] = (T)r.joint_axis[i][k]; }
-        for (int k = 0; k < 9; ++k) d.jrot[i][k] = (T)r.joint_rot[i][k];
-        // merge the bodies welded to link i: m, com, inertia about com in link coordinates
-        double m = 0, com[3] = {0, 0, 0};
-        for (int b = 0; b < TG_MAX_BODIES_PER_LINK; ++b) {
-            m += r.body_mass[i][b];
-            for (int k = 0; k < 3; ++k) com[k] += r.body_mass[i][b] * r.body_com[i][b][k];
-        }
-        if (m > 0) for (int k = 0; k < 3; ++k) com[k] /= m;
-        double I[3][3] = {{0}};
-        for (int b = 0; b < TG_MAX_BODIES_PER_LINK; ++b) {
-            const double mb = r.body_mass[i][b];
-            if (mb <= 0) continue;
-            const double* R = r.body_rot[i][b];
-            for (int a = 0; a < 3; ++a)
-                for (int c = 0; c < 3; ++c)
-                    for (int k = 0; k < 3; ++k) I[a][c] += R[3 * a + k] * r.body_inertia[i][b][k] * R[3 * c + k];
-            double dv[3];
-            for (int k = 0; k < 3; ++k) dv[k] = r.body_com[i][b][k] - com[k];
-            const double dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
-            for (int a = 0; a < 3; ++a)
-                for (int c = 0; c < 3; ++c) I[a][c] += mb * ((a == c ? dd : 0.0) - dv[a] * dv[c]);
-        }
-        // FK constants and the merged angular-damping inertia
-        {
-            const double* Rj = r.joint_rot[i];
-            const double* a = r.joint_axis[i];
-            const double aaT[9] = {a[0] * a[0], a[0] * a[1], a[0] * a[2], a[1] * a[0], a[1] * a[1], a[1] * a[2], a[2] * a[0], a[2] * a[1], a[2] * a[2]};
-            const double ax[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
-            for (int rr = 0; rr < 3; ++rr)
-                for (int cc = 0; cc < 3; ++cc) {
-                    double sa = 0, sb = 0, sc = 0;
-                    for (int k = 0; k < 3; ++k) {
-                        sa += Rj[3 * rr + k] * aaT[3 * k + cc];
-                        sb += Rj[3 * rr + k] * ((k == cc ? 1.0 : 0.0) - aaT[3 * k + cc]);
-                        sc += Rj[3 * rr + k] * ax[3 * k + cc];
-                    }
-                    d.fkA[i][3 * rr + cc] = (T)sa; d.fkB[i][3 * rr + cc] = (T)sb; d.fkC[i][3 * rr + cc] = (T)sc;
-                }
-            double Ia[3][3] = {{0}};
-            for (int b = 0; b < TG_MAX_BODIES_PER_LINK; ++b) {
-                if (r.body_mass[i][b] <= 0) continue;
-                const double* R = r.body_rot[i][b];
-                for (int aa = 0; aa < 3; ++aa)
-                    for (int c = 0; c < 3; ++c)
-                        for (int k = 0; k < 3; ++k) Ia[aa][c] += R[3 * aa + k] * r.body_inertia[i][b][k] * R[3 * c + k];
-            }
-            d.lang[i][0] = (T)Ia[0][0]; d.lang[i][1] = (T)Ia[0][1]; d.lang[i][2] = (T)Ia[0][2];
-            d.lang[i][3] = (T)Ia[1][1]; d.lang[i][4] = (T)Ia[1][2]; d.lang[i][5] = (T)Ia[2][2];
-        }
-        d.lmass[i] = (T)m;
-        for (int k = 0; k < 3; ++k) d.lcom[i][k] = (T)com[k];
-        d.linert[i][0] = (T)I[0][0]; d.linert[i][1] = (T)I[0][1]; d.linert[i][2] = (T)I[0][2];
-        d.linert[i][3] = (T)I[1][1]; d.linert[i][4] = (T)I[1][2]; d.linert[i][5] = (T)I[2][2];
-        for (int b = 0; b < TG_MAX_BODIES_PER_LINK; ++b) {
-            d.bmass[i][b] = (T)r.body_mass[i][b];
-            for (int k = 0; k < 3; ++k) { d.bcom[i][b][k] = (T)r.body_com[i][b][k]; d.binert[i][b][k] = (T)r.body_inertia[i][b][k]; }
-            for (int k = 0; k < 9; ++k) d.brot[i][b][k] = (T)r.body_rot[i][b][k];
-        }
-        d.rest_q[i] = (T)r.rest_q[i];
-    }
-    d.tcp_link = r.tcp_link; d.sensor_link = r.sensor_link;
-    for (int k = 0; k < 3; ++k) { d.tcp_pos[k] = (T)r.tcp_pos[k]; d.sensor_pos[k] = (T)r.sensor_pos[k]; d.gravity[k] = (T)r.gravity[k]; }
-    for (int k = 0; k < 9; ++k) { d.tcp_rot[k] = (T)r.tcp_rot[k]; d.sensor_rot[k] = (T)r.sensor_rot[k]; }
-    d.lin_damp = (T)r.linear_damping; d.ang_damp = (T)r.angular_damping; d.joint_damp = (T)r.joint_damping;
-    d.max_force = (T)r.max_force; d.pos_gain = (T)r.pos_gain; d.vel_gain = (T)r.vel_gain;
-    // Upper bound of trace(M(q)) over all joint angles (sim_tick's a-priori no-clamp test, tg_physics.hpp): M_ii is the inertia of
-    // the subtree of joint i about its axis <= sum over the subtree's links of trace(I_l) + m_l D^2, with D <= the summed lengths of the
-    // joint offsets on the way plus the link's own centre-of-mass offset.
-    {
-        auto parent = [&](int i) { return r.topology == 0 ? Topo<0>::parent(i) : Topo<1>::parent(i); };
-        auto len3 = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-        double tb = 0.0, dmax = 0.0;
-        for (int i = 0; i < kMaxDof; ++i) d.diag_sqrt[i] = (T)0;
-        for (int i = 0; i < N; ++i) {
-            double di = 0.0;
-            for (int l = i; l < N; ++l) {
-                double D = 0.0; int k = l; bool under = false;
-                while (k >= 0) { if (k == i) { under = true; break; } D += len3(r.joint_pos[k]); k = parent(k); }
-                if (!under) continue;
-                const double com[3] = {(double)d.lcom[l][0], (double)d.lcom[l][1], (double)d.lcom[l][2]};
-                D += len3(com);
-                di += ((double)d.linert[l][0] + (double)d.linert[l][3] + (double)d.linert[l][5]) + (double)d.lmass[l] * D * D;
-            }
-            tb += di;                                      // d_i >= M_ii(q): inertia of joint i's subtree about its axis
-            d.diag_sqrt[i] = (T)(std::sqrt(di) * 1.0000001);
-            dmax = di > dmax ? di : dmax;
-        }
-        d.trace_bound = (T)tb;
-        d.diag_sqrt_max = (T)(std::sqrt(dmax) * 1.0000001);
-    }
-    d.res_thr = (T)0;   // tg_config.solver_residual_threshold: set by tg_create; the function-level entry points run the default solver
-    return 0;
-}
-
-static int check_robot(const tg_robot* r) {
-    if (!r) return fail(-1, "robot is NULL");
-    if (r->topology == 0 && r->ndof != Topo<0>::N) return fail(-1, "topology 0 (serial chain) is built for ndof = 6");
-    if (r->topology == 1 && r->ndof != Topo<1>::N) return fail(-1, "topology 1 (MG400 tree) needs ndof = 8");
-    if (r->topology != 0 && r->topology != 1) return fail(-1, "unknown robot topology");
-    if (r->tcp_link < 0 || r->tcp_link >= r->ndof || r->sensor_link < 0 || r->sensor_link >= r->ndof) return fail(-1, "frame link out of range");
-    return 0;
-}
 
 template <typename T> static int build_env_const(const tg_config& cfg, const tg_sensor& sen, const tg_robot& rob, EnvConst<T>& c) {
     memset(&c, 0, sizeof c);
@@ -369,97 +193,6 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
 }  // namespace tg
 
 // ==================================================================================================== context
-struct tg_ctx {
-    tg_config cfg;
-    tg_robot robot;
-    int H, W, act_dim;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    bool tmpl_ready = false;               // object_balance: State.reset_tmpl has been (or will have been, in stream order) filled by a full reset
-    hipStream_t capture_stream = nullptr;   // the step graph is captured here, never on the stream work runs on (see tg_step)
-    void *d_robot = nullptr, *d_const = nullptr;   // DevRobot<T>, EnvConst<T>
-    // broadphase guard (tg_set_broadphase; tg_broadphase.hip): device scene + hull vertices, per-env results [3][n], totals {env-checks, pairs, hits}
-    tg::BpScene* d_bp = nullptr;
-    double* d_bp_hull = nullptr;
-    int32_t* d_bp_out = nullptr;
-    unsigned long long* d_bp_tot = nullptr;
-    bool bp_every_step = false;
-    tg::State st{};
-    tg::RasterParams rp{};
-    float *d_nodef_dep = nullptr, *d_verts = nullptr, *d_soup = nullptr, *d_actions = nullptr;
-    uint8_t* d_nodef_gray = nullptr;   // uint8(nodef_gray)
-    uint8_t *d_border = nullptr, *d_obs = nullptr, *d_term = nullptr, *d_mask = nullptr;
-    size_t packed_obs_bytes = 0, packed_bytes = 0, packed_feature_off = 0;   // d_obs = [obs | pad to 16 | reward f32[n] | done u8[n] | pad to 4 | feature f32[n][12]]
-    int32_t* d_tris = nullptr;
-    int n_tris = 0;
-    tg::Stimulus stim{};
-    // scene camera (tg_set_scene): shared triangle set, per-env eye<-frame transforms, rgb images
-    tg::SceneParams scene{};
-    tg::SceneView scene_view{};
-    bool scene_on = false, scene_every_step = false;
-    float *d_scene_verts = nullptr, *d_scene_xf = nullptr, *d_scene_spheres = nullptr;
-    int32_t* d_scene_tris = nullptr;
-    uint32_t *d_scene_attr = nullptr, *d_scene_local = nullptr;
-    unsigned long long* d_scene_static = nullptr;
-    tg::SceneChunk* d_scene_chunks = nullptr;
-    uint8_t *d_vis = nullptr, *d_vis_term = nullptr;
-    uint8_t* d_episode = nullptr;     // [ep_return f64[n] | ep_final_return f32[n] | ep_final_len i32[n]] (tg_get_episode_stats)
-    void* d_block_tables = nullptr;   // k_render_blocks' tables (rp.blockmax, rp.tmpl point into it)
-    uint8_t* d_tile_tmpl = nullptr;   // tile-sparse payload (tg_pack_tiles): the image every env shows without a contact - zero inside, the pasted ring outside
-    int32_t *d_int_idx = nullptr, *d_int_rank = nullptr;   // interior-only payload: pixel of interior position k / interior position of pixel p (-1: ring)
-    int n_interior = 0;
-    float* d_oracle = nullptr;        // [n][34] observation_mode "oracle" vectors (tg_get_obs_oracle), allocated on first use
-    float* d_oracle_term = nullptr;   // tg_enable_oracle_obs: the step's own vectors (before any reset): rows of finished envs = terminal observation
-    bool oracle_every_step = false;
-    bool cfg_turn_off_border = false;
-    // hipGraph of one tg_step launch sequence, keyed by the device action pointer it was captured with (launch-bound inner loop:
-    // 3-4 kernels per step, one graph launch instead)
-    hipStream_t aux_stream = nullptr;                // object_balance: the reset of finished envs runs here, beside the render
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // Render targets (tg_set_obs_targets, round 5): the tactile images of a step land in the context's own buffer (target 0) or in one of up to two
-    // caller-owned buffers (targets 1, 2: rank 0's blocks of the two alternating gathered batches, parallel.py) - each with its own changed-block
-    // record and its own captured graphs, since the destination is a kernel argument.
-    uint8_t* obs_ext[2] = {nullptr, nullptr};
-    unsigned long long* drawn_ext[2] = {nullptr, nullptr};
-    int obs_sel = 0;                                             // 0 own buffer, 1 / 2 = obs_ext[0 / 1]
-    hipGraphExec_t step_graph_t[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [target][0 reads d_actions, 1 the pinned caller-owned device buffer]
-    hipGraphExec_t* step_graph = step_graph_t[0];                // the selected target's pair
-    const float* step_graph_actions[2] = {nullptr, nullptr};
-    hipStream_t step_graph_stream[2] = {nullptr, nullptr};
-    bool graph_broken = false;
-    // tg_step_random: the policy of a random-action rollout (action_space.sample() for the whole batch) inside the step's graph
-    unsigned long long* d_draw = nullptr;      // [0] draw counter, [1] seed, [2] ticket of the sampler's last-block election
-    hipGraphExec_t random_graph_t[3] = {nullptr, nullptr, nullptr};
-    uint64_t random_seed = 0;
-    // reset bank (edge_follow / surface_follow, auto_reset; tg_kernels.hpp: BankAux)
-    tg::State bk{};                    // the bank view: st's layout, the reset-written arrays in allocations of the bank's own
-    tg::BankAux aux{};
-    int bank_mode = 0;                 // 0 off, 1 refills on bank_stream every bank_every steps, 2 as 1 and waited for (tests)
-    uint8_t* h_rows = nullptr;         // tg_copy_obs_rows: pinned staging block
-    size_t h_rows_bytes = 0;
-    int bank_every = 8;
-    static constexpr int kBankRing = 16, kBankLag = 8;    // bank_refill: markers on the step stream, one per visit; the host stays <= kBankLag visits ahead
-    hipEvent_t ev_bank_ring[kBankRing] = {};
-    unsigned long long bank_visits = 0;
-    long long bank_steps = 0;
-    hipStream_t bank_stream = nullptr;
-    hipEvent_t ev_bank = nullptr, ev_bank_done = nullptr;
-    std::vector<void*> bank_allocs;
-    void* d_bank = nullptr;            // BankDev {bk, aux} in device memory (k_reset's argument)
-    // profiling
-    bool profile = false;          // tg_profile_enable(1): HIP event pairs around every launch class, no graph
-    bool profile_clock = false;    // tg_profile_enable(2): the kernels' own clock only (tg_kt.hpp): the step stays ONE graph, reduce nodes behind its scopes
-    struct Ev { hipEvent_t a, b; int which; };
-    std::vector<Ev> events;
-    double prof_ms[6] = {0, 0, 0, 0, 0, 0};      // HIP events: step, render (k_step_render when fused), reset sequence, masked render, scene camera, an EMPTY
-    int64_t prof_n[6] = {0, 0, 0, 0, 0, 0};      // event pair (what every figure before it carries on top of its kernels)
-    // one launch per step (tg_fused.hip): -1 = TG_FUSED_STEP=0, 1 = TG_FUSED_STEP=1, 0 = where it measures faster (use_fused_step)
-    int fused_pref = 0;
-    // profiling by the kernels' own clock (tg_kt.hpp): per-wavefront {start, end} slots, reduced after every timed scope into {ticks, scopes}
-    unsigned long long* d_kt = nullptr;          // [kt_slots][2]
-    unsigned long long* d_kt_acc = nullptr;      // [8][2]
-    size_t kt_slots = 0;
-    double wall_clock_khz = 100000.0;
-};
 
 namespace tg {
 // Interior-only tactile payload (multi-GPU gather): the border ring of an image is a constant paste of the reference image
@@ -497,9 +230,6 @@ __global__ __launch_bounds__(256) void k_unpack_interior(const uint32_t* __restr
 
 }  // namespace tg
 
-static inline bool env_has_feature(int env_kind) {   // envs with an extended_feature observation (push 12, roll 3, surface_follow -v1 / -v2 6 of the 12-wide rows)
-    return env_kind == TG_ENV_OBJECT_PUSH || env_kind == TG_ENV_OBJECT_ROLL || env_kind == TG_ENV_SURFACE_FOLLOW_AUTO;
-}
 
 namespace tg {
 
@@ -542,17 +272,6 @@ struct Timer {
     }
 };
 
-static void drain_events(tg_ctx* c) {
-    for (auto& e : c->events) {
-        (void)hipEventSynchronize(e.b);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, e.a, e.b);
-        c->prof_ms[e.which] += ms;
-        c->prof_n[e.which] += 1;
-        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
-    }
-    c->events.clear();
-}
 
 template <typename T, int TOPO> static void launch_step_t(tg_ctx* c, const float* d_actions) {
     const int n = c->cfg.num_envs;
@@ -573,17 +292,6 @@ template <typename T, int TOPO> static void launch_bank_refill_t(tg_ctx* c, int 
     const int n = c->cfg.num_envs;
     hipLaunchKernelGGL((k_bank_refill<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->bank_stream, (const DevRobot<T>*)c->d_robot,
                        (const EnvConst<T>*)c->d_const, c->st, c->bk, c->aux, phase);
-}
-template <typename T, int TOPO> static void launch_refresh_t(tg_ctx* c) {
-    const int n = c->cfg.num_envs;
-    hipLaunchKernelGGL((k_refresh<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st);
-}
-
-template <typename T, int TOPO> static void launch_refresh_rpy_t(tg_ctx* c) {
-    const int n = c->cfg.num_envs;
-    hipLaunchKernelGGL((k_refresh_rpy<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                       (const EnvConst<T>*)c->d_const, c->st);
 }
 
 template <typename T> static void launch_step_body_t(tg_ctx* c, const float* d_actions) {
@@ -673,21 +381,6 @@ template <typename T, int TOPO> static void launch_reset_push_t(tg_ctx* c, const
                        (const EnvConst<T>*)c->d_const, c->st, d_mask);
 }
 
-#define TG_DISPATCH(ctx_dtype, ctx_topo, CALL)                                               \
-    do {                                                                                     \
-        if ((ctx_dtype) == TG_PHYSICS_F64) {                                                 \
-            if ((ctx_topo) == 0) { CALL(double, 0); } else { CALL(double, 1); }              \
-        } else {                                                                             \
-            if ((ctx_topo) == 0) { CALL(float, 0); } else { CALL(float, 1); }                \
-        }                                                                                    \
-    } while (0)
-
-static inline uint8_t* obs_buf(const tg_ctx* c) { return c->obs_sel == 0 ? c->d_obs : c->obs_ext[c->obs_sel - 1]; }   // where this step's images go
-static inline RasterParams raster_params(const tg_ctx* c) {   // ... and the changed-block record that belongs to that buffer
-    RasterParams P = c->rp;
-    if (c->obs_sel != 0) P.drawn = c->drawn_ext[c->obs_sel - 1];
-    return P;
-}
 static void render(tg_ctx* c, const uint8_t* d_mask, bool save_prev) {
     Timer t(c, d_mask ? 3 : 1);
     launch_render(raster_params(c), c->stim, c->st.stim_xform, 1, c->cfg.num_envs, d_mask, c->d_nodef_dep, c->d_nodef_gray,
@@ -700,38 +393,6 @@ static void render_fused(tg_ctx* c) {
                   c->d_border, obs_buf(c), nullptr, c->st.term_xform, c->st.done, c->d_term, c->stream);
 }
 
-// SoA [field][n] device -> AoS [n][field] host
-template <typename T> static int fetch_soa(tg_ctx* c, const T* dev, int fields, T* host) {
-    const int n = c->cfg.num_envs;
-    std::vector<T> tmp((size_t)fields * n);
-    hipError_t e = hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, c->stream);
-    if (e != hipSuccess) return fail(-2, hipGetErrorString(e));
-    e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return fail(-2, hipGetErrorString(e));
-    for (int f = 0; f < fields; ++f)
-        for (int i = 0; i < n; ++i) host[(size_t)i * fields + f] = tmp[(size_t)f * n + i];
-    return 0;
-}
-
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
-};
-
-template <typename T> static int upload_robot(const tg_robot* robot, DevBuf& buf) {
-    DevRobot<T> dr;
-    build_dev_robot(*robot, dr);
-    if (buf.alloc(sizeof dr)) return fail(-2, "hipMalloc failed");
-    if (hipMemcpy(buf.p, &dr, sizeof dr, hipMemcpyHostToDevice) != hipSuccess) return fail(-2, "hipMemcpy failed");
-    return 0;
-}
-
-static int need_device() {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "no HIP device visible — no CPU fallback");
-    return 0;
-}
 
 
 // env.reset() for the masked envs: task randomisation, (surface generation), robot reset.
@@ -828,7 +489,7 @@ static bool use_arm_wave(const tg_ctx* c) {
 // (profiles/r5_exp_fused_step.txt; DESIGN.md 4.1k has the why: the step code needs the SIMD's whole register file, so the draw runs on one
 // wavefront per SIMD without the occupancy the four-wavefront raster hides its latencies with, and four such wavefronts per CU slow each
 // other down by 1.7x).  Byte-identical images / rewards / dones (tests/test_gpu_fused_step.py).
-static bool use_fused_step(const tg_ctx* c) {
+bool use_fused_step(const tg_ctx* c) {
     if (c->fused_pref <= 0) return false;   // TG_FUSED_AUTO: off (see above)
     if (c->cfg.env_kind != TG_ENV_EDGE_FOLLOW || c->cfg.physics_dtype != TG_PHYSICS_F64 || c->cfg.control_mode != TG_CONTROL_TCP_VELOCITY) return false;
     if (use_arm_wave(c) || c->scene_every_step || c->oracle_every_step) return false;   // (the scene / oracle draws sit between the step and the reset)
@@ -1309,16 +970,9 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     return 0;
 }
 
-// Every entry point that touches the device first makes the context's device current: the caller may have switched devices
-// (torch.cuda.set_device, another thread) since tg_create.
-#define TG_ENTER(ctx)                                                                                        \
-    do {                                                                                                     \
-        int dev_ = -1;                                                                                       \
-        if (hipGetDevice(&dev_) != hipSuccess || dev_ != (ctx)->cfg.device) TG_HIP(hipSetDevice((ctx)->cfg.device)); \
-    } while (0)
 
 }  // extern "C"
-static void drop_step_graphs(tg_ctx* c) {   // every captured step graph of every render target (they are captured again on the next step)
+void drop_step_graphs(tg_ctx* c) {   // every captured step graph of every render target (they are captured again on the next step)
     for (int t = 0; t < 3; ++t) {
         for (int k = 0; k < 2; ++k) if (c->step_graph_t[t][k]) { (void)hipGraphExecDestroy(c->step_graph_t[t][k]); c->step_graph_t[t][k] = nullptr; }
         if (c->random_graph_t[t]) { (void)hipGraphExecDestroy(c->random_graph_t[t]); c->random_graph_t[t] = nullptr; }
@@ -1663,117 +1317,6 @@ int tg_select_obs_target(tg_ctx* c, int32_t index) {
     return 0;
 }
 
-int tg_set_broadphase(tg_ctx* c, const tg_broadphase* g) {
-    if (!c) return fail(-1, "NULL argument");
-    TG_ENTER(c);
-    TG_HIP(hipStreamSynchronize(c->stream));
-    drop_step_graphs(c);                         // the guard is (or stops being) a node of the step graphs
-    if (c->d_bp) { (void)hipFree(c->d_bp); c->d_bp = nullptr; }
-    if (c->d_bp_hull) { (void)hipFree(c->d_bp_hull); c->d_bp_hull = nullptr; }
-    c->bp_every_step = false;
-    if (!g) return 0;
-    if (g->n_hull_verts < 0 || (g->n_hull_verts > 0 && !g->hull_verts) || !(g->margin >= 0.0) || !(g->sphere_half > 0.0))
-        return fail(-1, "tg_set_broadphase: bad argument");
-    const int N = c->robot.ndof;
-    BpScene h{};
-    for (int k = 0; k < TG_BP_SLOTS; ++k) {
-        const tg_bp_box& b = g->box[k];
-        if (b.src < TG_BP_NONE || b.src > TG_BP_BALL) return fail(-1, "tg_set_broadphase: unknown pose source");
-        if (b.src == TG_BP_LINK && (b.link < -1 || b.link >= N)) return fail(-1, "tg_set_broadphase: link index out of range");
-        if (b.src == TG_BP_LINK && (b.hull_off < 0 || b.hull_n < 0 || b.hull_off + b.hull_n > g->n_hull_verts)) return fail(-1, "tg_set_broadphase: hull range out of bounds");
-        if ((b.src == TG_BP_BODY || b.src == TG_BP_SPHERE) && c->st.body_pos == nullptr) return fail(-1, "tg_set_broadphase: this env has no free body");
-        if (b.src == TG_BP_BALL && c->st.ball == nullptr) return fail(-1, "tg_set_broadphase: this env has no ball");
-        if (b.src == TG_BP_EDGE && c->cfg.env_kind != TG_ENV_EDGE_FOLLOW) return fail(-1, "tg_set_broadphase: TG_BP_EDGE outside edge_follow");
-        if (b.conj < -1 || b.conj >= TG_BP_SLOTS || (b.conj >= 0 && g->box[b.conj].src == TG_BP_NONE)) return fail(-1, "tg_set_broadphase: bad conj slot");
-        h.box[k] = b;
-    }
-    h.margin = g->margin; h.hull_margin = g->hull_margin; h.sphere_half = g->sphere_half; h.ball_radius = g->ball_radius;
-    for (int k = 0; k < 3; ++k) h.stim_pos[k] = c->cfg.stim_pos[k];
-    h.table_slot = 16; h.has_ball = c->st.ball != nullptr;
-    const size_t hb = (size_t)std::max(g->n_hull_verts, 1) * 3 * 8;
-    TG_HIP(hipMalloc(&c->d_bp_hull, hb));
-    if (g->n_hull_verts > 0) TG_HIP(hipMemcpy(c->d_bp_hull, g->hull_verts, (size_t)g->n_hull_verts * 3 * 8, hipMemcpyHostToDevice));
-    h.hull = c->d_bp_hull;
-    TG_HIP(hipMalloc(&c->d_bp, sizeof h)); TG_HIP(hipMemcpy(c->d_bp, &h, sizeof h, hipMemcpyHostToDevice));
-    const size_t ob = (size_t)3 * c->cfg.num_envs * 4;
-    if (!c->d_bp_out) TG_HIP(hipMalloc(&c->d_bp_out, ob));
-    if (!c->d_bp_tot) TG_HIP(hipMalloc(&c->d_bp_tot, 3 * 8));
-    TG_HIP(hipMemset(c->d_bp_out, 0, ob)); TG_HIP(hipMemset(c->d_bp_tot, 0, 3 * 8));
-    c->bp_every_step = g->every_step != 0;
-    return 0;
-}
-int tg_check_broadphase(tg_ctx* c) {
-    if (!c) return fail(-1, "NULL argument");
-    if (!c->d_bp) return fail(-1, "tg_check_broadphase: no guard (tg_set_broadphase)");
-    TG_ENTER(c);
-    if (launch_broadphase(c->cfg.physics_dtype, c->robot.topology, c->cfg.num_envs, c->stream, c->d_robot, c->d_bp, c->st, c->d_bp_out, c->d_bp_tot))
-        return fail(-3, "tg_check_broadphase: unsupported topology");
-    TG_HIP(hipGetLastError());
-    return 0;
-}
-int tg_get_broadphase_totals(tg_ctx* c, int64_t* checks, int64_t* pairs, int64_t* hits) {
-    if (!c || !checks || !pairs || !hits) return fail(-1, "NULL argument");
-    *checks = *pairs = *hits = 0;
-    if (!c->d_bp_tot) return 0;
-    TG_ENTER(c);
-    unsigned long long t[3];
-    TG_HIP(hipMemcpyAsync(t, c->d_bp_tot, sizeof t, hipMemcpyDeviceToHost, c->stream));
-    TG_HIP(hipStreamSynchronize(c->stream));
-    *checks = (int64_t)t[0]; *pairs = (int64_t)t[1]; *hits = (int64_t)t[2];
-    return 0;
-}
-
-int tg_get_step_mode(tg_ctx* c, int32_t* mode, int32_t* envs_per_wavefront) {
-    if (!c || !mode) return fail(-1, "NULL argument");
-    *mode = use_fused_step(c) ? 1 : 0;
-    if (envs_per_wavefront) *envs_per_wavefront = *mode ? fused_envs_per_wave(c->cfg.num_envs) : 0;
-    return 0;
-}
-
-int tg_get_actions(tg_ctx* c, void** dev_actions) {
-    if (!c || !dev_actions) return fail(-1, "NULL argument");
-    *dev_actions = c->d_actions;
-    return 0;
-}
-
-int tg_get_interior_count(tg_ctx* c, int32_t* k) {
-    if (!c || !k) return fail(-1, "NULL argument");
-    *k = c->cfg_turn_off_border ? -1 : 4 * c->n_interior;   // bytes per image; -1: the ring carries rendered values (turn_off_border), nothing to drop
-    return 0;
-}
-int tg_get_bank_stats(tg_ctx* c, int64_t* swapped, int64_t* late, int32_t* mode) {
-    if (!c || !swapped || !late || !mode) return fail(-1, "NULL argument");
-    TG_ENTER(c);
-    *swapped = 0; *late = 0; *mode = c->bank_mode;
-    if (c->st.tmpl_stats != nullptr) {           // object_push: the reset template's counters (mode 3; k_reset_contact_wave)
-        unsigned long long t[2] = {0, 0};
-        TG_HIP(hipMemcpyAsync(t, c->st.tmpl_stats, 16, hipMemcpyDeviceToHost, c->stream));
-        TG_HIP(hipStreamSynchronize(c->stream));
-        *swapped = (int64_t)t[0]; *late = (int64_t)t[1]; *mode = c->st.reset_tmpl != nullptr ? 3 : 0;
-        return 0;
-    }
-    if (c->bank_mode == 0) return 0;
-    unsigned long long h[2] = {0, 0};
-    TG_HIP(hipMemcpyAsync(h, c->aux.stats, 16, hipMemcpyDeviceToHost, c->stream));
-    TG_HIP(hipStreamSynchronize(c->stream));
-    *swapped = (int64_t)h[0]; *late = (int64_t)h[1];
-    return 0;
-}
-
-int tg_get_episode_stats(tg_ctx* c, void** ret_f32, void** len_i32) {
-    if (!c || !ret_f32 || !len_i32) return fail(-1, "NULL argument");
-    *ret_f32 = c->st.ep_final_return;
-    *len_i32 = c->st.ep_final_len;
-    return 0;
-}
-int tg_copy_episode_stats(tg_ctx* c, float* ret, int32_t* len) {
-    if (!c || !ret || !len) return fail(-1, "NULL argument");
-    TG_ENTER(c);
-    TG_HIP(hipMemcpyAsync(ret, c->st.ep_final_return, (size_t)c->cfg.num_envs * 4, hipMemcpyDeviceToHost, c->stream));
-    TG_HIP(hipMemcpyAsync(len, c->st.ep_final_len, (size_t)c->cfg.num_envs * 4, hipMemcpyDeviceToHost, c->stream));
-    TG_HIP(hipStreamSynchronize(c->stream));
-    return 0;
-}
 int tg_get_tile_template(tg_ctx* c, void** p) {
     if (!c || !p) return fail(-1, "NULL argument");
     *p = c->d_tile_tmpl;
@@ -2096,328 +1639,6 @@ int tg_copy_obs_rows(tg_ctx* c, int32_t visual, int32_t terminal, const int32_t*
         TG_HIP(hipStreamSynchronize(c->stream));
         memcpy(dst + (size_t)k0 * img, c->h_rows, (size_t)m * img);
     }
-    return 0;
-}
-
-int tg_get_state(tg_ctx* c, const tg_state_view* v) {
-    if (!c || !v) return fail(-1, "NULL argument");
-    TG_ENTER(c);
-    const int nd = c->robot.ndof;
-    int rc = 0;
-    if (v->q && (rc = fetch_soa(c, c->st.q, nd, v->q))) return rc;
-    if (v->qd && (rc = fetch_soa(c, c->st.qd, nd, v->qd))) return rc;
-    if (v->qd_target && (rc = fetch_soa(c, c->st.qd_target, nd, v->qd_target))) return rc;
-    if (v->tcp_rpy && (c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO)) {   // k_step leaves this read-back to be recomputed on demand
-#define CALL(T, TOPO) launch_refresh_rpy_t<T, TOPO>(c)
-        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
-#undef CALL
-    }
-    if (v->tcp_pos && (rc = fetch_soa(c, c->st.tcp_pos, 3, v->tcp_pos))) return rc;
-    if (v->tcp_rpy && (rc = fetch_soa(c, c->st.tcp_rpy, 3, v->tcp_rpy))) return rc;
-    if (v->edge_ang && (rc = fetch_soa(c, c->st.edge_ang, 1, v->edge_ang))) return rc;
-    if (v->embed_dist && (rc = fetch_soa(c, c->st.embed, 1, v->embed_dist))) return rc;
-    if (v->stim_xform && (rc = fetch_soa(c, c->st.stim_xform, 12, v->stim_xform))) return rc;
-    if (v->step_count && (rc = fetch_soa(c, c->st.step_count, 1, v->step_count))) return rc;
-    if (v->reset_ticks && (rc = fetch_soa(c, c->st.reset_ticks, 1, v->reset_ticks))) return rc;
-    if (v->rng_state && (rc = fetch_soa(c, c->st.rng, 1, v->rng_state))) return rc;
-    if (v->solver_sweeps && (rc = fetch_soa(c, c->st.sweeps, 1, v->solver_sweeps))) return rc;
-    {   // broadphase guard results of the last check (zeros without a guard)
-        int32_t* dst[3] = {v->broadphase_pairs, v->broadphase_hits, v->broadphase_mask};
-        for (int k = 0; k < 3; ++k) {
-            if (!dst[k]) continue;
-            if (c->d_bp_out) { if ((rc = fetch_soa(c, c->d_bp_out + (size_t)k * c->cfg.num_envs, 1, dst[k]))) return rc; }
-            else memset(dst[k], 0, (size_t)c->cfg.num_envs * 4);
-        }
-    }
-    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE) {
-        if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
-        if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;
-        if (v->body_linvel && (rc = fetch_soa(c, c->st.body_v, 3, v->body_linvel))) return rc;
-        if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
-        if (v->gravity_z && (rc = fetch_soa(c, c->st.gravity, 1, v->gravity_z))) return rc;
-        if (c->st.ball) {
-            if (v->ball_pos && (rc = fetch_soa(c, c->st.ball, 3, v->ball_pos))) return rc;
-            if (v->ball_linvel && (rc = fetch_soa(c, c->st.ball + (size_t)3 * c->cfg.num_envs, 3, v->ball_linvel))) return rc;
-            if (v->ball_angvel && (rc = fetch_soa(c, c->st.ball + (size_t)6 * c->cfg.num_envs, 3, v->ball_angvel))) return rc;
-            if (v->ball_impulse && (rc = fetch_soa(c, c->st.ball + (size_t)12 * c->cfg.num_envs, 1, v->ball_impulse))) return rc;
-        }
-    }
-    if (c->cfg.env_kind == TG_ENV_OBJECT_ROLL) {
-        if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
-        if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;
-        if (v->body_linvel && (rc = fetch_soa(c, c->st.body_v, 3, v->body_linvel))) return rc;
-        if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
-        if (v->goal_pos && (rc = fetch_soa(c, c->st.goal, 3, v->goal_pos))) return rc;          // goal_pos_tcp
-        if (v->obj_mass && (rc = fetch_soa(c, c->st.obj_mass, 1, v->obj_mass))) return rc;      // the episode's radius
-    }
-    if (c->cfg.env_kind == TG_ENV_OBJECT_PUSH) {
-        if (v->body_pos && (rc = fetch_soa(c, c->st.body_pos, 3, v->body_pos))) return rc;
-        if (v->body_rot && (rc = fetch_soa(c, c->st.body_rot, 9, v->body_rot))) return rc;
-        if (v->body_linvel && (rc = fetch_soa(c, c->st.body_v, 3, v->body_linvel))) return rc;
-        if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
-        if (v->traj && (rc = fetch_soa(c, c->st.traj, 3 * TG_MAX_TRAJ_POINTS, v->traj))) return rc;
-        if (v->goal_id && (rc = fetch_soa(c, c->st.goal_id, 1, v->goal_id))) return rc;
-        if (v->obj_mass && (rc = fetch_soa(c, c->st.obj_mass, 1, v->obj_mass))) return rc;
-    }
-    if (v->contact_count || v->contact_ids) {
-        // contact pairs of the last sim tick, in solver row order: the cube vertices on the table in vertex order (ids 0-7; the marble's
-        // single table contact is id 0), then the tip contact (id 8 + index of the tip-core hull vertex that made it; 8 for the marble)
-        const int n = c->cfg.num_envs;
-        std::vector<int32_t> code(n);
-        if ((rc = fetch_soa(c, c->st.contact_code, 1, code.data()))) return rc;
-        for (int i = 0; i < n; ++i) {
-            int cnt = 0;
-            int32_t ids[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-            for (int b = 0; b < 8 && cnt < 4; ++b) if ((code[i] >> b) & 1) ids[cnt++] = b;
-            if ((code[i] >> 30) & 1) {   // tg_config.narrowphase != 0: bits 8-11 = the live slots of the tip - cube manifold, ids 8 + slot
-                for (int k = 0; k < 4; ++k) if ((code[i] >> (8 + k)) & 1) ids[cnt++] = 8 + k;
-            } else if ((code[i] >> 8) & 1) ids[cnt++] = 8 + (code[i] >> 9);
-            if (v->contact_count) v->contact_count[i] = cnt;
-            if (v->contact_ids) for (int k = 0; k < 8; ++k) v->contact_ids[(size_t)i * 8 + k] = ids[k];
-        }
-    }
-    if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
-        if (v->goal_pos && (rc = fetch_soa(c, c->st.goal, 3, v->goal_pos))) return rc;
-        if (v->direction && (rc = fetch_soa(c, c->st.dir, 2, v->direction))) return rc;
-        if (v->surf_zoff && (rc = fetch_soa(c, c->st.surf_zoff, 1, v->surf_zoff))) return rc;
-        if (v->heights) {
-            TG_HIP(hipMemcpyAsync(v->heights, c->st.heights, (size_t)c->cfg.num_envs * c->cfg.surf_rows * c->cfg.surf_cols * 8, hipMemcpyDeviceToHost, c->stream));
-            TG_HIP(hipStreamSynchronize(c->stream));
-        }
-    }
-    return 0;
-}
-
-int tg_set_joint_state(tg_ctx* c, const double* q, const double* qd) {
-    if (!c || !q || !qd) return fail(-1, "NULL argument");
-    TG_ENTER(c);
-    if (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE || c->cfg.env_kind == TG_ENV_OBJECT_PUSH || c->cfg.env_kind == TG_ENV_OBJECT_ROLL)
-        return fail(-1, "tg_set_joint_state: not supported for envs with a free object");
-    const int n = c->cfg.num_envs, nd = c->robot.ndof;
-    std::vector<double> a((size_t)TG_MAX_DOF * n, 0.0), b((size_t)TG_MAX_DOF * n, 0.0);
-    for (int i = 0; i < n; ++i)
-        for (int f = 0; f < nd; ++f) { a[(size_t)f * n + i] = q[(size_t)i * nd + f]; b[(size_t)f * n + i] = qd[(size_t)i * nd + f]; }
-    TG_HIP(hipMemcpyAsync(c->st.q, a.data(), a.size() * 8, hipMemcpyHostToDevice, c->stream));
-    TG_HIP(hipMemcpyAsync(c->st.qd, b.data(), b.size() * 8, hipMemcpyHostToDevice, c->stream));
-    TG_HIP(hipMemsetAsync(c->st.licence, 0, (size_t)n * 4, c->stream));   // new configuration: full solve and exact sines / cosines next
-#define CALL(T, TOPO) launch_refresh_t<T, TOPO>(c)
-    TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
-#undef CALL
-    render(c, nullptr, false);
-    TG_HIP(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-int tg_profile_enable(tg_ctx* c, int32_t enable) {
-    if (!c) return fail(-1, "NULL ctx");
-    (void)hipStreamSynchronize(c->stream);
-    drain_events(c);
-    c->profile = enable == 1;
-    if (c->profile_clock != (enable == 2)) {
-        // the step graphs carry the slot pointer (or its absence) in their kernel arguments: captured again on the next step
-        drop_step_graphs(c);
-        c->profile_clock = enable == 2;
-    }
-    for (int k = 0; k < 6; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
-    if (enable && !c->d_kt) {
-        // slots for the largest launch of this context: a render of every env's image in 64-row tiles, two passes, four wavefronts each
-        const size_t n = (size_t)c->cfg.num_envs;
-        c->kt_slots = std::max<size_t>(n + 64, (size_t)((c->rp.W + 63) / 64) * (size_t)((c->rp.H + 63) / 64) * n * 8);
-        TG_HIP(hipMalloc(&c->d_kt, c->kt_slots * 16));
-        TG_HIP(hipMalloc(&c->d_kt_acc, 8 * 16));
-        std::vector<unsigned long long> init(c->kt_slots * 2);
-        for (size_t i = 0; i < c->kt_slots; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
-        TG_HIP(hipMemcpy(c->d_kt, init.data(), c->kt_slots * 16, hipMemcpyHostToDevice));
-        int khz = 0;
-        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
-    }
-    if (c->d_kt_acc) TG_HIP(hipMemset(c->d_kt_acc, 0, 8 * 16));
-    return 0;
-}
-// which: 0 step kernel, 1 render (the one launch of a fused step), 2 reset sequence, 3 masked render, 4 scene camera, 5 an empty event pair: by
-// HIP events on the launch stream; 8 + k (k = 0 .. 3): class k by the kernels' own clock (tg_kt.hpp: first wavefront start -> last wavefront end).
-int tg_profile_get(tg_ctx* c, int32_t which, double* total_ms, int64_t* launches) {
-    if (!c || which < 0 || (which > 5 && which < 8) || which > 11) return fail(-1, "bad argument");
-    (void)hipStreamSynchronize(c->stream);
-    drain_events(c);
-    if (which >= 8) {
-        unsigned long long h[2] = {0, 0};
-        if (c->d_kt_acc) TG_HIP(hipMemcpy(h, c->d_kt_acc + 2 * (which - 8), 16, hipMemcpyDeviceToHost));
-        if (total_ms) *total_ms = (double)h[0] / c->wall_clock_khz;
-        if (launches) *launches = (int64_t)h[1];
-        return 0;
-    }
-    if (total_ms) *total_ms = c->prof_ms[which];
-    if (launches) *launches = c->prof_n[which];
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------- function-level entry points
-#define TG_FN_DISPATCH(robot, dtype, KERNEL, n, ...)                                                                              \
-    do {                                                                                                                          \
-        DevBuf rb;                                                                                                                \
-        dim3 grid(((n) + 63) / 64), block(64);                                                                                    \
-        if ((dtype) == TG_PHYSICS_F64) {                                                                                          \
-            if (int rc = upload_robot<double>(robot, rb)) return rc;                                                              \
-            if ((robot)->topology == 0) hipLaunchKernelGGL((KERNEL<double, 0>), grid, block, 0, 0, (const DevRobot<double>*)rb.p, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<double, 1>), grid, block, 0, 0, (const DevRobot<double>*)rb.p, __VA_ARGS__);          \
-        } else {                                                                                                                  \
-            if (int rc = upload_robot<float>(robot, rb)) return rc;                                                               \
-            if ((robot)->topology == 0) hipLaunchKernelGGL((KERNEL<float, 0>), grid, block, 0, 0, (const DevRobot<float>*)rb.p, __VA_ARGS__);   \
-            else hipLaunchKernelGGL((KERNEL<float, 1>), grid, block, 0, 0, (const DevRobot<float>*)rb.p, __VA_ARGS__);            \
-        }                                                                                                                         \
-        TG_HIP(hipDeviceSynchronize());                                                                                           \
-    } while (0)
-
-int tg_inverse_dynamics(const tg_robot* robot, int32_t dtype, int32_t n, const double* q, const double* qd, const double* qdd, double* tau) {
-    if (int rc = check_robot(robot)) return rc;
-    if (int rc = need_device()) return rc;
-    const size_t bytes = (size_t)n * robot->ndof * 8;
-    DevBuf a, b, c, d;
-    if (a.alloc(bytes) || b.alloc(bytes) || c.alloc(bytes) || d.alloc(bytes)) return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(a.p, q, bytes, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(b.p, qd, bytes, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(c.p, qdd, bytes, hipMemcpyHostToDevice));
-    TG_FN_DISPATCH(robot, dtype, k_inverse_dynamics, n, n, (const double*)a.p, (const double*)b.p, (const double*)c.p, (double*)d.p);
-    TG_HIP(hipMemcpy(tau, d.p, bytes, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int tg_mass_matrix(const tg_robot* robot, int32_t dtype, int32_t n, const double* q, double* M) {
-    if (int rc = check_robot(robot)) return rc;
-    if (int rc = need_device()) return rc;
-    const int nd = robot->ndof;
-    DevBuf a, b;
-    if (a.alloc((size_t)n * nd * 8) || b.alloc((size_t)n * nd * nd * 8)) return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(a.p, q, (size_t)n * nd * 8, hipMemcpyHostToDevice));
-    TG_FN_DISPATCH(robot, dtype, k_mass_matrix, n, n, (const double*)a.p, (double*)b.p);
-    TG_HIP(hipMemcpy(M, b.p, (size_t)n * nd * nd * 8, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int tg_jacobian_tcp(const tg_robot* robot, int32_t dtype, int32_t n, const double* q, double* J, double* pos, double* rot) {
-    if (int rc = check_robot(robot)) return rc;
-    if (int rc = need_device()) return rc;
-    const int nd = robot->ndof;
-    DevBuf a, b, c, d;
-    if (a.alloc((size_t)n * nd * 8) || b.alloc((size_t)n * 6 * nd * 8) || c.alloc((size_t)n * 24) || d.alloc((size_t)n * 72)) return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(a.p, q, (size_t)n * nd * 8, hipMemcpyHostToDevice));
-    TG_FN_DISPATCH(robot, dtype, k_jacobian, n, n, (const double*)a.p, (double*)b.p, (double*)c.p, (double*)d.p);
-    if (J) TG_HIP(hipMemcpy(J, b.p, (size_t)n * 6 * nd * 8, hipMemcpyDeviceToHost));
-    if (pos) TG_HIP(hipMemcpy(pos, c.p, (size_t)n * 24, hipMemcpyDeviceToHost));
-    if (rot) TG_HIP(hipMemcpy(rot, d.p, (size_t)n * 72, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int tg_sim_ticks(const tg_robot* robot, int32_t dtype, int32_t n, int32_t n_ticks, int32_t iters, double dt, int32_t motor_mode,
-                 const double* q_des, const double* qd_des, double max_force, double* q, double* qd) {
-    if (int rc = check_robot(robot)) return rc;
-    if (int rc = need_device()) return rc;
-    const size_t bytes = (size_t)n * robot->ndof * 8;
-    DevBuf a, b, c, d;
-    if (a.alloc(bytes) || b.alloc(bytes) || c.alloc(bytes) || d.alloc(bytes)) return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(a.p, q, bytes, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(b.p, qd, bytes, hipMemcpyHostToDevice));
-    if (q_des) TG_HIP(hipMemcpy(c.p, q_des, bytes, hipMemcpyHostToDevice));
-    if (qd_des) TG_HIP(hipMemcpy(d.p, qd_des, bytes, hipMemcpyHostToDevice));
-    TG_FN_DISPATCH(robot, dtype, k_sim_ticks, n, n, n_ticks, iters, dt, motor_mode, q_des ? (const double*)c.p : (const double*)nullptr,
-                   qd_des ? (const double*)d.p : (const double*)nullptr, max_force, (double*)a.p, (double*)b.p);
-    TG_HIP(hipMemcpy(q, a.p, bytes, hipMemcpyDeviceToHost)); TG_HIP(hipMemcpy(qd, b.p, bytes, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int tg_inverse_kinematics(const tg_robot* robot, int32_t dtype, int32_t n, const double* q0, const double* target_pos, const double* target_rot,
-                          int32_t max_iters, double threshold, double* q_out, int32_t* iters) {
-    if (int rc = check_robot(robot)) return rc;
-    if (int rc = need_device()) return rc;
-    const int nd = robot->ndof;
-    DevBuf a, b, c, d, e;
-    if (a.alloc((size_t)n * nd * 8) || b.alloc((size_t)n * 24) || c.alloc((size_t)n * 72) || d.alloc((size_t)n * nd * 8) || e.alloc((size_t)n * 4))
-        return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(a.p, q0, (size_t)n * nd * 8, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(b.p, target_pos, (size_t)n * 24, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(c.p, target_rot, (size_t)n * 72, hipMemcpyHostToDevice));
-    TG_FN_DISPATCH(robot, dtype, k_ik, n, n, (const double*)a.p, (const double*)b.p, (const double*)c.p, max_iters, threshold, (double*)d.p,
-                   (int32_t*)e.p);
-    TG_HIP(hipMemcpy(q_out, d.p, (size_t)n * nd * 8, hipMemcpyDeviceToHost));
-    if (iters) TG_HIP(hipMemcpy(iters, e.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int tg_render_tactile(const tg_sensor* sen, const tg_mesh* mesh, int32_t n, const float* xf, uint8_t* out) {
-    if (!sen || !mesh || !xf || !out) return fail(-1, "NULL argument");
-    if (int rc = need_device()) return rc;
-    const int H = sen->image_h, W = sen->image_w;
-    if (!((H % 128 == 0 && W % 128 == 0) || (H == 64 && W == 64))) return fail(-1, "image size must be 64x64 or a multiple of 128");
-    const size_t npix = (size_t)H * W;
-    DevBuf nd, ng, bm, vv, tt, xx, oo;
-    if (nd.alloc(npix * 4) || ng.alloc(npix * 4) || bm.alloc(npix) || vv.alloc((size_t)mesh->n_verts * 12) || tt.alloc((size_t)mesh->n_tris * 12) ||
-        xx.alloc((size_t)n * 48) || oo.alloc(npix * n))
-        return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(nd.p, sen->nodef_dep, npix * 4, hipMemcpyHostToDevice));
-    { std::vector<uint8_t> g8(npix); make_gray_u8(sen->nodef_gray, (int)npix, g8.data()); TG_HIP(hipMemcpy(ng.p, g8.data(), npix, hipMemcpyHostToDevice)); }
-    TG_HIP(hipMemcpy(bm.p, sen->border_mask, npix, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(vv.p, mesh->verts, (size_t)mesh->n_verts * 12, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(tt.p, mesh->tris, (size_t)mesh->n_tris * 12, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(xx.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
-    TG_HIP(hipMemset(oo.p, 0, npix * n));
-    RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
-    DevBuf bt;
-    if (make_block_tables(P, sen->nodef_dep, sen->nodef_gray, sen->border_mask, n, &bt.p)) return fail(-2, "hipMalloc failed");
-    Stimulus S{};
-    S.closed_outward = (mesh_closed_outward(mesh) && getenv("TG_NO_BACKFACE_CULL") == nullptr) ? 1 : 0;   // env var: A/B measurements only
-    DevBuf sp;
-    {
-        std::vector<float> soup((size_t)mesh->n_tris * 9);
-        for (int t = 0; t < mesh->n_tris; ++t)
-            for (int k = 0; k < 3; ++k)
-                for (int a = 0; a < 3; ++a) soup[(size_t)t * 9 + 3 * k + a] = mesh->verts[3 * (size_t)mesh->tris[3 * t + k] + a];
-        if (sp.alloc(soup.size() * 4 + 4)) return fail(-2, "hipMalloc failed");
-        TG_HIP(hipMemcpy(sp.p, soup.data(), soup.size() * 4, hipMemcpyHostToDevice));
-    }
-    S.kind = 0; S.verts = (const float*)vv.p; S.tris = (const int32_t*)tt.p; S.soup = (const float*)sp.p; S.n_tris = mesh->n_tris;
-    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, nullptr, nullptr, nullptr, 0);
-    TG_HIP(hipDeviceSynchronize());
-    TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int tg_render_tactile_heightfield(const tg_sensor* sen, int32_t rows, int32_t cols, double grid_scale, int32_t n, const double* heights,
-                                  const float* zoff, const float* xf, uint8_t* out) {
-    if (!sen || !heights || !zoff || !xf || !out) return fail(-1, "NULL argument");
-    if (int rc = need_device()) return rc;
-    const int H = sen->image_h, W = sen->image_w;
-    if (!((H % 128 == 0 && W % 128 == 0) || (H == 64 && W == 64))) return fail(-1, "image size must be 64x64 or a multiple of 128");
-    const size_t npix = (size_t)H * W, cells = (size_t)rows * cols;
-    DevBuf nd, ng, bm, hh, zz, xx, oo;
-    if (nd.alloc(npix * 4) || ng.alloc(npix * 4) || bm.alloc(npix) || hh.alloc(cells * n * 8) || zz.alloc((size_t)n * 4) || xx.alloc((size_t)n * 48) ||
-        oo.alloc(npix * n))
-        return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(nd.p, sen->nodef_dep, npix * 4, hipMemcpyHostToDevice));
-    { std::vector<uint8_t> g8(npix); make_gray_u8(sen->nodef_gray, (int)npix, g8.data()); TG_HIP(hipMemcpy(ng.p, g8.data(), npix, hipMemcpyHostToDevice)); }
-    TG_HIP(hipMemcpy(bm.p, sen->border_mask, npix, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(hh.p, heights, cells * n * 8, hipMemcpyHostToDevice)); TG_HIP(hipMemcpy(zz.p, zoff, (size_t)n * 4, hipMemcpyHostToDevice));
-    TG_HIP(hipMemcpy(xx.p, xf, (size_t)n * 48, hipMemcpyHostToDevice));
-    TG_HIP(hipMemset(oo.p, 0, npix * n));
-    RasterParams P = make_raster_params(W, H, sen->fov_deg, sen->near_plane, sen->far_plane, sen->turn_off_border, sen->nodef_dep);
-    Stimulus S{};
-    S.kind = 1; S.heights = (const double*)hh.p; S.zoff = (const float*)zz.p; S.rows = rows; S.cols = cols; S.scale = (float)grid_scale;
-    S.n_tris = (rows - 1) * (cols - 1) * 2;
-    launch_render(P, S, (const float*)xx.p, 0, n, nullptr, (const float*)nd.p, (const uint8_t*)ng.p, (const uint8_t*)bm.p, (uint8_t*)oo.p, nullptr, nullptr, nullptr, nullptr, 0);
-    TG_HIP(hipDeviceSynchronize());
-    TG_HIP(hipMemcpy(out, oo.p, npix * n, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int tg_gen_heightfield(int32_t n, const int64_t* seeds, int32_t rows, int32_t cols, double interp, double range, double* heights, float* zoff) {
-    if (!seeds || !heights) return fail(-1, "NULL argument");
-    if (int rc = need_device()) return rc;
-    const size_t cells = (size_t)rows * cols;
-    DevBuf sd, hh, zz;
-    if (sd.alloc((size_t)n * 8) || hh.alloc(cells * n * 8) || zz.alloc((size_t)n * 4)) return fail(-2, "hipMalloc failed");
-    TG_HIP(hipMemcpy(sd.p, seeds, (size_t)n * 8, hipMemcpyHostToDevice));
-    launch_gen_surface(n, nullptr, (const int64_t*)sd.p, rows, cols, interp, range, 1, 0, (double*)hh.p, (float*)zz.p, 0);
-    TG_HIP(hipDeviceSynchronize());
-    TG_HIP(hipMemcpy(heights, hh.p, cells * n * 8, hipMemcpyDeviceToHost));
-    if (zoff) TG_HIP(hipMemcpy(zoff, zz.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -54,7 +54,7 @@ MAX_STEPS = {"object_balance-v0": 250, "object_push-v0": 1000, "object_roll-v0":
 ALGO_BYTES_PER_ENV_STEP = 16600.0   # BASELINE.md section 3 / SURVEY 8(d): 16 384 B image + ~0.2 KB state/action/reward
 ALGO_BYTES_SURFACE = 33000.0        # config 3: + the per-env 64x64 f32 heightfield read
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-TRAFFIC_FILE = os.path.join("profiles", "r5_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r6_traffic.json")
 
 
 def algo_bytes(env_id, image_size):
@@ -736,7 +736,7 @@ def main():
         staggered = {"value": round(1024 / sdt, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * sdt, 4), **sinfo,
                      "what": "the headline workload with every env's episode phase drawn uniformly (masked resets during the first 200 steps): ~5 of 1024 envs "
                              "finish in every step; finished envs take their precomputed reset from the reset bank (tg_config.reset_bank, on by default) "
-                             "and keep their solver licence (tools/desync_rate.py, profiles/r5_final_desync.txt)"}
+                             "and keep their solver licence (tools/desync_rate.py, profiles/r6_final_desync.txt)"}
 
     if rank == 0:
         total_envs = n * world

@@ -372,6 +372,15 @@ int tg_copy_obs_tactile(tg_ctx* ctx, uint8_t* host_dst, int32_t terminal);
  * episodes out of phase a handful of envs finish in nearly every step, and copying the whole terminal batch for them (16.8 MB at 1024 x
  * 128 x 128) was two thirds of the numpy step's time.  ABI v12. */
 int tg_copy_obs_rows(tg_ctx* ctx, int32_t visual, int32_t terminal, const int32_t* env_ids, int32_t count, uint8_t* host_dst);
+/* The same for the envs that finished in the last step, without the host naming them (ABI v13, round 6): ONE launch on the context's stream compacts
+ * the done flags and stores, straight into device-visible pinned host memory `dst_pinned` (tg_done_rows_bytes(cap) bytes, 16-byte aligned), a 16-byte
+ * header {u32 count = envs done, u32 cap, u32 num_envs, u32 magic 0x74674452}, then int32 ids[cap] (ascending), float32 episode returns[cap], int32
+ * episode lengths[cap] (the Monitor statistics of tg_get_episode_stats), then, 16-byte aligned, uint8 rows[cap][H * W]: the TERMINAL tactile images of
+ * the first min(count, cap) finished envs.  What info["terminal_observation"] / info["episode"] need arrives under the synchronisation the
+ * observation fetch makes anyway (sb3_helpers/rl_utils.py:17-37: SubprocVecEnv's workers send obs, reward, done and info in one message).
+ * count > cap: the caller falls back to tg_copy_obs_rows / tg_copy_episode_stats for that step. */
+int tg_done_rows_bytes(tg_ctx* ctx, int32_t cap, int64_t* bytes);
+int tg_pack_done_rows(tg_ctx* ctx, void* dst_pinned, int32_t cap);
 int tg_copy_obs_feature(tg_ctx* ctx, float* host_dst, int32_t terminal);   /* float32 [num_envs][12] */
 
 /* Parity / inspection view of the per-env state, host arrays sized by the caller ([num_envs][...]), any may be NULL. */

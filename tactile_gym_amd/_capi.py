@@ -195,6 +195,8 @@ SYMBOLS = {
     "tg_copy_obs_oracle_terminal": (C.c_int, [_ctx, _fp]),
     "tg_set_scene": (C.c_int, [_ctx, C.POINTER(TgScene)]),
     "tg_render_scene": (C.c_int, [_ctx]),
+    "tg_done_rows_bytes": (C.c_int, [_ctx, C.c_int32, C.POINTER(C.c_int64)]),
+    "tg_pack_done_rows": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
     "tg_set_broadphase": (C.c_int, [_ctx, C.POINTER(TgBroadphase)]),
     "tg_check_broadphase": (C.c_int, [_ctx]),
     "tg_get_broadphase_totals": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

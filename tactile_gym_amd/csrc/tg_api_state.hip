@@ -14,12 +14,57 @@ template <typename T, int TOPO> static void launch_refresh_rpy_t(tg_ctx* c) {
     hipLaunchKernelGGL((k_refresh_rpy<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
                        (const EnvConst<T>*)c->d_const, c->st);
 }
+// tg_pack_done_rows: one 256-thread workgroup per env; a finished env's slot is the number of finished envs before it (a prefix count over the
+// done flags: deterministic ascending order, no atomics), workgroup 0 also writes the header.  Everything goes straight into pinned host memory.
+__global__ __launch_bounds__(256) void k_pack_done_rows(const uint8_t* __restrict__ done, const uint8_t* __restrict__ term, const float* __restrict__ ep_ret,
+                                                        const int32_t* __restrict__ ep_len, int n, int cap, size_t img, uint8_t* __restrict__ dst) {
+    __shared__ int part[256];
+    const int env = blockIdx.x, t = threadIdx.x;
+    const bool mine = done[env] != 0;
+    if (!mine && env != 0) return;
+    const int upto = env == 0 ? n : env;                       // workgroup 0 counts them all (the header's count); the others the ones before them
+    int cnt = 0;
+    for (int i = t; i < upto; i += 256) cnt += done[i] != 0 ? 1 : 0;
+    part[t] = cnt;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (t < k) part[t] += part[t + k]; __syncthreads(); }
+    const int total = part[0];
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(dst);
+    if (env == 0 && t == 0) { hdr[0] = (uint32_t)total; hdr[1] = (uint32_t)cap; hdr[2] = (uint32_t)n; hdr[3] = 0x74674452u; }
+    if (!mine) return;
+    const int slot = env == 0 ? 0 : total;
+    if (slot >= cap) return;
+    int32_t* ids = reinterpret_cast<int32_t*>(dst + 16);
+    float* ret = reinterpret_cast<float*>(dst + 16 + (size_t)cap * 4);
+    int32_t* len = reinterpret_cast<int32_t*>(dst + 16 + (size_t)cap * 8);
+    if (t == 0) { ids[slot] = env; ret[slot] = ep_ret[env]; len[slot] = ep_len[env]; }
+    const size_t rows_off = (16 + (size_t)cap * 12 + 15) & ~(size_t)15;
+    const uint4* src = reinterpret_cast<const uint4*>(term + (size_t)env * img);
+    uint4* out = reinterpret_cast<uint4*>(dst + rows_off + (size_t)slot * img);
+    for (size_t w = t; w < img / 16; w += 256) out[w] = src[w];
+}
+
 }  // namespace tg
 
 using namespace tg;
 
 extern "C" {
 
+int tg_done_rows_bytes(tg_ctx* c, int32_t cap, int64_t* bytes) {
+    if (!c || !bytes || cap < 1) return fail(-1, "tg_done_rows_bytes: bad argument");
+    *bytes = (int64_t)(((16 + (size_t)cap * 12 + 15) & ~(size_t)15) + (size_t)cap * c->H * c->W);
+    return 0;
+}
+int tg_pack_done_rows(tg_ctx* c, void* dst, int32_t cap) {
+    if (!c || !dst || cap < 1 || ((uintptr_t)dst & 15)) return fail(-1, "tg_pack_done_rows: bad argument");
+    if (((size_t)c->H * c->W) % 16 != 0) return fail(-1, "tg_pack_done_rows: image bytes not a multiple of 16");
+    if (!c->cfg.auto_reset) return fail(-1, "tg_pack_done_rows: the context has no auto-reset (no terminal observations)");
+    TG_ENTER(c);
+    hipLaunchKernelGGL(k_pack_done_rows, dim3(c->cfg.num_envs), dim3(256), 0, c->stream, c->st.done, c->d_term, c->st.ep_final_return, c->st.ep_final_len,
+                       c->cfg.num_envs, cap, (size_t)c->H * c->W, (uint8_t*)dst);
+    TG_HIP(hipGetLastError());
+    return 0;
+}
 int tg_set_broadphase(tg_ctx* c, const tg_broadphase* g) {
     if (!c) return fail(-1, "NULL argument");
     TG_ENTER(c);

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64) void k_broadphase(const DevRobot<T>* __restrict
     __shared__ double bx[kS][kW];
     __shared__ int order[kS];
     __shared__ int acc[3];
+    __shared__ int cand[16], n_cand;                         // (robot link, table) pairs whose boxes overlap: stage 3 below
     const int env = blockIdx.x, lane = threadIdx.x, n = (int)gridDim.x;
     const BpScene& sc = *sp;
     {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64) void k_broadphase(const DevRobot<T>* __restrict
                 for (int e = 0; e < 9; ++e) fr[i][e] = (double)k.R[i].m[e];
                 fr[i][9] = (double)k.o[i].x; fr[i][10] = (double)k.o[i].y; fr[i][11] = (double)k.o[i].z;
             }
-            acc[0] = acc[1] = acc[2] = 0;
+            acc[0] = acc[1] = acc[2] = 0; n_cand = 0;
         }
     }
     __syncthreads();
@@ -157,27 +158,38 @@ __global__ __launch_bounds__(64) void k_broadphase(const DevRobot<T>* __restrict
             if (hit && b.conj >= 0) hit = obb_overlap(bx[b.conj], ot);
             const int rl = lane == sc.table_slot ? j : (j == sc.table_slot ? lane : -1);     // the robot box of a (robot link, table) pair
             if (hit && rl >= 0 && rl < 16 && sc.box[rl].src == TG_BP_LINK && sc.box[rl].hull_n > 0) {
-                const tg_bp_box& rb = sc.box[rl];
-                const double* tb = bx[sc.table_slot];
-                const double* F = fr[rb.link >= 0 ? rb.link : 0];
-                double zmin = 1e300;
-                for (int v = 0; v < rb.hull_n; ++v) {
-                    const double* hv = sc.hull + 3 * (size_t)(rb.hull_off + v);
-                    double wx = hv[0], wy = hv[1], wz = hv[2];
-                    if (rb.link >= 0) {
-                        wx = (F[0] * hv[0] + F[1] * hv[1] + F[2] * hv[2]) + F[9];
-                        wy = (F[3] * hv[0] + F[4] * hv[1] + F[5] * hv[2]) + F[10];
-                        wz = (F[6] * hv[0] + F[7] * hv[1] + F[8] * hv[2]) + F[11];
-                    }
-                    if (wx >= tb[0] && wx <= tb[3] && wy >= tb[1] && wy <= tb[4] && wz < zmin) zmin = wz;
-                }
-                hit = zmin < 1e299 && (zmin - sc.hull_margin) - sc.margin <= tb[5];
+                cand[atomicAdd(&n_cand, 1)] = rl;            // stage 3 is the whole wavefront's work (below): at most 16 such pairs
+                hit = false;
             }
             if (hit) { ++hits; mask |= (1u << lane) | (1u << j); }
         }
     }
     if (pairs) atomicAdd(&acc[0], pairs);
     if (hits) { atomicAdd(&acc[1], hits); atomicOr(&acc[2], (int)mask); }
+    __syncthreads();
+    // stage 3: a robot link whose BOX reaches the table - its convex hull decides (lowest vertex over the table top, less the hull's collision margin
+    // and the guard's).  The lanes share a candidate's vertices (a sensor tip's hull has 1089), the minimum is a wave reduction; min is exact in any order.
+    for (int k = 0; k < n_cand; ++k) {
+        const int rl = cand[k];
+        const tg_bp_box& rb = sc.box[rl];
+        const double* tb = bx[sc.table_slot];
+        const double* F = fr[rb.link >= 0 ? rb.link : 0];
+        double zmin = 1e300;
+        for (int v = lane; v < rb.hull_n; v += 64) {
+            const double* hv = sc.hull + 3 * (size_t)(rb.hull_off + v);
+            double wx = hv[0], wy = hv[1], wz = hv[2];
+            if (rb.link >= 0) {
+                wx = (F[0] * hv[0] + F[1] * hv[1] + F[2] * hv[2]) + F[9];
+                wy = (F[3] * hv[0] + F[4] * hv[1] + F[5] * hv[2]) + F[10];
+                wz = (F[6] * hv[0] + F[7] * hv[1] + F[8] * hv[2]) + F[11];
+            }
+            if (wx >= tb[0] && wx <= tb[3] && wy >= tb[1] && wy <= tb[4] && wz < zmin) zmin = wz;
+        }
+        for (int o = 1; o < 64; o <<= 1) { const double other = __shfl_xor(zmin, o); zmin = other < zmin ? other : zmin; }
+        if (lane == 0 && zmin < 1e299 && (zmin - sc.hull_margin) - sc.margin <= tb[5]) {
+            acc[1] += 1; acc[2] |= (1 << rl) | (1 << sc.table_slot);
+        }
+    }
     __syncthreads();
     if (lane == 0) {
         out[env] = acc[0]; out[n + env] = acc[1]; out[2 * n + env] = acc[2];

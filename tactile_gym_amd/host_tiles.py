@@ -13,6 +13,7 @@ import os
 
 import numpy as np
 
+from . import _capi as capi
 from .parallel import TILE_REC, TorchShard
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -145,6 +146,22 @@ class TileDownload:
         self.rew_host = self.host_np[self.cap:self.cap + 4 * n].view(np.float32)
         self.done_host = self.host_np[self.cap + 4 * n:self.cap + 5 * n]
         self.zero_copy = os.environ.get("TG_TILES_ZERO_COPY", "1") != "0"      # A/B switch for the measurement: "0" packs on the device and copies
+        # Round 6: what the finished envs' infos need - their ids, episode statistics and terminal images - rides along under the same synchronisation
+        # (tg_pack_done_rows: one launch, stores into this pinned block); until then step_wait made two more blocking round trips per step in which any
+        # env finished, i.e. nearly every step of an RL run.  DONE_CAP envs per step; a step with more falls back to the copies.
+        self.done_rows = None
+        self.done_cap = int(os.environ.get("TG_DONE_ROWS_CAP", "32"))
+        if self.zero_copy and venv._cfg.auto_reset and self.done_cap > 0 and (H * W) % 16 == 0:
+            nb = C.c_int64()
+            capi.check(venv._L.tg_done_rows_bytes(venv._ctx, self.done_cap, C.byref(nb)))
+            self.host_done = torch.zeros(int(nb.value), dtype=torch.uint8).pin_memory()
+            d = self.host_done.numpy()
+            cap = self.done_cap
+            off = (16 + 12 * cap + 15) & ~15
+            self._dr = dict(hdr=d[:16].view(np.uint32), ids=d[16:16 + 4 * cap].view(np.int32), ret=d[16 + 4 * cap:16 + 8 * cap].view(np.float32),
+                            len=d[16 + 8 * cap:16 + 12 * cap].view(np.int32), rows=d[off:off + cap * H * W].reshape(cap, H, W, 1))
+        else:
+            self.host_done = None
         if not self.zero_copy:
             self.pk = torch.zeros(self.cap + self.tail.numel(), dtype=torch.uint8, device=dev)
         tmpl = self.shard.tile_template().cpu().numpy()
@@ -182,9 +199,17 @@ class TileDownload:
         torch, v = self.torch, self.venv
         t0 = time.perf_counter()
         stream = torch.cuda.current_stream(self.tail.device)
+        self.done_rows = None
         if self.zero_copy:
+            if self.host_done is not None:               # (on the context's own - blocking - stream, ahead of the pack on torch's legacy default stream,
+                                                         #  which waits for it: the one synchronisation covers both)
+                capi.check(v._L.tg_pack_done_rows(v._ctx, C.c_void_p(self.host_done.data_ptr()), self.done_cap))
             self.shard.pack_tiles(self.host_pk.data_ptr(), self.counters, tail=self.tail, tail_offset=self.cap)
             stream.synchronize()
+            if self.host_done is not None:
+                k = int(self._dr["hdr"][0])
+                if k <= self.done_cap and int(self._dr["hdr"][3]) == 0x74674452:
+                    self.done_rows = (self._dr["ids"][:k].copy(), self._dr["ret"][:k].copy(), self._dr["len"][:k].copy(), self._dr["rows"][:k].copy())
             count = int(self.host_np[:4].view(np.int32)[0])
             nb = 16 + TILE_REC * count
         else:

@@ -314,14 +314,23 @@ class TactileVecEnv(_VecEnvBase):
         # empty dict (1024 dict constructions per step are a tenth of the numpy step's host time); an env's own dict is made when it has something to
         # say.  lazy_info=False restores a fresh dict per env for callers that write into the infos of running envs.
         infos = [_EMPTY_INFO] * self.num_envs if self._lazy_info else [{} for _ in range(self.num_envs)]
+        # tile download (round 6): the finished envs' ids, episode statistics and terminal images came along with the observation fetch
+        # (host_tiles.TileDownload.done_rows; tg_pack_done_rows) - no further round trip to the device in this step
+        dr = td.done_rows if (td is not None and td.rd_fresh and "tactile" in self.observation_mode and self.obs_mode != "torch") else None
+        if dr is not None and not np.array_equal(dr[0], np.nonzero(dones)[0]):
+            dr = None                                 # (cannot happen: the same done flags; the copies below are always right)
         if dones.any():
             # what the reference's callers read from the Monitor wrapper around every env (sb3_helpers/rl_utils.py:17-30, 59; SB3's logger and
             # EvalCallback consume info["episode"]): return and length of the episode that just ended, added up on the device
-            capi.check(self._L.tg_copy_episode_stats(self._ctx, self._ep_ret.ctypes.data_as(C.POINTER(C.c_float)),
-                                                     self._ep_len.ctypes.data_as(C.POINTER(C.c_int32))))
             t = round(time.time() - self._t_start, 6)
-            for i in np.nonzero(dones)[0]:
-                infos[i] = {"episode": {"r": round(float(self._ep_ret[i]), 6), "l": int(self._ep_len[i]), "t": t}}
+            if dr is not None:
+                stats = zip(dr[0].tolist(), dr[1].tolist(), dr[2].tolist())
+            else:
+                capi.check(self._L.tg_copy_episode_stats(self._ctx, self._ep_ret.ctypes.data_as(C.POINTER(C.c_float)),
+                                                         self._ep_len.ctypes.data_as(C.POINTER(C.c_int32))))
+                stats = ((int(i), float(self._ep_ret[i]), int(self._ep_len[i])) for i in np.nonzero(dones)[0])
+            for i, r, l in stats:
+                infos[i] = {"episode": {"r": round(float(np.float32(r)), 6), "l": int(l), "t": t}}
                 if self._monitor is not None:
                     self._monitor.write(infos[i]["episode"])
         if self._cfg.auto_reset and dones.any():
@@ -334,7 +343,7 @@ class TactileVecEnv(_VecEnvBase):
             else:
                 # only the finished envs' images cross PCIe (tg_copy_obs_rows): with the episodes out of phase some env finishes in nearly every
                 # step, and the whole terminal batch per such step (16.8 MB) was two thirds of the step's time (tools/pcie_rate.py --staggered)
-                term = self._terminal_rows(idx)
+                term = self._terminal_rows(idx, tactile_rows=dr[3] if dr is not None else None)
                 for j, i in enumerate(idx):
                     infos[i]["terminal_observation"] = {k: v[j] for k, v in term.items()}      # rows of arrays made for this step: owned
                     infos[i]["TimeLimit.truncated"] = False
@@ -552,13 +561,14 @@ class TactileVecEnv(_VecEnvBase):
                                             out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
-    def _terminal_rows(self, idx):
-        """The terminal observation of the envs `idx` only (numpy): images by tg_copy_obs_rows, the small per-env vectors from their whole-batch copies."""
+    def _terminal_rows(self, idx, tactile_rows=None):
+        """The terminal observation of the envs `idx` only (numpy): images by tg_copy_obs_rows (or `tactile_rows`, what the tile download brought along),
+        the small per-env vectors from their whole-batch copies."""
         obs = {}
         if "oracle" in self.observation_mode:
             obs["oracle"] = np.array(self.oracle_terminal()[idx])
         if "tactile" in self.observation_mode:
-            obs["tactile"] = self._image_rows(idx, False)
+            obs["tactile"] = tactile_rows if tactile_rows is not None else self._image_rows(idx, False)
         if self._visual:
             obs["visual"] = self._image_rows(idx, True)
         if "feature" in self.observation_mode:

@@ -152,12 +152,22 @@ def test_terminal_observations_of_finished_envs_equal_the_terminal_batch():
     """numpy VecEnv.step_wait hands info["terminal_observation"] of the finished envs from tg_copy_obs_rows (their images only, round 5) - the same
     bytes as those envs' rows of the whole terminal batch (tg_copy_obs_tactile(terminal=1)), with episodes that end in different steps, in the
     default and in the tile transfer mode; the scene camera's terminal images likewise."""
+    import ctypes as C
+    import os
     import tactile_gym_amd as tg
     n = 40
-    for modes, tiles in ((EDGE, False), (EDGE, True), (dict(EDGE, observation_mode="visuotactile"), False)):
+    for modes, tiles in ((EDGE, False), (EDGE, True), (EDGE, "cap4"), (dict(EDGE, observation_mode="visuotactile"), False)):
         venv = tg.make_vec("edge_follow-v0", num_envs=n, max_steps=9, image_size=[128, 128], env_modes=modes, seed=4, auto_reset=True)
         if tiles:
-            venv.set_obs_transfer("tiles")
+            # round 6: in tile mode the finished envs' ids, episode statistics and terminal images ride along with the observation fetch
+            # (tg_pack_done_rows, up to 32 envs per step); "cap4": more envs finish than the block holds - the step falls back to the copies
+            if tiles == "cap4":
+                os.environ["TG_DONE_ROWS_CAP"] = "4"
+            try:
+                venv.set_obs_transfer("tiles")
+            finally:
+                os.environ.pop("TG_DONE_ROWS_CAP", None)
+            assert venv._tile_download.done_cap == (4 if tiles == "cap4" else 32)
         venv.reset()
         rng = np.random.default_rng(2)
         m = np.zeros(n, np.uint8); m[::3] = 1
@@ -171,8 +181,14 @@ def test_terminal_observations_of_finished_envs_equal_the_terminal_batch():
                 whole = venv.tactile_numpy(True)
                 vis = venv.visual_numpy(True) if "visual" in obs else None
                 assert not done.all()
+                ret, ln = np.zeros(n, np.float32), np.zeros(n, np.int32)
+                venv._L.tg_copy_episode_stats(venv._ctx, ret.ctypes.data_as(C.POINTER(C.c_float)), ln.ctypes.data_as(C.POINTER(C.c_int32)))
+                if tiles:
+                    rode_along = venv._tile_download.done_rows is not None
+                    assert rode_along == (int(done.sum()) <= venv._tile_download.done_cap), (k, int(done.sum()))
                 for i in np.flatnonzero(done):
                     t = infos[i]["terminal_observation"]
+                    assert infos[i]["episode"]["l"] == int(ln[i]) and abs(infos[i]["episode"]["r"] - float(ret[i])) < 1e-6, (k, i)
                     assert t["tactile"].shape == whole[i].shape and np.array_equal(t["tactile"], whole[i]), (k, i)
                     if vis is not None:
                         assert np.array_equal(t["visual"], vis[i]), (k, i)

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6_final"
 src = os.path.join(ROOT, "gpurun_out", tag)
 for f in sorted(glob.glob(os.path.join(src, "*"))):
     if os.path.isfile(f) and not f.endswith(".err"):

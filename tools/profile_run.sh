@@ -1,15 +1,18 @@
 #!/bin/bash
-# Evidence run (rounds 3 - 5: TG_PROFILE_TAG names the output set) on the MI355X box (one gpurun call): the default bench line (headline + other_configs + literal + CPU baseline),
+# Evidence run (rounds 3 - 6: TG_PROFILE_TAG names the output set) on the MI355X box (one gpurun call): the default bench line (headline + other_configs + literal + CPU baseline),
 # one bench line per env, rocprofv3 kernel stats and SQ counters of the default command and of object_push / object_balance /
 # surface_follow-v2 (MG400, eight-sweep blocks) / the literal solver, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of
 # edge_follow, object_push and object_balance.  Outputs under gpurun_out/<tag>/; copied to profiles/<tag>_* afterwards (tools/profile_collect.py).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${TG_PROFILE_TAG:-r5_final}
+TAG=${TG_PROFILE_TAG:-r6_final}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python -c "import bench; print(bench.source_hash())" > $O/source_sha16.txt     # what every file of this run was measured on
-timeout 300 python bench.py 2>$O/bench_edge.err | grep metric > $O/bench_edge.json
+timeout 500 python bench.py 2>$O/bench_edge.err | grep metric > $O/bench_edge.json
+# the driver's own command (W = 5, K = 20), three times: what BENCH_rNN.json will hold; bench_driver_like.json = the first
+for k in 1 2 3; do timeout 500 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep metric > $O/bench_driver_like_$k.json; done
+cp $O/bench_driver_like_1.json $O/bench_driver_like.json
 B="timeout 200 python bench.py --no-cpu-baseline --no-companions"
 $B --sync-steps --no-literal 2>/dev/null | grep metric > $O/bench_edge_syncsteps.json
 $B --env surface_follow-v0 2>/dev/null | grep metric > $O/bench_surface_follow-v0.json
@@ -26,7 +29,10 @@ $B --env object_push-v0 --narrowphase gjk_manifold --steps 100 --warmup 10 2>/de
 TG_FUSED_STEP=1 $B --no-literal 2>/dev/null | grep metric > $O/bench_edge_fused_step.json          # the one-launch step (opt-in: measured slower)
 timeout 200 python tools/ball_rate.py 1024 8192 2>&1 | grep -v amdgpu > $O/ball_on_plate_rate.txt
 # episodes out of phase (round 5): the rollout an RL run sees, reset bank auto (= on) and off, configs 2 and 3
-(for e in edge_follow-v0 surface_follow-v0; do echo "$e, reset bank auto:"; timeout 100 python tools/desync_rate.py --env $e 2>&1 | grep aligned; echo "$e, TG_RESET_BANK=0:"; TG_RESET_BANK=0 timeout 100 python tools/desync_rate.py --env $e 2>&1 | grep aligned; done) > $O/desync.txt
+(for e in edge_follow-v0 surface_follow-v0; do echo "$e, reset bank auto:"; timeout 100 python tools/desync_rate.py --env $e 2>&1 | grep aligned; echo "$e, TG_RESET_BANK=0:"; TG_RESET_BANK=0 timeout 100 python tools/desync_rate.py --env $e 2>&1 | grep aligned; done
+ echo "object_push-v0 (1000-step episodes), reset template + optimistic move (round 6):"; timeout 200 python tools/desync_rate.py --env object_push-v0 --max-steps 1000 --steps 300 2>&1 | grep aligned
+ echo "object_push-v0, TG_RESET_BANK=0 (optimistic move, no template):"; TG_RESET_BANK=0 timeout 200 python tools/desync_rate.py --env object_push-v0 --max-steps 1000 --steps 300 2>&1 | grep aligned
+ echo "object_push-v0, TG_LITERAL_RESET=1 (round 5: every reset tick a contact tick):"; TG_LITERAL_RESET=1 timeout 200 python tools/desync_rate.py --env object_push-v0 --max-steps 1000 --steps 300 2>&1 | grep aligned) > $O/desync.txt
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank.json
 TG_NO_DIRECT_BATCH=1 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport ipc --payload tiles 2>/dev/null | grep metric > $O/bench_edge_ipc_tiles_1rank_copy_into_batch.json   # round 4's path: rank 0 copies its shard into the batch
 TG_BENCH_FORCE_COLLECTIVE=1 $B --no-literal --transport collective --payload interior 2>/dev/null | grep metric > $O/bench_edge_rccl_interior_1rank.json

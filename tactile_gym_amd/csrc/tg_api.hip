@@ -159,7 +159,7 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.ybin_lo = cfg.stim_pos[1] - ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
         c.ybin_hi = cfg.stim_pos[1] + ((cfg.surf_cols / 2.0) * cfg.surf_grid_scale);
     }
-    c.fused_reset = (cfg.auto_reset && cfg.env_kind == TG_ENV_EDGE_FOLLOW) ? 1 : 0;
+    c.fused_reset = (cfg.auto_reset && (cfg.env_kind == TG_ENV_EDGE_FOLLOW || cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO)) ? 1 : 0;
     if (cfg.control_mode != TG_CONTROL_TCP_VELOCITY && cfg.control_mode != TG_CONTROL_TCP_POSITION) return fail(-1, "Incorrect control mode specified");
     if (cfg.control_mode == TG_CONTROL_TCP_POSITION) {
         if (cfg.max_blocking_steps < 1) return fail(-1, "TCP_position_control: max_blocking_steps must be >= 1");
@@ -516,7 +516,7 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask, bool bank = false) 
 #undef CALL
         launch_gen_surface(c->cfg.num_envs, c->aux.late, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
                            c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->st.heights, c->st.surf_zoff, c->stream,
-                           c->aux.swapped, c->bk.heights);
+                           c->aux.swapped, c->st.hsel);
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, c->aux.late, 2, true)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
@@ -553,7 +553,7 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask, bool bank = false) 
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
         launch_gen_surface(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
-                           c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->st.heights, c->st.surf_zoff, c->stream);
+                           c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->st.heights, c->st.surf_zoff, c->stream, nullptr, c->st.hsel);
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 2)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
@@ -612,7 +612,7 @@ static void bank_refill(tg_ctx* c) {
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
         launch_gen_surface(c->cfg.num_envs, c->aux.need, c->bk.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
-                           c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->bk.heights, c->bk.surf_zoff, c->bank_stream);
+                           c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->bk.heights, c->bk.surf_zoff, c->bank_stream, nullptr, c->bk.hsel);
 #define CALL(T, TOPO) launch_bank_refill_t<T, TOPO>(c, 2)
         TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
@@ -857,12 +857,14 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     }
     if (cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         const size_t cells = (size_t)cfg->surf_rows * cfg->surf_cols;
-        TG_HIP(hipMalloc(&s.dir, 2 * n * 8)); TG_HIP(hipMalloc(&s.goal, 3 * n * 8)); TG_HIP(hipMalloc(&s.heights, cells * n * 8));
-        TG_HIP(hipMalloc(&s.surf_zoff, n * 4)); TG_HIP(hipMalloc(&s.noise_seed, n * 8)); TG_HIP(hipMalloc(&s.accum, n * 8));
-        TG_HIP(hipMemset(s.dir, 0, 2 * n * 8)); TG_HIP(hipMemset(s.goal, 0, 3 * n * 8)); TG_HIP(hipMemset(s.heights, 0, cells * n * 8));
-        TG_HIP(hipMemset(s.surf_zoff, 0, n * 4)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8)); TG_HIP(hipMemset(s.accum, 0, n * 8));
+        // (three surfaces per env - State::hsel: live 0, last 2, spare 1 to begin with)
+        TG_HIP(hipMalloc(&s.dir, 2 * n * 8)); TG_HIP(hipMalloc(&s.goal, 3 * n * 8)); TG_HIP(hipMalloc(&s.heights, 3 * cells * n * 8));
+        TG_HIP(hipMalloc(&s.hsel, n)); TG_HIP(hipMemset(s.hsel, 2 << 2, n));
+        TG_HIP(hipMalloc(&s.surf_zoff, 3 * n * 4)); TG_HIP(hipMalloc(&s.noise_seed, n * 8)); TG_HIP(hipMalloc(&s.accum, n * 8));
+        TG_HIP(hipMemset(s.dir, 0, 2 * n * 8)); TG_HIP(hipMemset(s.goal, 0, 3 * n * 8)); TG_HIP(hipMemset(s.heights, 0, 3 * cells * n * 8));
+        TG_HIP(hipMemset(s.surf_zoff, 0, 3 * n * 4)); TG_HIP(hipMemset(s.noise_seed, 0, n * 8)); TG_HIP(hipMemset(s.accum, 0, n * 8));
         TG_HIP(hipMalloc(&s.term_feature, (size_t)12 * n * 4)); TG_HIP(hipMemset(s.term_feature, 0, (size_t)12 * n * 4));
-        c->stim.kind = 1; c->stim.heights = s.heights; c->stim.zoff = s.surf_zoff;
+        c->stim.kind = 1; c->stim.heights = s.heights; c->stim.zoff = s.surf_zoff; c->stim.hsel = s.hsel;
         c->stim.rows = cfg->surf_rows; c->stim.cols = cfg->surf_cols; c->stim.scale = (float)cfg->surf_grid_scale;
         c->stim.n_tris = (cfg->surf_rows - 1) * (cfg->surf_cols - 1) * 2;
     } else {
@@ -944,9 +946,8 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
             bad |= grab(b.trig_sc, (size_t)16 * n * 8);
             bad |= grab(b.rng, (size_t)n * 8);
             if (cfg->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
-                const size_t cells = (size_t)cfg->surf_rows * cfg->surf_cols;
-                bad |= grab(b.dir, (size_t)2 * n * 8); bad |= grab(b.goal, (size_t)3 * n * 8); bad |= grab(b.heights, cells * n * 8);
-                bad |= grab(b.accum, (size_t)n * 8); bad |= grab(b.surf_zoff, (size_t)n * 4); bad |= grab(b.noise_seed, (size_t)n * 8);
+                bad |= grab(b.dir, (size_t)2 * n * 8); bad |= grab(b.goal, (size_t)3 * n * 8); bad |= grab(b.hsel, (size_t)n);   // (heights / surf_zoff: the env state's own, the entry's surface goes to the spare third)
+                bad |= grab(b.accum, (size_t)n * 8); bad |= grab(b.noise_seed, (size_t)n * 8);
                 if (s.feature) bad |= grab(b.feature, (size_t)12 * n * 4);
             }
             bad |= grab(c->aux.tag, (size_t)n * 8); bad |= grab(c->aux.rng_in, (size_t)n * 8);
@@ -1025,7 +1026,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->d_kt_acc) (void)hipFree(c->d_kt_acc);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.sweeps, s.tmpl_stats, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.sweeps, s.tmpl_stats, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.hsel, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -1129,7 +1130,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
     // after their reset below (their step image moves to the terminal buffer)
     if (c->scene_every_step) scene_draw(c, nullptr, false);
     if (c->oracle_every_step) oracle_draw(c, c->cfg.auto_reset ? c->d_oracle_term : c->d_oracle);   // the step's own vectors, before any reset
-    if (c->cfg.auto_reset && (c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE && c->st.reset_tmpl != nullptr))) {
+    if (c->cfg.auto_reset && (c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO || (c->cfg.env_kind == TG_ENV_OBJECT_BALANCE && c->st.reset_tmpl != nullptr))) {
         // (object_balance with the reset template: k_reset_body is a few microseconds - teleport, draws, one forward kinematics - so it runs
         //  in line like edge_follow's, without the fork / join of the branch below and without the masked second render: 236 -> 20x us per step)
         if (!reset_inlined) reset_sequence(c, c->st.done, c->bank_mode != 0); // k_reset keeps the terminal camera transform of the envs it resets
@@ -1434,7 +1435,7 @@ static int set_scene_impl(tg_ctx* c, const tg_scene* sc) {
     P.n_tris = sc->n_tris; P.n_frames = n_frames;
     if (sc->body_heightfield) {
         if (c->cfg.env_kind != TG_ENV_SURFACE_FOLLOW_AUTO) return fail(-1, "tg_set_scene: body_heightfield needs a surface env");
-        P.hf_heights = c->st.heights; P.hf_zoff = c->st.surf_zoff; P.hf_rows = c->cfg.surf_rows; P.hf_cols = c->cfg.surf_cols;
+        P.hf_heights = c->st.heights; P.hf_zoff = c->st.surf_zoff; P.hf_sel = c->st.hsel; P.hf_n = c->cfg.num_envs; P.hf_rows = c->cfg.surf_rows; P.hf_cols = c->cfg.surf_cols;
         P.hf_scale = (float)c->cfg.surf_grid_scale;
         P.hf_rgb = ((uint32_t)sc->body_rgb[0] << 16) | ((uint32_t)sc->body_rgb[1] << 8) | sc->body_rgb[2];
     }

@@ -16,6 +16,14 @@ template <typename T, int TOPO> static void launch_refresh_rpy_t(tg_ctx* c) {
 }
 // tg_pack_done_rows: one 256-thread workgroup per env; a finished env's slot is the number of finished envs before it (a prefix count over the
 // done flags: deterministic ascending order, no atomics), workgroup 0 also writes the header.  Everything goes straight into pinned host memory.
+// tg_get_state, surface_follow: each env's live surface (State::hsel) out of the three thirds, [n][cells]; workgroup x = env
+__global__ __launch_bounds__(256) void k_gather_live_surface(int n, int cells, const uint8_t* __restrict__ hsel, const double* __restrict__ heights,
+                                                             const float* __restrict__ zoff, double* __restrict__ out_h, float* __restrict__ out_z) {
+    const int env = blockIdx.x;
+    const size_t idx = (size_t)(hsel[env] & 3) * n + env;
+    if (out_h != nullptr) for (int k = threadIdx.x; k < cells; k += 256) out_h[(size_t)env * cells + k] = heights[idx * cells + k];
+    if (out_z != nullptr && threadIdx.x == 0) out_z[env] = zoff[idx];
+}
 __global__ __launch_bounds__(256) void k_pack_done_rows(const uint8_t* __restrict__ done, const uint8_t* __restrict__ term, const float* __restrict__ ep_ret,
                                                         const int32_t* __restrict__ ep_len, int n, int cap, size_t img, uint8_t* __restrict__ dst) {
     __shared__ int part[256];
@@ -256,9 +264,14 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
     if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         if (v->goal_pos && (rc = fetch_soa(c, c->st.goal, 3, v->goal_pos))) return rc;
         if (v->direction && (rc = fetch_soa(c, c->st.dir, 2, v->direction))) return rc;
-        if (v->surf_zoff && (rc = fetch_soa(c, c->st.surf_zoff, 1, v->surf_zoff))) return rc;
-        if (v->heights) {
-            TG_HIP(hipMemcpyAsync(v->heights, c->st.heights, (size_t)c->cfg.num_envs * c->cfg.surf_rows * c->cfg.surf_cols * 8, hipMemcpyDeviceToHost, c->stream));
+        if (v->surf_zoff || v->heights) {
+            const int n = c->cfg.num_envs, cells = c->cfg.surf_rows * c->cfg.surf_cols;
+            DevBuf hh, zz;
+            if ((v->heights && hh.alloc((size_t)n * cells * 8)) || (v->surf_zoff && zz.alloc((size_t)n * 4))) return fail(-2, "hipMalloc failed");
+            hipLaunchKernelGGL(k_gather_live_surface, dim3(n), dim3(256), 0, c->stream, n, cells, c->st.hsel, c->st.heights, c->st.surf_zoff,
+                               v->heights ? (double*)hh.p : nullptr, v->surf_zoff ? (float*)zz.p : nullptr);
+            if (v->heights) TG_HIP(hipMemcpyAsync(v->heights, hh.p, (size_t)n * cells * 8, hipMemcpyDeviceToHost, c->stream));
+            if (v->surf_zoff) TG_HIP(hipMemcpyAsync(v->surf_zoff, zz.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
             TG_HIP(hipStreamSynchronize(c->stream));
         }
     }

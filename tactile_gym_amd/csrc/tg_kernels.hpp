@@ -63,9 +63,12 @@ struct State {   // device pointers, SoA [field][num_envs]
     uint64_t* rng;
     uint8_t* done;
     // surface_follow
-    double *dir, *goal, *heights;   // [2][n], [3][n], [n][rows*cols]
+    double *dir, *goal, *heights;   // [2][n], [3][n], [3][n][rows*cols]: three surfaces per env - the live one, the last episode's, and a spare the reset bank fills
+    uint8_t* hsel;                  // [n] surface_follow: bits 0-1 the live third of heights / surf_zoff, bits 2-3 the last episode's (round 6).  The finished episode's
+                                    // surface stays where it is for the terminal image of that step (one fused render launch draws both images); the bank's precomputed
+                                    // surface is already in the spare third (no 32 KB copy: the env moves there); a reset on the spot overwrites the last episode's
     double* accum;                  // [n] sparse reward: the episode's accumulated dense reward
-    float* surf_zoff;               // [n]
+    float* surf_zoff;               // [3][n], indexed like heights
     int64_t* noise_seed;            // [n]
     // object_balance
     double *body_pos, *body_rot, *body_v, *body_w, *ext_pos, *gravity;   // [3][n], [9][n], [3][n], [3][n], [3][n], [n]
@@ -249,7 +252,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         int tj = digitize_linspace((double)ptcp.x, c.xbin_lo, c.xbin_hi, R);
         if (ti == Cc) ti -= 1;
         if (tj == R) tj -= 1;
-        const double* H = st.heights + (size_t)env * R * Cc;
+        const double* H = st.heights + ((size_t)(st.hsel[env] & 3) * n + env) * R * Cc;
         const T surf_z = (T)(H[(size_t)ti * Cc + tj] + (double)c.stim_pos[2]);
         const T gy_ = (T)grad_axis(H + tj, ti, R, Cc, c.surf_scale);               // np.gradient axis 0
         const T gx_ = (T)grad_axis(H + (size_t)ti * Cc, tj, Cc, 1, c.surf_scale);  // axis 1
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(64) void k_oracle_obs(const DevRobot<T>* __restrict
         int tj = digitize_linspace((double)ptcp.x, c.xbin_lo, c.xbin_hi, R);
         if (ti == Cc) ti -= 1;
         if (tj == R) tj -= 1;
-        const double* H = st.heights + (size_t)env * R * Cc;
+        const double* H = st.heights + ((size_t)(st.hsel[env] & 3) * n + env) * R * Cc;
         const T gy_ = (T)grad_axis(H + tj, ti, R, Cc, c.surf_scale), gx_ = (T)grad_axis(H + (size_t)ti * Cc, tj, Cc, 1, c.surf_scale);
         V3<T> nrm{-gx_, -gy_, T(1)};
         nrm = (T(1) / norm(nrm)) * nrm;
@@ -967,7 +970,7 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
     V3<T> init_world = load_v3(c.work_pos) + mul(c.work_R, mk(T(0), T(0), (T)embed));   // edge: work-frame (0, 0, embed)
     if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
         const int R = c.surf_rows, Cc = c.surf_cols;
-        const double* H = st.heights + (size_t)env * R * Cc;
+        const double* H = st.heights + ((size_t)(st.hsel[env] & 3) * n + env) * R * Cc;
         // make_goal (base_surface_env.py:518-575): goal on the surface, x_y_extent away along the drive direction
         const V3<T> wd = mul(c.work_R, mk((T)st.dir[0 * n + env], (T)st.dir[1 * n + env], T(0)));
         const double gx = (double)c.stim_pos[0] + c.surf_extent * (double)wd.x, gy = (double)c.stim_pos[1] + c.surf_extent * (double)wd.y;
@@ -1072,35 +1075,55 @@ __device__ __forceinline__ void reset_env(const DevRobot<T>& m, const EnvConst<T
 }
 
 // A finished env takes its precomputed post-reset state: everything reset_env writes, copied from the bank view, plus the fields a reset
-// sets to constants.  (surface_follow: the 32 KB of heights follow in k_bank_heights, one workgroup per env.)
+// sets to constants.  (surface_follow: the 32 KB of heights are not copied - the refill wrote them to the env's spare third, State::hsel.)
 template <typename T, int TOPO>
 __device__ __forceinline__ void bank_swap_in(const EnvConst<T>& c, const State& st, const State& bk, int env) {
     constexpr int N = Topo<TOPO>::N;
     const int n = c.num_envs;
+    // Every load first, then every store: the State pointers may alias as far as the compiler knows, so a copy written field by field is a chain
+    // of load - store round trips, one memory latency each (~60 of them: k_reset 15 us in every step of a rollout whose episodes are out of phase).
+    const bool surf = c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO, feat = surf && st.feature != nullptr;
+    double q[N], qd[N], ts[N], tc[N], pos[3], rpy[3], dir[2] = {0, 0}, goal[3] = {0, 0, 0}, accum = 0;
+    float xf[12], ft[6] = {0, 0, 0, 0, 0, 0};
+    int64_t nseed = 0;
+    uint8_t hs = 0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) { st.q[i * n + env] = bk.q[i * n + env]; st.qd[i * n + env] = bk.qd[i * n + env]; st.qd_target[i * n + env] = 0.0; }
-    st.embed[env] = bk.embed[env];
-    st.edge_ang[env] = bk.edge_ang[env];
-    st.edge_sc[0 * n + env] = bk.edge_sc[0 * n + env]; st.edge_sc[1 * n + env] = bk.edge_sc[1 * n + env];
-    st.reset_ticks[env] = bk.reset_ticks[env];
-    st.step_count[env] = 0;
-    st.licence[env] = bk.licence[env];
+    for (int i = 0; i < N; ++i) { q[i] = bk.q[i * n + env]; qd[i] = bk.qd[i * n + env]; ts[i] = bk.trig_sc[i * n + env]; tc[i] = bk.trig_sc[(8 + i) * n + env]; }
+    const double embed = bk.embed[env], edge_ang = bk.edge_ang[env], esc0 = bk.edge_sc[0 * n + env], esc1 = bk.edge_sc[1 * n + env];
+    const int32_t rticks = bk.reset_ticks[env], lic = bk.licence[env];
 #pragma unroll
-    for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = bk.trig_sc[i * n + env]; st.trig_sc[(8 + i) * n + env] = bk.trig_sc[(8 + i) * n + env]; }
+    for (int k = 0; k < 3; ++k) { pos[k] = bk.tcp_pos[k * n + env]; rpy[k] = bk.tcp_rpy[k * n + env]; }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { st.tcp_pos[k * n + env] = bk.tcp_pos[k * n + env]; st.tcp_rpy[k * n + env] = bk.tcp_rpy[k * n + env]; }
+    for (int k = 0; k < 12; ++k) xf[k] = bk.stim_xform[k * n + env];
+    if (surf) {
+        accum = bk.accum[env]; nseed = bk.noise_seed[env]; dir[0] = bk.dir[0 * n + env]; dir[1] = bk.dir[1 * n + env];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) st.stim_xform[k * n + env] = bk.stim_xform[k * n + env];
-    if (c.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
-        st.accum[env] = bk.accum[env];
-        st.noise_seed[env] = bk.noise_seed[env];
-        st.dir[0 * n + env] = bk.dir[0 * n + env]; st.dir[1 * n + env] = bk.dir[1 * n + env];
+        for (int k = 0; k < 3; ++k) goal[k] = bk.goal[k * n + env];
+        hs = (uint8_t)((bk.hsel[env] & 3) | ((st.hsel[env] & 3) << 2));   // the entry's surface (and its z offset) sit in the third the refill wrote: the env moves there
+        if (feat) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) st.goal[k * n + env] = bk.goal[k * n + env];
-        st.surf_zoff[env] = bk.surf_zoff[env];
-        if (st.feature != nullptr) {
+            for (int e = 0; e < 6; ++e) ft[e] = bk.feature[(size_t)env * 12 + e];
+        }
+    }
 #pragma unroll
-            for (int e = 0; e < 6; ++e) st.feature[(size_t)env * 12 + e] = bk.feature[(size_t)env * 12 + e];
+    for (int i = 0; i < N; ++i) {
+        st.q[i * n + env] = q[i]; st.qd[i * n + env] = qd[i]; st.qd_target[i * n + env] = 0.0;
+        st.trig_sc[i * n + env] = ts[i]; st.trig_sc[(8 + i) * n + env] = tc[i];
+    }
+    st.embed[env] = embed; st.edge_ang[env] = edge_ang; st.edge_sc[0 * n + env] = esc0; st.edge_sc[1 * n + env] = esc1;
+    st.reset_ticks[env] = rticks; st.step_count[env] = 0; st.licence[env] = lic;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { st.tcp_pos[k * n + env] = pos[k]; st.tcp_rpy[k * n + env] = rpy[k]; }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st.stim_xform[k * n + env] = xf[k];
+    if (surf) {
+        st.accum[env] = accum; st.noise_seed[env] = nseed; st.dir[0 * n + env] = dir[0]; st.dir[1 * n + env] = dir[1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st.goal[k * n + env] = goal[k];
+        st.hsel[env] = hs;
+        if (feat) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) st.feature[(size_t)env * 12 + e] = ft[e];
         }
     }
 }
@@ -1115,8 +1138,11 @@ __device__ __forceinline__ void reset_or_swap(const DevRobot<T>* __restrict__ mp
                                               bool in_step, int phase, const BankDev* __restrict__ bd) {
     if (cp->fused_reset && in_step) {           // auto-reset inside tg_step: keep the terminal observation's camera transform; the render
         const int n = cp->num_envs;             // launch that follows draws both images of this env
+        float xf[12];                           // (loads, then stores: see bank_swap_in)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) st.term_xform[k * n + env] = st.stim_xform[k * n + env];
+        for (int k = 0; k < 12; ++k) xf[k] = st.stim_xform[k * n + env];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) st.term_xform[k * n + env] = xf[k];
     }
     if (bd != nullptr && phase != 2) {
         const BankAux& aux = bd->aux;
@@ -1132,6 +1158,13 @@ __device__ __forceinline__ void reset_or_swap(const DevRobot<T>* __restrict__ mp
         }
         if (phase == 1) aux.late[env] = 1;
         atomicAdd(aux.stats + 1, 1ull);
+    }
+    // surface_follow, a reset on the spot (phase 1 = the task draws; k_gen_surface, which follows, writes the env's LIVE third): live and last
+    // trade places - the finished episode's surface stays readable for this step's terminal image, the new one overwrites the episode before
+    // it, and the spare third, which a refill may be writing at this moment, is left alone
+    if (phase == 1 && cp->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        const uint8_t b = st.hsel[env];
+        st.hsel[env] = (uint8_t)(((b >> 2) & 3) | ((b & 3) << 2));
     }
     reset_env<T, TOPO>(*mp, *cp, st, env, phase);
     if (bd != nullptr && phase == 2) bd->aux.late[env] = 0;
@@ -1169,6 +1202,10 @@ __global__ __launch_bounds__(64) void k_bank_refill(const DevRobot<T>* __restric
         __hip_atomic_store(aux.tag + env, ~r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         aux.rng_in[env] = r;
         bk.rng[env] = (uint64_t)r;
+        if (cp->env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {   // the spare third - neither live nor the last episode's - takes this entry's surface (the bank view's "live" slot)
+            const uint8_t b = st.hsel[env];          // (one byte: a reset on the spot running beside this launch swaps the two fields, the spare stays the spare)
+            bk.hsel[env] = (uint8_t)(3 - (b & 3) - ((b >> 2) & 3));
+        }
     } else if (aux.need[env] == 0) {
         return;
     }

@@ -85,18 +85,15 @@ __device__ inline double splitmix_uniform(unsigned long long state, unsigned lon
 // grid: n_envs blocks of 256 threads
 __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ seeds, int rows,
                                                      int cols, double interp, double range, int center_z, int mode,
-                                                     double* __restrict__ heights, float* __restrict__ zoff, uint8_t* __restrict__ copy_mask,
-                                                     const double* __restrict__ copy_src) {
+                                                     double* __restrict__ heights, float* __restrict__ zoff, uint8_t* __restrict__ skip_mask,
+                                                     const uint8_t* __restrict__ slot) {
     __shared__ int16_t perm[256];
     __shared__ int16_t source[256];
     __shared__ float red_min[256], red_max[256];
     const int env = blockIdx.x, tid = threadIdx.x;
     if (env >= n_envs) return;
-    if (copy_mask != nullptr && copy_mask[env] != 0) {   // reset bank: this env took its precomputed entry, the heights come with it
-        const size_t base = (size_t)env * rows * cols;
-        for (int k = tid; k < rows * cols; k += 256) heights[base + k] = copy_src[base + k];
-        __syncthreads();
-        if (tid == 0) copy_mask[env] = 0;
+    if (skip_mask != nullptr && skip_mask[env] != 0) {   // reset bank: this env took its precomputed entry - its surface is in the slot it switched to
+        if (tid == 0) skip_mask[env] = 0;
         return;
     }
     if (mask != nullptr && mask[env] == 0) return;
@@ -117,7 +114,10 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
         }
     }
     __syncthreads();
-    double* out = heights + (size_t)env * rows * cols;
+    // slot (surface_follow env states, round 6): heights / zoff are [3][n_envs][...] and slot[env] names the third this surface goes to (the env's live
+    // slot for a reset on the spot, the next one for the bank's refill); nullptr: one surface per env, [n_envs][...]
+    const size_t idx = slot != nullptr ? (size_t)(slot[env] & 3) * n_envs + env : (size_t)env;
+    double* out = heights + idx * rows * cols;
     float lo = 3.0e38f, hi = -3.0e38f;
     for (int k = tid; k < rows * cols; k += 256) {
         const int x = k / cols, y = k % cols;       // heightfield_data[x, y], base_surface_env.py:327-335
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_gen_surface(int n_envs, const uint8_t* 
         if (tid < s) { red_min[tid] = fminf(red_min[tid], red_min[tid + s]); red_max[tid] = fmaxf(red_max[tid], red_max[tid + s]); }
         __syncthreads();
     }
-    if (tid == 0 && zoff != nullptr) zoff[env] = center_z ? 0.5f * (red_min[0] + red_max[0]) : 0.0f;
+    if (tid == 0 && zoff != nullptr) zoff[idx] = center_z ? 0.5f * (red_min[0] + red_max[0]) : 0.0f;
 }
 
 // object_push make_goal -> update_trajectory_simplex (object_push_env.py:248-281): y_i = noise2(i * 0.1, 1) * max_perturb - y_0,
@@ -205,9 +205,9 @@ void launch_gen_traj(int n_envs, const uint8_t* mask, const int64_t* seeds, int 
 }
 
 void launch_gen_surface(int n_envs, const uint8_t* mask, const int64_t* seeds, int rows, int cols, double interp, double range, int center_z,
-                        int mode, double* heights, float* zoff, hipStream_t stream, uint8_t* copy_mask, const double* copy_src) {
+                        int mode, double* heights, float* zoff, hipStream_t stream, uint8_t* skip_mask, const uint8_t* slot) {
     hipLaunchKernelGGL(k_gen_surface, dim3(n_envs), dim3(256), 0, stream, n_envs, mask, seeds, rows, cols, interp, range, center_z, mode, heights,
-                       zoff, copy_mask, copy_src);
+                       zoff, skip_mask, slot);
 }
 
 }  // namespace tg

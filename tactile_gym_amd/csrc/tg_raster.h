@@ -14,6 +14,7 @@ struct RasterParams {
     float kx, ky, hw, hh, C0, C1, near_;
     float zcull;   // max of the undeformed depth image: triangles entirely behind it can never win the z-test
     int turn_off_border;
+    int term_layer;   // fused auto-reset (launch_render's term_xform): the grid z of the terminal layer: 1 = dispatched last (TG_TERM_LAYER=0: first - measured, no gain)
     // k_render_blocks (small shared meshes, 128-multiple images), both made by make_block_tables or both null (then k_render_small draws):
     const float* blockmax;    // [regions][64]: largest undeformed depth of each kBlockW x (256 / kBlockW) block of each 128 x 128 region
     unsigned long long* drawn;   // [n_envs][regions]: bit b = block b of the env's image (`out`) differs from tmpl (written by k_render_blocks; null: every launch rewrites every block)
@@ -36,8 +37,10 @@ struct Stimulus {
     const int32_t* tris;
     const float* soup;        // mesh, pre-expanded on the host: [n_tris][3][3] vertex coordinates (what the kernel reads)
     int n_tris;
-    const double* heights;    // heightfield: [n_envs][rows*cols]
-    const float* zoff;        // [n_envs]
+    const double* heights;    // heightfield: [n_envs][rows*cols]; with hsel: [3][n_envs][rows*cols]
+    const float* zoff;        // [n_envs]; with hsel: [3][n_envs]
+    const uint8_t* hsel;      // nullptr, or [n_envs]: the live third of heights / zoff per env (env states, round 6: the surface an episode ran on stays
+                              // in its slot for the terminal image while the next episode's is already in the next one - State::hsel)
     int rows, cols;
     float scale;
     int skip_quad_reject;     // 1: stimuli whose few triangles fill the camera's view (the pole's plate): the per-quad reject never fires

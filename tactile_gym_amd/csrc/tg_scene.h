@@ -32,6 +32,8 @@ struct SceneParams {
     // (j - (cols-1)/2) s, h[j rows + i] - zoff), cell (i, j) -> (i,j),(i,j+1),(i+1,j) and (i+1,j),(i,j+1),(i+1,j+1)
     const double* hf_heights;      // device [n_envs][rows * cols], nullptr: no heightfield
     const float* hf_zoff;          // device [n_envs]
+    const uint8_t* hf_sel;         // nullptr, or device [n_envs]: hf_heights / hf_zoff are [3][hf_n][...] and this names each env's live third (State::hsel)
+    int hf_n;                      // number of envs (the stride of a third)
     int hf_rows, hf_cols;
     float hf_scale;
     uint32_t hf_rgb;               // r << 16 | g << 8 | b

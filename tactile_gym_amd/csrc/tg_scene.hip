@@ -125,8 +125,9 @@ __device__ __forceinline__ bool setup_tri(const SceneParams& P, const float* __r
     }
     const int h = t - P.n_tris, cell = h >> 1, half = h & 1;
     const int ci = cell % (P.hf_rows - 1), cj = cell / (P.hf_rows - 1);
-    const double* H = P.hf_heights + (size_t)env * P.hf_rows * P.hf_cols;
-    const float zoff = P.hf_zoff[env], cx = 0.5f * (float)(P.hf_rows - 1), cy = 0.5f * (float)(P.hf_cols - 1);
+    const size_t hidx = P.hf_sel != nullptr ? (size_t)(P.hf_sel[env] & 3) * P.hf_n + env : (size_t)env;
+    const double* H = P.hf_heights + hidx * P.hf_rows * P.hf_cols;
+    const float zoff = P.hf_zoff[hidx], cx = 0.5f * (float)(P.hf_rows - 1), cy = 0.5f * (float)(P.hf_cols - 1);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         // half 0: (i,j),(i,j+1),(i+1,j)   half 1: (i+1,j),(i,j+1),(i+1,j+1)

@@ -9,6 +9,9 @@ Round 5, MI355X, 1024 envs (profiles/r5_final_desync.txt): aligned 24.1 M env-st
 licence dropped at every reset: k_step 49 us in every launch; every reset on the spot: 90 - 110 us per launch), 18.3 M with them (the reset
 renews the licence; reset bank on by default, its refill paced without a cross-stream wait).  TG_RESET_BANK=0 shows the on-the-spot resets.
 
+Round 6 (three surfaces per env, one render launch, a swap-in that loads before it stores - DESIGN.md 4.1h): edge_follow 21.1 M, surface_follow-v0
+7.0 -> 9.2 M with the episodes out of phase.
+
     python tools/desync_rate.py [--env edge_follow-v0] [--envs 1024] [--steps 2000]
 """
 import argparse

@@ -265,11 +265,11 @@ class Workload:
         return env.step(self.actions())
 
     def timed(self, env, steps, barrier, flush=None):
-        # (the collector is held off the timed region, as timeit does: a 20-step window is 0.86 ms on the headline and a young-generation pass of
-        #  a process that has torch imported can take 0.1 - 0.2 ms.  One of three driver-like runs in round 6 came out at 50.9 instead of 43.1 us per
-        #  step; its cause is not established - this takes one candidate away)
+        # The collector is held off the timed region, as timeit does (a 20-step window is 0.86 ms on the headline; a young-generation pass of a
+        # process with torch imported can take 0.1 - 0.2 ms).  No gc.collect() HERE: a full collection is ~0.1 s of host time during which the
+        # device idles, and the window then starts on a part that has clocked down - measured, round 6: driver-like runs 45.4 instead of 43.1 us
+        # per step, one_step_window_ms 0.090 instead of 0.058.  The collection runs once, before the spin-up (run_window).
         gc_was_on = gc.isenabled()
-        gc.collect()
         gc.disable()
         try:
             return self._timed(env, steps, barrier, flush)
@@ -590,6 +590,7 @@ def main():
         whether what rank 0 was handed is what the ranks rendered (byte sums of every rank's last tactile batch, outside the timed region)."""
         e = ShardedVecEnv(shard, dist, overlap=True, force_collective=force, payload=payload, transport=transport) if gathered else shard
         with w.on_stream():
+            gc.collect()                                   # (before the spin-up, never between it and the timed region: Workload.timed)
             if args.pre_warm_ms > 0 and steps is None:
                 # device spin-up, untimed and before the window's own reset: the timed region below is reset -> W warm-up steps -> K steps as always
                 e.reset()

@@ -1002,6 +1002,237 @@ void mb_step_body_ball(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p*
     }
 }
 
+/* ------------------------------------------------------------------------------------------------ arm + spool + P2P + dish (spinning_plate) */
+static void world_inertia(const mb_body* b, double* Iw, double* Iwi, double* xc) {
+    double RI[9], cw[3];
+    m3_mul(b->rot, b->inertia, RI);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Iw[3 * i + j] = RI[3 * i] * b->rot[3 * j] + RI[3 * i + 1] * b->rot[3 * j + 1] + RI[3 * i + 2] * b->rot[3 * j + 2];
+    invert3(Iw, Iwi);
+    m3_vec(b->rot, b->com, cw);
+    for (int k = 0; k < 3; ++k) xc[k] = b->pos[k] + cw[k];
+}
+static void plane_space1(const double* n, double* t1, double* t2) {                        /* btPlaneSpace1 */
+    if (fabs(n[2]) > 0.7071067811865475244) {
+        double a = n[1] * n[1] + n[2] * n[2], kk = 1.0 / sqrt(a);
+        t1[0] = 0; t1[1] = -n[2] * kk; t1[2] = n[1] * kk;
+        t2[0] = a * kk; t2[1] = -n[0] * t1[2]; t2[2] = n[0] * t1[1];
+    } else {
+        double a = n[0] * n[0] + n[1] * n[1], kk = 1.0 / sqrt(a);
+        t1[0] = -n[1] * kk; t1[1] = n[0] * kk; t1[2] = 0;
+        t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * kk;
+    }
+}
+void mb_step_spin(const mb_model* m, mb_state* s, mb_body* b, const mb_p2p* c, mb_spin* sp, double dt, int iters) {
+    enum { MAXC = 4, NR = MB_MAX_DOF + 3 + 3 * MAXC, NU = MB_MAX_DOF + 12 };
+    mb_body* dsh = &sp->dish;
+    int n = m->ndof, nu = n + 12, nr0 = n + 3;
+    /* ---- arm: unconstrained velocity (mb_step) */
+    double tau[MB_MAX_DOF], h[MB_MAX_DOF], Qd[MB_MAX_DOF], v[NU], M[MB_MAX_DOF * MB_MAX_DOF], Mi[MB_MAX_DOF * MB_MAX_DOF], zero[MB_MAX_DOF] = {0};
+    for (int i = 0; i < n; ++i) tau[i] = s->applied_torque[i] - m->joint_damping * s->qd[i];
+    mb_inverse_dynamics(m, s->q, s->qd, zero, h);
+    damping_force(m, s->q, s->qd, Qd);
+    mb_mass_matrix(m, s->q, M);
+    invert(M, n, Mi);
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += Mi[i * n + j] * (tau[j] - h[j] + Qd[j]);
+        v[i] = s->qd[i] + dt * acc;
+    }
+    /* ---- spool: gravity, Bullet's default velocity damping F = -m v (K + K |v|) (A27), gyroscopic torque */
+    double Iw[9], Iwi[9], xc[3];
+    world_inertia(b, Iw, Iwi, xc);
+    {
+        double sv = sp->lin_damp + sp->lin_damp * norm3(b->linvel), sw = sp->ang_damp + sp->ang_damp * norm3(b->angvel);
+        double Iwv[3], gyro[3], N[3], wacc[3];
+        m3_vec(Iw, b->angvel, Iwv); cross(b->angvel, Iwv, gyro);
+        for (int k = 0; k < 3; ++k) N[k] = -Iwv[k] * sw - gyro[k];
+        m3_vec(Iwi, N, wacc);
+        for (int k = 0; k < 3; ++k) { v[n + k] = b->linvel[k] + dt * (m->gravity[k] - b->linvel[k] * sv); v[n + 3 + k] = b->angvel[k] + dt * wacc[k]; }
+    }
+    /* ---- dish: gravity, the one-tick force and torque of reset_object (:357-358), gyroscopic torque; no damping (:338-345) */
+    double Dw[9], Dwi[9], xd[3];
+    world_inertia(dsh, Dw, Dwi, xd);
+    {
+        double F[3] = {dsh->mass * m->gravity[0], dsh->mass * m->gravity[1], dsh->mass * m->gravity[2]}, N[3] = {0, 0, 0};
+        if (dsh->ext_pending) {
+            double r[3] = {dsh->ext_pos[0] - xd[0], dsh->ext_pos[1] - xd[1], dsh->ext_pos[2] - xd[2]}, t[3];
+            cross(r, dsh->ext_force, t);
+            for (int k = 0; k < 3; ++k) { F[k] += dsh->ext_force[k]; N[k] += t[k]; }
+            dsh->ext_pending = 0;
+        }
+        if (sp->torque_pending) {                                                          /* LINK_FRAME: the dish's axes */
+            double tw[3]; m3_vec(dsh->rot, sp->ext_torque, tw);
+            for (int k = 0; k < 3; ++k) N[k] += tw[k];
+            sp->torque_pending = 0;
+        }
+        double Iwv[3], gyro[3], wacc[3];
+        m3_vec(Dw, dsh->angvel, Iwv); cross(dsh->angvel, Iwv, gyro);
+        for (int k = 0; k < 3; ++k) N[k] -= gyro[k];
+        m3_vec(Dwi, N, wacc);
+        for (int k = 0; k < 3; ++k) { v[n + 6 + k] = dsh->linvel[k] + dt * F[k] / dsh->mass; v[n + 9 + k] = dsh->angvel[k] + dt * wacc[k]; }
+    }
+    /* ---- narrowphase: the dish's hull in the spool's frame, AABB test of the pair, GJK / EPA, the manifold (as mb_step_push, narrowphase 1) */
+    {
+        static double ha[3 * 4096];
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, lob[3] = {1e300, 1e300, 1e300}, hib[3] = {-1e300, -1e300, -1e300};
+        const int na = sp->n_dish < 4096 ? sp->n_dish : 4096;
+        for (int i = 0; i < na; ++i) {
+            double t[3], w[3], d[3];
+            m3_vec(dsh->rot, sp->dish_hull + 3 * i, t);
+            for (int x = 0; x < 3; ++x) { w[x] = dsh->pos[x] + t[x]; d[x] = w[x] - b->pos[x]; if (w[x] < lo[x]) lo[x] = w[x]; if (w[x] > hi[x]) hi[x] = w[x]; }
+            for (int x = 0; x < 3; ++x) ha[3 * i + x] = b->rot[x] * d[0] + b->rot[3 + x] * d[1] + b->rot[6 + x] * d[2];
+        }
+        for (int i = 0; i < sp->n_spool; ++i) {
+            double t[3];
+            m3_vec(b->rot, sp->spool_hull + 3 * i, t);
+            for (int x = 0; x < 3; ++x) { const double w = b->pos[x] + t[x]; if (w < lob[x]) lob[x] = w; if (w > hib[x]) hib[x] = w; }
+        }
+        int overlap = na > 0 && sp->n_spool > 0;
+        const double pad = 2.0 * sp->margin + sp->breaking;
+        for (int x = 0; x < 3; ++x) if (lo[x] - pad > hib[x] || hi[x] + pad < lob[x]) overlap = 0;
+        if (!overlap) sp->mani.n = 0;
+        else {
+            double sd, nb[3], ab[3], bb[3];
+            if (mb_gjk_epa_hull_hull(ha, na, sp->spool_hull, sp->n_spool, &sd, nb, ab, bb)) {
+                const double depth = sd - 2.0 * sp->margin;
+                double nw[3], aw[3], bw[3], pa[3], pb[3];
+                m3_vec(b->rot, nb, nw); m3_vec(b->rot, ab, aw); m3_vec(b->rot, bb, bw);
+                for (int x = 0; x < 3; ++x) { pa[x] = (b->pos[x] + aw[x]) - nw[x] * sp->margin; pb[x] = (b->pos[x] + bw[x]) + nw[x] * sp->margin; }
+                mb_manifold_add(&sp->mani, sp->breaking, dsh->pos, dsh->rot, b->pos, b->rot, pa, pb, nw, depth);
+            }
+            mb_manifold_refresh(&sp->mani, sp->breaking, dsh->pos, dsh->rot, b->pos, b->rot);
+        }
+    }
+    const int nc = sp->mani.n, nr = nr0 + 3 * nc;
+    sp->n_contacts = nc; sp->normal_impulse = 0.0;
+    /* ---- rows: motors, P2P (arm - spool), then per contact the normal and the two friction directions (dish +d, spool -d) */
+    static double J[NR][NU], W[NU][NR];
+    double A[NR], rhs[NR], lim[NR], lam[NR], dv[NU];
+    memset(J, 0, sizeof J);
+    for (int i = 0; i < n; ++i) J[i][i] = 1.0;
+    kin_t k; double z3[3] = {0, 0, 0};
+    kinematics(m, s->q, zero, NULL, z3, &k);
+    double ra[3], pa[3], pb[3], rb[3], tvec[3];
+    m3_vec(k.R[c->link], c->pivot_a, ra);
+    for (int x = 0; x < 3; ++x) pa[x] = k.o[c->link][x] + ra[x];
+    m3_vec(b->rot, c->pivot_b, tvec);
+    for (int x = 0; x < 3; ++x) { pb[x] = b->pos[x] + tvec[x]; rb[x] = pb[x] - xc[x]; }
+    for (int i = 0; i < n; ++i) {
+        if (!is_in_subtree(m, c->link, i)) continue;
+        double r[3] = {pa[0] - k.o[i][0], pa[1] - k.o[i][1], pa[2] - k.o[i][2]}, jt[3];
+        cross(k.a[i], r, jt);
+        for (int x = 0; x < 3; ++x) J[n + x][i] = jt[x];
+    }
+    for (int x = 0; x < 3; ++x) {
+        double e[3] = {0, 0, 0}, rxe[3];
+        e[x] = 1.0;
+        cross(rb, e, rxe);
+        J[n + x][n + x] = -1.0;
+        for (int y = 0; y < 3; ++y) J[n + x][n + 3 + y] = -rxe[y];
+    }
+    for (int q = 0; q < nc; ++q) {
+        double t1[3], t2[3];
+        plane_space1(sp->mani.nrm[q], t1, t2);
+        const double* dirs[3] = {sp->mani.nrm[q], t1, t2};
+        double rda[3] = {sp->mani.pa[q][0] - xd[0], sp->mani.pa[q][1] - xd[1], sp->mani.pa[q][2] - xd[2]};
+        double rsb[3] = {sp->mani.pb[q][0] - xc[0], sp->mani.pb[q][1] - xc[1], sp->mani.pb[q][2] - xc[2]};
+        for (int r = 0; r < 3; ++r) {
+            const double* d = dirs[r];
+            double* row = J[nr0 + 3 * q + r];
+            double rxa[3], rxb[3];
+            cross(rda, d, rxa); cross(rsb, d, rxb);
+            for (int x = 0; x < 3; ++x) { row[n + 6 + x] = d[x]; row[n + 9 + x] = rxa[x]; row[n + x] = -d[x]; row[n + 3 + x] = -rxb[x]; }
+        }
+    }
+    for (int r = 0; r < nr; ++r) {
+        for (int i = 0; i < n; ++i) { double acc = 0; for (int j = 0; j < n; ++j) acc += Mi[i * n + j] * J[r][j]; W[i][r] = acc; }
+        for (int x = 0; x < 3; ++x) W[n + x][r] = J[r][n + x] / b->mass;
+        for (int x = 0; x < 3; ++x) W[n + 3 + x][r] = Iwi[3 * x] * J[r][n + 3] + Iwi[3 * x + 1] * J[r][n + 4] + Iwi[3 * x + 2] * J[r][n + 5];
+        for (int x = 0; x < 3; ++x) W[n + 6 + x][r] = J[r][n + 6 + x] / dsh->mass;
+        for (int x = 0; x < 3; ++x) W[n + 9 + x][r] = Dwi[3 * x] * J[r][n + 9] + Dwi[3 * x + 1] * J[r][n + 10] + Dwi[3 * x + 2] * J[r][n + 11];
+        double acc = 0; for (int u = 0; u < nu; ++u) acc += J[r][u] * W[u][r];
+        A[r] = acc;
+    }
+    for (int i = 0; i < n; ++i) {
+        double kp = (s->motor_mode[i] == MB_MOTOR_POSITION) ? s->motor_kp[i] : 0.0;
+        double des = kp * (s->motor_q_des[i] - s->q[i]) / dt + v[i] + s->motor_kd[i] * (s->motor_qd_des[i] - v[i]);
+        rhs[i] = (s->motor_mode[i] != MB_MOTOR_OFF) ? des - v[i] : 0.0;
+        lim[i] = (s->motor_mode[i] != MB_MOTOR_OFF) ? s->motor_max_force[i] * dt : 0.0;
+    }
+    for (int x = 0; x < 3; ++x) {
+        double cv = 0.0;
+        for (int u = 0; u < nu; ++u) cv += J[n + x][u] * v[u];
+        rhs[n + x] = (-c->erp * (pa[x] - pb[x]) / dt) - cv;
+        lim[n + x] = c->max_impulse;
+    }
+    for (int q = 0; q < nc; ++q)
+        for (int r = 0; r < 3; ++r) {
+            const int row = nr0 + 3 * q + r;
+            double rv = 0; for (int u = 0; u < nu; ++u) rv += J[row][u] * v[u];
+            const double depth = sp->mani.depth[q];
+            if (r == 0) rhs[row] = (depth > 0) ? (-rv - depth / dt) : (-depth * sp->erp / dt - rv);   /* restitution 0 */
+            else rhs[row] = -rv;
+        }
+    memset(lam, 0, sizeof lam); memset(dv, 0, sizeof dv);
+    mb_last_sweeps = 0;
+    for (int it = 0; it < iters; ++it) {
+        double residual = 0.0;
+        mb_last_sweeps = it + 1;
+        for (int jj = 0; jj < nr0; ++jj) {                           /* motors and P2P rows: reversed on even sweeps (mb_step_body) */
+            int r = (it & 1) ? jj : nr0 - 1 - jj;
+            if (lim[r] == 0.0) continue;
+            double jdv = 0.0;
+            for (int u = 0; u < nu; ++u) jdv += J[r][u] * dv[u];
+            double jdi = 1.0 / A[r];
+            double delta = rhs[r] * jdi - jdv * jdi, sum = lam[r] + delta;
+            if (sum < -lim[r]) { delta = -lim[r] - lam[r]; lam[r] = -lim[r]; }
+            else if (sum > lim[r]) { delta = lim[r] - lam[r]; lam[r] = lim[r]; }
+            else lam[r] = sum;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+            MB_RESIDUAL(delta / jdi);
+        }
+        for (int q = 0; q < nc; ++q) {                               /* contact normals */
+            int r = nr0 + 3 * q;
+            double jdv = 0; for (int u = 0; u < nu; ++u) jdv += J[r][u] * dv[u];
+            double jdi = 1.0 / A[r];
+            double delta = rhs[r] * jdi - jdv * jdi, sum = lam[r] + delta;
+            if (sum < 0.0) { delta = -lam[r]; lam[r] = 0.0; } else lam[r] = sum;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r] * delta;
+            MB_RESIDUAL(delta / jdi);
+        }
+        for (int q = 0; q < nc; ++q) {                               /* friction pairs, cone (enableConeFriction = 1) */
+            int r1 = nr0 + 3 * q + 1, r2 = r1 + 1;
+            double limit = sp->mu * lam[nr0 + 3 * q], jdv1 = 0, jdv2 = 0;
+            for (int u = 0; u < nu; ++u) { jdv1 += J[r1][u] * dv[u]; jdv2 += J[r2][u] * dv[u]; }
+            double d1 = (rhs[r1] - jdv1) / A[r1], d2 = (rhs[r2] - jdv2) / A[r2];
+            double s1 = lam[r1] + d1, s2 = lam[r2] + d2, tot = sqrt(s1 * s1 + s2 * s2);
+            if (tot > limit) { double f = tot > 0 ? limit / tot : 0.0; s1 *= f; s2 *= f; }
+            d1 = s1 - lam[r1]; d2 = s2 - lam[r2]; lam[r1] = s1; lam[r2] = s2;
+            for (int u = 0; u < nu; ++u) dv[u] += W[u][r1] * d1 + W[u][r2] * d2;
+            if (mb_res_thr > 0.0) MB_RESIDUAL(d1 * A[r1] + d2 * A[r2]);                              /* one residual per cone pair [A7c] */
+            else { MB_RESIDUAL(d1); MB_RESIDUAL(d2); }
+        }
+        if (residual <= mb_res_thr) break;
+    }
+    for (int q = 0; q < nc; ++q) sp->normal_impulse += lam[nr0 + 3 * q];
+    /* ---- integrate */
+    for (int i = 0; i < n; ++i) { s->qd[i] = v[i] + dv[i]; s->q[i] += dt * s->qd[i]; s->applied_torque[i] = 0.0; }
+    {
+        double cw[3];
+        for (int x = 0; x < 3; ++x) { b->linvel[x] = v[n + x] + dv[n + x]; b->angvel[x] = v[n + 3 + x] + dv[n + 3 + x]; }
+        for (int x = 0; x < 3; ++x) xc[x] += dt * b->linvel[x];
+        integrate_rotation(b->rot, b->angvel, dt);
+        m3_vec(b->rot, b->com, cw);
+        for (int x = 0; x < 3; ++x) b->pos[x] = xc[x] - cw[x];
+        for (int x = 0; x < 3; ++x) { dsh->linvel[x] = v[n + 6 + x] + dv[n + 6 + x]; dsh->angvel[x] = v[n + 9 + x] + dv[n + 9 + x]; }
+        for (int x = 0; x < 3; ++x) xd[x] += dt * dsh->linvel[x];
+        integrate_rotation(dsh->rot, dsh->angvel, dt);
+        m3_vec(dsh->rot, dsh->com, cw);
+        for (int x = 0; x < 3; ++x) dsh->pos[x] = xd[x] - cw[x];
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ arm + cube + contacts */
 typedef struct { double n[3], pa[3], pb[3], depth, mu, cfm_dt, erp; int arm_a; /* 1: body A is the arm tip, B the cube; 0: A cube, B table */ } contact_t;
 

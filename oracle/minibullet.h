@@ -169,6 +169,16 @@ typedef struct {
 /* Row order: joint motors, P2P x y z (these in reversed order on even sweeps), then the contact's normal, then its friction pair. */
 void mb_step_body_ball(const mb_model* m, mb_state* s, mb_body* plate, const mb_p2p* c, mb_ball* ball, double dt, int solver_iterations);
 
+/* object_balance, object_mode "spinning_plate" (object_balance_env.py:107-108, 198-239, 267-269, 355-358): the body tied to the TCP is the
+ * spool (plate_buffer.urdf, mass 0.1) and the free object is the dish (spinning_plate.urdf, mass 0.6) standing on the spool's spindle.  Both
+ * collide as the convex hull of their mesh (btConvexHullShape with the URDF margin 1e-3); the pair's contacts come from the general
+ * narrowphase (oracle/narrowphase.c: GJK / EPA on the two hulls in the spool's frame behind an AABB overlap test, one new point per tick into
+ * a persistent manifold of up to four, A35-A38) and are solved as in mb_step_push: normal rows, then cone-friction pairs, rigid (erp, cfm 0).
+ * The spool keeps Bullet's default velocity damping 0.04 (reset_object clears the damping of obj_id = the dish only, :338-345); the dish gets
+ * the one-tick torque and force of apply_random_torque_obj / apply_random_force_base (:357-358).  Neither body touches anything else: the
+ * tip's collision is off (t_s_core "no_core", :54) [PARITY_ASSUMPTIONS A41].  PARITY UNPINNED. */
+typedef struct mb_spin_s mb_spin;
+
 /* ----------------------------------------------------------------------------------------------------------
  * object_push: a free box (the cube) resting on the table and pushed by the sensor tip's collision core
  * (object_push_env.py; tip core collision on: t_s_core = "fixed", :60).  Restatement of a Bullet-style pipeline with this
@@ -222,8 +232,25 @@ typedef struct {
     mb_manifold mani;
 } mb_push_scene;
 
+struct mb_spin_s {
+    mb_body dish;                      /* the free object (body A of the manifold) */
+    double ext_torque[3];              /* applyExternalTorque(LINK_FRAME) on the dish: used by the next tick (with dish.ext_force), then cleared */
+    int32_t torque_pending;
+    int32_t n_dish, n_spool;
+    const double* dish_hull;           /* [n_dish][3] in the dish's base frame */
+    const double* spool_hull;          /* [n_spool][3] in the spool's base frame */
+    double margin, breaking, erp, mu;  /* URDF hull margin 1e-3 (both), contactBreakingThreshold 1e-4, contact ERP 0.2, friction 0.5 x 0.5 */
+    double lin_damp, ang_damp;         /* the spool's: 0.04 */
+    mb_manifold mani;                  /* la: on the dish, lb: on the spool, normals from the spool towards the dish */
+    int32_t n_contacts;                /* out */
+    double normal_impulse;             /* out: summed over the manifold's points */
+};
+/* Row order: joint motors, P2P x y z (these in reversed order on even sweeps), the contacts' normals, then their friction pairs. */
+void mb_step_spin(const mb_model* m, mb_state* s, mb_body* spool, const mb_p2p* c, mb_spin* sp, double dt, int solver_iterations);
+
 /* oracle/narrowphase.c.  hull [n][3] and the results in the box frame; *sdist < 0: overlap depth of the cores.  Returns 0 for touching cores. */
 int mb_gjk_epa_hull_box(const double* hull, int n, const double* half, double* sdist, double* nrm, double* pa, double* pb);
+int mb_gjk_epa_hull_hull(const double* hull, int n, const double* hull_b, int nb, double* sdist, double* nrm, double* pa, double* pb);
 void mb_manifold_add(mb_manifold* m, double breaking, const double* oa, const double* Ra, const double* ob, const double* Rb,
                      const double* pa_w, const double* pb_w, const double* n_w, double depth);
 void mb_manifold_refresh(mb_manifold* m, double breaking, const double* oa, const double* Ra, const double* ob, const double* Rb);

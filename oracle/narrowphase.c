@@ -25,10 +25,21 @@ static void cross3(const double* a, const double* b, double* o) {
 }
 static void sub3(const double* a, const double* b, double* o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
 
-static void support(const double* hull, int n, const double* e, const double* d, sv_t* out) {
+/* shape B: the box (half extents e) or, since round 6, a second convex hull hb [nb][3] in its own frame (object_balance's spinning_plate:
+ * the dish on the spool, both btConvexHullShape): its support point along -d is the vertex with the largest -d . b (ties: the lowest index) */
+typedef struct { const double* e; const double* hb; int nb; } shape_b;
+static void support(const double* hull, int n, const shape_b* B, const double* d, sv_t* out) {
     int best = 0; double bk = dot3(hull, d);
     for (int i = 1; i < n; ++i) { const double k = dot3(hull + 3 * i, d); if (k > bk) { bk = k; best = i; } }
-    for (int x = 0; x < 3; ++x) { out->a[x] = hull[3 * best + x]; out->w[x] = out->a[x] - (d[x] > 0.0 ? -e[x] : e[x]); }
+    if (B->hb == NULL) {
+        const double* e = B->e;
+        for (int x = 0; x < 3; ++x) { out->a[x] = hull[3 * best + x]; out->w[x] = out->a[x] - (d[x] > 0.0 ? -e[x] : e[x]); }
+        return;
+    }
+    const double nd[3] = {-d[0], -d[1], -d[2]};
+    int bb = 0; double bkb = dot3(B->hb, nd);
+    for (int i = 1; i < B->nb; ++i) { const double k = dot3(B->hb + 3 * i, nd); if (k > bkb) { bkb = k; bb = i; } }
+    for (int x = 0; x < 3; ++x) { out->a[x] = hull[3 * best + x]; out->w[x] = out->a[x] - B->hb[3 * bb + x]; }
 }
 
 /* ---- closest point of a simplex to the origin, with barycentric weights (Ericson, Real-Time Collision Detection 5.1: Voronoi regions) */
@@ -81,7 +92,7 @@ static int closest_tetra(const double p[4][3], double* lam) {
 
 /* ---- GJK.  Returns 0 separated (dist > 0, n from the box to the hull, a / b the witness points on the hull / the box), 1 overlapping with a
  * tetrahedron around the origin in S (EPA continues from it), 2 touching (dist 0 with a lower-dimensional simplex: reported as no contact depth). */
-static int gjk(const double* hull, int n, const double* e, sv_t S[4], int* ns_out, double* dist, double* nrm, double* pa, double* pb) {
+static int gjk(const double* hull, int n, const shape_b* e, sv_t S[4], int* ns_out, double* dist, double* nrm, double* pa, double* pb) {
     const double d0[3] = {1.0, 0.0, 0.0};
     int ns = 1;
     support(hull, n, e, d0, &S[0]);
@@ -131,7 +142,7 @@ static int make_face(const sv_t* V, int i0, int i1, int i2, face_t* f) {
     f->alive = 1;
     return 1;
 }
-static int epa(const double* hull, int n, const double* e, const sv_t S[4], double* depth, double* nrm, double* pa, double* pb) {
+static int epa(const double* hull, int n, const shape_b* e, const sv_t S[4], double* depth, double* nrm, double* pa, double* pb) {
     static sv_t V[EPA_MAXV]; static face_t F[EPA_MAXF];   /* single-threaded test infrastructure */
     int nv = 4, nf = 0;
     for (int k = 0; k < 4; ++k) V[k] = S[k];
@@ -176,15 +187,25 @@ static int epa(const double* hull, int n, const double* e, const sv_t S[4], doub
 
 /* Signed distance of the cores (negative: overlap depth), the unit normal from the box towards the hull and the witness points on the hull
  * (pa) and on the box (pb), all in the box frame.  hull: [n][3] in the box frame.  Returns 0 when no normal exists (touching cores). */
-int mb_gjk_epa_hull_box(const double* hull, int n, const double* half, double* sdist, double* nrm, double* pa, double* pb) {
+static int gjk_epa(const double* hull, int n, const shape_b* B, double* sdist, double* nrm, double* pa, double* pb) {
     sv_t S[4]; int ns = 0; double dist = 0.0;
-    const int r = gjk(hull, n, half, S, &ns, &dist, nrm, pa, pb);
+    const int r = gjk(hull, n, B, S, &ns, &dist, nrm, pa, pb);
     if (r == 0) { *sdist = dist; return 1; }
     if (r == 2) return 0;
     double depth = 0.0;
-    if (!epa(hull, n, half, S, &depth, nrm, pa, pb)) return 0;
+    if (!epa(hull, n, B, S, &depth, nrm, pa, pb)) return 0;
     *sdist = -depth;
     return 1;
+}
+int mb_gjk_epa_hull_box(const double* hull, int n, const double* half, double* sdist, double* nrm, double* pa, double* pb) {
+    const shape_b B = {half, NULL, 0};
+    return gjk_epa(hull, n, &B, sdist, nrm, pa, pb);
+}
+/* The same for two hulls: `hull` [n][3] is body A's, given in body B's frame; `hull_b` [nb][3] is body B's in its own frame.  sdist, the unit
+ * normal from B towards A and the witness points (pa on A, pb on B) come back in B's frame. */
+int mb_gjk_epa_hull_hull(const double* hull, int n, const double* hull_b, int nb, double* sdist, double* nrm, double* pa, double* pb) {
+    const shape_b B = {NULL, hull_b, nb};
+    return gjk_epa(hull, n, &B, sdist, nrm, pa, pb);
 }
 
 /* ---- btPersistentManifold's cache (A36-A38).  Local points: la in the tip link's frame, lb in the cube's frame (body A = the tip: the

@@ -220,6 +220,21 @@ def objects():
             save(os.path.join(OUT, "objects", f"{name}{suffix}.npz"), **d)
 
 
+def spinning_plate():
+    """object_balance, object_mode "spinning_plate" (object_balance_env.py:198-239): the dish (spinning_plate.urdf, the free object) and the spool
+    it stands on (plate_buffer.urdf, tied to the TCP).  Both collide as the CONVEX HULL of their mesh (a URDF <mesh> collision without the
+    concave flag: btConvexHullShape, optimizeConvexHull): `hull` = the hull's vertices in the link frame, in mesh order."""
+    from scipy.spatial import ConvexHull
+    d0 = "rl_env_assets/nonprehensile_manipulation/object_balance/spinning_plate"
+    for name in ("plate_buffer", "spinning_plate"):
+        d = compile_free_body(os.path.join(REF, d0, f"{name}.urdf"), inertia_mode="collision_aabb")
+        v = np.asarray(d["verts"], dtype=np.float64)
+        keep = np.unique(ConvexHull(v).vertices)
+        d["hull"] = v[keep]
+        save(os.path.join(OUT, "objects", f"{name}.npz"), **d)
+        print(f"  {name}: {len(v)} vertices, {len(keep)} on the hull")
+
+
 def sphere():
     """object_roll marble: sphere.urdf (mass 0.05, collision sphere r = 0.0025; inertia of a solid sphere, what Bullet computes from the
     collision shape) + the tessellation upstream ships next to it (sphere.obj, r = 0.0025) as the visual [PARITY_ASSUMPTIONS A30]."""
@@ -357,9 +372,13 @@ if __name__ == "__main__":
     if "--collision-only" in sys.argv:
         collision_boxes()
         sys.exit(0)
+    if "--spinning-plate-only" in sys.argv:
+        spinning_plate()
+        sys.exit(0)
     objects()
     sphere()
     balance_ball()
+    spinning_plate()
     robots()
     sensors()
     stimuli()

@@ -61,6 +61,13 @@ class MBManifold(C.Structure):
                 ("pa", (C.c_double * 3) * 4), ("pb", (C.c_double * 3) * 4), ("depth", C.c_double * 4)]
 
 
+class MBSpin(C.Structure):
+    _fields_ = [("dish", MBBody), ("ext_torque", C.c_double * 3), ("torque_pending", C.c_int32), ("n_dish", C.c_int32), ("n_spool", C.c_int32),
+                ("dish_hull", C.POINTER(C.c_double)), ("spool_hull", C.POINTER(C.c_double)), ("margin", C.c_double), ("breaking", C.c_double),
+                ("erp", C.c_double), ("mu", C.c_double), ("lin_damp", C.c_double), ("ang_damp", C.c_double), ("mani", MBManifold),
+                ("n_contacts", C.c_int32), ("normal_impulse", C.c_double)]
+
+
 class MBPushScene(C.Structure):
     _fields_ = [
         ("table_z", C.c_double), ("half", C.c_double * 3), ("mu_table", C.c_double), ("mu_tip", C.c_double),
@@ -105,6 +112,9 @@ def lib():
         _lib.mb_step_body_ball.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.POINTER(MBBall), C.c_double, C.c_int]
         _lib.mb_gjk_epa_hull_box.argtypes = [dp, C.c_int, dp, dp, dp, dp, dp]
         _lib.mb_gjk_epa_hull_box.restype = C.c_int
+        _lib.mb_gjk_epa_hull_hull.argtypes = [dp, C.c_int, dp, C.c_int, dp, dp, dp, dp]
+        _lib.mb_gjk_epa_hull_hull.restype = C.c_int
+        _lib.mb_step_spin.argtypes = [mp, sp, C.POINTER(MBBody), C.POINTER(MBP2P), C.POINTER(MBSpin), C.c_double, C.c_int]
         _lib.mb_opensimplex_perm.argtypes = [C.c_int64, C.POINTER(C.c_int16)]
         _lib.mb_opensimplex_noise2.argtypes = [C.POINTER(C.c_int16), C.c_double, C.c_double]
         _lib.mb_opensimplex_noise2.restype = C.c_double
@@ -272,6 +282,10 @@ class Arm:
     def step_simulation_body_ball(self, plate, p2p, ball, dt=1.0 / 240.0, iters=150):
         """stepSimulation with the round plate tied to the arm and the ball on it (object_balance, ball_on_plate)."""
         self.L.mb_step_body_ball(C.byref(self.model), C.byref(self.state), C.byref(plate), C.byref(p2p), C.byref(ball), dt, iters)
+
+    def step_simulation_spin(self, spool, p2p, spin, dt=1.0 / 240.0, iters=150):
+        """stepSimulation with the spool tied to the arm and the dish standing on it (object_balance, spinning_plate)."""
+        self.L.mb_step_spin(C.byref(self.model), C.byref(self.state), C.byref(spool), C.byref(p2p), C.byref(spin), dt, iters)
 
     def step_simulation_body(self, body, p2p, dt=1.0 / 240.0, iters=150):
         """stepSimulation with a free rigid body tied to the arm by a point-to-point constraint."""

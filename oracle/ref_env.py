@@ -752,7 +752,9 @@ class OracleSurfaceFollowVertEnv(OracleSurfaceFollowAutoEnv):
 class OracleObjectBalanceEnv(_OracleArmEnv):
     """object_balance-v0 (nonprehensile_manipulation/object_balance/object_balance_env.py + base_object_env.py): UR5 + TacTip pointing up;
     object_mode "pole": a pole tied to the TCP by a point-to-point constraint; "ball_on_plate": the round plate tied the same way and a ball
-    rolling on it (:105-106, 187-199, 245-260; mb_step_body_ball, PARITY A39)."""
+    rolling on it (:105-106, 187-199, 245-260; mb_step_body_ball, PARITY A39); "spinning_plate": the spool (plate_buffer.urdf) tied that way and
+    the dish standing on its spindle (:107-108, 198-239, 267-269, 355-358; mb_step_spin, PARITY A41) - the OBJECT of termination, reward and
+    the oracle observation is then the dish, what the sensor touches is the spool."""
 
     ACTION_REPEAT = 12                   # floor((1/20)/(1/240)), object_balance_env.py:33-35
 
@@ -760,8 +762,9 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
         modes = dict(movement_mode="xy", control_mode="TCP_velocity_control", object_mode="pole", rand_gravity=True, rand_embed_dist=True,
                      observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
         modes.update(env_modes or {})
-        assert modes["object_mode"] in ("pole", "ball_on_plate") and modes["movement_mode"] in ("xy", "xyz", "RxRy", "xyRxRy")
+        assert modes["object_mode"] in ("pole", "ball_on_plate", "spinning_plate") and modes["movement_mode"] in ("xy", "xyz", "RxRy", "xyRxRy")
         self.ball_mode = modes["object_mode"] == "ball_on_plate"
+        self.spin_mode = modes["object_mode"] == "spinning_plate"
         rest = [0.19826, -2.01062, -1.96602, -0.73808, 4.71286, -3.34064]                  # object_balance/rest_poses.py:4-20
         self._setup_arm(seed, modes, max_steps, image_size, "standard", rest, inertia)      # :46-48
         self.termination_dist_deg, self.termination_dist_pos = 35, 0.1                     # :50-51
@@ -774,22 +777,49 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
             v, w = 0.001, 1 * (math.pi / 180)                                              # :129-140
         self.act_lo, self.act_hi = np.array([-v, -v, -v, -w, -w, 0.0]), np.array([v, v, v, w, w, 0.0])
         self.obj_base_width, self.obj_base_height = (0.2 if self.ball_mode else 0.1), 0.0025   # :158-159, :188-189
+        self.buffer_height = 0.0
+        if self.spin_mode:
+            self.obj_base_width, self.obj_base_height, self.buffer_height = 0.15, 0.0267, 0.026   # :199-203
         suffix = "" if inertia == "collision_aabb" else "_urdfinertia"
-        z = np.load(os.path.join(_ASSETS, "objects", f"{'round_plate' if self.ball_mode else 'pole'}{suffix}.npz"))
-        self.obj_verts, self.obj_tris = z["verts"], z["tris"]
+        name = "plate_buffer" if self.spin_mode else f"{'round_plate' if self.ball_mode else 'pole'}{suffix}"
+        z = np.load(os.path.join(_ASSETS, "objects", f"{name}.npz"))
+        self.obj_verts, self.obj_tris = z["verts"], z["tris"]                              # (what stands on the sensor: pole / round plate / spool)
         self.init_obj_rpy = np.array([0.0, 0.0, -math.pi / 2])                             # :190
         self.init_obj_rot = pm.mat_from_quat(pm.quat_from_euler(self.init_obj_rpy))
-        self._set_init_obj_pos(buffer_height=0.0)
+        self._set_init_obj_pos(buffer_height=self.buffer_height)                           # :215-219
         b = mb.MBBody()
         b.mass = float(z["mass"])
         for k in range(3):
             b.com[k] = float(z["com"][k])
         for k in range(9):
             b.inertia[k] = float(z["inertia"].reshape(9)[k])
-        self.body = b
-        # load_object (base_object_env.py:66-70): loadURDF places the *link* frame at init_obj_pos; the inertial frame that
-        # get/resetBasePositionAndOrientation use sits root_inertial_pos away
-        self._teleport_body(self.init_obj_pos + self.init_obj_rot @ z["root_inertial_pos"], self.init_obj_rot)
+        self.body = b                                                                      # the body on the constraint
+        self.spin = None
+        if self.spin_mode:                                                                 # load_plate_buffer :223-239; the dish is the env's obj_id
+            assert inertia == "collision_aabb"
+            zd = np.load(os.path.join(_ASSETS, "objects", "spinning_plate.npz"))
+            sp = mb.MBSpin()
+            sp.dish.mass = float(zd["mass"])
+            for k in range(3):
+                sp.dish.com[k] = float(zd["com"][k])
+            for k in range(9):
+                sp.dish.inertia[k] = float(zd["inertia"].reshape(9)[k])
+            self._dish_hull = np.ascontiguousarray(zd["hull"], dtype=np.float64)
+            self._spool_hull = np.ascontiguousarray(z["hull"], dtype=np.float64)
+            dp = C.POINTER(C.c_double)
+            sp.n_dish, sp.n_spool = len(self._dish_hull), len(self._spool_hull)
+            sp.dish_hull, sp.spool_hull = self._dish_hull.ctypes.data_as(dp), self._spool_hull.ctypes.data_as(dp)
+            sp.margin, sp.breaking, sp.erp, sp.mu = 1e-3, 1e-4, 0.2, 0.5 * 0.5             # URDF hull margin, base_tactile_env.py:128-130, default frictions
+            sp.lin_damp = sp.ang_damp = 0.04
+            self.spin = sp
+            self.dish_verts, self.dish_tris = zd["verts"], zd["tris"]
+            self.init_buffer_pos = np.array([self.workframe_pos[0], self.workframe_pos[1], self.workframe_pos[2] + self.buffer_height / 2])   # :228-233
+            self._teleport(sp.dish, self.init_obj_pos + self.init_obj_rot @ zd["root_inertial_pos"], self.init_obj_rot)
+            self._teleport_body(self.init_buffer_pos, np.eye(3))
+        else:
+            # load_object (base_object_env.py:66-70): loadURDF places the *link* frame at init_obj_pos; the inertial frame that
+            # get/resetBasePositionAndOrientation use sits root_inertial_pos away
+            self._teleport_body(self.init_obj_pos + self.init_obj_rot @ z["root_inertial_pos"], self.init_obj_rot)
         link, fpos, _ = self.tg.frames["tcp_link"]
         c = mb.MBP2P()                                                                      # apply_constraints :261-283
         c.link, c.erp, c.max_impulse = int(link), 0.2, 500.0
@@ -821,20 +851,32 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
                                       self.workframe_pos[2] + buffer_height + (self.obj_base_height / 2) - self.embed_dist])   # :185-189,:317-321
 
     def _update_constraint(self):                                                           # :285-294
-        piv = [0.0, 0.0, -self.obj_base_height / 2 + self.embed_dist]
+        if self.spin_mode:                                                                  # :267-269: the spool's pivot, set once (update_constraints
+            if getattr(self, "_spool_pivot_set", False):                                    # :289 does nothing in this mode)
+                return
+            self._spool_pivot_set = True
+            piv = [0.0, 0.0, -self.buffer_height / 2 + self.embed_dist]
+        else:
+            piv = [0.0, 0.0, -self.obj_base_height / 2 + self.embed_dist]
         for k in range(3):
             self.p2p.pivot_b[k] = piv[k]
 
-    def _teleport_body(self, pos, rot):                                                     # resetBasePositionAndOrientation
+    @staticmethod
+    def _teleport(body, pos, rot):                                                          # resetBasePositionAndOrientation
         for k in range(3):
-            self.body.pos[k] = float(pos[k])
-            self.body.linvel[k] = 0.0
-            self.body.angvel[k] = 0.0
+            body.pos[k] = float(pos[k])
+            body.linvel[k] = 0.0
+            body.angvel[k] = 0.0
         for k in range(9):
-            self.body.rot[k] = float(np.asarray(rot).reshape(9)[k])
+            body.rot[k] = float(np.asarray(rot).reshape(9)[k])
+
+    def _teleport_body(self, pos, rot):
+        self._teleport(self.body, pos, rot)
 
     def _step_simulation(self):
-        if self.ball is not None:
+        if self.spin is not None:
+            self.arm.step_simulation_spin(self.body, self.p2p, self.spin, self.SIM_DT, self.SOLVER_ITERS)
+        elif self.ball is not None:
             self.arm.step_simulation_body_ball(self.body, self.p2p, self.ball, self.SIM_DT, self.SOLVER_ITERS)
         else:
             self.arm.step_simulation_body(self.body, self.p2p, self.SIM_DT, self.SOLVER_ITERS)
@@ -842,7 +884,11 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
     def task_spheres(self):                                                                 # visualise_goal = False (object_balance_env.py:70)
         return []
 
-    def body_pose(self):
+    def body_pose(self):                                                                    # the OBJECT (obj_id): pole / round plate / dish
+        b = self.spin.dish if self.spin is not None else self.body
+        return np.array(b.pos[:]), np.array(b.rot[:]).reshape(3, 3)
+
+    def stimulus_pose(self):                                                                # what stands on the sensor
         return np.array(self.body.pos[:]), np.array(self.body.rot[:]).reshape(3, 3)
 
     def reset(self):
@@ -853,9 +899,27 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
         if self.modes["rand_embed_dist"]:                                                   # :308-322
             lo, hi = {"tactip": (0.003, 0.006), "digitac": (0.001, 0.0025), "digit": (0.0015, 0.0025)}[self.t_s_name]
             self.embed_dist = self.rng.uniform(lo, hi)
-            self._set_init_obj_pos(buffer_height=0.0)
+            self._set_init_obj_pos(buffer_height=0.0)                                       # (:317-321 leaves the buffer height out in every mode)
             self._update_constraint()
         self._reset_robot(np.zeros(3), np.zeros(3))                                         # update_init_pose, base_object_env.py:96-103
+        if self.spin is not None:                                                           # reset_object :330-345, :355-358
+            self._teleport(self.spin.dish, self.init_obj_pos, self.init_obj_rot)
+            self._teleport_body(self.init_buffer_pos, np.eye(3))                            # reset_plate_buffer :322-323
+            self.spin.mani.n = 0                                                            # (a teleported pair starts a new manifold, as mb_push_scene's)
+            for k in range(3):
+                self.spin.ext_torque[k] = [0.0, 0.0, -1.0][k]                               # apply_random_torque_obj(1.0): LINK_FRAME :383-391
+            self.spin.torque_pending = 1
+            sx = -1.0 if self.rng.random() < 0.5 else 1.0                                   # apply_random_force_base(1.0) :360-381
+            rx = self.rng.random()
+            sy = -1.0 if self.rng.random() < 0.5 else 1.0
+            ry = self.rng.random()
+            fpos = self.init_obj_pos + np.array([sx * rx * self.obj_base_width / 2, sy * ry * self.obj_base_width / 2, 0.0])
+            for k in range(3):
+                self.spin.dish.ext_force[k] = [0.0, 0.0, -1.0][k]
+                self.spin.dish.ext_pos[k] = float(fpos[k])
+            self.spin.dish.ext_pending = 1
+            self._get_step_data()
+            return self._observation()
         self._teleport_body(self.init_obj_pos, self.init_obj_rot)                           # reset_object :330-345
         if self.ball is not None:                                                           # :350-352: reset_ball, apply_random_torque_ball(0.001)
             self._teleport_ball()
@@ -908,13 +972,18 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
 
     def stimulus_transform(self):
         cpos, cR = self.camera_pose()
-        pos, R = self.body_pose()
+        pos, R = self.stimulus_pose()
         return mb.cam_from_obj_matrix(cpos, cR, pos, R)
 
     def tactile_image(self):
         h, w = self.image_size
         cur = self.nodef_dep.copy()
         mb.render_depth(self.obj_verts, self.obj_tris, self.stimulus_transform(), self.cam["fov"], self.cam["near"], self.cam["far"], w, h, cur)
+        if self.spin is not None:                                                           # getCameraImage sees the dish too (it never is nearer than the
+            cpos, cR = self.camera_pose()                                                   # undeformed tip while an episode lasts: tests/test_oracle_spinning_plate.py)
+            pos, R = self.body_pose()
+            mb.render_depth(self.dish_verts, self.dish_tris, mb.cam_from_obj_matrix(cpos, cR, pos, R), self.cam["fov"], self.cam["near"],
+                            self.cam["far"], w, h, cur)
         return mb.t_s_camera(cur, self.nodef_dep, self.nodef_gray, self.border_mask)
 
     def _obj_work(self):                                                                    # base_object_env.py:118-139
@@ -922,7 +991,8 @@ class OracleObjectBalanceEnv(_OracleArmEnv):
         p, rpy = self._world_to_work(pos, pm.euler_from_quat(pm.quat_from_mat(R)))
         _, iq = pm.invert_transform(self.workframe_pos, self.workframe_orn)
         Rinv = pm.mat_from_quat(iq)
-        return p, rpy, pm.quat_from_euler(rpy), Rinv @ np.array(self.body.linvel[:]), Rinv @ np.array(self.body.angvel[:])
+        ob = self.spin.dish if self.spin is not None else self.body
+        return p, rpy, pm.quat_from_euler(rpy), Rinv @ np.array(ob.linvel[:]), Rinv @ np.array(ob.angvel[:])
 
     def oracle_obs(self):                                                                   # object_balance_env.py:528-563
         p, rpy, lv, av = self._tcp_work()

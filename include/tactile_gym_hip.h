@@ -24,7 +24,7 @@ extern "C" {
 
 #define TG_MAX_DOF 8
 #define TG_MAX_BODIES_PER_LINK 4
-#define TG_ABI_VERSION 13
+#define TG_ABI_VERSION 14
 #define TG_MAX_TRAJ_POINTS 16
 
 /* ---- robot description: the flattened URDF (replaces loadURDF, robots/arms/robot.py:95-112) --------------------- */
@@ -228,11 +228,27 @@ typedef struct {
      * per env after every sweep on every mapping; every tick is a full tick, no licence, no composed sweeps, no reset template
      * (tg_state_view.solver_sweeps reports the sweeps run).  pgs_full_sweeps is ignored in this mode.  (ABI v13) */
     double solver_residual_threshold;
+    /* object_balance, object_mode "spinning_plate" (balance_object = TG_BALANCE_SPINNING_PLATE; object_balance_env.py:107-108, 198-239, 267-269,
+     * 355-358; ABI v14): the body on the TCP's constraint is the spool (plate_buffer.urdf: obj_mass / obj_com / obj_inertia describe IT, the
+     * stimulus mesh is its mesh, its pivot sits at (0, 0, -spin_buffer_height / 2 + embed_dist) and is never updated) and the env's object - what
+     * termination, reward and the oracle observation look at - is the dish (spinning_plate.urdf: spin_dish_*) standing on the spool's spindle.
+     * Both collide as the convex hull of their mesh (margin spin_hull_margin each): the pair goes through the wave-mapped GJK / EPA and a
+     * persistent manifold of up to four points (csrc/tg_spin.hip, PARITY_ASSUMPTIONS A35-A38, A41), friction spin_mu under the cone,
+     * contact_breaking / contact_erp as for the other contact envs; the spool keeps obj_lin_damp / obj_ang_damp, the dish has none (:338-345).
+     * Reset: dish to init_obj_pos = workframe + (0, 0, spin_buffer_height + obj_base_height / 2 - embed) - without the buffer height when
+     * rand_embed is on, as upstream's reset_task (:317-321) -, spool to workframe + (0, 0, spin_buffer_height / 2), a one-tick torque (0, 0, -1)
+     * in the dish's frame and ext_force at a random point of the dish (:355-358).  f64, UR5 chain, one wavefront per env; not with
+     * solver_residual_threshold > 0.  Hull arrays are copied at tg_create. */
+    double spin_dish_mass, spin_dish_com[3], spin_dish_inertia[9];
+    double spin_buffer_height, spin_hull_margin, spin_mu;
+    int32_t spin_n_dish, spin_n_spool;      /* hull vertex counts: n_dish <= 1152, n_spool <= 256 */
+    const double* spin_dish_hull;           /* [spin_n_dish][3] in the dish's base frame */
+    const double* spin_spool_hull;          /* [spin_n_spool][3] in the spool's base frame */
 } tg_config;
 
 enum { TG_BANK_AUTO = 0, TG_BANK_OFF = 1, TG_BANK_SYNC = 2, TG_BANK_ON = 3 };
 enum { TG_NARROW_CLOSED_FORM = 0, TG_NARROW_GJK_MANIFOLD = 1, TG_NARROW_GJK_SINGLE = 2 };
-enum { TG_BALANCE_POLE = 0, TG_BALANCE_BALL_ON_PLATE = 1 };
+enum { TG_BALANCE_POLE = 0, TG_BALANCE_BALL_ON_PLATE = 1, TG_BALANCE_SPINNING_PLATE = 2 };
 enum { TG_FUSED_AUTO = 0, TG_FUSED_OFF = 1, TG_FUSED_ON = 2 };
 
 typedef struct tg_ctx tg_ctx;
@@ -419,6 +435,8 @@ typedef struct {
     double*  ball_linvel;    /* [num_envs][3] */
     double*  ball_angvel;    /* [num_envs][3] */
     double*  ball_impulse;   /* [num_envs] normal impulse of the ball - plate contact in the last sim tick (0: not touching) */
+    double*  dish_state;     /* [num_envs][20] spinning_plate: the dish's base position (0-2), orientation (3-11, row major), linear (12-14) and angular
+                                (15-17) velocity, the last tick's summed normal impulse (18) and number of manifold points (19); body_* is the spool */
     int32_t* broadphase_pairs;  /* [num_envs] last broadphase check (tg_set_broadphase): unexpected pairs whose world AABBs overlap (stage 1) */
     int32_t* broadphase_hits;   /* [num_envs] ... of which the oriented boxes / the hull also overlap (stages 2, 3): 0 = no unmodelled contact possible */
     int32_t* broadphase_mask;   /* [num_envs] bit k: slot k is part of a hit */

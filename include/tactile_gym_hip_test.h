@@ -18,6 +18,9 @@ extern "C" {
  * box of half extents half[3]: hulls [n_cases][n_hull][3] in the box frame (n_hull <= 1152); out [n_cases][11] = found (1 / 0), signed core
  * distance (< 0: overlap depth), unit normal from the box to the hull, witness point on the hull, witness point on the box. */
 int tg_selftest_narrowphase(int32_t n_cases, int32_t n_hull, const double* hulls, const double* half, double* out);
+/* The same for two hulls (csrc/tg_spin.hip's pair; oracle/narrowphase.c: mb_gjk_epa_hull_hull): hulls [n_cases][n_hull][3] = body A's hull in body
+ * B's frame, hull_b [n_b][3] = body B's in its own frame (n_b <= 256); out as above. */
+int tg_selftest_narrowphase_hulls(int32_t n_cases, int32_t n_hull, const double* hulls, int32_t n_b, const double* hull_b, double* out);
 
 /* Self-test of the raster's depth division (tactile_sensor.py:239-294 reads an IEEE depth buffer): n pseudo-random operand pairs
  * with exponents 2^-40 .. 2^24 divided by the kernels' refinement and by the correctly rounded `/`; *mismatches = quotients whose

@@ -8,7 +8,7 @@ import os
 
 MAX_DOF = 8
 MAX_BODIES_PER_LINK = 4
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_TRAJ_POINTS = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +29,7 @@ CONTACT_MAP = {"auto": 0, "lane": 1, "wave": 2}
 RESET_BANK = {"auto": 0, "off": 1, "sync": 2, "on": 3}
 FUSED_STEP = {"auto": 0, "off": 1, "on": 2}
 NARROWPHASE = {"closed_form": 0, "gjk_manifold": 1, "gjk_single": 2}
-BALANCE_OBJECT = {"pole": 0, "ball_on_plate": 1}
+BALANCE_OBJECT = {"pole": 0, "ball_on_plate": 1, "spinning_plate": 2}
 MOTOR_OFF, MOTOR_VELOCITY, MOTOR_POSITION = 0, 1, 2
 
 _d3 = C.c_double * 3
@@ -107,6 +107,10 @@ class TgConfig(C.Structure):
         ("balance_object", C.c_int32), ("ball_radius", C.c_double), ("ball_mass", C.c_double), ("ball_mu", C.c_double), ("plate_radius", C.c_double),
         ("fused_step", C.c_int32),
         ("solver_residual_threshold", C.c_double),
+        ("spin_dish_mass", C.c_double), ("spin_dish_com", C.c_double * 3), ("spin_dish_inertia", C.c_double * 9),
+        ("spin_buffer_height", C.c_double), ("spin_hull_margin", C.c_double), ("spin_mu", C.c_double),
+        ("spin_n_dish", C.c_int32), ("spin_n_spool", C.c_int32),
+        ("spin_dish_hull", C.POINTER(C.c_double)), ("spin_spool_hull", C.POINTER(C.c_double)),
     ]
 
 
@@ -138,6 +142,7 @@ class TgStateView(C.Structure):
         ("contact_count", C.POINTER(C.c_int32)), ("contact_ids", C.POINTER(C.c_int32)),
         ("ball_pos", C.POINTER(C.c_double)), ("ball_linvel", C.POINTER(C.c_double)), ("ball_angvel", C.POINTER(C.c_double)),
         ("ball_impulse", C.POINTER(C.c_double)),
+        ("dish_state", C.POINTER(C.c_double)),
         ("broadphase_pairs", C.POINTER(C.c_int32)), ("broadphase_hits", C.POINTER(C.c_int32)), ("broadphase_mask", C.POINTER(C.c_int32)),
         ("solver_sweeps", C.POINTER(C.c_int32)),
     ]
@@ -256,6 +261,7 @@ def _share_torch_hip_runtime():
 TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtactile_gym_hip_test.so")
 TEST_SYMBOLS = {
     "tg_selftest_narrowphase": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tg_selftest_narrowphase_hulls": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tg_selftest_division": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
     "tg_selftest_penetration_division": (C.c_int, [C.POINTER(C.c_int64)]),
     "tg_selftest_edge_exclusion": (C.c_int, [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),

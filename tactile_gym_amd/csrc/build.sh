@@ -32,8 +32,9 @@ cc tg_selftest -ffp-contract=off & p9=$!
 cc tg_broadphase -ffp-contract=off & p10=$!
 cc tg_api_state & p11=$!
 cc tg_api_ops & p12=$!
-wait $p1; wait $p2; wait $p3; wait $p4; wait $p5; wait $p6; wait $p7; wait $p8; wait $p9; wait $p10; wait $p11; wait $p12    # each wait returns its job's status: a failed translation unit fails the build (set -e)
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" "$OUT/tg_scene.o" "$OUT/tg_exchange.o" "$OUT/tg_fused.o" "$OUT/tg_broadphase.o" "$OUT/tg_api_state.o" "$OUT/tg_api_ops.o" -o "$OUT/libtactile_gym_hip.so"
+cc tg_spin & p13=$!
+wait $p1; wait $p2; wait $p3; wait $p4; wait $p5; wait $p6; wait $p7; wait $p8; wait $p9; wait $p10; wait $p11; wait $p12; wait $p13    # each wait returns its job's status: a failed translation unit fails the build (set -e)
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_raster.o" "$OUT/tg_noise.o" "$OUT/tg_api.o" "$OUT/tg_contact_wave.o" "$OUT/tg_scene.o" "$OUT/tg_exchange.o" "$OUT/tg_fused.o" "$OUT/tg_broadphase.o" "$OUT/tg_api_state.o" "$OUT/tg_api_ops.o" "$OUT/tg_spin.o" -o "$OUT/libtactile_gym_hip.so"
 # test infrastructure (include/tactile_gym_hip_test.h): device self-tests of the raster's division / block test and of the wave-mapped GJK / EPA
 $HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/tg_narrow_test.o" "$OUT/tg_selftest.o" -o "$OUT/libtactile_gym_hip_test.so"
 echo "built $OUT/libtactile_gym_hip.so $OUT/libtactile_gym_hip_test.so"

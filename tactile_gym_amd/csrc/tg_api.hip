@@ -56,7 +56,24 @@ template <typename T> static int build_env_const(const tg_config& cfg, const tg_
         c.body.erp = (T)cfg.p2p_erp; c.body.max_impulse = (T)cfg.p2p_max_impulse;
         c.body.link = rob.tcp_link;   // createConstraint parent = TCP link, parentFramePosition 0 in its inertial frame (:271-283)
         c.body.pivot_a = {(T)rob.tcp_pos[0], (T)rob.tcp_pos[1], (T)rob.tcp_pos[2]};
-        if (cfg.balance_object != TG_BALANCE_POLE && cfg.balance_object != TG_BALANCE_BALL_ON_PLATE) return fail(-1, "object_balance: unknown balance_object");
+        if (cfg.balance_object != TG_BALANCE_POLE && cfg.balance_object != TG_BALANCE_BALL_ON_PLATE && cfg.balance_object != TG_BALANCE_SPINNING_PLATE)
+            return fail(-1, "object_balance: unknown balance_object");
+        c.spin.n_dish = 0; c.spin.n_spool = 0; c.spin.buffer_height = T(0); c.spin.embed0 = T(0);
+        if (cfg.balance_object == TG_BALANCE_SPINNING_PLATE) {   // object_balance_env.py:198-239; csrc/tg_spin.hip
+            if (!(cfg.spin_dish_mass > 0 && cfg.spin_buffer_height > 0 && cfg.spin_hull_margin >= 0 && cfg.spin_mu >= 0 && cfg.contact_erp > 0))
+                return fail(-1, "object_balance spinning_plate: spin_dish_mass, spin_buffer_height, contact_erp must be positive");
+            if (cfg.spin_n_dish <= 0 || cfg.spin_n_dish > 1152 || cfg.spin_n_spool <= 0 || cfg.spin_n_spool > 256 || !cfg.spin_dish_hull || !cfg.spin_spool_hull)
+                return fail(-1, "object_balance spinning_plate: the hulls are missing or too large (dish <= 1152, spool <= 256 vertices)");
+            SpinConst<T>& sp = c.spin;
+            sp.mass = (T)cfg.spin_dish_mass;
+            sp.com = {(T)cfg.spin_dish_com[0], (T)cfg.spin_dish_com[1], (T)cfg.spin_dish_com[2]};
+            sp.inertia = {(T)cfg.spin_dish_inertia[0], (T)cfg.spin_dish_inertia[1], (T)cfg.spin_dish_inertia[2], (T)cfg.spin_dish_inertia[4],
+                          (T)cfg.spin_dish_inertia[5], (T)cfg.spin_dish_inertia[8]};
+            sp.margin = (T)cfg.spin_hull_margin; sp.breaking = (T)cfg.contact_breaking; sp.erp = (T)cfg.contact_erp; sp.mu = (T)cfg.spin_mu;
+            sp.lin_damp = (T)cfg.obj_lin_damp; sp.ang_damp = (T)cfg.obj_ang_damp;
+            sp.buffer_height = (T)cfg.spin_buffer_height; sp.embed0 = (T)cfg.embed_dist;
+            sp.n_dish = cfg.spin_n_dish; sp.n_spool = cfg.spin_n_spool;
+        }
         if (cfg.balance_object == TG_BALANCE_BALL_ON_PLATE) {
             if (!(cfg.ball_radius > 0 && cfg.ball_mass > 0 && cfg.ball_mu >= 0 && cfg.plate_radius > 0 && cfg.contact_erp > 0))
                 return fail(-1, "object_balance ball_on_plate: ball_radius, ball_mass, plate_radius, contact_erp must be positive");
@@ -314,6 +331,15 @@ template <typename T> static void launch_step_body_t(tg_ctx* c, const float* d_a
 }
 template <typename T> static void launch_reset_body_t(tg_ctx* c, const uint8_t* d_mask) {
     const int n = c->cfg.num_envs;
+    if (c->cfg.balance_object == TG_BALANCE_SPINNING_PLATE) {   // (the template is always there in this mode: tg_create)
+        if (c->tmpl_ready)
+            hipLaunchKernelGGL((k_reset_body<T, 0, false, true, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                               (const EnvConst<T>*)c->d_const, c->st, d_mask);
+        else
+            hipLaunchKernelGGL((k_reset_body<T, 0, false, false, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                               (const EnvConst<T>*)c->d_const, c->st, d_mask);
+        return;
+    }
     if (c->tmpl_ready) {   // a reset that covered env 0 has been enqueued before this one: the template is there when this launch runs
         if (c->cfg.balance_object == TG_BALANCE_BALL_ON_PLATE)
             hipLaunchKernelGGL((k_reset_body<T, 0, true, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
@@ -665,6 +691,11 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
     if (!sensor->nodef_dep || !sensor->nodef_gray || !sensor->border_mask) return fail(-1, "tg_create: sensor reference images missing");
     if (cfg->physics_dtype != TG_PHYSICS_F64 && cfg->physics_dtype != TG_PHYSICS_F32) return fail(-1, "tg_create: bad physics_dtype");
     if (cfg->narrowphase < 0 || cfg->narrowphase > TG_NARROW_GJK_SINGLE) return fail(-1, "tg_create: bad narrowphase");
+    if (cfg->env_kind == TG_ENV_OBJECT_BALANCE && cfg->balance_object == TG_BALANCE_SPINNING_PLATE) {
+        if (cfg->physics_dtype != TG_PHYSICS_F64) return fail(-1, "tg_create: object_balance spinning_plate is built for f64 physics");
+        if (!cfg->cone_friction) return fail(-1, "tg_create: object_balance spinning_plate is built with cone friction (enableConeFriction = 1)");
+        if (cfg->solver_residual_threshold > 0.0) return fail(-1, "tg_create: object_balance spinning_plate does not run in threshold mode (its reset takes the arm's template)");
+    }
     if (cfg->env_kind == TG_ENV_OBJECT_BALANCE && cfg->balance_object == TG_BALANCE_BALL_ON_PLATE) {
         if (cfg->contact_mapping == TG_CONTACT_MAP_WAVE) return fail(-1, "tg_create: object_balance ball_on_plate runs on the lane mapping (contact_mapping auto or lane)");
         if (!cfg->cone_friction) return fail(-1, "tg_create: object_balance ball_on_plate is built with cone friction (enableConeFriction = 1)");
@@ -775,7 +806,19 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
             bool tmpl = cfg->reset_bank != TG_BANK_OFF;
             if (const char* e = getenv("TG_RESET_BANK")) tmpl = e[0] != '0';
             if (cfg->solver_residual_threshold > 0.0) tmpl = false;   // threshold mode: the reset tick's truncated solve sees the fallen object (1e-6 rad): every reset is recomputed
+            if (cfg->balance_object == TG_BALANCE_SPINNING_PLATE) tmpl = true;   // (its literal reset moves the arm with the spool only: the template is that state)
             if (tmpl) { TG_HIP(hipMalloc(&s.reset_tmpl, (2 * TG_MAX_DOF + 2) * 8)); TG_HIP(hipMemset(s.reset_tmpl, 0, (2 * TG_MAX_DOF + 2) * 8)); }
+        }
+        if (cfg->balance_object == TG_BALANCE_SPINNING_PLATE) {
+            const size_t hw = (size_t)3 * (cfg->spin_n_dish + cfg->spin_n_spool);
+            double* dh = nullptr;
+            TG_HIP(hipMalloc(&dh, hw * 8));
+            TG_HIP(hipMemcpy(dh, cfg->spin_dish_hull, (size_t)3 * cfg->spin_n_dish * 8, hipMemcpyHostToDevice));
+            TG_HIP(hipMemcpy(dh + (size_t)3 * cfg->spin_n_dish, cfg->spin_spool_hull, (size_t)3 * cfg->spin_n_spool * 8, hipMemcpyHostToDevice));
+            s.spin_hulls = dh;
+            c->cfg.spin_dish_hull = nullptr; c->cfg.spin_spool_hull = nullptr;   // the host pointers are not kept
+            TG_HIP(hipMalloc(&s.dish, (size_t)20 * n * 8)); TG_HIP(hipMemset(s.dish, 0, (size_t)20 * n * 8));
+            TG_HIP(hipMalloc(&s.mani, (size_t)37 * n * 8)); TG_HIP(hipMemset(s.mani, 0, (size_t)37 * n * 8));
         }
         if (cfg->balance_object == TG_BALANCE_BALL_ON_PLATE) {   // load_ball (:241-260): at workframe + (0, 0, radius), at rest
             TG_HIP(hipMalloc(&s.ball, (size_t)13 * n * 8));
@@ -798,6 +841,17 @@ static int create_impl(const tg_config* cfg, const tg_robot* robot, const tg_sen
         for (int i = 0; i < n; ++i) {
             for (int a = 0; a < 3; ++a) bp[(size_t)a * n + i] = p0[a];
             for (int a = 0; a < 9; ++a) br[(size_t)a * n + i] = oR[a];
+        }
+        if (cfg->balance_object == TG_BALANCE_SPINNING_PLATE) {   // the dish where the pole would be, on top of the spool (:215-219); the spool at init_buffer_pos (:228-233)
+            std::vector<double> ds((size_t)20 * n, 0.0);
+            for (int i = 0; i < n; ++i) {
+                for (int a = 0; a < 3; ++a) ds[(size_t)a * n + i] = p0[a] + (a == 2 ? cfg->spin_buffer_height : 0.0);
+                for (int a = 0; a < 9; ++a) ds[(size_t)(3 + a) * n + i] = oR[a];
+                bp[(size_t)0 * n + i] = cfg->workframe_pos[0]; bp[(size_t)1 * n + i] = cfg->workframe_pos[1];
+                bp[(size_t)2 * n + i] = cfg->workframe_pos[2] + cfg->spin_buffer_height / 2;
+                for (int a = 0; a < 9; ++a) br[(size_t)a * n + i] = (a % 4 == 0) ? 1.0 : 0.0;
+            }
+            TG_HIP(hipMemcpy(s.dish, ds.data(), ds.size() * 8, hipMemcpyHostToDevice));
         }
         TG_HIP(hipMemcpy(s.body_pos, bp.data(), bp.size() * 8, hipMemcpyHostToDevice));
         TG_HIP(hipMemcpy(s.body_rot, br.data(), br.size() * 8, hipMemcpyHostToDevice));
@@ -1026,7 +1080,7 @@ int tg_destroy(tg_ctx* c) {
     if (c->d_kt_acc) (void)hipFree(c->d_kt_acc);
     State& s = c->st;
     void* ptrs[] = {c->d_robot, c->d_const, s.q, s.qd, s.qd_target, s.tcp_pos, s.tcp_rpy, s.edge_ang, s.embed, s.stim_xform, s.term_xform,
-                    s.step_count, s.reset_ticks, s.licence, s.sweeps, s.tmpl_stats, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.hsel, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
+                    s.step_count, s.reset_ticks, s.licence, s.sweeps, s.tmpl_stats, s.trig_sc, s.edge_sc, s.rng, s.dir, s.goal, s.heights, s.hsel, s.accum, s.surf_zoff, s.noise_seed, s.body_pos, s.body_rot, s.body_v, s.body_w, s.ext_pos, s.gravity, s.ext_pending, s.ball, s.dish, const_cast<double*>(s.spin_hulls), s.reset_tmpl, s.traj, s.obj_mass, s.goal_id, s.contact_code, s.term_feature, s.mani, const_cast<void*>(s.tip_verts), c->d_nodef_dep, c->d_nodef_gray, c->d_border, c->d_verts, c->d_soup, c->d_tris,
                     c->d_obs, c->d_term, c->d_mask, c->d_actions, c->d_scene_verts, c->d_scene_xf, c->d_scene_spheres, c->d_scene_tris, c->d_scene_attr, c->d_scene_local, c->d_scene_static, c->d_scene_chunks, c->d_vis, c->d_vis_term, c->d_oracle, c->d_oracle_term, c->d_int_idx, c->d_int_rank, c->d_tile_tmpl, c->d_episode, c->d_block_tables};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -1098,7 +1152,10 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
             // the step and the reset (they show the pre-reset state)
             const int inline_reset = (c->cfg.auto_reset && c->st.reset_tmpl != nullptr && c->tmpl_ready && c->cfg.balance_object == TG_BALANCE_POLE &&
                                       !c->scene_every_step && !c->oracle_every_step && getenv("TG_NO_INLINE_RESET") == nullptr) ? 1 : 0;
-            if (use_contact_wave(c) && launch_step_body_wave(c->cfg.physics_dtype, c->robot.topology, c->cfg.control_mode, c->cfg.num_envs, c->stream, c->d_robot,
+            if (c->cfg.balance_object == TG_BALANCE_SPINNING_PLATE) {
+                (void)launch_step_spin(c->cfg.physics_dtype, c->robot.topology, c->cfg.control_mode, c->cfg.num_envs, c->cfg.spin_n_dish, c->stream, c->d_robot,
+                                       c->d_const, c->st, d_act);   // one wavefront per env (tg_spin.hip); tg_create has checked the combination
+            } else if (use_contact_wave(c) && launch_step_body_wave(c->cfg.physics_dtype, c->robot.topology, c->cfg.control_mode, c->cfg.num_envs, c->stream, c->d_robot,
                                                              c->d_const, c->st, d_act, inline_reset) == 0) {
                 reset_inlined = inline_reset != 0;
                 // one wavefront per env: the env's own licence, full ticks on the wave mapping (tg_contact_wave.hip)

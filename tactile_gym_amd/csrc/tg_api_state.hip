@@ -220,6 +220,7 @@ int tg_get_state(tg_ctx* c, const tg_state_view* v) {
         if (v->body_linvel && (rc = fetch_soa(c, c->st.body_v, 3, v->body_linvel))) return rc;
         if (v->body_angvel && (rc = fetch_soa(c, c->st.body_w, 3, v->body_angvel))) return rc;
         if (v->gravity_z && (rc = fetch_soa(c, c->st.gravity, 1, v->gravity_z))) return rc;
+        if (c->st.dish && v->dish_state && (rc = fetch_soa(c, c->st.dish, 20, v->dish_state))) return rc;
         if (c->st.ball) {
             if (v->ball_pos && (rc = fetch_soa(c, c->st.ball, 3, v->ball_pos))) return rc;
             if (v->ball_linvel && (rc = fetch_soa(c, c->st.ball + (size_t)3 * c->cfg.num_envs, 3, v->ball_linvel))) return rc;

@@ -20,6 +20,7 @@
 #include "../../include/tactile_gym_hip.h"
 #include "tg_kernels.hpp"
 #include "tg_contact_wave.h"
+#include "tg_spin.h"
 #include "tg_fused.h"
 #include "tg_scene.h"
 #include "tg_noise.h"

@@ -36,6 +36,7 @@ template <typename T> struct EnvConst {
     // object_balance
     BodyConst<T> body;
     BallConst<T> ball;           // object_balance, object_mode ball_on_plate
+    SpinConst<T> spin;           // object_balance, object_mode spinning_plate (spin.n_dish > 0): `body` is the spool, the dish is the env's object
     M3<T> obj_init_rot;
     T obj_init_rpy_deg[3], obj_base_width, obj_base_height, term_deg, term_pos, ext_force[3];
     int rand_gravity, rand_embed;
@@ -76,6 +77,9 @@ struct State {   // device pointers, SoA [field][num_envs]
     unsigned long long* tmpl_stats; // [2] object_push: resets that took the reset template / that ran their blocking move (k_reset_contact_wave); null otherwise
     double* reset_tmpl;             // [2 N + 2] object_balance: the arm's state after Robot.reset (q, qd, ticks used, valid flag) - see k_reset_body
     double* ball;                   // [13][n] ball_on_plate: position, linear velocity, angular velocity, one-shot torque, last normal impulse
+    double* dish;                   // [20][n] spinning_plate: the dish's base position (0-2), orientation (3-11, row major), linear (12-14) and angular (15-17)
+                                    // velocity, the last tick's summed normal impulse (18) and number of contact points (19); null otherwise
+    const double* spin_hulls;       // spinning_plate: [n_dish][3] the dish's hull in its base frame, then [n_spool][3] the spool's
     // object_push
     double *traj, *obj_mass;        // [3][TG_MAX_TRAJ_POINTS][n] work-frame x, y, yaw; [n]
     int32_t* goal_id;               // [n]
@@ -400,14 +404,19 @@ __global__ __launch_bounds__(64) void k_oracle_obs(const DevRobot<T>* __restrict
         return;
     }
     // the free body (get_obj_pos_workframe / get_obj_vel_workframe, base_object_env.py:118-139)
+    // (spinning_plate: the env's object is the dish - State::dish -, body_* is the spool on the constraint)
+    const bool dish = st.dish != nullptr;
     M3<T> Rb;
 #pragma unroll
-    for (int e = 0; e < 9; ++e) Rb.m[e] = (T)st.body_rot[e * n + env];
-    const V3<T> pb = mk((T)st.body_pos[0 * n + env], (T)st.body_pos[1 * n + env], (T)st.body_pos[2 * n + env] - work_dz);
+    for (int e = 0; e < 9; ++e) Rb.m[e] = dish ? (T)st.dish[(3 + e) * n + env] : (T)st.body_rot[e * n + env];
+    const V3<T> pb = dish ? mk((T)st.dish[0 * n + env], (T)st.dish[1 * n + env], (T)st.dish[2 * n + env] - work_dz)
+                          : mk((T)st.body_pos[0 * n + env], (T)st.body_pos[1 * n + env], (T)st.body_pos[2 * n + env] - work_dz);
     V3<T> op; T orpy[3], orpyw[3];
     world_to_work(c, pb, Rb, op, orpy, orpyw);
-    const V3<T> ol = mul(c.work_Rinv, mk((T)st.body_v[0 * n + env], (T)st.body_v[1 * n + env], (T)st.body_v[2 * n + env]));
-    const V3<T> oa = mul(c.work_Rinv, mk((T)st.body_w[0 * n + env], (T)st.body_w[1 * n + env], (T)st.body_w[2 * n + env]));
+    const V3<T> ol = mul(c.work_Rinv, dish ? mk((T)st.dish[12 * n + env], (T)st.dish[13 * n + env], (T)st.dish[14 * n + env])
+                                           : mk((T)st.body_v[0 * n + env], (T)st.body_v[1 * n + env], (T)st.body_v[2 * n + env]));
+    const V3<T> oa = mul(c.work_Rinv, dish ? mk((T)st.dish[15 * n + env], (T)st.dish[16 * n + env], (T)st.dish[17 * n + env])
+                                           : mk((T)st.body_w[0 * n + env], (T)st.body_w[1 * n + env], (T)st.body_w[2 * n + env]));
     if (c.env_kind == TG_ENV_OBJECT_PUSH) {
         put3(op); put3(mk(orpy[0], orpy[1], orpy[2])); put3(ol); put3(oa);
         const int gid = st.goal_id[env], gi = gid < c.traj_n ? gid : c.traj_n - 1;
@@ -1248,13 +1257,36 @@ template <typename T> __device__ __forceinline__ T wrap_deg(T d) {   // ((d + 18
     return (x - T(360) * floor(x / T(360))) - T(180);
 }
 
+// spinning_plate: init_obj_pos - setup_object puts the dish on the spool (:215-219), reset_task's version for rand_embed_dist leaves the
+// buffer height out (:317-321), as upstream does
+template <typename T> __device__ __forceinline__ V3<T> spin_init_obj_pos(const EnvConst<T>& c, T embed) {
+    return mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.rand_embed ? T(0) : c.spin.buffer_height) + (c.obj_base_height / T(2)) - embed);
+}
+template <typename T> __device__ __forceinline__ FreeBody<T> load_dish(const State& st, int n, int env) {
+    FreeBody<T> d;
+    d.pos = mk((T)st.dish[0 * n + env], (T)st.dish[1 * n + env], (T)st.dish[2 * n + env]);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) d.R.m[e] = (T)st.dish[(3 + e) * n + env];
+    d.v = mk((T)st.dish[12 * n + env], (T)st.dish[13 * n + env], (T)st.dish[14 * n + env]);
+    d.w = mk((T)st.dish[15 * n + env], (T)st.dish[16 * n + env], (T)st.dish[17 * n + env]);
+    return d;
+}
+template <typename T> __device__ __forceinline__ void store_dish(const State& st, int n, int env, const FreeBody<T>& d, T impulse, int contacts) {
+    st.dish[0 * n + env] = (double)d.pos.x; st.dish[1 * n + env] = (double)d.pos.y; st.dish[2 * n + env] = (double)d.pos.z;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) st.dish[(3 + e) * n + env] = (double)d.R.m[e];
+    st.dish[12 * n + env] = (double)d.v.x; st.dish[13 * n + env] = (double)d.v.y; st.dish[14 * n + env] = (double)d.v.z;
+    st.dish[15 * n + env] = (double)d.w.x; st.dish[16 * n + env] = (double)d.w.y; st.dish[17 * n + env] = (double)d.w.z;
+    st.dish[18 * n + env] = (double)impulse; st.dish[19 * n + env] = (double)contacts;
+}
 // get_step_data / check_obj_fall / termination (object_balance_env.py:426-497) + camera<-object transform
 // (the frames of the TCP and of the sensor link at the env's q are the caller's: finish_body below takes them from its own forward kinematics,
 //  k_step_body_wave from the lane of its licensed walk that already stands at the step's last q)
 //  Returns the env's `done` (false without write_reward_done).
 template <typename T, int TOPO>
 __device__ __forceinline__ bool finish_body_frames(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const V3<T>& ptcp, const M3<T>& Rtcp,
-                                                   const V3<T>& pb, const M3<T>& Rb, const FreeBody<T>& b, T embed, int step_count, bool write_reward_done) {
+                                                   const V3<T>& pb, const M3<T>& Rb, const FreeBody<T>& b, T embed, int step_count, bool write_reward_done,
+                                                   const FreeBody<T>* obj = nullptr /* spinning_plate: the env's object (the dish); b = what stands on the sensor */) {
     const int n = c.num_envs;
     bool env_done = false;
     T rpy[3];
@@ -1262,12 +1294,13 @@ __device__ __forceinline__ bool finish_body_frames(const DevRobot<T>& m, const E
     st.tcp_pos[0 * n + env] = (double)ptcp.x; st.tcp_pos[1 * n + env] = (double)ptcp.y; st.tcp_pos[2 * n + env] = (double)ptcp.z;
     st.tcp_rpy[0 * n + env] = (double)rpy[0]; st.tcp_rpy[1 * n + env] = (double)rpy[1]; st.tcp_rpy[2 * n + env] = (double)rpy[2];
     if (write_reward_done) {
+        const FreeBody<T>& o = obj != nullptr ? *obj : b;
         T orpy[3];
-        { Q4<T> qq = quat_from_mat(b.R); euler_from_quat(qq, orpy[0], orpy[1], orpy[2]); }
+        { Q4<T> qq = quat_from_mat(o.R); euler_from_quat(qq, orpy[0], orpy[1], orpy[2]); }
         const T r2d = T(180) / T(3.141592653589793);
         const T d0 = tabs(wrap_deg(orpy[0] * r2d - c.obj_init_rpy_deg[0])), d1 = tabs(wrap_deg(orpy[1] * r2d - c.obj_init_rpy_deg[1]));
-        const V3<T> init = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - embed);
-        const bool fell = d0 > c.term_deg || d1 > c.term_deg || norm(b.pos - init) > c.term_pos;
+        const V3<T> init = obj != nullptr ? spin_init_obj_pos<T>(c, embed) : mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - embed);
+        const bool fell = d0 > c.term_deg || d1 > c.term_deg || norm(o.pos - init) > c.term_pos;
         const bool done = fell || step_count >= c.max_steps;
         const T reward = (c.reward_mode == TG_REWARD_SPARSE) ? (fell ? T(-1) : T(0)) : T(1);
         st.reward[env] = (float)reward;
@@ -1412,7 +1445,9 @@ __global__ __launch_bounds__(64) void k_step_body(const DevRobot<T>* __restrict_
 // BaseObjectEnv.reset (base_object_env.py:146-173) for object_balance: reset_task (gravity, embed), Robot.reset with the pole
 // still tied to the TCP, reset_object (teleport + one-shot random force).
 // (the reset of ONE env; k_reset_body below is its lane-per-env launch, k_step_body_wave calls the FAST form in its epilogue)
-template <typename T, int TOPO, bool BALL = false, bool FAST = false /* the template is known to be valid: no inverse kinematics / blocking move in the binary */>
+template <typename T, int TOPO, bool BALL = false, bool FAST = false /* the template is known to be valid: no inverse kinematics / blocking move in the binary */,
+          bool SPIN = false /* spinning_plate: `b` is the spool (the arm moves back with it on the constraint; the dish lies where it fell and is not part
+                               of that move - the position motors prescribe the arm's velocity whatever hangs on it, see below) */>
 __device__ __forceinline__ void reset_body_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env,
                                                const LinkFrames<T>* tmpl_frames = nullptr /* FAST: the frames at the template's q, if the caller has them */) {
     constexpr int N = Topo<TOPO>::N;
@@ -1425,7 +1460,7 @@ __device__ __forceinline__ void reset_body_env(const DevRobot<T>& m, const EnvCo
     st.embed[env] = embed;
     st.step_count[env] = 0;
     const V3<T> grav = mk(T(0), T(0), (T)gz);
-    const V3<T> pivot_b = mk(T(0), T(0), -c.obj_base_height / T(2) + (T)embed);
+    const V3<T> pivot_b = SPIN ? mk(T(0), T(0), -c.spin.buffer_height / T(2) + c.spin.embed0) : mk(T(0), T(0), -c.obj_base_height / T(2) + (T)embed);
     FreeBody<T> b = load_body<T>(st, n, env);
     T q[N], qd[N];
 #pragma unroll
@@ -1507,6 +1542,39 @@ __device__ __forceinline__ void reset_body_env(const DevRobot<T>& m, const EnvCo
     }
     st.reset_ticks[env] = used;
     st.licence[env] = 0;   // a new configuration: the next step verifies its solve again (k_step_body_wave)
+    if constexpr (SPIN) {
+        // reset_object (:330-358): the dish back on init_obj_pos, the spool on init_buffer_pos (:228-233, reset_plate_buffer), a new manifold, the
+        // one-tick torque (apply_random_torque_obj: no draw) and force (apply_random_force_base: four draws, about the DISH's init position)
+        FreeBody<T> d;
+        d.pos = spin_init_obj_pos<T>(c, (T)embed);
+        d.R = c.obj_init_rot;
+        d.v = z3; d.w = z3;
+        b.pos = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + c.spin.buffer_height / T(2));
+#pragma unroll
+        for (int e = 0; e < 9; ++e) b.R.m[e] = (e % 4 == 0) ? T(1) : T(0);
+        b.v = z3; b.w = z3;
+        st.mani[(size_t)36 * n + env] = 0.0;
+        const double sx = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
+        const double rx = rng_uniform(rs, 0.0, 1.0);
+        const double sy = rng_uniform(rs, 0.0, 1.0) < 0.5 ? -1.0 : 1.0;
+        const double ry = rng_uniform(rs, 0.0, 1.0);
+        st.rng[env] = rs;
+        st.ext_pos[0 * n + env] = (double)d.pos.x + sx * rx * (double)c.obj_base_width / 2.0;
+        st.ext_pos[1 * n + env] = (double)d.pos.y + sy * ry * (double)c.obj_base_width / 2.0;
+        st.ext_pos[2 * n + env] = (double)d.pos.z;
+        st.ext_pending[env] = 1;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { st.q[i * n + env] = (double)q[i]; st.qd[i * n + env] = (double)qd[i]; st.qd_target[i * n + env] = 0.0; }
+        store_body<T>(st, n, env, b);
+        store_dish<T>(st, n, env, d, T(0), 0);
+        Kin<T, TOPO> k;
+        forward_kinematics<T, TOPO>(m, q, k);
+        V3<T> ptcp, pbs; M3<T> Rtcp, Rbs;
+        link_frame<T, TOPO>(k, m.tcp_link, m.tcp_pos, m.tcp_rot, ptcp, Rtcp);
+        link_frame<T, TOPO>(k, m.sensor_link, m.sensor_pos, m.sensor_rot, pbs, Rbs);
+        (void)finish_body_frames<T, TOPO>(m, c, st, env, ptcp, Rtcp, pbs, Rbs, b, (T)embed, 0, false, &d);
+        return;
+    }
     // reset_object (object_balance_env.py:330-381): teleport, then a one-shot downward force at a random point of the base plate
     b.pos = mk(c.work_pos[0], c.work_pos[1], c.work_pos[2] + (c.obj_base_height / T(2)) - (T)embed);
     b.R = c.obj_init_rot;
@@ -1543,7 +1611,7 @@ __device__ __forceinline__ void reset_body_env(const DevRobot<T>& m, const EnvCo
     else
         finish_body<T, TOPO>(m, c, st, env, q, b, (T)embed, 0, false);
 }
-template <typename T, int TOPO, bool BALL = false, bool FAST = false>
+template <typename T, int TOPO, bool BALL = false, bool FAST = false, bool SPIN = false>
 __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
                                                    const uint8_t* __restrict__ mask) {
     // (no KtScope here: with it the ball_on_plate instantiation - 134 spilled VGPRs, > 1000 spilled SGPRs - came out of hipcc 7.2 producing NaNs in
@@ -1554,7 +1622,7 @@ __global__ __launch_bounds__(64) void k_reset_body(const DevRobot<T>* __restrict
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= cp->num_envs) return;
     if (mask != nullptr && mask[env] == 0) return;
-    reset_body_env<T, TOPO, BALL, FAST>(*mp, *cp, st, env);
+    reset_body_env<T, TOPO, BALL, FAST, SPIN>(*mp, *cp, st, env);
 }
 
 // ------------------------------------------------------------------------------------------------ object_push kernels

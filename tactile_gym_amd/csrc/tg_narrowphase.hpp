@@ -69,6 +69,40 @@ __device__ __forceinline__ void support(const Hull& H, const double* e, const do
     for (int x = 0; x < 3; ++x) out.w[x] = out.a[x] - (d[x] > 0.0 ? -e[x] : e[x]);
 }
 
+// Shape B as a second convex hull (round 6: object_balance's spinning_plate - the dish against the spool, oracle/narrowphase.c:
+// mb_gjk_epa_hull_hull): its vertices in B's own frame, lane-spread like Hull's; its support point along -d is the vertex with the largest
+// -d . b (ties: the lowest index).  gjk / epa / gjk_epa below take the box's half extents (const double*) or a const HullB*.
+constexpr int kSlotsB = 4;                                    // n <= 256 (the spool's hull has 133 vertices)
+struct HullB { double x[kSlotsB], y[kSlotsB], z[kSlotsB]; int n; };
+__device__ __forceinline__ void support(const Hull& H, const HullB* B, const double* d, SV& out, int lane) {
+#pragma clang fp contract(off)
+    double bk = -1.0e300, bx = 0.0, by = 0.0, bz = 0.0, ck = -1.0e300, cx = 0.0, cy = 0.0, cz = 0.0;
+    int bi = 0x7fffffff, ci = 0x7fffffff;
+    const double nd[3] = {-d[0], -d[1], -d[2]};
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) {
+        const int i = 64 * k + lane;
+        const double key = (H.x[k] * d[0] + H.y[k] * d[1]) + H.z[k] * d[2];
+        if (i < H.n && key > bk) { bk = key; bi = i; bx = H.x[k]; by = H.y[k]; bz = H.z[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < kSlotsB; ++k) {
+        const int i = 64 * k + lane;
+        const double key = (B->x[k] * nd[0] + B->y[k] * nd[1]) + B->z[k] * nd[2];
+        if (i < B->n && key > ck) { ck = key; ci = i; cx = B->x[k]; cy = B->y[k]; cz = B->z[k]; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ok = __shfl_xor(bk, off), pk = __shfl_xor(ck, off);
+        const int oi = __shfl_xor(bi, off), pi = __shfl_xor(ci, off);
+        if (ok > bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; }
+        if (pk > ck || (pk == ck && pi < ci)) { ck = pk; ci = pi; }
+    }
+    const int sa = __builtin_amdgcn_readfirstlane(bi) & 63, sb = __builtin_amdgcn_readfirstlane(ci) & 63;
+    out.a[0] = rdlane(bx, sa); out.a[1] = rdlane(by, sa); out.a[2] = rdlane(bz, sa);
+    out.w[0] = out.a[0] - rdlane(cx, sb); out.w[1] = out.a[1] - rdlane(cy, sb); out.w[2] = out.a[2] - rdlane(cz, sb);
+}
+
 // ---- closest point of a simplex to the origin as barycentric weights (Ericson, Real-Time Collision Detection 5.1)
 __device__ __forceinline__ void closest_segment(const double* a, const double* b, double* lam) {
 #pragma clang fp contract(off)
@@ -127,7 +161,7 @@ __device__ __forceinline__ bool closest_tetra(const SV* S, double* lam) {
 
 // GJK: 0 separated (dist, n from the box to the hull, witnesses pa on the hull / pb on the box), 1 overlapping (S = a tetrahedron around the
 // origin), 2 touching cores (no depth)
-__device__ __forceinline__ int gjk(const Hull& H, const double* e, SV* S, double& dist, double* nrm, double* pa, double* pb, int lane) {
+template <class BT> __device__ __forceinline__ int gjk(const Hull& H, BT e, SV* S, double& dist, double* nrm, double* pa, double* pb, int lane) {
 #pragma clang fp contract(off)
     const double d0[3] = {1.0, 0.0, 0.0};
     int ns = 1;
@@ -202,7 +236,7 @@ __device__ __forceinline__ bool make_face(lptr<double> sc, int i0, int i1, int i
     __syncthreads();
     return true;
 }
-__device__ __forceinline__ bool epa(const Hull& H, const double* e, const SV* S, lptr<double> sc, double& depth, double* nrm, double* pa, double* pb, int lane) {
+template <class BT> __device__ __forceinline__ bool epa(const Hull& H, BT e, const SV* S, lptr<double> sc, double& depth, double* nrm, double* pa, double* pb, int lane) {
 #pragma clang fp contract(off)
     lptr<int> fv = (lptr<int>)(sc + kOffFV);
     lptr<int> ed = (lptr<int>)(sc + kOffE);
@@ -277,7 +311,7 @@ __device__ __forceinline__ bool epa(const Hull& H, const double* e, const SV* S,
 }
 
 // signed core distance (< 0: overlap depth), normal from the box towards the hull, witnesses; false: touching cores (no contact normal)
-__device__ __forceinline__ bool gjk_epa_hull_box(const Hull& H, const double* e, lptr<double> sc, double& sdist, double* nrm, double* pa, double* pb, int lane) {
+template <class BT> __device__ __forceinline__ bool gjk_epa(const Hull& H, BT e, lptr<double> sc, double& sdist, double* nrm, double* pa, double* pb, int lane) {
     SV S[4]; double dist = 0.0;
     const int r = gjk(H, e, S, dist, nrm, pa, pb, lane);
     if (r == 0) { sdist = dist; return true; }
@@ -286,6 +320,13 @@ __device__ __forceinline__ bool gjk_epa_hull_box(const Hull& H, const double* e,
     if (!epa(H, e, S, sc, depth, nrm, pa, pb, lane)) return false;
     sdist = -depth;
     return true;
+}
+__device__ __forceinline__ bool gjk_epa_hull_box(const Hull& H, const double* e, lptr<double> sc, double& sdist, double* nrm, double* pa, double* pb, int lane) {
+    return gjk_epa<const double*>(H, e, sc, sdist, nrm, pa, pb, lane);
+}
+// the same for two hulls: H = body A's hull in body B's frame, B = body B's hull in its own frame; results in B's frame
+__device__ __forceinline__ bool gjk_epa_hull_hull(const Hull& H, const HullB& B, lptr<double> sc, double& sdist, double* nrm, double* pa, double* pb, int lane) {
+    return gjk_epa<const HullB*>(H, &B, sc, sdist, nrm, pa, pb, lane);
 }
 
 // ---- persistent manifold in LDS (`mf`: kManiWords doubles; body A = the tip link (oa, Ra), body B = the cube (ob, Rb); R row-major)

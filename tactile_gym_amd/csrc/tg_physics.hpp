@@ -1109,6 +1109,14 @@ __device__ __forceinline__ void sim_tick_body(const DevRobot<T>& m, T (&q)[Topo<
 template <typename T> __device__ __forceinline__ void plane_space(V3<T> n, V3<T>& t1, V3<T>& t2);   // btPlaneSpace1, below
 template <typename T> struct Ball { V3<T> pos, v, w; };
 template <typename T> struct BallConst { T radius, mass, inertia, mu, plate_radius, plate_half_len, breaking, erp, lin_damp, ang_damp; };
+// object_balance, object_mode "spinning_plate" (object_balance_env.py:198-239): BodyConst describes the spool (the body on the constraint), this the
+// dish standing on it and their contact (oracle/minibullet.h: mb_spin; tick: csrc/tg_spin.hip)
+template <typename T> struct SpinConst {
+    T mass; V3<T> com; S3<T> inertia;                    // the dish
+    T margin, breaking, erp, mu, lin_damp, ang_damp;     // hull margin (both), contactBreakingThreshold, contact ERP, friction dish x spool, the spool's damping
+    T buffer_height, embed0;                             // :202-203; the embed distance the spool's pivot was made with (:267-269: never updated)
+    int n_dish, n_spool;                                 // hull vertex counts (State::spin_hulls); n_dish > 0 <=> this mode
+};
 
 template <typename T, int TOPO, int MOTOR>
 __device__ __forceinline__ void sim_tick_body_ball(const DevRobot<T>& m, T (&q)[Topo<TOPO>::N], T (&qd)[Topo<TOPO>::N],

@@ -1,9 +1,11 @@
-"""object_balance-v0 (object_mode "pole" and "ball_on_plate") on the HIP path.
+"""object_balance-v0 (object_mode "pole", "ball_on_plate" and "spinning_plate") on the HIP path.
 
 Reference: tactile_gym/rl_envs/nonprehensile_manipulation/object_balance/object_balance_env.py on top of
 base_object_env.py: a UR5 + TacTip pointing up carries a pole tied to its TCP by a point-to-point constraint; the agent
 moves the TCP to keep the pole upright.  "ball_on_plate" (:187-199, 241-260): the round plate instead of the pole and a ball
-rolling on it (one ball - plate contact, sim_tick_body_ball).  "spinning_plate" (:200-213) is not built.
+rolling on it (one ball - plate contact, sim_tick_body_ball).  "spinning_plate" (:107-108, 198-239, 267-269, 355-358): the spool
+(plate_buffer.urdf) on the constraint and the dish (the env's object) on its spindle - two convex hulls through the wave-mapped GJK / EPA and
+a persistent manifold (csrc/tg_spin.hip).
 """
 import math
 import os
@@ -35,10 +37,10 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
             raise KeyError(k)                                                                   # object_balance_env.py:37-44
     arm, t_s_name, t_s_type = modes["arm_type"], modes["tactile_sensor_name"], "standard"       # :46
     if modes["object_mode"] not in capi.BALANCE_OBJECT:
-        if modes["object_mode"] == "spinning_plate":
-            raise NotImplementedError("object_mode spinning_plate (a plate spinning on the tip under a constant torque) is not built yet")
         raise ValueError(f"unknown object_mode {modes['object_mode']}")
-    ball_mode = modes["object_mode"] == "ball_on_plate"
+    ball_mode, spin_mode = modes["object_mode"] == "ball_on_plate", modes["object_mode"] == "spinning_plate"
+    if spin_mode and (physics_dtype != "f64" or inertia_mode != "collision_aabb"):
+        raise NotImplementedError("object_mode spinning_plate is built for f64 physics and collision-shape inertias")
     if modes["movement_mode"] not in capi.BMOVE:
         raise ValueError(f"unknown movement_mode {modes['movement_mode']}")
     if modes["control_mode"] not in capi.CONTROL:
@@ -77,16 +79,35 @@ def build_config(num_envs, max_steps, image_size, env_modes, physics_dtype="f64"
     cfg.rand_gravity, cfg.rand_embed = int(bool(modes["rand_gravity"])), int(bool(modes["rand_embed_dist"]))
     cfg.gravity_lo, cfg.gravity_hi, cfg.gravity_default = -1.0, -0.1, -0.1                      # :301-306
     suffix = "" if inertia_mode == "collision_aabb" else "_urdfinertia"
-    z = np.load(os.path.join(ASSETS, "objects", f"{'round_plate' if ball_mode else 'pole'}{suffix}.npz"))
+    name = "plate_buffer" if spin_mode else f"{'round_plate' if ball_mode else 'pole'}{suffix}"    # spinning_plate: the body on the constraint is the spool
+    z = np.load(os.path.join(ASSETS, "objects", f"{name}.npz"))
     cfg.obj_mass = float(z["mass"])
     for k in range(3):
         cfg.obj_com[k] = float(z["com"][k])
         cfg.obj_root_inertial_pos[k] = float(z["root_inertial_pos"][k])
         cfg.obj_init_rpy[k] = [0.0, 0.0, -math.pi / 2][k]                                       # :190
-        cfg.ext_force[k] = [0.0, 0.0, -0.1][k]                                                  # :347 force_mag 0.1, direction (0,0,-1) :374-375
+        cfg.ext_force[k] = [0.0, 0.0, -1.0 if spin_mode else -0.1][k]                           # :347 / :358 force_mag 0.1 / 1.0, direction (0,0,-1) :374-375
     for k in range(9):
         cfg.obj_inertia[k] = float(z["inertia"].reshape(9)[k])
     cfg.obj_base_width, cfg.obj_base_height = (0.2 if ball_mode else 0.1), 0.0025               # :158-159, :188-189
+    if spin_mode:                                                                               # :198-213, load_plate_buffer :223-239
+        cfg.obj_base_width, cfg.obj_base_height, cfg.spin_buffer_height = 0.15, 0.0267, 0.026
+        zd = np.load(os.path.join(ASSETS, "objects", "spinning_plate.npz"))
+        cfg.spin_dish_mass = float(zd["mass"])
+        for k in range(3):
+            cfg.spin_dish_com[k] = float(zd["com"][k])
+        for k in range(9):
+            cfg.spin_dish_inertia[k] = float(zd["inertia"].reshape(9)[k])
+        cfg.spin_hull_margin, cfg.spin_mu = 1e-3, 0.5 * 0.5                                     # URDF hull margin; default lateral frictions [A26, A41]
+        dish_hull = np.ascontiguousarray(zd["hull"], dtype=np.float64)
+        spool_hull = np.ascontiguousarray(z["hull"], dtype=np.float64)
+        cfg.spin_n_dish, cfg.spin_n_spool = len(dish_hull), len(spool_hull)
+        cfg.spin_dish_hull = dish_hull.ctypes.data_as(capi.C.POINTER(capi.C.c_double))
+        cfg.spin_spool_hull = spool_hull.ctypes.data_as(capi.C.POINTER(capi.C.c_double))
+        cfg._spin_keep = (dish_hull, spool_hull)                                                # (tg_create copies them)
+        cfg.contact_breaking, cfg.contact_erp = 1e-4, 0.2                                       # base_tactile_env.py:128-130; [A24]
+        cfg.obj_lin_damp, cfg.obj_ang_damp = 0.04, 0.04                                         # the spool keeps Bullet's defaults (:338-345 clear the dish's only)
+        cfg.cone_friction = 1
     cfg.balance_object = capi.BALANCE_OBJECT[modes["object_mode"]]
     if ball_mode:                                                                               # load_ball :241-260
         zb = np.load(os.path.join(ASSETS, "objects", "balance_ball.npz"))
@@ -121,7 +142,7 @@ class ObjectBalanceVecEnv(TactileVecEnv):
         super().__init__(cfg, robot, sensor, mesh, observation_mode=modes["observation_mode"], obs_mode=obs_mode, seed=seed, copy_obs=copy_obs,
                          act_dim=act_dim, oracle_dim=26,
                          guard_spec={"arm_type": modes["arm_type"], "t_s_core": "no_core",       # object_balance_env.py:54
-                                     "obj": "round_plate" if modes["object_mode"] == "ball_on_plate" else "pole",
+                                     "obj": {"ball_on_plate": "round_plate", "pole": "pole"}.get(modes["object_mode"]),   # (spinning_plate: the arm and the table only)
                                      "ball_radius": cfg.ball_radius if modes["object_mode"] == "ball_on_plate" else None},
                          scene_spec={"arm_type": modes["arm_type"], "camera": ([-0.1, 0.0, 0.25], 1.0, 90.0, -10.0, 75.0, 0.1, 100.0)})   # :162-171
 
@@ -129,6 +150,9 @@ class ObjectBalanceVecEnv(TactileVecEnv):
         """object_balance_env.py:528-563: TCP pos, orn (quaternion), lin/ang velocity and the pole's pos, orn, lin/ang velocity, all in
         the work frame; float32 [N, 26]."""
         st = self.get_state()
+        if "dish_state" in st:                                    # spinning_plate: the env's object is the dish, body_* the spool
+            d = st["dish_state"]
+            st = dict(st, body_pos=d[:, 0:3], body_rot=d[:, 3:12].reshape(-1, 3, 3), body_linvel=d[:, 12:15], body_angvel=d[:, 15:18])
         tp, _, tq, tl, ta = self._tcp_workframe_state(st)
         op, _, oq, ol, oa = self._obj_workframe_state(st)
         return np.hstack([tp, tq, tl, ta, op, oq, ol, oa]).astype(np.float32)

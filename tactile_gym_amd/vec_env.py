@@ -695,6 +695,8 @@ class TactileVecEnv(_VecEnvBase):
                        gravity_z=np.zeros(n))
             if self._cfg.balance_object == capi.BALANCE_OBJECT["ball_on_plate"]:
                 out.update(ball_pos=np.zeros((n, 3)), ball_linvel=np.zeros((n, 3)), ball_angvel=np.zeros((n, 3)), ball_impulse=np.zeros(n))
+            if self._cfg.balance_object == capi.BALANCE_OBJECT["spinning_plate"]:   # the dish (tg_state_view.dish_state); body_* is the spool
+                out.update(dish_state=np.zeros((n, 20)))
         if self._cfg.env_kind == capi.ENV_OBJECT_PUSH:
             out.update(body_pos=np.zeros((n, 3)), body_rot=np.zeros((n, 3, 3)), body_linvel=np.zeros((n, 3)), body_angvel=np.zeros((n, 3)),
                        traj=np.zeros((n, 3, capi.MAX_TRAJ_POINTS)), goal_id=np.zeros(n, np.int32), obj_mass=np.zeros(n))

@@ -1782,9 +1782,7 @@ def test_object_balance_ball_on_plate_matches_oracle(size, movement):
     venv.close()
 
 
-def test_object_balance_ball_on_plate_refuses_wave_and_spinning_plate():
+def test_object_balance_ball_on_plate_refuses_wave():
     import tactile_gym_amd as tg
     with pytest.raises(ValueError):
         tg.make_vec("object_balance-v0", num_envs=2, max_steps=4, image_size=[64, 64], env_modes=BALL_MODES, seed=1, contact_mapping="wave")
-    with pytest.raises(NotImplementedError):
-        tg.make_vec("object_balance-v0", num_envs=2, max_steps=4, image_size=[64, 64], env_modes=dict(BAL_MODES, object_mode="spinning_plate"), seed=1)

@@ -10,8 +10,8 @@
 // Mapping: one wavefront per env.  The arm's dynamics and the bodies' 3 x 3 algebra are wave-uniform (every lane computes the env's values, as
 // k_step_body_wave does); the hulls are spread over the lanes (support queries = one arg-max over the wavefront); the solve is the Delassus /
 // residual form of the other body kernels with one ROW PER LANE: J, W = Minv_sys J^T and A = J W sit in LDS, lane j carries the residual
-// r_j = rhs_j - sum_q A_jq lambda_q, a row update is  t = r_i / A_ii  (r_i by v_readlane), clamp, and every lane's  r_j -= A_ji delta  (one LDS
-// read each, stride 21 words: conflict-free).  21 rows at most: 6 motors + 3 P2P + 4 x (normal + 2 friction).
+// r_j = rhs_j - sum_q A_jq lambda_q with its impulse, limit and 1 / A_jj; a row update is  t = r_i / A_ii  (row i's values by v_readlane), clamp,
+// and every lane's  r_j -= A_ji delta  (one LDS read each, stride 21 words: conflict-free).  21 rows at most: 6 motors + 3 P2P + 4 x (normal + 2 friction).
 #include <hip/hip_runtime.h>
 
 #include "tg_kernels.hpp"
@@ -283,15 +283,19 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
             rj = (r == 0) ? (depth > T(0) ? (-cv - depth / dt) : (-depth * sc.erp / dt - cv)) : -cv;      // restitution 0
         }
     }
-    // ---- projected Gauss-Seidel
+    // ---- projected Gauss-Seidel.  Lane j keeps its row's residual, impulse, limit and 1 / A_jj in registers; a row update reads row i's four
+    // values through v_readlane and column i of A from LDS (until round 6's last hour the impulses, limits and diagonal sat in LDS too: three
+    // dependent LDS round trips and a division per row, 6.6 ms per step at 1024 envs)
     const int n_it = iters < 0 ? -iters : iters;
-    const T jdj = lane < nr ? T(1) / L[Y::DIAG + lane] : T(0);
+    const T ajj = lane < nr ? L[Y::DIAG + lane] : T(1);
+    const T jdj = lane < nr ? T(1) / ajj : T(0);
+    const T limj = lane < NP ? L[Y::LIM + lane] : T(0);
+    T lamj = T(0);
     T thr = wave_max(lane < nr ? tabs(rj * jdj) : T(0));
     thr = iters < 0 ? T(-1) : thr * T(1.3877787807814457e-17);
     const bool thr_mode = m.res_thr > T(0);
     int ran = 0;
     const int arow = Y::A + (lane < NR ? lane : 0) * NR;                               // (lanes >= nr carry rows of zeros; lanes >= NR shadow row 0, unread)
-    auto update = [&](int i, T delta) { rj -= L[arow + i] * delta; };
     for (int it = 0; it < n_it; ++it) {
         if (!thr_mode && (it & 7) == 0 && it > 0) {
             const T mx = wave_max(lane < nr ? tabs(rj * jdj) : T(0));
@@ -300,45 +304,46 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
         T res = T(0);
         for (int jj = 0; jj < NP; ++jj) {               // motors and P2P rows: reversed on even sweeps
             const int i = (it & 1) ? jj : NP - 1 - jj;
-            const T lim = L[Y::LIM + i], lam = L[Y::LAM + i], aii = L[Y::DIAG + i];
-            const T t = narrow::rdlane(rj, i) / aii;
+            const T acol = L[arow + i];
+            const T lim = narrow::rdlane(limj, i), lam = narrow::rdlane(lamj, i);
+            const T t = narrow::rdlane(rj, i) * narrow::rdlane(jdj, i);
             const T sum = lam + t;
             const T lo_ = sum < -lim ? -lim : sum;
             const T sc_ = lo_ > lim ? lim : lo_;
             const T delta = (sc_ == sum) ? t : sc_ - lam;
-            L[Y::LAM + i] = sc_;
-            update(i, delta);
-            const T dvel = delta * aii;
-            res = tmax(res, dvel * dvel);
+            lamj = lane == i ? sc_ : lamj;
+            rj -= acol * delta;
+            if (thr_mode) { const T dvel = delta * narrow::rdlane(ajj, i); res = tmax(res, dvel * dvel); }
         }
         for (int qc = 0; qc < nc; ++qc) {               // contact normals
             const int i = NP + 3 * qc;
-            const T lam = L[Y::LAM + i], aii = L[Y::DIAG + i];
-            const T t = narrow::rdlane(rj, i) / aii;
+            const T acol = L[arow + i];
+            const T lam = narrow::rdlane(lamj, i);
+            const T t = narrow::rdlane(rj, i) * narrow::rdlane(jdj, i);
             const T sum = lam + t;
             const T sc_ = sum < T(0) ? T(0) : sum;
             const T delta = (sc_ == sum) ? t : sc_ - lam;
-            L[Y::LAM + i] = sc_;
-            update(i, delta);
-            const T dvel = delta * aii;
-            res = tmax(res, dvel * dvel);
+            lamj = lane == i ? sc_ : lamj;
+            rj -= acol * delta;
+            if (thr_mode) { const T dvel = delta * narrow::rdlane(ajj, i); res = tmax(res, dvel * dvel); }
         }
         for (int qc = 0; qc < nc; ++qc) {               // friction pairs, cone (enableConeFriction = 1)
             const int i1 = NP + 3 * qc + 1, i2 = i1 + 1;
-            const T limit = sc.mu * L[Y::LAM + NP + 3 * qc];
-            const T l1 = L[Y::LAM + i1], l2 = L[Y::LAM + i2], a1 = L[Y::DIAG + i1], a2 = L[Y::DIAG + i2];
-            T s1 = l1 + narrow::rdlane(rj, i1) / a1, s2 = l2 + narrow::rdlane(rj, i2) / a2;
+            const T ac1 = L[arow + i1], ac2 = L[arow + i2];
+            const T limit = sc.mu * narrow::rdlane(lamj, i1 - 1);
+            const T l1 = narrow::rdlane(lamj, i1), l2 = narrow::rdlane(lamj, i2);
+            T s1 = l1 + narrow::rdlane(rj, i1) * narrow::rdlane(jdj, i1), s2 = l2 + narrow::rdlane(rj, i2) * narrow::rdlane(jdj, i2);
             const T tot = tsqrt(s1 * s1 + s2 * s2);
             if (tot > limit) { const T f = tot > T(0) ? limit / tot : T(0); s1 *= f; s2 *= f; }
             const T d1 = s1 - l1, d2 = s2 - l2;
-            L[Y::LAM + i1] = s1; L[Y::LAM + i2] = s2;
-            rj -= L[arow + i1] * d1 + L[arow + i2] * d2;
-            const T dvel = d1 * a1 + d2 * a2;           // one residual per cone pair [A7c]
-            res = tmax(res, dvel * dvel);
+            lamj = lane == i1 ? s1 : (lane == i2 ? s2 : lamj);
+            rj -= ac1 * d1 + ac2 * d2;
+            if (thr_mode) { const T dvel = d1 * narrow::rdlane(ajj, i1) + d2 * narrow::rdlane(ajj, i2); res = tmax(res, dvel * dvel); }   // one residual per cone pair [A7c]
         }
         ++ran;
         if (thr_mode && res <= m.res_thr) break;
     }
+    if (lane < NR) L[Y::LAM + lane] = lane < nr ? lamj : T(0);
     __syncthreads();
     // ---- impulses to velocities: dv = W lambda (lane u), then the env's new state (wave-uniform again)
     if (lane < NU) {

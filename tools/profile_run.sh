@@ -28,6 +28,7 @@ $B --env object_push-v0 --narrowphase gjk_manifold --steps 100 --warmup 10 2>/de
  echo "episodes out of phase (round 5):"; timeout 100 python tools/pcie_rate.py --tiles --staggered; timeout 100 python tools/pcie_rate.py --staggered) 2>&1 | grep -v amdgpu > $O/pcie_rate.txt
 TG_FUSED_STEP=1 $B --no-literal 2>/dev/null | grep metric > $O/bench_edge_fused_step.json          # the one-launch step (opt-in: measured slower)
 timeout 200 python tools/ball_rate.py 1024 8192 2>&1 | grep -v amdgpu > $O/ball_on_plate_rate.txt
+timeout 200 python tools/spin_rate.py 1024 8192 2>&1 | grep -v amdgpu > $O/spin_rate.txt                      # object_balance spinning_plate (round 6)
 # episodes out of phase (round 5): the rollout an RL run sees, reset bank auto (= on) and off, configs 2 and 3
 (for e in edge_follow-v0 surface_follow-v0; do echo "$e, reset bank auto:"; timeout 100 python tools/desync_rate.py --env $e 2>&1 | grep aligned; echo "$e, TG_RESET_BANK=0:"; TG_RESET_BANK=0 timeout 100 python tools/desync_rate.py --env $e 2>&1 | grep aligned; done
  echo "object_push-v0 (1000-step episodes), reset template + optimistic move (round 6):"; timeout 200 python tools/desync_rate.py --env object_push-v0 --max-steps 1000 --steps 300 2>&1 | grep aligned

@@ -1,6 +1,6 @@
 """Rate of object_balance's spinning_plate mode (device-resident random rollout, auto-reset on).  usage: spin_rate.py [num_envs ...]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import tactile_gym_amd as tg
@@ -8,6 +8,14 @@ import tactile_gym_amd as tg
 MODES = dict(movement_mode="xyRxRy", control_mode="TCP_velocity_control", object_mode="spinning_plate", rand_gravity=True, rand_embed_dist=False,
              observation_mode="tactile", reward_mode="dense", arm_type="ur5", tactile_sensor_name="tactip")
 if __name__ == "__main__":
+    if os.environ.get("SPIN_ITERS"):          # experiment: the solver's share of the tick (results are no longer the reference's)
+        from tactile_gym_amd.rl_envs import object_balance as ob
+        _bc = ob.build_config
+        def patched(*a, **k):
+            out = _bc(*a, **k)
+            out[0].solver_iterations = int(os.environ["SPIN_ITERS"])
+            return out
+        ob.build_config = patched
     for n in [int(x) for x in sys.argv[1:]] or [1024]:
         v = tg.make_vec("object_balance-v0", num_envs=n, max_steps=250, image_size=[128, 128], env_modes=MODES, seed=1, auto_reset=True, obs_mode="torch")
         v.reset()

@@ -53,6 +53,7 @@ __device__ __forceinline__ void support(const Hull& H, const double* e, const do
     int bi = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < kSlots; ++k) {
+        if (64 * k >= H.n) break;                             // (H.n is wave-uniform: a scalar branch; the dish's 640 vertices fill 10 of the 18 slots)
         const int i = 64 * k + lane;
         const double key = (H.x[k] * d[0] + H.y[k] * d[1]) + H.z[k] * d[2];
         if (i < H.n && key > bk) { bk = key; bi = i; bx = H.x[k]; by = H.y[k]; bz = H.z[k]; }
@@ -81,12 +82,14 @@ __device__ __forceinline__ void support(const Hull& H, const HullB* B, const dou
     const double nd[3] = {-d[0], -d[1], -d[2]};
 #pragma unroll
     for (int k = 0; k < kSlots; ++k) {
+        if (64 * k >= H.n) break;                             // (H.n is wave-uniform: a scalar branch; the dish's 640 vertices fill 10 of the 18 slots)
         const int i = 64 * k + lane;
         const double key = (H.x[k] * d[0] + H.y[k] * d[1]) + H.z[k] * d[2];
         if (i < H.n && key > bk) { bk = key; bi = i; bx = H.x[k]; by = H.y[k]; bz = H.z[k]; }
     }
 #pragma unroll
     for (int k = 0; k < kSlotsB; ++k) {
+        if (64 * k >= B->n) break;
         const int i = 64 * k + lane;
         const double key = (B->x[k] * nd[0] + B->y[k] * nd[1]) + B->z[k] * nd[2];
         if (i < B->n && key > ck) { ck = key; ci = i; cx = B->x[k]; cy = B->y[k]; cz = B->z[k]; }

@@ -14,6 +14,8 @@
 // and every lane's  r_j -= A_ji delta  (one LDS read each, stride 21 words: conflict-free).  21 rows at most: 6 motors + 3 P2P + 4 x (normal + 2 friction).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "tg_kernels.hpp"
 #include "tg_narrowphase.hpp"
 #include "tg_spin.h"
@@ -30,6 +32,8 @@ template <int N> struct SL {   // LDS layout of one env, in doubles
 };
 using lds = narrow::lptr<double>;
 
+__device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off); v = o > v ? o : v; }
@@ -55,6 +59,13 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
     constexpr int N = Topo<TOPO>::N;
     using Y = SL<N>;
     constexpr int NU = Y::NU, NP = Y::NP, NR = Y::NR;
+#ifdef TG_SPIN_STAMPS
+    unsigned long long stamp_[9];
+#define TG_SPIN_STAMP(k) stamp_[k] = wall_clock64()
+#else
+#define TG_SPIN_STAMP(k)
+#endif
+    TG_SPIN_STAMP(0);
     // ---- arm: unconstrained velocity
     T v[N];
     T Jt[3][N];
@@ -91,6 +102,7 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
 #pragma unroll
             for (int j = 0; j < N; ++j) L[Y::MI + i * N + j] = Minv[i][j];
     }
+    TG_SPIN_STAMP(1);
     // ---- spool: gravity, Bullet's default damping F = -m v (K + K |v|) [A27], gyroscopic torque
     const S3<T> Iw = rotate(b.R, bc.inertia), Iwi = inverse(Iw);
     V3<T> xc = b.pos + mul(b.R, bc.com);
@@ -113,6 +125,7 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
     const V3<T> vd = dsh.v + (dt / sc.mass) * Fd, wd = dsh.w + dt * mul(Dwi, Nd);
     s3_to9(Iwi, L + Y::IB);
     s3_to9(Dwi, L + Y::ID);
+    TG_SPIN_STAMP(2);
     // ---- narrowphase: the dish's hull in the spool's frame, AABBs, GJK / EPA, the manifold (tg_contact_wave.hip's NT = 4 block, two hulls)
     const lds mf = L + Y::MANI;
     {
@@ -127,6 +140,7 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
 #pragma clang fp contract(off)
 #pragma unroll
             for (int k = 0; k < narrow::kSlots; ++k) {
+                if (64 * k >= n_dish) break;
                 const int i = 64 * k + lane;
                 const int ii = i < n_dish ? i : 0;
                 const double v0 = L[Y::HULL + 3 * ii], v1 = L[Y::HULL + 3 * ii + 1], v2 = L[Y::HULL + 3 * ii + 2];
@@ -187,6 +201,7 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
     const int nc = __builtin_amdgcn_readfirstlane((int)mf[narrow::kMcount]);
     const int nr = NP + 3 * nc;
     contacts = nc;
+    TG_SPIN_STAMP(3);
     // ---- rows into LDS: J [NR][NU] (zeroed, then filled), the unconstrained velocity v [NU]
     for (int e = lane; e < NR * NU; e += 64) L[Y::J + e] = 0.0;
     __syncthreads();
@@ -231,6 +246,7 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
         }
     }
     __syncthreads();
+    TG_SPIN_STAMP(4);
     // ---- W = Minv_sys J^T  [NU][NR]
     const T imb = T(1) / bc.mass, imd = T(1) / sc.mass;
     for (int e = lane; e < NU * NR; e += 64) {
@@ -255,6 +271,7 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
         L[Y::A + e] = acc;
         if (i == j) L[Y::DIAG + i] = acc;
     }
+    TG_SPIN_STAMP(5);
     // ---- right-hand sides: lane j's row
     if (lane == 0) {
 #pragma unroll
@@ -283,68 +300,80 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
             rj = (r == 0) ? (depth > T(0) ? (-cv - depth / dt) : (-depth * sc.erp / dt - cv)) : -cv;      // restitution 0
         }
     }
+    TG_SPIN_STAMP(6);
     // ---- projected Gauss-Seidel.  Lane j keeps its row's residual, impulse, limit and 1 / A_jj in registers; a row update reads row i's four
     // values through v_readlane and column i of A from LDS (until round 6's last hour the impulses, limits and diagonal sat in LDS too: three
     // dependent LDS round trips and a division per row, 6.6 ms per step at 1024 envs)
+    // Every lane evaluates ITS row's candidate update from its own registers (t = r_j / A_jj, the clamp between its bounds, the impulse change);
+    // the row whose turn it is hands its change to the wavefront (one v_readlane pair) and commits its impulse.  The dependent chain of a row is
+    // FMA - mul - add - max - min - select - readlane - FMA (the first version read four row values through readlanes and clamped with compares:
+    // ~350 cycles per row).
     const int n_it = iters < 0 ? -iters : iters;
     const T ajj = lane < nr ? L[Y::DIAG + lane] : T(1);
     const T jdj = lane < nr ? T(1) / ajj : T(0);
-    const T limj = lane < NP ? L[Y::LIM + lane] : T(0);
+    const T hij = lane < NP ? L[Y::LIM + lane] : T(1e300);      // motors, P2P: +-limit; normals: [0, inf); (friction rows: the cone, below)
+    const T loj = lane < NP ? -hij : T(0);
     T lamj = T(0);
     T thr = wave_max(lane < nr ? tabs(rj * jdj) : T(0));
     thr = iters < 0 ? T(-1) : thr * T(1.3877787807814457e-17);
-    const bool thr_mode = m.res_thr > T(0);
+    const bool thr_mode = __builtin_amdgcn_ballot_w64(m.res_thr > T(0)) != 0;
     int ran = 0;
-    const int arow = Y::A + (lane < NR ? lane : 0) * NR;                               // (lanes >= nr carry rows of zeros; lanes >= NR shadow row 0, unread)
-    for (int it = 0; it < n_it; ++it) {
-        if (!thr_mode && (it & 7) == 0 && it > 0) {
-            const T mx = wave_max(lane < nr ? tabs(rj * jdj) : T(0));
-            if (mx <= thr) break;
-        }
-        T res = T(0);
-        for (int jj = 0; jj < NP; ++jj) {               // motors and P2P rows: reversed on even sweeps
-            const int i = (it & 1) ? jj : NP - 1 - jj;
-            const T acol = L[arow + i];
-            const T lim = narrow::rdlane(limj, i), lam = narrow::rdlane(lamj, i);
-            const T t = narrow::rdlane(rj, i) * narrow::rdlane(jdj, i);
-            const T sum = lam + t;
-            const T lo_ = sum < -lim ? -lim : sum;
-            const T sc_ = lo_ > lim ? lim : lo_;
-            const T delta = (sc_ == sum) ? t : sc_ - lam;
-            lamj = lane == i ? sc_ : lamj;
-            rj -= acol * delta;
-            if (thr_mode) { const T dvel = delta * narrow::rdlane(ajj, i); res = tmax(res, dvel * dvel); }
-        }
-        for (int qc = 0; qc < nc; ++qc) {               // contact normals
-            const int i = NP + 3 * qc;
-            const T acol = L[arow + i];
-            const T lam = narrow::rdlane(lamj, i);
-            const T t = narrow::rdlane(rj, i) * narrow::rdlane(jdj, i);
-            const T sum = lam + t;
-            const T sc_ = sum < T(0) ? T(0) : sum;
-            const T delta = (sc_ == sum) ? t : sc_ - lam;
-            lamj = lane == i ? sc_ : lamj;
-            rj -= acol * delta;
-            if (thr_mode) { const T dvel = delta * narrow::rdlane(ajj, i); res = tmax(res, dvel * dvel); }
-        }
-        for (int qc = 0; qc < nc; ++qc) {               // friction pairs, cone (enableConeFriction = 1)
-            const int i1 = NP + 3 * qc + 1, i2 = i1 + 1;
-            const T ac1 = L[arow + i1], ac2 = L[arow + i2];
-            const T limit = sc.mu * narrow::rdlane(lamj, i1 - 1);
-            const T l1 = narrow::rdlane(lamj, i1), l2 = narrow::rdlane(lamj, i2);
-            T s1 = l1 + narrow::rdlane(rj, i1) * narrow::rdlane(jdj, i1), s2 = l2 + narrow::rdlane(rj, i2) * narrow::rdlane(jdj, i2);
-            const T tot = tsqrt(s1 * s1 + s2 * s2);
-            if (tot > limit) { const T f = tot > T(0) ? limit / tot : T(0); s1 *= f; s2 *= f; }
-            const T d1 = s1 - l1, d2 = s2 - l2;
-            lamj = lane == i1 ? s1 : (lane == i2 ? s2 : lamj);
-            rj -= ac1 * d1 + ac2 * d2;
-            if (thr_mode) { const T dvel = d1 * narrow::rdlane(ajj, i1) + d2 * narrow::rdlane(ajj, i2); res = tmax(res, dvel * dvel); }   // one residual per cone pair [A7c]
-        }
-        ++ran;
-        if (thr_mode && res <= m.res_thr) break;
+    T acol[NR];                                         // lane j's row of A (= column, A is symmetric): the sweeps touch no memory
+    {
+        const int arow = Y::A + (lane < NR ? lane : 0) * NR;                           // (lanes >= nr carry rows of zeros; lanes >= NR shadow row 0, unread)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) acol[i] = L[arow + i];
     }
+    auto sweeps = [&](auto thr_tag) {
+        constexpr bool THR = decltype(thr_tag)::value;
+        auto row = [&](const int i, T& res) {           // i is a literal after unrolling
+            const T t = rj * jdj;
+            const T sum = lamj + t;
+            const T sc_ = vmin(vmax(sum, loj), hij);
+            const T dj = (sc_ == sum) ? t : sc_ - lamj;
+            const T delta = narrow::rdlane(dj, i);
+            lamj = lane == i ? sc_ : lamj;
+            rj -= acol[i] * delta;
+            if (THR) { const T dvel = delta * narrow::rdlane(ajj, i); res = tmax(res, dvel * dvel); }
+        };
+        for (int it = 0; it < n_it; ++it) {
+            if (!THR && (it & 7) == 0 && it > 0) {
+                const T mx = wave_max(lane < nr ? tabs(rj * jdj) : T(0));
+                if (mx <= thr) break;
+            }
+            T res = T(0);
+            if (it & 1) {                               // motors and P2P rows: reversed on even sweeps
+#pragma unroll
+                for (int i = 0; i < NP; ++i) row(i, res);
+            } else {
+#pragma unroll
+                for (int i = NP - 1; i >= 0; --i) row(i, res);
+            }
+#pragma unroll
+            for (int qc = 0; qc < kNC; ++qc)            // contact normals
+                if (qc < nc) row(NP + 3 * qc, res);
+#pragma unroll
+            for (int qc = 0; qc < kNC; ++qc) {          // friction pairs, cone (enableConeFriction = 1)
+                if (qc >= nc) break;
+                const int i1 = NP + 3 * qc + 1, i2 = i1 + 1;
+                const T sum = lamj + rj * jdj;
+                const T limit = sc.mu * narrow::rdlane(lamj, i1 - 1);
+                const T l1 = narrow::rdlane(lamj, i1), l2 = narrow::rdlane(lamj, i2);
+                T s1 = narrow::rdlane(sum, i1), s2 = narrow::rdlane(sum, i2);
+                friction_clamp(s1, s2, limit, true);    // the cone, branch-free through v_rsq (tg_physics.hpp; as the push / roll kernels)
+                const T d1 = s1 - l1, d2 = s2 - l2;
+                lamj = lane == i1 ? s1 : (lane == i2 ? s2 : lamj);
+                rj -= acol[i1] * d1 + acol[i2] * d2;
+                if (THR) { const T dvel = d1 * narrow::rdlane(ajj, i1) + d2 * narrow::rdlane(ajj, i2); res = tmax(res, dvel * dvel); }   // one residual per cone pair [A7c]
+            }
+            ++ran;
+            if (THR && res <= m.res_thr) break;
+        }
+    };
+    if (thr_mode) sweeps(std::true_type{}); else sweeps(std::false_type{});
     if (lane < NR) L[Y::LAM + lane] = lane < nr ? lamj : T(0);
     __syncthreads();
+    TG_SPIN_STAMP(7);
     // ---- impulses to velocities: dv = W lambda (lane u), then the env's new state (wave-uniform again)
     if (lane < NU) {
         T acc = T(0);
@@ -366,6 +395,14 @@ __device__ __noinline__ int sim_tick_spin(const DevRobot<double>& m, double (&q)
     integrate_rotation(dsh.R, dsh.w, dt);
     dsh.pos = xd - mul(dsh.R, sc.com);
     __syncthreads();
+    TG_SPIN_STAMP(8);
+#ifdef TG_SPIN_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && pending) {
+        printf("spin tick (env 0, first tick of an episode; 100 MHz ticks): dynamics %llu bodies %llu narrowphase %llu J %llu W+A %llu rhs %llu sweeps(%d) %llu finish %llu\n",
+               stamp_[1] - stamp_[0], stamp_[2] - stamp_[1], stamp_[3] - stamp_[2], stamp_[4] - stamp_[3], stamp_[5] - stamp_[4], stamp_[6] - stamp_[5], ran,
+               stamp_[7] - stamp_[6], stamp_[8] - stamp_[7]);
+    }
+#endif
     return ran;
 }
 

@@ -290,14 +290,25 @@ struct Timer {
 };
 
 
-template <typename T, int TOPO> static void launch_step_t(tg_ctx* c, const float* d_actions) {
+// reset_phase >= 0: the finished envs' auto-reset (k_reset's body, phase `reset_phase`) runs inside the step's launch (k_step<T, TOPO, true>;
+// the UR5 only - on the MG400 a step is 0.7 ms of full ticks and the launch it would save is noise); returns whether it did
+template <typename T, int TOPO> static bool launch_step_t(tg_ctx* c, const float* d_actions, int reset_phase = -1) {
     const int n = c->cfg.num_envs;
-    if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION)
+    if (c->cfg.control_mode == TG_CONTROL_TCP_POSITION) {
         hipLaunchKernelGGL((k_step_pos<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
                            (const EnvConst<T>*)c->d_const, c->st, d_actions);
-    else
-        hipLaunchKernelGGL((k_step<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
-                           (const EnvConst<T>*)c->d_const, c->st, d_actions);
+        return false;
+    }
+    if constexpr (TOPO == 0 && std::is_same<T, double>::value) {   // (f64 physics: the configuration every BASELINE config runs)
+        if (reset_phase >= 0) {
+            hipLaunchKernelGGL((k_step<T, TOPO, true>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                               (const EnvConst<T>*)c->d_const, c->st, d_actions, reset_phase, c->bank_mode != 0 ? (const BankDev*)c->d_bank : (const BankDev*)nullptr);
+            return true;
+        }
+    }
+    hipLaunchKernelGGL((k_step<T, TOPO>), dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevRobot<T>*)c->d_robot,
+                       (const EnvConst<T>*)c->d_const, c->st, d_actions, -1, (const BankDev*)nullptr);
+    return false;
 }
 template <typename T, int TOPO> static void launch_reset_t(tg_ctx* c, const uint8_t* d_mask, int phase, bool bank = false) {
     const int n = c->cfg.num_envs;
@@ -534,12 +545,14 @@ static int surf_gen_mode(const tg_ctx* c) {
 
 // bank: the auto-reset of tg_step with the reset bank on (k_reset mode 1): finished envs take their precomputed state, the rest (aux.late)
 // are reset by the launches that follow
-static void reset_sequence(tg_ctx* c, const uint8_t* d_mask, bool bank = false) {
+static void reset_sequence(tg_ctx* c, const uint8_t* d_mask, bool bank = false, bool phase1_done = false /* surface_follow: k_step<.., true> has run phase 1 */) {
     Timer t(c, 2);
     if (bank && c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        if (!phase1_done) {
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 1, true)
-        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
+        }
         launch_gen_surface(c->cfg.num_envs, c->aux.late, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
                            c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->st.heights, c->st.surf_zoff, c->stream,
                            c->aux.swapped, c->st.hsel);
@@ -575,9 +588,11 @@ static void reset_sequence(tg_ctx* c, const uint8_t* d_mask, bool bank = false) 
             launch_gen_traj(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.traj_n_points, c->cfg.traj_spacing, c->cfg.traj_max_perturb,
                             c->cfg.traj_init_offset, c->cfg.reset_goal_id, c->st.traj, c->st.feature, c->stream);
     } else if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) {
+        if (!phase1_done) {
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 1)
-        TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
+            TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
+        }
         launch_gen_surface(c->cfg.num_envs, d_mask, c->st.noise_seed, c->cfg.surf_rows, c->cfg.surf_cols, c->cfg.surf_interp,
                            c->cfg.surf_height_range, c->cfg.surf_center_z, surf_gen_mode(c), c->st.heights, c->st.surf_zoff, c->stream, nullptr, c->st.hsel);
 #define CALL(T, TOPO) launch_reset_t<T, TOPO>(c, d_mask, 2)
@@ -1176,7 +1191,13 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
                                                            c->d_const, c->st, d_act) == 0) {
             // edge_follow / surface_follow with one wavefront per env (tg_contact_wave.hip: k_step_arm_wave)
         } else {
-#define CALL(T, TOPO) launch_step_t<T, TOPO>(c, d_act)
+            // edge_follow / surface_follow: the auto-reset's first launch (edge_follow: its only one) inside the step kernel, unless something
+            // is drawn or checked between the step and the reset (scene / oracle observations, the broadphase guard: the pre-reset state)
+            static const bool no_inline = getenv("TG_NO_INLINE_RESET") != nullptr;
+            const bool fused_render_path = c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO;
+            const int reset_phase = (c->cfg.auto_reset && fused_render_path && !no_inline && !c->scene_every_step && !c->oracle_every_step && !(c->d_bp && c->bp_every_step))
+                                        ? (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO ? 1 : 0) : -1;
+#define CALL(T, TOPO) reset_inlined = launch_step_t<T, TOPO>(c, d_act, reset_phase)
             TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);
 #undef CALL
         }
@@ -1191,6 +1212,7 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
         // (object_balance with the reset template: k_reset_body is a few microseconds - teleport, draws, one forward kinematics - so it runs
         //  in line like edge_follow's, without the fork / join of the branch below and without the masked second render: 236 -> 20x us per step)
         if (!reset_inlined) reset_sequence(c, c->st.done, c->bank_mode != 0); // k_reset keeps the terminal camera transform of the envs it resets
+        else if (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO) reset_sequence(c, c->st.done, c->bank_mode != 0, true);   // phase 1 ran inside k_step
         render_fused(c);               // one launch draws the terminal and the post-reset observations
     } else if (c->cfg.auto_reset && c->aux_stream) {
         // object_balance: a pole falls somewhere in the batch on nearly every step, and its reset (rest pose, blocking move, settling: a

@@ -212,10 +212,11 @@ __device__ __forceinline__ void episode_step(const State& st, int env, float rew
 }
 
 template <typename T, int TOPO>
-__device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
+__device__ __forceinline__ bool finish_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const T (&q)[Topo<TOPO>::N],
                                            T edge_ang, int step_count, bool write_reward_done, const JointTrig<T, Topo<TOPO>::N>* trig = nullptr,
                                            bool lazy_rpy = false /* k_step: tcp_rpy is a read-back only, tg_get_state recomputes it (k_refresh_rpy) */) {
     const int n = c.num_envs;
+    bool done_flag = false;   // what went into st.done[env], for a caller that resets the env in the same launch (k_step<.., true>)
     Kin<T, TOPO> k;
     if (trig != nullptr) forward_kinematics<T, TOPO, true>(m, q, k, trig);
     else forward_kinematics<T, TOPO>(m, q, k);
@@ -246,6 +247,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         else reward = -((T(1) * goal_dist) + (T(10) * edge_dist) + T(0));
         st.reward[env] = (float)reward;
         st.done[env] = done ? 1 : 0;
+        done_flag = done;
         episode_step(st, env, (float)reward, done, step_count);
     }
     TG_KSTAMP(5)
@@ -291,6 +293,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
         if (write_reward_done) {
             st.reward[env] = (float)out;
             st.done[env] = (at_goal || step_count >= c.max_steps) ? 1 : 0;
+            done_flag = at_goal || step_count >= c.max_steps;
             episode_step(st, env, (float)out, at_goal || step_count >= c.max_steps, step_count);
         }
     }
@@ -330,6 +333,7 @@ __device__ __forceinline__ void finish_env(const DevRobot<T>& m, const EnvConst<
     X[3 * n + env] = (float)dot(u, ox);  X[4 * n + env] = (float)dot(u, oy);  X[5 * n + env] = (float)dot(u, oz);
     X[6 * n + env] = (float)dot(nf, ox); X[7 * n + env] = (float)dot(nf, oy); X[8 * n + env] = (float)dot(nf, oz);
     X[9 * n + env] = (float)dot(s, dp);  X[10 * n + env] = (float)dot(u, dp); X[11 * n + env] = (float)dot(nf, dp);
+    return done_flag;
 }
 
 // observation_mode "oracle" (get_oracle_obs of every env class) for the whole batch, float32 [n][dim], from the device state:
@@ -619,7 +623,8 @@ __device__ __forceinline__ void encode_arm_actions(const EnvConst<T>& c, const S
 // One env's step, one lane (k_step: 64 consecutive envs per wavefront; k_step_render in tg_fused.hip: the envs of one render wavefront).
 // Returns whether this step ran a full solve (development stamps only).
 template <typename T, int TOPO>
-__device__ __forceinline__ bool step_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const float* __restrict__ actions) {
+__device__ __forceinline__ bool step_env(const DevRobot<T>& m, const EnvConst<T>& c, const State& st, int env, const float* __restrict__ actions,
+                                         bool* done_out = nullptr /* what the step wrote to st.done[env] */) {
     constexpr int N = Topo<TOPO>::N;
     const int n = c.num_envs;
     TG_KSTAMP(0)
@@ -719,7 +724,8 @@ __device__ __forceinline__ bool step_env(const DevRobot<T>& m, const EnvConst<T>
 #pragma unroll
     for (int i = 0; i < N; ++i) { st.trig_sc[i * n + env] = (double)trig.s[i]; st.trig_sc[(8 + i) * n + env] = (double)trig.c[i]; }
     TG_KSTAMP(4)
-    finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
+    const bool done = finish_env<T, TOPO>(m, c, st, env, q, (T)st.edge_ang[env], step_count, true, &trig, true);
+    if (done_out != nullptr) *done_out = done;
     return ran_full;
 }
 // tg_step_random: every lane of every workgroup has read the draw counter long ago: the last workgroup to get here moves it on
@@ -768,14 +774,24 @@ __device__ __forceinline__ void draw_ticket_resolve(const State& st, unsigned lo
     if (last) { atomicExch(st.draw + 2, 0ull); atomicAdd(st.draw + 0, 1ull); }
 }
 
-template <typename T, int TOPO>
+template <typename T, int TOPO> __device__ __forceinline__ void reset_or_swap(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, const State& st,
+                                                                             int env, bool in_step, int phase, const BankDev* __restrict__ bd);
+// RESET (round 6): the auto-reset of the envs this step finished, inside the step's own launch - reset_or_swap, the body of k_reset, on the
+// env's lane straight after its step (reset_phase 0: the whole reset, edge_follow; 1: the task draws / the bank's swap-in, surface_follow,
+// whose k_gen_surface + phase-2 launches follow as before).  Same loads, same stores, same order per env as the k_reset launch it replaces
+// (an env's reset reads nothing another env's step writes): byte-identical, one dependent launch and its dispatch gap fewer per step.
+template <typename T, int TOPO, bool RESET = false>
 __global__ __launch_bounds__(64) void k_step(const DevRobot<T>* __restrict__ mp, const EnvConst<T>* __restrict__ cp, State st,
-                                             const float* __restrict__ actions) {
+                                             const float* __restrict__ actions, int reset_phase, const BankDev* __restrict__ bd) {
     KtScope kt_scope_(st.kt);
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     TG_TL(st.tl, 1);
     if (env >= cp->num_envs) return;
-    const bool ran_full = step_env<T, TOPO>(*mp, *cp, st, env, actions);
+    bool done = false;
+    const bool ran_full = step_env<T, TOPO>(*mp, *cp, st, env, actions, &done);
+    if (RESET) {   // (the flag from a register: reading st.done[env] back is a memory round trip at the end of the step's chain, +1 us)
+        if (done) reset_or_swap<T, TOPO>(mp, cp, st, env, true, reset_phase, bd);   // (out of line - a noinline wrapper - was measured: k_step 21.7 us, the call changes the whole kernel's register allocation)
+    }
     draw_counter_advance(st);
     TG_KSTAMP(9)
 #ifdef TG_KSTEP_STAMPS

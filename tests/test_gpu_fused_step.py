@@ -106,3 +106,25 @@ def test_one_launch_step_with_every_block_rewritten():
     assert a["mode"] == b["mode"] == "fused" and c["mode"] == "separate"
     assert a["sha"] == b["sha"] == c["sha"] and a["state"] == c["state"]
     _same_trajectories(a, c)
+
+
+SURF = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_mode="simplex", observation_mode="tactile",
+            reward_mode="dense", arm_type="ur5", tactile_sensor_name="digit")
+
+
+@pytest.mark.parametrize("env_id,n,steps,max_steps,modes,random_step,bank", [
+    ("edge_follow-v0", 1024, 40, 9, EDGE, 1, "1"),        # the headline's shape: bank swap-in (or the reset on the spot) inside k_step<.., true>
+    ("edge_follow-v0", 300, 30, 7, EDGE, 0, "0"),         # no bank: every finished env's IK + blocking move inside the step's launch
+    ("surface_follow-v0", 200, 30, 8, SURF, 0, "1"),      # phase 1 (task draws / swap-in) inside the step, k_gen_surface + phase 2 behind it
+    ("surface_follow-v0", 130, 24, 8, SURF, 1, "0"),
+])
+def test_reset_inside_the_step_launch_equals_the_reset_launch(env_id, n, steps, max_steps, modes, random_step, bank):
+    """Round 6: k_step<T, 0, true> runs reset_or_swap - the body of k_reset - on the finished env's lane straight after its step (one dependent
+    launch fewer per step).  TG_NO_INLINE_RESET=1 keeps the k_reset launch: same images, terminal images, rewards, dones, tick counts."""
+    a = _run(env_id, n, 128, steps, max_steps, modes, random_step, TG_FUSED_STEP="0", TG_RESET_BANK=bank)
+    b = _run(env_id, n, 128, steps, max_steps, modes, random_step, TG_FUSED_STEP="0", TG_RESET_BANK=bank, TG_NO_INLINE_RESET="1")
+    assert a["dones"] >= n and a["terms"] == a["dones"]
+    assert a["sums"] == b["sums"]
+    assert a["sha"] == b["sha"], "observations / rewards / dones / terminal observations differ between the in-step reset and the k_reset launch"
+    assert a["state"] == b["state"], "reset tick counts / step counts differ"
+    _same_trajectories(a, b)

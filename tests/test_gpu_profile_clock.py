@@ -43,8 +43,10 @@ def test_kernel_clock_durations_fit_inside_the_step():
     v.profile(False)
     v.step_random_async(9, 1000, restart=True)           # the plain graph is captured again and runs
     v.sync()
-    per = {k: clk[k + "_clock"][0] / max(clk[k + "_clock"][1], 1) for k in ("step", "render", "reset")}
+    # (round 6: edge_follow's auto-reset runs inside k_step's launch - no reset class unless TG_NO_INLINE_RESET is set)
+    per = {k: clk[k + "_clock"][0] / max(clk[k + "_clock"][1], 1) for k in ("step", "render", "reset") if clk[k + "_clock"][1] > 0}
     assert clk["step_clock"][1] == clk["render_clock"][1] == steps
+    assert clk["reset_clock"][1] in (0, steps)
     assert all(x > 0.0005 for x in per.values()), per
     assert sum(per.values()) < step_ms, (per, step_ms)                      # the kernels fit inside the step they make up ...
     assert sum(per.values()) > 0.6 * step_ms, (per, step_ms)                # ... and are most of it (the rest: dispatch gaps between the nodes)

@@ -1150,6 +1150,20 @@ int tg_reset(tg_ctx* c, const uint8_t* host_mask) {
     return 0;
 }
 
+// Whether a step is replayed as a captured graph or enqueued launch by launch.  Until round 6 every step was ONE graph launch; measured on an
+// MI355X with ROCm 7.2 (tools/dev/graph_floor.hip: 15-us kernels back to back, the device never idle) a graph launch costs ~6.6 us before its
+// first kernel starts and ~1.7 us per further dependent node, launches on the stream ~2.0 us each - and on the host a graph launch is ~9 us
+// against ~2.8 us per kernel launch.  The steps here are 2 - 4 launches (the policy draw and the auto-reset live inside k_step), so the stream
+// wins up to ~16 launches per step: headline 42.2 -> 37.2 us per step (24.3 -> 27.5 M env-steps/s), episodes out of phase 47.8 -> 42.8 us,
+// surface_follow-v0 100.4 -> 95.8 us, object_balance 117 -> 112.5 us (tools/desync_rate.py, same box, alternating).  Default: the stream.
+// TG_STEP_GRAPH=1 keeps the graphs (A/B measurements; a host that cannot keep two launches per step ahead of the device).
+static bool step_as_graph(const tg_ctx* c) {
+    static const int forced = getenv("TG_STEP_GRAPH") != nullptr ? atoi(getenv("TG_STEP_GRAPH")) : -1;
+    if (forced >= 0) return forced != 0;
+    (void)c;
+    return false;
+}
+
 static void enqueue_step(tg_ctx* c, const float* d_act) {
     if (c->profile) { Timer t(c, 5); }   // an empty event pair: what every per-kernel figure of this mode carries on top of its kernel
     bool reset_inlined = false;          // object_balance: k_step_body_wave has reset its finished envs itself
@@ -1262,7 +1276,7 @@ int tg_step(tg_ctx* c, const float* actions, int32_t on_device) {
     //   slot 1  reads the FIRST caller-owned device buffer seen, in place (a rollout that reuses one action tensor, e.g. bench.py).
     // Not while profiling (the per-kernel events are host calls between the launches) and not for the lane-per-env push kernels
     // (hipFuncSetAttribute on first launch).
-    const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL;
+    const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL && step_as_graph(c);
     if (want_graph) {
         int slot = 0;
         if (on_device) {
@@ -1330,7 +1344,7 @@ int tg_step_random(tg_ctx* c, uint64_t seed, uint64_t first_draw, int32_t restar
 #endif
                            );
     };
-    const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL;
+    const bool want_graph = !c->profile && !c->graph_broken && c->cfg.env_kind != TG_ENV_OBJECT_PUSH && c->cfg.env_kind != TG_ENV_OBJECT_ROLL && step_as_graph(c);
     // the lane-mapped k_step (edge_follow / surface_follow, TCP_velocity_control) draws its own actions: no sampler node at all - a dependent
     // kernel in this graph costs its ~6 us dispatch floor whatever it computes (profiles/r4_exp_reset_launch.txt)
     // (round 5: so does object_balance's k_step_body_wave - the conditions of launch_step_body_wave)

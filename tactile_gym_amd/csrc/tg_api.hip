@@ -1209,7 +1209,12 @@ static void enqueue_step(tg_ctx* c, const float* d_act) {
             // is drawn or checked between the step and the reset (scene / oracle observations, the broadphase guard: the pre-reset state)
             static const bool no_inline = getenv("TG_NO_INLINE_RESET") != nullptr;
             const bool fused_render_path = c->cfg.env_kind == TG_ENV_EDGE_FOLLOW || c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO;
-            const int reset_phase = (c->cfg.auto_reset && fused_render_path && !no_inline && !c->scene_every_step && !c->oracle_every_step && !(c->d_bp && c->bp_every_step))
+            // Only with the reset bank on: the swap-in is a copy, identical wherever it runs; a reset computed on the spot (IK, blocking move) inside
+            // k_step<.., true> is another instantiation of reset_env than k_reset's, and the compiler contracts each one's f64 expressions into FMAs
+            // on its own - measured: one build in which a bank-off rollout differed from the k_reset launch's in the last bits of q (12 grey levels
+            // of one image sum).  With the bank off the reset is 90 us on the spot anyway, and it stays the k_reset launch.  (With the bank on, an env
+            // that finds no entry - none in any measured rollout - is reset on the spot in here, as k_step_render does.)
+            const int reset_phase = (c->cfg.auto_reset && fused_render_path && c->bank_mode != 0 && !no_inline && !c->scene_every_step && !c->oracle_every_step && !(c->d_bp && c->bp_every_step))
                                         ? (c->cfg.env_kind == TG_ENV_SURFACE_FOLLOW_AUTO ? 1 : 0) : -1;
 #define CALL(T, TOPO) reset_inlined = launch_step_t<T, TOPO>(c, d_act, reset_phase)
             TG_DISPATCH(c->cfg.physics_dtype, c->robot.topology, CALL);

@@ -114,13 +114,14 @@ SURF = dict(movement_mode="xyzRxRy", control_mode="TCP_velocity_control", noise_
 
 @pytest.mark.parametrize("env_id,n,steps,max_steps,modes,random_step,bank", [
     ("edge_follow-v0", 1024, 40, 9, EDGE, 1, "1"),        # the headline's shape: bank swap-in (or the reset on the spot) inside k_step<.., true>
-    ("edge_follow-v0", 300, 30, 7, EDGE, 0, "0"),         # no bank: every finished env's IK + blocking move inside the step's launch
+    ("edge_follow-v0", 300, 30, 7, EDGE, 0, "0"),         # no bank: the reset stays the k_reset launch (a reset computed in another kernel instantiation may differ in the last bits)
     ("surface_follow-v0", 200, 30, 8, SURF, 0, "1"),      # phase 1 (task draws / swap-in) inside the step, k_gen_surface + phase 2 behind it
     ("surface_follow-v0", 130, 24, 8, SURF, 1, "0"),
 ])
 def test_reset_inside_the_step_launch_equals_the_reset_launch(env_id, n, steps, max_steps, modes, random_step, bank):
-    """Round 6: k_step<T, 0, true> runs reset_or_swap - the body of k_reset - on the finished env's lane straight after its step (one dependent
-    launch fewer per step).  TG_NO_INLINE_RESET=1 keeps the k_reset launch: same images, terminal images, rewards, dones, tick counts."""
+    """Round 6: with the reset bank on, k_step<T, 0, true> runs reset_or_swap - the body of k_reset - on the finished env's lane straight after its
+    step (one dependent launch fewer per step).  TG_NO_INLINE_RESET=1 keeps the k_reset launch: same images, terminal images, rewards, dones, tick
+    counts.  (Bank off: both runs take the k_reset launch.)"""
     a = _run(env_id, n, 128, steps, max_steps, modes, random_step, TG_FUSED_STEP="0", TG_RESET_BANK=bank)
     b = _run(env_id, n, 128, steps, max_steps, modes, random_step, TG_FUSED_STEP="0", TG_RESET_BANK=bank, TG_NO_INLINE_RESET="1")
     assert a["dones"] >= n and a["terms"] == a["dones"]

@@ -252,7 +252,7 @@ class Workload:
     def on_stream(self):
         return self.torch.cuda.stream(self.shard.stream) if self.shard.pipelined else contextlib.nullcontext()
 
-    fused_policy = True     # the uniform random policy as a node of the step's graph (tg_step_random); False: its own launch before every step
+    fused_policy = True     # the uniform random policy inside the step (tg_step_random: drawn by the step kernel itself, or the step's first launch); False: its own launch before every step
     _fused_synced = False   # the context's device-side draw counter equals self.draw
 
     def step(self, env):
@@ -292,14 +292,14 @@ class Workload:
         return time.perf_counter() - t0
 
     def profile(self, env, steps, barrier, clock=True):
-        """Per-kernel durations, outside the timed region.  First the rollout as it is timed - the same graph, the same in-graph policy - with the
+        """Per-kernel durations, outside the timed region.  First the rollout as it is timed - the same launches, the same in-step policy - with the
         kernels stamping their own clock (tg_profile_enable(2)); then a few steps launch by launch with HIP event pairs (tg_profile_enable(1)): the
         figures earlier rounds quoted, kept beside the clock's for comparison together with what an empty event pair measures."""
         prof = {}
-        if clock:       # (not under a process group: switching this mode on and off re-captures the step graphs, see TorchShard.prime)
+        if clock:       # (not under a process group: with TG_STEP_GRAPH=1 switching this mode on and off re-captures the step graphs, see TorchShard.prime)
             self.venv.profile("clock")
             self._fused_synced = False
-            self.step(env)                               # (the re-capture of the graphs happens here, outside the window below)
+            self.step(env)                               # (TG_STEP_GRAPH=1: the re-capture of the graphs happens here, outside the window below)
             barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -497,7 +497,7 @@ def main():
     ap.add_argument("--no-literal", action="store_true", help="skip the literal-solver companion run (keeps a rocprofv3 trace of this command to one solver mode)")
     ap.add_argument("--no-companions", action="store_true", help="skip other_configs / roofline_16384 (same purpose)")
     ap.add_argument("--separate-policy", action="store_true", help="launch the uniform random policy (tg_sample_actions) as its own kernel before every step instead of "
-                    "as a node of the step's graph (tg_step_random)")
+                    "inside the step (tg_step_random)")
     ap.add_argument("--sync-steps", action="store_true", help="block the host on every step (VecEnv.step_wait semantics) instead of pipelining")
     ap.add_argument("--full-sweeps", action="store_true",
                     help="always run all 150 PGS sweeps per tick instead of leaving the loop at convergence to the last bit (DESIGN.md 4.1)")
@@ -553,7 +553,8 @@ def main():
                  observation_mode=args.observation_mode, pipelined=not args.sync_steps, **extra)
     venv, shard, modes, max_steps = w.venv, w.shard, w.modes, w.max_steps
     if world > 1 or os.environ.get("TG_BENCH_FORCE_COLLECTIVE") == "1":
-        # every graph the rollout will launch is captured HERE, before the process group (and its watchdog thread) exists: no step below captures
+        # TG_STEP_GRAPH=1: every graph the rollout will launch is captured HERE, before the process group (and its watchdog thread) exists: no step below captures
+        # (default since round 6: the steps are enqueued launch by launch and nothing is ever captured)
         # anything (parallel.TorchShard.prime; rounds 3-4 slept three watchdog periods before the first capture instead)
         with w.on_stream():
             shard.prime(w.act_buf)
@@ -705,7 +706,7 @@ def main():
             dt_sp = w.timed(env, args.steps, barrier)
             Workload.fused_policy = True
             separate = {"value": round(n * args.steps / dt_sp, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * dt_sp / args.steps, 4),
-                        "what": "tg_sample_actions as its own kernel launch before every tg_step instead of a draw inside the step's graph"}
+                        "what": "tg_sample_actions as its own kernel launch before every tg_step instead of a draw inside the step"}
     exchange = env.exchange_info() if gathered and hasattr(env, "exchange_info") else None
     if exchange is not None:
         exchange["verified"] = verified
@@ -786,8 +787,8 @@ def main():
                       "default: PGS leaves at last-bit convergence; ticks whose motor solve is provably unclamped and demonstrably converged take "
                       "the solver's analytic fixed point (qd = target); joints within 1e-11 rad of the literal solver over 1024 envs x 260 steps incl. auto-resets "
                       "(tests/test_gpu_parity.py::test_default_solver_equals_literal_solver_at_config_scale; DESIGN.md 4.1)",
-            "policy": ("uniform random actions (action_space.sample() for the whole batch), drawn on the device inside the step's graph (tg_step_random: by the step kernel "
-                       "itself for edge_follow / surface_follow under velocity control, as the graph's first node elsewhere; draw k identical to tg_sample_actions(seed, k))") if Workload.fused_policy and hasattr(env, "step_random") else
+            "policy": ("uniform random actions (action_space.sample() for the whole batch), drawn on the device inside the step (tg_step_random: by the step kernel "
+                       "itself for edge_follow / surface_follow under velocity control, as the step's first launch elsewhere; draw k identical to tg_sample_actions(seed, k))") if Workload.fused_policy and hasattr(env, "step_random") else
                       "uniform random actions drawn on the device by tg_sample_actions, one launch before every step",
             "separate_policy_launch": separate,
             "literal_solver": literal,

@@ -449,8 +449,8 @@ int tg_set_joint_state(tg_ctx* ctx, const double* q, const double* qd);
 
 /* Per-kernel timing (bench.py's roofline leg).  enable = 1: HIP event pairs around every launch class on the launch stream, the step's launches
  * issued one by one (no graph); every figure carries what an EMPTY event pair measures (3 - 5 us).  enable = 2: only the kernels' own clock
- * (csrc/tg_kt.hpp: every wavefront stamps its start and end, wall_clock64; first start -> last end per class), the step stays one hipGraph -
- * the figures of the rollout itself.  enable = 0: off (the next step captures its graph again).
+ * (csrc/tg_kt.hpp: every wavefront stamps its start and end, wall_clock64; first start -> last end per class), the step's launches stay as the
+ * rollout issues them (since round 6: on the stream; one replayed hipGraph with TG_STEP_GRAPH=1) - the figures of the rollout itself.  enable = 0: off.
  * tg_profile_get which: 0 step kernel, 1 render of all envs (the one launch of a fused step), 2 reset sequence, 3 masked render (reset /
  * auto-reset envs only), 4 scene camera, 5 an empty event pair - by HIP events; 8 + k (k = 0 .. 3): class k by the kernels' own clock. */
 int tg_profile_enable(tg_ctx* ctx, int32_t enable);
@@ -557,8 +557,10 @@ int tg_gen_heightfield(int32_t n, const int64_t* seeds, int32_t rows, int32_t co
  * (seed, counter, i) only.  Enqueued on the context's stream, so a tg_step(dev_actions, on_device = 1) that follows sees it. */
 int tg_sample_actions(tg_ctx* ctx, uint64_t seed, uint64_t counter, float* dev_actions);
 /* A random-action rollout step (the north_star's synthetic rollout: `env.step(env.action_space.sample())`, examples/demo_rl_env_base.py:34, for the
- * whole batch): tg_sample_actions' draw followed by tg_step on it, captured as ONE graph - the sampler is a node of the step's graph, the draw
- * counter lives in device memory and moves on by one per call.  restart != 0 (or a new seed): the next step uses draw first_draw + 1.  The
+ * whole batch): tg_sample_actions' draw followed by tg_step on it as one sequence of launches - the draw is made by the step kernel itself where the
+ * lane-mapped k_step / k_step_body_wave runs, by the sequence's first launch elsewhere; the draw counter lives in device memory and moves on by one
+ * per call.  (Until round 6 the sequence was replayed as one captured hipGraph; TG_STEP_GRAPH=1 still does: a graph launch costs ~6.6 us before its
+ * first kernel starts on this stack, a launch on the stream ~2 us.)  restart != 0 (or a new seed): the next step uses draw first_draw + 1.  The
  * actions are the context's own buffer (tg_get_actions: device float32 [num_envs][act_dim]); draw k equals tg_sample_actions(seed, k). */
 int tg_step_random(tg_ctx* ctx, uint64_t seed, uint64_t first_draw, int32_t restart);
 int tg_get_actions(tg_ctx* ctx, void** dev_actions);

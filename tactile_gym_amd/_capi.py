@@ -303,6 +303,17 @@ def lib():
     return _lib
 
 
+def step_graphs_enabled():
+    """Whether the library replays a step as a captured graph (TG_STEP_GRAPH=1) or enqueues its launches on the stream (the default since round
+    6: a graph launch costs ~6.6 us before its first kernel on this stack, a stream launch ~2 us; csrc/tg_api.hip: step_as_graph).  Mirrors the
+    library's own reading of the variable: callers that must keep other threads' event polls away from a stream capture (parallel.py) ask here."""
+    v = os.environ.get("TG_STEP_GRAPH")
+    try:
+        return v is not None and int(v) != 0
+    except ValueError:
+        return False
+
+
 def check(rc):
     if rc != 0:
         raise TactileGymHipError(lib().tg_last_error().decode("utf-8", "replace") or f"libtactile_gym_hip error {rc}")

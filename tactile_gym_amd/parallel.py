@@ -671,6 +671,8 @@ class ShardedVecEnv:
         if not todo or self._solo:
             return
         self._captured.update(todo)
+        if not capi.step_graphs_enabled():
+            return                                   # round 6: steps are enqueued launch by launch - the library captures nothing, there is nothing to race with
         if getattr(self.local, "primed", False) and not getattr(self, "_quiesce_always", False):
             return                                   # TorchShard.prime(): the graphs were captured before the process group existed - nothing to wait for
         if not (getattr(self.local, "raw", False) and self.torch.cuda.is_available()):

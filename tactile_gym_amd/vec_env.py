@@ -183,8 +183,8 @@ class TactileVecEnv(_VecEnvBase):
 
     def _bind_torch_stream(self):
         """obs_mode="torch": the zero-copy observation / reward / done tensors and CUDA action tensors are produced and consumed on
-        torch's CURRENT stream, so the library is put on that stream before work is enqueued (tg_set_stream is a pointer swap; the step
-        graph is captured on a stream of the library's own and replays on whichever stream is bound).  Ordering between the policy's kernels and the env's is then the
+        torch's CURRENT stream, so the library is put on that stream before work is enqueued (tg_set_stream is a pointer swap; with
+        TG_STEP_GRAPH=1 the step graph is captured on a stream of the library's own and replays on whichever stream is bound).  Ordering between the policy's kernels and the env's is then the
         stream's own: no event, no host wait, and correct under non-default or per-thread torch streams as well."""
         if self.obs_mode != "torch" or self._pinned_stream:
             return
@@ -273,8 +273,8 @@ class TactileVecEnv(_VecEnvBase):
         return out
 
     def step_random_async(self, seed, first_draw=0, restart=False):
-        """One step of a random-action rollout, `step(action_space.sample())` for the whole batch, as ONE graph launch: the uniform draw (draw k =
-        sample_actions(seed, k)) is a node of the step's graph and the draw counter lives on the device (tg_step_random).  restart: the next draw
+        """One step of a random-action rollout, `step(action_space.sample())` for the whole batch, with the policy inside the step: the uniform draw (draw k =
+        sample_actions(seed, k)) is made by the step kernel itself (or by the step's first launch) and the draw counter lives on the device (tg_step_random).  restart: the next draw
         is first_draw + 1.  The actions used are `actions_torch()`."""
         self._bind_torch_stream()
         if self._obs_guard:
@@ -723,8 +723,8 @@ class TactileVecEnv(_VecEnvBase):
         capi.check(self._L.tg_set_joint_state(self._ctx, q.ctypes.data_as(dp), qd.ctypes.data_as(dp)))
 
     def profile(self, enable=True):
-        """True / 1: HIP events around every launch class (no graph) + the kernels' own clock; 2 / "clock": the own clock only, the step stays one
-        graph (what the rollout itself runs); False: off."""
+        """True / 1: HIP events around every launch class (no graph) + the kernels' own clock; 2 / "clock": the own clock only, the step's launches stay
+        as the rollout itself runs them; False: off."""
         capi.check(self._L.tg_profile_enable(self._ctx, 2 if enable == "clock" else int(enable)))
 
     def profile_get(self):

@@ -445,18 +445,22 @@ def companion(env_id, image_size, n, physics, steps, barrier, what, **kw):
     """A short run of another configuration on this GPU (after the headline's timed region): value, ms per step and its dominant
     kernel's roofline fraction."""
     w = Workload(env_id, n, image_size, physics, 0, 0, **kw)
+    # untimed steps before the window: enough for the reset bank's first refill of ALL envs (it runs beside the steps that follow a reset of the whole
+    # batch, on the bank's stream, and takes CUs from them: a 20-step window opened 10 steps after the reset - the driver's command - measured
+    # surface_follow-v0 at 113 us per step against 99 in steady state)
+    warm = 60
     with w.on_stream():
         w.shard.reset()
-        for _ in range(10):
+        for _ in range(warm):
             w.step(w.shard)
         dt = w.timed(w.shard, steps, barrier)
         w.shard.reset()                                    # the profile window covers the same phase of the episodes as the timed window
-        for _ in range(10):
+        for _ in range(warm):
             w.step(w.shard)
         prof = w.profile(w.shard, steps, barrier)
     roof = w.roofline(prof, ms_per_step=1e3 * dt / steps)
     out = {"workload": f"{env_id}, {w.modes['arm_type'].upper()} + {w.modes['tactile_sensor_name']}, {n} vec-envs, {image_size}x{image_size}" + what,
-           "value": round(n * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
+           "value": round(n * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * dt / steps, 4),
            "roofline": {k: roof[k] for k in ("kernel", "achieved", "frac", "step_frac", "traffic", "algorithmic_bytes_per_env_step", "kernel_ms",
                                              "kernel_ms_source", "kernel_ms_sum_per_step", "profiled_window_ms_per_step", "kernels")}}
     if not w.residual_threshold and n <= 1024:

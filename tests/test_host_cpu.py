@@ -465,3 +465,14 @@ def test_lazy_info_shares_one_empty_dict_and_gives_finished_envs_their_own():
     assert ve._EMPTY_INFO == {} and isinstance(ve._EMPTY_INFO, dict)
     src = open(ve.__file__).read()
     assert "infos[i] = {\"episode\":" in src                  # a finished env never writes into the shared dict
+
+
+def test_step_graphs_switch_mirrors_the_library(monkeypatch):
+    """TG_STEP_GRAPH (csrc/tg_api.hip: step_as_graph): unset / 0 -> the step's launches go on the stream and nothing is ever captured (round 6
+    default), non-zero -> one replayed hipGraph per step.  parallel.py asks this mirror before it quiesces the RCCL watchdog for a capture."""
+    from tactile_gym_amd import _capi
+    monkeypatch.delenv("TG_STEP_GRAPH", raising=False)
+    assert _capi.step_graphs_enabled() is False
+    for v, want in (("0", False), ("1", True), ("2", True), ("junk", False)):
+        monkeypatch.setenv("TG_STEP_GRAPH", v)
+        assert _capi.step_graphs_enabled() is want

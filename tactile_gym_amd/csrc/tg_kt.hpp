@@ -9,7 +9,7 @@
 // acknowledged (s_endpgm waits), and an atomic's round trip per wavefront showed as +25 us on a kernel whose wavefronts come in sixteen rounds
 // (16 384 envs), where a store rides under the image stores issued just before it - and only the workgroups that can hold the extremes stamp at
 // all: workgroups are dispatched in index order, so the first start is among the first kEdge of them and the last end (but for a straggler that
-// outlives 8192 later wavefronts) among the last kEdge.  A scope of several instrumented launches moves the base
+// outlives 8192 later wavefronts) among the last kEdge of a z-layer (see ~KtScope).  A scope of several instrumented launches moves the base
 // on between them (reset_sequence), so that a later launch does not overwrite the first one's start stamps.  base == nullptr (every launch outside
 // profiling mode, every graph): one uniform branch.
 #pragma once
@@ -37,8 +37,13 @@ struct KtScope {
     }
     __device__ __forceinline__ ~KtScope() {
         if (base != nullptr && (threadIdx.x & 63) == 0) {
-            const size_t wg = workgroup(), total = (size_t)gridDim.x * gridDim.y * gridDim.z;
-            if (wg + kEdge >= total) slot(base, wg)[1] = wall_clock64();
+            // the last kEdge workgroups of EVERY z-layer, not of the grid: the renders' second layer (the terminal images, blockIdx.z = 1) is
+            // workgroups that look at their env's flag and leave in nearly every launch - the grid's last workgroups by index, and long gone when the
+            // first layer's last wavefronts end (until this was found, late in round 6, the heightfield render read 44.7 us by this clock and 61 by
+            // rocprofv3, and surface_follow's kernels did not add up to its step by 20 us; k_render_blocks 16.4 against 17.3)
+            const size_t wg = workgroup(), layer = (size_t)gridDim.x * gridDim.y;
+            const size_t in_layer = (size_t)blockIdx.x + (size_t)gridDim.x * (size_t)blockIdx.y;
+            if (in_layer + kEdge >= layer) slot(base, wg)[1] = wall_clock64();
         }
     }
     KtScope(const KtScope&) = delete;
